@@ -1,0 +1,171 @@
+"""Pins the CPU oracle against every golden expectation the reference's own
+Tier-1 tests hold for the filter -> profile path (tests/golden/
+reference_expectations.json cites test file:line for each case)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import samio
+from conftest import GOLDEN, fixture_path
+
+EXP = json.load(open(os.path.join(GOLDEN, "reference_expectations.json")))
+
+
+def records_str(rec, emit):
+    return ",".join(f"{rec.name(i)}:{int(rec.flag[i])}" for i in emit)
+
+
+@pytest.mark.parametrize("case", EXP["filter"], ids=[c["name"] for c in EXP["filter"]])
+def test_filter_golden(case):
+    hdr, rec = samio.read_sam(fixture_path(case["fixture"]))
+    out = orc.run_filter(rec, **case["opts"])
+    assert out["rc"] == 0
+    assert records_str(rec, out["emit"]) == case["records"], case["src"]
+    for key, val in case.get("as", {}).items():
+        idx = [i for i in out["emit"] if f"{rec.name(i)}:{int(rec.flag[i])}" == key]
+        assert idx and all(out["as_out"][i] == val for i in idx), case["src"]
+
+
+def test_md_precedence_over_nm():
+    # test_filter.sh:120-123: md_precedence has NM:i:10 but MD:Z:100
+    hdr, rec = samio.read_sam(fixture_path("filter.sam"))
+    st = orc.aln_stats(rec)
+    i = [k for k in range(rec.n) if rec.name(k) == "md_precedence"][0]
+    assert rec.nm[i] == 10 and st["edit"][i] == 0 and st["length"][i] == 100
+
+
+def test_long_qname_besthit():
+    blk = EXP["long_qname"]
+    hdr, rec = samio.read_sam(fixture_path(blk["fixture"]))
+    for case in blk["cases"]:
+        out = orc.run_filter(rec, **case["opts"])
+        got = [[len(rec.name(i)), int(rec.flag[i]), hdr.target_name[rec.tid[i]], int(out["as_out"][i])]
+               for i in out["emit"]]
+        assert got == blk["expected"]
+
+
+@pytest.mark.parametrize("case", EXP["profile"], ids=[c["name"] for c in EXP["profile"]])
+def test_profile_golden(case):
+    hdr, rec = samio.read_sam(fixture_path(case["fixture"]))
+    sel = None
+    if "filter_opts" in case:
+        sel = orc.run_filter(rec, **case["filter_opts"])["emit"]
+    res = orc.run_profile(rec, hdr.n_targets, multi=case["multi"], sel=sel)
+    st = res["stats"]
+    for key, fld in (("mapped", "insert_count"), ("multi_mapped", "multi_mapper_count"),
+                     ("uniq_mapped", "uniq_mapper_count")):
+        if key in case:
+            assert getattr(st, fld) == case[key], (key, case["src"])
+    vals, purged, eff = orc.profile_finish(res["abundance"], hdr.target_len, st, unit=case["unit"],
+                                           nolen=case["nolen"], total=case["total"],
+                                           mincount=case.get("mincount", -1), multi=case["multi"])
+    if "effective" in case:
+        assert eff == case["effective"]
+    names = ["Unknown"] + hdr.target_name
+    for feat, (want, tol) in case["values"].items():
+        assert abs(vals[names.index(feat)] - want) <= tol, (feat, case["src"])
+
+
+def test_coverage_golden():
+    blk = EXP["coverage"]
+    hdr, rec = samio.read_sam(fixture_path(blk["fixture"]))
+    cov = orc.coverage(rec, hdr.target_len)
+    for t, name in enumerate(hdr.target_name):
+        assert cov[t].tolist() == blk["positions"][name]
+        tlen = hdr.target_len[t]
+        touched = int((cov[t] > 0).sum())
+        total = int(cov[t].sum())
+        # msam_coverage.c:217 summary formats; zero rows print "0\t0"
+        got = ["0", "0"] if total == 0 else ["%.8f" % (touched / tlen), "%.2f" % (total / tlen)]
+        assert got == blk["summary"][name]
+
+
+def test_tiny_aln_known_answers():
+    """BASELINE.json configs[0] / SURVEY 8c table."""
+    t = EXP["tiny_aln"]
+    hdr, rec = samio.read_bam(fixture_path(t["fixture"]))
+    assert rec.n == t["n_records"] and hdr.n_targets == t["n_targets"]
+    assert rec.flag.tolist() == t["flag"] and rec.tid.tolist() == t["tid"]
+    assert [rec.cigar_str(i) for i in range(rec.n)] == t["cigar"]
+    assert [rec.md_str(i) for i in range(rec.n)] == t["md"]
+    assert rec.nm.tolist() == t["nm"] and rec.as_.tolist() == t["as"]
+    st = orc.aln_stats(rec)
+    assert st["length"].tolist() == t["length"] and st["qlen"].tolist() == t["qlen"]
+    assert st["qclip"].tolist() == t["qclip"] and st["edit"].tolist() == t["edit"]
+    out = orc.run_filter(rec, **t["filter_opts"])
+    assert out["rc"] == 0 and out["emit"].tolist() == t["emit"]
+    uq = dict(t["filter_opts"], besthit=False, uniqhit=True)
+    assert orc.run_filter(rec, **uq)["emit"].tolist() == t["uniqhit_emit"]
+    res = orc.run_profile(rec, hdr.n_targets, multi="proportional", sel=out["emit"])
+    s = res["stats"]
+    assert (s.insert_count, s.uniq_mapper_count, s.multi_mapper_count, s.purged_insert_count) == \
+        (t["mapped"], t["uniq_mapped"], t["multi_mapped"], t["purged"])
+    assert s.iterations == 1 and s.converged == 1 and s.last_delta == 0.0
+    vals, purged, eff = orc.profile_finish(res["abundance"], hdr.target_len, s, unit="rel")
+    assert purged == 3 and eff == 4
+    nz = {hdr.target_name[i - 1]: vals[i] for i in range(1, len(vals)) if vals[i] != 0}
+    assert set(nz) == set(t["rel_values"]) and vals[0] == 0
+    for k, v in t["rel_values"].items():
+        assert float("%.8g" % nz[k]) == pytest.approx(v, rel=1e-7)
+
+
+# ---- semantics the reference source fixes but no reference test pins -------
+
+def _mk(cigars, mds, nms=None, flags=None, names=None, as_=None, tids=None):
+    b = samio._Builder()
+    n = len(cigars)
+    for i in range(n):
+        b.add((names[i] if names else f"r{i}").encode(), flags[i] if flags else 0,
+              tids[i] if tids else 0, 0, samio.parse_cigar_text(cigars[i]),
+              None if mds[i] is None else mds[i].encode(),
+              None if nms is None else nms[i], None if as_ is None else as_[i])
+    return b.build()
+
+
+def test_md_caret_deletion_rule():
+    # mBamVector.c:112-118: letters after '^' are not counted from MD (the CIGAR D op
+    # already counted them); a run at the very start of MD is skipped too.
+    rec = _mk(["50M2D48M", "10M", "10M", "5M1D5M"], ["50^AC48", "A9", "0A9", "5^A0T4"])
+    st = orc.aln_stats(rec)
+    assert st["edit"].tolist() == [2, 0, 1, 2]
+    assert st["length"].tolist() == [100, 10, 10, 11]
+
+
+def test_nm_path_odd_ops():
+    # mBamVector.c:23-38: on the NM path every op except S,H,N,P adds to length
+    # (including D and unknown ops >= 9); the MD path ignores unknown ops.
+    cig = [(5 << 4) | 0, (3 << 4) | 9, (2 << 4) | 2, (4 << 4) | 3, (1 << 4) | 6]
+    b = samio._Builder()
+    b.add(b"a", 0, 0, 0, cig, None, 1, None)
+    b.add(b"b", 0, 0, 0, cig, b"5", None, None)
+    st = orc.aln_stats(b.build())
+    assert st["length"].tolist() == [10, 7] and st["qlen"].tolist() == [5, 5]
+    assert st["edit"].tolist() == [1, 2]
+
+
+def test_missing_md_and_nm_is_fatal():
+    rec = _mk(["10M", "10M"], [None, None], nms=[0, None], names=["a", "b"])
+    out = orc.run_filter(rec, l=5)
+    assert out["rc"] == 1 and out["err_record"] == 1
+    # plain --besthit never looks at MD/NM (msam_filter.c:104) but needs AS
+    out = orc.run_filter(rec, besthit=True)
+    assert out["rc"] == 2 and out["err_record"] == 0
+
+
+def test_paired_pool_drops_both_or_neither_mate_bits():
+    # msam_filter.c:192-204: in a paired pool only flag&0xC0 == 0x40 / 0x80 participate
+    rec = _mk(["10M"] * 4, ["10"] * 4, flags=[0, 65, 129, 193], names=["q"] * 4, as_=[50, 10, 20, 99])
+    out = orc.run_filter(rec, besthit=True)
+    assert out["emit"].tolist() == [1, 2]
+
+
+def test_unmapped_flushes_pool_without_renaming():
+    # msam_filter.c:120-138,170: an unmapped record with a new QNAME flushes the pool;
+    # prev_read is only updated by mapped records.
+    rec = _mk(["10M", "*", "10M", "10M"], ["10", None, "10", "10"], flags=[0, 4, 256, 0],
+              names=["a", "b", "a", "c"], as_=[10, 0, 20, 5])
+    out = orc.run_filter(rec, besthit=True)
+    assert out["emit"].tolist() == [0, 2, 3]     # {a0} and {a2} are separate pools
