@@ -1,0 +1,291 @@
+/*
+ * msamtools_amd.h -- C ABI of the MI355X-native msamtools filter -> profile
+ * hot path (libmsamtools_amd.so).
+ *
+ * Plain C: pointers, sizes and PODs only; no HIP, torch or C++ types cross
+ * this boundary.  Every entry point names the reference seam it replaces
+ * (file:line under arumugamlab/msamtools v1.1.3).  The reference has no FFI
+ * or plugin interface; its seams for this path are the function pointers and
+ * per-pool calls inside msam_filter.c / msam_profile.c, so the
+ * binding a maintainer would add is a direct C call -- see INTEGRATION.md.
+ *
+ * Division of labour
+ *   host (C):  BGZF/BAM or SAM decode, the QNAME string compares that define
+ *              pools (group_off), SoA packing, record emission, profile text.
+ *   device:    everything per record / per pool / per feature:
+ *              CIGAR+MD walk, -l/-p/-z predicates, --rescore, pool membership
+ *              incl. the unmapped/-k/-v rules, --besthit/--uniqhit selection
+ *              and output order, insert counting, multi-mapper lists,
+ *              proportional sharing iterations, per-base coverage pile-up.
+ *
+ * Error convention: every int-returning function returns MSX_OK (0) or an
+ * MSX_ERR_* code; msx_last_error(ctx) holds the text.  Data errors carry the
+ * reference's own message (the caller prints "Fatal Error: <text>" to stderr
+ * and exits 1, as mDie does: mCommon.c:22-31).
+ */
+#ifndef MSAMTOOLS_AMD_H
+#define MSAMTOOLS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSX_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define MSX_OK              0
+#define MSX_ERR_NO_MD_NM    1   /* msam_filter.c:150-152 (mDie)                 */
+#define MSX_ERR_NO_AS       2   /* msam_filter.c:219-221 (mDie)                 */
+#define MSX_ERR_NO_FILTER   3   /* msam_filter.c:82-84   (mDie)                 */
+#define MSX_ERR_SHARE_TYPE  4   /* msam_profile.c:122-124, :188-190 (mDie)      */
+#define MSX_ERR_HIP       (-10) /* HIP runtime failure, text has the HIP error  */
+#define MSX_ERR_ARG       (-11) /* bad argument                                  */
+#define MSX_ERR_NOMEM     (-12) /* device or host allocation failed              */
+#define MSX_ERR_NO_DEVICE (-13) /* no usable gfx950 device: there is NO CPU fallback */
+
+/* ---- per-record aux presence bits (msx_batch.rflags) --------------------- */
+#define MSX_HAS_MD 1u   /* bam_aux_get(b,"MD") != NULL (msam_filter.c:146)      */
+#define MSX_HAS_NM 2u   /* bam_aux_get(b,"NM") != NULL (msam_filter.c:149)      */
+#define MSX_HAS_AS 4u   /* bam_aux_get(b,"AS") != NULL (msam_filter.c:219)      */
+
+/* ---- multi-mapper share types (msam_profile.c:5-8) ----------------------- */
+#define MSX_MULTI_ADD_ALL            1
+#define MSX_MULTI_SHARE_EQUAL        2
+#define MSX_MULTI_SHARE_PROPORTIONAL 3
+#define MSX_MULTI_IGNORE             4
+
+typedef struct msx_ctx msx_ctx;
+typedef struct msx_profile msx_profile;
+
+/*
+ * A batch of alignment records in input order, structure-of-arrays.
+ * Replaces the stream of bam1_t that mSamRead() hands to mFilterFile /
+ * mEstimateInsertCountOnFile (msam_helper.c:246-268, msam_filter.c:119,
+ * msam_profile.c:222).  All pointers of one batch live in the same memory
+ * space: host (for msx_batch_upload) or device (for the compute entry points).
+ *
+ * group_off: the pools.  group_off[g] is the index of the first record of pool
+ * g; group_off[n_groups] == n_records.  The host computes it with the exact
+ * string rule of the loop it feeds:
+ *   filter  (msam_filter.c:120-125,170): a pool closes when a record's QNAME
+ *           differs from the QNAME of the last MAPPED record seen;
+ *   profile (msam_profile.c:223-232): records with tid == -1 are transparent;
+ *           a pool closes when a QNAME differs from the previous such record.
+ * For a QNAME-grouped file both rules give "one pool per QNAME run".
+ * group_off may be NULL for plain -l/-p/-z filtering (output does not depend
+ * on pools: mWriteBamPool, mBamVector.c:343-348).
+ */
+typedef struct msx_batch {
+	int64_t         n_records;
+	int64_t         n_groups;
+	const uint16_t *flag;       /* [n] bam1_core_t.flag                          */
+	const uint8_t  *rflags;     /* [n] MSX_HAS_* bits                            */
+	const int32_t  *tid;        /* [n] bam1_core_t.tid                           */
+	const int32_t  *pos;        /* [n] bam1_core_t.pos (coverage only; may be NULL) */
+	const uint32_t *cigar_off;  /* [n+1] offsets into cigar                      */
+	const uint32_t *cigar;      /* bam_get_cigar(): len<<4|op                    */
+	const uint32_t *md_off;     /* [n+1] byte offsets into md                    */
+	const uint8_t  *md;         /* MD:Z payloads back to back, no terminators    */
+	const int32_t  *nm;         /* [n] (int32_t) bam_aux2i(NM); 0 when absent    */
+	const int32_t  *as;         /* [n] (int32_t) bam_aux2i(AS); 0 when absent    */
+	const uint32_t *group_off;  /* [n_groups+1], see above                       */
+	const uint64_t *qname_hash; /* [n] optional, not read by the kernels (shard routing) */
+} msx_batch;
+
+/* Thresholds and switches of `msamtools filter`, already validated/derived as
+ * msam_filter.c:420-457 does (PPT = 10*-p or --ppt; MAX_CLIP = 100 - -z). */
+typedef struct msx_filter_params {
+	int32_t min_length;     /* global->MIN_LENGTH                              */
+	int32_t ppt;            /* global->PPT                                     */
+	int32_t max_clip;       /* global->MAX_CLIP (100 when -z absent)           */
+	int32_t rescore;        /* --rescore                                       */
+	int32_t invert;         /* -v                                              */
+	int32_t keep_unmapped;  /* -k                                              */
+	int32_t besthit;        /* --besthit                                       */
+	int32_t uniqhit;        /* --uniqhit                                       */
+} msx_filter_params;
+
+/* Device output buffers of one filter call, caller-allocated (device memory).
+ * keep[i]: 0 = not written; 1 = written in the READ1/unpaired pass;
+ *          2 = written in the READ2 pass (msam_filter.c:247-263).
+ * emit_idx: indices of the records written, in the reference's output order
+ *          (pool by pool; within a pool all pass-1 records, then pass-2).
+ * as_out:  AS each record carries on output (only written with --rescore,
+ *          msam_filter.c:160-168; may be NULL otherwise). */
+typedef struct msx_filter_out {
+	uint8_t *keep;       /* [n_records]                                        */
+	int32_t *emit_idx;   /* [n_records] capacity; may be NULL if not wanted    */
+	int32_t *as_out;     /* [n_records] or NULL                                */
+} msx_filter_out;
+
+/* Host-side result of msx_filter_finish(). */
+typedef struct msx_filter_status {
+	int64_t n_emit;      /* number of valid entries in emit_idx / kept records */
+	int64_t err_record;  /* first offending record for MSX_ERR_NO_MD_NM/NO_AS  */
+} msx_filter_status;
+
+/* Counters of one profile (msam.h:36-38 + return value of msam_profile.c:204) */
+typedef struct msx_profile_stats {
+	uint32_t insert_count;        /* "Mapped inserts"                          */
+	uint32_t uniq_mapper_count;
+	uint32_t multi_mapper_count;
+	uint32_t purged_insert_count; /* msam_profile.c:394-405                    */
+	int32_t  iterations;          /* last k reached by the loop at :331        */
+	int32_t  converged;           /* 1 if DELTA^2 < 1e-10 was reached (:383)   */
+	double   delta[20];           /* delta[k] = DELTA^2 printed at :381, k>=1  */
+} msx_profile_stats;
+
+/* ---- context ------------------------------------------------------------- */
+
+/* Binds one GPU (one ctx per GPU / per rank).  Fails with MSX_ERR_NO_DEVICE if
+ * there is no gfx950 device: the library has no CPU path. */
+int  msx_ctx_create(msx_ctx **ctx, int device_id);
+void msx_ctx_destroy(msx_ctx *ctx);
+const char *msx_last_error(const msx_ctx *ctx);  /* ctx may be NULL: last create error */
+int  msx_abi_version(void);
+/* The HIP stream all work of this ctx is enqueued on (a hipStream_t), so the
+ * caller can record events on it or make other streams wait for it. */
+void *msx_ctx_stream(msx_ctx *ctx);
+int  msx_ctx_sync(msx_ctx *ctx);
+
+/* ---- batches ------------------------------------------------------------- */
+
+/* Copies a host batch into device memory owned by the ctx; *dev receives the
+ * device-pointer view.  Free with msx_batch_free.  (The pinned-buffer +
+ * hipMemcpyAsync path the host pipeline uses.) */
+int  msx_batch_upload(msx_ctx *ctx, const msx_batch *host, msx_batch *dev);
+void msx_batch_free(msx_ctx *ctx, msx_batch *dev);
+
+/* ---- filter: replaces mFilterFileWrapper/mFilterFile + writers ----------- */
+
+/* msam_filter.c:65-263 on one device batch.  Enqueues on the ctx stream and
+ * returns; out->* are valid after msx_filter_finish().  Kernels:
+ *   aln_stats_filter  bam_get_summary / bam_cigar2details + _FILTER_* + rescore
+ *                     (mBamVector.c:23-133, msam_filter.c:31-63,132-183)
+ *   besthit_select    mWriteBestHitBamPool{,ByMate} / Unique (msam_filter.c:192-263)
+ *   emit_order        the order of mSamWrite calls (msam_filter.c:235-244) */
+int  msx_filter_enqueue(msx_ctx *ctx, const msx_batch *dev,
+                        const msx_filter_params *params, const msx_filter_out *out);
+/* Waits for the stream; returns MSX_OK or the data error the reference would
+ * have died with (MSX_ERR_NO_MD_NM / MSX_ERR_NO_AS), status filled either way. */
+int  msx_filter_finish(msx_ctx *ctx, msx_filter_status *status);
+
+/* Per-record alignment statistics only (the mAlignmentSummary fields filter
+ * reads: mBamVector.h:38-47), for inspection and tests.  Any output may be
+ * NULL.  status[i] = 1 when the record has neither MD nor NM. */
+int  msx_aln_stats(msx_ctx *ctx, const msx_batch *dev, int32_t *length,
+                   int32_t *query_length, int32_t *query_clip, int32_t *edit,
+                   uint8_t *status);
+
+/* ---- profile: replaces mInitInsertCounts / mEstimateInsertCountOnPool /
+ *      mInsertCountToAbundanceMatrix (msam_profile.c:23-425) --------------- */
+
+/* fmap: host array [n_targets] tid -> feature (global->fmap, msam_profile.c:
+ * 757-852) or NULL for identity (n_features == n_targets). */
+int  msx_profile_create(msx_ctx *ctx, msx_profile **p, int32_t n_features,
+                        int32_t share_type, const int32_t *fmap, int32_t n_targets);
+void msx_profile_destroy(msx_ctx *ctx, msx_profile *p);
+int  msx_profile_reset(msx_ctx *ctx, msx_profile *p);
+
+/* mEstimateInsertCountOnFile + OnPool over one device batch (msam_profile.c:
+ * 65-243).  keep == NULL: every record of the batch is a record of the input
+ * stream (the `profile` subcommand).  keep != NULL (device, [n_records], from
+ * msx_filter): the stream is filter's output for this batch, in its output
+ * order -- the fused `filter ... | profile -` pipe; dev->group_off are then
+ * filter's pools (one pool per QNAME run).  Enqueues and returns. */
+int  msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *dev,
+                            const uint8_t *keep);
+
+/* Device pointers to the accumulators, for a cross-GPU all-reduce(sum) by the
+ * caller (RCCL): ui_insert_count u32[n_features], d_insert_count f64
+ * [n_features] (NULL unless share_type is EQUAL), counters u32[4] =
+ * {insert_count, uniq_mapper_count, multi_mapper_count, purged_insert_count}. */
+int  msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui,
+                              double **d, uint32_t **counters);
+
+/* Proportional sharing, split so a collective can sit between the halves
+ * (msam_profile.c:317-410):
+ *   begin  : a(i,0) = U(i) = ui/2 (+ d for EQUAL)              :284-289,:326
+ *   local  : increment += a(e)/sum over THIS rank's multi-mappers :341-365
+ *            (*inc = device f64[n_features]; all-reduce it across ranks)
+ *   apply  : a = U + increment, clamp < 1e-20, DELTA^2           :368-380
+ *            *delta receives DELTA^2 (host); identical on every rank
+ *   purged : this rank's multi-mappers whose features sum to 0   :394-404
+ */
+int  msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p);
+int  msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc);
+int  msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delta);
+int  msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *purged_local);
+
+/* Single-GPU convenience = mInsertCountToAbundanceMatrix for one sample:
+ * runs begin / (local, apply) x <=19 / purged on the device with no host
+ * round trip per iteration, then copies the abundance row (without the
+ * Unknown column) to abundance_host[n_features] and fills stats. */
+int  msx_profile_finalize(msx_ctx *ctx, msx_profile *p, double *abundance_host,
+                          msx_profile_stats *stats);
+/* Same device work, enqueued only (bench timing); results stay on the device.
+ * msx_profile_fetch() then syncs and copies them out. */
+int  msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p);
+int  msx_profile_fetch(msx_ctx *ctx, msx_profile *p, double *abundance_host,
+                       msx_profile_stats *stats);
+/* Device pointer of the current abundance vector a(i,k), f64[n_features]. */
+int  msx_profile_abundance_dev(msx_ctx *ctx, msx_profile *p, double **a);
+
+/* ---- coverage: replaces mUpdateCoverageForAlignment (msam_coverage.c:33-87) */
+
+/* cov: device int32[cov_off[n_targets]] (caller zeroes it once per file);
+ * cov_off: device int64[n_targets+1] prefix sum of target_len.  Adds 1 per
+ * aligned base (M,=,X); D and N advance; tid < 0 skipped. */
+int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
+                             const int64_t *cov_off, int32_t n_targets, int32_t *cov);
+
+/* ---- synthetic workloads (bench.py / tests) -------- */
+
+typedef struct msx_synth_params {
+	uint64_t seed;
+	int64_t  n_groups;       /* QNAME groups (reads/inserts)                    */
+	int32_t  n_refs;         /* references (= features)                         */
+	int32_t  mean_extra_hits;/* hits per read = 1 + Poisson(mean_extra_hits), <= 4 supported */
+	int64_t  first_group;    /* generate groups [first_group, first_group+n_groups) of the
+	                            infinite deterministic stream (sharding / prefixes) */
+} msx_synth_params;
+
+/* Sizes needed for the arrays of a synthetic batch (computed on the device). */
+typedef struct msx_synth_sizes {
+	int64_t n_records, n_cigar, n_md;
+} msx_synth_sizes;
+
+/* Generates a batch directly in device memory owned by the ctx (free with
+ * msx_batch_free).  Deterministic in (seed, group index): the same groups come
+ * out of msx_synth_host(). */
+int  msx_synth_device(msx_ctx *ctx, const msx_synth_params *sp, msx_batch *dev,
+                      msx_synth_sizes *sizes);
+/* Host twin (plain C loops, no GPU needed): allocates with malloc; free with
+ * msx_synth_host_free.  Used to feed the CPU oracle the same data. */
+int  msx_synth_host(const msx_synth_params *sp, msx_batch *host, msx_synth_sizes *sizes);
+void msx_synth_host_free(msx_batch *host);
+
+/* ---- raw device memory helpers for C callers (thin hipMalloc wrappers) ---- */
+int  msx_dev_alloc(msx_ctx *ctx, void **ptr, size_t bytes);
+void msx_dev_free(msx_ctx *ctx, void *ptr);
+int  msx_dev_zero(msx_ctx *ctx, void *ptr, size_t bytes);       /* async on ctx stream */
+int  msx_dev_to_host(msx_ctx *ctx, void *host, const void *dev, size_t bytes); /* sync */
+int  msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes); /* sync */
+
+/* ---- timing of the dominant kernel (bench.py roofline) -------------------- */
+
+/* Per-kernel accumulated device time measured with HIP events on the ctx
+ * stream while enabled.  names: "aln_stats_filter", "besthit_select",
+ * "emit_order", "insert_count", "prop_iter", "coverage_pileup", "scan".
+ * Returns total ms and number of launches since the last reset. */
+int  msx_timing_enable(msx_ctx *ctx, int on);
+int  msx_timing_reset(msx_ctx *ctx);
+int  msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSAMTOOLS_AMD_H */

@@ -1,0 +1,18 @@
+"""msamtools_amd -- MI355X-native msamtools filter -> profile hot path.
+
+The compute lives in libmsamtools_amd.so (hand-written HIP for gfx950 behind
+the C ABI of include/msamtools_amd.h).  Importing the package binds the
+library and fails loudly if it has not been built; creating a Context fails
+loudly without a gfx950 GPU.  There is no CPU fallback.
+"""
+from . import _lib
+from ._lib import MsxError
+
+_lib.load()
+
+from .api import (Context, DeviceBatch, FilterRun, HostSynth, Profile, aln_stats,  # noqa: E402
+                  coverage, filter_params, run_filter)
+from .grouping import filter_pools, profile_pools  # noqa: E402
+
+__all__ = ["Context", "DeviceBatch", "FilterRun", "HostSynth", "Profile", "MsxError", "aln_stats",
+           "coverage", "filter_params", "run_filter", "filter_pools", "profile_pools"]

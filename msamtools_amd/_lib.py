@@ -1,0 +1,135 @@
+"""ctypes binding of libmsamtools_amd.so (the C ABI in include/msamtools_amd.h).
+
+The library is built in-tree (msamtools_amd/libmsamtools_amd.so) by
+`make -C msamtools_amd/csrc` / __graft_entry__.build().  There is no Python or
+CPU fallback: if the shared object is missing, or no gfx950 device is present
+when a context is created, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsamtools_amd.so")
+
+MSX_OK = 0
+ERR_NO_MD_NM, ERR_NO_AS, ERR_NO_FILTER, ERR_SHARE_TYPE = 1, 2, 3, 4
+ERR_HIP, ERR_ARG, ERR_NOMEM, ERR_NO_DEVICE = -10, -11, -12, -13
+HAS_MD, HAS_NM, HAS_AS = 1, 2, 4
+MULTI = {"all": 1, "equal": 2, "proportional": 3, "ignore": 4}
+
+
+class MsxError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"[msx {code}] {text}")
+        self.code = code
+        self.text = text
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_int64), ("n_groups", C.c_int64),
+        ("flag", C.c_void_p), ("rflags", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p),
+        ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("md_off", C.c_void_p), ("md", C.c_void_p),
+        ("nm", C.c_void_p), ("as_", C.c_void_p), ("group_off", C.c_void_p), ("qname_hash", C.c_void_p),
+    ]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("min_length", "ppt", "max_clip", "rescore", "invert", "keep_unmapped", "besthit", "uniqhit")]
+
+
+class FilterOut(C.Structure):
+    _fields_ = [("keep", C.c_void_p), ("emit_idx", C.c_void_p), ("as_out", C.c_void_p)]
+
+
+class FilterStatus(C.Structure):
+    _fields_ = [("n_emit", C.c_int64), ("err_record", C.c_int64)]
+
+
+class ProfileStats(C.Structure):
+    _fields_ = [
+        ("insert_count", C.c_uint32), ("uniq_mapper_count", C.c_uint32),
+        ("multi_mapper_count", C.c_uint32), ("purged_insert_count", C.c_uint32),
+        ("iterations", C.c_int32), ("converged", C.c_int32), ("delta", C.c_double * 20),
+    ]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_groups", C.c_int64), ("n_refs", C.c_int32),
+                ("mean_extra_hits", C.c_int32), ("first_group", C.c_int64)]
+
+
+class SynthSizes(C.Structure):
+    _fields_ = [("n_records", C.c_int64), ("n_cigar", C.c_int64), ("n_md", C.c_int64)]
+
+
+# every symbol include/msamtools_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "msx_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "msx_ctx_destroy": (None, [_P]),
+    "msx_last_error": (C.c_char_p, [_P]),
+    "msx_abi_version": (C.c_int, []),
+    "msx_ctx_stream": (_P, [_P]),
+    "msx_ctx_sync": (C.c_int, [_P]),
+    "msx_batch_upload": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Batch)]),
+    "msx_batch_free": (None, [_P, C.POINTER(Batch)]),
+    "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),
+    "msx_filter_finish": (C.c_int, [_P, C.POINTER(FilterStatus)]),
+    "msx_aln_stats": (C.c_int, [_P, C.POINTER(Batch), _P, _P, _P, _P, _P]),
+    "msx_profile_create": (C.c_int, [_P, C.POINTER(_P), C.c_int32, C.c_int32, _P, C.c_int32]),
+    "msx_profile_destroy": (None, [_P, _P]),
+    "msx_profile_reset": (C.c_int, [_P, _P]),
+    "msx_profile_accumulate": (C.c_int, [_P, _P, C.POINTER(Batch), _P]),
+    "msx_profile_accumulators": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "msx_profile_prop_begin": (C.c_int, [_P, _P]),
+    "msx_profile_prop_local": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "msx_profile_prop_apply": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
+    "msx_profile_prop_purged": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
+    "msx_profile_finalize": (C.c_int, [_P, _P, _P, C.POINTER(ProfileStats)]),
+    "msx_profile_finalize_enqueue": (C.c_int, [_P, _P]),
+    "msx_profile_fetch": (C.c_int, [_P, _P, _P, C.POINTER(ProfileStats)]),
+    "msx_profile_abundance_dev": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "msx_coverage_accumulate": (C.c_int, [_P, C.POINTER(Batch), _P, C.c_int32, _P]),
+    "msx_synth_device": (C.c_int, [_P, C.POINTER(SynthParams), C.POINTER(Batch), C.POINTER(SynthSizes)]),
+    "msx_synth_host": (C.c_int, [C.POINTER(SynthParams), C.POINTER(Batch), C.POINTER(SynthSizes)]),
+    "msx_synth_host_free": (None, [C.POINTER(Batch)]),
+    "msx_dev_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
+    "msx_dev_free": (None, [_P, _P]),
+    "msx_dev_zero": (C.c_int, [_P, _P, C.c_size_t]),
+    "msx_dev_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msx_host_to_dev": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msx_timing_enable": (C.c_int, [_P, C.c_int]),
+    "msx_timing_reset": (C.c_int, [_P]),
+    "msx_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object and bind every declared symbol (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C msamtools_amd/csrc` "
+            "(hipcc --offload-arch=gfx950). msamtools_amd has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc):
+    if rc != MSX_OK:
+        text = load().msx_last_error(ctx_handle)
+        raise MsxError(rc, text.decode() if text else "")
+    return rc

@@ -1,0 +1,413 @@
+"""Host-side Python mirror of the filter -> profile seam, over the C ABI.
+
+Used by the tests and bench.py; the production host is the C command line in
+msamtools_amd/csrc/host (same ABI).  Naming follows the reference: a *pool* is
+the set of alignments of one QNAME (mBamPool), `filter_opts` are the CLI
+switches of `msamtools filter` (msam_filter.c:304-347), `multi` the --multi
+mode of `msamtools profile` (msam_profile.c:712-728).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def filter_params(l=0, p=None, ppt=None, z=None, rescore=False, invert=False,
+                  keep_unmapped=False, besthit=False, uniqhit=False):
+    """CLI options -> msx_filter_params, validated as msam_filter.c:398-457 does."""
+    if invert and (besthit or uniqhit):
+        raise ValueError("--invert cannot be combined with --besthit or --uniqhit")
+    if besthit and uniqhit:
+        raise ValueError("--besthit cannot be combined with --uniqhit")
+    if p is not None and ppt is not None:
+        raise ValueError("-p cannot be combined with --ppt")
+    fp = L.FilterParams()
+    fp.ppt = 0
+    if p is not None:
+        if not 0 <= int(p) <= 100:
+            raise ValueError("-p must be in the range [0,100]")
+        fp.ppt = 10 * int(p)
+    elif ppt is not None:
+        if not -1000 <= int(ppt) <= 1000:
+            raise ValueError("--ppt must be in the range [-1000,1000]")
+        fp.ppt = int(ppt)
+    fp.max_clip = 100
+    if z is not None:
+        fp.max_clip = 100 - int(z)
+        if not 0 <= fp.max_clip <= 100:
+            raise ValueError("-z must be in the range [0,100]")
+    fp.min_length = int(l or 0)
+    if fp.min_length < 0:
+        raise ValueError("-l must be a non-negative integer")
+    fp.rescore, fp.invert, fp.keep_unmapped = int(bool(rescore)), int(bool(invert)), int(bool(keep_unmapped))
+    fp.besthit, fp.uniqhit = int(bool(besthit)), int(bool(uniqhit))
+    return fp
+
+
+class Context:
+    """One GPU (msx_ctx).  Raises if there is no gfx950 device."""
+
+    def __init__(self, device_id=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(None, self.lib.msx_ctx_create(C.byref(h), int(device_id)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.msx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        return L.check(self.h, rc)
+
+    @property
+    def stream(self):
+        return self.lib.msx_ctx_stream(self.h)
+
+    def sync(self):
+        self.check(self.lib.msx_ctx_sync(self.h))
+
+    # raw device memory -----------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.msx_dev_alloc(self.h, C.byref(p), int(nbytes)))
+        return p.value
+
+    def free(self, ptr):
+        if ptr:
+            self.lib.msx_dev_free(self.h, C.c_void_p(ptr))
+
+    def zero(self, ptr, nbytes):
+        self.check(self.lib.msx_dev_zero(self.h, C.c_void_p(ptr), int(nbytes)))
+
+    def to_host(self, ptr, count, dtype):
+        out = np.empty(int(count), dtype=dtype)
+        if out.nbytes:
+            self.check(self.lib.msx_dev_to_host(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out
+
+    def to_dev(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            self.check(self.lib.msx_host_to_dev(self.h, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    # timing ---------------------------------------------------------------
+    def timing(self, on=True):
+        self.check(self.lib.msx_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self.check(self.lib.msx_timing_reset(self.h))
+
+    def timing_get(self, name):
+        ms = C.c_double(0)
+        cnt = C.c_int64(0)
+        self.check(self.lib.msx_timing_get(self.h, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+_FIELDS = (("flag", np.uint16), ("rflags", np.uint8), ("tid", np.int32), ("pos", np.int32),
+           ("cigar_off", np.uint32), ("cigar", np.uint32), ("md_off", np.uint32), ("md", np.uint8),
+           ("nm", np.int32), ("as_", np.int32), ("group_off", np.uint32))
+
+
+def host_batch_struct(rec, group_off=None):
+    """numpy SoA (attributes as in tests/samio.Records) -> (msx_batch with host pointers, keepalive)."""
+    b = L.Batch()
+    keep = []
+    b.n_records = int(rec.flag.shape[0])
+    for name, dt in _FIELDS:
+        src = group_off if name == "group_off" else getattr(rec, name, None)
+        if src is None:
+            setattr(b, name, None)
+            continue
+        a = np.ascontiguousarray(src, dtype=dt)
+        if a.size == 0:
+            a = np.zeros(1, dtype=dt)
+        keep.append(a)
+        setattr(b, name, a.ctypes.data_as(C.c_void_p))
+    b.n_groups = 0 if group_off is None else int(len(group_off) - 1)
+    b.qname_hash = None
+    return b, keep
+
+
+class DeviceBatch:
+    """A record batch resident in HBM (msx_batch with device pointers)."""
+
+    def __init__(self, ctx, b, sizes=None):
+        self.ctx = ctx
+        self.b = b
+        self.sizes = sizes
+
+    @classmethod
+    def upload(cls, ctx, rec, group_off=None):
+        hb, keep = host_batch_struct(rec, group_off)
+        db = L.Batch()
+        ctx.check(ctx.lib.msx_batch_upload(ctx.h, C.byref(hb), C.byref(db)))
+        return cls(ctx, db)
+
+    @classmethod
+    def synth(cls, ctx, seed, n_groups, n_refs, mean_extra_hits=4, first_group=0):
+        sp = L.SynthParams(seed, n_groups, n_refs, mean_extra_hits, first_group)
+        db = L.Batch()
+        sz = L.SynthSizes()
+        ctx.check(ctx.lib.msx_synth_device(ctx.h, C.byref(sp), C.byref(db), C.byref(sz)))
+        return cls(ctx, db, sz)
+
+    @property
+    def n_records(self):
+        return int(self.b.n_records)
+
+    @property
+    def n_groups(self):
+        return int(self.b.n_groups)
+
+    def fetch(self, name, count, dtype):
+        return self.ctx.to_host(getattr(self.b, name), count, dtype)
+
+    def to_host(self):
+        """Copy the whole batch back as a dict of numpy arrays."""
+        n, ng = self.n_records, self.n_groups
+        out = {}
+        for name, dt in _FIELDS:
+            if not getattr(self.b, name):
+                continue
+            if name == "cigar":
+                cnt = int(out["cigar_off"][n]) if n else 0
+            elif name == "md":
+                cnt = int(out["md_off"][n]) if n else 0
+            elif name in ("cigar_off", "md_off"):
+                cnt = n + 1
+            elif name == "group_off":
+                cnt = ng + 1
+            else:
+                cnt = n
+            out[name] = self.fetch(name, cnt, dt)
+        return out
+
+    def free(self):
+        if self.b is not None:
+            self.ctx.lib.msx_batch_free(self.ctx.h, C.byref(self.b))
+            self.b = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class HostSynth:
+    """Host twin of the synthetic generator (msx_synth_host): numpy views."""
+
+    def __init__(self, seed, n_groups, n_refs, mean_extra_hits=4, first_group=0):
+        lib = L.load()
+        sp = L.SynthParams(seed, n_groups, n_refs, mean_extra_hits, first_group)
+        hb = L.Batch()
+        sz = L.SynthSizes()
+        L.check(None, lib.msx_synth_host(C.byref(sp), C.byref(hb), C.byref(sz)))
+        n, ng = int(sz.n_records), int(n_groups)
+
+        def grab(ptr, cnt, dt):
+            if cnt == 0:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt, count=cnt).copy()
+        self.flag = grab(hb.flag, n, np.uint16)
+        self.rflags = grab(hb.rflags, n, np.uint8)
+        self.tid = grab(hb.tid, n, np.int32)
+        self.pos = grab(hb.pos, n, np.int32)
+        self.nm = grab(hb.nm, n, np.int32)
+        self.as_ = grab(hb.as_, n, np.int32)
+        self.cigar_off = grab(hb.cigar_off, n + 1, np.uint32)
+        self.md_off = grab(hb.md_off, n + 1, np.uint32)
+        self.cigar = grab(hb.cigar, int(sz.n_cigar), np.uint32)
+        self.md = grab(hb.md, int(sz.n_md), np.uint8)
+        self.group_off = grab(hb.group_off, ng + 1, np.uint32)
+        self.qname_off = None
+        self.qname = None
+        # the QNAME of a synthetic record is its group index
+        self.name_id = np.repeat(np.arange(ng, dtype=np.int32) + np.int32(first_group % (1 << 31)),
+                                 np.diff(self.group_off).astype(np.int64))
+        self.n_records, self.n_groups = n, ng
+        lib.msx_synth_host_free(C.byref(hb))
+
+
+class FilterResult:
+    def __init__(self, keep, emit, as_out, n_emit):
+        self.keep, self.emit, self.as_out, self.n_emit = keep, emit, as_out, n_emit
+
+
+class FilterRun:
+    """Device buffers + launch of one `filter` pass over a device batch."""
+
+    def __init__(self, ctx, batch, want_emit=True, **opts):
+        self.ctx, self.batch = ctx, batch
+        self.fp = opts.pop("params", None) or filter_params(**opts)
+        n = max(batch.n_records, 1)
+        self.keep = ctx.alloc(n)
+        self.emit = ctx.alloc(4 * n) if want_emit else None
+        self.as_out = ctx.alloc(4 * n) if self.fp.rescore else None
+        self.out = L.FilterOut(self.keep, self.emit, self.as_out)
+
+    def enqueue(self):
+        c = self.ctx
+        c.check(c.lib.msx_filter_enqueue(c.h, C.byref(self.batch.b), C.byref(self.fp), C.byref(self.out)))
+
+    def finish(self):
+        c = self.ctx
+        st = L.FilterStatus()
+        rc = c.lib.msx_filter_finish(c.h, C.byref(st))
+        self.status = st
+        c.check(rc)
+        return st
+
+    def result(self):
+        c, n = self.ctx, self.batch.n_records
+        ne = int(self.status.n_emit)
+        keep = c.to_host(self.keep, n, np.uint8)
+        emit = c.to_host(self.emit, ne, np.int32) if self.emit else None
+        as_out = c.to_host(self.as_out, n, np.int32) if self.as_out else None
+        return FilterResult(keep, emit, as_out, ne)
+
+    def free(self):
+        for p in (self.keep, self.emit, self.as_out):
+            self.ctx.free(p)
+        self.keep = self.emit = self.as_out = None
+
+
+def run_filter(ctx, batch, **opts):
+    """Enqueue + finish + fetch.  Raises MsxError with the reference's message on data errors."""
+    run = FilterRun(ctx, batch, **opts)
+    try:
+        run.enqueue()
+        run.finish()
+        return run.result()
+    finally:
+        run.free()
+
+
+def aln_stats(ctx, batch):
+    n = max(batch.n_records, 1)
+    ptrs = [ctx.alloc(4 * n) for _ in range(4)] + [ctx.alloc(n)]
+    try:
+        ctx.check(ctx.lib.msx_aln_stats(ctx.h, C.byref(batch.b), *[C.c_void_p(p) for p in ptrs]))
+        names = ("length", "qlen", "qclip", "edit")
+        out = {k: ctx.to_host(p, batch.n_records, np.int32) for k, p in zip(names, ptrs[:4])}
+        out["status"] = ctx.to_host(ptrs[4], batch.n_records, np.uint8)
+        return out
+    finally:
+        for p in ptrs:
+            ctx.free(p)
+
+
+class Profile:
+    """msx_profile: insert counting + proportional sharing for one sample."""
+
+    def __init__(self, ctx, n_features, multi="proportional", fmap=None):
+        self.ctx = ctx
+        self.n_features = int(n_features)
+        self.multi = multi
+        h = C.c_void_p()
+        fm, nt = None, 0
+        if fmap is not None:
+            fmap = np.ascontiguousarray(fmap, dtype=np.int32)
+            fm, nt = fmap.ctypes.data_as(C.c_void_p), int(fmap.size)
+        ctx.check(ctx.lib.msx_profile_create(ctx.h, C.byref(h), self.n_features, L.MULTI[multi], fm, nt))
+        self.h = h
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.msx_profile_reset(self.ctx.h, self.h))
+
+    def accumulate(self, batch, keep_ptr=None):
+        c = self.ctx
+        c.check(c.lib.msx_profile_accumulate(c.h, self.h, C.byref(batch.b),
+                                             C.c_void_p(keep_ptr) if keep_ptr else None))
+
+    def accumulators(self):
+        ui, d, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        c = self.ctx
+        c.check(c.lib.msx_profile_accumulators(c.h, self.h, C.byref(ui), C.byref(d), C.byref(cnt)))
+        return ui.value, d.value, cnt.value
+
+    def prop_begin(self):
+        self.ctx.check(self.ctx.lib.msx_profile_prop_begin(self.ctx.h, self.h))
+
+    def prop_local(self):
+        inc = C.c_void_p()
+        self.ctx.check(self.ctx.lib.msx_profile_prop_local(self.ctx.h, self.h, C.byref(inc)))
+        return inc.value
+
+    def prop_apply(self):
+        d = C.c_double(0)
+        self.ctx.check(self.ctx.lib.msx_profile_prop_apply(self.ctx.h, self.h, C.byref(d)))
+        return d.value
+
+    def prop_purged(self):
+        v = C.c_uint32(0)
+        self.ctx.check(self.ctx.lib.msx_profile_prop_purged(self.ctx.h, self.h, C.byref(v)))
+        return v.value
+
+    def abundance_ptr(self):
+        a = C.c_void_p()
+        self.ctx.check(self.ctx.lib.msx_profile_abundance_dev(self.ctx.h, self.h, C.byref(a)))
+        return a.value
+
+    def finalize_enqueue(self):
+        self.ctx.check(self.ctx.lib.msx_profile_finalize_enqueue(self.ctx.h, self.h))
+
+    def fetch(self):
+        ab = np.zeros(max(self.n_features, 1), np.float64)
+        st = L.ProfileStats()
+        c = self.ctx
+        c.check(c.lib.msx_profile_fetch(c.h, self.h, ab.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return ab[:self.n_features], st
+
+    def finalize(self):
+        self.finalize_enqueue()
+        return self.fetch()
+
+    def ui(self):
+        ui, _, _ = self.accumulators()
+        return self.ctx.to_host(ui, self.n_features, np.uint32)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.msx_profile_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+
+def coverage(ctx, batch, target_len):
+    """Per-base depth per target (msam_coverage.c:33-87) for one device batch."""
+    off = np.zeros(len(target_len) + 1, np.int64)
+    off[1:] = np.cumsum(np.asarray(target_len, dtype=np.int64))
+    total = int(off[-1])
+    d_off = ctx.alloc(off.nbytes)
+    d_cov = ctx.alloc(4 * max(total, 1) + 8)
+    try:
+        ctx.to_dev(d_off, off)
+        ctx.zero(d_cov, 4 * max(total, 1) + 8)
+        ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off),
+                                                  len(target_len), C.c_void_p(d_cov)))
+        cov = ctx.to_host(d_cov, total, np.int32)
+    finally:
+        ctx.free(d_off)
+        ctx.free(d_cov)
+    return [cov[off[i]:off[i + 1]] for i in range(len(target_len))]

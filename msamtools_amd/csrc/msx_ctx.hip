@@ -1,0 +1,277 @@
+// msx_ctx.hip -- context, workspace, error text, timing table, raw memory helpers.
+#include "msx_internal.h"
+
+#include <cstring>
+
+thread_local std::string msx_tls_err;
+
+int msx_fail(msx_ctx *ctx, int code, const char *fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	if (ctx) ctx->err = buf;
+	msx_tls_err = buf;
+	return code;
+}
+
+int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes) {
+	if (bytes <= b->cap && b->p) return MSX_OK;
+	size_t want = bytes + bytes / 8 + 256;   // slack so streaming batches settle quickly
+	if (b->p) {
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MSX_HIP(ctx, hipFree(b->p));
+		b->p = nullptr;
+		b->cap = 0;
+	}
+	hipError_t e = hipMalloc(&b->p, want);
+	if (e != hipSuccess) {
+		b->p = nullptr;
+		return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+	}
+	b->cap = want;
+	return MSX_OK;
+}
+
+static void free_buf(msx_buf *b) {
+	if (b->p) (void)hipFree(b->p);
+	b->p = nullptr;
+	b->cap = 0;
+}
+
+extern "C" int msx_abi_version(void) { return MSX_ABI_VERSION; }
+
+extern "C" const char *msx_last_error(const msx_ctx *ctx) {
+	return ctx ? ctx->err.c_str() : msx_tls_err.c_str();
+}
+
+extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
+	if (!out) return msx_fail(nullptr, MSX_ERR_ARG, "msx_ctx_create: null output pointer");
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return msx_fail(nullptr, MSX_ERR_NO_DEVICE,
+		                "no HIP device available (%s); libmsamtools_amd has no CPU fallback",
+		                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+	if (device_id < 0 || device_id >= ndev)
+		return msx_fail(nullptr, MSX_ERR_ARG, "device %d out of range (0..%d)", device_id, ndev - 1);
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, device_id);
+	if (e != hipSuccess)
+		return msx_fail(nullptr, MSX_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return msx_fail(nullptr, MSX_ERR_NO_DEVICE,
+		                "device %d is %s; this library carries gfx950 (MI355X) code objects only",
+		                device_id, prop.gcnArchName);
+	msx_ctx *ctx = new msx_ctx();
+	ctx->device = device_id;
+	ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (hipSetDevice(device_id) != hipSuccess ||
+	    hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipMalloc((void **)&ctx->d_status, sizeof(msx_dev_status)) != hipSuccess ||
+	    hipHostMalloc((void **)&ctx->h_status, sizeof(msx_dev_status), hipHostMallocDefault) != hipSuccess) {
+		int rc = msx_fail(nullptr, MSX_ERR_HIP, "context setup failed: %s",
+		                  hipGetErrorString(hipGetLastError()));
+		delete ctx;
+		return rc;
+	}
+	*out = ctx;
+	return MSX_OK;
+}
+
+extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	for (auto &t : ctx->timed) {
+		(void)hipEventDestroy(t.a);
+		(void)hipEventDestroy(t.b);
+	}
+	for (auto &ev : ctx->event_pool) (void)hipEventDestroy(ev);
+	msx_buf *bufs[] = {&ctx->pool_code, &ctx->gcount, &ctx->gbase, &ctx->scan_l1, &ctx->scan_l2,
+	                   &ctx->scan_l3, &ctx->mlen, &ctx->moff, &ctx->tmp_fid};
+	for (auto *b : bufs) free_buf(b);
+	if (ctx->d_status) (void)hipFree(ctx->d_status);
+	if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" void *msx_ctx_stream(msx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int msx_ctx_sync(msx_ctx *ctx) {
+	if (!ctx) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}
+
+// ---- timing ---------------------------------------------------------------
+
+static const char *k_names[MSX_K_COUNT] = {"aln_stats_filter", "besthit_select", "emit_order",
+                                           "insert_count",     "prop_iter",      "coverage_pileup",
+                                           "scan",             "synth"};
+
+static hipEvent_t get_event(msx_ctx *ctx) {
+	if (!ctx->event_pool.empty()) {
+		hipEvent_t e = ctx->event_pool.back();
+		ctx->event_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e = nullptr;
+	(void)hipEventCreate(&e);
+	return e;
+}
+
+void msx_time_begin(msx_ctx *ctx, int kid) {
+	if (!ctx->timing) return;
+	msx_timed t;
+	t.kid = kid;
+	t.a = get_event(ctx);
+	t.b = get_event(ctx);
+	(void)hipEventRecord(t.a, ctx->stream);
+	ctx->timed.push_back(t);
+}
+
+void msx_time_end(msx_ctx *ctx) {
+	if (!ctx->timing || ctx->timed.empty()) return;
+	(void)hipEventRecord(ctx->timed.back().b, ctx->stream);
+}
+
+extern "C" int msx_timing_enable(msx_ctx *ctx, int on) {
+	if (!ctx) return MSX_ERR_ARG;
+	ctx->timing = on != 0;
+	return MSX_OK;
+}
+
+extern "C" int msx_timing_reset(msx_ctx *ctx) {
+	if (!ctx) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (auto &t : ctx->timed) {
+		ctx->event_pool.push_back(t.a);
+		ctx->event_pool.push_back(t.b);
+	}
+	ctx->timed.clear();
+	return MSX_OK;
+}
+
+extern "C" int msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, int64_t *launches) {
+	if (!ctx || !name) return MSX_ERR_ARG;
+	int kid = -1;
+	for (int i = 0; i < MSX_K_COUNT; i++)
+		if (strcmp(name, k_names[i]) == 0) kid = i;
+	if (kid < 0) return msx_fail(ctx, MSX_ERR_ARG, "unknown kernel name '%s'", name);
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	double tot = 0;
+	int64_t cnt = 0;
+	for (auto &t : ctx->timed) {
+		if (t.kid != kid) continue;
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+			tot += ms;
+			cnt++;
+		}
+	}
+	if (ms_total) *ms_total = tot;
+	if (launches) *launches = cnt;
+	return MSX_OK;
+}
+
+// ---- raw memory helpers -----------------------------------------------------
+
+extern "C" int msx_dev_alloc(msx_ctx *ctx, void **ptr, size_t bytes) {
+	if (!ctx || !ptr) return MSX_ERR_ARG;
+	*ptr = nullptr;
+	hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+	if (e != hipSuccess)
+		return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+	return MSX_OK;
+}
+
+extern "C" void msx_dev_free(msx_ctx *ctx, void *ptr) {
+	(void)ctx;
+	if (ptr) (void)hipFree(ptr);
+}
+
+extern "C" int msx_dev_zero(msx_ctx *ctx, void *ptr, size_t bytes) {
+	if (!ctx) return MSX_ERR_ARG;
+	if (bytes) MSX_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
+	return MSX_OK;
+}
+
+extern "C" int msx_dev_to_host(msx_ctx *ctx, void *host, const void *dev, size_t bytes) {
+	if (!ctx) return MSX_ERR_ARG;
+	if (bytes) {
+		MSX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return MSX_OK;
+}
+
+extern "C" int msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes) {
+	if (!ctx) return MSX_ERR_ARG;
+	if (bytes) {
+		MSX_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return MSX_OK;
+}
+
+// ---- batches ---------------------------------------------------------------
+
+template <typename T>
+static int up(msx_ctx *ctx, const T *src, size_t count, size_t pad_elems, const T **dst) {
+	*dst = nullptr;
+	if (!src) return MSX_OK;
+	void *p = nullptr;
+	size_t bytes = (count + pad_elems) * sizeof(T);
+	hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+	if (e != hipSuccess)
+		return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+	*dst = (const T *)p;
+	if (count) MSX_HIP(ctx, hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+	return MSX_OK;
+}
+
+extern "C" void msx_batch_free(msx_ctx *ctx, msx_batch *dev) {
+	if (!dev) return;
+	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	const void *ptrs[] = {dev->flag, dev->rflags, dev->tid, dev->pos, dev->cigar_off, dev->cigar,
+	                      dev->md_off, dev->md, dev->nm, dev->as, dev->group_off, dev->qname_hash};
+	for (const void *p : ptrs)
+		if (p) (void)hipFree((void *)p);
+	memset(dev, 0, sizeof(*dev));
+}
+
+extern "C" int msx_batch_upload(msx_ctx *ctx, const msx_batch *h, msx_batch *d) {
+	if (!ctx || !h || !d) return MSX_ERR_ARG;
+	memset(d, 0, sizeof(*d));
+	size_t n = (size_t)h->n_records;
+	if (h->n_records < 0 || h->n_records > 0x7fffffffLL)
+		return msx_fail(ctx, MSX_ERR_ARG, "batch of %lld records exceeds the 2^31-1 per-batch limit",
+		                (long long)h->n_records);
+	if (!h->flag || !h->rflags || !h->tid || !h->cigar_off || !h->md_off || !h->nm || !h->as)
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_batch_upload: a required array is NULL");
+	size_t n_cig = n ? h->cigar_off[n] : 0, n_md = n ? h->md_off[n] : 0;
+	d->n_records = h->n_records;
+	d->n_groups = h->group_off ? h->n_groups : 0;
+	int rc;
+#define UP(field, count, pad) \
+	if ((rc = up(ctx, h->field, (count), (pad), &d->field)) != MSX_OK) { msx_batch_free(ctx, d); return rc; }
+	UP(flag, n, 0)
+	UP(rflags, n, 0)
+	UP(tid, n, 0)
+	UP(pos, n, 0)
+	UP(cigar_off, n + 1, 0)
+	UP(cigar, n_cig, 4)
+	UP(md_off, n + 1, 0)
+	UP(md, n_md, 16)       // the stats kernel reads MD as aligned dwords
+	UP(nm, n, 0)
+	UP(as, n, 0)
+	UP(group_off, h->group_off ? (size_t)h->n_groups + 1 : 0, 0)
+	UP(qname_hash, n, 0)
+#undef UP
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}

@@ -1,0 +1,509 @@
+// msx_filter.hip -- device side of `msamtools filter`:
+//   k_aln_stats_filter  per-record CIGAR/MD walk, -l/-p/-z predicates, --rescore,
+//                       pool membership          (mBamVector.c:23-133, msam_filter.c:31-63,132-183)
+//   k_besthit_select    per-pool best-hit / unique-best-hit selection, mate aware
+//                                                 (msam_filter.c:192-263)
+//   k_emit_*            the order in which the reference calls mSamWrite
+//                                                 (msam_filter.c:235-244, mBamVector.c:343-348)
+// All integer work, HBM-bound; no MFMA.  One wave64 lane per record (stats) or
+// per pool (selection); variable-length CIGAR/MD payloads of a 256-record tile
+// are staged into LDS with coalesced dword loads.
+#include "msx_internal.h"
+
+#include <climits>
+
+// LDS staging capacities per 256-record tile.  Typical tile: ~300 CIGAR words,
+// ~1.5 KB of MD.  Payload beyond the capacity is read straight from global.
+#define CAP_CIG 1024          // dwords
+#define CAP_MDW 1536          // dwords (6 KB)
+
+struct FilterArgs {
+	int64_t n;
+	const uint16_t *flag;
+	const uint8_t *rflags;
+	const uint32_t *cigar_off;
+	const uint32_t *cigar;
+	const uint32_t *md_off;
+	const uint8_t *md;
+	const int32_t *nm;
+	const int32_t *as;
+	int32_t min_length, ppt, max_clip;
+	int32_t choice;         // bit0 -l, bit1 -p/--ppt, bit2 -z (msam_filter.c:79-81)
+	int32_t rescore, invert, keep_unmapped;
+	int32_t md_aligned;     // md base is 4-byte aligned -> dword staging allowed
+	uint8_t *pool;          // [n] out: 1 = record enters the pool
+	int32_t *as_out;        // [n] out (rescore) or null
+	int32_t *o_len, *o_qlen, *o_qclip, *o_edit;   // optional per-record stats
+	uint8_t *o_status;
+	msx_dev_status *st;
+};
+
+// One MD byte through the token rule of mBamVector.c:112-118: count the bytes
+// of every maximal run of non-[^0-9] characters whose predecessor is a digit
+// (a run at the start of the string or right after '^' is not counted).
+struct MdState {
+	uint32_t prevL, prevD, counting;
+	int32_t edit;
+};
+
+__device__ __forceinline__ void md_byte(MdState &s, uint32_t c, bool valid) {
+	uint32_t isD = (c - 48u) < 10u;
+	uint32_t isL = (!isD && c != 94u) ? 1u : 0u;
+	if (valid) {
+		if (isL & (s.prevL ^ 1u)) s.counting = s.prevD;
+		s.edit += (int32_t)(isL & s.counting);
+		s.prevL = isL;
+		s.prevD = isD;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
+	__shared__ uint32_t s_coff[MSX_BLOCK + 1];
+	__shared__ uint32_t s_moff[MSX_BLOCK + 1];
+	__shared__ uint32_t s_cig[CAP_CIG];
+	__shared__ uint32_t s_md[CAP_MDW];
+
+	const int tid = threadIdx.x;
+	const int64_t n_tiles = (A.n + MSX_BLOCK - 1) / MSX_BLOCK;
+	const bool need_stats = (A.choice != 0) || A.rescore || A.o_len || A.o_status;
+
+	for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const int64_t t0 = tile * MSX_BLOCK;
+		const int nt = (int)((A.n - t0 < MSX_BLOCK) ? (A.n - t0) : MSX_BLOCK);
+		const int64_t t = t0 + tid;
+		const bool live = tid < nt;
+
+		uint32_t c0 = 0, clen = 0, m0a = 0, mbytes = 0;
+		if (need_stats) {
+			// offsets of the tile (one coalesced dword load per array)
+			if (tid <= nt) {
+				s_coff[tid] = A.cigar_off[t0 + tid];
+				s_moff[tid] = A.md_off[t0 + tid];
+			}
+			if (tid == 0 && nt == MSX_BLOCK) {
+				s_coff[MSX_BLOCK] = A.cigar_off[t0 + MSX_BLOCK];
+				s_moff[MSX_BLOCK] = A.md_off[t0 + MSX_BLOCK];
+			}
+			__syncthreads();
+			c0 = s_coff[0];
+			clen = s_coff[nt] - c0;
+			if (clen > CAP_CIG) clen = CAP_CIG;
+			for (uint32_t w = tid; w < clen; w += MSX_BLOCK) s_cig[w] = A.cigar[c0 + w];
+			if (A.md_aligned) {
+				uint32_t m0 = s_moff[0], m1 = s_moff[nt];
+				m0a = m0 & ~3u;
+				uint32_t mw = (m1 - m0a + 3u) >> 2;
+				if (mw > CAP_MDW) mw = CAP_MDW;
+				const uint32_t *md4 = reinterpret_cast<const uint32_t *>(A.md) + (m0a >> 2);
+				for (uint32_t w = tid; w < mw; w += MSX_BLOCK) s_md[w] = md4[w];
+				mbytes = mw << 2;
+			}
+			__syncthreads();
+		}
+
+		if (live) {
+			const uint32_t flag = A.flag[t];
+			const uint32_t rf = A.rflags[t];
+			uint32_t pooled = 0;
+			if (A.as_out) A.as_out[t] = A.as[t];   // replaced below when the record is rescored
+			if ((flag & MSX_F_UNMAP) && !A.o_len) {
+				// msam_filter.c:132-138 (msx_aln_stats reports statistics for every record)
+				pooled = (A.choice != 0 && A.keep_unmapped && A.ppt >= 0 && A.invert == 1) ? 1u : 0u;
+			} else if (!need_stats) {
+				pooled = 1;   // filter == NULL and no rescore (msam_filter.c:104,181)
+			} else {
+				uint32_t alen = 0, qlen = 0, qclip = 0, edit = 0;   // wrap like int32
+				bool bad = false;
+				const uint32_t cs = s_coff[tid], ce = s_coff[tid + 1];
+				if (rf & MSX_HAS_MD) {
+					// bam_get_summary, mBamVector.c:60-97
+					for (uint32_t k = cs; k < ce; ++k) {
+						uint32_t c = (k - c0 < clen) ? s_cig[k - c0] : A.cigar[k];
+						uint32_t op = c & 0xf, w = c >> 4;
+						if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {
+							qlen += w; alen += w;
+						} else if (op == MSX_OP_INS) {
+							qlen += w; edit += w; alen += w;
+						} else if (op == MSX_OP_DEL) {
+							edit += w; alen += w;
+						} else if (op == MSX_OP_SOFT_CLIP || op == MSX_OP_HARD_CLIP) {
+							qclip += w; qlen += w;
+						}
+					}
+					// MD walk, mBamVector.c:101-118
+					MdState s = {0u, 0u, 0u, 0};
+					const uint32_t ms = s_moff[tid], me = s_moff[tid + 1];
+					if (ms < me) {
+						if (A.md_aligned && (me - m0a) <= mbytes) {
+							const uint32_t bs = ms - m0a, be = me - m0a;
+							for (uint32_t w = bs >> 2; (w << 2) < be; ++w) {
+								const uint32_t word = s_md[w];
+								const uint32_t p = w << 2;
+								md_byte(s, word & 0xffu, p >= bs && p < be);
+								md_byte(s, (word >> 8) & 0xffu, p + 1 >= bs && p + 1 < be);
+								md_byte(s, (word >> 16) & 0xffu, p + 2 >= bs && p + 2 < be);
+								md_byte(s, word >> 24, p + 3 >= bs && p + 3 < be);
+							}
+						} else {
+							for (uint32_t j = ms; j < me; ++j) md_byte(s, A.md[j], true);
+						}
+					}
+					edit += (uint32_t)s.edit;
+				} else if (rf & MSX_HAS_NM) {
+					// bam_cigar2details, mBamVector.c:23-38
+					for (uint32_t k = cs; k < ce; ++k) {
+						uint32_t c = (k - c0 < clen) ? s_cig[k - c0] : A.cigar[k];
+						uint32_t op = c & 0xf, w = c >> 4;
+						if (op == MSX_OP_HARD_CLIP || op == MSX_OP_SOFT_CLIP) {
+							qclip += w; qlen += w;
+						} else if (!(op == MSX_OP_REF_SKIP || op == MSX_OP_PAD)) {
+							alen += w;
+							if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF || op == MSX_OP_INS)
+								qlen += w;
+						}
+					}
+					edit = (uint32_t)A.nm[t];   // msam_filter.c:155
+				} else {
+					bad = true;                 // msam_filter.c:150-152
+					atomicMin(&A.st->first_no_mdnm, (unsigned long long)t);
+				}
+				if (A.o_status) A.o_status[t] = bad ? 1 : 0;
+				if (A.o_len) {
+					A.o_len[t] = (int32_t)alen; A.o_qlen[t] = (int32_t)qlen;
+					A.o_qclip[t] = (int32_t)qclip; A.o_edit[t] = (int32_t)edit;
+				}
+				if (!bad) {
+					if (A.rescore)          // msam_filter.c:160-168: hit=+1, miss=-1
+						A.as_out[t] = (int32_t)((alen - edit) - edit);
+					// msam_filter.c:31-35 in wrapping int32 arithmetic
+					const int32_t L = (int32_t)alen;
+					bool fl = L < A.min_length;
+					bool fz = (int32_t)(100u * qclip) > (int32_t)((uint32_t)A.max_clip * qlen);
+					bool fp = (A.ppt < 0)
+					              ? ((int32_t)(1000u * (edit - alen)) < (int32_t)(alen * (uint32_t)A.ppt))
+					              : ((int32_t)(1000u * (alen - edit)) < (int32_t)(alen * (uint32_t)A.ppt));
+					bool fails = ((A.choice & 1) && fl) || ((A.choice & 2) && fp) || ((A.choice & 4) && fz);
+					pooled = (A.choice == 0 || (int)fails == A.invert) ? 1u : 0u;   // msam_filter.c:181
+				}
+			}
+			if (A.pool) A.pool[t] = (uint8_t)pooled;
+		}
+		if (need_stats) __syncthreads();   // LDS is reused by the next tile
+	}
+}
+
+// ---------------------------------------------------------------------------
+// best-hit selection: one lane per pool.
+// ---------------------------------------------------------------------------
+struct SelectArgs {
+	int64_t n, n_groups;
+	const uint32_t *group_off;
+	const uint16_t *flag;
+	const uint8_t *rflags;
+	const uint8_t *pool;      // null: pooled = mapped (plain --besthit, msam_filter.c:104)
+	const int32_t *as;        // AS to compare (as_out after --rescore)
+	int32_t rescored;         // every mapped pooled record has AS (msam_filter.c:167)
+	int32_t unique_only;      // --uniqhit
+	uint8_t *keep;            // [n]
+	uint32_t *gcount;         // [n_groups] records written per pool
+	msx_dev_status *st;
+};
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
+		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
+		// (best, count) per mate class: 0 = neither bit, 1 = READ1, 2 = READ2
+		int32_t b0 = INT_MIN, b1 = INT_MIN, b2 = INT_MIN;
+		uint32_t n0 = 0, n1 = 0, n2 = 0;
+		uint32_t paired = 0;
+		uint32_t noas0 = 0xffffffffu, noas1 = 0xffffffffu, noas2 = 0xffffffffu;  // first record lacking AS
+		for (uint32_t i = s; i < e; ++i) {
+			const uint32_t fl = A.flag[i];
+			const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+			if (!pooled) continue;
+			const uint32_t cls = fl & MSX_F_MATES;
+			paired |= cls;                                           // mBamPoolIsPaired :196-204
+			const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+			const int32_t sc = A.as[i];
+			if (cls == 0) {
+				if (!has) { if (noas0 == 0xffffffffu) noas0 = i; }
+				else if (sc > b0) { b0 = sc; n0 = 1; } else if (sc == b0) n0++;
+			} else if (cls == 0x40u) {
+				if (!has) { if (noas1 == 0xffffffffu) noas1 = i; }
+				else if (sc > b1) { b1 = sc; n1 = 1; } else if (sc == b1) n1++;
+			} else if (cls == 0x80u) {
+				if (!has) { if (noas2 == 0xffffffffu) noas2 = i; }
+				else if (sc > b2) { b2 = sc; n2 = 1; } else if (sc == b2) n2++;
+			}
+		}
+		// msam_filter.c:219-221: a participating record without AS is fatal
+		uint32_t bad = paired ? (noas1 < noas2 ? noas1 : noas2) : noas0;
+		if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
+		const bool w0 = !paired && n0 > 0 && (!A.unique_only || n0 == 1);   // :232-233
+		const bool w1 = paired && n1 > 0 && (!A.unique_only || n1 == 1);
+		const bool w2 = paired && n2 > 0 && (!A.unique_only || n2 == 1);
+		uint32_t cnt = 0;
+		for (uint32_t i = s; i < e; ++i) {
+			const uint32_t fl = A.flag[i];
+			const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+			uint8_t k = 0;
+			if (pooled) {
+				const uint32_t cls = fl & MSX_F_MATES;
+				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+				const int32_t sc = A.as[i];
+				if (has) {
+					if (cls == 0 && w0 && sc == b0) k = 1;
+					else if (cls == 0x40u && w1 && sc == b1) k = 1;
+					else if (cls == 0x80u && w2 && sc == b2) k = 2;
+				}
+			}
+			A.keep[i] = k;
+			cnt += (k != 0);
+		}
+		A.gcount[g] = cnt;
+	}
+}
+
+// emit order for pools: all pass-1 records of a pool, then its pass-2 records
+__global__ __launch_bounds__(MSX_BLOCK) void k_emit_groups(int64_t n_groups, const uint32_t *__restrict__ group_off,
+                                                           const uint8_t *__restrict__ keep,
+                                                           const uint32_t *__restrict__ gbase,
+                                                           int32_t *__restrict__ emit_idx, msx_dev_status *st) {
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < n_groups; g += stride) {
+		const uint32_t s = group_off[g], e = group_off[g + 1];
+		uint32_t o = gbase[g];
+		const uint32_t cnt = gbase[g + 1] - o;
+		if (cnt && emit_idx) {
+			uint32_t n2 = 0;
+			for (uint32_t i = s; i < e; ++i) {
+				const uint8_t k = keep[i];
+				if (k == 1) emit_idx[o++] = (int32_t)i;
+				n2 += (k == 2);
+			}
+			if (n2)
+				for (uint32_t i = s; i < e; ++i)
+					if (keep[i] == 2) emit_idx[o++] = (int32_t)i;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->n_emit = gbase[n_groups];
+}
+
+// plain filter (no best-hit): output = pooled records in input order.
+// count per 2048-record chunk -> scan -> ordered fill.
+#define EMIT_CHUNK 2048
+__global__ __launch_bounds__(MSX_BLOCK) void k_emit_count(int64_t n, const uint8_t *__restrict__ keep,
+                                                          uint32_t *__restrict__ ccount) {
+	__shared__ uint32_t s_w[4];
+	const int64_t base = (int64_t)blockIdx.x * EMIT_CHUNK;
+	uint32_t c = 0;
+	for (int k = 0; k < EMIT_CHUNK / MSX_BLOCK; k++) {
+		int64_t i = base + k * MSX_BLOCK + threadIdx.x;
+		if (i < n) c += keep[i] != 0;
+	}
+	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) ccount[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_emit_fill(int64_t n, int64_t n_chunks, const uint8_t *__restrict__ keep,
+                                                         const uint32_t *__restrict__ cbase,
+                                                         int32_t *__restrict__ emit_idx, msx_dev_status *st) {
+	__shared__ uint32_t s_w[4];
+	const int64_t base = (int64_t)blockIdx.x * EMIT_CHUNK;
+	uint32_t run = cbase[blockIdx.x];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int k = 0; k < EMIT_CHUNK / MSX_BLOCK; k++) {
+		int64_t i = base + k * MSX_BLOCK + threadIdx.x;
+		const bool kp = (i < n) && keep[i] != 0;
+		const unsigned long long bal = __ballot(kp);
+		if (lane == 0) s_w[w] = (uint32_t)__popcll(bal);
+		__syncthreads();
+		uint32_t before = 0, tot = 0;
+		for (int q = 0; q < 4; q++) {
+			if (q < w) before += s_w[q];
+			tot += s_w[q];
+		}
+		if (kp && emit_idx)
+			emit_idx[run + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
+		run += tot;
+		__syncthreads();
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->n_emit = cbase[n_chunks];
+}
+
+__global__ void k_status_init(msx_dev_status *st) {
+	st->first_no_mdnm = ~0ull;
+	st->first_no_as = ~0ull;
+	st->n_emit = 0;
+}
+
+// ---------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------
+static int filter_choice(const msx_filter_params *p) {
+	int c = 0;
+	if (p->min_length > 0) c |= 1;   // msam_filter.c:79-81
+	if (p->ppt != 0) c |= 2;
+	if (p->max_clip < 100) c |= 4;
+	return c;
+}
+
+static void fill_args(FilterArgs &A, const msx_batch *b) {
+	A.n = b->n_records;
+	A.flag = b->flag;
+	A.rflags = b->rflags;
+	A.cigar_off = b->cigar_off;
+	A.cigar = b->cigar;
+	A.md_off = b->md_off;
+	A.md = b->md;
+	A.nm = b->nm;
+	A.as = b->as;
+	A.md_aligned = (((uintptr_t)b->md) & 3u) == 0 ? 1 : 0;
+}
+
+extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p,
+                                  const msx_filter_out *out) {
+	if (!ctx || !b || !p || !out || !out->keep) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_enqueue: null argument");
+	const int choice = filter_choice(p);
+	const bool best = p->besthit || p->uniqhit;
+	if (choice == 0 && !best)
+		return msx_fail(ctx, MSX_ERR_NO_FILTER,
+		                "'filter' command requires atleast one of --ppt, -l, -p, -z, --besthit or --uniqhit");
+	if (best && !b->group_off)
+		return msx_fail(ctx, MSX_ERR_ARG, "--besthit/--uniqhit need msx_batch.group_off (QNAME pools)");
+	if (p->rescore && !out->as_out)
+		return msx_fail(ctx, MSX_ERR_ARG, "--rescore needs msx_filter_out.as_out");
+	if (b->n_records > 0x7fffffffLL) return msx_fail(ctx, MSX_ERR_ARG, "batch too large");
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	const int64_t n = b->n_records;
+	hipLaunchKernelGGL(k_status_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_status);
+	ctx->filter_pending = true;
+	if (n == 0) return MSX_OK;
+
+	const bool need_stats = choice != 0 || p->rescore;
+	uint8_t *pool = nullptr;
+	int rc;
+	if (need_stats) {
+		FilterArgs A = {};
+		fill_args(A, b);
+		A.min_length = p->min_length;
+		A.ppt = p->ppt;
+		A.max_clip = p->max_clip;
+		A.choice = choice;
+		A.rescore = p->rescore;
+		A.invert = p->invert;
+		A.keep_unmapped = p->keep_unmapped;
+		A.as_out = p->rescore ? out->as_out : nullptr;
+		A.st = ctx->d_status;
+		if (best) {
+			if ((rc = msx_reserve(ctx, &ctx->pool_code, (size_t)n))) return rc;
+			pool = (uint8_t *)ctx->pool_code.p;
+		} else {
+			pool = out->keep;   // mWriteBamPool: keep == pooled
+		}
+		A.pool = pool;
+		msx_time_begin(ctx, MSX_K_ALN_STATS);
+		hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid(ctx, n, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+		                   ctx->stream, A);
+		msx_time_end(ctx);
+	}
+	if (best) {
+		const int64_t ng = b->n_groups;
+		if ((rc = msx_reserve(ctx, &ctx->gcount, (size_t)(ng + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &ctx->gbase, (size_t)(ng + 8) * 4))) return rc;
+		SelectArgs S = {};
+		S.n = n;
+		S.n_groups = ng;
+		S.group_off = b->group_off;
+		S.flag = b->flag;
+		S.rflags = b->rflags;
+		S.pool = pool;
+		S.as = p->rescore ? out->as_out : b->as;
+		S.rescored = p->rescore;
+		S.unique_only = p->uniqhit ? 1 : 0;   // msam_filter.c:88-91: --uniqhit wins
+		S.keep = out->keep;
+		S.gcount = (uint32_t *)ctx->gcount.p;
+		S.st = ctx->d_status;
+		msx_time_begin(ctx, MSX_K_BESTHIT);
+		hipLaunchKernelGGL(k_besthit_select, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+		                   ctx->stream, S);
+		msx_time_end(ctx);
+		if ((rc = msx_scan_u32(ctx, S.gcount, (uint32_t *)ctx->gbase.p, ng))) return rc;
+		msx_time_begin(ctx, MSX_K_EMIT);
+		hipLaunchKernelGGL(k_emit_groups, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   ng, b->group_off, (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p,
+		                   out->emit_idx, ctx->d_status);
+		msx_time_end(ctx);
+	} else {
+		const int64_t nc = (n + EMIT_CHUNK - 1) / EMIT_CHUNK;
+		if ((rc = msx_reserve(ctx, &ctx->gcount, (size_t)(nc + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &ctx->gbase, (size_t)(nc + 8) * 4))) return rc;
+		msx_time_begin(ctx, MSX_K_EMIT);
+		hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nc), dim3(MSX_BLOCK), 0, ctx->stream, n,
+		                   (const uint8_t *)out->keep, (uint32_t *)ctx->gcount.p);
+		msx_time_end(ctx);
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)ctx->gcount.p, (uint32_t *)ctx->gbase.p, nc))) return rc;
+		msx_time_begin(ctx, MSX_K_EMIT);
+		hipLaunchKernelGGL(k_emit_fill, dim3((unsigned)nc), dim3(MSX_BLOCK), 0, ctx->stream, n, nc,
+		                   (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p, out->emit_idx,
+		                   ctx->d_status);
+		msx_time_end(ctx);
+	}
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_filter_finish(msx_ctx *ctx, msx_filter_status *status) {
+	if (!ctx) return MSX_ERR_ARG;
+	if (status) { status->n_emit = 0; status->err_record = -1; }
+	if (!ctx->filter_pending) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_finish without msx_filter_enqueue");
+	ctx->filter_pending = false;
+	MSX_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(msx_dev_status), hipMemcpyDeviceToHost,
+	                            ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const msx_dev_status s = *ctx->h_status;
+	if (status) status->n_emit = (int64_t)s.n_emit;
+	// the reference dies at the first offending record in stream order; stats
+	// errors are raised while reading (before the pool is written)
+	if (s.first_no_mdnm != ~0ull && (s.first_no_as == ~0ull || s.first_no_mdnm <= s.first_no_as)) {
+		if (status) status->err_record = (int64_t)s.first_no_mdnm;
+		return msx_fail(ctx, MSX_ERR_NO_MD_NM,
+		                "Either NM or MD must be present in SAM/BAM input for 'filter' command. "
+		                "Type 'msamtools filter -h' for details.");
+	}
+	if (s.first_no_as != ~0ull) {
+		if (status) status->err_record = (int64_t)s.first_no_as;
+		return msx_fail(ctx, MSX_ERR_NO_AS,
+		                "Required field AS not found in SAM/BAM input. Type 'msamtools -h' for details.");
+	}
+	return MSX_OK;
+}
+
+extern "C" int msx_aln_stats(msx_ctx *ctx, const msx_batch *b, int32_t *length, int32_t *qlen, int32_t *qclip,
+                             int32_t *edit, uint8_t *status) {
+	if (!ctx || !b) return MSX_ERR_ARG;
+	if (!length || !qlen || !qclip || !edit)
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_aln_stats: length/query_length/query_clip/edit are all required");
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(k_status_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_status);
+	if (b->n_records == 0) return MSX_OK;
+	FilterArgs A = {};
+	fill_args(A, b);
+	A.max_clip = 100;
+	A.o_len = length;
+	A.o_qlen = qlen;
+	A.o_qclip = qclip;
+	A.o_edit = edit;
+	A.o_status = status;
+	A.st = ctx->d_status;
+	msx_time_begin(ctx, MSX_K_ALN_STATS);
+	hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid(ctx, b->n_records, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+	                   ctx->stream, A);
+	msx_time_end(ctx);
+	MSX_HIP(ctx, hipGetLastError());
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}

@@ -1,0 +1,123 @@
+// msx_internal.h -- shared internals of libmsamtools_amd.so (HIP, gfx950 only).
+#ifndef MSX_INTERNAL_H
+#define MSX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/msamtools_amd.h"
+
+#define MSX_BLOCK 256          // 4 wave64 per workgroup
+#define MSX_WAVE 64
+
+// BAM constants (SAMv1 4.2)
+#define MSX_OP_MATCH 0
+#define MSX_OP_INS 1
+#define MSX_OP_DEL 2
+#define MSX_OP_REF_SKIP 3
+#define MSX_OP_SOFT_CLIP 4
+#define MSX_OP_HARD_CLIP 5
+#define MSX_OP_PAD 6
+#define MSX_OP_EQUAL 7
+#define MSX_OP_DIFF 8
+#define MSX_F_UNMAP 4u
+#define MSX_F_MATES 0xC0u      // BAM_FREAD1 | BAM_FREAD2
+
+// kernel ids for the timing table
+enum msx_kid {
+	MSX_K_ALN_STATS = 0,
+	MSX_K_BESTHIT,
+	MSX_K_EMIT,
+	MSX_K_INSERT_COUNT,
+	MSX_K_PROP_ITER,
+	MSX_K_COVERAGE,
+	MSX_K_SCAN,
+	MSX_K_SYNTH,
+	MSX_K_COUNT
+};
+
+// device-side status words of one filter call
+struct msx_dev_status {
+	unsigned long long first_no_mdnm;  // min record index, ~0ull if none
+	unsigned long long first_no_as;
+	unsigned long long n_emit;
+};
+
+struct msx_buf {
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct msx_timed {
+	int kid;
+	hipEvent_t a, b;
+};
+
+struct msx_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	int num_cu = 256;
+	// workspace, grown on demand and kept
+	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, mlen, moff, tmp_fid;
+	msx_dev_status *d_status = nullptr;
+	msx_dev_status *h_status = nullptr;  // pinned
+	bool filter_pending = false;
+	// timing
+	bool timing = false;
+	std::vector<msx_timed> timed;
+	std::vector<hipEvent_t> event_pool;
+};
+
+int msx_fail(msx_ctx *ctx, int code, const char *fmt, ...);
+int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes);
+extern thread_local std::string msx_tls_err;
+
+#define MSX_HIP(ctx, call)                                                              \
+	do {                                                                                \
+		hipError_t e_ = (call);                                                         \
+		if (e_ != hipSuccess)                                                           \
+			return msx_fail((ctx), MSX_ERR_HIP, "%s failed: %s (%s:%d)", #call,         \
+			                hipGetErrorString(e_), __FILE__, __LINE__);                 \
+	} while (0)
+
+// RAII-less timing bracket: records events around a launch when enabled
+void msx_time_begin(msx_ctx *ctx, int kid);
+void msx_time_end(msx_ctx *ctx);
+
+static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) {
+	int64_t nb = (items + per_block - 1) / per_block;
+	int64_t cap = (int64_t)ctx->num_cu * 8;   // 8 x 256-thread blocks per CU = 32 waves
+	if (nb > cap) nb = cap;
+	if (nb < 1) nb = 1;
+	return (int)nb;
+}
+
+// exclusive scan: out[0..m] (m+1 entries, out[m] = total), u32
+int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
+int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m);
+
+// profile state
+struct msx_profile {
+	int32_t n_features = 0, n_targets = 0, share_type = 0;
+	int32_t *fmap = nullptr;          // device [n_targets] or null
+	uint32_t *ui = nullptr;           // [n_features]
+	double *d = nullptr;              // [n_features] (EQUAL)
+	uint32_t *counters = nullptr;     // [4]
+	double *U = nullptr, *a = nullptr, *inc = nullptr;   // [n_features]
+	double *delta = nullptr;          // [20] device, delta[k]
+	int32_t *iter_state = nullptr;    // [2]: {done flag, iterations}
+	// compact multi-mapper CSR
+	msx_buf m_off;                    // u32 [n_lists+1] as list start offsets (u32 ok: < 4G entries)
+	msx_buf m_fid;                    // i32 entries
+	int64_t n_lists = 0, n_entries = 0;
+	bool begun = false;
+};
+
+#endif

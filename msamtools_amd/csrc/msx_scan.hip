@@ -1,0 +1,158 @@
+// msx_scan.hip -- exclusive prefix sum over u32 / u64 (reduce-then-scan, 2048
+// items per workgroup).  Used for the emit order of filter's output stream
+// (u32) and for compacting multi-mapper lists, where one u64 scan carries
+// (list count << 32 | entry count).  HBM-bound: reads the input twice, writes once.
+#include "msx_internal.h"
+
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (MSX_BLOCK * SCAN_ITEMS)   // 2048
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		T o = __shfl_up(v, d, 64);
+		if (lane >= d) v += o;
+	}
+	return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive
+// prefix, *total = block sum.  s_w needs 4 slots.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *s_w, T *total) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	T incl = wave_incl_scan<T>(v);
+	if (lane == 63) s_w[w] = incl;
+	__syncthreads();
+	T base = 0, tot = 0;
+#pragma unroll
+	for (int i = 0; i < MSX_BLOCK / 64; i++) {
+		T x = s_w[i];
+		if (i < w) base += x;
+		tot += x;
+	}
+	__syncthreads();
+	*total = tot;
+	return base + incl - v;
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const T *__restrict__ in, int64_t base, int64_t m, T (&v)[SCAN_ITEMS]) {
+	if (base + SCAN_ITEMS <= m) {
+		// 16-byte vector loads (chunk bases are multiples of 2048 items)
+		constexpr int PER = 16 / sizeof(T);
+		using V = typename std::conditional<sizeof(T) == 4, uint4, ulonglong2>::type;
+		const V *p = reinterpret_cast<const V *>(in + base);
+#pragma unroll
+		for (int q = 0; q < SCAN_ITEMS / PER; q++) {
+			V x = p[q];
+			const T *e = reinterpret_cast<const T *>(&x);
+#pragma unroll
+			for (int r = 0; r < PER; r++) v[q * PER + r] = e[r];
+		}
+	} else {
+#pragma unroll
+		for (int k = 0; k < SCAN_ITEMS; k++) v[k] = (base + k < m) ? in[base + k] : (T)0;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const T *__restrict__ in, int64_t m,
+                                                           T *__restrict__ partial) {
+	__shared__ T s_w[4];
+	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+	T v[SCAN_ITEMS];
+	load8<T>(in, base, m, v);
+	T s = 0;
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+	T tot;
+	(void)block_excl_scan<T>(s, s_w, &tot);
+	if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// carry == nullptr: single-chunk top level.  Writes out[i] for i < m and, from
+// the last block, out[m] = grand total.
+template <typename T>
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *__restrict__ in, T *__restrict__ out,
+                                                          int64_t m, const T *__restrict__ carry) {
+	__shared__ T s_w[4];
+	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+	T v[SCAN_ITEMS];
+	load8<T>(in, base, m, v);
+	T s = 0;
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+	T tot;
+	T ex = block_excl_scan<T>(s, s_w, &tot);
+	T c = carry ? carry[blockIdx.x] : (T)0;
+	T run = c + ex;
+	T o[SCAN_ITEMS];
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) {
+		o[k] = run;
+		run += v[k];
+	}
+	if (base + SCAN_ITEMS <= m) {
+		constexpr int PER = 16 / sizeof(T);
+		using V = typename std::conditional<sizeof(T) == 4, uint4, ulonglong2>::type;
+		V *q = reinterpret_cast<V *>(out + base);
+#pragma unroll
+		for (int j = 0; j < SCAN_ITEMS / PER; j++) {
+			V x;
+			T *e = reinterpret_cast<T *>(&x);
+#pragma unroll
+			for (int r = 0; r < PER; r++) e[r] = o[j * PER + r];
+			q[j] = x;
+		}
+	} else {
+#pragma unroll
+		for (int k = 0; k < SCAN_ITEMS; k++)
+			if (base + k < m) out[base + k] = o[k];
+	}
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = c + tot;
+}
+
+template <typename T>
+static int scan_rec(msx_ctx *ctx, const T *in, T *out, int64_t m, int level) {
+	int64_t nb = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+	if (nb < 1) nb = 1;
+	if (nb == 1) {
+		hipLaunchKernelGGL(k_scan_apply<T>, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+		                   (const T *)nullptr);
+		return MSX_OK;
+	}
+	if (level > 2) return msx_fail(ctx, MSX_ERR_ARG, "scan: input too large");
+	msx_buf *lv = level == 0 ? &ctx->scan_l1 : level == 1 ? &ctx->scan_l2 : &ctx->scan_l3;
+	// partial sums [nb] followed by their exclusive scan [nb+1]
+	int rc = msx_reserve(ctx, lv, (size_t)(2 * nb + 8) * sizeof(T));
+	if (rc) return rc;
+	T *partial = (T *)lv->p;
+	T *pscan = partial + ((nb + 3) & ~(int64_t)3);
+	hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, m, partial);
+	rc = scan_rec<T>(ctx, partial, pscan, nb, level + 1);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_scan_apply<T>, dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+	                   (const T *)pscan);
+	return MSX_OK;
+}
+
+int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
+	msx_time_begin(ctx, MSX_K_SCAN);
+	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0);
+	msx_time_end(ctx);
+	if (rc) return rc;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m) {
+	msx_time_begin(ctx, MSX_K_SCAN);
+	int rc = scan_rec<unsigned long long>(ctx, (const unsigned long long *)in, (unsigned long long *)out, m, 0);
+	msx_time_end(ctx);
+	if (rc) return rc;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
