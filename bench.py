@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the msamtools hot path on MI355X.
+
+A step = one pass of `filter -l 80 -p 95 -z 80 --besthit | profile
+--multi=proportional` over one synthetic record batch that is already resident
+in HBM (the metric of BASELINE.json).  Workload (default "c3",
+BASELINE.json configs[2]): 20 M QNAME groups ~ 100 M alignments, 1 M
+references, generated on the device by the library's deterministic generator.
+With --gpus N each rank holds its own shard of that shape (weak scaling): the
+filter/best-hit kernels need no communication; the per-reference count vector
+and, per proportional-sharing iteration, the increment vector are all-reduced
+over RCCL (torch.distributed backend "nccl").
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task prompt),
+including `roofline` for the dominant kernel (HIP-event timings taken on the
+library's own stream) and `cpu_baseline` (the CPU oracle, 1 thread, on a
+bounded sample of the same stream; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WORKLOADS = {
+    # name: (n_groups per GPU, n_refs, description)
+    "c3": (20_000_000, 1_000_000, "synthetic 100 M-alignment / 1 M-ref batch (BASELINE configs[2])"),
+    "c2": (2_000_000, 10_000, "synthetic 10 M-alignment / 10 k-ref batch (BASELINE configs[1])"),
+    "tiny": (20_000, 1_000, "smoke-size batch"),
+}
+FILTER_OPTS = dict(l=80, p=95, z=80, besthit=True)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+SEED = 13579
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--groups", type=int, default=0, help="override QNAME groups per GPU")
+    ap.add_argument("--refs", type=int, default=0, help="override number of references")
+    ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class _DevPtr:
+    """Expose library-owned device memory to torch (for the RCCL all-reduce)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def as_tensor(torch, ptr, n, typestr, dev):
+    return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+
+
+def algorithmic_bytes(name, n, ng, n_cig, n_md, n_emit, n_kept_groups, n_lists, n_entries, nf, iters):
+    """Bytes each kernel must move once (SURVEY.md 8d formulas; stated in DESIGN.md)."""
+    if name == "aln_stats_filter":
+        # reads flag, rflags, cigar_off, cigar, md_off, md ; writes the pool byte
+        return 2 * n + n + 4 * (n + 1) + 4 * n_cig + 4 * (n + 1) + n_md + n
+    if name == "besthit_select":
+        # reads group_off, flag, rflags, pool byte, AS ; writes keep, per-pool count
+        return 4 * (ng + 1) + 2 * n + n + n + 4 * n + n + 4 * ng
+    if name == "emit_order":
+        return 4 * (ng + 1) + n + 4 * (ng + 1) + 4 * n_emit
+    if name == "insert_count":
+        # reads group_off, keep, tid of kept records ; writes list lengths, lists ; RMW ui
+        return 4 * (ng + 1) + n + 4 * n_emit + 8 * ng + 4 * n_entries * 2 + 8 * n_kept_groups
+    if name == "prop_iter":
+        # per iteration: offsets + fid + gather a + atomic RMW inc per entry, 3 vectors swept per feature
+        return iters * (4 * n_lists + n_entries * (4 + 8 + 8) + 4 * 8 * nf)
+    if name == "scan":
+        return 3 * 4 * ng
+    return 0
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import msamtools_amd as m
+
+    dist = None
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                device_id=torch.device(dev))
+
+    ng, nrefs, desc = WORKLOADS[args.workload]
+    if args.groups:
+        ng = args.groups
+    if args.refs:
+        nrefs = args.refs
+
+    ctx = m.Context(local_rank)
+    # each rank owns the groups [rank*ng, (rank+1)*ng) of one deterministic stream
+    db = m.DeviceBatch.synth(ctx, SEED, ng, nrefs, 4, first_group=rank * ng)
+    n = db.n_records
+    run = m.FilterRun(ctx, db, **FILTER_OPTS)
+    prof = m.Profile(ctx, nrefs, "proportional")
+    ui_ptr, _, cnt_ptr = prof.accumulators()
+    t_ui = t_cnt = t_inc = t_purged = None
+    if dist is not None:
+        t_ui = as_tensor(torch, ui_ptr, nrefs, "<i4", dev)       # u32 sums wrap like i32 sums
+        t_cnt = as_tensor(torch, cnt_ptr, 4, "<i4", dev)
+        t_purged = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    state = {"iters": 0, "n_emit": 0}
+
+    def step():
+        nonlocal t_inc
+        prof.reset()
+        run.enqueue()                      # aln_stats_filter, besthit_select, scan, emit_order
+        prof.accumulate(db, run.keep)      # insert_count (+ scan + compaction)
+        if dist is None:
+            prof.finalize_enqueue()        # <= 19 proportional iterations, no host round trip
+            st = run.finish()              # one sync per step; raises on data errors
+            state["n_emit"] = int(st.n_emit)
+        else:
+            ctx.sync()
+            dist.all_reduce(t_ui)
+            dist.all_reduce(t_cnt)
+            torch.cuda.current_stream().synchronize()
+            prof.prop_begin()
+            k = 0
+            while k < 19:
+                inc_ptr = prof.prop_local()
+                if t_inc is None:
+                    t_inc = as_tensor(torch, inc_ptr, nrefs, "<f8", dev)
+                ctx.sync()
+                dist.all_reduce(t_inc)
+                torch.cuda.current_stream().synchronize()
+                delta = prof.prop_apply()
+                k += 1
+                if delta < 1e-10:
+                    break
+            t_purged[0] = prof.prop_purged()
+            dist.all_reduce(t_purged)
+            torch.cuda.current_stream().synchronize()
+            state["iters"] = k
+            st = run.finish()
+            state["n_emit"] = int(st.n_emit)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tn = torch.tensor([n], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn)
+        total_records = int(tn.item())
+    else:
+        total_records = n
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = total_records * args.steps / elapsed / 1e6
+
+    ab, pst = prof.fetch()
+    out = {
+        "metric": "M alignments/s through filter --besthit | profile",
+        "value": round(value, 3),
+        "unit": "M alignments/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32/f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {desc}; filter -l 80 -p 95 -z 80 --besthit | profile --multi=proportional; "
+                        "inputs resident in HBM",
+            "alignments_per_gpu": n, "qname_groups_per_gpu": ng, "references": nrefs,
+            "alignments_kept_rank0": state["n_emit"],
+            "prop_iterations": int(pst.iterations) if dist is None else state["iters"],
+            "parallelism": f"shard{world}" if world > 1 else "single",
+        },
+    }
+
+    # ---- roofline of the dominant kernel (HIP events on the library's stream) ----
+    if rank == 0 and not args.no_roofline:
+        ctx.timing(True)
+        ctx.timing_reset()
+        reps = 3
+        for _ in range(reps):
+            prof.reset()
+            run.enqueue()
+            prof.accumulate(db, run.keep)
+            prof.finalize_enqueue()
+            run.finish()
+        names = ["aln_stats_filter", "besthit_select", "emit_order", "insert_count", "prop_iter", "scan"]
+        tms = {}
+        for k in names:
+            ms, cnt = ctx.timing_get(k)
+            tms[k] = (ms / reps, cnt // reps)
+        ctx.timing(False)
+        ab1, st1 = prof.fetch()
+        sz = db.sizes
+        n_lists, n_entries = prof.multi_size()
+        dom = max(tms, key=lambda k: tms[k][0])
+        kept_groups = int(st1.insert_count)
+        bytes_ = algorithmic_bytes(dom, n, ng, int(sz.n_cigar), int(sz.n_md), state["n_emit"], kept_groups,
+                                   n_lists, n_entries, nrefs, max(int(st1.iterations), 1))
+        dur_ms = tms[dom][0]
+        achieved = bytes_ / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": int(bytes_), "avg_launch_ms": round(dur_ms, 5),
+            "per_kernel_ms_per_step": {k: round(v[0], 5) for k, v in tms.items()},
+        }
+        # the two streaming kernels, always reported for reference
+        for k in ("aln_stats_filter", "besthit_select"):
+            b = algorithmic_bytes(k, n, ng, int(sz.n_cigar), int(sz.n_md), state["n_emit"], kept_groups,
+                                  n_lists, n_entries, nrefs, 1)
+            if tms[k][0] > 0:
+                out["roofline"][k + "_GBps"] = round(b / (tms[k][0] * 1e-3) / 1e9, 2)
+
+    # ---- CPU baseline: the oracle (scalar C port of the reference path), 1 thread ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as orc
+        sg = min(args.cpu_sample_groups, ng)
+        hs = m.HostSynth(SEED, sg, nrefs, 4)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            f = orc.run_filter(hs, **FILTER_OPTS)
+            p = orc.run_profile(hs, nrefs, multi="proportional", sel=f["emit"])
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["cpu_baseline"] = {
+            "value": round(hs.n_records / best / 1e6, 3), "unit": "M alignments/s", "cores": 1, "kind": "port",
+            "sample": f"first {sg} QNAME groups ({hs.n_records} alignments) of the same synthetic stream, "
+                      f"{nrefs} references, records resident in RAM; best of 3 runs of oracle filter+profile "
+                      f"({best:.2f} s each)",
+        }
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    prof.close()
+    run.free()
+    db.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

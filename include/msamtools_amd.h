@@ -233,6 +233,10 @@ int  msx_profile_fetch(msx_ctx *ctx, msx_profile *p, double *abundance_host,
                        msx_profile_stats *stats);
 /* Device pointer of the current abundance vector a(i,k), f64[n_features]. */
 int  msx_profile_abundance_dev(msx_ctx *ctx, msx_profile *p, double **a);
+/* Size of this rank's multi-mapper store (global->multi_mappers, msam_profile.c:
+ * 36-39): number of multi-mapped inserts kept for sharing and the total number
+ * of (insert, feature) entries.  Synchronises the stream. */
+int  msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries);
 
 /* ---- coverage: replaces mUpdateCoverageForAlignment (msam_coverage.c:33-87) */
 

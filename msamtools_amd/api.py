@@ -218,11 +218,13 @@ class HostSynth:
         L.check(None, lib.msx_synth_host(C.byref(sp), C.byref(hb), C.byref(sz)))
         n, ng = int(sz.n_records), int(n_groups)
 
+        self._hb = hb      # numpy views below alias the C buffers; freed in __del__
+
         def grab(ptr, cnt, dt):
             if cnt == 0:
                 return np.zeros(0, dt)
-            buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dt, count=cnt).copy()
+            buf = (C.c_uint8 * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt, count=cnt)
         self.flag = grab(hb.flag, n, np.uint16)
         self.rflags = grab(hb.rflags, n, np.uint8)
         self.tid = grab(hb.tid, n, np.int32)
@@ -240,7 +242,15 @@ class HostSynth:
         self.name_id = np.repeat(np.arange(ng, dtype=np.int32) + np.int32(first_group % (1 << 31)),
                                  np.diff(self.group_off).astype(np.int64))
         self.n_records, self.n_groups = n, ng
-        lib.msx_synth_host_free(C.byref(hb))
+
+    def __del__(self):
+        try:
+            hb = getattr(self, "_hb", None)
+            if hb is not None:
+                self._hb = None
+                L.load().msx_synth_host_free(C.byref(hb))
+        except Exception:
+            pass
 
 
 class FilterResult:
@@ -362,6 +372,11 @@ class Profile:
         a = C.c_void_p()
         self.ctx.check(self.ctx.lib.msx_profile_abundance_dev(self.ctx.h, self.h, C.byref(a)))
         return a.value
+
+    def multi_size(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.ctx.check(self.ctx.lib.msx_profile_multi_size(self.ctx.h, self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def finalize_enqueue(self):
         self.ctx.check(self.ctx.lib.msx_profile_finalize_enqueue(self.ctx.h, self.h))

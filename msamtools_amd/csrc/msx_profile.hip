@@ -405,6 +405,17 @@ extern "C" int msx_profile_abundance_dev(msx_ctx *ctx, msx_profile *p, double **
 	return MSX_OK;
 }
 
+extern "C" int msx_profile_multi_size(msx_ctx *ctx, msx_profile *p0, int64_t *n_lists, int64_t *n_entries) {
+	if (!ctx || !p0) return MSX_ERR_ARG;
+	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
+	unsigned long long t[2] = {0, 0};
+	MSX_HIP(ctx, hipMemcpyAsync(t, p->csr_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n_lists) *n_lists = (int64_t)t[0];
+	if (n_entries) *n_entries = (int64_t)t[1];
+	return MSX_OK;
+}
+
 static int nf_grid(msx_ctx *ctx, int32_t nf) {
 	int g = msx_grid(ctx, nf, MSX_BLOCK);
 	return g > PROP_MAX_BLOCKS ? PROP_MAX_BLOCKS : g;
@@ -420,6 +431,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p0) {
 	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->inc, p->delta, p->iter_state);
 	msx_time_end(ctx);
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(p->counters + 3, 0, 4, ctx->stream));   // purged is recomputed per finalize
 	p->iter_k = 0;
 	p->begun = true;
 	MSX_HIP(ctx, hipGetLastError());

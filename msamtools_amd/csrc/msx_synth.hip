@@ -224,16 +224,36 @@ extern "C" int msx_synth_host(const msx_synth_params *sp, msx_batch *hb, msx_syn
 	uint8_t *rfl = (uint8_t *)malloc(nn);
 	int32_t *tid = (int32_t *)malloc(nn * 4), *pos = (int32_t *)malloc(nn * 4);
 	int32_t *nm = (int32_t *)malloc(nn * 4), *as = (int32_t *)malloc(nn * 4);
+	// sizing pass first: fresh pages are expensive, so allocate exactly
 	uint32_t *coff = (uint32_t *)malloc((nn + 1) * 4), *moff = (uint32_t *)malloc((nn + 1) * 4);
-	uint32_t *cig = (uint32_t *)malloc(nn * 3 * 4 + 16);
-	uint8_t *md = (uint8_t *)malloc(nn * MSX_SYNTH_MD_CAP + 16);
+	if (!coff || !moff) {
+		free(goff); free(coff); free(moff);
+		return msx_fail(nullptr, MSX_ERR_NOMEM, "malloc failed");
+	}
+	uint32_t tc = 0, tm = 0;
+	for (int64_t g = 0; g < ng; g++) {
+		const uint32_t s = goff[g], h = goff[g + 1] - s;
+		const uint64_t gg = (uint64_t)(sp->first_group + g);
+		const uint32_t mask = mates_mask(&m, gg, h);
+		for (uint32_t k = 0; k < h; k++) {
+			msx_synth_rec r;
+			msx_synth_record(&m, gg, k, h, mask, &r);
+			coff[s + k] = tc;
+			moff[s + k] = tm;
+			tc += r.n_cigar;
+			tm += r.md_len;
+		}
+	}
+	coff[n] = tc;
+	moff[n] = tm;
+	uint32_t *cig = (uint32_t *)malloc((size_t)tc * 4 + 16);
+	uint8_t *md = (uint8_t *)malloc((size_t)tm + 16);
 	hb->group_off = goff; hb->flag = flag; hb->rflags = rfl; hb->tid = tid; hb->pos = pos;
 	hb->nm = nm; hb->as = as; hb->cigar_off = coff; hb->md_off = moff; hb->cigar = cig; hb->md = md;
 	if (!flag || !rfl || !tid || !pos || !nm || !as || !coff || !moff || !cig || !md) {
 		msx_synth_host_free(hb);
 		return msx_fail(nullptr, MSX_ERR_NOMEM, "malloc failed");
 	}
-	uint32_t tc = 0, tm = 0;
 	for (int64_t g = 0; g < ng; g++) {
 		const uint32_t s = goff[g], h = goff[g + 1] - s;
 		const uint64_t gg = (uint64_t)(sp->first_group + g);
@@ -245,15 +265,10 @@ extern "C" int msx_synth_host(const msx_synth_params *sp, msx_batch *hb, msx_syn
 			flag[i] = r.flag;
 			rfl[i] = (uint8_t)(MSX_HAS_MD | MSX_HAS_NM | MSX_HAS_AS);
 			tid[i] = r.tid; pos[i] = r.pos; nm[i] = r.nm; as[i] = r.as;
-			coff[i] = tc;
-			for (uint32_t q = 0; q < r.n_cigar; q++) cig[tc++] = r.cigar[q];
-			moff[i] = tm;
-			memcpy(md + tm, r.md, r.md_len);
-			tm += r.md_len;
+			for (uint32_t q = 0; q < r.n_cigar; q++) cig[coff[i] + q] = r.cigar[q];
+			memcpy(md + moff[i], r.md, r.md_len);
 		}
 	}
-	coff[n] = tc;
-	moff[n] = tm;
 	hb->n_records = n;
 	hb->n_groups = ng;
 	if (sizes) {

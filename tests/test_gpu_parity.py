@@ -1,0 +1,432 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+the reference's golden expectations.  Bar: bit-exact for record selection,
+output order, integer statistics and counts; <= 1e-6 relative (stated in each
+test) for the double-precision proportional profile (BASELINE.json north_star).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import samio
+from conftest import GOLDEN, fixture_path
+
+pytestmark = pytest.mark.gpu
+
+EXP = json.load(open(os.path.join(GOLDEN, "reference_expectations.json")))
+REL_TOL = 1e-6      # north_star tolerance for the floating-point profile
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import msamtools_amd as m
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+def records_str(rec, emit):
+    return ",".join(f"{rec.name(i)}:{int(rec.flag[i])}" for i in emit)
+
+
+def gpu_filter(ctx, rec, **opts):
+    import msamtools_amd as m
+    best = opts.get("besthit") or opts.get("uniqhit")
+    goff = m.filter_pools(rec) if best else None
+    batch = m.DeviceBatch.upload(ctx, rec, goff)
+    try:
+        return m.run_filter(ctx, batch, **opts)
+    finally:
+        batch.free()
+
+
+def gpu_profile(ctx, rec, n_features, multi, goff, keep=None, fmap=None):
+    import msamtools_amd as m
+    batch = m.DeviceBatch.upload(ctx, rec, goff)
+    prof = m.Profile(ctx, n_features, multi, fmap)
+    kp = None
+    try:
+        if keep is not None:
+            kp = ctx.alloc(max(len(keep), 1))
+            ctx.to_dev(kp, np.ascontiguousarray(keep, dtype=np.uint8))
+        prof.accumulate(batch, kp)
+        ui = prof.ui()
+        ab, st = prof.finalize()
+        return ab.copy(), st, ui
+    finally:
+        if kp:
+            ctx.free(kp)
+        prof.close()
+        batch.free()
+
+
+def assert_profile_close(ab, st, ref, tol=REL_TOL):
+    s = ref["stats"]
+    assert (st.insert_count, st.uniq_mapper_count, st.multi_mapper_count, st.purged_insert_count) == \
+        (s.insert_count, s.uniq_mapper_count, s.multi_mapper_count, s.purged_insert_count)
+    want = ref["abundance"]
+    assert ((ab == 0) == (want == 0)).all()
+    scale = np.maximum(np.abs(want), 1e-300)
+    assert (np.abs(ab - want) / scale).max() <= tol
+
+
+# ---- the reference's golden vectors through the GPU ---------------------------
+
+@pytest.mark.parametrize("case", EXP["filter"], ids=[c["name"] for c in EXP["filter"]])
+def test_filter_golden_gpu(ctx, case):
+    hdr, rec = samio.read_sam(fixture_path(case["fixture"]))
+    res = gpu_filter(ctx, rec, **case["opts"])
+    assert records_str(rec, res.emit) == case["records"], case["src"]
+    want = orc.run_filter(rec, **case["opts"])
+    assert res.emit.tolist() == want["emit"].tolist()
+    assert res.n_emit == int((res.keep != 0).sum())
+    if case["opts"].get("rescore"):
+        mapped = (rec.flag & 4) == 0
+        assert (res.as_out[mapped] == want["as_out"][mapped]).all()
+        for key, val in case.get("as", {}).items():
+            idx = [i for i in res.emit if f"{rec.name(i)}:{int(rec.flag[i])}" == key]
+            assert idx and all(res.as_out[i] == val for i in idx)
+
+
+def test_long_qname_besthit_gpu(ctx):
+    blk = EXP["long_qname"]
+    hdr, rec = samio.read_sam(fixture_path(blk["fixture"]))
+    for case in blk["cases"]:
+        res = gpu_filter(ctx, rec, **case["opts"])
+        got = [[len(rec.name(i)), int(rec.flag[i]), hdr.target_name[rec.tid[i]], int(rec.as_[i])] for i in res.emit]
+        assert got == blk["expected"]
+
+
+@pytest.mark.parametrize("case", EXP["profile"], ids=[c["name"] for c in EXP["profile"]])
+def test_profile_golden_gpu(ctx, case):
+    import msamtools_amd as m
+    hdr, rec = samio.read_sam(fixture_path(case["fixture"]))
+    keep, sel = None, None
+    if "filter_opts" in case:
+        # the pipe `filter ... | profile -`: profile sees filter's output stream
+        res = gpu_filter(ctx, rec, **dict(case["filter_opts"]))
+        keep, sel = res.keep, res.emit
+        goff = m.filter_pools(rec)
+    else:
+        goff = m.profile_pools(rec)
+    ab, st, ui = gpu_profile(ctx, rec, hdr.n_targets, case["multi"], goff, keep)
+    ref = orc.run_profile(rec, hdr.n_targets, multi=case["multi"], sel=sel)
+    assert (ui == ref["ui"]).all()
+    assert_profile_close(ab, st, ref)
+    for key, fld in (("mapped", "insert_count"), ("multi_mapped", "multi_mapper_count"),
+                     ("uniq_mapped", "uniq_mapper_count")):
+        if key in case:
+            assert getattr(st, fld) == case[key], (key, case["src"])
+    ost = orc.OrcProfileStats()
+    for f in ("insert_count", "uniq_mapper_count", "multi_mapper_count", "purged_insert_count"):
+        setattr(ost, f, getattr(st, f))
+    vals, purged, eff = orc.profile_finish(ab, hdr.target_len, ost, unit=case["unit"], nolen=case["nolen"],
+                                           total=case["total"], mincount=case.get("mincount", -1),
+                                           multi=case["multi"])
+    names = ["Unknown"] + hdr.target_name
+    for feat, (want, tol) in case["values"].items():
+        assert abs(vals[names.index(feat)] - want) <= tol, (feat, case["src"])
+
+
+def test_tiny_aln_gpu(ctx):
+    """BASELINE.json configs[0]: tiny_aln.bam through filter -l 80 -p 95 -z 80 --besthit | profile."""
+    import msamtools_amd as m
+    t = EXP["tiny_aln"]
+    hdr, rec = samio.read_bam(fixture_path(t["fixture"]))
+    goff = m.filter_pools(rec)
+    batch = m.DeviceBatch.upload(ctx, rec, goff)
+    st = m.aln_stats(ctx, batch)
+    for k in ("length", "qlen", "qclip", "edit"):
+        assert st[k].tolist() == t[k]
+    res = m.run_filter(ctx, batch, **t["filter_opts"])
+    assert res.emit.tolist() == t["emit"]
+    uq = dict(t["filter_opts"], besthit=False, uniqhit=True)
+    assert m.run_filter(ctx, batch, **uq).emit.tolist() == t["uniqhit_emit"]
+    batch.free()
+    ab, ps, ui = gpu_profile(ctx, rec, hdr.n_targets, "proportional", goff, res.keep)
+    assert (ps.insert_count, ps.uniq_mapper_count, ps.multi_mapper_count, ps.purged_insert_count) == \
+        (t["mapped"], t["uniq_mapped"], t["multi_mapped"], t["purged"])
+    assert ps.iterations == 1 and ps.converged == 1 and ps.delta[1] == 0.0
+    ref = orc.run_profile(rec, hdr.n_targets, sel=np.array(t["emit"], np.int32))
+    assert (ab == ref["abundance"]).all()       # nothing is shared here: exact
+
+
+def test_coverage_golden_gpu(ctx):
+    import msamtools_amd as m
+    blk = EXP["coverage"]
+    hdr, rec = samio.read_sam(fixture_path(blk["fixture"]))
+    batch = m.DeviceBatch.upload(ctx, rec, None)
+    cov = m.coverage(ctx, batch, hdr.target_len)
+    batch.free()
+    for t, name in enumerate(hdr.target_name):
+        assert cov[t].tolist() == blk["positions"][name]
+
+
+# ---- error behaviour ---------------------------------------------------------------
+
+def _mk(cigars, mds, nms=None, flags=None, names=None, as_=None, tids=None):
+    b = samio._Builder()
+    for i in range(len(cigars)):
+        b.add((names[i] if names else f"r{i}").encode(), flags[i] if flags else 0,
+              tids[i] if tids else 0, 0, samio.parse_cigar_text(cigars[i]),
+              None if mds[i] is None else mds[i].encode(),
+              None if nms is None else nms[i], None if as_ is None else as_[i])
+    return b.build()
+
+
+def test_fatal_errors_match_reference_messages(ctx):
+    import msamtools_amd as m
+    rec = _mk(["10M", "10M"], [None, None], nms=[0, None], names=["a", "b"])
+    with pytest.raises(m.MsxError) as ei:
+        gpu_filter(ctx, rec, l=5)
+    assert ei.value.code == 1 and "Either NM or MD must be present" in ei.value.text
+    with pytest.raises(m.MsxError) as ei:
+        gpu_filter(ctx, rec, besthit=True)
+    assert ei.value.code == 2 and "Required field AS not found" in ei.value.text
+    batch = m.DeviceBatch.upload(ctx, rec, None)
+    with pytest.raises(m.MsxError) as ei:
+        m.run_filter(ctx, batch)
+    assert ei.value.code == 3 and "requires atleast one of" in ei.value.text
+    batch.free()
+
+
+def test_unpinned_semantics_match_oracle(ctx):
+    """'^' deletions in MD, odd CIGAR ops, mate-bit corner cases, unmapped flush rule."""
+    import msamtools_amd as m
+    rec = _mk(["50M2D48M", "10M", "10M", "5M1D5M"], ["50^AC48", "A9", "0A9", "5^A0T4"])
+    batch = m.DeviceBatch.upload(ctx, rec, None)
+    st = m.aln_stats(ctx, batch)
+    batch.free()
+    assert st["edit"].tolist() == [2, 0, 1, 2] and st["length"].tolist() == [100, 10, 10, 11]
+    cig = [(5 << 4) | 0, (3 << 4) | 9, (2 << 4) | 2, (4 << 4) | 3, (1 << 4) | 6]
+    b = samio._Builder()
+    b.add(b"a", 0, 0, 0, cig, None, 1, None)
+    b.add(b"b", 0, 0, 0, cig, b"5", None, None)
+    rec = b.build()
+    batch = m.DeviceBatch.upload(ctx, rec, None)
+    st = m.aln_stats(ctx, batch)
+    batch.free()
+    assert st["length"].tolist() == [10, 7] and st["qlen"].tolist() == [5, 5] and st["edit"].tolist() == [1, 2]
+    rec = _mk(["10M"] * 4, ["10"] * 4, flags=[0, 65, 129, 193], names=["q"] * 4, as_=[50, 10, 20, 99])
+    assert gpu_filter(ctx, rec, besthit=True).emit.tolist() == [1, 2]
+    rec = _mk(["10M", "*", "10M", "10M"], ["10", None, "10", "10"], flags=[0, 4, 256, 0],
+              names=["a", "b", "a", "c"], as_=[10, 0, 20, 5])
+    assert gpu_filter(ctx, rec, besthit=True).emit.tolist() == [0, 2, 3]
+
+
+def test_empty_and_single_record_batches(ctx):
+    import msamtools_amd as m
+    hdr, rec = samio.read_sam(fixture_path("profile_empty.sam"))
+    assert rec.n == 0
+    res = gpu_filter(ctx, rec, l=10, besthit=True)
+    assert res.n_emit == 0 and res.emit.size == 0
+    rec = _mk(["100M"], ["100"], as_=[100], names=["solo"])
+    res = gpu_filter(ctx, rec, p=95, besthit=True)
+    assert res.emit.tolist() == [0]
+    ab, st, ui = gpu_profile(ctx, rec, 3, "proportional", m.profile_pools(rec))
+    assert ab.tolist() == [1.0, 0.0, 0.0] and st.insert_count == 1 and st.uniq_mapper_count == 1
+
+
+# ---- seeded synthetic parity at oracle-friendly sizes ----------------------------------
+
+SYNTH_CASES = [
+    dict(l=80, p=95, z=80, besthit=True),
+    dict(l=80, p=95, z=80, uniqhit=True),
+    dict(p=97),
+    dict(ppt=-980),
+    dict(z=90, l=90),
+    dict(p=99, invert=True, keep_unmapped=True),
+    dict(besthit=True),
+    dict(rescore=True, besthit=True),
+    dict(l=70, rescore=True, uniqhit=True),
+]
+
+
+@pytest.fixture(scope="module")
+def synth(ctx):
+    import msamtools_amd as m
+    hs = m.HostSynth(13579, 60000, 2000, 4)
+    db = m.DeviceBatch.synth(ctx, 13579, 60000, 2000, 4)
+    yield hs, db
+    db.free()
+
+
+def test_device_synth_equals_host_twin(ctx, synth):
+    hs, db = synth
+    assert db.n_records == hs.n_records and db.n_groups == hs.n_groups
+    d = db.to_host()
+    for k in ("flag", "rflags", "tid", "pos", "cigar_off", "cigar", "md_off", "md", "nm", "as_", "group_off"):
+        assert (d[k] == getattr(hs, k)).all(), k
+
+
+def test_synth_stats_parity(ctx, synth):
+    import msamtools_amd as m
+    hs, db = synth
+    got = m.aln_stats(ctx, db)
+    want = orc.aln_stats(hs)
+    for k in ("length", "qlen", "qclip", "edit", "status"):
+        assert (got[k] == want[k]).all(), k
+
+
+@pytest.mark.parametrize("opts", SYNTH_CASES, ids=[json.dumps(o, sort_keys=True) for o in SYNTH_CASES])
+def test_synth_filter_parity(ctx, synth, opts):
+    import msamtools_amd as m
+    hs, db = synth
+    res = m.run_filter(ctx, db, **opts)
+    want = orc.run_filter(hs, **opts)
+    assert want["rc"] == 0
+    assert res.n_emit == len(want["emit"])
+    assert (res.emit == want["emit"]).all()
+    kept = np.zeros(hs.n_records, bool)
+    kept[want["emit"]] = True
+    assert ((res.keep != 0) == kept).all()
+    if opts.get("rescore"):
+        assert (res.as_out == want["as_out"]).all()
+
+
+@pytest.mark.parametrize("multi", ["proportional", "equal", "all", "ignore"])
+def test_synth_fused_filter_profile_parity(ctx, synth, multi):
+    """filter -l 80 -p 95 -z 80 --besthit | profile --multi=<mode> on the device vs the oracle pipe."""
+    import msamtools_amd as m
+    hs, db = synth
+    opts = dict(l=80, p=95, z=80, besthit=True)
+    run = m.FilterRun(ctx, db, **opts)
+    run.enqueue()
+    run.finish()
+    prof = m.Profile(ctx, 2000, multi)
+    prof.accumulate(db, run.keep)
+    ui = prof.ui()
+    ab, st = prof.finalize()
+    ab = ab.copy()
+    prof.close()
+    run.free()
+    sel = orc.run_filter(hs, **opts)["emit"]
+    ref = orc.run_profile(hs, 2000, multi=multi, sel=sel)
+    assert (ui == ref["ui"]).all()                     # integer counts: exact
+    assert_profile_close(ab, st, ref)                  # doubles: <= 1e-6 relative
+    if multi == "proportional":
+        assert st.iterations == ref["stats"].iterations and st.converged == ref["stats"].converged
+        assert abs(st.delta[st.iterations] - ref["stats"].last_delta) <= 1e-6 * max(ref["stats"].last_delta, 1e-30)
+
+
+def test_synth_profile_subcommand_with_fmap(ctx, synth):
+    """`profile` on the raw stream (keep == NULL) with a tid -> feature map (--genome)."""
+    import msamtools_amd as m
+    hs, db = synth
+    fmap = (np.arange(2000, dtype=np.int32) // 7).astype(np.int32)
+    nf = int(fmap.max()) + 1
+    prof = m.Profile(ctx, nf, "proportional", fmap)
+    prof.accumulate(db, None)
+    ui = prof.ui()
+    ab, st = prof.finalize()
+    ab = ab.copy()
+    prof.close()
+    ref = orc.run_profile(hs, nf, multi="proportional", fmap=fmap)
+    assert (ui == ref["ui"]).all()
+    assert_profile_close(ab, st, ref)
+
+
+def test_split_proportional_api_matches_finalize(ctx, synth):
+    """begin / (local, apply)* / purged -- the form a multi-GPU caller drives -- equals finalize."""
+    import msamtools_amd as m
+    hs, db = synth
+    prof = m.Profile(ctx, 2000, "proportional")
+    prof.accumulate(db, None)
+    ab1, st1 = prof.finalize()
+    ab1 = ab1.copy()
+    prof.prop_begin()
+    k, delta = 0, 1.0
+    while k < 19:
+        prof.prop_local()
+        delta = prof.prop_apply()
+        k += 1
+        if delta < 1e-10:
+            break
+    purged = prof.prop_purged()
+    ab2 = ctx.to_host(prof.abundance_ptr(), 2000, np.float64)
+    prof.close()
+    assert k == st1.iterations and purged == st1.purged_insert_count
+    assert np.allclose(ab1, ab2, rtol=1e-9, atol=0)
+
+
+def test_streaming_batches_equal_one_batch(ctx):
+    """Accumulating the stream in several QNAME-aligned batches gives the same profile."""
+    import msamtools_amd as m
+    whole = m.DeviceBatch.synth(ctx, 24680, 30000, 500, 4)
+    p1 = m.Profile(ctx, 500, "proportional")
+    p1.accumulate(whole, None)
+    ui1 = p1.ui()
+    ab1, st1 = p1.finalize()
+    ab1 = ab1.copy()
+    p2 = m.Profile(ctx, 500, "proportional")
+    for first in (0, 10000, 20000):
+        part = m.DeviceBatch.synth(ctx, 24680, 10000, 500, 4, first_group=first)
+        p2.accumulate(part, None)
+        ctx.sync()
+        part.free()
+    ui2 = p2.ui()
+    ab2, st2 = p2.finalize()
+    assert (ui1 == ui2).all()
+    assert (st1.insert_count, st1.uniq_mapper_count, st1.multi_mapper_count, st1.purged_insert_count) == \
+        (st2.insert_count, st2.uniq_mapper_count, st2.multi_mapper_count, st2.purged_insert_count)
+    assert np.allclose(ab1, ab2, rtol=1e-9, atol=0)
+    p1.close()
+    p2.close()
+    whole.free()
+
+
+def test_ragged_inputs(ctx):
+    """Very long CIGAR/MD payloads (beyond the LDS staging tile), a 5000-record pool,
+    pools with > 4 distinct references."""
+    import msamtools_amd as m
+    rng = np.random.default_rng(7)
+    b = samio._Builder()
+    # 300 records with 40-op CIGARs and long MD strings -> tile payload > LDS capacity
+    for i in range(300):
+        ops = []
+        for j in range(20):
+            ops += [(int(rng.integers(1, 9)) << 4) | 0, (1 << 4) | (1 if j % 2 else 2)]
+        md = "".join(f"{int(rng.integers(0, 30))}{'ACGT'[int(rng.integers(0, 4))]}" for _ in range(30)) + "5"
+        b.add(f"long{i // 3}".encode(), 0 if i % 3 == 0 else 256, int(rng.integers(0, 50)), 0, ops, md.encode(), None,
+              int(rng.integers(0, 200)))
+    # one pool of 5000 records over 37 references with many score ties
+    for i in range(5000):
+        b.add(b"huge", (65 if i % 2 else 129) | (256 if i > 1 else 0), int(rng.integers(0, 37)), 0,
+              [(100 << 4) | 0], b"100", None, int(rng.integers(90, 100)))
+    # pools with 6..12 distinct references
+    for g in range(200):
+        k = int(rng.integers(6, 13))
+        for j in range(k):
+            b.add(f"multi{g}".encode(), 0 if j == 0 else 256, int(rng.integers(0, 50)), 0, [(100 << 4) | 0], b"100",
+                  None, 100)
+    rec = b.build()
+    goff = m.filter_pools(rec)
+    batch = m.DeviceBatch.upload(ctx, rec, goff)
+    got = m.aln_stats(ctx, batch)
+    want = orc.aln_stats(rec)
+    for k in ("length", "qlen", "qclip", "edit"):
+        assert (got[k] == want[k]).all(), k
+    for opts in (dict(besthit=True), dict(uniqhit=True), dict(l=50, p=60, besthit=True)):
+        res = m.run_filter(ctx, batch, **opts)
+        w = orc.run_filter(rec, **opts)
+        assert (res.emit == w["emit"]).all() and res.n_emit == len(w["emit"])
+    batch.free()
+    for multi in ("proportional", "equal", "all"):
+        ab, st, ui = gpu_profile(ctx, rec, 50, multi, m.profile_pools(rec))
+        ref = orc.run_profile(rec, 50, multi=multi)
+        assert (ui == ref["ui"]).all()
+        assert_profile_close(ab, st, ref)
+
+
+def test_int32_wraparound_matches_oracle(ctx):
+    """Alignments > 2.1 Mbp overflow the reference's int32 threshold products; the kernel wraps like the oracle."""
+    import msamtools_amd as m
+    big = (1 << 28) - 1
+    b = samio._Builder()
+    b.add(b"a", 0, 0, 0, [(big << 4) | 0] * 9, None, 5, None)
+    b.add(b"b", 0, 0, 0, [(3000000 << 4) | 0, (100 << 4) | 4], None, 30000, None)
+    rec = b.build()
+    for opts in (dict(p=95), dict(z=50), dict(l=1000), dict(ppt=-900)):
+        assert gpu_filter(ctx, rec, **opts).emit.tolist() == orc.run_filter(rec, **opts)["emit"].tolist()

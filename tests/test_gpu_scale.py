@@ -1,0 +1,101 @@
+"""Full-size GPU checks (BASELINE.json configs[1]: 10 M alignments, 10 k refs,
+~5 hits/read) through size-independent properties, plus exact comparison of a
+prefix of the big batch with the oracle (pools are independent, so the first
+N pools of the big run must equal a run over those N pools alone)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+N_GROUPS = 2_000_000     # ~10 M alignments
+N_REFS = 10_000
+PREFIX = 100_000         # pools compared record by record with the oracle
+OPTS = dict(l=80, p=95, z=80, besthit=True)
+
+
+@pytest.fixture(scope="module")
+def big():
+    import msamtools_amd as m
+    ctx = m.Context(0)
+    db = m.DeviceBatch.synth(ctx, 13579, N_GROUPS, N_REFS, 4)
+    run = m.FilterRun(ctx, db, **OPTS)
+    run.enqueue()
+    run.finish()
+    res = run.result()
+    yield ctx, db, run, res
+    run.free()
+    db.free()
+    ctx.close()
+
+
+def test_c2_shape(big):
+    ctx, db, run, res = big
+    assert db.n_groups == N_GROUPS and 9_500_000 < db.n_records < 10_500_000
+
+
+def test_c2_emit_properties(big):
+    ctx, db, run, res = big
+    goff = db.fetch("group_off", N_GROUPS + 1, np.uint32).astype(np.int64)
+    keep, emit = res.keep, res.emit.astype(np.int64)
+    assert res.n_emit == int((keep != 0).sum()) == emit.size
+    # every record emitted exactly once, and only kept records
+    assert np.unique(emit).size == emit.size and (keep[emit] != 0).all()
+    # output is pool by pool: the pool id of the emitted records never decreases
+    gid = np.searchsorted(goff, emit, side="right") - 1
+    assert (np.diff(gid) >= 0).all()
+    # within a pool: all pass-1 (READ1) records before pass-2 (READ2), each in input order
+    same = np.diff(gid) == 0
+    k = keep[emit].astype(np.int64)
+    assert (np.diff(k)[same] >= 0).all()
+    asc = np.diff(emit) > 0
+    assert asc[same & (np.diff(k) == 0)].all()
+    # best-hit: every kept record has the maximum AS among its pool's kept-or-not candidates of the same mate
+    as_ = db.fetch("as_", db.n_records, np.int32)
+    flag = db.fetch("flag", db.n_records, np.uint16)
+    mate2 = (flag[emit] & 0x80) != 0
+    key = gid * 2 + mate2
+    best = {}
+    order = np.argsort(key, kind="stable")
+    ks, av = key[order], as_[emit][order]
+    starts = np.flatnonzero(np.r_[True, np.diff(ks) != 0])
+    mx = np.maximum.reduceat(av, starts)
+    mn = np.minimum.reduceat(av, starts)
+    assert (mx == mn).all()          # all winners of a (pool, mate) tie at the same score
+
+
+def test_c2_prefix_equals_oracle(big):
+    import msamtools_amd as m
+    ctx, db, run, res = big
+    hs = m.HostSynth(13579, PREFIX, N_REFS, 4)
+    want = orc.run_filter(hs, **OPTS)
+    n = hs.n_records
+    kept = np.zeros(n, bool)
+    kept[want["emit"]] = True
+    assert ((res.keep[:n] != 0) == kept).all()
+    ne = len(want["emit"])
+    assert (res.emit[:ne] == want["emit"]).all()
+
+
+def test_c2_fused_profile_properties(big):
+    import msamtools_amd as m
+    ctx, db, run, res = big
+    prof = m.Profile(ctx, N_REFS, "proportional")
+    prof.accumulate(db, run.keep)
+    ui = prof.ui().astype(np.int64)
+    ab, st = prof.finalize()
+    # integer accounting closes: every insert is unique or multi; ui holds 2 per unique insert
+    assert st.insert_count == st.uniq_mapper_count + st.multi_mapper_count
+    assert ui.sum() == 2 * st.uniq_mapper_count
+    kept_groups = np.unique(np.searchsorted(db.fetch("group_off", N_GROUPS + 1, np.uint32).astype(np.int64),
+                                            res.emit.astype(np.int64), side="right") - 1).size
+    assert st.insert_count == kept_groups
+    # mass conservation of proportional sharing: every non-purged multi-mapper adds exactly 1
+    total = st.uniq_mapper_count + st.multi_mapper_count - st.purged_insert_count
+    assert abs(ab.sum() - total) <= 1e-9 * total
+    assert (ab >= ui / 2 - 1e-12).all() and 1 <= st.iterations <= 19
+    # idempotence: a second finalize of the same counts gives the same vector within fp-atomic noise
+    ab2, st2 = prof.finalize()
+    assert st2.iterations == st.iterations and np.allclose(ab, ab2, rtol=1e-9, atol=0)
+    prof.close()
