@@ -78,8 +78,12 @@ def algorithmic_bytes(name, n, ng, n_cig, n_md, n_emit, n_kept_groups, n_lists, 
         # reads group_off, keep, tid of kept records ; writes list lengths, lists ; RMW ui
         return 4 * (ng + 1) + n + 4 * n_emit + 8 * ng + 4 * n_entries * 2 + 8 * n_kept_groups
     if name == "prop_iter":
-        # per iteration: offsets + fid + gather a + atomic RMW inc per entry, 3 vectors swept per feature
-        return iters * (4 * n_lists + n_entries * (4 + 8 + 8) + 4 * 8 * nf)
+        # per iteration: list pass (offsets 4L, fid 4E, gather a 8E, recip write 8L), feature pass
+        # (key 4E, list id 4E, gather recip 8E), update sweep (U, share r/w, a r/w = 40 B per feature)
+        return iters * (12 * n_lists + 28 * n_entries + 40 * nf)
+    if name == "prop_build":
+        # list ids 4E written; 3 radix passes: keys read twice + pairs read/written once each
+        return 4 * n_entries + 3 * (4 + 8 + 8) * n_entries
     if name == "scan":
         return 3 * 4 * ng
     return 0
@@ -223,7 +227,8 @@ def main():
             prof.accumulate(db, run.keep)
             prof.finalize_enqueue()
             run.finish()
-        names = ["aln_stats_filter", "besthit_select", "emit_order", "insert_count", "prop_iter", "scan"]
+        names = ["aln_stats_filter", "besthit_select", "emit_order", "insert_count", "prop_build", "prop_iter",
+                 "scan"]
         tms = {}
         for k in names:
             ms, cnt = ctx.timing_get(k)

@@ -283,7 +283,9 @@ int  msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes); /
 
 /* Per-kernel accumulated device time measured with HIP events on the ctx
  * stream while enabled.  names: "aln_stats_filter", "besthit_select",
- * "emit_order", "insert_count", "prop_iter", "coverage_pileup", "scan".
+ * "emit_order", "insert_count", "prop_build", "prop_iter", "coverage_pileup",
+ * "scan", "synth".  Brackets nest: "scan" launches issued inside another
+ * bracket are counted in both.
  * Returns total ms and number of launches since the last reset. */
 int  msx_timing_enable(msx_ctx *ctx, int on);
 int  msx_timing_reset(msx_ctx *ctx);

@@ -110,8 +110,8 @@ extern "C" int msx_ctx_sync(msx_ctx *ctx) {
 // ---- timing ---------------------------------------------------------------
 
 static const char *k_names[MSX_K_COUNT] = {"aln_stats_filter", "besthit_select", "emit_order",
-                                           "insert_count",     "prop_iter",      "coverage_pileup",
-                                           "scan",             "synth"};
+                                           "insert_count",     "prop_iter",      "prop_build",
+                                           "coverage_pileup",  "scan",           "synth"};
 
 static hipEvent_t get_event(msx_ctx *ctx) {
 	if (!ctx->event_pool.empty()) {
@@ -131,12 +131,15 @@ void msx_time_begin(msx_ctx *ctx, int kid) {
 	t.a = get_event(ctx);
 	t.b = get_event(ctx);
 	(void)hipEventRecord(t.a, ctx->stream);
+	ctx->timed_open.push_back((int)ctx->timed.size());
 	ctx->timed.push_back(t);
 }
 
 void msx_time_end(msx_ctx *ctx) {
-	if (!ctx->timing || ctx->timed.empty()) return;
-	(void)hipEventRecord(ctx->timed.back().b, ctx->stream);
+	if (!ctx->timing || ctx->timed_open.empty()) return;
+	const int idx = ctx->timed_open.back();
+	ctx->timed_open.pop_back();
+	(void)hipEventRecord(ctx->timed[idx].b, ctx->stream);
 }
 
 extern "C" int msx_timing_enable(msx_ctx *ctx, int on) {
@@ -153,6 +156,7 @@ extern "C" int msx_timing_reset(msx_ctx *ctx) {
 		ctx->event_pool.push_back(t.b);
 	}
 	ctx->timed.clear();
+	ctx->timed_open.clear();
 	return MSX_OK;
 }
 

@@ -36,6 +36,7 @@ enum msx_kid {
 	MSX_K_EMIT,
 	MSX_K_INSERT_COUNT,
 	MSX_K_PROP_ITER,
+	MSX_K_PROP_BUILD,
 	MSX_K_COVERAGE,
 	MSX_K_SCAN,
 	MSX_K_SYNTH,
@@ -72,6 +73,7 @@ struct msx_ctx {
 	// timing
 	bool timing = false;
 	std::vector<msx_timed> timed;
+	std::vector<int> timed_open;     // stack of open brackets (nesting allowed)
 	std::vector<hipEvent_t> event_pool;
 };
 
@@ -103,21 +105,40 @@ static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) {
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
 int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m);
 
-// profile state
+// profile state (one sample)
+#define PROP_MAX_BLOCKS 2048
 struct msx_profile {
 	int32_t n_features = 0, n_targets = 0, share_type = 0;
 	int32_t *fmap = nullptr;          // device [n_targets] or null
-	uint32_t *ui = nullptr;           // [n_features]
-	double *d = nullptr;              // [n_features] (EQUAL)
-	uint32_t *counters = nullptr;     // [4]
-	double *U = nullptr, *a = nullptr, *inc = nullptr;   // [n_features]
+	uint32_t *ui = nullptr;           // [n_features] global->ui_insert_count
+	double *d = nullptr;              // [n_features] global->d_insert_count (EQUAL)
+	uint32_t *counters = nullptr;     // [4] {inserts, uniq, multi, purged}
+	double *U = nullptr, *a = nullptr;   // [n_features] U(i), a(i,k)
+	double *share = nullptr;          // [n_features] sum over multi-mappers of 1/S (all-reduced across ranks)
 	double *delta = nullptr;          // [20] device, delta[k]
 	int32_t *iter_state = nullptr;    // [2]: {done flag, iterations}
-	// compact multi-mapper CSR
-	msx_buf m_off;                    // u32 [n_lists+1] as list start offsets (u32 ok: < 4G entries)
-	msx_buf m_fid;                    // i32 entries
-	int64_t n_lists = 0, n_entries = 0;
+	unsigned long long *csr_tot = nullptr;   // device {n_lists, n_entries}
+	double *partial = nullptr;        // device [PROP_MAX_BLOCKS]
+	uint32_t *purged_local = nullptr; // device [1]
+	// multi-mapper store, list-major CSR (global->multi_mappers)
+	msx_buf m_off;                    // u32 [n_lists+1]
+	msx_buf m_fid;                    // i32 [n_entries]
+	int64_t lists_ub = 0, entries_ub = 0;    // host upper bounds (capacity / grid sizing)
+	// feature-major view built once per finalize by a stable radix sort
+	msx_buf t_key[2], t_val[2];       // ping-pong (feature id, list id) pairs
+	msx_buf rs_hist, rs_off;          // radix-sort histograms
+	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper
+	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
+	bool transposed_valid = false;
+	int iter_k = 0;
 	bool begun = false;
 };
+
+// proportional-sharing engine (msx_prop.hip)
+int msx_prop_build(msx_ctx *ctx, msx_profile *p);            // feature-major view of the multi-mapper store
+int msx_prop_iteration(msx_ctx *ctx, msx_profile *p);        // share[f] = sum_j 1/S_j over this rank's lists
+int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k);
+int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
+int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
 
 #endif

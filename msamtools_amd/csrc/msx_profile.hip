@@ -3,7 +3,7 @@
 //                    (mEstimateInsertCountOnFile/OnPool, msam_profile.c:65-243)
 //   k_multi_compact  appends the pools' distinct-feature lists to the compact
 //                    multi-mapper CSR (global->multi_mappers, msam_profile.c:36-39,107-121,184-186)
-//   k_prop_*         iterative proportional sharing (msam_profile.c:317-410)
+// (the proportional-sharing iteration itself lives in msx_prop.hip)
 // Integer counters are exact (u32 atomics); the proportional iteration is
 // double precision with order-free atomic accumulation (<= 1e-6 relative to the
 // reference's sequential order, as BASELINE.json allows).
@@ -23,8 +23,33 @@ struct CountArgs {
 	unsigned long long *mlen; // [n_groups] (is_multi_list << 32) | n_distinct  (0 when not kept)
 };
 
+// Per-workgroup staging of the per-reference adds in LDS: a small open-addressed
+// table (feature -> pending count).  Hot references (a few references receive a
+// large share of all inserts) collapse to one global atomic per workgroup; an
+// add that finds no slot within 4 probes goes straight to global memory.
+#define UI_TBL 2048
+#define UI_EMPTY (-1)
+
+__device__ __forceinline__ void ui_add(int32_t *s_key, uint32_t *s_val, uint32_t *ui, int32_t fid, uint32_t v) {
+	uint32_t h = ((uint32_t)fid * 2654435761u) >> 21;   // 11 bits
+#pragma unroll
+	for (int probe = 0; probe < 4; ++probe) {
+		const uint32_t slot = (h + probe) & (UI_TBL - 1);
+		const int32_t old = atomicCAS(&s_key[slot], UI_EMPTY, fid);
+		if (old == UI_EMPTY || old == fid) {
+			atomicAdd(&s_val[slot], v);
+			return;
+		}
+	}
+	atomicAdd(&ui[fid], v);
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
+	__shared__ int32_t s_key[UI_TBL];
+	__shared__ uint32_t s_val[UI_TBL];
+	for (int i = threadIdx.x; i < UI_TBL; i += MSX_BLOCK) { s_key[i] = UI_EMPTY; s_val[i] = 0; }
+	__syncthreads();
 	uint32_t c_ins = 0, c_uniq = 0, c_multi = 0;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
@@ -62,18 +87,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 		if (nvalid > 0) {
 			c_ins++;                                          // one insert per pool (:230,:237)
 			if (nd == 1) {                                    // :75-78, :87-91, :152-159
-				atomicAdd(&A.ui[f0], 2u);
+				ui_add(s_key, s_val, A.ui, f0, 2u);
 				c_uniq++;
 			} else {
 				c_multi++;                                    // :95, :162
 				switch (A.share_type) {
 				case MSX_MULTI_ADD_ALL:                       // :99-102, :169-173
-					for (uint32_t k = 0; k < nd; ++k) atomicAdd(&A.ui[lst[k]], 2u);
+					for (uint32_t k = 0; k < nd; ++k) ui_add(s_key, s_val, A.ui, lst[k], 2u);
 					break;
 				case MSX_MULTI_SHARE_EQUAL:
 					if (nvalid == 2) {                        // :103-106 (integer halves)
-						atomicAdd(&A.ui[f0], 1u);
-						atomicAdd(&A.ui[f1], 1u);
+						ui_add(s_key, s_val, A.ui, f0, 1u);
+						ui_add(s_key, s_val, A.ui, f1, 1u);
 					} else {                                  // :175-182
 						const double share = 1.0 / (double)nd;
 						for (uint32_t k = 0; k < nd; ++k) atomicAdd(&A.d[lst[k]], share);
@@ -101,6 +126,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	if (threadIdx.x < 3) {
 		uint32_t v = s_c[threadIdx.x][0] + s_c[threadIdx.x][1] + s_c[threadIdx.x][2] + s_c[threadIdx.x][3];
 		if (v) atomicAdd(&A.counters[threadIdx.x], v);
+	}
+	// flush the staged adds (the barrier above ordered every ui_add before this)
+	for (int i = threadIdx.x; i < UI_TBL; i += MSX_BLOCK) {
+		const uint32_t v = s_val[i];
+		if (v) atomicAdd(&A.ui[s_key[i]], v);
 	}
 }
 
@@ -134,125 +164,10 @@ __global__ void k_multi_advance(int64_t n_groups, const unsigned long long *__re
 	m_off[nl] = (uint32_t)ne;     // CSR sentinel
 }
 
-// ---- proportional sharing ---------------------------------------------------
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint32_t *__restrict__ ui,
-                                                          const double *__restrict__ d, double *__restrict__ U,
-                                                          double *__restrict__ a, double *__restrict__ inc,
-                                                          double *__restrict__ delta, int32_t *iter_state) {
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
-		double u = 1.0 * ui[i] / 2;           // msam_profile.c:284-289
-		if (d) u += d[i];                     // :303-308
-		U[i] = u;
-		a[i] = u;                             // :326
-		inc[i] = 0.0;
-	}
-	if (blockIdx.x == 0 && threadIdx.x < 20) delta[threadIdx.x] = 0.0;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; }
-}
-
-// increment[e] += a[e] / sum over one rank's multi-mappers (msam_profile.c:341-365)
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_scatter(const unsigned long long *__restrict__ csr_tot,
-                                                            const uint32_t *__restrict__ m_off,
-                                                            const int32_t *__restrict__ m_fid,
-                                                            const double *__restrict__ a, double *__restrict__ inc,
-                                                            const int32_t *__restrict__ iter_state) {
-	if (iter_state[0]) return;
-	const int64_t n_lists = (int64_t)csr_tot[0];
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
-		const uint32_t s = m_off[j], e = m_off[j + 1];
-		double sum = 0;
-		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
-		if (sum > 0)
-			for (uint32_t k = s; k < e; ++k) {
-				const int32_t f = m_fid[k];
-				const double v = a[f] / sum;
-				if (v != 0.0) atomicAdd(&inc[f], v);      // adding +0.0 is a no-op
-			}
-	}
-}
-
-// a = U + increment, clamp, per-workgroup partial of sum(diff^2) (msam_profile.c:368-379)
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const double *__restrict__ U,
-                                                          double *__restrict__ inc, double *__restrict__ a,
-                                                          double *__restrict__ partial,
-                                                          const int32_t *__restrict__ iter_state) {
-	__shared__ double s_w[MSX_BLOCK / 64];
-	if (iter_state[0]) return;
-	double acc = 0;
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
-		double v = U[i] + inc[i];
-		if (v < 1e-20) v = 0;
-		const double diff = v - a[i];
-		acc += diff * diff;
-		a[i] = v;
-		inc[i] = 0.0;
-	}
-	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
-	__syncthreads();
-	if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_finish(int nparts, const double *__restrict__ partial, int32_t nf,
-                                                           double *__restrict__ delta, int32_t *iter_state, int k) {
-	__shared__ double s_w[MSX_BLOCK / 64];
-	if (iter_state[0]) return;
-	double acc = 0;
-	for (int i = threadIdx.x; i < nparts; i += MSX_BLOCK) acc += partial[i];
-	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		double dl = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) / nf;   // :380
-		delta[k] = dl;
-		iter_state[1] = k;
-		if (dl < 1e-10) iter_state[0] = 1;                      // :383
-	}
-}
-
-// multi-mappers whose features all ended at zero (msam_profile.c:394-404)
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long long *__restrict__ csr_tot,
-                                                           const uint32_t *__restrict__ m_off,
-                                                           const int32_t *__restrict__ m_fid,
-                                                           const double *__restrict__ a, uint32_t *out_count) {
-	__shared__ uint32_t s_w[MSX_BLOCK / 64];
-	const int64_t n_lists = (int64_t)csr_tot[0];
-	uint32_t c = 0;
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
-		const uint32_t s = m_off[j], e = m_off[j + 1];
-		double sum = 0;
-		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
-		c += (sum == 0);
-	}
-	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t v = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-		if (v) atomicAdd(out_count, v);
-	}
-}
-
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-#define PROP_MAX_BLOCKS 2048
-
-struct msx_profile_ext : msx_profile {
-	unsigned long long *csr_tot = nullptr;   // device {n_lists, n_entries}
-	double *partial = nullptr;               // device [PROP_MAX_BLOCKS]
-	uint32_t *purged_local = nullptr;        // device [1]
-	int64_t lists_ub = 0, entries_ub = 0;    // host upper bounds for capacity
-	int iter_k = 0;
-	bool finalized = false;
-};
-
-static int grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes) {
+int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes) {
 	if (bytes <= b->cap && b->p) return MSX_OK;
 	size_t want = bytes + bytes / 2 + 4096;
 	void *np = nullptr;
@@ -268,12 +183,13 @@ static int grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes) {
 	return MSX_OK;
 }
 
-extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p0) {
-	if (!p0) return;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
+extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
+	if (!p) return;
 	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->inc, p->delta, p->iter_state,
-	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local};
+	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
+	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
+	                p->t_key[0].p, p->t_key[1].p, p->t_val[0].p, p->t_val[1].p, p->rs_hist.p, p->rs_off.p,
+	                p->recip.p};
 	for (void *q : ptrs)
 		if (q) (void)hipFree(q);
 	delete p;
@@ -287,7 +203,7 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 		return msx_fail(ctx, MSX_ERR_SHARE_TYPE, "Do not understand share_type=%d", share_type);
 	if (n_features < 0) return msx_fail(ctx, MSX_ERR_ARG, "n_features < 0");
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
-	msx_profile_ext *p = new msx_profile_ext();
+	msx_profile *p = new msx_profile();
 	p->n_features = n_features;
 	p->n_targets = fmap ? n_targets : n_features;
 	p->share_type = share_type;
@@ -295,7 +211,7 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	bool ok = hipMalloc((void **)&p->ui, nf * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->counters, 4 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->U, nf * 8) == hipSuccess && hipMalloc((void **)&p->a, nf * 8) == hipSuccess &&
-	          hipMalloc((void **)&p->inc, nf * 8) == hipSuccess &&
+	          hipMalloc((void **)&p->share, nf * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->delta, 20 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->iter_state, 2 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->csr_tot, 2 * 8) == hipSuccess &&
@@ -312,8 +228,8 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 		msx_profile_destroy(ctx, p);
 		return rc;
 	}
-	int rc = grow_keep(ctx, &p->m_off, 4096);
-	if (!rc) rc = grow_keep(ctx, &p->m_fid, 4096);
+	int rc = msx_grow_keep(ctx, &p->m_off, 4096);
+	if (!rc) rc = msx_grow_keep(ctx, &p->m_fid, 4096);
 	if (!rc) rc = msx_profile_reset(ctx, p);
 	if (rc) {
 		msx_profile_destroy(ctx, p);
@@ -323,9 +239,8 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	return MSX_OK;
 }
 
-extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p0) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
+extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
+	if (!ctx || !p) return MSX_ERR_ARG;
 	const size_t nf = (size_t)(p->n_features > 0 ? p->n_features : 1);
 	MSX_HIP(ctx, hipMemsetAsync(p->ui, 0, nf * 4, ctx->stream));
 	if (p->d) MSX_HIP(ctx, hipMemsetAsync(p->d, 0, nf * 8, ctx->stream));
@@ -338,13 +253,12 @@ extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p0) {
 	p->lists_ub = p->entries_ub = 0;
 	p->iter_k = 0;
 	p->begun = false;
-	p->finalized = false;
+	p->transposed_valid = false;
 	return MSX_OK;
 }
 
-extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p0, const msx_batch *b, const uint8_t *keep) {
-	if (!ctx || !p0 || !b) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
+extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep) {
+	if (!ctx || !p || !b) return MSX_ERR_ARG;
 	if (!b->group_off || !b->tid) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_accumulate needs tid and group_off");
 	if (b->n_records == 0 || b->n_groups == 0) return MSX_OK;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
@@ -358,8 +272,9 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p0, const msx_b
 		p->lists_ub += ng;
 		p->entries_ub += n;
 		if (p->entries_ub > 0xffffff00LL) return msx_fail(ctx, MSX_ERR_ARG, "multi-mapper CSR exceeds 2^32 entries");
-		if ((rc = grow_keep(ctx, &p->m_off, (size_t)(p->lists_ub + 2) * 4))) return rc;
-		if ((rc = grow_keep(ctx, &p->m_fid, (size_t)(p->entries_ub + 2) * 4))) return rc;
+		if ((rc = msx_grow_keep(ctx, &p->m_off, (size_t)(p->lists_ub + 2) * 4))) return rc;
+		if ((rc = msx_grow_keep(ctx, &p->m_fid, (size_t)(p->entries_ub + 2) * 4))) return rc;
+		p->transposed_valid = false;
 	}
 	CountArgs A = {};
 	A.n_groups = ng;
@@ -405,152 +320,12 @@ extern "C" int msx_profile_abundance_dev(msx_ctx *ctx, msx_profile *p, double **
 	return MSX_OK;
 }
 
-extern "C" int msx_profile_multi_size(msx_ctx *ctx, msx_profile *p0, int64_t *n_lists, int64_t *n_entries) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
+extern "C" int msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries) {
+	if (!ctx || !p) return MSX_ERR_ARG;
 	unsigned long long t[2] = {0, 0};
 	MSX_HIP(ctx, hipMemcpyAsync(t, p->csr_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (n_lists) *n_lists = (int64_t)t[0];
 	if (n_entries) *n_entries = (int64_t)t[1];
 	return MSX_OK;
-}
-
-static int nf_grid(msx_ctx *ctx, int32_t nf) {
-	int g = msx_grid(ctx, nf, MSX_BLOCK);
-	return g > PROP_MAX_BLOCKS ? PROP_MAX_BLOCKS : g;
-}
-
-extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p0) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
-	MSX_HIP(ctx, hipSetDevice(ctx->device));
-	const int32_t nf = p->n_features;
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
-	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
-	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->inc, p->delta, p->iter_state);
-	msx_time_end(ctx);
-	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
-	MSX_HIP(ctx, hipMemsetAsync(p->counters + 3, 0, 4, ctx->stream));   // purged is recomputed per finalize
-	p->iter_k = 0;
-	p->begun = true;
-	MSX_HIP(ctx, hipGetLastError());
-	return MSX_OK;
-}
-
-static void launch_scatter(msx_ctx *ctx, msx_profile_ext *p) {
-	// grid from the host-side upper bound on lists; the kernel reads the exact count
-	int64_t lists = p->lists_ub > 0 ? p->lists_ub : 1;
-	hipLaunchKernelGGL(k_prop_scatter, dim3(msx_grid(ctx, lists, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-	                   (const int32_t *)p->m_fid.p, (const double *)p->a, p->inc, (const int32_t *)p->iter_state);
-}
-
-static void launch_apply(msx_ctx *ctx, msx_profile_ext *p, int k) {
-	const int32_t nf = p->n_features;
-	const int g = nf_grid(ctx, nf);
-	hipLaunchKernelGGL(k_prop_apply, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->inc, p->a,
-	                   p->partial, (const int32_t *)p->iter_state);
-	hipLaunchKernelGGL(k_prop_finish, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, g, (const double *)p->partial, nf,
-	                   p->delta, p->iter_state, k);
-}
-
-extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p0, double **inc) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
-	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local before msx_profile_prop_begin");
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
-	launch_scatter(ctx, p);
-	msx_time_end(ctx);
-	if (inc) *inc = p->inc;
-	MSX_HIP(ctx, hipGetLastError());
-	return MSX_OK;
-}
-
-extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p0, double *delta) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
-	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply before msx_profile_prop_begin");
-	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
-	p->iter_k++;
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
-	launch_apply(ctx, p, p->iter_k);
-	msx_time_end(ctx);
-	MSX_HIP(ctx, hipGetLastError());
-	double dl = 0;
-	MSX_HIP(ctx, hipMemcpyAsync(&dl, p->delta + p->iter_k, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (delta) *delta = dl;
-	return MSX_OK;
-}
-
-extern "C" int msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p0, uint32_t *purged_local) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
-	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
-	int64_t lists = p->lists_ub > 0 ? p->lists_ub : 1;
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
-	hipLaunchKernelGGL(k_prop_purged, dim3(msx_grid(ctx, lists, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-	                   (const int32_t *)p->m_fid.p, (const double *)p->a, p->purged_local);
-	msx_time_end(ctx);
-	MSX_HIP(ctx, hipGetLastError());
-	uint32_t v = 0;
-	MSX_HIP(ctx, hipMemcpyAsync(&v, p->purged_local, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (purged_local) *purged_local = v;
-	return MSX_OK;
-}
-
-extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p0) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
-	int rc = msx_profile_prop_begin(ctx, p);
-	if (rc) return rc;
-	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
-		msx_time_begin(ctx, MSX_K_PROP_ITER);
-		for (int k = 1; k < 20; k++) {            // msam_profile.c:331; converged iterations exit at once
-			launch_scatter(ctx, p);
-			launch_apply(ctx, p, k);
-		}
-		int64_t lists = p->lists_ub > 0 ? p->lists_ub : 1;
-		hipLaunchKernelGGL(k_prop_purged, dim3(msx_grid(ctx, lists, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-		                   (const int32_t *)p->m_fid.p, (const double *)p->a, p->counters + 3);
-		msx_time_end(ctx);
-	}
-	p->finalized = true;
-	MSX_HIP(ctx, hipGetLastError());
-	return MSX_OK;
-}
-
-extern "C" int msx_profile_fetch(msx_ctx *ctx, msx_profile *p0, double *abundance_host, msx_profile_stats *stats) {
-	if (!ctx || !p0) return MSX_ERR_ARG;
-	msx_profile_ext *p = static_cast<msx_profile_ext *>(p0);
-	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_fetch before finalize/prop_begin");
-	uint32_t c[4];
-	int32_t it[2];
-	double dl[20];
-	if (abundance_host && p->n_features > 0)
-		MSX_HIP(ctx, hipMemcpyAsync(abundance_host, p->a, (size_t)p->n_features * 8, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipMemcpyAsync(c, p->counters, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipMemcpyAsync(it, p->iter_state, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipMemcpyAsync(dl, p->delta, 160, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (stats) {
-		stats->insert_count = c[0];
-		stats->uniq_mapper_count = c[1];
-		stats->multi_mapper_count = c[2];
-		stats->purged_insert_count = c[3];
-		stats->converged = it[0];
-		stats->iterations = it[1];
-		for (int i = 0; i < 20; i++) stats->delta[i] = dl[i];
-	}
-	return MSX_OK;
-}
-
-extern "C" int msx_profile_finalize(msx_ctx *ctx, msx_profile *p, double *abundance_host, msx_profile_stats *stats) {
-	int rc = msx_profile_finalize_enqueue(ctx, p);
-	if (rc) return rc;
-	return msx_profile_fetch(ctx, p, abundance_host, stats);
 }

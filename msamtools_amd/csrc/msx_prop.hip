@@ -1,0 +1,461 @@
+// msx_prop.hip -- proportional sharing of multi-mapped inserts
+// (mInsertCountToAbundanceMatrix, msam_profile.c:317-410) without per-entry
+// floating-point atomics.
+//
+// The reference loops over multi-mappers j, computes S_j = sum_{e in j} a[e]
+// and adds a[e]/S_j to increment[e].  Here one iteration is two sparse
+// matrix-vector products over the 0/1 incidence matrix T (features x lists):
+//   recip = 1 / (T^t a)            one lane per list        (k_list_recip)
+//   share = T recip                segmented sum by feature  (k_share_reduce)
+//   increment[f] = a[f] * share[f] folded into the update    (k_prop_apply)
+// T's feature-major order is produced once per finalize by a stable LSD radix
+// sort of (feature, list) pairs, so entries of one feature are contiguous and
+// in ascending list order; hot features spread over many waves instead of
+// serialising on one address.  a[f]*sum(1/S) differs from sum(a[f]/S) only in
+// rounding (<= a few ulp, inside the 1e-6 relative bound of BASELINE.json).
+// Across ranks `share` is the vector to all-reduce (C1 in SURVEY.md section 2).
+#include "msx_internal.h"
+
+#define RS_ROWS 32
+#define RS_WAVE_ELEMS (RS_ROWS * 64)   // entries sorted by one wave per pass
+#define SR_CHUNK 2048                  // entries reduced by one wave
+
+// ---------------------------------------------------------------------------
+// build: (feature, list) pairs, stable radix sort by feature
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MSX_BLOCK) void k_entry_lists(const unsigned long long *__restrict__ csr_tot,
+                                                           const uint32_t *__restrict__ m_off,
+                                                           uint32_t *__restrict__ e_list) {
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
+		const uint32_t s = m_off[j], e = m_off[j + 1];
+		for (uint32_t k = s; k < e; ++k) e_list[k] = (uint32_t)j;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restrict__ keys,
+                                                       const unsigned long long *__restrict__ csr_tot, int shift,
+                                                       uint32_t *__restrict__ hist, int64_t n_waves) {
+	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t wave = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + w;
+	if (wave >= n_waves) return;
+	const int64_t E = (int64_t)csr_tot[1];
+	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
+	const int64_t base = wave * RS_WAVE_ELEMS;
+	for (int row = 0; row < RS_ROWS; row++) {
+		const int64_t k = base + row * 64 + lane;
+		if (k < E) atomicAdd(&s_cnt[w][(keys[k] >> shift) & 255u], 1u);
+	}
+	for (int q = 0; q < 4; q++) {
+		const int d = lane + 64 * q;
+		hist[(int64_t)d * n_waves + wave] = s_cnt[w][d];
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
+                                                          const uint32_t *__restrict__ vals_in,
+                                                          uint32_t *__restrict__ keys_out,
+                                                          uint32_t *__restrict__ vals_out,
+                                                          const unsigned long long *__restrict__ csr_tot, int shift,
+                                                          const uint32_t *__restrict__ hoff, int64_t n_waves) {
+	__shared__ uint32_t s_base[MSX_BLOCK / 64][256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t wave = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + w;
+	if (wave >= n_waves) return;
+	const int64_t E = (int64_t)csr_tot[1];
+	for (int q = 0; q < 4; q++) {
+		const int d = lane + 64 * q;
+		s_base[w][d] = hoff[(int64_t)d * n_waves + wave];
+	}
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const int64_t base = wave * RS_WAVE_ELEMS;
+	for (int row = 0; row < RS_ROWS; row++) {
+		const int64_t k = base + row * 64 + lane;
+		const bool valid = k < E;
+		if (__ballot(valid) == 0ull) break;
+		uint32_t key = 0, val = 0;
+		if (valid) { key = keys_in[k]; val = vals_in[k]; }
+		const uint32_t d = (key >> shift) & 255u;
+		// lanes of this row with the same digit, in lane order (stable)
+		unsigned long long m = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < 8; b++) {
+			const bool bit = (d >> b) & 1u;
+			const unsigned long long bal = __ballot(bit);
+			m &= bit ? bal : ~bal;
+		}
+		const uint32_t rank = (uint32_t)__popcll(m & lt);
+		const uint32_t cnt = (uint32_t)__popcll(m);
+		uint32_t pos = 0;
+		if (valid) pos = s_base[w][d];                 // every lane reads before the leader writes
+		if (valid && rank == 0) s_base[w][d] = pos + cnt;
+		if (valid) {
+			keys_out[pos + rank] = key;
+			vals_out[pos + rank] = val;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// per-iteration kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint32_t *__restrict__ ui,
+                                                          const double *__restrict__ d, double *__restrict__ U,
+                                                          double *__restrict__ a, double *__restrict__ share,
+                                                          double *__restrict__ delta, int32_t *iter_state) {
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
+		double u = 1.0 * ui[i] / 2;           // msam_profile.c:284-289
+		if (d) u += d[i];                     // :303-308
+		U[i] = u;
+		a[i] = u;                             // :326
+		share[i] = 0.0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x < 20) delta[threadIdx.x] = 0.0;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; }
+}
+
+// recip[j] = 1/S_j, S_j = sum of a over the features of multi-mapper j (0 when S_j == 0: :358)
+__global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long long *__restrict__ csr_tot,
+                                                          const uint32_t *__restrict__ m_off,
+                                                          const int32_t *__restrict__ m_fid,
+                                                          const double *__restrict__ a, double *__restrict__ recip,
+                                                          const int32_t *__restrict__ iter_state) {
+	if (iter_state[0]) return;
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
+		const uint32_t s = m_off[j], e = m_off[j + 1];
+		double sum = 0;
+		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
+		recip[j] = sum > 0 ? 1.0 / sum : 0.0;
+	}
+}
+
+// share[f] = sum of recip over the lists containing f.  One wave per SR_CHUNK
+// consecutive (feature-sorted) entries: segmented scan per 64-entry row, the
+// open segment is carried in registers across rows; a feature whose entries
+// all lie inside the chunk is written with a plain store, only the (at most
+// two) segments cut by the chunk boundary use an atomic.
+__global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
+                                                            const uint32_t *__restrict__ t_key,
+                                                            const uint32_t *__restrict__ t_val,
+                                                            const double *__restrict__ recip,
+                                                            double *__restrict__ share,
+                                                            const int32_t *__restrict__ iter_state) {
+	if (iter_state[0]) return;
+	const int64_t E = (int64_t)csr_tot[1];
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
+	const int64_t c0 = wave * SR_CHUNK;
+	if (c0 >= E) return;
+	const int64_t c1 = (c0 + SR_CHUNK < E) ? c0 + SR_CHUNK : E;
+	double carry = 0.0;
+	int carry_started = 0, carry_open = 0;
+	uint32_t carry_key = 0;
+	for (int64_t base = c0; base < c1; base += 64) {
+		const int64_t k = base + lane;
+		const bool valid = k < c1;
+		const uint32_t key = valid ? t_key[k] : 0xffffffffu;
+		double v = valid ? recip[t_val[k]] : 0.0;
+		uint32_t pk = __shfl_up(key, 1, 64);
+		if (lane == 0 && k > 0) pk = t_key[k - 1];
+		const bool head = valid && (k == 0 || pk != key);
+		uint32_t nk = __shfl_down(key, 1, 64);
+		if (valid && (lane == 63 || k + 1 >= c1)) nk = (k + 1 < E) ? t_key[k + 1] : ~key;
+		const bool tail = valid && (nk != key);
+		if (lane == 0 && !head) v += carry;
+		uint32_t f = (head || lane == 0) ? 1u : 0u;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const double ov = __shfl_up(v, d, 64);
+			const uint32_t of = __shfl_up(f, d, 64);
+			if (lane >= d && !f) { v += ov; f = of; }
+		}
+		const unsigned long long hb = __ballot(head);
+		const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+		const bool started = ((hb & upto) == 0ull) ? (carry_started != 0) : true;
+		if (tail) {
+			if (started) share[key] = v;
+			else atomicAdd(&share[key], v);
+		}
+		const int64_t rem = c1 - base - 1;
+		const int ll = rem < 63 ? (int)rem : 63;
+		const double cv = __shfl(v, ll, 64);
+		const int ct = __shfl((int)tail, ll, 64);
+		const int cs = __shfl((int)started, ll, 64);
+		carry_key = __shfl(key, ll, 64);
+		carry_open = !ct;
+		carry = ct ? 0.0 : cv;
+		carry_started = ct ? 0 : cs;
+	}
+	if (lane == 0 && carry_open) atomicAdd(&share[carry_key], carry);
+}
+
+// a = U + a*share, clamp, per-workgroup partial of sum(diff^2) (msam_profile.c:368-379)
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const double *__restrict__ U,
+                                                          double *__restrict__ share, double *__restrict__ a,
+                                                          double *__restrict__ partial,
+                                                          const int32_t *__restrict__ iter_state) {
+	__shared__ double s_w[MSX_BLOCK / 64];
+	if (iter_state[0]) return;
+	double acc = 0;
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
+		const double old = a[i];
+		double v = U[i] + old * share[i];
+		if (v < 1e-20) v = 0;
+		const double diff = v - old;
+		acc += diff * diff;
+		a[i] = v;
+		share[i] = 0.0;
+	}
+	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_finish(int nparts, const double *__restrict__ partial, int32_t nf,
+                                                           double *__restrict__ delta, int32_t *iter_state, int k) {
+	__shared__ double s_w[MSX_BLOCK / 64];
+	if (iter_state[0]) return;
+	double acc = 0;
+	for (int i = threadIdx.x; i < nparts; i += MSX_BLOCK) acc += partial[i];
+	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double dl = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) / nf;   // :380
+		delta[k] = dl;
+		iter_state[1] = k;
+		if (dl < 1e-10) iter_state[0] = 1;                      // :383
+	}
+}
+
+// multi-mappers whose features all ended at zero (msam_profile.c:394-404)
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long long *__restrict__ csr_tot,
+                                                           const uint32_t *__restrict__ m_off,
+                                                           const int32_t *__restrict__ m_fid,
+                                                           const double *__restrict__ a, uint32_t *out_count) {
+	__shared__ uint32_t s_w[MSX_BLOCK / 64];
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	uint32_t c = 0;
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
+		const uint32_t s = m_off[j], e = m_off[j + 1];
+		double sum = 0;
+		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
+		c += (sum == 0);
+	}
+	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t v = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+		if (v) atomicAdd(out_count, v);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int nf_grid(msx_ctx *ctx, int32_t nf) {
+	int g = msx_grid(ctx, nf, MSX_BLOCK);
+	return g > PROP_MAX_BLOCKS ? PROP_MAX_BLOCKS : g;
+}
+
+int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
+	if (p->transposed_valid) return MSX_OK;
+	const int64_t eub = p->entries_ub > 0 ? p->entries_ub : 1;
+	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
+	int rc;
+	for (int i = 0; i < 2; i++) {
+		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->t_val[i], (size_t)(eub + 64) * 4))) return rc;
+	}
+	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
+	const int64_t n_waves = (eub + RS_WAVE_ELEMS - 1) / RS_WAVE_ELEMS;
+	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16) * 4))) return rc;
+	const unsigned long long *tot = p->csr_tot;
+	hipLaunchKernelGGL(k_entry_lists, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
+	                   (const uint32_t *)p->m_off.p, (uint32_t *)p->t_val[0].p);
+	int bits = 0;
+	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
+	const int passes = (bits + 7) / 8;
+	const uint32_t *kin = (const uint32_t *)p->m_fid.p;
+	const uint32_t *vin = (const uint32_t *)p->t_val[0].p;
+	int cur = 0;   // buffer holding vals (and, after pass 0, keys)
+	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
+	for (int ps = 0; ps < passes; ps++) {
+		const int dst = cur ^ 1;
+		hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, tot, ps * 8,
+		                   (uint32_t *)p->rs_hist.p, n_waves);
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
+			return rc;
+		hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
+		                   (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, tot, ps * 8,
+		                   (const uint32_t *)p->rs_off.p, n_waves);
+		kin = (const uint32_t *)p->t_key[dst].p;
+		vin = (const uint32_t *)p->t_val[dst].p;
+		cur = dst;
+	}
+	if (passes == 0) {
+		// a single feature: the list-major order is already feature-major
+		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[0].p, p->m_fid.p, (size_t)eub * 4 < p->m_fid.cap ? (size_t)eub * 4 : p->m_fid.cap,
+		                            hipMemcpyDeviceToDevice, ctx->stream));
+		cur = 0;
+	}
+	p->sorted_buf = cur;
+	p->transposed_valid = true;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
+	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
+	const int64_t eub = p->entries_ub > 0 ? p->entries_ub : 1;
+	hipLaunchKernelGGL(k_list_recip, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
+	                   (const int32_t *)p->m_fid.p, (const double *)p->a, (double *)p->recip.p,
+	                   (const int32_t *)p->iter_state);
+	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
+	hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((n_waves + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
+	                   (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
+	                   (const int32_t *)p->iter_state);
+	return MSX_OK;
+}
+
+int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k) {
+	const int32_t nf = p->n_features;
+	const int g = nf_grid(ctx, nf);
+	hipLaunchKernelGGL(k_prop_apply, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
+	                   p->a, p->partial, (const int32_t *)p->iter_state);
+	hipLaunchKernelGGL(k_prop_finish, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, g, (const double *)p->partial, nf,
+	                   p->delta, p->iter_state, k);
+	return MSX_OK;
+}
+
+int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev) {
+	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
+	hipLaunchKernelGGL(k_prop_purged, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
+	                   (const int32_t *)p->m_fid.p, (const double *)p->a, out_dev);
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	const int32_t nf = p->n_features;
+	msx_time_begin(ctx, MSX_K_PROP_ITER);
+	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
+	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->share, p->delta, p->iter_state);
+	msx_time_end(ctx);
+	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(p->counters + 3, 0, 4, ctx->stream));   // purged is recomputed per finalize
+	p->iter_k = 0;
+	p->begun = true;
+	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		msx_time_begin(ctx, MSX_K_PROP_BUILD);
+		int rc = msx_prop_build(ctx, p);
+		msx_time_end(ctx);
+		if (rc) return rc;
+	}
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local before msx_profile_prop_begin");
+	if (p->share_type != MSX_MULTI_SHARE_PROPORTIONAL)
+		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
+	msx_time_begin(ctx, MSX_K_PROP_ITER);
+	msx_prop_iteration(ctx, p);
+	msx_time_end(ctx);
+	if (inc) *inc = p->share;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delta) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply before msx_profile_prop_begin");
+	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
+	p->iter_k++;
+	msx_time_begin(ctx, MSX_K_PROP_ITER);
+	msx_prop_apply_launch(ctx, p, p->iter_k);
+	msx_time_end(ctx);
+	MSX_HIP(ctx, hipGetLastError());
+	double dl = 0;
+	MSX_HIP(ctx, hipMemcpyAsync(&dl, p->delta + p->iter_k, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (delta) *delta = dl;
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *purged_local) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
+	msx_time_begin(ctx, MSX_K_PROP_ITER);
+	msx_prop_purged_launch(ctx, p, p->purged_local);
+	msx_time_end(ctx);
+	MSX_HIP(ctx, hipGetLastError());
+	uint32_t v = 0;
+	MSX_HIP(ctx, hipMemcpyAsync(&v, p->purged_local, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (purged_local) *purged_local = v;
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	int rc = msx_profile_prop_begin(ctx, p);
+	if (rc) return rc;
+	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		msx_time_begin(ctx, MSX_K_PROP_ITER);
+		for (int k = 1; k < 20; k++) {            // msam_profile.c:331; converged iterations exit at once
+			msx_prop_iteration(ctx, p);
+			msx_prop_apply_launch(ctx, p, k);
+		}
+		msx_prop_purged_launch(ctx, p, p->counters + 3);
+		msx_time_end(ctx);
+	}
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_fetch(msx_ctx *ctx, msx_profile *p, double *abundance_host, msx_profile_stats *stats) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_fetch before finalize/prop_begin");
+	uint32_t c[4];
+	int32_t it[2];
+	double dl[20];
+	if (abundance_host && p->n_features > 0)
+		MSX_HIP(ctx, hipMemcpyAsync(abundance_host, p->a, (size_t)p->n_features * 8, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipMemcpyAsync(c, p->counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipMemcpyAsync(it, p->iter_state, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipMemcpyAsync(dl, p->delta, 160, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (stats) {
+		stats->insert_count = c[0];
+		stats->uniq_mapper_count = c[1];
+		stats->multi_mapper_count = c[2];
+		stats->purged_insert_count = c[3];
+		stats->converged = it[0];
+		stats->iterations = it[1];
+		for (int i = 0; i < 20; i++) stats->delta[i] = dl[i];
+	}
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_finalize(msx_ctx *ctx, msx_profile *p, double *abundance_host, msx_profile_stats *stats) {
+	int rc = msx_profile_finalize_enqueue(ctx, p);
+	if (rc) return rc;
+	return msx_profile_fetch(ctx, p, abundance_host, stats);
+}
