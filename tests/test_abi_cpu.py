@@ -42,7 +42,7 @@ def test_library_carries_gfx950_code_object():
     from msamtools_amd import _lib
     data = open(_lib.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in data
-    for kern in (b"k_aln_stats_filter", b"k_besthit_select", b"k_insert_count", b"k_prop_scatter"):
+    for kern in (b"k_aln_stats_filter", b"k_besthit_select", b"k_insert_count", b"k_share_reduce", b"k_rs_scatter"):
         assert kern in data
 
 
