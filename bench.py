@@ -35,6 +35,9 @@ WORKLOADS = {
 }
 FILTER_OPTS = dict(l=80, p=95, z=80, besthit=True)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+# HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
+# filled from profiles/ when measured for the default workload; None = not measured.
+TRAFFIC = {}
 SEED = 13579
 
 
@@ -64,28 +67,38 @@ def as_tensor(torch, ptr, n, typestr, dev):
     return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
 
 
-def algorithmic_bytes(name, n, ng, n_cig, n_md, n_emit, n_kept_groups, n_lists, n_entries, nf, iters):
-    """Bytes each kernel must move once (SURVEY.md 8d formulas; stated in DESIGN.md)."""
-    if name == "aln_stats_filter":
-        # reads flag, rflags, cigar_off, cigar, md_off, md ; writes the pool byte
-        return 2 * n + n + 4 * (n + 1) + 4 * n_cig + 4 * (n + 1) + n_md + n
-    if name == "besthit_select":
+def algorithmic_bytes(name, w):
+    """Bytes one launch of `name` must move once (SURVEY.md 8d formulas).
+    w: dict with n (records), ng (pools), n_cig, n_md, n_emit, kept_groups, L (multi-mapper lists),
+    E (list entries), nf (features), uniq."""
+    n, ng, E, L, nf = w["n"], w["ng"], w["E"], w["L"], w["nf"]
+    if name == "k_aln_stats_filter":
+        # reads flag 2, rflags 1, cigar_off 4, cigar, md_off 4, md ; writes the pool byte
+        return 2 * n + n + 4 * (n + 1) + 4 * w["n_cig"] + 4 * (n + 1) + w["n_md"] + n
+    if name == "k_besthit_select":
         # reads group_off, flag, rflags, pool byte, AS ; writes keep, per-pool count
         return 4 * (ng + 1) + 2 * n + n + n + 4 * n + n + 4 * ng
-    if name == "emit_order":
-        return 4 * (ng + 1) + n + 4 * (ng + 1) + 4 * n_emit
-    if name == "insert_count":
-        # reads group_off, keep, tid of kept records ; writes list lengths, lists ; RMW ui
-        return 4 * (ng + 1) + n + 4 * n_emit + 8 * ng + 4 * n_entries * 2 + 8 * n_kept_groups
-    if name == "prop_iter":
-        # per iteration: list pass (offsets 4L, fid 4E, gather a 8E, recip write 8L), feature pass
-        # (key 4E, list id 4E, gather recip 8E), update sweep (U, share r/w, a r/w = 40 B per feature)
-        return iters * (12 * n_lists + 28 * n_entries + 40 * nf)
-    if name == "prop_build":
-        # list ids 4E written; 3 radix passes: keys read twice + pairs read/written once each
-        return 4 * n_entries + 3 * (4 + 8 + 8) * n_entries
+    if name == "k_emit_order":
+        return 4 * (ng + 1) + n + 4 * (ng + 1) + 4 * w["n_emit"]
+    if name == "k_insert_count":
+        # reads group_off, keep, tid of kept records ; writes list lengths and distinct lists ; RMW ui
+        return 4 * (ng + 1) + n + 4 * w["n_emit"] + 8 * ng + 4 * (E + w["uniq"]) + 8 * w["uniq"]
+    if name == "k_multi_compact":
+        return 16 * ng + 4 * L + 8 * E + 4 * L
+    if name == "k_list_recip":
+        # offsets 4(L+1), feature ids 4E, gather a 8E, recip write 8L
+        return 4 * (L + 1) + 12 * E + 8 * L
+    if name == "k_share_reduce":
+        # feature id 4E, list id 4E, gather recip 8E, share write 8 per feature
+        return 16 * E + 8 * nf
+    if name == "k_prop_apply":
+        return 40 * nf
+    if name == "k_rs_hist":
+        return 4 * E + 1024 * ((E + 2047) // 2048)
+    if name == "k_rs_scatter":
+        return 16 * E + 1024 * ((E + 2047) // 2048)
     if name == "scan":
-        return 3 * 4 * ng
+        return 12 * ng
     return 0
 
 
@@ -227,34 +240,38 @@ def main():
             prof.accumulate(db, run.keep)
             prof.finalize_enqueue()
             run.finish()
-        names = ["aln_stats_filter", "besthit_select", "emit_order", "insert_count", "prop_build", "prop_iter",
-                 "scan"]
+        names = ["k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
+                 "k_rs_hist", "k_rs_scatter", "k_list_recip", "k_share_reduce", "k_prop_apply", "scan"]
         tms = {}
         for k in names:
             ms, cnt = ctx.timing_get(k)
-            tms[k] = (ms / reps, cnt // reps)
+            tms[k] = (ms / reps, cnt / reps)          # ms per step, launches per step
         ctx.timing(False)
         ab1, st1 = prof.fetch()
         sz = db.sizes
         n_lists, n_entries = prof.multi_size()
-        dom = max(tms, key=lambda k: tms[k][0])
-        kept_groups = int(st1.insert_count)
-        bytes_ = algorithmic_bytes(dom, n, ng, int(sz.n_cigar), int(sz.n_md), state["n_emit"], kept_groups,
-                                   n_lists, n_entries, nrefs, max(int(st1.iterations), 1))
-        dur_ms = tms[dom][0]
-        achieved = bytes_ / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        w = dict(n=n, ng=ng, n_cig=int(sz.n_cigar), n_md=int(sz.n_md), n_emit=state["n_emit"],
+                 kept_groups=int(st1.insert_count), uniq=int(st1.uniq_mapper_count), L=n_lists, E=n_entries,
+                 nf=nrefs)
+
+        def gbps(k):
+            ms_step, launches = tms[k]
+            if ms_step <= 0 or launches <= 0:
+                return 0.0, 0.0
+            avg_ms = ms_step / launches
+            return algorithmic_bytes(k, w) / (avg_ms * 1e-3) / 1e9, avg_ms
+
+        dom = max((k for k in names if k != "scan"), key=lambda k: tms[k][0])
+        achieved, avg_ms = gbps(dom)
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "algorithmic_bytes_per_launch": int(bytes_), "avg_launch_ms": round(dur_ms, 5),
-            "per_kernel_ms_per_step": {k: round(v[0], 5) for k, v in tms.items()},
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
+            "algorithmic_bytes_per_launch": int(algorithmic_bytes(dom, w)),
+            "avg_launch_ms": round(avg_ms, 5), "launches_per_step": tms[dom][1],
+            "per_kernel": {k: {"ms_per_step": round(v[0], 4), "launches": v[1],
+                               "algorithmic_GBps": round(gbps(k)[0], 1)} for k, v in tms.items()},
+            "multi_mapper_lists": n_lists, "multi_mapper_entries": n_entries,
         }
-        # the two streaming kernels, always reported for reference
-        for k in ("aln_stats_filter", "besthit_select"):
-            b = algorithmic_bytes(k, n, ng, int(sz.n_cigar), int(sz.n_md), state["n_emit"], kept_groups,
-                                  n_lists, n_entries, nrefs, 1)
-            if tms[k][0] > 0:
-                out["roofline"][k + "_GBps"] = round(b / (tms[k][0] * 1e-3) / 1e9, 2)
 
     # ---- CPU baseline: the oracle (scalar C port of the reference path), 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -281,12 +281,12 @@ int  msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes); /
 
 /* ---- timing of the dominant kernel (bench.py roofline) -------------------- */
 
-/* Per-kernel accumulated device time measured with HIP events on the ctx
- * stream while enabled.  names: "aln_stats_filter", "besthit_select",
- * "emit_order", "insert_count", "prop_build", "prop_iter", "coverage_pileup",
- * "scan", "synth".  Brackets nest: "scan" launches issued inside another
- * bracket are counted in both.
- * Returns total ms and number of launches since the last reset. */
+/* Per-kernel device time measured with HIP events on the ctx stream while
+ * enabled (one event pair around every launch).  names: "k_aln_stats_filter",
+ * "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
+ * "k_list_recip", "k_share_reduce", "k_prop_apply", "k_rs_hist", "k_rs_scatter",
+ * "k_coverage_pileup", "scan", "synth".  Returns total ms and the number of
+ * timed launches since the last reset. */
 int  msx_timing_enable(msx_ctx *ctx, int on);
 int  msx_timing_reset(msx_ctx *ctx);
 int  msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, int64_t *launches);

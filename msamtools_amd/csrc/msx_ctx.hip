@@ -109,9 +109,10 @@ extern "C" int msx_ctx_sync(msx_ctx *ctx) {
 
 // ---- timing ---------------------------------------------------------------
 
-static const char *k_names[MSX_K_COUNT] = {"aln_stats_filter", "besthit_select", "emit_order",
-                                           "insert_count",     "prop_iter",      "prop_build",
-                                           "coverage_pileup",  "scan",           "synth"};
+static const char *k_names[MSX_K_COUNT] = {
+    "k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
+    "k_list_recip", "k_share_reduce", "k_prop_apply", "k_rs_hist", "k_rs_scatter",
+    "k_coverage_pileup", "scan", "synth"};
 
 static hipEvent_t get_event(msx_ctx *ctx) {
 	if (!ctx->event_pool.empty()) {

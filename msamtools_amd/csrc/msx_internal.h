@@ -31,15 +31,19 @@
 
 // kernel ids for the timing table
 enum msx_kid {
-	MSX_K_ALN_STATS = 0,
-	MSX_K_BESTHIT,
-	MSX_K_EMIT,
-	MSX_K_INSERT_COUNT,
-	MSX_K_PROP_ITER,
-	MSX_K_PROP_BUILD,
-	MSX_K_COVERAGE,
-	MSX_K_SCAN,
-	MSX_K_SYNTH,
+	MSX_K_ALN_STATS = 0,   // k_aln_stats_filter
+	MSX_K_BESTHIT,         // k_besthit_select
+	MSX_K_EMIT,            // k_emit_groups / k_emit_count + k_emit_fill
+	MSX_K_INSERT_COUNT,    // k_insert_count
+	MSX_K_MULTI_COMPACT,   // k_multi_compact + k_multi_advance
+	MSX_K_LIST_RECIP,      // k_list_recip
+	MSX_K_SHARE_REDUCE,    // k_share_reduce
+	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply + k_prop_finish / k_prop_purged
+	MSX_K_RS_HIST,         // k_entry_lists, k_rs_hist
+	MSX_K_RS_SCATTER,      // k_rs_scatter
+	MSX_K_COVERAGE,        // k_coverage_pileup
+	MSX_K_SCAN,            // k_scan_reduce + k_scan_apply (one bracket per scan call)
+	MSX_K_SYNTH,           // generator kernels
 	MSX_K_COUNT
 };
 
@@ -92,6 +96,12 @@ extern thread_local std::string msx_tls_err;
 // RAII-less timing bracket: records events around a launch when enabled
 void msx_time_begin(msx_ctx *ctx, int kid);
 void msx_time_end(msx_ctx *ctx);
+#define MSX_TIMED(ctx, kid, stmt)    \
+	do {                             \
+		msx_time_begin((ctx), (kid)); \
+		stmt;                        \
+		msx_time_end((ctx));         \
+	} while (0)
 
 static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) {
 	int64_t nb = (items + per_block - 1) / per_block;

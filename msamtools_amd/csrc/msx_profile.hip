@@ -293,7 +293,7 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	msx_time_end(ctx);
 	if (prop) {
 		if ((rc = msx_scan_u64(ctx, (const uint64_t *)ctx->mlen.p, (uint64_t *)ctx->moff.p, ng))) return rc;
-		msx_time_begin(ctx, MSX_K_INSERT_COUNT);
+		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);
 		hipLaunchKernelGGL(k_multi_compact, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, ng,
 		                   b->group_off, (const unsigned long long *)ctx->mlen.p,
 		                   (const unsigned long long *)ctx->moff.p, (const int32_t *)ctx->tmp_fid.p,

@@ -281,8 +281,9 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	const unsigned long long *tot = p->csr_tot;
-	hipLaunchKernelGGL(k_entry_lists, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
-	                   (const uint32_t *)p->m_off.p, (uint32_t *)p->t_val[0].p);
+	MSX_TIMED(ctx, MSX_K_RS_HIST,
+	          hipLaunchKernelGGL(k_entry_lists, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                             tot, (const uint32_t *)p->m_off.p, (uint32_t *)p->t_val[0].p));
 	int bits = 0;
 	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
 	const int passes = (bits + 7) / 8;
@@ -292,13 +293,15 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
-		hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, tot, ps * 8,
-		                   (uint32_t *)p->rs_hist.p, n_waves);
+		MSX_TIMED(ctx, MSX_K_RS_HIST,
+		          hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, tot, ps * 8,
+		                             (uint32_t *)p->rs_hist.p, n_waves));
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
 			return rc;
-		hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
-		                   (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, tot, ps * 8,
-		                   (const uint32_t *)p->rs_off.p, n_waves);
+		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
+		          hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
+		                             (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, tot, ps * 8,
+		                             (const uint32_t *)p->rs_off.p, n_waves));
 		kin = (const uint32_t *)p->t_key[dst].p;
 		vin = (const uint32_t *)p->t_val[dst].p;
 		cur = dst;
@@ -318,33 +321,38 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
 	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
 	const int64_t eub = p->entries_ub > 0 ? p->entries_ub : 1;
-	hipLaunchKernelGGL(k_list_recip, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-	                   (const int32_t *)p->m_fid.p, (const double *)p->a, (double *)p->recip.p,
-	                   (const int32_t *)p->iter_state);
+	MSX_TIMED(ctx, MSX_K_LIST_RECIP,
+	          hipLaunchKernelGGL(k_list_recip, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
+	                             (const int32_t *)p->m_fid.p, (const double *)p->a, (double *)p->recip.p,
+	                             (const int32_t *)p->iter_state));
 	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
-	hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((n_waves + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
-	                   (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
-	                   (const int32_t *)p->iter_state);
+	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
+	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((n_waves + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
+	                             (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
+	                             (const int32_t *)p->iter_state));
 	return MSX_OK;
 }
 
 int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k) {
 	const int32_t nf = p->n_features;
 	const int g = nf_grid(ctx, nf);
+	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	hipLaunchKernelGGL(k_prop_apply, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
 	                   p->a, p->partial, (const int32_t *)p->iter_state);
 	hipLaunchKernelGGL(k_prop_finish, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, g, (const double *)p->partial, nf,
 	                   p->delta, p->iter_state, k);
+	msx_time_end(ctx);
 	return MSX_OK;
 }
 
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev) {
 	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
-	hipLaunchKernelGGL(k_prop_purged, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-	                   (const int32_t *)p->m_fid.p, (const double *)p->a, out_dev);
+	MSX_TIMED(ctx, MSX_K_PROP_APPLY,
+	          hipLaunchKernelGGL(k_prop_purged, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
+	                             (const int32_t *)p->m_fid.p, (const double *)p->a, out_dev));
 	return MSX_OK;
 }
 
@@ -352,7 +360,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	const int32_t nf = p->n_features;
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
+	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
 	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->share, p->delta, p->iter_state);
 	msx_time_end(ctx);
@@ -361,9 +369,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	p->iter_k = 0;
 	p->begun = true;
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
-		msx_time_begin(ctx, MSX_K_PROP_BUILD);
 		int rc = msx_prop_build(ctx, p);
-		msx_time_end(ctx);
 		if (rc) return rc;
 	}
 	MSX_HIP(ctx, hipGetLastError());
@@ -375,9 +381,7 @@ extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local before msx_profile_prop_begin");
 	if (p->share_type != MSX_MULTI_SHARE_PROPORTIONAL)
 		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
 	msx_prop_iteration(ctx, p);
-	msx_time_end(ctx);
 	if (inc) *inc = p->share;
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
@@ -388,9 +392,7 @@ extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delt
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply before msx_profile_prop_begin");
 	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
 	p->iter_k++;
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
 	msx_prop_apply_launch(ctx, p, p->iter_k);
-	msx_time_end(ctx);
 	MSX_HIP(ctx, hipGetLastError());
 	double dl = 0;
 	MSX_HIP(ctx, hipMemcpyAsync(&dl, p->delta + p->iter_k, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -402,9 +404,7 @@ extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delt
 extern "C" int msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *purged_local) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
-	msx_time_begin(ctx, MSX_K_PROP_ITER);
 	msx_prop_purged_launch(ctx, p, p->purged_local);
-	msx_time_end(ctx);
 	MSX_HIP(ctx, hipGetLastError());
 	uint32_t v = 0;
 	MSX_HIP(ctx, hipMemcpyAsync(&v, p->purged_local, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -418,13 +418,11 @@ extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p) {
 	int rc = msx_profile_prop_begin(ctx, p);
 	if (rc) return rc;
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
-		msx_time_begin(ctx, MSX_K_PROP_ITER);
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331; converged iterations exit at once
 			msx_prop_iteration(ctx, p);
 			msx_prop_apply_launch(ctx, p, k);
 		}
 		msx_prop_purged_launch(ctx, p, p->counters + 3);
-		msx_time_end(ctx);
 	}
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
