@@ -38,6 +38,7 @@ enum msx_kid {
 	MSX_K_MULTI_COMPACT,   // k_multi_compact + k_multi_advance
 	MSX_K_LIST_RECIP,      // k_list_recip
 	MSX_K_SHARE_REDUCE,    // k_share_reduce
+	MSX_K_PARTIAL_REDUCE,  // k_partial_reduce
 	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply + k_prop_finish / k_prop_purged
 	MSX_K_RS_HIST,         // k_entry_lists, k_rs_hist
 	MSX_K_RS_SCATTER,      // k_rs_scatter
@@ -138,6 +139,7 @@ struct msx_profile {
 	msx_buf t_key[2], t_val[2];       // ping-pong (feature id, list id) pairs
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
 	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper
+	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
 	bool transposed_valid = false;
 	int iter_k = 0;

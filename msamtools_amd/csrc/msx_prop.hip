@@ -134,64 +134,162 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 	}
 }
 
-// share[f] = sum of recip over the lists containing f.  One wave per SR_CHUNK
-// consecutive (feature-sorted) entries: segmented scan per 64-entry row, the
-// open segment is carried in registers across rows; a feature whose entries
-// all lie inside the chunk is written with a plain store, only the (at most
-// two) segments cut by the chunk boundary use an atomic.
+// share[f] = sum of recip over the lists containing f -- a segmented sum over the
+// feature-sorted entries.  Level 1 (k_share_reduce): one wave per SR_CHUNK
+// consecutive entries, four 64-entry rows in flight per step (all loads issued
+// before the first scan), segmented scan per row, open segment carried in
+// registers.  A feature whose entries all lie inside the chunk is written with
+// a plain store.  The (at most two) segments cut by the chunk boundary are not
+// added with atomics -- a hot feature spans hundreds of chunks and would
+// serialise on one address -- but emitted as (feature, partial) pairs, two
+// slots per wave, in entry order.  Level 2 (k_partial_reduce) runs the same
+// segmented sum over those few pairs and adds each run once.
+#define SR_ROWS_PER_STEP 4
+#define SR_SENT 0xffffffffu
+
+struct SegRow {
+	double v;         // after seg_scan: inclusive segmented sum
+	bool tail;
+	bool started;     // the segment holding this lane began inside this wave's chunk
+};
+
+// one 64-entry row: head/tail flags come from the global neighbours (pk/nk)
+__device__ __forceinline__ SegRow seg_row(uint32_t key, double v, bool valid, uint32_t pk, uint32_t nk, int lane,
+                                          double carry, bool carry_started) {
+	const bool head = valid && (pk != key);
+	SegRow r;
+	r.tail = valid && (nk != key);
+	if (lane == 0 && !head) v += carry;
+	uint32_t f = (head || lane == 0) ? 1u : 0u;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const double ov = __shfl_up(v, d, 64);
+		const uint32_t of = __shfl_up(f, d, 64);
+		if (lane >= d && !f) { v += ov; f = of; }
+	}
+	const unsigned long long hb = __ballot(head);
+	const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+	r.started = ((hb & upto) == 0ull) ? carry_started : true;
+	r.v = v;
+	return r;
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const uint32_t *__restrict__ t_val,
                                                             const double *__restrict__ recip,
                                                             double *__restrict__ share,
+                                                            uint32_t *__restrict__ part_key,
+                                                            double *__restrict__ part_val,
                                                             const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
 	const int64_t c0 = wave * SR_CHUNK;
-	if (c0 >= E) return;
+	if (c0 >= E) {   // idle wave: neutral slots (sorted after every real feature id)
+		if (lane < 2) { part_key[2 * wave + lane] = SR_SENT; part_val[2 * wave + lane] = 0.0; }
+		return;
+	}
 	const int64_t c1 = (c0 + SR_CHUNK < E) ? c0 + SR_CHUNK : E;
 	double carry = 0.0;
-	int carry_started = 0, carry_open = 0;
-	uint32_t carry_key = 0;
-	for (int64_t base = c0; base < c1; base += 64) {
-		const int64_t k = base + lane;
-		const bool valid = k < c1;
-		const uint32_t key = valid ? t_key[k] : 0xffffffffu;
-		double v = valid ? recip[t_val[k]] : 0.0;
-		uint32_t pk = __shfl_up(key, 1, 64);
-		if (lane == 0 && k > 0) pk = t_key[k - 1];
-		const bool head = valid && (k == 0 || pk != key);
-		uint32_t nk = __shfl_down(key, 1, 64);
-		if (valid && (lane == 63 || k + 1 >= c1)) nk = (k + 1 < E) ? t_key[k + 1] : ~key;
-		const bool tail = valid && (nk != key);
-		if (lane == 0 && !head) v += carry;
-		uint32_t f = (head || lane == 0) ? 1u : 0u;
+	bool carry_started = false, carry_open = false;
+	uint32_t carry_key = 0, first_key = 0;
+	double slot_a = 0.0;          // partial of the chunk's first segment when it began in an earlier chunk
+	for (int64_t base = c0; base < c1; base += 64 * SR_ROWS_PER_STEP) {
+		uint32_t key[SR_ROWS_PER_STEP], val[SR_ROWS_PER_STEP];
+		bool valid[SR_ROWS_PER_STEP];
+		double v[SR_ROWS_PER_STEP];
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const double ov = __shfl_up(v, d, 64);
-			const uint32_t of = __shfl_up(f, d, 64);
-			if (lane >= d && !f) { v += ov; f = of; }
+		for (int r = 0; r < SR_ROWS_PER_STEP; r++) {
+			const int64_t k = base + r * 64 + lane;
+			valid[r] = k < c1;
+			key[r] = valid[r] ? t_key[k] : SR_SENT;
+			val[r] = valid[r] ? t_val[k] : 0u;
 		}
-		const unsigned long long hb = __ballot(head);
-		const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-		const bool started = ((hb & upto) == 0ull) ? (carry_started != 0) : true;
-		if (tail) {
-			if (started) share[key] = v;
-			else atomicAdd(&share[key], v);
+		// global neighbours of the step: entry before lane 0 of row 0, entry after the last valid one
+		uint32_t before = SR_SENT, after = SR_SENT;
+		if (lane == 0) {
+			if (base > 0) before = t_key[base - 1];
+			const int64_t nxt = (base + 64 * SR_ROWS_PER_STEP < c1) ? base + 64 * SR_ROWS_PER_STEP : c1;
+			if (nxt < E) after = t_key[nxt];
 		}
-		const int64_t rem = c1 - base - 1;
+		before = __shfl(before, 0, 64);
+		after = __shfl(after, 0, 64);
+#pragma unroll
+		for (int r = 0; r < SR_ROWS_PER_STEP; r++) v[r] = valid[r] ? recip[val[r]] : 0.0;
+		if (base == c0) first_key = __shfl(key[0], 0, 64);
+#pragma unroll
+		for (int r = 0; r < SR_ROWS_PER_STEP; r++) {
+			const int64_t rb = base + r * 64;
+			if (rb >= c1) break;
+			const int64_t k = rb + lane;
+			// previous / next keys: neighbours in the row, else the adjacent row, else the global ones
+			uint32_t pk = __shfl_up(key[r], 1, 64);
+			const uint32_t prow63 = __shfl(key[r > 0 ? r - 1 : 0], 63, 64);   // every lane takes part in the shuffle
+			if (lane == 0) pk = (r == 0) ? ((rb > 0) ? before : ~key[r]) : prow63;
+			uint32_t nk = __shfl_down(key[r], 1, 64);
+			const bool last_in_chunk = (k + 1 >= c1);
+			uint32_t nrow0 = (r + 1 < SR_ROWS_PER_STEP) ? __shfl(key[r + 1 < SR_ROWS_PER_STEP ? r + 1 : r], 0, 64) : after;
+			if (last_in_chunk) nk = (k + 1 < E) ? after : ~key[r];
+			else if (lane == 63) nk = nrow0;
+			const SegRow s = seg_row(key[r], v[r], valid[r], pk, nk, lane, carry, carry_started);
+			if (s.tail && s.started) share[key[r]] = s.v;        // whole feature inside this chunk
+			const unsigned long long cut = __ballot(s.tail && !s.started);
+			if (cut) slot_a = __shfl(s.v, __ffsll((long long)cut) - 1, 64);
+			const int64_t rem = c1 - rb - 1;
+			const int ll = rem < 63 ? (int)rem : 63;
+			const double cv = __shfl(s.v, ll, 64);
+			const int ct = __shfl((int)s.tail, ll, 64);
+			const int cs = __shfl((int)s.started, ll, 64);
+			carry_key = __shfl(key[r], ll, 64);
+			carry_open = !ct;
+			carry = ct ? 0.0 : cv;
+			carry_started = ct ? false : (cs != 0);
+		}
+	}
+	if (lane == 0) {
+		part_key[2 * wave] = first_key;
+		part_val[2 * wave] = slot_a;
+		part_key[2 * wave + 1] = carry_key;
+		part_val[2 * wave + 1] = carry_open ? carry : 0.0;
+	}
+}
+
+// level 2: runs of equal feature ids among the boundary partials -> one add per run
+__global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const uint32_t *__restrict__ pkey,
+                                                              const double *__restrict__ pval,
+                                                              double *__restrict__ share,
+                                                              const int32_t *__restrict__ iter_state) {
+	if (iter_state[0]) return;
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
+	const int64_t c0 = wave * SR_CHUNK;
+	if (c0 >= M) return;
+	const int64_t c1 = (c0 + SR_CHUNK < M) ? c0 + SR_CHUNK : M;
+	double carry = 0.0;
+	bool carry_open = false;
+	uint32_t carry_key = 0;
+	for (int64_t rb = c0; rb < c1; rb += 64) {
+		const int64_t k = rb + lane;
+		const bool valid = k < c1;
+		const uint32_t key = valid ? pkey[k] : SR_SENT;
+		const double v = valid ? pval[k] : 0.0;
+		uint32_t pk = __shfl_up(key, 1, 64);
+		if (lane == 0) pk = (k > 0) ? pkey[k - 1] : ~key;
+		uint32_t nk = __shfl_down(key, 1, 64);
+		if (valid && (lane == 63 || k + 1 >= c1)) nk = (k + 1 < M) ? pkey[k + 1] : ~key;
+		const SegRow s = seg_row(key, v, valid, pk, nk, lane, carry, true);
+		if (s.tail && key != SR_SENT && s.v != 0.0) atomicAdd(&share[key], s.v);
+		const int64_t rem = c1 - rb - 1;
 		const int ll = rem < 63 ? (int)rem : 63;
-		const double cv = __shfl(v, ll, 64);
-		const int ct = __shfl((int)tail, ll, 64);
-		const int cs = __shfl((int)started, ll, 64);
+		const double cv = __shfl(s.v, ll, 64);
+		const int ct = __shfl((int)s.tail, ll, 64);
 		carry_key = __shfl(key, ll, 64);
 		carry_open = !ct;
 		carry = ct ? 0.0 : cv;
-		carry_started = ct ? 0 : cs;
 	}
-	if (lane == 0 && carry_open) atomicAdd(&share[carry_key], carry);
+	if (lane == 0 && carry_open && carry_key != SR_SENT && carry != 0.0) atomicAdd(&share[carry_key], carry);
 }
 
 // a = U + a*share, clamp, per-workgroup partial of sum(diff^2) (msam_profile.c:368-379)
@@ -277,6 +375,11 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if ((rc = msx_reserve(ctx, &p->t_val[i], (size_t)(eub + 64) * 4))) return rc;
 	}
 	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
+	{
+		const int64_t sw = ((eub + SR_CHUNK - 1) / SR_CHUNK + 3) / 4 * 4;   // waves launched by k_share_reduce
+		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * sw + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * sw + 8) * 8))) return rc;
+	}
 	const int64_t n_waves = (eub + RS_WAVE_ELEMS - 1) / RS_WAVE_ELEMS;
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16) * 4))) return rc;
@@ -327,11 +430,19 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
 	                             (const int32_t *)p->m_fid.p, (const double *)p->a, (double *)p->recip.p,
 	                             (const int32_t *)p->iter_state));
 	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
+	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
+	const int64_t M = (int64_t)nblk * 4 * 2;              // two partial slots per launched wave
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
-	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((n_waves + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
+	          hipLaunchKernelGGL(k_share_reduce, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
 	                             (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
+	                             (uint32_t *)p->part_key.p, (double *)p->part_val.p,
 	                             (const int32_t *)p->iter_state));
+	const int64_t n_waves2 = (M + SR_CHUNK - 1) / SR_CHUNK;
+	MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
+	          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((n_waves2 + 3) / 4)), dim3(MSX_BLOCK), 0,
+	                             ctx->stream, M, (const uint32_t *)p->part_key.p, (const double *)p->part_val.p,
+	                             p->share, (const int32_t *)p->iter_state));
 	return MSX_OK;
 }
 
