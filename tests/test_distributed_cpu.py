@@ -1,0 +1,119 @@
+"""world_size-2 gloo test of the multi-GPU arithmetic.
+
+Each rank owns a pool-aligned shard of one synthetic stream, runs filter +
+insert counting on its shard alone, and the ranks exchange exactly what
+bench.py exchanges over RCCL: all-reduce(sum) of the per-reference counts and
+counters, then per proportional-sharing iteration all-reduce(sum) of the
+`share` vector (sum over the rank's multi-mappers of 1/S).  The result must
+equal the single-process oracle on the whole stream (counts exact, abundances
+<= 1e-6 relative).  The per-shard compute here is numpy/oracle (no GPU in this
+container); the collective pattern and the sharding rule are the ones under test.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+G, REFS, SEED = 6000, 300, 24680
+OPTS = dict(l=80, p=95, z=80, besthit=True)
+
+
+def shard_counts(hs, emit, n_refs):
+    """ui (2 per unique insert) and the multi-mapper lists of one shard, from filter's output stream."""
+    gid = hs.name_id[emit]
+    tid = hs.tid[emit]
+    ui = np.zeros(n_refs, np.int64)
+    lists = []
+    uniq = multi = 0
+    bounds = np.flatnonzero(np.r_[True, gid[1:] != gid[:-1], True])
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        fids = list(dict.fromkeys(tid[s:e].tolist()))      # first-appearance order
+        if len(fids) == 1:
+            ui[fids[0]] += 2
+            uniq += 1
+        else:
+            lists.append(np.asarray(fids))
+            multi += 1
+    return ui, lists, len(bounds) - 1, uniq, multi
+
+
+def worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    import msamtools_amd as m
+    import oracle_lib as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs = m.HostSynth(SEED, G, REFS, 4, first_group=rank * G)       # the rank's shard: groups [rank*G, (rank+1)*G)
+    emit = orc.run_filter(hs, **OPTS)["emit"]
+    ui, lists, inserts, uniq, multi = shard_counts(hs, emit, REFS)
+    t_ui = torch.from_numpy(ui)
+    t_cnt = torch.tensor([inserts, uniq, multi], dtype=torch.int64)
+    dist.all_reduce(t_ui)
+    dist.all_reduce(t_cnt)
+    U = t_ui.numpy().astype(np.float64) / 2
+    a = U.copy()
+    flat = np.concatenate(lists) if lists else np.zeros(0, np.int64)
+    owner = np.repeat(np.arange(len(lists)), [len(x) for x in lists]) if lists else np.zeros(0, np.int64)
+    k, converged = 0, False
+    while k < 19:
+        S = np.bincount(owner, weights=a[flat], minlength=len(lists))
+        recip = np.where(S > 0, 1.0 / np.where(S > 0, S, 1.0), 0.0)
+        share = torch.from_numpy(np.bincount(flat, weights=recip[owner], minlength=REFS))
+        dist.all_reduce(share)                                       # the per-iteration collective
+        new = U + a * share.numpy()
+        new[new < 1e-20] = 0
+        delta = float(((new - a) ** 2).sum() / REFS)
+        a = new
+        k += 1
+        if delta < 1e-10:
+            converged = True
+            break
+    S = np.bincount(owner, weights=a[flat], minlength=len(lists))
+    purged = torch.tensor([int((S == 0).sum())])
+    dist.all_reduce(purged)
+    if rank == 0:
+        np.savez(out, a=a, ui=t_ui.numpy(), cnt=t_cnt.numpy(), purged=purged.numpy(), k=k, conv=converged)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_profile_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    import msamtools_amd as m
+    import oracle_lib as orc
+    out = str(tmp_path / "rank0.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    whole = m.HostSynth(SEED, 2 * G, REFS, 4)
+    sel = orc.run_filter(whole, **OPTS)["emit"]
+    ref = orc.run_profile(whole, REFS, multi="proportional", sel=sel)
+    s = ref["stats"]
+    assert (got["ui"] == ref["ui"].astype(np.int64)).all()
+    assert got["cnt"].tolist() == [s.insert_count, s.uniq_mapper_count, s.multi_mapper_count]
+    assert int(got["purged"][0]) == s.purged_insert_count
+    assert int(got["k"]) == s.iterations and bool(got["conv"]) == bool(s.converged)
+    want = ref["abundance"]
+    assert ((got["a"] == 0) == (want == 0)).all()
+    rel = np.abs(got["a"] - want) / np.maximum(np.abs(want), 1e-300)
+    assert rel.max() <= 1e-6
+
+
+def test_shards_are_prefix_stable():
+    """Rank r's shard equals groups [r*G, (r+1)*G) of the unsharded stream (no pool is split)."""
+    import msamtools_amd as m
+    whole = m.HostSynth(SEED, 2 * G, REFS, 4)
+    for r in range(2):
+        part = m.HostSynth(SEED, G, REFS, 4, first_group=r * G)
+        s, e = int(whole.group_off[r * G]), int(whole.group_off[(r + 1) * G])
+        assert part.n_records == e - s
+        assert (part.flag == whole.flag[s:e]).all() and (part.tid == whole.tid[s:e]).all()
+        assert (part.group_off.astype(np.int64) + s == whole.group_off[r * G:(r + 1) * G + 1]).all()
