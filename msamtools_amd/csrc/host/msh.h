@@ -1,0 +1,97 @@
+/*
+ * msh.h -- host side (C) of the MI355X-native msamtools filter/profile path:
+ * BGZF/BAM and SAM-text input and output, QNAME pools, SoA batch packing, and
+ * the `msamtools filter` / `msamtools profile` command lines.  Counterpart of
+ * the reference's msam_helper.c + htslib usage (msam_helper.c:196-293) and of
+ * the drivers msam_filter.c:267-507 / msam_profile.c:503-1015; all compute
+ * goes through the C ABI of include/msamtools_amd.h.
+ */
+#ifndef MSH_H
+#define MSH_H
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/msamtools_amd.h"
+
+#define PROGRAM "msamtools"
+#ifndef MSH_VERSION
+#define MSH_VERSION "1.1.3-amd"
+#endif
+#ifndef MSH_GIT_COMMIT
+#define MSH_GIT_COMMIT "unknown"
+#endif
+
+/* ---- errors (mCommon.c:3-31) ---------------------------------------------- */
+void mDie(const char *fmt, ...);    /* "Fatal Error: ..." on stderr, exit 1 */
+void mQuit(const char *fmt, ...);   /* text on stderr, exit 1               */
+
+/* ---- growable byte string -------------------------------------------------- */
+typedef struct {
+	char *s;
+	size_t l, m;
+} kstr;
+void ks_reserve(kstr *k, size_t extra);
+void ks_put(kstr *k, const void *p, size_t n);
+void ks_puts(kstr *k, const char *s);
+void ks_putc(kstr *k, int c);
+void ks_printf(kstr *k, const char *fmt, ...);
+
+/* ---- header ----------------------------------------------------------------- */
+typedef struct {
+	kstr text;              /* SAM header text ('\n'-terminated lines)  */
+	int32_t n_targets;
+	char **target_name;
+	uint32_t *target_len;
+} msh_hdr;
+/* value of @HD SO: or NULL (caller frees) -- sam_hdr_find_tag_hd(h,"SO") */
+char *msh_hdr_sort_order(const msh_hdr *h);
+/* sam_hdr_add_pg(): unique ID, PP chained to every existing @PG chain end */
+void msh_hdr_add_pg(kstr *text, const char *name, const char *vn, const char *cl, const char *ds);
+int32_t msh_hdr_name2tid(const msh_hdr *h, const char *name);
+
+/* ---- BAM record accessors (SAMv1 4.2; record bytes WITHOUT block_size) ------ */
+static inline int32_t le32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
+static inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+#define REC_TID(r) le32((r) + 0)
+#define REC_POS(r) le32((r) + 4)
+#define REC_LQNAME(r) ((r)[8])
+#define REC_MAPQ(r) ((r)[9])
+#define REC_NCIGAR(r) le16((r) + 12)
+#define REC_FLAG(r) le16((r) + 14)
+#define REC_LSEQ(r) le32((r) + 16)
+#define REC_QNAME(r) ((const char *)(r) + 32)
+#define REC_CIGAR(r) ((r) + 32 + REC_LQNAME(r))
+#define REC_AUX(r) (REC_CIGAR(r) + 4 * REC_NCIGAR(r) + (REC_LSEQ(r) + 1) / 2 + REC_LSEQ(r))
+/* bam_aux_get: first tag match, pointer to the type byte or NULL */
+const uint8_t *msh_aux_get(const uint8_t *rec, size_t len, const char tag[2]);
+/* bam_aux2i: c C s S i I, 0 for anything else */
+int64_t msh_aux2i(const uint8_t *type_ptr);
+/* size in bytes of the aux field starting at its type byte (type + payload) */
+size_t msh_aux_size(const uint8_t *type_ptr, const uint8_t *end);
+
+/* ---- input: BAM (BGZF, multi-threaded inflate) or SAM text, file or "-" ---- */
+typedef struct msh_in msh_in;
+msh_in *msh_open(const char *path);             /* format is auto-detected, as htslib does */
+const msh_hdr *msh_header(msh_in *in);
+int msh_read(msh_in *in, kstr *rec);            /* 0 = record in rec (l = length), -1 = EOF */
+void msh_close(msh_in *in);
+
+/* ---- output ------------------------------------------------------------------ */
+enum { MSH_OUT_SAM = 0, MSH_OUT_SAM_HDR = 1, MSH_OUT_BAM = 2, MSH_OUT_UBAM = 3 };
+typedef struct msh_out msh_out;
+msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text);
+void msh_write(msh_out *o, const uint8_t *rec, size_t len);
+void msh_out_close(msh_out *o);
+
+/* SAM text <-> BAM record */
+void msh_sam_format(const msh_hdr *h, const uint8_t *rec, size_t len, kstr *line);   /* no trailing '\n' */
+void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec);                        /* line is modified */
+
+/* ---- subcommands ------------------------------------------------------------- */
+int msam_filter_main(int argc, char *argv[]);
+int msam_profile_main(int argc, char *argv[]);
+
+#endif

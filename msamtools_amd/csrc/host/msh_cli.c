@@ -1,0 +1,894 @@
+/*
+ * msh_cli.c -- `msamtools filter` and `msamtools profile` on the MI355X path.
+ *
+ * Keeps the reference's command-line surface (msam_filter.c:304-347,
+ * msam_profile.c:554-570), its validation messages and their stdout/stderr
+ * split, the QNAME-grouping preflight (msam_helper.c:295-484), the @PG /
+ * '#' provenance lines (msam_helper.c:139-184) and the profile
+ * post-processing + text format (msam_profile.c:858-983, mMatrix.c:359-376).
+ * Records are decoded on the host, packed into structure-of-arrays batches cut
+ * at QNAME-pool boundaries and handed to libmsamtools_amd.so; the library
+ * returns the indices of the records to write, in the reference's order.
+ */
+#include "msh.h"
+
+#include <getopt.h>
+#include <math.h>
+#include <zlib.h>
+
+#define QNAME_GROUP_CHECK_RECORDS 10000      /* msam_helper.c:4-6 */
+#define COORD_ORDER_CHECK_RECORDS 100000
+#define COORD_ORDER_MIN_RECORDS 10000
+
+static msx_ctx *g_ctx;
+
+static void ctx_open(void) {
+	const char *dev = getenv("MSX_DEVICE");
+	if (msx_ctx_create(&g_ctx, dev ? atoi(dev) : 0) != MSX_OK) mDie("%s", msx_last_error(NULL));
+}
+#define MSX(call) do { if ((call) != MSX_OK) mDie("%s", msx_last_error(g_ctx)); } while (0)
+
+static size_t batch_target(void) {
+	const char *e = getenv("MSX_BATCH_RECORDS");
+	long n = e ? strtol(e, NULL, 10) : (1L << 21);
+	return n < 1 ? 1 : (size_t)n;
+}
+
+/* stringify_argv() as used by mBuildCommandLine (msam_helper.c:59-76) */
+static char *command_line(int argc, char *argv[]) {
+	kstr k = {0, 0, 0};
+	int i;
+	char *p;
+	ks_puts(&k, PROGRAM);
+	for (i = 0; i < argc; i++) {
+		ks_putc(&k, ' ');
+		ks_puts(&k, argv[i]);
+	}
+	for (p = k.s; *p; p++)
+		if (*p == '\t') *p = ' ';
+	return k.s;
+}
+
+/* ------------------------------------------------------------------------ */
+/* record batch: BAM blobs + the SoA view the kernels read                    */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+	size_t n, cap;
+	kstr blob;                 /* record bytes back to back  */
+	size_t *rec_off;           /* [n+1]                      */
+	uint16_t *flag;
+	uint8_t *rflags;
+	int32_t *tid, *pos, *nm, *as;
+	uint32_t *cigar_off, *md_off;
+	uint32_t *cigar; size_t cigar_cap;
+	uint8_t *md; size_t md_cap;
+	uint32_t *group_off; size_t n_groups, group_cap;
+} rbatch;
+
+static void rb_reserve(rbatch *b) {
+	if (b->n + 2 > b->cap) {
+		size_t c = b->cap ? b->cap * 2 : 65536;
+		b->rec_off = (size_t *)realloc(b->rec_off, (c + 1) * sizeof(size_t));
+		b->flag = (uint16_t *)realloc(b->flag, c * 2);
+		b->rflags = (uint8_t *)realloc(b->rflags, c);
+		b->tid = (int32_t *)realloc(b->tid, c * 4);
+		b->pos = (int32_t *)realloc(b->pos, c * 4);
+		b->nm = (int32_t *)realloc(b->nm, c * 4);
+		b->as = (int32_t *)realloc(b->as, c * 4);
+		b->cigar_off = (uint32_t *)realloc(b->cigar_off, (c + 1) * 4);
+		b->md_off = (uint32_t *)realloc(b->md_off, (c + 1) * 4);
+		if (!b->rec_off || !b->flag || !b->rflags || !b->tid || !b->pos || !b->nm || !b->as || !b->cigar_off || !b->md_off)
+			mDie("Out of memory");
+		b->cap = c;
+	}
+}
+
+static void rb_clear(rbatch *b) {
+	b->n = 0;
+	b->blob.l = 0;
+	b->n_groups = 0;
+	rb_reserve(b);
+	b->rec_off[0] = 0;
+	b->cigar_off[0] = 0;
+	b->md_off[0] = 0;
+}
+
+static void rb_mark_group(rbatch *b) {   /* a pool starts at the record about to be appended */
+	if (b->n_groups + 2 > b->group_cap) {
+		b->group_cap = b->group_cap ? b->group_cap * 2 : 65536;
+		b->group_off = (uint32_t *)realloc(b->group_off, b->group_cap * 4);
+		if (!b->group_off) mDie("Out of memory");
+	}
+	b->group_off[b->n_groups++] = (uint32_t)b->n;
+}
+
+/* one pass over the aux block for MD, NM, AS (first occurrence wins, as bam_aux_get) */
+static void rb_append(rbatch *b, const uint8_t *r, size_t len, int want_stats) {
+	size_t i = b->n;
+	uint32_t nc = REC_NCIGAR(r);
+	const uint8_t *p, *end = r + len, *md = NULL, *nm = NULL, *as = NULL;
+	rb_reserve(b);
+	ks_put(&b->blob, r, len);
+	b->rec_off[i + 1] = b->blob.l;
+	b->flag[i] = (uint16_t)REC_FLAG(r);
+	b->tid[i] = REC_TID(r);
+	b->pos[i] = REC_POS(r);
+	for (p = REC_AUX(r); p + 3 <= end; p += 2 + msh_aux_size(p + 2, end)) {
+		if (p[0] == 'M' && p[1] == 'D' && !md) md = p + 2;
+		else if (p[0] == 'N' && p[1] == 'M' && !nm) nm = p + 2;
+		else if (p[0] == 'A' && p[1] == 'S' && !as) as = p + 2;
+	}
+	b->rflags[i] = (uint8_t)((md ? MSX_HAS_MD : 0) | (nm ? MSX_HAS_NM : 0) | (as ? MSX_HAS_AS : 0));
+	b->nm[i] = nm ? (int32_t)msh_aux2i(nm) : 0;
+	b->as[i] = as ? (int32_t)msh_aux2i(as) : 0;
+	if (want_stats) {
+		size_t ml = (md && *md == 'Z') ? strlen((const char *)md + 1) : 0;
+		if (b->cigar_off[i] + nc + 4 > b->cigar_cap) {
+			b->cigar_cap = (b->cigar_cap ? b->cigar_cap * 2 : 1 << 20) + nc;
+			b->cigar = (uint32_t *)realloc(b->cigar, b->cigar_cap * 4);
+		}
+		if (b->md_off[i] + ml + 16 > b->md_cap) {
+			b->md_cap = (b->md_cap ? b->md_cap * 2 : 1 << 22) + ml;
+			b->md = (uint8_t *)realloc(b->md, b->md_cap);
+		}
+		if (!b->cigar || !b->md) mDie("Out of memory");
+		memcpy(b->cigar + b->cigar_off[i], REC_CIGAR(r), 4 * (size_t)nc);
+		if (ml) memcpy(b->md + b->md_off[i], md + 1, ml);
+		b->cigar_off[i + 1] = b->cigar_off[i] + nc;
+		b->md_off[i + 1] = b->md_off[i] + (uint32_t)ml;
+	} else {
+		b->cigar_off[i + 1] = b->cigar_off[i];
+		b->md_off[i + 1] = b->md_off[i];
+	}
+	b->n++;
+}
+
+static void rb_host_view(rbatch *b, msx_batch *h, int with_groups) {
+	static uint32_t zero_c[4];
+	static uint8_t zero_m[16];
+	memset(h, 0, sizeof(*h));
+	h->n_records = (int64_t)b->n;
+	h->flag = b->flag; h->rflags = b->rflags; h->tid = b->tid; h->pos = b->pos;
+	h->cigar_off = b->cigar_off; h->cigar = b->cigar ? b->cigar : zero_c;
+	h->md_off = b->md_off; h->md = b->md ? b->md : zero_m;
+	h->nm = b->nm; h->as = b->as;
+	if (with_groups) {
+		b->group_off[b->n_groups] = (uint32_t)b->n;       /* sentinel */
+		h->group_off = b->group_off;
+		h->n_groups = (int64_t)b->n_groups;
+	}
+}
+
+/* ------------------------------------------------------------------------ */
+/* QNAME grouping preflight (msam_helper.c:78-137, 295-484) on the first      */
+/* records of the stream; `first` holds at least COORD_ORDER_CHECK_RECORDS    */
+/* records unless the input is shorter.                                       */
+/* ------------------------------------------------------------------------ */
+typedef enum { QN_NOT_REQUIRED = 0, QN_HEADER_CONFIRMED, QN_SAMPLE_OK, QN_SAMPLE_WARNING } qn_status;
+typedef struct {
+	qn_status status;
+	size_t qname_records_checked, input_records_checked, mapped_records_checked;
+} qn_result;
+
+static void qn_format(const qn_result *r, char *buf, size_t n) {
+	switch (r->status) {
+	case QN_NOT_REQUIRED: snprintf(buf, n, "QNAME grouping check: not required for this operation"); break;
+	case QN_HEADER_CONFIRMED: snprintf(buf, n, "QNAME grouping check: confirmed by input header SO:queryname"); break;
+	case QN_SAMPLE_OK:
+		if (r->input_records_checked < QNAME_GROUP_CHECK_RECORDS)
+			snprintf(buf, n, "QNAME grouping check: no QNAME grouping violation detected in all %zu records",
+			         r->qname_records_checked);
+		else
+			snprintf(buf, n, "QNAME grouping check: no QNAME grouping violation detected in first %zu records",
+			         r->qname_records_checked);
+		break;
+	default:
+		snprintf(buf, n,
+		         "QNAME grouping check: WARNING - no QNAME grouping violation detected in first %zu records; "
+		         "%zu mapped records among the first %zu input records were consistent with coordinate ordering",
+		         r->qname_records_checked, r->mapped_records_checked, r->input_records_checked);
+	}
+}
+
+/* open-addressing set of closed QNAMEs -> last record number of the group */
+typedef struct { const char *name; size_t last; } qn_slot;
+static uint64_t str_hash(const char *s) {
+	uint64_t h = 1469598103934665603ull;
+	while (*s) { h ^= (uint8_t)*s++; h *= 1099511628211ull; }
+	return h;
+}
+
+static qn_result qn_check(const msh_hdr *hdr, const rbatch *first) {
+	qn_result res = {QN_SAMPLE_OK, 0, 0, 0};
+	char *so = msh_hdr_sort_order(hdr);
+	size_t i, cap = 1 << 15, limit;
+	qn_slot *tab;
+	const char *cur = NULL;
+	size_t cur_first = 0;
+	int coordinate_ordered = 1, coordinate_relevant = 0, have_prev = 0;
+	int32_t prev_tid = -1, prev_pos = -1;
+	if (so) {                                              /* header declarations are authoritative */
+		if (strcmp(so, "queryname") == 0) { res.status = QN_HEADER_CONFIRMED; free(so); return res; }
+		if (strcmp(so, "coordinate") == 0)
+			mDie("Input SAM/BAM declares 'SO:coordinate', but this operation requires records to be grouped by QNAME.\n"
+			     "             Please name-sort the input, for example with "
+			     "'samtools sort -n input.bam -o input.name_sorted.bam'.");
+		free(so);
+	}
+	tab = (qn_slot *)calloc(cap, sizeof(qn_slot));
+	limit = first->n < COORD_ORDER_CHECK_RECORDS ? first->n : COORD_ORDER_CHECK_RECORDS;
+	for (i = 0; i < limit; i++) {
+		const uint8_t *r = (const uint8_t *)first->blob.s + first->rec_off[i];
+		const char *q = REC_QNAME(r);
+		size_t recno = i + 1;
+		res.input_records_checked++;
+		if (recno <= QNAME_GROUP_CHECK_RECORDS) {
+			res.qname_records_checked++;
+			if (!cur) { cur = q; cur_first = recno; }
+			else if (strcmp(q, cur) != 0) {
+				uint64_t h = str_hash(cur) & (cap - 1);
+				while (tab[h].name && strcmp(tab[h].name, cur) != 0) h = (h + 1) & (cap - 1);
+				tab[h].name = cur;
+				tab[h].last = recno - 1;
+				h = str_hash(q) & (cap - 1);
+				while (tab[h].name && strcmp(tab[h].name, q) != 0) h = (h + 1) & (cap - 1);
+				if (tab[h].name)
+					mDie("SAM/BAM file is not grouped by QNAME. Read '%s' reappears at record %zu after its previous "
+					     "group ended at record %zu (%zu intervening records). Please name-sort the input, for example "
+					     "with 'samtools sort -n input.bam -o input.name_sorted.bam'.",
+					     q, recno, tab[h].last, recno - tab[h].last - 1);
+				cur = q;
+				cur_first = recno;
+			}
+		}
+		if (!(first->flag[i] & 4) && first->tid[i] >= 0) {
+			res.mapped_records_checked++;
+			if (have_prev && (first->tid[i] < prev_tid || (first->tid[i] == prev_tid && first->pos[i] < prev_pos)))
+				coordinate_ordered = 0;
+			prev_tid = first->tid[i];
+			prev_pos = first->pos[i];
+			have_prev = 1;
+		}
+		if (first->flag[i] & (0x1 | 0x100 | 0x800)) coordinate_relevant = 1;
+	}
+	(void)cur_first;
+	free(tab);
+	if (coordinate_ordered && coordinate_relevant && res.mapped_records_checked >= COORD_ORDER_MIN_RECORDS) {
+		char w[1024];
+		res.status = QN_SAMPLE_WARNING;
+		qn_format(&res, w, sizeof w);
+		fprintf(stderr, "WARNING: %s\n", w);
+	}
+	return res;
+}
+
+/* ------------------------------------------------------------------------ */
+/* filter                                                                     */
+/* ------------------------------------------------------------------------ */
+static void filter_help(FILE *out) {
+	fprintf(out,
+	        "Usage:\n------\n\n%s filter [-buhSkv] <bamfile> [--help] [-l <int>] [-p <int>] [--ppt=<int>] [-z <int>] "
+	        "[--rescore] [--besthit] [--uniqhit]\n"
+	        "\nGeneral options:\n----------------\n\n"
+	        "These options specify the input/output formats of BAM/SAM files \n(same meaning as in 'samtools view'):\n"
+	        "  -b                        output BAM (default: false)\n"
+	        "  -u                        uncompressed BAM output (force -b) (default: false)\n"
+	        "  -h                        print header for the SAM output (default: false)\n"
+	        "  -S                        input is SAM (default: false)\n"
+	        "  <bamfile>                 input SAM/BAM file\n"
+	        "  --help                    print this help and exit\n\n"
+	        "Specific options:\n-----------------\n\n"
+	        "  -l <int>                  min. length of alignment (default: 0)\n"
+	        "  -p <int>                  min. sequence identity of alignment, in percentage, integer between 0 and 100; "
+	        "requires MD or NM field to be present (default: 0)\n"
+	        "  --ppt=<int>               min/max sequence identity of alignment, in parts per thousand, integer between "
+	        "-1000 and 1000; requires MD or NM field to be present (default: 0)\n"
+	        "  -z <int>                  min. percent of the query that must be aligned, between 0 and 100 (default: 0)\n"
+	        "  -k, --keep_unmapped       report unmapped reads, when filtering using upper-limit thresholds (default: false)\n"
+	        "  -v, --invert              invert the effect of the filter (default: false)\n"
+	        "  --rescore                 rescore alignments using MD or NM fields, in that order (default: false)\n\n"
+	        "Special filters:\n----------------\n\n"
+	        "  --besthit                 keep all highest scoring hit(s) per read (default: false)\n"
+	        "  --uniqhit                 keep only one highest scoring hit per read, only if it is unique (default: false)\n",
+	        PROGRAM);
+}
+
+typedef struct {
+	msh_in *in;
+	kstr rec;
+	int have_pending;            /* rec holds a record read but not yet batched */
+	int eof;
+	/* R5 grouping state (msam_filter.c:107,117-125,170) */
+	char prev_read[256];
+	int have_prev;
+} reader;
+
+/* Fill `b` with up to `target` records; with pools, stop at the first pool
+ * boundary at or after the target so no pool straddles two batches. */
+static void fill_filter_batch(reader *rd, rbatch *b, size_t target, int pools, int want_stats) {
+	rb_clear(b);
+	if (pools) rb_mark_group(b);
+	for (;;) {
+		const uint8_t *r;
+		const char *q;
+		int flush;
+		if (!rd->have_pending) {
+			if (rd->eof || msh_read(rd->in, &rd->rec) < 0) { rd->eof = 1; return; }
+			rd->have_pending = 1;
+		}
+		r = (const uint8_t *)rd->rec.s;
+		q = REC_QNAME(r);
+		flush = rd->have_prev && strcmp(q, rd->prev_read) != 0;          /* :120-121 */
+		if (pools) {
+			if (flush && b->n >= target) return;                          /* record stays pending */
+			if (flush && b->n > b->group_off[b->n_groups - 1]) rb_mark_group(b);
+		} else if (b->n >= target) {
+			return;
+		}
+		if (!(REC_FLAG(r) & 4)) {                                         /* :170, mapped records only */
+			strcpy(rd->prev_read, q);
+			rd->have_prev = 1;
+		}
+		rb_append(b, r, rd->rec.l, want_stats);
+		rd->have_pending = 0;
+	}
+}
+
+/* --rescore: drop the first AS and append AS:i (msam_filter.c:162-167) */
+static void rescore_record(const uint8_t *r, size_t len, int32_t score, kstr *out) {
+	const uint8_t *as = msh_aux_get(r, len, "AS");
+	out->l = 0;
+	if (as) {
+		size_t sz = msh_aux_size(as, r + len);
+		ks_put(out, r, (size_t)(as - 2 - r));
+		ks_put(out, as + sz, (size_t)(r + len - (as + sz)));
+	} else {
+		ks_put(out, r, len);
+	}
+	ks_put(out, "ASi", 3);
+	{
+		uint8_t b4[4] = {(uint8_t)score, (uint8_t)((uint32_t)score >> 8), (uint8_t)((uint32_t)score >> 16),
+		                 (uint8_t)((uint32_t)score >> 24)};
+		ks_put(out, b4, 4);
+	}
+}
+
+int msam_filter_main(int argc, char *argv[]) {
+	static const struct option lopts[] = {
+	    {"help", no_argument, 0, 1000},       {"ppt", required_argument, 0, 1001},
+	    {"rescore", no_argument, 0, 1002},    {"besthit", no_argument, 0, 1003},
+	    {"uniqhit", no_argument, 0, 1004},    {"keep_unmapped", no_argument, 0, 'k'},
+	    {"invert", no_argument, 0, 'v'},      {0, 0, 0, 0}};
+	int o_b = 0, o_u = 0, o_h = 0, o_S = 0, o_help = 0, o_k = 0, o_v = 0, o_rescore = 0, o_best = 0, o_uniq = 0;
+	int n_l = 0, n_p = 0, n_ppt = 0, n_z = 0, nerrors = 0, c;
+	long v_l = 0, v_p = 0, v_ppt = 0, v_z = 0;
+	msx_filter_params fp;
+	const char *infile;
+	char *cl;
+	reader rd;
+	rbatch b;
+	qn_result qn = {QN_NOT_REQUIRED, 0, 0, 0};
+	char qmsg[1024], ds[1300];
+	kstr htext = {0, 0, 0}, tmp = {0, 0, 0};
+	const msh_hdr *hdr;
+	msh_out *out;
+	int mode, pools, want_stats, choice;
+	size_t target = batch_target();
+	int32_t *emit = NULL, *as_out = NULL;
+	size_t emit_cap = 0;
+
+	(void)o_S;
+	opterr = 0;
+	optind = 1;
+	while ((c = getopt_long(argc, argv, "buhSkvl:p:z:", lopts, NULL)) != -1) {
+		switch (c) {
+		case 'b': o_b++; break;
+		case 'u': o_u++; break;
+		case 'h': o_h++; break;
+		case 'S': o_S++; break;
+		case 'k': o_k++; break;
+		case 'v': o_v++; break;
+		case 'l': n_l++; v_l = strtol(optarg, NULL, 10); break;
+		case 'p': n_p++; v_p = strtol(optarg, NULL, 10); break;
+		case 'z': n_z++; v_z = strtol(optarg, NULL, 10); break;
+		case 1000: o_help++; break;
+		case 1001: n_ppt++; v_ppt = strtol(optarg, NULL, 10); break;
+		case 1002: o_rescore++; break;
+		case 1003: o_best++; break;
+		case 1004: o_uniq++; break;
+		default:
+			fprintf(stderr, "%s: invalid option \"%s\"\n", PROGRAM, argv[optind - 1]);
+			nerrors++;
+		}
+	}
+	if (o_help > 0 || argc < 2) {                                     /* msam_filter.c:383-386 */
+		filter_help(stdout);
+		exit(EXIT_SUCCESS);
+	}
+	if (argc - optind < 1) { fprintf(stderr, "%s: missing option <bamfile>\n", PROGRAM); nerrors++; }
+	if (nerrors > 0) {                                                /* :389-393 (stderr) */
+		fprintf(stderr, "Use --help for usage instructions!\n");
+		mQuit("");
+	}
+	if (argc - optind > 1) {                                          /* mMultipleFileError */
+		fprintf(stderr, "Multiple input files not supported in filter.\n");
+		fprintf(stderr, "Use 'samtools merge' to combine BAM/SAM files.\n");
+		filter_help(stdout);
+		mQuit("");
+	}
+#define BAIL(msg) do { fprintf(stdout, "%s\n", msg); filter_help(stdout); mQuit(""); } while (0)
+	if (o_v > 0 && (o_best > 0 || o_uniq > 0)) BAIL("--invert cannot be combined with --besthit or --uniqhit");   /* :398-418 */
+	else if (o_best > 0 && o_uniq > 0) BAIL("--besthit cannot be combined with --uniqhit");
+	else if (n_p > 0 && n_ppt > 0) BAIL("-p cannot be combined with --ppt");
+	else if (!n_l && !n_p && !n_ppt && !o_uniq && !o_best && !n_z)
+		BAIL("--mode filter needs -l, -p, --ppt, -z, --besthit or --uniqhit");
+	memset(&fp, 0, sizeof fp);
+	if (n_p > 0) {                                                    /* :420-457 */
+		if (v_p < 0 || v_p > 100) BAIL("-p must be in the range [0,100]");
+		fp.ppt = (int32_t)(10 * v_p);
+	} else if (n_ppt > 0) {
+		fp.ppt = (int32_t)v_ppt;
+		if (fp.ppt < -1000 || fp.ppt > 1000) BAIL("--ppt must be in the range [-1000,1000]");
+	}
+	fp.max_clip = 100;
+	if (n_z > 0) {
+		fp.max_clip = (int32_t)(100 - v_z);
+		if (fp.max_clip < 0 || fp.max_clip > 100) BAIL("-z must be in the range [0,100]");
+	}
+	if (n_l > 0) {
+		fp.min_length = (int32_t)v_l;
+		if (fp.min_length < 0) BAIL("-l must be a non-negative integer");
+	}
+#undef BAIL
+	fp.rescore = o_rescore > 0;
+	fp.invert = o_v > 0;
+	fp.keep_unmapped = o_k > 0;
+	fp.besthit = o_best > 0;
+	fp.uniqhit = o_uniq > 0;
+	mode = o_u ? MSH_OUT_UBAM : o_b ? MSH_OUT_BAM : o_h ? MSH_OUT_SAM_HDR : MSH_OUT_SAM;   /* :464-470 */
+	pools = fp.besthit || fp.uniqhit;
+	choice = (fp.min_length > 0) | (fp.ppt != 0) << 1 | (fp.max_clip < 100) << 2;
+	want_stats = choice != 0 || fp.rescore;
+
+	infile = argv[optind];
+	memset(&rd, 0, sizeof rd);
+	memset(&b, 0, sizeof b);
+	rd.in = msh_open(infile);
+	hdr = msh_header(rd.in);
+
+	/* first batch: large enough for the preflight window */
+	fill_filter_batch(&rd, &b, target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS, pools, want_stats);
+	if (pools) qn = qn_check(hdr, &b);                                /* :478-482 */
+	ctx_open();
+	qn_format(&qn, qmsg, sizeof qmsg);
+	cl = command_line(argc, argv);
+	snprintf(ds, sizeof ds, "git=%s; %s", MSH_GIT_COMMIT, qmsg);      /* msam_helper.c:159-164 */
+	if (hdr->text.l) ks_put(&htext, hdr->text.s, hdr->text.l);
+	msh_hdr_add_pg(&htext, PROGRAM, MSH_VERSION, cl, ds);
+	out = msh_out_open(stdout, mode, hdr, htext.s);
+
+	for (;;) {
+		if (b.n > 0) {
+			msx_batch hb, db;
+			msx_filter_out fo;
+			msx_filter_status st;
+			void *d_keep, *d_emit, *d_as = NULL;
+			size_t i;
+			int rc;
+			rb_host_view(&b, &hb, pools);
+			MSX(msx_batch_upload(g_ctx, &hb, &db));
+			MSX(msx_dev_alloc(g_ctx, &d_keep, b.n));
+			MSX(msx_dev_alloc(g_ctx, &d_emit, 4 * b.n));
+			if (fp.rescore) MSX(msx_dev_alloc(g_ctx, &d_as, 4 * b.n));
+			fo.keep = (uint8_t *)d_keep; fo.emit_idx = (int32_t *)d_emit; fo.as_out = (int32_t *)d_as;
+			MSX(msx_filter_enqueue(g_ctx, &db, &fp, &fo));
+			rc = msx_filter_finish(g_ctx, &st);
+			if (rc != MSX_OK) mDie("%s", msx_last_error(g_ctx));      /* the reference's own mDie texts */
+			if ((size_t)st.n_emit > emit_cap || !emit) {
+				emit_cap = (size_t)st.n_emit + 1024;
+				emit = (int32_t *)realloc(emit, emit_cap * 4);
+			}
+			MSX(msx_dev_to_host(g_ctx, emit, d_emit, 4 * (size_t)st.n_emit));
+			if (fp.rescore) {
+				as_out = (int32_t *)realloc(as_out, 4 * b.n);
+				MSX(msx_dev_to_host(g_ctx, as_out, d_as, 4 * b.n));
+			}
+			for (i = 0; i < (size_t)st.n_emit; i++) {
+				size_t k = (size_t)emit[i];
+				const uint8_t *r = (const uint8_t *)b.blob.s + b.rec_off[k];
+				size_t len = b.rec_off[k + 1] - b.rec_off[k];
+				if (fp.rescore && !(b.flag[k] & 4)) {
+					rescore_record(r, len, as_out[k], &tmp);
+					msh_write(out, (const uint8_t *)tmp.s, tmp.l);
+				} else {
+					msh_write(out, r, len);
+				}
+			}
+			msx_dev_free(g_ctx, d_keep);
+			msx_dev_free(g_ctx, d_emit);
+			msx_dev_free(g_ctx, d_as);
+			msx_batch_free(g_ctx, &db);
+		}
+		if (rd.eof && !rd.have_pending) break;
+		fill_filter_batch(&rd, &b, target, pools, want_stats);
+	}
+	msh_out_close(out);
+	msh_close(rd.in);
+	msx_ctx_destroy(g_ctx);
+	free(cl);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* profile                                                                    */
+/* ------------------------------------------------------------------------ */
+static void profile_help(FILE *out) {
+	fprintf(out,
+	        "Usage:\n------\n\n%s profile [-S] <bamfile> [--help] -o <file> --label=<string> [--genome=<string>] "
+	        "[--total=<int>] [--mincount=<int>] [--unit=<string>] [--pandas] [--no-pandas] [--nolen] [--multi=<string>]\n"
+	        "\nGeneral options:\n----------------\n\n"
+	        "These options specify the input/output formats of BAM/SAM files \n(same meaning as in 'samtools view'):\n"
+	        "  -S                        input is SAM (default: false)\n"
+	        "  <bamfile>                 input SAM/BAM file\n"
+	        "  --help                    print this help and exit\n\n"
+	        "Specific options:\n-----------------\n\n"
+	        "  -o <file>                 name of output file (required)\n"
+	        "  --label=<string>          label to use for the profile; typically the sample id (required)\n"
+	        "  --genome=<string>         tab-delimited genome definition file - 'genome-id<tab>seq-id' (default: none)\n"
+	        "  --total=<int>             number of high-quality inserts (mate-pairs/paired-ends) that were input to the aligner (default: unknown)\n"
+	        "  --mincount=<int>          minimum number of inserts mapped to a feature, below which the feature is counted as absent (default: 0)\n"
+	        "  --unit=<string>           unit of abundance to report {ab | rel | fpkm | tpm} (default: rel)\n"
+	        "  --pandas                  print two columns (ID, sample-label) as header compatible with python pandas (default)\n"
+	        "  --no-pandas               use legacy profile header without the ID column\n"
+	        "  --nolen                   do not normalize the abundance (only relevant for ab or rel) for sequence length (default: normalize)\n"
+	        "  --multi=<string>          how to deal with multi-mappers {all | equal | proportional | ignore} (default: proportional)\n",
+	        PROGRAM);
+}
+
+/* mPrintInsertStats / mPrintInsertStatsDouble (msam_profile.c:434-499) */
+static void print_stats_int(gzFile s, int left, const char *type, int number, int total, const char *post) {
+	int width = 7;
+	if (total > 0) width = (int)(1 + log10(total));
+	gzprintf(s, "# ");
+	if (left) gzprintf(s, "%-20s: ", type); else gzprintf(s, "%20s: ", type);
+	if (strcmp(type, "Total inserts") == 0 && number == -1) gzprintf(s, "%*s (", width, "NA");
+	else gzprintf(s, "%*d (", width, number);
+	if (total > 0) gzprintf(s, "%6.2f", 100.0 * number / total); else gzprintf(s, "%6s", "NA");
+	gzprintf(s, "%%)");
+	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
+}
+static void print_stats_dbl(gzFile s, int left, const char *type, double number, int total, const char *post) {
+	gzprintf(s, "# ");
+	if (left) gzprintf(s, "%-20s: ", type); else gzprintf(s, "%20s: ", type);
+	gzprintf(s, "%10.7g (", number);
+	if (total > 0) gzprintf(s, "%6.2f", 100.0 * number / total); else gzprintf(s, "%6s", "NA");
+	gzprintf(s, "%%)");
+	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
+}
+
+/* --genome definition: feature order = order of first appearance in the file
+ * (the reference orders features by its hash table's key walk,
+ * zoeTools.c:258-266,365 -- documented difference). */
+static int32_t *load_genome_map(const char *path, const msh_hdr *h, int32_t *n_features, char ***names, uint32_t **lens) {
+	FILE *f = fopen(path, "r");
+	char line[8192], g[4096], s[4096];
+	int32_t *fmap = (int32_t *)malloc(sizeof(int32_t) * (size_t)(h->n_targets ? h->n_targets : 1)), i, nf = 0;
+	char **gn = NULL;
+	if (!f) mDie("Cannot open file %s", path);
+	for (i = 0; i < h->n_targets; i++) fmap[i] = -1;
+	while (fgets(line, sizeof line, f)) {
+		int32_t gi, tid;
+		if (sscanf(line, "%4095s\t%4095s", g, s) != 2) mDie("GENOME DEFINITION LINE ERROR");
+		for (gi = 0; gi < nf; gi++) if (strcmp(gn[gi], g) == 0) break;
+		if (gi == nf) {
+			gn = (char **)realloc(gn, sizeof(char *) * (size_t)(nf + 1));
+			gn[nf++] = strdup(g);
+		}
+		tid = msh_hdr_name2tid(h, s);
+		if (tid < 0) mDie("Sequence '%s' not found in BAM file", s);
+		fmap[tid] = gi;
+	}
+	fclose(f);
+	*lens = (uint32_t *)calloc((size_t)(nf ? nf : 1), sizeof(uint32_t));
+	for (i = 0; i < h->n_targets; i++) {
+		if (fmap[i] == -1) mDie("Sequence '%s' not found in genome definition", h->target_name[i]);
+		(*lens)[fmap[i]] += h->target_len[i];
+	}
+	*n_features = nf;
+	*names = gn;
+	return fmap;
+}
+
+int msam_profile_main(int argc, char *argv[]) {
+	static const struct option lopts[] = {
+	    {"help", no_argument, 0, 1000},        {"label", required_argument, 0, 1001},
+	    {"genome", required_argument, 0, 1002},{"total", required_argument, 0, 1003},
+	    {"mincount", required_argument, 0, 1004},{"unit", required_argument, 0, 1005},
+	    {"pandas", no_argument, 0, 1006},      {"no-pandas", no_argument, 0, 1007},
+	    {"nolen", no_argument, 0, 1008},       {"multi", required_argument, 0, 1009},
+	    {0, 0, 0, 0}};
+	const char *o_out = NULL, *o_label = NULL, *o_genome = NULL, *o_unit = NULL, *o_multi = NULL;
+	int n_out = 0, n_label = 0, n_total = 0, n_mincount = 0, o_pandas = 0, o_nopandas = 0, o_nolen = 0, o_help = 0;
+	long v_total = 0, v_mincount = 0;
+	int nerrors = 0, c, i;
+	int share_type, unit_type, length_normalize = 1, total_inserts = -1, mapped_inserts;
+	double purged_insert_equivalent = 0, purged_inserts, effective_inserts;
+	msh_in *in;
+	const msh_hdr *hdr;
+	rbatch b;
+	qn_result qn;
+	int32_t n_features, *fmap = NULL;
+	char **feature_name;
+	uint32_t *feature_len;
+	msx_profile *prof;
+	msx_profile_stats st;
+	double *row;
+	kstr rec = {0, 0, 0};
+	char prev_read[256], qmsg[1024], *cl;
+	int have_prev = 0, eof = 0, have_pending = 0, first = 1;
+	size_t target = batch_target();
+	gzFile gz;
+
+	opterr = 0;
+	optind = 1;
+	while ((c = getopt_long(argc, argv, "So:", lopts, NULL)) != -1) {
+		switch (c) {
+		case 'S': break;
+		case 'o': n_out++; o_out = optarg; break;
+		case 1000: o_help++; break;
+		case 1001: n_label++; o_label = optarg; break;
+		case 1002: o_genome = optarg; break;
+		case 1003: n_total++; v_total = strtol(optarg, NULL, 10); break;
+		case 1004: n_mincount++; v_mincount = strtol(optarg, NULL, 10); break;
+		case 1005: o_unit = optarg; break;
+		case 1006: o_pandas++; break;
+		case 1007: o_nopandas++; break;
+		case 1008: o_nolen++; break;
+		case 1009: o_multi = optarg; break;
+		default:
+			fprintf(stdout, "%s: invalid option \"%s\"\n", PROGRAM, argv[optind - 1]);
+			nerrors++;
+		}
+	}
+	if (o_help > 0 || argc < 2) { profile_help(stdout); exit(EXIT_SUCCESS); }
+	if (argc - optind < 1) { fprintf(stdout, "%s: missing option <bamfile>\n", PROGRAM); nerrors++; }
+	if (n_out == 0) { fprintf(stdout, "%s: missing option -o <file>\n", PROGRAM); nerrors++; }
+	if (n_label == 0) { fprintf(stdout, "%s: missing option --label=<string>\n", PROGRAM); nerrors++; }
+	if (nerrors > 0) {                                                /* msam_profile.c:664-668 (stdout) */
+		fprintf(stdout, "Use --help for usage instructions!\n");
+		mQuit("");
+	}
+	if (argc - optind > 1) {
+		fprintf(stderr, "Multiple input files not supported in profile.\n");
+		fprintf(stderr, "Use 'samtools merge' to combine BAM/SAM files.\n");
+		profile_help(stdout);
+		mQuit("");
+	}
+#define BAIL(msg) do { fprintf(stdout, "%s\n", msg); profile_help(stdout); mQuit(""); } while (0)
+	if (n_label != 1 || n_out != 1) BAIL("requires --label and -o");
+	if (o_pandas > 0 && o_nopandas > 0) BAIL("--pandas and --no-pandas cannot be used together");
+	if (n_total > 0) {
+		total_inserts = (int)v_total;
+		if (total_inserts <= 0) BAIL("--total must be a positive integer");
+	}
+	if (n_mincount > 0 && v_mincount < 0) BAIL("--mincount must be a non-negative integer");
+#undef BAIL
+
+	in = msh_open(argv[optind]);
+	hdr = msh_header(in);
+
+	share_type = MSX_MULTI_SHARE_PROPORTIONAL;                        /* :712-728, prefix match */
+	if (o_multi) {
+		const char *types[5] = {"", "all", "equal", "proportional", "ignore"};
+		share_type = -1;
+		for (i = 1; i <= 4; i++)
+			if (strncmp(o_multi, types[i], strlen(o_multi)) == 0) { share_type = i; break; }
+		if (share_type == -1) mDie("Do not understand --multi=%s", o_multi);
+	}
+	unit_type = 1;                                                    /* :732-748 */
+	if (o_unit) {
+		const char *types[5] = {"", "relative", "fpkm", "tpm", "abundance"};
+		unit_type = -1;
+		for (i = 1; i <= 4; i++)
+			if (strncmp(o_unit, types[i], strlen(o_unit)) == 0) { unit_type = i; break; }
+		if (unit_type == -1) mDie("Do not understand --unit=%s", o_unit);
+	}
+	if (unit_type == 1 || unit_type == 4) length_normalize = (o_nolen == 0);   /* :752-755 */
+
+	if (o_genome) {
+		fmap = load_genome_map(o_genome, hdr, &n_features, &feature_name, &feature_len);
+	} else {
+		n_features = hdr->n_targets;
+		feature_name = hdr->target_name;
+		feature_len = hdr->target_len;
+	}
+
+	/* mEstimateInsertCountOnFile (:204-243): pools by QNAME over records with tid != -1 */
+	memset(&b, 0, sizeof b);
+	memset(&qn, 0, sizeof qn);
+	for (;;) {
+		size_t tgt = first && target < COORD_ORDER_CHECK_RECORDS ? COORD_ORDER_CHECK_RECORDS : target;
+		rb_clear(&b);
+		rb_mark_group(&b);
+		for (;;) {
+			const uint8_t *r;
+			int valid, newgrp;
+			if (!have_pending) {
+				if (eof || msh_read(in, &rec) < 0) { eof = 1; break; }
+				have_pending = 1;
+			}
+			r = (const uint8_t *)rec.s;
+			valid = REC_TID(r) != -1;                                 /* :223-225 */
+			newgrp = valid && have_prev && strcmp(REC_QNAME(r), prev_read) != 0;
+			if (newgrp && b.n >= tgt) break;
+			if (newgrp && b.n > b.group_off[b.n_groups - 1]) rb_mark_group(&b);
+			if (valid) { strcpy(prev_read, REC_QNAME(r)); have_prev = 1; }
+			rb_append(&b, r, rec.l, 0);
+			have_pending = 0;
+		}
+		if (first) {
+			qn = qn_check(hdr, &b);                                   /* :708, always for profile */
+			first = 0;
+			ctx_open();
+			MSX(msx_profile_create(g_ctx, &prof, n_features, share_type, fmap, hdr->n_targets));   /* :855 */
+		}
+		if (b.n > 0) {
+			msx_batch hb, db;
+			rb_host_view(&b, &hb, 1);
+			hb.cigar_off = NULL; hb.cigar = NULL; hb.md_off = NULL; hb.md = NULL;   /* profile reads tid only */
+			MSX(msx_batch_upload(g_ctx, &hb, &db));
+			MSX(msx_profile_accumulate(g_ctx, prof, &db, NULL));
+			MSX(msx_ctx_sync(g_ctx));
+			msx_batch_free(g_ctx, &db);
+		}
+		if (eof && !have_pending) break;
+	}
+
+	/* mInsertCountToAbundanceMatrix (:248-425) */
+	row = (double *)calloc((size_t)n_features + 1, sizeof(double));
+	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) fprintf(stderr, "# Start PropSharing:\n");
+	MSX(msx_profile_finalize(g_ctx, prof, row + 1, &st));
+	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		int k;
+		for (k = 1; k <= st.iterations; k++)
+			fprintf(stderr, "#     PropSharing Iteration: %2d; DELTA^2=%g%s\n", k, st.delta[k],
+			        (k == st.iterations && st.converged) ? ". CONVERGED!" : "");
+		fprintf(stderr, "# End   PropSharing!\n");
+		fprintf(stderr, "# Purged %d inserts that mapped to features without unique inserts.\n",
+		        (int)st.purged_insert_count);
+	}
+	mapped_inserts = (int)st.insert_count;
+	row[0] = 0.0;
+
+	if (n_mincount > 0) {                                             /* :858-869 */
+		int mincount = (int)v_mincount;
+		for (i = 1; i < n_features + 1; i++)
+			if (row[i] < mincount) { purged_insert_equivalent += row[i]; row[i] = 0; }
+		fprintf(stderr, "# Purged %.7g insert-equivalents from low-abundance features based on --mincount.\n",
+		        purged_insert_equivalent);
+	}
+	if (total_inserts > 0 && total_inserts < mapped_inserts) {        /* :873-876 */
+		fprintf(stderr, "# Ignoring 'unknown' fraction, as total inserts (%d) < mapped inserts (%d)!\n", total_inserts,
+		        mapped_inserts);
+		total_inserts = -1;
+	}
+	gz = strcmp(o_out, "-") == 0 ? gzdopen(fileno(stdout), "wb") : gzopen(o_out, "wb");   /* :879-883 */
+	if (!gz) mDie("Cannot open %s for writing", o_out);
+	cl = command_line(argc, argv);
+	qn_format(&qn, qmsg, sizeof qmsg);
+	gzprintf(gz, "# msamtools version: %s\n", MSH_VERSION);           /* msam_helper.c:145-148 */
+	gzprintf(gz, "# msamtools git commit: %s\n", MSH_GIT_COMMIT);
+	gzprintf(gz, "# Command line: %s\n", cl);
+	gzprintf(gz, "# %s\n", qmsg);
+	purged_inserts = st.purged_insert_count + purged_insert_equivalent;   /* :889-903 */
+	effective_inserts = mapped_inserts - purged_inserts;
+	if (share_type == MSX_MULTI_IGNORE) effective_inserts -= st.multi_mapper_count;
+	print_stats_int(gz, 1, "Total inserts", total_inserts, total_inserts, NULL);
+	print_stats_int(gz, 1, "Mapped inserts", mapped_inserts, total_inserts, NULL);
+	print_stats_int(gz, 0, "- Multiple mapped ", (int)st.multi_mapper_count, total_inserts, NULL);
+	print_stats_int(gz, 0, "- Uniquely mapped ", (int)st.uniq_mapper_count, total_inserts, NULL);
+	print_stats_dbl(gz, 1, "Purged inserts", purged_inserts, total_inserts,
+	                "due to ambiguous mapping or low abundance features");
+	print_stats_dbl(gz, 1, "Effective inserts", effective_inserts, total_inserts, NULL);
+	if (total_inserts <= 0) gzprintf(gz, "# Estimated seq. length for 'Unknown': NA\n");
+	if (total_inserts > 0) {                                          /* :906-934 */
+		row[0] = total_inserts - mapped_inserts + purged_inserts;
+		if (share_type == MSX_MULTI_IGNORE) row[0] += st.multi_mapper_count;
+		if (length_normalize) {
+			int count = 0;
+			uint64_t sum = 0;
+			uint32_t unknown_size;
+			for (i = 0; i < n_features; i++) { sum += feature_len[i]; count++; }
+			unknown_size = (uint32_t)(sum / (uint64_t)count);
+			gzprintf(gz, "# Estimated seq. length for 'Unknown': %dbp\n", unknown_size);
+			row[0] = 1.0 * row[0] / unknown_size;
+		} else {
+			gzprintf(gz, "# Estimated seq. length for 'Unknown': NA\n");
+		}
+	}
+	if (length_normalize)                                             /* :937-947 */
+		for (i = 0; i < n_features; i++) row[1 + i] /= feature_len[i];
+	switch (unit_type) {                                              /* :950-975, mMatrix.c:137-179 */
+	case 2: {
+		double d = total_inserts > 0 ? 1.0E9 / total_inserts : 1.0E9 / mapped_inserts;
+		for (i = 0; i < n_features + 1; i++) row[i] *= d;
+		break;
+	}
+	case 3:
+	case 1: {
+		double sum = 0;
+		for (i = 0; i < n_features + 1; i++) sum += row[i];
+		for (i = 0; i < n_features + 1; i++) row[i] /= sum;
+		if (unit_type == 3)
+			for (i = 0; i < n_features + 1; i++) row[i] *= 1.0E6;
+		break;
+	}
+	default: break;
+	}
+	if (o_nopandas == 0) gzprintf(gz, "ID\t");                        /* mMatrix.c:359-376 */
+	gzprintf(gz, "%s\n", o_label);
+	gzprintf(gz, "Unknown\t%.8g\n", row[0]);
+	for (i = 0; i < n_features; i++) gzprintf(gz, "%s\t%.8g\n", feature_name[i], row[1 + i]);
+	gzclose(gz);
+
+	msx_profile_destroy(g_ctx, prof);
+	msx_ctx_destroy(g_ctx);
+	msh_close(in);
+	free(row);
+	free(cl);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* msamtools.c:8-49                                                           */
+/* ------------------------------------------------------------------------ */
+static int usage(FILE *out) {
+	fprintf(out, "\n");
+	fprintf(out, "Program: %s (Metagenomics-related extension to samtools; MI355X filter/profile path)\n", PROGRAM);
+	fprintf(out, "Version: %s (git %s; own BGZF/BAM reader, no htslib)\n", MSH_VERSION, MSH_GIT_COMMIT);
+	fprintf(out, "\n");
+	fprintf(out, "Usage:   %s <command> [options]\n\n", PROGRAM);
+	fprintf(out, "Commands:\n");
+	fprintf(out, " -- Filtering\n");
+	fprintf(out, "     filter         filter alignments based on alignment statistics\n");
+	fprintf(out, "\n");
+	fprintf(out, " -- Profiling\n");
+	fprintf(out, "     profile        estimate relative abundance profile of reference sequences or genomes in bam file\n");
+	fprintf(out, "\n");
+	return 1;
+}
+
+/* Host I/O self-test (no GPU): `msamtools recode [-b|-u|-h] <file>` reads any
+ * supported input and writes every record back out.  Not part of the
+ * reference's surface; used by the test-suite to check the readers/writers. */
+static int recode_main(int argc, char *argv[]) {
+	int mode = MSH_OUT_SAM, i;
+	const char *path = NULL;
+	msh_in *in;
+	msh_out *out;
+	kstr rec = {0, 0, 0};
+	for (i = 1; i < argc; i++) {
+		if (strcmp(argv[i], "-b") == 0) mode = MSH_OUT_BAM;
+		else if (strcmp(argv[i], "-u") == 0) mode = MSH_OUT_UBAM;
+		else if (strcmp(argv[i], "-h") == 0) mode = MSH_OUT_SAM_HDR;
+		else path = argv[i];
+	}
+	if (!path) mQuit("usage: %s recode [-b|-u|-h] <file>", PROGRAM);
+	in = msh_open(path);
+	out = msh_out_open(stdout, mode, msh_header(in), msh_header(in)->text.s ? msh_header(in)->text.s : "");
+	while (msh_read(in, &rec) == 0) msh_write(out, (const uint8_t *)rec.s, rec.l);
+	msh_out_close(out);
+	msh_close(in);
+	return 0;
+}
+
+int main(int argc, char *argv[]) {
+	if (argc < 2) return usage(stderr);
+	if (strcmp(argv[1], "recode") == 0) return recode_main(argc - 1, argv + 1);
+	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "help") == 0) { usage(stdout); return 0; }
+	fprintf(stderr, "[msamtools] unrecognized command '%s'\n", argv[1]);
+	usage(stderr);
+	return 1;
+}

@@ -256,9 +256,9 @@ extern "C" int msx_batch_upload(msx_ctx *ctx, const msx_batch *h, msx_batch *d) 
 	if (h->n_records < 0 || h->n_records > 0x7fffffffLL)
 		return msx_fail(ctx, MSX_ERR_ARG, "batch of %lld records exceeds the 2^31-1 per-batch limit",
 		                (long long)h->n_records);
-	if (!h->flag || !h->rflags || !h->tid || !h->cigar_off || !h->md_off || !h->nm || !h->as)
-		return msx_fail(ctx, MSX_ERR_ARG, "msx_batch_upload: a required array is NULL");
-	size_t n_cig = n ? h->cigar_off[n] : 0, n_md = n ? h->md_off[n] : 0;
+	// arrays a caller does not need may be NULL (e.g. `profile` reads tid and group_off only);
+	// each compute entry point checks for the arrays it reads
+	size_t n_cig = (n && h->cigar_off) ? h->cigar_off[n] : 0, n_md = (n && h->md_off) ? h->md_off[n] : 0;
 	d->n_records = h->n_records;
 	d->n_groups = h->group_off ? h->n_groups : 0;
 	int rc;

@@ -377,6 +377,10 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 	if (p->rescore && !out->as_out)
 		return msx_fail(ctx, MSX_ERR_ARG, "--rescore needs msx_filter_out.as_out");
 	if (b->n_records > 0x7fffffffLL) return msx_fail(ctx, MSX_ERR_ARG, "batch too large");
+	if (!b->flag || !b->rflags) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_enqueue: flag/rflags missing");
+	if ((choice != 0 || p->rescore) && (!b->cigar_off || !b->cigar || !b->md_off || !b->md || !b->nm))
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_enqueue: -l/-p/-z/--rescore need cigar, md and nm arrays");
+	if (best && !b->as) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_enqueue: --besthit/--uniqhit need the as array");
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	const int64_t n = b->n_records;
 	hipLaunchKernelGGL(k_status_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_status);
@@ -487,6 +491,8 @@ extern "C" int msx_aln_stats(msx_ctx *ctx, const msx_batch *b, int32_t *length, 
 	if (!ctx || !b) return MSX_ERR_ARG;
 	if (!length || !qlen || !qclip || !edit)
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_aln_stats: length/query_length/query_clip/edit are all required");
+	if (!b->flag || !b->rflags || !b->cigar_off || !b->cigar || !b->md_off || !b->md || !b->nm)
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_aln_stats: flag, rflags, cigar, md and nm arrays are required");
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	hipLaunchKernelGGL(k_status_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_status);
 	if (b->n_records == 0) return MSX_OK;

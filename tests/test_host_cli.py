@@ -1,0 +1,276 @@
+"""The C host command line (msamtools_amd/bin/msamtools).
+
+CPU part: readers/writers (SAM text <-> BAM/BGZF round trips against the
+independent Python parser), the reference's CLI validation messages and their
+stdout/stderr split (tests/test_errors.sh), the QNAME preflight
+(tests/test_qname_order.sh).  GPU part (-m gpu): the reference's Tier-1 filter /
+besthit / profile / integration expectations end to end through the binary.
+"""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import samio
+from conftest import GOLDEN, ROOT, fixture_path
+
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+EXP = json.load(open(os.path.join(GOLDEN, "reference_expectations.json")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "msamtools_amd", "csrc", "host")])
+
+
+def run(args, stdin=None, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([BIN] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+
+
+def body(path):
+    return [l for l in open(path).read().split("\n") if l and not l.startswith("@")]
+
+
+# ---- host I/O (no GPU) ------------------------------------------------------------
+
+@pytest.mark.parametrize("fx", ["filter.sam", "cigar_eqx.sam", "besthit.sam", "long_qname.sam", "profile.sam",
+                                "integration.sam", "coverage.sam"])
+def test_sam_text_roundtrip(fx):
+    r = run(["recode", fixture_path(fx)])
+    assert r.returncode == 0 and r.stdout.decode().split("\n")[:-1] == body(fixture_path(fx))
+    r = run(["recode", "-h", fixture_path(fx)])
+    assert r.stdout.decode() == open(fixture_path(fx)).read()
+
+
+@pytest.mark.parametrize("flag", ["-b", "-u"])
+def test_bam_write_read_roundtrip(tmp_path, flag):
+    src = fixture_path("besthit.sam")
+    bam = tmp_path / "x.bam"
+    bam.write_bytes(run(["recode", flag, src]).stdout)
+    # an independent reader (python gzip + struct) sees the same records
+    hdr, rec = samio.read_bam(str(bam))
+    h2, want = samio.read_sam(src)
+    assert hdr.target_name == h2.target_name and hdr.target_len == h2.target_len
+    for k in ("flag", "tid", "pos", "cigar", "nm", "as_", "rflags"):
+        assert (getattr(rec, k) == getattr(want, k)).all(), k
+    assert bam.read_bytes().endswith(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, 0x1b, 0, 3, 0,
+                                            0, 0, 0, 0, 0, 0, 0, 0]))          # BGZF EOF marker
+    back = run(["recode", "-h", str(bam)])
+    assert back.stdout.decode() == open(src).read()
+
+
+def test_reads_reference_bam_and_stdin():
+    path = fixture_path("tiny_aln.bam")
+    out = run(["recode", path]).stdout.decode().split("\n")[:-1]
+    hdr, rec = samio.read_bam(path)
+    assert len(out) == rec.n == 16
+    for i, line in enumerate(out):
+        f = line.split("\t")
+        assert f[0] == rec.name(i) and int(f[1]) == rec.flag[i] and f[5] == rec.cigar_str(i)
+        assert f"MD:Z:{rec.md_str(i)}" in f and f"AS:i:{rec.as_[i]}" in f and f"NM:i:{rec.nm[i]}" in f
+    piped = run(["recode", "-"], stdin=open(path, "rb").read())
+    assert piped.stdout.decode().split("\n")[:-1] == out
+    for threads in ("1", "4"):
+        assert run(["recode", path], env={"MSX_THREADS": threads}).stdout.decode().split("\n")[:-1] == out
+
+
+def test_multi_block_bam_roundtrip(tmp_path):
+    """Enough records for many BGZF blocks and several inflate batches."""
+    hdr = "@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:A\tLN:100000\n"
+    lines = [f"r{i:07d}\t{0 if i % 3 else 256}\tA\t{1 + i % 9000}\t60\t50M\t*\t0\t0\t{'ACGT' * 12}AC\t{'I' * 50}\tNM:i:{i % 5}"
+             f"\tMD:Z:50\tAS:i:{50 - i % 7}\tXX:Z:tag{i}\tXB:B:s,1,-2,{i % 100}" for i in range(60000)]
+    sam = tmp_path / "big.sam"
+    sam.write_text(hdr + "\n".join(lines) + "\n")
+    bam = tmp_path / "big.bam"
+    bam.write_bytes(run(["recode", "-b", str(sam)]).stdout)
+    assert bam.stat().st_size < sam.stat().st_size / 3
+    assert run(["recode", str(bam)]).stdout.decode().split("\n")[:-1] == lines
+    assert len(gzip.open(str(bam)).read()) > 6_000_000
+
+
+# ---- CLI validation (tests/test_errors.sh) ------------------------------------------
+
+ERR_CASES = [
+    (["filter", "-S", "-h", "FX"], "needs -l, -p, --ppt, -z, --besthit or --uniqhit", "stdout"),
+    (["filter", "-S", "--besthit", "--uniqhit", "FX"], "--besthit cannot be combined with --uniqhit", "stdout"),
+    (["filter", "-S", "-p", "95", "--ppt", "950", "FX"], "-p cannot be combined with --ppt", "stdout"),
+    (["filter", "-S", "-p", "101", "FX"], "-p must be in the range [0,100]", "stdout"),
+    (["filter", "-S", "-p", "-1", "FX"], "-p must be in the range [0,100]", "stdout"),
+    (["filter", "-S", "-l", "-1", "FX"], "-l must be a non-negative integer", "stdout"),
+    (["filter", "-S", "-z", "101", "FX"], "-z must be in the range [0,100]", "stdout"),
+    (["filter", "-S", "-z", "-1", "FX"], "-z must be in the range [0,100]", "stdout"),
+    (["filter", "-S", "-v", "--besthit", "FX"], "--invert cannot be combined with --besthit or --uniqhit", "stdout"),
+    (["filter", "-S", "--ppt", "1001", "FX"], "--ppt must be in the range [-1000,1000]", "stdout"),
+    (["profile", "-S", "FX"], "Use --help for usage instructions", "stdout"),
+    (["profile", "-S", "--label", "x", "--pandas", "--no-pandas", "-o", "/dev/null", "FX"],
+     "--pandas and --no-pandas cannot be used together", "stdout"),
+    (["profile", "-S", "--label", "x", "--mincount", "-1", "-o", "/dev/null", "FX"],
+     "--mincount must be a non-negative integer", "stdout"),
+    (["profile", "-S", "--label", "x", "--total", "0", "-o", "/dev/null", "FX"],
+     "--total must be a positive integer", "stdout"),
+    (["definitely-not-a-command"], "unrecognized command", "stderr"),
+]
+
+
+@pytest.mark.parametrize("args,msg,stream", ERR_CASES, ids=[" ".join(c[0][:4]) for c in ERR_CASES])
+def test_cli_validation_messages(args, msg, stream):
+    r = run([fixture_path("filter.sam") if a == "FX" else a for a in args])
+    assert r.returncode == 1
+    assert msg in getattr(r, stream).decode()
+    assert "@HD" not in r.stdout.decode()          # no header before validation (test_errors.sh:34-36)
+
+
+def test_help_exits_zero():
+    for sub in ("filter", "profile"):
+        r = run([sub, "--help"])
+        assert r.returncode == 0 and b"Usage:" in r.stdout
+    assert run(["help"]).returncode == 0
+
+
+def test_qname_preflight_rejects_bad_order(tmp_path):
+    # tests/test_qname_order.sh:29-63
+    r = run(["filter", "-S", "--besthit", fixture_path("qname_coordinate.sam")])
+    assert r.returncode == 1 and b"declares 'SO:coordinate'" in r.stderr and r.stdout == b""
+    r = run(["filter", "-S", "--besthit", fixture_path("qname_reopened.sam")])
+    assert r.returncode == 1 and b"is not grouped by QNAME" in r.stderr and b"reappears at record 3" in r.stderr
+    out = tmp_path / "p.gz"
+    r = run(["profile", "-S", "--label", "x", "-o", str(out), fixture_path("qname_reopened.sam")])
+    assert r.returncode == 1 and not out.exists()
+
+
+# ---- end to end on the GPU ---------------------------------------------------------------
+
+def cli_opts(opts):
+    a = []
+    for k, v in opts.items():
+        if k in ("l", "p", "z"):
+            a += [f"-{k}", str(v)]
+        elif k == "ppt":
+            a += ["--ppt", str(v)]
+        elif v:
+            a += [{"invert": "-v", "keep_unmapped": "-k"}.get(k, f"--{k}")]
+    return a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXP["filter"], ids=[c["name"] for c in EXP["filter"]])
+def test_cli_filter_golden(case):
+    r = run(["filter", "-S", "-h"] + cli_opts(case["opts"]) + [fixture_path(case["fixture"])])
+    assert r.returncode == 0, r.stderr.decode()
+    lines = r.stdout.decode().split("\n")
+    recs = [l.split("\t") for l in lines if l and not l.startswith("@")]
+    assert ",".join(f"{f[0]}:{f[1]}" for f in recs) == case["records"], case["src"]
+    pg = [l for l in lines if l.startswith("@PG")]
+    assert len(pg) == 1 and "\tPN:msamtools\t" in pg[0] and "CL:msamtools filter -S -h" in pg[0]
+    if case["opts"].get("besthit") or case["opts"].get("uniqhit"):
+        assert "QNAME grouping check: confirmed by input header SO:queryname" in pg[0]     # test_besthit.sh:36-38
+    else:
+        assert "QNAME grouping check: not required for this operation" in pg[0]
+    for key, val in case.get("as", {}).items():
+        hit = [f for f in recs if f"{f[0]}:{f[1]}" == key]
+        assert hit and all(f"AS:i:{val}" in f and sum(x.startswith("AS:") for x in f) == 1 for f in hit)
+
+
+@pytest.mark.gpu
+def test_cli_filter_bam_in_bam_out(tmp_path):
+    t = EXP["tiny_aln"]
+    src = fixture_path(t["fixture"])
+    args = ["filter", "-b", "-l", "80", "-p", "95", "-z", "80", "--besthit", src]
+    out = run(args, env={"MSX_BATCH_RECORDS": "3"})        # tiny batches: pools carried across batch cuts
+    assert out.returncode == 0, out.stderr.decode()
+    bam = tmp_path / "f.bam"
+    bam.write_bytes(out.stdout)
+    got = run(["recode", str(bam)]).stdout.decode().split("\n")[:-1]
+    want = run(["recode", src]).stdout.decode().split("\n")[:-1]
+    assert got == [want[i] for i in t["emit"]]             # records byte-identical as text, reference order
+    ub = run(["filter", "-bu", "-l", "80", "-p", "95", "-z", "80", "--besthit", src])
+    (tmp_path / "u.bam").write_bytes(ub.stdout)
+    assert run(["recode", str(tmp_path / "u.bam")]).stdout.decode().split("\n")[:-1] == got
+
+
+def read_profile(path):
+    text = gzip.open(path, "rt").read()
+    head = [l for l in text.split("\n") if l.startswith("#")]
+    rows = [l.split("\t") for l in text.split("\n") if l and not l.startswith("#")]
+    return head, rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXP["profile"], ids=[c["name"] for c in EXP["profile"]])
+def test_cli_profile_golden(case, tmp_path):
+    src = fixture_path(case["fixture"])
+    if "filter_opts" in case:      # test_integration.sh:49-69: filter output fed back to profile
+        f = run(["filter", "-S", "-h"] + cli_opts(case["filter_opts"]) + [src])
+        assert f.returncode == 0
+        src = str(tmp_path / "filtered.sam")
+        open(src, "wb").write(f.stdout)
+    out = str(tmp_path / "p.tsv.gz")
+    args = ["profile", "-S", "--label", "test", "--unit", case["unit"], "--multi", case["multi"], "--pandas", "-o", out]
+    if case["nolen"]:
+        args.append("--nolen")
+    if case["total"] > 0:
+        args += ["--total", str(case["total"])]
+    if "mincount" in case:
+        args += ["--mincount", str(case["mincount"])]
+    r = run(args + [src])
+    assert r.returncode == 0, r.stderr.decode()
+    head, rows = read_profile(out)
+    assert rows[0] == ["ID", "test"]
+    vals = {r[0]: float(r[1]) for r in rows[1:]}
+    for feat, (want, tol) in case["values"].items():
+        assert abs(vals[feat] - want) <= tol, (feat, case["src"])
+    text = "\n".join(head)
+    assert "QNAME grouping check: confirmed by input header SO:queryname" in text
+    if case["name"] in ("all", "equal", "ignore", "proportional"):     # test_profile.sh:39-46
+        for s in ("Total inserts       : 7", "Mapped inserts      : 7", "- Multiple mapped : 1", "- Uniquely mapped : 6"):
+            assert s in text
+    if case["name"] in ("empty", "unmapped"):                           # test_profile.sh:119-126
+        for s in ("Mapped inserts      :       0", "- Multiple mapped :       0", "- Uniquely mapped :       0",
+                  "Effective inserts   :          0"):
+            assert s in text
+
+
+@pytest.mark.gpu
+def test_cli_profile_header_modes_and_pipe(tmp_path):
+    src = fixture_path("profile.sam")
+    base = ["profile", "-S", "--unit", "ab", "--nolen", "--total", "7", "--multi", "equal"]
+    out = str(tmp_path / "a.gz")
+    assert run(base + ["--label", "default_output", "-o", out, src]).returncode == 0
+    assert read_profile(out)[1][0] == ["ID", "default_output"]          # test_profile.sh:175-199
+    assert run(base + ["--label", "legacy_output", "--no-pandas", "-o", out, src]).returncode == 0
+    assert read_profile(out)[1][0] == ["legacy_output"]                 # :226-246
+    # filter -bu ... | profile -   (README pipe; uncompressed BAM on stdin, gz profile on stdout)
+    t = EXP["tiny_aln"]
+    f = run(["filter", "-bu", "-l", "80", "-p", "95", "-z", "80", "--besthit", fixture_path(t["fixture"])])
+    p = run(["profile", "--label", "S", "-o", "-", "-"], stdin=f.stdout)
+    assert p.returncode == 0, p.stderr.decode()
+    text = gzip.decompress(p.stdout).decode()
+    rows = {l.split("\t")[0]: l.split("\t")[1] for l in text.split("\n") if l and not l.startswith("#")}
+    for k, v in t["rel_values"].items():
+        assert float(rows[k]) == pytest.approx(v, rel=1e-7)
+    assert sum(1 for k, v in rows.items() if k not in ("ID",) and float(v) != 0) == 4
+    assert "Purged inserts      :          3" in text and "Effective inserts   :          4" in text
+    assert b"# Purged 3 inserts that mapped to features without unique inserts." in p.stderr
+    assert b"PropSharing Iteration:  1; DELTA^2=0. CONVERGED!" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_streaming_boundary(tmp_path):
+    """tests/test_streaming.sh: a QNAME group straddling the 100 000-record preflight window."""
+    lines = ["@SQ\tSN:A\tLN:1000", "@SQ\tSN:B\tLN:1000"]
+    for i in range(1, 100000):
+        lines.append(f"r{i:06d}\t0\tA\t100\t60\t10M\t*\t0\t0\tAAAAAAAAAA\tIIIIIIIIII\tAS:i:10\tNM:i:0")
+    lines.append("boundary\t0\tA\t300\t60\t10M\t*\t0\t0\tAAAAAAAAAA\tIIIIIIIIII\tAS:i:5\tNM:i:0")
+    lines.append("boundary\t256\tB\t400\t60\t10M\t*\t0\t0\tAAAAAAAAAA\tIIIIIIIIII\tAS:i:9\tNM:i:0")
+    r = run(["filter", "-S", "--besthit", "-"], stdin=("\n".join(lines) + "\n").encode())
+    assert r.returncode == 0, r.stderr.decode()[:500]
+    out = r.stdout.decode().split("\n")[:-1]
+    assert len(out) == 100000
+    last = out[-1].split("\t")
+    assert (last[0], last[1], last[2], last[3]) == ("boundary", "256", "B", "400")
