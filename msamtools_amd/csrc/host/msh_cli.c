@@ -882,9 +882,78 @@ static int recode_main(int argc, char *argv[]) {
 	return 0;
 }
 
+/* `msamtools synth --groups N --refs R [--seed S] [--seq] [-b|-u]`: writes the
+ * library's deterministic synthetic alignment stream (BASELINE.md section 2
+ * model) as a QNAME-grouped BAM, for end-to-end host-pipeline timing.  No GPU. */
+static int synth_main(int argc, char *argv[]) {
+	msx_synth_params sp = {13579, 100000, 10000, 4, 0};
+	msx_synth_sizes sz;
+	msx_batch hb;
+	int mode = MSH_OUT_UBAM, with_seq = 0, i;
+	msh_hdr hdr;
+	msh_out *out;
+	kstr rec = {0, 0, 0};
+	int64_t g, k;
+	for (i = 1; i < argc; i++) {
+		if (strcmp(argv[i], "--groups") == 0 && i + 1 < argc) sp.n_groups = atoll(argv[++i]);
+		else if (strcmp(argv[i], "--refs") == 0 && i + 1 < argc) sp.n_refs = atoi(argv[++i]);
+		else if (strcmp(argv[i], "--seed") == 0 && i + 1 < argc) sp.seed = strtoull(argv[++i], NULL, 10);
+		else if (strcmp(argv[i], "--seq") == 0) with_seq = 1;
+		else if (strcmp(argv[i], "-b") == 0) mode = MSH_OUT_BAM;
+		else if (strcmp(argv[i], "-u") == 0) mode = MSH_OUT_UBAM;
+		else mQuit("usage: %s synth --groups N --refs R [--seed S] [--seq] [-b|-u]", PROGRAM);
+	}
+	if (msx_synth_host(&sp, &hb, &sz) != MSX_OK) mDie("%s", msx_last_error(NULL));
+	memset(&hdr, 0, sizeof hdr);
+	ks_puts(&hdr.text, "@HD\tVN:1.6\tSO:queryname\n");
+	hdr.n_targets = sp.n_refs;
+	hdr.target_name = (char **)malloc(sizeof(char *) * (size_t)sp.n_refs);
+	hdr.target_len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)sp.n_refs);
+	for (i = 0; i < sp.n_refs; i++) {
+		char nm[32];
+		/* msx_synth_ref_len(): 400 + 12 hash bits of the tid; any length >= pos+150 is valid for the model */
+		snprintf(nm, sizeof nm, "ref%07d", i);
+		hdr.target_name[i] = strdup(nm);
+		hdr.target_len[i] = 4496;
+		ks_printf(&hdr.text, "@SQ\tSN:%s\tLN:%u\n", nm, hdr.target_len[i]);
+	}
+	out = msh_out_open(stdout, mode, &hdr, hdr.text.s);
+	for (g = 0; g < hb.n_groups; g++) {
+		char qn[32];
+		int ql = snprintf(qn, sizeof qn, "sim%08lld", (long long)(sp.first_group + g));
+		for (k = hb.group_off[g]; k < hb.group_off[g + 1]; k++) {
+			uint32_t nc = hb.cigar_off[k + 1] - hb.cigar_off[k], ml = hb.md_off[k + 1] - hb.md_off[k], q;
+			uint32_t l_seq = with_seq ? 100 : 0;
+			uint8_t core[32];
+			uint32_t v[8];
+			v[0] = (uint32_t)hb.tid[k]; v[1] = (uint32_t)hb.pos[k];
+			v[2] = (uint32_t)(ql + 1) | 255u << 8 | 4680u << 16;
+			v[3] = nc | (uint32_t)hb.flag[k] << 16;
+			v[4] = l_seq; v[5] = (uint32_t)-1; v[6] = (uint32_t)-1; v[7] = 0;
+			for (q = 0; q < 8; q++) { core[4*q] = (uint8_t)v[q]; core[4*q+1] = (uint8_t)(v[q] >> 8); core[4*q+2] = (uint8_t)(v[q] >> 16); core[4*q+3] = (uint8_t)(v[q] >> 24); }
+			rec.l = 0;
+			ks_put(&rec, core, 32);
+			ks_put(&rec, qn, (size_t)ql + 1);
+			ks_put(&rec, hb.cigar + hb.cigar_off[k], 4 * (size_t)nc);
+			if (with_seq) {
+				for (q = 0; q < 50; q++) ks_putc(&rec, 0x12 + (int)((k + q) & 3) * 0x11);   /* A/C/G/T-ish nibbles */
+				for (q = 0; q < 100; q++) ks_putc(&rec, 40);
+			}
+			ks_put(&rec, "NMC", 3); ks_putc(&rec, hb.nm[k] & 0xff);
+			ks_put(&rec, "MDZ", 3); ks_put(&rec, hb.md + hb.md_off[k], ml); ks_putc(&rec, 0);
+			ks_put(&rec, "ASc", 3); ks_putc(&rec, hb.as[k] & 0xff);
+			msh_write(out, (const uint8_t *)rec.s, rec.l);
+		}
+	}
+	msh_out_close(out);
+	msx_synth_host_free(&hb);
+	return 0;
+}
+
 int main(int argc, char *argv[]) {
 	if (argc < 2) return usage(stderr);
 	if (strcmp(argv[1], "recode") == 0) return recode_main(argc - 1, argv + 1);
+	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "help") == 0) { usage(stdout); return 0; }
