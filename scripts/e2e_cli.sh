@@ -5,13 +5,13 @@
 set -e
 B=msamtools_amd/bin/msamtools
 make -C msamtools_amd/csrc/host >/dev/null 2>&1 || true
-GROUPS=${1:-2000000}
+NGRP=${1:-2000000}
 REFS=${2:-10000}
 T=/tmp/msx_e2e
 mkdir -p $T
-echo "host: $(nproc) cores; groups=$GROUPS refs=$REFS"
-/usr/bin/time -f "synth(-u)      %e s" $B synth --groups $GROUPS --refs $REFS -u > $T/in_u.bam
-/usr/bin/time -f "synth(-b)      %e s" $B synth --groups $GROUPS --refs $REFS -b > $T/in_b.bam
+echo "host: $(nproc) cores; groups=$NGRP refs=$REFS"
+time $B synth --groups $NGRP --refs $REFS -u > $T/in_u.bam
+time $B synth --groups $NGRP --refs $REFS -b > $T/in_b.bam
 N=$($B recode $T/in_u.bam | wc -l)
 ls -la $T/in_u.bam $T/in_b.bam
 echo "records=$N"
