@@ -241,7 +241,7 @@ def main():
             prof.finalize_enqueue()
             run.finish()
         names = ["k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
-                 "k_rs_hist", "k_rs_scatter", "k_list_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply",
+                 "k_list_order", "k_rs_hist", "k_rs_scatter", "k_list_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply",
                  "scan"]
         tms = {}
         for k in names:

@@ -40,6 +40,7 @@ enum msx_kid {
 	MSX_K_SHARE_REDUCE,    // k_share_reduce
 	MSX_K_PARTIAL_REDUCE,  // k_partial_reduce
 	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply + k_prop_finish / k_prop_purged
+	MSX_K_LIST_ORDER,      // k_list_minkey, k_perm_len, k_perm_gather
 	MSX_K_RS_HIST,         // k_entry_lists, k_rs_hist
 	MSX_K_RS_SCATTER,      // k_rs_scatter
 	MSX_K_COVERAGE,        // k_coverage_pileup
@@ -140,6 +141,7 @@ struct msx_profile {
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
 	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
+	msx_buf m_off_alt, m_fid_alt, len2;   // second CSR copy for the list renumbering
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
 	bool transposed_valid = false;
 	int iter_k = 0;

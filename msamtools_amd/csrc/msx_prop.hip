@@ -35,13 +35,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_lists(const unsigned long l
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restrict__ keys,
-                                                       const unsigned long long *__restrict__ csr_tot, int shift,
+                                                       const unsigned long long *__restrict__ n_ptr, int shift,
                                                        uint32_t *__restrict__ hist, int64_t n_waves) {
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t wave = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + w;
 	if (wave >= n_waves) return;
-	const int64_t E = (int64_t)csr_tot[1];
+	const int64_t E = (int64_t)*n_ptr;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	const int64_t base = wave * RS_WAVE_ELEMS;
 	for (int row = 0; row < RS_ROWS; row++) {
@@ -58,13 +58,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
                                                           const uint32_t *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
                                                           uint32_t *__restrict__ vals_out,
-                                                          const unsigned long long *__restrict__ csr_tot, int shift,
+                                                          const unsigned long long *__restrict__ n_ptr, int shift,
                                                           const uint32_t *__restrict__ hoff, int64_t n_waves) {
 	__shared__ uint32_t s_base[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t wave = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + w;
 	if (wave >= n_waves) return;
-	const int64_t E = (int64_t)csr_tot[1];
+	const int64_t E = (int64_t)*n_ptr;
 	for (int q = 0; q < 4; q++) {
 		const int d = lane + 64 * q;
 		s_base[w][d] = hoff[(int64_t)d * n_waves + wave];
@@ -95,6 +95,62 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 			keys_out[pos + rank] = key;
 			vals_out[pos + rank] = val;
 		}
+	}
+}
+
+// --- locality: renumber the multi-mappers by their smallest feature ------------
+// The sharing iteration gathers a[feature] per list and recip[list] per feature
+// entry.  Inserts that multi-map inside one family of similar references share
+// features, so ordering the lists by their smallest feature id puts the lists a
+// feature belongs to next to each other (dense cache lines instead of one line
+// per 8-byte gather).  Pure renumbering: sums only change their order.
+__global__ __launch_bounds__(MSX_BLOCK) void k_list_minkey(const unsigned long long *__restrict__ csr_tot,
+                                                           const uint32_t *__restrict__ m_off,
+                                                           const int32_t *__restrict__ m_fid,
+                                                           uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
+		const uint32_t s = m_off[j], e = m_off[j + 1];
+		uint32_t mn = 0xffffffffu;
+		for (uint32_t k = s; k < e; ++k) {
+			const uint32_t f = (uint32_t)m_fid[k];
+			mn = f < mn ? f : mn;
+		}
+		key[j] = mn;
+		val[j] = (uint32_t)j;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_perm_len(const unsigned long long *__restrict__ csr_tot, int64_t m,
+                                                        const uint32_t *__restrict__ perm,
+                                                        const uint32_t *__restrict__ m_off,
+                                                        uint32_t *__restrict__ len2) {
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < m; i += stride) {
+		uint32_t l = 0;
+		if (i < n_lists) {
+			const uint32_t j = perm[i];
+			l = m_off[j + 1] - m_off[j];
+		}
+		len2[i] = l;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_perm_gather(const unsigned long long *__restrict__ csr_tot,
+                                                           const uint32_t *__restrict__ perm,
+                                                           const uint32_t *__restrict__ m_off,
+                                                           const int32_t *__restrict__ m_fid,
+                                                           const uint32_t *__restrict__ m_off2,
+                                                           int32_t *__restrict__ m_fid2) {
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n_lists; i += stride) {
+		const uint32_t j = perm[i];
+		const uint32_t s = m_off[j], e = m_off[j + 1];
+		uint32_t o = m_off2[i];
+		for (uint32_t k = s; k < e; ++k) m_fid2[o++] = m_fid[k];
 	}
 }
 
@@ -365,6 +421,33 @@ static int nf_grid(msx_ctx *ctx, int32_t nf) {
 	return g > PROP_MAX_BLOCKS ? PROP_MAX_BLOCKS : g;
 }
 
+// stable LSD radix sort of (key, val) pairs; *n_ptr (device) items, at most n_ub.
+// Ping-pongs between p->t_key/t_val[0] and [1]; returns the buffer holding the result.
+static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, const uint32_t *vin, int vin_buf,
+                            const unsigned long long *n_ptr, int64_t n_ub, int bits, int *out_buf) {
+	const int passes = (bits + 7) / 8;
+	const int64_t n_waves = (n_ub + RS_WAVE_ELEMS - 1) / RS_WAVE_ELEMS;
+	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
+	int cur = vin_buf, rc;
+	for (int ps = 0; ps < passes; ps++) {
+		const int dst = cur ^ 1;
+		MSX_TIMED(ctx, MSX_K_RS_HIST,
+		          hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr, ps * 8,
+		                             (uint32_t *)p->rs_hist.p, n_waves));
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
+			return rc;
+		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
+		          hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
+		                             (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, n_ptr, ps * 8,
+		                             (const uint32_t *)p->rs_off.p, n_waves));
+		kin = (const uint32_t *)p->t_key[dst].p;
+		vin = (const uint32_t *)p->t_val[dst].p;
+		cur = dst;
+	}
+	*out_buf = cur;
+	return MSX_OK;
+}
+
 int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	if (p->transposed_valid) return MSX_OK;
 	const int64_t eub = p->entries_ub > 0 ? p->entries_ub : 1;
@@ -384,36 +467,48 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	const unsigned long long *tot = p->csr_tot;
+	int bits = 0;
+	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
+
+	// (a) renumber the lists by smallest feature (locality of both gathers)
+	if (bits > 0) {
+		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap))) return rc;
+		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap))) return rc;
+		if ((rc = msx_reserve(ctx, &p->len2, (size_t)(lub + 8) * 4))) return rc;
+		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
+		          hipLaunchKernelGGL(k_list_minkey, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             tot, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		                             (uint32_t *)p->t_key[0].p, (uint32_t *)p->t_val[0].p));
+		int sb = 0;
+		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p, (const uint32_t *)p->t_val[0].p, 0, tot + 0,
+		                           lub, bits, &sb)))
+			return rc;
+		const uint32_t *perm = (const uint32_t *)p->t_val[sb].p;
+		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
+		          hipLaunchKernelGGL(k_perm_len, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
+		                             lub, perm, (const uint32_t *)p->m_off.p, (uint32_t *)p->len2.p));
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->m_off_alt.p, lub))) return rc;
+		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
+		          hipLaunchKernelGGL(k_perm_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             tot, perm, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		                             (const uint32_t *)p->m_off_alt.p, (int32_t *)p->m_fid_alt.p));
+		msx_buf t = p->m_off; p->m_off = p->m_off_alt; p->m_off_alt = t;
+		t = p->m_fid; p->m_fid = p->m_fid_alt; p->m_fid_alt = t;
+	}
+
+	// (b) feature-major view: (feature, list) pairs sorted by feature
 	MSX_TIMED(ctx, MSX_K_RS_HIST,
 	          hipLaunchKernelGGL(k_entry_lists, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             tot, (const uint32_t *)p->m_off.p, (uint32_t *)p->t_val[0].p));
-	int bits = 0;
-	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
-	const int passes = (bits + 7) / 8;
-	const uint32_t *kin = (const uint32_t *)p->m_fid.p;
-	const uint32_t *vin = (const uint32_t *)p->t_val[0].p;
-	int cur = 0;   // buffer holding vals (and, after pass 0, keys)
-	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
-	for (int ps = 0; ps < passes; ps++) {
-		const int dst = cur ^ 1;
-		MSX_TIMED(ctx, MSX_K_RS_HIST,
-		          hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, tot, ps * 8,
-		                             (uint32_t *)p->rs_hist.p, n_waves));
-		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
+	int cur = 0;
+	if (bits > 0) {
+		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_fid.p, (const uint32_t *)p->t_val[0].p, 0, tot + 1, eub,
+		                           bits, &cur)))
 			return rc;
-		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
-		          hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
-		                             (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, tot, ps * 8,
-		                             (const uint32_t *)p->rs_off.p, n_waves));
-		kin = (const uint32_t *)p->t_key[dst].p;
-		vin = (const uint32_t *)p->t_val[dst].p;
-		cur = dst;
-	}
-	if (passes == 0) {
+	} else {
 		// a single feature: the list-major order is already feature-major
-		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[0].p, p->m_fid.p, (size_t)eub * 4 < p->m_fid.cap ? (size_t)eub * 4 : p->m_fid.cap,
-		                            hipMemcpyDeviceToDevice, ctx->stream));
-		cur = 0;
+		size_t nb = (size_t)eub * 4 < p->m_fid.cap ? (size_t)eub * 4 : p->m_fid.cap;
+		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[0].p, p->m_fid.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
 	}
 	p->sorted_buf = cur;
 	p->transposed_valid = true;
