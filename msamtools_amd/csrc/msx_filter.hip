@@ -57,64 +57,132 @@ __device__ __forceinline__ void md_byte(MdState &s, uint32_t c, bool valid) {
 	}
 }
 
+// Software-pipelined over the tiles of a workgroup (tile k of block b is tile
+// b + k*gridDim.x): while tile i is being walked out of LDS, the payload of tile
+// i+1 (CIGAR words, MD dwords, FLAG, aux bits) and the offsets of tile i+2 are
+// already in flight into registers; they are written to LDS after the barrier
+// that ends tile i.  No global-memory latency sits between two tiles.
+#define CIG_REGS (CAP_CIG / MSX_BLOCK)   // 4
+#define MD_REGS (CAP_MDW / MSX_BLOCK)    // 6
+
+struct TileOff {          // offsets of one tile, one entry per thread (+1 extra held by thread 0)
+	uint32_t co, mo, co_last, mo_last;
+};
+
+__device__ __forceinline__ void load_offsets(const FilterArgs &A, int64_t tile, int tid, TileOff &o) {
+	const int64_t t0 = tile * MSX_BLOCK;
+	const int64_t left = A.n - t0;
+	const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
+	o.co = o.mo = o.co_last = o.mo_last = 0;
+	if (tid <= nt && t0 + tid <= A.n) {
+		o.co = A.cigar_off[t0 + tid];
+		o.mo = A.md_off[t0 + tid];
+	}
+	if (tid == 0 && nt == MSX_BLOCK) {
+		o.co_last = A.cigar_off[t0 + MSX_BLOCK];
+		o.mo_last = A.md_off[t0 + MSX_BLOCK];
+	}
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
-	__shared__ uint32_t s_coff[MSX_BLOCK + 1];
-	__shared__ uint32_t s_moff[MSX_BLOCK + 1];
+	__shared__ uint32_t s_coff[2][MSX_BLOCK + 1];
+	__shared__ uint32_t s_moff[2][MSX_BLOCK + 1];
 	__shared__ uint32_t s_cig[CAP_CIG];
 	__shared__ uint32_t s_md[CAP_MDW];
 
 	const int tid = threadIdx.x;
 	const int64_t n_tiles = (A.n + MSX_BLOCK - 1) / MSX_BLOCK;
-	const bool need_stats = (A.choice != 0) || A.rescore || A.o_len || A.o_status;
+	const int64_t first = blockIdx.x, step = gridDim.x;
+	if (first >= n_tiles) return;
+	const uint32_t *md4 = reinterpret_cast<const uint32_t *>(A.md);
 
-	for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	uint32_t cr[CIG_REGS], mr[MD_REGS];
+	uint32_t fl_n = 0, rf_n = 0;
+	TileOff on;
+
+	// helpers as lambdas over the LDS arrays
+	auto store_offsets = [&](int buf, int64_t tile, const TileOff &o) {
+		const int64_t left = A.n - tile * MSX_BLOCK;
+		const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
+		if (tid <= nt) { s_coff[buf][tid] = o.co; s_moff[buf][tid] = o.mo; }
+		if (tid == 0 && nt == MSX_BLOCK) { s_coff[buf][MSX_BLOCK] = o.co_last; s_moff[buf][MSX_BLOCK] = o.mo_last; }
+	};
+	auto issue_payload = [&](int buf, int64_t tile) {
+		const int64_t t0 = tile * MSX_BLOCK;
+		const int64_t left = A.n - t0;
+		const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
+		const uint32_t c0 = s_coff[buf][0];
+		uint32_t clen = s_coff[buf][nt] - c0;
+		if (clen > CAP_CIG) clen = CAP_CIG;
+#pragma unroll
+		for (int q = 0; q < CIG_REGS; q++) {
+			const uint32_t w = tid + q * MSX_BLOCK;
+			cr[q] = (w < clen) ? A.cigar[c0 + w] : 0u;
+		}
+		if (A.md_aligned) {
+			const uint32_t m0a = s_moff[buf][0] & ~3u;
+			uint32_t mw = (s_moff[buf][nt] - m0a + 3u) >> 2;
+			if (mw > CAP_MDW) mw = CAP_MDW;
+#pragma unroll
+			for (int q = 0; q < MD_REGS; q++) {
+				const uint32_t w = tid + q * MSX_BLOCK;
+				mr[q] = (w < mw) ? md4[(m0a >> 2) + w] : 0u;
+			}
+		}
+		if (tid < nt) { fl_n = A.flag[t0 + tid]; rf_n = A.rflags[t0 + tid]; }
+	};
+	auto store_payload = [&]() {
+#pragma unroll
+		for (int q = 0; q < CIG_REGS; q++) s_cig[tid + q * MSX_BLOCK] = cr[q];
+#pragma unroll
+		for (int q = 0; q < MD_REGS; q++) s_md[tid + q * MSX_BLOCK] = mr[q];
+	};
+
+	// prologue: offsets(0) -> LDS, payload(0) and offsets(1) -> registers -> LDS
+	load_offsets(A, first, tid, on);
+	store_offsets(0, first, on);
+	__syncthreads();
+	issue_payload(0, first);
+	if (first + step < n_tiles) load_offsets(A, first + step, tid, on);
+	store_payload();
+	if (first + step < n_tiles) store_offsets(1, first + step, on);
+	__syncthreads();
+
+	int buf = 0;
+	for (int64_t tile = first; tile < n_tiles; tile += step, buf ^= 1) {
 		const int64_t t0 = tile * MSX_BLOCK;
 		const int nt = (int)((A.n - t0 < MSX_BLOCK) ? (A.n - t0) : MSX_BLOCK);
 		const int64_t t = t0 + tid;
 		const bool live = tid < nt;
+		const uint32_t flag = fl_n, rf = rf_n;          // this tile's, loaded one iteration ago
+		const bool has_next = tile + step < n_tiles, has_next2 = tile + 2 * step < n_tiles;
 
-		uint32_t c0 = 0, clen = 0, m0a = 0, mbytes = 0;
-		if (need_stats) {
-			// offsets of the tile (one coalesced dword load per array)
-			if (tid <= nt) {
-				s_coff[tid] = A.cigar_off[t0 + tid];
-				s_moff[tid] = A.md_off[t0 + tid];
-			}
-			if (tid == 0 && nt == MSX_BLOCK) {
-				s_coff[MSX_BLOCK] = A.cigar_off[t0 + MSX_BLOCK];
-				s_moff[MSX_BLOCK] = A.md_off[t0 + MSX_BLOCK];
-			}
-			__syncthreads();
-			c0 = s_coff[0];
-			clen = s_coff[nt] - c0;
-			if (clen > CAP_CIG) clen = CAP_CIG;
-			for (uint32_t w = tid; w < clen; w += MSX_BLOCK) s_cig[w] = A.cigar[c0 + w];
-			if (A.md_aligned) {
-				uint32_t m0 = s_moff[0], m1 = s_moff[nt];
-				m0a = m0 & ~3u;
-				uint32_t mw = (m1 - m0a + 3u) >> 2;
-				if (mw > CAP_MDW) mw = CAP_MDW;
-				const uint32_t *md4 = reinterpret_cast<const uint32_t *>(A.md) + (m0a >> 2);
-				for (uint32_t w = tid; w < mw; w += MSX_BLOCK) s_md[w] = md4[w];
-				mbytes = mw << 2;
-			}
-			__syncthreads();
+		// geometry of the staged payload of this tile
+		const uint32_t c0 = s_coff[buf][0];
+		uint32_t clen = s_coff[buf][nt] - c0;
+		if (clen > CAP_CIG) clen = CAP_CIG;
+		uint32_t m0a = 0, mbytes = 0;
+		if (A.md_aligned) {
+			m0a = s_moff[buf][0] & ~3u;
+			uint32_t mw = (s_moff[buf][nt] - m0a + 3u) >> 2;
+			if (mw > CAP_MDW) mw = CAP_MDW;
+			mbytes = mw << 2;
 		}
 
+		// in flight while this tile is computed
+		if (has_next) issue_payload(buf ^ 1, tile + step);
+		if (has_next2) load_offsets(A, tile + 2 * step, tid, on);
+
 		if (live) {
-			const uint32_t flag = A.flag[t];
-			const uint32_t rf = A.rflags[t];
 			uint32_t pooled = 0;
 			if (A.as_out) A.as_out[t] = A.as[t];   // replaced below when the record is rescored
 			if ((flag & MSX_F_UNMAP) && !A.o_len) {
 				// msam_filter.c:132-138 (msx_aln_stats reports statistics for every record)
 				pooled = (A.choice != 0 && A.keep_unmapped && A.ppt >= 0 && A.invert == 1) ? 1u : 0u;
-			} else if (!need_stats) {
-				pooled = 1;   // filter == NULL and no rescore (msam_filter.c:104,181)
 			} else {
 				uint32_t alen = 0, qlen = 0, qclip = 0, edit = 0;   // wrap like int32
 				bool bad = false;
-				const uint32_t cs = s_coff[tid], ce = s_coff[tid + 1];
+				const uint32_t cs = s_coff[buf][tid], ce = s_coff[buf][tid + 1];
 				if (rf & MSX_HAS_MD) {
 					// bam_get_summary, mBamVector.c:60-97
 					for (uint32_t k = cs; k < ce; ++k) {
@@ -132,7 +200,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 					}
 					// MD walk, mBamVector.c:101-118
 					MdState s = {0u, 0u, 0u, 0};
-					const uint32_t ms = s_moff[tid], me = s_moff[tid + 1];
+					const uint32_t ms = s_moff[buf][tid], me = s_moff[buf][tid + 1];
 					if (ms < me) {
 						if (A.md_aligned && (me - m0a) <= mbytes) {
 							const uint32_t bs = ms - m0a, be = me - m0a;
@@ -188,7 +256,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 			}
 			if (A.pool) A.pool[t] = (uint8_t)pooled;
 		}
-		if (need_stats) __syncthreads();   // LDS is reused by the next tile
+		__syncthreads();                 // every lane is done with this tile's LDS image
+		if (has_next) store_payload();
+		if (has_next2) store_offsets(buf, tile + 2 * step, on);
+		__syncthreads();
 	}
 }
 
