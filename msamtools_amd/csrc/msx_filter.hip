@@ -9,6 +9,7 @@
 // per pool (selection); variable-length CIGAR/MD payloads of a 256-record tile
 // are staged into LDS with coalesced dword loads.
 #include "msx_internal.h"
+#include "msx_md.h"
 
 #include <climits>
 
@@ -37,25 +38,6 @@ struct FilterArgs {
 	uint8_t *o_status;
 	msx_dev_status *st;
 };
-
-// One MD byte through the token rule of mBamVector.c:112-118: count the bytes
-// of every maximal run of non-[^0-9] characters whose predecessor is a digit
-// (a run at the start of the string or right after '^' is not counted).
-struct MdState {
-	uint32_t prevL, prevD, counting;
-	int32_t edit;
-};
-
-__device__ __forceinline__ void md_byte(MdState &s, uint32_t c, bool valid) {
-	uint32_t isD = (c - 48u) < 10u;
-	uint32_t isL = (!isD && c != 94u) ? 1u : 0u;
-	if (valid) {
-		if (isL & (s.prevL ^ 1u)) s.counting = s.prevD;
-		s.edit += (int32_t)(isL & s.counting);
-		s.prevL = isL;
-		s.prevD = isD;
-	}
-}
 
 // Software-pipelined over the tiles of a workgroup (tile k of block b is tile
 // b + k*gridDim.x): while tile i is being walked out of LDS, the payload of tile
@@ -169,6 +151,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 			mbytes = mw << 2;
 		}
 
+		// tile-uniform: every CIGAR word and MD byte of this tile was staged
+		const bool all_staged = A.md_aligned && (s_coff[buf][nt] - c0) <= CAP_CIG &&
+		                        (s_moff[buf][nt] - m0a) <= mbytes;
+
 		// in flight while this tile is computed
 		if (has_next) issue_payload(buf ^ 1, tile + step);
 		if (has_next2) load_offsets(A, tile + 2 * step, tid, on);
@@ -183,7 +169,35 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 				uint32_t alen = 0, qlen = 0, qclip = 0, edit = 0;   // wrap like int32
 				bool bad = false;
 				const uint32_t cs = s_coff[buf][tid], ce = s_coff[buf][tid + 1];
-				if (rf & MSX_HAS_MD) {
+				if (all_staged) {
+					// fast path: the whole tile's payload is in LDS.  CIGAR by per-op bit tables
+					// (bit i = op i contributes): MD path mBamVector.c:60-97, NM path :23-38.
+					const bool mdp = (rf & MSX_HAS_MD) != 0;
+					bad = !mdp && !(rf & MSX_HAS_NM);
+					const uint32_t T_ALEN = mdp ? 0x187u : 0xff87u;    // M I D = X (NM path: all but N P S H)
+					const uint32_t T_EDIT = mdp ? 0x006u : 0u;         // I D
+					for (uint32_t k = cs; k < ce; ++k) {
+						const uint32_t c = s_cig[k - c0];
+						const uint32_t op = c & 0xf, w = c >> 4;
+						alen += w & (0u - ((T_ALEN >> op) & 1u));
+						qlen += w & (0u - ((0x1b3u >> op) & 1u));      // M I S H = X
+						edit += w & (0u - ((T_EDIT >> op) & 1u));
+						qclip += w & (0u - ((0x030u >> op) & 1u));     // S H
+					}
+					if (mdp) {
+						MdState s = {0u, 0u, 0u, 0};
+						const uint32_t bs = s_moff[buf][tid] - m0a, be = s_moff[buf][tid + 1] - m0a;
+						for (uint32_t w = bs >> 2; (w << 2) < be; ++w) {
+							const uint32_t p = w << 2;
+							md_word(s, s_md[w], bs > p ? bs - p : 0u, be - p < 4u ? be - p : 4u);
+						}
+						edit += (uint32_t)s.edit;
+					} else if (!bad) {
+						edit = (uint32_t)A.nm[t];                      // msam_filter.c:155
+					} else {
+						atomicMin(&A.st->first_no_mdnm, (unsigned long long)t);   // msam_filter.c:150-152
+					}
+				} else if (rf & MSX_HAS_MD) {
 					// bam_get_summary, mBamVector.c:60-97
 					for (uint32_t k = cs; k < ce; ++k) {
 						uint32_t c = (k - c0 < clen) ? s_cig[k - c0] : A.cigar[k];
