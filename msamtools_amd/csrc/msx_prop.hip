@@ -201,6 +201,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 // slots per wave, in entry order.  Level 2 (k_partial_reduce) runs the same
 // segmented sum over those few pairs and adds each run once.
 #define SR_ROWS_PER_STEP 4
+#define PR_CHUNK 256                   // partials reduced by one wave (level 2)
 #define SR_SENT 0xffffffffu
 
 struct SegRow {
@@ -320,9 +321,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 	if (iter_state[0]) return;
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
-	const int64_t c0 = wave * SR_CHUNK;
+	const int64_t c0 = wave * PR_CHUNK;
 	if (c0 >= M) return;
-	const int64_t c1 = (c0 + SR_CHUNK < M) ? c0 + SR_CHUNK : M;
+	const int64_t c1 = (c0 + PR_CHUNK < M) ? c0 + PR_CHUNK : M;
 	double carry = 0.0;
 	bool carry_open = false;
 	uint32_t carry_key = 0;
@@ -533,7 +534,7 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
 	                             (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
 	                             (uint32_t *)p->part_key.p, (double *)p->part_val.p,
 	                             (const int32_t *)p->iter_state));
-	const int64_t n_waves2 = (M + SR_CHUNK - 1) / SR_CHUNK;
+	const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
 	MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
 	          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((n_waves2 + 3) / 4)), dim3(MSX_BLOCK), 0,
 	                             ctx->stream, M, (const uint32_t *)p->part_key.p, (const double *)p->part_val.p,
