@@ -59,15 +59,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 		int32_t *lst = A.tmp_fid + s;
 		// the stream profile sees: the batch itself, or filter's output order
 		// (all pass-1 records of the pool, then its pass-2 records)
-		int npass = A.keep ? 2 : 1;
+		const int npass = A.keep ? 2 : 1;
 		for (int pass = 1; pass <= npass; ++pass) {
-			bool later = false;                              // any pass-2 record seen while doing pass 1
 			for (uint32_t i = s; i < e; ++i) {
-				if (A.keep) {
-					const uint8_t kc = A.keep[i];
-					later |= (kc == 2);
-					if (kc != pass) continue;
-				}
+				if (A.keep && A.keep[i] != pass) continue;
 				const int32_t t = A.tid[i];
 				if (t == -1) continue;                       // msam_profile.c:223-225
 				const int32_t fid = A.fmap ? A.fmap[t] : t;
@@ -87,7 +82,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 					nd++;
 				}
 			}
-			if (pass == 1 && !later) break;                  // the pool has no READ2-pass records
 		}
 		unsigned long long ml = 0;
 		if (nvalid > 0) {
