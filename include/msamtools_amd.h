@@ -240,11 +240,16 @@ int  msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int6
 
 /* ---- coverage: replaces mUpdateCoverageForAlignment (msam_coverage.c:33-87) */
 
-/* cov: device int32[cov_off[n_targets]] (caller zeroes it once per file);
- * cov_off: device int64[n_targets+1] prefix sum of target_len.  Adds 1 per
- * aligned base (M,=,X); D and N advance; tid < 0 skipped. */
+/* cov: device int32[cov_off[n_targets] + 1], zeroed by the caller once per
+ * file; cov_off: device int64[n_targets+1] prefix sum of target_len.
+ * accumulate records every M/=/X run as +1/-1 differences (D and N advance;
+ * I, S, H, P do not; tid < 0 skipped); after the last batch
+ * msx_coverage_finish() converts the buffer in place into per-base depths
+ * (what mUpdateCoverageForAlignment builds by adding 1 per base).  Like the
+ * reference, runs are assumed to stay inside their target (no bounds check). */
 int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
                              const int64_t *cov_off, int32_t n_targets, int32_t *cov);
+int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);
 
 /* ---- synthetic workloads (bench.py / tests) -------- */
 

@@ -116,6 +116,7 @@ static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) {
 // exclusive scan: out[0..m] (m+1 entries, out[m] = total), u32
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
 int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m);
+int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m);
 
 // profile state (one sample)
 #define PROP_MAX_BLOCKS 2048

@@ -75,9 +75,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const T *__restrict__
 
 // carry == nullptr: single-chunk top level.  Writes out[i] for i < m and, from
 // the last block, out[m] = grand total.
-template <typename T>
-__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *__restrict__ in, T *__restrict__ out,
-                                                          int64_t m, const T *__restrict__ carry) {
+template <typename T, bool INCL>
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *in, T *out, int64_t m,
+                                                          const T *__restrict__ carry) {
 	__shared__ T s_w[4];
 	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
 	T v[SCAN_ITEMS];
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *__restrict__ 
 	T o[SCAN_ITEMS];
 #pragma unroll
 	for (int k = 0; k < SCAN_ITEMS; k++) {
-		o[k] = run;
-		run += v[k];
+		if (INCL) { run += v[k]; o[k] = run; }
+		else { o[k] = run; run += v[k]; }
 	}
 	if (base + SCAN_ITEMS <= m) {
 		constexpr int PER = 16 / sizeof(T);
@@ -112,15 +112,15 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *__restrict__ 
 		for (int k = 0; k < SCAN_ITEMS; k++)
 			if (base + k < m) out[base + k] = o[k];
 	}
-	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = c + tot;
+	if (!INCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = c + tot;
 }
 
-template <typename T>
+template <typename T, bool INCL = false>
 static int scan_rec(msx_ctx *ctx, const T *in, T *out, int64_t m, int level) {
 	int64_t nb = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
 	if (nb < 1) nb = 1;
 	if (nb == 1) {
-		hipLaunchKernelGGL(k_scan_apply<T>, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+		hipLaunchKernelGGL((k_scan_apply<T, INCL>), dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
 		                   (const T *)nullptr);
 		return MSX_OK;
 	}
@@ -132,9 +132,9 @@ static int scan_rec(msx_ctx *ctx, const T *in, T *out, int64_t m, int level) {
 	T *partial = (T *)lv->p;
 	T *pscan = partial + ((nb + 3) & ~(int64_t)3);
 	hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, m, partial);
-	rc = scan_rec<T>(ctx, partial, pscan, nb, level + 1);
+	rc = scan_rec<T, false>(ctx, partial, pscan, nb, level + 1);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_scan_apply<T>, dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+	hipLaunchKernelGGL((k_scan_apply<T, INCL>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
 	                   (const T *)pscan);
 	return MSX_OK;
 }
@@ -142,6 +142,16 @@ static int scan_rec(msx_ctx *ctx, const T *in, T *out, int64_t m, int level) {
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
 	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0);
+	msx_time_end(ctx);
+	if (rc) return rc;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+// inclusive, in place (each workgroup reads its 2048 items into registers before writing them)
+int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
+	msx_time_begin(ctx, MSX_K_SCAN);
+	int rc = scan_rec<uint32_t, true>(ctx, data, data, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
 	MSX_HIP(ctx, hipGetLastError());

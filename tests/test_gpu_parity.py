@@ -430,3 +430,15 @@ def test_int32_wraparound_matches_oracle(ctx):
     rec = b.build()
     for opts in (dict(p=95), dict(z=50), dict(l=1000), dict(ppt=-900)):
         assert gpu_filter(ctx, rec, **opts).emit.tolist() == orc.run_filter(rec, **opts)["emit"].tolist()
+
+
+def test_synth_coverage_parity(ctx, synth):
+    """Per-base depth (difference array + prefix sum) equals the oracle's per-base counting."""
+    import msamtools_amd as m
+    hs, db = synth
+    tlen = [5000] * 2000
+    cov = m.coverage(ctx, db, tlen)
+    want = orc.coverage(hs, tlen)
+    for t in range(len(tlen)):
+        assert (cov[t] == want[t]).all(), t
+    assert sum(int(c.sum()) for c in cov) > 0
