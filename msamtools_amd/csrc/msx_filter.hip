@@ -294,78 +294,59 @@ struct SelectArgs {
 	msx_dev_status *st;
 };
 
-// The keep codes of a workgroup's 256 pools cover one contiguous record range;
-// they are staged in LDS and written back with contiguous byte stores (one
-// 64-byte request per wave instead of 64 scattered single-byte writes).
-#define KEEP_CAP 6144
-
 __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
-	__shared__ uint8_t s_keep[KEEP_CAP];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t gb = (int64_t)blockIdx.x * MSX_BLOCK; gb < A.n_groups; gb += stride) {
-		const int64_t g = gb + threadIdx.x;
-		const bool active = g < A.n_groups;
-		const int64_t gend = (gb + MSX_BLOCK < A.n_groups) ? gb + MSX_BLOCK : A.n_groups;
-		const uint32_t r0 = A.group_off[gb], r1 = A.group_off[gend];
-		if (active) {
-			const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
-			// (best, count) per mate class: 0 = neither bit, 1 = READ1, 2 = READ2
-			int32_t b0 = INT_MIN, b1 = INT_MIN, b2 = INT_MIN;
-			uint32_t n0 = 0, n1 = 0, n2 = 0;
-			uint32_t paired = 0;
-			uint32_t noas0 = 0xffffffffu, noas1 = 0xffffffffu, noas2 = 0xffffffffu;  // first record lacking AS
-			for (uint32_t i = s; i < e; ++i) {
-				const uint32_t fl = A.flag[i];
-				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-				if (!pooled) continue;
+	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
+		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
+		// (best, count) per mate class: 0 = neither bit, 1 = READ1, 2 = READ2
+		int32_t b0 = INT_MIN, b1 = INT_MIN, b2 = INT_MIN;
+		uint32_t n0 = 0, n1 = 0, n2 = 0;
+		uint32_t paired = 0;
+		uint32_t noas0 = 0xffffffffu, noas1 = 0xffffffffu, noas2 = 0xffffffffu;  // first record lacking AS
+		for (uint32_t i = s; i < e; ++i) {
+			const uint32_t fl = A.flag[i];
+			const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+			if (!pooled) continue;
+			const uint32_t cls = fl & MSX_F_MATES;
+			paired |= cls;                                           // mBamPoolIsPaired :196-204
+			const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+			const int32_t sc = A.as[i];
+			if (cls == 0) {
+				if (!has) { if (noas0 == 0xffffffffu) noas0 = i; }
+				else if (sc > b0) { b0 = sc; n0 = 1; } else if (sc == b0) n0++;
+			} else if (cls == 0x40u) {
+				if (!has) { if (noas1 == 0xffffffffu) noas1 = i; }
+				else if (sc > b1) { b1 = sc; n1 = 1; } else if (sc == b1) n1++;
+			} else if (cls == 0x80u) {
+				if (!has) { if (noas2 == 0xffffffffu) noas2 = i; }
+				else if (sc > b2) { b2 = sc; n2 = 1; } else if (sc == b2) n2++;
+			}
+		}
+		// msam_filter.c:219-221: a participating record without AS is fatal
+		uint32_t bad = paired ? (noas1 < noas2 ? noas1 : noas2) : noas0;
+		if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
+		const bool w0 = !paired && n0 > 0 && (!A.unique_only || n0 == 1);   // :232-233
+		const bool w1 = paired && n1 > 0 && (!A.unique_only || n1 == 1);
+		const bool w2 = paired && n2 > 0 && (!A.unique_only || n2 == 1);
+		uint32_t cnt = 0;
+		for (uint32_t i = s; i < e; ++i) {
+			const uint32_t fl = A.flag[i];
+			const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+			uint8_t k = 0;
+			if (pooled) {
 				const uint32_t cls = fl & MSX_F_MATES;
-				paired |= cls;                                           // mBamPoolIsPaired :196-204
 				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
 				const int32_t sc = A.as[i];
-				if (cls == 0) {
-					if (!has) { if (noas0 == 0xffffffffu) noas0 = i; }
-					else if (sc > b0) { b0 = sc; n0 = 1; } else if (sc == b0) n0++;
-				} else if (cls == 0x40u) {
-					if (!has) { if (noas1 == 0xffffffffu) noas1 = i; }
-					else if (sc > b1) { b1 = sc; n1 = 1; } else if (sc == b1) n1++;
-				} else if (cls == 0x80u) {
-					if (!has) { if (noas2 == 0xffffffffu) noas2 = i; }
-					else if (sc > b2) { b2 = sc; n2 = 1; } else if (sc == b2) n2++;
+				if (has) {
+					if (cls == 0 && w0 && sc == b0) k = 1;
+					else if (cls == 0x40u && w1 && sc == b1) k = 1;
+					else if (cls == 0x80u && w2 && sc == b2) k = 2;
 				}
 			}
-			// msam_filter.c:219-221: a participating record without AS is fatal
-			uint32_t bad = paired ? (noas1 < noas2 ? noas1 : noas2) : noas0;
-			if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
-			const bool w0 = !paired && n0 > 0 && (!A.unique_only || n0 == 1);   // :232-233
-			const bool w1 = paired && n1 > 0 && (!A.unique_only || n1 == 1);
-			const bool w2 = paired && n2 > 0 && (!A.unique_only || n2 == 1);
-			uint32_t cnt = 0;
-			for (uint32_t i = s; i < e; ++i) {
-				const uint32_t fl = A.flag[i];
-				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-				uint8_t k = 0;
-				if (pooled) {
-					const uint32_t cls = fl & MSX_F_MATES;
-					const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-					const int32_t sc = A.as[i];
-					if (has) {
-						if (cls == 0 && w0 && sc == b0) k = 1;
-						else if (cls == 0x40u && w1 && sc == b1) k = 1;
-						else if (cls == 0x80u && w2 && sc == b2) k = 2;
-					}
-				}
-				if (i - r0 < KEEP_CAP) s_keep[i - r0] = k;
-				else A.keep[i] = k;
-				cnt += (k != 0);
-			}
-			A.gcount[g] = cnt;
+			A.keep[i] = k;
+			cnt += (k != 0);
 		}
-		__syncthreads();
-		{
-			const uint32_t len = (r1 - r0 < KEEP_CAP) ? r1 - r0 : KEEP_CAP;
-			for (uint32_t x = threadIdx.x; x < len; x += MSX_BLOCK) A.keep[r0 + x] = s_keep[x];
-		}
-		__syncthreads();
+		A.gcount[g] = cnt;
 	}
 }
 

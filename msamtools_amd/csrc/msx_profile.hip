@@ -44,51 +44,6 @@ __device__ __forceinline__ void ui_add(int32_t *s_key, uint32_t *s_val, uint32_t
 	atomicAdd(&ui[fid], v);
 }
 
-// Distinct features of one pool in first-appearance order (msam_profile.c:131-145)
-// over the stream profile sees: the batch itself, or filter's output order (all
-// pass-1 records of the pool, then its pass-2 records).  The first four live in
-// registers; only a pool with more than four spills the rest to its scratch slice
-// lst[4..] (aligned with the pool's records), so the common case writes nothing.
-// `limit` stops the walk once that many distinct features are known.
-struct PoolFeat {
-	int32_t f0, f1, f2, f3;
-	uint32_t nd, nvalid;
-};
-
-__device__ __forceinline__ PoolFeat pool_distinct(const CountArgs &A, uint32_t s, uint32_t e, int32_t *lst,
-                                                  uint32_t limit, bool spill) {
-	PoolFeat r = {-1, -1, -1, -1, 0u, 0u};
-	const int npass = A.keep ? 2 : 1;
-	for (int pass = 1; pass <= npass; ++pass) {
-		for (uint32_t i = s; i < e; ++i) {
-			if (A.keep && A.keep[i] != pass) continue;
-			const int32_t t = A.tid[i];
-			if (t == -1) continue;                       // msam_profile.c:223-225
-			const int32_t fid = A.fmap ? A.fmap[t] : t;
-			r.nvalid++;
-			bool seen = (r.nd > 0 && fid == r.f0) || (r.nd > 1 && fid == r.f1) || (r.nd > 2 && fid == r.f2) ||
-			            (r.nd > 3 && fid == r.f3);
-			if (!seen && r.nd > 4)
-				for (uint32_t k = 4; k < r.nd; ++k)
-					if (lst[k] == fid) { seen = true; break; }
-			if (!seen) {
-				if (r.nd == 0) r.f0 = fid;
-				else if (r.nd == 1) r.f1 = fid;
-				else if (r.nd == 2) r.f2 = fid;
-				else if (r.nd == 3) r.f3 = fid;
-				else if (spill) lst[r.nd] = fid;
-				r.nd++;
-				if (r.nd >= limit) return r;
-			}
-		}
-	}
-	return r;
-}
-
-__device__ __forceinline__ int32_t pool_feat(const PoolFeat &r, const int32_t *lst, uint32_t k) {
-	return k == 0 ? r.f0 : k == 1 ? r.f1 : k == 2 ? r.f2 : k == 3 ? r.f3 : lst[k];
-}
-
 __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
 	__shared__ int32_t s_key[UI_TBL];
@@ -99,28 +54,54 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
 		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
+		uint32_t nvalid = 0, nd = 0;
+		int32_t f0 = -1, f1 = -1, f2 = -1, f3 = -1;
 		int32_t *lst = A.tmp_fid + s;
-		const PoolFeat r = pool_distinct(A, s, e, lst, 0xffffffffu, true);
-		const uint32_t nd = r.nd;
+		// the stream profile sees: the batch itself, or filter's output order
+		// (all pass-1 records of the pool, then its pass-2 records)
+		const int npass = A.keep ? 2 : 1;
+		for (int pass = 1; pass <= npass; ++pass) {
+			for (uint32_t i = s; i < e; ++i) {
+				if (A.keep && A.keep[i] != pass) continue;
+				const int32_t t = A.tid[i];
+				if (t == -1) continue;                       // msam_profile.c:223-225
+				const int32_t fid = A.fmap ? A.fmap[t] : t;
+				nvalid++;
+				// distinct features in first-appearance order (msam_profile.c:131-145)
+				bool seen = (nd > 0 && fid == f0) || (nd > 1 && fid == f1) || (nd > 2 && fid == f2) ||
+				            (nd > 3 && fid == f3);
+				if (!seen && nd > 4)
+					for (uint32_t k = 4; k < nd; ++k)
+						if (lst[k] == fid) { seen = true; break; }
+				if (!seen) {
+					if (nd == 0) f0 = fid;
+					else if (nd == 1) f1 = fid;
+					else if (nd == 2) f2 = fid;
+					else if (nd == 3) f3 = fid;
+					lst[nd] = fid;
+					nd++;
+				}
+			}
+		}
 		unsigned long long ml = 0;
-		if (r.nvalid > 0) {
+		if (nvalid > 0) {
 			c_ins++;                                          // one insert per pool (:230,:237)
 			if (nd == 1) {                                    // :75-78, :87-91, :152-159
-				ui_add(s_key, s_val, A.ui, r.f0, 2u);
+				ui_add(s_key, s_val, A.ui, f0, 2u);
 				c_uniq++;
 			} else {
 				c_multi++;                                    // :95, :162
 				switch (A.share_type) {
 				case MSX_MULTI_ADD_ALL:                       // :99-102, :169-173
-					for (uint32_t k = 0; k < nd; ++k) ui_add(s_key, s_val, A.ui, pool_feat(r, lst, k), 2u);
+					for (uint32_t k = 0; k < nd; ++k) ui_add(s_key, s_val, A.ui, lst[k], 2u);
 					break;
 				case MSX_MULTI_SHARE_EQUAL:
-					if (r.nvalid == 2) {                      // :103-106 (integer halves)
-						ui_add(s_key, s_val, A.ui, r.f0, 1u);
-						ui_add(s_key, s_val, A.ui, r.f1, 1u);
+					if (nvalid == 2) {                        // :103-106 (integer halves)
+						ui_add(s_key, s_val, A.ui, f0, 1u);
+						ui_add(s_key, s_val, A.ui, f1, 1u);
 					} else {                                  // :175-182
 						const double share = 1.0 / (double)nd;
-						for (uint32_t k = 0; k < nd; ++k) atomicAdd(&A.d[pool_feat(r, lst, k)], share);
+						for (uint32_t k = 0; k < nd; ++k) atomicAdd(&A.d[lst[k]], share);
 					}
 					break;
 				case MSX_MULTI_SHARE_PROPORTIONAL:            // :107-121, :184-186
@@ -153,30 +134,27 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	}
 }
 
-// Appends the multi-mapped pools' feature lists to the compact CSR.  The first
-// four features of a list are recomputed from the records (cheaper than having
-// k_insert_count write every pool's list to scratch); longer lists take the rest
-// from the scratch slice k_insert_count spilled.
-__global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(CountArgs A, const unsigned long long *__restrict__ mscan,
+// csr_tot = {n_lists, n_entries} running totals of the compact CSR
+__global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(int64_t n_groups, const uint32_t *__restrict__ group_off,
+                                                             const unsigned long long *__restrict__ mlen,
+                                                             const unsigned long long *__restrict__ mscan,
+                                                             const int32_t *__restrict__ tmp_fid,
                                                              const unsigned long long *__restrict__ csr_tot,
                                                              uint32_t *__restrict__ m_off, int32_t *__restrict__ m_fid) {
 	const unsigned long long base_l = csr_tot[0], base_e = csr_tot[1];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
-		const unsigned long long ml = A.mlen[g];
+	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < n_groups; g += stride) {
+		const unsigned long long ml = mlen[g];
 		if (!ml) continue;
 		const uint32_t nd = (uint32_t)ml;
 		const unsigned long long sc = mscan[g];
 		const unsigned long long li = base_l + (sc >> 32), ei = base_e + (sc & 0xffffffffull);
 		m_off[li] = (uint32_t)ei;
-		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
-		const int32_t *lst = A.tmp_fid + s;
-		const PoolFeat r = pool_distinct(A, s, e, const_cast<int32_t *>(lst), nd < 4u ? nd : 4u, false);
-		for (uint32_t k = 0; k < nd; ++k) m_fid[ei + k] = pool_feat(r, lst, k);
+		const int32_t *src = tmp_fid + group_off[g];
+		for (uint32_t k = 0; k < nd; ++k) m_fid[ei + k] = src[k];
 	}
 }
 
-// csr_tot = {n_lists, n_entries} running totals of the compact CSR
 __global__ void k_multi_advance(int64_t n_groups, const unsigned long long *__restrict__ mscan,
                                 unsigned long long *csr_tot, uint32_t *m_off) {
 	const unsigned long long tot = mscan[n_groups];
@@ -316,9 +294,10 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	if (prop) {
 		if ((rc = msx_scan_u64(ctx, (const uint64_t *)ctx->mlen.p, (uint64_t *)ctx->moff.p, ng))) return rc;
 		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);
-		hipLaunchKernelGGL(k_multi_compact, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A,
-		                   (const unsigned long long *)ctx->moff.p, (const unsigned long long *)p->csr_tot,
-		                   (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p);
+		hipLaunchKernelGGL(k_multi_compact, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, ng,
+		                   b->group_off, (const unsigned long long *)ctx->mlen.p,
+		                   (const unsigned long long *)ctx->moff.p, (const int32_t *)ctx->tmp_fid.p,
+		                   (const unsigned long long *)p->csr_tot, (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p);
 		hipLaunchKernelGGL(k_multi_advance, dim3(1), dim3(1), 0, ctx->stream, ng,
 		                   (const unsigned long long *)ctx->moff.p, p->csr_tot, (uint32_t *)p->m_off.p);
 		msx_time_end(ctx);
