@@ -38,6 +38,17 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
 # filled from profiles/ when measured for the default workload; None = not measured.
 TRAFFIC = {}
+_PMC = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_c3.json")
+
+
+def load_traffic(workload, ng, nrefs):
+    """PMC-measured HBM bytes per launch; only valid for the workload they were collected on (c3 defaults)."""
+    if workload == "c3" and (ng, nrefs) == WORKLOADS["c3"][:2] and os.path.exists(_PMC):
+        try:
+            for k, v in json.load(open(_PMC))["kernels"].items():
+                TRAFFIC[k] = int(v["hbm_bytes_per_launch"])
+        except Exception:
+            pass
 SEED = 13579
 
 
@@ -262,6 +273,7 @@ def main():
             avg_ms = ms_step / launches
             return algorithmic_bytes(k, w) / (avg_ms * 1e-3) / 1e9, avg_ms
 
+        load_traffic(args.workload, ng, nrefs)
         dom = max((k for k in names if k != "scan"), key=lambda k: tms[k][0])
         achieved, avg_ms = gbps(dom)
         out["roofline"] = {
