@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-GPU step (RCCL all-reduces between the split profile calls) even with one rank")
+    ap.add_argument("--print-checksum", action="store_true", help="add a checksum of the abundance vector to the JSON")
     return ap.parse_args()
 
 
@@ -128,10 +131,11 @@ def main():
     dist = None
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", world_size=world, rank=rank,
                                 device_id=torch.device(dev))
 
@@ -217,6 +221,9 @@ def main():
     value = total_records * args.steps / elapsed / 1e6
 
     ab, pst = prof.fetch()
+    if dist is not None:
+        # the split API leaves "purged" to the caller: sum over ranks
+        pst.purged_insert_count = int(t_purged.item())
     out = {
         "metric": "M alignments/s through filter --besthit | profile",
         "value": round(value, 3),
@@ -239,6 +246,13 @@ def main():
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
     }
+
+    if args.print_checksum:
+        import hashlib
+        out["checksum"] = {"abundance_sum": float(ab.sum()), "abundance_sha1_6dp": hashlib.sha1(
+            np.round(ab, 6).tobytes()).hexdigest(), "inserts": int(pst.insert_count), "uniq": int(pst.uniq_mapper_count),
+            "multi": int(pst.multi_mapper_count), "purged": int(pst.purged_insert_count),
+            "iterations": int(pst.iterations) if dist is None else state["iters"]}
 
     # ---- roofline of the dominant kernel (HIP events on the library's stream) ----
     if rank == 0 and not args.no_roofline:

@@ -99,3 +99,23 @@ def test_c2_fused_profile_properties(big):
     ab2, st2 = prof.finalize()
     assert st2.iterations == st.iterations and np.allclose(ab, ab2, rtol=1e-9, atol=0)
     prof.close()
+
+
+def test_bench_multi_gpu_step_on_one_rank():
+    """bench.py's N>1 step (torch tensors aliasing the library's device buffers, RCCL all-reduce between
+    the split proportional-sharing calls) run with a one-rank process group must reproduce the N=1 result."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--groups", "200000", "--refs", "5000",
+            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--print-checksum"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    a = json.loads(subprocess.check_output(base, env=env).decode().strip().split("\n")[-1])
+    b = json.loads(subprocess.check_output(base + ["--force-dist"], env=env).decode().strip().split("\n")[-1])
+    ca, cb = a["checksum"], b["checksum"]
+    for k in ("inserts", "uniq", "multi", "purged", "iterations"):
+        assert ca[k] == cb[k], k
+    assert abs(ca["abundance_sum"] - cb["abundance_sum"]) <= 1e-9 * ca["abundance_sum"]
+    assert ca["abundance_sha1_6dp"] == cb["abundance_sha1_6dp"]
