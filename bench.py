@@ -319,14 +319,21 @@ def main():
                       f"({best:.2f} s each)",
         }
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     prof.close()
     run.free()
     db.free()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -114,6 +114,7 @@ def test_bench_multi_gpu_step_on_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     a = json.loads(subprocess.check_output(base, env=env).decode().strip().split("\n")[-1])
     b = json.loads(subprocess.check_output(base + ["--force-dist"], env=env).decode().strip().split("\n")[-1])
+    assert b["config"]["prop_iterations"] == a["config"]["prop_iterations"]
     ca, cb = a["checksum"], b["checksum"]
     for k in ("inserts", "uniq", "multi", "purged", "iterations"):
         assert ca[k] == cb[k], k
