@@ -152,47 +152,40 @@ def main():
     run = m.FilterRun(ctx, db, **FILTER_OPTS)
     prof = m.Profile(ctx, nrefs, "proportional")
     ui_ptr, _, cnt_ptr = prof.accumulators()
-    t_ui = t_cnt = t_inc = t_purged = None
+    t_ui = t_cnt = t_share = t_purged = None
     if dist is not None:
         t_ui = as_tensor(torch, ui_ptr, nrefs, "<i4", dev)       # u32 sums wrap like i32 sums
-        t_cnt = as_tensor(torch, cnt_ptr, 4, "<i4", dev)
-        t_purged = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_cnt = as_tensor(torch, cnt_ptr, 3, "<i4", dev)         # inserts, uniq, multi (purged is reduced separately)
 
     state = {"iters": 0, "n_emit": 0}
 
+    ext = None
+    if dist is not None:
+        # run torch's collectives on the library's own HIP stream: kernels and all-reduces are
+        # ordered by the stream, no host synchronisation inside a step
+        ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+        t_share = as_tensor(torch, prof.share_ptr(), nrefs, "<f8", dev)
+        t_purged = as_tensor(torch, prof.prop_purged_enqueue(), 1, "<i4", dev)
+
     def step():
-        nonlocal t_inc
         prof.reset()
         run.enqueue()                      # aln_stats_filter, besthit_select, scan, emit_order
         prof.accumulate(db, run.keep)      # insert_count (+ scan + compaction)
         if dist is None:
             prof.finalize_enqueue()        # <= 19 proportional iterations, no host round trip
-            st = run.finish()              # one sync per step; raises on data errors
-            state["n_emit"] = int(st.n_emit)
         else:
-            ctx.sync()
-            dist.all_reduce(t_ui)
-            dist.all_reduce(t_cnt)
-            torch.cuda.current_stream().synchronize()
-            prof.prop_begin()
-            k = 0
-            while k < 19:
-                inc_ptr = prof.prop_local()
-                if t_inc is None:
-                    t_inc = as_tensor(torch, inc_ptr, nrefs, "<f8", dev)
-                ctx.sync()
-                dist.all_reduce(t_inc)
-                torch.cuda.current_stream().synchronize()
-                delta = prof.prop_apply()
-                k += 1
-                if delta < 1e-10:
-                    break
-            t_purged[0] = prof.prop_purged()
-            dist.all_reduce(t_purged)
-            torch.cuda.current_stream().synchronize()
-            state["iters"] = k
-            st = run.finish()
-            state["n_emit"] = int(st.n_emit)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t_ui)          # exact (integer)
+                dist.all_reduce(t_cnt)
+                prof.prop_begin()
+                for _ in range(19):            # msam_profile.c:331; no-ops after convergence
+                    prof.prop_local()
+                    dist.all_reduce(t_share)
+                    prof.prop_apply_enqueue()
+                prof.prop_purged_enqueue()
+                dist.all_reduce(t_purged)
+        st = run.finish()                  # one sync per step; raises on data errors
+        state["n_emit"] = int(st.n_emit)
 
     def barrier():
         ctx.sync()
@@ -242,7 +235,7 @@ def main():
                         "inputs resident in HBM",
             "alignments_per_gpu": n, "qname_groups_per_gpu": ng, "references": nrefs,
             "alignments_kept_rank0": state["n_emit"],
-            "prop_iterations": int(pst.iterations) if dist is None else state["iters"],
+            "prop_iterations": int(pst.iterations),
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
     }
@@ -252,7 +245,7 @@ def main():
         out["checksum"] = {"abundance_sum": float(ab.sum()), "abundance_sha1_6dp": hashlib.sha1(
             np.round(ab, 6).tobytes()).hexdigest(), "inserts": int(pst.insert_count), "uniq": int(pst.uniq_mapper_count),
             "multi": int(pst.multi_mapper_count), "purged": int(pst.purged_insert_count),
-            "iterations": int(pst.iterations) if dist is None else state["iters"]}
+            "iterations": int(pst.iterations)}
 
     # ---- roofline of the dominant kernel (HIP events on the library's stream) ----
     if rank == 0 and not args.no_roofline:

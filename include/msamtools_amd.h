@@ -215,6 +215,17 @@ int  msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui,
  *            *delta receives DELTA^2 (host); identical on every rank
  *   purged : this rank's multi-mappers whose features sum to 0   :394-404
  */
+/* Fully asynchronous form (no host round trip per iteration; used by bench.py
+ * with RCCL running on the ctx stream): call local/apply_enqueue 19 times
+ * unconditionally -- a device-side flag turns the launches after convergence
+ * into no-ops, and every rank sees the same flag because it sees the same
+ * all-reduced `share`.  purged_enqueue leaves this rank's count in a device
+ * word (*purged_dev, u32) for a final all-reduce; msx_profile_fetch() then
+ * returns iterations / converged / delta[]. */
+int  msx_profile_prop_apply_enqueue(msx_ctx *ctx, msx_profile *p);
+/* device pointer of the per-iteration all-reduce vector (f64[n_features]); fixed for the profile's lifetime */
+int  msx_profile_share_dev(msx_ctx *ctx, msx_profile *p, double **share);
+int  msx_profile_prop_purged_enqueue(msx_ctx *ctx, msx_profile *p, uint32_t **purged_dev);
 int  msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p);
 int  msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc);
 int  msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delta);

@@ -89,6 +89,9 @@ SYMBOLS = {
     "msx_profile_prop_local": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "msx_profile_prop_apply": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "msx_profile_prop_purged": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
+    "msx_profile_prop_apply_enqueue": (C.c_int, [_P, _P]),
+    "msx_profile_share_dev": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "msx_profile_prop_purged_enqueue": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "msx_profile_finalize": (C.c_int, [_P, _P, _P, C.POINTER(ProfileStats)]),
     "msx_profile_finalize_enqueue": (C.c_int, [_P, _P]),
     "msx_profile_fetch": (C.c_int, [_P, _P, _P, C.POINTER(ProfileStats)]),

@@ -363,6 +363,20 @@ class Profile:
         self.ctx.check(self.ctx.lib.msx_profile_prop_apply(self.ctx.h, self.h, C.byref(d)))
         return d.value
 
+    def share_ptr(self):
+        """Device pointer of the vector all-reduced per iteration (valid after create)."""
+        inc = C.c_void_p()
+        self.ctx.check(self.ctx.lib.msx_profile_share_dev(self.ctx.h, self.h, C.byref(inc)))
+        return inc.value
+
+    def prop_apply_enqueue(self):
+        self.ctx.check(self.ctx.lib.msx_profile_prop_apply_enqueue(self.ctx.h, self.h))
+
+    def prop_purged_enqueue(self):
+        d = C.c_void_p()
+        self.ctx.check(self.ctx.lib.msx_profile_prop_purged_enqueue(self.ctx.h, self.h, C.byref(d)))
+        return d.value
+
     def prop_purged(self):
         v = C.c_uint32(0)
         self.ctx.check(self.ctx.lib.msx_profile_prop_purged(self.ctx.h, self.h, C.byref(v)))

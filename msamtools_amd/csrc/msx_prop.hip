@@ -608,6 +608,31 @@ extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delt
 	return MSX_OK;
 }
 
+extern "C" int msx_profile_share_dev(msx_ctx *ctx, msx_profile *p, double **share) {
+	if (!ctx || !p || !share) return MSX_ERR_ARG;
+	*share = p->share;
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_apply_enqueue(msx_ctx *ctx, msx_profile *p) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply_enqueue before msx_profile_prop_begin");
+	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
+	p->iter_k++;
+	msx_prop_apply_launch(ctx, p, p->iter_k);
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_purged_enqueue(msx_ctx *ctx, msx_profile *p, uint32_t **purged_dev) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
+	msx_prop_purged_launch(ctx, p, p->purged_local);
+	if (purged_dev) *purged_dev = p->purged_local;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
 extern "C" int msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *purged_local) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
