@@ -14,6 +14,7 @@
 
 #include <getopt.h>
 #include <math.h>
+#include <time.h>
 #include <zlib.h>
 
 #define QNAME_GROUP_CHECK_RECORDS 10000      /* msam_helper.c:4-6 */
@@ -21,6 +22,16 @@
 #define COORD_ORDER_MIN_RECORDS 10000
 
 static msx_ctx *g_ctx;
+
+/* stage timers, printed to stderr when MSX_TIMING is set */
+static double now_s(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static double t_decode, t_upload, t_gpu, t_fetch, t_write;
+#define TIC double t0_ = now_s()
+#define TOC(acc) do { double t1_ = now_s(); (acc) += t1_ - t0_; t0_ = t1_; } while (0)
 
 static void ctx_open(void) {
 	const char *dev = getenv("MSX_DEVICE");
@@ -457,7 +468,11 @@ int msam_filter_main(int argc, char *argv[]) {
 	hdr = msh_header(rd.in);
 
 	/* first batch: large enough for the preflight window */
-	fill_filter_batch(&rd, &b, target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS, pools, want_stats);
+	{
+		TIC;
+		fill_filter_batch(&rd, &b, target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS, pools, want_stats);
+		TOC(t_decode);
+	}
 	if (pools) qn = qn_check(hdr, &b);                                /* :478-482 */
 	ctx_open();
 	qn_format(&qn, qmsg, sizeof qmsg);
@@ -475,8 +490,10 @@ int msam_filter_main(int argc, char *argv[]) {
 			void *d_keep, *d_emit, *d_as = NULL;
 			size_t i;
 			int rc;
+			TIC;
 			rb_host_view(&b, &hb, pools);
 			MSX(msx_batch_upload(g_ctx, &hb, &db));
+			TOC(t_upload);
 			MSX(msx_dev_alloc(g_ctx, &d_keep, b.n));
 			MSX(msx_dev_alloc(g_ctx, &d_emit, 4 * b.n));
 			if (fp.rescore) MSX(msx_dev_alloc(g_ctx, &d_as, 4 * b.n));
@@ -484,6 +501,7 @@ int msam_filter_main(int argc, char *argv[]) {
 			MSX(msx_filter_enqueue(g_ctx, &db, &fp, &fo));
 			rc = msx_filter_finish(g_ctx, &st);
 			if (rc != MSX_OK) mDie("%s", msx_last_error(g_ctx));      /* the reference's own mDie texts */
+			TOC(t_gpu);
 			if ((size_t)st.n_emit > emit_cap || !emit) {
 				emit_cap = (size_t)st.n_emit + 1024;
 				emit = (int32_t *)realloc(emit, emit_cap * 4);
@@ -493,6 +511,7 @@ int msam_filter_main(int argc, char *argv[]) {
 				as_out = (int32_t *)realloc(as_out, 4 * b.n);
 				MSX(msx_dev_to_host(g_ctx, as_out, d_as, 4 * b.n));
 			}
+			TOC(t_fetch);
 			for (i = 0; i < (size_t)st.n_emit; i++) {
 				size_t k = (size_t)emit[i];
 				const uint8_t *r = (const uint8_t *)b.blob.s + b.rec_off[k];
@@ -504,15 +523,23 @@ int msam_filter_main(int argc, char *argv[]) {
 					msh_write(out, r, len);
 				}
 			}
+			TOC(t_write);
 			msx_dev_free(g_ctx, d_keep);
 			msx_dev_free(g_ctx, d_emit);
 			msx_dev_free(g_ctx, d_as);
 			msx_batch_free(g_ctx, &db);
 		}
 		if (rd.eof && !rd.have_pending) break;
-		fill_filter_batch(&rd, &b, target, pools, want_stats);
+		{
+			TIC;
+			fill_filter_batch(&rd, &b, target, pools, want_stats);
+			TOC(t_decode);
+		}
 	}
 	msh_out_close(out);
+	if (getenv("MSX_TIMING"))
+		fprintf(stderr, "# filter stages: decode+pack %.3f s, upload %.3f s, gpu %.3f s, fetch %.3f s, write %.3f s\n",
+		        t_decode, t_upload, t_gpu, t_fetch, t_write);
 	msh_close(rd.in);
 	msx_ctx_destroy(g_ctx);
 	free(cl);
