@@ -79,11 +79,25 @@ const msh_hdr *msh_header(msh_in *in);
 int msh_read(msh_in *in, kstr *rec);            /* 0 = record in rec (l = length), -1 = EOF */
 void msh_close(msh_in *in);
 
+/* bulk access for BAM input: a contiguous span of inflated bytes holding whole records
+ * (each with its 4-byte block_size prefix) and possibly one trailing partial record */
+int msh_is_bam(const msh_in *in);
+int msh_span_fill(msh_in *in);                        /* inflate the next batch of blocks; 0 at EOF */
+const uint8_t *msh_span(msh_in *in, size_t *len);     /* unconsumed bytes; invalidated by msh_span_fill */
+void msh_span_consume(msh_in *in, size_t n);
+
+/* ---- threads ------------------------------------------------------------------ */
+int msh_threads(void);                                 /* MSX_THREADS or the online CPU count, <= 64 */
+typedef void (*msh_pf)(void *arg, int tid, int nth);
+void msh_parallel(int nth, msh_pf fn, void *arg);      /* fn(arg, tid, nth) on nth threads */
+
 /* ---- output ------------------------------------------------------------------ */
 enum { MSH_OUT_SAM = 0, MSH_OUT_SAM_HDR = 1, MSH_OUT_BAM = 2, MSH_OUT_UBAM = 3 };
 typedef struct msh_out msh_out;
 msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text);
 void msh_write(msh_out *o, const uint8_t *rec, size_t len);
+/* records base + rec_off[idx[k]] (+4 = past the block_size prefix), k = 0..n-1; multi-threaded */
+void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, const int32_t *idx, size_t n);
 void msh_out_close(msh_out *o);
 
 /* SAM text <-> BAM record */

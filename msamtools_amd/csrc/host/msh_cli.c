@@ -65,8 +65,11 @@ static char *command_line(int argc, char *argv[]) {
 /* ------------------------------------------------------------------------ */
 typedef struct {
 	size_t n, cap;
-	kstr blob;                 /* record bytes back to back  */
-	size_t *rec_off;           /* [n+1]                      */
+	kstr blob;                 /* SAM-text path: [block_size | record] back to back          */
+	const uint8_t *base;       /* records live at base + rec_off[i] + 4 (blob or the BAM span) */
+	size_t *rec_off;           /* [n+1] offsets of the block_size fields                     */
+	uint32_t *md_rel;          /* bulk path scratch: offset of the MD string inside the record */
+	uint8_t *bound;            /* bulk path scratch: record starts a pool                    */
 	uint16_t *flag;
 	uint8_t *rflags;
 	int32_t *tid, *pos, *nm, *as;
@@ -88,6 +91,9 @@ static void rb_reserve(rbatch *b) {
 		b->as = (int32_t *)realloc(b->as, c * 4);
 		b->cigar_off = (uint32_t *)realloc(b->cigar_off, (c + 1) * 4);
 		b->md_off = (uint32_t *)realloc(b->md_off, (c + 1) * 4);
+		b->md_rel = (uint32_t *)realloc(b->md_rel, c * 4);
+		b->bound = (uint8_t *)realloc(b->bound, c);
+		if (!b->md_rel || !b->bound) mDie("Out of memory");
 		if (!b->rec_off || !b->flag || !b->rflags || !b->tid || !b->pos || !b->nm || !b->as || !b->cigar_off || !b->md_off)
 			mDie("Out of memory");
 		b->cap = c;
@@ -104,6 +110,9 @@ static void rb_clear(rbatch *b) {
 	b->md_off[0] = 0;
 }
 
+#define RB_REC(b, i) ((b)->base + (b)->rec_off[i] + 4)
+#define RB_LEN(b, i) ((b)->rec_off[(i) + 1] - (b)->rec_off[i] - 4)
+
 static void rb_mark_group(rbatch *b) {   /* a pool starts at the record about to be appended */
 	if (b->n_groups + 2 > b->group_cap) {
 		b->group_cap = b->group_cap ? b->group_cap * 2 : 65536;
@@ -119,7 +128,12 @@ static void rb_append(rbatch *b, const uint8_t *r, size_t len, int want_stats) {
 	uint32_t nc = REC_NCIGAR(r);
 	const uint8_t *p, *end = r + len, *md = NULL, *nm = NULL, *as = NULL;
 	rb_reserve(b);
+	{
+		uint8_t b4[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+		ks_put(&b->blob, b4, 4);
+	}
 	ks_put(&b->blob, r, len);
+	b->base = (const uint8_t *)b->blob.s;
 	b->rec_off[i + 1] = b->blob.l;
 	b->flag[i] = (uint16_t)REC_FLAG(r);
 	b->tid[i] = REC_TID(r);
@@ -229,7 +243,7 @@ static qn_result qn_check(const msh_hdr *hdr, const rbatch *first) {
 	tab = (qn_slot *)calloc(cap, sizeof(qn_slot));
 	limit = first->n < COORD_ORDER_CHECK_RECORDS ? first->n : COORD_ORDER_CHECK_RECORDS;
 	for (i = 0; i < limit; i++) {
-		const uint8_t *r = (const uint8_t *)first->blob.s + first->rec_off[i];
+		const uint8_t *r = RB_REC(first, i);
 		const char *q = REC_QNAME(r);
 		size_t recno = i + 1;
 		res.input_records_checked++;
@@ -312,6 +326,9 @@ typedef struct {
 	/* R5 grouping state (msam_filter.c:107,117-125,170) */
 	char prev_read[256];
 	int have_prev;
+	/* bulk (BAM) path */
+	size_t consume_pending;      /* span bytes used by the batch being processed */
+	int done;
 } reader;
 
 /* Fill `b` with up to `target` records; with pools, stop at the first pool
@@ -343,6 +360,161 @@ static void fill_filter_batch(reader *rd, rbatch *b, size_t target, int pools, i
 		rb_append(b, r, rd->rec.l, want_stats);
 		rd->have_pending = 0;
 	}
+}
+
+/* ---- bulk path for BAM input ---------------------------------------------------
+ * The inflated BAM bytes form one contiguous span; record boundaries are found
+ * with one cheap serial walk, everything else (aux scan for MD/NM/AS, pool
+ * boundaries, SoA fill) runs on all host threads.  A batch ends at the last pool
+ * boundary of the scanned records; the open pool stays in the span.
+ * mode: 0 = no pools (plain -l/-p/-z), 1 = filter pools (msam_filter.c:120-125,
+ * 170), 2 = profile pools (msam_profile.c:223-232). */
+typedef struct {
+	rbatch *b;
+	const uint8_t *base;
+	size_t n;
+	int mode, want_stats;
+	const char *carry_name;      /* QNAME of the last mapped / tid != -1 record of earlier batches */
+} pack_job;
+
+static void pack_scan(void *arg, int tid, int nth) {
+	pack_job *J = (pack_job *)arg;
+	rbatch *b = J->b;
+	size_t lo = J->n * (size_t)tid / (size_t)nth, hi = J->n * (size_t)(tid + 1) / (size_t)nth, i;
+	for (i = lo; i < hi; i++) {
+		const uint8_t *r = J->base + b->rec_off[i] + 4;
+		size_t len = b->rec_off[i + 1] - b->rec_off[i] - 4;
+		const uint8_t *p, *end = r + len, *md = NULL, *nm = NULL, *as = NULL;
+		uint8_t bd = 0;
+		b->flag[i] = (uint16_t)REC_FLAG(r);
+		b->tid[i] = REC_TID(r);
+		b->pos[i] = REC_POS(r);
+		for (p = REC_AUX(r); p + 3 <= end; p += 2 + msh_aux_size(p + 2, end)) {
+			if (p[0] == 'M' && p[1] == 'D' && !md) md = p + 2;
+			else if (p[0] == 'N' && p[1] == 'M' && !nm) nm = p + 2;
+			else if (p[0] == 'A' && p[1] == 'S' && !as) as = p + 2;
+		}
+		b->rflags[i] = (uint8_t)((md ? MSX_HAS_MD : 0) | (nm ? MSX_HAS_NM : 0) | (as ? MSX_HAS_AS : 0));
+		b->nm[i] = nm ? (int32_t)msh_aux2i(nm) : 0;
+		b->as[i] = as ? (int32_t)msh_aux2i(as) : 0;
+		if (J->want_stats) {
+			size_t ml = (md && *md == 'Z') ? strlen((const char *)md + 1) : 0;
+			b->cigar_off[i + 1] = REC_NCIGAR(r);           /* counts; prefix-summed afterwards */
+			b->md_off[i + 1] = (uint32_t)ml;
+			b->md_rel[i] = ml ? (uint32_t)(md + 1 - r) : 0;
+		} else {
+			b->cigar_off[i + 1] = 0;
+			b->md_off[i + 1] = 0;
+		}
+		if (J->mode == 1 || (J->mode == 2 && REC_TID(r) != -1)) {
+			/* QNAME of the nearest earlier record that counts for the rule */
+			const char *pn = NULL;
+			size_t j = i;
+			while (j > 0) {
+				const uint8_t *pr = J->base + b->rec_off[j - 1] + 4;
+				if (J->mode == 1 ? !(REC_FLAG(pr) & 4) : (REC_TID(pr) != -1)) { pn = REC_QNAME(pr); break; }
+				j--;
+			}
+			if (!pn) pn = J->carry_name;
+			bd = (pn && strcmp(REC_QNAME(r), pn) != 0) ? 1 : 0;
+		}
+		b->bound[i] = bd;
+	}
+}
+
+static void pack_copy(void *arg, int tid, int nth) {
+	pack_job *J = (pack_job *)arg;
+	rbatch *b = J->b;
+	size_t lo = J->n * (size_t)tid / (size_t)nth, hi = J->n * (size_t)(tid + 1) / (size_t)nth, i;
+	for (i = lo; i < hi; i++) {
+		const uint8_t *r = J->base + b->rec_off[i] + 4;
+		uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i], ml = b->md_off[i + 1] - b->md_off[i];
+		if (nc) memcpy(b->cigar + b->cigar_off[i], REC_CIGAR(r), 4 * (size_t)nc);
+		if (ml) memcpy(b->md + b->md_off[i], r + b->md_rel[i], ml);
+	}
+}
+
+static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int want_stats) {
+	msh_in *in = rd->in;
+	size_t len = 0, off = 0, n = 0, n_batch, i;
+	const uint8_t *span;
+	pack_job J;
+	if (rd->consume_pending) { msh_span_consume(in, rd->consume_pending); rd->consume_pending = 0; }
+	b->n = 0;
+	b->n_groups = 0;
+	for (;;) {
+		/* 1. record boundaries (serial: a pointer chase over block_size fields) */
+		for (;;) {
+			span = msh_span(in, &len);
+			while (off + 4 <= len) {
+				int32_t bs = le32(span + off);
+				if (bs < 32) mDie("Corrupt BAM record (block_size %d)", bs);
+				if (off + 4 + (size_t)bs > len) break;
+				b->n = n;
+				rb_reserve(b);
+				b->rec_off[n++] = off;
+				off += 4 + (size_t)bs;
+			}
+			if (n > target || rd->eof) break;
+			if (!msh_span_fill(in)) rd->eof = 1;
+		}
+		if (rd->eof && off != len) mDie("Truncated BAM record");
+		b->n = n;
+		rb_reserve(b);
+		b->rec_off[n] = off;
+		if (n == 0) { rd->done = 1; b->n = 0; return; }
+		/* 2. parallel: aux scan, SoA scalars, pool boundaries */
+		J.b = b; J.base = span; J.n = n; J.mode = mode; J.want_stats = want_stats;
+		J.carry_name = rd->have_prev ? rd->prev_read : NULL;
+		msh_parallel(msh_threads(), pack_scan, &J);
+		/* 3. where the batch ends: the last pool boundary (the open pool waits for more data) */
+		n_batch = n;
+		if (mode != 0 && !rd->eof) {
+			size_t k = n;
+			while (k > 1 && !b->bound[k - 1]) k--;
+			n_batch = k - 1;
+			if (n_batch == 0) {          /* one pool fills the whole span: read more */
+				target = n + target;
+				if (!msh_span_fill(in)) rd->eof = 1;
+				continue;
+			}
+		}
+		break;
+	}
+	/* 4. offsets and pools (serial prefix sums, a few ms per million records) */
+	b->cigar_off[0] = 0;
+	b->md_off[0] = 0;
+	for (i = 0; i < n_batch; i++) {
+		b->cigar_off[i + 1] += b->cigar_off[i];
+		b->md_off[i + 1] += b->md_off[i];
+	}
+	if (mode != 0) {
+		b->n = 0;
+		rb_mark_group(b);
+		for (i = 1; i < n_batch; i++)
+			if (b->bound[i]) { b->n = i; rb_mark_group(b); }
+	}
+	if (want_stats) {
+		size_t nc = b->cigar_off[n_batch], nm = b->md_off[n_batch];
+		if (nc + 4 > b->cigar_cap) { b->cigar_cap = nc + nc / 4 + 1024; b->cigar = (uint32_t *)realloc(b->cigar, b->cigar_cap * 4); }
+		if (nm + 16 > b->md_cap) { b->md_cap = nm + nm / 4 + 4096; b->md = (uint8_t *)realloc(b->md, b->md_cap); }
+		if (!b->cigar || !b->md) mDie("Out of memory");
+		J.n = n_batch;
+		msh_parallel(msh_threads(), pack_copy, &J);
+	}
+	b->n = n_batch;
+	b->base = span;
+	/* carry the grouping state into the next batch */
+	for (i = n_batch; i > 0; i--) {
+		const uint8_t *r = span + b->rec_off[i - 1] + 4;
+		if (mode == 2 ? (REC_TID(r) != -1) : !(REC_FLAG(r) & 4)) {
+			strcpy(rd->prev_read, REC_QNAME(r));
+			rd->have_prev = 1;
+			break;
+		}
+	}
+	rd->consume_pending = b->rec_off[n_batch];
+	if (rd->eof && n_batch == n) rd->done = 1;
 }
 
 /* --rescore: drop the first AS and append AS:i (msam_filter.c:162-167) */
@@ -383,7 +555,7 @@ int msam_filter_main(int argc, char *argv[]) {
 	kstr htext = {0, 0, 0}, tmp = {0, 0, 0};
 	const msh_hdr *hdr;
 	msh_out *out;
-	int mode, pools, want_stats, choice;
+	int mode, pools, want_stats, choice, bulk;
 	size_t target = batch_target();
 	int32_t *emit = NULL, *as_out = NULL;
 	size_t emit_cap = 0;
@@ -468,9 +640,12 @@ int msam_filter_main(int argc, char *argv[]) {
 	hdr = msh_header(rd.in);
 
 	/* first batch: large enough for the preflight window */
+	bulk = msh_is_bam(rd.in);
 	{
+		size_t t1 = target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS;
 		TIC;
-		fill_filter_batch(&rd, &b, target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS, pools, want_stats);
+		if (bulk) fill_batch_bulk(&rd, &b, t1, pools ? 1 : 0, want_stats);
+		else fill_filter_batch(&rd, &b, t1, pools, want_stats);
 		TOC(t_decode);
 	}
 	if (pools) qn = qn_check(hdr, &b);                                /* :478-482 */
@@ -512,10 +687,14 @@ int msam_filter_main(int argc, char *argv[]) {
 				MSX(msx_dev_to_host(g_ctx, as_out, d_as, 4 * b.n));
 			}
 			TOC(t_fetch);
+			if (!fp.rescore) {
+				msh_write_many(out, b.base, b.rec_off, emit, (size_t)st.n_emit);
+				st.n_emit = 0;          /* nothing left for the per-record loop */
+			}
 			for (i = 0; i < (size_t)st.n_emit; i++) {
 				size_t k = (size_t)emit[i];
-				const uint8_t *r = (const uint8_t *)b.blob.s + b.rec_off[k];
-				size_t len = b.rec_off[k + 1] - b.rec_off[k];
+				const uint8_t *r = RB_REC(&b, k);
+				size_t len = RB_LEN(&b, k);
 				if (fp.rescore && !(b.flag[k] & 4)) {
 					rescore_record(r, len, as_out[k], &tmp);
 					msh_write(out, (const uint8_t *)tmp.s, tmp.l);
@@ -529,10 +708,11 @@ int msam_filter_main(int argc, char *argv[]) {
 			msx_dev_free(g_ctx, d_as);
 			msx_batch_free(g_ctx, &db);
 		}
-		if (rd.eof && !rd.have_pending) break;
+		if (bulk ? rd.done : (rd.eof && !rd.have_pending)) break;
 		{
 			TIC;
-			fill_filter_batch(&rd, &b, target, pools, want_stats);
+			if (bulk) fill_batch_bulk(&rd, &b, target, pools ? 1 : 0, want_stats);
+			else fill_filter_batch(&rd, &b, target, pools, want_stats);
 			TOC(t_decode);
 		}
 	}
@@ -655,6 +835,7 @@ int msam_profile_main(int argc, char *argv[]) {
 	int have_prev = 0, eof = 0, have_pending = 0, first = 1;
 	size_t target = batch_target();
 	gzFile gz;
+	static reader prof_rd;
 
 	opterr = 0;
 	optind = 1;
@@ -735,6 +916,14 @@ int msam_profile_main(int argc, char *argv[]) {
 	memset(&qn, 0, sizeof qn);
 	for (;;) {
 		size_t tgt = first && target < COORD_ORDER_CHECK_RECORDS ? COORD_ORDER_CHECK_RECORDS : target;
+		if (msh_is_bam(in)) {
+			reader *prd = &prof_rd;
+			prd->in = in;
+			fill_batch_bulk(prd, &b, tgt, 2, 0);
+			eof = prd->done;
+			have_pending = 0;
+			goto batch_ready;
+		}
 		rb_clear(&b);
 		rb_mark_group(&b);
 		for (;;) {
@@ -753,6 +942,7 @@ int msam_profile_main(int argc, char *argv[]) {
 			rb_append(&b, r, rec.l, 0);
 			have_pending = 0;
 		}
+batch_ready:
 		if (first) {
 			qn = qn_check(hdr, &b);                                   /* :708, always for profile */
 			first = 0;

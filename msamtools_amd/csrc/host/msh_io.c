@@ -280,26 +280,64 @@ int64_t msh_aux2i(const uint8_t *s) {
 }
 
 /* ------------------------------------------------------------------------ */
-/* BGZF reader with batched, multi-threaded inflate                           */
+/* threads                                                                    */
+/* ------------------------------------------------------------------------ */
+int msh_threads(void) {
+	static int cached = 0;
+	if (!cached) {
+		const char *e = getenv("MSX_THREADS");
+		long n = e ? strtol(e, NULL, 10) : sysconf(_SC_NPROCESSORS_ONLN);
+		if (n < 1) n = 1;
+		if (n > 64) n = 64;
+		cached = (int)n;
+	}
+	return cached;
+}
+
+typedef struct {
+	msh_pf fn;
+	void *arg;
+	int tid, nth;
+} pf_job;
+
+static void *pf_thunk(void *p) {
+	pf_job *j = (pf_job *)p;
+	j->fn(j->arg, j->tid, j->nth);
+	return NULL;
+}
+
+void msh_parallel(int nth, msh_pf fn, void *arg) {
+	pthread_t th[64];
+	pf_job job[64];
+	int i;
+	if (nth > 64) nth = 64;
+	if (nth <= 1) { fn(arg, 0, 1); return; }
+	for (i = 1; i < nth; i++) {
+		job[i].fn = fn; job[i].arg = arg; job[i].tid = i; job[i].nth = nth;
+		if (pthread_create(&th[i], NULL, pf_thunk, &job[i]) != 0) mDie("pthread_create failed");
+	}
+	fn(arg, 0, nth);
+	for (i = 1; i < nth; i++) pthread_join(th[i], NULL);
+}
+
+/* ------------------------------------------------------------------------ */
+/* BGZF reader: batches of raw blocks inflated in parallel into one           */
+/* contiguous "span" of BAM bytes                                             */
 /* ------------------------------------------------------------------------ */
 #define BGZF_MAX 65536
-#define BGZF_BATCH 128
+#define BGZF_BATCH 256
 
 typedef struct {
 	FILE *fp;
 	uint8_t *cbuf;                       /* BGZF_BATCH compressed blocks back to back   */
 	size_t coff[BGZF_BATCH + 1];
-	uint8_t *ubuf;                       /* BGZF_BATCH * 64 KiB inflated                 */
-	uint32_t ulen[BGZF_BATCH];
-	int nblk, cur;                       /* blocks in the batch, block being consumed    */
-	uint32_t upos;                       /* offset in the current block                  */
-	int eof, nthreads;
+	size_t uoff[BGZF_BATCH + 1];         /* where each block inflates to, relative to dst */
+	uint8_t *dst;
+	int nblk, eof;
+	/* the span: inflated, not yet consumed bytes */
+	uint8_t *span;
+	size_t span_beg, span_end, span_cap;
 } bgz_in;
-
-typedef struct {
-	bgz_in *b;
-	int first, step;
-} bgz_job;
 
 static void inflate_block(bgz_in *b, int i) {
 	const uint8_t *c = b->cbuf + b->coff[i];
@@ -307,50 +345,38 @@ static void inflate_block(bgz_in *b, int i) {
 	uint32_t xlen = le16(c + 10);
 	const uint8_t *data = c + 12 + xlen;
 	size_t dlen = clen - 12 - xlen - 8;
-	uint32_t isize = (uint32_t)le32(c + clen - 4);
+	uint32_t isize = (uint32_t)(b->uoff[i + 1] - b->uoff[i]);
+	uint8_t *out = b->dst + b->uoff[i];
 	z_stream zs;
+	if (isize == 0) return;
 	memset(&zs, 0, sizeof zs);
-	if (isize > BGZF_MAX) mDie("Corrupt BGZF block (ISIZE %u)", isize);
 	zs.next_in = (Bytef *)data;
 	zs.avail_in = (uInt)dlen;
-	zs.next_out = b->ubuf + (size_t)i * BGZF_MAX;
-	zs.avail_out = BGZF_MAX;
+	zs.next_out = out;
+	zs.avail_out = isize;
 	if (inflateInit2(&zs, -15) != Z_OK) mDie("zlib inflateInit2 failed");
-	if (isize && inflate(&zs, Z_FINISH) != Z_STREAM_END) mDie("Corrupt BGZF block (inflate failed)");
+	if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize) mDie("Corrupt BGZF block (inflate failed)");
 	inflateEnd(&zs);
-	if (isize && zs.total_out != isize) mDie("Corrupt BGZF block (size mismatch)");
-	if ((uint32_t)crc32(crc32(0L, NULL, 0), b->ubuf + (size_t)i * BGZF_MAX, isize) != (uint32_t)le32(c + clen - 8))
+	if ((uint32_t)crc32(crc32(0L, NULL, 0), out, isize) != (uint32_t)le32(c + clen - 8))
 		mDie("Corrupt BGZF block (CRC mismatch)");
-	b->ulen[i] = isize;
 }
 
-static void *inflate_worker(void *arg) {
-	bgz_job *j = (bgz_job *)arg;
+static void inflate_worker(void *arg, int tid, int nth) {
+	bgz_in *b = (bgz_in *)arg;
 	int i;
-	for (i = j->first; i < j->b->nblk; i += j->step) inflate_block(j->b, i);
-	return NULL;
+	for (i = tid; i < b->nblk; i += nth) inflate_block(b, i);
 }
 
-static int host_threads(void) {
-	const char *e = getenv("MSX_THREADS");
-	long n = e ? strtol(e, NULL, 10) : sysconf(_SC_NPROCESSORS_ONLN);
-	if (n < 1) n = 1;
-	if (n > 32) n = 32;
-	return (int)n;
-}
-
-/* read the next batch of raw blocks and inflate them; returns 0 at EOF */
+/* read the next batch of raw blocks and append their inflated bytes to the span; 0 at EOF */
 static int bgz_fill(bgz_in *b) {
-	size_t off = 0;
-	int t;
+	size_t off = 0, total = 0;
 	b->nblk = 0;
-	b->cur = 0;
-	b->upos = 0;
 	if (b->eof) return 0;
+	b->uoff[0] = 0;
 	while (b->nblk < BGZF_BATCH) {
 		uint8_t *h = b->cbuf + off;
 		size_t got = fread(h, 1, 18, b->fp);
-		uint32_t bsize;
+		uint32_t bsize, isize;
 		if (got == 0) { b->eof = 1; break; }
 		if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
 			mDie("Input is not BGZF-compressed BAM (bad block header)");
@@ -359,63 +385,54 @@ static int bgz_fill(bgz_in *b) {
 			if (xlen == 6 && h[12] == 'B' && h[13] == 'C') {
 				bsize = le16(h + 16) + 1;
 			} else {
-				uint8_t extra[65536];
 				uint32_t p = 0;
 				int found = 0;
-				memcpy(extra, h + 12, 6);
-				if (xlen > 6 && fread(extra + 6, 1, xlen - 6, b->fp) != xlen - 6) mDie("Truncated BGZF block");
-				memcpy(h + 12, extra, xlen);
+				if (xlen > 6 && fread(h + 18, 1, xlen - 6, b->fp) != xlen - 6) mDie("Truncated BGZF block");
 				bsize = 0;
 				while (p + 4 <= xlen) {
-					uint32_t sl = le16(extra + p + 2);
-					if (extra[p] == 'B' && extra[p + 1] == 'C' && sl == 2) { bsize = le16(extra + p + 4) + 1; found = 1; }
+					uint32_t sl = le16(h + 12 + p + 2);
+					if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) { bsize = le16(h + 12 + p + 4) + 1; found = 1; }
 					p += 4 + sl;
 				}
 				if (!found) mDie("BGZF block without BC subfield");
 				got = 12 + xlen;
 			}
 		}
-		if (bsize < got || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
+		if (bsize < got + 8 || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
 		if (fread(h + got, 1, bsize - got, b->fp) != bsize - got) mDie("Truncated BGZF block");
+		isize = (uint32_t)le32(h + bsize - 4);
+		if (isize > BGZF_MAX) mDie("Corrupt BGZF block (ISIZE %u)", isize);
 		b->coff[b->nblk] = off;
 		off += bsize;
+		total += isize;
 		b->nblk++;
 		b->coff[b->nblk] = off;
+		b->uoff[b->nblk] = total;
 	}
 	if (b->nblk == 0) return 0;
-	t = b->nthreads < b->nblk ? b->nthreads : b->nblk;
-	if (t <= 1) {
-		int i;
-		for (i = 0; i < b->nblk; i++) inflate_block(b, i);
-	} else {
-		pthread_t th[32];
-		bgz_job job[32];
-		int i;
-		for (i = 0; i < t; i++) {
-			job[i].b = b; job[i].first = i; job[i].step = t;
-			if (pthread_create(&th[i], NULL, inflate_worker, &job[i]) != 0) mDie("pthread_create failed");
+	/* make room: compact the unconsumed bytes to the front when that frees enough, else grow */
+	if (b->span_end + total > b->span_cap) {
+		size_t live = b->span_end - b->span_beg;
+		if (live + total > b->span_cap) {
+			size_t cap = b->span_cap ? b->span_cap : ((size_t)4 << 20);
+			uint8_t *ns;
+			while (cap < live + total) cap += cap >> 1;
+			ns = (uint8_t *)malloc(cap);
+			if (!ns) mDie("Out of memory");
+			if (live) memcpy(ns, b->span + b->span_beg, live);
+			free(b->span);
+			b->span = ns;
+			b->span_cap = cap;
+		} else if (live) {
+			memmove(b->span, b->span + b->span_beg, live);
 		}
-		for (i = 0; i < t; i++) pthread_join(th[i], NULL);
+		b->span_beg = 0;
+		b->span_end = live;
 	}
+	b->dst = b->span + b->span_end;
+	msh_parallel(msh_threads() < b->nblk ? msh_threads() : b->nblk, inflate_worker, b);
+	b->span_end += total;
 	return 1;
-}
-
-/* returns bytes copied (< n only at EOF) */
-static size_t bgz_read(bgz_in *b, void *dst, size_t n) {
-	size_t done = 0;
-	while (done < n) {
-		uint32_t avail;
-		if (b->cur >= b->nblk) {
-			if (!bgz_fill(b)) break;
-		}
-		avail = b->ulen[b->cur] - b->upos;
-		if (avail == 0) { b->cur++; b->upos = 0; continue; }
-		if (avail > n - done) avail = (uint32_t)(n - done);
-		memcpy((uint8_t *)dst + done, b->ubuf + (size_t)b->cur * BGZF_MAX + b->upos, avail);
-		b->upos += avail;
-		done += avail;
-	}
-	return done;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -661,6 +678,24 @@ struct msh_in {
 	int has_pending;
 };
 
+int msh_is_bam(const msh_in *in) { return in->is_bam; }
+
+/* ensure at least n unconsumed bytes in the span (BAM); returns 0 if EOF comes first */
+static int span_need(msh_in *in, size_t n) {
+	while (in->bz.span_end - in->bz.span_beg < n)
+		if (!bgz_fill(&in->bz)) return 0;
+	return 1;
+}
+
+int msh_span_fill(msh_in *in) { return bgz_fill(&in->bz); }
+
+const uint8_t *msh_span(msh_in *in, size_t *len) {
+	*len = in->bz.span_end - in->bz.span_beg;
+	return in->bz.span + in->bz.span_beg;
+}
+
+void msh_span_consume(msh_in *in, size_t n) { in->bz.span_beg += n; }
+
 msh_in *msh_open(const char *path) {
 	msh_in *in = (msh_in *)calloc(1, sizeof(*in));
 	int c0, c1;
@@ -674,33 +709,32 @@ msh_in *msh_open(const char *path) {
 	if (c0 != EOF) ungetc(c0, in->fp);   /* two-byte pushback works on glibc full-buffered streams */
 	in->is_bam = (c0 == 0x1f && c1 == 0x8b);
 	if (in->is_bam) {
-		uint8_t magic[8];
+		const uint8_t *p;
 		int32_t l_text, n_ref, i;
+		size_t at;
 		in->bz.fp = in->fp;
 		in->bz.cbuf = (uint8_t *)malloc((size_t)BGZF_BATCH * (BGZF_MAX + 1024));
-		in->bz.ubuf = (uint8_t *)malloc((size_t)BGZF_BATCH * BGZF_MAX);
-		in->bz.nthreads = host_threads();
-		if (!in->bz.cbuf || !in->bz.ubuf) mDie("Out of memory");
-		if (bgz_read(&in->bz, magic, 8) != 8 || memcmp(magic, "BAM\1", 4) != 0)
-			mDie("Cannot read header from %s", path);
-		l_text = le32(magic + 4);
-		ks_reserve(&in->hdr.text, (size_t)l_text + 1);
-		if (bgz_read(&in->bz, in->hdr.text.s, (size_t)l_text) != (size_t)l_text) mDie("Cannot read header from %s", path);
-		in->hdr.text.l = strnlen(in->hdr.text.s, (size_t)l_text);
-		in->hdr.text.s[in->hdr.text.l] = 0;
-		if (bgz_read(&in->bz, magic, 4) != 4) mDie("Cannot read header from %s", path);
-		n_ref = le32(magic);
+		if (!in->bz.cbuf) mDie("Out of memory");
+		if (!span_need(in, 12)) mDie("Cannot read header from %s", path);
+		p = in->bz.span + in->bz.span_beg;
+		if (memcmp(p, "BAM\1", 4) != 0) mDie("Cannot read header from %s", path);
+		l_text = le32(p + 4);
+		if (l_text < 0 || !span_need(in, 12 + (size_t)l_text)) mDie("Cannot read header from %s", path);
+		p = in->bz.span + in->bz.span_beg;
+		ks_put(&in->hdr.text, p + 8, strnlen((const char *)p + 8, (size_t)l_text));
+		n_ref = le32(p + 8 + l_text);
+		at = 12 + (size_t)l_text;
 		for (i = 0; i < n_ref; i++) {
-			uint8_t b4[4];
-			char name[65536];
 			int32_t l_name;
-			if (bgz_read(&in->bz, b4, 4) != 4) mDie("Cannot read header from %s", path);
-			l_name = le32(b4);
-			if (l_name <= 0 || l_name > 65535 || bgz_read(&in->bz, name, (size_t)l_name) != (size_t)l_name)
-				mDie("Cannot read header from %s", path);
-			if (bgz_read(&in->bz, b4, 4) != 4) mDie("Cannot read header from %s", path);
-			hdr_add_target(&in->hdr, name, strnlen(name, (size_t)l_name), (uint32_t)le32(b4));
+			if (!span_need(in, at + 4)) mDie("Cannot read header from %s", path);
+			l_name = le32(in->bz.span + in->bz.span_beg + at);
+			if (l_name <= 0 || !span_need(in, at + 8 + (size_t)l_name)) mDie("Cannot read header from %s", path);
+			p = in->bz.span + in->bz.span_beg + at;
+			hdr_add_target(&in->hdr, (const char *)p + 4, strnlen((const char *)p + 4, (size_t)l_name),
+			               (uint32_t)le32(p + 4 + l_name));
+			at += 8 + (size_t)l_name;
 		}
+		msh_span_consume(in, at);
 	} else {
 		ssize_t n;
 		while ((n = getline(&in->line, &in->line_cap, in->fp)) > 0) {
@@ -721,17 +755,17 @@ const msh_hdr *msh_header(msh_in *in) { return &in->hdr; }
 
 int msh_read(msh_in *in, kstr *rec) {
 	if (in->is_bam) {
-		uint8_t b4[4];
-		size_t got = bgz_read(&in->bz, b4, 4);
 		int32_t bs;
-		if (got == 0) return -1;
-		if (got != 4) mDie("Truncated BAM record");
-		bs = le32(b4);
+		if (!span_need(in, 4)) {
+			if (in->bz.span_end != in->bz.span_beg) mDie("Truncated BAM record");
+			return -1;
+		}
+		bs = le32(in->bz.span + in->bz.span_beg);
 		if (bs < 32) mDie("Corrupt BAM record (block_size %d)", bs);
+		if (!span_need(in, 4 + (size_t)bs)) mDie("Truncated BAM record");
 		rec->l = 0;
-		ks_reserve(rec, (size_t)bs);
-		if (bgz_read(&in->bz, rec->s, (size_t)bs) != (size_t)bs) mDie("Truncated BAM record");
-		rec->l = (size_t)bs;
+		ks_put(rec, in->bz.span + in->bz.span_beg + 4, (size_t)bs);
+		msh_span_consume(in, 4 + (size_t)bs);
 		return 0;
 	} else {
 		char *ln;
@@ -763,7 +797,7 @@ void msh_close(msh_in *in) {
 	free(in->hdr.target_len);
 	free(in->hdr.text.s);
 	free(in->bz.cbuf);
-	free(in->bz.ubuf);
+	free(in->bz.span);
 	free(in->line);
 	free(in->pending.s);
 	free(in);
@@ -783,29 +817,11 @@ struct msh_out {
 };
 #define BGZF_PAYLOAD 0xff00
 
+static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level);
+
 static void bgz_flush_block(msh_out *o) {
 	uint8_t out[BGZF_MAX + 1024];
-	z_stream zs;
-	uint32_t clen, crc, total;
-	static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-	memset(&zs, 0, sizeof zs);
-	if (deflateInit2(&zs, o->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("zlib deflateInit2 failed");
-	zs.next_in = o->ubuf;
-	zs.avail_in = o->ulen;
-	zs.next_out = out + 18;
-	zs.avail_out = sizeof out - 18 - 8;
-	if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mDie("BGZF deflate failed");
-	clen = (uint32_t)zs.total_out;
-	deflateEnd(&zs);
-	memcpy(out, head, 16);
-	total = 18 + clen + 8;
-	out[16] = (uint8_t)((total - 1) & 0xff);
-	out[17] = (uint8_t)((total - 1) >> 8);
-	crc = (uint32_t)crc32(crc32(0L, NULL, 0), o->ubuf, o->ulen);
-	out[18 + clen + 0] = (uint8_t)crc; out[18 + clen + 1] = (uint8_t)(crc >> 8);
-	out[18 + clen + 2] = (uint8_t)(crc >> 16); out[18 + clen + 3] = (uint8_t)(crc >> 24);
-	out[18 + clen + 4] = (uint8_t)o->ulen; out[18 + clen + 5] = (uint8_t)(o->ulen >> 8);
-	out[18 + clen + 6] = (uint8_t)(o->ulen >> 16); out[18 + clen + 7] = (uint8_t)(o->ulen >> 24);
+	uint32_t total = bgzf_compress(out, o->ubuf, o->ulen, o->level);
 	if (fwrite(out, 1, total, o->fp) != total) mDie("Write failed");
 	o->ulen = 0;
 }
@@ -865,6 +881,155 @@ void msh_write(msh_out *o, const uint8_t *rec, size_t len) {
 		msh_sam_format(o->hdr, rec, len, &o->line);
 		ks_putc(&o->line, '\n');
 		if (fwrite(o->line.s, 1, o->line.l, o->fp) != o->line.l) mDie("Write failed");
+	}
+}
+
+/* ---- bulk, multi-threaded writer ------------------------------------------------
+ * Writes the records base + rec_off[idx[k]] (each preceded by its 4-byte
+ * block_size, as in the BAM stream) for k = 0..n-1.  BAM: the records are packed
+ * greedily into BGZF blocks (whole records per block), blocks are deflated in
+ * parallel and written in order.  SAM: lines are formatted in parallel. */
+#define WCHUNK_BLOCKS 1024
+#define WCHUNK_LINES 262144
+
+typedef struct {
+	msh_out *o;
+	const uint8_t *base;
+	const size_t *rec_off;
+	const int32_t *idx;
+	/* BAM */
+	size_t nblk;
+	size_t *first;          /* [nblk+1] first emitted-record index of each block */
+	uint8_t *slots;         /* nblk * SLOT bytes */
+	uint32_t *slot_len;
+	/* SAM */
+	size_t lo, hi;
+	kstr *lines;            /* one per thread */
+} wjob;
+#define WSLOT (BGZF_MAX + 1024)
+
+static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level) {
+	z_stream zs;
+	uint32_t clen, crc, total;
+	static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+	memset(&zs, 0, sizeof zs);
+	if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("zlib deflateInit2 failed");
+	zs.next_in = (Bytef *)in;
+	zs.avail_in = n;
+	zs.next_out = out + 18;
+	zs.avail_out = WSLOT - 18 - 8;
+	if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mDie("BGZF deflate failed");
+	clen = (uint32_t)zs.total_out;
+	deflateEnd(&zs);
+	memcpy(out, head, 16);
+	total = 18 + clen + 8;
+	out[16] = (uint8_t)((total - 1) & 0xff);
+	out[17] = (uint8_t)((total - 1) >> 8);
+	crc = (uint32_t)crc32(crc32(0L, NULL, 0), in, n);
+	out[18 + clen + 0] = (uint8_t)crc; out[18 + clen + 1] = (uint8_t)(crc >> 8);
+	out[18 + clen + 2] = (uint8_t)(crc >> 16); out[18 + clen + 3] = (uint8_t)(crc >> 24);
+	out[18 + clen + 4] = (uint8_t)n; out[18 + clen + 5] = (uint8_t)(n >> 8);
+	out[18 + clen + 6] = (uint8_t)(n >> 16); out[18 + clen + 7] = (uint8_t)(n >> 24);
+	return total;
+}
+
+static void wbam_worker(void *arg, int tid, int nth) {
+	wjob *w = (wjob *)arg;
+	uint8_t *payload = (uint8_t *)malloc(BGZF_MAX);
+	size_t k, r;
+	if (!payload) mDie("Out of memory");
+	for (k = (size_t)tid; k < w->nblk; k += (size_t)nth) {
+		uint32_t n = 0;
+		for (r = w->first[k]; r < w->first[k + 1]; r++) {
+			size_t i = (size_t)w->idx[r], sz = w->rec_off[i + 1] - w->rec_off[i];
+			memcpy(payload + n, w->base + w->rec_off[i], sz);
+			n += (uint32_t)sz;
+		}
+		w->slot_len[k] = bgzf_compress(w->slots + k * WSLOT, payload, n, w->o->level);
+	}
+	free(payload);
+}
+
+static void wsam_worker(void *arg, int tid, int nth) {
+	wjob *w = (wjob *)arg;
+	size_t n = w->hi - w->lo, a = w->lo + n * (size_t)tid / (size_t)nth, b = w->lo + n * (size_t)(tid + 1) / (size_t)nth, r;
+	kstr *ln = &w->lines[tid];
+	ln->l = 0;
+	for (r = a; r < b; r++) {
+		size_t i = (size_t)w->idx[r];
+		msh_sam_format(w->o->hdr, w->base + w->rec_off[i] + 4, w->rec_off[i + 1] - w->rec_off[i] - 4, ln);
+		ks_putc(ln, '\n');
+	}
+}
+
+void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, const int32_t *idx, size_t n) {
+	int nth = msh_threads();
+	wjob w;
+	size_t r;
+	if (n == 0) return;
+	memset(&w, 0, sizeof w);
+	w.o = o; w.base = base; w.rec_off = rec_off; w.idx = idx;
+	if (o->mode == MSH_OUT_BAM || o->mode == MSH_OUT_UBAM) {
+		size_t done = 0;
+		for (r = 0; r < n; r++)          /* a record larger than one block: leave everything to the serial writer */
+			if (rec_off[(size_t)idx[r] + 1] - rec_off[(size_t)idx[r]] > BGZF_PAYLOAD) {
+				for (r = 0; r < n; r++) {
+					size_t i = (size_t)idx[r];
+					msh_write(o, base + rec_off[i] + 4, rec_off[i + 1] - rec_off[i] - 4);
+				}
+				return;
+			}
+		if (o->ulen) bgz_flush_block(o);
+		w.first = (size_t *)malloc((WCHUNK_BLOCKS + 2) * sizeof(size_t));
+		w.slots = (uint8_t *)malloc((size_t)WCHUNK_BLOCKS * WSLOT);
+		w.slot_len = (uint32_t *)malloc(WCHUNK_BLOCKS * sizeof(uint32_t));
+		if (!w.first || !w.slots || !w.slot_len) mDie("Out of memory");
+		while (done < n) {
+			/* plan up to WCHUNK_BLOCKS blocks of whole records */
+			size_t k = 0, cur = 0;
+			w.first[0] = done;
+			for (r = done; r < n; r++) {
+				size_t sz = rec_off[(size_t)idx[r] + 1] - rec_off[(size_t)idx[r]];
+				if (cur + sz > BGZF_PAYLOAD) {
+					w.first[++k] = r;
+					cur = 0;
+					if (k == WCHUNK_BLOCKS) break;
+				}
+				cur += sz;
+			}
+			if (k < WCHUNK_BLOCKS) {
+				/* r == n: the last, partly filled block stays in the writer's buffer */
+				size_t q;
+				w.nblk = k;
+				for (q = w.first[k]; q < n; q++) {
+					size_t i = (size_t)idx[q], sz = rec_off[i + 1] - rec_off[i];
+					memcpy(o->ubuf + o->ulen, base + rec_off[i], sz);
+					o->ulen += (uint32_t)sz;
+				}
+				done = n;
+			} else {
+				w.nblk = k;
+				done = w.first[k];
+			}
+			if (w.nblk) {
+				size_t q;
+				msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_worker, &w);
+				for (q = 0; q < w.nblk; q++)
+					if (fwrite(w.slots + q * WSLOT, 1, w.slot_len[q], o->fp) != w.slot_len[q]) mDie("Write failed");
+			}
+		}
+		free(w.first); free(w.slots); free(w.slot_len);
+	} else {
+		int t;
+		w.lines = (kstr *)calloc((size_t)nth, sizeof(kstr));
+		for (w.lo = 0; w.lo < n; w.lo = w.hi) {
+			w.hi = w.lo + WCHUNK_LINES < n ? w.lo + WCHUNK_LINES : n;
+			msh_parallel(nth, wsam_worker, &w);
+			for (t = 0; t < nth; t++)
+				if (w.lines[t].l && fwrite(w.lines[t].s, 1, w.lines[t].l, o->fp) != w.lines[t].l) mDie("Write failed");
+		}
+		for (t = 0; t < nth; t++) free(w.lines[t].s);
+		free(w.lines);
 	}
 }
 
