@@ -294,59 +294,101 @@ struct SelectArgs {
 	msx_dev_status *st;
 };
 
+// The 256 pools of a workgroup step cover one contiguous record range.  Its
+// FLAG / pool byte / AS / aux bits are staged in LDS with coalesced loads (two
+// global round trips per step instead of a dependent chain per lane), walked
+// there, and the keep codes go back through LDS as contiguous byte stores.
+// Records beyond the staging capacity are read from / written to global.
+#define BH_CAP 3072
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
+	__shared__ uint32_t s_goff[MSX_BLOCK + 1];
+	__shared__ int32_t s_as[BH_CAP];
+	__shared__ uint16_t s_flag[BH_CAP];
+	__shared__ uint8_t s_pool[BH_CAP], s_has[BH_CAP], s_keep[BH_CAP];
+	const int tid = threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
-		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
-		// (best, count) per mate class: 0 = neither bit, 1 = READ1, 2 = READ2
-		int32_t b0 = INT_MIN, b1 = INT_MIN, b2 = INT_MIN;
-		uint32_t n0 = 0, n1 = 0, n2 = 0;
-		uint32_t paired = 0;
-		uint32_t noas0 = 0xffffffffu, noas1 = 0xffffffffu, noas2 = 0xffffffffu;  // first record lacking AS
-		for (uint32_t i = s; i < e; ++i) {
+	for (int64_t gb = (int64_t)blockIdx.x * MSX_BLOCK; gb < A.n_groups; gb += stride) {
+		const int ngb = (int)((A.n_groups - gb < MSX_BLOCK) ? (A.n_groups - gb) : MSX_BLOCK);
+		if (tid <= ngb) s_goff[tid] = A.group_off[gb + tid];
+		if (tid == 0 && ngb == MSX_BLOCK) s_goff[MSX_BLOCK] = A.group_off[gb + MSX_BLOCK];
+		__syncthreads();
+		const uint32_t r0 = s_goff[0], r1 = s_goff[ngb];
+		const uint32_t len = (r1 - r0 < BH_CAP) ? r1 - r0 : BH_CAP;
+		for (uint32_t x = tid; x < len; x += MSX_BLOCK) {
+			const uint32_t i = r0 + x;
 			const uint32_t fl = A.flag[i];
-			const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-			if (!pooled) continue;
-			const uint32_t cls = fl & MSX_F_MATES;
-			paired |= cls;                                           // mBamPoolIsPaired :196-204
-			const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-			const int32_t sc = A.as[i];
-			if (cls == 0) {
-				if (!has) { if (noas0 == 0xffffffffu) noas0 = i; }
-				else if (sc > b0) { b0 = sc; n0 = 1; } else if (sc == b0) n0++;
-			} else if (cls == 0x40u) {
-				if (!has) { if (noas1 == 0xffffffffu) noas1 = i; }
-				else if (sc > b1) { b1 = sc; n1 = 1; } else if (sc == b1) n1++;
-			} else if (cls == 0x80u) {
-				if (!has) { if (noas2 == 0xffffffffu) noas2 = i; }
-				else if (sc > b2) { b2 = sc; n2 = 1; } else if (sc == b2) n2++;
-			}
+			s_flag[x] = (uint16_t)fl;
+			s_as[x] = A.as[i];
+			s_pool[x] = A.pool ? A.pool[i] : (uint8_t)((fl & MSX_F_UNMAP) ? 0 : 1);
+			s_has[x] = (uint8_t)(((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP))) ? 1 : 0);
 		}
-		// msam_filter.c:219-221: a participating record without AS is fatal
-		uint32_t bad = paired ? (noas1 < noas2 ? noas1 : noas2) : noas0;
-		if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
-		const bool w0 = !paired && n0 > 0 && (!A.unique_only || n0 == 1);   // :232-233
-		const bool w1 = paired && n1 > 0 && (!A.unique_only || n1 == 1);
-		const bool w2 = paired && n2 > 0 && (!A.unique_only || n2 == 1);
-		uint32_t cnt = 0;
-		for (uint32_t i = s; i < e; ++i) {
-			const uint32_t fl = A.flag[i];
-			const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-			uint8_t k = 0;
-			if (pooled) {
+		__syncthreads();
+		if (tid < ngb) {
+			const uint32_t s = s_goff[tid], e = s_goff[tid + 1];
+			// (best, count) per mate class: 0 = neither bit, 1 = READ1, 2 = READ2
+			int32_t b0 = INT_MIN, b1 = INT_MIN, b2 = INT_MIN;
+			uint32_t n0 = 0, n1 = 0, n2 = 0;
+			uint32_t paired = 0;
+			uint32_t noas0 = 0xffffffffu, noas1 = 0xffffffffu, noas2 = 0xffffffffu;  // first record lacking AS
+			for (uint32_t i = s; i < e; ++i) {
+				const uint32_t x = i - r0;
+				uint32_t fl, pooled, has;
+				int32_t sc;
+				if (x < len) { fl = s_flag[x]; pooled = s_pool[x]; has = s_has[x]; sc = s_as[x]; }
+				else {
+					fl = A.flag[i];
+					pooled = A.pool ? A.pool[i] : ((fl & MSX_F_UNMAP) ? 0u : 1u);
+					has = ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP))) ? 1u : 0u;
+					sc = A.as[i];
+				}
+				if (!pooled) continue;
 				const uint32_t cls = fl & MSX_F_MATES;
-				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-				const int32_t sc = A.as[i];
-				if (has) {
+				paired |= cls;                                           // mBamPoolIsPaired :196-204
+				if (cls == 0) {
+					if (!has) { if (noas0 == 0xffffffffu) noas0 = i; }
+					else if (sc > b0) { b0 = sc; n0 = 1; } else if (sc == b0) n0++;
+				} else if (cls == 0x40u) {
+					if (!has) { if (noas1 == 0xffffffffu) noas1 = i; }
+					else if (sc > b1) { b1 = sc; n1 = 1; } else if (sc == b1) n1++;
+				} else if (cls == 0x80u) {
+					if (!has) { if (noas2 == 0xffffffffu) noas2 = i; }
+					else if (sc > b2) { b2 = sc; n2 = 1; } else if (sc == b2) n2++;
+				}
+			}
+			// msam_filter.c:219-221: a participating record without AS is fatal
+			uint32_t bad = paired ? (noas1 < noas2 ? noas1 : noas2) : noas0;
+			if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
+			const bool w0 = !paired && n0 > 0 && (!A.unique_only || n0 == 1);   // :232-233
+			const bool w1 = paired && n1 > 0 && (!A.unique_only || n1 == 1);
+			const bool w2 = paired && n2 > 0 && (!A.unique_only || n2 == 1);
+			uint32_t cnt = 0;
+			for (uint32_t i = s; i < e; ++i) {
+				const uint32_t x = i - r0;
+				uint32_t fl, pooled, has;
+				int32_t sc;
+				if (x < len) { fl = s_flag[x]; pooled = s_pool[x]; has = s_has[x]; sc = s_as[x]; }
+				else {
+					fl = A.flag[i];
+					pooled = A.pool ? A.pool[i] : ((fl & MSX_F_UNMAP) ? 0u : 1u);
+					has = ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP))) ? 1u : 0u;
+					sc = A.as[i];
+				}
+				uint8_t k = 0;
+				if (pooled && has) {
+					const uint32_t cls = fl & MSX_F_MATES;
 					if (cls == 0 && w0 && sc == b0) k = 1;
 					else if (cls == 0x40u && w1 && sc == b1) k = 1;
 					else if (cls == 0x80u && w2 && sc == b2) k = 2;
 				}
+				if (x < len) s_keep[x] = k;
+				else A.keep[i] = k;
+				cnt += (k != 0);
 			}
-			A.keep[i] = k;
-			cnt += (k != 0);
+			A.gcount[gb + tid] = cnt;
 		}
-		A.gcount[g] = cnt;
+		__syncthreads();
+		for (uint32_t x = tid; x < len; x += MSX_BLOCK) A.keep[r0 + x] = s_keep[x];
 	}
 }
 
