@@ -1,6 +1,7 @@
 // msx_ctx.hip -- context, workspace, error text, timing table, raw memory helpers.
 #include "msx_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 
 thread_local std::string msx_tls_err;
@@ -68,6 +69,10 @@ extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
 	msx_ctx *ctx = new msx_ctx();
 	ctx->device = device_id;
 	ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (const char *e = getenv("MSX_BLOCKS_PER_CU")) {
+		int v = atoi(e);
+		if (v >= 1 && v <= 64) ctx->blocks_per_cu = v;
+	}
 	if (hipSetDevice(device_id) != hipSuccess ||
 	    hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipMalloc((void **)&ctx->d_status, sizeof(msx_dev_status)) != hipSuccess ||

@@ -71,6 +71,7 @@ struct msx_ctx {
 	hipStream_t stream = nullptr;
 	std::string err;
 	int num_cu = 256;
+	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
 	// workspace, grown on demand and kept
 	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, mlen, moff, tmp_fid;
 	msx_dev_status *d_status = nullptr;
@@ -107,7 +108,7 @@ void msx_time_end(msx_ctx *ctx);
 
 static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) {
 	int64_t nb = (items + per_block - 1) / per_block;
-	int64_t cap = (int64_t)ctx->num_cu * 8;   // 8 x 256-thread blocks per CU = 32 waves
+	int64_t cap = (int64_t)ctx->num_cu * ctx->blocks_per_cu;   // default 8 x 256-thread blocks per CU = 32 waves
 	if (nb > cap) nb = cap;
 	if (nb < 1) nb = 1;
 	return (int)nb;
