@@ -537,7 +537,7 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 		}
 		A.pool = pool;
 		msx_time_begin(ctx, MSX_K_ALN_STATS);
-		hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid(ctx, n, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+		hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid_x(ctx, n, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
 		                   ctx->stream, A);
 		msx_time_end(ctx);
 	}
@@ -559,7 +559,7 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 		S.gcount = (uint32_t *)ctx->gcount.p;
 		S.st = ctx->d_status;
 		msx_time_begin(ctx, MSX_K_BESTHIT);
-		hipLaunchKernelGGL(k_besthit_select, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+		hipLaunchKernelGGL(k_besthit_select, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
 		                   ctx->stream, S);
 		msx_time_end(ctx);
 		if ((rc = msx_scan_u32(ctx, S.gcount, (uint32_t *)ctx->gbase.p, ng))) return rc;
