@@ -9,6 +9,8 @@
 // reference's sequential order, as BASELINE.json allows).
 #include "msx_internal.h"
 
+#include <cstdlib>
+
 struct CountArgs {
 	int64_t n_groups;
 	const uint32_t *group_off;
@@ -21,6 +23,7 @@ struct CountArgs {
 	uint32_t *counters;       // {inserts, uniq, multi, purged}
 	int32_t *tmp_fid;         // [n_records] scratch: pool g's distinct features at tmp_fid[group_off[g]..]
 	unsigned long long *mlen; // [n_groups] (is_multi_list << 32) | n_distinct  (0 when not kept)
+	uint32_t tbl_mask;        // LDS staging table size - 1 (power of two, <= UI_TBL)
 };
 
 // Per-workgroup staging of the per-reference adds in LDS: a small open-addressed
@@ -30,11 +33,12 @@ struct CountArgs {
 #define UI_TBL 2048
 #define UI_EMPTY (-1)
 
-__device__ __forceinline__ void ui_add(int32_t *s_key, uint32_t *s_val, uint32_t *ui, int32_t fid, uint32_t v) {
+__device__ __forceinline__ void ui_add(int32_t *s_key, uint32_t *s_val, uint32_t *ui, int32_t fid, uint32_t v,
+                                       uint32_t mask) {
 	uint32_t h = ((uint32_t)fid * 2654435761u) >> 21;   // 11 bits
 #pragma unroll
 	for (int probe = 0; probe < 4; ++probe) {
-		const uint32_t slot = (h + probe) & (UI_TBL - 1);
+		const uint32_t slot = (h + probe) & mask;
 		const int32_t old = atomicCAS(&s_key[slot], UI_EMPTY, fid);
 		if (old == UI_EMPTY || old == fid) {
 			atomicAdd(&s_val[slot], v);
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
 	__shared__ int32_t s_key[UI_TBL];
 	__shared__ uint32_t s_val[UI_TBL];
-	for (int i = threadIdx.x; i < UI_TBL; i += MSX_BLOCK) { s_key[i] = UI_EMPTY; s_val[i] = 0; }
+	const int tbl = (int)A.tbl_mask + 1;
+	for (int i = threadIdx.x; i < tbl; i += MSX_BLOCK) { s_key[i] = UI_EMPTY; s_val[i] = 0; }
 	__syncthreads();
 	uint32_t c_ins = 0, c_uniq = 0, c_multi = 0;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
@@ -87,18 +92,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 		if (nvalid > 0) {
 			c_ins++;                                          // one insert per pool (:230,:237)
 			if (nd == 1) {                                    // :75-78, :87-91, :152-159
-				ui_add(s_key, s_val, A.ui, f0, 2u);
+				ui_add(s_key, s_val, A.ui, f0, 2u, A.tbl_mask);
 				c_uniq++;
 			} else {
 				c_multi++;                                    // :95, :162
 				switch (A.share_type) {
 				case MSX_MULTI_ADD_ALL:                       // :99-102, :169-173
-					for (uint32_t k = 0; k < nd; ++k) ui_add(s_key, s_val, A.ui, lst[k], 2u);
+					for (uint32_t k = 0; k < nd; ++k) ui_add(s_key, s_val, A.ui, lst[k], 2u, A.tbl_mask);
 					break;
 				case MSX_MULTI_SHARE_EQUAL:
 					if (nvalid == 2) {                        // :103-106 (integer halves)
-						ui_add(s_key, s_val, A.ui, f0, 1u);
-						ui_add(s_key, s_val, A.ui, f1, 1u);
+						ui_add(s_key, s_val, A.ui, f0, 1u, A.tbl_mask);
+						ui_add(s_key, s_val, A.ui, f1, 1u, A.tbl_mask);
 					} else {                                  // :175-182
 						const double share = 1.0 / (double)nd;
 						for (uint32_t k = 0; k < nd; ++k) atomicAdd(&A.d[lst[k]], share);
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 		if (v) atomicAdd(&A.counters[threadIdx.x], v);
 	}
 	// flush the staged adds (the barrier above ordered every ui_add before this)
-	for (int i = threadIdx.x; i < UI_TBL; i += MSX_BLOCK) {
+	for (int i = threadIdx.x; i < tbl; i += MSX_BLOCK) {
 		const uint32_t v = s_val[i];
 		if (v) atomicAdd(&A.ui[s_key[i]], v);
 	}
@@ -288,6 +293,17 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	A.counters = p->counters;
 	A.tmp_fid = (int32_t *)ctx->tmp_fid.p;
 	A.mlen = prop ? (unsigned long long *)ctx->mlen.p : nullptr;
+	{
+		static int tbl = 0;
+		if (!tbl) {
+			const char *e = getenv("MSX_UI_TBL");
+			int v = e ? atoi(e) : 256;
+			tbl = 256;
+			while (tbl < v && tbl < UI_TBL) tbl <<= 1;
+			if (v > 0 && v < 256) { tbl = 1; while (tbl < v) tbl <<= 1; }
+		}
+		A.tbl_mask = (uint32_t)tbl - 1u;
+	}
 	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
 	hipLaunchKernelGGL(k_insert_count, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A);
 	msx_time_end(ctx);
