@@ -259,7 +259,9 @@ int  msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int6
  * (what mUpdateCoverageForAlignment builds by adding 1 per base).  Like the
  * reference, runs are assumed to stay inside their target (no bounds check). */
 int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
-                             const int64_t *cov_off, int32_t n_targets, int32_t *cov);
+                             const int64_t *cov_off, int32_t n_targets, int32_t *cov,
+                             uint8_t *covered /* device u8[n_targets] or NULL: global->covered[tid],
+                                                 set for every target that has an alignment (msam_coverage.c:45-49) */);
 int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);
 
 /* ---- synthetic workloads (bench.py / tests) -------- */

@@ -107,5 +107,6 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec);                    
 /* ---- subcommands ------------------------------------------------------------- */
 int msam_filter_main(int argc, char *argv[]);
 int msam_profile_main(int argc, char *argv[]);
+int msam_coverage_main(int argc, char *argv[]);
 
 #endif

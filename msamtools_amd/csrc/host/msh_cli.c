@@ -1057,6 +1057,163 @@ batch_ready:
 }
 
 /* ------------------------------------------------------------------------ */
+/* coverage (msam_coverage.c:143-390)                                         */
+/* ------------------------------------------------------------------------ */
+static void coverage_help(FILE *out) {
+	fprintf(out,
+	        "Usage:\n------\n\n%s coverage [-Sxz] <bamfile> [--help] -o <file> [--summary] [-w <int>]\n"
+	        "\nGeneral options:\n----------------\n\n"
+	        "These options specify the input/output formats of BAM/SAM files \n(same meaning as in 'samtools view'):\n"
+	        "  -S                        input is SAM (default: false)\n"
+	        "  <bamfile>                 input SAM/BAM file\n"
+	        "  --help                    print this help and exit\n\n"
+	        "Specific options:\n-----------------\n\n"
+	        "  -o <file>                 name of output file (required)\n"
+	        "  --summary                 do not report per-position coverage but report fraction of sequence covered (default: false)\n"
+	        "  -x, --skipuncovered       do not report coverage for sequences without aligned reads (default: false)\n"
+	        "  -w, --wordsize=<int>      number of words (coverage values) per line (default: 17)\n"
+	        "  -z, --gzip                compress output file using gzip (default; option retained for backward compatibility)\n",
+	        PROGRAM);
+}
+
+static void gz_flush_buf(gzFile gz, kstr *k) {
+	if (k->l && gzwrite(gz, k->s, (unsigned)k->l) != (int)k->l) mDie("Write failed");
+	k->l = 0;
+}
+
+int msam_coverage_main(int argc, char *argv[]) {
+	static const struct option lopts[] = {{"help", no_argument, 0, 1000},    {"summary", no_argument, 0, 1001},
+	                                      {"skipuncovered", no_argument, 0, 'x'}, {"wordsize", required_argument, 0, 'w'},
+	                                      {"gzip", no_argument, 0, 'z'},     {0, 0, 0, 0}};
+	const char *o_out = NULL;
+	int n_out = 0, o_summary = 0, o_skip = 0, o_help = 0, n_w = 0, nerrors = 0, c;
+	long v_w = 17;
+	msh_in *in;
+	const msh_hdr *hdr;
+	reader rd;
+	rbatch b;
+	gzFile gz;
+	int64_t *off, total;
+	void *d_off, *d_cov, *d_covered;
+	int32_t *cov, tid;
+	uint8_t *covered;
+	kstr line = {0, 0, 0};
+	kstr rec = {0, 0, 0};
+	size_t target = batch_target();
+
+	opterr = 0;
+	optind = 1;
+	while ((c = getopt_long(argc, argv, "Sxzo:w:", lopts, NULL)) != -1) {
+		switch (c) {
+		case 'S': case 'z': break;
+		case 'x': o_skip++; break;
+		case 'o': n_out++; o_out = optarg; break;
+		case 'w': n_w++; v_w = strtol(optarg, NULL, 10); break;
+		case 1000: o_help++; break;
+		case 1001: o_summary++; break;
+		default:
+			fprintf(stderr, "%s: invalid option \"%s\"\n", PROGRAM, argv[optind - 1]);
+			nerrors++;
+		}
+	}
+	if (o_help > 0 || argc < 2) { coverage_help(stdout); exit(EXIT_SUCCESS); }
+	if (argc - optind < 1) { fprintf(stderr, "%s: missing option <bamfile>\n", PROGRAM); nerrors++; }
+	if (n_out == 0) { fprintf(stderr, "%s: missing option -o <file>\n", PROGRAM); nerrors++; }
+	if (nerrors > 0) {                                                /* msam_coverage.c:322-326 (stderr) */
+		fprintf(stderr, "Use --help for usage instructions!\n");
+		mQuit("");
+	}
+	if (n_w > 0 && v_w < 1) {                                         /* :332-339 */
+		fprintf(stdout, "-w must be a non-zero positive integer\n");
+		coverage_help(stdout);
+		mQuit("");
+	}
+	if (n_out != 1) { fprintf(stdout, "requires -o\n"); coverage_help(stdout); mQuit(""); }
+	gz = strcmp(o_out, "-") == 0 ? gzdopen(fileno(stdout), "wb") : gzopen(o_out, "wb");   /* :348-353 */
+	if (!gz) mDie("Cannot open %s for writing", o_out);
+	gzbuffer(gz, 1 << 20);
+
+	in = msh_open(argv[optind]);
+	hdr = msh_header(in);
+	ctx_open();
+	off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)hdr->n_targets + 1));
+	off[0] = 0;
+	for (tid = 0; tid < hdr->n_targets; tid++) off[tid + 1] = off[tid] + hdr->target_len[tid];
+	total = off[hdr->n_targets];
+	MSX(msx_dev_alloc(g_ctx, &d_off, sizeof(int64_t) * ((size_t)hdr->n_targets + 1)));
+	MSX(msx_dev_alloc(g_ctx, &d_cov, 4 * (size_t)total + 8));
+	MSX(msx_dev_alloc(g_ctx, &d_covered, (size_t)hdr->n_targets + 8));
+	MSX(msx_host_to_dev(g_ctx, d_off, off, sizeof(int64_t) * ((size_t)hdr->n_targets + 1)));
+	MSX(msx_dev_zero(g_ctx, d_cov, 4 * (size_t)total + 8));
+	MSX(msx_dev_zero(g_ctx, d_covered, (size_t)hdr->n_targets + 8));
+
+	/* mEstimateCoverageOnFile (:106-139): every alignment adds 1, pools do not matter */
+	memset(&rd, 0, sizeof rd);
+	memset(&b, 0, sizeof b);
+	rd.in = in;
+	for (;;) {
+		if (msh_is_bam(in)) {
+			fill_batch_bulk(&rd, &b, target, 0, 1);
+		} else {
+			rb_clear(&b);
+			while (b.n < target && msh_read(in, &rec) == 0) rb_append(&b, (const uint8_t *)rec.s, rec.l, 1);
+			if (b.n < target) rd.done = 1;
+		}
+		if (b.n > 0) {
+			msx_batch hb, db;
+			rb_host_view(&b, &hb, 0);
+			hb.md_off = NULL; hb.md = NULL; hb.nm = NULL; hb.as = NULL;
+			MSX(msx_batch_upload(g_ctx, &hb, &db));
+			MSX(msx_coverage_accumulate(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, (int32_t *)d_cov,
+			                            (uint8_t *)d_covered));
+			MSX(msx_ctx_sync(g_ctx));
+			msx_batch_free(g_ctx, &db);
+		}
+		if (rd.done) break;
+	}
+	MSX(msx_coverage_finish(g_ctx, (int32_t *)d_cov, total));
+	cov = (int32_t *)malloc(4 * (size_t)(total > 0 ? total : 1));
+	covered = (uint8_t *)malloc((size_t)hdr->n_targets + 1);
+	if (!cov || !covered) mDie("Out of memory");
+	MSX(msx_dev_to_host(g_ctx, cov, d_cov, 4 * (size_t)total));
+	MSX(msx_dev_to_host(g_ctx, covered, d_covered, (size_t)hdr->n_targets));
+
+	for (tid = 0; tid < hdr->n_targets; tid++) {
+		const int32_t *cv = cov + off[tid];
+		int64_t tlen = hdr->target_len[tid], i;
+		if (o_summary) {                                              /* mWriteCoverageSummaryToStream :188-219 */
+			if (!covered[tid]) {
+				if (!o_skip) ks_printf(&line, "%s\t%d\t%d\n", hdr->target_name[tid], 0, 0);
+			} else {
+				int64_t touched = 0, sum = 0;
+				for (i = 0; i < tlen; i++) { touched += (cv[i] != 0); sum += cv[i]; }
+				ks_printf(&line, "%s\t%.8f\t%.2f\n", hdr->target_name[tid], 1.0 * touched / tlen, 1.0 * sum / tlen);
+			}
+		} else {                                                      /* mWriteCoverageToStream :143-186 */
+			if (!covered[tid] && o_skip) continue;
+			ks_printf(&line, ">%s\n", hdr->target_name[tid]);
+			for (i = 0; i < tlen - 1; i++) {
+				ks_printf(&line, "%d%c", covered[tid] ? cv[i] : 0, ((i + 1) % v_w == 0) ? '\n' : ' ');
+				if (line.l > (1 << 20)) gz_flush_buf(gz, &line);
+			}
+			ks_printf(&line, "%d\n", (covered[tid] && tlen > 0) ? cv[tlen - 1] : 0);
+		}
+		if (line.l > (1 << 20)) gz_flush_buf(gz, &line);
+	}
+	gz_flush_buf(gz, &line);
+	gzclose(gz);
+	msx_dev_free(g_ctx, d_off);
+	msx_dev_free(g_ctx, d_cov);
+	msx_dev_free(g_ctx, d_covered);
+	msx_ctx_destroy(g_ctx);
+	msh_close(in);
+	free(cov);
+	free(covered);
+	free(off);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* msamtools.c:8-49                                                           */
 /* ------------------------------------------------------------------------ */
 static int usage(FILE *out) {
@@ -1071,6 +1228,9 @@ static int usage(FILE *out) {
 	fprintf(out, "\n");
 	fprintf(out, " -- Profiling\n");
 	fprintf(out, "     profile        estimate relative abundance profile of reference sequences or genomes in bam file\n");
+	fprintf(out, "\n");
+	fprintf(out, " -- Coverage\n");
+	fprintf(out, "     coverage       estimate per-base or per-sequence read coverage of each reference sequence\n");
 	fprintf(out, "\n");
 	return 1;
 }
@@ -1173,6 +1333,7 @@ int main(int argc, char *argv[]) {
 	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "coverage") == 0) return msam_coverage_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "help") == 0) { usage(stdout); return 0; }
 	fprintf(stderr, "[msamtools] unrecognized command '%s'\n", argv[1]);
 	usage(stderr);

@@ -293,11 +293,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
                                                                const uint32_t *__restrict__ cigar_off,
                                                                const uint32_t *__restrict__ cigar,
                                                                const int64_t *__restrict__ cov_off,
-                                                               int32_t *__restrict__ diff) {
+                                                               int32_t *__restrict__ diff,
+                                                               uint8_t *__restrict__ covered) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n; i += stride) {
 		const int32_t t = tid[i];
 		if (t < 0) continue;                                   // :42
+		if (covered) covered[t] = 1;                           // :45-49 (same value from every lane)
 		int32_t *c = diff + cov_off[t];
 		int64_t p = pos[i];
 		const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 }
 
 extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets,
-                                       int32_t *cov) {
+                                       int32_t *cov, uint8_t *covered) {
 	(void)n_targets;
 	if (!ctx || !b || !cov_off || !cov) return MSX_ERR_ARG;
 	if (!b->pos || !b->tid || !b->cigar_off || !b->cigar)
@@ -330,7 +332,7 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	msx_time_begin(ctx, MSX_K_COVERAGE);
 	hipLaunchKernelGGL(k_coverage_pileup, dim3(msx_grid(ctx, b->n_records, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
-	                   ctx->stream, b->n_records, b->tid, b->pos, b->cigar_off, b->cigar, cov_off, cov);
+	                   ctx->stream, b->n_records, b->tid, b->pos, b->cigar_off, b->cigar, cov_off, cov, covered);
 	msx_time_end(ctx);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;

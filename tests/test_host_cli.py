@@ -274,3 +274,38 @@ def test_cli_streaming_boundary(tmp_path):
     assert len(out) == 100000
     last = out[-1].split("\t")
     assert (last[0], last[1], last[2], last[3]) == ("boundary", "256", "B", "400")
+
+
+def test_coverage_cli_validation():
+    # tests/test_errors.sh (coverage block): -w must be positive, -o required
+    r = run(["coverage", "-S", "-w", "0", "-o", "/dev/null", fixture_path("coverage.sam")])
+    assert r.returncode == 1 and b"-w must be a non-zero positive integer" in r.stdout
+    r = run(["coverage", "-S", fixture_path("coverage.sam")])
+    assert r.returncode == 1
+    assert run(["coverage", "--help"]).returncode == 0
+
+
+@pytest.mark.gpu
+def test_cli_coverage_golden(tmp_path):
+    """tests/test_coverage.sh:31-80: per-position text with -w 4, --summary, --skipuncovered."""
+    blk = EXP["coverage"]
+    src = fixture_path(blk["fixture"])
+    out = str(tmp_path / "positions.gz")
+    r = run(["coverage", "-S", "-w", "4", "-o", out, src])
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b""
+    want = []
+    for name in ("A", "B", "C", "D"):
+        v = blk["positions"][name]
+        want.append(">" + name)
+        for i in range(0, len(v), 4):
+            want.append(" ".join(str(x) for x in v[i:i + 4]))
+    assert gzip.open(out, "rt").read().split("\n")[:-1] == want
+    r = run(["coverage", "-S", "--summary", "-o", out, src])
+    assert r.returncode == 0
+    assert gzip.open(out, "rt").read().split("\n")[:-1] == [f"{k}\t{v[0]}\t{v[1]}" for k, v in blk["summary"].items()]
+    r = run(["coverage", "-S", "--summary", "--skipuncovered", "-o", out, src])
+    assert gzip.open(out, "rt").read().split("\n")[:-1] == \
+        [f"{k}\t{v[0]}\t{v[1]}" for k, v in blk["summary"].items() if k != "B"]
+    r = run(["coverage", "-S", "-x", "-o", "-", src])
+    text = gzip.decompress(r.stdout).decode()
+    assert ">B" not in text and ">A" in text
