@@ -173,3 +173,24 @@ def coverage(rec, target_len):
     cov = np.zeros(max(int(off[-1]), 1), np.int32)
     lib().orc_coverage(C.byref(r), _p(off), C.c_int32(len(target_len)), _p(cov))
     return [cov[off[i]:off[i + 1]].copy() for i in range(len(target_len))]
+
+
+def make_records_slice(rec, name_id, lo, hi):
+    """View of records [lo, hi) sharing the payload arrays (offsets stay absolute)."""
+    class _V:
+        pass
+    v = _V()
+    v.qname_off = None
+    v.qname = None
+    v.name_id = np.ascontiguousarray(name_id[lo:hi])
+    v.flag = rec.flag[lo:hi]
+    v.rflags = rec.rflags[lo:hi]
+    v.tid = rec.tid[lo:hi]
+    v.pos = rec.pos[lo:hi]
+    v.cigar_off = rec.cigar_off[lo:hi + 1]
+    v.cigar = rec.cigar
+    v.md_off = rec.md_off[lo:hi + 1]
+    v.md = rec.md
+    v.nm = rec.nm[lo:hi]
+    v.as_ = rec.as_[lo:hi]
+    return v
