@@ -268,7 +268,8 @@ def main():
         ctx.timing(False)
         ab1, st1 = prof.fetch()
         sz = db.sizes
-        n_lists, n_entries = prof.multi_size()
+        n_lists0, n_entries0 = prof.multi_size()       # multi-mapped inserts as accumulated
+        n_lists, n_entries = prof.shared_size()        # after identical feature sets were merged
         w = dict(n=n, ng=ng, n_cig=int(sz.n_cigar), n_md=int(sz.n_md), n_emit=state["n_emit"],
                  kept_groups=int(st1.insert_count), uniq=int(st1.uniq_mapper_count), L=n_lists, E=n_entries,
                  nf=nrefs)
@@ -290,7 +291,8 @@ def main():
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": tms[dom][1],
             "per_kernel": {k: {"ms_per_step": round(v[0], 4), "launches": v[1],
                                "algorithmic_GBps": round(gbps(k)[0], 1)} for k, v in tms.items()},
-            "multi_mapper_lists": n_lists, "multi_mapper_entries": n_entries,
+            "multi_mapper_lists": n_lists0, "multi_mapper_entries": n_entries0,
+            "merged_lists": n_lists, "merged_entries": n_entries,
         }
 
     # ---- CPU baseline: the oracle (scalar C port of the reference path), 1 thread ----

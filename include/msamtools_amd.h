@@ -248,6 +248,10 @@ int  msx_profile_abundance_dev(msx_ctx *ctx, msx_profile *p, double **a);
  * 36-39): number of multi-mapped inserts kept for sharing and the total number
  * of (insert, feature) entries.  Synchronises the stream. */
 int  msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries);
+/* Size of the derived store the sharing iterations run on (built by prop_begin /
+ * finalize: lists renumbered for locality, identical feature sets merged into one
+ * weighted list).  Synchronises the stream. */
+int  msx_profile_shared_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries);
 
 /* ---- coverage: replaces mUpdateCoverageForAlignment (msam_coverage.c:33-87) */
 

@@ -392,6 +392,11 @@ class Profile:
         self.ctx.check(self.ctx.lib.msx_profile_multi_size(self.ctx.h, self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def shared_size(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.ctx.check(self.ctx.lib.msx_profile_shared_size(self.ctx.h, self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def finalize_enqueue(self):
         self.ctx.check(self.ctx.lib.msx_profile_finalize_enqueue(self.ctx.h, self.h))
 

@@ -194,7 +194,8 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->t_val[0].p, p->t_val[1].p, p->rs_hist.p, p->rs_off.p,
-	                p->recip.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p};
+	                p->recip.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p,
+	                p->head.p, p->uidx.p, p->eoff.p, p->hpos.p, p->d_tot};
 	for (void *q : ptrs)
 		if (q) (void)hipFree(q);
 	delete p;
@@ -220,6 +221,7 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	          hipMalloc((void **)&p->delta, 20 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->iter_state, 2 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->csr_tot, 2 * 8) == hipSuccess &&
+	          hipMalloc((void **)&p->d_tot, 2 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->partial, PROP_MAX_BLOCKS * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->purged_local, 4) == hipSuccess;
 	if (ok && share_type == MSX_MULTI_SHARE_EQUAL) ok = hipMalloc((void **)&p->d, nf * 8) == hipSuccess;
@@ -251,6 +253,7 @@ extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
 	if (p->d) MSX_HIP(ctx, hipMemsetAsync(p->d, 0, nf * 8, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->counters, 0, 16, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->csr_tot, 0, 16, ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(p->d_tot, 0, 16, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->iter_state, 0, 8, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->delta, 0, 160, ctx->stream));
@@ -341,6 +344,16 @@ extern "C" int msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_l
 	if (!ctx || !p) return MSX_ERR_ARG;
 	unsigned long long t[2] = {0, 0};
 	MSX_HIP(ctx, hipMemcpyAsync(t, p->csr_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n_lists) *n_lists = (int64_t)t[0];
+	if (n_entries) *n_entries = (int64_t)t[1];
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_shared_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	unsigned long long t[2] = {0, 0};
+	MSX_HIP(ctx, hipMemcpyAsync(t, p->d_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (n_lists) *n_lists = (int64_t)t[0];
 	if (n_entries) *n_entries = (int64_t)t[1];

@@ -98,59 +98,111 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	}
 }
 
-// --- locality: renumber the multi-mappers by their smallest feature ------------
+// --- derived multi-mapper store: renumbered for locality, duplicates merged ---------
 // The sharing iteration gathers a[feature] per list and recip[list] per feature
 // entry.  Inserts that multi-map inside one family of similar references share
-// features, so ordering the lists by their smallest feature id puts the lists a
-// feature belongs to next to each other (dense cache lines instead of one line
-// per 8-byte gather).  Pure renumbering: sums only change their order.
-__global__ __launch_bounds__(MSX_BLOCK) void k_list_minkey(const unsigned long long *__restrict__ csr_tot,
-                                                           const uint32_t *__restrict__ m_off,
-                                                           const int32_t *__restrict__ m_fid,
-                                                           uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+// features, so (1) ordering the lists by their smallest feature id puts the lists
+// a feature belongs to next to each other (dense cache lines instead of one line
+// per 8-byte gather), and (2) many inserts hit exactly the same set of references:
+// identical lists are merged into one list with a weight w (it contributes
+// w/S instead of w times 1/S).  Sort key = smallest feature in the high bits (the
+// locality order) and an order-independent hash of the set in the low bits, so
+// equal sets end up adjacent; adjacency is then verified exactly, set against
+// set.  The accumulated store (m_off/m_fid) is left untouched for later batches.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+	x ^= x >> 16; x *= 0x7feb352du;
+	x ^= x >> 15; x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long *__restrict__ csr_tot,
+                                                        const uint32_t *__restrict__ m_off,
+                                                        const int32_t *__restrict__ m_fid, int hash_bits,
+                                                        uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
 		const uint32_t s = m_off[j], e = m_off[j + 1];
-		uint32_t mn = 0xffffffffu;
+		uint32_t mn = 0xffffffffu, h = (e - s) * 0x9e3779b9u;
 		for (uint32_t k = s; k < e; ++k) {
 			const uint32_t f = (uint32_t)m_fid[k];
 			mn = f < mn ? f : mn;
+			h += mix32(f);                                   // commutative: a hash of the set
 		}
-		key[j] = mn;
+		const uint32_t hb = hash_bits > 0 ? (h & ((1u << hash_bits) - 1u)) : 0u;
+		key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
 		val[j] = (uint32_t)j;
 	}
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_perm_len(const unsigned long long *__restrict__ csr_tot, int64_t m,
+// head[i] = 1 when the list at sorted position i is not the same set as its predecessor;
+// len2[i] = its length for heads, 0 for merged duplicates (and beyond the last list)
+__global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long *__restrict__ csr_tot, int64_t m,
+                                                        const uint32_t *__restrict__ skey,
                                                         const uint32_t *__restrict__ perm,
                                                         const uint32_t *__restrict__ m_off,
-                                                        uint32_t *__restrict__ len2) {
+                                                        const int32_t *__restrict__ m_fid,
+                                                        uint32_t *__restrict__ head, uint32_t *__restrict__ len2) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < m; i += stride) {
-		uint32_t l = 0;
+		uint32_t hd = 0, l = 0;
 		if (i < n_lists) {
 			const uint32_t j = perm[i];
-			l = m_off[j + 1] - m_off[j];
+			const uint32_t s = m_off[j], e = m_off[j + 1];
+			l = e - s;
+			hd = 1;
+			if (i > 0 && skey[i] == skey[i - 1] && l <= 32u) {
+				const uint32_t jp = perm[i - 1];
+				const uint32_t sp = m_off[jp], ep = m_off[jp + 1];
+				if (ep - sp == l) {
+					// both lists hold distinct features, so equal sizes + inclusion = equal sets
+					bool same = true;
+					for (uint32_t k = s; k < e && same; ++k) {
+						const int32_t f = m_fid[k];
+						bool found = false;
+						for (uint32_t q = sp; q < ep; ++q) found |= (m_fid[q] == f);
+						same = found;
+					}
+					if (same) hd = 0;
+				}
+			}
 		}
-		len2[i] = l;
+		head[i] = hd;
+		len2[i] = hd ? l : 0u;
 	}
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_perm_gather(const unsigned long long *__restrict__ csr_tot,
+// unique list u (sorted position i, a head): offsets, entries, and the sorted position itself
+// (weights are differences of consecutive head positions)
+__global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long long *__restrict__ csr_tot,
                                                            const uint32_t *__restrict__ perm,
+                                                           const uint32_t *__restrict__ head,
+                                                           const uint32_t *__restrict__ uidx,
+                                                           const uint32_t *__restrict__ eoff,
                                                            const uint32_t *__restrict__ m_off,
                                                            const int32_t *__restrict__ m_fid,
-                                                           const uint32_t *__restrict__ m_off2,
-                                                           int32_t *__restrict__ m_fid2) {
+                                                           uint32_t *__restrict__ d_off, int32_t *__restrict__ d_fid,
+                                                           uint32_t *__restrict__ hpos, int64_t m,
+                                                           unsigned long long *__restrict__ d_tot) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n_lists; i += stride) {
-		const uint32_t j = perm[i];
+		if (!head[i]) continue;
+		const uint32_t u = uidx[i], j = perm[i];
 		const uint32_t s = m_off[j], e = m_off[j + 1];
-		uint32_t o = m_off2[i];
-		for (uint32_t k = s; k < e; ++k) m_fid2[o++] = m_fid[k];
+		uint32_t o = eoff[i];
+		d_off[u] = o;
+		hpos[u] = (uint32_t)i;
+		for (uint32_t k = s; k < e; ++k) d_fid[o++] = m_fid[k];
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		const uint32_t U = uidx[m], E2 = eoff[m];
+		d_tot[0] = U;
+		d_tot[1] = E2;
+		d_off[U] = E2;                 // CSR sentinel
+		hpos[U] = (uint32_t)n_lists;   // so that weight(u) = hpos[u+1] - hpos[u]
 	}
 }
 
@@ -173,10 +225,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint
 	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; }
 }
 
-// recip[j] = 1/S_j, S_j = sum of a over the features of multi-mapper j (0 when S_j == 0: :358)
+// recip[j] = w_j/S_j, S_j = sum of a over the features of (merged) multi-mapper j, w_j the number
+// of inserts it stands for (0 when S_j == 0: :358)
 __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long long *__restrict__ csr_tot,
                                                           const uint32_t *__restrict__ m_off,
                                                           const int32_t *__restrict__ m_fid,
+                                                          const uint32_t *__restrict__ hpos,
                                                           const double *__restrict__ a, double *__restrict__ recip,
                                                           const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
@@ -186,7 +240,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 		const uint32_t s = m_off[j], e = m_off[j + 1];
 		double sum = 0;
 		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
-		recip[j] = sum > 0 ? 1.0 / sum : 0.0;
+		recip[j] = sum > 0 ? (double)(hpos[j + 1] - hpos[j]) / sum : 0.0;
 	}
 }
 
@@ -394,6 +448,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_finish(int nparts, const dou
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long long *__restrict__ csr_tot,
                                                            const uint32_t *__restrict__ m_off,
                                                            const int32_t *__restrict__ m_fid,
+                                                           const uint32_t *__restrict__ hpos,
                                                            const double *__restrict__ a, uint32_t *out_count) {
 	__shared__ uint32_t s_w[MSX_BLOCK / 64];
 	const int64_t n_lists = (int64_t)csr_tot[0];
@@ -403,7 +458,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long l
 		const uint32_t s = m_off[j], e = m_off[j + 1];
 		double sum = 0;
 		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
-		c += (sum == 0);
+		if (sum == 0) c += hpos[j + 1] - hpos[j];
 	}
 	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -471,45 +526,56 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	int bits = 0;
 	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
 
-	// (a) renumber the lists by smallest feature (locality of both gathers)
-	if (bits > 0) {
-		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap))) return rc;
-		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap))) return rc;
+	// (a) derived store: lists ordered by (smallest feature, set hash), identical sets merged
+	{
+		int hash_bits = 32 - bits;
+		if (hash_bits > 12) hash_bits = 12;
+		if (hash_bits < 0) hash_bits = 0;
+		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap + 64))) return rc;
+		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->len2, (size_t)(lub + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->head, (size_t)(lub + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->uidx, (size_t)(lub + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->eoff, (size_t)(lub + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->hpos, (size_t)(lub + 8) * 4))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
-		          hipLaunchKernelGGL(k_list_minkey, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                             tot, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		          hipLaunchKernelGGL(k_list_key, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
+		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits,
 		                             (uint32_t *)p->t_key[0].p, (uint32_t *)p->t_val[0].p));
 		int sb = 0;
 		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p, (const uint32_t *)p->t_val[0].p, 0, tot + 0,
-		                           lub, bits, &sb)))
+		                           lub, bits + hash_bits, &sb)))
 			return rc;
+		const uint32_t *skey = (const uint32_t *)p->t_key[sb].p;
 		const uint32_t *perm = (const uint32_t *)p->t_val[sb].p;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
-		          hipLaunchKernelGGL(k_perm_len, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
-		                             lub, perm, (const uint32_t *)p->m_off.p, (uint32_t *)p->len2.p));
-		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->m_off_alt.p, lub))) return rc;
+		          hipLaunchKernelGGL(k_dup_mark, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
+		                             lub, skey, perm, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p));
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub))) return rc;
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
-		          hipLaunchKernelGGL(k_perm_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                             tot, perm, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
-		                             (const uint32_t *)p->m_off_alt.p, (int32_t *)p->m_fid_alt.p));
-		msx_buf t = p->m_off; p->m_off = p->m_off_alt; p->m_off_alt = t;
-		t = p->m_fid; p->m_fid = p->m_fid_alt; p->m_fid_alt = t;
+		          hipLaunchKernelGGL(k_uniq_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             tot, perm, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
+		                             (const uint32_t *)p->eoff.p, (const uint32_t *)p->m_off.p,
+		                             (const int32_t *)p->m_fid.p, (uint32_t *)p->m_off_alt.p,
+		                             (int32_t *)p->m_fid_alt.p, (uint32_t *)p->hpos.p, lub, p->d_tot));
 	}
+	tot = p->d_tot;      // everything below works on the derived store
 
 	// (b) feature-major view: (feature, list) pairs sorted by feature
 	MSX_TIMED(ctx, MSX_K_RS_HIST,
 	          hipLaunchKernelGGL(k_entry_lists, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             tot, (const uint32_t *)p->m_off.p, (uint32_t *)p->t_val[0].p));
+	                             tot, (const uint32_t *)p->m_off_alt.p, (uint32_t *)p->t_val[0].p));
 	int cur = 0;
 	if (bits > 0) {
-		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_fid.p, (const uint32_t *)p->t_val[0].p, 0, tot + 1, eub,
-		                           bits, &cur)))
+		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_fid_alt.p, (const uint32_t *)p->t_val[0].p, 0, tot + 1,
+		                           eub, bits, &cur)))
 			return rc;
 	} else {
 		// a single feature: the list-major order is already feature-major
-		size_t nb = (size_t)eub * 4 < p->m_fid.cap ? (size_t)eub * 4 : p->m_fid.cap;
-		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[0].p, p->m_fid.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+		size_t nb = (size_t)eub * 4 < p->m_fid_alt.cap ? (size_t)eub * 4 : p->m_fid_alt.cap;
+		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[0].p, p->m_fid_alt.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
 	}
 	p->sorted_buf = cur;
 	p->transposed_valid = true;
@@ -522,15 +588,15 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
 	const int64_t eub = p->entries_ub > 0 ? p->entries_ub : 1;
 	MSX_TIMED(ctx, MSX_K_LIST_RECIP,
 	          hipLaunchKernelGGL(k_list_recip, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-	                             (const int32_t *)p->m_fid.p, (const double *)p->a, (double *)p->recip.p,
-	                             (const int32_t *)p->iter_state));
+	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
+	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p, (const double *)p->a,
+	                             (double *)p->recip.p, (const int32_t *)p->iter_state));
 	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
 	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
 	const int64_t M = (int64_t)nblk * 4 * 2;              // two partial slots per launched wave
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
 	          hipLaunchKernelGGL(k_share_reduce, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
+	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
 	                             (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
 	                             (uint32_t *)p->part_key.p, (double *)p->part_val.p,
 	                             (const int32_t *)p->iter_state));
@@ -558,8 +624,9 @@ int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev) {
 	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
 	MSX_TIMED(ctx, MSX_K_PROP_APPLY,
 	          hipLaunchKernelGGL(k_prop_purged, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             (const unsigned long long *)p->csr_tot, (const uint32_t *)p->m_off.p,
-	                             (const int32_t *)p->m_fid.p, (const double *)p->a, out_dev));
+	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
+	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p, (const double *)p->a,
+	                             out_dev));
 	return MSX_OK;
 }
 
