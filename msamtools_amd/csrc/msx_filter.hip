@@ -392,8 +392,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
 	}
 }
 
-// emit order for pools: all pass-1 records of a pool, then its pass-2 records
-__global__ __launch_bounds__(MSX_BLOCK) void k_emit_groups(int64_t n_groups, const uint32_t *__restrict__ group_off,
+// emit order for pools: all pass-1 records of a pool, then its pass-2 records.
+// The keep codes of a pool (<= 20 records) arrive as six independent aligned dword
+// loads -- one memory round trip per pool instead of one per record.
+__global__ __launch_bounds__(MSX_BLOCK) void k_emit_groups(int64_t n_records, int64_t n_groups,
+                                                           const uint32_t *__restrict__ group_off,
                                                            const uint8_t *__restrict__ keep,
                                                            const uint32_t *__restrict__ gbase,
                                                            int32_t *__restrict__ emit_idx, msx_dev_status *st) {
@@ -402,7 +405,29 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_emit_groups(int64_t n_groups, con
 		const uint32_t s = group_off[g], e = group_off[g + 1];
 		uint32_t o = gbase[g];
 		const uint32_t cnt = gbase[g + 1] - o;
-		if (cnt && emit_idx) {
+		if (!cnt || !emit_idx) continue;
+		if (e - s <= 20u && (uint64_t)(s & ~3u) + 24u <= (uint64_t)n_records) {
+			const uint32_t base = s & ~3u, sh = s - base, len = e - s;
+			const uint32_t *kw = reinterpret_cast<const uint32_t *>(keep) + (base >> 2);
+			uint32_t w[6];
+#pragma unroll
+			for (int q = 0; q < 6; q++) w[q] = kw[q];
+			uint32_t m1 = 0, m2 = 0;
+#pragma unroll
+			for (int q = 0; q < 6; q++) {
+#pragma unroll
+				for (int bq = 0; bq < 4; bq++) {
+					const uint32_t r = (uint32_t)(q * 4 + bq) - sh;
+					const uint32_t kc = (w[q] >> (8 * bq)) & 0xffu;
+					if ((uint32_t)(q * 4 + bq) >= sh && r < len) {
+						m1 |= (kc == 1u ? 1u : 0u) << r;
+						m2 |= (kc == 2u ? 1u : 0u) << r;
+					}
+				}
+			}
+			while (m1) { const uint32_t b = (uint32_t)__ffs((int)m1) - 1u; m1 &= m1 - 1u; emit_idx[o++] = (int32_t)(s + b); }
+			while (m2) { const uint32_t b = (uint32_t)__ffs((int)m2) - 1u; m2 &= m2 - 1u; emit_idx[o++] = (int32_t)(s + b); }
+		} else {
 			uint32_t n2 = 0;
 			for (uint32_t i = s; i < e; ++i) {
 				const uint8_t k = keep[i];
@@ -565,7 +590,7 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 		if ((rc = msx_scan_u32(ctx, S.gcount, (uint32_t *)ctx->gbase.p, ng))) return rc;
 		msx_time_begin(ctx, MSX_K_EMIT);
 		hipLaunchKernelGGL(k_emit_groups, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   ng, b->group_off, (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p,
+		                   n, ng, b->group_off, (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p,
 		                   out->emit_idx, ctx->d_status);
 		msx_time_end(ctx);
 	} else {

@@ -13,6 +13,7 @@
 
 struct CountArgs {
 	int64_t n_groups;
+	int64_t n_records;
 	const uint32_t *group_off;
 	const int32_t *tid;
 	const uint8_t *keep;      // null: all records; else filter's keep codes (1 then 2 = output order)
@@ -62,17 +63,71 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 		uint32_t nvalid = 0, nd = 0;
 		int32_t f0 = -1, f1 = -1, f2 = -1, f3 = -1;
 		int32_t *lst = A.tmp_fid + s;
-		// the stream profile sees: the batch itself, or filter's output order
-		// (all pass-1 records of the pool, then its pass-2 records)
-		const int npass = A.keep ? 2 : 1;
-		for (int pass = 1; pass <= npass; ++pass) {
-			for (uint32_t i = s; i < e; ++i) {
-				if (A.keep && A.keep[i] != pass) continue;
-				const int32_t t = A.tid[i];
-				if (t == -1) continue;                       // msam_profile.c:223-225
+		// one record of the stream profile sees: count it, remember its feature if new
+		// (distinct features in first-appearance order, msam_profile.c:131-145)
+		auto visit = [&](uint32_t i) {
+			const int32_t t = A.tid[i];
+			if (t == -1) return;                             // msam_profile.c:223-225
+			const int32_t fid = A.fmap ? A.fmap[t] : t;
+			nvalid++;
+			bool seen = (nd > 0 && fid == f0) || (nd > 1 && fid == f1) || (nd > 2 && fid == f2) ||
+			            (nd > 3 && fid == f3);
+			if (!seen && nd > 4)
+				for (uint32_t k = 4; k < nd; ++k)
+					if (lst[k] == fid) { seen = true; break; }
+			if (!seen) {
+				if (nd == 0) f0 = fid;
+				else if (nd == 1) f1 = fid;
+				else if (nd == 2) f2 = fid;
+				else if (nd == 3) f3 = fid;
+				lst[nd] = fid;
+				nd++;
+			}
+		};
+		// the stream: the batch itself, or filter's output order (all pass-1 records of the
+		// pool, then its pass-2 records)
+		if (!A.keep) {
+			for (uint32_t i = s; i < e; ++i) visit(i);
+		} else if (e - s <= 20u && (uint64_t)(s & ~3u) + 24u <= (uint64_t)A.n_records) {
+			// memory-level parallelism: the pool's keep codes arrive as six independent aligned
+			// dword loads (one round trip instead of one per record), the tids of the kept records
+			// as up to eight independent loads; only then are they walked in output order.
+			const uint32_t base = s & ~3u, sh = s - base, len = e - s;
+			const uint32_t *kw = reinterpret_cast<const uint32_t *>(A.keep) + (base >> 2);
+			uint32_t w[6];
+#pragma unroll
+			for (int q = 0; q < 6; q++) w[q] = kw[q];
+			uint32_t m1 = 0, m2 = 0;
+#pragma unroll
+			for (int q = 0; q < 6; q++) {
+#pragma unroll
+				for (int bq = 0; bq < 4; bq++) {
+					const uint32_t r = (uint32_t)(q * 4 + bq) - sh;          // record index inside the pool
+					const uint32_t kc = (w[q] >> (8 * bq)) & 0xffu;
+					if ((uint32_t)(q * 4 + bq) >= sh && r < len) {
+						m1 |= (kc == 1u ? 1u : 0u) << r;
+						m2 |= (kc == 2u ? 1u : 0u) << r;
+					}
+				}
+			}
+			// order of the stream: pass-1 records, then pass-2 records
+			uint32_t idx[8];
+			int32_t tv[8];
+			uint32_t nk = 0, rest1 = m1, rest2 = m2;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				uint32_t bpos = 0xffffffffu;
+				if (rest1) { bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; }
+				else if (rest2) { bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; }
+				idx[q] = bpos;
+				nk += (bpos != 0xffffffffu);
+			}
+#pragma unroll
+			for (int q = 0; q < 8; q++) tv[q] = (idx[q] != 0xffffffffu) ? A.tid[s + idx[q]] : -1;
+			auto visit_t = [&](int32_t t) {
+				if (t == -1) return;
 				const int32_t fid = A.fmap ? A.fmap[t] : t;
 				nvalid++;
-				// distinct features in first-appearance order (msam_profile.c:131-145)
 				bool seen = (nd > 0 && fid == f0) || (nd > 1 && fid == f1) || (nd > 2 && fid == f2) ||
 				            (nd > 3 && fid == f3);
 				if (!seen && nd > 4)
@@ -86,7 +141,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 					lst[nd] = fid;
 					nd++;
 				}
-			}
+			};
+#pragma unroll
+			for (int q = 0; q < 8; q++) visit_t(tv[q]);
+			// more than eight kept records: the rest one by one
+			while (rest1) { const uint32_t bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; visit(s + bpos); }
+			while (rest2) { const uint32_t bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; visit(s + bpos); }
+			(void)nk;
+		} else {
+			for (uint32_t pass = 1; pass <= 2; ++pass)
+				for (uint32_t i = s; i < e; ++i)
+					if (A.keep[i] == pass) visit(i);
 		}
 		unsigned long long ml = 0;
 		if (nvalid > 0) {
@@ -286,6 +351,7 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	}
 	CountArgs A = {};
 	A.n_groups = ng;
+	A.n_records = n;
 	A.group_off = b->group_off;
 	A.tid = b->tid;
 	A.keep = keep;
