@@ -294,101 +294,133 @@ struct SelectArgs {
 	msx_dev_status *st;
 };
 
-// The 256 pools of a workgroup step cover one contiguous record range.  Its
-// FLAG / pool byte / AS / aux bits are staged in LDS with coalesced loads (two
-// global round trips per step instead of a dependent chain per lane), walked
-// there, and the keep codes go back through LDS as contiguous byte stores.
-// Records beyond the staging capacity are read from / written to global.
-#define BH_CAP 3072
+// One lane per pool.  Pools are short (1 + Poisson(4) hits per read), so a lane
+// fetches its pool's FLAGs, pool bytes, aux bits and AS values (<= 12 records) with
+// ~27 independent loads issued back to back -- one memory round trip per pool
+// instead of one per record -- realigns the sub-dword windows with alignbit /
+// alignbyte so that record r sits at a compile-time position, and runs both
+// passes (max + tie count per mate class; keep codes) out of registers.  Longer
+// pools take the per-record loop.
+#define BH_WIN 12
+
+struct BhAcc {
+	int32_t b0, b1, b2;          // best AS per mate class: neither bit, READ1, READ2
+	uint32_t n0, n1, n2;         // ties
+	uint32_t paired;
+	uint32_t noas0, noas1, noas2;   // first participating record without AS
+};
+
+__device__ __forceinline__ void bh_count(BhAcc &c, uint32_t i, uint32_t fl, bool pooled, bool has, int32_t sc) {
+	if (!pooled) return;
+	const uint32_t cls = fl & MSX_F_MATES;
+	c.paired |= cls;                                                 // mBamPoolIsPaired :196-204
+	if (cls == 0) {
+		if (!has) { if (c.noas0 == 0xffffffffu) c.noas0 = i; }
+		else if (sc > c.b0) { c.b0 = sc; c.n0 = 1; } else if (sc == c.b0) c.n0++;
+	} else if (cls == 0x40u) {
+		if (!has) { if (c.noas1 == 0xffffffffu) c.noas1 = i; }
+		else if (sc > c.b1) { c.b1 = sc; c.n1 = 1; } else if (sc == c.b1) c.n1++;
+	} else if (cls == 0x80u) {
+		if (!has) { if (c.noas2 == 0xffffffffu) c.noas2 = i; }
+		else if (sc > c.b2) { c.b2 = sc; c.n2 = 1; } else if (sc == c.b2) c.n2++;
+	}
+}
+
+__device__ __forceinline__ uint8_t bh_keep(const BhAcc &c, bool w0, bool w1, bool w2, uint32_t fl, bool pooled,
+                                           bool has, int32_t sc) {
+	if (!pooled || !has) return 0;
+	const uint32_t cls = fl & MSX_F_MATES;
+	if (cls == 0 && w0 && sc == c.b0) return 1;
+	if (cls == 0x40u && w1 && sc == c.b1) return 1;
+	if (cls == 0x80u && w2 && sc == c.b2) return 2;
+	return 0;
+}
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
-	__shared__ uint32_t s_goff[MSX_BLOCK + 1];
-	__shared__ int32_t s_as[BH_CAP];
-	__shared__ uint16_t s_flag[BH_CAP];
-	__shared__ uint8_t s_pool[BH_CAP], s_has[BH_CAP], s_keep[BH_CAP];
-	const int tid = threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t gb = (int64_t)blockIdx.x * MSX_BLOCK; gb < A.n_groups; gb += stride) {
-		const int ngb = (int)((A.n_groups - gb < MSX_BLOCK) ? (A.n_groups - gb) : MSX_BLOCK);
-		if (tid <= ngb) s_goff[tid] = A.group_off[gb + tid];
-		if (tid == 0 && ngb == MSX_BLOCK) s_goff[MSX_BLOCK] = A.group_off[gb + MSX_BLOCK];
-		__syncthreads();
-		const uint32_t r0 = s_goff[0], r1 = s_goff[ngb];
-		const uint32_t len = (r1 - r0 < BH_CAP) ? r1 - r0 : BH_CAP;
-		for (uint32_t x = tid; x < len; x += MSX_BLOCK) {
-			const uint32_t i = r0 + x;
-			const uint32_t fl = A.flag[i];
-			s_flag[x] = (uint16_t)fl;
-			s_as[x] = A.as[i];
-			s_pool[x] = A.pool ? A.pool[i] : (uint8_t)((fl & MSX_F_UNMAP) ? 0 : 1);
-			s_has[x] = (uint8_t)(((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP))) ? 1 : 0);
-		}
-		__syncthreads();
-		if (tid < ngb) {
-			const uint32_t s = s_goff[tid], e = s_goff[tid + 1];
-			// (best, count) per mate class: 0 = neither bit, 1 = READ1, 2 = READ2
-			int32_t b0 = INT_MIN, b1 = INT_MIN, b2 = INT_MIN;
-			uint32_t n0 = 0, n1 = 0, n2 = 0;
-			uint32_t paired = 0;
-			uint32_t noas0 = 0xffffffffu, noas1 = 0xffffffffu, noas2 = 0xffffffffu;  // first record lacking AS
-			for (uint32_t i = s; i < e; ++i) {
-				const uint32_t x = i - r0;
-				uint32_t fl, pooled, has;
-				int32_t sc;
-				if (x < len) { fl = s_flag[x]; pooled = s_pool[x]; has = s_has[x]; sc = s_as[x]; }
-				else {
-					fl = A.flag[i];
-					pooled = A.pool ? A.pool[i] : ((fl & MSX_F_UNMAP) ? 0u : 1u);
-					has = ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP))) ? 1u : 0u;
-					sc = A.as[i];
-				}
-				if (!pooled) continue;
-				const uint32_t cls = fl & MSX_F_MATES;
-				paired |= cls;                                           // mBamPoolIsPaired :196-204
-				if (cls == 0) {
-					if (!has) { if (noas0 == 0xffffffffu) noas0 = i; }
-					else if (sc > b0) { b0 = sc; n0 = 1; } else if (sc == b0) n0++;
-				} else if (cls == 0x40u) {
-					if (!has) { if (noas1 == 0xffffffffu) noas1 = i; }
-					else if (sc > b1) { b1 = sc; n1 = 1; } else if (sc == b1) n1++;
-				} else if (cls == 0x80u) {
-					if (!has) { if (noas2 == 0xffffffffu) noas2 = i; }
-					else if (sc > b2) { b2 = sc; n2 = 1; } else if (sc == b2) n2++;
+	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
+		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
+		const uint32_t len = e - s;
+		BhAcc c = {INT_MIN, INT_MIN, INT_MIN, 0u, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+		uint32_t cnt = 0;
+		if (len <= BH_WIN && (uint64_t)(s & ~3u) + 16u <= (uint64_t)A.n && (uint64_t)s + BH_WIN <= (uint64_t)A.n) {
+			// ---- bulk loads (independent of each other) ----
+			const uint32_t *f32p = reinterpret_cast<const uint32_t *>(A.flag) + (s >> 1);
+			uint32_t fw[7];
+#pragma unroll
+			for (int q = 0; q < 7; q++) fw[q] = (2u * ((s >> 1) + (uint32_t)q) < (uint32_t)A.n) ? f32p[q] : 0u;
+			const uint32_t *r32p = reinterpret_cast<const uint32_t *>(A.rflags) + (s >> 2);
+			uint32_t rw[4], pw[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+#pragma unroll
+			for (int q = 0; q < 4; q++) rw[q] = r32p[q];
+			if (A.pool) {
+				const uint32_t *p32p = reinterpret_cast<const uint32_t *>(A.pool) + (s >> 2);
+#pragma unroll
+				for (int q = 0; q < 4; q++) pw[q] = p32p[q];
+			}
+			int32_t sc[BH_WIN];
+#pragma unroll
+			for (int r = 0; r < BH_WIN; r++) sc[r] = A.as[s + r];
+			// ---- realign so that record r is at a fixed position ----
+			const uint32_t fsh = 16u * (s & 1u), bsh = s & 3u;
+			uint32_t fa[6], ra[3], pa[3];
+#pragma unroll
+			for (int q = 0; q < 6; q++) fa[q] = __builtin_amdgcn_alignbit(fw[q + 1], fw[q], fsh);
+#pragma unroll
+			for (int q = 0; q < 3; q++) {
+				ra[q] = __builtin_amdgcn_alignbyte(rw[q + 1], rw[q], bsh);
+				pa[q] = __builtin_amdgcn_alignbyte(pw[q + 1], pw[q], bsh);
+			}
+			// ---- pass 1: best score and ties per mate class ----
+#pragma unroll
+			for (int r = 0; r < BH_WIN; r++) {
+				if ((uint32_t)r < len) {
+					const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+					const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
+					const bool pooled = A.pool ? (((pa[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0) : !(fl & MSX_F_UNMAP);
+					const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+					bh_count(c, s + (uint32_t)r, fl, pooled, has, sc[r]);
 				}
 			}
-			// msam_filter.c:219-221: a participating record without AS is fatal
-			uint32_t bad = paired ? (noas1 < noas2 ? noas1 : noas2) : noas0;
-			if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
-			const bool w0 = !paired && n0 > 0 && (!A.unique_only || n0 == 1);   // :232-233
-			const bool w1 = paired && n1 > 0 && (!A.unique_only || n1 == 1);
-			const bool w2 = paired && n2 > 0 && (!A.unique_only || n2 == 1);
-			uint32_t cnt = 0;
+			const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);   // :232-233
+			const bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
+			const bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
+			// ---- pass 2: keep codes ----
+#pragma unroll
+			for (int r = 0; r < BH_WIN; r++) {
+				if ((uint32_t)r < len) {
+					const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+					const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
+					const bool pooled = A.pool ? (((pa[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0) : !(fl & MSX_F_UNMAP);
+					const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+					const uint8_t k = bh_keep(c, w0, w1, w2, fl, pooled, has, sc[r]);
+					A.keep[s + r] = k;
+					cnt += (k != 0);
+				}
+			}
+		} else {
 			for (uint32_t i = s; i < e; ++i) {
-				const uint32_t x = i - r0;
-				uint32_t fl, pooled, has;
-				int32_t sc;
-				if (x < len) { fl = s_flag[x]; pooled = s_pool[x]; has = s_has[x]; sc = s_as[x]; }
-				else {
-					fl = A.flag[i];
-					pooled = A.pool ? A.pool[i] : ((fl & MSX_F_UNMAP) ? 0u : 1u);
-					has = ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP))) ? 1u : 0u;
-					sc = A.as[i];
-				}
-				uint8_t k = 0;
-				if (pooled && has) {
-					const uint32_t cls = fl & MSX_F_MATES;
-					if (cls == 0 && w0 && sc == b0) k = 1;
-					else if (cls == 0x40u && w1 && sc == b1) k = 1;
-					else if (cls == 0x80u && w2 && sc == b2) k = 2;
-				}
-				if (x < len) s_keep[x] = k;
-				else A.keep[i] = k;
+				const uint32_t fl = A.flag[i];
+				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+				bh_count(c, i, fl, pooled, has, A.as[i]);
+			}
+			const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);
+			const bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
+			const bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
+			for (uint32_t i = s; i < e; ++i) {
+				const uint32_t fl = A.flag[i];
+				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+				const uint8_t k = bh_keep(c, w0, w1, w2, fl, pooled, has, A.as[i]);
+				A.keep[i] = k;
 				cnt += (k != 0);
 			}
-			A.gcount[gb + tid] = cnt;
 		}
-		__syncthreads();
-		for (uint32_t x = tid; x < len; x += MSX_BLOCK) A.keep[r0 + x] = s_keep[x];
+		// msam_filter.c:219-221: a participating record without AS is fatal
+		const uint32_t bad = c.paired ? (c.noas1 < c.noas2 ? c.noas1 : c.noas2) : c.noas0;
+		if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
+		A.gcount[g] = cnt;
 	}
 }
 
