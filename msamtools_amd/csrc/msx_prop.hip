@@ -16,8 +16,8 @@
 // Across ranks `share` is the vector to all-reduce (C1 in SURVEY.md section 2).
 #include "msx_internal.h"
 
-#define RS_ROWS 32
-#define RS_WAVE_ELEMS (RS_ROWS * 64)   // entries sorted by one wave per pass
+#define RS_EPT 16                      // elements per thread in a radix pass
+#define RS_TILE (RS_EPT * MSX_BLOCK)    // elements per workgroup tile
 #define SR_CHUNK 2048                  // entries reduced by one wave
 
 // ---------------------------------------------------------------------------
@@ -34,24 +34,45 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_lists(const unsigned long l
 	}
 }
 
+// One radix pass (8-bit digit) = k_rs_hist + scan + k_rs_scatter, both on tiles of
+// RS_TILE consecutive elements per 256-thread workgroup.
+//   k_rs_hist     per-tile digit counts, hist[digit * n_tiles + tile]; keys read as 16-B vectors
+//   k_rs_scatter  every thread first issues all its loads (RS_EPT keys + values, independent),
+//                 ranks them (ballot match inside a row of 64, running per-wave digit counts in
+//                 LDS, then a prefix over the four waves), moves the tile into LDS in digit
+//                 order and writes it out from there: consecutive threads write consecutive
+//                 addresses inside a digit's run instead of 64 scattered 4-byte stores per row.
+// Order inside a digit is (wave, row, lane) = input order, so the pass is stable.
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restrict__ keys,
                                                        const unsigned long long *__restrict__ n_ptr, int shift,
-                                                       uint32_t *__restrict__ hist, int64_t n_waves) {
+                                                       uint32_t *__restrict__ hist, int64_t n_tiles) {
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int64_t wave = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + w;
-	if (wave >= n_waves) return;
+	const int64_t tile = blockIdx.x;
 	const int64_t E = (int64_t)*n_ptr;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
-	const int64_t base = wave * RS_WAVE_ELEMS;
-	for (int row = 0; row < RS_ROWS; row++) {
-		const int64_t k = base + row * 64 + lane;
-		if (k < E) atomicAdd(&s_cnt[w][(keys[k] >> shift) & 255u], 1u);
+	const int64_t base = tile * RS_TILE;
+	if (base + RS_TILE <= E) {
+		const uint4 *kv = reinterpret_cast<const uint4 *>(keys + base);
+		uint4 v[RS_EPT / 4];
+#pragma unroll
+		for (int q = 0; q < RS_EPT / 4; q++) v[q] = kv[q * MSX_BLOCK + threadIdx.x];
+#pragma unroll
+		for (int q = 0; q < RS_EPT / 4; q++) {
+			atomicAdd(&s_cnt[w][(v[q].x >> shift) & 255u], 1u);
+			atomicAdd(&s_cnt[w][(v[q].y >> shift) & 255u], 1u);
+			atomicAdd(&s_cnt[w][(v[q].z >> shift) & 255u], 1u);
+			atomicAdd(&s_cnt[w][(v[q].w >> shift) & 255u], 1u);
+		}
+	} else {
+		for (int q = 0; q < RS_EPT; q++) {
+			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
+			if (k < E) atomicAdd(&s_cnt[w][(keys[k] >> shift) & 255u], 1u);
+		}
 	}
-	for (int q = 0; q < 4; q++) {
-		const int d = lane + 64 * q;
-		hist[(int64_t)d * n_waves + wave] = s_cnt[w][d];
-	}
+	__syncthreads();
+	const int d = threadIdx.x;
+	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
@@ -59,26 +80,36 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
                                                           uint32_t *__restrict__ keys_out,
                                                           uint32_t *__restrict__ vals_out,
                                                           const unsigned long long *__restrict__ n_ptr, int shift,
-                                                          const uint32_t *__restrict__ hoff, int64_t n_waves) {
-	__shared__ uint32_t s_base[MSX_BLOCK / 64][256];
+                                                          const uint32_t *__restrict__ hoff, int64_t n_tiles) {
+	__shared__ uint32_t s_key[RS_TILE];
+	__shared__ uint32_t s_val[RS_TILE];
+	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];   // per wave: running digit counts, then the wave's offset
+	__shared__ uint32_t s_dstart[256];                // first position of the digit inside the sorted tile
+	__shared__ uint32_t s_gbase[256];                 // global position of the digit's run minus s_dstart
+	__shared__ uint32_t s_wsum[MSX_BLOCK / 64];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int64_t wave = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + w;
-	if (wave >= n_waves) return;
+	const int64_t tile = blockIdx.x;
 	const int64_t E = (int64_t)*n_ptr;
-	for (int q = 0; q < 4; q++) {
-		const int d = lane + 64 * q;
-		s_base[w][d] = hoff[(int64_t)d * n_waves + wave];
+	const int64_t base = tile * RS_TILE;
+	if (base >= E) return;
+	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
+	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
+	// 1. all loads up front; wave w owns elements [w*RS_EPT*64, (w+1)*RS_EPT*64) of the tile
+	uint32_t key[RS_EPT], val[RS_EPT];
+	const uint32_t wbase = (uint32_t)w * (RS_EPT * 64) + (uint32_t)lane;
+#pragma unroll
+	for (int r = 0; r < RS_EPT; r++) {
+		const uint32_t i = wbase + (uint32_t)r * 64u;
+		key[r] = 0; val[r] = 0;
+		if (i < n_here) { key[r] = keys_in[base + i]; val[r] = vals_in[base + i]; }
 	}
+	// 2. rank inside the wave
 	const unsigned long long lt = (1ull << lane) - 1ull;
-	const int64_t base = wave * RS_WAVE_ELEMS;
-	for (int row = 0; row < RS_ROWS; row++) {
-		const int64_t k = base + row * 64 + lane;
-		const bool valid = k < E;
-		if (__ballot(valid) == 0ull) break;
-		uint32_t key = 0, val = 0;
-		if (valid) { key = keys_in[k]; val = vals_in[k]; }
-		const uint32_t d = (key >> shift) & 255u;
-		// lanes of this row with the same digit, in lane order (stable)
+	uint32_t pos[RS_EPT];
+#pragma unroll
+	for (int r = 0; r < RS_EPT; r++) {
+		const bool valid = wbase + (uint32_t)r * 64u < n_here;
+		const uint32_t d = (key[r] >> shift) & 255u;
 		unsigned long long m = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < 8; b++) {
@@ -88,12 +119,53 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		}
 		const uint32_t rank = (uint32_t)__popcll(m & lt);
 		const uint32_t cnt = (uint32_t)__popcll(m);
-		uint32_t pos = 0;
-		if (valid) pos = s_base[w][d];                 // every lane reads before the leader writes
-		if (valid && rank == 0) s_base[w][d] = pos + cnt;
-		if (valid) {
-			keys_out[pos + rank] = key;
-			vals_out[pos + rank] = val;
+		uint32_t p0 = 0;
+		if (valid) p0 = s_cnt[w][d];                       // every lane reads before the leader writes
+		if (valid && rank == 0) s_cnt[w][d] = p0 + cnt;
+		pos[r] = p0 + rank;
+	}
+	__syncthreads();
+	// 3. digit d = threadIdx.x: offsets of the four waves inside the digit, digit starts inside the tile
+	{
+		const int d = threadIdx.x;
+		const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+		const uint32_t tot = c0 + c1 + c2 + c3;
+		uint32_t inc = tot;                                // inclusive scan over the 256 digits
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		if (lane == 63) s_wsum[w] = inc;
+		s_cnt[0][d] = 0; s_cnt[1][d] = c0; s_cnt[2][d] = c0 + c1; s_cnt[3][d] = c0 + c1 + c2;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (int q = 0; q < w; q++) woff += s_wsum[q];
+		const uint32_t ds = woff + inc - tot;
+		s_dstart[d] = ds;
+		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] - ds;
+	}
+	__syncthreads();
+	// 4. the tile in digit order, in LDS
+#pragma unroll
+	for (int r = 0; r < RS_EPT; r++) {
+		if (wbase + (uint32_t)r * 64u < n_here) {
+			const uint32_t d = (key[r] >> shift) & 255u;
+			const uint32_t p = s_dstart[d] + s_cnt[w][d] + pos[r];
+			s_key[p] = key[r];
+			s_val[p] = val[r];
+		}
+	}
+	__syncthreads();
+	// 5. out: position p of the sorted tile goes to its digit's global run
+#pragma unroll
+	for (int q = 0; q < RS_EPT; q++) {
+		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
+		if (p < n_here) {
+			const uint32_t k = s_key[p];
+			const uint32_t dst = s_gbase[(k >> shift) & 255u] + p;
+			keys_out[dst] = k;
+			vals_out[dst] = s_val[p];
 		}
 	}
 }
@@ -482,8 +554,8 @@ static int nf_grid(msx_ctx *ctx, int32_t nf) {
 static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, const uint32_t *vin, int vin_buf,
                             const unsigned long long *n_ptr, int64_t n_ub, int bits, int *out_buf) {
 	const int passes = (bits + 7) / 8;
-	const int64_t n_waves = (n_ub + RS_WAVE_ELEMS - 1) / RS_WAVE_ELEMS;
-	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
+	const int64_t n_waves = (n_ub + RS_TILE - 1) / RS_TILE;   // tiles
+	const unsigned nblk = (unsigned)n_waves;
 	int cur = vin_buf, rc;
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
@@ -519,7 +591,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * sw + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * sw + 8) * 8))) return rc;
 	}
-	const int64_t n_waves = (eub + RS_WAVE_ELEMS - 1) / RS_WAVE_ELEMS;
+	const int64_t n_waves = ((eub > lub ? eub : lub) + RS_TILE - 1) / RS_TILE;
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16) * 4))) return rc;
 	const unsigned long long *tot = p->csr_tot;
