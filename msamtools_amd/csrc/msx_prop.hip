@@ -23,17 +23,6 @@
 // ---------------------------------------------------------------------------
 // build: (feature, list) pairs, stable radix sort by feature
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(MSX_BLOCK) void k_entry_lists(const unsigned long long *__restrict__ csr_tot,
-                                                           const uint32_t *__restrict__ m_off,
-                                                           uint32_t *__restrict__ e_list) {
-	const int64_t n_lists = (int64_t)csr_tot[0];
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
-		const uint32_t s = m_off[j], e = m_off[j + 1];
-		for (uint32_t k = s; k < e; ++k) e_list[k] = (uint32_t)j;
-	}
-}
-
 // One radix pass (8-bit digit) = k_rs_hist + scan + k_rs_scatter, both on tiles of
 // RS_TILE consecutive elements per 256-thread workgroup.
 //   k_rs_hist     per-tile digit counts, hist[digit * n_tiles + tile]; keys read as 16-B vectors
@@ -188,61 +177,116 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 	return x;
 }
 
+// Signature of a list: sets of <= 3 features (the common case) are packed exactly --
+// three 21-bit fields in ascending order, unused fields = SIG_PAD -- so that equal
+// signatures mean equal sets and the set itself can be rebuilt from the signature;
+// anything else gets bit 63 and a hash, and is compared entry by entry.
+#define SIG_PAD 0x1fffffu
+#define SIG_HASHED (1ull << 63)
+
+__device__ __forceinline__ uint32_t sig_len(unsigned long long sg) {
+	return 1u + (((sg >> 21) & SIG_PAD) != SIG_PAD) + (((sg >> 42) & SIG_PAD) != SIG_PAD);
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long *__restrict__ csr_tot,
                                                         const uint32_t *__restrict__ m_off,
                                                         const int32_t *__restrict__ m_fid, int hash_bits,
-                                                        uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+                                                        uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                        unsigned long long *__restrict__ sig) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
 		const uint32_t s = m_off[j], e = m_off[j + 1];
-		uint32_t mn = 0xffffffffu, h = (e - s) * 0x9e3779b9u;
-		for (uint32_t k = s; k < e; ++k) {
-			const uint32_t f = (uint32_t)m_fid[k];
-			mn = f < mn ? f : mn;
-			h += mix32(f);                                   // commutative: a hash of the set
+		uint32_t mn = 0xffffffffu, h = (e - s) * 0x9e3779b9u, h2 = (e - s) * 0x85ebca6bu;
+		unsigned long long sg;
+		if (e - s <= 3u) {
+			// independent loads, then a 3-element sorting network
+			uint32_t f0 = SIG_PAD, f1 = SIG_PAD, f2 = SIG_PAD;
+			if (e - s > 0u) f0 = (uint32_t)m_fid[s];
+			if (e - s > 1u) f1 = (uint32_t)m_fid[s + 1];
+			if (e - s > 2u) f2 = (uint32_t)m_fid[s + 2];
+			const bool fits = (e - s > 0u) && f0 < SIG_PAD && (e - s < 2u || f1 < SIG_PAD) && (e - s < 3u || f2 < SIG_PAD);
+			if (e - s > 0u) { h += mix32(f0); h2 += mix32(f0 ^ 0x5bd1e995u); }
+			if (e - s > 1u) { h += mix32(f1); h2 += mix32(f1 ^ 0x5bd1e995u); }
+			if (e - s > 2u) { h += mix32(f2); h2 += mix32(f2 ^ 0x5bd1e995u); }
+			uint32_t a = f0, b = f1, c = f2, t;
+			if (a > b) { t = a; a = b; b = t; }
+			if (b > c) { t = b; b = c; c = t; }
+			if (a > b) { t = a; a = b; b = t; }
+			mn = a;
+			sg = fits ? ((unsigned long long)a | ((unsigned long long)b << 21) | ((unsigned long long)c << 42))
+			          : (SIG_HASHED | ((unsigned long long)h2 << 31) | (h >> 1));
+			if (e == s) mn = 0xffffffffu;
+		} else {
+			for (uint32_t k = s; k < e; ++k) {
+				const uint32_t f = (uint32_t)m_fid[k];
+				mn = f < mn ? f : mn;
+				h += mix32(f);                                   // commutative: a hash of the set
+				h2 += mix32(f ^ 0x5bd1e995u);
+			}
+			sg = SIG_HASHED | ((unsigned long long)h2 << 31) | (h >> 1);
 		}
 		const uint32_t hb = hash_bits > 0 ? (h & ((1u << hash_bits) - 1u)) : 0u;
 		key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
 		val[j] = (uint32_t)j;
+		sig[j] = sg;
 	}
 }
 
 // head[i] = 1 when the list at sorted position i is not the same set as its predecessor;
-// len2[i] = its length for heads, 0 for merged duplicates (and beyond the last list)
+// len2[i] = its length for heads, 0 for merged duplicates (and beyond the last list);
+// ssig[i] = its signature (sorted order, for k_uniq_gather)
 __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long *__restrict__ csr_tot, int64_t m,
                                                         const uint32_t *__restrict__ skey,
                                                         const uint32_t *__restrict__ perm,
+                                                        const unsigned long long *__restrict__ sig,
                                                         const uint32_t *__restrict__ m_off,
                                                         const int32_t *__restrict__ m_fid,
-                                                        uint32_t *__restrict__ head, uint32_t *__restrict__ len2) {
+                                                        uint32_t *__restrict__ head, uint32_t *__restrict__ len2,
+                                                        unsigned long long *__restrict__ ssig) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < m; i += stride) {
+	const int lane = threadIdx.x & 63;
+	for (int64_t i0 = (int64_t)blockIdx.x * MSX_BLOCK; i0 < m; i0 += stride) {
+		const int64_t i = i0 + threadIdx.x;
+		const bool in = i < n_lists;
+		uint32_t j = 0;
+		unsigned long long sg = 0;
+		if (in) { j = perm[i]; sg = sig[j]; }
+		// the predecessor's signature: the lane below has it, except for lane 0
+		unsigned long long prev = __shfl_up(sg, 1, 64);
+		if (in && lane == 0 && i > 0) prev = sig[perm[i - 1]];
 		uint32_t hd = 0, l = 0;
-		if (i < n_lists) {
-			const uint32_t j = perm[i];
-			const uint32_t s = m_off[j], e = m_off[j + 1];
-			l = e - s;
+		if (in) {
 			hd = 1;
-			if (i > 0 && skey[i] == skey[i - 1] && l <= 32u) {
-				const uint32_t jp = perm[i - 1];
-				const uint32_t sp = m_off[jp], ep = m_off[jp + 1];
-				if (ep - sp == l) {
-					// both lists hold distinct features, so equal sizes + inclusion = equal sets
-					bool same = true;
-					for (uint32_t k = s; k < e && same; ++k) {
-						const int32_t f = m_fid[k];
-						bool found = false;
-						for (uint32_t q = sp; q < ep; ++q) found |= (m_fid[q] == f);
-						same = found;
+			if (!(sg & SIG_HASHED)) {
+				l = sig_len(sg);
+				if (i > 0 && sg == prev) hd = 0;                  // exact: equal signature = equal set
+			} else {
+				const uint32_t s = m_off[j], e = m_off[j + 1];
+				l = e - s;
+				if (i > 0 && sg == prev && skey[i] == skey[i - 1] && l <= 32u) {
+					const uint32_t jp = perm[i - 1];
+					const uint32_t sp = m_off[jp], ep = m_off[jp + 1];
+					if (ep - sp == l) {
+						// both lists hold distinct features, so equal sizes + inclusion = equal sets
+						bool same = true;
+						for (uint32_t k = s; k < e && same; ++k) {
+							const int32_t f = m_fid[k];
+							bool found = false;
+							for (uint32_t q = sp; q < ep; ++q) found |= (m_fid[q] == f);
+							same = found;
+						}
+						if (same) hd = 0;
 					}
-					if (same) hd = 0;
 				}
 			}
 		}
-		head[i] = hd;
-		len2[i] = hd ? l : 0u;
+		if (i < m) {
+			head[i] = hd;
+			len2[i] = hd ? l : 0u;
+			if (in) ssig[i] = sg;
+		}
 	}
 }
 
@@ -253,21 +297,34 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
                                                            const uint32_t *__restrict__ head,
                                                            const uint32_t *__restrict__ uidx,
                                                            const uint32_t *__restrict__ eoff,
+                                                           const unsigned long long *__restrict__ ssig,
                                                            const uint32_t *__restrict__ m_off,
                                                            const int32_t *__restrict__ m_fid,
                                                            uint32_t *__restrict__ d_off, int32_t *__restrict__ d_fid,
+                                                           uint32_t *__restrict__ e_list,
                                                            uint32_t *__restrict__ hpos, int64_t m,
                                                            unsigned long long *__restrict__ d_tot) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n_lists; i += stride) {
 		if (!head[i]) continue;
-		const uint32_t u = uidx[i], j = perm[i];
-		const uint32_t s = m_off[j], e = m_off[j + 1];
+		const uint32_t u = uidx[i];
 		uint32_t o = eoff[i];
+		const unsigned long long sg = ssig[i];
 		d_off[u] = o;
 		hpos[u] = (uint32_t)i;
-		for (uint32_t k = s; k < e; ++k) d_fid[o++] = m_fid[k];
+		if (!(sg & SIG_HASHED)) {
+			// the set is in the signature (ascending feature order)
+			const uint32_t a = (uint32_t)(sg & SIG_PAD), b = (uint32_t)((sg >> 21) & SIG_PAD),
+			               c = (uint32_t)((sg >> 42) & SIG_PAD);
+			d_fid[o] = (int32_t)a; e_list[o] = u; o++;
+			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_list[o] = u; o++; }
+			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_list[o] = u; }
+		} else {
+			const uint32_t j = perm[i];
+			const uint32_t s = m_off[j], e = m_off[j + 1];
+			for (uint32_t k = s; k < e; ++k) { d_fid[o] = m_fid[k]; e_list[o] = u; o++; }
+		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		const uint32_t U = uidx[m], E2 = eoff[m];
@@ -599,6 +656,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
 
 	// (a) derived store: lists ordered by (smallest feature, set hash), identical sets merged
+	int ebuf = 1;
 	{
 		int hash_bits = 32 - bits;
 		if (hash_bits > 12) hash_bits = 12;
@@ -610,10 +668,13 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if ((rc = msx_reserve(ctx, &p->uidx, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->eoff, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->hpos, (size_t)(lub + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->sig, (size_t)(lub + 8) * 8))) return rc;
+		if ((rc = msx_reserve(ctx, &p->ssig, (size_t)(lub + 8) * 8))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_list_key, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
 		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits,
-		                             (uint32_t *)p->t_key[0].p, (uint32_t *)p->t_val[0].p));
+		                             (uint32_t *)p->t_key[0].p, (uint32_t *)p->t_val[0].p,
+		                             (unsigned long long *)p->sig.p));
 		int sb = 0;
 		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p, (const uint32_t *)p->t_val[0].p, 0, tot + 0,
 		                           lub, bits + hash_bits, &sb)))
@@ -622,32 +683,34 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		const uint32_t *perm = (const uint32_t *)p->t_val[sb].p;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_dup_mark, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
-		                             lub, skey, perm, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
-		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p));
+		                             lub, skey, perm, (const unsigned long long *)p->sig.p,
+		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p, (unsigned long long *)p->ssig.p));
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub))) return rc;
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub))) return rc;
+		// the (feature, list) pairs of the derived store are written as it is built: features to
+		// m_fid_alt, list numbers to the value buffer the list sort is not holding its result in
+		ebuf = sb ^ 1;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_uniq_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                             tot, perm, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
-		                             (const uint32_t *)p->eoff.p, (const uint32_t *)p->m_off.p,
-		                             (const int32_t *)p->m_fid.p, (uint32_t *)p->m_off_alt.p,
-		                             (int32_t *)p->m_fid_alt.p, (uint32_t *)p->hpos.p, lub, p->d_tot));
+		                             (const uint32_t *)p->eoff.p, (const unsigned long long *)p->ssig.p,
+		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		                             (uint32_t *)p->m_off_alt.p, (int32_t *)p->m_fid_alt.p,
+		                             (uint32_t *)p->t_val[ebuf].p, (uint32_t *)p->hpos.p, lub, p->d_tot));
 	}
 	tot = p->d_tot;      // everything below works on the derived store
 
 	// (b) feature-major view: (feature, list) pairs sorted by feature
-	MSX_TIMED(ctx, MSX_K_RS_HIST,
-	          hipLaunchKernelGGL(k_entry_lists, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             tot, (const uint32_t *)p->m_off_alt.p, (uint32_t *)p->t_val[0].p));
-	int cur = 0;
+	int cur = ebuf;
 	if (bits > 0) {
-		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_fid_alt.p, (const uint32_t *)p->t_val[0].p, 0, tot + 1,
-		                           eub, bits, &cur)))
+		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_fid_alt.p, (const uint32_t *)p->t_val[ebuf].p, ebuf,
+		                           tot + 1, eub, bits, &cur)))
 			return rc;
 	} else {
 		// a single feature: the list-major order is already feature-major
 		size_t nb = (size_t)eub * 4 < p->m_fid_alt.cap ? (size_t)eub * 4 : p->m_fid_alt.cap;
-		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[0].p, p->m_fid_alt.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[ebuf].p, p->m_fid_alt.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
 	}
 	p->sorted_buf = cur;
 	p->transposed_valid = true;
