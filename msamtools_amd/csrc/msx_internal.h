@@ -73,7 +73,7 @@ struct msx_ctx {
 	int num_cu = 256;
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
 	// workspace, grown on demand and kept
-	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, mlen, moff, tmp_fid;
+	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, mlen, moff, tmp_fid, ukey, ukey2;
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;
@@ -163,5 +163,8 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p);        // share[f] = sum_j
 int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
+// ui[key] += add for every key != 0xffffffff of keys[0..n) by partition + LDS counting (n_features <= 2 M)
+int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add);
+#define MSX_COUNT_KEYS_MAX_FEATURES (256 * 8192)
 
 #endif

@@ -25,6 +25,8 @@ struct CountArgs {
 	int32_t *tmp_fid;         // [n_records] scratch: pool g's distinct features at tmp_fid[group_off[g]..]
 	unsigned long long *mlen; // [n_groups] (is_multi_list << 32) | n_distinct  (0 when not kept)
 	uint32_t tbl_mask;        // LDS staging table size - 1 (power of two, <= UI_TBL)
+	uint32_t *ukey;           // non-null: [n_groups] feature of a uniquely mapped insert (else 0xffffffff),
+	                          // counted afterwards by msx_count_keys instead of ui_add here
 };
 
 // Per-workgroup staging of the per-reference adds in LDS: a small open-addressed
@@ -154,10 +156,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 					if (A.keep[i] == pass) visit(i);
 		}
 		unsigned long long ml = 0;
+		uint32_t uk = 0xffffffffu;
 		if (nvalid > 0) {
 			c_ins++;                                          // one insert per pool (:230,:237)
 			if (nd == 1) {                                    // :75-78, :87-91, :152-159
-				ui_add(s_key, s_val, A.ui, f0, 2u, A.tbl_mask);
+				if (A.ukey) uk = (uint32_t)f0;
+				else ui_add(s_key, s_val, A.ui, f0, 2u, A.tbl_mask);
 				c_uniq++;
 			} else {
 				c_multi++;                                    // :95, :162
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 			}
 		}
 		if (A.mlen) A.mlen[g] = ml;
+		if (A.ukey) A.ukey[g] = uk;
 	}
 	// one set of counter atomics per workgroup
 	for (int d = 32; d > 0; d >>= 1) {
@@ -374,9 +379,20 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 		}
 		A.tbl_mask = (uint32_t)tbl - 1u;
 	}
+	// uniquely mapped inserts: counted by partition when there are enough of them and the features
+	// are too many for the staging tables to absorb (MSX_COUNT_BY_PARTITION=0/1 overrides)
+	bool by_part = p->n_features > 100000 && p->n_features <= MSX_COUNT_KEYS_MAX_FEATURES && ng >= (1 << 20);
+	if (const char *e = getenv("MSX_COUNT_BY_PARTITION"))
+		by_part = atoi(e) != 0 && p->n_features <= MSX_COUNT_KEYS_MAX_FEATURES;
+	if (by_part) {
+		if ((rc = msx_reserve(ctx, &ctx->ukey, (size_t)(ng + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &ctx->ukey2, (size_t)(ng + 8) * 4))) return rc;
+		A.ukey = (uint32_t *)ctx->ukey.p;
+	}
 	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
 	hipLaunchKernelGGL(k_insert_count, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A);
 	msx_time_end(ctx);
+	if (by_part && (rc = msx_count_keys(ctx, p, (const uint32_t *)ctx->ukey.p, (uint32_t *)ctx->ukey2.p, ng, 2u))) return rc;
 	if (prop) {
 		if ((rc = msx_scan_u64(ctx, (const uint64_t *)ctx->mlen.p, (uint64_t *)ctx->moff.p, ng))) return rc;
 		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);

@@ -32,16 +32,28 @@
 //                 order and writes it out from there: consecutive threads write consecutive
 //                 addresses inside a digit's run instead of 64 scattered 4-byte stores per row.
 // Order inside a digit is (wave, row, lane) = input order, so the pass is stable.
+// SKIP: keys equal to RS_NOKEY are not part of the input (k_part_count's producer marks
+// pools without a key that way); n_ptr == nullptr: the element count is n_host.
+#define RS_NOKEY 0xffffffffu
+template <bool SKIP>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restrict__ keys,
-                                                       const unsigned long long *__restrict__ n_ptr, int shift,
-                                                       uint32_t *__restrict__ hist, int64_t n_tiles) {
+                                                       const unsigned long long *__restrict__ n_ptr, int64_t n_host,
+                                                       int shift, uint32_t *__restrict__ hist, int64_t n_tiles) {
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t tile = blockIdx.x;
-	const int64_t E = (int64_t)*n_ptr;
+	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	const int64_t base = tile * RS_TILE;
-	if (base + RS_TILE <= E) {
+	if (SKIP) {
+		for (int q = 0; q < RS_EPT; q++) {
+			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
+			if (k < E) {
+				const uint32_t key = keys[k];
+				if (key != RS_NOKEY) atomicAdd(&s_cnt[w][(key >> shift) & 255u], 1u);
+			}
+		}
+	} else if (base + RS_TILE <= E) {
 		const uint4 *kv = reinterpret_cast<const uint4 *>(keys + base);
 		uint4 v[RS_EPT / 4];
 #pragma unroll
@@ -64,21 +76,24 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
+template <bool PAIRS, bool SKIP>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
                                                           const uint32_t *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
                                                           uint32_t *__restrict__ vals_out,
-                                                          const unsigned long long *__restrict__ n_ptr, int shift,
-                                                          const uint32_t *__restrict__ hoff, int64_t n_tiles) {
+                                                          const unsigned long long *__restrict__ n_ptr, int64_t n_host,
+                                                          int shift, const uint32_t *__restrict__ hoff,
+                                                          int64_t n_tiles) {
 	__shared__ uint32_t s_key[RS_TILE];
-	__shared__ uint32_t s_val[RS_TILE];
+	__shared__ uint32_t s_val[PAIRS ? RS_TILE : 1];
+	__shared__ uint32_t s_nvalid;
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];   // per wave: running digit counts, then the wave's offset
 	__shared__ uint32_t s_dstart[256];                // first position of the digit inside the sorted tile
 	__shared__ uint32_t s_gbase[256];                 // global position of the digit's run minus s_dstart
 	__shared__ uint32_t s_wsum[MSX_BLOCK / 64];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t tile = blockIdx.x;
-	const int64_t E = (int64_t)*n_ptr;
+	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
 	const int64_t base = tile * RS_TILE;
 	if (base >= E) return;
 	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
@@ -89,15 +104,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const uint32_t i = wbase + (uint32_t)r * 64u;
-		key[r] = 0; val[r] = 0;
-		if (i < n_here) { key[r] = keys_in[base + i]; val[r] = vals_in[base + i]; }
+		key[r] = SKIP ? RS_NOKEY : 0u; val[r] = 0;
+		if (i < n_here) {
+			key[r] = keys_in[base + i];
+			if (PAIRS) val[r] = vals_in[base + i];
+		}
 	}
 	// 2. rank inside the wave
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	uint32_t pos[RS_EPT];
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
-		const bool valid = wbase + (uint32_t)r * 64u < n_here;
+		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || key[r] != RS_NOKEY);
 		const uint32_t d = (key[r] >> shift) & 255u;
 		unsigned long long m = __ballot(valid);
 #pragma unroll
@@ -133,30 +151,106 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		const uint32_t ds = woff + inc - tot;
 		s_dstart[d] = ds;
 		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] - ds;
+		if (d == 255) s_nvalid = ds + tot;
 	}
 	__syncthreads();
 	// 4. the tile in digit order, in LDS
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
-		if (wbase + (uint32_t)r * 64u < n_here) {
+		if ((wbase + (uint32_t)r * 64u < n_here) && (!SKIP || key[r] != RS_NOKEY)) {
 			const uint32_t d = (key[r] >> shift) & 255u;
 			const uint32_t p = s_dstart[d] + s_cnt[w][d] + pos[r];
 			s_key[p] = key[r];
-			s_val[p] = val[r];
+			if (PAIRS) s_val[p] = val[r];
 		}
 	}
 	__syncthreads();
 	// 5. out: position p of the sorted tile goes to its digit's global run
+	const uint32_t n_out = SKIP ? s_nvalid : n_here;
 #pragma unroll
 	for (int q = 0; q < RS_EPT; q++) {
 		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
-		if (p < n_here) {
+		if (p < n_out) {
 			const uint32_t k = s_key[p];
 			const uint32_t dst = s_gbase[(k >> shift) & 255u] + p;
 			keys_out[dst] = k;
-			vals_out[dst] = s_val[p];
+			if (PAIRS) vals_out[dst] = s_val[p];
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------
+// Per-reference insert counts without one global atomic per insert: the keys
+// (feature of every uniquely mapped insert, RS_NOKEY for the other pools) are
+// partitioned by their high bits in one radix pass, then every partition --
+// <= PC_RANGE consecutive features -- is counted in LDS and added to ui[] with
+// one write per feature.  (Scattered atomics run memory-side at ~27 G/s on this
+// chip whatever their locality; 20 M of them cost more than the two passes.)
+// ---------------------------------------------------------------------------
+#define PC_RANGE 8192          // features per partition at most (32 KB of LDS counters)
+#define PC_SPLIT 64            // a partition is shared by at most this many workgroups
+#define PC_CHUNK 32768u        // keys per workgroup before a partition is split
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_part_count(const uint32_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ hoff, int64_t n_tiles,
+                                                          int shift, int32_t nf, uint32_t add,
+                                                          uint32_t *__restrict__ ui) {
+	__shared__ uint32_t s_cnt[PC_RANGE];
+	const uint32_t d = blockIdx.y, b = blockIdx.x;
+	const uint32_t start = hoff[(int64_t)d * n_tiles], end = hoff[(int64_t)(d + 1) * n_tiles];
+	const uint32_t size = end - start;
+	uint32_t chunk = (size + PC_SPLIT - 1) / PC_SPLIT;
+	if (chunk < PC_CHUNK) chunk = PC_CHUNK;
+	const uint64_t lo64 = (uint64_t)start + (uint64_t)b * chunk;
+	if (lo64 >= end) return;
+	const uint32_t lo = (uint32_t)lo64, hi = (end - lo > chunk) ? lo + chunk : end;
+	const uint32_t range = 1u << shift, mask = range - 1u;
+	for (uint32_t i = threadIdx.x; i < range; i += MSX_BLOCK) s_cnt[i] = 0;
+	__syncthreads();
+	uint32_t k = lo + threadIdx.x;
+	for (; k + 3u * MSX_BLOCK < hi; k += 4u * MSX_BLOCK) {
+		const uint32_t k0 = keys[k], k1 = keys[k + MSX_BLOCK], k2 = keys[k + 2 * MSX_BLOCK], k3 = keys[k + 3 * MSX_BLOCK];
+		atomicAdd(&s_cnt[k0 & mask], add);
+		atomicAdd(&s_cnt[k1 & mask], add);
+		atomicAdd(&s_cnt[k2 & mask], add);
+		atomicAdd(&s_cnt[k3 & mask], add);
+	}
+	for (; k < hi; k += MSX_BLOCK) atomicAdd(&s_cnt[keys[k] & mask], add);
+	__syncthreads();
+	const bool alone = size <= chunk;                      // this workgroup owns the whole partition
+	for (uint32_t i = threadIdx.x; i < range; i += MSX_BLOCK) {
+		const uint32_t c = s_cnt[i];
+		const uint32_t f = (d << shift) + i;
+		if (c && f < (uint32_t)nf) {
+			if (alone) ui[f] += c;
+			else atomicAdd(&ui[f], c);
+		}
+	}
+}
+
+// ui[key] += add for every key != RS_NOKEY among keys[0..n); keys < nf <= 256 * PC_RANGE.
+// key2 = scratch of n keys.
+int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add) {
+	int shift = 0;
+	while (((int64_t)256 << shift) < (int64_t)p->n_features) shift++;
+	if ((1 << shift) > PC_RANGE) return msx_fail(ctx, MSX_ERR_ARG, "msx_count_keys: too many features");
+	const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
+	int rc;
+	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_tiles + 16) * 4))) return rc;
+	MSX_TIMED(ctx, MSX_K_INSERT_COUNT,
+	          hipLaunchKernelGGL(k_rs_hist<true>, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, keys,
+	                             (const unsigned long long *)nullptr, n, shift, (uint32_t *)p->rs_hist.p, n_tiles));
+	if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_tiles))) return rc;
+	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
+	hipLaunchKernelGGL((k_rs_scatter<false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, keys,
+	                   (const uint32_t *)nullptr, key2, (uint32_t *)nullptr, (const unsigned long long *)nullptr, n,
+	                   shift, (const uint32_t *)p->rs_off.p, n_tiles);
+	hipLaunchKernelGGL(k_part_count, dim3(PC_SPLIT, 256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)key2,
+	                   (const uint32_t *)p->rs_off.p, n_tiles, shift, p->n_features, add, p->ui);
+	msx_time_end(ctx);
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
 }
 
 // --- derived multi-mapper store: renumbered for locality, duplicates merged ---------
@@ -617,14 +711,14 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
 		MSX_TIMED(ctx, MSX_K_RS_HIST,
-		          hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr, ps * 8,
-		                             (uint32_t *)p->rs_hist.p, n_waves));
+		          hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr,
+		                             (int64_t)0, ps * 8, (uint32_t *)p->rs_hist.p, n_waves));
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
 			return rc;
 		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
-		          hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
-		                             (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, n_ptr, ps * 8,
-		                             (const uint32_t *)p->rs_off.p, n_waves));
+		          hipLaunchKernelGGL((k_rs_scatter<true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
+		                             (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, n_ptr, (int64_t)0,
+		                             ps * 8, (const uint32_t *)p->rs_off.p, n_waves));
 		kin = (const uint32_t *)p->t_key[dst].p;
 		vin = (const uint32_t *)p->t_val[dst].p;
 		cur = dst;
