@@ -461,9 +461,23 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
 		const uint32_t s = m_off[j], e = m_off[j + 1];
+		const uint32_t w = hpos[j + 1] - hpos[j];
 		double sum = 0;
-		for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
-		recip[j] = sum > 0 ? (double)(hpos[j + 1] - hpos[j]) / sum : 0.0;
+		if (e - s <= 4u) {
+			// short list: feature ids, then abundances, as independent loads; summed in list order
+			int32_t f[4];
+			double x[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) f[q] = (s + (uint32_t)q < e) ? m_fid[s + q] : -1;
+#pragma unroll
+			for (int q = 0; q < 4; q++) x[q] = (f[q] >= 0) ? a[f[q]] : 0.0;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				if (s + (uint32_t)q < e) sum += x[q];
+		} else {
+			for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
+		}
+		recip[j] = sum > 0 ? (double)w / sum : 0.0;
 	}
 }
 
@@ -508,6 +522,9 @@ __device__ __forceinline__ SegRow seg_row(uint32_t key, double v, bool valid, ui
 	return r;
 }
 
+#define SR_EPL 8                       // consecutive entries summed by one lane
+#define SR_STEP (64 * SR_EPL)          // entries per wave step
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const uint32_t *__restrict__ t_val,
@@ -519,6 +536,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	if (iter_state[0]) return;
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
+	// (consecutive workgroups -- which the dispatcher deals round-robin to the 8 XCDs -- take
+	// consecutive chunks; giving every XCD one contiguous eighth instead, to keep its gathers in one
+	// part of recip[], measured slower: 70 vs 65 us)
 	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
 	const int64_t c0 = wave * SR_CHUNK;
 	if (c0 >= E) {   // idle wave: neutral slots (sorted after every real feature id)
@@ -526,66 +546,112 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		return;
 	}
 	const int64_t c1 = (c0 + SR_CHUNK < E) ? c0 + SR_CHUNK : E;
+	// the open segment carried from step to step (its sum so far, whether it began inside this chunk)
 	double carry = 0.0;
 	bool carry_started = false, carry_open = false;
-	uint32_t carry_key = 0, first_key = 0;
+	uint32_t carry_key = 0, first_key = 0, prev_last = 0;
 	double slot_a = 0.0;          // partial of the chunk's first segment when it began in an earlier chunk
-	for (int64_t base = c0; base < c1; base += 64 * SR_ROWS_PER_STEP) {
-		uint32_t key[SR_ROWS_PER_STEP], val[SR_ROWS_PER_STEP];
-		bool valid[SR_ROWS_PER_STEP];
-		double v[SR_ROWS_PER_STEP];
+	const unsigned long long below = (1ull << lane) - 1ull;
+	for (int64_t base = c0; base < c1; base += SR_STEP) {
+		// ---- loads: SR_EPL consecutive entries per lane, then their reciprocals, all independent ----
+		const int64_t r0 = base + (int64_t)lane * SR_EPL;
+		uint32_t k[SR_EPL], lv[SR_EPL];
+		if (base + SR_STEP <= c1) {
+			const uint4 *kp = reinterpret_cast<const uint4 *>(t_key + r0);
+			const uint4 *vp = reinterpret_cast<const uint4 *>(t_val + r0);
+			const uint4 ka = kp[0], kb = kp[1], va = vp[0], vb = vp[1];
+			k[0] = ka.x; k[1] = ka.y; k[2] = ka.z; k[3] = ka.w; k[4] = kb.x; k[5] = kb.y; k[6] = kb.z; k[7] = kb.w;
+			lv[0] = va.x; lv[1] = va.y; lv[2] = va.z; lv[3] = va.w; lv[4] = vb.x; lv[5] = vb.y; lv[6] = vb.z; lv[7] = vb.w;
+		} else {
 #pragma unroll
-		for (int r = 0; r < SR_ROWS_PER_STEP; r++) {
-			const int64_t k = base + r * 64 + lane;
-			valid[r] = k < c1;
-			key[r] = valid[r] ? t_key[k] : SR_SENT;
-			val[r] = valid[r] ? t_val[k] : 0u;
+			for (int i = 0; i < SR_EPL; i++) {
+				const bool ok = r0 + i < c1;
+				k[i] = ok ? t_key[r0 + i] : SR_SENT;        // entries past the end: a neutral last segment
+				lv[i] = ok ? t_val[r0 + i] : 0u;
+			}
 		}
-		// global neighbours of the step: entry before lane 0 of row 0, entry after the last valid one
-		uint32_t before = SR_SENT, after = SR_SENT;
-		if (lane == 0) {
-			if (base > 0) before = t_key[base - 1];
-			const int64_t nxt = (base + 64 * SR_ROWS_PER_STEP < c1) ? base + 64 * SR_ROWS_PER_STEP : c1;
-			if (nxt < E) after = t_key[nxt];
-		}
-		before = __shfl(before, 0, 64);
-		after = __shfl(after, 0, 64);
+		uint32_t after = SR_SENT;                            // key of the entry following this step
+		if (lane == 63 && base + SR_STEP < E) after = t_key[base + SR_STEP];
+		uint32_t before = 0;
+		if (lane == 0 && base == c0 && c0 > 0) before = t_key[c0 - 1];
+		double x[SR_EPL];
 #pragma unroll
-		for (int r = 0; r < SR_ROWS_PER_STEP; r++) v[r] = valid[r] ? recip[val[r]] : 0.0;
-		if (base == c0) first_key = __shfl(key[0], 0, 64);
+		for (int i = 0; i < SR_EPL; i++) x[i] = (k[i] != SR_SENT) ? recip[lv[i]] : 0.0;
+
+		// ---- neighbours across lanes ----
+		uint32_t pk = __shfl_up(k[SR_EPL - 1], 1, 64);
+		if (lane == 0) pk = (base == c0) ? (c0 > 0 ? before : ~k[0]) : prev_last;
+		uint32_t nk = __shfl_down(k[0], 1, 64);
+		if (lane == 63) nk = after;
+		if (base == c0) first_key = __shfl(k[0], 0, 64);
+
+		// ---- the lane's run: head segment, complete interior segments, tail segment ----
+		const bool B = (k[0] != pk);                         // a segment starts at the lane's first entry
+		uint32_t cur = k[0];
+		const uint32_t head_key = k[0];
+		double run = x[0], head_sum = 0.0;
+		bool in_head = true;
 #pragma unroll
-		for (int r = 0; r < SR_ROWS_PER_STEP; r++) {
-			const int64_t rb = base + r * 64;
-			if (rb >= c1) break;
-			const int64_t k = rb + lane;
-			// previous / next keys: neighbours in the row, else the adjacent row, else the global ones
-			uint32_t pk = __shfl_up(key[r], 1, 64);
-			const uint32_t prow63 = __shfl(key[r > 0 ? r - 1 : 0], 63, 64);   // every lane takes part in the shuffle
-			if (lane == 0) pk = (r == 0) ? ((rb > 0) ? before : ~key[r]) : prow63;
-			uint32_t nk = __shfl_down(key[r], 1, 64);
-			const bool last_in_chunk = (k + 1 >= c1);
-			uint32_t nrow0 = (r + 1 < SR_ROWS_PER_STEP) ? __shfl(key[r + 1 < SR_ROWS_PER_STEP ? r + 1 : r], 0, 64) : after;
-			if (last_in_chunk) nk = (k + 1 < E) ? after : ~key[r];
-			else if (lane == 63) nk = nrow0;
-			const SegRow s = seg_row(key[r], v[r], valid[r], pk, nk, lane, carry, carry_started);
-			if (s.tail && s.started) share[key[r]] = s.v;        // whole feature inside this chunk
-			const unsigned long long cut = __ballot(s.tail && !s.started);
-			if (cut) slot_a = __shfl(s.v, __ffsll((long long)cut) - 1, 64);
-			const int64_t rem = c1 - rb - 1;
-			const int ll = rem < 63 ? (int)rem : 63;
-			const double cv = __shfl(s.v, ll, 64);
-			const int ct = __shfl((int)s.tail, ll, 64);
-			const int cs = __shfl((int)s.started, ll, 64);
-			carry_key = __shfl(key[r], ll, 64);
-			carry_open = !ct;
-			carry = ct ? 0.0 : cv;
-			carry_started = ct ? false : (cs != 0);
+		for (int i = 1; i < SR_EPL; i++) {
+			if (k[i] != cur) {
+				if (in_head) { head_sum = run; in_head = false; }
+				else if (cur != SR_SENT) share[cur] = run;   // began and ended inside this lane's run
+				cur = k[i];
+				run = x[i];
+			} else {
+				run += x[i];
+			}
 		}
+		const bool pass = in_head;                           // one key over the whole run
+		const bool G = B || !pass;                           // the tail segment starts in this lane
+		const bool Eend = (nk != cur);                       // ... and ends with this lane's last entry
+
+		// ---- segmented inclusive scan of the tail sums over the lanes ----
+		double v = run;
+		if (lane == 0 && !G) v += carry;
+		uint32_t f = (G || lane == 0) ? 1u : 0u;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const double ov = __shfl_up(v, d, 64);
+			const uint32_t of = __shfl_up(f, d, 64);
+			if (lane >= d && !f) { v += ov; f = of; }
+		}
+		double cin = __shfl_up(v, 1, 64);                    // what flows into this lane's first segment
+		if (lane == 0) cin = carry;
+		if (B) cin = 0.0;
+		const unsigned long long gb = __ballot(G);
+		const bool started_in = B ? true : (((gb & below) != 0ull) ? true : carry_started);
+		// head segment: ends inside this lane
+		if (!pass) {
+			const double tot = head_sum + cin;
+			if (started_in) { if (head_key != SR_SENT) share[head_key] = tot; }
+			else slot_a = tot;
+		}
+		// tail segment: v is its sum up to this lane's last entry
+		const bool started_tail = G ? true : started_in;
+		if (Eend) {
+			if (started_tail) { if (cur != SR_SENT) share[cur] = v; }
+			else slot_a = v;
+		}
+		// slot_a is set by at most one lane of the chunk: share it
+		{
+			const unsigned long long cut = __ballot((!pass && !started_in) || (Eend && !started_tail));
+			if (cut) slot_a = __shfl(slot_a, __ffsll((long long)cut) - 1, 64);
+		}
+		// carry out of lane 63
+		const double cv = __shfl(v, 63, 64);
+		const int ce = __shfl((int)Eend, 63, 64);
+		const int cs = __shfl((int)started_tail, 63, 64);
+		prev_last = __shfl(k[SR_EPL - 1], 63, 64);
+		carry_key = __shfl(cur, 63, 64);
+		carry_open = !ce;
+		carry = ce ? 0.0 : cv;
+		carry_started = ce ? false : (cs != 0);
 	}
 	if (lane == 0) {
 		part_key[2 * wave] = first_key;
 		part_val[2 * wave] = slot_a;
-		part_key[2 * wave + 1] = carry_key;
+		part_key[2 * wave + 1] = carry_open ? carry_key : SR_SENT;
 		part_val[2 * wave + 1] = carry_open ? carry : 0.0;
 	}
 }
@@ -738,7 +804,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	}
 	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
 	{
-		const int64_t sw = ((eub + SR_CHUNK - 1) / SR_CHUNK + 3) / 4 * 4;   // waves launched by k_share_reduce
+		const int64_t sw = (((eub + SR_CHUNK - 1) / SR_CHUNK + 3) / 4 + 7) / 8 * 8 * 4;   // waves launched by k_share_reduce
 		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * sw + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * sw + 8) * 8))) return rc;
 	}
@@ -821,7 +887,7 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
 	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p, (const double *)p->a,
 	                             (double *)p->recip.p, (const int32_t *)p->iter_state));
 	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
-	const unsigned nblk = (unsigned)((n_waves + 3) / 4);
+	const unsigned nblk = (unsigned)(((n_waves + 3) / 4 + 7) / 8 * 8);
 	const int64_t M = (int64_t)nblk * 4 * 2;              // two partial slots per launched wave
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
 	          hipLaunchKernelGGL(k_share_reduce, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream,
