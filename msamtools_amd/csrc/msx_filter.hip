@@ -70,7 +70,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 	__shared__ uint32_t s_coff[2][MSX_BLOCK + 1];
 	__shared__ uint32_t s_moff[2][MSX_BLOCK + 1];
 	__shared__ uint32_t s_cig[CAP_CIG];
-	__shared__ uint32_t s_md[CAP_MDW];
+	__shared__ uint32_t s_md[CAP_MDW + 2];    // +2: the realigned walk reads one word past a string's last
 
 	const int tid = threadIdx.x;
 	const int64_t n_tiles = (A.n + MSX_BLOCK - 1) / MSX_BLOCK;
@@ -179,19 +179,28 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 					for (uint32_t k = cs; k < ce; ++k) {
 						const uint32_t c = s_cig[k - c0];
 						const uint32_t op = c & 0xf, w = c >> 4;
-						alen += w & (0u - ((T_ALEN >> op) & 1u));
-						qlen += w & (0u - ((0x1b3u >> op) & 1u));      // M I S H = X
-						edit += w & (0u - ((T_EDIT >> op) & 1u));
-						qclip += w & (0u - ((0x030u >> op) & 1u));     // S H
+						alen += w & (uint32_t)__builtin_amdgcn_sbfe((int)T_ALEN, op, 1u);    // 0 or ~0: bit `op` of the table
+						qlen += w & (uint32_t)__builtin_amdgcn_sbfe(0x1b3, op, 1u);          // M I S H = X
+						edit += w & (uint32_t)__builtin_amdgcn_sbfe((int)T_EDIT, op, 1u);
+						qclip += w & (uint32_t)__builtin_amdgcn_sbfe(0x030, op, 1u);         // S H
 					}
 					if (mdp) {
-						MdState s = {0u, 0u, 0u, 0};
-						const uint32_t bs = s_moff[buf][tid] - m0a, be = s_moff[buf][tid + 1] - m0a;
-						for (uint32_t w = bs >> 2; (w << 2) < be; ++w) {
-							const uint32_t p = w << 2;
-							md_word(s, s_md[w], bs > p ? bs - p : 0u, be - p < 4u ? be - p : 4u);
+						// words realigned to the start of the string: full words, then one masked tail
+						MdBits s = {0u, 0u, 0u, 0u};
+						const uint32_t ms = s_moff[buf][tid], bs = ms - m0a, len = s_moff[buf][tid + 1] - ms;
+						const uint32_t sh = bs & 3u, nfull = len >> 2, rem = len & 3u;
+						uint32_t wi = bs >> 2;
+						uint32_t lo = s_md[wi];
+						for (uint32_t q = 0; q < nfull; ++q) {
+							const uint32_t hi = s_md[++wi];
+							md_word_aligned(s, MSX_ALIGNBYTE(hi, lo, sh), 0x80808080u);
+							lo = hi;
 						}
-						edit += (uint32_t)s.edit;
+						if (rem) {
+							const uint32_t hi = s_md[wi + 1];
+							md_word_aligned(s, MSX_ALIGNBYTE(hi, lo, sh), 0x80808080u >> (8u * (4u - rem)));
+						}
+						edit += s.edit;
 					} else if (!bad) {
 						edit = (uint32_t)A.nm[t];                      // msam_filter.c:155
 					} else {

@@ -1,4 +1,5 @@
-/* Host harness: the dword-at-a-time MD walk of the stats kernel (md_word) must
+/* Host harness: the dword-at-a-time MD walks of the stats kernel (md_word, and
+ * md_word_aligned on realigned words as the kernel's fast path forms them) must
  * agree with the byte-at-a-time rule (md_byte) on arbitrary byte strings at
  * every alignment.  Built and run by tests/test_md_swar_cpu.py. */
 #include <stdio.h>
@@ -26,6 +27,23 @@ int main(int argc, char **argv) {
 		}
 		for (i = 0; i < n; i++) md_byte(b, buf[off + i], 1);
 		if (a.edit != b.edit) bad++;
+		{
+			/* the fast path: words realigned to the start of the string, full words then one masked tail */
+			MdBits c = {0, 0, 0, 0};
+			const uint32_t sh = bs & 3u, w0 = bs >> 2, nfull = (uint32_t)n >> 2, rem = (uint32_t)n & 3u;
+			uint32_t lo, hi, q;
+			memcpy(&lo, buf + 4 * w0, 4);
+			for (q = 0; q < nfull; q++) {
+				memcpy(&hi, buf + 4 * (w0 + q + 1), 4);
+				md_word_aligned(c, MSX_ALIGNBYTE(hi, lo, sh), 0x80808080u);
+				lo = hi;
+			}
+			if (rem) {
+				memcpy(&hi, buf + 4 * (w0 + nfull + 1), 4);
+				md_word_aligned(c, MSX_ALIGNBYTE(hi, lo, sh), 0x80808080u >> (8u * (4u - rem)));
+			}
+			if ((int32_t)c.edit != b.edit) bad++;
+		}
 	}
 	printf("checked=%ld bad=%ld\n", iters, bad);
 	return bad != 0;
