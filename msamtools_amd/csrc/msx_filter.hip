@@ -93,22 +93,32 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 		const int64_t t0 = tile * MSX_BLOCK;
 		const int64_t left = A.n - t0;
 		const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
-		const uint32_t c0 = s_coff[buf][0];
-		uint32_t clen = s_coff[buf][nt] - c0;
+		// tile geometry is workgroup-uniform: keep it in scalar registers so that whole 256-word
+		// slices beyond the tile's payload are skipped by scalar branches, not predicated off
+		const uint32_t c0 = __builtin_amdgcn_readfirstlane(s_coff[buf][0]);
+		uint32_t clen = __builtin_amdgcn_readfirstlane(s_coff[buf][nt]) - c0;
 		if (clen > CAP_CIG) clen = CAP_CIG;
+		const uint32_t *cbase = A.cigar + c0;
 #pragma unroll
 		for (int q = 0; q < CIG_REGS; q++) {
-			const uint32_t w = tid + q * MSX_BLOCK;
-			cr[q] = (w < clen) ? A.cigar[c0 + w] : 0u;
+			cr[q] = 0u;
+			if ((uint32_t)(q * MSX_BLOCK) < clen) {
+				const uint32_t w = tid + q * MSX_BLOCK;
+				if (w < clen) cr[q] = cbase[w];
+			}
 		}
 		if (A.md_aligned) {
-			const uint32_t m0a = s_moff[buf][0] & ~3u;
-			uint32_t mw = (s_moff[buf][nt] - m0a + 3u) >> 2;
+			const uint32_t m0a = __builtin_amdgcn_readfirstlane(s_moff[buf][0]) & ~3u;
+			uint32_t mw = (__builtin_amdgcn_readfirstlane(s_moff[buf][nt]) - m0a + 3u) >> 2;
 			if (mw > CAP_MDW) mw = CAP_MDW;
+			const uint32_t *mbase = md4 + (m0a >> 2);
 #pragma unroll
 			for (int q = 0; q < MD_REGS; q++) {
-				const uint32_t w = tid + q * MSX_BLOCK;
-				mr[q] = (w < mw) ? md4[(m0a >> 2) + w] : 0u;
+				mr[q] = 0u;
+				if ((uint32_t)(q * MSX_BLOCK) < mw) {
+					const uint32_t w = tid + q * MSX_BLOCK;
+					if (w < mw) mr[q] = mbase[w];
+				}
 			}
 		}
 		if (tid < nt) { fl_n = A.flag[t0 + tid]; rf_n = A.rflags[t0 + tid]; }
@@ -140,20 +150,21 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 		const bool has_next = tile + step < n_tiles, has_next2 = tile + 2 * step < n_tiles;
 
 		// geometry of the staged payload of this tile
-		const uint32_t c0 = s_coff[buf][0];
-		uint32_t clen = s_coff[buf][nt] - c0;
+		const uint32_t c0 = __builtin_amdgcn_readfirstlane(s_coff[buf][0]);
+		const uint32_t c_end = __builtin_amdgcn_readfirstlane(s_coff[buf][nt]);
+		uint32_t clen = c_end - c0;
 		if (clen > CAP_CIG) clen = CAP_CIG;
-		uint32_t m0a = 0, mbytes = 0;
+		uint32_t m0a = 0, mbytes = 0, m_end = 0;
 		if (A.md_aligned) {
-			m0a = s_moff[buf][0] & ~3u;
-			uint32_t mw = (s_moff[buf][nt] - m0a + 3u) >> 2;
+			m0a = __builtin_amdgcn_readfirstlane(s_moff[buf][0]) & ~3u;
+			m_end = __builtin_amdgcn_readfirstlane(s_moff[buf][nt]);
+			uint32_t mw = (m_end - m0a + 3u) >> 2;
 			if (mw > CAP_MDW) mw = CAP_MDW;
 			mbytes = mw << 2;
 		}
 
 		// tile-uniform: every CIGAR word and MD byte of this tile was staged
-		const bool all_staged = A.md_aligned && (s_coff[buf][nt] - c0) <= CAP_CIG &&
-		                        (s_moff[buf][nt] - m0a) <= mbytes;
+		const bool all_staged = A.md_aligned && (c_end - c0) <= CAP_CIG && (m_end - m0a) <= mbytes;
 
 		// in flight while this tile is computed
 		if (has_next) issue_payload(buf ^ 1, tile + step);
