@@ -391,33 +391,56 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
 				ra[q] = __builtin_amdgcn_alignbyte(rw[q + 1], rw[q], bsh);
 				pa[q] = __builtin_amdgcn_alignbyte(pw[q + 1], pw[q], bsh);
 			}
-			// ---- pass 1: best score and ties per mate class ----
+			// ---- who takes part: code = mate bits | 0x100 (participates) | 0x200 (has AS) ----
+			uint32_t code[BH_WIN];
+			uint32_t paired = 0;
 #pragma unroll
 			for (int r = 0; r < BH_WIN; r++) {
-				if ((uint32_t)r < len) {
-					const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
-					const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
-					const bool pooled = A.pool ? (((pa[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0) : !(fl & MSX_F_UNMAP);
-					const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-					bh_count(c, s + (uint32_t)r, fl, pooled, has, sc[r]);
-				}
+				const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+				const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
+				const bool part = ((uint32_t)r < len) &&
+				                  (A.pool ? (((pa[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0) : !(fl & MSX_F_UNMAP));
+				const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+				code[r] = part ? ((fl & MSX_F_MATES) | 0x100u | (has ? 0x200u : 0u)) : 0u;
+				paired |= code[r] & MSX_F_MATES;                                 // mBamPoolIsPaired :196-204
 			}
-			const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);   // :232-233
-			const bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
-			const bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
-			// ---- pass 2: keep codes ----
+			// a paired pool is judged per mate (READ1 -> A, READ2 -> B), an unpaired one as a whole (A)
+			const uint32_t selA = paired ? 0x140u : 0x100u, selB = paired ? 0x180u : 0xffffu;
+			int32_t bA = INT_MIN, bB = INT_MIN;
+			uint32_t hasA = 0, hasB = 0, noas = 0;                                // bit r = record r
 #pragma unroll
 			for (int r = 0; r < BH_WIN; r++) {
-				if ((uint32_t)r < len) {
-					const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
-					const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
-					const bool pooled = A.pool ? (((pa[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0) : !(fl & MSX_F_UNMAP);
-					const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-					const uint8_t k = bh_keep(c, w0, w1, w2, fl, pooled, has, sc[r]);
-					A.keep[s + r] = k;
-					cnt += (k != 0);
-				}
+				const uint32_t cl = code[r] & 0x1c0u;
+				const bool inA = (cl == selA), inB = (cl == selB), has = (code[r] & 0x200u) != 0;
+				hasA |= (inA && has) ? (1u << r) : 0u;
+				hasB |= (inB && has) ? (1u << r) : 0u;
+				noas |= ((inA || inB) && !has) ? (1u << r) : 0u;
+				const int32_t sa = (inA && has) ? sc[r] : INT_MIN, sb = (inB && has) ? sc[r] : INT_MIN;
+				bA = sa > bA ? sa : bA;
+				bB = sb > bB ? sb : bB;
 			}
+			uint32_t eqA = 0, eqB = 0;
+#pragma unroll
+			for (int r = 0; r < BH_WIN; r++) {
+				eqA |= (sc[r] == bA) ? (1u << r) : 0u;
+				eqB |= (sc[r] == bB) ? (1u << r) : 0u;
+			}
+			eqA &= hasA;                                                          // the records holding the best score
+			eqB &= hasB;
+			const uint32_t nA = (uint32_t)__popc(eqA), nB = (uint32_t)__popc(eqB);
+			const bool wA = nA > 0 && (!A.unique_only || nA == 1);                // :232-233
+			const bool wB = nB > 0 && (!A.unique_only || nB == 1);
+			// keep codes: 1 = written in the first pass (unpaired winners, READ1 winners), 2 = READ2 winners
+			const uint32_t k1 = wA ? eqA : 0u, k2 = wB ? eqB : 0u;
+#pragma unroll
+			for (int r = 0; r < BH_WIN; r++)
+				if ((uint32_t)r < len) A.keep[s + r] = (uint8_t)(((k1 >> r) & 1u) | (((k2 >> r) & 1u) << 1));
+			cnt = (uint32_t)__popc(k1 | k2);
+			if (noas) {
+				const uint32_t first = s + (uint32_t)__ffs((int)noas) - 1u;
+				if (paired) c.noas1 = first; else c.noas0 = first;
+			}
+			c.paired = paired;
 		} else {
 			for (uint32_t i = s; i < e; ++i) {
 				const uint32_t fl = A.flag[i];
