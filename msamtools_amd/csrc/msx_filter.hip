@@ -368,19 +368,20 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
 			const uint32_t *f32p = reinterpret_cast<const uint32_t *>(A.flag) + (s >> 1);
 			uint32_t fw[7];
 #pragma unroll
-			for (int q = 0; q < 7; q++) fw[q] = (2u * ((s >> 1) + (uint32_t)q) < (uint32_t)A.n) ? f32p[q] : 0u;
+			for (int q = 0; q < 7; q++)        // only the dwords the pool reaches into
+				fw[q] = (2u * ((s >> 1) + (uint32_t)q) < e) ? f32p[q] : 0u;
 			const uint32_t *r32p = reinterpret_cast<const uint32_t *>(A.rflags) + (s >> 2);
 			uint32_t rw[4], pw[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
 #pragma unroll
-			for (int q = 0; q < 4; q++) rw[q] = r32p[q];
+			for (int q = 0; q < 4; q++) rw[q] = (4u * ((s >> 2) + (uint32_t)q) < e) ? r32p[q] : 0u;
 			if (A.pool) {
 				const uint32_t *p32p = reinterpret_cast<const uint32_t *>(A.pool) + (s >> 2);
 #pragma unroll
-				for (int q = 0; q < 4; q++) pw[q] = p32p[q];
+				for (int q = 0; q < 4; q++) pw[q] = (4u * ((s >> 2) + (uint32_t)q) < e) ? p32p[q] : 0u;
 			}
 			int32_t sc[BH_WIN];
 #pragma unroll
-			for (int r = 0; r < BH_WIN; r++) sc[r] = A.as[s + r];
+			for (int r = 0; r < BH_WIN; r++) sc[r] = ((uint32_t)r < len) ? A.as[s + r] : INT_MIN;
 			// ---- realign so that record r is at a fixed position ----
 			const uint32_t fsh = 16u * (s & 1u), bsh = s & 3u;
 			uint32_t fa[6], ra[3], pa[3];
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_emit_groups(int64_t n_records, in
 			const uint32_t *kw = reinterpret_cast<const uint32_t *>(keep) + (base >> 2);
 			uint32_t w[6];
 #pragma unroll
-			for (int q = 0; q < 6; q++) w[q] = kw[q];
+			for (int q = 0; q < 6; q++) w[q] = (base + 4u * (uint32_t)q < e) ? kw[q] : 0u;   // only the dwords the pool reaches into
 			uint32_t m1 = 0, m2 = 0;
 #pragma unroll
 			for (int q = 0; q < 6; q++) {

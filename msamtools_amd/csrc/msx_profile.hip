@@ -98,7 +98,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 			const uint32_t *kw = reinterpret_cast<const uint32_t *>(A.keep) + (base >> 2);
 			uint32_t w[6];
 #pragma unroll
-			for (int q = 0; q < 6; q++) w[q] = kw[q];
+			for (int q = 0; q < 6; q++) w[q] = (base + 4u * (uint32_t)q < e) ? kw[q] : 0u;   // only the dwords the pool reaches into
 			uint32_t m1 = 0, m2 = 0;
 #pragma unroll
 			for (int q = 0; q < 6; q++) {
