@@ -169,8 +169,8 @@ def main():
 
     def step():
         prof.reset()
-        run.enqueue()                      # aln_stats_filter, besthit_select, scan, emit_order
-        prof.accumulate(db, run.keep)      # insert_count (+ scan + compaction)
+        run.enqueue_with_profile(prof)     # filter | profile: aln_stats_filter, besthit_select with the
+                                           # insert accounting inside, scans, emit_order, list compaction
         if dist is None:
             prof.finalize_enqueue()        # <= 19 proportional iterations, no host round trip
         else:
@@ -254,8 +254,7 @@ def main():
         reps = 3
         for _ in range(reps):
             prof.reset()
-            run.enqueue()
-            prof.accumulate(db, run.keep)
+            run.enqueue_with_profile(prof)
             prof.finalize_enqueue()
             run.finish()
         names = ["k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",

@@ -169,6 +169,14 @@ void msx_batch_free(msx_ctx *ctx, msx_batch *dev);
  *   emit_order        the order of mSamWrite calls (msam_filter.c:235-244) */
 int  msx_filter_enqueue(msx_ctx *ctx, const msx_batch *dev,
                         const msx_filter_params *params, const msx_filter_out *out);
+/* The pipe `msamtools filter ... | msamtools profile -` on one device batch, in
+ * one call: exactly msx_filter_enqueue(ctx, dev, params, out) followed by
+ * msx_profile_accumulate(ctx, p, dev, out->keep) -- same outputs, same
+ * accumulators -- but with --besthit / --uniqhit the per-pool insert accounting
+ * (msam_profile.c:65-243) runs inside the best-hit kernel, on the winners it
+ * has just selected (msam_filter.c:192-263), instead of in a second pass over
+ * the pools.  Declared after msx_profile below. */
+
 /* Waits for the stream; returns MSX_OK or the data error the reference would
  * have died with (MSX_ERR_NO_MD_NM / MSX_ERR_NO_AS), status filled either way. */
 int  msx_filter_finish(msx_ctx *ctx, msx_filter_status *status);
@@ -198,6 +206,10 @@ int  msx_profile_reset(msx_ctx *ctx, msx_profile *p);
  * filter's pools (one pool per QNAME run).  Enqueues and returns. */
 int  msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *dev,
                             const uint8_t *keep);
+
+int  msx_filter_profile_enqueue(msx_ctx *ctx, const msx_batch *dev,
+                                const msx_filter_params *params, const msx_filter_out *out,
+                                msx_profile *p);
 
 /* Device pointers to the accumulators, for a cross-GPU all-reduce(sum) by the
  * caller (RCCL): ui_insert_count u32[n_features], d_insert_count f64

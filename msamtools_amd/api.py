@@ -274,6 +274,12 @@ class FilterRun:
         c = self.ctx
         c.check(c.lib.msx_filter_enqueue(c.h, C.byref(self.batch.b), C.byref(self.fp), C.byref(self.out)))
 
+    def enqueue_with_profile(self, prof):
+        """filter | profile in one call (msx_filter_profile_enqueue)."""
+        c = self.ctx
+        c.check(c.lib.msx_filter_profile_enqueue(c.h, C.byref(self.batch.b), C.byref(self.fp), C.byref(self.out),
+                                                 prof.h))
+
     def finish(self):
         c = self.ctx
         st = L.FilterStatus()

@@ -1,0 +1,183 @@
+// msx_count.h -- per-pool insert accounting shared by k_insert_count (msx_profile.hip)
+// and the fused best-hit + count kernel (msx_filter.hip):
+// mEstimateInsertCountOnFile/OnPool, msam_profile.c:65-243.
+#ifndef MSX_COUNT_H
+#define MSX_COUNT_H
+
+#include "msx_internal.h"
+
+struct CountArgs {
+	int64_t n_groups;
+	int64_t n_records;
+	const uint32_t *group_off;
+	const int32_t *tid;
+	const uint8_t *keep;      // null: all records; else filter's keep codes (1 then 2 = output order)
+	const int32_t *fmap;      // null: identity
+	int32_t share_type;
+	uint32_t *ui;
+	double *d;
+	uint32_t *counters;       // {inserts, uniq, multi, purged}
+	int32_t *tmp_fid;         // [n_records] scratch: pool g's distinct features at tmp_fid[group_off[g]..]
+	unsigned long long *mlen; // [n_groups] (is_multi_list << 32) | n_distinct  (0 when not kept)
+	uint32_t tbl_mask;        // LDS staging table size - 1 (power of two, <= UI_TBL)
+	uint32_t *ukey;           // non-null: [n_groups] feature of a uniquely mapped insert (else 0xffffffff),
+	                          // counted afterwards by msx_count_keys instead of ui_add here
+};
+
+// Per-workgroup staging of the per-reference adds in LDS: a small open-addressed
+// table (feature -> pending count).  Hot references (a few references receive a
+// large share of all inserts) collapse to one global atomic per workgroup; an
+// add that finds no slot within 4 probes goes straight to global memory.
+#define UI_TBL 2048
+#define UI_EMPTY (-1)
+
+__device__ __forceinline__ void ui_add(int32_t *s_key, uint32_t *s_val, uint32_t *ui, int32_t fid, uint32_t v,
+                                       uint32_t mask) {
+	uint32_t h = ((uint32_t)fid * 2654435761u) >> 21;   // 11 bits
+#pragma unroll
+	for (int probe = 0; probe < 4; ++probe) {
+		const uint32_t slot = (h + probe) & mask;
+		const int32_t old = atomicCAS(&s_key[slot], UI_EMPTY, fid);
+		if (old == UI_EMPTY || old == fid) {
+			atomicAdd(&s_val[slot], v);
+			return;
+		}
+	}
+	atomicAdd(&ui[fid], v);
+}
+
+// what one pool's walk accumulates: records with a reference, distinct features in
+// first-appearance order (msam_profile.c:131-145; the first four in registers)
+struct PoolAcc {
+	uint32_t nvalid, nd;
+	int32_t f0, f1, f2, f3;
+	int32_t *lst;
+};
+
+__device__ __forceinline__ void pool_begin(const CountArgs &A, PoolAcc &v, uint32_t s) {
+	v.nvalid = 0; v.nd = 0;
+	v.f0 = v.f1 = v.f2 = v.f3 = -1;
+	v.lst = A.tmp_fid + s;
+}
+
+// one record of the stream profile sees, given its tid
+__device__ __forceinline__ void pool_visit(const CountArgs &A, PoolAcc &v, int32_t t) {
+	if (t == -1) return;                             // msam_profile.c:223-225
+	const int32_t fid = A.fmap ? A.fmap[t] : t;
+	v.nvalid++;
+	bool seen = (v.nd > 0 && fid == v.f0) || (v.nd > 1 && fid == v.f1) || (v.nd > 2 && fid == v.f2) ||
+	            (v.nd > 3 && fid == v.f3);
+	if (!seen && v.nd > 4)
+		for (uint32_t k = 4; k < v.nd; ++k)
+			if (v.lst[k] == fid) { seen = true; break; }
+	if (!seen) {
+		if (v.nd == 0) v.f0 = fid;
+		else if (v.nd == 1) v.f1 = fid;
+		else if (v.nd == 2) v.f2 = fid;
+		else if (v.nd == 3) v.f3 = fid;
+		v.lst[v.nd] = fid;
+		v.nd++;
+	}
+}
+
+// The records of the pool at s whose bit is set in m1, then those in m2 (filter's output
+// order: first-pass records, then second-pass records).  Memory-level parallelism: the
+// tids of the first eight are fetched with independent loads before any is looked at.
+__device__ __forceinline__ void pool_visit_masks(const CountArgs &A, PoolAcc &v, uint32_t s, uint32_t m1, uint32_t m2) {
+	uint32_t idx[8];
+	int32_t tv[8];
+	uint32_t rest1 = m1, rest2 = m2;
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		uint32_t bpos = 0xffffffffu;
+		if (rest1) { bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; }
+		else if (rest2) { bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; }
+		idx[q] = bpos;
+	}
+#pragma unroll
+	for (int q = 0; q < 8; q++) tv[q] = (idx[q] != 0xffffffffu) ? A.tid[s + idx[q]] : -1;
+#pragma unroll
+	for (int q = 0; q < 8; q++) pool_visit(A, v, tv[q]);
+	// more than eight kept records: the rest one by one
+	while (rest1) { const uint32_t bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; pool_visit(A, v, A.tid[s + bpos]); }
+	while (rest2) { const uint32_t bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; pool_visit(A, v, A.tid[s + bpos]); }
+}
+
+struct BlockCounts {
+	uint32_t ins, uniq, multi;
+};
+
+// the pool's insert: unique / multi-mapper accounting
+__device__ __forceinline__ void pool_finish(const CountArgs &A, int64_t g, const PoolAcc &v, int32_t *s_key,
+                                            uint32_t *s_val, BlockCounts &c) {
+	unsigned long long ml = 0;
+	uint32_t uk = 0xffffffffu;
+	if (v.nvalid > 0) {
+		c.ins++;                                          // one insert per pool (:230,:237)
+		if (v.nd == 1) {                                  // :75-78, :87-91, :152-159
+			if (A.ukey) uk = (uint32_t)v.f0;
+			else ui_add(s_key, s_val, A.ui, v.f0, 2u, A.tbl_mask);
+			c.uniq++;
+		} else {
+			c.multi++;                                    // :95, :162
+			switch (A.share_type) {
+			case MSX_MULTI_ADD_ALL:                       // :99-102, :169-173
+				for (uint32_t k = 0; k < v.nd; ++k) ui_add(s_key, s_val, A.ui, v.lst[k], 2u, A.tbl_mask);
+				break;
+			case MSX_MULTI_SHARE_EQUAL:
+				if (v.nvalid == 2) {                      // :103-106 (integer halves)
+					ui_add(s_key, s_val, A.ui, v.f0, 1u, A.tbl_mask);
+					ui_add(s_key, s_val, A.ui, v.f1, 1u, A.tbl_mask);
+				} else {                                  // :175-182
+					const double share = 1.0 / (double)v.nd;
+					for (uint32_t k = 0; k < v.nd; ++k) atomicAdd(&A.d[v.lst[k]], share);
+				}
+				break;
+			case MSX_MULTI_SHARE_PROPORTIONAL:            // :107-121, :184-186
+				ml = (1ull << 32) | v.nd;
+				break;
+			default:                                      // MULTI_IGNORE
+				break;
+			}
+		}
+	}
+	if (A.mlen) A.mlen[g] = ml;
+	if (A.ukey) A.ukey[g] = uk;
+}
+
+// workgroup prologue / epilogue around the pools loop
+__device__ __forceinline__ void count_block_begin(const CountArgs &A, int32_t *s_key, uint32_t *s_val) {
+	const int tbl = (int)A.tbl_mask + 1;
+	for (int i = threadIdx.x; i < tbl; i += MSX_BLOCK) { s_key[i] = UI_EMPTY; s_val[i] = 0; }
+	__syncthreads();
+}
+
+__device__ __forceinline__ void count_block_end(const CountArgs &A, int32_t *s_key, uint32_t *s_val,
+                                                uint32_t (*s_c)[MSX_BLOCK / 64], BlockCounts c) {
+	// one set of counter atomics per workgroup
+	for (int d = 32; d > 0; d >>= 1) {
+		c.ins += __shfl_down(c.ins, d, 64);
+		c.uniq += __shfl_down(c.uniq, d, 64);
+		c.multi += __shfl_down(c.multi, d, 64);
+	}
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0) { s_c[0][w] = c.ins; s_c[1][w] = c.uniq; s_c[2][w] = c.multi; }
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		uint32_t v = s_c[threadIdx.x][0] + s_c[threadIdx.x][1] + s_c[threadIdx.x][2] + s_c[threadIdx.x][3];
+		if (v) atomicAdd(&A.counters[threadIdx.x], v);
+	}
+	// flush the staged adds (the barrier above ordered every ui_add before this)
+	const int tbl = (int)A.tbl_mask + 1;
+	for (int i = threadIdx.x; i < tbl; i += MSX_BLOCK) {
+		const uint32_t v = s_val[i];
+		if (v) atomicAdd(&A.ui[s_key[i]], v);
+	}
+}
+
+// host side (msx_profile.hip)
+int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep, CountArgs *out,
+                              bool *by_part_out);
+int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, bool by_part);
+
+#endif

@@ -9,6 +9,7 @@
 // per pool (selection); variable-length CIGAR/MD payloads of a 256-record tile
 // are staged into LDS with coalesced dword loads.
 #include "msx_internal.h"
+#include "msx_count.h"
 #include "msx_md.h"
 
 #include <climits>
@@ -356,7 +357,16 @@ __device__ __forceinline__ uint8_t bh_keep(const BhAcc &c, bool w0, bool w1, boo
 	return 0;
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
+// COUNT: the fused `filter | profile` form.  The pool's winners are in registers (k1/k2
+// masks) when the selection is done, so the insert accounting of msx_count.h runs right
+// here instead of in a second kernel that would fetch group_off and the keep codes again.
+template <bool COUNT>
+__global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, CountArgs P) {
+	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
+	__shared__ int32_t s_key[COUNT ? UI_TBL : 1];
+	__shared__ uint32_t s_val[COUNT ? UI_TBL : 1];
+	BlockCounts bc = {0u, 0u, 0u};
+	if (COUNT) count_block_begin(P, s_key, s_val);
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
 		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
@@ -437,6 +447,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
 			for (int r = 0; r < BH_WIN; r++)
 				if ((uint32_t)r < len) A.keep[s + r] = (uint8_t)(((k1 >> r) & 1u) | (((k2 >> r) & 1u) << 1));
 			cnt = (uint32_t)__popc(k1 | k2);
+			if (COUNT) {
+				PoolAcc v;
+				pool_begin(P, v, s);
+				pool_visit_masks(P, v, s, k1, k2);
+				pool_finish(P, g, v, s_key, s_val, bc);
+			}
 			if (noas) {
 				const uint32_t first = s + (uint32_t)__ffs((int)noas) - 1u;
 				if (paired) c.noas1 = first; else c.noas0 = first;
@@ -460,12 +476,22 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A) {
 				A.keep[i] = k;
 				cnt += (k != 0);
 			}
+			if (COUNT) {
+				// long pool: the keep codes this lane just wrote, in output order
+				PoolAcc v;
+				pool_begin(P, v, s);
+				for (uint32_t pass = 1; pass <= 2; ++pass)
+					for (uint32_t i = s; i < e; ++i)
+						if (A.keep[i] == pass) pool_visit(P, v, P.tid[i]);
+				pool_finish(P, g, v, s_key, s_val, bc);
+			}
 		}
 		// msam_filter.c:219-221: a participating record without AS is fatal
 		const uint32_t bad = c.paired ? (c.noas1 < c.noas2 ? c.noas1 : c.noas2) : c.noas0;
 		if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
 		A.gcount[g] = cnt;
 	}
+	if (COUNT) count_block_end(P, s_key, s_val, s_c, bc);
 }
 
 // emit order for pools: all pass-1 records of a pool, then its pass-2 records.
@@ -592,9 +618,11 @@ static void fill_args(FilterArgs &A, const msx_batch *b) {
 	A.md_aligned = (((uintptr_t)b->md) & 3u) == 0 ? 1 : 0;
 }
 
-extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p,
-                                  const msx_filter_out *out) {
+static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p, const msx_filter_out *out,
+                               msx_profile *prof) {
 	if (!ctx || !b || !p || !out || !out->keep) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_enqueue: null argument");
+	if (prof && (!b->group_off || !b->tid))
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_profile_enqueue needs tid and group_off");
 	const int choice = filter_choice(p);
 	const bool best = p->besthit || p->uniqhit;
 	if (choice == 0 && !best)
@@ -659,10 +687,18 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 		S.keep = out->keep;
 		S.gcount = (uint32_t *)ctx->gcount.p;
 		S.st = ctx->d_status;
+		CountArgs P = {};
+		bool by_part = false;
+		if (prof && ng > 0 && (rc = msx_profile_count_prepare(ctx, prof, b, out->keep, &P, &by_part))) return rc;
 		msx_time_begin(ctx, MSX_K_BESTHIT);
-		hipLaunchKernelGGL(k_besthit_select, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
-		                   ctx->stream, S);
+		if (prof && ng > 0)
+			hipLaunchKernelGGL(k_besthit_select<true>, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
+			                   ctx->stream, S, P);
+		else
+			hipLaunchKernelGGL(k_besthit_select<false>, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
+			                   ctx->stream, S, P);
 		msx_time_end(ctx);
+		if (prof && ng > 0 && (rc = msx_profile_count_finish(ctx, prof, b, by_part))) return rc;
 		if ((rc = msx_scan_u32(ctx, S.gcount, (uint32_t *)ctx->gbase.p, ng))) return rc;
 		msx_time_begin(ctx, MSX_K_EMIT);
 		hipLaunchKernelGGL(k_emit_groups, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
@@ -683,9 +719,22 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 		                   (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p, out->emit_idx,
 		                   ctx->d_status);
 		msx_time_end(ctx);
+		// without best-hit selection there is no per-pool kernel to fuse into: plain sequence
+		if (prof && (rc = msx_profile_accumulate(ctx, prof, b, out->keep))) return rc;
 	}
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
+}
+
+extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p,
+                                  const msx_filter_out *out) {
+	return filter_enqueue_impl(ctx, b, p, out, nullptr);
+}
+
+extern "C" int msx_filter_profile_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p,
+                                          const msx_filter_out *out, msx_profile *prof) {
+	if (!prof) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_profile_enqueue: null profile");
+	return filter_enqueue_impl(ctx, b, p, out, prof);
 }
 
 extern "C" int msx_filter_finish(msx_ctx *ctx, msx_filter_status *status) {

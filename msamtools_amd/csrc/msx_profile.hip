@@ -8,92 +8,28 @@
 // double precision with order-free atomic accumulation (<= 1e-6 relative to the
 // reference's sequential order, as BASELINE.json allows).
 #include "msx_internal.h"
+#include "msx_count.h"
 
 #include <cstdlib>
-
-struct CountArgs {
-	int64_t n_groups;
-	int64_t n_records;
-	const uint32_t *group_off;
-	const int32_t *tid;
-	const uint8_t *keep;      // null: all records; else filter's keep codes (1 then 2 = output order)
-	const int32_t *fmap;      // null: identity
-	int32_t share_type;
-	uint32_t *ui;
-	double *d;
-	uint32_t *counters;       // {inserts, uniq, multi, purged}
-	int32_t *tmp_fid;         // [n_records] scratch: pool g's distinct features at tmp_fid[group_off[g]..]
-	unsigned long long *mlen; // [n_groups] (is_multi_list << 32) | n_distinct  (0 when not kept)
-	uint32_t tbl_mask;        // LDS staging table size - 1 (power of two, <= UI_TBL)
-	uint32_t *ukey;           // non-null: [n_groups] feature of a uniquely mapped insert (else 0xffffffff),
-	                          // counted afterwards by msx_count_keys instead of ui_add here
-};
-
-// Per-workgroup staging of the per-reference adds in LDS: a small open-addressed
-// table (feature -> pending count).  Hot references (a few references receive a
-// large share of all inserts) collapse to one global atomic per workgroup; an
-// add that finds no slot within 4 probes goes straight to global memory.
-#define UI_TBL 2048
-#define UI_EMPTY (-1)
-
-__device__ __forceinline__ void ui_add(int32_t *s_key, uint32_t *s_val, uint32_t *ui, int32_t fid, uint32_t v,
-                                       uint32_t mask) {
-	uint32_t h = ((uint32_t)fid * 2654435761u) >> 21;   // 11 bits
-#pragma unroll
-	for (int probe = 0; probe < 4; ++probe) {
-		const uint32_t slot = (h + probe) & mask;
-		const int32_t old = atomicCAS(&s_key[slot], UI_EMPTY, fid);
-		if (old == UI_EMPTY || old == fid) {
-			atomicAdd(&s_val[slot], v);
-			return;
-		}
-	}
-	atomicAdd(&ui[fid], v);
-}
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
 	__shared__ int32_t s_key[UI_TBL];
 	__shared__ uint32_t s_val[UI_TBL];
-	const int tbl = (int)A.tbl_mask + 1;
-	for (int i = threadIdx.x; i < tbl; i += MSX_BLOCK) { s_key[i] = UI_EMPTY; s_val[i] = 0; }
-	__syncthreads();
-	uint32_t c_ins = 0, c_uniq = 0, c_multi = 0;
+	count_block_begin(A, s_key, s_val);
+	BlockCounts c = {0u, 0u, 0u};
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
 		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
-		uint32_t nvalid = 0, nd = 0;
-		int32_t f0 = -1, f1 = -1, f2 = -1, f3 = -1;
-		int32_t *lst = A.tmp_fid + s;
-		// one record of the stream profile sees: count it, remember its feature if new
-		// (distinct features in first-appearance order, msam_profile.c:131-145)
-		auto visit = [&](uint32_t i) {
-			const int32_t t = A.tid[i];
-			if (t == -1) return;                             // msam_profile.c:223-225
-			const int32_t fid = A.fmap ? A.fmap[t] : t;
-			nvalid++;
-			bool seen = (nd > 0 && fid == f0) || (nd > 1 && fid == f1) || (nd > 2 && fid == f2) ||
-			            (nd > 3 && fid == f3);
-			if (!seen && nd > 4)
-				for (uint32_t k = 4; k < nd; ++k)
-					if (lst[k] == fid) { seen = true; break; }
-			if (!seen) {
-				if (nd == 0) f0 = fid;
-				else if (nd == 1) f1 = fid;
-				else if (nd == 2) f2 = fid;
-				else if (nd == 3) f3 = fid;
-				lst[nd] = fid;
-				nd++;
-			}
-		};
+		PoolAcc v;
+		pool_begin(A, v, s);
 		// the stream: the batch itself, or filter's output order (all pass-1 records of the
 		// pool, then its pass-2 records)
 		if (!A.keep) {
-			for (uint32_t i = s; i < e; ++i) visit(i);
+			for (uint32_t i = s; i < e; ++i) pool_visit(A, v, A.tid[i]);
 		} else if (e - s <= 20u && (uint64_t)(s & ~3u) + 24u <= (uint64_t)A.n_records) {
-			// memory-level parallelism: the pool's keep codes arrive as six independent aligned
-			// dword loads (one round trip instead of one per record), the tids of the kept records
-			// as up to eight independent loads; only then are they walked in output order.
+			// the pool's keep codes arrive as up to six independent aligned dword loads (one round
+			// trip instead of one per record)
 			const uint32_t base = s & ~3u, sh = s - base, len = e - s;
 			const uint32_t *kw = reinterpret_cast<const uint32_t *>(A.keep) + (base >> 2);
 			uint32_t w[6];
@@ -112,101 +48,15 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 					}
 				}
 			}
-			// order of the stream: pass-1 records, then pass-2 records
-			uint32_t idx[8];
-			int32_t tv[8];
-			uint32_t nk = 0, rest1 = m1, rest2 = m2;
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				uint32_t bpos = 0xffffffffu;
-				if (rest1) { bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; }
-				else if (rest2) { bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; }
-				idx[q] = bpos;
-				nk += (bpos != 0xffffffffu);
-			}
-#pragma unroll
-			for (int q = 0; q < 8; q++) tv[q] = (idx[q] != 0xffffffffu) ? A.tid[s + idx[q]] : -1;
-			auto visit_t = [&](int32_t t) {
-				if (t == -1) return;
-				const int32_t fid = A.fmap ? A.fmap[t] : t;
-				nvalid++;
-				bool seen = (nd > 0 && fid == f0) || (nd > 1 && fid == f1) || (nd > 2 && fid == f2) ||
-				            (nd > 3 && fid == f3);
-				if (!seen && nd > 4)
-					for (uint32_t k = 4; k < nd; ++k)
-						if (lst[k] == fid) { seen = true; break; }
-				if (!seen) {
-					if (nd == 0) f0 = fid;
-					else if (nd == 1) f1 = fid;
-					else if (nd == 2) f2 = fid;
-					else if (nd == 3) f3 = fid;
-					lst[nd] = fid;
-					nd++;
-				}
-			};
-#pragma unroll
-			for (int q = 0; q < 8; q++) visit_t(tv[q]);
-			// more than eight kept records: the rest one by one
-			while (rest1) { const uint32_t bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; visit(s + bpos); }
-			while (rest2) { const uint32_t bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; visit(s + bpos); }
-			(void)nk;
+			pool_visit_masks(A, v, s, m1, m2);
 		} else {
 			for (uint32_t pass = 1; pass <= 2; ++pass)
 				for (uint32_t i = s; i < e; ++i)
-					if (A.keep[i] == pass) visit(i);
+					if (A.keep[i] == pass) pool_visit(A, v, A.tid[i]);
 		}
-		unsigned long long ml = 0;
-		uint32_t uk = 0xffffffffu;
-		if (nvalid > 0) {
-			c_ins++;                                          // one insert per pool (:230,:237)
-			if (nd == 1) {                                    // :75-78, :87-91, :152-159
-				if (A.ukey) uk = (uint32_t)f0;
-				else ui_add(s_key, s_val, A.ui, f0, 2u, A.tbl_mask);
-				c_uniq++;
-			} else {
-				c_multi++;                                    // :95, :162
-				switch (A.share_type) {
-				case MSX_MULTI_ADD_ALL:                       // :99-102, :169-173
-					for (uint32_t k = 0; k < nd; ++k) ui_add(s_key, s_val, A.ui, lst[k], 2u, A.tbl_mask);
-					break;
-				case MSX_MULTI_SHARE_EQUAL:
-					if (nvalid == 2) {                        // :103-106 (integer halves)
-						ui_add(s_key, s_val, A.ui, f0, 1u, A.tbl_mask);
-						ui_add(s_key, s_val, A.ui, f1, 1u, A.tbl_mask);
-					} else {                                  // :175-182
-						const double share = 1.0 / (double)nd;
-						for (uint32_t k = 0; k < nd; ++k) atomicAdd(&A.d[lst[k]], share);
-					}
-					break;
-				case MSX_MULTI_SHARE_PROPORTIONAL:            // :107-121, :184-186
-					ml = (1ull << 32) | nd;
-					break;
-				default:                                      // MULTI_IGNORE
-					break;
-				}
-			}
-		}
-		if (A.mlen) A.mlen[g] = ml;
-		if (A.ukey) A.ukey[g] = uk;
+		pool_finish(A, g, v, s_key, s_val, c);
 	}
-	// one set of counter atomics per workgroup
-	for (int d = 32; d > 0; d >>= 1) {
-		c_ins += __shfl_down(c_ins, d, 64);
-		c_uniq += __shfl_down(c_uniq, d, 64);
-		c_multi += __shfl_down(c_multi, d, 64);
-	}
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	if (lane == 0) { s_c[0][w] = c_ins; s_c[1][w] = c_uniq; s_c[2][w] = c_multi; }
-	__syncthreads();
-	if (threadIdx.x < 3) {
-		uint32_t v = s_c[threadIdx.x][0] + s_c[threadIdx.x][1] + s_c[threadIdx.x][2] + s_c[threadIdx.x][3];
-		if (v) atomicAdd(&A.counters[threadIdx.x], v);
-	}
-	// flush the staged adds (the barrier above ordered every ui_add before this)
-	for (int i = threadIdx.x; i < tbl; i += MSX_BLOCK) {
-		const uint32_t v = s_val[i];
-		if (v) atomicAdd(&A.ui[s_key[i]], v);
-	}
+	count_block_end(A, s_key, s_val, s_c, c);
 }
 
 // csr_tot = {n_lists, n_entries} running totals of the compact CSR
@@ -335,11 +185,11 @@ extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
 	return MSX_OK;
 }
 
-extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep) {
-	if (!ctx || !p || !b) return MSX_ERR_ARG;
-	if (!b->group_off || !b->tid) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_accumulate needs tid and group_off");
-	if (b->n_records == 0 || b->n_groups == 0) return MSX_OK;
-	MSX_HIP(ctx, hipSetDevice(ctx->device));
+// msx_profile_accumulate in two halves, so that the fused filter + profile call can run the
+// per-pool accounting inside its best-hit kernel: prepare fills the kernel arguments (and grows
+// the stores), finish counts the staged keys and appends the pools' lists to the multi-mapper CSR.
+int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep, CountArgs *out,
+                              bool *by_part_out) {
 	const int64_t n = b->n_records, ng = b->n_groups;
 	const bool prop = p->share_type == MSX_MULTI_SHARE_PROPORTIONAL;
 	int rc;
@@ -389,9 +239,15 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 		if ((rc = msx_reserve(ctx, &ctx->ukey2, (size_t)(ng + 8) * 4))) return rc;
 		A.ukey = (uint32_t *)ctx->ukey.p;
 	}
-	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
-	hipLaunchKernelGGL(k_insert_count, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A);
-	msx_time_end(ctx);
+	*out = A;
+	*by_part_out = by_part;
+	return MSX_OK;
+}
+
+int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, bool by_part) {
+	const int64_t ng = b->n_groups;
+	const bool prop = p->share_type == MSX_MULTI_SHARE_PROPORTIONAL;
+	int rc;
 	if (by_part && (rc = msx_count_keys(ctx, p, (const uint32_t *)ctx->ukey.p, (uint32_t *)ctx->ukey2.p, ng, 2u))) return rc;
 	if (prop) {
 		if ((rc = msx_scan_u64(ctx, (const uint64_t *)ctx->mlen.p, (uint64_t *)ctx->moff.p, ng))) return rc;
@@ -406,6 +262,21 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	}
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
+}
+
+extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep) {
+	if (!ctx || !p || !b) return MSX_ERR_ARG;
+	if (!b->group_off || !b->tid) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_accumulate needs tid and group_off");
+	if (b->n_records == 0 || b->n_groups == 0) return MSX_OK;
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	CountArgs A;
+	bool by_part = false;
+	int rc;
+	if ((rc = msx_profile_count_prepare(ctx, p, b, keep, &A, &by_part))) return rc;
+	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
+	hipLaunchKernelGGL(k_insert_count, dim3(msx_grid(ctx, b->n_groups, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A);
+	msx_time_end(ctx);
+	return msx_profile_count_finish(ctx, p, b, by_part);
 }
 
 extern "C" int msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui, double **d, uint32_t **counters) {

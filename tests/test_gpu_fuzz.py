@@ -124,6 +124,19 @@ def test_fuzz_besthit_and_fused_profile(ctx, seed):
             assert ((ab == 0) == (want == 0)).all()
             assert (np.abs(ab - want) <= 1e-6 * np.maximum(np.abs(want), 1e-300)).all(), (opts, multi)
             prof.close()
+            # the same pipe as one call
+            run1 = m.FilterRun(ctx, batch, **opts)
+            prof1 = m.Profile(ctx, 37, multi)
+            run1.enqueue_with_profile(prof1)
+            run1.finish()
+            assert (run1.result().emit == w["emit"]).all(), (opts, multi)
+            assert (prof1.ui() == ref["ui"]).all(), (opts, multi)
+            ab1, st1 = prof1.finalize()
+            assert (st1.insert_count, st1.uniq_mapper_count, st1.multi_mapper_count, st1.purged_insert_count) == \
+                (s.insert_count, s.uniq_mapper_count, s.multi_mapper_count, s.purged_insert_count), (opts, multi)
+            assert (np.abs(ab1 - want) <= 1e-6 * np.maximum(np.abs(want), 1e-300)).all(), (opts, multi)
+            prof1.close()
+            run1.free()
         run.free()
     batch.free()
 

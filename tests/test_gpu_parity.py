@@ -311,6 +311,46 @@ def test_synth_fused_filter_profile_parity(ctx, synth, multi):
         assert abs(st.delta[st.iterations] - ref["stats"].last_delta) <= 1e-6 * max(ref["stats"].last_delta, 1e-30)
 
 
+@pytest.mark.parametrize("multi", ["proportional", "equal", "all", "ignore"])
+@pytest.mark.parametrize("opts", [dict(l=80, p=95, z=80, besthit=True), dict(uniqhit=True), dict(l=60, p=90)],
+                         ids=["lpz_besthit", "uniqhit", "plain"])
+def test_one_call_filter_profile_equals_two_calls_and_oracle(ctx, synth, multi, opts):
+    """msx_filter_profile_enqueue == msx_filter_enqueue + msx_profile_accumulate (and the oracle pipe)."""
+    import msamtools_amd as m
+    hs, db = synth
+    run = m.FilterRun(ctx, db, **opts)
+    prof = m.Profile(ctx, 2000, multi)
+    run.enqueue_with_profile(prof)
+    run.finish()
+    res = run.result()
+    ui = prof.ui()
+    ab, st = prof.finalize()
+    ab = ab.copy()
+    prof.close()
+    # two calls
+    run2 = m.FilterRun(ctx, db, **opts)
+    run2.enqueue()
+    run2.finish()
+    res2 = run2.result()
+    prof2 = m.Profile(ctx, 2000, multi)
+    prof2.accumulate(db, run2.keep)
+    ui2 = prof2.ui()
+    ab2, st2 = prof2.finalize()
+    assert (res.keep == res2.keep).all() and (res.emit == res2.emit).all() and res.n_emit == res2.n_emit
+    assert (ui == ui2).all()
+    assert (st.insert_count, st.uniq_mapper_count, st.multi_mapper_count, st.purged_insert_count) == \
+        (st2.insert_count, st2.uniq_mapper_count, st2.multi_mapper_count, st2.purged_insert_count)
+    assert (np.abs(ab - ab2) <= 1e-9 * np.maximum(np.abs(ab2), 1e-300)).all()
+    prof2.close()
+    run.free()
+    run2.free()
+    ref_f = orc.run_filter(hs, **opts)
+    assert (res.emit == ref_f["emit"]).all()
+    ref = orc.run_profile(hs, 2000, multi=multi, sel=ref_f["emit"])
+    assert (ui == ref["ui"]).all()
+    assert_profile_close(ab, st, ref)
+
+
 def test_synth_profile_subcommand_with_fmap(ctx, synth):
     """`profile` on the raw stream (keep == NULL) with a tid -> feature map (--genome)."""
     import msamtools_amd as m
