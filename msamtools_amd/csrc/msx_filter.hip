@@ -368,8 +368,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 	BlockCounts bc = {0u, 0u, 0u};
 	if (COUNT) count_block_begin(P, s_key, s_val);
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
-		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
+	int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	// the next pool's bounds are fetched while this one is processed (one round trip less per pool)
+	uint32_t s_nx = 0, e_nx = 0;
+	if (g < A.n_groups) { s_nx = A.group_off[g]; e_nx = A.group_off[g + 1]; }
+	for (; g < A.n_groups; g += stride) {
+		const uint32_t s = s_nx, e = e_nx;
+		if (g + stride < A.n_groups) { s_nx = A.group_off[g + stride]; e_nx = A.group_off[g + stride + 1]; }
 		const uint32_t len = e - s;
 		BhAcc c = {INT_MIN, INT_MIN, INT_MIN, 0u, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 		uint32_t cnt = 0;
