@@ -143,7 +143,9 @@ struct msx_profile {
 	msx_buf m_fid;                    // i32 [n_entries]
 	int64_t lists_ub = 0, entries_ub = 0;    // host upper bounds (capacity / grid sizing)
 	// feature-major view built once per finalize by a stable radix sort
-	msx_buf t_key[2], t_val[2];       // ping-pong (feature id, list id) pairs
+	msx_buf t_key[2], t_val[2];       // ping-pong (key, 32-bit value) pairs of the radix sort
+	msx_buf t_val64[2];               // ping-pong 64-bit values: the entries' list signatures (msx_prop.hip)
+	msx_buf gen;                      // u8 [n_lists]: 1 = list takes the general (recip[]) path
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
 	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
@@ -152,6 +154,7 @@ struct msx_profile {
 	msx_buf head, uidx, eoff, hpos;       // dedupe scratch; hpos[u+1]-hpos[u] = weight of merged list u
 	unsigned long long *d_tot = nullptr;  // device {lists, entries} of the derived store
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
+	int key_bits = 0;                 // bits of the feature id in an entry key (the list weight sits above)
 	bool transposed_valid = false;
 	int iter_k = 0;
 	bool begun = false;

@@ -35,10 +35,24 @@
 // SKIP: keys equal to RS_NOKEY are not part of the input (k_part_count's producer marks
 // pools without a key that way); n_ptr == nullptr: the element count is n_host.
 #define RS_NOKEY 0xffffffffu
+// one key into the wave's digit counters; when every lane of the wave holds the same digit
+// (sorted or heavily skewed input) one lane adds the whole row instead of 64 conflicting atomics
+__device__ __forceinline__ void hist_add(uint32_t *cnt, uint32_t d, bool valid) {
+	const unsigned long long act = __ballot(valid);
+	if (!act) return;
+	const uint32_t d0 = __shfl(d, __ffsll((long long)act) - 1, 64);
+	if (__ballot(valid && d == d0) == act) {
+		if ((threadIdx.x & 63) == __ffsll((long long)act) - 1) cnt[d0] += (uint32_t)__popcll(act);
+	} else if (valid) {
+		atomicAdd(&cnt[d], 1u);
+	}
+}
+
 template <bool SKIP>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restrict__ keys,
                                                        const unsigned long long *__restrict__ n_ptr, int64_t n_host,
-                                                       int shift, uint32_t *__restrict__ hist, int64_t n_tiles) {
+                                                       int shift, uint32_t dmask, uint32_t *__restrict__ hist,
+                                                       int64_t n_tiles) {
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t tile = blockIdx.x;
@@ -50,7 +64,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
 			if (k < E) {
 				const uint32_t key = keys[k];
-				if (key != RS_NOKEY) atomicAdd(&s_cnt[w][(key >> shift) & 255u], 1u);
+				if (key != RS_NOKEY) atomicAdd(&s_cnt[w][(key >> shift) & dmask], 1u);
 			}
 		}
 	} else if (base + RS_TILE <= E) {
@@ -60,15 +74,16 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 		for (int q = 0; q < RS_EPT / 4; q++) v[q] = kv[q * MSX_BLOCK + threadIdx.x];
 #pragma unroll
 		for (int q = 0; q < RS_EPT / 4; q++) {
-			atomicAdd(&s_cnt[w][(v[q].x >> shift) & 255u], 1u);
-			atomicAdd(&s_cnt[w][(v[q].y >> shift) & 255u], 1u);
-			atomicAdd(&s_cnt[w][(v[q].z >> shift) & 255u], 1u);
-			atomicAdd(&s_cnt[w][(v[q].w >> shift) & 255u], 1u);
+			hist_add(s_cnt[w], (v[q].x >> shift) & dmask, true);
+			hist_add(s_cnt[w], (v[q].y >> shift) & dmask, true);
+			hist_add(s_cnt[w], (v[q].z >> shift) & dmask, true);
+			hist_add(s_cnt[w], (v[q].w >> shift) & dmask, true);
 		}
 	} else {
 		for (int q = 0; q < RS_EPT; q++) {
 			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
-			if (k < E) atomicAdd(&s_cnt[w][(keys[k] >> shift) & 255u], 1u);
+			const bool ok = k < E;
+			hist_add(s_cnt[w], ok ? ((keys[k] >> shift) & dmask) : 0u, ok);
 		}
 	}
 	__syncthreads();
@@ -76,16 +91,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
-template <bool PAIRS, bool SKIP>
+// V: type of the value travelling with each key (uint32_t or unsigned long long); PAIRS = false: keys only
+template <typename V, bool PAIRS, bool SKIP>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
-                                                          const uint32_t *__restrict__ vals_in,
+                                                          const V *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
-                                                          uint32_t *__restrict__ vals_out,
+                                                          V *__restrict__ vals_out,
                                                           const unsigned long long *__restrict__ n_ptr, int64_t n_host,
-                                                          int shift, const uint32_t *__restrict__ hoff,
-                                                          int64_t n_tiles) {
+                                                          int shift, uint32_t dmask,
+                                                          const uint32_t *__restrict__ hoff, int64_t n_tiles) {
 	__shared__ uint32_t s_key[RS_TILE];
-	__shared__ uint32_t s_val[PAIRS ? RS_TILE : 1];
+	__shared__ V s_val[PAIRS ? RS_TILE : 1];
 	__shared__ uint32_t s_nvalid;
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];   // per wave: running digit counts, then the wave's offset
 	__shared__ uint32_t s_dstart[256];                // first position of the digit inside the sorted tile
@@ -99,7 +115,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	// 1. all loads up front; wave w owns elements [w*RS_EPT*64, (w+1)*RS_EPT*64) of the tile
-	uint32_t key[RS_EPT], val[RS_EPT];
+	uint32_t key[RS_EPT];
+	V val[RS_EPT];
 	const uint32_t wbase = (uint32_t)w * (RS_EPT * 64) + (uint32_t)lane;
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || key[r] != RS_NOKEY);
-		const uint32_t d = (key[r] >> shift) & 255u;
+		const uint32_t d = (key[r] >> shift) & dmask;
 		unsigned long long m = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < 8; b++) {
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		if ((wbase + (uint32_t)r * 64u < n_here) && (!SKIP || key[r] != RS_NOKEY)) {
-			const uint32_t d = (key[r] >> shift) & 255u;
+			const uint32_t d = (key[r] >> shift) & dmask;
 			const uint32_t p = s_dstart[d] + s_cnt[w][d] + pos[r];
 			s_key[p] = key[r];
 			if (PAIRS) s_val[p] = val[r];
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
 		if (p < n_out) {
 			const uint32_t k = s_key[p];
-			const uint32_t dst = s_gbase[(k >> shift) & 255u] + p;
+			const uint32_t dst = s_gbase[(k >> shift) & dmask] + p;
 			keys_out[dst] = k;
 			if (PAIRS) vals_out[dst] = s_val[p];
 		}
@@ -240,12 +257,13 @@ int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t 
 	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_tiles + 16) * 4))) return rc;
 	MSX_TIMED(ctx, MSX_K_INSERT_COUNT,
 	          hipLaunchKernelGGL(k_rs_hist<true>, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, keys,
-	                             (const unsigned long long *)nullptr, n, shift, (uint32_t *)p->rs_hist.p, n_tiles));
+	                             (const unsigned long long *)nullptr, n, shift, 255u, (uint32_t *)p->rs_hist.p,
+	                             n_tiles));
 	if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_tiles))) return rc;
 	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
-	hipLaunchKernelGGL((k_rs_scatter<false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, keys,
-	                   (const uint32_t *)nullptr, key2, (uint32_t *)nullptr, (const unsigned long long *)nullptr, n,
-	                   shift, (const uint32_t *)p->rs_off.p, n_tiles);
+	hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   keys, (const uint32_t *)nullptr, key2, (uint32_t *)nullptr, (const unsigned long long *)nullptr,
+	                   n, shift, 255u, (const uint32_t *)p->rs_off.p, n_tiles);
 	hipLaunchKernelGGL(k_part_count, dim3(PC_SPLIT, 256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)key2,
 	                   (const uint32_t *)p->rs_off.p, n_tiles, shift, p->n_features, add, p->ui);
 	msx_time_end(ctx);
@@ -395,7 +413,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
                                                            const uint32_t *__restrict__ m_off,
                                                            const int32_t *__restrict__ m_fid,
                                                            uint32_t *__restrict__ d_off, int32_t *__restrict__ d_fid,
-                                                           uint32_t *__restrict__ e_list,
+                                                           uint32_t *__restrict__ e_key,
+                                                           unsigned long long *__restrict__ e_val,
                                                            uint32_t *__restrict__ hpos, int64_t m,
                                                            unsigned long long *__restrict__ d_tot) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
@@ -411,13 +430,16 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 			// the set is in the signature (ascending feature order)
 			const uint32_t a = (uint32_t)(sg & SIG_PAD), b = (uint32_t)((sg >> 21) & SIG_PAD),
 			               c = (uint32_t)((sg >> 42) & SIG_PAD);
-			d_fid[o] = (int32_t)a; e_list[o] = u; o++;
-			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_list[o] = u; o++; }
-			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_list[o] = u; }
+			// the feature-major entries of such a list carry the set itself (k_share_reduce)
+			d_fid[o] = (int32_t)a; e_key[o] = a; e_val[o] = sg; o++;
+			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_key[o] = b; e_val[o] = sg; o++; }
+			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_key[o] = c; e_val[o] = sg; }
 		} else {
 			const uint32_t j = perm[i];
 			const uint32_t s = m_off[j], e = m_off[j + 1];
-			for (uint32_t k = s; k < e; ++k) { d_fid[o] = m_fid[k]; e_list[o] = u; o++; }
+			for (uint32_t k = s; k < e; ++k) {
+				d_fid[o] = m_fid[k]; e_key[o] = (uint32_t)m_fid[k]; e_val[o] = SIG_HASHED | u; o++;
+			}
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -426,6 +448,35 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 		d_tot[1] = E2;
 		d_off[U] = E2;                 // CSR sentinel
 		hpos[U] = (uint32_t)n_lists;   // so that weight(u) = hpos[u+1] - hpos[u]
+	}
+}
+
+// The weight of a merged list (how many inserts had exactly this set) rides in the key bits
+// above the feature id of its entries; a list whose weight does not fit there, like a list
+// whose set did not fit a signature, takes the general path: its entries name the list
+// (SIG_HASHED | u) and k_list_recip computes recip[u] for it.  gen[u] = 1 for those.
+__global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(const unsigned long long *__restrict__ d_tot,
+                                                            const uint32_t *__restrict__ d_off,
+                                                            const uint32_t *__restrict__ hpos, int bits,
+                                                            uint32_t *__restrict__ e_key,
+                                                            unsigned long long *__restrict__ e_val,
+                                                            uint8_t *__restrict__ gen) {
+	const int64_t n_lists = (int64_t)d_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t u = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; u < n_lists; u += stride) {
+		const uint32_t s = d_off[u], e = d_off[u + 1];
+		const uint32_t w = hpos[u + 1] - hpos[u];
+		const bool hashed = (e_val[s] & SIG_HASHED) != 0;
+		// (w + 1: the all-ones key is the sentinel of k_share_reduce)
+		const bool fits = bits < 32 && (((unsigned long long)w + 1ull) >> (32 - bits)) == 0ull;
+		if (!hashed && fits) {
+			for (uint32_t o = s; o < e; ++o) e_key[o] |= w << bits;
+			gen[u] = 0;
+		} else {
+			if (!hashed)
+				for (uint32_t o = s; o < e; ++o) e_val[o] = SIG_HASHED | (unsigned long long)u;
+			gen[u] = 1;
+		}
 	}
 }
 
@@ -454,12 +505,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
                                                           const uint32_t *__restrict__ m_off,
                                                           const int32_t *__restrict__ m_fid,
                                                           const uint32_t *__restrict__ hpos,
+                                                          const uint8_t *__restrict__ gen,
                                                           const double *__restrict__ a, double *__restrict__ recip,
                                                           const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
+		if (!gen[j]) continue;          // the entries of this list carry its set: nothing to precompute
 		const uint32_t s = m_off[j], e = m_off[j + 1];
 		const uint32_t w = hpos[j + 1] - hpos[j];
 		double sum = 0;
@@ -527,8 +580,9 @@ __device__ __forceinline__ SegRow seg_row(uint32_t key, double v, bool valid, ui
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
-                                                            const uint32_t *__restrict__ t_val,
+                                                            const unsigned long long *__restrict__ t_val,
                                                             const double *__restrict__ recip,
+                                                            const double *__restrict__ a, int bits,
                                                             double *__restrict__ share,
                                                             uint32_t *__restrict__ part_key,
                                                             double *__restrict__ part_val,
@@ -546,6 +600,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		return;
 	}
 	const int64_t c1 = (c0 + SR_CHUNK < E) ? c0 + SR_CHUNK : E;
+	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	// the open segment carried from step to step (its sum so far, whether it began inside this chunk)
 	double carry = 0.0;
 	bool carry_started = false, carry_open = false;
@@ -555,28 +610,57 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	for (int64_t base = c0; base < c1; base += SR_STEP) {
 		// ---- loads: SR_EPL consecutive entries per lane, then their reciprocals, all independent ----
 		const int64_t r0 = base + (int64_t)lane * SR_EPL;
-		uint32_t k[SR_EPL], lv[SR_EPL];
+		uint32_t k[SR_EPL];
+		unsigned long long lv[SR_EPL];
 		if (base + SR_STEP <= c1) {
 			const uint4 *kp = reinterpret_cast<const uint4 *>(t_key + r0);
-			const uint4 *vp = reinterpret_cast<const uint4 *>(t_val + r0);
-			const uint4 ka = kp[0], kb = kp[1], va = vp[0], vb = vp[1];
+			const ulonglong2 *vp = reinterpret_cast<const ulonglong2 *>(t_val + r0);
+			const uint4 ka = kp[0], kb = kp[1];
+			const ulonglong2 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
 			k[0] = ka.x; k[1] = ka.y; k[2] = ka.z; k[3] = ka.w; k[4] = kb.x; k[5] = kb.y; k[6] = kb.z; k[7] = kb.w;
-			lv[0] = va.x; lv[1] = va.y; lv[2] = va.z; lv[3] = va.w; lv[4] = vb.x; lv[5] = vb.y; lv[6] = vb.z; lv[7] = vb.w;
+			lv[0] = v0.x; lv[1] = v0.y; lv[2] = v1.x; lv[3] = v1.y; lv[4] = v2.x; lv[5] = v2.y; lv[6] = v3.x; lv[7] = v3.y;
 		} else {
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool ok = r0 + i < c1;
 				k[i] = ok ? t_key[r0 + i] : SR_SENT;        // entries past the end: a neutral last segment
-				lv[i] = ok ? t_val[r0 + i] : 0u;
+				lv[i] = ok ? t_val[r0 + i] : 0ull;
 			}
 		}
 		uint32_t after = SR_SENT;                            // key of the entry following this step
-		if (lane == 63 && base + SR_STEP < E) after = t_key[base + SR_STEP];
+		if (lane == 63 && base + SR_STEP < E) after = t_key[base + SR_STEP] & fmask;
 		uint32_t before = 0;
-		if (lane == 0 && base == c0 && c0 > 0) before = t_key[c0 - 1];
+		if (lane == 0 && base == c0 && c0 > 0) before = t_key[c0 - 1] & fmask;
+		// Each entry's term w/S.  A list of <= 3 features travels with its entries (signature in
+		// the value, weight above the feature id in the key): S is summed here from a[] -- 8 MB that
+		// the L2s hold well -- in ascending feature order, the order k_list_recip and
+		// k_prop_purged use, so every entry of a list gets the same bits.  Other lists: recip[u].
 		double x[SR_EPL];
+		{
+			double a0[SR_EPL], a1[SR_EPL], a2[SR_EPL];
 #pragma unroll
-		for (int i = 0; i < SR_EPL; i++) x[i] = (k[i] != SR_SENT) ? recip[lv[i]] : 0.0;
+			for (int i = 0; i < SR_EPL; i++) {
+				const bool live = k[i] != SR_SENT;
+				const bool general = (lv[i] & SIG_HASHED) != 0;
+				const uint32_t fa = (uint32_t)(lv[i] & SIG_PAD), fb = (uint32_t)((lv[i] >> 21) & SIG_PAD),
+				               fc = (uint32_t)((lv[i] >> 42) & SIG_PAD);
+				a0[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[fa];
+				a1[i] = (live && !general && fb != SIG_PAD) ? a[fb] : 0.0;
+				a2[i] = (live && !general && fc != SIG_PAD) ? a[fc] : 0.0;
+			}
+#pragma unroll
+			for (int i = 0; i < SR_EPL; i++) {
+				const bool live = k[i] != SR_SENT;
+				const bool general = (lv[i] & SIG_HASHED) != 0;
+				const uint32_t fb = (uint32_t)((lv[i] >> 21) & SIG_PAD), fc = (uint32_t)((lv[i] >> 42) & SIG_PAD);
+				double sum = a0[i];
+				if (fb != SIG_PAD) sum += a1[i];
+				if (fc != SIG_PAD) sum += a2[i];
+				const double w = (double)(bits < 32 ? (k[i] >> bits) : 0u);
+				x[i] = !live ? 0.0 : general ? a0[i] : (sum > 0 ? w / sum : 0.0);
+				if (live) k[i] &= fmask;                     // from here on: the feature id
+			}
+		}
 
 		// ---- neighbours across lanes ----
 		uint32_t pk = __shfl_up(k[SR_EPL - 1], 1, 64);
@@ -766,27 +850,33 @@ static int nf_grid(msx_ctx *ctx, int32_t nf) {
 	return g > PROP_MAX_BLOCKS ? PROP_MAX_BLOCKS : g;
 }
 
-// stable LSD radix sort of (key, val) pairs; *n_ptr (device) items, at most n_ub.
-// Ping-pongs between p->t_key/t_val[0] and [1]; returns the buffer holding the result.
-static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, const uint32_t *vin, int vin_buf,
+// stable LSD radix sort of (key, val) pairs on the low `bits` bits of the key; *n_ptr (device)
+// items, at most n_ub.  V = uint32_t: values ping-pong between p->t_val[0] and [1];
+// V = unsigned long long: between p->t_val64[0] and [1]; keys between p->t_key[0] and [1].
+// Returns the buffer holding the result.
+template <typename V>
+static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, const V *vin, int vin_buf,
                             const unsigned long long *n_ptr, int64_t n_ub, int bits, int *out_buf) {
 	const int passes = (bits + 7) / 8;
 	const int64_t n_waves = (n_ub + RS_TILE - 1) / RS_TILE;   // tiles
 	const unsigned nblk = (unsigned)n_waves;
+	msx_buf *vbuf = sizeof(V) == 8 ? p->t_val64 : p->t_val;
 	int cur = vin_buf, rc;
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
+		const int left = bits - 8 * ps;
+		const uint32_t dmask = left >= 8 ? 255u : ((1u << left) - 1u);
 		MSX_TIMED(ctx, MSX_K_RS_HIST,
 		          hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr,
-		                             (int64_t)0, ps * 8, (uint32_t *)p->rs_hist.p, n_waves));
+		                             (int64_t)0, ps * 8, dmask, (uint32_t *)p->rs_hist.p, n_waves));
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
 			return rc;
 		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
-		          hipLaunchKernelGGL((k_rs_scatter<true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, vin,
-		                             (uint32_t *)p->t_key[dst].p, (uint32_t *)p->t_val[dst].p, n_ptr, (int64_t)0,
-		                             ps * 8, (const uint32_t *)p->rs_off.p, n_waves));
+		          hipLaunchKernelGGL((k_rs_scatter<V, true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin,
+		                             vin, (uint32_t *)p->t_key[dst].p, (V *)vbuf[dst].p, n_ptr, (int64_t)0, ps * 8,
+		                             dmask, (const uint32_t *)p->rs_off.p, n_waves));
 		kin = (const uint32_t *)p->t_key[dst].p;
-		vin = (const uint32_t *)p->t_val[dst].p;
+		vin = (const V *)vbuf[dst].p;
 		cur = dst;
 	}
 	*out_buf = cur;
@@ -848,30 +938,35 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p, (unsigned long long *)p->ssig.p));
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub))) return rc;
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub))) return rc;
-		// the (feature, list) pairs of the derived store are written as it is built: features to
-		// m_fid_alt, list numbers to the value buffer the list sort is not holding its result in
+		// the feature-major entries are written as the derived store is built: key = feature (the
+		// sorted list keys in t_key[] are no longer needed), value = the list's signature or number
 		ebuf = sb ^ 1;
+		for (int i = 0; i < 2; i++)
+			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64) * 8))) return rc;
+		if ((rc = msx_reserve(ctx, &p->gen, (size_t)(lub + 8)))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_uniq_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                             tot, perm, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
 		                             (const uint32_t *)p->eoff.p, (const unsigned long long *)p->ssig.p,
 		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
 		                             (uint32_t *)p->m_off_alt.p, (int32_t *)p->m_fid_alt.p,
-		                             (uint32_t *)p->t_val[ebuf].p, (uint32_t *)p->hpos.p, lub, p->d_tot));
+		                             (uint32_t *)p->t_key[ebuf].p, (unsigned long long *)p->t_val64[ebuf].p,
+		                             (uint32_t *)p->hpos.p, lub, p->d_tot));
+		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
+		          hipLaunchKernelGGL(k_entry_weight, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
+		                             (const uint32_t *)p->hpos.p, bits, (uint32_t *)p->t_key[ebuf].p,
+		                             (unsigned long long *)p->t_val64[ebuf].p, (uint8_t *)p->gen.p));
 	}
 	tot = p->d_tot;      // everything below works on the derived store
+	p->key_bits = bits;
 
 	// (b) feature-major view: (feature, list) pairs sorted by feature
-	int cur = ebuf;
-	if (bits > 0) {
-		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_fid_alt.p, (const uint32_t *)p->t_val[ebuf].p, ebuf,
-		                           tot + 1, eub, bits, &cur)))
-			return rc;
-	} else {
-		// a single feature: the list-major order is already feature-major
-		size_t nb = (size_t)eub * 4 < p->m_fid_alt.cap ? (size_t)eub * 4 : p->m_fid_alt.cap;
-		MSX_HIP(ctx, hipMemcpyAsync(p->t_key[ebuf].p, p->m_fid_alt.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
-	}
+	int cur = ebuf;     // (a single feature: the list-major order is already feature-major)
+	if (bits > 0 && (rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[ebuf].p,
+	                                       (const unsigned long long *)p->t_val64[ebuf].p, ebuf, tot + 1, eub, bits,
+	                                       &cur)))
+		return rc;
 	p->sorted_buf = cur;
 	p->transposed_valid = true;
 	MSX_HIP(ctx, hipGetLastError());
@@ -884,16 +979,18 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
 	MSX_TIMED(ctx, MSX_K_LIST_RECIP,
 	          hipLaunchKernelGGL(k_list_recip, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
-	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p, (const double *)p->a,
-	                             (double *)p->recip.p, (const int32_t *)p->iter_state));
+	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p,
+	                             (const uint8_t *)p->gen.p, (const double *)p->a, (double *)p->recip.p,
+	                             (const int32_t *)p->iter_state));
 	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
 	const unsigned nblk = (unsigned)(((n_waves + 3) / 4 + 7) / 8 * 8);
 	const int64_t M = (int64_t)nblk * 4 * 2;              // two partial slots per launched wave
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
 	          hipLaunchKernelGGL(k_share_reduce, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
-	                             (const uint32_t *)p->t_val[p->sorted_buf].p, (const double *)p->recip.p, p->share,
-	                             (uint32_t *)p->part_key.p, (double *)p->part_val.p,
+	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
+	                             (const double *)p->a, p->key_bits, p->share, (uint32_t *)p->part_key.p,
+	                             (double *)p->part_val.p,
 	                             (const int32_t *)p->iter_state));
 	const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
 	MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
