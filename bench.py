@@ -90,27 +90,30 @@ def algorithmic_bytes(name, w):
         # reads flag 2, rflags 1, cigar_off 4, cigar, md_off 4, md ; writes the pool byte
         return 2 * n + n + 4 * (n + 1) + 4 * w["n_cig"] + 4 * (n + 1) + w["n_md"] + n
     if name == "k_besthit_select":
-        # reads group_off, flag, rflags, pool byte, AS ; writes keep, per-pool count
-        return 4 * (ng + 1) + 2 * n + n + n + 4 * n + n + 4 * ng
+        # reads group_off, flag, rflags, pool byte, AS ; writes keep, per-pool count ; fused insert accounting:
+        # reads tid of the kept records ; writes the unique-insert key 4, the list length 8 and the
+        # distinct features of multi-mapped pools (E0 entries as accumulated)
+        return 4 * (ng + 1) + 2 * n + n + n + 4 * n + n + 4 * ng + 4 * w["n_emit"] + 12 * ng + 4 * w["E0"]
     if name == "k_emit_order":
         return 4 * (ng + 1) + n + 4 * (ng + 1) + 4 * w["n_emit"]
     if name == "k_insert_count":
-        # reads group_off, keep, tid of kept records ; writes list lengths and distinct lists ; RMW ui
-        return 4 * (ng + 1) + n + 4 * w["n_emit"] + 8 * ng + 4 * (E + w["uniq"]) + 8 * w["uniq"]
+        # counting the unique-insert keys by partition: histogram reads the keys, scatter reads them again and
+        # writes the kept ones, the count kernel reads those and updates ui once per feature
+        return 8 * ng + 8 * w["uniq"] + 8 * nf
     if name == "k_multi_compact":
         return 16 * ng + 4 * L + 8 * E + 4 * L
     if name == "k_list_recip":
         # offsets 4(L+1), feature ids 4E, gather a 8E, recip write 8L
         return 4 * (L + 1) + 12 * E + 8 * L
     if name == "k_share_reduce":
-        # feature id 4E, list id 4E, gather recip 8E, share write 8 per feature
-        return 16 * E + 8 * nf
+        # entry key 4E + value 8E (the list's signature), a[] read once 8 per feature, share written 8 per feature
+        return 12 * E + 16 * nf
     if name == "k_prop_apply":
         return 40 * nf
     if name == "k_rs_hist":
         return 4 * E + 1024 * ((E + 2047) // 2048)
     if name == "k_rs_scatter":
-        return 16 * E + 1024 * ((E + 2047) // 2048)
+        return 20 * E + 1024 * ((E + 4095) // 4096)
     if name == "scan":
         return 12 * ng
     return 0
@@ -271,7 +274,7 @@ def main():
         n_lists, n_entries = prof.shared_size()        # after identical feature sets were merged
         w = dict(n=n, ng=ng, n_cig=int(sz.n_cigar), n_md=int(sz.n_md), n_emit=state["n_emit"],
                  kept_groups=int(st1.insert_count), uniq=int(st1.uniq_mapper_count), L=n_lists, E=n_entries,
-                 nf=nrefs)
+                 E0=n_entries0, nf=nrefs)
 
         def gbps(k):
             ms_step, launches = tms[k]
