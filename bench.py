@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--groups", type=int, default=0, help="override QNAME groups per GPU")
     ap.add_argument("--refs", type=int, default=0, help="override number of references")
-    ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-groups", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -103,8 +103,9 @@ def algorithmic_bytes(name, w):
     if name == "k_multi_compact":
         return 16 * ng + 4 * L + 8 * E + 4 * L
     if name == "k_list_recip":
-        # offsets 4(L+1), feature ids 4E, gather a 8E, recip write 8L
-        return 4 * (L + 1) + 12 * E + 8 * L
+        # only the lists that do not travel with their entries (> 3 features) are processed; their number is
+        # not known on the host, so this kernel is not priced (0 = no algorithmic figure)
+        return 0
     if name == "k_share_reduce":
         # entry key 4E + value 8E (the list's signature), a[] read once 8 per feature, share written 8 per feature
         return 12 * E + 16 * nf
@@ -316,8 +317,9 @@ def main():
                       f"({best:.2f} s each)",
         }
 
-        # the same oracle on every host core: pool-aligned shards of the sample run in parallel
-        # (ctypes releases the GIL), counts would be reduced on the host -- the "best CPU" figure
+        # the same oracle with every host core: filter (the per-record walk + best hit, the bulk of the
+        # time) on pool-aligned shards in parallel (ctypes releases the GIL), then one profile pass over
+        # the concatenated selection -- the "best CPU" figure
         try:
             from concurrent.futures import ThreadPoolExecutor
             ncores = min(os.cpu_count() or 1, 64)
@@ -326,20 +328,24 @@ def main():
             shards = [orc.make_records_slice(hs, hs.name_id, cuts[i], cuts[i + 1]) for i in range(ncores)
                       if cuts[i + 1] > cuts[i]]
 
+            starts = [cuts[i] for i in range(ncores) if cuts[i + 1] > cuts[i]]
+
             def one(sh):
-                f2 = orc.run_filter(sh, name_id=sh.name_id, **FILTER_OPTS)
-                orc.run_profile(sh, nrefs, multi="proportional", sel=f2["emit"], name_id=sh.name_id)
+                return orc.run_filter(sh, name_id=sh.name_id, **FILTER_OPTS)["emit"]
 
             bestn = None
             with ThreadPoolExecutor(max_workers=len(shards)) as ex:
                 for _ in range(2):
                     t0 = time.perf_counter()
-                    list(ex.map(one, shards))
+                    parts = list(ex.map(one, shards))
+                    sel = np.concatenate([e.astype(np.int64) + st for e, st in zip(parts, starts)]).astype(np.int32)
+                    orc.run_profile(hs, nrefs, multi="proportional", sel=sel)
                     dt = time.perf_counter() - t0
                     bestn = dt if bestn is None else min(bestn, dt)
             out["cpu_baseline_all_cores"] = {
                 "value": round(hs.n_records / bestn / 1e6, 2), "unit": "M alignments/s", "cores": len(shards),
-                "kind": "port", "sample": f"same sample cut into {len(shards)} pool-aligned shards, one thread each"}
+                "kind": "port", "sample": f"same sample; filter on {len(shards)} pool-aligned shards in parallel "
+                                          f"threads, then one profile pass ({bestn:.2f} s)"}
         except Exception as exc:      # never let the extra figure break the bench line
             out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
 
