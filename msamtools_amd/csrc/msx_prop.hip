@@ -516,16 +516,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 		const uint32_t s = m_off[j], e = m_off[j + 1];
 		const uint32_t w = hpos[j + 1] - hpos[j];
 		double sum = 0;
-		if (e - s <= 4u) {
-			// short list: feature ids, then abundances, as independent loads; summed in list order
-			int32_t f[4];
-			double x[4];
+		if (e - s <= 8u) {
+			// feature ids, then abundances, as independent loads; summed in list order
+			// (the lists that reach this kernel have more than three features)
+			int32_t f[8];
+			double x[8];
 #pragma unroll
-			for (int q = 0; q < 4; q++) f[q] = (s + (uint32_t)q < e) ? m_fid[s + q] : -1;
+			for (int q = 0; q < 8; q++) f[q] = (s + (uint32_t)q < e) ? m_fid[s + q] : -1;
 #pragma unroll
-			for (int q = 0; q < 4; q++) x[q] = (f[q] >= 0) ? a[f[q]] : 0.0;
+			for (int q = 0; q < 8; q++) x[q] = (f[q] >= 0) ? a[f[q]] : 0.0;
 #pragma unroll
-			for (int q = 0; q < 4; q++)
+			for (int q = 0; q < 8; q++)
 				if (s + (uint32_t)q < e) sum += x[q];
 		} else {
 			for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
