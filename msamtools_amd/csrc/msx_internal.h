@@ -150,7 +150,6 @@ struct msx_profile {
 	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
 	msx_buf m_off_alt, m_fid_alt, len2;   // derived store: renumbered, duplicate lists merged
-	msx_buf sig, ssig;                    // per-list set signatures (accumulated order / sorted order)
 	msx_buf head, uidx, eoff, hpos;       // dedupe scratch; hpos[u+1]-hpos[u] = weight of merged list u
 	unsigned long long *d_tot = nullptr;  // device {lists, entries} of the derived store
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs

@@ -292,7 +292,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // Signature of a list: sets of <= 3 features (the common case) are packed exactly --
 // three 21-bit fields in ascending order, unused fields = SIG_PAD -- so that equal
 // signatures mean equal sets and the set itself can be rebuilt from the signature;
-// anything else gets bit 63 and a hash, and is compared entry by entry.
+// anything else gets bit 63, a 31-bit hash of the set and, in the low half, the number of the
+// list (so that it can be found again after the sort), and is compared entry by entry.
 #define SIG_PAD 0x1fffffu
 #define SIG_HASHED (1ull << 63)
 
@@ -303,7 +304,7 @@ __device__ __forceinline__ uint32_t sig_len(unsigned long long sg) {
 __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long *__restrict__ csr_tot,
                                                         const uint32_t *__restrict__ m_off,
                                                         const int32_t *__restrict__ m_fid, int hash_bits,
-                                                        uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                        uint32_t *__restrict__ key,
                                                         unsigned long long *__restrict__ sig) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long
 			if (a > b) { t = a; a = b; b = t; }
 			mn = a;
 			sg = fits ? ((unsigned long long)a | ((unsigned long long)b << 21) | ((unsigned long long)c << 42))
-			          : (SIG_HASHED | ((unsigned long long)h2 << 31) | (h >> 1));
+			          : (SIG_HASHED | ((unsigned long long)(h2 >> 1) << 32) | (unsigned long long)(uint32_t)j);
 			if (e == s) mn = 0xffffffffu;
 		} else {
 			for (uint32_t k = s; k < e; ++k) {
@@ -336,38 +337,34 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long
 				h += mix32(f);                                   // commutative: a hash of the set
 				h2 += mix32(f ^ 0x5bd1e995u);
 			}
-			sg = SIG_HASHED | ((unsigned long long)h2 << 31) | (h >> 1);
+			sg = SIG_HASHED | ((unsigned long long)(h2 >> 1) << 32) | (unsigned long long)(uint32_t)j;
 		}
 		const uint32_t hb = hash_bits > 0 ? (h & ((1u << hash_bits) - 1u)) : 0u;
 		key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
-		val[j] = (uint32_t)j;
-		sig[j] = sg;
+		sig[j] = sg;                                          // travels through the sort as the value
 	}
 }
 
 // head[i] = 1 when the list at sorted position i is not the same set as its predecessor;
-// len2[i] = its length for heads, 0 for merged duplicates (and beyond the last list);
-// ssig[i] = its signature (sorted order, for k_uniq_gather)
+// len2[i] = its length for heads, 0 for merged duplicates (and beyond the last list).
+// ssig = the signatures in sorted order (the values of the list sort): no gather is needed
 __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long *__restrict__ csr_tot, int64_t m,
                                                         const uint32_t *__restrict__ skey,
-                                                        const uint32_t *__restrict__ perm,
-                                                        const unsigned long long *__restrict__ sig,
+                                                        const unsigned long long *__restrict__ ssig,
                                                         const uint32_t *__restrict__ m_off,
                                                         const int32_t *__restrict__ m_fid,
-                                                        uint32_t *__restrict__ head, uint32_t *__restrict__ len2,
-                                                        unsigned long long *__restrict__ ssig) {
+                                                        uint32_t *__restrict__ head, uint32_t *__restrict__ len2) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	const int lane = threadIdx.x & 63;
 	for (int64_t i0 = (int64_t)blockIdx.x * MSX_BLOCK; i0 < m; i0 += stride) {
 		const int64_t i = i0 + threadIdx.x;
 		const bool in = i < n_lists;
-		uint32_t j = 0;
 		unsigned long long sg = 0;
-		if (in) { j = perm[i]; sg = sig[j]; }
+		if (in) sg = ssig[i];
 		// the predecessor's signature: the lane below has it, except for lane 0
 		unsigned long long prev = __shfl_up(sg, 1, 64);
-		if (in && lane == 0 && i > 0) prev = sig[perm[i - 1]];
+		if (in && lane == 0 && i > 0) prev = ssig[i - 1];
 		uint32_t hd = 0, l = 0;
 		if (in) {
 			hd = 1;
@@ -375,10 +372,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 				l = sig_len(sg);
 				if (i > 0 && sg == prev) hd = 0;                  // exact: equal signature = equal set
 			} else {
+				const uint32_t j = (uint32_t)sg;
 				const uint32_t s = m_off[j], e = m_off[j + 1];
 				l = e - s;
-				if (i > 0 && sg == prev && skey[i] == skey[i - 1] && l <= 32u) {
-					const uint32_t jp = perm[i - 1];
+				if (i > 0 && (sg >> 32) == (prev >> 32) && skey[i] == skey[i - 1] && l <= 32u) {
+					const uint32_t jp = (uint32_t)prev;
 					const uint32_t sp = m_off[jp], ep = m_off[jp + 1];
 					if (ep - sp == l) {
 						// both lists hold distinct features, so equal sizes + inclusion = equal sets
@@ -397,7 +395,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 		if (i < m) {
 			head[i] = hd;
 			len2[i] = hd ? l : 0u;
-			if (in) ssig[i] = sg;
 		}
 	}
 }
@@ -405,7 +402,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 // unique list u (sorted position i, a head): offsets, entries, and the sorted position itself
 // (weights are differences of consecutive head positions)
 __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long long *__restrict__ csr_tot,
-                                                           const uint32_t *__restrict__ perm,
                                                            const uint32_t *__restrict__ head,
                                                            const uint32_t *__restrict__ uidx,
                                                            const uint32_t *__restrict__ eoff,
@@ -435,7 +431,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_key[o] = b; e_val[o] = sg; o++; }
 			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_key[o] = c; e_val[o] = sg; }
 		} else {
-			const uint32_t j = perm[i];
+			const uint32_t j = (uint32_t)sg;
 			const uint32_t s = m_off[j], e = m_off[j + 1];
 			for (uint32_t k = s; k < e; ++k) {
 				d_fid[o] = m_fid[k]; e_key[o] = (uint32_t)m_fid[k]; e_val[o] = SIG_HASHED | u; o++;
@@ -902,7 +898,6 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	int rc;
 	for (int i = 0; i < 2; i++) {
 		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &p->t_val[i], (size_t)(eub + 64) * 4))) return rc;
 	}
 	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
 	{
@@ -930,36 +925,32 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if ((rc = msx_reserve(ctx, &p->uidx, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->eoff, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->hpos, (size_t)(lub + 8) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &p->sig, (size_t)(lub + 8) * 8))) return rc;
-		if ((rc = msx_reserve(ctx, &p->ssig, (size_t)(lub + 8) * 8))) return rc;
+		for (int i = 0; i < 2; i++)
+			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64) * 8))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_list_key, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
 		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits,
-		                             (uint32_t *)p->t_key[0].p, (uint32_t *)p->t_val[0].p,
-		                             (unsigned long long *)p->sig.p));
+		                             (uint32_t *)p->t_key[0].p, (unsigned long long *)p->t_val64[0].p));
 		int sb = 0;
-		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p, (const uint32_t *)p->t_val[0].p, 0, tot + 0,
-		                           lub, bits + hash_bits, &sb)))
+		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p,
+		                           (const unsigned long long *)p->t_val64[0].p, 0, tot + 0, lub, bits + hash_bits, &sb)))
 			return rc;
 		const uint32_t *skey = (const uint32_t *)p->t_key[sb].p;
-		const uint32_t *perm = (const uint32_t *)p->t_val[sb].p;
+		const unsigned long long *ssig = (const unsigned long long *)p->t_val64[sb].p;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_dup_mark, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
-		                             lub, skey, perm, (const unsigned long long *)p->sig.p,
-		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
-		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p, (unsigned long long *)p->ssig.p));
+		                             lub, skey, ssig, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
+		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p));
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub))) return rc;
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub))) return rc;
-		// the feature-major entries are written as the derived store is built: key = feature (the
-		// sorted list keys in t_key[] are no longer needed), value = the list's signature or number
+		// the feature-major entries are written as the derived store is built, into the buffers the
+		// list sort is not holding its result in: key = feature, value = the list's signature or number
 		ebuf = sb ^ 1;
-		for (int i = 0; i < 2; i++)
-			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64) * 8))) return rc;
 		if ((rc = msx_reserve(ctx, &p->gen, (size_t)(lub + 8)))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_uniq_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                             tot, perm, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
-		                             (const uint32_t *)p->eoff.p, (const unsigned long long *)p->ssig.p,
+		                             tot, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
+		                             (const uint32_t *)p->eoff.p, ssig,
 		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
 		                             (uint32_t *)p->m_off_alt.p, (int32_t *)p->m_fid_alt.p,
 		                             (uint32_t *)p->t_key[ebuf].p, (unsigned long long *)p->t_val64[ebuf].p,
