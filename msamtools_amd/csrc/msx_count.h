@@ -17,12 +17,17 @@ struct CountArgs {
 	uint32_t *ui;
 	double *d;
 	uint32_t *counters;       // {inserts, uniq, multi, purged}
-	int32_t *tmp_fid;         // [n_records] scratch: pool g's distinct features at tmp_fid[group_off[g]..]
-	unsigned long long *mlen; // [n_groups] (is_multi_list << 32) | n_distinct  (0 when not kept)
+	int32_t *tmp_fid;         // [n_records] scratch: a multi-mapped pool g's distinct features at tmp_fid[group_off[g]..]
 	uint32_t tbl_mask;        // LDS staging table size - 1 (power of two, <= UI_TBL)
-	uint32_t *ukey;           // non-null: [n_groups] feature of a uniquely mapped insert (else 0xffffffff),
-	                          // counted afterwards by msx_count_keys instead of ui_add here
+	// one word per pool for the passes that follow (null: not needed):
+	//   feature id            uniquely mapped insert whose +2 is still to be counted (count_keys mode)
+	//   MSX_PINFO_LIST | nd   multi-mapped insert whose nd distinct features go to the multi-mapper store
+	//   MSX_PINFO_NONE        nothing to do
+	uint32_t *pinfo;
+	int32_t count_keys;       // unique inserts are counted afterwards by msx_count_keys, not by ui_add here
 };
+#define MSX_PINFO_LIST 0x80000000u
+#define MSX_PINFO_NONE 0xffffffffu
 
 // Per-workgroup staging of the per-reference adds in LDS: a small open-addressed
 // table (feature -> pending count).  Hot references (a few references receive a
@@ -75,7 +80,10 @@ __device__ __forceinline__ void pool_visit(const CountArgs &A, PoolAcc &v, int32
 		else if (v.nd == 1) v.f1 = fid;
 		else if (v.nd == 2) v.f2 = fid;
 		else if (v.nd == 3) v.f3 = fid;
-		v.lst[v.nd] = fid;
+		// the scratch list is only read for pools with two or more distinct features: the first
+		// feature is written when the second arrives (most pools never get there)
+		if (v.nd == 1) v.lst[0] = v.f0;
+		if (v.nd >= 1) v.lst[v.nd] = fid;
 		v.nd++;
 	}
 }
@@ -110,12 +118,11 @@ struct BlockCounts {
 // the pool's insert: unique / multi-mapper accounting
 __device__ __forceinline__ void pool_finish(const CountArgs &A, int64_t g, const PoolAcc &v, int32_t *s_key,
                                             uint32_t *s_val, BlockCounts &c) {
-	unsigned long long ml = 0;
-	uint32_t uk = 0xffffffffu;
+	uint32_t info = MSX_PINFO_NONE;
 	if (v.nvalid > 0) {
 		c.ins++;                                          // one insert per pool (:230,:237)
 		if (v.nd == 1) {                                  // :75-78, :87-91, :152-159
-			if (A.ukey) uk = (uint32_t)v.f0;
+			if (A.count_keys) info = (uint32_t)v.f0;
 			else ui_add(s_key, s_val, A.ui, v.f0, 2u, A.tbl_mask);
 			c.uniq++;
 		} else {
@@ -134,15 +141,14 @@ __device__ __forceinline__ void pool_finish(const CountArgs &A, int64_t g, const
 				}
 				break;
 			case MSX_MULTI_SHARE_PROPORTIONAL:            // :107-121, :184-186
-				ml = (1ull << 32) | v.nd;
+				info = MSX_PINFO_LIST | v.nd;
 				break;
 			default:                                      // MULTI_IGNORE
 				break;
 			}
 		}
 	}
-	if (A.mlen) A.mlen[g] = ml;
-	if (A.ukey) A.ukey[g] = uk;
+	if (A.pinfo) A.pinfo[g] = info;
 }
 
 // workgroup prologue / epilogue around the pools loop

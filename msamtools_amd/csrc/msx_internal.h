@@ -73,7 +73,7 @@ struct msx_ctx {
 	int num_cu = 256;
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
 	// workspace, grown on demand and kept
-	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, mlen, moff, tmp_fid, ukey, ukey2;
+	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, pinfo, moff, tmp_fid, ukey2;
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;
@@ -121,6 +121,8 @@ static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) { return 
 // exclusive scan: out[0..m] (m+1 entries, out[m] = total), u32
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
 int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m);
+// exclusive u64 scan of (1 << 32 | nd) over the pools whose word is MSX_PINFO_LIST | nd (msx_count.h), 0 for the others
+int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m);
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m);
 
 // profile state (one sample)
@@ -165,7 +167,7 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p);        // share[f] = sum_j
 int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
-// ui[key] += add for every key != 0xffffffff of keys[0..n) by partition + LDS counting (n_features <= 2 M)
+// ui[key] += add for every key < 0x80000000 of keys[0..n) by partition + LDS counting (n_features <= 2 M)
 int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add);
 #define MSX_COUNT_KEYS_MAX_FEATURES (256 * 8192)
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 
 // csr_tot = {n_lists, n_entries} running totals of the compact CSR
 __global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(int64_t n_groups, const uint32_t *__restrict__ group_off,
-                                                             const unsigned long long *__restrict__ mlen,
+                                                             const uint32_t *__restrict__ pinfo,
                                                              const unsigned long long *__restrict__ mscan,
                                                              const int32_t *__restrict__ tmp_fid,
                                                              const unsigned long long *__restrict__ csr_tot,
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(int64_t n_groups, c
 	const unsigned long long base_l = csr_tot[0], base_e = csr_tot[1];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < n_groups; g += stride) {
-		const unsigned long long ml = mlen[g];
-		if (!ml) continue;
-		const uint32_t nd = (uint32_t)ml;
+		const uint32_t info = pinfo[g];
+		if (!(info & MSX_PINFO_LIST) || info == MSX_PINFO_NONE) continue;
+		const uint32_t nd = info & ~MSX_PINFO_LIST;
 		const unsigned long long sc = mscan[g];
 		const unsigned long long li = base_l + (sc >> 32), ei = base_e + (sc & 0xffffffffull);
 		m_off[li] = (uint32_t)ei;
@@ -196,7 +196,6 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	int rc;
 	if ((rc = msx_reserve(ctx, &ctx->tmp_fid, (size_t)n * 4))) return rc;
 	if (prop) {
-		if ((rc = msx_reserve(ctx, &ctx->mlen, (size_t)(ng + 8) * 8))) return rc;
 		if ((rc = msx_reserve(ctx, &ctx->moff, (size_t)(ng + 8) * 8))) return rc;
 		p->lists_ub += ng;
 		p->entries_ub += n;
@@ -217,7 +216,6 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	A.d = p->d;
 	A.counters = p->counters;
 	A.tmp_fid = (int32_t *)ctx->tmp_fid.p;
-	A.mlen = prop ? (unsigned long long *)ctx->mlen.p : nullptr;
 	{
 		// Staging-table size (measured on MI355X): with ~1 M features a large table is needed to
 		// catch the hot references among the cold ones (2048: 1.5 ms vs 256: 2.7 ms at 20 M pools);
@@ -237,10 +235,11 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	bool by_part = p->n_features <= MSX_COUNT_KEYS_MAX_FEATURES && ng >= (1 << 20);
 	if (const char *e = getenv("MSX_COUNT_BY_PARTITION"))
 		by_part = atoi(e) != 0 && p->n_features <= MSX_COUNT_KEYS_MAX_FEATURES;
-	if (by_part) {
-		if ((rc = msx_reserve(ctx, &ctx->ukey, (size_t)(ng + 8) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &ctx->ukey2, (size_t)(ng + 8) * 4))) return rc;
-		A.ukey = (uint32_t *)ctx->ukey.p;
+	if (by_part && (rc = msx_reserve(ctx, &ctx->ukey2, (size_t)(ng + 8) * 4))) return rc;
+	A.count_keys = by_part ? 1 : 0;
+	if (by_part || prop) {
+		if ((rc = msx_reserve(ctx, &ctx->pinfo, (size_t)(ng + 8) * 4))) return rc;
+		A.pinfo = (uint32_t *)ctx->pinfo.p;
 	}
 	*out = A;
 	*by_part_out = by_part;
@@ -251,12 +250,12 @@ int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, b
 	const int64_t ng = b->n_groups;
 	const bool prop = p->share_type == MSX_MULTI_SHARE_PROPORTIONAL;
 	int rc;
-	if (by_part && (rc = msx_count_keys(ctx, p, (const uint32_t *)ctx->ukey.p, (uint32_t *)ctx->ukey2.p, ng, 2u))) return rc;
+	if (by_part && (rc = msx_count_keys(ctx, p, (const uint32_t *)ctx->pinfo.p, (uint32_t *)ctx->ukey2.p, ng, 2u))) return rc;
 	if (prop) {
-		if ((rc = msx_scan_u64(ctx, (const uint64_t *)ctx->mlen.p, (uint64_t *)ctx->moff.p, ng))) return rc;
+		if ((rc = msx_scan_pinfo(ctx, (const uint32_t *)ctx->pinfo.p, (uint64_t *)ctx->moff.p, ng))) return rc;
 		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);
 		hipLaunchKernelGGL(k_multi_compact, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, ng,
-		                   b->group_off, (const unsigned long long *)ctx->mlen.p,
+		                   b->group_off, (const uint32_t *)ctx->pinfo.p,
 		                   (const unsigned long long *)ctx->moff.p, (const int32_t *)ctx->tmp_fid.p,
 		                   (const unsigned long long *)p->csr_tot, (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p);
 		hipLaunchKernelGGL(k_multi_advance, dim3(1), dim3(1), 0, ctx->stream, ng,

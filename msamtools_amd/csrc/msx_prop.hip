@@ -32,9 +32,10 @@
 //                 order and writes it out from there: consecutive threads write consecutive
 //                 addresses inside a digit's run instead of 64 scattered 4-byte stores per row.
 // Order inside a digit is (wave, row, lane) = input order, so the pass is stable.
-// SKIP: keys equal to RS_NOKEY are not part of the input (k_part_count's producer marks
-// pools without a key that way); n_ptr == nullptr: the element count is n_host.
+// SKIP: keys with bit 31 set are not part of the input (the per-pool word of msx_count.h: only
+// a uniquely mapped insert holds a feature id there); n_ptr == nullptr: the element count is n_host.
 #define RS_NOKEY 0xffffffffu
+#define RS_SKIPPED(k) (((k) & 0x80000000u) != 0u)
 // one key into the wave's digit counters; when every lane of the wave holds the same digit
 // (sorted or heavily skewed input) one lane adds the whole row instead of 64 conflicting atomics
 __device__ __forceinline__ void hist_add(uint32_t *cnt, uint32_t d, bool valid) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
 			if (k < E) {
 				const uint32_t key = keys[k];
-				if (key != RS_NOKEY) atomicAdd(&s_cnt[w][(key >> shift) & dmask], 1u);
+				if (!RS_SKIPPED(key)) atomicAdd(&s_cnt[w][(key >> shift) & dmask], 1u);
 			}
 		}
 	} else if (base + RS_TILE <= E) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	uint32_t pos[RS_EPT];
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
-		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || key[r] != RS_NOKEY);
+		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]));
 		const uint32_t d = (key[r] >> shift) & dmask;
 		unsigned long long m = __ballot(valid);
 #pragma unroll
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	// 4. the tile in digit order, in LDS
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
-		if ((wbase + (uint32_t)r * 64u < n_here) && (!SKIP || key[r] != RS_NOKEY)) {
+		if ((wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]))) {
 			const uint32_t d = (key[r] >> shift) & dmask;
 			const uint32_t p = s_dstart[d] + s_cnt[w][d] + pos[r];
 			s_key[p] = key[r];
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_part_count(const uint32_t *__rest
 	}
 }
 
-// ui[key] += add for every key != RS_NOKEY among keys[0..n); keys < nf <= 256 * PC_RANGE.
+// ui[key] += add for every key without bit 31 among keys[0..n); such keys < nf <= 256 * PC_RANGE.
 // key2 = scratch of n keys.
 int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add) {
 	int shift = 0;

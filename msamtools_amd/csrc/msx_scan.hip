@@ -58,13 +58,30 @@ __device__ __forceinline__ void load8(const T *__restrict__ in, int64_t base, in
 	}
 }
 
-template <typename T>
-__global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const T *__restrict__ in, int64_t m,
+// PINFO: the input is the per-pool word of msx_count.h (u32); a pool with a multi-mapper list of
+// nd features counts as (1 << 32 | nd), every other pool as 0 -- the scan then carries
+// (list count << 32 | entry count) without the 8-byte-per-pool array ever being written.
+template <typename T, bool PINFO>
+__device__ __forceinline__ void load8x(const void *__restrict__ in, int64_t base, int64_t m, T (&v)[SCAN_ITEMS]) {
+	if (PINFO) {
+		uint32_t w[SCAN_ITEMS];
+		load8<uint32_t>(reinterpret_cast<const uint32_t *>(in), base, m, w);
+#pragma unroll
+		for (int k = 0; k < SCAN_ITEMS; k++)
+			v[k] = ((w[k] & 0x80000000u) && w[k] != 0xffffffffu && base + k < m)
+			           ? (T)((1ull << 32) | (unsigned long long)(w[k] & 0x7fffffffu)) : (T)0;
+	} else {
+		load8<T>(reinterpret_cast<const T *>(in), base, m, v);
+	}
+}
+
+template <typename T, bool PINFO = false>
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const void *__restrict__ in, int64_t m,
                                                            T *__restrict__ partial) {
 	__shared__ T s_w[4];
 	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
 	T v[SCAN_ITEMS];
-	load8<T>(in, base, m, v);
+	load8x<T, PINFO>(in, base, m, v);
 	T s = 0;
 #pragma unroll
 	for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
@@ -75,13 +92,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const T *__restrict__
 
 // carry == nullptr: single-chunk top level.  Writes out[i] for i < m and, from
 // the last block, out[m] = grand total.
-template <typename T, bool INCL>
-__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *in, T *out, int64_t m,
+template <typename T, bool INCL, bool PINFO = false>
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const void *in, T *out, int64_t m,
                                                           const T *__restrict__ carry) {
 	__shared__ T s_w[4];
 	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
 	T v[SCAN_ITEMS];
-	load8<T>(in, base, m, v);
+	load8x<T, PINFO>(in, base, m, v);
 	T s = 0;
 #pragma unroll
 	for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
@@ -115,12 +132,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const T *in, T *out, i
 	if (!INCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = c + tot;
 }
 
-template <typename T, bool INCL = false>
-static int scan_rec(msx_ctx *ctx, const T *in, T *out, int64_t m, int level) {
+template <typename T, bool INCL = false, bool PINFO = false>
+static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level) {
 	int64_t nb = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
 	if (nb < 1) nb = 1;
 	if (nb == 1) {
-		hipLaunchKernelGGL((k_scan_apply<T, INCL>), dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+		hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
 		                   (const T *)nullptr);
 		return MSX_OK;
 	}
@@ -131,10 +148,10 @@ static int scan_rec(msx_ctx *ctx, const T *in, T *out, int64_t m, int level) {
 	if (rc) return rc;
 	T *partial = (T *)lv->p;
 	T *pscan = partial + ((nb + 3) & ~(int64_t)3);
-	hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, m, partial);
-	rc = scan_rec<T, false>(ctx, partial, pscan, nb, level + 1);
+	hipLaunchKernelGGL((k_scan_reduce<T, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, m, partial);
+	rc = scan_rec<T, false, false>(ctx, partial, pscan, nb, level + 1);
 	if (rc) return rc;
-	hipLaunchKernelGGL((k_scan_apply<T, INCL>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+	hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
 	                   (const T *)pscan);
 	return MSX_OK;
 }
@@ -152,6 +169,15 @@ int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
 	int rc = scan_rec<uint32_t, true>(ctx, data, data, m, 0);
+	msx_time_end(ctx);
+	if (rc) return rc;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m) {
+	msx_time_begin(ctx, MSX_K_SCAN);
+	int rc = scan_rec<unsigned long long, false, true>(ctx, pinfo, (unsigned long long *)out, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
 	MSX_HIP(ctx, hipGetLastError());
