@@ -361,7 +361,7 @@ __device__ __forceinline__ uint8_t bh_keep(const BhAcc &c, bool w0, bool w1, boo
 // masks) when the selection is done, so the insert accounting of msx_count.h runs right
 // here instead of in a second kernel that would fetch group_off and the keep codes again.
 template <bool COUNT>
-__global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, CountArgs P) {
+__global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_besthit_select(SelectArgs A, CountArgs P) {
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
 	__shared__ int32_t s_key[COUNT ? UI_TBL : 1];
 	__shared__ uint32_t s_val[COUNT ? UI_TBL : 1];
