@@ -104,6 +104,19 @@ void msh_out_close(msh_out *o);
 void msh_sam_format(const msh_hdr *h, const uint8_t *rec, size_t len, kstr *line);   /* no trailing '\n' */
 void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec);                        /* line is modified */
 
+/* ---- ordered string set with the key order of the reference's hash table (msh_genome.c) ---- */
+typedef struct msh_keyset msh_keyset;
+msh_keyset *msh_keyset_new(void);
+int32_t msh_keyset_put(msh_keyset *k, const char *key, int32_t val);   /* id (order of first insertion); sets the value */
+int32_t msh_keyset_find(const msh_keyset *k, const char *key);          /* id or -1 */
+int32_t msh_keyset_size(const msh_keyset *k);
+int32_t msh_keyset_walk(const msh_keyset *k, int32_t pos);              /* id at position pos of the key walk */
+const char *msh_keyset_key(const msh_keyset *k, int32_t id);
+int32_t msh_keyset_value(const msh_keyset *k, int32_t id);
+void msh_keyset_free(msh_keyset *k);
+/* profile --genome=<file> (msam_profile.c:760-852): fmap[n_targets], feature names and summed lengths */
+int32_t *msh_genome_map(const char *path, const msh_hdr *h, int32_t *n_features, char ***names, uint32_t **lens);
+
 /* ---- subcommands ------------------------------------------------------------- */
 int msam_filter_main(int argc, char *argv[]);
 int msam_profile_main(int argc, char *argv[]);

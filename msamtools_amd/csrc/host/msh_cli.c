@@ -773,39 +773,6 @@ static void print_stats_dbl(gzFile s, int left, const char *type, double number,
 	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
 }
 
-/* --genome definition: feature order = order of first appearance in the file
- * (the reference orders features by its hash table's key walk,
- * zoeTools.c:258-266,365 -- documented difference). */
-static int32_t *load_genome_map(const char *path, const msh_hdr *h, int32_t *n_features, char ***names, uint32_t **lens) {
-	FILE *f = fopen(path, "r");
-	char line[8192], g[4096], s[4096];
-	int32_t *fmap = (int32_t *)malloc(sizeof(int32_t) * (size_t)(h->n_targets ? h->n_targets : 1)), i, nf = 0;
-	char **gn = NULL;
-	if (!f) mDie("Cannot open file %s", path);
-	for (i = 0; i < h->n_targets; i++) fmap[i] = -1;
-	while (fgets(line, sizeof line, f)) {
-		int32_t gi, tid;
-		if (sscanf(line, "%4095s\t%4095s", g, s) != 2) mDie("GENOME DEFINITION LINE ERROR");
-		for (gi = 0; gi < nf; gi++) if (strcmp(gn[gi], g) == 0) break;
-		if (gi == nf) {
-			gn = (char **)realloc(gn, sizeof(char *) * (size_t)(nf + 1));
-			gn[nf++] = strdup(g);
-		}
-		tid = msh_hdr_name2tid(h, s);
-		if (tid < 0) mDie("Sequence '%s' not found in BAM file", s);
-		fmap[tid] = gi;
-	}
-	fclose(f);
-	*lens = (uint32_t *)calloc((size_t)(nf ? nf : 1), sizeof(uint32_t));
-	for (i = 0; i < h->n_targets; i++) {
-		if (fmap[i] == -1) mDie("Sequence '%s' not found in genome definition", h->target_name[i]);
-		(*lens)[fmap[i]] += h->target_len[i];
-	}
-	*n_features = nf;
-	*names = gn;
-	return fmap;
-}
-
 int msam_profile_main(int argc, char *argv[]) {
 	static const struct option lopts[] = {
 	    {"help", no_argument, 0, 1000},        {"label", required_argument, 0, 1001},
@@ -904,7 +871,7 @@ int msam_profile_main(int argc, char *argv[]) {
 	if (unit_type == 1 || unit_type == 4) length_normalize = (o_nolen == 0);   /* :752-755 */
 
 	if (o_genome) {
-		fmap = load_genome_map(o_genome, hdr, &n_features, &feature_name, &feature_len);
+		fmap = msh_genome_map(o_genome, hdr, &n_features, &feature_name, &feature_len);
 	} else {
 		n_features = hdr->n_targets;
 		feature_name = hdr->target_name;
@@ -1329,6 +1296,19 @@ static int synth_main(int argc, char *argv[]) {
 
 int main(int argc, char *argv[]) {
 	if (argc < 2) return usage(stderr);
+	if (strcmp(argv[1], "keyorder") == 0) {
+		/* hidden, host only: names on stdin (one per line) -> the reference's key order on stdout */
+		char line[8192];
+		msh_keyset *k = msh_keyset_new();
+		int32_t i;
+		while (fgets(line, sizeof line, stdin)) {
+			line[strcspn(line, "\n")] = 0;
+			msh_keyset_put(k, line, 1);
+		}
+		for (i = 0; i < msh_keyset_size(k); i++) printf("%s\n", msh_keyset_key(k, msh_keyset_walk(k, i)));
+		msh_keyset_free(k);
+		return 0;
+	}
 	if (strcmp(argv[1], "recode") == 0) return recode_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);

@@ -8,6 +8,7 @@
 #include "msx_oracle.h"
 
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -672,4 +673,68 @@ void orc_coverage(const orc_records *r, const int64_t *cov_off,
 			}
 		}
 	}
+}
+
+/* ------------------------------------------------------------------------- */
+/* zoeTools.c:202-363: the hash table whose key list orders the genomes       */
+/* ------------------------------------------------------------------------- */
+typedef struct { int32_t *item; int32_t n, cap; } orc_ivec;
+
+static void ivec_push(orc_ivec *v, int32_t x) {
+	if (v->n == v->cap) {
+		v->cap = v->cap ? 2 * v->cap : 4;
+		v->item = (int32_t *)realloc(v->item, sizeof(int32_t) * (size_t)v->cap);
+	}
+	v->item[v->n++] = x;
+}
+
+/* zoeHashFunc, :218-228 (plain char arithmetic, multipliers :202-210) */
+static int orc_zoe_slot(int slots, const char *key) {
+	static const double mult[7] = {3.1415926536, 2.7182818285, 1.6180339887, 1.7320508076,
+	                               2.2360679775, 2.6457513111, 3.3166247904};
+	double sum = 0;
+	size_t i;
+	for (i = 0; i < strlen(key); i++) sum += key[i] * mult[i % 7];
+	return (int)(slots * (sum - floor(sum)));
+}
+
+int32_t orc_key_order(const char *const *names, int32_t n, int32_t *order) {
+	int level = 1, slots = 4, s;                 /* zoeNewHash -> zoeExpandHash: level 1, pow(4, 1) slots (:304-314, :214-216) */
+	orc_ivec *bucket = (orc_ivec *)calloc((size_t)slots, sizeof(orc_ivec));
+	orc_ivec keys = {0, 0, 0};                   /* hash->keys: first-occurrence indices in list order */
+	int32_t i, j, nk;
+	for (i = 0; i < n; i++) {
+		/* zoeSetHash :330-357 */
+		orc_ivec *b = &bucket[orc_zoe_slot(slots, names[i])];
+		int found = 0;
+		for (j = 0; j < b->n; j++)
+			if (strcmp(names[b->item[j]], names[i]) == 0) { found = 1; break; }
+		if (found) continue;
+		ivec_push(&keys, i);
+		ivec_push(b, i);
+		if ((float)keys.n / (float)slots >= 2.0f) {
+			/* zoeExpandHash :230-279: one level up, old buckets re-inserted in slot order */
+			const int old_slots = slots;
+			orc_ivec *old = bucket;
+			level++;
+			slots = (int)pow(4, level);
+			bucket = (orc_ivec *)calloc((size_t)slots, sizeof(orc_ivec));
+			keys.n = 0;
+			for (s = 0; s < old_slots; s++) {
+				for (j = 0; j < old[s].n; j++) {
+					const int32_t id = old[s].item[j];
+					ivec_push(&keys, id);
+					ivec_push(&bucket[orc_zoe_slot(slots, names[id])], id);
+				}
+				free(old[s].item);
+			}
+			free(old);
+		}
+	}
+	nk = keys.n;
+	for (i = 0; i < nk; i++) order[i] = keys.item[i];     /* zoeKeysOfHash :365 */
+	for (s = 0; s < slots; s++) free(bucket[s].item);
+	free(bucket);
+	free(keys.item);
+	return nk;
 }

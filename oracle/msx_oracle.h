@@ -153,6 +153,15 @@ void orc_profile_finish(double *values, int32_t n_features,
 void orc_coverage(const orc_records *r, const int64_t *cov_off,
                   int32_t n_targets, int32_t *cov);
 
+/* --- feature order of `profile --genome` (msam_profile.c:779-805, zoeTools.c:202-363) --- */
+
+/* names[n] are inserted one by one into the reference's string hash table
+ * (zoeSetHash); order[] receives, for every position of zoeKeysOfHash, the
+ * index into names[] of the first occurrence of that key; returns the number
+ * of distinct keys.  Pinned by tests/golden/genome_order_vectors.json, which
+ * was produced by the reference's own zoeTools.c. */
+int32_t orc_key_order(const char *const *names, int32_t n, int32_t *order);
+
 #ifdef __cplusplus
 }
 #endif

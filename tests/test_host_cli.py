@@ -309,3 +309,69 @@ def test_cli_coverage_golden(tmp_path):
     r = run(["coverage", "-S", "-x", "-o", "-", src])
     text = gzip.decompress(r.stdout).decode()
     assert ">B" not in text and ">A" in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("multi", ["proportional", "all"])
+def test_cli_profile_genome_order_and_values(tmp_path, multi):
+    """profile --genome (msam_profile.c:760-852): features = genomes in the key order of the reference's
+    hash table (12 genomes: the 8th re-shuffles the first eight), values = the oracle's profile over
+    the tid -> genome map."""
+    import ctypes as C
+    import oracle_lib as orc
+    rnd = np.random.RandomState(5)
+    n_seq, n_gen = 40, 12
+    seq = [f"contig_{i:03d}" for i in range(n_seq)]
+    gen_of = [f"strain_{(i * 7) % n_gen:02d}" for i in range(n_seq)]
+    lens = [int(x) for x in rnd.randint(500, 3000, n_seq)]
+    lines = ["@HD\tVN:1.6\tSO:queryname"] + [f"@SQ\tSN:{s}\tLN:{l}" for s, l in zip(seq, lens)]
+    for r in range(400):
+        hits = rnd.choice(n_seq, size=int(rnd.choice([1, 1, 1, 2, 3])), replace=False)
+        for h in hits:
+            lines.append(f"read{r:04d}\t0\t{seq[h]}\t{int(rnd.randint(1, 400))}\t60\t50M\t*\t0\t0\t" + "A" * 50 + "\t" + "I" * 50 +
+                         "\tAS:i:50\tNM:i:0\tMD:Z:50")
+    sam = str(tmp_path / "g.sam")
+    open(sam, "w").write("\n".join(lines) + "\n")
+    gdef = str(tmp_path / "genomes.tsv")
+    order_in_file = list(rnd.permutation(n_seq))
+    open(gdef, "w").write("".join(f"{gen_of[i]}\t{seq[i]}\n" for i in order_in_file))
+    out = str(tmp_path / "p.gz")
+    r = run(["profile", "-S", "--label", "t", "--unit", "rel", "--multi", multi, "--genome", gdef, "-o", out, sam])
+    assert r.returncode == 0, r.stderr.decode()
+    head, rows = read_profile(out)
+    # expected order: the oracle's restatement of the reference's key walk (pinned to the reference's own
+    # table by tests/test_genome_order_cpu.py)
+    names = [gen_of[i].encode() for i in order_in_file]
+    arr = (C.c_char_p * len(names))(*names)
+    order = (C.c_int32 * len(names))()
+    lib = orc.lib()
+    lib.orc_key_order.restype = C.c_int32
+    nk = lib.orc_key_order(arr, C.c_int32(len(names)), order)
+    feats = [names[order[i]].decode() for i in range(nk)]
+    assert nk == n_gen and feats != sorted(feats) and feats != list(dict.fromkeys(n.decode() for n in names))
+    assert [row[0] for row in rows] == ["ID", "Unknown"] + feats
+    # expected values
+    fidx = {g: i for i, g in enumerate(feats)}
+    fmap = np.array([fidx[g] for g in gen_of], dtype=np.int32)
+    flen = np.zeros(n_gen, dtype=np.uint32)
+    for i in range(n_seq):
+        flen[fmap[i]] += lens[i]
+    _, rec = samio.read_sam(sam)
+    ref = orc.run_profile(rec, n_gen, multi=multi, fmap=fmap)
+    vals, _, _ = orc.profile_finish(ref["abundance"], flen, ref["stats"], unit="rel", multi=multi)
+    got = np.array([float(row[1]) for row in rows[1:]])
+    assert got.shape == vals.shape
+    assert (np.abs(got - vals) <= 1e-6 * np.maximum(np.abs(vals), 1e-12)).all(), (got, vals)
+
+
+def test_cli_profile_genome_errors(tmp_path):
+    """msam_profile.c:787,826,835: the three fatal messages of the genome definition (raised on the host,
+    before any device work)."""
+    sam = str(tmp_path / "g.sam")
+    open(sam, "w").write("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:a\tLN:100\n@SQ\tSN:b\tLN:100\n")
+    for text, msg in (("g1\n", b"GENOME DEFINITION LINE ERROR"), ("g1\ta\ng1\tzzz\n", b"Sequence 'zzz' not found in BAM file"),
+                      ("g1\ta\n", b"Sequence 'b' not found in genome definition")):
+        gdef = str(tmp_path / "d.tsv")
+        open(gdef, "w").write(text)
+        r = run(["profile", "-S", "--label", "t", "--genome", gdef, "-o", str(tmp_path / "o.gz"), sam])
+        assert r.returncode == 1 and msg in r.stderr, (text, r.stderr)
