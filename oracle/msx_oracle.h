@@ -14,6 +14,9 @@
  * tests/test_filter.sh, test_besthit.sh, test_profile.sh, test_integration.sh
  * and test_coverage.sh on the reference's fixtures (tests/golden/), plus the
  * SURVEY section 8c known-answer table for tests/tiny_aln.bam.
+ * The one exception: zoeTools.c is self-contained, so `make ref` compiles it in
+ * place into oracle/_ref/libzoe_ref.so; orc_key_order() is pinned by key-order
+ * vectors that library produced (tests/golden/genome_order_vectors.json).
  * Third-party boundary restated here: htslib 1.24 kstrtok() (kstring.c) and
  * bam_aux2i() truncation semantics -- see orc_md_edit().
  * Not pinned by any reference test (stated in DESIGN.md): MD strings with '^'
