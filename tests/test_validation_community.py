@@ -1,0 +1,152 @@
+"""End-to-end validation on a synthetic community with ground truth (SURVEY.md section 8f-4,
+BASELINE.json configs[4]): `profile --genome ... --total N --multi {all,equal,ignore,prop}` on a
+QNAME-grouped paired-end SAM whose source genome per insert is known, with the checks of the
+reference's validate_profiles.py restated: header counts == truth (:859-876), sum of relative
+abundances = 1 +- 5e-6 (:879), exact insert-count recovery in the no-sharing control for every mode
+(:458-538), Bray-Curtis against the true cell abundances (:579-611).
+
+CPU: the oracle runs the pipeline (this validates generator + oracle against the truth).
+GPU: the command line does, and must agree with the oracle to 1e-6 and pass the same checks."""
+import ctypes as C
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import community as cm
+import oracle_lib as orc
+import samio
+from conftest import ROOT
+
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+MODES = {"all": "all", "equal": "equal", "ignore": "ignore", "prop": "proportional"}
+N = 3000
+
+
+def key_order(names):
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    order = (C.c_int32 * len(names))()
+    lib = orc.lib()
+    lib.orc_key_order.restype = C.c_int32
+    nk = lib.orc_key_order(arr, C.c_int32(len(names)), order)
+    return [names[order[i]] for i in range(nk)]
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    d = tmp_path_factory.mktemp("community")
+    comm = cm.Community(seed=11)
+    sam = str(d / "alignments.sam")
+    truth = comm.write(sam, N, seed=12)
+    ctrl = cm.Community(seed=13, sharing=False)
+    sam0 = str(d / "control.sam")
+    truth0 = ctrl.write(sam0, N, shared_fraction=0.0, seed=14, exclude_cross=True)
+    return dict(dir=d, comm=comm, sam=sam, truth=truth, ctrl=ctrl, sam0=sam0, truth0=truth0)
+
+
+def features(comm, level):
+    return key_order([g[level] for g in comm.genomes])
+
+
+def oracle_profile(comm, sam, level, mode, unit, nolen=False):
+    feats = features(comm, level)
+    fidx = {f: i for i, f in enumerate(feats)}
+    fmap = np.array([fidx[g[level]] for g in comm.genomes], dtype=np.int32)
+    flen = np.zeros(len(feats), dtype=np.uint32)
+    for g in comm.genomes:
+        flen[fidx[g[level]]] += len(g["seq"])
+    _, rec = samio.read_sam(sam)
+    ref = orc.run_profile(rec, len(feats), multi=MODES[mode], fmap=fmap)
+    vals, _, _ = orc.profile_finish(ref["abundance"], flen, ref["stats"], unit=unit, nolen=nolen, total=N, multi=MODES[mode])
+    return feats, vals, ref["stats"]
+
+
+def expected_multi(comm, truth, level):
+    lv = [g[level] for g in comm.genomes]
+    return sum(1 for t in truth["targets"] if len({lv[g] for g in t}) > 1)
+
+
+def check_against_truth(comm, truth, level, mode, feats, vals, counts):
+    assert counts == (N, N, expected_multi(comm, truth, level))            # total, mapped, multi-mapped inserts
+    assert abs(float(np.sum(vals)) - 1.0) <= 5e-6
+    est = dict(zip(["Unknown"] + feats, [float(v) for v in vals]))     # (Unknown > 0 with --multi ignore: dropped inserts)
+    bc = cm.bray_curtis(cm.truth_rel(comm, level), est)
+    if mode == "prop":      # the reference reports Bray-Curtis without a threshold; with 3000 inserts and a quarter
+        assert bc < 0.08, (level, bc)      # of them drawn from shared loci, proportional sharing lands at 0.05-0.07
+    return bc
+
+
+@pytest.mark.parametrize("level", ["strain", "species"])
+def test_oracle_recovers_the_community(world, level):
+    bc = {}
+    for mode in MODES:
+        feats, vals, st = oracle_profile(world["comm"], world["sam"], level, mode, "rel")
+        bc[mode] = check_against_truth(world["comm"], world["truth"], level, mode, feats, vals,
+                                       (N, st.insert_count, st.multi_mapper_count))
+    # what proportional sharing is for: closer to the truth than counting every hit or dropping multi-mappers
+    assert bc["prop"] <= min(bc["all"], bc["ignore"]), bc
+
+
+def test_oracle_exact_recovery_in_the_no_sharing_control(world):
+    ctrl, truth0 = world["ctrl"], world["truth0"]
+    want = None
+    for mode in MODES:
+        feats, vals, st = oracle_profile(ctrl, world["sam0"], "strain", mode, "ab", nolen=True)
+        exp = np.zeros(len(feats) + 1)
+        for g in truth0["source"]:
+            exp[1 + feats.index(ctrl.genomes[g]["strain"])] += 1
+        assert (vals == exp).all(), mode                                   # exact insert counts, every mode
+        assert st.multi_mapper_count == 0
+        want = vals if want is None else want
+        assert (vals == want).all()
+
+
+# ---- the command line on the GPU --------------------------------------------------------------------
+def cli_profile(sam, gdef, mode, out, unit="rel", nolen=False):
+    args = [BIN, "profile", "-S", f"--unit={unit}", "--pandas", "--label", "test", "--genome", gdef, "--total", str(N),
+            "--multi", mode, "-o", out, sam]
+    if nolen:
+        args.insert(4, "--nolen")
+    r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    text = gzip.open(out, "rt").read()
+    head = "\n".join(l for l in text.split("\n") if l.startswith("#"))
+    rows = [l.split("\t") for l in text.split("\n") if l and not l.startswith("#")]
+    get = lambda name: int(re.search(name + r"\s*:\s*(\d+)", head).group(1))
+    counts = (get("Total inserts"), get("Mapped inserts"), get("- Multiple mapped"))
+    return [r[0] for r in rows[1:]], np.array([float(r[1]) for r in rows[1:]]), counts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["strain", "species"])
+def test_cli_recovers_the_community(world, level):
+    gdef = str(world["dir"] / f"reference_to_{level}.tsv")
+    open(gdef, "w").write(world["comm"].genome_map(level))
+    bc = {}
+    for mode in MODES:
+        names, got, counts = cli_profile(world["sam"], gdef, mode, str(world["dir"] / f"{level}_{mode}.gz"))
+        feats, vals, st = oracle_profile(world["comm"], world["sam"], level, mode, "rel")
+        assert names == ["Unknown"] + feats
+        assert (np.abs(got - vals) <= 1e-6 * np.maximum(np.abs(vals), 1e-12)).all(), mode
+        bc[mode] = check_against_truth(world["comm"], world["truth"], level, mode, feats, got, counts)
+    assert bc["prop"] <= min(bc["all"], bc["ignore"]), bc
+
+
+@pytest.mark.gpu
+def test_cli_exact_recovery_in_the_no_sharing_control(world):
+    ctrl, truth0 = world["ctrl"], world["truth0"]
+    gdef = str(world["dir"] / "control_to_strain.tsv")
+    open(gdef, "w").write(ctrl.genome_map("strain"))
+    first = None
+    for mode in MODES:
+        names, got, counts = cli_profile(world["sam0"], gdef, mode, str(world["dir"] / f"exact_{mode}.gz"), unit="ab", nolen=True)
+        exp = {n: 0.0 for n in names}
+        for g in truth0["source"]:
+            exp[ctrl.genomes[g]["strain"]] += 1
+        assert [exp[n] for n in names] == list(got), mode
+        assert counts == (N, N, 0)
+        first = got if first is None else first
+        assert (got == first).all()
