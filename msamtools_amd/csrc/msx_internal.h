@@ -120,7 +120,6 @@ static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) { return 
 
 // exclusive scan: out[0..m] (m+1 entries, out[m] = total), u32
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
-int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m);
 // exclusive u64 scan of (1 << 32 | nd) over the pools whose word is MSX_PINFO_LIST | nd (msx_count.h), 0 for the others
 int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m);
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m);
@@ -145,8 +144,8 @@ struct msx_profile {
 	msx_buf m_fid;                    // i32 [n_entries]
 	int64_t lists_ub = 0, entries_ub = 0;    // host upper bounds (capacity / grid sizing)
 	// feature-major view built once per finalize by a stable radix sort
-	msx_buf t_key[2], t_val[2];       // ping-pong (key, 32-bit value) pairs of the radix sort
-	msx_buf t_val64[2];               // ping-pong 64-bit values: the entries' list signatures (msx_prop.hip)
+	msx_buf t_key[2];                 // ping-pong keys of the radix sorts (list keys, then entry keys)
+	msx_buf t_val64[2];               // ping-pong 64-bit values travelling with them: set signatures (msx_prop.hip)
 	msx_buf gen;                      // u8 [n_lists]: 1 = list takes the general (recip[]) path
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
 	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper

@@ -862,16 +862,16 @@ static int nf_grid(msx_ctx *ctx, int32_t nf) {
 }
 
 // stable LSD radix sort of (key, val) pairs on the low `bits` bits of the key; *n_ptr (device)
-// items, at most n_ub.  V = uint32_t: values ping-pong between p->t_val[0] and [1];
-// V = unsigned long long: between p->t_val64[0] and [1]; keys between p->t_key[0] and [1].
-// Returns the buffer holding the result.
+// items, at most n_ub.  Values (8 bytes) ping-pong between p->t_val64[0] and [1], keys between
+// p->t_key[0] and [1].  Returns the buffer holding the result.
 template <typename V>
 static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, const V *vin, int vin_buf,
                             const unsigned long long *n_ptr, int64_t n_ub, int bits, int *out_buf) {
 	const int passes = (bits + 7) / 8;
 	const int64_t n_waves = (n_ub + RS_TILE - 1) / RS_TILE;   // tiles
 	const unsigned nblk = (unsigned)n_waves;
-	msx_buf *vbuf = sizeof(V) == 8 ? p->t_val64 : p->t_val;
+	static_assert(sizeof(V) == 8, "the value buffers hold 8-byte values");
+	msx_buf *vbuf = p->t_val64;
 	int cur = vin_buf, rc;
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;

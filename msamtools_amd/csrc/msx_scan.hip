@@ -1,7 +1,8 @@
 // msx_scan.hip -- exclusive prefix sum over u32 / u64 (reduce-then-scan, 2048
 // items per workgroup).  Used for the emit order of filter's output stream
-// (u32) and for compacting multi-mapper lists, where one u64 scan carries
-// (list count << 32 | entry count).  HBM-bound: reads the input twice, writes once.
+// (u32), the radix passes, and for compacting multi-mapper lists, where one u64
+// scan carries (list count << 32 | entry count) and reads the 4-byte per-pool
+// words directly.  HBM-bound: reads the input twice, writes once.
 #include "msx_internal.h"
 
 #define SCAN_ITEMS 8
@@ -184,11 +185,3 @@ int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m
 	return MSX_OK;
 }
 
-int msx_scan_u64(msx_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t m) {
-	msx_time_begin(ctx, MSX_K_SCAN);
-	int rc = scan_rec<unsigned long long>(ctx, (const unsigned long long *)in, (unsigned long long *)out, m, 0);
-	msx_time_end(ctx);
-	if (rc) return rc;
-	MSX_HIP(ctx, hipGetLastError());
-	return MSX_OK;
-}

@@ -417,6 +417,39 @@ def test_streaming_batches_equal_one_batch(ctx):
     whole.free()
 
 
+def test_streaming_one_call_filter_profile_equals_one_batch(ctx):
+    """msx_filter_profile_enqueue batch by batch (the command-line pipe's shape) == one batch."""
+    import msamtools_amd as m
+    opts = dict(l=80, p=95, z=80, besthit=True)
+    whole = m.DeviceBatch.synth(ctx, 97531, 30000, 500, 4)
+    r1 = m.FilterRun(ctx, whole, **opts)
+    p1 = m.Profile(ctx, 500, "proportional")
+    r1.enqueue_with_profile(p1)
+    r1.finish()
+    ui1 = p1.ui()
+    ab1, st1 = p1.finalize()
+    ab1 = ab1.copy()
+    p2 = m.Profile(ctx, 500, "proportional")
+    n_emit = 0
+    for first in (0, 7000, 19000):
+        part = m.DeviceBatch.synth(ctx, 97531, (7000, 12000, 11000)[(0, 7000, 19000).index(first)], 500, 4, first_group=first)
+        r2 = m.FilterRun(ctx, part, **opts)
+        r2.enqueue_with_profile(p2)
+        n_emit += int(r2.finish().n_emit)
+        r2.free()
+        part.free()
+    assert n_emit == int(r1.status.n_emit)
+    assert (ui1 == p2.ui()).all()
+    ab2, st2 = p2.finalize()
+    assert (st1.insert_count, st1.uniq_mapper_count, st1.multi_mapper_count, st1.purged_insert_count) == \
+        (st2.insert_count, st2.uniq_mapper_count, st2.multi_mapper_count, st2.purged_insert_count)
+    assert np.allclose(ab1, ab2, rtol=1e-9, atol=0)
+    for x in (p1, p2):
+        x.close()
+    r1.free()
+    whole.free()
+
+
 def test_ragged_inputs(ctx):
     """Very long CIGAR/MD payloads (beyond the LDS staging tile), a 5000-record pool,
     pools with > 4 distinct references."""
