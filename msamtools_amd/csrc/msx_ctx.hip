@@ -82,14 +82,71 @@ extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
 		delete ctx;
 		return rc;
 	}
+	ctx->main_stream = ctx->stream;
+	{
+		const char *ser = getenv("MSX_SERIAL");
+		bool ok = !(ser && atoi(ser) != 0) && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+		for (int i = 0; ok && i < MSX_SIDE_LANES; i++)
+			ok = hipStreamCreateWithFlags(&ctx->side[i].stream, hipStreamNonBlocking) == hipSuccess &&
+			     hipEventCreateWithFlags(&ctx->side[i].done, hipEventDisableTiming) == hipSuccess;
+		ctx->lanes_ok = ok;      // without them everything simply runs on the main stream
+	}
 	*out = ctx;
 	return MSX_OK;
+}
+
+// ---- side lanes -------------------------------------------------------------------------------
+bool msx_fork(msx_ctx *ctx) {
+	if (!ctx->lanes_ok || ctx->timing || ctx->forked) return false;
+	if (hipEventRecord(ctx->ev_fork, ctx->main_stream) != hipSuccess) return false;
+	for (int i = 0; i < MSX_SIDE_LANES; i++)
+		if (hipStreamWaitEvent(ctx->side[i].stream, ctx->ev_fork, 0) != hipSuccess) return false;
+	ctx->forked = true;
+	return true;
+}
+
+static void swap_scan_ws(msx_ctx *ctx, msx_lane &l) {
+	std::swap(ctx->scan_l1, l.scan_l1);
+	std::swap(ctx->scan_l2, l.scan_l2);
+	std::swap(ctx->scan_l3, l.scan_l3);
+}
+
+void msx_lane_enter(msx_ctx *ctx, int lane) {
+	if (!ctx->forked || ctx->in_lane >= 0) return;
+	ctx->in_lane = lane;
+	ctx->stream = ctx->side[lane].stream;
+	swap_scan_ws(ctx, ctx->side[lane]);
+}
+
+void msx_lane_leave(msx_ctx *ctx) {
+	if (ctx->in_lane < 0) return;
+	swap_scan_ws(ctx, ctx->side[ctx->in_lane]);
+	ctx->stream = ctx->main_stream;
+	ctx->in_lane = -1;
+}
+
+void msx_join(msx_ctx *ctx) {
+	if (!ctx->forked) return;
+	msx_lane_leave(ctx);
+	for (int i = 0; i < MSX_SIDE_LANES; i++) {
+		(void)hipEventRecord(ctx->side[i].done, ctx->side[i].stream);
+		(void)hipStreamWaitEvent(ctx->main_stream, ctx->side[i].done, 0);
+	}
+	ctx->forked = false;
 }
 
 extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
+	msx_join(ctx);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	for (int i = 0; i < MSX_SIDE_LANES; i++) {
+		msx_lane &l = ctx->side[i];
+		if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+		if (l.done) (void)hipEventDestroy(l.done);
+		free_buf(&l.scan_l1); free_buf(&l.scan_l2); free_buf(&l.scan_l3);
+	}
+	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	for (auto &t : ctx->timed) {
 		(void)hipEventDestroy(t.a);
 		(void)hipEventDestroy(t.b);

@@ -703,13 +703,22 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 			hipLaunchKernelGGL(k_besthit_select<false>, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
 			                   ctx->stream, S, P);
 		msx_time_end(ctx);
-		if (prof && ng > 0 && (rc = msx_profile_count_finish(ctx, prof, b, by_part))) return rc;
-		if ((rc = msx_scan_u32(ctx, S.gcount, (uint32_t *)ctx->gbase.p, ng))) return rc;
-		msx_time_begin(ctx, MSX_K_EMIT);
-		hipLaunchKernelGGL(k_emit_groups, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   n, ng, b->group_off, (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p,
-		                   out->emit_idx, ctx->d_status);
-		msx_time_end(ctx);
+		// three independent chains from here: counting the unique-insert keys (side lane 0, inside
+		// msx_profile_count_finish), appending the multi-mapper lists (main stream), and filter's own
+		// output order (side lane 1); all three are latency-bound and overlap well
+		const bool forked = prof && ng > 0 && msx_fork(ctx);
+		if (prof && ng > 0 && (rc = msx_profile_count_finish(ctx, prof, b, by_part))) { msx_join(ctx); return rc; }
+		if (forked) msx_lane_enter(ctx, 1);
+		rc = msx_scan_u32(ctx, S.gcount, (uint32_t *)ctx->gbase.p, ng);
+		if (!rc) {
+			msx_time_begin(ctx, MSX_K_EMIT);
+			hipLaunchKernelGGL(k_emit_groups, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+			                   n, ng, b->group_off, (const uint8_t *)out->keep, (const uint32_t *)ctx->gbase.p,
+			                   out->emit_idx, ctx->d_status);
+			msx_time_end(ctx);
+		}
+		msx_join(ctx);
+		if (rc) return rc;
 	} else {
 		const int64_t nc = (n + EMIT_CHUNK - 1) / EMIT_CHUNK;
 		if ((rc = msx_reserve(ctx, &ctx->gcount, (size_t)(nc + 8) * 4))) return rc;

@@ -66,9 +66,26 @@ struct msx_timed {
 	hipEvent_t a, b;
 };
 
+// A side lane: a second HIP stream with its own scan workspace, so that a chain of kernels that
+// does not depend on what the main stream is doing can run beside it (the chains after the
+// best-hit kernel are latency-bound and leave most of the chip idle when run one after another).
+struct msx_lane {
+	hipStream_t stream = nullptr;
+	msx_buf scan_l1, scan_l2, scan_l3;
+	hipEvent_t done = nullptr;
+};
+#define MSX_SIDE_LANES 2
+
 struct msx_ctx {
 	int device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;      // the stream every launch helper uses: the main one, or a side lane's
+	                                   // between msx_lane_enter and msx_lane_leave
+	hipStream_t main_stream = nullptr;
+	msx_lane side[MSX_SIDE_LANES];
+	hipEvent_t ev_fork = nullptr;
+	int in_lane = -1;                  // side lane currently entered, -1 = main
+	bool forked = false;
+	bool lanes_ok = false;             // side lanes created; MSX_SERIAL=1 keeps everything on the main stream
 	std::string err;
 	int num_cu = 256;
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
@@ -85,6 +102,12 @@ struct msx_ctx {
 };
 
 int msx_fail(msx_ctx *ctx, int code, const char *fmt, ...);
+// fork / join around independent chains (no-ops returning false when timing is on or lanes are off):
+//   if (msx_fork(ctx)) ...; msx_lane_enter(ctx, i); <launches>; msx_lane_leave(ctx); ...; msx_join(ctx);
+bool msx_fork(msx_ctx *ctx);
+void msx_lane_enter(msx_ctx *ctx, int lane);
+void msx_lane_leave(msx_ctx *ctx);
+void msx_join(msx_ctx *ctx);
 int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes);
 extern thread_local std::string msx_tls_err;
 

@@ -246,11 +246,19 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	return MSX_OK;
 }
 
+// The two chains that follow the per-pool accounting are independent of each other (one reads the
+// unique-insert keys and updates ui[], the other appends the multi-mapped pools' lists to the store):
+// a caller that has forked runs the first on a side lane.
 int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, bool by_part) {
 	const int64_t ng = b->n_groups;
 	const bool prop = p->share_type == MSX_MULTI_SHARE_PROPORTIONAL;
 	int rc;
-	if (by_part && (rc = msx_count_keys(ctx, p, (const uint32_t *)ctx->pinfo.p, (uint32_t *)ctx->ukey2.p, ng, 2u))) return rc;
+	if (by_part) {
+		msx_lane_enter(ctx, 0);
+		rc = msx_count_keys(ctx, p, (const uint32_t *)ctx->pinfo.p, (uint32_t *)ctx->ukey2.p, ng, 2u);
+		msx_lane_leave(ctx);
+		if (rc) return rc;
+	}
 	if (prop) {
 		if ((rc = msx_scan_pinfo(ctx, (const uint32_t *)ctx->pinfo.p, (uint64_t *)ctx->moff.p, ng))) return rc;
 		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);
