@@ -58,8 +58,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t tile = blockIdx.x;
 	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
-	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	const int64_t base = tile * RS_TILE;
+	// The launch is sized for the host's upper bound of the element count; a tile beyond the data
+	// leaves its (pre-zeroed) column of the table alone -- 256 strided 4-byte stores per idle tile
+	// were the larger part of this kernel's time when the bound is loose.
+	if (base >= E) return;
+	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	if (SKIP) {
 		for (int q = 0; q < RS_EPT; q++) {
 			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
@@ -873,6 +877,9 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 	static_assert(sizeof(V) == 8, "the value buffers hold 8-byte values");
 	msx_buf *vbuf = p->t_val64;
 	int cur = vin_buf, rc;
+	// columns of tiles beyond the data are never written by k_rs_hist: zero the table once per sort
+	// (the set of such tiles is the same in every pass)
+	MSX_HIP(ctx, hipMemsetAsync(p->rs_hist.p, 0, (size_t)(256 * n_waves) * 4, ctx->stream));
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
 		const int left = bits - 8 * ps;
