@@ -146,6 +146,9 @@ int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
 // exclusive u64 scan of (1 << 32 | nd) over the pools whose word is MSX_PINFO_LIST | nd (msx_count.h), 0 for the others
 int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m);
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m);
+// exclusive u32 scan whose data length is known on the device only: min(m, mul * ceil(*n_ptr / div)) items
+int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m, const unsigned long long *n_ptr,
+                     int64_t div, int64_t mul);
 
 // profile state (one sample)
 #define PROP_MAX_BLOCKS 2048

@@ -59,10 +59,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	const int64_t tile = blockIdx.x;
 	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
 	const int64_t base = tile * RS_TILE;
-	// The launch is sized for the host's upper bound of the element count; a tile beyond the data
-	// leaves its (pre-zeroed) column of the table alone -- 256 strided 4-byte stores per idle tile
-	// were the larger part of this kernel's time when the bound is loose.
+	// The launch is sized for the host's upper bound of the element count.  With a device-side
+	// count the table is laid out for the tiles that exist (stride nt = ceil(E / RS_TILE)), so a
+	// tile beyond the data has no column at all -- 256 strided 4-byte stores per idle tile were
+	// the larger part of this kernel's time when the bound is loose -- and the scan stops there too.
 	if (base >= E) return;
+	if (n_ptr) n_tiles = (E + RS_TILE - 1) / RS_TILE;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	if (SKIP) {
 		for (int q = 0; q < RS_EPT; q++) {
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
 	const int64_t base = tile * RS_TILE;
 	if (base >= E) return;
+	if (n_ptr) n_tiles = (E + RS_TILE - 1) / RS_TILE;      // the table's stride, as k_rs_hist laid it out
 	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	// 1. all loads up front; wave w owns elements [w*RS_EPT*64, (w+1)*RS_EPT*64) of the tile
@@ -362,7 +365,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	const int lane = threadIdx.x & 63;
-	for (int64_t i0 = (int64_t)blockIdx.x * MSX_BLOCK; i0 < m; i0 += stride) {
+	// (positions at and beyond n_lists are not written: the scans that follow stop at n_lists)
+	for (int64_t i0 = (int64_t)blockIdx.x * MSX_BLOCK; i0 < n_lists && i0 < m; i0 += stride) {
 		const int64_t i = i0 + threadIdx.x;
 		const bool in = i < n_lists;
 		unsigned long long sg = 0;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 				}
 			}
 		}
-		if (i < m) {
+		if (in) {
 			head[i] = hd;
 			len2[i] = hd ? l : 0u;
 		}
@@ -877,9 +881,6 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 	static_assert(sizeof(V) == 8, "the value buffers hold 8-byte values");
 	msx_buf *vbuf = p->t_val64;
 	int cur = vin_buf, rc;
-	// columns of tiles beyond the data are never written by k_rs_hist: zero the table once per sort
-	// (the set of such tiles is the same in every pass)
-	MSX_HIP(ctx, hipMemsetAsync(p->rs_hist.p, 0, (size_t)(256 * n_waves) * 4, ctx->stream));
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
 		const int left = bits - 8 * ps;
@@ -887,7 +888,8 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 		MSX_TIMED(ctx, MSX_K_RS_HIST,
 		          hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr,
 		                             (int64_t)0, ps * 8, dmask, (uint32_t *)p->rs_hist.p, n_waves));
-		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves)))
+		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves, n_ptr,
+		                           RS_TILE, 256)))
 			return rc;
 		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
 		          hipLaunchKernelGGL((k_rs_scatter<V, true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin,
@@ -951,8 +953,8 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		          hipLaunchKernelGGL(k_dup_mark, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
 		                             lub, skey, ssig, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
 		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p));
-		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub))) return rc;
-		if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub))) return rc;
+		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub, tot, 1, 1))) return rc;
+		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub, tot, 1, 1))) return rc;
 		// the feature-major entries are written as the derived store is built, into the buffers the
 		// list sort is not holding its result in: key = feature, value = the list's signature or number
 		ebuf = sb ^ 1;

@@ -76,10 +76,30 @@ __device__ __forceinline__ void load8x(const void *__restrict__ in, int64_t base
 	}
 }
 
+// Device-side length: the launches are sized for the host's upper bound m, but only the first
+// min(m, mul * ceil(*n_ptr / div)) items hold data (the rest would be zeros); workgroups beyond
+// that touch no memory.  n_ptr == nullptr: all m items.
+struct ScanLen {
+	const unsigned long long *n_ptr;
+	int64_t div, mul;
+};
+
+__device__ __forceinline__ int64_t scan_len(const ScanLen &L, int64_t m) {
+	if (!L.n_ptr) return m;
+	const int64_t n = (int64_t)*L.n_ptr;
+	const int64_t e = L.mul * ((n + L.div - 1) / L.div);
+	return e < m ? e : m;
+}
+
 template <typename T, bool PINFO = false>
-__global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const void *__restrict__ in, int64_t m,
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const void *__restrict__ in, int64_t m_ub, ScanLen L,
                                                            T *__restrict__ partial) {
 	__shared__ T s_w[4];
+	const int64_t m = scan_len(L, m_ub);
+	if ((int64_t)blockIdx.x * SCAN_CHUNK >= m) {
+		if (threadIdx.x == 0) partial[blockIdx.x] = 0;
+		return;
+	}
 	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
 	T v[SCAN_ITEMS];
 	load8x<T, PINFO>(in, base, m, v);
@@ -94,9 +114,15 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_reduce(const void *__restric
 // carry == nullptr: single-chunk top level.  Writes out[i] for i < m and, from
 // the last block, out[m] = grand total.
 template <typename T, bool INCL, bool PINFO = false>
-__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const void *in, T *out, int64_t m,
+__global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const void *in, T *out, int64_t m_ub, ScanLen L,
                                                           const T *__restrict__ carry) {
 	__shared__ T s_w[4];
+	const int64_t m = scan_len(L, m_ub);
+	if ((int64_t)blockIdx.x * SCAN_CHUNK >= m && (blockIdx.x > 0 || m_ub > 0)) {
+		// nothing but zeros from here on: only the grand total is still owed (at the host's index)
+		if (!INCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m_ub] = carry ? carry[blockIdx.x] : (T)0;
+		return;
+	}
 	int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
 	T v[SCAN_ITEMS];
 	load8x<T, PINFO>(in, base, m, v);
@@ -130,15 +156,15 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const void *in, T *out
 		for (int k = 0; k < SCAN_ITEMS; k++)
 			if (base + k < m) out[base + k] = o[k];
 	}
-	if (!INCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = c + tot;
+	if (!INCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m_ub] = c + tot;
 }
 
 template <typename T, bool INCL = false, bool PINFO = false>
-static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level) {
+static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level, ScanLen L = ScanLen{nullptr, 1, 1}) {
 	int64_t nb = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
 	if (nb < 1) nb = 1;
 	if (nb == 1) {
-		hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+		hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m, L,
 		                   (const T *)nullptr);
 		return MSX_OK;
 	}
@@ -149,10 +175,10 @@ static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level) 
 	if (rc) return rc;
 	T *partial = (T *)lv->p;
 	T *pscan = partial + ((nb + 3) & ~(int64_t)3);
-	hipLaunchKernelGGL((k_scan_reduce<T, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, m, partial);
+	hipLaunchKernelGGL((k_scan_reduce<T, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, m, L, partial);
 	rc = scan_rec<T, false, false>(ctx, partial, pscan, nb, level + 1);
 	if (rc) return rc;
-	hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
+	hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m, L,
 	                   (const T *)pscan);
 	return MSX_OK;
 }
@@ -160,6 +186,18 @@ static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level) 
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
 	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0);
+	msx_time_end(ctx);
+	if (rc) return rc;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+// the same with a device-side length: items at and beyond min(m, mul * ceil(*n_ptr / div)) count as zeros and
+// are neither read nor written; out[m] still receives the total
+int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m, const unsigned long long *n_ptr,
+                     int64_t div, int64_t mul) {
+	msx_time_begin(ctx, MSX_K_SCAN);
+	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0, ScanLen{n_ptr, div, mul});
 	msx_time_end(ctx);
 	if (rc) return rc;
 	MSX_HIP(ctx, hipGetLastError());
