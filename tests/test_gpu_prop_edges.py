@@ -1,0 +1,102 @@
+"""Edge cases of the proportional-sharing build on the device against the oracle: merge weights too large
+for the entry key (general path), duplicate lists of more than three features (hashed signatures,
+compared entry by entry), feature ids beyond the 21-bit signature fields, one or two features only,
+and both ways of counting unique inserts."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class Rec:
+    """Profile-only records: pools given by name_id, one tid per record."""
+
+    def __init__(self, pools):
+        tids = [t for p in pools for t in p]
+        n = len(tids)
+        self.tid = np.array(tids, dtype=np.int32)
+        self.name_id = np.repeat(np.arange(len(pools), dtype=np.int32), [len(p) for p in pools])
+        self.group_off = np.concatenate([[0], np.cumsum([len(p) for p in pools])]).astype(np.uint32)
+        self.flag = np.zeros(n, np.uint16)
+        self.rflags = np.zeros(n, np.uint8)
+        self.pos = np.zeros(n, np.int32)
+        self.cigar_off = np.zeros(n + 1, np.uint32)
+        self.cigar = np.zeros(1, np.uint32)
+        self.md_off = np.zeros(n + 1, np.uint32)
+        self.md = np.zeros(1, np.uint8)
+        self.nm = np.zeros(n, np.int32)
+        self.as_ = np.zeros(n, np.int32)
+        self.qname_off = None
+        self.qname = None
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import msamtools_amd as m
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+def check(ctx, pools, nf, multi="proportional"):
+    import msamtools_amd as m
+    rec = Rec(pools)
+    db = m.DeviceBatch.upload(ctx, rec, rec.group_off)
+    prof = m.Profile(ctx, nf, multi)
+    prof.accumulate(db, None)
+    ui = prof.ui()
+    ab, st = prof.finalize()
+    ref = orc.run_profile(rec, nf, multi=multi, name_id=rec.name_id)
+    s = ref["stats"]
+    assert (ui == ref["ui"]).all()
+    assert (st.insert_count, st.uniq_mapper_count, st.multi_mapper_count, st.purged_insert_count, st.iterations) == \
+        (s.insert_count, s.uniq_mapper_count, s.multi_mapper_count, s.purged_insert_count, s.iterations)
+    want = ref["abundance"]
+    assert ((ab == 0) == (want == 0)).all()
+    assert (np.abs(ab - want) <= 1e-6 * np.maximum(np.abs(want), 1e-300)).all()
+    shared = prof.shared_size()
+    prof.close()
+    db.free()
+    return shared
+
+
+def mixed_pools(rng, base=0):
+    pools = [[base + 5, base + 9]] * 6000                     # one pair 6000 times: weight beyond 12 bits at 2^20 features
+    pools += [[base + 5, base + 9, base + 11]] * 3000
+    pools += [[base + 1, base + 2, base + 3, base + 4, base + 5]] * 50    # > 3 features: hashed signature, duplicates
+    pools += [[base + 1, base + 2, base + 3, base + 4, base + 6]] * 40
+    pools += [[base + 7, base + 7, base + 8]] * 30            # repeated feature inside a pool
+    pools += [[int(t)] for t in base + rng.integers(0, 20, 20000)]   # unique inserts
+    pools += [[-1], [-1, base + 3]]                           # no reference / partly without
+    order = rng.permutation(len(pools))
+    return [pools[i] for i in order]
+
+
+@pytest.mark.parametrize("by_part", ["0", "1"])
+def test_heavy_weights_and_long_duplicate_lists(ctx, monkeypatch, by_part):
+    monkeypatch.setenv("MSX_COUNT_BY_PARTITION", by_part)
+    rng = np.random.default_rng(1)
+    lists, entries = check(ctx, mixed_pools(rng), 1 << 20)
+    assert lists == 5 and entries == 2 + 3 + 5 + 5 + 2          # every distinct set once
+
+
+def test_feature_ids_beyond_the_signature_fields(ctx, monkeypatch):
+    monkeypatch.setenv("MSX_COUNT_BY_PARTITION", "0")           # 2.5 M features: more than the partition count takes
+    rng = np.random.default_rng(2)
+    lists, entries = check(ctx, mixed_pools(rng, base=2_400_000), 2_500_000)
+    assert lists == 5
+
+
+@pytest.mark.parametrize("nf", [1, 2, 3])
+def test_one_two_three_features(ctx, nf):
+    rng = np.random.default_rng(nf)
+    pools = [[int(t) for t in rng.integers(0, nf, int(rng.integers(1, 4)))] for _ in range(3000)]
+    check(ctx, pools, nf)
+
+
+@pytest.mark.parametrize("multi", ["all", "equal", "ignore"])
+def test_other_modes_on_the_mixed_pools(ctx, multi):
+    rng = np.random.default_rng(3)
+    check(ctx, mixed_pools(rng), 4096, multi=multi)
