@@ -19,6 +19,10 @@
 #define CAP_CIG 1024          // dwords
 #define CAP_MDW 1536          // dwords (6 KB)
 
+// pool byte written for k_besthit_select (FilterArgs.pool_as_code): bits 6-7 are FLAG's READ1/READ2
+#define MSX_PC_IN 0x01u
+#define MSX_PC_HAS_AS 0x02u
+
 struct FilterArgs {
 	int64_t n;
 	const uint16_t *flag;
@@ -34,6 +38,8 @@ struct FilterArgs {
 	int32_t rescore, invert, keep_unmapped;
 	int32_t md_aligned;     // md base is 4-byte aligned -> dword staging allowed
 	uint8_t *pool;          // [n] out: 1 = record enters the pool
+	int32_t pool_as_code;   // best-hit follows: a pooled record's byte is MSX_PC_IN | MSX_PC_HAS_AS | its mate bits,
+	                        // everything k_besthit_select needs to know about it besides its score
 	int32_t *as_out;        // [n] out (rescore) or null
 	int32_t *o_len, *o_qlen, *o_qclip, *o_edit;   // optional per-record stats
 	uint8_t *o_status;
@@ -67,7 +73,8 @@ __device__ __forceinline__ void load_offsets(const FilterArgs &A, int64_t tile, 
 	}
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
+// (waves per SIMD pinned: the kernel is instruction-bound and loses 10 % when a few more registers drop it to 5)
+__global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_aln_stats_filter(FilterArgs A) {
 	__shared__ uint32_t s_coff[2][MSX_BLOCK + 1];
 	__shared__ uint32_t s_moff[2][MSX_BLOCK + 1];
 	__shared__ uint32_t s_cig[CAP_CIG];
@@ -289,7 +296,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_filter(FilterArgs A) {
 					pooled = (A.choice == 0 || (int)fails == A.invert) ? 1u : 0u;   // msam_filter.c:181
 				}
 			}
-			if (A.pool) A.pool[t] = (uint8_t)pooled;
+			if (A.pool) {
+				if (A.pool_as_code && pooled) {
+					// msam_filter.c:223: AS is read from the record; after --rescore every mapped record has one (:167)
+					const bool has = (rf & MSX_HAS_AS) || (A.rescore && !(flag & MSX_F_UNMAP));
+					pooled = MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (flag & MSX_F_MATES);
+				}
+				A.pool[t] = (uint8_t)pooled;
+			}
 		}
 		__syncthreads();                 // every lane is done with this tile's LDS image
 		if (has_next) store_payload();
@@ -307,6 +321,7 @@ struct SelectArgs {
 	const uint16_t *flag;
 	const uint8_t *rflags;
 	const uint8_t *pool;      // null: pooled = mapped (plain --besthit, msam_filter.c:104)
+	int32_t pool_is_code;     // pool bytes are MSX_PC_* codes: FLAG and the aux bits need not be fetched
 	const int32_t *as;        // AS to compare (as_out after --rescore)
 	int32_t rescored;         // every mapped pooled record has AS (msam_filter.c:167)
 	int32_t unique_only;      // --uniqhit
@@ -380,15 +395,18 @@ __global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
 		uint32_t cnt = 0;
 		if (len <= BH_WIN && (uint64_t)(s & ~3u) + 16u <= (uint64_t)A.n && (uint64_t)s + BH_WIN <= (uint64_t)A.n) {
 			// ---- bulk loads (independent of each other) ----
+			const bool coded = A.pool_is_code != 0;      // (kernel argument: a scalar branch)
 			const uint32_t *f32p = reinterpret_cast<const uint32_t *>(A.flag) + (s >> 1);
-			uint32_t fw[7];
-#pragma unroll
-			for (int q = 0; q < 7; q++)        // only the dwords the pool reaches into
-				fw[q] = (2u * ((s >> 1) + (uint32_t)q) < e) ? f32p[q] : 0u;
+			uint32_t fw[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
 			const uint32_t *r32p = reinterpret_cast<const uint32_t *>(A.rflags) + (s >> 2);
-			uint32_t rw[4], pw[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+			uint32_t rw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+			if (!coded) {
 #pragma unroll
-			for (int q = 0; q < 4; q++) rw[q] = (4u * ((s >> 2) + (uint32_t)q) < e) ? r32p[q] : 0u;
+				for (int q = 0; q < 7; q++)        // only the dwords the pool reaches into
+					fw[q] = (2u * ((s >> 1) + (uint32_t)q) < e) ? f32p[q] : 0u;
+#pragma unroll
+				for (int q = 0; q < 4; q++) rw[q] = (4u * ((s >> 2) + (uint32_t)q) < e) ? r32p[q] : 0u;
+			}
 			if (A.pool) {
 				const uint32_t *p32p = reinterpret_cast<const uint32_t *>(A.pool) + (s >> 2);
 #pragma unroll
@@ -412,12 +430,18 @@ __global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
 			uint32_t paired = 0;
 #pragma unroll
 			for (int r = 0; r < BH_WIN; r++) {
-				const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
-				const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
-				const bool part = ((uint32_t)r < len) &&
-				                  (A.pool ? (((pa[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0) : !(fl & MSX_F_UNMAP));
-				const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-				code[r] = part ? ((fl & MSX_F_MATES) | 0x100u | (has ? 0x200u : 0u)) : 0u;
+				const uint32_t pb = (pa[r >> 2] >> (8 * (r & 3))) & 0xffu;
+				if (coded) {
+					// the stats kernel has already decided participation and looked at FLAG and the aux bits
+					code[r] = ((uint32_t)r < len && (pb & MSX_PC_IN))
+					              ? ((pb & MSX_F_MATES) | 0x100u | ((pb & MSX_PC_HAS_AS) ? 0x200u : 0u)) : 0u;
+				} else {
+					const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+					const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
+					const bool part = ((uint32_t)r < len) && (A.pool ? (pb != 0) : !(fl & MSX_F_UNMAP));
+					const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+					code[r] = part ? ((fl & MSX_F_MATES) | 0x100u | (has ? 0x200u : 0u)) : 0u;
+				}
 				paired |= code[r] & MSX_F_MATES;                                 // mBamPoolIsPaired :196-204
 			}
 			// a paired pool is judged per mate (READ1 -> A, READ2 -> B), an unpaired one as a whole (A)
@@ -467,7 +491,8 @@ __global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
 			for (uint32_t i = s; i < e; ++i) {
 				const uint32_t fl = A.flag[i];
 				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+				const bool has = A.pool_is_code ? ((A.pool[i] & MSX_PC_HAS_AS) != 0)
+				                                : ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP)));
 				bh_count(c, i, fl, pooled, has, A.as[i]);
 			}
 			const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);
@@ -476,7 +501,8 @@ __global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
 			for (uint32_t i = s; i < e; ++i) {
 				const uint32_t fl = A.flag[i];
 				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-				const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+				const bool has = A.pool_is_code ? ((A.pool[i] & MSX_PC_HAS_AS) != 0)
+				                                : ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP)));
 				const uint8_t k = bh_keep(c, w0, w1, w2, fl, pooled, has, A.as[i]);
 				A.keep[i] = k;
 				cnt += (k != 0);
@@ -666,6 +692,7 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 		if (best) {
 			if ((rc = msx_reserve(ctx, &ctx->pool_code, (size_t)n))) return rc;
 			pool = (uint8_t *)ctx->pool_code.p;
+			A.pool_as_code = 1;
 		} else {
 			pool = out->keep;   // mWriteBamPool: keep == pooled
 		}
@@ -686,6 +713,7 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 		S.flag = b->flag;
 		S.rflags = b->rflags;
 		S.pool = pool;
+		S.pool_is_code = (pool && need_stats) ? 1 : 0;
 		S.as = p->rescore ? out->as_out : b->as;
 		S.rescored = p->rescore;
 		S.unique_only = p->uniqhit ? 1 : 0;   // msam_filter.c:88-91: --uniqhit wins
