@@ -12,7 +12,9 @@ note = sys.argv[3] if len(sys.argv) > 3 else ""
 res = json.load(open(src))
 out = {"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/pmc_l2.sh), "
                    "bench.py workload c3; per-launch averages. hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                   "per MI355X_MICROARCH.md (gfx950 FETCH_SIZE halving). " + note,
+                   "per MI355X_MICROARCH.md (gfx950 FETCH_SIZE halving; the guide calibrates this for 16-byte streaming "
+                   "accesses only -- 8-byte gathers are uncalibrated -- and Infinity-Cache hits are counted, so this is fabric "
+                   "traffic out of the L2s, an upper bound of HBM traffic). " + note,
        "kernels": {}}
 for name, cs in sorted(res.items()):
     if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
