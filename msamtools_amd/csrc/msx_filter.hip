@@ -288,10 +288,23 @@ __global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7)
 					// msam_filter.c:31-35 in wrapping int32 arithmetic
 					const int32_t L = (int32_t)alen;
 					bool fl = L < A.min_length;
-					bool fz = (int32_t)(100u * qclip) > (int32_t)((uint32_t)A.max_clip * qlen);
-					bool fp = (A.ppt < 0)
-					              ? ((int32_t)(1000u * (edit - alen)) < (int32_t)(alen * (uint32_t)A.ppt))
-					              : ((int32_t)(1000u * (alen - edit)) < (int32_t)(alen * (uint32_t)A.ppt));
+					bool fz, fp;
+					// 32-bit integer multiplies run at quarter rate; when every operand of this wave fits 24 bits
+					// (always, for real reads) v_mul_u32_u24 gives the same low 32 bits at full rate
+					const uint32_t ident = alen - edit;
+					const bool small = A.ppt >= 0 && (uint32_t)A.ppt < (1u << 24) && (uint32_t)A.max_clip < (1u << 24) &&
+					                   __ballot(((alen | qlen | qclip | ident) >> 24) != 0u) == 0ull;
+					if (small) {
+						fz = (int32_t)__umul24(100u, qclip) >
+						     (int32_t)__umul24((uint32_t)A.max_clip, qlen);
+						fp = (int32_t)__umul24(1000u, ident) <
+						     (int32_t)__umul24(alen, (uint32_t)A.ppt);
+					} else {
+						fz = (int32_t)(100u * qclip) > (int32_t)((uint32_t)A.max_clip * qlen);
+						fp = (A.ppt < 0)
+						         ? ((int32_t)(1000u * (edit - alen)) < (int32_t)(alen * (uint32_t)A.ppt))
+						         : ((int32_t)(1000u * (alen - edit)) < (int32_t)(alen * (uint32_t)A.ppt));
+					}
 					bool fails = ((A.choice & 1) && fl) || ((A.choice & 2) && fp) || ((A.choice & 4) && fz);
 					pooled = (A.choice == 0 || (int)fails == A.invert) ? 1u : 0u;   // msam_filter.c:181
 				}
