@@ -34,14 +34,14 @@ enum msx_kid {
 	MSX_K_ALN_STATS = 0,   // k_aln_stats_filter
 	MSX_K_BESTHIT,         // k_besthit_select
 	MSX_K_EMIT,            // k_emit_groups / k_emit_count + k_emit_fill
-	MSX_K_INSERT_COUNT,    // k_insert_count
+	MSX_K_INSERT_COUNT,    // k_insert_count; the partition count of the unique-insert keys (msx_count_keys)
 	MSX_K_MULTI_COMPACT,   // k_multi_compact + k_multi_advance
 	MSX_K_LIST_RECIP,      // k_list_recip
 	MSX_K_SHARE_REDUCE,    // k_share_reduce
 	MSX_K_PARTIAL_REDUCE,  // k_partial_reduce
 	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply + k_prop_finish / k_prop_purged
-	MSX_K_LIST_ORDER,      // k_list_minkey, k_perm_len, k_perm_gather
-	MSX_K_RS_HIST,         // k_entry_lists, k_rs_hist
+	MSX_K_LIST_ORDER,      // k_list_key, k_dup_mark, k_uniq_gather, k_entry_weight
+	MSX_K_RS_HIST,         // k_rs_hist
 	MSX_K_RS_SCATTER,      // k_rs_scatter
 	MSX_K_COVERAGE,        // k_coverage_pileup
 	MSX_K_SCAN,            // k_scan_reduce + k_scan_apply (one bracket per scan call)

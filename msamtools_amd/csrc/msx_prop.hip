@@ -540,17 +540,16 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 	}
 }
 
-// share[f] = sum of recip over the lists containing f -- a segmented sum over the
+// share[f] = sum of w/S over the lists containing f -- a segmented sum over the
 // feature-sorted entries.  Level 1 (k_share_reduce): one wave per SR_CHUNK
-// consecutive entries, four 64-entry rows in flight per step (all loads issued
-// before the first scan), segmented scan per row, open segment carried in
-// registers.  A feature whose entries all lie inside the chunk is written with
-// a plain store.  The (at most two) segments cut by the chunk boundary are not
-// added with atomics -- a hot feature spans hundreds of chunks and would
-// serialise on one address -- but emitted as (feature, partial) pairs, two
-// slots per wave, in entry order.  Level 2 (k_partial_reduce) runs the same
-// segmented sum over those few pairs and adds each run once.
-#define SR_ROWS_PER_STEP 4
+// consecutive entries in steps of SR_STEP; a lane sums SR_EPL consecutive entries
+// itself, one segmented scan over the lanes joins the open ends, the open segment
+// is carried in registers from step to step.  A feature whose entries all lie
+// inside the chunk is written with a plain store.  The (at most two) segments cut
+// by the chunk boundary are not added with atomics -- a hot feature spans hundreds
+// of chunks and would serialise on one address -- but emitted as (feature,
+// partial) pairs, two slots per wave, in entry order.  Level 2 (k_partial_reduce)
+// runs a segmented sum over those few pairs, 64 per row, and adds each run once.
 #define PR_CHUNK 256                   // partials reduced by one wave (level 2)
 #define SR_SENT 0xffffffffu
 
