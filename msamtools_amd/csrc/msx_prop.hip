@@ -598,8 +598,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
 	// (consecutive workgroups -- which the dispatcher deals round-robin to the 8 XCDs -- take
-	// consecutive chunks; giving every XCD one contiguous eighth instead, to keep its gathers in one
-	// part of recip[], measured slower: 70 vs 65 us)
+	// consecutive chunks, so the XCDs walk the feature range together.  Keeping windows of it on one
+	// XCD measured slower the longer the window: groups of 4 / 16 / 64 workgroups per XCD 58 / 60 / 67 us
+	// against 58, a contiguous eighth each 70 against 65 -- lines one XCD has fetched are then no longer
+	// served to the others out of the Infinity Cache while they are there)
 	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
 	const int64_t c0 = wave * SR_CHUNK;
 	if (c0 >= E) {   // idle wave: neutral slots (sorted after every real feature id)
