@@ -410,6 +410,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 
 // unique list u (sorted position i, a head): offsets, entries, and the sorted position itself
 // (weights are differences of consecutive head positions)
+__device__ __forceinline__ unsigned long long pack_others(uint32_t o1, uint32_t o2, uint32_t o3) {
+	return (unsigned long long)o1 | ((unsigned long long)o2 << 21) | ((unsigned long long)o3 << 42);
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long long *__restrict__ csr_tot,
                                                            const uint32_t *__restrict__ head,
                                                            const uint32_t *__restrict__ uidx,
@@ -431,19 +435,46 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 		const unsigned long long sg = ssig[i];
 		d_off[u] = o;
 		hpos[u] = (uint32_t)i;
+		// A list of up to four features travels with its feature-major entries (k_share_reduce): the
+		// entry of feature x carries the OTHER features of the list, ascending, three 21-bit fields.
 		if (!(sg & SIG_HASHED)) {
 			// the set is in the signature (ascending feature order)
 			const uint32_t a = (uint32_t)(sg & SIG_PAD), b = (uint32_t)((sg >> 21) & SIG_PAD),
 			               c = (uint32_t)((sg >> 42) & SIG_PAD);
-			// the feature-major entries of such a list carry the set itself (k_share_reduce)
-			d_fid[o] = (int32_t)a; e_key[o] = a; e_val[o] = sg; o++;
-			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_key[o] = b; e_val[o] = sg; o++; }
-			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_key[o] = c; e_val[o] = sg; }
+			d_fid[o] = (int32_t)a; e_key[o] = a; e_val[o] = pack_others(b, c, SIG_PAD); o++;
+			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_key[o] = b; e_val[o] = pack_others(a, c, SIG_PAD); o++; }
+			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_key[o] = c; e_val[o] = pack_others(a, b, SIG_PAD); }
 		} else {
 			const uint32_t j = (uint32_t)sg;
 			const uint32_t s = m_off[j], e = m_off[j + 1];
-			for (uint32_t k = s; k < e; ++k) {
-				d_fid[o] = m_fid[k]; e_key[o] = (uint32_t)m_fid[k]; e_val[o] = SIG_HASHED | u; o++;
+			bool four = (e - s == 4u);
+			uint32_t f[4] = {SIG_PAD, SIG_PAD, SIG_PAD, SIG_PAD};
+			if (four) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) f[k] = (uint32_t)m_fid[s + k];
+				four = f[0] < SIG_PAD && f[1] < SIG_PAD && f[2] < SIG_PAD && f[3] < SIG_PAD;
+			}
+			if (four) {
+				// ascending copy (5-comparator network); entry k keeps the list's own order in d_fid
+				uint32_t q0 = f[0], q1 = f[1], q2 = f[2], q3 = f[3], t;
+				if (q0 > q1) { t = q0; q0 = q1; q1 = t; }
+				if (q2 > q3) { t = q2; q2 = q3; q3 = t; }
+				if (q0 > q2) { t = q0; q0 = q2; q2 = t; }
+				if (q1 > q3) { t = q1; q1 = q3; q3 = t; }
+				if (q1 > q2) { t = q1; q1 = q2; q2 = t; }
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint32_t x = f[k];
+					// the sorted list without x
+					const uint32_t o1 = (x == q0) ? q1 : q0;
+					const uint32_t o2 = (x == q0 || x == q1) ? q2 : q1;
+					const uint32_t o3 = (x == q3) ? q2 : q3;
+					d_fid[o] = (int32_t)x; e_key[o] = x; e_val[o] = pack_others(o1, o2, o3); o++;
+				}
+			} else {
+				for (uint32_t k = s; k < e; ++k) {
+					d_fid[o] = m_fid[k]; e_key[o] = (uint32_t)m_fid[k]; e_val[o] = SIG_HASHED | u; o++;
+				}
 			}
 		}
 	}
@@ -638,47 +669,49 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		after = SR_SENT;
 		if (lane == 63 && base + SR_STEP < E) after = t_key[base + SR_STEP] & fmask;
 	};
-	// two-stage pipeline: the entries of step i+1 are in flight while step i gathers and sums
-	uint32_t kn[SR_EPL], after_n;
-	unsigned long long lvn[SR_EPL];
-	load_step(c0, kn, lvn, after_n);
+	// (keeping the entries of step i+1 in flight while step i gathers costs 24 registers: with the four
+	// operand arrays below that is the difference between 3 and 2 waves per SIMD)
 	uint32_t before = 0;
 	if (lane == 0 && c0 > 0) before = t_key[c0 - 1] & fmask;
 	for (int64_t base = c0; base < c1; base += SR_STEP) {
-		uint32_t k[SR_EPL];
+		uint32_t k[SR_EPL], after;
 		unsigned long long lv[SR_EPL];
-#pragma unroll
-		for (int i = 0; i < SR_EPL; i++) { k[i] = kn[i]; lv[i] = lvn[i]; }
-		const uint32_t after = after_n;
-		if (base + SR_STEP < c1) load_step(base + SR_STEP, kn, lvn, after_n);
-		// Each entry's term w/S.  A list of <= 3 features travels with its entries (signature in
-		// the value, weight above the feature id in the key): S is summed here from a[] -- 8 MB that
-		// the L2s hold well -- in ascending feature order, the order k_list_recip and
-		// k_prop_purged use, so every entry of a list gets the same bits.  Other lists: recip[u].
+		load_step(base, k, lv, after);
+		// Each entry's term w/S.  A list of <= 4 features travels with its entries (the other
+		// features in the value, weight above the feature id in the key): S is summed here from a[] --
+		// 8 MB that the caches hold well, unlike one 8-byte recip[] per list out of tens of MB -- always
+		// in ascending feature order, so every entry of a list gets the same bits.  Other lists: recip[u].
 		double x[SR_EPL];
 		{
-			double a0[SR_EPL], a1[SR_EPL], a2[SR_EPL];
+			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
 				const bool general = (lv[i] & SIG_HASHED) != 0;
-				const uint32_t fa = (uint32_t)(lv[i] & SIG_PAD), fb = (uint32_t)((lv[i] >> 21) & SIG_PAD),
-				               fc = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				a0[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[fa];
-				a1[i] = (live && !general && fb != SIG_PAD) ? a[fb] : 0.0;
-				a2[i] = (live && !general && fc != SIG_PAD) ? a[fc] : 0.0;
+				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
+				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
+				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
+				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
+				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
+				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
 			}
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
 				const bool general = (lv[i] & SIG_HASHED) != 0;
-				const uint32_t fb = (uint32_t)((lv[i] >> 21) & SIG_PAD), fc = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				double sum = a0[i];
-				if (fb != SIG_PAD) sum += a1[i];
-				if (fc != SIG_PAD) sum += a2[i];
+				const uint32_t f = k[i] & fmask;
+				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
+				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
+				// own feature merged into the ascending others (absent ones are SIG_PAD > f and add +0.0)
+				const int p = (int)(f > o1) + (int)(f > o2) + (int)(f > o3);
+				const double t1 = p == 0 ? af[i] : a1[i];
+				const double t2 = p == 0 ? a1[i] : (p == 1 ? af[i] : a2[i]);
+				const double t3 = p <= 1 ? a2[i] : (p == 2 ? af[i] : a3[i]);
+				const double t4 = p <= 2 ? a3[i] : af[i];
+				const double sum = ((t1 + t2) + t3) + t4;
 				const double w = (double)(bits < 32 ? (k[i] >> bits) : 0u);
-				x[i] = !live ? 0.0 : general ? a0[i] : (sum > 0 ? w / sum : 0.0);
-				if (live) k[i] &= fmask;                     // from here on: the feature id
+				x[i] = !live ? 0.0 : general ? af[i] : (sum > 0 ? w / sum : 0.0);
+				if (live) k[i] = f;                          // from here on: the feature id
 			}
 		}
 
