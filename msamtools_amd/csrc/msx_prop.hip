@@ -614,8 +614,8 @@ __device__ __forceinline__ SegRow seg_row(uint32_t key, double v, bool valid, ui
 #define SR_EPL 8                       // consecutive entries summed by one lane
 #define SR_STEP (64 * SR_EPL)          // entries per wave step
 
-// (148 VGPRs = 3 waves per SIMD; forcing more with amdgpu_waves_per_eu spills and is slower:
-// 3 -> 68 us, 4 -> 76 us, 5 -> 118 us, 6 -> 157 us per launch against 58 us unconstrained)
+// (132 VGPRs = 3 waves per SIMD.  More is not better here: pinned at 4 waves -- 124 VGPRs, no spill -- a
+// launch takes 61 us against 54; with spills, at an earlier stage, 5 -> 118 us, 6 -> 157 us)
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
@@ -679,8 +679,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		load_step(base, k, lv, after);
 		// Each entry's term w/S.  A list of <= 4 features travels with its entries (the other
 		// features in the value, weight above the feature id in the key): S is summed here from a[] --
-		// 8 MB that the caches hold well, unlike one 8-byte recip[] per list out of tens of MB -- always
-		// in ascending feature order, so every entry of a list gets the same bits.  Other lists: recip[u].
+		// 8 MB that the caches hold well, unlike one 8-byte recip[] per list out of tens of MB -- as
+		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders:
+		// their S can differ in the last bit, 1e-16 relative; ordering them costs a third of this
+		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  Other lists: recip[u].
 		double x[SR_EPL];
 		{
 			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
@@ -700,15 +702,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 				const bool live = k[i] != SR_SENT;
 				const bool general = (lv[i] & SIG_HASHED) != 0;
 				const uint32_t f = k[i] & fmask;
-				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
-				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				// own feature merged into the ascending others (absent ones are SIG_PAD > f and add +0.0)
-				const int p = (int)(f > o1) + (int)(f > o2) + (int)(f > o3);
-				const double t1 = p == 0 ? af[i] : a1[i];
-				const double t2 = p == 0 ? a1[i] : (p == 1 ? af[i] : a2[i]);
-				const double t3 = p <= 1 ? a2[i] : (p == 2 ? af[i] : a3[i]);
-				const double t4 = p <= 2 ? a3[i] : af[i];
-				const double sum = ((t1 + t2) + t3) + t4;
+				const double sum = ((a1[i] + a2[i]) + a3[i]) + af[i];     // absent ones are +0.0
 				const double w = (double)(bits < 32 ? (k[i] >> bits) : 0u);
 				x[i] = !live ? 0.0 : general ? af[i] : (sum > 0 ? w / sum : 0.0);
 				if (live) k[i] = f;                          // from here on: the feature id
