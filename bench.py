@@ -216,6 +216,11 @@ def main():
     else:
         total_records = n
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(local_rank)
+        hbm_used_gib = round((total_b - free_b) / 2**30, 2)      # batch + outputs + every workspace, this rank
+    except Exception:
+        hbm_used_gib = None
     value = total_records * args.steps / elapsed / 1e6
 
     ab, pst = prof.fetch()
@@ -241,6 +246,7 @@ def main():
             "alignments_per_gpu": n, "qname_groups_per_gpu": ng, "references": nrefs,
             "alignments_kept_rank0": state["n_emit"],
             "prop_iterations": int(pst.iterations),
+            "hbm_used_gib_rank0": hbm_used_gib,
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
     }
