@@ -78,6 +78,16 @@ class _DevPtr:
                                          "version": 2, "strides": None}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def as_tensor(torch, ptr, n, typestr, dev):
     return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
 
@@ -335,8 +345,37 @@ def main():
             p = orc.run_profile(hs, nrefs, multi="proportional", sel=f["emit"])
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
+
+        # ---- parity of the timed workload itself: the GPU results of this very batch against the oracle
+        # run that was just paid for (bit-exact selection / order / counts, <= 1e-6 relative on the profile)
+        res = run.result()
+        ne = len(f["emit"])
+        par = {"checked": "whole batch" if sg == ng else f"first {sg} pools (filter output only)",
+               "emit_equal": bool(ne <= res.n_emit and np.array_equal(res.emit[:ne], f["emit"])
+                                  and (sg < ng or res.n_emit == ne)),
+               "n_emit_gpu": int(res.n_emit), "n_emit_oracle": int(ne)}
+        if sg == ng:
+            s = p["stats"]
+            ui_gpu = prof.ui()
+            par["ui_equal"] = bool(np.array_equal(ui_gpu, p["ui"]))
+            par["counters_equal"] = bool(
+                (int(pst.insert_count), int(pst.uniq_mapper_count), int(pst.multi_mapper_count),
+                 int(pst.purged_insert_count)) ==
+                (int(s.insert_count), int(s.uniq_mapper_count), int(s.multi_mapper_count), int(s.purged_insert_count)))
+            par["iterations_equal"] = bool((int(pst.iterations), int(pst.converged)) == (int(s.iterations), int(s.converged)))
+            want = p["abundance"]
+            par["zero_pattern_equal"] = bool(np.array_equal(ab == 0, want == 0))
+            par["max_rel_err"] = float((np.abs(ab - want) / np.maximum(np.abs(want), 1e-300)).max())
+            par["tolerance"] = 1e-6
+            par["ok"] = bool(par["emit_equal"] and par["ui_equal"] and par["counters_equal"] and
+                             par["iterations_equal"] and par["zero_pattern_equal"] and par["max_rel_err"] <= 1e-6)
+        else:
+            par["ok"] = par["emit_equal"]
+        out["parity"] = par
+        del res
         out["cpu_baseline"] = {
             "value": round(hs.n_records / best / 1e6, 3), "unit": "M alignments/s", "cores": 1, "kind": "port",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
             "sample": f"first {sg} QNAME groups ({hs.n_records} alignments) of the same synthetic stream, "
                       f"{nrefs} references, copied back from the device batch, resident in RAM; best of 2 runs of oracle filter+profile "
                       f"({best:.2f} s each)",
