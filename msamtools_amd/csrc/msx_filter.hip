@@ -11,40 +11,15 @@
 #include "msx_internal.h"
 #include "msx_count.h"
 #include "msx_md.h"
+#include "msx_stats.h"
 
 #include <climits>
+#include <cstdlib>
 
 // LDS staging capacities per 256-record tile.  Typical tile: ~300 CIGAR words,
 // ~1.5 KB of MD.  Payload beyond the capacity is read straight from global.
 #define CAP_CIG 1024          // dwords
 #define CAP_MDW 1536          // dwords (6 KB)
-
-// pool byte written for k_besthit_select (FilterArgs.pool_as_code): bits 6-7 are FLAG's READ1/READ2
-#define MSX_PC_IN 0x01u
-#define MSX_PC_HAS_AS 0x02u
-
-struct FilterArgs {
-	int64_t n;
-	const uint16_t *flag;
-	const uint8_t *rflags;
-	const uint32_t *cigar_off;
-	const uint32_t *cigar;
-	const uint32_t *md_off;
-	const uint8_t *md;
-	const int32_t *nm;
-	const int32_t *as;
-	int32_t min_length, ppt, max_clip;
-	int32_t choice;         // bit0 -l, bit1 -p/--ppt, bit2 -z (msam_filter.c:79-81)
-	int32_t rescore, invert, keep_unmapped;
-	int32_t md_aligned;     // md base is 4-byte aligned -> dword staging allowed
-	uint8_t *pool;          // [n] out: 1 = record enters the pool
-	int32_t pool_as_code;   // best-hit follows: a pooled record's byte is MSX_PC_IN | MSX_PC_HAS_AS | its mate bits,
-	                        // everything k_besthit_select needs to know about it besides its score
-	int32_t *as_out;        // [n] out (rescore) or null
-	int32_t *o_len, *o_qlen, *o_qclip, *o_edit;   // optional per-record stats
-	uint8_t *o_status;
-	msx_dev_status *st;
-};
 
 // Software-pipelined over the tiles of a workgroup (tile k of block b is tile
 // b + k*gridDim.x): while tile i is being walked out of LDS, the payload of tile
@@ -649,6 +624,21 @@ static int filter_choice(const msx_filter_params *p) {
 	return c;
 }
 
+// The statistics kernel: k_aln_stats_flat (msx_stats.hip); MSX_STATS_V1=1 keeps the lane-per-record
+// LDS-staged kernel of round 1 above for comparison runs.
+static void launch_stats(msx_ctx *ctx, FilterArgs &A) {
+	static const bool v1 = [] { const char *e = getenv("MSX_STATS_V1"); return e && atoi(e) != 0; }();
+	if (v1) {
+		hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid_x(ctx, A.n, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
+		                   ctx->stream, A);
+		return;
+	}
+	const uintptr_t al8 = (uintptr_t)A.cigar_off | (uintptr_t)A.md_off;
+	A.wide_ok = ((al8 & 7u) == 0 && ((uintptr_t)A.flag & 3u) == 0 && ((uintptr_t)A.rflags & 1u) == 0 &&
+	             ((uintptr_t)A.pool & 1u) == 0) ? 1 : 0;
+	msx_launch_aln_stats_flat(ctx, A, msx_grid_x(ctx, A.n, 128 * (MSX_BLOCK / 64), 4));
+}
+
 static void fill_args(FilterArgs &A, const msx_batch *b) {
 	A.n = b->n_records;
 	A.flag = b->flag;
@@ -711,8 +701,7 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 		}
 		A.pool = pool;
 		msx_time_begin(ctx, MSX_K_ALN_STATS);
-		hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid_x(ctx, n, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
-		                   ctx->stream, A);
+		launch_stats(ctx, A);
 		msx_time_end(ctx);
 	}
 	if (best) {
@@ -838,8 +827,7 @@ extern "C" int msx_aln_stats(msx_ctx *ctx, const msx_batch *b, int32_t *length, 
 	A.o_status = status;
 	A.st = ctx->d_status;
 	msx_time_begin(ctx, MSX_K_ALN_STATS);
-	hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid(ctx, b->n_records, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
-	                   ctx->stream, A);
+	launch_stats(ctx, A);
 	msx_time_end(ctx);
 	MSX_HIP(ctx, hipGetLastError());
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));

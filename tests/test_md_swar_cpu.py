@@ -12,3 +12,13 @@ def test_md_word_equals_md_byte(tmp_path):
     subprocess.check_call(["g++", "-O2", "-x", "c++", "-o", exe, os.path.join(ROOT, "tests", "c", "md_swar_test.c")])
     out = subprocess.check_output([exe, "3000000"]).decode()
     assert "bad=0" in out, out
+
+
+def test_md_flat_walk_equals_md_byte(tmp_path):
+    """The flat walk of k_aln_stats_flat (carry-chain form of the token rule, 16 bytes per lane,
+    ballot carries between lanes, prefix differences per string, several passes for long strings)
+    simulated lane by lane on the host against the byte-at-a-time rule."""
+    exe = str(tmp_path / "md_flat_test")
+    subprocess.check_call(["g++", "-O2", "-x", "c++", "-o", exe, os.path.join(ROOT, "tests", "c", "md_flat_test.c")])
+    out = subprocess.check_output([exe, "6000"]).decode()
+    assert "bad=0" in out, out
