@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSX_ABI_VERSION 1
+#define MSX_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSX_OK              0
@@ -45,6 +45,7 @@ extern "C" {
 #define MSX_ERR_ARG       (-11) /* bad argument                                  */
 #define MSX_ERR_NOMEM     (-12) /* device or host allocation failed              */
 #define MSX_ERR_NO_DEVICE (-13) /* no usable gfx950 device: there is NO CPU fallback */
+#define MSX_ERR_DIST      (-14) /* RCCL / rendezvous failure                      */
 
 /* ---- per-record aux presence bits (msx_batch.rflags) --------------------- */
 #define MSX_HAS_MD 1u   /* bam_aux_get(b,"MD") != NULL (msam_filter.c:146)      */
@@ -264,6 +265,46 @@ int  msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int6
  * finalize: lists renumbered for locality, identical feature sets merged into one
  * weighted list).  Synchronises the stream. */
 int  msx_profile_shared_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries);
+
+/* ---- several GPUs: one process (rank) per GPU, RCCL over xGMI ------------------
+ *
+ * The reference is one process over one file.  Here the record stream is cut at
+ * pool (QNAME) boundaries into one shard per rank; msam_filter.c:98-263 and the
+ * per-pool part of msam_profile.c:65-243 need no communication.  What the
+ * reference accumulates over the WHOLE file is exchanged: the per-reference
+ * counts and counters once (msam_profile.c:75-186, integer, bit-exact under any
+ * order), and inside the loop of msam_profile.c:331-389 the per-iteration
+ * increment, as the vector `share` (f64[n_features]).  Every rank then applies
+ * the same update and takes the same convergence decision (:383), so no rank
+ * waits for its host.  librccl is loaded at run time by msx_dist_init only.
+ *
+ * A rank creates its context on its own GPU (msx_ctx_create(LOCAL_RANK)), then
+ * either msx_dist_init_env (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set
+ * by torchrun, mpirun wrappers, ...; the 128-byte communicator id travels over a
+ * TCP rendezvous on MSX_DIST_PORT, default MASTER_PORT + 17) or msx_dist_init with
+ * an id the caller has distributed itself (msx_dist_unique_id on rank 0). */
+#define MSX_DIST_ID_BYTES 128
+int  msx_dist_unique_id(uint8_t id[MSX_DIST_ID_BYTES]);
+int  msx_dist_init(msx_ctx *ctx, const uint8_t id[MSX_DIST_ID_BYTES], int rank, int world);
+int  msx_dist_init_env(msx_ctx *ctx);
+void msx_dist_finalize(msx_ctx *ctx);
+int  msx_dist_rank(const msx_ctx *ctx);    /* 0 without a communicator */
+int  msx_dist_world(const msx_ctx *ctx);   /* 1 without a communicator */
+/* rank 0 sends `bytes` of payload to every other rank (plain TCP; used by msx_dist_init_env) */
+int  msx_dist_rendezvous(const char *addr, int port, int rank, int world, void *payload, size_t bytes,
+                         int timeout_s);
+/* stream-ordered reductions of one host value over all ranks (harness use: barrier, the slowest
+ * rank's elapsed time, record totals); identity with one rank */
+int  msx_dist_barrier(msx_ctx *ctx);
+int  msx_dist_max_f64(msx_ctx *ctx, double *value);
+int  msx_dist_sum_i64(msx_ctx *ctx, int64_t *value);
+/* all-reduce(sum) of ui / d / {inserts, uniq, multi} of this rank's profile, enqueued on the ctx stream */
+int  msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p);
+/* mInsertCountToAbundanceMatrix over all ranks' shards: msx_profile_allreduce_counts, then
+ * msx_profile_finalize_enqueue's device work with `share` all-reduced inside every iteration and the
+ * purged count summed at the end; nothing waits for the host.  Identical results on every rank
+ * (fetch them with msx_profile_fetch).  With one rank it IS msx_profile_finalize_enqueue. */
+int  msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p);
 
 /* ---- coverage: replaces mUpdateCoverageForAlignment (msam_coverage.c:33-87) */
 

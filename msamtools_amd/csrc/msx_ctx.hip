@@ -139,6 +139,7 @@ extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	msx_join(ctx);
+	msx_dist_finalize(ctx);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (int i = 0; i < MSX_SIDE_LANES; i++) {
 		msx_lane &l = ctx->side[i];

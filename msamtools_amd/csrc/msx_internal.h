@@ -76,8 +76,11 @@ struct msx_lane {
 };
 #define MSX_SIDE_LANES 2
 
+struct msx_dist;     // msx_dist.hip: RCCL communicator of this rank
+
 struct msx_ctx {
 	int device = 0;
+	msx_dist *dist = nullptr;          // null: single GPU
 	hipStream_t stream = nullptr;      // the stream every launch helper uses: the main one, or a side lane's
 	                                   // between msx_lane_enter and msx_lane_leave
 	hipStream_t main_stream = nullptr;
@@ -192,6 +195,9 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p);        // share[f] = sum_j
 int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
+// msx_dist.hip: in-place all-reduce(sum) on the ctx stream; no-ops without a communicator
+int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p);
+int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count);
 // ui[key] += add for every key < 0x80000000 of keys[0..n) by partition + LDS counting (n_features <= 2 M)
 int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add);
 #define MSX_COUNT_KEYS_MAX_FEATURES (256 * 8192)

@@ -1162,6 +1162,26 @@ extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p) {
 	return MSX_OK;
 }
 
+extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	int rc = msx_profile_allreduce_counts(ctx, p);           // ui, d, {inserts, uniq, multi} over all shards
+	if (rc) return rc;
+	if ((rc = msx_profile_prop_begin(ctx, p))) return rc;      // a = U = ui/2 (+d): identical on every rank
+	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
+			msx_prop_iteration(ctx, p);           // share = this rank's part of the increment
+			// (after convergence the local kernels are no-ops and leave `share` at zero on every rank;
+			// the all-reduce still runs -- every rank enqueues the same 19 -- and sums zeros)
+			if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;
+			msx_prop_apply_launch(ctx, p, k);     // same numbers, same decision (:383) everywhere
+		}
+		msx_prop_purged_launch(ctx, p, p->counters + 3);       // this rank's multi-mappers whose sum is 0
+		if ((rc = msx_dist_allreduce_u32(ctx, p->counters + 3, 1))) return rc;
+	}
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
 extern "C" int msx_profile_fetch(msx_ctx *ctx, msx_profile *p, double *abundance_host, msx_profile_stats *stats) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_fetch before finalize/prop_begin");
