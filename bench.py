@@ -9,7 +9,9 @@ references, generated on the device by the library's deterministic generator.
 With --gpus N each rank holds its own shard of that shape (weak scaling): the
 filter/best-hit kernels need no communication; the per-reference count vector
 and, per proportional-sharing iteration, the increment vector are all-reduced
-over RCCL (torch.distributed backend "nccl").
+over RCCL inside the library (msx_profile_finalize_dist_enqueue; torch.distributed is not
+used: the launcher's environment -- RANK / WORLD_SIZE / MASTER_* -- only carries the
+128-byte communicator id from rank 0 to the others).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task prompt),
 including `roofline` for the dominant kernel (HIP-event timings taken on the
@@ -65,31 +67,36 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the multi-GPU step (RCCL all-reduces between the split profile calls) even with one rank")
+                    help="run the multi-GPU step (msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator) "
+                         "even with one rank")
     ap.add_argument("--print-checksum", action="store_true", help="add a checksum of the abundance vector to the JSON")
     return ap.parse_args()
 
 
-class _DevPtr:
-    """Expose library-owned device memory to torch (for the RCCL all-reduce)."""
-
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def cpu_model():
+def exchange_comm_id(m, rank, world):
+    """The RCCL communicator id, made on rank 0, to every rank: through the launcher's key-value store
+    (torchrun hosts one on MASTER_ADDR:MASTER_PORT) or, failing that, the library's own TCP rendezvous
+    (msx_dist_init_env).  Returns the id bytes, or None for "use msx_dist_init_env"."""
+    if world == 1:
+        return m.dist_unique_id()
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def as_tensor(torch, ptr, n, typestr, dev):
-    return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
+                         world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300),
+                         wait_for_workers=False)
+        key = "msx_comm_id/" + os.environ.get("TORCHELASTIC_RUN_ID", "0")
+        if rank == 0:
+            uid = m.dist_unique_id()
+            store.set(key, uid)
+        else:
+            uid = bytes(store.get(key))
+        return uid
+    except Exception as exc:      # no store reachable: the C rendezvous on MSX_DIST_PORT / MASTER_PORT + 17
+        print(f"[bench rank {rank}] launcher store unavailable ({exc}); using the library's TCP rendezvous",
+              file=sys.stderr, flush=True)
+        return None
 
 
 def algorithmic_bytes(name, w):
@@ -143,16 +150,9 @@ def main():
     import torch
     import msamtools_amd as m
 
-    dist = None
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
-                                device_id=torch.device(dev))
+    use_dist = world > 1 or args.force_dist
 
     ng, nrefs, desc = WORKLOADS[args.workload]
     if args.groups:
@@ -166,47 +166,33 @@ def main():
     n = db.n_records
     run = m.FilterRun(ctx, db, **FILTER_OPTS)
     prof = m.Profile(ctx, nrefs, "proportional")
-    ui_ptr, _, cnt_ptr = prof.accumulators()
-    t_ui = t_cnt = t_share = t_purged = None
-    if dist is not None:
-        t_ui = as_tensor(torch, ui_ptr, nrefs, "<i4", dev)       # u32 sums wrap like i32 sums
-        t_cnt = as_tensor(torch, cnt_ptr, 3, "<i4", dev)         # inserts, uniq, multi (purged is reduced separately)
+    if use_dist:
+        # one communicator per rank, owned by the library; every collective of a step is enqueued by
+        # the C entry points on the library's own stream
+        uid = exchange_comm_id(m, rank, world)
+        if uid is None:
+            ctx.dist_init_env()
+        else:
+            ctx.dist_init(uid, rank, world)
 
     state = {"iters": 0, "n_emit": 0}
 
-    ext = None
-    if dist is not None:
-        # run torch's collectives on the library's own HIP stream: kernels and all-reduces are
-        # ordered by the stream, no host synchronisation inside a step
-        ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-        t_share = as_tensor(torch, prof.share_ptr(), nrefs, "<f8", dev)
-        t_purged = as_tensor(torch, prof.prop_purged_enqueue(), 1, "<i4", dev)
-
     def step():
         prof.reset()
-        run.enqueue_with_profile(prof)     # filter | profile: aln_stats_filter, besthit_select with the
+        run.enqueue_with_profile(prof)     # filter | profile: aln_stats_flat, besthit_select with the
                                            # insert accounting inside, scans, emit_order, list compaction
-        if dist is None:
+        if not use_dist:
             prof.finalize_enqueue()        # <= 19 proportional iterations, no host round trip
         else:
-            with torch.cuda.stream(ext):
-                dist.all_reduce(t_ui)          # exact (integer)
-                dist.all_reduce(t_cnt)
-                prof.prop_begin()
-                for _ in range(19):            # msam_profile.c:331; no-ops after convergence
-                    prof.prop_local()
-                    dist.all_reduce(t_share)
-                    prof.prop_apply_enqueue()
-                prof.prop_purged_enqueue()
-                dist.all_reduce(t_purged)
+            # counts all-reduced once, `share` all-reduced inside each of the 19 iterations, purged at the
+            # end: RCCL on the library's stream between its kernels, no host synchronisation
+            prof.finalize_dist_enqueue()
         st = run.finish()                  # one sync per step; raises on data errors
         state["n_emit"] = int(st.n_emit)
 
     def barrier():
-        ctx.sync()
+        ctx.barrier()                      # stream sync, and over RCCL a one-element all-reduce + sync
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -216,15 +202,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tn = torch.tensor([n], dtype=torch.int64, device=dev)
-        dist.all_reduce(tn)
-        total_records = int(tn.item())
-    else:
-        total_records = n
+    elapsed = ctx.max_over_ranks(elapsed)          # the slowest rank's time
+    total_records = ctx.sum_over_ranks(n)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     try:
         free_b, total_b = torch.cuda.mem_get_info(local_rank)
@@ -234,9 +213,6 @@ def main():
     value = total_records * args.steps / elapsed / 1e6
 
     ab, pst = prof.fetch()
-    if dist is not None:
-        # the split API leaves "purged" to the caller: sum over ranks
-        pst.purged_insert_count = int(t_purged.item())
     out = {
         "metric": "M alignments/s through filter --besthit | profile",
         "value": round(value, 3),
@@ -417,8 +393,6 @@ def main():
     run.free()
     db.free()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
         try:

@@ -11,8 +11,8 @@ from ._lib import MsxError
 _lib.load()
 
 from .api import (Context, DeviceBatch, FilterRun, HostSynth, Profile, aln_stats,  # noqa: E402
-                  coverage, filter_params, run_filter)
+                  coverage, dist_unique_id, filter_params, run_filter)
 from .grouping import filter_pools, profile_pools  # noqa: E402
 
 __all__ = ["Context", "DeviceBatch", "FilterRun", "HostSynth", "Profile", "MsxError", "aln_stats",
-           "coverage", "filter_params", "run_filter", "filter_pools", "profile_pools"]
+           "coverage", "dist_unique_id", "filter_params", "run_filter", "filter_pools", "profile_pools"]

@@ -66,6 +66,8 @@ class SynthSizes(C.Structure):
     _fields_ = [("n_records", C.c_int64), ("n_cigar", C.c_int64), ("n_md", C.c_int64)]
 
 
+DIST_ID_BYTES = 128
+
 # every symbol include/msamtools_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -109,6 +111,18 @@ SYMBOLS = {
     "msx_dev_zero": (C.c_int, [_P, _P, C.c_size_t]),
     "msx_dev_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msx_host_to_dev": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msx_dist_unique_id": (C.c_int, [_P]),
+    "msx_dist_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "msx_dist_init_env": (C.c_int, [_P]),
+    "msx_dist_finalize": (None, [_P]),
+    "msx_dist_rank": (C.c_int, [_P]),
+    "msx_dist_world": (C.c_int, [_P]),
+    "msx_dist_rendezvous": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
+    "msx_dist_barrier": (C.c_int, [_P]),
+    "msx_dist_max_f64": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "msx_dist_sum_i64": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "msx_profile_allreduce_counts": (C.c_int, [_P, _P]),
+    "msx_profile_finalize_dist_enqueue": (C.c_int, [_P, _P]),
     "msx_timing_enable": (C.c_int, [_P, C.c_int]),
     "msx_timing_reset": (C.c_int, [_P]),
     "msx_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -47,6 +47,14 @@ def filter_params(l=0, p=None, ppt=None, z=None, rescore=False, invert=False,
     return fp
 
 
+def dist_unique_id():
+    """ncclGetUniqueId on the calling rank (rank 0 distributes the 128 bytes)."""
+    lib = L.load()
+    buf = (C.c_uint8 * L.DIST_ID_BYTES)()
+    L.check(None, lib.msx_dist_unique_id(buf))
+    return bytes(buf)
+
+
 class Context:
     """One GPU (msx_ctx).  Raises if there is no gfx950 device."""
 
@@ -76,6 +84,36 @@ class Context:
 
     def sync(self):
         self.check(self.lib.msx_ctx_sync(self.h))
+
+    # several GPUs: one rank per process (msx_dist_*) ------------------------
+    def dist_init(self, id_bytes, rank, world):
+        buf = (C.c_uint8 * L.DIST_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        self.check(self.lib.msx_dist_init(self.h, buf, int(rank), int(world)))
+
+    def dist_init_env(self):
+        self.check(self.lib.msx_dist_init_env(self.h))
+
+    @property
+    def rank(self):
+        return self.lib.msx_dist_rank(self.h)
+
+    @property
+    def world(self):
+        return self.lib.msx_dist_world(self.h)
+
+    def barrier(self):
+        """Stream sync + (with a communicator) a one-element all-reduce over the ranks."""
+        self.check(self.lib.msx_dist_barrier(self.h))
+
+    def max_over_ranks(self, value):
+        v = C.c_double(float(value))
+        self.check(self.lib.msx_dist_max_f64(self.h, C.byref(v)))
+        return v.value
+
+    def sum_over_ranks(self, value):
+        v = C.c_int64(int(value))
+        self.check(self.lib.msx_dist_sum_i64(self.h, C.byref(v)))
+        return v.value
 
     # raw device memory -----------------------------------------------------
     def alloc(self, nbytes):
@@ -405,6 +443,13 @@ class Profile:
 
     def finalize_enqueue(self):
         self.ctx.check(self.ctx.lib.msx_profile_finalize_enqueue(self.ctx.h, self.h))
+
+    def finalize_dist_enqueue(self):
+        """mInsertCountToAbundanceMatrix over all ranks' shards (RCCL inside the library)."""
+        self.ctx.check(self.ctx.lib.msx_profile_finalize_dist_enqueue(self.ctx.h, self.h))
+
+    def allreduce_counts(self):
+        self.ctx.check(self.ctx.lib.msx_profile_allreduce_counts(self.ctx.h, self.h))
 
     def fetch(self):
         ab = np.zeros(max(self.n_features, 1), np.float64)

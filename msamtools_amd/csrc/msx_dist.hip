@@ -275,7 +275,7 @@ extern "C" int msx_dist_sum_i64(msx_ctx *ctx, int64_t *value) {
 extern "C" int msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	msx_dist *d = ctx->dist;
-	if (!d || d->world == 1) return MSX_OK;
+	if (!d) return MSX_OK;          // (a one-rank communicator still runs the collective: the same code path)
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	MSX_NCCL(ctx, g_rccl.GroupStart());
 	int r1 = g_rccl.AllReduce(p->ui, p->ui, (size_t)p->n_features, MSX_NCCL_UINT32, MSX_NCCL_SUM, d->comm, ctx->stream);
@@ -291,7 +291,7 @@ extern "C" int msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p) {
 
 int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p) {
 	msx_dist *d = ctx->dist;
-	if (!d || d->world == 1) return MSX_OK;
+	if (!d) return MSX_OK;          // (a one-rank communicator still runs the collective: the same code path)
 	MSX_NCCL(ctx, g_rccl.AllReduce(p->share, p->share, (size_t)p->n_features, MSX_NCCL_FLOAT64, MSX_NCCL_SUM, d->comm,
 	                                ctx->stream));
 	return MSX_OK;
@@ -299,7 +299,7 @@ int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p) {
 
 int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count) {
 	msx_dist *d = ctx->dist;
-	if (!d || d->world == 1) return MSX_OK;
+	if (!d) return MSX_OK;          // (a one-rank communicator still runs the collective: the same code path)
 	MSX_NCCL(ctx, g_rccl.AllReduce(dev, dev, count, MSX_NCCL_UINT32, MSX_NCCL_SUM, d->comm, ctx->stream));
 	return MSX_OK;
 }

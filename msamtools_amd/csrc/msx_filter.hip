@@ -1,13 +1,10 @@
 // msx_filter.hip -- device side of `msamtools filter`:
-//   k_aln_stats_filter  per-record CIGAR/MD walk, -l/-p/-z predicates, --rescore,
-//                       pool membership          (mBamVector.c:23-133, msam_filter.c:31-63,132-183)
+//   (k_aln_stats_flat, the per-record CIGAR/MD walk with the -l/-p/-z predicates, is in msx_stats.hip)
 //   k_besthit_select    per-pool best-hit / unique-best-hit selection, mate aware
 //                                                 (msam_filter.c:192-263)
 //   k_emit_*            the order in which the reference calls mSamWrite
 //                                                 (msam_filter.c:235-244, mBamVector.c:343-348)
-// All integer work, HBM-bound; no MFMA.  One wave64 lane per record (stats) or
-// per pool (selection); variable-length CIGAR/MD payloads of a 256-record tile
-// are staged into LDS with coalesced dword loads.
+// All integer work, HBM-bound; no MFMA.  One wave64 lane per pool.
 #include "msx_internal.h"
 #include "msx_count.h"
 #include "msx_md.h"
@@ -15,290 +12,6 @@
 
 #include <climits>
 #include <cstdlib>
-
-// LDS staging capacities per 256-record tile.  Typical tile: ~300 CIGAR words,
-// ~1.5 KB of MD.  Payload beyond the capacity is read straight from global.
-#define CAP_CIG 1024          // dwords
-#define CAP_MDW 1536          // dwords (6 KB)
-
-// Software-pipelined over the tiles of a workgroup (tile k of block b is tile
-// b + k*gridDim.x): while tile i is being walked out of LDS, the payload of tile
-// i+1 (CIGAR words, MD dwords, FLAG, aux bits) and the offsets of tile i+2 are
-// already in flight into registers; they are written to LDS after the barrier
-// that ends tile i.  No global-memory latency sits between two tiles.
-#define CIG_REGS (CAP_CIG / MSX_BLOCK)   // 4
-#define MD_REGS (CAP_MDW / MSX_BLOCK)    // 6
-
-struct TileOff {          // offsets of one tile, one entry per thread (+1 extra held by thread 0)
-	uint32_t co, mo, co_last, mo_last;
-};
-
-__device__ __forceinline__ void load_offsets(const FilterArgs &A, int64_t tile, int tid, TileOff &o) {
-	const int64_t t0 = tile * MSX_BLOCK;
-	const int64_t left = A.n - t0;
-	const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
-	o.co = o.mo = o.co_last = o.mo_last = 0;
-	if (tid <= nt && t0 + tid <= A.n) {
-		o.co = A.cigar_off[t0 + tid];
-		o.mo = A.md_off[t0 + tid];
-	}
-	if (tid == 0 && nt == MSX_BLOCK) {
-		o.co_last = A.cigar_off[t0 + MSX_BLOCK];
-		o.mo_last = A.md_off[t0 + MSX_BLOCK];
-	}
-}
-
-// (waves per SIMD pinned: the kernel is instruction-bound and loses 10 % when a few more registers drop it to 5)
-__global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_aln_stats_filter(FilterArgs A) {
-	__shared__ uint32_t s_coff[2][MSX_BLOCK + 1];
-	__shared__ uint32_t s_moff[2][MSX_BLOCK + 1];
-	__shared__ uint32_t s_cig[CAP_CIG];
-	__shared__ uint32_t s_md[CAP_MDW + 2];    // +2: the realigned walk reads one word past a string's last
-
-	const int tid = threadIdx.x;
-	const int64_t n_tiles = (A.n + MSX_BLOCK - 1) / MSX_BLOCK;
-	const int64_t first = blockIdx.x, step = gridDim.x;
-	if (first >= n_tiles) return;
-	const uint32_t *md4 = reinterpret_cast<const uint32_t *>(A.md);
-
-	uint32_t cr[CIG_REGS], mr[MD_REGS];
-	uint32_t fl_n = 0, rf_n = 0;
-	TileOff on;
-
-	// helpers as lambdas over the LDS arrays
-	auto store_offsets = [&](int buf, int64_t tile, const TileOff &o) {
-		const int64_t left = A.n - tile * MSX_BLOCK;
-		const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
-		if (tid <= nt) { s_coff[buf][tid] = o.co; s_moff[buf][tid] = o.mo; }
-		if (tid == 0 && nt == MSX_BLOCK) { s_coff[buf][MSX_BLOCK] = o.co_last; s_moff[buf][MSX_BLOCK] = o.mo_last; }
-	};
-	auto issue_payload = [&](int buf, int64_t tile) {
-		const int64_t t0 = tile * MSX_BLOCK;
-		const int64_t left = A.n - t0;
-		const int nt = left < MSX_BLOCK ? (int)left : MSX_BLOCK;
-		// tile geometry is workgroup-uniform: keep it in scalar registers so that whole 256-word
-		// slices beyond the tile's payload are skipped by scalar branches, not predicated off
-		const uint32_t c0 = __builtin_amdgcn_readfirstlane(s_coff[buf][0]);
-		uint32_t clen = __builtin_amdgcn_readfirstlane(s_coff[buf][nt]) - c0;
-		if (clen > CAP_CIG) clen = CAP_CIG;
-		const uint32_t *cbase = A.cigar + c0;
-#pragma unroll
-		for (int q = 0; q < CIG_REGS; q++) {
-			cr[q] = 0u;
-			if ((uint32_t)(q * MSX_BLOCK) < clen) {
-				const uint32_t w = tid + q * MSX_BLOCK;
-				if (w < clen) cr[q] = cbase[w];
-			}
-		}
-		if (A.md_aligned) {
-			const uint32_t m0a = __builtin_amdgcn_readfirstlane(s_moff[buf][0]) & ~3u;
-			uint32_t mw = (__builtin_amdgcn_readfirstlane(s_moff[buf][nt]) - m0a + 3u) >> 2;
-			if (mw > CAP_MDW) mw = CAP_MDW;
-			const uint32_t *mbase = md4 + (m0a >> 2);
-#pragma unroll
-			for (int q = 0; q < MD_REGS; q++) {
-				mr[q] = 0u;
-				if ((uint32_t)(q * MSX_BLOCK) < mw) {
-					const uint32_t w = tid + q * MSX_BLOCK;
-					if (w < mw) mr[q] = mbase[w];
-				}
-			}
-		}
-		if (tid < nt) { fl_n = A.flag[t0 + tid]; rf_n = A.rflags[t0 + tid]; }
-	};
-	auto store_payload = [&]() {
-#pragma unroll
-		for (int q = 0; q < CIG_REGS; q++) s_cig[tid + q * MSX_BLOCK] = cr[q];
-#pragma unroll
-		for (int q = 0; q < MD_REGS; q++) s_md[tid + q * MSX_BLOCK] = mr[q];
-	};
-
-	// prologue: offsets(0) -> LDS, payload(0) and offsets(1) -> registers -> LDS
-	load_offsets(A, first, tid, on);
-	store_offsets(0, first, on);
-	__syncthreads();
-	issue_payload(0, first);
-	if (first + step < n_tiles) load_offsets(A, first + step, tid, on);
-	store_payload();
-	if (first + step < n_tiles) store_offsets(1, first + step, on);
-	__syncthreads();
-
-	int buf = 0;
-	for (int64_t tile = first; tile < n_tiles; tile += step, buf ^= 1) {
-		const int64_t t0 = tile * MSX_BLOCK;
-		const int nt = (int)((A.n - t0 < MSX_BLOCK) ? (A.n - t0) : MSX_BLOCK);
-		const int64_t t = t0 + tid;
-		const bool live = tid < nt;
-		const uint32_t flag = fl_n, rf = rf_n;          // this tile's, loaded one iteration ago
-		const bool has_next = tile + step < n_tiles, has_next2 = tile + 2 * step < n_tiles;
-
-		// geometry of the staged payload of this tile
-		const uint32_t c0 = __builtin_amdgcn_readfirstlane(s_coff[buf][0]);
-		const uint32_t c_end = __builtin_amdgcn_readfirstlane(s_coff[buf][nt]);
-		uint32_t clen = c_end - c0;
-		if (clen > CAP_CIG) clen = CAP_CIG;
-		uint32_t m0a = 0, mbytes = 0, m_end = 0;
-		if (A.md_aligned) {
-			m0a = __builtin_amdgcn_readfirstlane(s_moff[buf][0]) & ~3u;
-			m_end = __builtin_amdgcn_readfirstlane(s_moff[buf][nt]);
-			uint32_t mw = (m_end - m0a + 3u) >> 2;
-			if (mw > CAP_MDW) mw = CAP_MDW;
-			mbytes = mw << 2;
-		}
-
-		// tile-uniform: every CIGAR word and MD byte of this tile was staged
-		const bool all_staged = A.md_aligned && (c_end - c0) <= CAP_CIG && (m_end - m0a) <= mbytes;
-
-		// in flight while this tile is computed
-		if (has_next) issue_payload(buf ^ 1, tile + step);
-		if (has_next2) load_offsets(A, tile + 2 * step, tid, on);
-
-		if (live) {
-			uint32_t pooled = 0;
-			if (A.as_out) A.as_out[t] = A.as[t];   // replaced below when the record is rescored
-			if ((flag & MSX_F_UNMAP) && !A.o_len) {
-				// msam_filter.c:132-138 (msx_aln_stats reports statistics for every record)
-				pooled = (A.choice != 0 && A.keep_unmapped && A.ppt >= 0 && A.invert == 1) ? 1u : 0u;
-			} else {
-				uint32_t alen = 0, qlen = 0, qclip = 0, edit = 0;   // wrap like int32
-				bool bad = false;
-				const uint32_t cs = s_coff[buf][tid], ce = s_coff[buf][tid + 1];
-				if (all_staged) {
-					// fast path: the whole tile's payload is in LDS.  CIGAR by per-op bit tables
-					// (bit i = op i contributes): MD path mBamVector.c:60-97, NM path :23-38.
-					const bool mdp = (rf & MSX_HAS_MD) != 0;
-					bad = !mdp && !(rf & MSX_HAS_NM);
-					const uint32_t T_ALEN = mdp ? 0x187u : 0xff87u;    // M I D = X (NM path: all but N P S H)
-					const uint32_t T_EDIT = mdp ? 0x006u : 0u;         // I D
-					for (uint32_t k = cs; k < ce; ++k) {
-						const uint32_t c = s_cig[k - c0];
-						const uint32_t op = c & 0xf, w = c >> 4;
-						alen += w & (uint32_t)__builtin_amdgcn_sbfe((int)T_ALEN, op, 1u);    // 0 or ~0: bit `op` of the table
-						qlen += w & (uint32_t)__builtin_amdgcn_sbfe(0x1b3, op, 1u);          // M I S H = X
-						edit += w & (uint32_t)__builtin_amdgcn_sbfe((int)T_EDIT, op, 1u);
-						qclip += w & (uint32_t)__builtin_amdgcn_sbfe(0x030, op, 1u);         // S H
-					}
-					if (mdp) {
-						// words realigned to the start of the string: full words, then one masked tail
-						MdBits s = {0u, 0u, 0u, 0u};
-						const uint32_t ms = s_moff[buf][tid], bs = ms - m0a, len = s_moff[buf][tid + 1] - ms;
-						const uint32_t sh = bs & 3u, nfull = len >> 2, rem = len & 3u;
-						uint32_t wi = bs >> 2;
-						uint32_t lo = s_md[wi];
-						for (uint32_t q = 0; q < nfull; ++q) {
-							const uint32_t hi = s_md[++wi];
-							md_word_aligned(s, MSX_ALIGNBYTE(hi, lo, sh), 0x80808080u);
-							lo = hi;
-						}
-						if (rem) {
-							const uint32_t hi = s_md[wi + 1];
-							md_word_aligned(s, MSX_ALIGNBYTE(hi, lo, sh), 0x80808080u >> (8u * (4u - rem)));
-						}
-						edit += s.edit;
-					} else if (!bad) {
-						edit = (uint32_t)A.nm[t];                      // msam_filter.c:155
-					} else {
-						atomicMin(&A.st->first_no_mdnm, (unsigned long long)t);   // msam_filter.c:150-152
-					}
-				} else if (rf & MSX_HAS_MD) {
-					// bam_get_summary, mBamVector.c:60-97
-					for (uint32_t k = cs; k < ce; ++k) {
-						uint32_t c = (k - c0 < clen) ? s_cig[k - c0] : A.cigar[k];
-						uint32_t op = c & 0xf, w = c >> 4;
-						if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {
-							qlen += w; alen += w;
-						} else if (op == MSX_OP_INS) {
-							qlen += w; edit += w; alen += w;
-						} else if (op == MSX_OP_DEL) {
-							edit += w; alen += w;
-						} else if (op == MSX_OP_SOFT_CLIP || op == MSX_OP_HARD_CLIP) {
-							qclip += w; qlen += w;
-						}
-					}
-					// MD walk, mBamVector.c:101-118
-					MdState s = {0u, 0u, 0u, 0};
-					const uint32_t ms = s_moff[buf][tid], me = s_moff[buf][tid + 1];
-					if (ms < me) {
-						if (A.md_aligned && (me - m0a) <= mbytes) {
-							const uint32_t bs = ms - m0a, be = me - m0a;
-							for (uint32_t w = bs >> 2; (w << 2) < be; ++w) {
-								const uint32_t word = s_md[w];
-								const uint32_t p = w << 2;
-								md_byte(s, word & 0xffu, p >= bs && p < be);
-								md_byte(s, (word >> 8) & 0xffu, p + 1 >= bs && p + 1 < be);
-								md_byte(s, (word >> 16) & 0xffu, p + 2 >= bs && p + 2 < be);
-								md_byte(s, word >> 24, p + 3 >= bs && p + 3 < be);
-							}
-						} else {
-							for (uint32_t j = ms; j < me; ++j) md_byte(s, A.md[j], true);
-						}
-					}
-					edit += (uint32_t)s.edit;
-				} else if (rf & MSX_HAS_NM) {
-					// bam_cigar2details, mBamVector.c:23-38
-					for (uint32_t k = cs; k < ce; ++k) {
-						uint32_t c = (k - c0 < clen) ? s_cig[k - c0] : A.cigar[k];
-						uint32_t op = c & 0xf, w = c >> 4;
-						if (op == MSX_OP_HARD_CLIP || op == MSX_OP_SOFT_CLIP) {
-							qclip += w; qlen += w;
-						} else if (!(op == MSX_OP_REF_SKIP || op == MSX_OP_PAD)) {
-							alen += w;
-							if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF || op == MSX_OP_INS)
-								qlen += w;
-						}
-					}
-					edit = (uint32_t)A.nm[t];   // msam_filter.c:155
-				} else {
-					bad = true;                 // msam_filter.c:150-152
-					atomicMin(&A.st->first_no_mdnm, (unsigned long long)t);
-				}
-				if (A.o_status) A.o_status[t] = bad ? 1 : 0;
-				if (A.o_len) {
-					A.o_len[t] = (int32_t)alen; A.o_qlen[t] = (int32_t)qlen;
-					A.o_qclip[t] = (int32_t)qclip; A.o_edit[t] = (int32_t)edit;
-				}
-				if (!bad) {
-					if (A.rescore)          // msam_filter.c:160-168: hit=+1, miss=-1
-						A.as_out[t] = (int32_t)((alen - edit) - edit);
-					// msam_filter.c:31-35 in wrapping int32 arithmetic
-					const int32_t L = (int32_t)alen;
-					bool fl = L < A.min_length;
-					bool fz, fp;
-					// 32-bit integer multiplies run at quarter rate; when every operand of this wave fits 24 bits
-					// (always, for real reads) v_mul_u32_u24 gives the same low 32 bits at full rate
-					const uint32_t ident = alen - edit;
-					const bool small = A.ppt >= 0 && (uint32_t)A.ppt < (1u << 24) && (uint32_t)A.max_clip < (1u << 24) &&
-					                   __ballot(((alen | qlen | qclip | ident) >> 24) != 0u) == 0ull;
-					if (small) {
-						fz = (int32_t)__umul24(100u, qclip) >
-						     (int32_t)__umul24((uint32_t)A.max_clip, qlen);
-						fp = (int32_t)__umul24(1000u, ident) <
-						     (int32_t)__umul24(alen, (uint32_t)A.ppt);
-					} else {
-						fz = (int32_t)(100u * qclip) > (int32_t)((uint32_t)A.max_clip * qlen);
-						fp = (A.ppt < 0)
-						         ? ((int32_t)(1000u * (edit - alen)) < (int32_t)(alen * (uint32_t)A.ppt))
-						         : ((int32_t)(1000u * (alen - edit)) < (int32_t)(alen * (uint32_t)A.ppt));
-					}
-					bool fails = ((A.choice & 1) && fl) || ((A.choice & 2) && fp) || ((A.choice & 4) && fz);
-					pooled = (A.choice == 0 || (int)fails == A.invert) ? 1u : 0u;   // msam_filter.c:181
-				}
-			}
-			if (A.pool) {
-				if (A.pool_as_code && pooled) {
-					// msam_filter.c:223: AS is read from the record; after --rescore every mapped record has one (:167)
-					const bool has = (rf & MSX_HAS_AS) || (A.rescore && !(flag & MSX_F_UNMAP));
-					pooled = MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (flag & MSX_F_MATES);
-				}
-				A.pool[t] = (uint8_t)pooled;
-			}
-		}
-		__syncthreads();                 // every lane is done with this tile's LDS image
-		if (has_next) store_payload();
-		if (has_next2) store_offsets(buf, tile + 2 * step, on);
-		__syncthreads();
-	}
-}
 
 // ---------------------------------------------------------------------------
 // best-hit selection: one lane per pool.
@@ -624,15 +337,8 @@ static int filter_choice(const msx_filter_params *p) {
 	return c;
 }
 
-// The statistics kernel: k_aln_stats_flat (msx_stats.hip); MSX_STATS_V1=1 keeps the lane-per-record
-// LDS-staged kernel of round 1 above for comparison runs.
+// The statistics kernel: k_aln_stats_flat (msx_stats.hip), one wave per 128 records
 static void launch_stats(msx_ctx *ctx, FilterArgs &A) {
-	static const bool v1 = [] { const char *e = getenv("MSX_STATS_V1"); return e && atoi(e) != 0; }();
-	if (v1) {
-		hipLaunchKernelGGL(k_aln_stats_filter, dim3(msx_grid_x(ctx, A.n, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
-		                   ctx->stream, A);
-		return;
-	}
 	const uintptr_t al8 = (uintptr_t)A.cigar_off | (uintptr_t)A.md_off;
 	A.wide_ok = ((al8 & 7u) == 0 && ((uintptr_t)A.flag & 3u) == 0 && ((uintptr_t)A.rflags & 1u) == 0 &&
 	             ((uintptr_t)A.pool & 1u) == 0) ? 1 : 0;
@@ -649,7 +355,6 @@ static void fill_args(FilterArgs &A, const msx_batch *b) {
 	A.md = b->md;
 	A.nm = b->nm;
 	A.as = b->as;
-	A.md_aligned = (((uintptr_t)b->md) & 3u) == 0 ? 1 : 0;
 }
 
 static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p, const msx_filter_out *out,

@@ -21,8 +21,7 @@ struct FilterArgs {
 	int32_t min_length, ppt, max_clip;
 	int32_t choice;         // bit0 -l, bit1 -p/--ppt, bit2 -z (msam_filter.c:79-81)
 	int32_t rescore, invert, keep_unmapped;
-	int32_t md_aligned;     // md base is 4-byte aligned -> dword staging allowed (k_aln_stats_filter)
-	int32_t wide_ok;        // cigar_off/md_off 8-byte, flag 4-byte, rflags and pool 2-byte aligned (k_aln_stats_flat)
+	int32_t wide_ok;        // cigar_off/md_off 8-byte, flag 4-byte, rflags and pool 2-byte aligned
 	uint8_t *pool;          // [n] out: 1 = record enters the pool
 	int32_t pool_as_code;   // best-hit follows: a pooled record's byte is MSX_PC_IN | MSX_PC_HAS_AS | its mate bits,
 	                        // everything k_besthit_select needs to know about it besides its score

@@ -1,4 +1,4 @@
-/* Host harness for the flat MD walk of k_aln_stats_filter (msx_md.h, "Flat walk"):
+/* Host harness for the flat MD walk of k_aln_stats_flat (msx_md.h, "Flat walk"):
  * one simulated wave of 64 lanes takes up to 128 consecutive MD strings stored back
  * to back, 16 bytes per lane and 1 KiB per pass, resolves the carries between lanes
  * with two "ballots" and one 64-bit addition, keeps per-word counts + prefix sums,
@@ -6,7 +6,7 @@
  * steps of the kernel, in the same order, with plain loops standing in for lanes.
  * The result must equal the byte-at-a-time rule (md_byte, mBamVector.c:112-118) for
  * arbitrary bytes, empty strings, strings longer than a pass and every alignment of
- * the buffer.  Built and run by tests/test_md_swar_cpu.py. */
+ * the buffer.  Built and run by tests/test_md_flat_cpu.py. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -35,14 +35,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version():
     from msamtools_amd import _lib
-    assert _lib.load().msx_abi_version() == 1
+    assert _lib.load().msx_abi_version() == 2
 
 
 def test_library_carries_gfx950_code_object():
     from msamtools_amd import _lib
     data = open(_lib.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in data
-    for kern in (b"k_aln_stats_filter", b"k_besthit_select", b"k_insert_count", b"k_share_reduce", b"k_rs_scatter"):
+    for kern in (b"k_aln_stats_flat", b"k_besthit_select", b"k_insert_count", b"k_share_reduce", b"k_rs_scatter"):
         assert kern in data
 
 

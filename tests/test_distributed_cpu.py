@@ -2,9 +2,10 @@
 
 Each rank owns a pool-aligned shard of one synthetic stream, runs filter +
 insert counting on its shard alone, and the ranks exchange exactly what
-bench.py exchanges over RCCL: all-reduce(sum) of the per-reference counts and
-counters, then per proportional-sharing iteration all-reduce(sum) of the
-`share` vector (sum over the rank's multi-mappers of 1/S).  The result must
+msx_profile_finalize_dist_enqueue (msx_dist.hip) exchanges over RCCL:
+all-reduce(sum) of the per-reference counts and counters, then per
+proportional-sharing iteration all-reduce(sum) of the `share` vector (sum over
+the rank's multi-mappers of 1/S), then the purged count.  The result must
 equal the single-process oracle on the whole stream (counts exact, abundances
 <= 1e-6 relative).  The per-shard compute here is numpy/oracle (no GPU in this
 container); the collective pattern and the sharding rule are the ones under test.
@@ -117,3 +118,42 @@ def test_shards_are_prefix_stable():
         assert part.n_records == e - s
         assert (part.flag == whole.flag[s:e]).all() and (part.tid == whole.tid[s:e]).all()
         assert (part.group_off.astype(np.int64) + s == whole.group_off[r * G:(r + 1) * G + 1]).all()
+
+
+def _rendezvous_worker(rank, world, port, q):
+    import ctypes as C
+    from msamtools_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_uint8 * 128)()
+    if rank == 0:
+        for i in range(128):
+            buf[i] = (7 * i + 3) & 0xFF
+    rc = lib.msx_dist_rendezvous(b"127.0.0.1", port, rank, world, buf, 128, 30)
+    q.put((rank, rc, bytes(buf)))
+
+
+def test_c_rendezvous_hands_the_communicator_id_to_every_rank():
+    """msx_dist_rendezvous (the TCP hand-over msx_dist_init_env uses for the 128-byte RCCL id), three
+    processes, through the C ABI -- no GPU involved."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    world = 3
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, port, q)) for r in (2, 1, 0)]   # rank 0 last
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+    want = bytes((7 * i + 3) & 0xFF for i in range(128))
+    assert [(r, rc) for r, rc, _ in got] == [(0, 0), (1, 0), (2, 0)]
+    assert all(b == want for _, _, b in got)
+
+
+def test_dist_entry_points_without_a_context():
+    """Rank / world of "no communicator" are 0 / 1; initialisation needs a context (hence a gfx950 device)."""
+    from msamtools_amd import _lib
+    lib = _lib.load()
+    assert lib.msx_dist_world(None) == 1 and lib.msx_dist_rank(None) == 0
+    assert lib.msx_dist_init_env(None) != 0
