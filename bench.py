@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
 # filled from profiles/ when measured for the default workload; None = not measured.
 TRAFFIC = {}
-_PMC = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_c3.json")
+_PMC = os.path.join(ROOT, "profiles", "round2", "pmc_traffic_c3.json")
 
 
 def load_traffic(workload, ng, nrefs):
@@ -99,19 +99,20 @@ def exchange_comm_id(m, rank, world):
         return None
 
 
-def algorithmic_bytes(name, w):
-    """Bytes one launch of `name` must move once (SURVEY.md 8d formulas).
-    w: dict with n (records), ng (pools), n_cig, n_md, n_emit, kept_groups, L (multi-mapper lists),
-    E (list entries), nf (features), uniq."""
-    n, ng, E, L, nf = w["n"], w["ng"], w["E"], w["L"], w["nf"]
+def algorithmic_bytes_per_step(name, w):
+    """Bytes the launches of `name` in ONE step must move once, or None
+    when the kernel is not priced.  w: n (records), ng (pools), n_cig, n_md, n_emit, uniq, L0/E0 (multi-mapper
+    lists / entries as accumulated), L/E (after identical sets were merged), nf (features), iters (sharing
+    iterations that ran), lib (bytes the library attached to its own launches: scans and radix passes, each
+    priced by its own length)."""
+    n, ng, E, L, E0, L0, nf, it = w["n"], w["ng"], w["E"], w["L"], w["E0"], w["L0"], w["nf"], w["iters"]
     if name == "k_aln_stats_filter":
         # reads flag 2, rflags 1, cigar_off 4, cigar, md_off 4, md ; writes the pool byte
         return 2 * n + n + 4 * (n + 1) + 4 * w["n_cig"] + 4 * (n + 1) + w["n_md"] + n
     if name == "k_besthit_select":
-        # reads group_off, flag, rflags, pool byte, AS ; writes keep, per-pool count ; fused insert accounting:
-        # reads tid of the kept records ; writes the unique-insert key 4, the list length 8 and the
-        # distinct features of multi-mapped pools (E0 entries as accumulated)
-        return 4 * (ng + 1) + 2 * n + n + n + 4 * n + n + 4 * ng + 4 * w["n_emit"] + 12 * ng + 4 * w["E0"]
+        # reads group_off, pool byte, AS ; writes keep, per-pool count ; fused insert accounting: reads tid of
+        # the kept records ; writes the per-pool word 4 and the distinct features of multi-mapped pools
+        return 4 * (ng + 1) + n + 4 * n + n + 4 * ng + 4 * w["n_emit"] + 4 * ng + 4 * E0
     if name == "k_emit_order":
         return 4 * (ng + 1) + n + 4 * (ng + 1) + 4 * w["n_emit"]
     if name == "k_insert_count":
@@ -119,23 +120,23 @@ def algorithmic_bytes(name, w):
         # writes the kept ones, the count kernel reads those and updates ui once per feature
         return 8 * ng + 8 * w["uniq"] + 8 * nf
     if name == "k_multi_compact":
-        return 16 * ng + 4 * L + 8 * E + 4 * L
-    if name == "k_list_recip":
-        # only the lists that do not travel with their entries (> 3 features) are processed; their number is
-        # not known on the host, so this kernel is not priced (0 = no algorithmic figure)
-        return 0
+        # on the lists as accumulated: per-pool word 4, scan value 8, group_off 4 ; scratch features in, CSR out
+        return 16 * ng + 4 * L0 + 8 * E0
+    if name == "k_list_order":
+        # k_list_key (m_off, m_fid in; key 4 + signature 8 out), k_dup_mark (signatures in; head, length out),
+        # k_uniq_gather (head, index, offset, signature in; CSR, entry key 4 + value 8, head position out),
+        # k_entry_weight (offsets, positions, first value in; entry keys read and written)
+        return 36 * L0 + 4 * E0 + 40 * L + 24 * E
     if name == "k_share_reduce":
-        # entry key 4E + value 8E (the list's signature), a[] read once 8 per feature, share written 8 per feature
-        return 12 * E + 16 * nf
+        # per launch: entry key 4 + value 8, a[] read once, share[] written once
+        return it * (12 * E + 16 * nf)
     if name == "k_prop_apply":
-        return 40 * nf
-    if name == "k_rs_hist":
-        return 4 * E + 1024 * ((E + 2047) // 2048)
-    if name == "k_rs_scatter":
-        return 20 * E + 1024 * ((E + 4095) // 4096)
-    if name == "scan":
-        return 12 * ng
-    return 0
+        # per iteration U, share, a in; a, share out (k_prop_apply) ; once: k_prop_begin (ui in; U, a, share,
+        # share2 out) and k_prop_purged (offsets, positions, features in, a[] gathered)
+        return it * 40 * nf + 36 * nf + 8 * L + 12 * E
+    if name in ("scan", "k_rs_hist", "k_rs_scatter"):
+        return w["lib"].get(name) or None
+    return None        # k_general_share (a few thousand lists), k_partial_reduce: not priced
 
 
 def main():
@@ -255,38 +256,49 @@ def main():
             prof.finalize_enqueue()
             run.finish()
         names = ["k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
-                 "k_list_order", "k_rs_hist", "k_rs_scatter", "k_list_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply",
-                 "scan"]
-        tms = {}
+                 "k_list_order", "k_rs_hist", "k_rs_scatter", "k_general_share", "k_share_reduce", "k_partial_reduce",
+                 "k_prop_apply", "scan"]
+        tms, lib_bytes = {}, {}
         for k in names:
             ms, cnt = ctx.timing_get(k)
             tms[k] = (ms / reps, cnt / reps)          # ms per step, launches per step
+            lib_bytes[k] = ctx.timing_bytes(k) / reps
         ctx.timing(False)
         ab1, st1 = prof.fetch()
         sz = db.sizes
         n_lists0, n_entries0 = prof.multi_size()       # multi-mapped inserts as accumulated
         n_lists, n_entries = prof.shared_size()        # after identical feature sets were merged
         w = dict(n=n, ng=ng, n_cig=int(sz.n_cigar), n_md=int(sz.n_md), n_emit=state["n_emit"],
-                 kept_groups=int(st1.insert_count), uniq=int(st1.uniq_mapper_count), L=n_lists, E=n_entries,
-                 E0=n_entries0, nf=nrefs)
+                 uniq=int(st1.uniq_mapper_count), L=n_lists, E=n_entries, L0=n_lists0, E0=n_entries0, nf=nrefs,
+                 iters=int(st1.iterations), lib=lib_bytes)
 
-        def gbps(k):
+        def price(k):
+            """(bytes per step, GB/s over the kernel's whole time in a step, average launch ms)"""
             ms_step, launches = tms[k]
+            b = algorithmic_bytes_per_step(k, w)
             if ms_step <= 0 or launches <= 0:
-                return 0.0, 0.0
-            avg_ms = ms_step / launches
-            return algorithmic_bytes(k, w) / (avg_ms * 1e-3) / 1e9, avg_ms
+                return b, None, 0.0
+            return b, (b / (ms_step * 1e-3) / 1e9 if b else None), ms_step / launches
 
         load_traffic(args.workload, ng, nrefs)
-        dom = max((k for k in names if k != "scan"), key=lambda k: tms[k][0])
-        achieved, avg_ms = gbps(dom)
+        # the dominant kernel: the largest share of the step among the kernels that are priced
+        dom = max((k for k in names if algorithmic_bytes_per_step(k, w) and k not in ("scan", "k_rs_hist", "k_rs_scatter")),
+                  key=lambda k: tms[k][0])
+        dom_bytes, achieved, avg_ms = price(dom)
+        per_kernel = {}
+        for k, v in tms.items():
+            b, g, _ = price(k)
+            per_kernel[k] = {"ms_per_step": round(v[0], 4), "launches": v[1],
+                             "algorithmic_bytes_per_step": int(b) if b else None,
+                             "algorithmic_GBps": round(g, 1) if g else None}
+            # a figure above the roof means the formula is wrong, not that the kernel is fast
+            assert g is None or g <= HBM_PEAK_GBS, (k, g)
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
-            "algorithmic_bytes_per_launch": int(algorithmic_bytes(dom, w)),
+            "algorithmic_bytes_per_launch": int(dom_bytes / tms[dom][1]),
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": tms[dom][1],
-            "per_kernel": {k: {"ms_per_step": round(v[0], 4), "launches": v[1],
-                               "algorithmic_GBps": round(gbps(k)[0], 1)} for k, v in tms.items()},
+            "per_kernel": per_kernel,
             "multi_mapper_lists": n_lists0, "multi_mapper_entries": n_entries0,
             "merged_lists": n_lists, "merged_entries": n_entries,
         }

@@ -359,13 +359,17 @@ int  msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes); /
 /* Per-kernel device time measured with HIP events on the ctx stream while
  * enabled (one event pair around every launch).  names: "k_aln_stats_filter",
  * "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
- * "k_list_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order",
+ * "k_general_share", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order",
  * "k_rs_hist", "k_rs_scatter",
  * "k_coverage_pileup", "scan", "synth".  Returns total ms and the number of
  * timed launches since the last reset. */
 int  msx_timing_enable(msx_ctx *ctx, int on);
 int  msx_timing_reset(msx_ctx *ctx);
 int  msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, int64_t *launches);
+/* Algorithmic bytes of the timed launches of `name`, for the kernels whose element counts exist on the
+ * device only ("scan", "k_rs_hist", "k_rs_scatter": every launch priced by its own length); 0 for the
+ * others, which the caller prices from the batch sizes (bench.py). */
+int  msx_timing_get_bytes(msx_ctx *ctx, const char *name, int64_t *bytes_total);
 
 #ifdef __cplusplus
 }

@@ -126,6 +126,7 @@ SYMBOLS = {
     "msx_timing_enable": (C.c_int, [_P, C.c_int]),
     "msx_timing_reset": (C.c_int, [_P]),
     "msx_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "msx_timing_get_bytes": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -152,6 +152,11 @@ class Context:
         self.check(self.lib.msx_timing_get(self.h, name.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def timing_bytes(self, name):
+        b = C.c_int64(0)
+        self.check(self.lib.msx_timing_get_bytes(self.h, name.encode(), C.byref(b)))
+        return b.value
+
 
 _FIELDS = (("flag", np.uint16), ("rflags", np.uint8), ("tid", np.int32), ("pos", np.int32),
            ("cigar_off", np.uint32), ("cigar", np.uint32), ("md_off", np.uint32), ("md", np.uint8),

@@ -174,7 +174,7 @@ extern "C" int msx_ctx_sync(msx_ctx *ctx) {
 
 static const char *k_names[MSX_K_COUNT] = {
     "k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
-    "k_list_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order", "k_rs_hist", "k_rs_scatter",
+    "k_general_share", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order", "k_rs_hist", "k_rs_scatter",
     "k_coverage_pileup", "scan", "synth"};
 
 static hipEvent_t get_event(msx_ctx *ctx) {
@@ -197,6 +197,14 @@ void msx_time_begin(msx_ctx *ctx, int kid) {
 	(void)hipEventRecord(t.a, ctx->stream);
 	ctx->timed_open.push_back((int)ctx->timed.size());
 	ctx->timed.push_back(t);
+}
+
+void msx_time_bytes(msx_ctx *ctx, int64_t fixed, int64_t per_item, int64_t items_cap, const unsigned long long *n_ptr,
+                    int64_t div, int64_t mul) {
+	if (!ctx->timing || ctx->timed_open.empty()) return;
+	msx_timed &t = ctx->timed[ctx->timed_open.back()];
+	t.bytes_fixed = fixed; t.per_item = per_item; t.cap = items_cap;
+	t.n_ptr = n_ptr; t.div = div > 0 ? div : 1; t.mul = mul > 0 ? mul : 1;
 }
 
 void msx_time_end(msx_ctx *ctx) {
@@ -243,6 +251,31 @@ extern "C" int msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, 
 	}
 	if (ms_total) *ms_total = tot;
 	if (launches) *launches = cnt;
+	return MSX_OK;
+}
+
+// Sum of the algorithmic bytes the library attached to the timed launches of `name` (scans and radix
+// passes, whose lengths live on the device); 0 for kernels it does not price.
+extern "C" int msx_timing_get_bytes(msx_ctx *ctx, const char *name, int64_t *bytes_total) {
+	if (!ctx || !name || !bytes_total) return MSX_ERR_ARG;
+	int kid = -1;
+	for (int i = 0; i < MSX_K_COUNT; i++)
+		if (strcmp(name, k_names[i]) == 0) kid = i;
+	if (kid < 0) return msx_fail(ctx, MSX_ERR_ARG, "unknown kernel name '%s'", name);
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	int64_t tot = 0;
+	for (auto &t : ctx->timed) {
+		if (t.kid != kid) continue;
+		int64_t items = t.cap;
+		if (t.n_ptr) {
+			unsigned long long nv = 0;
+			MSX_HIP(ctx, hipMemcpy(&nv, t.n_ptr, 8, hipMemcpyDeviceToHost));
+			const int64_t it = t.mul * (((int64_t)nv + t.div - 1) / t.div);
+			if (it < items) items = it;
+		}
+		tot += t.bytes_fixed + t.per_item * items;
+	}
+	*bytes_total = tot;
 	return MSX_OK;
 }
 

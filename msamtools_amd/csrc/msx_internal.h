@@ -36,11 +36,11 @@ enum msx_kid {
 	MSX_K_EMIT,            // k_emit_groups / k_emit_count + k_emit_fill
 	MSX_K_INSERT_COUNT,    // k_insert_count; the partition count of the unique-insert keys (msx_count_keys)
 	MSX_K_MULTI_COMPACT,   // k_multi_compact + k_multi_advance
-	MSX_K_LIST_RECIP,      // k_list_recip
+	MSX_K_GENERAL_SHARE,   // k_general_share
 	MSX_K_SHARE_REDUCE,    // k_share_reduce
 	MSX_K_PARTIAL_REDUCE,  // k_partial_reduce
-	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply + k_prop_finish / k_prop_purged
-	MSX_K_LIST_ORDER,      // k_list_key, k_dup_mark, k_uniq_gather, k_entry_weight
+	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply / k_prop_purged
+	MSX_K_LIST_ORDER,      // k_list_key, k_dup_mark, k_uniq_gather, k_entry_weight, k_part_index
 	MSX_K_RS_HIST,         // k_rs_hist
 	MSX_K_RS_SCATTER,      // k_rs_scatter
 	MSX_K_COVERAGE,        // k_coverage_pileup
@@ -64,6 +64,10 @@ struct msx_buf {
 struct msx_timed {
 	int kid;
 	hipEvent_t a, b;
+	// algorithmic bytes of the bracket: fixed + per_item * items, items = cap or, with a device-side
+	// count, min(cap, mul * ceil(*n_ptr / div)) -- resolved when the figure is asked for
+	int64_t bytes_fixed = 0, per_item = 0, cap = 0, div = 1, mul = 1;
+	const unsigned long long *n_ptr = nullptr;
 };
 
 // A side lane: a second HIP stream with its own scan workspace, so that a chain of kernels that
@@ -125,6 +129,9 @@ extern thread_local std::string msx_tls_err;
 // RAII-less timing bracket: records events around a launch when enabled
 void msx_time_begin(msx_ctx *ctx, int kid);
 void msx_time_end(msx_ctx *ctx);
+// algorithmic bytes of the innermost open bracket (no-op unless timing is on)
+void msx_time_bytes(msx_ctx *ctx, int64_t fixed, int64_t per_item, int64_t items_cap,
+                    const unsigned long long *n_ptr = nullptr, int64_t div = 1, int64_t mul = 1);
 #define MSX_TIMED(ctx, kid, stmt)    \
 	do {                             \
 		msx_time_begin((ctx), (kid)); \
@@ -163,10 +170,11 @@ struct msx_profile {
 	uint32_t *counters = nullptr;     // [4] {inserts, uniq, multi, purged}
 	double *U = nullptr, *a = nullptr;   // [n_features] U(i), a(i,k)
 	double *share = nullptr;          // [n_features] sum over multi-mappers of 1/S (all-reduced across ranks)
+	double *share2 = nullptr;         // [n_features] the general lists' part (single-GPU iteration)
 	double *delta = nullptr;          // [20] device, delta[k]
-	int32_t *iter_state = nullptr;    // [2]: {done flag, iterations}
+	int32_t *iter_state = nullptr;    // [4]: {done flag, iterations, arrival ticket of k_prop_apply, -}
 	unsigned long long *csr_tot = nullptr;   // device {n_lists, n_entries}
-	double *partial = nullptr;        // device [PROP_MAX_BLOCKS]
+	double *partial = nullptr;        // device [workgroups of k_prop_apply]: their sums of diff^2
 	uint32_t *purged_local = nullptr; // device [1]
 	// multi-mapper store, list-major CSR (global->multi_mappers)
 	msx_buf m_off;                    // u32 [n_lists+1]
@@ -175,13 +183,13 @@ struct msx_profile {
 	// feature-major view built once per finalize by a stable radix sort
 	msx_buf t_key[2];                 // ping-pong keys of the radix sorts (list keys, then entry keys)
 	msx_buf t_val64[2];               // ping-pong 64-bit values travelling with them: set signatures (msx_prop.hip)
-	msx_buf gen;                      // u8 [n_lists]: 1 = list takes the general (recip[]) path
+	msx_buf gl_idx;                   // u32 [general lists]: numbers of the lists k_general_share handles
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
-	msx_buf recip;                    // f64 [n_lists] 1/S per multi-mapper
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
+	msx_buf pstart;                   // u32 [workgroups of k_prop_apply + 1]: first partial slot of each
 	msx_buf m_off_alt, m_fid_alt, len2;   // derived store: renumbered, duplicate lists merged
 	msx_buf head, uidx, eoff, hpos;       // dedupe scratch; hpos[u+1]-hpos[u] = weight of merged list u
-	unsigned long long *d_tot = nullptr;  // device {lists, entries} of the derived store
+	unsigned long long *d_tot = nullptr;  // device {lists, entries, general lists} of the derived store
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
 	int key_bits = 0;                 // bits of the feature id in an entry key (the list weight sits above)
 	bool transposed_valid = false;
@@ -191,8 +199,10 @@ struct msx_profile {
 
 // proportional-sharing engine (msx_prop.hip)
 int msx_prop_build(msx_ctx *ctx, msx_profile *p);            // feature-major view of the multi-mapper store
-int msx_prop_iteration(msx_ctx *ctx, msx_profile *p);        // share[f] = sum_j 1/S_j over this rank's lists
-int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k);
+int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete);   // share[f] = sum_j w_j/S_j over this rank's lists
+int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused);
+int64_t msx_share_waves(msx_ctx *ctx);
+int64_t msx_apply_blocks(int32_t nf);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
 // msx_dist.hip: in-place all-reduce(sum) on the ctx stream; no-ops without a communicator

@@ -3,11 +3,13 @@
 // floating-point atomics.
 //
 // The reference loops over multi-mappers j, computes S_j = sum_{e in j} a[e]
-// and adds a[e]/S_j to increment[e].  Here one iteration is two sparse
-// matrix-vector products over the 0/1 incidence matrix T (features x lists):
-//   recip = 1 / (T^t a)            one lane per list        (k_list_recip)
-//   share = T recip                segmented sum by feature  (k_share_reduce)
-//   increment[f] = a[f] * share[f] folded into the update    (k_prop_apply)
+// and adds a[e]/S_j to increment[e].  Here one iteration is
+//   share[f] = sum over the lists containing f of w/S    segmented sum by feature (k_share_reduce;
+//                                                         lists of <= 4 features carry their set with
+//                                                         every entry, so S is summed there from a[])
+//   share2[f] += w/S for the few longer lists             one lane per such list (k_general_share)
+//   a[f] = U[f] + a[f] * (share[f] + share2[f] + the partial sums of segments cut by a chunk boundary),
+//   clamp, DELTA^2 and the convergence flag               (k_prop_apply, last workgroup finishes)
 // T's feature-major order is produced once per finalize by a stable LSD radix
 // sort of (feature, list) pairs, so entries of one feature are contiguous and
 // in ascending list order; hot features spread over many waves instead of
@@ -15,6 +17,8 @@
 // rounding (<= a few ulp, inside the 1e-6 relative bound of BASELINE.json).
 // Across ranks `share` is the vector to all-reduce (C1 in SURVEY.md section 2).
 #include "msx_internal.h"
+
+#include <cstdlib>
 
 #define RS_EPT 16                      // elements per thread in a radix pass
 #define RS_TILE (RS_EPT * MSX_BLOCK)    // elements per workgroup tile
@@ -482,21 +486,23 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 		const uint32_t U = uidx[m], E2 = eoff[m];
 		d_tot[0] = U;
 		d_tot[1] = E2;
+		d_tot[2] = 0;                  // general lists, counted by k_entry_weight
 		d_off[U] = E2;                 // CSR sentinel
 		hpos[U] = (uint32_t)n_lists;   // so that weight(u) = hpos[u+1] - hpos[u]
 	}
 }
 
 // The weight of a merged list (how many inserts had exactly this set) rides in the key bits
-// above the feature id of its entries; a list whose weight does not fit there, like a list
-// whose set did not fit a signature, takes the general path: its entries name the list
-// (SIG_HASHED | u) and k_list_recip computes recip[u] for it.  gen[u] = 1 for those.
-__global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(const unsigned long long *__restrict__ d_tot,
+// above the feature id of its entries.  A list whose weight does not fit there, or whose set did
+// not fit a signature (more than four features, feature ids of 21 bits and more), is a *general*
+// list: its entries stay in the feature-major stream with weight 0 and no other features -- they
+// contribute nothing there -- and its number goes to gl_idx[]; k_general_share adds its w/S.
+__global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(unsigned long long *__restrict__ d_tot,
                                                             const uint32_t *__restrict__ d_off,
                                                             const uint32_t *__restrict__ hpos, int bits,
                                                             uint32_t *__restrict__ e_key,
                                                             unsigned long long *__restrict__ e_val,
-                                                            uint8_t *__restrict__ gen) {
+                                                            uint32_t *__restrict__ gl_idx) {
 	const int64_t n_lists = (int64_t)d_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t u = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; u < n_lists; u += stride) {
@@ -507,11 +513,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(const unsigned long 
 		const bool fits = bits < 32 && (((unsigned long long)w + 1ull) >> (32 - bits)) == 0ull;
 		if (!hashed && fits) {
 			for (uint32_t o = s; o < e; ++o) e_key[o] |= w << bits;
-			gen[u] = 0;
 		} else {
-			if (!hashed)
-				for (uint32_t o = s; o < e; ++o) e_val[o] = SIG_HASHED | (unsigned long long)u;
-			gen[u] = 1;
+			for (uint32_t o = s; o < e; ++o) e_val[o] = pack_others(SIG_PAD, SIG_PAD, SIG_PAD);
+			gl_idx[atomicAdd(&d_tot[2], 1ull)] = (uint32_t)u;
 		}
 	}
 }
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(const unsigned long 
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint32_t *__restrict__ ui,
                                                           const double *__restrict__ d, double *__restrict__ U,
                                                           double *__restrict__ a, double *__restrict__ share,
+                                                          double *__restrict__ share2,
                                                           double *__restrict__ delta, int32_t *iter_state) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
@@ -530,32 +535,34 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint
 		U[i] = u;
 		a[i] = u;                             // :326
 		share[i] = 0.0;
+		share2[i] = 0.0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x < 20) delta[threadIdx.x] = 0.0;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; iter_state[2] = 0; }
 }
 
-// recip[j] = w_j/S_j, S_j = sum of a over the features of (merged) multi-mapper j, w_j the number
-// of inserts it stands for (0 when S_j == 0: :358)
-__global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long long *__restrict__ csr_tot,
-                                                          const uint32_t *__restrict__ m_off,
-                                                          const int32_t *__restrict__ m_fid,
-                                                          const uint32_t *__restrict__ hpos,
-                                                          const uint8_t *__restrict__ gen,
-                                                          const double *__restrict__ a, double *__restrict__ recip,
-                                                          const int32_t *__restrict__ iter_state) {
+// dst[f] += w_j/S_j for every feature f of every general list j (S_j = sum of a over its features,
+// w_j the number of inserts it stands for; nothing when S_j == 0: msam_profile.c:358).  These are the
+// lists of five and more features (0.6 % of the lists on the IGC-scale workload): one lane per list,
+// floating-point atomics -- a feature receives few of these adds, in no fixed order (last-bit noise).
+__global__ __launch_bounds__(MSX_BLOCK) void k_general_share(const unsigned long long *__restrict__ d_tot,
+                                                             const uint32_t *__restrict__ m_off,
+                                                             const int32_t *__restrict__ m_fid,
+                                                             const uint32_t *__restrict__ hpos,
+                                                             const uint32_t *__restrict__ gl_idx,
+                                                             const double *__restrict__ a, double *__restrict__ dst,
+                                                             const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
-	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t n = (int64_t)d_tot[2];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
-		if (!gen[j]) continue;          // the entries of this list carry its set: nothing to precompute
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n; i += stride) {
+		const uint32_t j = gl_idx[i];
 		const uint32_t s = m_off[j], e = m_off[j + 1];
 		const uint32_t w = hpos[j + 1] - hpos[j];
 		double sum = 0;
+		int32_t f[8];
 		if (e - s <= 8u) {
 			// feature ids, then abundances, as independent loads; summed in list order
-			// (the lists that reach this kernel have more than three features)
-			int32_t f[8];
 			double x[8];
 #pragma unroll
 			for (int q = 0; q < 8; q++) f[q] = (s + (uint32_t)q < e) ? m_fid[s + q] : -1;
@@ -567,22 +574,36 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_recip(const unsigned long lo
 		} else {
 			for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
 		}
-		recip[j] = sum > 0 ? (double)w / sum : 0.0;
+		if (!(sum > 0)) continue;
+		const double r = (double)w / sum;
+		if (e - s <= 8u) {
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				if (f[q] >= 0) atomicAdd(&dst[f[q]], r);
+		} else {
+			for (uint32_t k = s; k < e; ++k) atomicAdd(&dst[m_fid[k]], r);
+		}
 	}
 }
 
 // share[f] = sum of w/S over the lists containing f -- a segmented sum over the
-// feature-sorted entries.  Level 1 (k_share_reduce): one wave per SR_CHUNK
-// consecutive entries in steps of SR_STEP; a lane sums SR_EPL consecutive entries
-// itself, one segmented scan over the lanes joins the open ends, the open segment
-// is carried in registers from step to step.  A feature whose entries all lie
-// inside the chunk is written with a plain store.  The (at most two) segments cut
-// by the chunk boundary are not added with atomics -- a hot feature spans hundreds
-// of chunks and would serialise on one address -- but emitted as (feature,
-// partial) pairs, two slots per wave, in entry order.  Level 2 (k_partial_reduce)
-// runs a segmented sum over those few pairs, 64 per row, and adds each run once.
-#define PR_CHUNK 256                   // partials reduced by one wave (level 2)
+// feature-sorted entries.  k_share_reduce: the entries are split evenly over the W waves the
+// launch holds at once (one contiguous chunk each, a multiple of SR_STEP, sized on the device from
+// the true entry count: no second, partly filled round of waves); a wave walks its chunk in steps of
+// SR_STEP entries: a lane sums SR_EPL consecutive entries itself, one segmented scan over the lanes
+// joins the open ends, the open segment is carried in registers from step to step.  A feature
+// whose entries all lie inside the chunk is written with a plain store.  The (at most two)
+// segments cut by the chunk boundary are not added with atomics -- a hot feature spans hundreds
+// of chunks and would serialise on one address -- but left as partial sums, two slots per wave in
+// entry order, whose keys (part_key, fixed for a build: k_part_index) ascend.  Single GPU:
+// k_prop_apply adds the slots that fall into its workgroup's feature range, in slot order.
+// With a collective between the halves of an iteration (msx_profile_prop_local): k_partial_reduce
+// runs a segmented sum over the slots, 64 per row, and adds each run to share[] once.
+#define PR_CHUNK 256                   // partials reduced by one wave (k_partial_reduce)
 #define SR_SENT 0xffffffffu
+#define SR_EPL 8                       // consecutive entries summed by one lane
+#define SR_STEP (64 * SR_EPL)          // entries per wave step
+#define SR_WAVES_PER_SIMD 4            // what the kernel's registers allow (126 VGPRs): the launch is ONE round of waves
 
 struct SegRow {
 	double v;         // after seg_scan: inclusive segmented sum
@@ -611,18 +632,17 @@ __device__ __forceinline__ SegRow seg_row(uint32_t key, double v, bool valid, ui
 	return r;
 }
 
-#define SR_EPL 8                       // consecutive entries summed by one lane
-#define SR_STEP (64 * SR_EPL)          // entries per wave step
+// entries per wave: the E entries in W equal chunks, rounded up to whole steps
+__device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
+	const int64_t per = (E + W - 1) / W;
+	return (per + SR_STEP - 1) / SR_STEP * SR_STEP;
+}
 
-// (132 VGPRs = 3 waves per SIMD.  More is not better here: pinned at 4 waves -- 124 VGPRs, no spill -- a
-// launch takes 61 us against 54; with spills, at an earlier stage, 5 -> 118 us, 6 -> 157 us)
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
-                                                            const double *__restrict__ recip,
-                                                            const double *__restrict__ a, int bits,
+                                                            const double *__restrict__ a, int bits, int64_t W,
                                                             double *__restrict__ share,
-                                                            uint32_t *__restrict__ part_key,
                                                             double *__restrict__ part_val,
                                                             const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
@@ -634,17 +654,19 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	// against 58, a contiguous eighth each 70 against 65 -- lines one XCD has fetched are then no longer
 	// served to the others out of the Infinity Cache while they are there)
 	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
-	const int64_t c0 = wave * SR_CHUNK;
-	if (c0 >= E) {   // idle wave: neutral slots (sorted after every real feature id)
-		if (lane < 2) { part_key[2 * wave + lane] = SR_SENT; part_val[2 * wave + lane] = 0.0; }
+	if (wave >= W) return;
+	const int64_t per = sr_chunk(E, W);
+	const int64_t c0 = wave * per;
+	if (c0 >= E) {   // idle wave: neutral slots
+		if (lane < 2) part_val[2 * wave + lane] = 0.0;
 		return;
 	}
-	const int64_t c1 = (c0 + SR_CHUNK < E) ? c0 + SR_CHUNK : E;
+	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
 	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	// the open segment carried from step to step (its sum so far, whether it began inside this chunk)
 	double carry = 0.0;
 	bool carry_started = false, carry_open = false;
-	uint32_t carry_key = 0, first_key = 0, prev_last = 0;
+	uint32_t prev_last = 0;
 	double slot_a = 0.0;          // partial of the chunk's first segment when it began in an earlier chunk
 	const unsigned long long below = (1ull << lane) - 1ull;
 	// entries of one step: SR_EPL consecutive ones per lane, and the key following the step
@@ -682,29 +704,28 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		// 8 MB that the caches hold well, unlike one 8-byte recip[] per list out of tens of MB -- as
 		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders:
 		// their S can differ in the last bit, 1e-16 relative; ordering them costs a third of this
-		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  Other lists: recip[u].
+		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  An entry of a
+		// general list has weight 0 and no others: it adds nothing here (k_general_share).
 		double x[SR_EPL];
 		{
 			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
-				const bool general = (lv[i] & SIG_HASHED) != 0;
 				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
 				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
-				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
-				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
-				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
+				af[i] = live ? a[k[i] & fmask] : 0.0;
+				a1[i] = (live && o1 != SIG_PAD) ? a[o1] : 0.0;
+				a2[i] = (live && o2 != SIG_PAD) ? a[o2] : 0.0;
+				a3[i] = (live && o3 != SIG_PAD) ? a[o3] : 0.0;
 			}
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
-				const bool general = (lv[i] & SIG_HASHED) != 0;
 				const uint32_t f = k[i] & fmask;
 				const double sum = ((a1[i] + a2[i]) + a3[i]) + af[i];     // absent ones are +0.0
 				const double w = (double)(bits < 32 ? (k[i] >> bits) : 0u);
-				x[i] = !live ? 0.0 : general ? af[i] : (sum > 0 ? w / sum : 0.0);
+				x[i] = (live && sum > 0) ? w / sum : 0.0;
 				if (live) k[i] = f;                          // from here on: the feature id
 			}
 		}
@@ -714,7 +735,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		if (lane == 0) pk = (base == c0) ? (c0 > 0 ? before : ~k[0]) : prev_last;
 		uint32_t nk = __shfl_down(k[0], 1, 64);
 		if (lane == 63) nk = after;
-		if (base == c0) first_key = __shfl(k[0], 0, 64);
 
 		// ---- the lane's run: head segment, complete interior segments, tail segment ----
 		const bool B = (k[0] != pk);                         // a segment starts at the lane's first entry
@@ -774,16 +794,48 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		const int ce = __shfl((int)Eend, 63, 64);
 		const int cs = __shfl((int)started_tail, 63, 64);
 		prev_last = __shfl(k[SR_EPL - 1], 63, 64);
-		carry_key = __shfl(cur, 63, 64);
 		carry_open = !ce;
 		carry = ce ? 0.0 : cv;
 		carry_started = ce ? false : (cs != 0);
 	}
+	// slot 2w: the part of the chunk's first segment when it began in an earlier chunk (key = the chunk's
+	// first feature); slot 2w + 1: the segment left open at the chunk's end (key = its last feature)
 	if (lane == 0) {
-		part_key[2 * wave] = first_key;
 		part_val[2 * wave] = slot_a;
-		part_key[2 * wave + 1] = carry_open ? carry_key : SR_SENT;
 		part_val[2 * wave + 1] = carry_open ? carry : 0.0;
+	}
+}
+
+// The keys of the partial slots -- they depend on the sorted entries and on W only, so they are set once
+// per build -- and, for k_prop_apply, the first slot whose key falls into each workgroup's feature range
+// (pstart[b] = lower bound of b * PA_FPB among the ascending keys; idle waves hold SR_SENT).
+#define PA_FPB 1024                    // features per workgroup of k_prop_apply
+__device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t fmask) {
+	const int64_t c0 = (j >> 1) * per;
+	if (c0 >= E) return SR_SENT;
+	if (!(j & 1)) return t_key[c0] & fmask;
+	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
+	return t_key[c1 - 1] & fmask;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long long *__restrict__ csr_tot,
+                                                          const uint32_t *__restrict__ t_key, int bits, int64_t W,
+                                                          int64_t n_apply_blocks, uint32_t *__restrict__ part_key,
+                                                          uint32_t *__restrict__ pstart) {
+	const int64_t E = (int64_t)csr_tot[1];
+	const int64_t per = sr_chunk(E, W);
+	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < 2 * W; j += stride)
+		part_key[j] = part_key_at(j, E, per, t_key, fmask);
+	for (int64_t b = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; b <= n_apply_blocks; b += stride) {
+		const uint64_t want = (uint64_t)b * PA_FPB;
+		int64_t lo = 0, hi = 2 * W;                // first j with key(j) >= want
+		while (lo < hi) {
+			const int64_t mid = (lo + hi) >> 1;
+			if ((uint64_t)part_key_at(mid, E, per, t_key, fmask) < want) lo = mid + 1; else hi = mid;
+		}
+		pstart[b] = (uint32_t)lo;
 	}
 }
 
@@ -823,44 +875,87 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 	if (lane == 0 && carry_open && carry_key != SR_SENT && carry != 0.0) atomicAdd(&share[carry_key], carry);
 }
 
-// a = U + a*share, clamp, per-workgroup partial of sum(diff^2) (msam_profile.c:368-379)
+// a = U + a * share, clamp, DELTA^2, convergence (msam_profile.c:368-389).  A workgroup owns PA_FPB
+// consecutive features.  FUSED (single GPU, no collective inside the iteration): share[] holds the
+// segments k_share_reduce stored directly; the partial slots whose keys fall into the workgroup's
+// range are added here, in slot order (one lane: a fixed summation order), and share2[] carries the
+// general lists.  Not FUSED: share[] is complete (k_partial_reduce, k_general_share and the caller's
+// all-reduce have run).  The workgroup that finishes last adds the per-workgroup sums of diff^2 in
+// index order and sets delta[k], the iteration count and the done flag -- no separate launch.
+template <bool FUSED>
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const double *__restrict__ U,
-                                                          double *__restrict__ share, double *__restrict__ a,
-                                                          double *__restrict__ partial,
-                                                          const int32_t *__restrict__ iter_state) {
+                                                          double *__restrict__ share, double *__restrict__ share2,
+                                                          double *__restrict__ a,
+                                                          const unsigned long long *__restrict__ d_tot,
+                                                          const uint32_t *__restrict__ part_key,
+                                                          const double *__restrict__ part_val,
+                                                          const uint32_t *__restrict__ pstart,
+                                                          double *__restrict__ partial, double *__restrict__ delta,
+                                                          int32_t *iter_state, int k) {
+	__shared__ double s_add[FUSED ? PA_FPB : 1];
 	__shared__ double s_w[MSX_BLOCK / 64];
+	__shared__ int s_last;
 	if (iter_state[0]) return;
+	const int64_t i0 = (int64_t)blockIdx.x * PA_FPB;
+	bool with2 = false;
+	if (FUSED) {
+		with2 = d_tot[2] != 0ull;              // general lists exist: share2[] is live
+		for (int q = threadIdx.x; q < PA_FPB; q += MSX_BLOCK) s_add[q] = 0.0;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const uint32_t ps = pstart[blockIdx.x], pe = pstart[blockIdx.x + 1];
+			for (uint32_t q = ps; q < pe; ++q) s_add[part_key[q] - (uint32_t)i0] += part_val[q];
+		}
+		__syncthreads();
+	}
 	double acc = 0;
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
-		const double old = a[i];
-		double v = U[i] + old * share[i];
-		if (v < 1e-20) v = 0;
-		const double diff = v - old;
-		acc += diff * diff;
-		a[i] = v;
-		share[i] = 0.0;
+#pragma unroll
+	for (int q = 0; q < PA_FPB / MSX_BLOCK; q++) {
+		const int64_t i = i0 + q * MSX_BLOCK + threadIdx.x;
+		if (i < nf) {
+			const double old = a[i];
+			double sh = share[i];
+			if (FUSED) {
+				sh += s_add[q * MSX_BLOCK + threadIdx.x];
+				if (with2) { sh += share2[i]; share2[i] = 0.0; }
+			}
+			double v = U[i] + old * sh;
+			if (v < 1e-20) v = 0;
+			const double diff = v - old;
+			acc += diff * diff;
+			a[i] = v;
+			share[i] = 0.0;
+		}
 	}
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_finish(int nparts, const double *__restrict__ partial, int32_t nf,
-                                                           double *__restrict__ delta, int32_t *iter_state, int k) {
-	__shared__ double s_w[MSX_BLOCK / 64];
-	if (iter_state[0]) return;
-	double acc = 0;
-	for (int i = threadIdx.x; i < nparts; i += MSX_BLOCK) acc += partial[i];
-	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+	// ---- the last workgroup to arrive finishes the iteration (agent-scope release / acquire around a ticket)
+	if (threadIdx.x == 0) {
+		partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const int old = __hip_atomic_fetch_add(&iter_state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+		if (s_last) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+	}
+	__syncthreads();
+	if (!s_last) return;
+	double tot = 0;
+	for (int i = threadIdx.x; i < (int)gridDim.x; i += MSX_BLOCK) tot += partial[i];
+	for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = tot;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		double dl = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) / nf;   // :380
+		const double dl = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) / nf;   // :380
 		delta[k] = dl;
 		iter_state[1] = k;
-		if (dl < 1e-10) iter_state[0] = 1;                      // :383
+		iter_state[2] = 0;                                         // the ticket, for the next iteration
+		if (dl < 1e-10) iter_state[0] = 1;                         // :383
 	}
 }
 
@@ -892,6 +987,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long l
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// waves of one k_share_reduce launch: what the chip holds at once
+int64_t msx_share_waves(msx_ctx *ctx) {
+	static const int wps = [] {
+		const char *e = getenv("MSX_SR_WPS");          // experiments: waves per SIMD the launch is sized for
+		const int v = e ? atoi(e) : 0;
+		return (v >= 1 && v <= 8) ? v : SR_WAVES_PER_SIMD;
+	}();
+	return (int64_t)ctx->num_cu * 4 * wps;
+}
+int64_t msx_apply_blocks(int32_t nf) { return nf > 0 ? ((int64_t)nf + PA_FPB - 1) / PA_FPB : 1; }
+
 static int nf_grid(msx_ctx *ctx, int32_t nf) {
 	int g = msx_grid(ctx, nf, MSX_BLOCK);
 	return g > PROP_MAX_BLOCKS ? PROP_MAX_BLOCKS : g;
@@ -913,16 +1019,20 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 		const int dst = cur ^ 1;
 		const int left = bits - 8 * ps;
 		const uint32_t dmask = left >= 8 ? 255u : ((1u << left) - 1u);
-		MSX_TIMED(ctx, MSX_K_RS_HIST,
-		          hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr,
-		                             (int64_t)0, ps * 8, dmask, (uint32_t *)p->rs_hist.p, n_waves));
+		msx_time_begin(ctx, MSX_K_RS_HIST);
+		msx_time_bytes(ctx, 0, 4, n_ub, n_ptr);           // keys in (+ 1 KB of counters per 4096-key tile)
+		hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr,
+		                   (int64_t)0, ps * 8, dmask, (uint32_t *)p->rs_hist.p, n_waves);
+		msx_time_end(ctx);
 		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves, n_ptr,
 		                           RS_TILE, 256)))
 			return rc;
-		MSX_TIMED(ctx, MSX_K_RS_SCATTER,
-		          hipLaunchKernelGGL((k_rs_scatter<V, true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin,
-		                             vin, (uint32_t *)p->t_key[dst].p, (V *)vbuf[dst].p, n_ptr, (int64_t)0, ps * 8,
-		                             dmask, (const uint32_t *)p->rs_off.p, n_waves));
+		msx_time_begin(ctx, MSX_K_RS_SCATTER);
+		msx_time_bytes(ctx, 0, 24, n_ub, n_ptr);          // key + 8-byte value in and out
+		hipLaunchKernelGGL((k_rs_scatter<V, true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin,
+		                   vin, (uint32_t *)p->t_key[dst].p, (V *)vbuf[dst].p, n_ptr, (int64_t)0, ps * 8,
+		                   dmask, (const uint32_t *)p->rs_off.p, n_waves);
+		msx_time_end(ctx);
 		kin = (const uint32_t *)p->t_key[dst].p;
 		vin = (const V *)vbuf[dst].p;
 		cur = dst;
@@ -939,11 +1049,11 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	for (int i = 0; i < 2; i++) {
 		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64) * 4))) return rc;
 	}
-	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
 	{
-		const int64_t sw = (((eub + SR_CHUNK - 1) / SR_CHUNK + 3) / 4 + 7) / 8 * 8 * 4;   // waves launched by k_share_reduce
-		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * sw + 8) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * sw + 8) * 8))) return rc;
+		const int64_t W = msx_share_waves(ctx);
+		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * W + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * W + 8) * 8))) return rc;
+		if ((rc = msx_reserve(ctx, &p->pstart, (size_t)(msx_apply_blocks(p->n_features) + 8) * 4))) return rc;
 	}
 	const int64_t n_waves = ((eub > lub ? eub : lub) + RS_TILE - 1) / RS_TILE;
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
@@ -986,7 +1096,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		// the feature-major entries are written as the derived store is built, into the buffers the
 		// list sort is not holding its result in: key = feature, value = the list's signature or number
 		ebuf = sb ^ 1;
-		if ((rc = msx_reserve(ctx, &p->gen, (size_t)(lub + 8)))) return rc;
+		if ((rc = msx_reserve(ctx, &p->gl_idx, (size_t)(lub + 8) * 4))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_uniq_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                             tot, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
@@ -997,9 +1107,9 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		                             (uint32_t *)p->hpos.p, lub, p->d_tot));
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_entry_weight, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
+		                             p->d_tot, (const uint32_t *)p->m_off_alt.p,
 		                             (const uint32_t *)p->hpos.p, bits, (uint32_t *)p->t_key[ebuf].p,
-		                             (unsigned long long *)p->t_val64[ebuf].p, (uint8_t *)p->gen.p));
+		                             (unsigned long long *)p->t_val64[ebuf].p, (uint32_t *)p->gl_idx.p));
 	}
 	tot = p->d_tot;      // everything below works on the derived store
 	p->key_bits = bits;
@@ -1011,46 +1121,66 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	                                       &cur)))
 		return rc;
 	p->sorted_buf = cur;
+	// (c) keys of the partial slots and where each k_prop_apply workgroup finds its own
+	{
+		const int64_t W = msx_share_waves(ctx), nba = msx_apply_blocks(p->n_features);
+		const int64_t items = 2 * W > nba + 1 ? 2 * W : nba + 1;
+		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
+		          hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, items, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W, nba,
+		                             (uint32_t *)p->part_key.p, (uint32_t *)p->pstart.p));
+	}
 	p->transposed_valid = true;
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
 
-int msx_prop_iteration(msx_ctx *ctx, msx_profile *p) {
+// One iteration's sums.  complete = false (single GPU, msx_profile_finalize_enqueue): share[] gets the
+// segments that lie inside one chunk, share2[] the general lists, the partial slots stay in part_val --
+// k_prop_apply<true> puts the three together.  complete = true (a collective follows): everything is
+// added into share[].
+int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
-	const int64_t eub = p->entries_ub > 0 ? p->entries_ub : 1;
-	MSX_TIMED(ctx, MSX_K_LIST_RECIP,
-	          hipLaunchKernelGGL(k_list_recip, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	const int64_t W = msx_share_waves(ctx);
+	int gg = msx_grid(ctx, lub, MSX_BLOCK);
+	if (gg > 128) gg = 128;                                  // the general lists are few: a small grid strides over them
+	MSX_TIMED(ctx, MSX_K_GENERAL_SHARE,
+	          hipLaunchKernelGGL(k_general_share, dim3(gg), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
 	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p,
-	                             (const uint8_t *)p->gen.p, (const double *)p->a, (double *)p->recip.p,
+	                             (const uint32_t *)p->gl_idx.p, (const double *)p->a, complete ? p->share : p->share2,
 	                             (const int32_t *)p->iter_state));
-	const int64_t n_waves = (eub + SR_CHUNK - 1) / SR_CHUNK;
-	const unsigned nblk = (unsigned)(((n_waves + 3) / 4 + 7) / 8 * 8);
-	const int64_t M = (int64_t)nblk * 4 * 2;              // two partial slots per launched wave
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
-	          hipLaunchKernelGGL(k_share_reduce, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream,
+	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
-	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
-	                             (const double *)p->a, p->key_bits, p->share, (uint32_t *)p->part_key.p,
-	                             (double *)p->part_val.p,
+	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p,
+	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
 	                             (const int32_t *)p->iter_state));
-	const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
-	MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
-	          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((n_waves2 + 3) / 4)), dim3(MSX_BLOCK), 0,
-	                             ctx->stream, M, (const uint32_t *)p->part_key.p, (const double *)p->part_val.p,
-	                             p->share, (const int32_t *)p->iter_state));
+	if (complete) {
+		const int64_t M = 2 * W;
+		const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
+		MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
+		          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((n_waves2 + 3) / 4)), dim3(MSX_BLOCK), 0,
+		                             ctx->stream, M, (const uint32_t *)p->part_key.p, (const double *)p->part_val.p,
+		                             p->share, (const int32_t *)p->iter_state));
+	}
 	return MSX_OK;
 }
 
-int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k) {
+int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused) {
 	const int32_t nf = p->n_features;
-	const int g = nf_grid(ctx, nf);
+	const unsigned g = (unsigned)msx_apply_blocks(nf);
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
-	hipLaunchKernelGGL(k_prop_apply, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
-	                   p->a, p->partial, (const int32_t *)p->iter_state);
-	hipLaunchKernelGGL(k_prop_finish, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, g, (const double *)p->partial, nf,
-	                   p->delta, p->iter_state, k);
+	if (fused)
+		hipLaunchKernelGGL(k_prop_apply<true>, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
+		                   p->share2, p->a, (const unsigned long long *)p->d_tot, (const uint32_t *)p->part_key.p,
+		                   (const double *)p->part_val.p, (const uint32_t *)p->pstart.p, p->partial, p->delta,
+		                   p->iter_state, k);
+	else
+		hipLaunchKernelGGL(k_prop_apply<false>, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
+		                   p->share2, p->a, (const unsigned long long *)p->d_tot, (const uint32_t *)p->part_key.p,
+		                   (const double *)p->part_val.p, (const uint32_t *)p->pstart.p, p->partial, p->delta,
+		                   p->iter_state, k);
 	msx_time_end(ctx);
 	return MSX_OK;
 }
@@ -1071,7 +1201,8 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	const int32_t nf = p->n_features;
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
-	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->share, p->delta, p->iter_state);
+	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->share, p->share2, p->delta,
+	                   p->iter_state);
 	msx_time_end(ctx);
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->counters + 3, 0, 4, ctx->stream));   // purged is recomputed per finalize
@@ -1090,7 +1221,7 @@ extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local before msx_profile_prop_begin");
 	if (p->share_type != MSX_MULTI_SHARE_PROPORTIONAL)
 		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
-	msx_prop_iteration(ctx, p);
+	msx_prop_iteration(ctx, p, true);         // share[] complete: the caller all-reduces it
 	if (inc) *inc = p->share;
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
@@ -1101,7 +1232,7 @@ extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delt
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply before msx_profile_prop_begin");
 	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
 	p->iter_k++;
-	msx_prop_apply_launch(ctx, p, p->iter_k);
+	msx_prop_apply_launch(ctx, p, p->iter_k, false);
 	MSX_HIP(ctx, hipGetLastError());
 	double dl = 0;
 	MSX_HIP(ctx, hipMemcpyAsync(&dl, p->delta + p->iter_k, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1121,7 +1252,7 @@ extern "C" int msx_profile_prop_apply_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply_enqueue before msx_profile_prop_begin");
 	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
 	p->iter_k++;
-	msx_prop_apply_launch(ctx, p, p->iter_k);
+	msx_prop_apply_launch(ctx, p, p->iter_k, false);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
@@ -1153,8 +1284,8 @@ extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (rc) return rc;
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331; converged iterations exit at once
-			msx_prop_iteration(ctx, p);
-			msx_prop_apply_launch(ctx, p, k);
+			msx_prop_iteration(ctx, p, false);
+			msx_prop_apply_launch(ctx, p, k, true);
 		}
 		msx_prop_purged_launch(ctx, p, p->counters + 3);
 	}
@@ -1169,11 +1300,11 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if ((rc = msx_profile_prop_begin(ctx, p))) return rc;      // a = U = ui/2 (+d): identical on every rank
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
-			msx_prop_iteration(ctx, p);           // share = this rank's part of the increment
+			msx_prop_iteration(ctx, p, true);     // share = this rank's part of the increment, complete
 			// (after convergence the local kernels are no-ops and leave `share` at zero on every rank;
 			// the all-reduce still runs -- every rank enqueues the same 19 -- and sums zeros)
 			if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;
-			msx_prop_apply_launch(ctx, p, k);     // same numbers, same decision (:383) everywhere
+			msx_prop_apply_launch(ctx, p, k, false);   // same numbers, same decision (:383) everywhere
 		}
 		msx_prop_purged_launch(ctx, p, p->counters + 3);       // this rank's multi-mappers whose sum is 0
 		if ((rc = msx_dist_allreduce_u32(ctx, p->counters + 3, 1))) return rc;

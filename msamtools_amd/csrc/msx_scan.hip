@@ -185,6 +185,7 @@ static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level, 
 
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
+	msx_time_bytes(ctx, 0, 12, m);                       // reduce pass reads, apply pass reads and writes
 	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
@@ -197,6 +198,7 @@ int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m, const unsigned long long *n_ptr,
                      int64_t div, int64_t mul) {
 	msx_time_begin(ctx, MSX_K_SCAN);
+	msx_time_bytes(ctx, 0, 12, m, n_ptr, div, mul);
 	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0, ScanLen{n_ptr, div, mul});
 	msx_time_end(ctx);
 	if (rc) return rc;
@@ -207,6 +209,7 @@ int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m,
 // inclusive, in place (each workgroup reads its 2048 items into registers before writing them)
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
+	msx_time_bytes(ctx, 0, 12, m);
 	int rc = scan_rec<uint32_t, true>(ctx, data, data, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
@@ -216,6 +219,7 @@ int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
 
 int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
+	msx_time_bytes(ctx, 0, 16, m);                       // 4-byte words in (twice), 8-byte sums out
 	int rc = scan_rec<unsigned long long, false, true>(ctx, pinfo, (unsigned long long *)out, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
