@@ -131,12 +131,12 @@ def algorithmic_bytes_per_step(name, w):
         # per launch: entry key 4 + value 8, a[] read once, share[] written once
         return it * (12 * E + 16 * nf)
     if name == "k_prop_apply":
-        # per iteration U, share, a in; a, share out (k_prop_apply) ; once: k_prop_begin (ui in; U, a, share,
-        # share2 out) and k_prop_purged (offsets, positions, features in, a[] gathered)
-        return it * 40 * nf + 36 * nf + 8 * L + 12 * E
+        # per iteration U, share, a in; a, share out (k_prop_apply) ; once: k_prop_begin (ui in; U, a, share
+        # out) and k_prop_purged (offsets, positions, features in, a[] gathered)
+        return it * 40 * nf + 28 * nf + 8 * L + 12 * E
     if name in ("scan", "k_rs_hist", "k_rs_scatter"):
         return w["lib"].get(name) or None
-    return None        # k_general_share (a few thousand lists), k_partial_reduce: not priced
+    return None        # k_general_recip (a few thousand lists), k_partial_reduce: not priced
 
 
 def main():
@@ -256,7 +256,7 @@ def main():
             prof.finalize_enqueue()
             run.finish()
         names = ["k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
-                 "k_list_order", "k_rs_hist", "k_rs_scatter", "k_general_share", "k_share_reduce", "k_partial_reduce",
+                 "k_list_order", "k_rs_hist", "k_rs_scatter", "k_general_recip", "k_share_reduce", "k_partial_reduce",
                  "k_prop_apply", "scan"]
         tms, lib_bytes = {}, {}
         for k in names:

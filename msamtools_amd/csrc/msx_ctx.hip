@@ -174,7 +174,7 @@ extern "C" int msx_ctx_sync(msx_ctx *ctx) {
 
 static const char *k_names[MSX_K_COUNT] = {
     "k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
-    "k_general_share", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order", "k_rs_hist", "k_rs_scatter",
+    "k_general_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order", "k_rs_hist", "k_rs_scatter",
     "k_coverage_pileup", "scan", "synth"};
 
 static hipEvent_t get_event(msx_ctx *ctx) {

@@ -36,7 +36,7 @@ enum msx_kid {
 	MSX_K_EMIT,            // k_emit_groups / k_emit_count + k_emit_fill
 	MSX_K_INSERT_COUNT,    // k_insert_count; the partition count of the unique-insert keys (msx_count_keys)
 	MSX_K_MULTI_COMPACT,   // k_multi_compact + k_multi_advance
-	MSX_K_GENERAL_SHARE,   // k_general_share
+	MSX_K_GENERAL_RECIP,   // k_general_recip
 	MSX_K_SHARE_REDUCE,    // k_share_reduce
 	MSX_K_PARTIAL_REDUCE,  // k_partial_reduce
 	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply / k_prop_purged
@@ -170,7 +170,6 @@ struct msx_profile {
 	uint32_t *counters = nullptr;     // [4] {inserts, uniq, multi, purged}
 	double *U = nullptr, *a = nullptr;   // [n_features] U(i), a(i,k)
 	double *share = nullptr;          // [n_features] sum over multi-mappers of 1/S (all-reduced across ranks)
-	double *share2 = nullptr;         // [n_features] the general lists' part (single-GPU iteration)
 	double *delta = nullptr;          // [20] device, delta[k]
 	int32_t *iter_state = nullptr;    // [4]: {done flag, iterations, arrival ticket of k_prop_apply, -}
 	unsigned long long *csr_tot = nullptr;   // device {n_lists, n_entries}
@@ -183,7 +182,8 @@ struct msx_profile {
 	// feature-major view built once per finalize by a stable radix sort
 	msx_buf t_key[2];                 // ping-pong keys of the radix sorts (list keys, then entry keys)
 	msx_buf t_val64[2];               // ping-pong 64-bit values travelling with them: set signatures (msx_prop.hip)
-	msx_buf gl_idx;                   // u32 [general lists]: numbers of the lists k_general_share handles
+	msx_buf gl_idx;                   // u32 [general lists]: numbers of the lists k_general_recip handles
+	msx_buf recip;                    // f64 [n_lists]: w/S of the general lists
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
 	msx_buf pstart;                   // u32 [workgroups of k_prop_apply + 1]: first partial slot of each

@@ -114,7 +114,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p,
-	                p->share2, p->pstart.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p,
+	                p->recip.p, p->pstart.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p,
 	                p->head.p, p->uidx.p, p->eoff.p, p->hpos.p, p->d_tot,
 	                p->t_val64[0].p, p->t_val64[1].p, p->gl_idx.p};
 	for (void *q : ptrs)
@@ -139,7 +139,6 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	          hipMalloc((void **)&p->counters, 4 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->U, nf * 8) == hipSuccess && hipMalloc((void **)&p->a, nf * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->share, nf * 8) == hipSuccess &&
-	          hipMalloc((void **)&p->share2, nf * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->delta, 20 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->iter_state, 4 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->csr_tot, 2 * 8) == hipSuccess &&

@@ -7,8 +7,9 @@
 //   share[f] = sum over the lists containing f of w/S    segmented sum by feature (k_share_reduce;
 //                                                         lists of <= 4 features carry their set with
 //                                                         every entry, so S is summed there from a[])
-//   share2[f] += w/S for the few longer lists             one lane per such list (k_general_share)
-//   a[f] = U[f] + a[f] * (share[f] + share2[f] + the partial sums of segments cut by a chunk boundary),
+//   recip[j] = w/S for the few longer lists                one lane per such list (k_general_recip);
+//                                                         their entries gather it in k_share_reduce
+//   a[f] = U[f] + a[f] * (share[f] + the partial sums of segments cut by a chunk boundary),
 //   clamp, DELTA^2 and the convergence flag               (k_prop_apply, last workgroup finishes)
 // T's feature-major order is produced once per finalize by a stable LSD radix
 // sort of (feature, list) pairs, so entries of one feature are contiguous and
@@ -495,8 +496,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 // The weight of a merged list (how many inserts had exactly this set) rides in the key bits
 // above the feature id of its entries.  A list whose weight does not fit there, or whose set did
 // not fit a signature (more than four features, feature ids of 21 bits and more), is a *general*
-// list: its entries stay in the feature-major stream with weight 0 and no other features -- they
-// contribute nothing there -- and its number goes to gl_idx[]; k_general_share adds its w/S.
+// list: its entries name the list (SIG_HASHED | u), its number goes to gl_idx[], k_general_recip
+// computes recip[u] = w/S for it and k_share_reduce gathers that.
 __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(unsigned long long *__restrict__ d_tot,
                                                             const uint32_t *__restrict__ d_off,
                                                             const uint32_t *__restrict__ hpos, int bits,
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(unsigned long long *
 		if (!hashed && fits) {
 			for (uint32_t o = s; o < e; ++o) e_key[o] |= w << bits;
 		} else {
-			for (uint32_t o = s; o < e; ++o) e_val[o] = pack_others(SIG_PAD, SIG_PAD, SIG_PAD);
+			for (uint32_t o = s; o < e; ++o) e_val[o] = SIG_HASHED | (unsigned long long)u;
 			gl_idx[atomicAdd(&d_tot[2], 1ull)] = (uint32_t)u;
 		}
 	}
@@ -526,7 +527,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(unsigned long long *
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint32_t *__restrict__ ui,
                                                           const double *__restrict__ d, double *__restrict__ U,
                                                           double *__restrict__ a, double *__restrict__ share,
-                                                          double *__restrict__ share2,
                                                           double *__restrict__ delta, int32_t *iter_state) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
@@ -535,22 +535,20 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint
 		U[i] = u;
 		a[i] = u;                             // :326
 		share[i] = 0.0;
-		share2[i] = 0.0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x < 20) delta[threadIdx.x] = 0.0;
 	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; iter_state[2] = 0; }
 }
 
-// dst[f] += w_j/S_j for every feature f of every general list j (S_j = sum of a over its features,
-// w_j the number of inserts it stands for; nothing when S_j == 0: msam_profile.c:358).  These are the
-// lists of five and more features (0.6 % of the lists on the IGC-scale workload): one lane per list,
-// floating-point atomics -- a feature receives few of these adds, in no fixed order (last-bit noise).
-__global__ __launch_bounds__(MSX_BLOCK) void k_general_share(const unsigned long long *__restrict__ d_tot,
+// recip[j] = w_j/S_j for every general list j (S_j = sum of a over its features, w_j the number of
+// inserts it stands for; 0 when S_j == 0: msam_profile.c:358).  These are the lists of five and more
+// features (0.6 % of the lists on the IGC-scale workload), reached through gl_idx[]: one lane per list.
+__global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(const unsigned long long *__restrict__ d_tot,
                                                              const uint32_t *__restrict__ m_off,
                                                              const int32_t *__restrict__ m_fid,
                                                              const uint32_t *__restrict__ hpos,
                                                              const uint32_t *__restrict__ gl_idx,
-                                                             const double *__restrict__ a, double *__restrict__ dst,
+                                                             const double *__restrict__ a, double *__restrict__ recip,
                                                              const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
 	const int64_t n = (int64_t)d_tot[2];
@@ -560,9 +558,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_share(const unsigned long
 		const uint32_t s = m_off[j], e = m_off[j + 1];
 		const uint32_t w = hpos[j + 1] - hpos[j];
 		double sum = 0;
-		int32_t f[8];
 		if (e - s <= 8u) {
 			// feature ids, then abundances, as independent loads; summed in list order
+			int32_t f[8];
 			double x[8];
 #pragma unroll
 			for (int q = 0; q < 8; q++) f[q] = (s + (uint32_t)q < e) ? m_fid[s + q] : -1;
@@ -574,15 +572,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_share(const unsigned long
 		} else {
 			for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
 		}
-		if (!(sum > 0)) continue;
-		const double r = (double)w / sum;
-		if (e - s <= 8u) {
-#pragma unroll
-			for (int q = 0; q < 8; q++)
-				if (f[q] >= 0) atomicAdd(&dst[f[q]], r);
-		} else {
-			for (uint32_t k = s; k < e; ++k) atomicAdd(&dst[m_fid[k]], r);
-		}
+		recip[j] = sum > 0 ? (double)w / sum : 0.0;
 	}
 }
 
@@ -641,6 +631,7 @@ __device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
+                                                            const double *__restrict__ recip,
                                                             const double *__restrict__ a, int bits, int64_t W,
                                                             double *__restrict__ share,
                                                             double *__restrict__ part_val,
@@ -704,28 +695,29 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		// 8 MB that the caches hold well, unlike one 8-byte recip[] per list out of tens of MB -- as
 		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders:
 		// their S can differ in the last bit, 1e-16 relative; ordering them costs a third of this
-		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  An entry of a
-		// general list has weight 0 and no others: it adds nothing here (k_general_share).
+		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  General lists: recip[u].
 		double x[SR_EPL];
 		{
 			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
+				const bool general = (lv[i] & SIG_HASHED) != 0;
 				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
 				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				af[i] = live ? a[k[i] & fmask] : 0.0;
-				a1[i] = (live && o1 != SIG_PAD) ? a[o1] : 0.0;
-				a2[i] = (live && o2 != SIG_PAD) ? a[o2] : 0.0;
-				a3[i] = (live && o3 != SIG_PAD) ? a[o3] : 0.0;
+				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
+				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
+				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
+				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
 			}
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
+				const bool general = (lv[i] & SIG_HASHED) != 0;
 				const uint32_t f = k[i] & fmask;
 				const double sum = ((a1[i] + a2[i]) + a3[i]) + af[i];     // absent ones are +0.0
 				const double w = (double)(bits < 32 ? (k[i] >> bits) : 0u);
-				x[i] = (live && sum > 0) ? w / sum : 0.0;
+				x[i] = !live ? 0.0 : general ? af[i] : (sum > 0 ? w / sum : 0.0);
 				if (live) k[i] = f;                          // from here on: the feature id
 			}
 		}
@@ -878,15 +870,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 // a = U + a * share, clamp, DELTA^2, convergence (msam_profile.c:368-389).  A workgroup owns PA_FPB
 // consecutive features.  FUSED (single GPU, no collective inside the iteration): share[] holds the
 // segments k_share_reduce stored directly; the partial slots whose keys fall into the workgroup's
-// range are added here, in slot order (one lane: a fixed summation order), and share2[] carries the
-// general lists.  Not FUSED: share[] is complete (k_partial_reduce, k_general_share and the caller's
-// all-reduce have run).  The workgroup that finishes last adds the per-workgroup sums of diff^2 in
+// range are added here, into an LDS image of the range (ds_add_f64: the hot references of the first
+// workgroups receive hundreds of slots each, so all threads share the work; a feature that was cut
+// receives its few partial sums in no fixed order -- last-bit noise, as with k_partial_reduce's
+// atomics).  Not FUSED: share[] is complete (k_partial_reduce and the caller's all-reduce have run).  The workgroup that finishes last adds the per-workgroup sums of diff^2 in
 // index order and sets delta[k], the iteration count and the done flag -- no separate launch.
 template <bool FUSED>
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const double *__restrict__ U,
-                                                          double *__restrict__ share, double *__restrict__ share2,
-                                                          double *__restrict__ a,
-                                                          const unsigned long long *__restrict__ d_tot,
+                                                          double *__restrict__ share, double *__restrict__ a,
                                                           const uint32_t *__restrict__ part_key,
                                                           const double *__restrict__ part_val,
                                                           const uint32_t *__restrict__ pstart,
@@ -897,14 +888,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const doub
 	__shared__ int s_last;
 	if (iter_state[0]) return;
 	const int64_t i0 = (int64_t)blockIdx.x * PA_FPB;
-	bool with2 = false;
 	if (FUSED) {
-		with2 = d_tot[2] != 0ull;              // general lists exist: share2[] is live
 		for (int q = threadIdx.x; q < PA_FPB; q += MSX_BLOCK) s_add[q] = 0.0;
 		__syncthreads();
-		if (threadIdx.x == 0) {
-			const uint32_t ps = pstart[blockIdx.x], pe = pstart[blockIdx.x + 1];
-			for (uint32_t q = ps; q < pe; ++q) s_add[part_key[q] - (uint32_t)i0] += part_val[q];
+		const uint32_t ps = pstart[blockIdx.x], pe = pstart[blockIdx.x + 1];
+		for (uint32_t q = ps + threadIdx.x; q < pe; q += MSX_BLOCK) {
+			const double v = part_val[q];
+			if (v != 0.0) atomicAdd(&s_add[part_key[q] - (uint32_t)i0], v);
 		}
 		__syncthreads();
 	}
@@ -915,10 +905,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const doub
 		if (i < nf) {
 			const double old = a[i];
 			double sh = share[i];
-			if (FUSED) {
-				sh += s_add[q * MSX_BLOCK + threadIdx.x];
-				if (with2) { sh += share2[i]; share2[i] = 0.0; }
-			}
+			if (FUSED) sh += s_add[q * MSX_BLOCK + threadIdx.x];
 			double v = U[i] + old * sh;
 			if (v < 1e-20) v = 0;
 			const double diff = v - old;
@@ -1049,6 +1036,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	for (int i = 0; i < 2; i++) {
 		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64) * 4))) return rc;
 	}
+	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
 	{
 		const int64_t W = msx_share_waves(ctx);
 		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * W + 8) * 4))) return rc;
@@ -1136,24 +1124,23 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 }
 
 // One iteration's sums.  complete = false (single GPU, msx_profile_finalize_enqueue): share[] gets the
-// segments that lie inside one chunk, share2[] the general lists, the partial slots stay in part_val --
-// k_prop_apply<true> puts the three together.  complete = true (a collective follows): everything is
-// added into share[].
+// segments that lie inside one chunk, the partial slots stay in part_val -- k_prop_apply<true> puts the
+// two together.  complete = true (a collective follows): the slots are added into share[] here.
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
 	const int64_t W = msx_share_waves(ctx);
 	int gg = msx_grid(ctx, lub, MSX_BLOCK);
 	if (gg > 128) gg = 128;                                  // the general lists are few: a small grid strides over them
-	MSX_TIMED(ctx, MSX_K_GENERAL_SHARE,
-	          hipLaunchKernelGGL(k_general_share, dim3(gg), dim3(MSX_BLOCK), 0, ctx->stream,
+	MSX_TIMED(ctx, MSX_K_GENERAL_RECIP,
+	          hipLaunchKernelGGL(k_general_recip, dim3(gg), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
 	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p,
-	                             (const uint32_t *)p->gl_idx.p, (const double *)p->a, complete ? p->share : p->share2,
+	                             (const uint32_t *)p->gl_idx.p, (const double *)p->a, (double *)p->recip.p,
 	                             (const int32_t *)p->iter_state));
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
 	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
-	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p,
+	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
 	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
 	                             (const int32_t *)p->iter_state));
 	if (complete) {
@@ -1173,12 +1160,12 @@ int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused) {
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	if (fused)
 		hipLaunchKernelGGL(k_prop_apply<true>, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
-		                   p->share2, p->a, (const unsigned long long *)p->d_tot, (const uint32_t *)p->part_key.p,
+		                   p->a, (const uint32_t *)p->part_key.p,
 		                   (const double *)p->part_val.p, (const uint32_t *)p->pstart.p, p->partial, p->delta,
 		                   p->iter_state, k);
 	else
 		hipLaunchKernelGGL(k_prop_apply<false>, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
-		                   p->share2, p->a, (const unsigned long long *)p->d_tot, (const uint32_t *)p->part_key.p,
+		                   p->a, (const uint32_t *)p->part_key.p,
 		                   (const double *)p->part_val.p, (const uint32_t *)p->pstart.p, p->partial, p->delta,
 		                   p->iter_state, k);
 	msx_time_end(ctx);
@@ -1201,8 +1188,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	const int32_t nf = p->n_features;
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
-	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->share, p->share2, p->delta,
-	                   p->iter_state);
+	                   (const uint32_t *)p->ui, (const double *)p->d, p->U, p->a, p->share, p->delta, p->iter_state);
 	msx_time_end(ctx);
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->counters + 3, 0, 4, ctx->stream));   // purged is recomputed per finalize

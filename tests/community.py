@@ -39,6 +39,71 @@ def md_nm(ref, query):
     return "".join(out), nm
 
 
+def build_flag(mate, reverse, mate_reverse, secondary, mate_present):
+    """FLAG of one record: paired, READ1/READ2, strand, proper pair + mate strand when the mate is
+    mapped (mate-unmapped otherwise), secondary for alternative occurrences."""
+    flag = 0x1 | (0x40 if mate == 1 else 0x80)
+    if reverse:
+        flag |= 0x10
+    if mate_present:
+        flag |= 0x2
+        if mate_reverse:
+            flag |= 0x20
+    else:
+        flag |= 0x8
+    if secondary:
+        flag |= 0x100
+    return flag
+
+
+def occurrence_geometry(start, orientation, mate):
+    """(start0, reverse, mate_start0, mate_reverse, tlen) of one mate at a 175-bp occurrence: the mate on
+    the forward strand (mate 1 of a '+' occurrence, mate 2 of a '-' one) is leftmost."""
+    fwd_mate = 1 if orientation == "+" else 2
+    if mate == fwd_mate:
+        return start, False, start + INSERT - READ, True, INSERT
+    return start + INSERT - READ, True, start, False, -INSERT
+
+
+def sam_record(qname, chrom_name, chrom_seq, start, orientation, mate, both_mapped, is_source, read):
+    """One SAM line (no newline).  read = the mate's sequence as sequenced; the record carries it in
+    reference orientation.  AS = 100 - 2 NM; QUAL is all 'I'; MAPQ 255."""
+    pos0, reverse, mpos0, mate_reverse, tlen = occurrence_geometry(start, orientation, mate)
+    seq = revcomp(read) if reverse else read
+    md, nm = md_nm(chrom_seq[pos0:pos0 + READ], seq)
+    if both_mapped:
+        rnext, pnext = "=", mpos0 + 1
+    else:
+        rnext, pnext, tlen, mate_reverse = "*", 0, 0, False
+    flag = build_flag(mate, reverse, mate_reverse, not is_source, both_mapped)
+    return "\t".join([qname, str(flag), chrom_name, str(pos0 + 1), "255", f"{READ}M", rnext, str(pnext), str(tlen), seq,
+                      "I" * READ, f"NM:i:{nm}", f"MD:Z:{md}", f"AS:i:{READ - 2 * nm}"])
+
+
+def largest_remainder_counts(probabilities, total):
+    """Integer allocation of `total` by probability: floors, then the largest remainders (ties by key)."""
+    exact = {k: probabilities[k] * total for k in probabilities}
+    counts = {k: int(np.floor(v)) for k, v in exact.items()}
+    order = sorted(probabilities, key=lambda k: (-(exact[k] - counts[k]), k))
+    for k in order[:total - sum(counts.values())]:
+        counts[k] += 1
+    return counts
+
+
+def parse_profile_text(text):
+    """(feature names, values, {total, mapped, multi-mapped inserts}) of a pandas-style profile."""
+    import re
+    head = "\n".join(line for line in text.split("\n") if line.startswith("#"))
+    rows = [line.split("\t") for line in text.split("\n") if line.strip() and not line.startswith("#")]
+    assert rows and rows[0][0] == "ID"
+
+    def get(name):
+        return int(re.search(name + r"\s*:\s*([0-9]+)", head).group(1))
+    counts = {"reported_total_inserts": get("Total inserts"), "reported_mapped_inserts": get("Mapped inserts"),
+              "reported_multimapped_inserts": get("Multiple mapped")}
+    return [r[0] for r in rows[1:]], [float(r[1]) for r in rows[1:]], counts
+
+
 class Community:
     def __init__(self, seed=1, n_species=3, strains=(3, 2, 2), chrom_len=(14000, 22000), n_shared=36, n_within=4,
                  sharing=True):
@@ -102,6 +167,10 @@ class Community:
         lens = np.array([len(g["seq"]) for g in self.genomes], dtype=float)
         w = self.abundance * lens
         w /= w.sum()
+        # inserts per source genome by largest remainder (as the reference allocates them), in random order
+        alloc = largest_remainder_counts({i: float(w[i]) for i in range(len(w))}, n_inserts)
+        plan = np.repeat(np.arange(len(w)), [alloc[i] for i in range(len(w))])
+        rng.shuffle(plan)
         src, tgt = [], []
         with open(path, "w") as f:
             f.write("@HD\tVN:1.6\tSO:queryname\n")
@@ -113,7 +182,7 @@ class Community:
                     gi, s0, L = self.shared_sites[int(rng.randint(len(self.shared_sites)))]
                     start = s0 + int(rng.randint(0, L - INSERT + 1))
                 else:
-                    gi = int(rng.choice(len(self.genomes), p=w))
+                    gi = int(plan[i])
                     start = int(rng.randint(0, len(self.genomes[gi]["seq"]) - INSERT + 1))
                 frag = self.genomes[gi]["seq"][start:start + INSERT]
                 occ = list(self.index[frag])
@@ -137,25 +206,8 @@ class Community:
                     todo = [((gi, start, "+"), 1 if status == "r1" else 2)]
                     genomes_hit = {gi}
                 for (g2, s2, orient), mate in todo:
-                    fwd_mate = 1 if orient == "+" else 2            # the mate lying on the forward strand at s2
-                    reverse = mate != fwd_mate
-                    pos0 = s2 if not reverse else s2 + INSERT - READ
-                    mpos0 = s2 + INSERT - READ if not reverse else s2
-                    seq = revcomp(reads[mate]) if reverse else reads[mate]
-                    ref = self.genomes[g2]["seq"][pos0:pos0 + READ]
-                    md, nm = md_nm(ref, seq)
-                    flag = 0x1 | (0x40 if mate == 1 else 0x80) | (0x10 if reverse else 0)
-                    if status == "both":
-                        flag |= 0x2 | (0x20 if not reverse else 0)
-                        rnext, pnext, tlen = "=", mpos0 + 1, (INSERT if not reverse else -INSERT)
-                    else:
-                        flag |= 0x8
-                        rnext, pnext, tlen = "*", 0, 0
-                    if (g2, s2, orient) != (gi, start, "+"):
-                        flag |= 0x100
-                    f.write("\t".join([qname, str(flag), self.genomes[g2]["name"], str(pos0 + 1), "255", f"{READ}M", rnext,
-                                       str(pnext), str(tlen), seq, "I" * READ, f"NM:i:{nm}", f"MD:Z:{md}",
-                                       f"AS:i:{READ - 2 * nm}"]) + "\n")
+                    f.write(sam_record(qname, self.genomes[g2]["name"], self.genomes[g2]["seq"], s2, orient, mate,
+                                       status == "both", (g2, s2, orient) == (gi, start, "+"), reads[mate]) + "\n")
                 src.append(gi)
                 tgt.append(genomes_hit)
                 i += 1
