@@ -498,25 +498,44 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 // not fit a signature (more than four features, feature ids of 21 bits and more), is a *general*
 // list: its entries name the list (SIG_HASHED | u), its number goes to gl_idx[], k_general_recip
 // computes recip[u] = w/S for it and k_share_reduce gathers that.
+#define EW_STAGE 1024                  // general list numbers a workgroup collects before appending them
 __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(unsigned long long *__restrict__ d_tot,
                                                             const uint32_t *__restrict__ d_off,
                                                             const uint32_t *__restrict__ hpos, int bits,
                                                             uint32_t *__restrict__ e_key,
                                                             unsigned long long *__restrict__ e_val,
                                                             uint32_t *__restrict__ gl_idx) {
+	// (one global add per workgroup: thousands of lanes adding 1 to the same word serialise at ~12 ns each)
+	__shared__ uint32_t s_gl[EW_STAGE];
+	__shared__ uint32_t s_n, s_base;
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
 	const int64_t n_lists = (int64_t)d_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t u = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; u < n_lists; u += stride) {
-		const uint32_t s = d_off[u], e = d_off[u + 1];
-		const uint32_t w = hpos[u + 1] - hpos[u];
-		const bool hashed = (e_val[s] & SIG_HASHED) != 0;
-		// (w + 1: the all-ones key is the sentinel of k_share_reduce)
-		const bool fits = bits < 32 && (((unsigned long long)w + 1ull) >> (32 - bits)) == 0ull;
-		if (!hashed && fits) {
-			for (uint32_t o = s; o < e; ++o) e_key[o] |= w << bits;
-		} else {
-			for (uint32_t o = s; o < e; ++o) e_val[o] = SIG_HASHED | (unsigned long long)u;
-			gl_idx[atomicAdd(&d_tot[2], 1ull)] = (uint32_t)u;
+	for (int64_t u0 = (int64_t)blockIdx.x * MSX_BLOCK; u0 < n_lists; u0 += stride) {
+		const int64_t u = u0 + threadIdx.x;
+		if (u < n_lists) {
+			const uint32_t s = d_off[u], e = d_off[u + 1];
+			const uint32_t w = hpos[u + 1] - hpos[u];
+			const bool hashed = (e_val[s] & SIG_HASHED) != 0;
+			// (w + 1: the all-ones key is the sentinel of k_share_reduce)
+			const bool fits = bits < 32 && (((unsigned long long)w + 1ull) >> (32 - bits)) == 0ull;
+			if (!hashed && fits) {
+				for (uint32_t o = s; o < e; ++o) e_key[o] |= w << bits;
+			} else {
+				for (uint32_t o = s; o < e; ++o) e_val[o] = SIG_HASHED | (unsigned long long)u;
+				s_gl[atomicAdd(&s_n, 1u)] = (uint32_t)u;     // (<= 256 per round: flushed below before it can overflow)
+			}
+		}
+		__syncthreads();
+		if (s_n > EW_STAGE - MSX_BLOCK || u0 + stride >= n_lists) {      // workgroup-uniform
+			const uint32_t cnt = s_n;
+			if (threadIdx.x == 0 && cnt) s_base = (uint32_t)atomicAdd(&d_tot[2], (unsigned long long)cnt);
+			__syncthreads();
+			for (uint32_t q = threadIdx.x; q < cnt; q += MSX_BLOCK) gl_idx[s_base + q] = s_gl[q];
+			__syncthreads();
+			if (threadIdx.x == 0) s_n = 0;
+			__syncthreads();
 		}
 	}
 }
@@ -870,10 +889,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 // a = U + a * share, clamp, DELTA^2, convergence (msam_profile.c:368-389).  A workgroup owns PA_FPB
 // consecutive features.  FUSED (single GPU, no collective inside the iteration): share[] holds the
 // segments k_share_reduce stored directly; the partial slots whose keys fall into the workgroup's
-// range are added here, into an LDS image of the range (ds_add_f64: the hot references of the first
-// workgroups receive hundreds of slots each, so all threads share the work; a feature that was cut
-// receives its few partial sums in no fixed order -- last-bit noise, as with k_partial_reduce's
-// atomics).  Not FUSED: share[] is complete (k_partial_reduce and the caller's all-reduce have run).  The workgroup that finishes last adds the per-workgroup sums of diff^2 in
+// range are added here, run by run, in slot order (a fixed summation order: results repeat bit for
+// bit).  Not FUSED: share[] is complete (k_partial_reduce -- atomics -- and the caller's all-reduce
+// have run).  The workgroup that finishes last adds the per-workgroup sums of diff^2 in
 // index order and sets delta[k], the iteration count and the done flag -- no separate launch.
 template <bool FUSED>
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const double *__restrict__ U,
@@ -891,10 +909,16 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const doub
 	if (FUSED) {
 		for (int q = threadIdx.x; q < PA_FPB; q += MSX_BLOCK) s_add[q] = 0.0;
 		__syncthreads();
+		// the slots of one feature are neighbours (ascending keys): the thread that holds the first slot of
+		// a run adds the run, in slot order, and owns the feature's LDS cell -- no atomics, a fixed order.
+		// (The hot references of the first workgroups have runs of a few hundred slots.)
 		const uint32_t ps = pstart[blockIdx.x], pe = pstart[blockIdx.x + 1];
 		for (uint32_t q = ps + threadIdx.x; q < pe; q += MSX_BLOCK) {
-			const double v = part_val[q];
-			if (v != 0.0) atomicAdd(&s_add[part_key[q] - (uint32_t)i0], v);
+			const uint32_t key = part_key[q];
+			if (q > ps && part_key[q - 1] == key) continue;
+			double sum = part_val[q];
+			for (uint32_t r = q + 1; r < pe && part_key[r] == key; ++r) sum += part_val[r];
+			s_add[key - (uint32_t)i0] = sum;
 		}
 		__syncthreads();
 	}

@@ -100,3 +100,51 @@ def test_one_two_three_features(ctx, nf):
 def test_other_modes_on_the_mixed_pools(ctx, multi):
     rng = np.random.default_rng(3)
     check(ctx, mixed_pools(rng), 4096, multi=multi)
+
+
+def test_convergence_decision_next_to_the_threshold(ctx):
+    """msam_profile.c:383 stops when DELTA^2 = sum(diff^2) / n_features < 1e-10.  The device adds the same
+    numbers in another order (and a * sum(w/S) instead of sum(a/S)), so its DELTA^2 differs from the
+    reference's in the last bits -- about 1e-26 absolute here.  Policy: the decision must be the
+    reference's whenever DELTA^2 is farther than that from 1e-10.  n_features only divides the sum
+    (references without inserts add nothing to it), so the number of features F* at which the decision
+    of one iteration flips is found with the oracle by bisection: at F* the loop stops at iteration k,
+    at F* - 1 it runs one more, and the two DELTA^2 values straddle 1e-10 by less than 1e-13."""
+    import msamtools_amd as m
+    refs = 3000
+    hs = m.HostSynth(97531, 200000, refs, 1)     # converges at iteration 16 with n_features = refs
+    goff = m.profile_pools(hs)
+
+    def orc_iters(nf):
+        st = orc.run_profile(hs, nf, multi="proportional")["stats"]
+        return st.iterations, st.converged, st.last_delta
+
+    k0, conv0, _ = orc_iters(refs)
+    assert conv0 and 3 <= k0 <= 19
+    lo, hi = refs, 64 * refs                    # iterations(lo) == k0, iterations(hi) < k0
+    assert orc_iters(hi)[0] < k0
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if orc_iters(mid)[0] < k0:
+            hi = mid
+        else:
+            lo = mid
+    f_star = hi
+    (k_a, c_a, d_a), (k_b, c_b, d_b) = orc_iters(f_star), orc_iters(f_star - 1)
+    assert (k_a, c_a) == (k0 - 1, 1) and (k_b, c_b) == (k0, 1)
+    # DELTA^2 of iteration k0 - 1 on either side of the threshold: d_a below it, N / (F* - 1) at or above it
+    above = d_a * f_star / (f_star - 1)
+    assert d_a < 1e-10 <= above and above - d_a < 1e-13
+    batch = m.DeviceBatch.upload(ctx, hs, goff)
+    try:
+        for nf, want_k, want_d in ((f_star, k_a, d_a), (f_star - 1, k_b, d_b)):
+            prof = m.Profile(ctx, nf, "proportional")
+            prof.accumulate(batch, None)
+            ab, st = prof.finalize()
+            assert (st.iterations, st.converged) == (want_k, 1), (nf, st.iterations, want_k)
+            assert abs(st.delta[want_k] - want_d) <= 1e-9 * want_d
+            ref = orc.run_profile(hs, nf, multi="proportional")
+            assert (np.abs(ab - ref["abundance"]) <= 1e-6 * np.maximum(np.abs(ref["abundance"]), 1e-300)).all()
+            prof.close()
+    finally:
+        batch.free()
