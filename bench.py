@@ -73,6 +73,16 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def exchange_comm_id(m, rank, world):
     """The RCCL communicator id, made on rank 0, to every rank: through the launcher's key-value store
     (torchrun hosts one on MASTER_ADDR:MASTER_PORT) or, failing that, the library's own TCP rendezvous

@@ -114,7 +114,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p,
-	                p->recip.p, p->pstart.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p,
+	                p->recip.p, p->runs.p, p->owned.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p,
 	                p->head.p, p->uidx.p, p->eoff.p, p->hpos.p, p->d_tot,
 	                p->t_val64[0].p, p->t_val64[1].p, p->gl_idx.p};
 	for (void *q : ptrs)
@@ -143,7 +143,7 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	          hipMalloc((void **)&p->iter_state, 4 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->csr_tot, 2 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->d_tot, 4 * 8) == hipSuccess &&
-	          hipMalloc((void **)&p->partial, (size_t)(msx_apply_blocks(n_features) + 8) * 8) == hipSuccess &&
+	          hipMalloc((void **)&p->partial, (size_t)(msx_apply_blocks(n_features) + 2 * msx_share_waves(ctx) / MSX_BLOCK + 16) * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->purged_local, 4) == hipSuccess;
 	if (ok && share_type == MSX_MULTI_SHARE_EQUAL) ok = hipMalloc((void **)&p->d, nf * 8) == hipSuccess;
 	if (ok && fmap && n_targets > 0) {

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(const unsigned long
 #define SR_SENT 0xffffffffu
 #define SR_EPL 8                       // consecutive entries summed by one lane
 #define SR_STEP (64 * SR_EPL)          // entries per wave step
-#define SR_WAVES_PER_SIMD 4            // what the kernel's registers allow (126 VGPRs): the launch is ONE round of waves
+#define SR_WAVES_PER_SIMD 3            // the kernel is held to 168 registers: the launch is ONE round of waves
 
 struct SegRow {
 	double v;         // after seg_scan: inclusive segmented sum
@@ -647,7 +647,8 @@ __device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
 	return (per + SR_STEP - 1) / SR_STEP * SR_STEP;
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
+__global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(SR_WAVES_PER_SIMD, SR_WAVES_PER_SIMD)))
+void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
                                                             const double *__restrict__ recip,
@@ -715,19 +716,41 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders:
 		// their S can differ in the last bit, 1e-16 relative; ordering them costs a third of this
 		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  General lists: recip[u].
+		// A lane's 8 consecutive entries mostly share their feature (sorted by feature) and often their
+		// other features too (one family of references): an index equal to the previous entry's is not
+		// fetched again -- the gathers, one cache-line lookup per active lane, are what this kernel waits for.
 		double x[SR_EPL];
 		{
+			const uint32_t NONE = 0xffffffffu;
+			// index q (0 = own: a feature, or with bit 31 a general list's number; 1..3 = the others) of entry i,
+			// recomputed where it is needed instead of held in 32 registers
+			auto idx = [&](int i, int q) -> uint32_t {
+				if (k[i] == SR_SENT) return NONE;
+				const bool general = (lv[i] & SIG_HASHED) != 0;
+				if (q == 0) return general ? (0x80000000u | (uint32_t)lv[i]) : (k[i] & fmask);
+				const uint32_t o = (uint32_t)((lv[i] >> (21 * (q - 1))) & SIG_PAD);
+				return (general || o == SIG_PAD) ? NONE : o;
+			};
 			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
-				const bool live = k[i] != SR_SENT;
-				const bool general = (lv[i] & SIG_HASHED) != 0;
-				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
-				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
-				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
-				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
-				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
+				const uint32_t j0 = idx(i, 0), j1 = idx(i, 1), j2 = idx(i, 2), j3 = idx(i, 3);
+				const bool n0 = j0 != NONE && (i == 0 || j0 != idx(i - 1, 0));
+				const bool n1 = j1 != NONE && (i == 0 || j1 != idx(i - 1, 1));
+				const bool n2 = j2 != NONE && (i == 0 || j2 != idx(i - 1, 2));
+				const bool n3 = j3 != NONE && (i == 0 || j3 != idx(i - 1, 3));
+				af[i] = !n0 ? 0.0 : (j0 & 0x80000000u) ? recip[j0 & 0x7fffffffu] : a[j0];
+				a1[i] = n1 ? a[j1] : 0.0;
+				a2[i] = n2 ? a[j2] : 0.0;
+				a3[i] = n3 ? a[j3] : 0.0;
+			}
+#pragma unroll
+			for (int i = 1; i < SR_EPL; i++) {
+				const uint32_t j0 = idx(i, 0), j1 = idx(i, 1), j2 = idx(i, 2), j3 = idx(i, 3);
+				if (j0 != NONE && j0 == idx(i - 1, 0)) af[i] = af[i - 1];
+				if (j1 != NONE && j1 == idx(i - 1, 1)) a1[i] = a1[i - 1];
+				if (j2 != NONE && j2 == idx(i - 1, 2)) a2[i] = a2[i - 1];
+				if (j3 != NONE && j3 == idx(i - 1, 3)) a3[i] = a3[i - 1];
 			}
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
@@ -817,13 +840,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	}
 }
 
-// The keys of the partial slots -- they depend on the sorted entries and on W only, so they are set once
-// per build -- and, for k_prop_apply, the first slot whose key falls into each workgroup's feature range
-// (pstart[b] = lower bound of b * PA_FPB among the ascending keys; idle waves hold SR_SENT).
-#define PA_FPB 1024                    // features per workgroup of k_prop_apply
+// The keys of the partial slots depend on the sorted entries and on W only, so they are set once per
+// build (k_part_index), and so is what k_prop_apply needs to fold the slots into the update
+// (k_part_runs): the slots of one feature are neighbours (the keys ascend), a *run*; runs[] lists every
+// run as (feature, first slot, number of slots), and a bitmap marks the features that own one.
+#define PA_FPB 1024                    // features per streaming workgroup of k_prop_apply
 __device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t fmask) {
 	const int64_t c0 = (j >> 1) * per;
-	if (c0 >= E) return SR_SENT;
+	if (c0 >= E) return SR_SENT;          // idle wave
 	if (!(j & 1)) return t_key[c0] & fmask;
 	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
 	return t_key[c1 - 1] & fmask;
@@ -831,23 +855,46 @@ __device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t pe
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long long *__restrict__ csr_tot,
                                                           const uint32_t *__restrict__ t_key, int bits, int64_t W,
-                                                          int64_t n_apply_blocks, uint32_t *__restrict__ part_key,
-                                                          uint32_t *__restrict__ pstart) {
+                                                          uint32_t *__restrict__ part_key, unsigned long long *d_tot) {
 	const int64_t E = (int64_t)csr_tot[1];
 	const int64_t per = sr_chunk(E, W);
 	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < 2 * W; j += stride)
 		part_key[j] = part_key_at(j, E, per, t_key, fmask);
-	for (int64_t b = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; b <= n_apply_blocks; b += stride) {
-		const uint64_t want = (uint64_t)b * PA_FPB;
-		int64_t lo = 0, hi = 2 * W;                // first j with key(j) >= want
-		while (lo < hi) {
-			const int64_t mid = (lo + hi) >> 1;
-			if ((uint64_t)part_key_at(mid, E, per, t_key, fmask) < want) lo = mid + 1; else hi = mid;
+	if (blockIdx.x == 0 && threadIdx.x == 0) d_tot[3] = 0;      // number of runs, counted by k_part_runs
+}
+
+struct PartRun {
+	uint32_t key, first, n, pad;
+};
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_part_runs(const uint32_t *__restrict__ part_key, int64_t M,
+                                                         PartRun *__restrict__ runs, uint32_t *__restrict__ owned,
+                                                         unsigned long long *d_tot) {
+	__shared__ uint32_t s_n, s_base;
+	__shared__ PartRun s_run[MSX_BLOCK];
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
+	const int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (j < M) {
+		const uint32_t key = part_key[j];
+		if (key != SR_SENT && (j == 0 || part_key[j - 1] != key)) {
+			int64_t lo = j + 1, hi = M;                 // first slot beyond the run (keys ascend)
+			while (lo < hi) {
+				const int64_t mid = (lo + hi) >> 1;
+				if (part_key[mid] <= key) lo = mid + 1; else hi = mid;
+			}
+			const PartRun r = {key, (uint32_t)j, (uint32_t)(lo - j), 0u};
+			s_run[atomicAdd(&s_n, 1u)] = r;
+			atomicOr(&owned[key >> 5], 1u << (key & 31u));
 		}
-		pstart[b] = (uint32_t)lo;
 	}
+	__syncthreads();
+	const uint32_t cnt = s_n;
+	if (threadIdx.x == 0 && cnt) s_base = (uint32_t)atomicAdd(&d_tot[3], (unsigned long long)cnt);
+	__syncthreads();
+	if (threadIdx.x < cnt) runs[s_base + threadIdx.x] = s_run[threadIdx.x];
 }
 
 // level 2: runs of equal feature ids among the boundary partials -> one add per run
@@ -886,56 +933,56 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 	if (lane == 0 && carry_open && carry_key != SR_SENT && carry != 0.0) atomicAdd(&share[carry_key], carry);
 }
 
-// a = U + a * share, clamp, DELTA^2, convergence (msam_profile.c:368-389).  A workgroup owns PA_FPB
-// consecutive features.  FUSED (single GPU, no collective inside the iteration): share[] holds the
-// segments k_share_reduce stored directly; the partial slots whose keys fall into the workgroup's
-// range are added here, run by run, in slot order (a fixed summation order: results repeat bit for
-// bit).  Not FUSED: share[] is complete (k_partial_reduce -- atomics -- and the caller's all-reduce
-// have run).  The workgroup that finishes last adds the per-workgroup sums of diff^2 in
-// index order and sets delta[k], the iteration count and the done flag -- no separate launch.
+// a = U + a * share, clamp, DELTA^2, convergence (msam_profile.c:368-389).  The first `nsb` workgroups
+// stream the features, PA_FPB each.  FUSED (single GPU, no collective inside the iteration): share[]
+// holds the segments k_share_reduce stored directly; a feature whose segment was cut by a chunk boundary
+// owns a run of partial slots instead -- the streaming workgroups leave those features (bitmap `owned`)
+// to the workgroups behind them, where one thread per run adds its slots in slot order (a fixed
+// summation order: results repeat bit for bit) and updates the feature.  Not FUSED: share[] is complete
+// (k_partial_reduce -- atomics -- and the caller's all-reduce have run).  The workgroup that finishes
+// last adds the per-workgroup sums of diff^2 in index order and sets delta[k], the iteration count and
+// the done flag -- no separate launch.
+__device__ __forceinline__ double prop_update(int64_t i, double sh, const double *U, double *a, double *share) {
+	const double old = a[i];
+	double v = U[i] + old * sh;
+	if (v < 1e-20) v = 0;
+	a[i] = v;
+	share[i] = 0.0;
+	const double diff = v - old;
+	return diff * diff;
+}
+
 template <bool FUSED>
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, const double *__restrict__ U,
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, const double *__restrict__ U,
                                                           double *__restrict__ share, double *__restrict__ a,
-                                                          const uint32_t *__restrict__ part_key,
+                                                          const unsigned long long *__restrict__ d_tot,
+                                                          const PartRun *__restrict__ runs,
                                                           const double *__restrict__ part_val,
-                                                          const uint32_t *__restrict__ pstart,
+                                                          const uint32_t *__restrict__ owned,
                                                           double *__restrict__ partial, double *__restrict__ delta,
                                                           int32_t *iter_state, int k) {
-	__shared__ double s_add[FUSED ? PA_FPB : 1];
 	__shared__ double s_w[MSX_BLOCK / 64];
 	__shared__ int s_last;
 	if (iter_state[0]) return;
-	const int64_t i0 = (int64_t)blockIdx.x * PA_FPB;
-	if (FUSED) {
-		for (int q = threadIdx.x; q < PA_FPB; q += MSX_BLOCK) s_add[q] = 0.0;
-		__syncthreads();
-		// the slots of one feature are neighbours (ascending keys): the thread that holds the first slot of
-		// a run adds the run, in slot order, and owns the feature's LDS cell -- no atomics, a fixed order.
-		// (The hot references of the first workgroups have runs of a few hundred slots.)
-		const uint32_t ps = pstart[blockIdx.x], pe = pstart[blockIdx.x + 1];
-		for (uint32_t q = ps + threadIdx.x; q < pe; q += MSX_BLOCK) {
-			const uint32_t key = part_key[q];
-			if (q > ps && part_key[q - 1] == key) continue;
-			double sum = part_val[q];
-			for (uint32_t r = q + 1; r < pe && part_key[r] == key; ++r) sum += part_val[r];
-			s_add[key - (uint32_t)i0] = sum;
-		}
-		__syncthreads();
-	}
 	double acc = 0;
+	if ((int)blockIdx.x < nsb) {
+		const int64_t i0 = (int64_t)blockIdx.x * PA_FPB;
 #pragma unroll
-	for (int q = 0; q < PA_FPB / MSX_BLOCK; q++) {
-		const int64_t i = i0 + q * MSX_BLOCK + threadIdx.x;
-		if (i < nf) {
-			const double old = a[i];
-			double sh = share[i];
-			if (FUSED) sh += s_add[q * MSX_BLOCK + threadIdx.x];
-			double v = U[i] + old * sh;
-			if (v < 1e-20) v = 0;
-			const double diff = v - old;
-			acc += diff * diff;
-			a[i] = v;
-			share[i] = 0.0;
+		for (int q = 0; q < PA_FPB / MSX_BLOCK; q++) {
+			const int64_t i = i0 + q * MSX_BLOCK + threadIdx.x;
+			if (i < nf) {
+				// (32 consecutive lanes read the same bitmap word)
+				if (FUSED && ((owned[i >> 5] >> (i & 31)) & 1u)) continue;
+				acc += prop_update(i, share[i], U, a, share);
+			}
+		}
+	} else if (FUSED) {
+		const int64_t r = (int64_t)((int)blockIdx.x - nsb) * MSX_BLOCK + threadIdx.x;
+		if (r < (int64_t)d_tot[3]) {
+			const PartRun R = runs[r];
+			double sum = 0;
+			for (uint32_t q = 0; q < R.n; ++q) sum += part_val[R.first + q];
+			acc = prop_update(R.key, share[R.key] + sum, U, a, share);
 		}
 	}
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
@@ -1065,7 +1112,8 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		const int64_t W = msx_share_waves(ctx);
 		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * W + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * W + 8) * 8))) return rc;
-		if ((rc = msx_reserve(ctx, &p->pstart, (size_t)(msx_apply_blocks(p->n_features) + 8) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->runs, (size_t)(2 * W + 8) * sizeof(PartRun)))) return rc;
+		if ((rc = msx_reserve(ctx, &p->owned, (size_t)(p->n_features / 32 + 8) * 4))) return rc;
 	}
 	const int64_t n_waves = ((eub > lub ? eub : lub) + RS_TILE - 1) / RS_TILE;
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
@@ -1133,14 +1181,17 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	                                       &cur)))
 		return rc;
 	p->sorted_buf = cur;
-	// (c) keys of the partial slots and where each k_prop_apply workgroup finds its own
+	// (c) keys of the partial slots, their runs, and the features that own one
 	{
-		const int64_t W = msx_share_waves(ctx), nba = msx_apply_blocks(p->n_features);
-		const int64_t items = 2 * W > nba + 1 ? 2 * W : nba + 1;
-		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
-		          hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, items, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W, nba,
-		                             (uint32_t *)p->part_key.p, (uint32_t *)p->pstart.p));
+		const int64_t W = msx_share_waves(ctx);
+		MSX_HIP(ctx, hipMemsetAsync(p->owned.p, 0, (size_t)(p->n_features / 32 + 1) * 4, ctx->stream));
+		msx_time_begin(ctx, MSX_K_LIST_ORDER);
+		hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, 2 * W, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W,
+		                   (uint32_t *)p->part_key.p, p->d_tot);
+		hipLaunchKernelGGL(k_part_runs, dim3((unsigned)((2 * W + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
+		msx_time_end(ctx);
 	}
 	p->transposed_valid = true;
 	MSX_HIP(ctx, hipGetLastError());
@@ -1180,18 +1231,19 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 
 int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused) {
 	const int32_t nf = p->n_features;
-	const unsigned g = (unsigned)msx_apply_blocks(nf);
+	const int nsb = (int)msx_apply_blocks(nf);
+	const int nrb = (int)((2 * msx_share_waves(ctx) + MSX_BLOCK - 1) / MSX_BLOCK);   // one thread per run at most
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	if (fused)
-		hipLaunchKernelGGL(k_prop_apply<true>, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
-		                   p->a, (const uint32_t *)p->part_key.p,
-		                   (const double *)p->part_val.p, (const uint32_t *)p->pstart.p, p->partial, p->delta,
-		                   p->iter_state, k);
+		hipLaunchKernelGGL(k_prop_apply<true>, dim3((unsigned)(nsb + nrb)), dim3(MSX_BLOCK), 0, ctx->stream, nf, nsb,
+		                   (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
+		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
+		                   p->partial, p->delta, p->iter_state, k);
 	else
-		hipLaunchKernelGGL(k_prop_apply<false>, dim3(g), dim3(MSX_BLOCK), 0, ctx->stream, nf, (const double *)p->U, p->share,
-		                   p->a, (const uint32_t *)p->part_key.p,
-		                   (const double *)p->part_val.p, (const uint32_t *)p->pstart.p, p->partial, p->delta,
-		                   p->iter_state, k);
+		hipLaunchKernelGGL(k_prop_apply<false>, dim3((unsigned)nsb), dim3(MSX_BLOCK), 0, ctx->stream, nf, nsb,
+		                   (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
+		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
+		                   p->partial, p->delta, p->iter_state, k);
 	msx_time_end(ctx);
 	return MSX_OK;
 }
