@@ -313,8 +313,9 @@ int  msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p);
  * accumulate records every M/=/X run as +1/-1 differences (D and N advance;
  * I, S, H, P do not; tid < 0 skipped); after the last batch
  * msx_coverage_finish() converts the buffer in place into per-base depths
- * (what mUpdateCoverageForAlignment builds by adding 1 per base).  Like the
- * reference, runs are assumed to stay inside their target (no bounds check). */
+ * (what mUpdateCoverageForAlignment builds by adding 1 per base).  The
+ * reference has no bounds check (a run past its target's end writes past that
+ * target's array); here such a run is cut at the target's ends. */
 int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
                              const int64_t *cov_off, int32_t n_targets, int32_t *cov,
                              uint8_t *covered /* device u8[n_targets] or NULL: global->covered[tid],

@@ -282,42 +282,112 @@ int64_t msh_aux2i(const uint8_t *s) {
 /* ------------------------------------------------------------------------ */
 /* threads                                                                    */
 /* ------------------------------------------------------------------------ */
+#define MSH_MAX_THREADS 128
 int msh_threads(void) {
 	static int cached = 0;
 	if (!cached) {
 		const char *e = getenv("MSX_THREADS");
 		long n = e ? strtol(e, NULL, 10) : sysconf(_SC_NPROCESSORS_ONLN);
 		if (n < 1) n = 1;
-		if (n > 64) n = 64;
+		if (!e && n > 96) n = 96;           /* beyond that the stages of this pipeline stop gaining */
+		if (n > MSH_MAX_THREADS) n = MSH_MAX_THREADS;
 		cached = (int)n;
 	}
 	return cached;
 }
 
-typedef struct {
+/* A persistent pool: the pipeline calls msh_parallel thousands of times per file, from several
+ * stage threads at once.  A job is a counter of thread slots; workers and the caller itself claim
+ * slots until none are left, the caller then waits for the stragglers. */
+typedef struct pf_job {
 	msh_pf fn;
 	void *arg;
-	int tid, nth;
+	int nth;
+	int next;                 /* next unclaimed slot (under pool.mu) */
+	int done;                 /* finished slots (under pool.mu) */
+	pthread_cond_t fin;
+	struct pf_job *link;
 } pf_job;
 
-static void *pf_thunk(void *p) {
-	pf_job *j = (pf_job *)p;
-	j->fn(j->arg, j->tid, j->nth);
+static struct {
+	pthread_mutex_t mu;
+	pthread_cond_t work;
+	pf_job *head, *tail;      /* jobs with unclaimed slots */
+	int started;
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, NULL, 0};
+
+static void pool_run_slot(pf_job *j, int slot) {     /* called without the lock */
+	j->fn(j->arg, slot, j->nth);
+	pthread_mutex_lock(&pool.mu);
+	if (++j->done == j->nth) pthread_cond_signal(&j->fin);
+	pthread_mutex_unlock(&pool.mu);
+}
+
+static void *pool_worker(void *unused) {
+	(void)unused;
+	pthread_mutex_lock(&pool.mu);
+	for (;;) {
+		pf_job *j;
+		int slot;
+		while (!pool.head) pthread_cond_wait(&pool.work, &pool.mu);
+		j = pool.head;
+		slot = j->next++;
+		if (j->next == j->nth) {             /* fully claimed: off the list */
+			pool.head = j->link;
+			if (!pool.head) pool.tail = NULL;
+		}
+		pthread_mutex_unlock(&pool.mu);
+		pool_run_slot(j, slot);
+		pthread_mutex_lock(&pool.mu);
+	}
 	return NULL;
 }
 
-void msh_parallel(int nth, msh_pf fn, void *arg) {
-	pthread_t th[64];
-	pf_job job[64];
-	int i;
-	if (nth > 64) nth = 64;
-	if (nth <= 1) { fn(arg, 0, 1); return; }
-	for (i = 1; i < nth; i++) {
-		job[i].fn = fn; job[i].arg = arg; job[i].tid = i; job[i].nth = nth;
-		if (pthread_create(&th[i], NULL, pf_thunk, &job[i]) != 0) mDie("pthread_create failed");
+static void pool_start(void) {
+	int i, n = msh_threads() - 1;
+	pool.started = 1;
+	for (i = 0; i < n; i++) {
+		pthread_t th;
+		pthread_attr_t at;
+		pthread_attr_init(&at);
+		pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+		if (pthread_create(&th, &at, pool_worker, NULL) != 0) mDie("pthread_create failed");
+		pthread_attr_destroy(&at);
 	}
-	fn(arg, 0, nth);
-	for (i = 1; i < nth; i++) pthread_join(th[i], NULL);
+}
+
+void msh_parallel(int nth, msh_pf fn, void *arg) {
+	pf_job job;
+	if (nth > MSH_MAX_THREADS) nth = MSH_MAX_THREADS;
+	if (nth <= 1) { fn(arg, 0, 1); return; }
+	job.fn = fn; job.arg = arg; job.nth = nth; job.next = 1; job.done = 0; job.link = NULL;   /* slot 0 is the caller's */
+	pthread_cond_init(&job.fin, NULL);
+	pthread_mutex_lock(&pool.mu);
+	if (!pool.started) pool_start();
+	if (pool.tail) pool.tail->link = &job; else pool.head = &job;
+	pool.tail = &job;
+	pthread_cond_broadcast(&pool.work);
+	pthread_mutex_unlock(&pool.mu);
+	pool_run_slot(&job, 0);
+	/* help with whatever of this job is still unclaimed, then wait for the rest */
+	pthread_mutex_lock(&pool.mu);
+	while (job.next < job.nth) {
+		int slot = job.next++;
+		if (job.next == job.nth) {
+			pf_job **pp = &pool.head, *prev = NULL;
+			while (*pp && *pp != &job) { prev = *pp; pp = &(*pp)->link; }
+			if (*pp == &job) {
+				*pp = job.link;
+				if (pool.tail == &job) pool.tail = prev;
+			}
+		}
+		pthread_mutex_unlock(&pool.mu);
+		pool_run_slot(&job, slot);
+		pthread_mutex_lock(&pool.mu);
+	}
+	while (job.done < job.nth) pthread_cond_wait(&job.fin, &pool.mu);
+	pthread_mutex_unlock(&pool.mu);
+	pthread_cond_destroy(&job.fin);
 }
 
 /* ------------------------------------------------------------------------ */

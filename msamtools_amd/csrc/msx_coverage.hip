@@ -7,10 +7,20 @@
 // of every M/=/X run.  Here a run [p, p+w) is recorded as +1 at p and -1 at p+w
 // in the per-base vector (two integer atomics per run instead of w), and
 // msx_coverage_finish() turns the differences into depths with one in-place
-// inclusive prefix sum over the concatenated targets.  A run that stays inside
-// its target leaves the running sum at 0 at every target boundary, so one scan
-// over all targets is exact (int32 wrap-around identical to counting).
+// inclusive prefix sum over the concatenated targets.  Runs are cut at their
+// target's ends (cov_add_run), so the running sum is 0 at every target boundary and
+// one scan over all targets is exact (int32 wrap-around identical to counting).
 // ---------------------------------------------------------------------------
+// +1 at the first base of a run, -1 behind its last.  The reference adds per base with no bounds check
+// (a record reaching past its target's end writes past the target's array there); here the run is cut
+// at the target's ends, so that a malformed record cannot shift the depths of the targets behind it --
+// inside the target the depths are the reference's.
+__device__ __forceinline__ void cov_add_run(int32_t *c, int64_t s, int64_t e, int64_t t_len) {
+	if (s < 0) s = 0;
+	if (e > t_len) e = t_len;
+	if (e > s) { atomicAdd(&c[s], 1); atomicAdd(&c[e], -1); }
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const int32_t *__restrict__ tid,
                                                                const int32_t *__restrict__ pos,
                                                                const uint32_t *__restrict__ cigar_off,
@@ -23,7 +33,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 		const int32_t t = tid[i];
 		if (t < 0) continue;                                   // :42
 		if (covered) covered[t] = 1;                           // :45-49 (same value from every lane)
-		int32_t *c = diff + cov_off[t];
+		const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
+		int32_t *c = diff + t_beg;
 		int64_t p = pos[i];
 		const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
 		int64_t run_start = -1;                                // adjacent M/=/X runs merge into one interval
@@ -34,14 +45,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 				p += w;
 			} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
 				if (run_start >= 0 && w > 0) {
-					if (p > run_start) { atomicAdd(&c[run_start], 1); atomicAdd(&c[p], -1); }
+					cov_add_run(c, run_start, p, t_len);
 					run_start = -1;
 				}
 				p += w;
 			}
 			// I, S, H, P and unknown ops: no reference bases, the covered interval continues
 		}
-		if (run_start >= 0 && p > run_start) { atomicAdd(&c[run_start], 1); atomicAdd(&c[p], -1); }
+		if (run_start >= 0) cov_add_run(c, run_start, p, t_len);
 	}
 }
 

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(const unsigned long
 #define SR_SENT 0xffffffffu
 #define SR_EPL 8                       // consecutive entries summed by one lane
 #define SR_STEP (64 * SR_EPL)          // entries per wave step
-#define SR_WAVES_PER_SIMD 3            // the kernel is held to 168 registers: the launch is ONE round of waves
+#define SR_WAVES_PER_SIMD 3            // 126 registers would allow 4; 3 measured faster (52 us against 55): ONE round of waves
 
 struct SegRow {
 	double v;         // after seg_scan: inclusive segmented sum
@@ -647,8 +647,7 @@ __device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
 	return (per + SR_STEP - 1) / SR_STEP * SR_STEP;
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(SR_WAVES_PER_SIMD, SR_WAVES_PER_SIMD)))
-void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
+__global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
                                                             const double *__restrict__ recip,
@@ -716,41 +715,21 @@ void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
 		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders:
 		// their S can differ in the last bit, 1e-16 relative; ordering them costs a third of this
 		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  General lists: recip[u].
-		// A lane's 8 consecutive entries mostly share their feature (sorted by feature) and often their
-		// other features too (one family of references): an index equal to the previous entry's is not
-		// fetched again -- the gathers, one cache-line lookup per active lane, are what this kernel waits for.
 		double x[SR_EPL];
 		{
-			const uint32_t NONE = 0xffffffffu;
-			// index q (0 = own: a feature, or with bit 31 a general list's number; 1..3 = the others) of entry i,
-			// recomputed where it is needed instead of held in 32 registers
-			auto idx = [&](int i, int q) -> uint32_t {
-				if (k[i] == SR_SENT) return NONE;
-				const bool general = (lv[i] & SIG_HASHED) != 0;
-				if (q == 0) return general ? (0x80000000u | (uint32_t)lv[i]) : (k[i] & fmask);
-				const uint32_t o = (uint32_t)((lv[i] >> (21 * (q - 1))) & SIG_PAD);
-				return (general || o == SIG_PAD) ? NONE : o;
-			};
+			// (fetching an index only when it differs from the previous entry's -- a lane's 8 entries mostly
+			// share their feature -- measured slower: 67 us against 55; the selects cost more than the lanes saved)
 			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
-				const uint32_t j0 = idx(i, 0), j1 = idx(i, 1), j2 = idx(i, 2), j3 = idx(i, 3);
-				const bool n0 = j0 != NONE && (i == 0 || j0 != idx(i - 1, 0));
-				const bool n1 = j1 != NONE && (i == 0 || j1 != idx(i - 1, 1));
-				const bool n2 = j2 != NONE && (i == 0 || j2 != idx(i - 1, 2));
-				const bool n3 = j3 != NONE && (i == 0 || j3 != idx(i - 1, 3));
-				af[i] = !n0 ? 0.0 : (j0 & 0x80000000u) ? recip[j0 & 0x7fffffffu] : a[j0];
-				a1[i] = n1 ? a[j1] : 0.0;
-				a2[i] = n2 ? a[j2] : 0.0;
-				a3[i] = n3 ? a[j3] : 0.0;
-			}
-#pragma unroll
-			for (int i = 1; i < SR_EPL; i++) {
-				const uint32_t j0 = idx(i, 0), j1 = idx(i, 1), j2 = idx(i, 2), j3 = idx(i, 3);
-				if (j0 != NONE && j0 == idx(i - 1, 0)) af[i] = af[i - 1];
-				if (j1 != NONE && j1 == idx(i - 1, 1)) a1[i] = a1[i - 1];
-				if (j2 != NONE && j2 == idx(i - 1, 2)) a2[i] = a2[i - 1];
-				if (j3 != NONE && j3 == idx(i - 1, 3)) a3[i] = a3[i - 1];
+				const bool live = k[i] != SR_SENT;
+				const bool general = (lv[i] & SIG_HASHED) != 0;
+				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
+				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
+				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
+				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
+				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
+				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
 			}
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
@@ -845,6 +824,7 @@ void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
 // (k_part_runs): the slots of one feature are neighbours (the keys ascend), a *run*; runs[] lists every
 // run as (feature, first slot, number of slots), and a bitmap marks the features that own one.
 #define PA_FPB 1024                    // features per streaming workgroup of k_prop_apply
+#define PA_SHORT 8                     // slots one lane adds by itself
 __device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t fmask) {
 	const int64_t c0 = (j >> 1) * per;
 	if (c0 >= E) return SR_SENT;          // idle wave
@@ -977,13 +957,28 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, c
 			}
 		}
 	} else if (FUSED) {
+		// one lane per run; a run of more than PA_SHORT slots (a hot reference cut by hundreds of chunk
+		// boundaries) is added by the whole wave, lane-strided and then lane by lane: a fixed order too
+		const int lane = threadIdx.x & 63;
 		const int64_t r = (int64_t)((int)blockIdx.x - nsb) * MSX_BLOCK + threadIdx.x;
-		if (r < (int64_t)d_tot[3]) {
-			const PartRun R = runs[r];
-			double sum = 0;
+		const bool have = r < (int64_t)d_tot[3];
+		PartRun R = {0u, 0u, 0u, 0u};
+		if (have) R = runs[r];
+		double sum = 0;
+		if (have && R.n <= PA_SHORT)
 			for (uint32_t q = 0; q < R.n; ++q) sum += part_val[R.first + q];
-			acc = prop_update(R.key, share[R.key] + sum, U, a, share);
+		unsigned long long longs = __ballot(have && R.n > PA_SHORT);
+		while (longs) {
+			const int src = __ffsll((long long)longs) - 1;
+			longs &= longs - 1ull;
+			const uint32_t first = (uint32_t)__shfl((int)R.first, src, 64), n = (uint32_t)__shfl((int)R.n, src, 64);
+			double part = 0;
+			for (uint32_t q = (uint32_t)lane; q < n; q += 64u) part += part_val[first + q];
+			double tot = 0;
+			for (int l = 0; l < 64; l++) tot += __shfl(part, l, 64);     // lane order, every lane computes the same total
+			if (lane == src) sum = tot;
 		}
+		if (have) acc = prop_update(R.key, share[R.key] + sum, U, a, share);
 	}
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
@@ -1321,6 +1316,8 @@ extern "C" int msx_profile_prop_apply_enqueue(msx_ctx *ctx, msx_profile *p) {
 
 extern "C" int msx_profile_prop_purged_enqueue(msx_ctx *ctx, msx_profile *p, uint32_t **purged_dev) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun || (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL && !p->transposed_valid))
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_purged_enqueue before msx_profile_prop_begin");
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	msx_prop_purged_launch(ctx, p, p->purged_local);
 	if (purged_dev) *purged_dev = p->purged_local;
@@ -1330,6 +1327,8 @@ extern "C" int msx_profile_prop_purged_enqueue(msx_ctx *ctx, msx_profile *p, uin
 
 extern "C" int msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *purged_local) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun || (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL && !p->transposed_valid))
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_purged before msx_profile_prop_begin");
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	msx_prop_purged_launch(ctx, p, p->purged_local);
 	MSX_HIP(ctx, hipGetLastError());
