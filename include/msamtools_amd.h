@@ -154,11 +154,33 @@ int  msx_ctx_sync(msx_ctx *ctx);
 
 /* ---- batches ------------------------------------------------------------- */
 
-/* Copies a host batch into device memory owned by the ctx; *dev receives the
- * device-pointer view.  Free with msx_batch_free.  (The pinned-buffer +
- * hipMemcpyAsync path the host pipeline uses.) */
+/* Copies a host batch into freshly allocated device memory; *dev receives the
+ * device-pointer view.  Synchronous (pageable source, one allocation per array):
+ * the simple form, used by the tests.  Free with msx_batch_free. */
 int  msx_batch_upload(msx_ctx *ctx, const msx_batch *host, msx_batch *dev);
 void msx_batch_free(msx_ctx *ctx, msx_batch *dev);
+
+/* The streaming form the command line uses (counterpart of mSamRead handing
+ * record after record to the loops of msam_filter.c:119 / msam_profile.c:222,
+ * msam_helper.c:246-268): a *stage* is a set of device buffers that is reused
+ * batch after batch -- no allocation, no synchronisation per batch.
+ * msx_stage_upload enqueues hipMemcpyAsync copies on the ctx stream; they are
+ * true DMA transfers that overlap the host's work on the next batch when the
+ * host arrays are page-locked: allocate them with msx_host_alloc, or pin
+ * existing memory with msx_host_register.  The host arrays must stay untouched
+ * until the stream has passed the copies (msx_filter_finish / msx_ctx_sync).
+ * msx_stage_outputs hands out the stage's keep / emit_idx / as_out buffers. */
+typedef struct msx_stage msx_stage;
+int  msx_stage_create(msx_ctx *ctx, msx_stage **stage);
+void msx_stage_destroy(msx_ctx *ctx, msx_stage *stage);
+int  msx_stage_upload(msx_ctx *ctx, msx_stage *stage, const msx_batch *host, msx_batch *dev);
+int  msx_stage_outputs(msx_ctx *ctx, msx_stage *stage, int64_t n_records, int want_as_out, msx_filter_out *out);
+int  msx_host_alloc(msx_ctx *ctx, void **ptr, size_t bytes);     /* hipHostMalloc */
+void msx_host_free(msx_ctx *ctx, void *ptr);
+int  msx_host_register(msx_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegister: pins memory the caller owns */
+int  msx_host_unregister(msx_ctx *ctx, void *ptr);
+/* asynchronous device -> host copy on the ctx stream (host memory should be page-locked) */
+int  msx_dev_to_host_async(msx_ctx *ctx, void *host, const void *dev, size_t bytes);
 
 /* ---- filter: replaces mFilterFileWrapper/mFilterFile + writers ----------- */
 

@@ -79,6 +79,15 @@ SYMBOLS = {
     "msx_ctx_sync": (C.c_int, [_P]),
     "msx_batch_upload": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Batch)]),
     "msx_batch_free": (None, [_P, C.POINTER(Batch)]),
+    "msx_stage_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "msx_stage_destroy": (None, [_P, _P]),
+    "msx_stage_upload": (C.c_int, [_P, _P, C.POINTER(Batch), C.POINTER(Batch)]),
+    "msx_stage_outputs": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.POINTER(FilterOut)]),
+    "msx_host_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
+    "msx_host_free": (None, [_P, _P]),
+    "msx_host_register": (C.c_int, [_P, _P, C.c_size_t]),
+    "msx_host_unregister": (C.c_int, [_P, _P]),
+    "msx_dev_to_host_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),
     "msx_filter_finish": (C.c_int, [_P, C.POINTER(FilterStatus)]),
     "msx_aln_stats": (C.c_int, [_P, C.POINTER(Batch), _P, _P, _P, _P, _P]),

@@ -85,6 +85,8 @@ int msh_is_bam(const msh_in *in);
 int msh_span_fill(msh_in *in);                        /* inflate the next batch of blocks; 0 at EOF */
 const uint8_t *msh_span(msh_in *in, size_t *len);     /* unconsumed bytes; invalidated by msh_span_fill */
 void msh_span_consume(msh_in *in, size_t n);
+/* pipelined reader: inflate the next batch of blocks onto the end of a caller-owned buffer; 0 at EOF */
+size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
 
 /* ---- threads ------------------------------------------------------------------ */
 int msh_threads(void);                                 /* MSX_THREADS or the online CPU count, <= 64 */

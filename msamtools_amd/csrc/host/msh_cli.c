@@ -381,6 +381,18 @@ static void pack_scan(void *arg, int tid, int nth) {
 	pack_job *J = (pack_job *)arg;
 	rbatch *b = J->b;
 	size_t lo = J->n * (size_t)tid / (size_t)nth, hi = J->n * (size_t)(tid + 1) / (size_t)nth, i;
+	/* QNAME of the nearest earlier record that counts for the pool rule (mapped for filter, tid != -1 for
+	 * profile): found once by walking back from this thread's first record, then carried forward */
+	const char *pn = NULL;
+	if (J->mode != 0) {
+		size_t j = lo;
+		while (j > 0) {
+			const uint8_t *pr = J->base + b->rec_off[j - 1] + 4;
+			if (J->mode == 1 ? !(REC_FLAG(pr) & 4) : (REC_TID(pr) != -1)) { pn = REC_QNAME(pr); break; }
+			j--;
+		}
+		if (!pn) pn = J->carry_name;
+	}
 	for (i = lo; i < hi; i++) {
 		const uint8_t *r = J->base + b->rec_off[i] + 4;
 		size_t len = b->rec_off[i + 1] - b->rec_off[i] - 4;
@@ -406,19 +418,10 @@ static void pack_scan(void *arg, int tid, int nth) {
 			b->cigar_off[i + 1] = 0;
 			b->md_off[i + 1] = 0;
 		}
-		if (J->mode == 1 || (J->mode == 2 && REC_TID(r) != -1)) {
-			/* QNAME of the nearest earlier record that counts for the rule */
-			const char *pn = NULL;
-			size_t j = i;
-			while (j > 0) {
-				const uint8_t *pr = J->base + b->rec_off[j - 1] + 4;
-				if (J->mode == 1 ? !(REC_FLAG(pr) & 4) : (REC_TID(pr) != -1)) { pn = REC_QNAME(pr); break; }
-				j--;
-			}
-			if (!pn) pn = J->carry_name;
+		if (J->mode == 1 || (J->mode == 2 && REC_TID(r) != -1))
 			bd = (pn && strcmp(REC_QNAME(r), pn) != 0) ? 1 : 0;
-		}
 		b->bound[i] = bd;
+		if (J->mode == 1 ? !(REC_FLAG(r) & 4) : (J->mode == 2 && REC_TID(r) != -1)) pn = REC_QNAME(r);
 	}
 }
 

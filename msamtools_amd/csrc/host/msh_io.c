@@ -395,7 +395,7 @@ void msh_parallel(int nth, msh_pf fn, void *arg) {
 /* contiguous "span" of BAM bytes                                             */
 /* ------------------------------------------------------------------------ */
 #define BGZF_MAX 65536
-#define BGZF_BATCH 256
+#define BGZF_BATCH 1024
 
 typedef struct {
 	FILE *fp;
@@ -437,8 +437,8 @@ static void inflate_worker(void *arg, int tid, int nth) {
 	for (i = tid; i < b->nblk; i += nth) inflate_block(b, i);
 }
 
-/* read the next batch of raw blocks and append their inflated bytes to the span; 0 at EOF */
-static int bgz_fill(bgz_in *b) {
+/* read the next batch of raw blocks into cbuf; returns the number of bytes they inflate to (0 at EOF) */
+static size_t bgz_read_blocks(bgz_in *b) {
 	size_t off = 0, total = 0;
 	b->nblk = 0;
 	if (b->eof) return 0;
@@ -479,6 +479,12 @@ static int bgz_fill(bgz_in *b) {
 		b->coff[b->nblk] = off;
 		b->uoff[b->nblk] = total;
 	}
+	return total;
+}
+
+/* read the next batch of raw blocks and append their inflated bytes to the span; 0 at EOF */
+static int bgz_fill(bgz_in *b) {
+	size_t total = bgz_read_blocks(b);
 	if (b->nblk == 0) return 0;
 	/* make room: compact the unconsumed bytes to the front when that frees enough, else grow */
 	if (b->span_end + total > b->span_cap) {
@@ -765,6 +771,36 @@ const uint8_t *msh_span(msh_in *in, size_t *len) {
 }
 
 void msh_span_consume(msh_in *in, size_t n) { in->bz.span_beg += n; }
+
+/* The pipelined reader owns its batch buffers: append the inflated bytes of the next batch of blocks
+ * to *buf (grown as needed; *len bytes in use).  What msh_open left in the span goes first.  Returns the
+ * number of bytes appended, 0 at EOF. */
+size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
+	bgz_in *b = &in->bz;
+	size_t total, live = b->span_end - b->span_beg;
+	if (live) {
+		total = live;
+	} else {
+		total = bgz_read_blocks(b);
+		if (b->nblk == 0) return 0;
+	}
+	if (*len + total + 64 > *cap) {
+		size_t nc = *cap ? *cap : ((size_t)16 << 20);
+		while (nc < *len + total + 64) nc += nc >> 1;
+		*buf = (uint8_t *)realloc(*buf, nc);
+		if (!*buf) mDie("Out of memory");
+		*cap = nc;
+	}
+	if (live) {
+		memcpy(*buf + *len, b->span + b->span_beg, live);
+		b->span_beg = b->span_end = 0;
+	} else {
+		b->dst = *buf + *len;
+		msh_parallel(msh_threads() < b->nblk ? msh_threads() : b->nblk, inflate_worker, b);
+	}
+	*len += total;
+	return total;
+}
 
 msh_in *msh_open(const char *path) {
 	msh_in *in = (msh_in *)calloc(1, sizeof(*in));

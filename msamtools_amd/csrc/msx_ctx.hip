@@ -376,3 +376,110 @@ extern "C" int msx_batch_upload(msx_ctx *ctx, const msx_batch *h, msx_batch *d) 
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MSX_OK;
 }
+
+// ---- stages: device buffers reused batch after batch (the command line's streaming path) -------------
+struct msx_stage {
+	msx_buf arr[12];          // flag rflags tid pos cigar_off cigar md_off md nm as group_off qname_hash
+	msx_buf keep, emit, as_out;
+};
+
+extern "C" int msx_stage_create(msx_ctx *ctx, msx_stage **stage) {
+	if (!ctx || !stage) return MSX_ERR_ARG;
+	*stage = new msx_stage();
+	return MSX_OK;
+}
+
+extern "C" void msx_stage_destroy(msx_ctx *ctx, msx_stage *st) {
+	if (!st) return;
+	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	for (auto &b : st->arr) free_buf(&b);
+	free_buf(&st->keep);
+	free_buf(&st->emit);
+	free_buf(&st->as_out);
+	delete st;
+}
+
+template <typename T>
+static int stage_up(msx_ctx *ctx, msx_buf *buf, const T *src, size_t count, size_t pad_elems, const T **dst) {
+	*dst = nullptr;
+	if (!src) return MSX_OK;
+	int rc = msx_reserve(ctx, buf, (count + pad_elems) * sizeof(T) + 16);
+	if (rc) return rc;
+	*dst = (const T *)buf->p;
+	if (count) MSX_HIP(ctx, hipMemcpyAsync(buf->p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+	return MSX_OK;
+}
+
+extern "C" int msx_stage_upload(msx_ctx *ctx, msx_stage *st, const msx_batch *h, msx_batch *d) {
+	if (!ctx || !st || !h || !d) return MSX_ERR_ARG;
+	memset(d, 0, sizeof(*d));
+	const size_t n = (size_t)h->n_records;
+	if (h->n_records < 0 || h->n_records > 0x7fffffffLL)
+		return msx_fail(ctx, MSX_ERR_ARG, "batch of %lld records exceeds the 2^31-1 per-batch limit", (long long)h->n_records);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t n_cig = (n && h->cigar_off) ? h->cigar_off[n] : 0, n_md = (n && h->md_off) ? h->md_off[n] : 0;
+	d->n_records = h->n_records;
+	d->n_groups = h->group_off ? h->n_groups : 0;
+	int rc;
+#define UP(i, field, count, pad) if ((rc = stage_up(ctx, &st->arr[i], h->field, (count), (pad), &d->field)) != MSX_OK) return rc;
+	UP(0, flag, n, 2)
+	UP(1, rflags, n, 2)
+	UP(2, tid, n, 0)
+	UP(3, pos, n, 0)
+	UP(4, cigar_off, n + 1, 2)
+	UP(5, cigar, n_cig, 4)
+	UP(6, md_off, n + 1, 2)
+	UP(7, md, n_md, 16)
+	UP(8, nm, n, 0)
+	UP(9, as, n, 0)
+	UP(10, group_off, h->group_off ? (size_t)h->n_groups + 1 : 0, 0)
+	UP(11, qname_hash, n, 0)
+#undef UP
+	return MSX_OK;
+}
+
+extern "C" int msx_stage_outputs(msx_ctx *ctx, msx_stage *st, int64_t n_records, int want_as, msx_filter_out *out) {
+	if (!ctx || !st || !out || n_records < 0) return MSX_ERR_ARG;
+	const size_t n = (size_t)(n_records > 0 ? n_records : 1);
+	int rc;
+	if ((rc = msx_reserve(ctx, &st->keep, n + 16))) return rc;
+	if ((rc = msx_reserve(ctx, &st->emit, 4 * n + 16))) return rc;
+	if (want_as && (rc = msx_reserve(ctx, &st->as_out, 4 * n + 16))) return rc;
+	out->keep = (uint8_t *)st->keep.p;
+	out->emit_idx = (int32_t *)st->emit.p;
+	out->as_out = want_as ? (int32_t *)st->as_out.p : nullptr;
+	return MSX_OK;
+}
+
+extern "C" int msx_host_alloc(msx_ctx *ctx, void **ptr, size_t bytes) {
+	if (!ctx || !ptr) return MSX_ERR_ARG;
+	*ptr = nullptr;
+	hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault);
+	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+	return MSX_OK;
+}
+
+extern "C" void msx_host_free(msx_ctx *ctx, void *ptr) {
+	(void)ctx;
+	if (ptr) (void)hipHostFree(ptr);
+}
+
+extern "C" int msx_host_register(msx_ctx *ctx, void *ptr, size_t bytes) {
+	if (!ctx || !ptr || !bytes) return MSX_ERR_ARG;
+	hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_HIP, "hipHostRegister(%zu) failed: %s", bytes, hipGetErrorString(e));
+	return MSX_OK;
+}
+
+extern "C" int msx_host_unregister(msx_ctx *ctx, void *ptr) {
+	if (!ctx || !ptr) return MSX_ERR_ARG;
+	hipError_t e = hipHostUnregister(ptr);
+	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+	return MSX_OK;
+}
+
+extern "C" int msx_dev_to_host_async(msx_ctx *ctx, void *host, const void *dev, size_t bytes) {
+	if (!ctx) return MSX_ERR_ARG;
+	if (bytes) MSX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	return MSX_OK;
+}

@@ -983,22 +983,30 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, c
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	// ---- the last workgroup to arrive finishes the iteration (agent-scope release / acquire around a ticket)
+	// ---- the last workgroup to arrive finishes the iteration.  Hand-over by memory-side atomics only:
+	// the sum goes out with an atomic exchange, waited for before the ticket is drawn; the last
+	// workgroup reads the sums back with returning ORs of zero.  (A release fence per workgroup writes
+	// back the whole XCD L2 -- a[] and share[] just dirtied -- a thousand times per launch: 44 us.)
 	if (threadIdx.x == 0) {
-		partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const double mine = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+		unsigned long long bits;
+		__builtin_memcpy(&bits, &mine, 8);
+		(void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(partial) + blockIdx.x, bits, __ATOMIC_RELAXED,
+		                            __HIP_MEMORY_SCOPE_AGENT);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the exchange has been performed before the ticket is drawn
 		const int old = __hip_atomic_fetch_add(&iter_state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-		if (s_last) {
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
 	}
 	__syncthreads();
 	if (!s_last) return;
 	double tot = 0;
-	for (int i = threadIdx.x; i < (int)gridDim.x; i += MSX_BLOCK) tot += partial[i];
+	for (int i = threadIdx.x; i < (int)gridDim.x; i += MSX_BLOCK) {
+		const unsigned long long bits = __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(partial) + i, 0ull,
+		                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		double v;
+		__builtin_memcpy(&v, &bits, 8);
+		tot += v;
+	}
 	for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
 	__syncthreads();
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = tot;
