@@ -13,6 +13,7 @@
 #include "msh.h"
 
 #include <getopt.h>
+#include <pthread.h>
 #include <math.h>
 #include <time.h>
 #include <zlib.h>
@@ -520,6 +521,425 @@ static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int 
 	if (rd->eof && n_batch == n) rd->done = 1;
 }
 
+/* ------------------------------------------------------------------------ */
+/* The pipelined BAM path: decode | device | encode run as three stages on    */
+/* their own threads over a ring of batch slots, the parallel parts of every  */
+/* stage on the shared worker pool (counterpart of the loop msam_filter.c:    */
+/* 119-186 / msam_helper.c:246-272, whose read, compute and write are one     */
+/* thread).  A slot owns the inflated bytes of its batch, so the writer can   */
+/* still copy records out of batch i while batch i+1 is being decoded; the    */
+/* bytes of the pool left open at a batch's end are carried into the next.    */
+/* ------------------------------------------------------------------------ */
+#define PIPE_SLOTS 3
+
+typedef struct {
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	int item[PIPE_SLOTS + 2], n;
+} pq;
+static void pq_init(pq *q) { pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL); q->n = 0; }
+static void pq_push(pq *q, int v) {
+	pthread_mutex_lock(&q->mu);
+	q->item[q->n++] = v;
+	pthread_cond_signal(&q->cv);
+	pthread_mutex_unlock(&q->mu);
+}
+static int pq_pop(pq *q) {
+	int v, i;
+	pthread_mutex_lock(&q->mu);
+	while (q->n == 0) pthread_cond_wait(&q->cv, &q->mu);
+	v = q->item[0];
+	for (i = 1; i < q->n; i++) q->item[i - 1] = q->item[i];
+	q->n--;
+	pthread_mutex_unlock(&q->mu);
+	return v;
+}
+
+typedef struct {
+	rbatch b;                  /* fixed-capacity SoA (page-locked by the device stage) + rec_off; b.base = ubuf */
+	uint8_t *ubuf;             /* inflated BAM bytes of this batch */
+	size_t ulen, ucap;
+	int32_t *emit;             /* filter: indices of the records to write, in output order */
+	int64_t n_emit;
+	int eof;                   /* end-of-stream marker */
+	int pinned;
+} pslot;
+
+typedef struct {
+	msh_in *in;
+	const msh_hdr *hdr;
+	int mode, want_stats;      /* pool rule (0 none / 1 filter / 2 profile), cigar+md wanted */
+	size_t batch_bytes, cap_rec, cap_cig, cap_md;
+	pslot slot[PIPE_SLOTS];
+	pq q_free, q_dev, q_out;
+	/* decode state */
+	kstr carry;                /* bytes of the open pool (and of a cut record) left by the previous batch */
+	char prev_read[256];
+	int have_prev, in_eof, have_first;
+	size_t **seg_list, *seg_cnt, *seg_end, *seg_from, *seg_extra_n;
+	size_t **seg_extra;
+	int nseg_cap;
+	double t_decode, t_wait_free;
+} pipe_t;
+
+static size_t env_size(const char *name, size_t dflt) {
+	const char *e = getenv(name);
+	long long v = e ? strtoll(e, NULL, 10) : 0;
+	return v > 0 ? (size_t)v : dflt;
+}
+
+static void *xmalloc(size_t n) {
+	void *p = malloc(n ? n : 1);
+	if (!p) mDie("Out of memory");
+	return p;
+}
+
+static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats) {
+	int i;
+	memset(P, 0, sizeof *P);
+	P->in = in;
+	P->hdr = msh_header(in);
+	P->mode = mode;
+	P->want_stats = want_stats;
+	P->batch_bytes = env_size("MSX_BATCH_BYTES", (size_t)96 << 20);
+	P->cap_rec = env_size("MSX_BATCH_RECORDS", (size_t)3 << 20);
+	if (P->cap_rec < COORD_ORDER_CHECK_RECORDS + 1024) P->cap_rec = COORD_ORDER_CHECK_RECORDS + 1024;
+	P->cap_cig = want_stats ? 2 * P->cap_rec : 4;
+	P->cap_md = want_stats ? 16 * P->cap_rec : 16;
+	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out);
+	for (i = 0; i < PIPE_SLOTS; i++) {
+		pslot *s = &P->slot[i];
+		rbatch *b = &s->b;
+		const size_t c = P->cap_rec + 8;
+		b->cap = c;
+		b->rec_off = (size_t *)xmalloc((c + 1) * sizeof(size_t));
+		b->flag = (uint16_t *)xmalloc(c * 2);
+		b->rflags = (uint8_t *)xmalloc(c);
+		b->tid = (int32_t *)xmalloc(c * 4);
+		b->pos = (int32_t *)xmalloc(c * 4);
+		b->nm = (int32_t *)xmalloc(c * 4);
+		b->as = (int32_t *)xmalloc(c * 4);
+		b->cigar_off = (uint32_t *)xmalloc((c + 1) * 4);
+		b->md_off = (uint32_t *)xmalloc((c + 1) * 4);
+		b->md_rel = (uint32_t *)xmalloc(c * 4);
+		b->bound = (uint8_t *)xmalloc(c);
+		b->cigar_cap = P->cap_cig; b->cigar = (uint32_t *)xmalloc(b->cigar_cap * 4);
+		b->md_cap = P->cap_md; b->md = (uint8_t *)xmalloc(b->md_cap);
+		b->group_cap = c + 1; b->group_off = (uint32_t *)xmalloc(b->group_cap * 4);
+		s->emit = (int32_t *)xmalloc(c * 4);
+		pq_push(&P->q_free, i);
+	}
+}
+
+/* ---- record boundaries: a speculative parallel chase -------------------------------------------
+ * The block_size chain is serial by nature.  Here every worker guesses a record start near the
+ * beginning of its segment (a header that looks like one, followed by two more that do) and walks
+ * its segment from there; the segments are then stitched in order: where a worker's first offset
+ * is not the true one the stitcher walks on by itself until both chains meet (from any true start
+ * the chain is the true chain).  Guesses only decide how much of the walk ran in parallel. */
+static int chase_sloppy = -1;      /* MSX_CHASE_SLOPPY=1 (tests): accept almost anything as a record start, so that
+                                      most guesses are wrong and the stitcher has to repair them */
+static int rec_plausible(const uint8_t *u, size_t off, size_t len, int32_t nt) {
+	const uint8_t *r;
+	int32_t bs, tid, pos, mtid, mpos, ls;
+	uint32_t lq, nc, k;
+	if (off + 36 > len) return 0;
+	bs = le32(u + off);
+	if (bs < 32 || bs > (64 << 20)) return 0;
+	if (chase_sloppy < 0) chase_sloppy = getenv("MSX_CHASE_SLOPPY") != NULL;
+	if (chase_sloppy) return bs < 4096;
+	r = u + off + 4;
+	tid = REC_TID(r); pos = REC_POS(r); mtid = le32(r + 20); mpos = le32(r + 24);
+	if (tid < -1 || tid >= nt || mtid < -1 || mtid >= nt || pos < -1 || mpos < -1) return 0;
+	lq = REC_LQNAME(r); nc = REC_NCIGAR(r); ls = REC_LSEQ(r);
+	if (lq < 1 || ls < 0) return 0;
+	if (32ull + lq + 4ull * nc + ((uint64_t)ls + 1) / 2 + (uint64_t)ls > (uint64_t)bs) return 0;
+	if (off + 4 + 32 + lq > len) return 1;
+	if (r[32 + lq - 1] != 0) return 0;
+	for (k = 0; k + 1 < lq; k++)
+		if (r[32 + k] < 33 || r[32 + k] > 126) return 0;
+	return 1;
+}
+
+typedef struct {
+	pipe_t *P;
+	const uint8_t *u;
+	size_t len;
+	int nseg;
+} chase_job;
+
+static void chase_worker(void *arg, int k, int nth) {
+	chase_job *J = (chase_job *)arg;
+	pipe_t *P = J->P;
+	const uint8_t *u = J->u;
+	const size_t len = J->len, lo = len * (size_t)k / (size_t)J->nseg, hi = len * (size_t)(k + 1) / (size_t)J->nseg;
+	size_t off = lo, n = 0, *list = P->seg_list[k];
+	(void)nth;
+	if (k > 0) {
+		const int32_t nt = P->hdr->n_targets;
+		const size_t lim = lo + ((size_t)1 << 20) < hi ? lo + ((size_t)1 << 20) : hi;
+		int found = 0;
+		for (; off < lim; off++) {
+			size_t o2, o3;
+			if (!rec_plausible(u, off, len, nt)) continue;
+			o2 = off + 4 + (size_t)le32(u + off);
+			if (o2 + 36 <= len) {
+				if (!rec_plausible(u, o2, len, nt)) continue;
+				o3 = o2 + 4 + (size_t)le32(u + o2);
+				if (o3 + 36 <= len && !rec_plausible(u, o3, len, nt)) continue;
+			}
+			found = 1;
+			break;
+		}
+		if (!found) { P->seg_cnt[k] = 0; P->seg_end[k] = (size_t)-1; return; }
+	}
+	while (off < hi && off + 4 <= len) {
+		const int32_t bs = le32(u + off);
+		if (bs < 32 || off + 4 + (size_t)bs > len) break;      /* a cut record, or not a record at all (wrong guess) */
+		list[n++] = off;
+		off += 4 + (size_t)bs;
+	}
+	P->seg_cnt[k] = n;
+	P->seg_end[k] = off;
+}
+
+typedef struct {
+	pipe_t *P;
+	rbatch *b;
+	size_t *base;          /* first output index of every segment's part */
+	int nseg;
+} chase_copy_job;
+
+static void chase_copy_worker(void *arg, int k, int nth) {
+	chase_copy_job *J = (chase_copy_job *)arg;
+	pipe_t *P = J->P;
+	size_t o = J->base[k];
+	(void)nth;
+	if (P->seg_extra_n[k]) { memcpy(J->b->rec_off + o, P->seg_extra[k], P->seg_extra_n[k] * sizeof(size_t)); o += P->seg_extra_n[k]; }
+	if (P->seg_cnt[k] > P->seg_from[k])
+		memcpy(J->b->rec_off + o, P->seg_list[k] + P->seg_from[k], (P->seg_cnt[k] - P->seg_from[k]) * sizeof(size_t));
+}
+
+/* offsets of the complete records of u[0, len) into b->rec_off (at most max_rec of them);
+ * returns their number, *tail = offset of the first byte not covered by them */
+static size_t chase_records(pipe_t *P, rbatch *b, const uint8_t *u, size_t len, size_t max_rec, size_t *tail) {
+	int nseg = msh_threads(), k;
+	chase_job J;
+	chase_copy_job C;
+	size_t cur = 0, total = 0, *base;
+	if ((size_t)nseg > len / ((size_t)1 << 20) + 1) nseg = (int)(len / ((size_t)1 << 20) + 1);
+	if (nseg > P->nseg_cap) {
+		P->seg_list = (size_t **)realloc(P->seg_list, sizeof(size_t *) * (size_t)nseg);
+		P->seg_extra = (size_t **)realloc(P->seg_extra, sizeof(size_t *) * (size_t)nseg);
+		for (k = P->nseg_cap; k < nseg; k++) { P->seg_list[k] = NULL; P->seg_extra[k] = NULL; }
+		P->seg_cnt = (size_t *)realloc(P->seg_cnt, sizeof(size_t) * (size_t)nseg);
+		P->seg_end = (size_t *)realloc(P->seg_end, sizeof(size_t) * (size_t)nseg);
+		P->seg_from = (size_t *)realloc(P->seg_from, sizeof(size_t) * (size_t)nseg);
+		P->seg_extra_n = (size_t *)realloc(P->seg_extra_n, sizeof(size_t) * (size_t)nseg);
+		P->nseg_cap = nseg;
+	}
+	for (k = 0; k < nseg; k++) {
+		const size_t seg = len / (size_t)nseg + 2;
+		P->seg_list[k] = (size_t *)realloc(P->seg_list[k], (seg / 36 + 4) * sizeof(size_t));
+		P->seg_extra[k] = (size_t *)realloc(P->seg_extra[k], (seg / 36 + 4) * sizeof(size_t));
+		if (!P->seg_list[k] || !P->seg_extra[k]) mDie("Out of memory");
+	}
+	J.P = P; J.u = u; J.len = len; J.nseg = nseg;
+	msh_parallel(nseg, chase_worker, &J);
+	/* stitch */
+	base = (size_t *)xmalloc(sizeof(size_t) * (size_t)(nseg + 1));
+	for (k = 0; k < nseg; k++) {
+		const size_t hi = len * (size_t)(k + 1) / (size_t)nseg;
+		const size_t *list = P->seg_list[k];
+		const size_t cnt = P->seg_cnt[k];
+		size_t j = 0, ne = 0;
+		int joined = 0;
+		base[k] = total;
+		P->seg_extra_n[k] = 0;
+		P->seg_from[k] = cnt;
+		if (cur < hi) {
+			while (j < cnt && list[j] < cur) j++;
+			if (j < cnt && list[j] == cur) {
+				joined = 1;
+			} else {
+				/* the guess was off: walk from the true position until the chains meet */
+				while (cur < hi && cur + 4 <= len) {
+					const int32_t bs = le32(u + cur);
+					if (bs < 32) mDie("Corrupt BAM record (block_size %d)", bs);
+					if (cur + 4 + (size_t)bs > len) break;
+					P->seg_extra[k][ne++] = cur;
+					cur += 4 + (size_t)bs;
+					while (j < cnt && list[j] < cur) j++;
+					if (j < cnt && list[j] == cur) { joined = 1; break; }
+				}
+			}
+			P->seg_extra_n[k] = ne;
+			if (joined) { P->seg_from[k] = j; cur = P->seg_end[k]; }
+		}
+		total += ne + (P->seg_cnt[k] - P->seg_from[k]);
+	}
+	base[nseg] = total;
+	if (cur + 4 <= len) {                 /* the chain stopped inside the buffer: a cut record, or garbage */
+		const int32_t bs = le32(u + cur);
+		if (bs < 32) mDie("Corrupt BAM record (block_size %d)", bs);
+	}
+	*tail = cur;
+	if (total > max_rec) {
+		/* more records than a slot holds: keep the first max_rec (rare: only with very short records) */
+		size_t keep = max_rec, kk;
+		for (k = 0; k < nseg; k++) {
+			const size_t have = base[k + 1] - base[k];
+			if (base[k] >= keep) { P->seg_extra_n[k] = 0; P->seg_from[k] = P->seg_cnt[k]; continue; }
+			if (base[k] + have <= keep) continue;
+			kk = keep - base[k];               /* entries of this segment to keep */
+			if (kk <= P->seg_extra_n[k]) {
+				*tail = P->seg_extra[k][kk];     /* (kk < extra_n, or the first list entry follows) */
+				if (kk == P->seg_extra_n[k]) *tail = P->seg_list[k][P->seg_from[k]];
+				P->seg_extra_n[k] = kk; P->seg_cnt[k] = P->seg_from[k];
+			} else {
+				const size_t jj = P->seg_from[k] + (kk - P->seg_extra_n[k]);
+				*tail = P->seg_list[k][jj];
+				P->seg_cnt[k] = jj;
+			}
+		}
+		total = keep;
+	}
+	C.P = P; C.b = b; C.base = base; C.nseg = nseg;
+	msh_parallel(nseg, chase_copy_worker, &C);
+	b->rec_off[total] = *tail;
+	free(base);
+	return total;
+}
+
+/* one batch into slot s: returns the number of records (0 = end of stream) */
+static size_t pipe_fill(pipe_t *P, pslot *s) {
+	rbatch *b = &s->b;
+	size_t n = 0, tail = 0, n_batch, i;
+	pack_job J;
+	s->ulen = 0;
+	if (P->carry.l) {
+		if (P->carry.l + 64 > s->ucap) { s->ucap = P->carry.l + P->batch_bytes + 64; s->ubuf = (uint8_t *)realloc(s->ubuf, s->ucap); if (!s->ubuf) mDie("Out of memory"); }
+		memcpy(s->ubuf, P->carry.s, P->carry.l);
+		s->ulen = P->carry.l;
+		P->carry.l = 0;
+	}
+	for (;;) {
+		size_t want = P->batch_bytes;
+		while (!P->in_eof && s->ulen < want)
+			if (!msh_inflate_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
+		if (s->ulen == 0) return 0;
+		n = chase_records(P, b, s->ubuf, s->ulen, P->cap_rec, &tail);
+		if (P->in_eof && n < P->cap_rec && tail != s->ulen) mDie("Truncated BAM record");
+		if (!P->have_first && n < COORD_ORDER_CHECK_RECORDS && !P->in_eof) {   /* the preflight window (msam_helper.c:4-6) */
+			P->batch_bytes += P->batch_bytes;
+			continue;
+		}
+		if (n == 0) {
+			if (P->in_eof) return 0;
+			P->batch_bytes += P->batch_bytes;            /* a record larger than the batch: read on */
+			continue;
+		}
+		/* aux scan, SoA scalars, pool boundaries */
+		J.b = b; J.base = s->ubuf; J.n = n; J.mode = P->mode; J.want_stats = P->want_stats;
+		J.carry_name = P->have_prev ? P->prev_read : NULL;
+		msh_parallel(msh_threads(), pack_scan, &J);
+		n_batch = n;
+		if (P->mode != 0 && !(P->in_eof && tail == s->ulen && n < P->cap_rec)) {
+			size_t k = n;
+			while (k > 1 && !b->bound[k - 1]) k--;
+			n_batch = k - 1;
+			if (n_batch == 0) {          /* one pool fills the whole batch: take more bytes */
+				if (P->in_eof && tail == s->ulen) { n_batch = n; break; }
+				if (n >= P->cap_rec) mDie("A single QNAME group exceeds the batch capacity (%zu records); raise MSX_BATCH_RECORDS", P->cap_rec);
+				P->batch_bytes += P->batch_bytes / 2;
+				continue;
+			}
+		}
+		break;
+	}
+	/* offsets (serial prefix sums), cut where the payload arrays are full */
+	b->cigar_off[0] = 0;
+	b->md_off[0] = 0;
+	for (i = 0; i < n_batch; i++) {
+		b->cigar_off[i + 1] += b->cigar_off[i];
+		b->md_off[i + 1] += b->md_off[i];
+		if (b->cigar_off[i + 1] + 4 > b->cigar_cap || b->md_off[i + 1] + 16 > b->md_cap) {
+			size_t k = i + 1;
+			if (P->mode != 0) { while (k > 1 && !b->bound[k - 1]) k--; k--; }
+			else k = i;
+			if (k == 0) mDie("CIGAR/MD payload of one QNAME group exceeds the batch capacity; raise MSX_BATCH_RECORDS");
+			n_batch = k;
+			break;
+		}
+	}
+	if (P->mode != 0) {
+		b->n = 0;
+		b->n_groups = 0;
+		rb_mark_group(b);
+		for (i = 1; i < n_batch; i++)
+			if (b->bound[i]) { b->n = i; rb_mark_group(b); }
+	}
+	if (P->want_stats) {
+		J.n = n_batch;
+		msh_parallel(msh_threads(), pack_copy, &J);
+	}
+	b->n = n_batch;
+	b->base = s->ubuf;
+	P->have_first = 1;
+	for (i = n_batch; i > 0; i--) {       /* grouping state for the next batch */
+		const uint8_t *r = s->ubuf + b->rec_off[i - 1] + 4;
+		if (P->mode == 2 ? (REC_TID(r) != -1) : !(REC_FLAG(r) & 4)) {
+			strcpy(P->prev_read, REC_QNAME(r));
+			P->have_prev = 1;
+			break;
+		}
+	}
+	/* what lies behind the batch goes to the next one */
+	P->carry.l = 0;
+	if (b->rec_off[n_batch] < s->ulen) ks_put(&P->carry, s->ubuf + b->rec_off[n_batch], s->ulen - b->rec_off[n_batch]);
+	return n_batch;
+}
+
+static void *pipe_decode_thread(void *arg) {
+	pipe_t *P = (pipe_t *)arg;
+	for (;;) {
+		double t0 = now_s(), t1;
+		const int si = pq_pop(&P->q_free);
+		pslot *s = &P->slot[si];
+		size_t n;
+		t1 = now_s();
+		P->t_wait_free += t1 - t0;
+		n = pipe_fill(P, s);
+		P->t_decode += now_s() - t1;
+		s->eof = n == 0;
+		pq_push(&P->q_dev, si);
+		if (n == 0) return NULL;
+	}
+}
+
+/* page-lock the slot's SoA arrays once (they never move): uploads become asynchronous DMA */
+static void pipe_pin_slot(pipe_t *P, pslot *s) {
+	rbatch *b = &s->b;
+	const size_t c = b->cap;
+	if (s->pinned || getenv("MSX_NO_PIN")) return;
+	s->pinned = 1;
+	MSX(msx_host_register(g_ctx, b->flag, c * 2));
+	MSX(msx_host_register(g_ctx, b->rflags, c));
+	MSX(msx_host_register(g_ctx, b->tid, c * 4));
+	if (P->mode != 2) {
+		MSX(msx_host_register(g_ctx, b->nm, c * 4));
+		MSX(msx_host_register(g_ctx, b->as, c * 4));
+		MSX(msx_host_register(g_ctx, s->emit, c * 4));
+	}
+	if (P->want_stats) {
+		MSX(msx_host_register(g_ctx, b->cigar_off, (c + 1) * 4));
+		MSX(msx_host_register(g_ctx, b->md_off, (c + 1) * 4));
+		MSX(msx_host_register(g_ctx, b->cigar, b->cigar_cap * 4));
+		MSX(msx_host_register(g_ctx, b->md, b->md_cap));
+	}
+	if (P->mode != 0) MSX(msx_host_register(g_ctx, b->group_off, b->group_cap * 4));
+}
+
 /* --rescore: drop the first AS and append AS:i (msam_filter.c:162-167) */
 static void rescore_record(const uint8_t *r, size_t len, int32_t score, kstr *out) {
 	const uint8_t *as = msh_aux_get(r, len, "AS");
@@ -537,6 +957,110 @@ static void rescore_record(const uint8_t *r, size_t len, int32_t score, kstr *ou
 		                 (uint8_t)((uint32_t)score >> 24)};
 		ks_put(out, b4, 4);
 	}
+}
+
+/* ---- filter over the pipeline ----------------------------------------------------------------------- */
+typedef struct {
+	pipe_t *P;
+	const msx_filter_params *fp;
+	int pools, out_mode, argc;
+	char **argv;
+	msh_out *out;               /* created by the device stage after the preflight of the first batch */
+	double t_ctx, t_upload, t_gpu, t_fetch, t_wait;
+} fdev_t;
+
+static void *filter_dev_thread(void *arg) {
+	fdev_t *F = (fdev_t *)arg;
+	pipe_t *P = F->P;
+	msx_stage *stage = NULL;
+	int first = 1;
+	{
+		double t0 = now_s();
+		ctx_open();                          /* HIP start-up runs beside the decoding of the first batch */
+		MSX(msx_stage_create(g_ctx, &stage));
+		F->t_ctx = now_s() - t0;
+	}
+	for (;;) {
+		double t0 = now_s(), t1;
+		const int si = pq_pop(&P->q_dev);
+		pslot *s = &P->slot[si];
+		rbatch *b = &s->b;
+		msx_batch hb, db;
+		msx_filter_out fo;
+		msx_filter_status st;
+		t1 = now_s();
+		F->t_wait += t1 - t0;
+		if (first) {
+			/* preflight on the first records (msam_filter.c:478-482), then the header with its @PG line */
+			qn_result qn = {QN_NOT_REQUIRED, 0, 0, 0};
+			char qmsg[1024], ds[1300], *cl;
+			kstr htext = {0, 0, 0};
+			if (F->pools && !s->eof) qn = qn_check(P->hdr, b);
+			qn_format(&qn, qmsg, sizeof qmsg);
+			cl = command_line(F->argc, F->argv);
+			snprintf(ds, sizeof ds, "git=%s; %s", MSH_GIT_COMMIT, qmsg);      /* msam_helper.c:159-164 */
+			if (P->hdr->text.l) ks_put(&htext, P->hdr->text.s, P->hdr->text.l);
+			msh_hdr_add_pg(&htext, PROGRAM, MSH_VERSION, cl, ds);
+			F->out = msh_out_open(stdout, F->out_mode, P->hdr, htext.s);
+			free(cl);
+			free(htext.s);
+			first = 0;
+			t1 = now_s();
+		}
+		if (s->eof) { pq_push(&P->q_out, si); break; }
+		pipe_pin_slot(P, s);
+		rb_host_view(b, &hb, F->pools);
+		MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
+		MSX(msx_stage_outputs(g_ctx, stage, (int64_t)b->n, 0, &fo));
+		F->t_upload += now_s() - t1; t1 = now_s();
+		MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
+		if (msx_filter_finish(g_ctx, &st) != MSX_OK) mDie("%s", msx_last_error(g_ctx));   /* the reference's own mDie texts */
+		F->t_gpu += now_s() - t1; t1 = now_s();
+		s->n_emit = st.n_emit;
+		MSX(msx_dev_to_host(g_ctx, s->emit, fo.emit_idx, 4 * (size_t)st.n_emit));
+		F->t_fetch += now_s() - t1;
+		pq_push(&P->q_out, si);
+	}
+	msx_stage_destroy(g_ctx, stage);
+	return NULL;
+}
+
+static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, int want_stats, int out_mode, int argc,
+                            char *argv[]) {
+	static pipe_t P;
+	fdev_t F;
+	pthread_t th_dec, th_dev;
+	double t_start = now_s(), tw = 0, t_wait = 0;
+	size_t n_in = 0, n_out = 0;
+	pipe_init(&P, in, pools ? 1 : 0, want_stats);
+	memset(&F, 0, sizeof F);
+	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv;
+	if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0 || pthread_create(&th_dev, NULL, filter_dev_thread, &F) != 0)
+		mDie("pthread_create failed");
+	for (;;) {                                   /* this thread is the encode stage */
+		double t0 = now_s(), t1;
+		const int si = pq_pop(&P.q_out);
+		pslot *s = &P.slot[si];
+		t1 = now_s();
+		t_wait += t1 - t0;
+		if (s->eof) break;
+		msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
+		n_in += s->b.n;
+		n_out += (size_t)s->n_emit;
+		tw += now_s() - t1;
+		pq_push(&P.q_free, si);
+	}
+	pthread_join(th_dec, NULL);
+	pthread_join(th_dev, NULL);
+	msh_out_close(F.out);
+	if (getenv("MSX_TIMING"))
+		fprintf(stderr, "# filter pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
+		        "upload %.3f, kernels %.3f, fetch %.3f (+%.3f waiting for a batch); encode+write %.3f s (+%.3f waiting); "
+		        "%zu records in, %zu out, %d threads\n",
+		        now_s() - t_start, P.t_decode, P.t_wait_free, F.t_ctx, F.t_upload, F.t_gpu, F.t_fetch, F.t_wait, tw, t_wait,
+		        n_in, n_out, msh_threads());
+	msx_ctx_destroy(g_ctx);
+	return 0;
 }
 
 int msam_filter_main(int argc, char *argv[]) {
@@ -642,8 +1166,15 @@ int msam_filter_main(int argc, char *argv[]) {
 	rd.in = msh_open(infile);
 	hdr = msh_header(rd.in);
 
-	/* first batch: large enough for the preflight window */
 	bulk = msh_is_bam(rd.in);
+	if (bulk && !fp.rescore && !getenv("MSX_SERIAL_IO")) {
+		/* BAM in: decode | device | encode as three overlapping stages */
+		int rc = filter_pipelined(rd.in, &fp, pools, want_stats, mode, argc, argv);
+		msh_close(rd.in);
+		return rc;
+	}
+	/* SAM text in, or --rescore (records are rewritten one by one): one batch at a time */
+	/* first batch: large enough for the preflight window */
 	{
 		size_t t1 = target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS;
 		TIC;
@@ -884,6 +1415,52 @@ int msam_profile_main(int argc, char *argv[]) {
 	/* mEstimateInsertCountOnFile (:204-243): pools by QNAME over records with tid != -1 */
 	memset(&b, 0, sizeof b);
 	memset(&qn, 0, sizeof qn);
+	if (msh_is_bam(in) && !getenv("MSX_SERIAL_IO")) {
+		/* BAM in: the decode stage runs on its own thread, this one feeds the device */
+		static pipe_t P;
+		pthread_t th_dec;
+		msx_stage *stage = NULL;
+		double t_start = now_s(), t_dev = 0, t_wait = 0, t_ctx;
+		size_t n_in = 0;
+		pipe_init(&P, in, 2, 0);
+		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
+		ctx_open();                              /* HIP start-up runs beside the decoding of the first batch */
+		MSX(msx_stage_create(g_ctx, &stage));
+		t_ctx = now_s() - t_start;
+		for (;;) {
+			double t0 = now_s(), t1;
+			const int si = pq_pop(&P.q_dev);
+			pslot *s = &P.slot[si];
+			t1 = now_s();
+			t_wait += t1 - t0;
+			if (first) {
+				if (!s->eof) qn = qn_check(hdr, &s->b); else { rbatch e; memset(&e, 0, sizeof e); qn = qn_check(hdr, &e); }   /* :708, always for profile */
+				first = 0;
+				MSX(msx_profile_create(g_ctx, &prof, n_features, share_type, fmap, hdr->n_targets));   /* :855 */
+			}
+			if (s->eof) break;
+			{
+				msx_batch hb, db;
+				pipe_pin_slot(&P, s);
+				rb_host_view(&s->b, &hb, 1);
+				hb.cigar_off = NULL; hb.cigar = NULL; hb.md_off = NULL; hb.md = NULL;   /* profile reads tid only */
+				hb.nm = NULL; hb.as = NULL; hb.pos = NULL; hb.flag = NULL; hb.rflags = NULL;
+				MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
+				MSX(msx_profile_accumulate(g_ctx, prof, &db, NULL));
+				MSX(msx_ctx_sync(g_ctx));                 /* the slot's arrays are free again */
+				n_in += s->b.n;
+			}
+			t_dev += now_s() - t1;
+			pq_push(&P.q_free, si);
+		}
+		pthread_join(th_dec, NULL);
+		msx_stage_destroy(g_ctx, stage);
+		if (getenv("MSX_TIMING"))
+			fprintf(stderr, "# profile pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
+			        "upload+accumulate %.3f (+%.3f waiting for a batch); %zu records, %d threads\n",
+			        now_s() - t_start, P.t_decode, P.t_wait_free, t_ctx, t_dev, t_wait, n_in, msh_threads());
+		goto accumulated;
+	}
 	for (;;) {
 		size_t tgt = first && target < COORD_ORDER_CHECK_RECORDS ? COORD_ORDER_CHECK_RECORDS : target;
 		if (msh_is_bam(in)) {
@@ -931,6 +1508,7 @@ batch_ready:
 		if (eof && !have_pending) break;
 	}
 
+accumulated:
 	/* mInsertCountToAbundanceMatrix (:248-425) */
 	row = (double *)calloc((size_t)n_features + 1, sizeof(double));
 	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) fprintf(stderr, "# Start PropSharing:\n");
@@ -1229,6 +1807,55 @@ static int recode_main(int argc, char *argv[]) {
 	return 0;
 }
 
+typedef struct {
+	const msx_batch *hb;
+	int with_seq, pass;
+	int64_t g0, g1, first_group;
+	size_t r0;
+	size_t *rec_off;          /* pass 0: size of record i (with its 4-byte length); then its offset in blob */
+	int32_t *idx;
+	uint8_t *blob;
+	size_t blob_cap;
+} synth_job;
+
+static void synth_worker(void *arg, int tid, int nth) {
+	synth_job *J = (synth_job *)arg;
+	const msx_batch *hb = J->hb;
+	const int64_t span = J->g1 - J->g0, ga = J->g0 + span * tid / nth, gb = J->g0 + span * (tid + 1) / nth;
+	int64_t g, k;
+	for (g = ga; g < gb; g++) {
+		char qn[32];
+		int ql = snprintf(qn, sizeof qn, "sim%08lld", (long long)(J->first_group + g));
+		for (k = hb->group_off[g]; k < hb->group_off[g + 1]; k++) {
+			const uint32_t nc = hb->cigar_off[k + 1] - hb->cigar_off[k], ml = hb->md_off[k + 1] - hb->md_off[k];
+			const uint32_t l_seq = J->with_seq ? 100 : 0;
+			const size_t len = 32 + (size_t)ql + 1 + 4 * (size_t)nc + (J->with_seq ? 150 : 0) + 4 + 3 + ml + 1 + 4;
+			const size_t i = (size_t)k - J->r0;
+			uint8_t *o;
+			uint32_t v[8], q;
+			if (J->pass == 0) { J->rec_off[i] = 4 + len; continue; }
+			o = J->blob + J->rec_off[i];
+			o[0] = (uint8_t)len; o[1] = (uint8_t)(len >> 8); o[2] = (uint8_t)(len >> 16); o[3] = (uint8_t)(len >> 24);
+			o += 4;
+			v[0] = (uint32_t)hb->tid[k]; v[1] = (uint32_t)hb->pos[k];
+			v[2] = (uint32_t)(ql + 1) | 255u << 8 | 4680u << 16;
+			v[3] = nc | (uint32_t)hb->flag[k] << 16;
+			v[4] = l_seq; v[5] = (uint32_t)-1; v[6] = (uint32_t)-1; v[7] = 0;
+			for (q = 0; q < 8; q++) { o[4*q] = (uint8_t)v[q]; o[4*q+1] = (uint8_t)(v[q] >> 8); o[4*q+2] = (uint8_t)(v[q] >> 16); o[4*q+3] = (uint8_t)(v[q] >> 24); }
+			o += 32;
+			memcpy(o, qn, (size_t)ql + 1); o += ql + 1;
+			memcpy(o, hb->cigar + hb->cigar_off[k], 4 * (size_t)nc); o += 4 * (size_t)nc;
+			if (J->with_seq) {
+				for (q = 0; q < 50; q++) *o++ = (uint8_t)(0x12 + (int)((k + q) & 3) * 0x11);   /* A/C/G/T-ish nibbles */
+				for (q = 0; q < 100; q++) *o++ = 40;
+			}
+			memcpy(o, "NMC", 3); o += 3; *o++ = (uint8_t)(hb->nm[k] & 0xff);
+			memcpy(o, "MDZ", 3); o += 3; memcpy(o, hb->md + hb->md_off[k], ml); o += ml; *o++ = 0;
+			memcpy(o, "ASc", 3); o += 3; *o++ = (uint8_t)(hb->as[k] & 0xff);
+		}
+	}
+}
+
 /* `msamtools synth --groups N --refs R [--seed S] [--seq] [-b|-u]`: writes the
  * library's deterministic synthetic alignment stream (BASELINE.md section 2
  * model) as a QNAME-grouped BAM, for end-to-end host-pipeline timing.  No GPU. */
@@ -1265,36 +1892,121 @@ static int synth_main(int argc, char *argv[]) {
 		ks_printf(&hdr.text, "@SQ\tSN:%s\tLN:%u\n", nm, hdr.target_len[i]);
 	}
 	out = msh_out_open(stdout, mode, &hdr, hdr.text.s);
-	for (g = 0; g < hb.n_groups; g++) {
-		char qn[32];
-		int ql = snprintf(qn, sizeof qn, "sim%08lld", (long long)(sp.first_group + g));
-		for (k = hb.group_off[g]; k < hb.group_off[g + 1]; k++) {
-			uint32_t nc = hb.cigar_off[k + 1] - hb.cigar_off[k], ml = hb.md_off[k + 1] - hb.md_off[k], q;
-			uint32_t l_seq = with_seq ? 100 : 0;
-			uint8_t core[32];
-			uint32_t v[8];
-			v[0] = (uint32_t)hb.tid[k]; v[1] = (uint32_t)hb.pos[k];
-			v[2] = (uint32_t)(ql + 1) | 255u << 8 | 4680u << 16;
-			v[3] = nc | (uint32_t)hb.flag[k] << 16;
-			v[4] = l_seq; v[5] = (uint32_t)-1; v[6] = (uint32_t)-1; v[7] = 0;
-			for (q = 0; q < 8; q++) { core[4*q] = (uint8_t)v[q]; core[4*q+1] = (uint8_t)(v[q] >> 8); core[4*q+2] = (uint8_t)(v[q] >> 16); core[4*q+3] = (uint8_t)(v[q] >> 24); }
-			rec.l = 0;
-			ks_put(&rec, core, 32);
-			ks_put(&rec, qn, (size_t)ql + 1);
-			ks_put(&rec, hb.cigar + hb.cigar_off[k], 4 * (size_t)nc);
-			if (with_seq) {
-				for (q = 0; q < 50; q++) ks_putc(&rec, 0x12 + (int)((k + q) & 3) * 0x11);   /* A/C/G/T-ish nibbles */
-				for (q = 0; q < 100; q++) ks_putc(&rec, 40);
-			}
-			ks_put(&rec, "NMC", 3); ks_putc(&rec, hb.nm[k] & 0xff);
-			ks_put(&rec, "MDZ", 3); ks_put(&rec, hb.md + hb.md_off[k], ml); ks_putc(&rec, 0);
-			ks_put(&rec, "ASc", 3); ks_putc(&rec, hb.as[k] & 0xff);
-			msh_write(out, (const uint8_t *)rec.s, rec.l);
+	{
+		/* records are built and compressed chunk by chunk on the worker pool */
+		const int64_t chunk = 1 << 18;
+		synth_job J;
+		memset(&J, 0, sizeof J);
+		J.hb = &hb; J.with_seq = with_seq; J.first_group = sp.first_group;
+		for (g = 0; g < hb.n_groups; g += chunk) {
+			const int64_t g1 = g + chunk < hb.n_groups ? g + chunk : hb.n_groups;
+			const size_t r0 = hb.group_off[g], r1 = hb.group_off[g1], n = r1 - r0;
+			size_t i, tot = 0;
+			J.g0 = g; J.g1 = g1; J.r0 = r0;
+			J.rec_off = (size_t *)realloc(J.rec_off, (n + 1) * sizeof(size_t));
+			J.idx = (int32_t *)realloc(J.idx, (n + 1) * sizeof(int32_t));
+			J.pass = 0;
+			msh_parallel(msh_threads(), synth_worker, &J);          /* sizes */
+			for (i = 0; i < n; i++) { size_t sz = J.rec_off[i]; J.rec_off[i] = tot; tot += sz; J.idx[i] = (int32_t)i; }
+			J.rec_off[n] = tot;
+			if (tot > J.blob_cap) { J.blob_cap = tot + tot / 4; J.blob = (uint8_t *)realloc(J.blob, J.blob_cap); if (!J.blob) mDie("Out of memory"); }
+			J.pass = 1;
+			msh_parallel(msh_threads(), synth_worker, &J);          /* bytes */
+			msh_write_many(out, J.blob, J.rec_off, J.idx, n);
 		}
+		free(J.rec_off); free(J.idx); free(J.blob);
 	}
+	(void)rec; (void)k;
 	msh_out_close(out);
 	msx_synth_host_free(&hb);
 	return 0;
+}
+
+/* hidden, host only: `msamtools pipetest <mode 0|1|2> <stats 0|1> <bam>` runs the pipeline's decode stage
+ * alone and prints one line per batch boundary-independent digest: records, pools, and a hash over every
+ * SoA field -- and the same computed with the record-at-a-time reader.  tests/test_host_cli.py compares. */
+static uint64_t mix_u64(uint64_t h, uint64_t v) {
+	h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+	return h;
+}
+
+static int pipetest_main(int argc, char *argv[]) {
+	static pipe_t P;
+	pthread_t th;
+	msh_in *in;
+	int mode, stats;
+	uint64_t h = 0, hp = 0, pools = 0, recs = 0, batches = 0;
+	if (argc < 4) mQuit("usage: %s pipetest <mode> <stats> <bam>", PROGRAM);
+	mode = atoi(argv[1]); stats = atoi(argv[2]);
+	in = msh_open(argv[3]);
+	if (!msh_is_bam(in)) mQuit("pipetest needs BAM input");
+	pipe_init(&P, in, mode, stats);
+	if (pthread_create(&th, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
+	for (;;) {
+		const int si = pq_pop(&P.q_dev);
+		pslot *s = &P.slot[si];
+		rbatch *b = &s->b;
+		size_t i, g;
+		if (s->eof) break;
+		batches++;
+		for (i = 0; i < b->n; i++) {
+			const uint8_t *r = RB_REC(b, i);
+			size_t len = RB_LEN(b, i), k;
+			h = mix_u64(h, len);
+			for (k = 0; k < len; k += 8) { uint64_t v = 0; memcpy(&v, r + k, len - k < 8 ? len - k : 8); h = mix_u64(h, v); }
+			h = mix_u64(h, b->flag[i]); h = mix_u64(h, b->rflags[i]); h = mix_u64(h, (uint32_t)b->tid[i]);
+			h = mix_u64(h, (uint32_t)b->pos[i]); h = mix_u64(h, (uint32_t)b->nm[i]); h = mix_u64(h, (uint32_t)b->as[i]);
+			if (stats) {
+				for (k = b->cigar_off[i]; k < b->cigar_off[i + 1]; k++) h = mix_u64(h, b->cigar[k]);
+				for (k = b->md_off[i]; k < b->md_off[i + 1]; k++) h = mix_u64(h, b->md[k]);
+			}
+		}
+		if (mode != 0) {
+			for (g = 0; g < b->n_groups; g++) hp = mix_u64(hp, (uint64_t)(recs + b->group_off[g]));
+			pools += b->n_groups;
+		}
+		recs += b->n;
+		pq_push(&P.q_free, si);
+	}
+	pthread_join(th, NULL);
+	printf("pipeline records=%llu pools=%llu hash=%016llx pool_hash=%016llx batches=%llu\n", (unsigned long long)recs,
+	       (unsigned long long)pools, (unsigned long long)h, (unsigned long long)hp, (unsigned long long)batches);
+	msh_close(in);
+	{   /* the same digest through msh_read and the per-record rules of msam_filter.c:120-125,170 / msam_profile.c:223-232 */
+		rbatch b;
+		kstr rec = {0, 0, 0};
+		char prev[256];
+		int have_prev = 0;
+		uint64_t h2 = 0, hp2 = 0, pools2 = 0, recs2 = 0;
+		memset(&b, 0, sizeof b);
+		in = msh_open(argv[3]);
+		while (msh_read(in, &rec) == 0) {
+			const uint8_t *r = (const uint8_t *)rec.s;
+			size_t len = rec.l, k;
+			int counts = mode == 1 ? !(REC_FLAG(r) & 4) : (mode == 2 && REC_TID(r) != -1);
+			int rule = mode == 1 || (mode == 2 && REC_TID(r) != -1);
+			rb_clear(&b);
+			rb_append(&b, r, len, stats);
+			if (mode != 0 && (recs2 == 0 || (rule && have_prev && strcmp(REC_QNAME(r), prev) != 0))) {
+				hp2 = mix_u64(hp2, recs2);
+				pools2++;
+			}
+			h2 = mix_u64(h2, len);
+			for (k = 0; k < len; k += 8) { uint64_t v = 0; memcpy(&v, r + k, len - k < 8 ? len - k : 8); h2 = mix_u64(h2, v); }
+			h2 = mix_u64(h2, b.flag[0]); h2 = mix_u64(h2, b.rflags[0]); h2 = mix_u64(h2, (uint32_t)b.tid[0]);
+			h2 = mix_u64(h2, (uint32_t)b.pos[0]); h2 = mix_u64(h2, (uint32_t)b.nm[0]); h2 = mix_u64(h2, (uint32_t)b.as[0]);
+			if (stats) {
+				for (k = 0; k < b.cigar_off[1]; k++) h2 = mix_u64(h2, b.cigar[k]);
+				for (k = 0; k < b.md_off[1]; k++) h2 = mix_u64(h2, b.md[k]);
+			}
+			if (counts) { strcpy(prev, REC_QNAME(r)); have_prev = 1; }
+			recs2++;
+		}
+		printf("serial   records=%llu pools=%llu hash=%016llx pool_hash=%016llx\n", (unsigned long long)recs2,
+		       (unsigned long long)pools2, (unsigned long long)h2, (unsigned long long)hp2);
+		msh_close(in);
+		return (recs2 == recs && h2 == h && pools2 == pools && hp2 == hp) ? 0 : 1;
+	}
 }
 
 int main(int argc, char *argv[]) {
@@ -1313,6 +2025,7 @@ int main(int argc, char *argv[]) {
 		return 0;
 	}
 	if (strcmp(argv[1], "recode") == 0) return recode_main(argc - 1, argv + 1);
+	if (strcmp(argv[1], "pipetest") == 0) return pipetest_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);

@@ -189,7 +189,7 @@ struct msx_profile {
 	msx_buf runs, owned;              // runs of partial slots (feature, first slot, count) and the bitmap of the features that own one
 	msx_buf m_off_alt, m_fid_alt, len2;   // derived store: renumbered, duplicate lists merged
 	msx_buf head, uidx, eoff, hpos;       // dedupe scratch; hpos[u+1]-hpos[u] = weight of merged list u
-	unsigned long long *d_tot = nullptr;  // device {lists, entries, general lists, runs of partial slots} of the derived store
+	unsigned long long *d_tot = nullptr;  // device {lists, entries, general lists, short runs, long runs of partial slots} of the derived store
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
 	int key_bits = 0;                 // bits of the feature id in an entry key (the list weight sits above)
 	bool transposed_valid = false;

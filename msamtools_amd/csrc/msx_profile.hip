@@ -142,7 +142,7 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	          hipMalloc((void **)&p->delta, 20 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->iter_state, 4 * 4) == hipSuccess &&
 	          hipMalloc((void **)&p->csr_tot, 2 * 8) == hipSuccess &&
-	          hipMalloc((void **)&p->d_tot, 4 * 8) == hipSuccess &&
+	          hipMalloc((void **)&p->d_tot, 8 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->partial, (size_t)(msx_apply_blocks(n_features) + 2 * msx_share_waves(ctx) / MSX_BLOCK + 16) * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->purged_local, 4) == hipSuccess;
 	if (ok && share_type == MSX_MULTI_SHARE_EQUAL) ok = hipMalloc((void **)&p->d, nf * 8) == hipSuccess;
@@ -174,7 +174,7 @@ extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
 	if (p->d) MSX_HIP(ctx, hipMemsetAsync(p->d, 0, nf * 8, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->counters, 0, 16, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->csr_tot, 0, 16, ctx->stream));
-	MSX_HIP(ctx, hipMemsetAsync(p->d_tot, 0, 32, ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(p->d_tot, 0, 64, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->iter_state, 0, 16, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->delta, 0, 160, ctx->stream));

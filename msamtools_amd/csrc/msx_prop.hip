@@ -824,7 +824,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 // (k_part_runs): the slots of one feature are neighbours (the keys ascend), a *run*; runs[] lists every
 // run as (feature, first slot, number of slots), and a bitmap marks the features that own one.
 #define PA_FPB 1024                    // features per streaming workgroup of k_prop_apply
-#define PA_SHORT 8                     // slots one lane adds by itself
 __device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t fmask) {
 	const int64_t c0 = (j >> 1) * per;
 	if (c0 >= E) return SR_SENT;          // idle wave
@@ -842,19 +841,22 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long lo
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < 2 * W; j += stride)
 		part_key[j] = part_key_at(j, E, per, t_key, fmask);
-	if (blockIdx.x == 0 && threadIdx.x == 0) d_tot[3] = 0;      // number of runs, counted by k_part_runs
+	if (blockIdx.x == 0 && threadIdx.x == 0) { d_tot[3] = 0; d_tot[4] = 0; }   // short / long runs, counted by k_part_runs
 }
 
 struct PartRun {
 	uint32_t key, first, n, pad;
 };
 
+// runs of up to PA_SHORT slots go to runs[0 .. d_tot[3]), longer ones (a hot reference cut by hundreds of
+// chunk boundaries) to the far end of the same array, runs[cap - 1 - i] for i < d_tot[4]
+#define PA_SHORT 8                     // slots one lane adds by itself
 __global__ __launch_bounds__(MSX_BLOCK) void k_part_runs(const uint32_t *__restrict__ part_key, int64_t M,
                                                          PartRun *__restrict__ runs, uint32_t *__restrict__ owned,
                                                          unsigned long long *d_tot) {
-	__shared__ uint32_t s_n, s_base;
-	__shared__ PartRun s_run[MSX_BLOCK];
-	if (threadIdx.x == 0) s_n = 0;
+	__shared__ uint32_t s_n[2], s_base[2];
+	__shared__ PartRun s_run[2][MSX_BLOCK];
+	if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
 	__syncthreads();
 	const int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (j < M) {
@@ -866,15 +868,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_part_runs(const uint32_t *__restr
 				if (part_key[mid] <= key) lo = mid + 1; else hi = mid;
 			}
 			const PartRun r = {key, (uint32_t)j, (uint32_t)(lo - j), 0u};
-			s_run[atomicAdd(&s_n, 1u)] = r;
+			const int big = r.n > PA_SHORT ? 1 : 0;
+			s_run[big][atomicAdd(&s_n[big], 1u)] = r;
 			atomicOr(&owned[key >> 5], 1u << (key & 31u));
 		}
 	}
 	__syncthreads();
-	const uint32_t cnt = s_n;
-	if (threadIdx.x == 0 && cnt) s_base = (uint32_t)atomicAdd(&d_tot[3], (unsigned long long)cnt);
+	if (threadIdx.x < 2 && s_n[threadIdx.x])
+		s_base[threadIdx.x] = (uint32_t)atomicAdd(&d_tot[3 + threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
 	__syncthreads();
-	if (threadIdx.x < cnt) runs[s_base + threadIdx.x] = s_run[threadIdx.x];
+	if (threadIdx.x < s_n[0]) runs[s_base[0] + threadIdx.x] = s_run[0][threadIdx.x];
+	if (threadIdx.x < s_n[1]) runs[M - 1 - (s_base[1] + threadIdx.x)] = s_run[1][threadIdx.x];
 }
 
 // level 2: runs of equal feature ids among the boundary partials -> one add per run
@@ -933,7 +937,7 @@ __device__ __forceinline__ double prop_update(int64_t i, double sh, const double
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, const double *__restrict__ U,
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, int64_t n_slots, const double *__restrict__ U,
                                                           double *__restrict__ share, double *__restrict__ a,
                                                           const unsigned long long *__restrict__ d_tot,
                                                           const PartRun *__restrict__ runs,
@@ -957,28 +961,26 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, c
 			}
 		}
 	} else if (FUSED) {
-		// one lane per run; a run of more than PA_SHORT slots (a hot reference cut by hundreds of chunk
-		// boundaries) is added by the whole wave, lane-strided and then lane by lane: a fixed order too
+		// the workgroups behind the streaming ones: one lane per short run, then one wave per long run --
+		// lane-strided partial sums, added lane by lane: a fixed order too
 		const int lane = threadIdx.x & 63;
 		const int64_t r = (int64_t)((int)blockIdx.x - nsb) * MSX_BLOCK + threadIdx.x;
-		const bool have = r < (int64_t)d_tot[3];
-		PartRun R = {0u, 0u, 0u, 0u};
-		if (have) R = runs[r];
-		double sum = 0;
-		if (have && R.n <= PA_SHORT)
+		if (r < (int64_t)d_tot[3]) {
+			const PartRun R = runs[r];
+			double sum = 0;
 			for (uint32_t q = 0; q < R.n; ++q) sum += part_val[R.first + q];
-		unsigned long long longs = __ballot(have && R.n > PA_SHORT);
-		while (longs) {
-			const int src = __ffsll((long long)longs) - 1;
-			longs &= longs - 1ull;
-			const uint32_t first = (uint32_t)__shfl((int)R.first, src, 64), n = (uint32_t)__shfl((int)R.n, src, 64);
-			double part = 0;
-			for (uint32_t q = (uint32_t)lane; q < n; q += 64u) part += part_val[first + q];
-			double tot = 0;
-			for (int l = 0; l < 64; l++) tot += __shfl(part, l, 64);     // lane order, every lane computes the same total
-			if (lane == src) sum = tot;
+			acc = prop_update(R.key, share[R.key] + sum, U, a, share);
 		}
-		if (have) acc = prop_update(R.key, share[R.key] + sum, U, a, share);
+		const int64_t n_long = (int64_t)d_tot[4];
+		const int64_t n_waves = (int64_t)((int)gridDim.x - nsb) * (MSX_BLOCK / 64);
+		for (int64_t w = ((int64_t)((int)blockIdx.x - nsb) * MSX_BLOCK + threadIdx.x) >> 6; w < n_long; w += n_waves) {
+			const PartRun R = runs[n_slots - 1 - w];
+			double part = 0;
+			for (uint32_t q = (uint32_t)lane; q < R.n; q += 64u) part += part_val[R.first + q];
+			double tot = 0;
+			for (int l = 0; l < 64; l++) tot += __shfl(part, l, 64);     // every lane computes the same total
+			if (lane == 0) acc += prop_update(R.key, share[R.key] + tot, U, a, share);
+		}
 	}
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
@@ -1239,12 +1241,12 @@ int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused) {
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	if (fused)
 		hipLaunchKernelGGL(k_prop_apply<true>, dim3((unsigned)(nsb + nrb)), dim3(MSX_BLOCK), 0, ctx->stream, nf, nsb,
-		                   (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
+		                   2 * msx_share_waves(ctx), (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
 		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
 		                   p->partial, p->delta, p->iter_state, k);
 	else
 		hipLaunchKernelGGL(k_prop_apply<false>, dim3((unsigned)nsb), dim3(MSX_BLOCK), 0, ctx->stream, nf, nsb,
-		                   (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
+		                   2 * msx_share_waves(ctx), (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
 		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
 		                   p->partial, p->delta, p->iter_state, k);
 	msx_time_end(ctx);

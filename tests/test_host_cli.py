@@ -10,6 +10,7 @@ import gzip
 import json
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -375,3 +376,62 @@ def test_cli_profile_genome_errors(tmp_path):
         open(gdef, "w").write(text)
         r = run(["profile", "-S", "--label", "t", "--genome", gdef, "-o", str(tmp_path / "o.gz"), sam])
         assert r.returncode == 1 and msg in r.stderr, (text, r.stderr)
+
+
+# ---- the pipelined BAM reader (decode stage only: no GPU needed) ---------------------------------------
+def _pipetest(path, mode, stats, **env):
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    r = subprocess.run([BIN, "pipetest", str(mode), str(stats), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=e, timeout=300)
+    return r.returncode, r.stdout.decode() + r.stderr.decode()
+
+
+@pytest.fixture(scope="module")
+def synth_bams(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pipe")
+    out = {}
+    for flag in ("b", "u"):
+        p = str(d / f"in_{flag}.bam")
+        with open(p, "wb") as fh:
+            subprocess.check_call([BIN, "synth", "--groups", "60000", "--refs", "500", f"-{flag}"], stdout=fh)
+        out[flag] = p
+    return out
+
+
+@pytest.mark.parametrize("mode,stats", [(0, 1), (1, 1), (1, 0), (2, 0)])
+def test_pipeline_decode_equals_record_reader(synth_bams, mode, stats):
+    """Speculative parallel record chase, SoA packing, pool boundaries (msam_filter.c:120-125,170 /
+    msam_profile.c:223-232) and the carry between batches against msh_read + the per-record rules: same
+    records, same SoA fields, same pools -- for many small batches, few threads or many."""
+    for flag, env in (("b", dict(MSX_BATCH_BYTES=2_000_000, MSX_THREADS=8)),
+                      ("u", dict(MSX_BATCH_BYTES=300_000, MSX_BATCH_RECORDS=110_000, MSX_THREADS=5)),
+                      ("u", dict(MSX_THREADS=3))):
+        rc, text = _pipetest(synth_bams[flag], mode, stats, **env)
+        assert rc == 0, text
+
+
+def test_pipeline_chase_repairs_wrong_guesses(synth_bams):
+    """With MSX_CHASE_SLOPPY nearly every guessed record start is wrong: the stitcher must still
+    deliver the true chain."""
+    rc, text = _pipetest(synth_bams["u"], 1, 1, MSX_CHASE_SLOPPY=1, MSX_BATCH_BYTES=4_000_000, MSX_THREADS=16)
+    assert rc == 0, text
+
+
+def test_pipeline_long_unmapped_stretch_is_linear(tmp_path):
+    """A name-grouped file with a long tail of unmapped records (the pool rule walked back
+    from every record to the last mapped one, quadratic in the length of such a stretch)."""
+    sam = tmp_path / "tail.sam"
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:r1\tLN:1000\n")
+        for i in range(2000):
+            fh.write(f"m{i:06d}\t0\tr1\t10\t255\t10M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:10\tAS:i:10\n")
+        for i in range(400_000):
+            fh.write(f"u{i:07d}\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n")
+    bam = tmp_path / "tail.bam"
+    with open(bam, "wb") as fh:
+        subprocess.check_call([BIN, "recode", "-u", str(sam)], stdout=fh)
+    t0 = time.time()
+    rc, text = _pipetest(str(bam), 1, 1, MSX_THREADS=4)
+    assert rc == 0, text
+    assert "pools=402000" in text            # every unmapped record with a new name closes a pool (msam_filter.c:120-125)
+    assert time.time() - t0 < 60
