@@ -580,6 +580,7 @@ typedef struct {
 	size_t **seg_extra;
 	int nseg_cap;
 	double t_decode, t_wait_free;
+	double t_inflate, t_chase, t_scan, t_serial, t_copy;    /* inside t_decode */
 } pipe_t;
 
 static size_t env_size(const char *name, size_t dflt) {
@@ -825,10 +826,13 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 	}
 	for (;;) {
 		size_t want = P->batch_bytes;
+		double tq = now_s(), tq2;
 		while (!P->in_eof && s->ulen < want)
 			if (!msh_inflate_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
+		tq2 = now_s(); P->t_inflate += tq2 - tq; tq = tq2;
 		if (s->ulen == 0) return 0;
 		n = chase_records(P, b, s->ubuf, s->ulen, P->cap_rec, &tail);
+		tq2 = now_s(); P->t_chase += tq2 - tq; tq = tq2;
 		if (P->in_eof && n < P->cap_rec && tail != s->ulen) mDie("Truncated BAM record");
 		if (!P->have_first && n < COORD_ORDER_CHECK_RECORDS && !P->in_eof) {   /* the preflight window (msam_helper.c:4-6) */
 			P->batch_bytes += P->batch_bytes;
@@ -843,6 +847,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		J.b = b; J.base = s->ubuf; J.n = n; J.mode = P->mode; J.want_stats = P->want_stats;
 		J.carry_name = P->have_prev ? P->prev_read : NULL;
 		msh_parallel(msh_threads(), pack_scan, &J);
+		P->t_scan += now_s() - tq;
 		n_batch = n;
 		if (P->mode != 0 && !(P->in_eof && tail == s->ulen && n < P->cap_rec)) {
 			size_t k = n;
@@ -858,6 +863,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		break;
 	}
 	/* offsets (serial prefix sums), cut where the payload arrays are full */
+	{ double tser = now_s();
 	b->cigar_off[0] = 0;
 	b->md_off[0] = 0;
 	for (i = 0; i < n_batch; i++) {
@@ -879,10 +885,12 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		for (i = 1; i < n_batch; i++)
 			if (b->bound[i]) { b->n = i; rb_mark_group(b); }
 	}
+	P->t_serial += now_s() - tser; tser = now_s();
 	if (P->want_stats) {
 		J.n = n_batch;
 		msh_parallel(msh_threads(), pack_copy, &J);
 	}
+	P->t_copy += now_s() - tser; }
 	b->n = n_batch;
 	b->base = s->ubuf;
 	P->have_first = 1;
@@ -1053,6 +1061,9 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	pthread_join(th_dec, NULL);
 	pthread_join(th_dev, NULL);
 	msh_out_close(F.out);
+	if (getenv("MSX_TIMING"))
+		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
+		        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 	if (getenv("MSX_TIMING"))
 		fprintf(stderr, "# filter pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
 		        "upload %.3f, kernels %.3f, fetch %.3f (+%.3f waiting for a batch); encode+write %.3f s (+%.3f waiting); "
@@ -1455,6 +1466,9 @@ int msam_profile_main(int argc, char *argv[]) {
 		}
 		pthread_join(th_dec, NULL);
 		msx_stage_destroy(g_ctx, stage);
+		if (getenv("MSX_TIMING"))
+			fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
+			        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 		if (getenv("MSX_TIMING"))
 			fprintf(stderr, "# profile pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
 			        "upload+accumulate %.3f (+%.3f waiting for a batch); %zu records, %d threads\n",

@@ -3,11 +3,15 @@
  * Written from the SAM/BAM specification (SAMv1 sections 1.3-1.5, 4.1-4.2);
  * replaces what the reference gets from htslib through msam_helper.c:196-293.
  */
+#define _GNU_SOURCE
 #include "msh.h"
 
 #include <ctype.h>
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdarg.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -399,7 +403,10 @@ void msh_parallel(int nth, msh_pf fn, void *arg) {
 
 typedef struct {
 	FILE *fp;
-	uint8_t *cbuf;                       /* BGZF_BATCH compressed blocks back to back   */
+	const uint8_t *map;                  /* a regular file is mapped: blocks are inflated straight out of the page cache */
+	size_t map_len, map_pos;
+	uint8_t *cbuf;                       /* otherwise: BGZF_BATCH compressed blocks back to back */
+	const uint8_t *cptr[BGZF_BATCH];     /* where each raw block starts */
 	size_t coff[BGZF_BATCH + 1];
 	size_t uoff[BGZF_BATCH + 1];         /* where each block inflates to, relative to dst */
 	uint8_t *dst;
@@ -410,7 +417,7 @@ typedef struct {
 } bgz_in;
 
 static void inflate_block(bgz_in *b, int i) {
-	const uint8_t *c = b->cbuf + b->coff[i];
+	const uint8_t *c = b->cptr[i];
 	size_t clen = b->coff[i + 1] - b->coff[i];
 	uint32_t xlen = le16(c + 10);
 	const uint8_t *data = c + 12 + xlen;
@@ -444,34 +451,61 @@ static size_t bgz_read_blocks(bgz_in *b) {
 	if (b->eof) return 0;
 	b->uoff[0] = 0;
 	while (b->nblk < BGZF_BATCH) {
-		uint8_t *h = b->cbuf + off;
-		size_t got = fread(h, 1, 18, b->fp);
 		uint32_t bsize, isize;
-		if (got == 0) { b->eof = 1; break; }
-		if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
-			mDie("Input is not BGZF-compressed BAM (bad block header)");
-		{   /* locate the BC subfield (normally the only one) */
-			uint32_t xlen = le16(h + 10);
-			if (xlen == 6 && h[12] == 'B' && h[13] == 'C') {
-				bsize = le16(h + 16) + 1;
-			} else {
-				uint32_t p = 0;
-				int found = 0;
-				if (xlen > 6 && fread(h + 18, 1, xlen - 6, b->fp) != xlen - 6) mDie("Truncated BGZF block");
-				bsize = 0;
-				while (p + 4 <= xlen) {
-					uint32_t sl = le16(h + 12 + p + 2);
-					if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) { bsize = le16(h + 12 + p + 4) + 1; found = 1; }
-					p += 4 + sl;
-				}
-				if (!found) mDie("BGZF block without BC subfield");
-				got = 12 + xlen;
+		const uint8_t *blk;
+		if (b->map) {
+			/* mapped file: nothing is copied here, the inflating threads read the pages themselves */
+			const uint8_t *h = b->map + b->map_pos;
+			const size_t left = b->map_len - b->map_pos;
+			uint32_t xlen, p = 0;
+			int found = 0;
+			if (left == 0) { b->eof = 1; break; }
+			if (left < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
+				mDie("Input is not BGZF-compressed BAM (bad block header)");
+			xlen = le16(h + 10);
+			if (12 + (size_t)xlen > left) mDie("Truncated BGZF block");
+			bsize = 0;
+			while (p + 4 <= xlen) {
+				uint32_t sl = le16(h + 12 + p + 2);
+				if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) { bsize = le16(h + 12 + p + 4) + 1; found = 1; }
+				p += 4 + sl;
 			}
+			if (!found) mDie("BGZF block without BC subfield");
+			if (bsize < 12 + xlen + 8 || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
+			if (bsize > left) mDie("Truncated BGZF block");
+			blk = h;
+			b->map_pos += bsize;
+		} else {
+			uint8_t *h = b->cbuf + off;
+			size_t got = fread(h, 1, 18, b->fp);
+			if (got == 0) { b->eof = 1; break; }
+			if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
+				mDie("Input is not BGZF-compressed BAM (bad block header)");
+			{   /* locate the BC subfield (normally the only one) */
+				uint32_t xlen = le16(h + 10);
+				if (xlen == 6 && h[12] == 'B' && h[13] == 'C') {
+					bsize = le16(h + 16) + 1;
+				} else {
+					uint32_t p = 0;
+					int found = 0;
+					if (xlen > 6 && fread(h + 18, 1, xlen - 6, b->fp) != xlen - 6) mDie("Truncated BGZF block");
+					bsize = 0;
+					while (p + 4 <= xlen) {
+						uint32_t sl = le16(h + 12 + p + 2);
+						if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) { bsize = le16(h + 12 + p + 4) + 1; found = 1; }
+						p += 4 + sl;
+					}
+					if (!found) mDie("BGZF block without BC subfield");
+					got = 12 + xlen;
+				}
+			}
+			if (bsize < got + 8 || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
+			if (fread(h + got, 1, bsize - got, b->fp) != bsize - got) mDie("Truncated BGZF block");
+			blk = h;
 		}
-		if (bsize < got + 8 || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
-		if (fread(h + got, 1, bsize - got, b->fp) != bsize - got) mDie("Truncated BGZF block");
-		isize = (uint32_t)le32(h + bsize - 4);
+		isize = (uint32_t)le32(blk + bsize - 4);
 		if (isize > BGZF_MAX) mDie("Corrupt BGZF block (ISIZE %u)", isize);
+		b->cptr[b->nblk] = blk;
 		b->coff[b->nblk] = off;
 		off += bsize;
 		total += isize;
@@ -808,7 +842,7 @@ msh_in *msh_open(const char *path) {
 	if (!in) mDie("Out of memory");
 	in->fp = strcmp(path, "-") == 0 ? stdin : fopen(path, "rb");
 	if (!in->fp) mDie("Cannot open %s for reading", path);
-	setvbuf(in->fp, NULL, _IOFBF, 1 << 20);
+	setvbuf(in->fp, NULL, _IOFBF, (size_t)4 << 20);
 	c0 = fgetc(in->fp);
 	c1 = c0 == EOF ? EOF : fgetc(in->fp);
 	if (c1 != EOF) ungetc(c1, in->fp);
@@ -819,8 +853,25 @@ msh_in *msh_open(const char *path) {
 		int32_t l_text, n_ref, i;
 		size_t at;
 		in->bz.fp = in->fp;
-		in->bz.cbuf = (uint8_t *)malloc((size_t)BGZF_BATCH * (BGZF_MAX + 1024));
-		if (!in->bz.cbuf) mDie("Out of memory");
+		{
+			struct stat sb;
+			if (in->fp != stdin && fstat(fileno(in->fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 &&
+			    !getenv("MSX_NO_MMAP")) {
+				void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(in->fp), 0);
+				if (m != MAP_FAILED) {
+					in->bz.map = (const uint8_t *)m;
+					in->bz.map_len = (size_t)sb.st_size;
+					(void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+				}
+			}
+		}
+		if (!in->bz.map) {
+			in->bz.cbuf = (uint8_t *)malloc((size_t)BGZF_BATCH * (BGZF_MAX + 1024));
+			if (!in->bz.cbuf) mDie("Out of memory");
+#ifdef F_SETPIPE_SZ
+			(void)fcntl(fileno(in->fp), F_SETPIPE_SZ, 1 << 20);      /* a pipe from `msamtools filter -bu`: fewer, larger reads */
+#endif
+		}
 		if (!span_need(in, 12)) mDie("Cannot read header from %s", path);
 		p = in->bz.span + in->bz.span_beg;
 		if (memcmp(p, "BAM\1", 4) != 0) mDie("Cannot read header from %s", path);
@@ -903,6 +954,7 @@ void msh_close(msh_in *in) {
 	free(in->hdr.target_len);
 	free(in->hdr.text.s);
 	free(in->bz.cbuf);
+	if (in->bz.map) munmap((void *)in->bz.map, in->bz.map_len);
 	free(in->bz.span);
 	free(in->line);
 	free(in->pending.s);
@@ -914,6 +966,8 @@ void msh_close(msh_in *in) {
 /* ------------------------------------------------------------------------ */
 struct msh_out {
 	FILE *fp;
+	int fd;              /* >= 0: stdout is a regular file, written with pwrite at `pos` (several threads at once) */
+	off_t pos;
 	int mode;
 	const msh_hdr *hdr;
 	kstr line;
@@ -925,10 +979,23 @@ struct msh_out {
 
 static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level);
 
+static void out_bytes(msh_out *o, const void *p, size_t n) {
+	if (o->fd >= 0) {
+		const uint8_t *s = (const uint8_t *)p;
+		while (n) {
+			ssize_t k = pwrite(o->fd, s, n, o->pos);
+			if (k <= 0) mDie("Write failed");
+			s += k; n -= (size_t)k; o->pos += k;
+		}
+	} else if (fwrite(p, 1, n, o->fp) != n) {
+		mDie("Write failed");
+	}
+}
+
 static void bgz_flush_block(msh_out *o) {
 	uint8_t out[BGZF_MAX + 1024];
 	uint32_t total = bgzf_compress(out, o->ubuf, o->ulen, o->level);
-	if (fwrite(out, 1, total, o->fp) != total) mDie("Write failed");
+	out_bytes(o, out, total);
 	o->ulen = 0;
 }
 
@@ -950,7 +1017,20 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 	o->fp = fp;
 	o->mode = mode;
 	o->hdr = h;
+	o->fd = -1;
 	setvbuf(fp, NULL, _IOFBF, 1 << 20);
+	{
+		struct stat sb;
+		const int fd = fileno(fp), fl = fcntl(fd, F_GETFL);
+		if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && fl >= 0 && !(fl & O_APPEND) && !getenv("MSX_NO_PWRITE")) {
+			o->fd = fd;
+			o->pos = lseek(fd, 0, SEEK_CUR);
+			if (o->pos < 0) o->fd = -1;
+		}
+#ifdef F_SETPIPE_SZ
+		if (o->fd < 0) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);       /* a pipe into `msamtools profile -` */
+#endif
+	}
 	if (mode == MSH_OUT_BAM || mode == MSH_OUT_UBAM) {
 		kstr b = {0, 0, 0};
 		int32_t i;
@@ -971,7 +1051,7 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 		if (o->ulen) bgz_flush_block(o);      /* header in its own block(s), as htslib does */
 		free(b.s);
 	} else if (mode == MSH_OUT_SAM_HDR) {
-		fputs(hdr_text, fp);
+		out_bytes(o, hdr_text, strlen(hdr_text));
 	}
 	return o;
 }
@@ -986,7 +1066,7 @@ void msh_write(msh_out *o, const uint8_t *rec, size_t len) {
 		o->line.l = 0;
 		msh_sam_format(o->hdr, rec, len, &o->line);
 		ks_putc(&o->line, '\n');
-		if (fwrite(o->line.s, 1, o->line.l, o->fp) != o->line.l) mDie("Write failed");
+		out_bytes(o, o->line.s, o->line.l);
 	}
 }
 
@@ -995,7 +1075,7 @@ void msh_write(msh_out *o, const uint8_t *rec, size_t len) {
  * block_size, as in the BAM stream) for k = 0..n-1.  BAM: the records are packed
  * greedily into BGZF blocks (whole records per block), blocks are deflated in
  * parallel and written in order.  SAM: lines are formatted in parallel. */
-#define WCHUNK_BLOCKS 1024
+#define WCHUNK_BLOCKS 2048
 #define WCHUNK_LINES 262144
 
 typedef struct {
@@ -1005,19 +1085,32 @@ typedef struct {
 	const int32_t *idx;
 	/* BAM */
 	size_t nblk;
-	size_t *first;          /* [nblk+1] first emitted-record index of each block */
+	const size_t *first;    /* [nblk+1] first emitted-record index of each block */
 	uint8_t *slots;         /* nblk * SLOT bytes */
 	uint32_t *slot_len;
+	off_t *slot_pos;        /* file position of each block (regular-file output) */
 	/* SAM */
 	size_t lo, hi;
 	kstr *lines;            /* one per thread */
 } wjob;
 #define WSLOT (BGZF_MAX + 1024)
 
+static const uint8_t BGZF_HEAD[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+
+static void bgzf_finish(uint8_t *out, uint32_t clen, uint32_t crc, uint32_t n) {
+	const uint32_t total = 18 + clen + 8;
+	memcpy(out, BGZF_HEAD, 16);
+	out[16] = (uint8_t)((total - 1) & 0xff);
+	out[17] = (uint8_t)((total - 1) >> 8);
+	out[18 + clen + 0] = (uint8_t)crc; out[18 + clen + 1] = (uint8_t)(crc >> 8);
+	out[18 + clen + 2] = (uint8_t)(crc >> 16); out[18 + clen + 3] = (uint8_t)(crc >> 24);
+	out[18 + clen + 4] = (uint8_t)n; out[18 + clen + 5] = (uint8_t)(n >> 8);
+	out[18 + clen + 6] = (uint8_t)(n >> 16); out[18 + clen + 7] = (uint8_t)(n >> 24);
+}
+
 static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level) {
 	z_stream zs;
-	uint32_t clen, crc, total;
-	static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+	uint32_t clen;
 	memset(&zs, 0, sizeof zs);
 	if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("zlib deflateInit2 failed");
 	zs.next_in = (Bytef *)in;
@@ -1027,33 +1120,50 @@ static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int l
 	if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mDie("BGZF deflate failed");
 	clen = (uint32_t)zs.total_out;
 	deflateEnd(&zs);
-	memcpy(out, head, 16);
-	total = 18 + clen + 8;
-	out[16] = (uint8_t)((total - 1) & 0xff);
-	out[17] = (uint8_t)((total - 1) >> 8);
-	crc = (uint32_t)crc32(crc32(0L, NULL, 0), in, n);
-	out[18 + clen + 0] = (uint8_t)crc; out[18 + clen + 1] = (uint8_t)(crc >> 8);
-	out[18 + clen + 2] = (uint8_t)(crc >> 16); out[18 + clen + 3] = (uint8_t)(crc >> 24);
-	out[18 + clen + 4] = (uint8_t)n; out[18 + clen + 5] = (uint8_t)(n >> 8);
-	out[18 + clen + 6] = (uint8_t)(n >> 16); out[18 + clen + 7] = (uint8_t)(n >> 24);
-	return total;
+	bgzf_finish(out, clen, (uint32_t)crc32(crc32(0L, NULL, 0), in, n), n);
+	return 18 + clen + 8;
 }
 
 static void wbam_worker(void *arg, int tid, int nth) {
 	wjob *w = (wjob *)arg;
-	uint8_t *payload = (uint8_t *)malloc(BGZF_MAX);
+	const int stored = w->o->level == 0;
+	uint8_t *payload = stored ? NULL : (uint8_t *)malloc(BGZF_MAX);
 	size_t k, r;
-	if (!payload) mDie("Out of memory");
+	if (!stored && !payload) mDie("Out of memory");
 	for (k = (size_t)tid; k < w->nblk; k += (size_t)nth) {
+		uint8_t *slot = w->slots + k * WSLOT;
+		/* -u: one stored deflate block, the records gathered straight into their place */
+		uint8_t *dst = stored ? slot + 18 + 5 : payload;
 		uint32_t n = 0;
 		for (r = w->first[k]; r < w->first[k + 1]; r++) {
 			size_t i = (size_t)w->idx[r], sz = w->rec_off[i + 1] - w->rec_off[i];
-			memcpy(payload + n, w->base + w->rec_off[i], sz);
+			memcpy(dst + n, w->base + w->rec_off[i], sz);
 			n += (uint32_t)sz;
 		}
-		w->slot_len[k] = bgzf_compress(w->slots + k * WSLOT, payload, n, w->o->level);
+		if (stored) {
+			slot[18] = 1; slot[19] = (uint8_t)n; slot[20] = (uint8_t)(n >> 8); slot[21] = (uint8_t)~n; slot[22] = (uint8_t)(~n >> 8);
+			bgzf_finish(slot, 5 + n, (uint32_t)crc32(crc32(0L, NULL, 0), dst, n), n);
+			w->slot_len[k] = 18 + 5 + n + 8;
+		} else {
+			w->slot_len[k] = bgzf_compress(slot, payload, n, w->o->level);
+		}
 	}
 	free(payload);
+}
+
+static void wbam_pwrite_worker(void *arg, int tid, int nth) {
+	wjob *w = (wjob *)arg;
+	size_t k;
+	for (k = (size_t)tid; k < w->nblk; k += (size_t)nth) {
+		const uint8_t *s = w->slots + k * WSLOT;
+		size_t n = w->slot_len[k];
+		off_t at = w->slot_pos[k];
+		while (n) {
+			ssize_t g = pwrite(w->o->fd, s, n, at);
+			if (g <= 0) mDie("Write failed");
+			s += g; n -= (size_t)g; at += g;
+		}
+	}
 }
 
 static void wsam_worker(void *arg, int tid, int nth) {
@@ -1076,7 +1186,6 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 	memset(&w, 0, sizeof w);
 	w.o = o; w.base = base; w.rec_off = rec_off; w.idx = idx;
 	if (o->mode == MSH_OUT_BAM || o->mode == MSH_OUT_UBAM) {
-		size_t done = 0;
 		for (r = 0; r < n; r++)          /* a record larger than one block: leave everything to the serial writer */
 			if (rec_off[(size_t)idx[r] + 1] - rec_off[(size_t)idx[r]] > BGZF_PAYLOAD) {
 				for (r = 0; r < n; r++) {
@@ -1086,45 +1195,45 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 				return;
 			}
 		if (o->ulen) bgz_flush_block(o);
-		w.first = (size_t *)malloc((WCHUNK_BLOCKS + 2) * sizeof(size_t));
-		w.slots = (uint8_t *)malloc((size_t)WCHUNK_BLOCKS * WSLOT);
-		w.slot_len = (uint32_t *)malloc(WCHUNK_BLOCKS * sizeof(uint32_t));
-		if (!w.first || !w.slots || !w.slot_len) mDie("Out of memory");
-		while (done < n) {
-			/* plan up to WCHUNK_BLOCKS blocks of whole records */
-			size_t k = 0, cur = 0;
-			w.first[0] = done;
-			for (r = done; r < n; r++) {
+		{
+			/* plan: whole records per block, greedily; the last, partly filled block stays in the writer's buffer */
+			size_t cap = 1024, nb = 0, cur = 0, done, *first = (size_t *)malloc((cap + 2) * sizeof(size_t));
+			if (!first) mDie("Out of memory");
+			first[0] = 0;
+			for (r = 0; r < n; r++) {
 				size_t sz = rec_off[(size_t)idx[r] + 1] - rec_off[(size_t)idx[r]];
 				if (cur + sz > BGZF_PAYLOAD) {
-					w.first[++k] = r;
+					if (nb + 2 > cap) { cap *= 2; first = (size_t *)realloc(first, (cap + 2) * sizeof(size_t)); if (!first) mDie("Out of memory"); }
+					first[++nb] = r;
 					cur = 0;
-					if (k == WCHUNK_BLOCKS) break;
 				}
 				cur += sz;
 			}
-			if (k < WCHUNK_BLOCKS) {
-				/* r == n: the last, partly filled block stays in the writer's buffer */
-				size_t q;
-				w.nblk = k;
-				for (q = w.first[k]; q < n; q++) {
-					size_t i = (size_t)idx[q], sz = rec_off[i + 1] - rec_off[i];
-					memcpy(o->ubuf + o->ulen, base + rec_off[i], sz);
-					o->ulen += (uint32_t)sz;
-				}
-				done = n;
-			} else {
-				w.nblk = k;
-				done = w.first[k];
+			for (r = first[nb]; r < n; r++) {
+				size_t i = (size_t)idx[r], sz = rec_off[i + 1] - rec_off[i];
+				memcpy(o->ubuf + o->ulen, base + rec_off[i], sz);
+				o->ulen += (uint32_t)sz;
 			}
-			if (w.nblk) {
+			w.slots = (uint8_t *)malloc((size_t)(nb < WCHUNK_BLOCKS ? nb + 1 : WCHUNK_BLOCKS) * WSLOT);
+			w.slot_len = (uint32_t *)malloc(WCHUNK_BLOCKS * sizeof(uint32_t));
+			w.slot_pos = (off_t *)malloc(WCHUNK_BLOCKS * sizeof(off_t));
+			if (!w.slots || !w.slot_len || !w.slot_pos) mDie("Out of memory");
+			for (done = 0; done < nb; done += w.nblk) {
 				size_t q;
+				w.nblk = nb - done < WCHUNK_BLOCKS ? nb - done : WCHUNK_BLOCKS;
+				w.first = first + done;
 				msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_worker, &w);
-				for (q = 0; q < w.nblk; q++)
-					if (fwrite(w.slots + q * WSLOT, 1, w.slot_len[q], o->fp) != w.slot_len[q]) mDie("Write failed");
+				if (o->fd >= 0) {
+					/* a regular file: every block goes to its own position, from all threads at once */
+					for (q = 0; q < w.nblk; q++) { w.slot_pos[q] = o->pos; o->pos += w.slot_len[q]; }
+					msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_pwrite_worker, &w);
+				} else {
+					for (q = 0; q < w.nblk; q++)
+						if (fwrite(w.slots + q * WSLOT, 1, w.slot_len[q], o->fp) != w.slot_len[q]) mDie("Write failed");
+				}
 			}
+			free(first); free(w.slots); free(w.slot_len); free(w.slot_pos);
 		}
-		free(w.first); free(w.slots); free(w.slot_len);
 	} else {
 		int t;
 		w.lines = (kstr *)calloc((size_t)nth, sizeof(kstr));
@@ -1132,7 +1241,7 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 			w.hi = w.lo + WCHUNK_LINES < n ? w.lo + WCHUNK_LINES : n;
 			msh_parallel(nth, wsam_worker, &w);
 			for (t = 0; t < nth; t++)
-				if (w.lines[t].l && fwrite(w.lines[t].s, 1, w.lines[t].l, o->fp) != w.lines[t].l) mDie("Write failed");
+				if (w.lines[t].l) out_bytes(o, w.lines[t].s, w.lines[t].l);
 		}
 		for (t = 0; t < nth; t++) free(w.lines[t].s);
 		free(w.lines);
@@ -1145,9 +1254,10 @@ void msh_out_close(msh_out *o) {
 		static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
 		                                      0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if (o->ulen) bgz_flush_block(o);
-		fwrite(eof_block, 1, 28, o->fp);
+		out_bytes(o, eof_block, 28);
 	}
 	fflush(o->fp);
+	if (o->fd >= 0) (void)lseek(o->fd, o->pos, SEEK_SET);
 	free(o->ubuf);
 	free(o->line.s);
 	free(o);
