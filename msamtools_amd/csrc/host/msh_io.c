@@ -11,7 +11,9 @@
 #include <pthread.h>
 #include <stdarg.h>
 #include <sys/mman.h>
+#include <errno.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -424,16 +426,23 @@ static void inflate_block(bgz_in *b, int i) {
 	size_t dlen = clen - 12 - xlen - 8;
 	uint32_t isize = (uint32_t)(b->uoff[i + 1] - b->uoff[i]);
 	uint8_t *out = b->dst + b->uoff[i];
-	z_stream zs;
+	/* one stream per thread, reset between blocks: initialising one per block means an allocation per
+	 * block, and with a hundred threads those serialise inside the allocator */
+	static __thread z_stream zs;
+	static __thread int zs_ready = 0;
 	if (isize == 0) return;
-	memset(&zs, 0, sizeof zs);
+	if (!zs_ready) {
+		memset(&zs, 0, sizeof zs);
+		if (inflateInit2(&zs, -15) != Z_OK) mDie("zlib inflateInit2 failed");
+		zs_ready = 1;
+	} else if (inflateReset(&zs) != Z_OK) {
+		mDie("zlib inflateReset failed");
+	}
 	zs.next_in = (Bytef *)data;
 	zs.avail_in = (uInt)dlen;
 	zs.next_out = out;
 	zs.avail_out = isize;
-	if (inflateInit2(&zs, -15) != Z_OK) mDie("zlib inflateInit2 failed");
 	if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize) mDie("Corrupt BGZF block (inflate failed)");
-	inflateEnd(&zs);
 	if ((uint32_t)crc32(crc32(0L, NULL, 0), out, isize) != (uint32_t)le32(c + clen - 8))
 		mDie("Corrupt BGZF block (CRC mismatch)");
 }
@@ -966,8 +975,7 @@ void msh_close(msh_in *in) {
 /* ------------------------------------------------------------------------ */
 struct msh_out {
 	FILE *fp;
-	int fd;              /* >= 0: stdout is a regular file, written with pwrite at `pos` (several threads at once) */
-	off_t pos;
+	int fd;              /* >= 0 (BAM output): written with write/writev, whole chunks of blocks per call */
 	int mode;
 	const msh_hdr *hdr;
 	kstr line;
@@ -983,9 +991,10 @@ static void out_bytes(msh_out *o, const void *p, size_t n) {
 	if (o->fd >= 0) {
 		const uint8_t *s = (const uint8_t *)p;
 		while (n) {
-			ssize_t k = pwrite(o->fd, s, n, o->pos);
+			ssize_t k = write(o->fd, s, n);
+			if (k < 0 && errno == EINTR) continue;
 			if (k <= 0) mDie("Write failed");
-			s += k; n -= (size_t)k; o->pos += k;
+			s += k; n -= (size_t)k;
 		}
 	} else if (fwrite(p, 1, n, o->fp) != n) {
 		mDie("Write failed");
@@ -1019,16 +1028,11 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 	o->hdr = h;
 	o->fd = -1;
 	setvbuf(fp, NULL, _IOFBF, 1 << 20);
-	{
-		struct stat sb;
-		const int fd = fileno(fp), fl = fcntl(fd, F_GETFL);
-		if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && fl >= 0 && !(fl & O_APPEND) && !getenv("MSX_NO_PWRITE")) {
-			o->fd = fd;
-			o->pos = lseek(fd, 0, SEEK_CUR);
-			if (o->pos < 0) o->fd = -1;
-		}
+	if (mode == MSH_OUT_BAM || mode == MSH_OUT_UBAM) {
+		fflush(fp);
+		o->fd = fileno(fp);              /* nothing of the BAM stream goes through stdio */
 #ifdef F_SETPIPE_SZ
-		if (o->fd < 0) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);       /* a pipe into `msamtools profile -` */
+		(void)fcntl(o->fd, F_SETPIPE_SZ, 1 << 20);       /* a pipe into `msamtools profile -`: fewer, larger transfers */
 #endif
 	}
 	if (mode == MSH_OUT_BAM || mode == MSH_OUT_UBAM) {
@@ -1088,7 +1092,6 @@ typedef struct {
 	const size_t *first;    /* [nblk+1] first emitted-record index of each block */
 	uint8_t *slots;         /* nblk * SLOT bytes */
 	uint32_t *slot_len;
-	off_t *slot_pos;        /* file position of each block (regular-file output) */
 	/* SAM */
 	size_t lo, hi;
 	kstr *lines;            /* one per thread */
@@ -1109,17 +1112,24 @@ static void bgzf_finish(uint8_t *out, uint32_t clen, uint32_t crc, uint32_t n) {
 }
 
 static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level) {
-	z_stream zs;
+	/* one deflate state per thread (a quarter of a megabyte each): created once, reset per block */
+	static __thread z_stream zs;
+	static __thread int zs_level = -100;
 	uint32_t clen;
-	memset(&zs, 0, sizeof zs);
-	if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("zlib deflateInit2 failed");
+	if (zs_level != level) {
+		if (zs_level != -100) deflateEnd(&zs);
+		memset(&zs, 0, sizeof zs);
+		if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("zlib deflateInit2 failed");
+		zs_level = level;
+	} else if (deflateReset(&zs) != Z_OK) {
+		mDie("zlib deflateReset failed");
+	}
 	zs.next_in = (Bytef *)in;
 	zs.avail_in = n;
 	zs.next_out = out + 18;
 	zs.avail_out = WSLOT - 18 - 8;
 	if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mDie("BGZF deflate failed");
 	clen = (uint32_t)zs.total_out;
-	deflateEnd(&zs);
 	bgzf_finish(out, clen, (uint32_t)crc32(crc32(0L, NULL, 0), in, n), n);
 	return 18 + clen + 8;
 }
@@ -1127,9 +1137,9 @@ static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int l
 static void wbam_worker(void *arg, int tid, int nth) {
 	wjob *w = (wjob *)arg;
 	const int stored = w->o->level == 0;
-	uint8_t *payload = stored ? NULL : (uint8_t *)malloc(BGZF_MAX);
+	static __thread uint8_t *payload = NULL;
 	size_t k, r;
-	if (!stored && !payload) mDie("Out of memory");
+	if (!stored && !payload && !(payload = (uint8_t *)malloc(BGZF_MAX))) mDie("Out of memory");
 	for (k = (size_t)tid; k < w->nblk; k += (size_t)nth) {
 		uint8_t *slot = w->slots + k * WSLOT;
 		/* -u: one stored deflate block, the records gathered straight into their place */
@@ -1146,22 +1156,6 @@ static void wbam_worker(void *arg, int tid, int nth) {
 			w->slot_len[k] = 18 + 5 + n + 8;
 		} else {
 			w->slot_len[k] = bgzf_compress(slot, payload, n, w->o->level);
-		}
-	}
-	free(payload);
-}
-
-static void wbam_pwrite_worker(void *arg, int tid, int nth) {
-	wjob *w = (wjob *)arg;
-	size_t k;
-	for (k = (size_t)tid; k < w->nblk; k += (size_t)nth) {
-		const uint8_t *s = w->slots + k * WSLOT;
-		size_t n = w->slot_len[k];
-		off_t at = w->slot_pos[k];
-		while (n) {
-			ssize_t g = pwrite(w->o->fd, s, n, at);
-			if (g <= 0) mDie("Write failed");
-			s += g; n -= (size_t)g; at += g;
 		}
 	}
 }
@@ -1216,23 +1210,35 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 			}
 			w.slots = (uint8_t *)malloc((size_t)(nb < WCHUNK_BLOCKS ? nb + 1 : WCHUNK_BLOCKS) * WSLOT);
 			w.slot_len = (uint32_t *)malloc(WCHUNK_BLOCKS * sizeof(uint32_t));
-			w.slot_pos = (off_t *)malloc(WCHUNK_BLOCKS * sizeof(off_t));
-			if (!w.slots || !w.slot_len || !w.slot_pos) mDie("Out of memory");
+			if (!w.slots || !w.slot_len) mDie("Out of memory");
 			for (done = 0; done < nb; done += w.nblk) {
 				size_t q;
 				w.nblk = nb - done < WCHUNK_BLOCKS ? nb - done : WCHUNK_BLOCKS;
 				w.first = first + done;
 				msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_worker, &w);
-				if (o->fd >= 0) {
-					/* a regular file: every block goes to its own position, from all threads at once */
-					for (q = 0; q < w.nblk; q++) { w.slot_pos[q] = o->pos; o->pos += w.slot_len[q]; }
-					msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_pwrite_worker, &w);
-				} else {
-					for (q = 0; q < w.nblk; q++)
-						if (fwrite(w.slots + q * WSLOT, 1, w.slot_len[q], o->fp) != w.slot_len[q]) mDie("Write failed");
+				/* the chunk's blocks in order, up to IOV_MAX of them per system call */
+				for (q = 0; q < w.nblk;) {
+					struct iovec iv[512];
+					int niv = 0, v;
+					size_t want = 0;
+					ssize_t got;
+					for (; q < w.nblk && niv < 512; q++, niv++) {
+						iv[niv].iov_base = w.slots + q * WSLOT;
+						iv[niv].iov_len = w.slot_len[q];
+						want += w.slot_len[q];
+					}
+					v = 0;
+					while (want) {
+						got = writev(o->fd, iv + v, niv - v);
+						if (got < 0 && errno == EINTR) continue;
+						if (got <= 0) mDie("Write failed");
+						want -= (size_t)got;
+						while (got > 0 && (size_t)got >= iv[v].iov_len) { got -= (ssize_t)iv[v].iov_len; v++; }
+						if (got > 0) { iv[v].iov_base = (uint8_t *)iv[v].iov_base + got; iv[v].iov_len -= (size_t)got; }
+					}
 				}
 			}
-			free(first); free(w.slots); free(w.slot_len); free(w.slot_pos);
+			free(first); free(w.slots); free(w.slot_len);
 		}
 	} else {
 		int t;
@@ -1257,7 +1263,6 @@ void msh_out_close(msh_out *o) {
 		out_bytes(o, eof_block, 28);
 	}
 	fflush(o->fp);
-	if (o->fd >= 0) (void)lseek(o->fd, o->pos, SEEK_SET);
 	free(o->ubuf);
 	free(o->line.s);
 	free(o);
