@@ -16,6 +16,7 @@
 #include <pthread.h>
 #include <math.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #define QNAME_GROUP_CHECK_RECORDS 10000      /* msam_helper.c:4-6 */
@@ -33,6 +34,16 @@ static double now_s(void) {
 static double t_decode, t_upload, t_gpu, t_fetch, t_write;
 #define TIC double t0_ = now_s()
 #define TOC(acc) do { double t1_ = now_s(); (acc) += t1_ - t0_; t0_ = t1_; } while (0)
+
+/* Everything has been written: leave without tearing down the HIP runtime, the page-locked arenas and
+ * a gigabyte of batch buffers (a quarter of a second on a one-second run).  MSX_CLEAN_EXIT=1 keeps the
+ * orderly shutdown (leak checks). */
+static void fast_exit(void) {
+	if (getenv("MSX_CLEAN_EXIT")) return;
+	fflush(stdout);
+	fflush(stderr);
+	_exit(0);
+}
 
 static void ctx_open(void) {
 	const char *dev = getenv("MSX_DEVICE");
@@ -531,6 +542,7 @@ static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int 
 /* bytes of the pool left open at a batch's end are carried into the next.    */
 /* ------------------------------------------------------------------------ */
 #define PIPE_SLOTS 3
+#define MSH_POOL_MAX 128
 
 typedef struct {
 	pthread_mutex_t mu;
@@ -812,6 +824,39 @@ static size_t chase_records(pipe_t *P, rbatch *b, const uint8_t *u, size_t len, 
 	return total;
 }
 
+/* counts -> offsets (cigar_off, md_off) and pool starts (group_off), two passes over per-thread ranges */
+typedef struct {
+	rbatch *b;
+	size_t n;
+	int mode, pass;
+	uint64_t sum_c[MSH_POOL_MAX], sum_m[MSH_POOL_MAX], sum_g[MSH_POOL_MAX];
+} offs_job;
+
+static void offs_worker(void *arg, int tid, int nth) {
+	offs_job *O = (offs_job *)arg;
+	rbatch *b = O->b;
+	const size_t lo = O->n * (size_t)tid / (size_t)nth, hi = O->n * (size_t)(tid + 1) / (size_t)nth;
+	size_t i;
+	if (O->pass == 0) {
+		uint64_t c = 0, m = 0, g = 0;
+		for (i = lo; i < hi; i++) {
+			c += b->cigar_off[i + 1];
+			m += b->md_off[i + 1];
+			g += (O->mode != 0 && (i == 0 || b->bound[i]));
+		}
+		O->sum_c[tid] = c; O->sum_m[tid] = m; O->sum_g[tid] = g;
+	} else {
+		uint64_t c = O->sum_c[tid], m = O->sum_m[tid], g = O->sum_g[tid];
+		for (i = lo; i < hi; i++) {
+			if (O->mode != 0 && (i == 0 || b->bound[i])) b->group_off[g++] = (uint32_t)i;
+			c += b->cigar_off[i + 1];
+			m += b->md_off[i + 1];
+			b->cigar_off[i + 1] = (uint32_t)c;
+			b->md_off[i + 1] = (uint32_t)m;
+		}
+	}
+}
+
 /* one batch into slot s: returns the number of records (0 = end of stream) */
 static size_t pipe_fill(pipe_t *P, pslot *s) {
 	rbatch *b = &s->b;
@@ -862,28 +907,39 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		}
 		break;
 	}
-	/* offsets (serial prefix sums), cut where the payload arrays are full */
+	/* offsets and pools: per-thread sums, a short serial pass over the threads, per-thread fill */
 	{ double tser = now_s();
-	b->cigar_off[0] = 0;
-	b->md_off[0] = 0;
-	for (i = 0; i < n_batch; i++) {
-		b->cigar_off[i + 1] += b->cigar_off[i];
-		b->md_off[i + 1] += b->md_off[i];
-		if (b->cigar_off[i + 1] + 4 > b->cigar_cap || b->md_off[i + 1] + 16 > b->md_cap) {
-			size_t k = i + 1;
-			if (P->mode != 0) { while (k > 1 && !b->bound[k - 1]) k--; k--; }
-			else k = i;
-			if (k == 0) mDie("CIGAR/MD payload of one QNAME group exceeds the batch capacity; raise MSX_BATCH_RECORDS");
-			n_batch = k;
-			break;
+	{
+		offs_job O;
+		int nth = msh_threads(), t;
+		size_t cut = n_batch;
+		if ((size_t)nth > n_batch / 65536 + 1) nth = (int)(n_batch / 65536 + 1);
+		O.b = b; O.n = n_batch; O.mode = P->mode; O.pass = 0;
+		msh_parallel(nth, offs_worker, &O);
+		{
+			uint64_t c = 0, m = 0, g = 0;
+			for (t = 0; t < nth; t++) {
+				uint64_t tc = O.sum_c[t], tm = O.sum_m[t], tg = O.sum_g[t];
+				O.sum_c[t] = c; O.sum_m[t] = m; O.sum_g[t] = g;
+				c += tc; m += tm; g += tg;
+			}
+			if (c > 0xfffffff0ull || m > 0xfffffff0ull) mDie("CIGAR/MD payload of a batch exceeds 2^32 bytes; lower MSX_BATCH_BYTES");
+			b->n_groups = (size_t)g;
 		}
-	}
-	if (P->mode != 0) {
-		b->n = 0;
-		b->n_groups = 0;
-		rb_mark_group(b);
-		for (i = 1; i < n_batch; i++)
-			if (b->bound[i]) { b->n = i; rb_mark_group(b); }
+		O.pass = 1;
+		msh_parallel(nth, offs_worker, &O);
+		b->cigar_off[0] = 0;
+		b->md_off[0] = 0;
+		/* cut where the payload arrays are full (rare): at the last pool boundary that still fits */
+		if (b->cigar_off[n_batch] + 4 > b->cigar_cap || b->md_off[n_batch] + 16 > b->md_cap) {
+			size_t k = n_batch;
+			while (k > 0 && (b->cigar_off[k] + 4 > b->cigar_cap || b->md_off[k] + 16 > b->md_cap)) k--;
+			if (P->mode != 0) { while (k > 1 && !b->bound[k]) k--; if (!b->bound[k]) k = 0; }
+			if (k == 0) mDie("CIGAR/MD payload of one QNAME group exceeds the batch capacity; raise MSX_BATCH_RECORDS");
+			cut = k;
+			if (P->mode != 0) { size_t gq = 0, q; for (q = 0; q < cut; q++) gq += (q == 0 || b->bound[q]); b->n_groups = gq; }
+		}
+		n_batch = cut;
 	}
 	P->t_serial += now_s() - tser; tser = now_s();
 	if (P->want_stats) {
@@ -1070,6 +1126,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		        "%zu records in, %zu out, %d threads\n",
 		        now_s() - t_start, P.t_decode, P.t_wait_free, F.t_ctx, F.t_upload, F.t_gpu, F.t_fetch, F.t_wait, tw, t_wait,
 		        n_in, n_out, msh_threads());
+	fast_exit();
 	msx_ctx_destroy(g_ctx);
 	return 0;
 }
@@ -1610,6 +1667,7 @@ accumulated:
 	for (i = 0; i < n_features; i++) gzprintf(gz, "%s\t%.8g\n", feature_name[i], row[1 + i]);
 	gzclose(gz);
 
+	fast_exit();
 	msx_profile_destroy(g_ctx, prof);
 	msx_ctx_destroy(g_ctx);
 	msh_close(in);

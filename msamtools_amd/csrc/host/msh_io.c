@@ -9,6 +9,7 @@
 #include <ctype.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <sys/mman.h>
 #include <errno.h>
@@ -294,8 +295,20 @@ int msh_threads(void) {
 	if (!cached) {
 		const char *e = getenv("MSX_THREADS");
 		long n = e ? strtol(e, NULL, 10) : sysconf(_SC_NPROCESSORS_ONLN);
+		if (!e) {
+			/* what this process may actually use: its affinity mask and the cgroup's CPU quota */
+			cpu_set_t set;
+			FILE *f;
+			if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+			if ((f = fopen("/sys/fs/cgroup/cpu.max", "r")) != NULL) {
+				long long quota = 0, period = 0;
+				if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0 && (quota + period - 1) / period < n)
+					n = (long)((quota + period - 1) / period);
+				fclose(f);
+			}
+			if (n > 96) n = 96;                /* beyond that the stages of this pipeline stop gaining */
+		}
 		if (n < 1) n = 1;
-		if (!e && n > 96) n = 96;           /* beyond that the stages of this pipeline stop gaining */
 		if (n > MSH_MAX_THREADS) n = MSH_MAX_THREADS;
 		cached = (int)n;
 	}

@@ -1002,12 +1002,22 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, i
 	__syncthreads();
 	if (!s_last) return;
 	double tot = 0;
-	for (int i = threadIdx.x; i < (int)gridDim.x; i += MSX_BLOCK) {
-		const unsigned long long bits = __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(partial) + i, 0ull,
-		                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		double v;
-		__builtin_memcpy(&v, &bits, 8);
-		tot += v;
+	for (int i0 = 0; i0 < (int)gridDim.x; i0 += 8 * MSX_BLOCK) {
+		// eight reads in flight per thread (each is a round trip to the memory side), added in index order
+		unsigned long long bits[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const int i = i0 + q * MSX_BLOCK + threadIdx.x;
+			bits[q] = i < (int)gridDim.x ? __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(partial) + i, 0ull,
+			                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+			                           : 0ull;
+		}
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			double v;
+			__builtin_memcpy(&v, &bits[q], 8);
+			tot += v;
+		}
 	}
 	for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
 	__syncthreads();

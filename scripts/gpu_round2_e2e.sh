@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/e2e
 rm -rf $OUT; mkdir -p $OUT
+(nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; taskset -p $$; grep -m1 "model name" /proc/cpuinfo; free -g | head -2) > $OUT/host.txt 2>&1; cat $OUT/host.txt
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 tail -6 $OUT/pytest_gpu.log
 timeout 1500 python scripts/e2e_cli.py ${1:-10000000} 100000 > $OUT/e2e.json 2> $OUT/e2e.err
