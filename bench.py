@@ -66,6 +66,8 @@ def parse():
                     help="QNAME groups the CPU oracle is timed on (0 = the whole batch: ~7 s per run on c3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the command-line end-to-end timing (BAM file in, BAM + profile out)")
+    ap.add_argument("--e2e-groups", type=int, default=10_000_000, help="QNAME groups of the end-to-end BAM (~5 records each)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU step (msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator) "
                          "even with one rank")
@@ -81,6 +83,73 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def e2e_cli(groups, refs):
+    """The command line end to end on this box: a synthetic BAM of `groups` QNAME groups (BGZF level 6, records
+    without SEQ/QUAL) through `msamtools filter -l 80 -p 95 -z 80 --besthit -bu | msamtools profile -` -- the
+    reference's own two-process workflow -- and through either command alone.  Host-bound (BGZF inflate, record
+    walk, deflate); reported next to `value`, never as it (SURVEY.md 8d metric (ii))."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+    if not os.path.exists(exe):
+        return {"error": "msamtools_amd/bin/msamtools not built"}
+    tmp = tempfile.mkdtemp(prefix="msx_e2e_", dir="/tmp")
+    filt = "filter -l 80 -p 95 -z 80 --besthit -bu"
+    env = dict(os.environ, MSX_TIMING="1")
+
+    def stages(err, kind):
+        d = {}
+        for line in err.split("\n"):
+            if line.startswith(f"# {kind} pipeline:"):
+                for key, pat in (("wall_s", r"wall ([0-9.]+) s"), ("decode_s", r"decode ([0-9.]+) s"), ("hip_startup_s", r"start-up ([0-9.]+)"),
+                                 ("upload_s", r"upload ([0-9.]+)"), ("gpu_s", r"kernels ([0-9.]+)"), ("fetch_s", r"fetch ([0-9.]+)"),
+                                 ("upload_accumulate_s", r"upload\+accumulate ([0-9.]+)"), ("encode_s", r"encode\+write ([0-9.]+) s"),
+                                 ("threads", r"(\d+) threads")):
+                    mm = re.search(pat, line)
+                    if mm:
+                        d[key] = float(mm.group(1)) if key != "threads" else int(mm.group(1))
+        return d
+
+    def run(cmd):
+        t = time.perf_counter()
+        r = subprocess.run(cmd, shell=True, env=env, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+        dt = time.perf_counter() - t
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr.decode()[-500:])
+        return dt, r.stderr.decode()
+    try:
+        t0 = time.perf_counter()
+        subprocess.check_call(f"{exe} synth --groups {groups} --refs {refs} -b > {tmp}/in.bam", shell=True)
+        synth_s = time.perf_counter() - t0
+        n = int(subprocess.check_output(f"{exe} synth --groups {groups} --refs {refs} -u | wc -c", shell=True))   # uncompressed size
+        size_u = n
+        n = int(subprocess.check_output(f"{exe} recode {tmp}/in.bam | wc -l", shell=True))
+        dt_f, err_f = run(f"{exe} {filt} {tmp}/in.bam > {tmp}/f.bam")
+        dt_p, err_p = run(f"{exe} profile --label S -o {tmp}/p1.gz {tmp}/in.bam")
+        dt_fp, err_fp = run(f"{exe} {filt} {tmp}/in.bam | {exe} profile --label S -o {tmp}/p.gz -")
+        sf, sp = stages(err_fp, "filter"), stages(err_fp, "profile")
+        return {
+            "M_alignments_per_s": round(n / dt_fp / 1e6, 2),
+            "command": f"msamtools {filt} in.bam | msamtools profile --label S -o p.gz -",
+            "seconds": round(dt_fp, 3), "records": n,
+            "decode_s": sf.get("decode_s"), "upload_s": sf.get("upload_s"), "gpu_s": sf.get("gpu_s"), "encode_s": sf.get("encode_s"),
+            "profile_decode_s": sp.get("decode_s"), "profile_upload_accumulate_s": sp.get("upload_accumulate_s"),
+            "threads": sf.get("threads"), "host_cpus_online": os.cpu_count(),
+            "bgzf_level": {"input": 6, "pipe": 0}, "bytes_per_record": round(size_u / n, 1),
+            "input_MB": round(os.path.getsize(f"{tmp}/in.bam") / 1e6, 1),
+            "filter_alone": {"M_alignments_per_s": round(n / dt_f / 1e6, 2), "seconds": round(dt_f, 3), **stages(err_f, "filter")},
+            "profile_alone": {"M_alignments_per_s": round(n / dt_p / 1e6, 2), "seconds": round(dt_p, 3), **stages(err_p, "profile")},
+            "synth_s": round(synth_s, 1),
+            "note": "stage times are busy times of overlapping pipeline stages (decode | device | encode), not a sum",
+        }
+    except Exception as exc:
+        return {"error": str(exc)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def exchange_comm_id(m, rank, world):
@@ -415,6 +484,8 @@ def main():
     run.free()
     db.free()
     ctx.close()
+    if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
+        out["e2e"] = e2e_cli(args.e2e_groups, 100_000)
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
         try:

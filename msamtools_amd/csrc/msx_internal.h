@@ -39,7 +39,7 @@ enum msx_kid {
 	MSX_K_GENERAL_RECIP,   // k_general_recip
 	MSX_K_SHARE_REDUCE,    // k_share_reduce
 	MSX_K_PARTIAL_REDUCE,  // k_partial_reduce
-	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply / k_prop_purged
+	MSX_K_PROP_APPLY,      // k_prop_begin / k_prop_apply + k_prop_finish / k_prop_purged
 	MSX_K_LIST_ORDER,      // k_list_key, k_dup_mark, k_uniq_gather, k_entry_weight, k_part_index
 	MSX_K_RS_HIST,         // k_rs_hist
 	MSX_K_RS_SCATTER,      // k_rs_scatter
@@ -171,7 +171,7 @@ struct msx_profile {
 	double *U = nullptr, *a = nullptr;   // [n_features] U(i), a(i,k)
 	double *share = nullptr;          // [n_features] sum over multi-mappers of 1/S (all-reduced across ranks)
 	double *delta = nullptr;          // [20] device, delta[k]
-	int32_t *iter_state = nullptr;    // [4]: {done flag, iterations, arrival ticket of k_prop_apply, -}
+	int32_t *iter_state = nullptr;    // [4]: {done flag, iterations, -, -}
 	unsigned long long *csr_tot = nullptr;   // device {n_lists, n_entries}
 	double *partial = nullptr;        // device [workgroups of k_prop_apply]: their sums of diff^2
 	uint32_t *purged_local = nullptr; // device [1]

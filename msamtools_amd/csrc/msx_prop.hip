@@ -10,7 +10,7 @@
 //   recip[j] = w/S for the few longer lists                one lane per such list (k_general_recip);
 //                                                         their entries gather it in k_share_reduce
 //   a[f] = U[f] + a[f] * (share[f] + the partial sums of segments cut by a chunk boundary),
-//   clamp, DELTA^2 and the convergence flag               (k_prop_apply, last workgroup finishes)
+//   clamp, DELTA^2 and the convergence flag               (k_prop_apply, k_prop_finish)
 // T's feature-major order is produced once per finalize by a stable LSD radix
 // sort of (feature, list) pairs, so entries of one feature are contiguous and
 // in ascending list order; hot features spread over many waves instead of
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint
 		share[i] = 0.0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x < 20) delta[threadIdx.x] = 0.0;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; iter_state[2] = 0; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) { iter_state[0] = 0; iter_state[1] = 0; }
 }
 
 // recip[j] = w_j/S_j for every general list j (S_j = sum of a over its features, w_j the number of
@@ -923,9 +923,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 // owns a run of partial slots instead -- the streaming workgroups leave those features (bitmap `owned`)
 // to the workgroups behind them, where one thread per run adds its slots in slot order (a fixed
 // summation order: results repeat bit for bit) and updates the feature.  Not FUSED: share[] is complete
-// (k_partial_reduce -- atomics -- and the caller's all-reduce have run).  The workgroup that finishes
-// last adds the per-workgroup sums of diff^2 in index order and sets delta[k], the iteration count and
-// the done flag -- no separate launch.
+// (k_partial_reduce -- atomics -- and the caller's all-reduce have run).  Every workgroup leaves its sum
+// of diff^2 for k_prop_finish.
 __device__ __forceinline__ double prop_update(int64_t i, double sh, const double *U, double *a, double *share) {
 	const double old = a[i];
 	double v = U[i] + old * sh;
@@ -943,10 +942,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, i
                                                           const PartRun *__restrict__ runs,
                                                           const double *__restrict__ part_val,
                                                           const uint32_t *__restrict__ owned,
-                                                          double *__restrict__ partial, double *__restrict__ delta,
-                                                          int32_t *iter_state, int k) {
+                                                          double *__restrict__ partial,
+                                                          const int32_t *__restrict__ iter_state) {
 	__shared__ double s_w[MSX_BLOCK / 64];
-	__shared__ int s_last;
 	if (iter_state[0]) return;
 	double acc = 0;
 	if ((int)blockIdx.x < nsb) {
@@ -985,49 +983,26 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, i
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
 	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	// ---- the last workgroup to arrive finishes the iteration.  Hand-over by memory-side atomics only:
-	// the sum goes out with an atomic exchange, waited for before the ticket is drawn; the last
-	// workgroup reads the sums back with returning ORs of zero.  (A release fence per workgroup writes
-	// back the whole XCD L2 -- a[] and share[] just dirtied -- a thousand times per launch: 44 us.)
-	if (threadIdx.x == 0) {
-		const double mine = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-		unsigned long long bits;
-		__builtin_memcpy(&bits, &mine, 8);
-		(void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(partial) + blockIdx.x, bits, __ATOMIC_RELAXED,
-		                            __HIP_MEMORY_SCOPE_AGENT);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the exchange has been performed before the ticket is drawn
-		const int old = __hip_atomic_fetch_add(&iter_state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-	}
-	__syncthreads();
-	if (!s_last) return;
-	double tot = 0;
-	for (int i0 = 0; i0 < (int)gridDim.x; i0 += 8 * MSX_BLOCK) {
-		// eight reads in flight per thread (each is a round trip to the memory side), added in index order
-		unsigned long long bits[8];
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const int i = i0 + q * MSX_BLOCK + threadIdx.x;
-			bits[q] = i < (int)gridDim.x ? __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(partial) + i, 0ull,
-			                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-			                           : 0ull;
-		}
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			double v;
-			__builtin_memcpy(&v, &bits[q], 8);
-			tot += v;
-		}
-	}
-	for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
-	__syncthreads();
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = tot;
+	if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// DELTA^2 = sum of the per-workgroup sums, in index order, over n_features; convergence (:380-383).
+// (A launch of its own: letting the last workgroup of k_prop_apply do it needs a ticket that a thousand
+// workgroups draw from one address -- 12 us of serialised atomics -- or a release fence per workgroup,
+// which writes back the whole L2 each time -- 44 us; a dependent launch costs 2.)
+__global__ __launch_bounds__(MSX_BLOCK) void k_prop_finish(int nparts, const double *__restrict__ partial, int32_t nf,
+                                                           double *__restrict__ delta, int32_t *iter_state, int k) {
+	__shared__ double s_w[MSX_BLOCK / 64];
+	if (iter_state[0]) return;
+	double acc = 0;
+	for (int i = threadIdx.x; i < nparts; i += MSX_BLOCK) acc += partial[i];
+	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		const double dl = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) / nf;   // :380
 		delta[k] = dl;
 		iter_state[1] = k;
-		iter_state[2] = 0;                                         // the ticket, for the next iteration
 		if (dl < 1e-10) iter_state[0] = 1;                         // :383
 	}
 }
@@ -1253,12 +1228,14 @@ int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused) {
 		hipLaunchKernelGGL(k_prop_apply<true>, dim3((unsigned)(nsb + nrb)), dim3(MSX_BLOCK), 0, ctx->stream, nf, nsb,
 		                   2 * msx_share_waves(ctx), (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
 		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
-		                   p->partial, p->delta, p->iter_state, k);
+		                   p->partial, (const int32_t *)p->iter_state);
 	else
 		hipLaunchKernelGGL(k_prop_apply<false>, dim3((unsigned)nsb), dim3(MSX_BLOCK), 0, ctx->stream, nf, nsb,
 		                   2 * msx_share_waves(ctx), (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
 		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
-		                   p->partial, p->delta, p->iter_state, k);
+		                   p->partial, (const int32_t *)p->iter_state);
+	hipLaunchKernelGGL(k_prop_finish, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, fused ? nsb + nrb : nsb,
+	                   (const double *)p->partial, nf, p->delta, p->iter_state, k);
 	msx_time_end(ctx);
 	return MSX_OK;
 }

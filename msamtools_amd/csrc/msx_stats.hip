@@ -102,19 +102,14 @@ __device__ __forceinline__ void sf_load_tile(const FilterArgs &A, uint32_t n, ui
 // One pass of the flat MD walk: bytes [lo, lo + SF_BYTES) of the tile's span (positions relative to the
 // 16-byte aligned `base`).  p0/p1/p2 = the lane's three string boundaries in that space.  MULTI: the tile
 // needs more than one pass, so boundaries are clamped to this pass.
-// this lane's 16 bytes of the pass that starts at `lo` (an aligned block holding >= 1 valid byte, or nothing)
-__device__ __forceinline__ uint4 sf_md_chunk(const uint8_t *base, uint32_t span, uint32_t lo, int lane) {
-	const uint32_t cpos = lo + 16u * (uint32_t)lane;
-	uint4 xv = make_uint4(0u, 0u, 0u, 0u);
-	if (cpos < span) xv = *reinterpret_cast<const uint4 *>(base + cpos);
-	return xv;
-}
-
 template <bool MULTI>
-__device__ __forceinline__ void sf_md_pass(SfLds &L, int lane, uint4 xv, uint32_t lo,
+__device__ __forceinline__ void sf_md_pass(SfLds &L, int lane, const uint8_t *base, uint32_t span, uint32_t lo,
                                            uint32_t p0, uint32_t p1, uint32_t p2, bool realA, bool realB,
                                            uint32_t &cin_pass, uint32_t &mdeA, uint32_t &mdeB) {
 	*reinterpret_cast<uint4 *>(&L.start[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+	const uint32_t cpos = lo + 16u * (uint32_t)lane;
+	uint4 xv = make_uint4(0u, 0u, 0u, 0u);
+	if (cpos < span) xv = *reinterpret_cast<const uint4 *>(base + cpos);   // aligned block holding >= 1 valid byte
 	wave_sync();
 	{
 		const uint32_t pa = p0 - lo, pb = p1 - lo;     // wraps when the string begins before this pass
@@ -158,29 +153,6 @@ __device__ __forceinline__ void sf_md_pass(SfLds &L, int lane, uint4 xv, uint32_
 }
 
 // the part of a record after its statistics: --rescore, predicates, pool byte (msam_filter.c:31-63,132-183)
-struct SfPay {               // the loads of a tile that need its offsets: issued one tile ahead
-	uint4 md;                // this lane's 16 bytes of the first MD pass
-	uint32_t cA, cB;         // first CIGAR word of either record (0 when absent: zero M bases)
-};
-
-template <bool EXTRA>
-__device__ __forceinline__ void sf_issue_payload(const FilterArgs &A, uint32_t n, uint32_t tile, int lane, uint32_t d,
-                                                 const SfTile &o, SfPay &p) {
-	const uint32_t tA = tile * SF_RECS + 2u * (uint32_t)lane;
-	const bool stats_all = EXTRA && A.o_len != nullptr;
-	const bool walkA = tA < n && (stats_all || !((o.fl & 0xffffu) & MSX_F_UNMAP));
-	const bool walkB = tA + 1 < n && (stats_all || !((o.fl >> 16) & MSX_F_UNMAP));
-	p.cA = (walkA && o.co1 != o.co0) ? A.cigar[o.co0] : 0u;
-	p.cB = (walkB && o.co2 != o.co1) ? A.cigar[o.co1] : 0u;
-	const uint32_t m_begin = __builtin_amdgcn_readfirstlane(o.mo0);
-	const uint32_t m_end = __builtin_amdgcn_readlane(o.mo2, 63);
-	p.md = make_uint4(0u, 0u, 0u, 0u);
-	if (m_end > m_begin) {
-		const uint32_t B0 = (m_begin + d) & ~15u;
-		p.md = sf_md_chunk(A.md + ((int64_t)B0 - (int64_t)d), m_end + d - B0, 0u, lane);
-	}
-}
-
 // EXTRA = false: the plain filter call (no per-record statistics out, no --rescore), the variant the
 // bench runs; its dead arguments cost no scalar registers.
 template <bool EXTRA>
@@ -238,18 +210,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_flat(FilterArgs A) {
 	const uint32_t d = (uint32_t)(reinterpret_cast<uintptr_t>(A.md) & 15u);
 	const bool stats_all = EXTRA && A.o_len != nullptr;      // msx_aln_stats: statistics for every record, mapped or not
 
-	// Three tiles in flight per wave: the offsets of tile i+2 and the payload of tile i+1 (its first CIGAR
-	// words and its MD bytes, whose addresses need that tile's offsets) are loading while tile i is
-	// computed -- the kernel is bound by memory latency, not by instructions or bytes.
-	SfTile cur, nxt, nn;
-	SfPay pay, pay_n;
+	// (also tried: the next tile's first CIGAR words and MD bytes in flight as well, three tiles per wave --
+	// 22 more registers, 5 waves per SIMD instead of 8, 0.65 ms against 0.59)
+	SfTile cur, nxt;
 	sf_load_tile(A, n, first, lane, cur);
-	if (first + step < n_tiles) sf_load_tile(A, n, first + step, lane, nxt);
-	sf_issue_payload<EXTRA>(A, n, first, lane, d, cur, pay);
 	for (uint32_t tile = first; tile < n_tiles; tile += step) {
-		const bool has_next = tile + step < n_tiles;       // (n_tiles + 2 * step < 2^32: n < 2^31)
-		if (tile + 2 * step < n_tiles) sf_load_tile(A, n, tile + 2 * step, lane, nn);
-		if (has_next) sf_issue_payload<EXTRA>(A, n, tile + step, lane, d, nxt, pay_n);
+		const bool has_next = tile + step < n_tiles;       // (n_tiles + step < 2^32: n < 2^31)
+		if (has_next) sf_load_tile(A, n, tile + step, lane, nxt);      // in flight while this tile is computed
 
 		const uint32_t tA = tile * SF_RECS + 2u * (uint32_t)lane, tB = tA + 1;
 		const bool realA = tA < n, realB = tB < n;
@@ -259,8 +226,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_flat(FilterArgs A) {
 		const bool walkA = realA && (stats_all || !(flagA & MSX_F_UNMAP));
 		const bool walkB = realB && (stats_all || !(flagB & MSX_F_UNMAP));
 		const bool mdA = (rfA & MSX_HAS_MD) != 0, mdB = (rfB & MSX_HAS_MD) != 0;
+
+		// ---- first CIGAR words: issued before the MD pass so that they arrive underneath it ----
 		const uint32_t nA = cur.co1 - cur.co0, nB = cur.co2 - cur.co1;
-		const uint32_t cA = pay.cA, cB = pay.cB;
+		uint32_t cA = 0, cB = 0;
+		if (walkA && nA) cA = A.cigar[cur.co0];
+		if (walkB && nB) cB = A.cigar[cur.co1];
 
 		// ---- MD: flat walk over the tile's bytes ----
 		uint32_t mdeA = 0, mdeB = 0;
@@ -276,12 +247,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_flat(FilterArgs A) {
 				const uint32_t p0 = cur.mo0 + d - B0, p1 = cur.mo1 + d - B0, p2 = cur.mo2 + d - B0;
 				uint32_t cin_pass = 0;
 				if (span <= SF_BYTES) {
-					sf_md_pass<false>(L, lane, pay.md, 0u, p0, p1, p2, realA, realB, cin_pass, mdeA, mdeB);
+					sf_md_pass<false>(L, lane, base, span, 0u, p0, p1, p2, realA, realB, cin_pass, mdeA, mdeB);
 				} else {
-					sf_md_pass<true>(L, lane, pay.md, 0u, p0, p1, p2, realA, realB, cin_pass, mdeA, mdeB);
-					for (uint32_t lo = SF_BYTES; lo < span; lo += SF_BYTES)
-						sf_md_pass<true>(L, lane, sf_md_chunk(base, span, lo, lane), lo, p0, p1, p2, realA, realB, cin_pass,
-						                 mdeA, mdeB);
+					for (uint32_t lo = 0; lo < span; lo += SF_BYTES)
+						sf_md_pass<true>(L, lane, base, span, lo, p0, p1, p2, realA, realB, cin_pass, mdeA, mdeB);
 				}
 			}
 		}
@@ -342,8 +311,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_aln_stats_flat(FilterArgs A) {
 			}
 		}
 		cur = nxt;
-		pay = pay_n;
-		nxt = nn;
 	}
 }
 
