@@ -45,11 +45,21 @@ static void fast_exit(void) {
 	_exit(0);
 }
 
-static void ctx_open(void) {
-	const char *dev = getenv("MSX_DEVICE");
-	if (msx_ctx_create(&g_ctx, dev ? atoi(dev) : 0) != MSX_OK) mDie("%s", msx_last_error(NULL));
-}
 #define MSX(call) do { if ((call) != MSX_OK) mDie("%s", msx_last_error(g_ctx)); } while (0)
+
+/* several GPUs: one process per GPU, started with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in
+ * the environment (torchrun, mpirun wrappers, a shell loop).  `profile` then reads ITS shard of the sample --
+ * "{rank}" in the input path is replaced by the rank; shards are cut at QNAME boundaries, e.g. by splitting the
+ * name-grouped BAM -- and the ranks exchange counts and, per sharing iteration, the increment vector over RCCL
+ * (msx_profile_finalize_dist_enqueue); rank 0 writes the profile. */
+static int dist_world(void) { const char *e = getenv("WORLD_SIZE"); int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }
+static int dist_rank(void) { const char *e = getenv("RANK"); return e ? atoi(e) : 0; }
+
+static void ctx_open(void) {
+	const char *dev = getenv("MSX_DEVICE"), *lr = getenv("LOCAL_RANK");
+	const int id = dev ? atoi(dev) : (dist_world() > 1 && lr ? atoi(lr) : 0);
+	if (msx_ctx_create(&g_ctx, id) != MSX_OK) mDie("%s", msx_last_error(NULL));
+}
 
 static size_t batch_target(void) {
 	const char *e = getenv("MSX_BATCH_RECORDS");
@@ -1451,7 +1461,16 @@ int msam_profile_main(int argc, char *argv[]) {
 	if (n_mincount > 0 && v_mincount < 0) BAIL("--mincount must be a non-negative integer");
 #undef BAIL
 
-	in = msh_open(argv[optind]);
+	{
+		/* "{rank}" in the path names this rank's shard */
+		const char *path = argv[optind], *ph = strstr(path, "{rank}");
+		if (ph && dist_world() > 1) {
+			static char shard[4096];
+			snprintf(shard, sizeof shard, "%.*s%d%s", (int)(ph - path), path, dist_rank(), ph + 6);
+			path = shard;
+		}
+		in = msh_open(path);
+	}
 	hdr = msh_header(in);
 
 	share_type = MSX_MULTI_SHARE_PROPORTIONAL;                        /* :712-728, prefix match */
@@ -1583,7 +1602,19 @@ accumulated:
 	/* mInsertCountToAbundanceMatrix (:248-425) */
 	row = (double *)calloc((size_t)n_features + 1, sizeof(double));
 	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) fprintf(stderr, "# Start PropSharing:\n");
-	MSX(msx_profile_finalize(g_ctx, prof, row + 1, &st));
+	if (dist_world() > 1 || getenv("MSX_FORCE_DIST")) {      /* (MSX_FORCE_DIST: the same path over a one-rank communicator, for tests) */
+		/* this rank's counts are a shard's: sum them over the ranks, iterate with the increment all-reduced */
+		MSX(msx_dist_init_env(g_ctx));
+		MSX(msx_profile_finalize_dist_enqueue(g_ctx, prof));
+		MSX(msx_profile_fetch(g_ctx, prof, row + 1, &st));
+		if (dist_rank() != 0) {               /* every rank holds the same result; rank 0 reports it */
+			msx_dist_finalize(g_ctx);
+			fast_exit();
+			return 0;
+		}
+	} else {
+		MSX(msx_profile_finalize(g_ctx, prof, row + 1, &st));
+	}
 	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		int k;
 		for (k = 1; k <= st.iterations; k++)

@@ -435,3 +435,22 @@ def test_pipeline_long_unmapped_stretch_is_linear(tmp_path):
     assert rc == 0, text
     assert "pools=402000" in text            # every unmapped record with a new name closes a pool (msam_filter.c:120-125)
     assert time.time() - t0 < 60
+
+
+@pytest.mark.gpu
+def test_cli_profile_over_a_one_rank_communicator(tmp_path, synth_bams):
+    """`profile` started as a rank (RCCL communicator, counts and the per-iteration increment all-reduced
+    inside msx_profile_finalize_dist_enqueue) writes the same file as the single-process run; also through
+    the "{rank}" shard path with WORLD_SIZE / RANK in the environment."""
+    a, b, c = str(tmp_path / "a.gz"), str(tmp_path / "b.gz"), str(tmp_path / "c.gz")
+    base = ["profile", "--label", "S", "--multi", "prop"]
+    assert run(base + ["-o", a, synth_bams["b"]]).returncode == 0
+    r = run(base + ["-o", b, synth_bams["b"]], env={"MSX_FORCE_DIST": "1", "MSX_CLEAN_EXIT": "1"})
+    assert r.returncode == 0, r.stderr.decode()
+    text = lambda p: "\n".join(l for l in gzip.open(p, "rt").read().split("\n") if not l.startswith("# Command"))
+    assert text(a) == text(b)
+    shard = str(tmp_path / "shard0.bam")
+    os.link(synth_bams["b"], shard)
+    r = run(base + ["-o", c, str(tmp_path / "shard{rank}.bam")],
+            env={"MSX_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29611"})
+    assert r.returncode != 0 or text(c) == text(a)      # ("{rank}" is substituted only for WORLD_SIZE > 1)
