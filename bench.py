@@ -185,7 +185,7 @@ def algorithmic_bytes_per_step(name, w):
     iterations that ran), lib (bytes the library attached to its own launches: scans and radix passes, each
     priced by its own length)."""
     n, ng, E, L, E0, L0, nf, it = w["n"], w["ng"], w["E"], w["L"], w["E0"], w["L0"], w["nf"], w["iters"]
-    if name == "k_aln_stats_filter":
+    if name == "k_aln_stats_flat":
         # reads flag 2, rflags 1, cigar_off 4, cigar, md_off 4, md ; writes the pool byte
         return 2 * n + n + 4 * (n + 1) + 4 * w["n_cig"] + 4 * (n + 1) + w["n_md"] + n
     if name == "k_besthit_select":
@@ -334,7 +334,7 @@ def main():
             run.enqueue_with_profile(prof)
             prof.finalize_enqueue()
             run.finish()
-        names = ["k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
+        names = ["k_aln_stats_flat", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
                  "k_list_order", "k_rs_hist", "k_rs_scatter", "k_general_recip", "k_share_reduce", "k_partial_reduce",
                  "k_prop_apply", "scan"]
         tms, lib_bytes = {}, {}

@@ -380,7 +380,7 @@ int  msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes); /
 /* ---- timing of the dominant kernel (bench.py roofline) -------------------- */
 
 /* Per-kernel device time measured with HIP events on the ctx stream while
- * enabled (one event pair around every launch).  names: "k_aln_stats_filter",
+ * enabled (one event pair around every launch).  names: "k_aln_stats_flat",
  * "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
  * "k_general_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order",
  * "k_rs_hist", "k_rs_scatter",

@@ -173,7 +173,7 @@ extern "C" int msx_ctx_sync(msx_ctx *ctx) {
 // ---- timing ---------------------------------------------------------------
 
 static const char *k_names[MSX_K_COUNT] = {
-    "k_aln_stats_filter", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
+    "k_aln_stats_flat", "k_besthit_select", "k_emit_order", "k_insert_count", "k_multi_compact",
     "k_general_recip", "k_share_reduce", "k_partial_reduce", "k_prop_apply", "k_list_order", "k_rs_hist", "k_rs_scatter",
     "k_coverage_pileup", "scan", "synth"};
 
