@@ -31,7 +31,7 @@
 
 // kernel ids for the timing table
 enum msx_kid {
-	MSX_K_ALN_STATS = 0,   // k_aln_stats_filter
+	MSX_K_ALN_STATS = 0,   // k_aln_stats_flat
 	MSX_K_BESTHIT,         // k_besthit_select
 	MSX_K_EMIT,            // k_emit_groups / k_emit_count + k_emit_fill
 	MSX_K_INSERT_COUNT,    // k_insert_count; the partition count of the unique-insert keys (msx_count_keys)

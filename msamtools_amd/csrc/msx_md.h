@@ -26,7 +26,7 @@ struct MdState {
 // ---------------------------------------------------------------------------
 // Flat walk: the same rule over a whole span of MD strings stored back to back,
 // sixteen bytes per lane, work proportional to the bytes instead of to the
-// longest string of the wave (k_aln_stats_filter).
+// longest string of the wave (k_aln_stats_flat).
 //
 // Restated rule: a byte that is neither a digit nor '^' (a "letter") counts
 // unless the maximal run of letters it belongs to begins at the first byte of

@@ -612,7 +612,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(const unsigned long
 #define SR_SENT 0xffffffffu
 #define SR_EPL 8                       // consecutive entries summed by one lane
 #define SR_STEP (64 * SR_EPL)          // entries per wave step
-#define SR_WIN 512                     // features of a[] a wave stages in LDS per step
 #define SR_WAVES_PER_SIMD 3            // 126 registers would allow 4; 3 measured faster (52 us against 55): ONE round of waves
 
 struct SegRow {
@@ -653,19 +652,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
                                                             const unsigned long long *__restrict__ t_val,
                                                             const double *__restrict__ recip,
                                                             const double *__restrict__ a, int bits, int64_t W,
-                                                            int32_t nf, int win_on,
                                                             double *__restrict__ share,
                                                             double *__restrict__ part_val,
                                                             const int32_t *__restrict__ iter_state) {
-	// a[] of the SR_WIN features from the step's first one on, staged per wave: the entries are sorted by
-	// feature and the other features of a list mostly belong to the same family of references, so most
-	// gathers fall into this window and become LDS reads -- a scattered 8-byte global gather costs the
-	// vector cache one cycle per lane, and those cycles are what this kernel spends its time on
-	__shared__ double s_win[MSX_BLOCK / 64][SR_WIN + 8];
 	if (iter_state[0]) return;
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
-	double *win = s_win[threadIdx.x >> 6];
 	// (consecutive workgroups -- which the dispatcher deals round-robin to the 8 XCDs -- take
 	// consecutive chunks, so the XCDs walk the feature range together.  Keeping windows of it on one
 	// XCD measured slower the longer the window: groups of 4 / 16 / 64 workgroups per XCD 58 / 60 / 67 us
@@ -725,35 +717,20 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  General lists: recip[u].
 		double x[SR_EPL];
 		{
-			// (fetching an index only when it differs from the previous entry's -- a lane's 8 entries mostly
-			// share their feature -- measured slower: 67 us against 55; the selects cost more than the lanes saved)
+			// (measured slower: fetching an index only when it differs from the previous entry's -- a lane's 8
+			// entries mostly share their feature -- 67 us against 55; a[] of the 512 features from the step's
+			// first one on staged in LDS, in-window gathers as ds_read_b64 -- 65 us against 53)
 			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
-			uint32_t w_lo = 0xffffffffu;                     // (no window: every index is "outside")
-			if (win_on) {
-				w_lo = __builtin_amdgcn_readfirstlane(k[0] & fmask);     // lane 0's first entry exists (base < c1)
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();                         // the previous step's reads are done
-				const uint32_t f0 = w_lo + (uint32_t)lane * 8u;
-#pragma unroll
-				for (int j = 0; j < 8; j++) win[lane * 8 + j] = (f0 + (uint32_t)j < (uint32_t)nf) ? a[f0 + j] : 0.0;
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			}
-			auto fetch = [&](uint32_t idx) -> double {
-				const uint32_t r = idx - w_lo;
-				return (r < SR_WIN) ? win[r] : a[idx];
-			};
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
 				const bool live = k[i] != SR_SENT;
 				const bool general = (lv[i] & SIG_HASHED) != 0;
 				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
 				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : fetch(k[i] & fmask);
-				a1[i] = (live && !general && o1 != SIG_PAD) ? fetch(o1) : 0.0;
-				a2[i] = (live && !general && o2 != SIG_PAD) ? fetch(o2) : 0.0;
-				a3[i] = (live && !general && o3 != SIG_PAD) ? fetch(o3) : 0.0;
+				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
+				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
+				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
+				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
 			}
 #pragma unroll
 			for (int i = 0; i < SR_EPL; i++) {
@@ -1068,10 +1045,6 @@ int64_t msx_share_waves(msx_ctx *ctx) {
 	}();
 	return (int64_t)ctx->num_cu * 4 * wps;
 }
-static int msx_share_window(void) {
-	static const int on = [] { const char *e = getenv("MSX_SR_WIN"); return e ? atoi(e) != 0 : 1; }();   // experiments
-	return on;
-}
 int64_t msx_apply_blocks(int32_t nf) { return nf > 0 ? ((int64_t)nf + PA_FPB - 1) / PA_FPB : 1; }
 
 static int nf_grid(msx_ctx *ctx, int32_t nf) {
@@ -1234,8 +1207,8 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
 	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
-	                             (const double *)p->a, p->key_bits, W, p->n_features, msx_share_window(), p->share,
-	                             (double *)p->part_val.p, (const int32_t *)p->iter_state));
+	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
+	                             (const int32_t *)p->iter_state));
 	if (complete) {
 		const int64_t M = 2 * W;
 		const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;

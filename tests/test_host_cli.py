@@ -454,3 +454,30 @@ def test_cli_profile_over_a_one_rank_communicator(tmp_path, synth_bams):
     r = run(base + ["-o", c, str(tmp_path / "shard{rank}.bam")],
             env={"MSX_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29611"})
     assert r.returncode != 0 or text(c) == text(a)      # ("{rank}" is substituted only for WORLD_SIZE > 1)
+
+
+@pytest.mark.gpu
+def test_cli_fatal_record_leaves_no_partial_batch(tmp_path):
+    """A record with neither MD nor NM is fatal for -p (msam_filter.c:150-152).  The reference dies AT that
+    record, after having written the pools before it; here the error is reported for the batch the record
+    is in, so nothing of that batch is written (the stated difference).  Same message,
+    same exit status."""
+    sam = tmp_path / "bad.sam"
+    good = "r{0}\t0\tchr1\t{1}\t255\t50M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:50\tAS:i:50\n"
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:chr1\tLN:100000\n")
+        for i in range(3):
+            fh.write(good.format(i, 100 + i))
+        fh.write("r3\t0\tchr1\t200\t255\t50M\t*\t0\t0\t*\t*\tAS:i:50\n")          # no MD, no NM
+        fh.write(good.format(4, 300))
+    r = run(["filter", "-S", "-p", "95", str(sam)])
+    assert r.returncode == 1
+    assert r.stderr.decode().strip().endswith(
+        "Fatal Error: Either NM or MD must be present in SAM/BAM input for 'filter' command. "
+        "Type 'msamtools filter -h' for details.")
+    assert r.stdout == b""            # the reference would have printed r0..r2 before dying
+    # the same file through the BAM pipeline
+    bam = tmp_path / "bad.bam"
+    bam.write_bytes(run(["recode", "-b", str(sam)]).stdout)
+    r = run(["filter", "-p", "95", str(bam)])
+    assert r.returncode == 1 and r.stdout == b"" and b"Either NM or MD must be present" in r.stderr
