@@ -2,6 +2,8 @@
 // configs[3]): per-base depth of every reference (msam_coverage.c:33-87, 106-139).
 #include "msx_internal.h"
 
+#include <cstdlib>
+
 // ---------------------------------------------------------------------------
 // coverage pile-up (msam_coverage.c:33-87).  The reference adds 1 to every base
 // of every M/=/X run.  Here a run [p, p+w) is recorded as +1 at p and -1 at p+w
@@ -56,14 +58,165 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Large batches: the binned pile-up.  Scattered global atomics run memory-side at
+// ~27 G/s on this chip (one per run end: 100 M of them for 50 M reads), so for a batch
+// that is large against the depth array the +1 / -1 marks are not added one by one:
+//   k_cov_emit   every run end becomes an item (tile, cell inside the tile, sign);
+//                a wave reserves room for its items with one global add
+//   radix sort   of the items by tile (2 passes for 16 K-cell tiles of a 250 M-cell array)
+//   k_cov_tile   one workgroup per tile adds its items into an LDS image of the tile
+//                (ds_add) and then adds the image to the depth array, coalesced
+// The depth array keeps holding differences, so both paths can feed one sample.
+// ---------------------------------------------------------------------------
+#define CV_TILE_SHIFT 14
+#define CV_TILE (1u << CV_TILE_SHIFT)
+#define CV_LANE_ITEMS 8               // run ends a lane keeps in registers; a record with more falls back to atomics
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit(int64_t n, const int32_t *__restrict__ tid,
+                                                        const int32_t *__restrict__ pos,
+                                                        const uint32_t *__restrict__ cigar_off,
+                                                        const uint32_t *__restrict__ cigar,
+                                                        const int64_t *__restrict__ cov_off, int32_t *__restrict__ diff,
+                                                        uint8_t *__restrict__ covered, uint32_t *__restrict__ ikey,
+                                                        uint32_t *__restrict__ ival, unsigned long long *n_items) {
+	const int lane = threadIdx.x & 63;
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i0 = (int64_t)blockIdx.x * MSX_BLOCK; i0 < n; i0 += stride) {
+		const int64_t i = i0 + threadIdx.x;
+		int64_t cell[CV_LANE_ITEMS];      // global cell index of a mark; even slots +1, odd slots -1
+		int cnt = 0;
+		if (i < n) {
+			const int32_t t = tid[i];
+			if (t >= 0) {                                        // :42
+				if (covered) covered[t] = 1;                     // :45-49
+				const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
+				int64_t p = pos[i];
+				const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
+				int64_t run_start = -1;
+				auto mark = [&](int64_t s, int64_t e) {
+					if (s < 0) s = 0;
+					if (e > t_len) e = t_len;
+					if (e <= s) return;
+					if (cnt + 2 <= CV_LANE_ITEMS) { cell[cnt++] = t_beg + s; cell[cnt++] = t_beg + e; }
+					else { atomicAdd(&diff[t_beg + s], 1); atomicAdd(&diff[t_beg + e], -1); }
+				};
+				for (uint32_t k = ks; k < ke; ++k) {
+					const uint32_t op = cigar[k] & 0xf, w = cigar[k] >> 4;
+					if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
+						if (run_start < 0) run_start = p;
+						p += w;
+					} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
+						if (run_start >= 0 && w > 0) { mark(run_start, p); run_start = -1; }
+						p += w;
+					}
+				}
+				if (run_start >= 0) mark(run_start, p);
+			}
+		}
+		// room for the wave's items: an exclusive prefix over the lanes, one global add
+		uint32_t incl = (uint32_t)cnt;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += o;
+		}
+		const uint32_t total = __shfl(incl, 63, 64);
+		unsigned long long base = 0;
+		if (lane == 0 && total) base = atomicAdd(n_items, (unsigned long long)total);
+		base = __shfl(base, 0, 64) + (incl - (uint32_t)cnt);
+		for (int q = 0; q < cnt; q++) {
+			ikey[base + q] = (uint32_t)(cell[q] >> CV_TILE_SHIFT);
+			ival[base + q] = (uint32_t)(cell[q] & (CV_TILE - 1)) | ((q & 1) ? 0x80000000u : 0u);
+		}
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ikey, const uint32_t *__restrict__ ival,
+                                                        const unsigned long long *__restrict__ n_items, int64_t total_cells,
+                                                        int32_t *__restrict__ diff) {
+	__shared__ int32_t s_d[CV_TILE];
+	__shared__ uint32_t s_lo, s_hi;
+	const uint32_t tile = blockIdx.x;
+	if (threadIdx.x < 2) {
+		// the tile's items: [lower bound of tile, lower bound of tile + 1) among the sorted keys
+		const uint32_t want = tile + threadIdx.x;
+		int64_t lo = 0, hi = (int64_t)*n_items;
+		while (lo < hi) {
+			const int64_t mid = (lo + hi) >> 1;
+			if (ikey[mid] < want) lo = mid + 1; else hi = mid;
+		}
+		if (threadIdx.x == 0) s_lo = (uint32_t)lo; else s_hi = (uint32_t)lo;
+	}
+	__syncthreads();
+	const uint32_t lo = s_lo, hi = s_hi;
+	if (lo == hi) return;
+	for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) s_d[q] = 0;
+	__syncthreads();
+	for (uint32_t q = lo + threadIdx.x; q < hi; q += MSX_BLOCK) {
+		const uint32_t v = ival[q];
+		atomicAdd(&s_d[v & (CV_TILE - 1)], (v & 0x80000000u) ? -1 : 1);
+	}
+	__syncthreads();
+	const int64_t c0 = (int64_t)tile << CV_TILE_SHIFT;
+	for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) {
+		const int32_t d = s_d[q];
+		if (d != 0 && c0 + q <= total_cells) diff[c0 + q] += d;        // (this workgroup alone owns the tile's cells)
+	}
+}
+
 extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets,
                                        int32_t *cov, uint8_t *covered) {
-	(void)n_targets;
 	if (!ctx || !b || !cov_off || !cov) return MSX_ERR_ARG;
 	if (!b->pos || !b->tid || !b->cigar_off || !b->cigar)
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_accumulate needs tid, pos and cigar arrays");
 	if (b->n_records == 0) return MSX_OK;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	static const int64_t binned_from = [] {
+		const char *e = getenv("MSX_COV_BINNED_FROM");          // records per batch from which the binned path is used
+		return e ? atoll(e) : (int64_t)(2 << 20);
+	}();
+	if (b->n_records >= binned_from && n_targets > 0) {
+		// sizes that live on the device: the end of the depth array, the number of CIGAR words (a record yields
+		// at most one run per word, plus the marks it keeps in registers are bounded per lane)
+		int64_t total_cells = 0;
+		uint32_t n_cig = 0;
+		MSX_HIP(ctx, hipMemcpyAsync(&total_cells, cov_off + n_targets, 8, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(&n_cig, b->cigar_off + b->n_records, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		const int64_t cap = (int64_t)CV_LANE_ITEMS * b->n_records < 2 * (int64_t)n_cig ? (int64_t)CV_LANE_ITEMS * b->n_records
+		                                                                               : 2 * (int64_t)n_cig;
+		const int64_t n_tiles = (total_cells + 1 + CV_TILE - 1) >> CV_TILE_SHIFT;
+		int bits = 1;
+		while (((int64_t)1 << bits) < n_tiles) bits++;
+		int rc;
+		for (int q = 0; q < 2; q++) {
+			if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(cap + 64) * 4))) return rc;
+			if ((rc = msx_reserve(ctx, &ctx->cv_val[q], (size_t)(cap + 64) * 4))) return rc;
+		}
+		if ((rc = msx_reserve(ctx, &ctx->cv_cnt, 16))) return rc;
+		MSX_HIP(ctx, hipMemsetAsync(ctx->cv_cnt.p, 0, 8, ctx->stream));
+		msx_time_begin(ctx, MSX_K_COVERAGE);
+		hipLaunchKernelGGL(k_cov_emit, dim3(msx_grid_x(ctx, b->n_records, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   b->n_records, b->tid, b->pos, b->cigar_off, b->cigar, cov_off, cov, covered,
+		                   (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_val[0].p, (unsigned long long *)ctx->cv_cnt.p);
+		unsigned long long n_items = 0;
+		MSX_HIP(ctx, hipMemcpyAsync(&n_items, ctx->cv_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (n_items) {
+			int sel = 0;
+			if ((rc = msx_sort_pairs32(ctx, (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_val[0].p,
+			                           (uint32_t *)ctx->cv_key[1].p, (uint32_t *)ctx->cv_val[1].p, (int64_t)n_items, bits,
+			                           &ctx->cv_hist, &ctx->cv_off, &sel)))
+				return rc;
+			hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
+			                   (const uint32_t *)ctx->cv_key[sel].p, (const uint32_t *)ctx->cv_val[sel].p,
+			                   (const unsigned long long *)ctx->cv_cnt.p, total_cells, cov);
+		}
+		msx_time_end(ctx);
+		MSX_HIP(ctx, hipGetLastError());
+		return MSX_OK;
+	}
 	msx_time_begin(ctx, MSX_K_COVERAGE);
 	hipLaunchKernelGGL(k_coverage_pileup, dim3(msx_grid(ctx, b->n_records, MSX_BLOCK)), dim3(MSX_BLOCK), 0,
 	                   ctx->stream, b->n_records, b->tid, b->pos, b->cigar_off, b->cigar, cov_off, cov, covered);

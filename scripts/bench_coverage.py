@@ -42,10 +42,17 @@ hs = m.HostSynth(13579, 200_000, refs, 4)
 t0 = time.perf_counter()
 orc.coverage(hs, [tl] * refs)
 cpu = time.perf_counter() - t0
+# algorithmic bytes of the pile-up: tid 4, pos 4, cigar_off 4, cigar words in; two 4-byte marks per run out (read-modify-write)
+sz = db.sizes
+runs = db.n_records          # the synthetic records have one M/=/X run each, a deletion splits 2.5 % of them in two
+pile_bytes = 12 * db.n_records + 4 * int(sz.n_cigar) + 16 * runs
 print(json.dumps({
     "workload": f"coverage: {db.n_records} alignments, {refs} refs x {tl} bp ({4 * total / 1e9:.2f} GB of int32 depths)",
     "M_alignments_per_s": round(db.n_records / best / 1e6, 1), "ms": round(best * 1e3, 3),
     "k_coverage_pileup_ms": round(pile_ms / pile_n, 3), "prefix_sum_ms": round(scan_ms / scan_n, 3),
+    "path": "binned" if db.n_records >= int(os.environ.get("MSX_COV_BINNED_FROM", 2 << 20)) else "atomics",
+    "pileup_algorithmic_GBps": round(pile_bytes / (pile_ms / pile_n * 1e-3) / 1e9, 1),
+    "pileup_marks_per_s_G": round(2 * runs / (pile_ms / pile_n * 1e-3) / 1e9, 2),
     "prefix_sum_GBps": round(2 * 4 * total / (scan_ms / scan_n * 1e-3) / 1e9, 1),
     "depth_sum": int(cov.astype(np.int64).sum()),
     "cpu_oracle_M_alignments_per_s": round(hs.n_records / cpu / 1e6, 2)}))

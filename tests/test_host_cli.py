@@ -481,3 +481,26 @@ def test_cli_fatal_record_leaves_no_partial_batch(tmp_path):
     bam.write_bytes(run(["recode", "-b", str(sam)]).stdout)
     r = run(["filter", "-p", "95", str(bam)])
     assert r.returncode == 1 and r.stdout == b"" and b"Either NM or MD must be present" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_coverage_binned_path_equals_atomic_path(tmp_path, synth_bams):
+    """The binned pile-up (items sorted by tile, LDS image per tile) is what large batches take; forced on a
+    small input (MSX_COV_BINNED_FROM=1) it must write the same per-base depths as the atomic path, and the
+    reference's golden coverage table still holds through it (msam_coverage.c:33-87)."""
+    a, b = str(tmp_path / "a.gz"), str(tmp_path / "b.gz")
+    assert run(["coverage", "-o", a, synth_bams["b"]], env={"MSX_COV_BINNED_FROM": "1000000000"}).returncode == 0
+    r = run(["coverage", "-o", b, synth_bams["b"]], env={"MSX_COV_BINNED_FROM": "1"})
+    assert r.returncode == 0, r.stderr.decode()
+    assert gzip.open(a, "rb").read() == gzip.open(b, "rb").read()
+    blk = EXP["coverage"]
+    out = str(tmp_path / "positions.gz")
+    r = run(["coverage", "-S", "-w", "4", "-o", out, fixture_path(blk["fixture"])], env={"MSX_COV_BINNED_FROM": "1"})
+    assert r.returncode == 0
+    want = []
+    for name in ("A", "B", "C", "D"):
+        v = blk["positions"][name]
+        want.append(">" + name)
+        for i in range(0, len(v), 4):
+            want.append(" ".join(str(x) for x in v[i:i + 4]))
+    assert gzip.open(out, "rt").read().split("\n")[:-1] == want
