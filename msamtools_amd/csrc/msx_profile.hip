@@ -197,6 +197,16 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	if ((rc = msx_reserve(ctx, &ctx->tmp_fid, (size_t)n * 4))) return rc;
 	if (prop) {
 		if ((rc = msx_reserve(ctx, &ctx->moff, (size_t)(ng + 8) * 8))) return rc;
+		// the bounds grow by the whole batch (the host never waits for the true counts); once they near the
+		// 32-bit offsets of the store -- a file of billions of records, few of them multi-mapped -- they are
+		// folded back to what the device has really stored (one 16-byte read-back)
+		if (p->entries_ub + n > 0xffffff00LL || p->lists_ub + ng > 0xffffff00LL) {
+			unsigned long long t[2] = {0, 0};
+			MSX_HIP(ctx, hipMemcpyAsync(t, p->csr_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+			MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			p->lists_ub = (int64_t)t[0];
+			p->entries_ub = (int64_t)t[1];
+		}
 		p->lists_ub += ng;
 		p->entries_ub += n;
 		if (p->entries_ub > 0xffffff00LL) return msx_fail(ctx, MSX_ERR_ARG, "multi-mapper CSR exceeds 2^32 entries");
