@@ -64,12 +64,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 // that is large against the depth array the +1 / -1 marks are not added one by one:
 //   k_cov_emit   every run end becomes an item (tile, cell inside the tile, sign);
 //                a wave reserves room for its items with one global add
-//   radix sort   of the items by tile (2 passes for 16 K-cell tiles of a 250 M-cell array)
+//   radix sort   of the items by tile (2 passes for 8 K-cell tiles of a 250 M-cell array)
 //   k_cov_tile   one workgroup per tile adds its items into an LDS image of the tile
 //                (ds_add) and then adds the image to the depth array, coalesced
 // The depth array keeps holding differences, so both paths can feed one sample.
 // ---------------------------------------------------------------------------
-#define CV_TILE_SHIFT 14
+#define CV_TILE_SHIFT 13
 #define CV_TILE (1u << CV_TILE_SHIFT)
 #define CV_LANE_ITEMS 8               // run ends a lane keeps in registers; a record with more falls back to atomics
 
@@ -132,36 +132,52 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit(int64_t n, const int32_t
 	}
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ikey, const uint32_t *__restrict__ ival,
-                                                        const unsigned long long *__restrict__ n_items, int64_t total_cells,
-                                                        int32_t *__restrict__ diff) {
-	__shared__ int32_t s_d[CV_TILE];
-	__shared__ uint32_t s_lo, s_hi;
-	const uint32_t tile = blockIdx.x;
-	if (threadIdx.x < 2) {
-		// the tile's items: [lower bound of tile, lower bound of tile + 1) among the sorted keys
-		const uint32_t want = tile + threadIdx.x;
-		int64_t lo = 0, hi = (int64_t)*n_items;
-		while (lo < hi) {
-			const int64_t mid = (lo + hi) >> 1;
-			if (ikey[mid] < want) lo = mid + 1; else hi = mid;
-		}
-		if (threadIdx.x == 0) s_lo = (uint32_t)lo; else s_hi = (uint32_t)lo;
+// first item of every tile among the sorted keys (lower bounds, one thread per tile; tile_start[n_tiles] = n)
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *__restrict__ ikey,
+                                                               const unsigned long long *__restrict__ n_items,
+                                                               int64_t n_tiles, uint32_t *__restrict__ tile_start) {
+	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (t > n_tiles) return;
+	int64_t lo = 0, hi = (int64_t)*n_items;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if ((int64_t)ikey[mid] < t) lo = mid + 1; else hi = mid;
 	}
-	__syncthreads();
-	const uint32_t lo = s_lo, hi = s_hi;
+	tile_start[t] = (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ival,
+                                                        const uint32_t *__restrict__ tile_start, int64_t total_cells,
+                                                        int32_t *__restrict__ diff) {
+	__shared__ __attribute__((aligned(16))) int32_t s_d[CV_TILE];
+	const uint32_t tile = blockIdx.x;
+	const uint32_t lo = tile_start[tile], hi = tile_start[tile + 1];
 	if (lo == hi) return;
-	for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) s_d[q] = 0;
+	for (uint32_t q = threadIdx.x; q < CV_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = make_int4(0, 0, 0, 0);
 	__syncthreads();
 	for (uint32_t q = lo + threadIdx.x; q < hi; q += MSX_BLOCK) {
 		const uint32_t v = ival[q];
 		atomicAdd(&s_d[v & (CV_TILE - 1)], (v & 0x80000000u) ? -1 : 1);
 	}
 	__syncthreads();
+	// the image onto the tile's cells: this workgroup alone owns them; four 16-byte loads in flight per thread
 	const int64_t c0 = (int64_t)tile << CV_TILE_SHIFT;
-	for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) {
-		const int32_t d = s_d[q];
-		if (d != 0 && c0 + q <= total_cells) diff[c0 + q] += d;        // (this workgroup alone owns the tile's cells)
+	int4 *g4 = reinterpret_cast<int4 *>(diff + c0);
+	if (c0 + CV_TILE <= total_cells + 1 && (reinterpret_cast<uintptr_t>(g4) & 15u) == 0) {
+		for (uint32_t q0 = 0; q0 < CV_TILE / 4; q0 += 4 * MSX_BLOCK) {
+			int4 v[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) v[j] = g4[q0 + j * MSX_BLOCK + threadIdx.x];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int4 d = reinterpret_cast<const int4 *>(s_d)[q0 + j * MSX_BLOCK + threadIdx.x];
+				v[j].x += d.x; v[j].y += d.y; v[j].z += d.z; v[j].w += d.w;
+				g4[q0 + j * MSX_BLOCK + threadIdx.x] = v[j];
+			}
+		}
+	} else {
+		for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK)
+			if (s_d[q] != 0 && c0 + q <= total_cells) diff[c0 + q] += s_d[q];
 	}
 }
 
@@ -209,9 +225,12 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 			                           (uint32_t *)ctx->cv_key[1].p, (uint32_t *)ctx->cv_val[1].p, (int64_t)n_items, bits,
 			                           &ctx->cv_hist, &ctx->cv_off, &sel)))
 				return rc;
+			if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(n_tiles + 8) * 4))) return rc;
+			hipLaunchKernelGGL(k_cov_tile_starts, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+			                   ctx->stream, (const uint32_t *)ctx->cv_key[sel].p, (const unsigned long long *)ctx->cv_cnt.p,
+			                   n_tiles, (uint32_t *)ctx->cv_start.p);
 			hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-			                   (const uint32_t *)ctx->cv_key[sel].p, (const uint32_t *)ctx->cv_val[sel].p,
-			                   (const unsigned long long *)ctx->cv_cnt.p, total_cells, cov);
+			                   (const uint32_t *)ctx->cv_val[sel].p, (const uint32_t *)ctx->cv_start.p, total_cells, cov);
 		}
 		msx_time_end(ctx);
 		MSX_HIP(ctx, hipGetLastError());

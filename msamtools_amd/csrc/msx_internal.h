@@ -98,7 +98,7 @@ struct msx_ctx {
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
 	// workspace, grown on demand and kept
 	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, pinfo, moff, tmp_fid, ukey2;
-	msx_buf cv_key[2], cv_val[2], cv_hist, cv_off, cv_cnt;   // coverage: binned pile-up items
+	msx_buf cv_key[2], cv_val[2], cv_hist, cv_off, cv_cnt, cv_start;   // coverage: binned pile-up items
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;
