@@ -65,8 +65,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 //   k_cov_emit   every run end becomes an item (tile, cell inside the tile, sign);
 //                a wave reserves room for its items with one global add
 //   radix sort   of the items by tile (2 passes for 8 K-cell tiles of a 250 M-cell array)
-//   k_cov_tile   one workgroup per tile adds its items into an LDS image of the tile
-//                (ds_add) and then adds the image to the depth array, coalesced
+//   k_cov_tile   one workgroup per chunk of sorted items adds them into an LDS image of their tile
+//                (ds_add) and the image onto the depth array with atomic adds of consecutive cells
 // The depth array keeps holding differences, so both paths can feed one sample.
 // ---------------------------------------------------------------------------
 #define CV_TILE_SHIFT 13
@@ -146,38 +146,39 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *_
 	tile_start[t] = (uint32_t)lo;
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ival,
+// One workgroup per CHUNK of CV_CHUNK sorted items (equal work whatever the skew: the hottest reference of a
+// metagenome receives millions of marks, all in one tile), tile by tile inside the chunk: the tile's items of
+// this chunk are added into an LDS image (ds_add), and the image onto the tile's cells with atomic adds of
+// consecutive cells (a tile can be shared with the neighbouring chunks; 256 contiguous bytes per wave
+// instruction is the shape the memory-side adders take at full rate, and rows of zeros are skipped).
+#define CV_CHUNK 8192
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ikey, const uint32_t *__restrict__ ival,
+                                                        const unsigned long long *__restrict__ n_items,
                                                         const uint32_t *__restrict__ tile_start, int64_t total_cells,
                                                         int32_t *__restrict__ diff) {
-	__shared__ __attribute__((aligned(16))) int32_t s_d[CV_TILE];
-	const uint32_t tile = blockIdx.x;
-	const uint32_t lo = tile_start[tile], hi = tile_start[tile + 1];
-	if (lo == hi) return;
-	for (uint32_t q = threadIdx.x; q < CV_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = make_int4(0, 0, 0, 0);
-	__syncthreads();
-	for (uint32_t q = lo + threadIdx.x; q < hi; q += MSX_BLOCK) {
-		const uint32_t v = ival[q];
-		atomicAdd(&s_d[v & (CV_TILE - 1)], (v & 0x80000000u) ? -1 : 1);
-	}
-	__syncthreads();
-	// the image onto the tile's cells: this workgroup alone owns them; four 16-byte loads in flight per thread
-	const int64_t c0 = (int64_t)tile << CV_TILE_SHIFT;
-	int4 *g4 = reinterpret_cast<int4 *>(diff + c0);
-	if (c0 + CV_TILE <= total_cells + 1 && (reinterpret_cast<uintptr_t>(g4) & 15u) == 0) {
-		for (uint32_t q0 = 0; q0 < CV_TILE / 4; q0 += 4 * MSX_BLOCK) {
-			int4 v[4];
-#pragma unroll
-			for (int j = 0; j < 4; j++) v[j] = g4[q0 + j * MSX_BLOCK + threadIdx.x];
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const int4 d = reinterpret_cast<const int4 *>(s_d)[q0 + j * MSX_BLOCK + threadIdx.x];
-				v[j].x += d.x; v[j].y += d.y; v[j].z += d.z; v[j].w += d.w;
-				g4[q0 + j * MSX_BLOCK + threadIdx.x] = v[j];
-			}
+	__shared__ int32_t s_d[CV_TILE];
+	const int64_t n = (int64_t)*n_items;
+	const int64_t lo_c = (int64_t)blockIdx.x * CV_CHUNK;
+	if (lo_c >= n) return;
+	const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
+	const uint32_t t_first = ikey[lo_c], t_last = ikey[hi_c - 1];
+	for (uint32_t t = t_first; t <= t_last; ++t) {
+		const int64_t a = (int64_t)tile_start[t] > lo_c ? (int64_t)tile_start[t] : lo_c;
+		const int64_t b = (int64_t)tile_start[t + 1] < hi_c ? (int64_t)tile_start[t + 1] : hi_c;
+		if (a >= b) continue;                                   // (workgroup-uniform)
+		for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) s_d[q] = 0;
+		__syncthreads();
+		for (int64_t q = a + threadIdx.x; q < b; q += MSX_BLOCK) {
+			const uint32_t v = ival[q];
+			atomicAdd(&s_d[v & (CV_TILE - 1)], (v & 0x80000000u) ? -1 : 1);
 		}
-	} else {
-		for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK)
-			if (s_d[q] != 0 && c0 + q <= total_cells) diff[c0 + q] += s_d[q];
+		__syncthreads();
+		const int64_t c0 = (int64_t)t << CV_TILE_SHIFT;
+		for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) {
+			const int32_t d = s_d[q];
+			if (__ballot(d != 0) != 0ull && c0 + q <= total_cells) atomicAdd(&diff[c0 + q], d);
+		}
+		__syncthreads();
 	}
 }
 
@@ -229,8 +230,9 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 			hipLaunchKernelGGL(k_cov_tile_starts, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
 			                   ctx->stream, (const uint32_t *)ctx->cv_key[sel].p, (const unsigned long long *)ctx->cv_cnt.p,
 			                   n_tiles, (uint32_t *)ctx->cv_start.p);
-			hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-			                   (const uint32_t *)ctx->cv_val[sel].p, (const uint32_t *)ctx->cv_start.p, total_cells, cov);
+			hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream,
+			                   (const uint32_t *)ctx->cv_key[sel].p, (const uint32_t *)ctx->cv_val[sel].p,
+			                   (const unsigned long long *)ctx->cv_cnt.p, (const uint32_t *)ctx->cv_start.p, total_cells, cov);
 		}
 		msx_time_end(ctx);
 		MSX_HIP(ctx, hipGetLastError());
