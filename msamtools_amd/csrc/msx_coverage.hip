@@ -62,8 +62,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 // Large batches: the binned pile-up.  Scattered global atomics run memory-side at
 // ~27 G/s on this chip (one per run end: 100 M of them for 50 M reads), so for a batch
 // that is large against the depth array the +1 / -1 marks are not added one by one:
-//   k_cov_emit   every run end becomes an item (tile, cell inside the tile, sign);
-//                a wave reserves room for its items with one global add
+//   k_cov_emit   the two ends of a record's first run become items (tile, cell inside the tile, sign)
+//                in the record's own two slots
 //   radix sort   of the items by tile (2 passes for 8 K-cell tiles of a 250 M-cell array)
 //   k_cov_tile   one workgroup per chunk of sorted items adds them into an LDS image of their tile
 //                (ds_add) and the image onto the depth array with atomic adds of consecutive cells
@@ -71,74 +71,61 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 // ---------------------------------------------------------------------------
 #define CV_TILE_SHIFT 13
 #define CV_TILE (1u << CV_TILE_SHIFT)
-#define CV_LANE_ITEMS 8               // run ends a lane keeps in registers; a record with more falls back to atomics
-
+// Every record owns two item slots (2i, 2i+1): the ends of its first run of M/=/X bases, which is all a read
+// without D/N has.  No counter and no prefix -- a shared counter costs one same-address atomic per wave
+// (~12 ns each, 9 ms for 50 M reads) -- at the price of sorting the empty slots of unmapped records along
+// (key n_tiles, behind every tile).  Further runs of a record (after a D or N) go to the depth array directly.
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit(int64_t n, const int32_t *__restrict__ tid,
                                                         const int32_t *__restrict__ pos,
                                                         const uint32_t *__restrict__ cigar_off,
                                                         const uint32_t *__restrict__ cigar,
                                                         const int64_t *__restrict__ cov_off, int32_t *__restrict__ diff,
-                                                        uint8_t *__restrict__ covered, uint32_t *__restrict__ ikey,
-                                                        uint32_t *__restrict__ ival, unsigned long long *n_items) {
-	const int lane = threadIdx.x & 63;
+                                                        uint8_t *__restrict__ covered, uint2 *__restrict__ ikey,
+                                                        uint2 *__restrict__ ival, uint32_t null_key) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i0 = (int64_t)blockIdx.x * MSX_BLOCK; i0 < n; i0 += stride) {
-		const int64_t i = i0 + threadIdx.x;
-		int64_t cell[CV_LANE_ITEMS];      // global cell index of a mark; even slots +1, odd slots -1
-		int cnt = 0;
-		if (i < n) {
-			const int32_t t = tid[i];
-			if (t >= 0) {                                        // :42
-				if (covered) covered[t] = 1;                     // :45-49
-				const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
-				int64_t p = pos[i];
-				const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
-				int64_t run_start = -1;
-				auto mark = [&](int64_t s, int64_t e) {
-					if (s < 0) s = 0;
-					if (e > t_len) e = t_len;
-					if (e <= s) return;
-					if (cnt + 2 <= CV_LANE_ITEMS) { cell[cnt++] = t_beg + s; cell[cnt++] = t_beg + e; }
-					else { atomicAdd(&diff[t_beg + s], 1); atomicAdd(&diff[t_beg + e], -1); }
-				};
-				for (uint32_t k = ks; k < ke; ++k) {
-					const uint32_t op = cigar[k] & 0xf, w = cigar[k] >> 4;
-					if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
-						if (run_start < 0) run_start = p;
-						p += w;
-					} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
-						if (run_start >= 0 && w > 0) { mark(run_start, p); run_start = -1; }
-						p += w;
-					}
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n; i += stride) {
+		uint2 key = make_uint2(null_key, null_key), val = make_uint2(0u, 0u);
+		const int32_t t = tid[i];
+		if (t >= 0) {                                        // :42
+			if (covered) covered[t] = 1;                     // :45-49
+			const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
+			int64_t p = pos[i];
+			const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
+			int64_t run_start = -1;
+			bool first = true;
+			auto mark = [&](int64_t s, int64_t e) {
+				if (s < 0) s = 0;
+				if (e > t_len) e = t_len;
+				if (e <= s) return;
+				if (first) {
+					first = false;
+					key = make_uint2((uint32_t)((t_beg + s) >> CV_TILE_SHIFT), (uint32_t)((t_beg + e) >> CV_TILE_SHIFT));
+					val = make_uint2((uint32_t)((t_beg + s) & (CV_TILE - 1)), (uint32_t)((t_beg + e) & (CV_TILE - 1)) | 0x80000000u);
+				} else { atomicAdd(&diff[t_beg + s], 1); atomicAdd(&diff[t_beg + e], -1); }
+			};
+			for (uint32_t k = ks; k < ke; ++k) {
+				const uint32_t op = cigar[k] & 0xf, w = cigar[k] >> 4;
+				if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
+					if (run_start < 0) run_start = p;
+					p += w;
+				} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
+					if (run_start >= 0 && w > 0) { mark(run_start, p); run_start = -1; }
+					p += w;
 				}
-				if (run_start >= 0) mark(run_start, p);
 			}
+			if (run_start >= 0) mark(run_start, p);
 		}
-		// room for the wave's items: an exclusive prefix over the lanes, one global add
-		uint32_t incl = (uint32_t)cnt;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t o = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += o;
-		}
-		const uint32_t total = __shfl(incl, 63, 64);
-		unsigned long long base = 0;
-		if (lane == 0 && total) base = atomicAdd(n_items, (unsigned long long)total);
-		base = __shfl(base, 0, 64) + (incl - (uint32_t)cnt);
-		for (int q = 0; q < cnt; q++) {
-			ikey[base + q] = (uint32_t)(cell[q] >> CV_TILE_SHIFT);
-			ival[base + q] = (uint32_t)(cell[q] & (CV_TILE - 1)) | ((q & 1) ? 0x80000000u : 0u);
-		}
+		ikey[i] = key;
+		ival[i] = val;
 	}
 }
 
 // first item of every tile among the sorted keys (lower bounds, one thread per tile; tile_start[n_tiles] = n)
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *__restrict__ ikey,
-                                                               const unsigned long long *__restrict__ n_items,
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *__restrict__ ikey, int64_t n_items,
                                                                int64_t n_tiles, uint32_t *__restrict__ tile_start) {
 	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (t > n_tiles) return;
-	int64_t lo = 0, hi = (int64_t)*n_items;
+	int64_t lo = 0, hi = n_items;
 	while (lo < hi) {
 		const int64_t mid = (lo + hi) >> 1;
 		if ((int64_t)ikey[mid] < t) lo = mid + 1; else hi = mid;
@@ -153,11 +140,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *_
 // instruction is the shape the memory-side adders take at full rate, and rows of zeros are skipped).
 #define CV_CHUNK 8192
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ikey, const uint32_t *__restrict__ ival,
-                                                        const unsigned long long *__restrict__ n_items,
-                                                        const uint32_t *__restrict__ tile_start, int64_t total_cells,
-                                                        int32_t *__restrict__ diff) {
+                                                        int64_t n_tiles, const uint32_t *__restrict__ tile_start,
+                                                        int64_t total_cells, int32_t *__restrict__ diff) {
 	__shared__ int32_t s_d[CV_TILE];
-	const int64_t n = (int64_t)*n_items;
+	const int64_t n = (int64_t)tile_start[n_tiles];          // the empty slots sort behind the last tile
 	const int64_t lo_c = (int64_t)blockIdx.x * CV_CHUNK;
 	if (lo_c >= n) return;
 	const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
@@ -194,46 +180,34 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 		return e ? atoll(e) : (int64_t)(2 << 20);
 	}();
 	if (b->n_records >= binned_from && n_targets > 0) {
-		// sizes that live on the device: the end of the depth array, the number of CIGAR words (a record yields
-		// at most one run per word, plus the marks it keeps in registers are bounded per lane)
-		int64_t total_cells = 0;
-		uint32_t n_cig = 0;
+		int64_t total_cells = 0;                                 // the end of the depth array lives on the device
 		MSX_HIP(ctx, hipMemcpyAsync(&total_cells, cov_off + n_targets, 8, hipMemcpyDeviceToHost, ctx->stream));
-		MSX_HIP(ctx, hipMemcpyAsync(&n_cig, b->cigar_off + b->n_records, 4, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		const int64_t cap = (int64_t)CV_LANE_ITEMS * b->n_records < 2 * (int64_t)n_cig ? (int64_t)CV_LANE_ITEMS * b->n_records
-		                                                                               : 2 * (int64_t)n_cig;
+		const int64_t n_items = 2 * b->n_records;
 		const int64_t n_tiles = (total_cells + 1 + CV_TILE - 1) >> CV_TILE_SHIFT;
+		if (n_items >= ((int64_t)1 << 32)) return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_accumulate: batch too large");
 		int bits = 1;
-		while (((int64_t)1 << bits) < n_tiles) bits++;
+		while (((int64_t)1 << bits) <= n_tiles) bits++;          // keys 0 .. n_tiles (n_tiles = an empty slot)
 		int rc;
 		for (int q = 0; q < 2; q++) {
-			if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(cap + 64) * 4))) return rc;
-			if ((rc = msx_reserve(ctx, &ctx->cv_val[q], (size_t)(cap + 64) * 4))) return rc;
+			if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(n_items + 64) * 4))) return rc;
+			if ((rc = msx_reserve(ctx, &ctx->cv_val[q], (size_t)(n_items + 64) * 4))) return rc;
 		}
-		if ((rc = msx_reserve(ctx, &ctx->cv_cnt, 16))) return rc;
-		MSX_HIP(ctx, hipMemsetAsync(ctx->cv_cnt.p, 0, 8, ctx->stream));
 		msx_time_begin(ctx, MSX_K_COVERAGE);
-		hipLaunchKernelGGL(k_cov_emit, dim3(msx_grid_x(ctx, b->n_records, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0, ctx->stream,
+		hipLaunchKernelGGL(k_cov_emit, dim3(msx_grid_x(ctx, b->n_records, MSX_BLOCK, 8)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   b->n_records, b->tid, b->pos, b->cigar_off, b->cigar, cov_off, cov, covered,
-		                   (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_val[0].p, (unsigned long long *)ctx->cv_cnt.p);
-		unsigned long long n_items = 0;
-		MSX_HIP(ctx, hipMemcpyAsync(&n_items, ctx->cv_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		if (n_items) {
-			int sel = 0;
-			if ((rc = msx_sort_pairs32(ctx, (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_val[0].p,
-			                           (uint32_t *)ctx->cv_key[1].p, (uint32_t *)ctx->cv_val[1].p, (int64_t)n_items, bits,
-			                           &ctx->cv_hist, &ctx->cv_off, &sel)))
-				return rc;
-			if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(n_tiles + 8) * 4))) return rc;
-			hipLaunchKernelGGL(k_cov_tile_starts, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
-			                   ctx->stream, (const uint32_t *)ctx->cv_key[sel].p, (const unsigned long long *)ctx->cv_cnt.p,
-			                   n_tiles, (uint32_t *)ctx->cv_start.p);
-			hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream,
-			                   (const uint32_t *)ctx->cv_key[sel].p, (const uint32_t *)ctx->cv_val[sel].p,
-			                   (const unsigned long long *)ctx->cv_cnt.p, (const uint32_t *)ctx->cv_start.p, total_cells, cov);
-		}
+		                   (uint2 *)ctx->cv_key[0].p, (uint2 *)ctx->cv_val[0].p, (uint32_t)n_tiles);
+		int sel = 0;
+		if ((rc = msx_sort_pairs32(ctx, (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_val[0].p,
+		                           (uint32_t *)ctx->cv_key[1].p, (uint32_t *)ctx->cv_val[1].p, n_items, bits,
+		                           &ctx->cv_hist, &ctx->cv_off, &sel)))
+			return rc;
+		if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(n_tiles + 8) * 4))) return rc;
+		hipLaunchKernelGGL(k_cov_tile_starts, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+		                   ctx->stream, (const uint32_t *)ctx->cv_key[sel].p, n_items, n_tiles, (uint32_t *)ctx->cv_start.p);
+		hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   (const uint32_t *)ctx->cv_key[sel].p, (const uint32_t *)ctx->cv_val[sel].p, n_tiles,
+		                   (const uint32_t *)ctx->cv_start.p, total_cells, cov);
 		msx_time_end(ctx);
 		MSX_HIP(ctx, hipGetLastError());
 		return MSX_OK;
