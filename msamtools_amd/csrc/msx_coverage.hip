@@ -62,9 +62,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_coverage_pileup(int64_t n, const 
 // Large batches: the binned pile-up.  Scattered global atomics run memory-side at
 // ~27 G/s on this chip (one per run end: 100 M of them for 50 M reads), so for a batch
 // that is large against the depth array the +1 / -1 marks are not added one by one:
-//   k_cov_emit   the two ends of a record's first run become items (tile, cell inside the tile, sign)
+//   k_cov_emit   the two ends of a record's first run become items (one word: cell << 1 | sign)
 //                in the record's own two slots
-//   radix sort   of the items by tile (2 passes for 8 K-cell tiles of a 250 M-cell array)
+//   radix sort   of the items by tile = the bits above the cell-inside-the-tile field (keys only,
+//                2 passes for 8 K-cell tiles of a 250 M-cell array)
 //   k_cov_tile   one workgroup per chunk of sorted items adds them into an LDS image of their tile
 //                (ds_add) and the image onto the depth array with atomic adds of consecutive cells
 // The depth array keeps holding differences, so both paths can feed one sample.
@@ -80,11 +81,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit(int64_t n, const int32_t
                                                         const uint32_t *__restrict__ cigar_off,
                                                         const uint32_t *__restrict__ cigar,
                                                         const int64_t *__restrict__ cov_off, int32_t *__restrict__ diff,
-                                                        uint8_t *__restrict__ covered, uint2 *__restrict__ ikey,
-                                                        uint2 *__restrict__ ival, uint32_t null_key) {
+                                                        uint8_t *__restrict__ covered, uint2 *__restrict__ items,
+                                                        uint32_t null_item) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n; i += stride) {
-		uint2 key = make_uint2(null_key, null_key), val = make_uint2(0u, 0u);
+		uint2 it = make_uint2(null_item, null_item);
 		const int32_t t = tid[i];
 		if (t >= 0) {                                        // :42
 			if (covered) covered[t] = 1;                     // :45-49
@@ -99,8 +100,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit(int64_t n, const int32_t
 				if (e <= s) return;
 				if (first) {
 					first = false;
-					key = make_uint2((uint32_t)((t_beg + s) >> CV_TILE_SHIFT), (uint32_t)((t_beg + e) >> CV_TILE_SHIFT));
-					val = make_uint2((uint32_t)((t_beg + s) & (CV_TILE - 1)), (uint32_t)((t_beg + e) & (CV_TILE - 1)) | 0x80000000u);
+					it = make_uint2((uint32_t)(t_beg + s) << 1, (uint32_t)(t_beg + e) << 1 | 1u);
 				} else { atomicAdd(&diff[t_beg + s], 1); atomicAdd(&diff[t_beg + e], -1); }
 			};
 			for (uint32_t k = ks; k < ke; ++k) {
@@ -115,8 +115,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit(int64_t n, const int32_t
 			}
 			if (run_start >= 0) mark(run_start, p);
 		}
-		ikey[i] = key;
-		ival[i] = val;
+		items[i] = it;
 	}
 }
 
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *_
 	int64_t lo = 0, hi = n_items;
 	while (lo < hi) {
 		const int64_t mid = (lo + hi) >> 1;
-		if ((int64_t)ikey[mid] < t) lo = mid + 1; else hi = mid;
+		if ((int64_t)(ikey[mid] >> (CV_TILE_SHIFT + 1)) < t) lo = mid + 1; else hi = mid;
 	}
 	tile_start[t] = (uint32_t)lo;
 }
@@ -139,15 +138,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile_starts(const uint32_t *_
 // consecutive cells (a tile can be shared with the neighbouring chunks; 256 contiguous bytes per wave
 // instruction is the shape the memory-side adders take at full rate, and rows of zeros are skipped).
 #define CV_CHUNK 8192
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ ikey, const uint32_t *__restrict__ ival,
-                                                        int64_t n_tiles, const uint32_t *__restrict__ tile_start,
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restrict__ items, int64_t n_tiles, const uint32_t *__restrict__ tile_start,
                                                         int64_t total_cells, int32_t *__restrict__ diff) {
 	__shared__ int32_t s_d[CV_TILE];
 	const int64_t n = (int64_t)tile_start[n_tiles];          // the empty slots sort behind the last tile
 	const int64_t lo_c = (int64_t)blockIdx.x * CV_CHUNK;
 	if (lo_c >= n) return;
 	const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
-	const uint32_t t_first = ikey[lo_c], t_last = ikey[hi_c - 1];
+	const uint32_t t_first = items[lo_c] >> (CV_TILE_SHIFT + 1), t_last = items[hi_c - 1] >> (CV_TILE_SHIFT + 1);
 	for (uint32_t t = t_first; t <= t_last; ++t) {
 		const int64_t a = (int64_t)tile_start[t] > lo_c ? (int64_t)tile_start[t] : lo_c;
 		const int64_t b = (int64_t)tile_start[t + 1] < hi_c ? (int64_t)tile_start[t + 1] : hi_c;
@@ -155,8 +153,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restri
 		for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) s_d[q] = 0;
 		__syncthreads();
 		for (int64_t q = a + threadIdx.x; q < b; q += MSX_BLOCK) {
-			const uint32_t v = ival[q];
-			atomicAdd(&s_d[v & (CV_TILE - 1)], (v & 0x80000000u) ? -1 : 1);
+			const uint32_t v = items[q];
+			atomicAdd(&s_d[(v >> 1) & (CV_TILE - 1)], (v & 1u) ? -1 : 1);
 		}
 		__syncthreads();
 		const int64_t c0 = (int64_t)t << CV_TILE_SHIFT;
@@ -179,35 +177,35 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 		const char *e = getenv("MSX_COV_BINNED_FROM");          // records per batch from which the binned path is used
 		return e ? atoll(e) : (int64_t)(2 << 20);
 	}();
+	int64_t total_cells = 0;                                     // the end of the depth array lives on the device
 	if (b->n_records >= binned_from && n_targets > 0) {
-		int64_t total_cells = 0;                                 // the end of the depth array lives on the device
 		MSX_HIP(ctx, hipMemcpyAsync(&total_cells, cov_off + n_targets, 8, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	// an item is one word (cell << 1 | sign) and tile n_tiles marks an empty slot: depth arrays of 2^31 cells
+	// and more take the direct path
+	if (total_cells > 0 && total_cells + 2 * (int64_t)CV_TILE < ((int64_t)1 << 31)) {
 		const int64_t n_items = 2 * b->n_records;
 		const int64_t n_tiles = (total_cells + 1 + CV_TILE - 1) >> CV_TILE_SHIFT;
 		if (n_items >= ((int64_t)1 << 32)) return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_accumulate: batch too large");
 		int bits = 1;
-		while (((int64_t)1 << bits) <= n_tiles) bits++;          // keys 0 .. n_tiles (n_tiles = an empty slot)
+		while (((int64_t)1 << bits) <= n_tiles) bits++;          // tiles 0 .. n_tiles (n_tiles = an empty slot)
 		int rc;
-		for (int q = 0; q < 2; q++) {
+		for (int q = 0; q < 2; q++)
 			if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(n_items + 64) * 4))) return rc;
-			if ((rc = msx_reserve(ctx, &ctx->cv_val[q], (size_t)(n_items + 64) * 4))) return rc;
-		}
 		msx_time_begin(ctx, MSX_K_COVERAGE);
 		hipLaunchKernelGGL(k_cov_emit, dim3(msx_grid_x(ctx, b->n_records, MSX_BLOCK, 8)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   b->n_records, b->tid, b->pos, b->cigar_off, b->cigar, cov_off, cov, covered,
-		                   (uint2 *)ctx->cv_key[0].p, (uint2 *)ctx->cv_val[0].p, (uint32_t)n_tiles);
+		                   (uint2 *)ctx->cv_key[0].p, (uint32_t)n_tiles << (CV_TILE_SHIFT + 1));
 		int sel = 0;
-		if ((rc = msx_sort_pairs32(ctx, (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_val[0].p,
-		                           (uint32_t *)ctx->cv_key[1].p, (uint32_t *)ctx->cv_val[1].p, n_items, bits,
-		                           &ctx->cv_hist, &ctx->cv_off, &sel)))
+		if ((rc = msx_sort_keys32(ctx, (uint32_t *)ctx->cv_key[0].p, (uint32_t *)ctx->cv_key[1].p, n_items, CV_TILE_SHIFT + 1,
+		                          bits, &ctx->cv_hist, &ctx->cv_off, &sel)))
 			return rc;
 		if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(n_tiles + 8) * 4))) return rc;
 		hipLaunchKernelGGL(k_cov_tile_starts, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
 		                   ctx->stream, (const uint32_t *)ctx->cv_key[sel].p, n_items, n_tiles, (uint32_t *)ctx->cv_start.p);
 		hipLaunchKernelGGL(k_cov_tile, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   (const uint32_t *)ctx->cv_key[sel].p, (const uint32_t *)ctx->cv_val[sel].p, n_tiles,
-		                   (const uint32_t *)ctx->cv_start.p, total_cells, cov);
+		                   (const uint32_t *)ctx->cv_key[sel].p, n_tiles, (const uint32_t *)ctx->cv_start.p, total_cells, cov);
 		msx_time_end(ctx);
 		MSX_HIP(ctx, hipGetLastError());
 		return MSX_OK;

@@ -98,7 +98,7 @@ struct msx_ctx {
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
 	// workspace, grown on demand and kept
 	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, pinfo, moff, tmp_fid, ukey2;
-	msx_buf cv_key[2], cv_val[2], cv_hist, cv_off, cv_cnt, cv_start;   // coverage: binned pile-up items
+	msx_buf cv_key[2], cv_hist, cv_off, cv_start;   // coverage: binned pile-up items
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;
@@ -206,8 +206,8 @@ int64_t msx_share_waves(msx_ctx *ctx);
 int64_t msx_apply_blocks(int32_t nf);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
-int msx_sort_pairs32(msx_ctx *ctx, uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, int64_t n, int bits,
-                     msx_buf *hist, msx_buf *off, int *sel);
+int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shift0, int bits, msx_buf *hist, msx_buf *off,
+                    int *sel);
 // msx_dist.hip: in-place all-reduce(sum) on the ctx stream; no-ops without a communicator
 int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p);
 int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count);

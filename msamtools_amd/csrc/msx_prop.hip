@@ -1090,14 +1090,14 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 	return MSX_OK;
 }
 
-// Stable LSD radix sort of (key, 32-bit value) pairs on the low `bits` bits of the key, for callers outside
-// the profile (msx_coverage.hip): n items (host count), ping-pong between (k0, v0) and (k1, v1); *sel tells
-// which pair holds the result.  hist / off: workspace, grown here.
-int msx_sort_pairs32(msx_ctx *ctx, uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, int64_t n, int bits,
-                     msx_buf *hist, msx_buf *off, int *sel) {
+// Stable LSD radix sort of 32-bit keys on bits [shift0, shift0 + bits), for callers outside the profile
+// (msx_coverage.hip): n keys (host count), ping-pong between k0 and k1; *sel tells which one holds the
+// result.  hist / off: workspace, grown here.
+int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shift0, int bits, msx_buf *hist, msx_buf *off,
+                    int *sel) {
 	const int passes = (bits + 7) / 8;
 	const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
-	uint32_t *kk[2] = {k0, k1}, *vv[2] = {v0, v1};
+	uint32_t *kk[2] = {k0, k1};
 	int cur = 0, rc;
 	if ((rc = msx_reserve(ctx, hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
 	if ((rc = msx_reserve(ctx, off, (size_t)(256 * n_tiles + 16) * 4))) return rc;
@@ -1105,11 +1105,11 @@ int msx_sort_pairs32(msx_ctx *ctx, uint32_t *k0, uint32_t *v0, uint32_t *k1, uin
 		const int left = bits - 8 * ps;
 		const uint32_t dmask = left >= 8 ? 255u : ((1u << left) - 1u);
 		hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)kk[cur],
-		                   (const unsigned long long *)nullptr, n, ps * 8, dmask, (uint32_t *)hist->p, n_tiles);
+		                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (uint32_t *)hist->p, n_tiles);
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)hist->p, (uint32_t *)off->p, 256 * n_tiles))) return rc;
-		hipLaunchKernelGGL((k_rs_scatter<uint32_t, true, false>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   (const uint32_t *)kk[cur], (const uint32_t *)vv[cur], kk[cur ^ 1], vv[cur ^ 1],
-		                   (const unsigned long long *)nullptr, n, ps * 8, dmask, (const uint32_t *)off->p, n_tiles);
+		hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, false>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   (const uint32_t *)kk[cur], (const uint32_t *)nullptr, kk[cur ^ 1], (uint32_t *)nullptr,
+		                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (const uint32_t *)off->p, n_tiles);
 		cur ^= 1;
 	}
 	*sel = cur;
