@@ -31,15 +31,6 @@ struct SelectArgs {
 	msx_dev_status *st;
 };
 
-// One lane per pool.  Pools are short (1 + Poisson(4) hits per read), so a lane
-// fetches its pool's FLAGs, pool bytes, aux bits and AS values (<= 12 records) with
-// ~27 independent loads issued back to back -- one memory round trip per pool
-// instead of one per record -- realigns the sub-dword windows with alignbit /
-// alignbyte so that record r sits at a compile-time position, and runs both
-// passes (max + tie count per mate class; keep codes) out of registers.  Longer
-// pools take the per-record loop.
-#define BH_WIN 12
-
 struct BhAcc {
 	int32_t b0, b1, b2;          // best AS per mate class: neither bit, READ1, READ2
 	uint32_t n0, n1, n2;         // ties
@@ -73,155 +64,211 @@ __device__ __forceinline__ uint8_t bh_keep(const BhAcc &c, bool w0, bool w1, boo
 	return 0;
 }
 
-// COUNT: the fused `filter | profile` form.  The pool's winners are in registers (k1/k2
-// masks) when the selection is done, so the insert accounting of msx_count.h runs right
-// here instead of in a second kernel that would fetch group_off and the keep codes again.
+// The pool walked by one lane, record after record: any pool length (a wave whose 64 pools do not fit the
+// flat path below takes it).
+__device__ __forceinline__ uint32_t bh_rec_code(const SelectArgs &A, uint32_t i) {
+	// MSX_PC_IN | MSX_PC_HAS_AS | mate bits of a record that takes part, 0 otherwise
+	if (A.pool_is_code) return A.pool[i];                // k_aln_stats_flat has looked at FLAG and the aux bits already
+	const uint32_t fl = A.flag[i];
+	const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
+	const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
+	return pooled ? (MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (fl & MSX_F_MATES)) : 0u;
+}
+
 template <bool COUNT>
-__global__ __launch_bounds__(MSX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_besthit_select(SelectArgs A, CountArgs P) {
+__device__ __forceinline__ void bh_pool_serial(const SelectArgs &A, const CountArgs &P, int64_t g, uint32_t s, uint32_t e,
+                                               int32_t *s_key, uint32_t *s_val, BlockCounts &bc) {
+	BhAcc c = {INT_MIN, INT_MIN, INT_MIN, 0u, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+	uint32_t cnt = 0;
+	for (uint32_t i = s; i < e; ++i) {
+		const uint32_t pc = bh_rec_code(A, i);
+		bh_count(c, i, pc & MSX_F_MATES, (pc & MSX_PC_IN) != 0, (pc & MSX_PC_HAS_AS) != 0, A.as[i]);
+	}
+	const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);
+	const bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
+	const bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
+	for (uint32_t i = s; i < e; ++i) {
+		const uint32_t pc = bh_rec_code(A, i);
+		const uint8_t k = bh_keep(c, w0, w1, w2, pc & MSX_F_MATES, (pc & MSX_PC_IN) != 0, (pc & MSX_PC_HAS_AS) != 0, A.as[i]);
+		A.keep[i] = k;
+		cnt += (k != 0);
+	}
+	if (COUNT) {
+		// the keep codes this lane just wrote, in output order
+		PoolAcc v;
+		pool_begin(P, v, s);
+		for (uint32_t pass = 1; pass <= 2; ++pass)
+			for (uint32_t i = s; i < e; ++i)
+				if (A.keep[i] == pass) pool_visit(P, v, P.tid[i]);
+		pool_finish(P, g, v, s_key, s_val, bc);
+	}
+	// msam_filter.c:219-221: a participating record without AS is fatal
+	const uint32_t bad = c.paired ? (c.noas1 < c.noas2 ? c.noas1 : c.noas2) : c.noas0;
+	if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
+	A.gcount[g] = cnt;
+}
+
+// ---------------------------------------------------------------------------
+// k_besthit_select: one wave per 64 consecutive pools, one lane per RECORD for the selection.
+// The records of 64 pools are one contiguous range [S, S + R) of the batch (R ~ 320 at 5 hits per read), so the
+// pool bytes, scores and keep codes move as whole rows of 64 consecutive records -- coalesced, where one lane
+// per pool fetched ~27 dwords per pool through sub-dword windows and spent 966 lane-instructions on it:
+//   1  lane p puts its pool's start into a bitmap of the range (LDS); a record's pool is the number of
+//      starts at or before it (word prefix + popcount)
+//   2  every record adds its score to its pool's maximum per mate class, and its mate bits to the pool's
+//      "paired" word (LDS atomics; msam_filter.c:196-230)
+//   3  every record compares itself with its pool's maximum (--uniqhit: ties counted in between, :232-233),
+//      writes its keep code and sets its bit in the pool's first-pass / second-pass winner mask
+//   4  lane p again: records written, the fatal-record check and -- COUNT, the fused `filter | profile`
+//      form -- the insert accounting of msx_count.h straight from the winner masks.
+// A wave whose range exceeds BF_RMAX records, or with a pool of more than 32 records (the masks) or none,
+// walks its pools one lane each (bh_pool_serial).
+// ---------------------------------------------------------------------------
+#define BF_ROWS 12
+#define BF_RMAX (64 * BF_ROWS)
+#define BF_WORDS (BF_RMAX / 32)
+
+struct BfWave {
+	uint32_t bits[BF_WORDS], wpre[BF_WORDS];
+	int32_t best[3][64];          // per mate class: neither bit, READ1, READ2
+	uint32_t ties[3][64], noas[3][64];
+	uint32_t pair[64], k1[64], k2[64], start[64];
+};
+
+__device__ __forceinline__ void bf_wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, CountArgs P) {
+	__shared__ BfWave s_w[MSX_BLOCK / 64];
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
 	__shared__ int32_t s_key[COUNT ? UI_TBL : 1];
 	__shared__ uint32_t s_val[COUNT ? UI_TBL : 1];
 	BlockCounts bc = {0u, 0u, 0u};
 	if (COUNT) count_block_begin(P, s_key, s_val);
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	// the next pool's bounds are fetched while this one is processed (one round trip less per pool)
+	const uint32_t lane = threadIdx.x & 63u;
+	BfWave &L = s_w[threadIdx.x >> 6];
+	const int64_t n_tiles = (A.n_groups + 63) >> 6;
+	const int64_t wstride = (int64_t)gridDim.x * (MSX_BLOCK / 64);
+	int64_t tile = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + (threadIdx.x >> 6);
+	// the next tile's bounds are fetched while this one is processed
 	uint32_t s_nx = 0, e_nx = 0;
-	if (g < A.n_groups) { s_nx = A.group_off[g]; e_nx = A.group_off[g + 1]; }
-	for (; g < A.n_groups; g += stride) {
+	if (tile * 64 + lane < A.n_groups) { s_nx = A.group_off[tile * 64 + lane]; e_nx = A.group_off[tile * 64 + lane + 1]; }
+	for (; tile < n_tiles; tile += wstride) {
+		const int64_t g = tile * 64 + lane;
+		const bool gv = g < A.n_groups;
 		const uint32_t s = s_nx, e = e_nx;
-		if (g + stride < A.n_groups) { s_nx = A.group_off[g + stride]; e_nx = A.group_off[g + stride + 1]; }
-		const uint32_t len = e - s;
-		BhAcc c = {INT_MIN, INT_MIN, INT_MIN, 0u, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-		uint32_t cnt = 0;
-		if (len <= BH_WIN && (uint64_t)(s & ~3u) + 16u <= (uint64_t)A.n && (uint64_t)s + BH_WIN <= (uint64_t)A.n) {
-			// ---- bulk loads (independent of each other) ----
-			const bool coded = A.pool_is_code != 0;      // (kernel argument: a scalar branch)
-			const uint32_t *f32p = reinterpret_cast<const uint32_t *>(A.flag) + (s >> 1);
-			uint32_t fw[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-			const uint32_t *r32p = reinterpret_cast<const uint32_t *>(A.rflags) + (s >> 2);
-			uint32_t rw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
-			if (!coded) {
+		{
+			const int64_t gn = g + wstride * 64;
+			if (gn < A.n_groups) { s_nx = A.group_off[gn]; e_nx = A.group_off[gn + 1]; }
+		}
+		const unsigned long long vm = __ballot(gv);
+		const uint32_t S = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+		const uint32_t E = (uint32_t)__builtin_amdgcn_readlane((int)e, 63 - __clzll((long long)vm));
+		const uint32_t R = E - S, len = e - s;
+		if (R > BF_RMAX || __ballot(gv && (len == 0u || len > 32u)) != 0ull) {
+			if (gv) bh_pool_serial<COUNT>(A, P, g, s, e, s_key, s_val, bc);
+			continue;
+		}
+		// ---- 1: pool slots, start bitmap ----
+		if (lane < BF_WORDS) L.bits[lane] = 0u;
+		L.best[0][lane] = INT_MIN; L.best[1][lane] = INT_MIN; L.best[2][lane] = INT_MIN;
+		L.noas[0][lane] = 0xffffffffu; L.noas[1][lane] = 0xffffffffu; L.noas[2][lane] = 0xffffffffu;
+		L.pair[lane] = 0u; L.k1[lane] = 0u; L.k2[lane] = 0u;
+		L.start[lane] = s - S;
+		if (A.unique_only) { L.ties[0][lane] = 0u; L.ties[1][lane] = 0u; L.ties[2][lane] = 0u; }
+		// all of the range's records in flight before anything is looked at
+		uint32_t pc[BF_ROWS];
+		int32_t sc[BF_ROWS];
 #pragma unroll
-				for (int q = 0; q < 7; q++)        // only the dwords the pool reaches into
-					fw[q] = (2u * ((s >> 1) + (uint32_t)q) < e) ? f32p[q] : 0u;
+		for (int r = 0; r < BF_ROWS; r++) {
+			const uint32_t off = 64u * (uint32_t)r + lane;
+			pc[r] = 0u; sc[r] = 0;
+			if (off < R) { pc[r] = bh_rec_code(A, S + off); sc[r] = A.as[S + off]; }
+		}
+		bf_wave_sync();
+		if (gv) atomicOr(&L.bits[(s - S) >> 5], 1u << ((s - S) & 31u));
+		bf_wave_sync();
+		{
+			const uint32_t wc = lane < BF_WORDS ? (uint32_t)__popc(L.bits[lane]) : 0u;
+			uint32_t incl = wc;
 #pragma unroll
-				for (int q = 0; q < 4; q++) rw[q] = (4u * ((s >> 2) + (uint32_t)q) < e) ? r32p[q] : 0u;
+			for (int d = 1; d < 32; d <<= 1) {
+				const uint32_t o = __shfl_up(incl, d, 64);
+				if (lane >= (uint32_t)d) incl += o;
 			}
-			if (A.pool) {
-				const uint32_t *p32p = reinterpret_cast<const uint32_t *>(A.pool) + (s >> 2);
+			if (lane < BF_WORDS) L.wpre[lane] = incl - wc;
+		}
+		bf_wave_sync();
+		// ---- 2: maxima per pool and mate class ----
 #pragma unroll
-				for (int q = 0; q < 4; q++) pw[q] = (4u * ((s >> 2) + (uint32_t)q) < e) ? p32p[q] : 0u;
-			}
-			int32_t sc[BH_WIN];
-#pragma unroll
-			for (int r = 0; r < BH_WIN; r++) sc[r] = ((uint32_t)r < len) ? A.as[s + r] : INT_MIN;
-			// ---- realign so that record r is at a fixed position ----
-			const uint32_t fsh = 16u * (s & 1u), bsh = s & 3u;
-			uint32_t fa[6], ra[3], pa[3];
-#pragma unroll
-			for (int q = 0; q < 6; q++) fa[q] = __builtin_amdgcn_alignbit(fw[q + 1], fw[q], fsh);
-#pragma unroll
-			for (int q = 0; q < 3; q++) {
-				ra[q] = __builtin_amdgcn_alignbyte(rw[q + 1], rw[q], bsh);
-				pa[q] = __builtin_amdgcn_alignbyte(pw[q + 1], pw[q], bsh);
-			}
-			// ---- who takes part: code = mate bits | 0x100 (participates) | 0x200 (has AS) ----
-			uint32_t code[BH_WIN];
-			uint32_t paired = 0;
-#pragma unroll
-			for (int r = 0; r < BH_WIN; r++) {
-				const uint32_t pb = (pa[r >> 2] >> (8 * (r & 3))) & 0xffu;
-				if (coded) {
-					// the stats kernel has already decided participation and looked at FLAG and the aux bits
-					code[r] = ((uint32_t)r < len && (pb & MSX_PC_IN))
-					              ? ((pb & MSX_F_MATES) | 0x100u | ((pb & MSX_PC_HAS_AS) ? 0x200u : 0u)) : 0u;
-				} else {
-					const uint32_t fl = (fa[r >> 1] >> (16 * (r & 1))) & 0xffffu;
-					const uint32_t rf = (ra[r >> 2] >> (8 * (r & 3))) & 0xffu;
-					const bool part = ((uint32_t)r < len) && (A.pool ? (pb != 0) : !(fl & MSX_F_UNMAP));
-					const bool has = (rf & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-					code[r] = part ? ((fl & MSX_F_MATES) | 0x100u | (has ? 0x200u : 0u)) : 0u;
+		for (int r = 0; r < BF_ROWS; r++) {
+			if (64u * (uint32_t)r >= R) break;                                   // (wave-uniform)
+			const uint32_t off = 64u * (uint32_t)r + lane;
+			if (off < R) {
+				const uint32_t wd = off >> 5;
+				const uint32_t pid = L.wpre[wd] + (uint32_t)__popc(L.bits[wd] & (0xffffffffu >> (31u - (off & 31u)))) - 1u;
+				const uint32_t c = pc[r], cls = c & MSX_F_MATES, ci = cls >> 6;
+				if (c & MSX_PC_IN) {
+					if (cls) atomicOr(&L.pair[pid], cls);                         // mBamPoolIsPaired :196-204
+					if (ci < 3u) {
+						if (c & MSX_PC_HAS_AS) atomicMax(&L.best[ci][pid], sc[r]);
+						else atomicMin(&L.noas[ci][pid], S + off);
+					}
 				}
-				paired |= code[r] & MSX_F_MATES;                                 // mBamPoolIsPaired :196-204
+				pc[r] = c | (pid << 8);
 			}
-			// a paired pool is judged per mate (READ1 -> A, READ2 -> B), an unpaired one as a whole (A)
-			const uint32_t selA = paired ? 0x140u : 0x100u, selB = paired ? 0x180u : 0xffffu;
-			int32_t bA = INT_MIN, bB = INT_MIN;
-			uint32_t hasA = 0, hasB = 0, noas = 0;                                // bit r = record r
+		}
+		bf_wave_sync();
+		// ---- 3: winners ----
 #pragma unroll
-			for (int r = 0; r < BH_WIN; r++) {
-				const uint32_t cl = code[r] & 0x1c0u;
-				const bool inA = (cl == selA), inB = (cl == selB), has = (code[r] & 0x200u) != 0;
-				hasA |= (inA && has) ? (1u << r) : 0u;
-				hasB |= (inB && has) ? (1u << r) : 0u;
-				noas |= ((inA || inB) && !has) ? (1u << r) : 0u;
-				const int32_t sa = (inA && has) ? sc[r] : INT_MIN, sb = (inB && has) ? sc[r] : INT_MIN;
-				bA = sa > bA ? sa : bA;
-				bB = sb > bB ? sb : bB;
+		for (int r = 0; r < BF_ROWS; r++) {
+			if (64u * (uint32_t)r >= R) break;
+			const uint32_t off = 64u * (uint32_t)r + lane;
+			const uint32_t c = pc[r], ci = (c & MSX_F_MATES) >> 6, pid = c >> 8;
+			bool win = false;
+			if (off < R && (c & MSX_PC_IN) && (c & MSX_PC_HAS_AS) && ci < 3u) {
+				// a paired pool is judged per mate (READ1, READ2), an unpaired one as a whole
+				const bool judged = L.pair[pid] ? (ci != 0u) : (ci == 0u);
+				win = judged && sc[r] == L.best[ci][pid];
 			}
-			uint32_t eqA = 0, eqB = 0;
+			if (A.unique_only && win) atomicAdd(&L.ties[ci][pid], 1u);
+			pc[r] = (c & ~(uint32_t)MSX_PC_IN) | (win ? MSX_PC_IN : 0u);          // bit 0 from here on: winner
+		}
+		if (A.unique_only) bf_wave_sync();
 #pragma unroll
-			for (int r = 0; r < BH_WIN; r++) {
-				eqA |= (sc[r] == bA) ? (1u << r) : 0u;
-				eqB |= (sc[r] == bB) ? (1u << r) : 0u;
+		for (int r = 0; r < BF_ROWS; r++) {
+			if (64u * (uint32_t)r >= R) break;
+			const uint32_t off = 64u * (uint32_t)r + lane;
+			if (off < R) {
+				const uint32_t c = pc[r], ci = (c & MSX_F_MATES) >> 6, pid = c >> 8;
+				bool win = (c & MSX_PC_IN) != 0u;
+				if (A.unique_only && win && L.ties[ci][pid] != 1u) win = false;   // :232-233
+				// keep codes: 1 = written in the first pass (unpaired winners, READ1 winners), 2 = READ2 winners
+				A.keep[S + off] = (uint8_t)(win ? (ci == 2u ? 2u : 1u) : 0u);
+				if (win) atomicOr(ci == 2u ? &L.k2[pid] : &L.k1[pid], 1u << (off - L.start[pid]));
 			}
-			eqA &= hasA;                                                          // the records holding the best score
-			eqB &= hasB;
-			const uint32_t nA = (uint32_t)__popc(eqA), nB = (uint32_t)__popc(eqB);
-			const bool wA = nA > 0 && (!A.unique_only || nA == 1);                // :232-233
-			const bool wB = nB > 0 && (!A.unique_only || nB == 1);
-			// keep codes: 1 = written in the first pass (unpaired winners, READ1 winners), 2 = READ2 winners
-			const uint32_t k1 = wA ? eqA : 0u, k2 = wB ? eqB : 0u;
-#pragma unroll
-			for (int r = 0; r < BH_WIN; r++)
-				if ((uint32_t)r < len) A.keep[s + r] = (uint8_t)(((k1 >> r) & 1u) | (((k2 >> r) & 1u) << 1));
-			cnt = (uint32_t)__popc(k1 | k2);
+		}
+		bf_wave_sync();
+		// ---- 4: per pool ----
+		if (gv) {
+			const uint32_t k1 = L.k1[lane], k2 = L.k2[lane];
+			A.gcount[g] = (uint32_t)__popc(k1 | k2);
+			// msam_filter.c:219-221: a participating record without AS is fatal
+			const uint32_t n1 = L.noas[1][lane], n2 = L.noas[2][lane];
+			const uint32_t bad = L.pair[lane] ? (n1 < n2 ? n1 : n2) : L.noas[0][lane];
+			if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
 			if (COUNT) {
 				PoolAcc v;
 				pool_begin(P, v, s);
 				pool_visit_masks(P, v, s, k1, k2);
 				pool_finish(P, g, v, s_key, s_val, bc);
 			}
-			if (noas) {
-				const uint32_t first = s + (uint32_t)__ffs((int)noas) - 1u;
-				if (paired) c.noas1 = first; else c.noas0 = first;
-			}
-			c.paired = paired;
-		} else {
-			for (uint32_t i = s; i < e; ++i) {
-				const uint32_t fl = A.flag[i];
-				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-				const bool has = A.pool_is_code ? ((A.pool[i] & MSX_PC_HAS_AS) != 0)
-				                                : ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP)));
-				bh_count(c, i, fl, pooled, has, A.as[i]);
-			}
-			const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);
-			const bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
-			const bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
-			for (uint32_t i = s; i < e; ++i) {
-				const uint32_t fl = A.flag[i];
-				const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
-				const bool has = A.pool_is_code ? ((A.pool[i] & MSX_PC_HAS_AS) != 0)
-				                                : ((A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP)));
-				const uint8_t k = bh_keep(c, w0, w1, w2, fl, pooled, has, A.as[i]);
-				A.keep[i] = k;
-				cnt += (k != 0);
-			}
-			if (COUNT) {
-				// long pool: the keep codes this lane just wrote, in output order
-				PoolAcc v;
-				pool_begin(P, v, s);
-				for (uint32_t pass = 1; pass <= 2; ++pass)
-					for (uint32_t i = s; i < e; ++i)
-						if (A.keep[i] == pass) pool_visit(P, v, P.tid[i]);
-				pool_finish(P, g, v, s_key, s_val, bc);
-			}
 		}
-		// msam_filter.c:219-221: a participating record without AS is fatal
-		const uint32_t bad = c.paired ? (c.noas1 < c.noas2 ? c.noas1 : c.noas2) : c.noas0;
-		if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
-		A.gcount[g] = cnt;
+		bf_wave_sync();                                                            // the slots are reused by the next tile
 	}
 	if (COUNT) count_block_end(P, s_key, s_val, s_c, bc);
 }
