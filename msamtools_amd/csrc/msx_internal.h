@@ -195,6 +195,7 @@ struct msx_profile {
 	int key_bits = 0;                 // bits of the feature id in an entry key (the list weight sits above)
 	bool transposed_valid = false;
 	int iter_k = 0;
+	bool recip_valid = false;   // recip[] of the general lists belongs to the current a[]
 	bool begun = false;
 };
 

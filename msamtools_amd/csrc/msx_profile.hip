@@ -181,6 +181,7 @@ extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
 	MSX_HIP(ctx, hipMemsetAsync(p->m_off.p, 0, 4, ctx->stream));
 	p->lists_ub = p->entries_ub = 0;
 	p->iter_k = 0;
+	p->recip_valid = false;
 	p->begun = false;
 	p->transposed_valid = false;
 	return MSX_OK;

@@ -562,37 +562,45 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint
 // recip[j] = w_j/S_j for every general list j (S_j = sum of a over its features, w_j the number of
 // inserts it stands for; 0 when S_j == 0: msam_profile.c:358).  These are the lists of five and more
 // features (0.6 % of the lists on the IGC-scale workload), reached through gl_idx[]: one lane per list.
-__global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(const unsigned long long *__restrict__ d_tot,
-                                                             const uint32_t *__restrict__ m_off,
-                                                             const int32_t *__restrict__ m_fid,
-                                                             const uint32_t *__restrict__ hpos,
-                                                             const uint32_t *__restrict__ gl_idx,
-                                                             const double *__restrict__ a, double *__restrict__ recip,
-                                                             const int32_t *__restrict__ iter_state) {
-	if (iter_state[0]) return;
-	const int64_t n = (int64_t)d_tot[2];
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n; i += stride) {
-		const uint32_t j = gl_idx[i];
-		const uint32_t s = m_off[j], e = m_off[j + 1];
-		const uint32_t w = hpos[j + 1] - hpos[j];
+struct RecipArgs {
+	const unsigned long long *d_tot;
+	const uint32_t *m_off;
+	const int32_t *m_fid;
+	const uint32_t *hpos;
+	const uint32_t *gl_idx;
+	const double *a;
+	double *recip;
+};
+
+__device__ __forceinline__ void general_recip_body(const RecipArgs &G, int64_t first, int64_t stride) {
+	const int64_t n = (int64_t)G.d_tot[2];
+	for (int64_t i = first; i < n; i += stride) {
+		const uint32_t j = G.gl_idx[i];
+		const uint32_t s = G.m_off[j], e = G.m_off[j + 1];
+		const uint32_t w = G.hpos[j + 1] - G.hpos[j];
 		double sum = 0;
 		if (e - s <= 8u) {
 			// feature ids, then abundances, as independent loads; summed in list order
 			int32_t f[8];
 			double x[8];
 #pragma unroll
-			for (int q = 0; q < 8; q++) f[q] = (s + (uint32_t)q < e) ? m_fid[s + q] : -1;
+			for (int q = 0; q < 8; q++) f[q] = (s + (uint32_t)q < e) ? G.m_fid[s + q] : -1;
 #pragma unroll
-			for (int q = 0; q < 8; q++) x[q] = (f[q] >= 0) ? a[f[q]] : 0.0;
+			for (int q = 0; q < 8; q++) x[q] = (f[q] >= 0) ? G.a[f[q]] : 0.0;
 #pragma unroll
 			for (int q = 0; q < 8; q++)
 				if (s + (uint32_t)q < e) sum += x[q];
 		} else {
-			for (uint32_t k = s; k < e; ++k) sum += a[m_fid[k]];
+			for (uint32_t k = s; k < e; ++k) sum += G.a[G.m_fid[k]];
 		}
-		recip[j] = sum > 0 ? (double)w / sum : 0.0;
+		G.recip[j] = sum > 0 ? (double)w / sum : 0.0;
 	}
+}
+
+// (a launch of its own before the first iteration only: afterwards the lists ride along with k_prop_finish)
+__global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(RecipArgs G, const int32_t *__restrict__ iter_state) {
+	if (iter_state[0]) return;
+	general_recip_body(G, (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x, (int64_t)gridDim.x * MSX_BLOCK);
 }
 
 // share[f] = sum of w/S over the lists containing f -- a segmented sum over the
@@ -991,10 +999,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_apply(int32_t nf, int nsb, i
 // (A launch of its own: letting the last workgroup of k_prop_apply do it needs a ticket that a thousand
 // workgroups draw from one address -- 12 us of serialised atomics -- or a release fence per workgroup,
 // which writes back the whole L2 each time -- 44 us; a dependent launch costs 2.)
+// Workgroups 1.. of the same launch: recip[] of the general lists for the NEXT iteration -- it depends on a[]
+// like this sum does, and a launch of its own cost 5 us per iteration.  (They read the convergence flag as the
+// iterations before left it: once more than needed when this one converges, into an array nobody reads again.)
 __global__ __launch_bounds__(MSX_BLOCK) void k_prop_finish(int nparts, const double *__restrict__ partial, int32_t nf,
-                                                           double *__restrict__ delta, int32_t *iter_state, int k) {
+                                                           double *__restrict__ delta, int32_t *iter_state, int k,
+                                                           RecipArgs G) {
 	__shared__ double s_w[MSX_BLOCK / 64];
 	if (iter_state[0]) return;
+	if (blockIdx.x > 0) {
+		general_recip_body(G, (int64_t)(blockIdx.x - 1) * MSX_BLOCK + threadIdx.x, (int64_t)(gridDim.x - 1) * MSX_BLOCK);
+		return;
+	}
 	double acc = 0;
 	for (int i = threadIdx.x; i < nparts; i += MSX_BLOCK) acc += partial[i];
 	for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
@@ -1219,17 +1235,24 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 // One iteration's sums.  complete = false (single GPU, msx_profile_finalize_enqueue): share[] gets the
 // segments that lie inside one chunk, the partial slots stay in part_val -- k_prop_apply<true> puts the
 // two together.  complete = true (a collective follows): the slots are added into share[] here.
+static int recip_grid(msx_ctx *ctx, const msx_profile *p) {
+	int gg = msx_grid(ctx, p->lists_ub > 0 ? p->lists_ub : 1, MSX_BLOCK);
+	return gg > 128 ? 128 : gg;                              // the general lists are few: a small grid strides over them
+}
+
+static RecipArgs recip_args(const msx_profile *p) {
+	return RecipArgs{(const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p, (const int32_t *)p->m_fid_alt.p,
+	                 (const uint32_t *)p->hpos.p, (const uint32_t *)p->gl_idx.p, (const double *)p->a, (double *)p->recip.p};
+}
+
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
-	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
 	const int64_t W = msx_share_waves(ctx);
-	int gg = msx_grid(ctx, lub, MSX_BLOCK);
-	if (gg > 128) gg = 128;                                  // the general lists are few: a small grid strides over them
-	MSX_TIMED(ctx, MSX_K_GENERAL_RECIP,
-	          hipLaunchKernelGGL(k_general_recip, dim3(gg), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p,
-	                             (const int32_t *)p->m_fid_alt.p, (const uint32_t *)p->hpos.p,
-	                             (const uint32_t *)p->gl_idx.p, (const double *)p->a, (double *)p->recip.p,
-	                             (const int32_t *)p->iter_state));
+	if (!p->recip_valid) {
+		MSX_TIMED(ctx, MSX_K_GENERAL_RECIP,
+		          hipLaunchKernelGGL(k_general_recip, dim3(recip_grid(ctx, p)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             recip_args(p), (const int32_t *)p->iter_state));
+		p->recip_valid = true;
+	}
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
 	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
@@ -1262,8 +1285,10 @@ int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused) {
 		                   2 * msx_share_waves(ctx), (const double *)p->U, p->share, p->a, (const unsigned long long *)p->d_tot,
 		                   (const PartRun *)p->runs.p, (const double *)p->part_val.p, (const uint32_t *)p->owned.p,
 		                   p->partial, (const int32_t *)p->iter_state);
-	hipLaunchKernelGGL(k_prop_finish, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, fused ? nsb + nrb : nsb,
-	                   (const double *)p->partial, nf, p->delta, p->iter_state, k);
+	// (the sum of diff^2 in workgroup 0, recip[] of the general lists for the next iteration in the others)
+	hipLaunchKernelGGL(k_prop_finish, dim3(1 + (k < 19 ? recip_grid(ctx, p) : 0)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   fused ? nsb + nrb : nsb, (const double *)p->partial, nf, p->delta, p->iter_state, k, recip_args(p));
+	p->recip_valid = true;
 	msx_time_end(ctx);
 	return MSX_OK;
 }
@@ -1289,6 +1314,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->counters + 3, 0, 4, ctx->stream));   // purged is recomputed per finalize
 	p->iter_k = 0;
+	p->recip_valid = false;
 	p->begun = true;
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		int rc = msx_prop_build(ctx, p);
