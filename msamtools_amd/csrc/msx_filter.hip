@@ -119,28 +119,20 @@ __device__ __forceinline__ void bh_pool_serial(const SelectArgs &A, const CountA
 //      "paired" word (LDS atomics; msam_filter.c:196-230)
 //   3  every record compares itself with its pool's maximum (--uniqhit: ties counted in between, :232-233),
 //      writes its keep code and sets its bit in the pool's first-pass / second-pass winner mask
-//   4  COUNT, the fused `filter | profile` form: the pool's distinct features in first-appearance order
-//      (msam_profile.c:131-145), still one lane per record -- a winner's place in the pool's output order
-//      is a popcount of the winner masks, it puts its feature there (LDS), looks at the places before its
-//      own for the same feature, and the first occurrences close ranks
-//   5  lane p again: records written, the fatal-record check, the insert accounting of msx_count.h.
+//   4  lane p again: records written, the fatal-record check and -- COUNT, the fused `filter | profile`
+//      form -- the insert accounting of msx_count.h straight from the winner masks.
 // A wave whose range exceeds BF_RMAX records, or with a pool of more than 32 records (the masks) or none,
 // walks its pools one lane each (bh_pool_serial).
 // ---------------------------------------------------------------------------
-#define BF_ROWS 10
+#define BF_ROWS 12
 #define BF_RMAX (64 * BF_ROWS)
 #define BF_WORDS (BF_RMAX / 32)
-#define BF_UI_TBL 512             // slots of the staging table of msx_count.h in this kernel (LDS is the occupancy limit here)
 
 struct BfWave {
 	uint32_t bits[BF_WORDS], wpre[BF_WORDS];
 	int32_t best[3][64];          // per mate class: neither bit, READ1, READ2
 	uint32_t ties[3][64], noas[3][64];
 	uint32_t pair[64], k1[64], k2[64], start[64];
-};
-struct BfCount {                  // COUNT only
-	uint32_t notid[64], nw[64];   // winners without a reference (msam_profile.c:223); first occurrences, by place
-	int32_t fid[BF_RMAX];         // a pool's features at [start, start + winners): by place, then the distinct ones
 };
 
 __device__ __forceinline__ void bf_wave_sync() {
@@ -152,15 +144,13 @@ __device__ __forceinline__ void bf_wave_sync() {
 template <bool COUNT>
 __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, CountArgs P) {
 	__shared__ BfWave s_w[MSX_BLOCK / 64];
-	__shared__ BfCount s_cn[COUNT ? MSX_BLOCK / 64 : 1];
 	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
-	__shared__ int32_t s_key[COUNT ? BF_UI_TBL : 1];
-	__shared__ uint32_t s_val[COUNT ? BF_UI_TBL : 1];
+	__shared__ int32_t s_key[COUNT ? UI_TBL : 1];
+	__shared__ uint32_t s_val[COUNT ? UI_TBL : 1];
 	BlockCounts bc = {0u, 0u, 0u};
 	if (COUNT) count_block_begin(P, s_key, s_val);
 	const uint32_t lane = threadIdx.x & 63u;
 	BfWave &L = s_w[threadIdx.x >> 6];
-	BfCount &C = s_cn[COUNT ? (threadIdx.x >> 6) : 0];
 	const int64_t n_tiles = (A.n_groups + 63) >> 6;
 	const int64_t wstride = (int64_t)gridDim.x * (MSX_BLOCK / 64);
 	int64_t tile = (int64_t)blockIdx.x * (MSX_BLOCK / 64) + (threadIdx.x >> 6);
@@ -190,19 +180,14 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 		L.pair[lane] = 0u; L.k1[lane] = 0u; L.k2[lane] = 0u;
 		L.start[lane] = s - S;
 		if (A.unique_only) { L.ties[0][lane] = 0u; L.ties[1][lane] = 0u; L.ties[2][lane] = 0u; }
-		if (COUNT) { C.notid[lane] = 0u; C.nw[lane] = 0u; }
 		// all of the range's records in flight before anything is looked at
 		uint32_t pc[BF_ROWS];
-		int32_t sc[BF_ROWS], tv[COUNT ? BF_ROWS : 1];
+		int32_t sc[BF_ROWS];
 #pragma unroll
 		for (int r = 0; r < BF_ROWS; r++) {
 			const uint32_t off = 64u * (uint32_t)r + lane;
 			pc[r] = 0u; sc[r] = 0;
-			if (COUNT) tv[r] = -1;
-			if (off < R) {
-				pc[r] = bh_rec_code(A, S + off); sc[r] = A.as[S + off];
-				if (COUNT) tv[r] = P.tid[S + off];
-			}
+			if (off < R) { pc[r] = bh_rec_code(A, S + off); sc[r] = A.as[S + off]; }
 		}
 		bf_wave_sync();
 		if (gv) atomicOr(&L.bits[(s - S) >> 5], 1u << ((s - S) & 31u));
@@ -264,62 +249,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 				if (A.unique_only && win && L.ties[ci][pid] != 1u) win = false;   // :232-233
 				// keep codes: 1 = written in the first pass (unpaired winners, READ1 winners), 2 = READ2 winners
 				A.keep[S + off] = (uint8_t)(win ? (ci == 2u ? 2u : 1u) : 0u);
-				const uint32_t bit = 1u << (off - L.start[pid]);
-				if (win) atomicOr(ci == 2u ? &L.k2[pid] : &L.k1[pid], bit);
-				if (COUNT) {
-					// bit 1 from here on: a winner profile counts (it has a reference); tv: its feature
-					const bool cw = win && tv[r] != -1;
-					if (win && !cw) atomicOr(&C.notid[pid], bit);
-					if (cw && P.fmap) tv[r] = P.fmap[tv[r]];
-					pc[r] = (c & ~(uint32_t)MSX_PC_HAS_AS) | (cw ? MSX_PC_HAS_AS : 0u);
-				}
+				if (win) atomicOr(ci == 2u ? &L.k2[pid] : &L.k1[pid], 1u << (off - L.start[pid]));
 			}
 		}
 		bf_wave_sync();
-		if (COUNT) {
-			// ---- 4: distinct features per pool, in the order the winners are written ----
-#pragma unroll
-			for (int r = 0; r < BF_ROWS; r++) {
-				if (64u * (uint32_t)r >= R) break;
-				const uint32_t c = pc[r];
-				if (c & MSX_PC_HAS_AS) {
-					const uint32_t off = 64u * (uint32_t)r + lane, ci = (c & MSX_F_MATES) >> 6, pid = (c >> 8) & 63u;
-					const uint32_t ok = ~C.notid[pid], m1 = L.k1[pid] & ok, m2 = L.k2[pid] & ok;
-					const uint32_t below = (1u << (off - L.start[pid])) - 1u;
-					const uint32_t j = ci == 2u ? (uint32_t)__popc(m1) + (uint32_t)__popc(m2 & below) : (uint32_t)__popc(m1 & below);
-					C.fid[L.start[pid] + j] = tv[r];
-					pc[r] = c | (j << 16);
-				}
-			}
-			bf_wave_sync();
-#pragma unroll
-			for (int r = 0; r < BF_ROWS; r++) {
-				if (64u * (uint32_t)r >= R) break;
-				const uint32_t c = pc[r], pid = (c >> 8) & 63u, j = c >> 16;
-				const bool cw = (c & MSX_PC_HAS_AS) != 0u;
-				const uint32_t base = cw ? L.start[pid] : 0u;
-				bool first = cw;
-				for (uint32_t jj = 0; __ballot(cw && jj < j) != 0ull; jj++)
-					if (cw && jj < j && C.fid[base + jj] == tv[r]) first = false;
-				if (first) atomicOr(&C.nw[pid], 1u << j);
-				pc[r] = (c & ~(uint32_t)MSX_PC_HAS_AS) | (first ? MSX_PC_HAS_AS : 0u);   // bit 1: a first occurrence
-			}
-			bf_wave_sync();
-#pragma unroll
-			for (int r = 0; r < BF_ROWS; r++) {
-				if (64u * (uint32_t)r >= R) break;
-				const uint32_t c = pc[r];
-				if (c & MSX_PC_HAS_AS) {
-					const uint32_t pid = (c >> 8) & 63u, j = c >> 16, nw = C.nw[pid];
-					const uint32_t dpos = (uint32_t)__popc(nw & ((1u << j) - 1u));
-					C.fid[L.start[pid] + dpos] = tv[r];
-					// the list itself is only read for pools with two or more distinct features (k_multi_compact)
-					if (nw & (nw - 1u)) P.tmp_fid[S + L.start[pid] + dpos] = tv[r];
-				}
-			}
-			bf_wave_sync();
-		}
-		// ---- 5: per pool ----
+		// ---- 4: per pool ----
 		if (gv) {
 			const uint32_t k1 = L.k1[lane], k2 = L.k2[lane];
 			A.gcount[g] = (uint32_t)__popc(k1 | k2);
@@ -329,12 +263,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 			if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
 			if (COUNT) {
 				PoolAcc v;
-				v.nvalid = (uint32_t)__popc((k1 | k2) & ~C.notid[lane]);
-				v.nd = (uint32_t)__popc(C.nw[lane]);
-				v.lst = &C.fid[s - S];
-				v.f0 = v.nd > 0u ? v.lst[0] : -1;
-				v.f1 = v.nd > 1u ? v.lst[1] : -1;
-				v.f2 = v.f3 = -1;
+				pool_begin(P, v, s);
+				pool_visit_masks(P, v, s, k1, k2);
 				pool_finish(P, g, v, s_key, s_val, bc);
 			}
 		}
@@ -547,7 +477,6 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 		CountArgs P = {};
 		bool by_part = false;
 		if (prof && ng > 0 && (rc = msx_profile_count_prepare(ctx, prof, b, out->keep, &P, &by_part))) return rc;
-		if (P.tbl_mask > BF_UI_TBL - 1u) P.tbl_mask = BF_UI_TBL - 1u;
 		msx_time_begin(ctx, MSX_K_BESTHIT);
 		if (prof && ng > 0)
 			hipLaunchKernelGGL(k_besthit_select<true>, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
