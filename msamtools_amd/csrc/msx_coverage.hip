@@ -171,6 +171,7 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 	if (!ctx || !b || !cov_off || !cov) return MSX_ERR_ARG;
 	if (!b->pos || !b->tid || !b->cigar_off || !b->cigar)
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_accumulate needs tid, pos and cigar arrays");
+	msx_join(ctx);
 	if (b->n_records == 0) return MSX_OK;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	static const int64_t binned_from = [] {
@@ -220,6 +221,7 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 
 extern "C" int msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len) {
 	if (!ctx || !cov || total_len < 0) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (total_len == 0) return MSX_OK;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	return msx_scan_inclusive_u32(ctx, (uint32_t *)cov, total_len);

@@ -167,6 +167,7 @@ extern "C" void *msx_ctx_stream(msx_ctx *ctx) { return ctx ? (void *)ctx->stream
 
 extern "C" int msx_ctx_sync(msx_ctx *ctx) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MSX_OK;
 }
@@ -217,12 +218,14 @@ void msx_time_end(msx_ctx *ctx) {
 
 extern "C" int msx_timing_enable(msx_ctx *ctx, int on) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	ctx->timing = on != 0;
 	return MSX_OK;
 }
 
 extern "C" int msx_timing_reset(msx_ctx *ctx) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	for (auto &t : ctx->timed) {
 		ctx->event_pool.push_back(t.a);
@@ -235,6 +238,7 @@ extern "C" int msx_timing_reset(msx_ctx *ctx) {
 
 extern "C" int msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, int64_t *launches) {
 	if (!ctx || !name) return MSX_ERR_ARG;
+	msx_join(ctx);
 	int kid = -1;
 	for (int i = 0; i < MSX_K_COUNT; i++)
 		if (strcmp(name, k_names[i]) == 0) kid = i;
@@ -259,6 +263,7 @@ extern "C" int msx_timing_get(msx_ctx *ctx, const char *name, double *ms_total, 
 // passes, whose lengths live on the device); 0 for kernels it does not price.
 extern "C" int msx_timing_get_bytes(msx_ctx *ctx, const char *name, int64_t *bytes_total) {
 	if (!ctx || !name || !bytes_total) return MSX_ERR_ARG;
+	msx_join(ctx);
 	int kid = -1;
 	for (int i = 0; i < MSX_K_COUNT; i++)
 		if (strcmp(name, k_names[i]) == 0) kid = i;
@@ -298,12 +303,14 @@ extern "C" void msx_dev_free(msx_ctx *ctx, void *ptr) {
 
 extern "C" int msx_dev_zero(msx_ctx *ctx, void *ptr, size_t bytes) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (bytes) MSX_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
 	return MSX_OK;
 }
 
 extern "C" int msx_dev_to_host(msx_ctx *ctx, void *host, const void *dev, size_t bytes) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (bytes) {
 		MSX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -313,6 +320,7 @@ extern "C" int msx_dev_to_host(msx_ctx *ctx, void *host, const void *dev, size_t
 
 extern "C" int msx_host_to_dev(msx_ctx *ctx, void *dev, const void *host, size_t bytes) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (bytes) {
 		MSX_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -348,6 +356,7 @@ extern "C" void msx_batch_free(msx_ctx *ctx, msx_batch *dev) {
 
 extern "C" int msx_batch_upload(msx_ctx *ctx, const msx_batch *h, msx_batch *d) {
 	if (!ctx || !h || !d) return MSX_ERR_ARG;
+	msx_join(ctx);
 	memset(d, 0, sizeof(*d));
 	size_t n = (size_t)h->n_records;
 	if (h->n_records < 0 || h->n_records > 0x7fffffffLL)
@@ -413,6 +422,7 @@ static int stage_up(msx_ctx *ctx, msx_buf *buf, const T *src, size_t count, size
 
 extern "C" int msx_stage_upload(msx_ctx *ctx, msx_stage *st, const msx_batch *h, msx_batch *d) {
 	if (!ctx || !st || !h || !d) return MSX_ERR_ARG;
+	msx_join(ctx);
 	memset(d, 0, sizeof(*d));
 	const size_t n = (size_t)h->n_records;
 	if (h->n_records < 0 || h->n_records > 0x7fffffffLL)
@@ -441,6 +451,7 @@ extern "C" int msx_stage_upload(msx_ctx *ctx, msx_stage *st, const msx_batch *h,
 
 extern "C" int msx_stage_outputs(msx_ctx *ctx, msx_stage *st, int64_t n_records, int want_as, msx_filter_out *out) {
 	if (!ctx || !st || !out || n_records < 0) return MSX_ERR_ARG;
+	msx_join(ctx);
 	const size_t n = (size_t)(n_records > 0 ? n_records : 1);
 	int rc;
 	if ((rc = msx_reserve(ctx, &st->keep, n + 16))) return rc;
@@ -481,6 +492,7 @@ extern "C" int msx_host_unregister(msx_ctx *ctx, void *ptr) {
 
 extern "C" int msx_dev_to_host_async(msx_ctx *ctx, void *host, const void *dev, size_t bytes) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (bytes) MSX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
 	return MSX_OK;
 }

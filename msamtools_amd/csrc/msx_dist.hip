@@ -254,6 +254,7 @@ static int reduce_host(msx_ctx *ctx, void *val, size_t bytes, int dtype, int op)
 
 extern "C" int msx_dist_barrier(msx_ctx *ctx) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	int32_t one = 1;
 	if (!ctx->dist) { MSX_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MSX_OK; }
 	return reduce_host(ctx, &one, 4, MSX_NCCL_INT32, MSX_NCCL_SUM);
@@ -261,11 +262,13 @@ extern "C" int msx_dist_barrier(msx_ctx *ctx) {
 
 extern "C" int msx_dist_max_f64(msx_ctx *ctx, double *value) {
 	if (!ctx || !value) return MSX_ERR_ARG;
+	msx_join(ctx);
 	return reduce_host(ctx, value, 8, MSX_NCCL_FLOAT64, MSX_NCCL_MAX);
 }
 
 extern "C" int msx_dist_sum_i64(msx_ctx *ctx, int64_t *value) {
 	if (!ctx || !value) return MSX_ERR_ARG;
+	msx_join(ctx);
 	return reduce_host(ctx, value, 8, MSX_NCCL_INT64, MSX_NCCL_SUM);
 }
 
@@ -274,6 +277,7 @@ extern "C" int msx_dist_sum_i64(msx_ctx *ctx, int64_t *value) {
 // counts every insert of the file, whichever rank read it.  Integer sums are order-free: bit-exact.
 extern "C" int msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	msx_join(ctx);
 	msx_dist *d = ctx->dist;
 	if (!d) return MSX_OK;          // (a one-rank communicator still runs the collective: the same code path)
 	MSX_HIP(ctx, hipSetDevice(ctx->device));

@@ -425,6 +425,7 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 	if (best && !b->as) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_enqueue: --besthit/--uniqhit need the as array");
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	const int64_t n = b->n_records;
+	msx_join(ctx);
 	hipLaunchKernelGGL(k_status_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_status);
 	ctx->filter_pending = true;
 	if (n == 0) return MSX_OK;
@@ -499,8 +500,11 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 			                   out->emit_idx, ctx->d_status);
 			msx_time_end(ctx);
 		}
-		msx_join(ctx);
-		if (rc) return rc;
+		// The side lanes are left running: whatever follows on this context joins them first (msx_join at the
+		// head of every entry point) -- except the build of the sharing store in msx_profile_prop_begin,
+		// which does not depend on them and overlaps their tails.
+		msx_lane_leave(ctx);
+		if (rc) { msx_join(ctx); return rc; }
 	} else {
 		const int64_t nc = (n + EMIT_CHUNK - 1) / EMIT_CHUNK;
 		if ((rc = msx_reserve(ctx, &ctx->gcount, (size_t)(nc + 8) * 4))) return rc;
@@ -535,6 +539,7 @@ extern "C" int msx_filter_profile_enqueue(msx_ctx *ctx, const msx_batch *b, cons
 
 extern "C" int msx_filter_finish(msx_ctx *ctx, msx_filter_status *status) {
 	if (!ctx) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (status) { status->n_emit = 0; status->err_record = -1; }
 	if (!ctx->filter_pending) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_finish without msx_filter_enqueue");
 	ctx->filter_pending = false;
@@ -566,6 +571,7 @@ extern "C" int msx_aln_stats(msx_ctx *ctx, const msx_batch *b, int32_t *length, 
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_aln_stats: length/query_length/query_clip/edit are all required");
 	if (!b->flag || !b->rflags || !b->cigar_off || !b->cigar || !b->md_off || !b->md || !b->nm)
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_aln_stats: flag, rflags, cigar, md and nm arrays are required");
+	msx_join(ctx);
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	hipLaunchKernelGGL(k_status_init, dim3(1), dim3(1), 0, ctx->stream, ctx->d_status);
 	if (b->n_records == 0) return MSX_OK;

@@ -110,10 +110,11 @@ int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes) {
 
 extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	if (!p) return;
+	if (ctx) msx_join(ctx);
 	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
-	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p,
+	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p, p->ck_hist.p, p->ck_off.p,
 	                p->recip.p, p->runs.p, p->owned.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p, p->len2.p,
 	                p->head.p, p->uidx.p, p->eoff.p, p->hpos.p, p->d_tot,
 	                p->t_val64[0].p, p->t_val64[1].p, p->gl_idx.p};
@@ -125,6 +126,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_features, int32_t share_type,
                                   const int32_t *fmap, int32_t n_targets) {
 	if (!ctx || !out) return MSX_ERR_ARG;
+	msx_join(ctx);
 	*out = nullptr;
 	if (share_type < MSX_MULTI_ADD_ALL || share_type > MSX_MULTI_IGNORE)
 		return msx_fail(ctx, MSX_ERR_SHARE_TYPE, "Do not understand share_type=%d", share_type);
@@ -169,6 +171,7 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 
 extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	msx_join(ctx);
 	const size_t nf = (size_t)(p->n_features > 0 ? p->n_features : 1);
 	MSX_HIP(ctx, hipMemsetAsync(p->ui, 0, nf * 4, ctx->stream));
 	if (p->d) MSX_HIP(ctx, hipMemsetAsync(p->d, 0, nf * 8, ctx->stream));
@@ -288,6 +291,7 @@ int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, b
 extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep) {
 	if (!ctx || !p || !b) return MSX_ERR_ARG;
 	if (!b->group_off || !b->tid) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_accumulate needs tid and group_off");
+	msx_join(ctx);
 	if (b->n_records == 0 || b->n_groups == 0) return MSX_OK;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	CountArgs A;
@@ -302,6 +306,7 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 
 extern "C" int msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui, double **d, uint32_t **counters) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	msx_join(ctx);
 	if (ui) *ui = p->ui;
 	if (d) *d = p->d;
 	if (counters) *counters = p->counters;
@@ -310,12 +315,14 @@ extern "C" int msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t *
 
 extern "C" int msx_profile_abundance_dev(msx_ctx *ctx, msx_profile *p, double **a) {
 	if (!ctx || !p || !a) return MSX_ERR_ARG;
+	msx_join(ctx);
 	*a = p->a;
 	return MSX_OK;
 }
 
 extern "C" int msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	msx_join(ctx);
 	unsigned long long t[2] = {0, 0};
 	MSX_HIP(ctx, hipMemcpyAsync(t, p->csr_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -326,6 +333,7 @@ extern "C" int msx_profile_multi_size(msx_ctx *ctx, msx_profile *p, int64_t *n_l
 
 extern "C" int msx_profile_shared_size(msx_ctx *ctx, msx_profile *p, int64_t *n_lists, int64_t *n_entries) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	msx_join(ctx);
 	unsigned long long t[2] = {0, 0};
 	MSX_HIP(ctx, hipMemcpyAsync(t, p->d_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -266,19 +266,19 @@ int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t 
 	if ((1 << shift) > PC_RANGE) return msx_fail(ctx, MSX_ERR_ARG, "msx_count_keys: too many features");
 	const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
 	int rc;
-	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
-	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_tiles + 16) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, &p->ck_hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, &p->ck_off, (size_t)(256 * n_tiles + 16) * 4))) return rc;
 	MSX_TIMED(ctx, MSX_K_INSERT_COUNT,
 	          hipLaunchKernelGGL(k_rs_hist<true>, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, keys,
-	                             (const unsigned long long *)nullptr, n, shift, 255u, (uint32_t *)p->rs_hist.p,
+	                             (const unsigned long long *)nullptr, n, shift, 255u, (uint32_t *)p->ck_hist.p,
 	                             n_tiles));
-	if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_tiles))) return rc;
+	if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->ck_hist.p, (uint32_t *)p->ck_off.p, 256 * n_tiles))) return rc;
 	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
 	hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
 	                   keys, (const uint32_t *)nullptr, key2, (uint32_t *)nullptr, (const unsigned long long *)nullptr,
-	                   n, shift, 255u, (const uint32_t *)p->rs_off.p, n_tiles);
+	                   n, shift, 255u, (const uint32_t *)p->ck_off.p, n_tiles);
 	hipLaunchKernelGGL(k_part_count, dim3(PC_SPLIT, 256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)key2,
-	                   (const uint32_t *)p->rs_off.p, n_tiles, shift, p->n_features, add, p->ui);
+	                   (const uint32_t *)p->ck_off.p, n_tiles, shift, p->n_features, add, p->ui);
 	msx_time_end(ctx);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
@@ -1306,6 +1306,14 @@ int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev) {
 extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	// The derived store needs the multi-mapper lists only: it is built while the side lanes
+	// msx_filter_profile_enqueue left running (the unique-insert counts, filter's output order) finish;
+	// the abundances wait for the counts.
+	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		int rc = msx_prop_build(ctx, p);
+		if (rc) { msx_join(ctx); return rc; }
+	}
+	msx_join(ctx);
 	const int32_t nf = p->n_features;
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
@@ -1316,10 +1324,6 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 	p->iter_k = 0;
 	p->recip_valid = false;
 	p->begun = true;
-	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
-		int rc = msx_prop_build(ctx, p);
-		if (rc) return rc;
-	}
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
@@ -1327,6 +1331,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local before msx_profile_prop_begin");
+	msx_join(ctx);
 	if (p->share_type != MSX_MULTI_SHARE_PROPORTIONAL)
 		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
 	msx_prop_iteration(ctx, p, true);         // share[] complete: the caller all-reduces it
@@ -1338,6 +1343,7 @@ extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc
 extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delta) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply before msx_profile_prop_begin");
+	msx_join(ctx);
 	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
 	p->iter_k++;
 	msx_prop_apply_launch(ctx, p, p->iter_k, false);
@@ -1351,6 +1357,7 @@ extern "C" int msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delt
 
 extern "C" int msx_profile_share_dev(msx_ctx *ctx, msx_profile *p, double **share) {
 	if (!ctx || !p || !share) return MSX_ERR_ARG;
+	msx_join(ctx);
 	*share = p->share;
 	return MSX_OK;
 }
@@ -1358,6 +1365,7 @@ extern "C" int msx_profile_share_dev(msx_ctx *ctx, msx_profile *p, double **shar
 extern "C" int msx_profile_prop_apply_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_apply_enqueue before msx_profile_prop_begin");
+	msx_join(ctx);
 	if (p->iter_k >= 19) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing runs at most 19 iterations");
 	p->iter_k++;
 	msx_prop_apply_launch(ctx, p, p->iter_k, false);
@@ -1369,6 +1377,7 @@ extern "C" int msx_profile_prop_purged_enqueue(msx_ctx *ctx, msx_profile *p, uin
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun || (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL && !p->transposed_valid))
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_purged_enqueue before msx_profile_prop_begin");
+	msx_join(ctx);
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	msx_prop_purged_launch(ctx, p, p->purged_local);
 	if (purged_dev) *purged_dev = p->purged_local;
@@ -1380,6 +1389,7 @@ extern "C" int msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *p
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun || (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL && !p->transposed_valid))
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_purged before msx_profile_prop_begin");
+	msx_join(ctx);
 	MSX_HIP(ctx, hipMemsetAsync(p->purged_local, 0, 4, ctx->stream));
 	msx_prop_purged_launch(ctx, p, p->purged_local);
 	MSX_HIP(ctx, hipGetLastError());
@@ -1407,6 +1417,7 @@ extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p) {
 
 extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
+	msx_join(ctx);
 	int rc = msx_profile_allreduce_counts(ctx, p);           // ui, d, {inserts, uniq, multi} over all shards
 	if (rc) return rc;
 	if ((rc = msx_profile_prop_begin(ctx, p))) return rc;      // a = U = ui/2 (+d): identical on every rank
@@ -1428,6 +1439,7 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 extern "C" int msx_profile_fetch(msx_ctx *ctx, msx_profile *p, double *abundance_host, msx_profile_stats *stats) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_fetch before finalize/prop_begin");
+	msx_join(ctx);
 	uint32_t c[4];
 	int32_t it[2];
 	double dl[20];

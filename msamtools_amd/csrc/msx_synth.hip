@@ -105,6 +105,7 @@ static int dalloc(msx_ctx *ctx, T **p, size_t count) {
 
 extern "C" int msx_synth_device(msx_ctx *ctx, const msx_synth_params *sp, msx_batch *dev, msx_synth_sizes *sizes) {
 	if (!ctx || !dev) return MSX_ERR_ARG;
+	msx_join(ctx);
 	int rc = check_params(ctx, sp);
 	if (rc) return rc;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
