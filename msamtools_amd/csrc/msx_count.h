@@ -80,10 +80,9 @@ __device__ __forceinline__ void pool_visit(const CountArgs &A, PoolAcc &v, int32
 		else if (v.nd == 1) v.f1 = fid;
 		else if (v.nd == 2) v.f2 = fid;
 		else if (v.nd == 3) v.f3 = fid;
-		// the scratch list is only read for pools with two or more distinct features: the first
-		// feature is written when the second arrives (most pools never get there)
-		if (v.nd == 1) v.lst[0] = v.f0;
-		if (v.nd >= 1) v.lst[v.nd] = fid;
+		// the first four stay in registers until the pool is done (pool_finish writes them out, and only
+		// for a pool with two or more -- the scratch list of any other pool is never read)
+		if (v.nd >= 4) v.lst[v.nd] = fid;
 		v.nd++;
 	}
 }
@@ -105,7 +104,10 @@ __device__ __forceinline__ void pool_visit_masks(const CountArgs &A, PoolAcc &v,
 #pragma unroll
 	for (int q = 0; q < 8; q++) tv[q] = (idx[q] != 0xffffffffu) ? A.tid[s + idx[q]] : -1;
 #pragma unroll
-	for (int q = 0; q < 8; q++) pool_visit(A, v, tv[q]);
+	for (int q = 0; q < 8; q++) {
+		if (__ballot(idx[q] != 0xffffffffu) == 0ull) break;   // (wave-uniform) no lane has a q-th kept record
+		pool_visit(A, v, tv[q]);
+	}
 	// more than eight kept records: the rest one by one
 	while (rest1) { const uint32_t bpos = (uint32_t)__ffs((int)rest1) - 1u; rest1 &= rest1 - 1u; pool_visit(A, v, A.tid[s + bpos]); }
 	while (rest2) { const uint32_t bpos = (uint32_t)__ffs((int)rest2) - 1u; rest2 &= rest2 - 1u; pool_visit(A, v, A.tid[s + bpos]); }
@@ -119,6 +121,11 @@ struct BlockCounts {
 __device__ __forceinline__ void pool_finish(const CountArgs &A, int64_t g, const PoolAcc &v, int32_t *s_key,
                                             uint32_t *s_val, BlockCounts &c) {
 	uint32_t info = MSX_PINFO_NONE;
+	if (v.nd >= 2) {
+		v.lst[0] = v.f0; v.lst[1] = v.f1;
+		if (v.nd > 2) v.lst[2] = v.f2;
+		if (v.nd > 3) v.lst[3] = v.f3;
+	}
 	if (v.nvalid > 0) {
 		c.ins++;                                          // one insert per pool (:230,:237)
 		if (v.nd == 1) {                                  // :75-78, :87-91, :152-159
