@@ -1,8 +1,8 @@
-// msx_scan.hip -- exclusive prefix sum over u32 / u64 (2048 items per workgroup; one chained launch,
-// or reduce-then-scan with MSX_SCAN_CHAINED=0).  Used for the emit order of filter's output stream
+// msx_scan.hip -- exclusive prefix sum over u32 / u64 (reduce-then-scan, 2048
+// items per workgroup).  Used for the emit order of filter's output stream
 // (u32), the radix passes, and for compacting multi-mapper lists, where one u64
 // scan carries (list count << 32 | entry count) and reads the 4-byte per-pool
-// words directly.  HBM-bound: reads the input once (chained) or twice, writes once.
+// words directly.  HBM-bound: reads the input twice, writes once.
 #include "msx_internal.h"
 
 #define SCAN_ITEMS 8
@@ -159,117 +159,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_scan_apply(const void *in, T *out
 	if (!INCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m_ub] = c + tot;
 }
 
-// ---------------------------------------------------------------------------
-// One launch instead of three: the chained scan (decoupled look-back).  A workgroup draws its tile
-// number from a ticket -- so every tile before it is running or done -- scans its 2048 items in
-// registers, publishes its sum (flag A), adds up what the tiles before it have published until it
-// meets one that already knows its inclusive prefix (flag P), publishes its own, and writes.  Sum and
-// flag travel in ONE 8-byte word (62 + 2 bits; relaxed agent-scope loads and stores, which go past the
-// per-XCD L2s): no fence anywhere.  The input is read once instead of twice.
-// ---------------------------------------------------------------------------
-#define SC_A (1ull << 62)
-#define SC_P (2ull << 62)
-#define SC_VAL(x) ((x) & ((1ull << 62) - 1ull))
-
-// inclusive prefix through tile j, by one whole wave: windows of 64 tiles, nearest first
-__device__ __forceinline__ unsigned long long scan_lookback(const unsigned long long *state, int64_t j) {
-	const int lane = threadIdx.x & 63;
-	unsigned long long sum = 0;
-	for (int64_t hi = j;; hi -= 64) {
-		const int64_t idx = hi - lane;
-		unsigned long long v = SC_P;                       // before tile 0: an inclusive prefix of 0
-		do {
-			if (idx >= 0) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		} while (__ballot((v >> 62) == 0ull) != 0ull);
-		const unsigned long long pm = __ballot((v >> 62) == 2ull);
-		const int first = pm ? __ffsll((long long)pm) - 1 : 64;
-		unsigned long long c = (lane <= first) ? SC_VAL(v) : 0ull;
-#pragma unroll
-		for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-		sum += __shfl(c, 0, 64);
-		if (pm) break;
-	}
-	return sum;
-}
-
-template <typename T, bool INCL, bool PINFO>
-__global__ __launch_bounds__(MSX_BLOCK) void k_scan_chained(const void *in, T *out, int64_t m_ub, ScanLen L,
-                                                            unsigned long long *ws) {
-	__shared__ T s_w[4];
-	__shared__ unsigned long long s_bc[2];
-	unsigned long long *state = ws + 2;
-	if (threadIdx.x == 0) s_bc[0] = atomicAdd(ws, 1ull);
-	__syncthreads();
-	const int64_t tile = (int64_t)s_bc[0];
-	const int64_t m = scan_len(L, m_ub);
-	const int64_t n_data = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
-	const bool last = tile == (int64_t)gridDim.x - 1;
-	if (tile >= n_data) {
-		// nothing but zeros from here on: only the grand total is still owed (at the host's index)
-		if (!INCL && last && threadIdx.x < 64) {
-			const unsigned long long tot = n_data > 0 ? scan_lookback(state, n_data - 1) : 0ull;
-			if (threadIdx.x == 0) out[m_ub] = (T)tot;
-		}
-		return;
-	}
-	const int64_t base = tile * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-	T v[SCAN_ITEMS];
-	load8x<T, PINFO>(in, base, m, v);
-	T s = 0;
-#pragma unroll
-	for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
-	T tot;
-	const T ex = block_excl_scan<T>(s, s_w, &tot);
-	if (threadIdx.x == 0)
-		__hip_atomic_store(&state[tile], (tile == 0 ? SC_P : SC_A) | SC_VAL((unsigned long long)tot), __ATOMIC_RELAXED,
-		                   __HIP_MEMORY_SCOPE_AGENT);
-	if (threadIdx.x < 64) {
-		unsigned long long pre = 0;
-		if (tile > 0) {
-			pre = scan_lookback(state, tile - 1);
-			if (threadIdx.x == 0)
-				__hip_atomic_store(&state[tile], SC_P | SC_VAL(pre + (unsigned long long)tot), __ATOMIC_RELAXED,
-				                   __HIP_MEMORY_SCOPE_AGENT);
-		}
-		if (threadIdx.x == 0) s_bc[1] = pre;
-	}
-	__syncthreads();
-	const T c = (T)s_bc[1];
-	T run = c + ex;
-	T o[SCAN_ITEMS];
-#pragma unroll
-	for (int k = 0; k < SCAN_ITEMS; k++) {
-		if (INCL) { run += v[k]; o[k] = run; }
-		else { o[k] = run; run += v[k]; }
-	}
-	if (base + SCAN_ITEMS <= m) {
-		constexpr int PER = 16 / sizeof(T);
-		using V = typename std::conditional<sizeof(T) == 4, uint4, ulonglong2>::type;
-		V *q = reinterpret_cast<V *>(out + base);
-#pragma unroll
-		for (int j = 0; j < SCAN_ITEMS / PER; j++) {
-			V x;
-			T *e = reinterpret_cast<T *>(&x);
-#pragma unroll
-			for (int r = 0; r < PER; r++) e[r] = o[j * PER + r];
-			q[j] = x;
-		}
-	} else {
-#pragma unroll
-		for (int k = 0; k < SCAN_ITEMS; k++)
-			if (base + k < m) out[base + k] = o[k];
-	}
-	if (!INCL && last && threadIdx.x == 0) out[m_ub] = c + tot;
-}
-
-static bool scan_chained_on() {
-	static const bool on = [] {
-		const char *e = getenv("MSX_SCAN_CHAINED");
-		return !(e && atoi(e) == 0);
-	}();
-	return on;
-}
-
 template <typename T, bool INCL = false, bool PINFO = false>
 static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level, ScanLen L = ScanLen{nullptr, 1, 1}) {
 	int64_t nb = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -277,17 +166,6 @@ static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level, 
 	if (nb == 1) {
 		hipLaunchKernelGGL((k_scan_apply<T, INCL, PINFO>), dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m, L,
 		                   (const T *)nullptr);
-		return MSX_OK;
-	}
-	const bool chained = scan_chained_on();
-	// (the packed state holds 62 bits: the u64 sums carry a list count above bit 32, which stays below 2^30
-	// as long as the input is shorter than that)
-	if (chained && level == 0 && m < ((int64_t)1 << 30)) {
-		int rc = msx_reserve(ctx, &ctx->scan_l1, (size_t)(nb + 2) * 8);
-		if (rc) return rc;
-		MSX_HIP(ctx, hipMemsetAsync(ctx->scan_l1.p, 0, (size_t)(nb + 2) * 8, ctx->stream));
-		hipLaunchKernelGGL((k_scan_chained<T, INCL, PINFO>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, in, out, m,
-		                   L, (unsigned long long *)ctx->scan_l1.p);
 		return MSX_OK;
 	}
 	if (level > 2) return msx_fail(ctx, MSX_ERR_ARG, "scan: input too large");
@@ -307,7 +185,7 @@ static int scan_rec(msx_ctx *ctx, const void *in, T *out, int64_t m, int level, 
 
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
-	msx_time_bytes(ctx, 0, scan_chained_on() ? 8 : 12, m);   // read once (chained) or twice, written once
+	msx_time_bytes(ctx, 0, 12, m);                       // reduce pass reads, apply pass reads and writes
 	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
@@ -320,7 +198,7 @@ int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m) {
 int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m, const unsigned long long *n_ptr,
                      int64_t div, int64_t mul) {
 	msx_time_begin(ctx, MSX_K_SCAN);
-	msx_time_bytes(ctx, 0, scan_chained_on() ? 8 : 12, m, n_ptr, div, mul);
+	msx_time_bytes(ctx, 0, 12, m, n_ptr, div, mul);
 	int rc = scan_rec<uint32_t>(ctx, in, out, m, 0, ScanLen{n_ptr, div, mul});
 	msx_time_end(ctx);
 	if (rc) return rc;
@@ -331,7 +209,7 @@ int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m,
 // inclusive, in place (each workgroup reads its 2048 items into registers before writing them)
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
-	msx_time_bytes(ctx, 0, scan_chained_on() ? 8 : 12, m);
+	msx_time_bytes(ctx, 0, 12, m);
 	int rc = scan_rec<uint32_t, true>(ctx, data, data, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
@@ -341,7 +219,7 @@ int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
 
 int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m) {
 	msx_time_begin(ctx, MSX_K_SCAN);
-	msx_time_bytes(ctx, 0, scan_chained_on() ? 12 : 16, m);  // 4-byte words in (once or twice), 8-byte sums out
+	msx_time_bytes(ctx, 0, 16, m);                       // 4-byte words in (twice), 8-byte sums out
 	int rc = scan_rec<unsigned long long, false, true>(ctx, pinfo, (unsigned long long *)out, m, 0);
 	msx_time_end(ctx);
 	if (rc) return rc;
