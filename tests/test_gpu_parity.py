@@ -450,6 +450,44 @@ def test_streaming_one_call_filter_profile_equals_one_batch(ctx):
     whole.free()
 
 
+@pytest.mark.parametrize("multi", ["proportional", "equal"])
+def test_finalize_straight_after_the_fused_enqueue(ctx, multi):
+    """msx_filter_profile_enqueue leaves its side lanes (unique-insert counts, filter's output order) running;
+    msx_profile_finalize builds the sharing store beside them and joins before it needs the counts, and
+    msx_filter_finish -- called only afterwards here, as bench.py does -- still sees the whole output order.
+    Same numbers as the step-by-step sequence."""
+    import msamtools_amd as m
+    opts = dict(l=80, p=95, z=80, besthit=True)
+    batch = m.DeviceBatch.synth(ctx, 24680, 60000, 2000, 4)
+    ref_run = m.FilterRun(ctx, batch, **opts)
+    ref_run.enqueue()
+    ref_run.finish()
+    want = ref_run.result()
+    p1 = m.Profile(ctx, 2000, multi)
+    p1.accumulate(batch, ref_run.keep)
+    ui1 = p1.ui()
+    ab1, st1 = p1.finalize()
+    ab1 = ab1.copy()
+    for _ in range(3):                    # repeated: a later call must not trip over lanes an earlier one left behind
+        p2 = m.Profile(ctx, 2000, multi)
+        run = m.FilterRun(ctx, batch, **opts)
+        run.enqueue_with_profile(p2)
+        ab2, st2 = p2.finalize()          # no msx_filter_finish in between
+        run.finish()
+        got = run.result()
+        assert got.n_emit == want.n_emit
+        assert (got.keep == want.keep).all() and (got.emit == want.emit).all()
+        assert (p2.ui() == ui1).all()
+        assert (st1.insert_count, st1.uniq_mapper_count, st1.multi_mapper_count, st1.purged_insert_count, st1.iterations) == \
+            (st2.insert_count, st2.uniq_mapper_count, st2.multi_mapper_count, st2.purged_insert_count, st2.iterations)
+        assert np.allclose(ab1, ab2, rtol=1e-9, atol=0)
+        run.free()
+        p2.close()
+    p1.close()
+    ref_run.free()
+    batch.free()
+
+
 def test_ragged_inputs(ctx):
     """Very long CIGAR/MD payloads (beyond the LDS staging tile), a 5000-record pool,
     pools with > 4 distinct references."""
