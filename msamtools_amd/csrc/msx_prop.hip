@@ -618,7 +618,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(RecipArgs G, const 
 // runs a segmented sum over the slots, 64 per row, and adds each run to share[] once.
 #define PR_CHUNK 256                   // partials reduced by one wave (k_partial_reduce)
 #define SR_SENT 0xffffffffu
-#define SR_EPL 8                       // consecutive entries summed by one lane
+#define SR_EPL 4                       // consecutive entries summed by one lane
 #define SR_STEP (64 * SR_EPL)          // entries per wave step
 #define SR_WAVES_PER_SIMD 3            // 126 registers would allow 4; 3 measured faster (52 us against 55): ONE round of waves
 
@@ -687,70 +687,102 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	uint32_t prev_last = 0;
 	double slot_a = 0.0;          // partial of the chunk's first segment when it began in an earlier chunk
 	const unsigned long long below = (1ull << lane) - 1ull;
-	// entries of one step: SR_EPL consecutive ones per lane, and the key following the step
+	// Entries of one step: SR_EPL consecutive ones per lane, and the key following the step.  Every load below is
+	// unconditional (addresses clamped, results masked afterwards): with loads under branches the compiler
+	// cannot tell how many are in flight and waits for all of them -- vmcnt(0) -- before the first use, which
+	// undoes the pipeline.
 	auto load_step = [&](int64_t base, uint32_t *k, unsigned long long *lv, uint32_t &after) {
-		const int64_t r0 = base + (int64_t)lane * SR_EPL;
-		if (base + SR_STEP <= c1) {
-			const uint4 *kp = reinterpret_cast<const uint4 *>(t_key + r0);
-			const ulonglong2 *vp = reinterpret_cast<const ulonglong2 *>(t_val + r0);
-			// (non-temporal loads for these two streams, to keep a[] in the L2s, measured slower: 74 vs 58 us)
-			const uint4 ka = kp[0], kb = kp[1];
-			const ulonglong2 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
-			k[0] = ka.x; k[1] = ka.y; k[2] = ka.z; k[3] = ka.w; k[4] = kb.x; k[5] = kb.y; k[6] = kb.z; k[7] = kb.w;
-			lv[0] = v0.x; lv[1] = v0.y; lv[2] = v1.x; lv[3] = v1.y; lv[4] = v2.x; lv[5] = v2.y; lv[6] = v3.x; lv[7] = v3.y;
-		} else {
+		const int64_t r0 = base + (int64_t)lane * SR_EPL;            // (the buffers are padded by a step)
+		const uint4 *kp = reinterpret_cast<const uint4 *>(t_key + r0);
+		const ulonglong2 *vp = reinterpret_cast<const ulonglong2 *>(t_val + r0);
+		// (non-temporal loads for these two streams, to keep a[] in the L2s, measured slower: 74 vs 58 us)
 #pragma unroll
-			for (int i = 0; i < SR_EPL; i++) {
-				const bool ok = r0 + i < c1;
-				k[i] = ok ? t_key[r0 + i] : SR_SENT;        // entries past the end: a neutral last segment
-				lv[i] = ok ? t_val[r0 + i] : 0ull;
-			}
+		for (int q = 0; q < SR_EPL / 4; q++) {
+			const uint4 ka = kp[q];
+			k[4 * q] = ka.x; k[4 * q + 1] = ka.y; k[4 * q + 2] = ka.z; k[4 * q + 3] = ka.w;
 		}
-		after = SR_SENT;
-		if (lane == 63 && base + SR_STEP < E) after = t_key[base + SR_STEP] & fmask;
+#pragma unroll
+		for (int q = 0; q < SR_EPL / 2; q++) {
+			const ulonglong2 v = vp[q];
+			lv[2 * q] = v.x; lv[2 * q + 1] = v.y;
+		}
+		const int64_t nx = base + SR_STEP < E ? base + SR_STEP : E - 1;
+		after = t_key[nx];
 	};
-	// (keeping the entries of step i+1 in flight while step i gathers costs 24 registers: with the four
-	// operand arrays below that is the difference between 3 and 2 waves per SIMD)
+	// entries past the chunk's end: a neutral last segment
+	auto mask_step = [&](int64_t base, uint32_t *k, unsigned long long *lv, uint32_t &after) {
+		const int64_t r0 = base + (int64_t)lane * SR_EPL;
+#pragma unroll
+		for (int i = 0; i < SR_EPL; i++)
+			if (r0 + i >= c1) { k[i] = SR_SENT; lv[i] = 0ull; }
+		after = (lane == 63 && base + SR_STEP < E) ? (after & fmask) : SR_SENT;
+	};
+	// The operands of each entry's term w/S.  A list of <= 4 features travels with its entries (the other
+	// features in the value, weight above the feature id in the key): S is summed from a[] -- 8 MB that
+	// the caches hold well, unlike one 8-byte recip[] per list out of tens of MB.  General lists: recip[u].
+	// An operand that does not exist is fetched from a[0] and dropped when the sum is formed.
+	// (measured slower: fetching an index only when it differs from the previous entry's -- a lane's
+	// entries mostly share their feature -- 67 us against 55; a[] of the 512 features from the step's
+	// first one on staged in LDS, in-window gathers as ds_read_b64 -- 65 us against 53)
+	auto gather_step = [&](const uint32_t *k, const unsigned long long *lv, double *af, double *a1, double *a2, double *a3) {
+#pragma unroll
+		for (int i = 0; i < SR_EPL; i++) {
+			const bool live = k[i] != SR_SENT;
+			const bool general = live && (lv[i] & SIG_HASHED) != 0;
+			const bool exact = live && !general;
+			const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
+			               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
+			const double *src = general ? recip : a;
+			af[i] = src[general ? (uint32_t)lv[i] : (exact ? (k[i] & fmask) : 0u)];
+			a1[i] = a[(exact && o1 != SIG_PAD) ? o1 : 0u];
+			a2[i] = a[(exact && o2 != SIG_PAD) ? o2 : 0u];
+			a3[i] = a[(exact && o3 != SIG_PAD) ? o3 : 0u];
+		}
+	};
+	// A three-stage pipeline over the steps of the chunk: while step i is summed, the gathers of step i+1 and
+	// the entries of step i+2 are in flight -- the two round trips of a step (entries, then what they point
+	// at) were what the kernel waited for, with the vector ALUs busy 30 % of the time.
+	struct Ent { uint32_t k[SR_EPL]; unsigned long long lv[SR_EPL]; uint32_t after; };
+	struct Ops { double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL]; };
+	Ent e0, e1, e2;
+	Ops g0, g1;
+	const int64_t n_steps = (c1 - c0 + SR_STEP - 1) / SR_STEP;
+	const int64_t last_base = c0 + (n_steps - 1) * SR_STEP;
+	int64_t b1 = c0 + SR_STEP < last_base ? c0 + SR_STEP : last_base;     // the step e1 holds
+	load_step(c0, e0.k, e0.lv, e0.after);
+	load_step(b1, e1.k, e1.lv, e1.after);
+	mask_step(c0, e0.k, e0.lv, e0.after);
+	gather_step(e0.k, e0.lv, g0.af, g0.a1, g0.a2, g0.a3);
 	uint32_t before = 0;
 	if (lane == 0 && c0 > 0) before = t_key[c0 - 1] & fmask;
-	for (int64_t base = c0; base < c1; base += SR_STEP) {
-		uint32_t k[SR_EPL], after;
-		unsigned long long lv[SR_EPL];
-		load_step(base, k, lv, after);
-		// Each entry's term w/S.  A list of <= 4 features travels with its entries (the other
-		// features in the value, weight above the feature id in the key): S is summed here from a[] --
-		// 8 MB that the caches hold well, unlike one 8-byte recip[] per list out of tens of MB -- as
-		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders:
-		// their S can differ in the last bit, 1e-16 relative; ordering them costs a third of this
-		// kernel's instructions and buys nothing at the 1e-6 the profile is held to.)  General lists: recip[u].
+	for (int64_t step = 0; step < n_steps; step++) {
+		const int64_t base = c0 + step * SR_STEP;
+		// (beyond the chunk's last step the same step is fetched again and not used)
+		const int64_t b2 = base + 2 * SR_STEP < last_base ? base + 2 * SR_STEP : last_base;
+		load_step(b2, e2.k, e2.lv, e2.after);
+		mask_step(b1, e1.k, e1.lv, e1.after);
+		gather_step(e1.k, e1.lv, g1.af, g1.a1, g1.a2, g1.a3);
+		uint32_t k[SR_EPL];
+		const uint32_t after = e0.after;
+		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders: their S
+		// can differ in the last bit, 1e-16 relative; ordering them costs a third of this kernel's
+		// instructions and buys nothing at the 1e-6 the profile is held to.)
 		double x[SR_EPL];
-		{
-			// (measured slower: fetching an index only when it differs from the previous entry's -- a lane's 8
-			// entries mostly share their feature -- 67 us against 55; a[] of the 512 features from the step's
-			// first one on staged in LDS, in-window gathers as ds_read_b64 -- 65 us against 53)
-			double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL];
 #pragma unroll
-			for (int i = 0; i < SR_EPL; i++) {
-				const bool live = k[i] != SR_SENT;
-				const bool general = (lv[i] & SIG_HASHED) != 0;
-				const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
-				               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-				af[i] = !live ? 0.0 : general ? recip[(uint32_t)lv[i]] : a[k[i] & fmask];
-				a1[i] = (live && !general && o1 != SIG_PAD) ? a[o1] : 0.0;
-				a2[i] = (live && !general && o2 != SIG_PAD) ? a[o2] : 0.0;
-				a3[i] = (live && !general && o3 != SIG_PAD) ? a[o3] : 0.0;
-			}
-#pragma unroll
-			for (int i = 0; i < SR_EPL; i++) {
-				const bool live = k[i] != SR_SENT;
-				const bool general = (lv[i] & SIG_HASHED) != 0;
-				const uint32_t f = k[i] & fmask;
-				const double sum = ((a1[i] + a2[i]) + a3[i]) + af[i];     // absent ones are +0.0
-				const double w = (double)(bits < 32 ? (k[i] >> bits) : 0u);
-				x[i] = !live ? 0.0 : general ? af[i] : (sum > 0 ? w / sum : 0.0);
-				if (live) k[i] = f;                          // from here on: the feature id
-			}
+		for (int i = 0; i < SR_EPL; i++) {
+			const bool live = e0.k[i] != SR_SENT;
+			const bool general = (e0.lv[i] & SIG_HASHED) != 0;
+			const uint32_t o1 = (uint32_t)(e0.lv[i] & SIG_PAD), o2 = (uint32_t)((e0.lv[i] >> 21) & SIG_PAD),
+			               o3 = (uint32_t)((e0.lv[i] >> 42) & SIG_PAD);
+			const double v1 = o1 != SIG_PAD ? g0.a1[i] : 0.0, v2 = o2 != SIG_PAD ? g0.a2[i] : 0.0,
+			             v3 = o3 != SIG_PAD ? g0.a3[i] : 0.0;
+			const double sum = ((v1 + v2) + v3) + g0.af[i];                       // absent ones are +0.0
+			const double w = (double)(bits < 32 ? (e0.k[i] >> bits) : 0u);
+			x[i] = !live ? 0.0 : general ? g0.af[i] : (sum > 0 ? w / sum : 0.0);
+			k[i] = live ? (e0.k[i] & fmask) : e0.k[i];                            // from here on: the feature id
 		}
+		e0 = e1; e1 = e2; g0 = g1;
+		b1 = b2;
 
 		// ---- neighbours across lanes ----
 		uint32_t pk = __shfl_up(k[SR_EPL - 1], 1, 64);
@@ -1139,7 +1171,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	const int64_t lub = p->lists_ub > 0 ? p->lists_ub : 1;
 	int rc;
 	for (int i = 0; i < 2; i++) {
-		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64 + SR_STEP) * 4))) return rc;
 	}
 	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
 	{
@@ -1170,7 +1202,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if ((rc = msx_reserve(ctx, &p->eoff, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->hpos, (size_t)(lub + 8) * 4))) return rc;
 		for (int i = 0; i < 2; i++)
-			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64) * 8))) return rc;
+			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64 + SR_STEP) * 8))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_list_key, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
 		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits,
