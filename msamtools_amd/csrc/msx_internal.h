@@ -186,8 +186,6 @@ struct msx_profile {
 	msx_buf gl_idx;                   // u32 [general lists]: numbers of the lists k_general_recip handles
 	msx_buf recip;                    // f64 [n_lists]: w/S of the general lists
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
-	msx_buf seg_start, seg_end, hot_slot, hot_feat, a_hot, hot_hist;   // hot features of k_share_reduce (msx_prop.hip)
-	bool hot_on = false;
 	msx_buf ck_hist, ck_off;          // the same for msx_count_keys, which runs on a side lane while the store is being built
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
 	msx_buf runs, owned;              // runs of partial slots (feature, first slot, count) and the bitmap of the features that own one

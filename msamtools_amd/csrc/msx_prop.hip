@@ -562,105 +562,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_begin(int32_t nf, const uint
 // recip[j] = w_j/S_j for every general list j (S_j = sum of a over its features, w_j the number of
 // inserts it stands for; 0 when S_j == 0: msam_profile.c:358).  These are the lists of five and more
 // features (0.6 % of the lists on the IGC-scale workload), reached through gl_idx[]: one lane per list.
-// ---------------------------------------------------------------------------
-// Hot features.  What bounds k_share_reduce is the rate at which a CU's vector L1 looks up the cache
-// lines of scattered lanes (one per gathered a[other feature]), and the references of a metagenome are
-// anything but uniform: the SR_HOT features with the most entries receive most of those gathers (77 % on
-// the Zipf(1.1) community of the benchmark).  So, once per build: the features' degrees from the sorted
-// entries (segment bounds), a histogram of the degrees, the threshold that leaves at most SR_HOT features
-// above it, slots for those, and every "other feature" field of the entries that names one of them is
-// rewritten to SIG_HOT | slot (fields are 21 bits wide, feature ids at most 20: n_features <= 2^20, otherwise
-// none of this happens).  Per iteration a_hot[slot] = a[feature of slot] is refreshed next to recip[]
-// (k_prop_finish's other workgroups), every workgroup of k_share_reduce copies the 32 KB into LDS, and a
-// hot operand is one ds_read_b64 instead of a line lookup.
-// ---------------------------------------------------------------------------
-#define SR_HOT 4096
-#define SIG_HOT 0x100000u
-#define HOT_NONE 0xffffu
-#define HOT_BINS 1024
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_seg_bounds(const unsigned long long *__restrict__ d_tot,
-                                                          const uint32_t *__restrict__ t_key, int bits,
-                                                          uint32_t *__restrict__ seg_start, uint32_t *__restrict__ seg_end) {
-	const int64_t E = (int64_t)d_tot[1];
-	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < E; i += stride) {
-		const uint32_t f = t_key[i] & fmask;
-		if (i == 0 || (t_key[i - 1] & fmask) != f) seg_start[f] = (uint32_t)i;
-		if (i == E - 1 || (t_key[i + 1] & fmask) != f) seg_end[f] = (uint32_t)(i + 1);
-	}
-}
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_deg_hist(int32_t nf, const uint32_t *__restrict__ seg_start,
-                                                        const uint32_t *__restrict__ seg_end, uint32_t *__restrict__ hist) {
-	__shared__ uint32_t s_h[HOT_BINS];
-	for (int i = threadIdx.x; i < HOT_BINS; i += MSX_BLOCK) s_h[i] = 0;
-	__syncthreads();
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t f = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; f < nf; f += stride) {
-		const uint32_t d = seg_end[f] - seg_start[f];
-		if (d >= 2u) atomicAdd(&s_h[d < HOT_BINS ? d : HOT_BINS - 1], 1u);
-	}
-	__syncthreads();
-	for (int i = threadIdx.x; i < HOT_BINS; i += MSX_BLOCK)
-		if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-}
-
-// hist[HOT_BINS] <- the smallest degree T >= 2 with at most SR_HOT features of degree >= T; hist[HOT_BINS + 1] <- 0 (slot counter)
-__global__ void k_hot_threshold(uint32_t *hist) {
-	uint32_t cum = 0, T = HOT_BINS;
-	for (int d = HOT_BINS - 1; d >= 2; --d) {
-		if (cum + hist[d] > SR_HOT) break;
-		cum += hist[d];
-		T = (uint32_t)d;
-	}
-	hist[HOT_BINS] = T;
-	hist[HOT_BINS + 1] = 0;
-}
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_hot_assign(int32_t nf, const uint32_t *__restrict__ seg_start,
-                                                          const uint32_t *__restrict__ seg_end, uint32_t *hist,
-                                                          uint16_t *__restrict__ hot_slot, uint32_t *__restrict__ hot_feat) {
-	__shared__ uint32_t s_n, s_base;
-	const uint32_t T = hist[HOT_BINS];
-	const int64_t f = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	if (threadIdx.x == 0) s_n = 0;
-	__syncthreads();
-	const bool hot = f < nf && (seg_end[f] - seg_start[f]) >= T && T < HOT_BINS;
-	uint32_t my = 0;
-	if (hot) my = atomicAdd(&s_n, 1u);
-	__syncthreads();
-	if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&hist[HOT_BINS + 1], s_n);
-	__syncthreads();
-	uint16_t slot = HOT_NONE;
-	if (hot && s_base + my < SR_HOT) {
-		slot = (uint16_t)(s_base + my);
-		hot_feat[slot] = (uint32_t)f;
-	}
-	if (f < nf) hot_slot[f] = slot;
-}
-
-__global__ __launch_bounds__(MSX_BLOCK) void k_sig_hot(const unsigned long long *__restrict__ d_tot,
-                                                       unsigned long long *__restrict__ t_val,
-                                                       const uint16_t *__restrict__ hot_slot) {
-	const int64_t E = (int64_t)d_tot[1];
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < E; i += stride) {
-		unsigned long long sg = t_val[i];
-		if (sg & SIG_HASHED) continue;
-		uint32_t o[3] = {(uint32_t)(sg & SIG_PAD), (uint32_t)((sg >> 21) & SIG_PAD), (uint32_t)((sg >> 42) & SIG_PAD)};
-		uint16_t h[3];
-#pragma unroll
-		for (int q = 0; q < 3; q++) h[q] = o[q] != SIG_PAD ? hot_slot[o[q]] : (uint16_t)HOT_NONE;
-		bool any = false;
-#pragma unroll
-		for (int q = 0; q < 3; q++)
-			if (h[q] != HOT_NONE) { o[q] = SIG_HOT | h[q]; any = true; }
-		if (any) t_val[i] = (sg & ~((1ull << 63) - 1ull)) | o[0] | ((unsigned long long)o[1] << 21) | ((unsigned long long)o[2] << 42);
-	}
-}
-
 struct RecipArgs {
 	const unsigned long long *d_tot;
 	const uint32_t *m_off;
@@ -669,16 +570,9 @@ struct RecipArgs {
 	const uint32_t *gl_idx;
 	const double *a;
 	double *recip;
-	const uint32_t *hot_feat;     // null: no hot features
-	const uint32_t *hot_n;        // their number (device)
-	double *a_hot;
 };
 
 __device__ __forceinline__ void general_recip_body(const RecipArgs &G, int64_t first, int64_t stride) {
-	if (G.hot_feat) {                                            // a_hot[slot] for k_share_reduce's LDS copy
-		const uint32_t nh = *G.hot_n < SR_HOT ? *G.hot_n : SR_HOT;
-		for (int64_t sl = first; sl < (int64_t)nh; sl += stride) G.a_hot[sl] = G.a[G.hot_feat[sl]];
-	}
 	const int64_t n = (int64_t)G.d_tot[2];
 	for (int64_t i = first; i < n; i += stride) {
 		const uint32_t j = G.gl_idx[i];
@@ -768,18 +662,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
                                                             const double *__restrict__ a, int bits, int64_t W,
                                                             double *__restrict__ share,
                                                             double *__restrict__ part_val,
-                                                            const int32_t *__restrict__ iter_state,
-                                                            const double *__restrict__ a_hot,
-                                                            const uint32_t *__restrict__ hot_n) {
-	__shared__ double s_hot[SR_HOT];
+                                                            const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
-	if (a_hot) {                                                 // (kernel argument: uniform)
-		const uint32_t nh = *hot_n < SR_HOT ? *hot_n : SR_HOT;
-		for (uint32_t q = threadIdx.x * 2u; q < nh; q += MSX_BLOCK * 2u)
-			*reinterpret_cast<double2 *>(&s_hot[q]) = *reinterpret_cast<const double2 *>(&a_hot[q]);
-		__syncthreads();
-	}
-	const uint32_t hotbit = a_hot ? SIG_HOT : 0u;                // (without hot features a field is a feature id, whatever its bits)
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
 	// (consecutive workgroups -- which the dispatcher deals round-robin to the 8 XCDs -- take
@@ -836,8 +720,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	// The operands of each entry's term w/S.  A list of <= 4 features travels with its entries (the other
 	// features in the value, weight above the feature id in the key): S is summed from a[] -- 8 MB that
 	// the caches hold well, unlike one 8-byte recip[] per list out of tens of MB.  General lists: recip[u].
-	// An operand that does not exist, or that is a hot feature (SIG_HOT | slot: read from the LDS copy when the
-	// sum is formed), is fetched from a[0] and dropped.
+	// An operand that does not exist is fetched from a[0] and dropped when the sum is formed.
 	// (measured slower: fetching an index only when it differs from the previous entry's -- a lane's
 	// entries mostly share their feature -- 67 us against 55; a[] of the 512 features from the step's
 	// first one on staged in LDS, in-window gathers as ds_read_b64 -- 65 us against 53)
@@ -851,9 +734,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 			               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
 			const double *src = general ? recip : a;
 			af[i] = src[general ? (uint32_t)lv[i] : (exact ? (k[i] & fmask) : 0u)];
-			a1[i] = a[(exact && o1 != SIG_PAD && !(o1 & hotbit)) ? o1 : 0u];
-			a2[i] = a[(exact && o2 != SIG_PAD && !(o2 & hotbit)) ? o2 : 0u];
-			a3[i] = a[(exact && o3 != SIG_PAD && !(o3 & hotbit)) ? o3 : 0u];
+			a1[i] = a[(exact && o1 != SIG_PAD) ? o1 : 0u];
+			a2[i] = a[(exact && o2 != SIG_PAD) ? o2 : 0u];
+			a3[i] = a[(exact && o3 != SIG_PAD) ? o3 : 0u];
 		}
 	};
 	// A three-stage pipeline over the steps of the chunk: while step i is summed, the gathers of step i+1 and
@@ -891,10 +774,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 			const bool general = (e0.lv[i] & SIG_HASHED) != 0;
 			const uint32_t o1 = (uint32_t)(e0.lv[i] & SIG_PAD), o2 = (uint32_t)((e0.lv[i] >> 21) & SIG_PAD),
 			               o3 = (uint32_t)((e0.lv[i] >> 42) & SIG_PAD);
-			const double h1 = s_hot[o1 & (SR_HOT - 1)], h2 = s_hot[o2 & (SR_HOT - 1)], h3 = s_hot[o3 & (SR_HOT - 1)];
-			const double v1 = o1 == SIG_PAD ? 0.0 : (o1 & hotbit) ? h1 : g0.a1[i],
-			             v2 = o2 == SIG_PAD ? 0.0 : (o2 & hotbit) ? h2 : g0.a2[i],
-			             v3 = o3 == SIG_PAD ? 0.0 : (o3 & hotbit) ? h3 : g0.a3[i];
+			const double v1 = o1 != SIG_PAD ? g0.a1[i] : 0.0, v2 = o2 != SIG_PAD ? g0.a2[i] : 0.0,
+			             v3 = o3 != SIG_PAD ? g0.a3[i] : 0.0;
 			const double sum = ((v1 + v2) + v3) + g0.af[i];                       // absent ones are +0.0
 			const double w = (double)(bits < 32 ? (e0.k[i] >> bits) : 0u);
 			x[i] = !live ? 0.0 : general ? g0.af[i] : (sum > 0 ? w / sum : 0.0);
@@ -1366,40 +1247,6 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	                                       &cur)))
 		return rc;
 	p->sorted_buf = cur;
-	// (b') the hot features and their slots
-	{
-		static const bool hot_env = [] {
-			const char *e = getenv("MSX_SR_HOT");
-			return !(e && atoi(e) == 0);
-		}();
-		p->hot_on = hot_env && bits > 0 && bits <= 20;           // a 21-bit field has to hold a feature id or SIG_HOT | slot
-		if (p->hot_on) {
-			const int32_t nf = p->n_features;
-			if ((rc = msx_reserve(ctx, &p->seg_start, (size_t)(nf + 8) * 4))) return rc;
-			if ((rc = msx_reserve(ctx, &p->seg_end, (size_t)(nf + 8) * 4))) return rc;
-			if ((rc = msx_reserve(ctx, &p->hot_slot, (size_t)(nf + 8) * 2))) return rc;
-			if ((rc = msx_reserve(ctx, &p->hot_feat, (size_t)SR_HOT * 4))) return rc;
-			if ((rc = msx_reserve(ctx, &p->a_hot, (size_t)SR_HOT * 8))) return rc;
-			if ((rc = msx_reserve(ctx, &p->hot_hist, (size_t)(HOT_BINS + 8) * 4))) return rc;
-			MSX_HIP(ctx, hipMemsetAsync(p->seg_start.p, 0, (size_t)nf * 4, ctx->stream));
-			MSX_HIP(ctx, hipMemsetAsync(p->seg_end.p, 0, (size_t)nf * 4, ctx->stream));
-			MSX_HIP(ctx, hipMemsetAsync(p->hot_hist.p, 0, (size_t)(HOT_BINS + 8) * 4, ctx->stream));
-			msx_time_begin(ctx, MSX_K_LIST_ORDER);
-			hipLaunchKernelGGL(k_seg_bounds, dim3(msx_grid(ctx, eub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-			                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits,
-			                   (uint32_t *)p->seg_start.p, (uint32_t *)p->seg_end.p);
-			hipLaunchKernelGGL(k_deg_hist, dim3(msx_grid(ctx, nf, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
-			                   (const uint32_t *)p->seg_start.p, (const uint32_t *)p->seg_end.p, (uint32_t *)p->hot_hist.p);
-			hipLaunchKernelGGL(k_hot_threshold, dim3(1), dim3(1), 0, ctx->stream, (uint32_t *)p->hot_hist.p);
-			hipLaunchKernelGGL(k_hot_assign, dim3((unsigned)((nf + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-			                   nf, (const uint32_t *)p->seg_start.p, (const uint32_t *)p->seg_end.p, (uint32_t *)p->hot_hist.p,
-			                   (uint16_t *)p->hot_slot.p, (uint32_t *)p->hot_feat.p);
-			hipLaunchKernelGGL(k_sig_hot, dim3(msx_grid(ctx, eub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-			                   (const unsigned long long *)p->d_tot, (unsigned long long *)p->t_val64[cur].p,
-			                   (const uint16_t *)p->hot_slot.p);
-			msx_time_end(ctx);
-		}
-	}
 	// (c) keys of the partial slots, their runs, and the features that own one
 	{
 		const int64_t W = msx_share_waves(ctx);
@@ -1427,9 +1274,7 @@ static int recip_grid(msx_ctx *ctx, const msx_profile *p) {
 
 static RecipArgs recip_args(const msx_profile *p) {
 	return RecipArgs{(const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p, (const int32_t *)p->m_fid_alt.p,
-	                 (const uint32_t *)p->hpos.p, (const uint32_t *)p->gl_idx.p, (const double *)p->a, (double *)p->recip.p,
-	                 p->hot_on ? (const uint32_t *)p->hot_feat.p : nullptr,
-	                 p->hot_on ? (const uint32_t *)p->hot_hist.p + HOT_BINS + 1 : nullptr, (double *)p->a_hot.p};
+	                 (const uint32_t *)p->hpos.p, (const uint32_t *)p->gl_idx.p, (const double *)p->a, (double *)p->recip.p};
 }
 
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
@@ -1445,8 +1290,7 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
 	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
 	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
-	                             (const int32_t *)p->iter_state, p->hot_on ? (const double *)p->a_hot.p : nullptr,
-	                             p->hot_on ? (const uint32_t *)p->hot_hist.p + HOT_BINS + 1 : nullptr));
+	                             (const int32_t *)p->iter_state));
 	if (complete) {
 		const int64_t M = 2 * W;
 		const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
