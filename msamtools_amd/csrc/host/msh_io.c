@@ -989,6 +989,7 @@ void msh_close(msh_in *in) {
 struct msh_out {
 	FILE *fp;
 	int fd;              /* >= 0 (BAM output): written with write/writev, whole chunks of blocks per call */
+	int is_pipe;         /* fd is a FIFO: finished blocks are handed over by reference (vmsplice), see msh_write_many */
 	int mode;
 	const msh_hdr *hdr;
 	kstr line;
@@ -1047,6 +1048,11 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 #ifdef F_SETPIPE_SZ
 		(void)fcntl(o->fd, F_SETPIPE_SZ, 1 << 20);       /* a pipe into `msamtools profile -`: fewer, larger transfers */
 #endif
+		{
+			struct stat st;
+			const char *e = getenv("MSX_VMSPLICE");
+			o->is_pipe = fstat(o->fd, &st) == 0 && S_ISFIFO(st.st_mode) && !(e && atoi(e) == 0);
+		}
 	}
 	if (mode == MSH_OUT_BAM || mode == MSH_OUT_UBAM) {
 		kstr b = {0, 0, 0};
@@ -1221,13 +1227,24 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 				memcpy(o->ubuf + o->ulen, base + rec_off[i], sz);
 				o->ulen += (uint32_t)sz;
 			}
-			w.slots = (uint8_t *)malloc((size_t)(nb < WCHUNK_BLOCKS ? nb + 1 : WCHUNK_BLOCKS) * WSLOT);
+			/* Into a pipe the finished blocks are not copied but handed over by reference (vmsplice): the kernel
+			 * pins their pages for the reader.  Such pages must never be written again, so every chunk gets a
+			 * fresh anonymous mapping that is unmapped as soon as it has been handed over -- the pipe's
+			 * references keep the pages alive until they are read, whatever this process does meanwhile. */
+			const size_t slots_bytes = (size_t)(nb < WCHUNK_BLOCKS ? nb + 1 : WCHUNK_BLOCKS) * WSLOT;
+			if (!o->is_pipe) w.slots = (uint8_t *)malloc(slots_bytes);
 			w.slot_len = (uint32_t *)malloc(WCHUNK_BLOCKS * sizeof(uint32_t));
-			if (!w.slots || !w.slot_len) mDie("Out of memory");
+			if ((!o->is_pipe && !w.slots) || !w.slot_len) mDie("Out of memory");
 			for (done = 0; done < nb; done += w.nblk) {
 				size_t q;
+				const int spliced = o->is_pipe;
 				w.nblk = nb - done < WCHUNK_BLOCKS ? nb - done : WCHUNK_BLOCKS;
 				w.first = first + done;
+				if (!spliced && !w.slots && !(w.slots = (uint8_t *)malloc(slots_bytes))) mDie("Out of memory");
+				if (spliced) {
+					w.slots = (uint8_t *)mmap(NULL, slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+					if (w.slots == (uint8_t *)MAP_FAILED) mDie("Out of memory");
+				}
 				msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_worker, &w);
 				/* the chunk's blocks in order, up to IOV_MAX of them per system call */
 				for (q = 0; q < w.nblk;) {
@@ -1242,7 +1259,12 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 					}
 					v = 0;
 					while (want) {
-						got = writev(o->fd, iv + v, niv - v);
+						if (o->is_pipe) {
+							got = vmsplice(o->fd, iv + v, (unsigned long)(niv - v), 0);
+							if (got < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { o->is_pipe = 0; continue; }   /* not here: copy */
+						} else {
+							got = writev(o->fd, iv + v, niv - v);
+						}
 						if (got < 0 && errno == EINTR) continue;
 						if (got <= 0) mDie("Write failed");
 						want -= (size_t)got;
@@ -1250,6 +1272,7 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 						if (got > 0) { iv[v].iov_base = (uint8_t *)iv[v].iov_base + got; iv[v].iov_len -= (size_t)got; }
 					}
 				}
+				if (spliced) { munmap(w.slots, slots_bytes); w.slots = NULL; }
 			}
 			free(first); free(w.slots); free(w.slot_len);
 		}
