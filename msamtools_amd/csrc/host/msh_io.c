@@ -420,7 +420,9 @@ typedef struct {
 	FILE *fp;
 	const uint8_t *map;                  /* a regular file is mapped: blocks are inflated straight out of the page cache */
 	size_t map_len, map_pos;
-	uint8_t *cbuf;                       /* otherwise: BGZF_BATCH compressed blocks back to back */
+	uint8_t *cbuf;                       /* otherwise (a pipe): raw bytes read(2) straight into this buffer, blocks parsed in place */
+	size_t cbeg, cend, ccap;             /* unconsumed raw bytes of cbuf */
+	int fd, fd_eof;
 	const uint8_t *cptr[BGZF_BATCH];     /* where each raw block starts */
 	size_t coff[BGZF_BATCH + 1];
 	size_t uoff[BGZF_BATCH + 1];         /* where each block inflates to, relative to dst */
@@ -472,6 +474,11 @@ static size_t bgz_read_blocks(bgz_in *b) {
 	b->nblk = 0;
 	if (b->eof) return 0;
 	b->uoff[0] = 0;
+	if (!b->map && b->cbeg) {            /* (the blocks of the previous batch have been inflated by now) */
+		memmove(b->cbuf, b->cbuf + b->cbeg, b->cend - b->cbeg);
+		b->cend -= b->cbeg;
+		b->cbeg = 0;
+	}
 	while (b->nblk < BGZF_BATCH) {
 		uint32_t bsize, isize;
 		const uint8_t *blk;
@@ -498,32 +505,46 @@ static size_t bgz_read_blocks(bgz_in *b) {
 			blk = h;
 			b->map_pos += bsize;
 		} else {
-			uint8_t *h = b->cbuf + off;
-			size_t got = fread(h, 1, 18, b->fp);
-			if (got == 0) { b->eof = 1; break; }
-			if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
-				mDie("Input is not BGZF-compressed BAM (bad block header)");
-			{   /* locate the BC subfield (normally the only one) */
-				uint32_t xlen = le16(h + 10);
-				if (xlen == 6 && h[12] == 'B' && h[13] == 'C') {
-					bsize = le16(h + 16) + 1;
-				} else {
-					uint32_t p = 0;
-					int found = 0;
-					if (xlen > 6 && fread(h + 18, 1, xlen - 6, b->fp) != xlen - 6) mDie("Truncated BGZF block");
-					bsize = 0;
-					while (p + 4 <= xlen) {
-						uint32_t sl = le16(h + 12 + p + 2);
-						if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) { bsize = le16(h + 12 + p + 4) + 1; found = 1; }
-						p += 4 + sl;
+			/* whole blocks out of the raw buffer; more is read (as much as there is room for -- a pipe gives
+			 * up to its capacity per call) only when the next block is not complete yet */
+			int got_block = 0;
+			bsize = 0;
+			for (;;) {
+				const size_t have = b->cend - b->cbeg;
+				if (have >= 18) {
+					const uint8_t *h = b->cbuf + b->cbeg;
+					const uint32_t xlen = le16(h + 10);
+					if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
+						mDie("Input is not BGZF-compressed BAM (bad block header)");
+					if (have >= 12 + (size_t)xlen) {
+						uint32_t p = 0;
+						int found = 0;
+						while (p + 4 <= xlen) {
+							uint32_t sl = le16(h + 12 + p + 2);
+							if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) { bsize = le16(h + 12 + p + 4) + 1; found = 1; }
+							p += 4 + sl;
+						}
+						if (!found) mDie("BGZF block without BC subfield");
+						if (bsize < 12 + xlen + 8 || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
+						if (have >= bsize) { got_block = 1; break; }
 					}
-					if (!found) mDie("BGZF block without BC subfield");
-					got = 12 + xlen;
+				}
+				if (b->fd_eof) {
+					if (have == 0) { b->eof = 1; break; }
+					mDie(have < 18 ? "Input is not BGZF-compressed BAM (bad block header)" : "Truncated BGZF block");
+				}
+				if (b->cend == b->ccap) break;           /* no room: this batch ends here, the rest moves to the front next time */
+				{
+					ssize_t k = read(b->fd, b->cbuf + b->cend, b->ccap - b->cend);
+					if (k < 0 && errno == EINTR) continue;
+					if (k < 0) mDie("Read failed");
+					if (k == 0) b->fd_eof = 1;
+					b->cend += (size_t)k;
 				}
 			}
-			if (bsize < got + 8 || bsize > BGZF_MAX + 1024) mDie("Corrupt BGZF block size");
-			if (fread(h + got, 1, bsize - got, b->fp) != bsize - got) mDie("Truncated BGZF block");
-			blk = h;
+			if (!got_block) break;
+			blk = b->cbuf + b->cbeg;
+			b->cbeg += bsize;
 		}
 		isize = (uint32_t)le32(blk + bsize - 4);
 		if (isize > BGZF_MAX) mDie("Corrupt BGZF block (ISIZE %u)", isize);
@@ -865,11 +886,25 @@ msh_in *msh_open(const char *path) {
 	in->fp = strcmp(path, "-") == 0 ? stdin : fopen(path, "rb");
 	if (!in->fp) mDie("Cannot open %s for reading", path);
 	setvbuf(in->fp, NULL, _IOFBF, (size_t)4 << 20);
-	c0 = fgetc(in->fp);
-	c1 = c0 == EOF ? EOF : fgetc(in->fp);
-	if (c1 != EOF) ungetc(c1, in->fp);
-	if (c0 != EOF) ungetc(c0, in->fp);   /* two-byte pushback works on glibc full-buffered streams */
-	in->is_bam = (c0 == 0x1f && c1 == 0x8b);
+	{
+		/* The first two bytes tell BAM from SAM text.  They are read with read(2), before stdio has touched the
+		 * descriptor: a BAM stream from a pipe is then read without stdio (and its second copy) altogether. */
+		uint8_t two[2];
+		size_t n2 = 0;
+		while (n2 < 2) {
+			ssize_t k = read(fileno(in->fp), two + n2, 2 - n2);
+			if (k < 0 && errno == EINTR) continue;
+			if (k <= 0) break;
+			n2 += (size_t)k;
+		}
+		c0 = n2 > 0 ? two[0] : EOF;
+		c1 = n2 > 1 ? two[1] : EOF;
+		in->is_bam = (c0 == 0x1f && c1 == 0x8b);
+		if (!in->is_bam) {
+			if (c1 != EOF) ungetc(c1, in->fp);
+			if (c0 != EOF) ungetc(c0, in->fp);   /* two-byte pushback works on glibc full-buffered streams */
+		}
+	}
 	if (in->is_bam) {
 		const uint8_t *p;
 		int32_t l_text, n_ref, i;
@@ -888,8 +923,12 @@ msh_in *msh_open(const char *path) {
 			}
 		}
 		if (!in->bz.map) {
-			in->bz.cbuf = (uint8_t *)malloc((size_t)BGZF_BATCH * (BGZF_MAX + 1024));
+			in->bz.ccap = (size_t)BGZF_BATCH * (BGZF_MAX + 1024);
+			in->bz.cbuf = (uint8_t *)malloc(in->bz.ccap);
 			if (!in->bz.cbuf) mDie("Out of memory");
+			in->bz.fd = fileno(in->fp);
+			in->bz.cbuf[0] = 0x1f; in->bz.cbuf[1] = 0x8b;      /* the two bytes looked at above */
+			in->bz.cend = 2;
 #ifdef F_SETPIPE_SZ
 			(void)fcntl(fileno(in->fp), F_SETPIPE_SZ, 1 << 20);      /* a pipe from `msamtools filter -bu`: fewer, larger reads */
 #endif
