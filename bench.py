@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the command-line end-to-end timing (BAM file in, BAM + profile out)")
-    ap.add_argument("--e2e-groups", type=int, default=10_000_000, help="QNAME groups of the end-to-end BAM (~5 records each)")
+    ap.add_argument("--e2e-groups", type=int, default=20_000_000,
+                    help="QNAME groups of the end-to-end BAM (~5 records each; the default is the size of the c3 batch)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU step (msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator) "
                          "even with one rank")
