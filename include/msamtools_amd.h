@@ -148,7 +148,13 @@ void msx_ctx_destroy(msx_ctx *ctx);
 const char *msx_last_error(const msx_ctx *ctx);  /* ctx may be NULL: last create error */
 int  msx_abi_version(void);
 /* The HIP stream all work of this ctx is enqueued on (a hipStream_t), so the
- * caller can record events on it or make other streams wait for it. */
+ * caller can record events on it or make other streams wait for it.  One
+ * exception to "all work": msx_filter_profile_enqueue leaves two chains running
+ * on internal side streams (see there); every entry point of this library that
+ * takes the ctx joins them into this stream before it does anything else, so
+ * the exception is only visible to a caller that enqueues its own work on this
+ * stream right after msx_filter_profile_enqueue -- call msx_ctx_sync() or
+ * msx_filter_finish() first in that case. */
 void *msx_ctx_stream(msx_ctx *ctx);
 int  msx_ctx_sync(msx_ctx *ctx);
 
@@ -233,6 +239,10 @@ int  msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *dev,
 int  msx_filter_profile_enqueue(msx_ctx *ctx, const msx_batch *dev,
                                 const msx_filter_params *params, const msx_filter_out *out,
                                 msx_profile *p);
+/* (Returns with filter's output order -- out->emit_idx -- and the unique-insert
+ * counts still being computed on two side streams; they are joined by the next
+ * call on this ctx, whichever it is.  msx_profile_finalize_enqueue makes use of
+ * that: it builds the sharing store, which needs neither, before it joins.) */
 
 /* Device pointers to the accumulators, for a cross-GPU all-reduce(sum) by the
  * caller (RCCL): ui_insert_count u32[n_features], d_insert_count f64

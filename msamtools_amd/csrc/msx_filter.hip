@@ -4,7 +4,7 @@
 //                                                 (msam_filter.c:192-263)
 //   k_emit_*            the order in which the reference calls mSamWrite
 //                                                 (msam_filter.c:235-244, mBamVector.c:343-348)
-// All integer work, HBM-bound; no MFMA.  One wave64 lane per pool.
+// All integer work, HBM-bound; no MFMA.
 #include "msx_internal.h"
 #include "msx_count.h"
 #include "msx_md.h"
