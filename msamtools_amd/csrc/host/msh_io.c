@@ -415,14 +415,29 @@ void msh_parallel(int nth, msh_pf fn, void *arg) {
 /* ------------------------------------------------------------------------ */
 #define BGZF_MAX 65536
 #define BGZF_BATCH 1024
+#define RD_NBUF 3
+#define RD_HEAD (BGZF_MAX + 1024)    /* headroom in front of a ring buffer's data: the tail of the block its predecessor cut */
 
 typedef struct {
 	FILE *fp;
 	const uint8_t *map;                  /* a regular file is mapped: blocks are inflated straight out of the page cache */
 	size_t map_len, map_pos;
-	uint8_t *cbuf;                       /* otherwise (a pipe): raw bytes read(2) straight into this buffer, blocks parsed in place */
-	size_t cbeg, cend, ccap;             /* unconsumed raw bytes of cbuf */
-	int fd, fd_eof;
+	/* otherwise (a pipe): a thread of its own keeps draining the descriptor with read(2) into a ring of raw
+	 * buffers -- the writer at the other end never waits for this process to finish parsing a batch -- and
+	 * the blocks are parsed in place.  A block cut by a buffer's end is completed in the headroom in front of
+	 * the next buffer's data. */
+	uint8_t *cbuf;                       /* the buffer being parsed (one of rd_buf[]) */
+	size_t cbeg, cend, ccap;             /* unparsed raw bytes of cbuf; capacity of a ring buffer's data area */
+	int fd;
+	int cur;                             /* ring slot cbuf points into, -1: none */
+	uint8_t *rd_buf[RD_NBUF];
+	size_t rd_len[RD_NBUF];
+	int rd_full[RD_NBUF];
+	int rd_head, rd_eof, rd_wait, rd_started;
+	size_t rd_prefill;
+	pthread_t rd_thr;
+	pthread_mutex_t rd_mu;
+	pthread_cond_t rd_cv_full, rd_cv_free;
 	const uint8_t *cptr[BGZF_BATCH];     /* where each raw block starts */
 	size_t coff[BGZF_BATCH + 1];
 	size_t uoff[BGZF_BATCH + 1];         /* where each block inflates to, relative to dst */
@@ -468,17 +483,91 @@ static void inflate_worker(void *arg, int tid, int nth) {
 	for (i = tid; i < b->nblk; i += nth) inflate_block(b, i);
 }
 
+/* the draining thread: fills free ring buffers in order; a buffer is handed over when it is full, at end of
+ * input, or -- so that a slow producer does not hold a batch back -- as soon as the parser is waiting and
+ * there is a megabyte to give it */
+static void *bgz_reader_main(void *arg) {
+	bgz_in *b = (bgz_in *)arg;
+	int slot = 0;
+	for (;;) {
+		size_t n = 0;
+		int eof = 0;
+		pthread_mutex_lock(&b->rd_mu);
+		while (b->rd_full[slot]) pthread_cond_wait(&b->rd_cv_free, &b->rd_mu);
+		pthread_mutex_unlock(&b->rd_mu);
+		if (b->rd_prefill) {             /* the bytes msh_open looked at */
+			b->rd_buf[slot][RD_HEAD] = 0x1f; b->rd_buf[slot][RD_HEAD + 1] = 0x8b;
+			n = b->rd_prefill;
+			b->rd_prefill = 0;
+		}
+		while (n < b->ccap) {
+			ssize_t k = read(b->fd, b->rd_buf[slot] + RD_HEAD + n, b->ccap - n);
+			if (k < 0 && errno == EINTR) continue;
+			if (k < 0) mDie("Read failed");
+			if (k == 0) { eof = 1; break; }
+			n += (size_t)k;
+			if (n >= ((size_t)1 << 20) && b->rd_wait) break;
+		}
+		pthread_mutex_lock(&b->rd_mu);
+		b->rd_len[slot] = n;
+		b->rd_full[slot] = 1;
+		if (eof) b->rd_eof = 1;
+		pthread_cond_signal(&b->rd_cv_full);
+		pthread_mutex_unlock(&b->rd_mu);
+		if (eof) break;
+		slot = (slot + 1) % RD_NBUF;
+	}
+	return NULL;
+}
+
+/* The buffer being parsed is used up (what is left of it, less than a block, is carried over): give it back
+ * and take the next one.  Returns 0 at the end of the input, *left = the bytes that were carried to nowhere. */
+static int bgz_next_buffer(bgz_in *b, size_t *left_out) {
+	const size_t left = b->cur >= 0 ? b->cend - b->cbeg : 0;
+	uint8_t tail[RD_HEAD];
+	int slot;
+	if (!b->rd_started) {
+		int i;
+		for (i = 0; i < RD_NBUF; i++)
+			if (!(b->rd_buf[i] = (uint8_t *)malloc(RD_HEAD + b->ccap))) mDie("Out of memory");
+		pthread_mutex_init(&b->rd_mu, NULL);
+		pthread_cond_init(&b->rd_cv_full, NULL);
+		pthread_cond_init(&b->rd_cv_free, NULL);
+		if (pthread_create(&b->rd_thr, NULL, bgz_reader_main, b) != 0) mDie("Cannot start the reader thread");
+		b->rd_started = 1;
+	}
+	if (left) memcpy(tail, b->cbuf + b->cbeg, left);
+	*left_out = left;
+	pthread_mutex_lock(&b->rd_mu);
+	if (b->cur >= 0) {
+		b->rd_full[b->cur] = 0;
+		pthread_cond_signal(&b->rd_cv_free);
+		b->cur = -1;
+	}
+	slot = b->rd_head;
+	b->rd_wait = 1;
+	while (!b->rd_full[slot] && !b->rd_eof) pthread_cond_wait(&b->rd_cv_full, &b->rd_mu);   /* (the last buffer and rd_eof are set together) */
+	b->rd_wait = 0;
+	if (!b->rd_full[slot]) {             /* the reader has handed over its last buffer, and that one is behind us */
+		pthread_mutex_unlock(&b->rd_mu);
+		return 0;
+	}
+	pthread_mutex_unlock(&b->rd_mu);
+	b->rd_head = (slot + 1) % RD_NBUF;
+	b->cur = slot;
+	b->cbuf = b->rd_buf[slot];
+	b->cbeg = RD_HEAD - left;
+	b->cend = RD_HEAD + b->rd_len[slot];
+	if (left) memcpy(b->cbuf + b->cbeg, tail, left);
+	return 1;
+}
+
 /* read the next batch of raw blocks into cbuf; returns the number of bytes they inflate to (0 at EOF) */
 static size_t bgz_read_blocks(bgz_in *b) {
 	size_t off = 0, total = 0;
 	b->nblk = 0;
 	if (b->eof) return 0;
 	b->uoff[0] = 0;
-	if (!b->map && b->cbeg) {            /* (the blocks of the previous batch have been inflated by now) */
-		memmove(b->cbuf, b->cbuf + b->cbeg, b->cend - b->cbeg);
-		b->cend -= b->cbeg;
-		b->cbeg = 0;
-	}
 	while (b->nblk < BGZF_BATCH) {
 		uint32_t bsize, isize;
 		const uint8_t *blk;
@@ -505,12 +594,12 @@ static size_t bgz_read_blocks(bgz_in *b) {
 			blk = h;
 			b->map_pos += bsize;
 		} else {
-			/* whole blocks out of the raw buffer; more is read (as much as there is room for -- a pipe gives
-			 * up to its capacity per call) only when the next block is not complete yet */
+			/* whole blocks out of the raw buffer; when the next block is not complete in it, the batch ends here if
+			 * it has blocks (they point into this buffer, which therefore stays), otherwise the next buffer is taken */
 			int got_block = 0;
 			bsize = 0;
 			for (;;) {
-				const size_t have = b->cend - b->cbeg;
+				const size_t have = b->cur >= 0 ? b->cend - b->cbeg : 0;
 				if (have >= 18) {
 					const uint8_t *h = b->cbuf + b->cbeg;
 					const uint32_t xlen = le16(h + 10);
@@ -529,17 +618,13 @@ static size_t bgz_read_blocks(bgz_in *b) {
 						if (have >= bsize) { got_block = 1; break; }
 					}
 				}
-				if (b->fd_eof) {
-					if (have == 0) { b->eof = 1; break; }
-					mDie(have < 18 ? "Input is not BGZF-compressed BAM (bad block header)" : "Truncated BGZF block");
-				}
-				if (b->cend == b->ccap) break;           /* no room: this batch ends here, the rest moves to the front next time */
+				if (b->nblk > 0) break;
 				{
-					ssize_t k = read(b->fd, b->cbuf + b->cend, b->ccap - b->cend);
-					if (k < 0 && errno == EINTR) continue;
-					if (k < 0) mDie("Read failed");
-					if (k == 0) b->fd_eof = 1;
-					b->cend += (size_t)k;
+					size_t left = 0;
+					if (!bgz_next_buffer(b, &left)) {
+						if (left == 0) { b->eof = 1; break; }
+						mDie(left < 18 ? "Input is not BGZF-compressed BAM (bad block header)" : "Truncated BGZF block");
+					}
 				}
 			}
 			if (!got_block) break;
@@ -924,11 +1009,9 @@ msh_in *msh_open(const char *path) {
 		}
 		if (!in->bz.map) {
 			in->bz.ccap = (size_t)BGZF_BATCH * (BGZF_MAX + 1024);
-			in->bz.cbuf = (uint8_t *)malloc(in->bz.ccap);
-			if (!in->bz.cbuf) mDie("Out of memory");
 			in->bz.fd = fileno(in->fp);
-			in->bz.cbuf[0] = 0x1f; in->bz.cbuf[1] = 0x8b;      /* the two bytes looked at above */
-			in->bz.cend = 2;
+			in->bz.cur = -1;
+			in->bz.rd_prefill = 2;                              /* the two bytes looked at above */
 #ifdef F_SETPIPE_SZ
 			(void)fcntl(fileno(in->fp), F_SETPIPE_SZ, 1 << 20);      /* a pipe from `msamtools filter -bu`: fewer, larger reads */
 #endif
@@ -1014,7 +1097,11 @@ void msh_close(msh_in *in) {
 	free(in->hdr.target_name);
 	free(in->hdr.target_len);
 	free(in->hdr.text.s);
-	free(in->bz.cbuf);
+	if (in->bz.rd_started && in->bz.rd_eof) {           /* (a reader still waiting for input is left to the process's end) */
+		int i;
+		pthread_join(in->bz.rd_thr, NULL);
+		for (i = 0; i < RD_NBUF; i++) free(in->bz.rd_buf[i]);
+	}
 	if (in->bz.map) munmap((void *)in->bz.map, in->bz.map_len);
 	free(in->bz.span);
 	free(in->line);
