@@ -92,6 +92,7 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
 int msh_threads(void);                                 /* MSX_THREADS or the online CPU count, <= 64 */
 typedef void (*msh_pf)(void *arg, int tid, int nth);
 void msh_parallel(int nth, msh_pf fn, void *arg);      /* fn(arg, tid, nth) on nth threads */
+uint32_t msh_crc32(const void *p, size_t n);           /* CRC-32 of a BGZF payload (carry-less multiplication where the CPU has it) */
 
 /* ---- output ------------------------------------------------------------------ */
 enum { MSH_OUT_SAM = 0, MSH_OUT_SAM_HDR = 1, MSH_OUT_BAM = 2, MSH_OUT_UBAM = 3 };

@@ -410,6 +410,112 @@ void msh_parallel(int nth, msh_pf fn, void *arg) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* CRC-32 of a BGZF payload.  zlib's table-driven crc32 runs at about a          */
+/* gigabyte per second and core, and every byte that enters or leaves as BAM      */
+/* passes through it; with carry-less multiplication (the folding method of      */
+/* Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ") */
+/* the same value costs a tenth of that.  Constants for the reflected IEEE        */
+/* polynomial: x^(4*128+64), x^(4*128), x^(128+64), x^128, x^64 mod P, then P and  */
+/* the Barrett quotient.  Anything the fast path does not take (short buffers,   */
+/* the last bytes, other CPUs) goes to zlib.                                      */
+/* ------------------------------------------------------------------------ */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t crc32_fold(const uint8_t *buf, size_t len, uint32_t crc) {   /* len >= 64, a multiple of 16; crc pre-inverted */
+	const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596LL, 0x0154442bd4LL);
+	const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009eLL, 0x01751997d0LL);
+	const __m128i k5k0 = _mm_set_epi64x(0x0000000000LL, 0x0163cd6124LL);
+	const __m128i poly = _mm_set_epi64x(0x01f7011641LL, 0x01db710641LL);
+	__m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+	x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
+	x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+	x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
+	x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+	x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+	x0 = k1k2;
+	buf += 64;
+	len -= 64;
+	while (len >= 64) {                  /* four lanes of 128 bits, folded 512 bits ahead */
+		x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+		x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+		x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+		x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+		x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+		x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+		x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+		x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+		y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
+		y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+		y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
+		y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+		x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+		x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+		x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+		x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+		buf += 64;
+		len -= 64;
+	}
+	x0 = k3k4;                           /* the four lanes into one */
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+	x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+	x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+	x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+	x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+	x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+	x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+	while (len >= 16) {                  /* single 128-bit folds */
+		x2 = _mm_loadu_si128((const __m128i *)buf);
+		x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+		x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+		x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+		buf += 16;
+		len -= 16;
+	}
+	x2 = _mm_clmulepi64_si128(x1, x0, 0x10);     /* 128 -> 64 bits */
+	x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+	x1 = _mm_srli_si128(x1, 8);
+	x1 = _mm_xor_si128(x1, x2);
+	x0 = k5k0;
+	x2 = _mm_srli_si128(x1, 4);
+	x1 = _mm_and_si128(x1, x3);
+	x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+	x1 = _mm_xor_si128(x1, x2);
+	x0 = poly;                           /* Barrett reduction to 32 bits */
+	x2 = _mm_and_si128(x1, x3);
+	x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+	x2 = _mm_and_si128(x2, x3);
+	x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+	x1 = _mm_xor_si128(x1, x2);
+	return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+
+uint32_t msh_crc32(const void *p, size_t n) {
+	const uint8_t *s = (const uint8_t *)p;
+	uLong c = crc32(0L, NULL, 0);
+#if defined(__x86_64__)
+	static int fast = -1;
+	if (fast < 0) fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("MSX_NO_PCLMUL");
+	if (fast && n >= 64) {
+		const size_t m = n & ~(size_t)15;
+		c = (uLong)(~crc32_fold(s, m, ~(uint32_t)c) & 0xffffffffu);
+		s += m;
+		n -= m;
+	}
+#endif
+	while (n) {                          /* (zlib takes an unsigned int at a time) */
+		const size_t k = n > 0x40000000u ? 0x40000000u : n;
+		c = crc32(c, s, (uInt)k);
+		s += k;
+		n -= k;
+	}
+	return (uint32_t)c;
+}
+
+/* ------------------------------------------------------------------------ */
 /* BGZF reader: batches of raw blocks inflated in parallel into one           */
 /* contiguous "span" of BAM bytes                                             */
 /* ------------------------------------------------------------------------ */
@@ -473,7 +579,7 @@ static void inflate_block(bgz_in *b, int i) {
 	zs.next_out = out;
 	zs.avail_out = isize;
 	if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize) mDie("Corrupt BGZF block (inflate failed)");
-	if ((uint32_t)crc32(crc32(0L, NULL, 0), out, isize) != (uint32_t)le32(c + clen - 8))
+	if (msh_crc32(out, isize) != (uint32_t)le32(c + clen - 8))
 		mDie("Corrupt BGZF block (CRC mismatch)");
 }
 
@@ -1275,7 +1381,7 @@ static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int l
 	zs.avail_out = WSLOT - 18 - 8;
 	if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mDie("BGZF deflate failed");
 	clen = (uint32_t)zs.total_out;
-	bgzf_finish(out, clen, (uint32_t)crc32(crc32(0L, NULL, 0), in, n), n);
+	bgzf_finish(out, clen, msh_crc32(in, n), n);
 	return 18 + clen + 8;
 }
 
@@ -1297,7 +1403,7 @@ static void wbam_worker(void *arg, int tid, int nth) {
 		}
 		if (stored) {
 			slot[18] = 1; slot[19] = (uint8_t)n; slot[20] = (uint8_t)(n >> 8); slot[21] = (uint8_t)~n; slot[22] = (uint8_t)(~n >> 8);
-			bgzf_finish(slot, 5 + n, (uint32_t)crc32(crc32(0L, NULL, 0), dst, n), n);
+			bgzf_finish(slot, 5 + n, msh_crc32(dst, n), n);
 			w->slot_len[k] = 18 + 5 + n + 8;
 		} else {
 			w->slot_len[k] = bgzf_compress(slot, payload, n, w->o->level);
