@@ -92,6 +92,8 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
 int msh_threads(void);                                 /* MSX_THREADS or the online CPU count, <= 64 */
 typedef void (*msh_pf)(void *arg, int tid, int nth);
 void msh_parallel(int nth, msh_pf fn, void *arg);      /* fn(arg, tid, nth) on nth threads */
+/* raw DEFLATE of one BGZF block, whole input to whole output (msh_inflate.c); 0: not vouched for, give it to zlib */
+int msh_fast_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
 uint32_t msh_crc32(const void *p, size_t n);           /* CRC-32 of a BGZF payload (carry-less multiplication where the CPU has it) */
 
 /* ---- output ------------------------------------------------------------------ */

@@ -566,7 +566,12 @@ static void inflate_block(bgz_in *b, int i) {
 	 * block, and with a hundred threads those serialise inside the allocator */
 	static __thread z_stream zs;
 	static __thread int zs_ready = 0;
+	static int fast = -1;
 	if (isize == 0) return;
+	if (fast < 0) fast = !getenv("MSX_NO_FAST_INFLATE");
+	/* the decoder of msh_inflate.c first (twice zlib's speed on BAM records); whatever it does not vouch for,
+	 * and whatever fails the CRC afterwards, is decoded again by zlib, whose verdict stands */
+	if (fast && msh_fast_inflate(data, dlen, out, isize) && msh_crc32(out, isize) == (uint32_t)le32(c + clen - 8)) return;
 	if (!zs_ready) {
 		memset(&zs, 0, sizeof zs);
 		if (inflateInit2(&zs, -15) != Z_OK) mDie("zlib inflateInit2 failed");
