@@ -1227,6 +1227,12 @@ struct msh_out {
 	FILE *fp;
 	int fd;              /* >= 0 (BAM output): written with write/writev, whole chunks of blocks per call */
 	int is_pipe;         /* fd is a FIFO: finished blocks are handed over by reference (vmsplice), see msh_write_many */
+	/* finished chunks of blocks are written by a thread of their own, so that the next chunk is built meanwhile */
+	int wr_on, wr_n, wr_head, wr_busy, wr_quit;
+	struct wchunk *wr_q[2];
+	pthread_t wr_thr;
+	pthread_mutex_t wr_mu;
+	pthread_cond_t wr_cv_put, wr_cv_got;
 	int mode;
 	const msh_hdr *hdr;
 	kstr line;
@@ -1238,7 +1244,94 @@ struct msh_out {
 
 static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level);
 
+/* a chunk of finished BGZF blocks on its way out */
+struct wchunk {
+	uint8_t *slots;          /* nblk blocks, WSLOT apart */
+	size_t slots_bytes, nblk;
+	uint32_t *slot_len;
+	int mapped;              /* slots is an anonymous mapping of its own (vmsplice) rather than heap memory */
+};
+
+static void chunk_write(msh_out *o, struct wchunk *c) {
+	size_t q;
+	/* the chunk's blocks in order, up to 512 of them per system call */
+	for (q = 0; q < c->nblk;) {
+		struct iovec iv[512];
+		int niv = 0, v = 0;
+		size_t want = 0;
+		ssize_t got;
+		for (; q < c->nblk && niv < 512; q++, niv++) {
+			iv[niv].iov_base = c->slots + q * (BGZF_MAX + 1024);
+			iv[niv].iov_len = c->slot_len[q];
+			want += c->slot_len[q];
+		}
+		while (want) {
+			if (c->mapped && o->is_pipe) {
+				got = vmsplice(o->fd, iv + v, (unsigned long)(niv - v), 0);
+				if (got < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { o->is_pipe = 0; continue; }   /* not here: copy */
+			} else {
+				got = writev(o->fd, iv + v, niv - v);
+			}
+			if (got < 0 && errno == EINTR) continue;
+			if (got <= 0) mDie("Write failed");
+			want -= (size_t)got;
+			while (got > 0 && (size_t)got >= iv[v].iov_len) { got -= (ssize_t)iv[v].iov_len; v++; }
+			if (got > 0) { iv[v].iov_base = (uint8_t *)iv[v].iov_base + got; iv[v].iov_len -= (size_t)got; }
+		}
+	}
+	if (c->mapped) munmap(c->slots, c->slots_bytes); else free(c->slots);
+	free(c->slot_len);
+	free(c);
+}
+
+static void *writer_main(void *arg) {
+	msh_out *o = (msh_out *)arg;
+	pthread_mutex_lock(&o->wr_mu);
+	for (;;) {
+		struct wchunk *c;
+		while (o->wr_n == 0 && !o->wr_quit) pthread_cond_wait(&o->wr_cv_put, &o->wr_mu);
+		if (o->wr_n == 0) break;
+		c = o->wr_q[o->wr_head];
+		o->wr_head = (o->wr_head + 1) % 2;
+		o->wr_n--;
+		o->wr_busy = 1;
+		pthread_cond_broadcast(&o->wr_cv_got);
+		pthread_mutex_unlock(&o->wr_mu);
+		chunk_write(o, c);
+		pthread_mutex_lock(&o->wr_mu);
+		o->wr_busy = 0;
+		pthread_cond_broadcast(&o->wr_cv_got);
+	}
+	pthread_mutex_unlock(&o->wr_mu);
+	return NULL;
+}
+
+/* everything handed to the writer thread so far is in the descriptor */
+static void writer_drain(msh_out *o) {
+	if (!o->wr_on) return;
+	pthread_mutex_lock(&o->wr_mu);
+	while (o->wr_n > 0 || o->wr_busy) pthread_cond_wait(&o->wr_cv_got, &o->wr_mu);
+	pthread_mutex_unlock(&o->wr_mu);
+}
+
+static void writer_put(msh_out *o, struct wchunk *c) {
+	if (!o->wr_on) {
+		pthread_mutex_init(&o->wr_mu, NULL);
+		pthread_cond_init(&o->wr_cv_put, NULL);
+		pthread_cond_init(&o->wr_cv_got, NULL);
+		if (pthread_create(&o->wr_thr, NULL, writer_main, o) != 0) mDie("Cannot start the writer thread");
+		o->wr_on = 1;
+	}
+	pthread_mutex_lock(&o->wr_mu);
+	while (o->wr_n == 2) pthread_cond_wait(&o->wr_cv_got, &o->wr_mu);
+	o->wr_q[(o->wr_head + o->wr_n) % 2] = c;
+	o->wr_n++;
+	pthread_cond_signal(&o->wr_cv_put);
+	pthread_mutex_unlock(&o->wr_mu);
+}
+
 static void out_bytes(msh_out *o, const void *p, size_t n) {
+	writer_drain(o);                     /* (bytes written here follow whatever the writer thread still holds) */
 	if (o->fd >= 0) {
 		const uint8_t *s = (const uint8_t *)p;
 		while (n) {
@@ -1444,11 +1537,18 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 				}
 				return;
 			}
-		if (o->ulen) bgz_flush_block(o);
 		{
-			/* plan: whole records per block, greedily; the last, partly filled block stays in the writer's buffer */
+			/* plan: whole records per block, greedily; the last, partly filled block stays in the writer's buffer.
+			 * What the previous call left there becomes block 0 of this call's first chunk. */
 			size_t cap = 1024, nb = 0, cur = 0, done, *first = (size_t *)malloc((cap + 2) * sizeof(size_t));
+			uint8_t *carry = NULL;
+			uint32_t carry_len = 0;
 			if (!first) mDie("Out of memory");
+			if (o->ulen) {
+				if (!(carry = (uint8_t *)malloc(BGZF_MAX + 1024))) mDie("Out of memory");
+				carry_len = bgzf_compress(carry, o->ubuf, o->ulen, o->level);
+				o->ulen = 0;
+			}
 			first[0] = 0;
 			for (r = 0; r < n; r++) {
 				size_t sz = rec_off[(size_t)idx[r] + 1] - rec_off[(size_t)idx[r]];
@@ -1464,54 +1564,44 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 				memcpy(o->ubuf + o->ulen, base + rec_off[i], sz);
 				o->ulen += (uint32_t)sz;
 			}
-			/* Into a pipe the finished blocks are not copied but handed over by reference (vmsplice): the kernel
+			if (nb == 0 && carry) {              /* nothing but the carried block to write */
+				out_bytes(o, carry, carry_len);
+				free(carry);
+				carry = NULL;
+			}
+			/* Chunks of up to WCHUNK_BLOCKS blocks: built by all threads, then handed to the writer thread, which
+			 * writes them in order while the next chunk (of this call or the next) is built.
+			 * Into a pipe the finished blocks are not copied but handed over by reference (vmsplice): the kernel
 			 * pins their pages for the reader.  Such pages must never be written again, so every chunk gets a
 			 * fresh anonymous mapping that is unmapped as soon as it has been handed over -- the pipe's
 			 * references keep the pages alive until they are read, whatever this process does meanwhile. */
-			const size_t slots_bytes = (size_t)(nb < WCHUNK_BLOCKS ? nb + 1 : WCHUNK_BLOCKS) * WSLOT;
-			if (!o->is_pipe) w.slots = (uint8_t *)malloc(slots_bytes);
-			w.slot_len = (uint32_t *)malloc(WCHUNK_BLOCKS * sizeof(uint32_t));
-			if ((!o->is_pipe && !w.slots) || !w.slot_len) mDie("Out of memory");
-			for (done = 0; done < nb; done += w.nblk) {
-				size_t q;
-				const int spliced = o->is_pipe;
-				w.nblk = nb - done < WCHUNK_BLOCKS ? nb - done : WCHUNK_BLOCKS;
+			for (done = 0; done < nb;) {
+				struct wchunk *c = (struct wchunk *)calloc(1, sizeof(*c));
+				const size_t extra = carry ? 1 : 0;
+				size_t take = nb - done < WCHUNK_BLOCKS - extra ? nb - done : WCHUNK_BLOCKS - extra;
+				if (!c) mDie("Out of memory");
+				c->nblk = take + extra;
+				c->slots_bytes = c->nblk * WSLOT;
+				c->mapped = o->is_pipe;
+				c->slots = c->mapped ? (uint8_t *)mmap(NULL, c->slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)
+				                     : (uint8_t *)malloc(c->slots_bytes);
+				c->slot_len = (uint32_t *)malloc(c->nblk * sizeof(uint32_t));
+				if (!c->slots || c->slots == (uint8_t *)MAP_FAILED || !c->slot_len) mDie("Out of memory");
+				if (carry) {
+					memcpy(c->slots, carry, carry_len);
+					c->slot_len[0] = carry_len;
+					free(carry);
+					carry = NULL;
+				}
+				w.nblk = take;
 				w.first = first + done;
-				if (!spliced && !w.slots && !(w.slots = (uint8_t *)malloc(slots_bytes))) mDie("Out of memory");
-				if (spliced) {
-					w.slots = (uint8_t *)mmap(NULL, slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-					if (w.slots == (uint8_t *)MAP_FAILED) mDie("Out of memory");
-				}
+				w.slots = c->slots + extra * WSLOT;
+				w.slot_len = c->slot_len + extra;
 				msh_parallel(nth < (int)w.nblk ? nth : (int)w.nblk, wbam_worker, &w);
-				/* the chunk's blocks in order, up to IOV_MAX of them per system call */
-				for (q = 0; q < w.nblk;) {
-					struct iovec iv[512];
-					int niv = 0, v;
-					size_t want = 0;
-					ssize_t got;
-					for (; q < w.nblk && niv < 512; q++, niv++) {
-						iv[niv].iov_base = w.slots + q * WSLOT;
-						iv[niv].iov_len = w.slot_len[q];
-						want += w.slot_len[q];
-					}
-					v = 0;
-					while (want) {
-						if (o->is_pipe) {
-							got = vmsplice(o->fd, iv + v, (unsigned long)(niv - v), 0);
-							if (got < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { o->is_pipe = 0; continue; }   /* not here: copy */
-						} else {
-							got = writev(o->fd, iv + v, niv - v);
-						}
-						if (got < 0 && errno == EINTR) continue;
-						if (got <= 0) mDie("Write failed");
-						want -= (size_t)got;
-						while (got > 0 && (size_t)got >= iv[v].iov_len) { got -= (ssize_t)iv[v].iov_len; v++; }
-						if (got > 0) { iv[v].iov_base = (uint8_t *)iv[v].iov_base + got; iv[v].iov_len -= (size_t)got; }
-					}
-				}
-				if (spliced) { munmap(w.slots, slots_bytes); w.slots = NULL; }
+				writer_put(o, c);
+				done += take;
 			}
-			free(first); free(w.slots); free(w.slot_len);
+			free(first);
 		}
 	} else {
 		int t;
@@ -1534,6 +1624,14 @@ void msh_out_close(msh_out *o) {
 		                                      0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if (o->ulen) bgz_flush_block(o);
 		out_bytes(o, eof_block, 28);
+	}
+	if (o->wr_on) {
+		writer_drain(o);
+		pthread_mutex_lock(&o->wr_mu);
+		o->wr_quit = 1;
+		pthread_cond_signal(&o->wr_cv_put);
+		pthread_mutex_unlock(&o->wr_mu);
+		pthread_join(o->wr_thr, NULL);
 	}
 	fflush(o->fp);
 	free(o->ubuf);
