@@ -71,6 +71,7 @@ const uint8_t *msh_aux_get(const uint8_t *rec, size_t len, const char tag[2]);
 int64_t msh_aux2i(const uint8_t *type_ptr);
 /* size in bytes of the aux field starting at its type byte (type + payload) */
 size_t msh_aux_size(const uint8_t *type_ptr, const uint8_t *end);
+void msh_rec_check(const uint8_t *r, size_t len);       /* dies unless the fields the record announces fit its length */
 
 /* ---- input: BAM (BGZF, multi-threaded inflate) or SAM text, file or "-" ---- */
 typedef struct msh_in msh_in;

@@ -157,7 +157,7 @@ static void rb_mark_group(rbatch *b) {   /* a pool starts at the record about to
 /* one pass over the aux block for MD, NM, AS (first occurrence wins, as bam_aux_get) */
 static void rb_append(rbatch *b, const uint8_t *r, size_t len, int want_stats) {
 	size_t i = b->n;
-	uint32_t nc = REC_NCIGAR(r);
+	uint32_t nc = (msh_rec_check(r, len), REC_NCIGAR(r));
 	const uint8_t *p, *end = r + len, *md = NULL, *nm = NULL, *as = NULL;
 	rb_reserve(b);
 	{
@@ -430,6 +430,7 @@ static void pack_scan(void *arg, int tid, int nth) {
 		size_t len = b->rec_off[i + 1] - b->rec_off[i] - 4;
 		const uint8_t *p, *end = r + len, *md = NULL, *nm = NULL, *as = NULL;
 		uint8_t bd = 0;
+		msh_rec_check(r, len);
 		b->flag[i] = (uint16_t)REC_FLAG(r);
 		b->tid[i] = REC_TID(r);
 		b->pos[i] = REC_POS(r);

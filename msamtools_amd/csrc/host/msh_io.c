@@ -248,21 +248,38 @@ static size_t aux_type_size(int t) {
 	}
 }
 
+/* size of the aux field whose type byte is at t (type byte included); a field that does not end inside the
+ * record is fatal, like any other damage to a record */
 size_t msh_aux_size(const uint8_t *t, const uint8_t *end) {
 	int ty = *t;
 	size_t fs = aux_type_size(ty);
-	if (fs) return 1 + fs;
-	if (ty == 'Z' || ty == 'H') {
-		const uint8_t *z = memchr(t + 1, 0, (size_t)(end - t - 1));
-		return z ? (size_t)(z - t) + 1 : (size_t)(end - t);
+	if (fs) {
+		if ((size_t)(end - t) < 1 + fs) mDie("Corrupt aux field of type '%c' in BAM record", ty);
+		return 1 + fs;
 	}
-	if (ty == 'B') {
+	if (ty == 'Z' || ty == 'H') {
+		const uint8_t *z = (const uint8_t *)memchr(t + 1, 0, (size_t)(end - t - 1));
+		if (!z) mDie("Corrupt aux field of type '%c' in BAM record", ty);
+		return (size_t)(z - t) + 1;
+	}
+	if (ty == 'B' && end - t >= 6) {
 		size_t es = aux_type_size(t[1]);
 		uint32_t cnt = (uint32_t)le32(t + 2);
-		return 1 + 1 + 4 + es * cnt;
+		if (es && (size_t)(end - t - 6) / es >= cnt) return 1 + 1 + 4 + es * cnt;
 	}
 	mDie("Corrupt aux field of type '%c' in BAM record", ty);
 	return 0;
+}
+
+/* the fixed part of a BAM record and the variable-length fields it announces lie inside the record, and the
+ * read name is a string */
+void msh_rec_check(const uint8_t *r, size_t len) {
+	if (len >= 32) {
+		const size_t lq = REC_LQNAME(r), nc = REC_NCIGAR(r);
+		const int32_t ls = REC_LSEQ(r);
+		if (lq >= 1 && ls >= 0 && 32 + lq + 4 * nc + ((size_t)ls + 1) / 2 + (size_t)ls <= len && r[32 + lq - 1] == 0) return;
+	}
+	mDie("Corrupt BAM record (its fields do not fit its length)");
 }
 
 const uint8_t *msh_aux_get(const uint8_t *rec, size_t len, const char tag[2]) {
@@ -947,14 +964,14 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 }
 
 void msh_sam_format(const msh_hdr *h, const uint8_t *r, size_t len, kstr *o) {
-	int32_t tid = REC_TID(r), mtid = le32(r + 20);
+	int32_t tid = (msh_rec_check(r, len), REC_TID(r)), mtid = le32(r + 20);
 	uint32_t n_cigar = REC_NCIGAR(r), l_seq = (uint32_t)REC_LSEQ(r), k;
 	const uint8_t *cig = REC_CIGAR(r), *seq = cig + 4 * n_cigar, *qual = seq + (l_seq + 1) / 2;
 	const uint8_t *p = qual + l_seq, *end = r + len;
 	ks_puts(o, REC_QNAME(r));
 	ks_printf(o, "\t%u\t", REC_FLAG(r));
 	ks_puts(o, tid >= 0 && tid < h->n_targets ? h->target_name[tid] : "*");
-	ks_printf(o, "\t%d\t%u\t", REC_POS(r) + 1, REC_MAPQ(r));
+	ks_printf(o, "\t%lld\t%u\t", (long long)REC_POS(r) + 1, REC_MAPQ(r));
 	if (n_cigar == 0) ks_putc(o, '*');
 	for (k = 0; k < n_cigar; k++) {
 		uint32_t c = (uint32_t)le32(cig + 4 * k);
@@ -964,7 +981,7 @@ void msh_sam_format(const msh_hdr *h, const uint8_t *r, size_t len, kstr *o) {
 	if (mtid < 0) ks_putc(o, '*');
 	else if (mtid == tid) ks_putc(o, '=');
 	else ks_puts(o, mtid < h->n_targets ? h->target_name[mtid] : "*");
-	ks_printf(o, "\t%d\t%d\t", le32(r + 24) + 1, le32(r + 28));
+	ks_printf(o, "\t%lld\t%d\t", (long long)le32(r + 24) + 1, le32(r + 28));
 	if (l_seq == 0) ks_putc(o, '*');
 	else {
 		ks_reserve(o, l_seq);
@@ -980,6 +997,7 @@ void msh_sam_format(const msh_hdr *h, const uint8_t *r, size_t len, kstr *o) {
 	}
 	while (p + 3 <= end) {
 		int ty = p[2];
+		const size_t fsz = msh_aux_size(p + 2, end);       /* (checks that the field ends inside the record) */
 		ks_putc(o, '\t');
 		ks_put(o, p, 2);
 		switch (ty) {
@@ -1008,7 +1026,7 @@ void msh_sam_format(const msh_hdr *h, const uint8_t *r, size_t len, kstr *o) {
 		}
 		default: mDie("Corrupt aux field of type '%c' in BAM record", ty);
 		}
-		p += 2 + msh_aux_size(p + 2, end);
+		p += 2 + fsz;
 	}
 }
 
