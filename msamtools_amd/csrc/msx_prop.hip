@@ -103,22 +103,64 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
-// V: type of the value travelling with each key (uint32_t or unsigned long long); PAIRS = false: keys only
-template <typename V, bool PAIRS, bool SKIP>
+// Between the two: the per-tile digit counts become positions.  hist[] is laid out digit-major, so the
+// tiles of one digit are a contiguous row: k_rs_rowscan scans every row by itself (256 workgroups, none
+// waiting for another) and leaves the rows' totals in dtot[256]; the scatter kernel adds the exclusive
+// prefix over those 256 totals itself.  One launch where a scan over the whole table took three.
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_rowscan(const uint32_t *__restrict__ hist,
+                                                          const unsigned long long *__restrict__ n_ptr, int64_t n_tiles,
+                                                          uint32_t *__restrict__ off, uint32_t *__restrict__ dtot) {
+	__shared__ uint32_t s_w[MSX_BLOCK / 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (n_ptr) n_tiles = ((int64_t)*n_ptr + RS_TILE - 1) / RS_TILE;
+	const uint32_t *row = hist + (int64_t)blockIdx.x * n_tiles;
+	uint32_t *out = off + (int64_t)blockIdx.x * n_tiles;
+	uint32_t running = 0;
+	for (int64_t base = 0; base < n_tiles; base += MSX_BLOCK * 8) {
+		const int64_t i0 = base + (int64_t)threadIdx.x * 8;
+		uint32_t v[8], s = 0;
+#pragma unroll
+		for (int q = 0; q < 8; q++) { v[q] = i0 + q < n_tiles ? row[i0 + q] : 0u; s += v[q]; }
+		uint32_t inc = s;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		uint32_t woff = 0, tot = 0;
+		for (int q = 0; q < MSX_BLOCK / 64; q++) { if (q < w) woff += s_w[q]; tot += s_w[q]; }
+		uint32_t run = running + woff + inc - s;
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			if (i0 + q < n_tiles) out[i0 + q] = run;
+			run += v[q];
+		}
+		running += tot;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) dtot[blockIdx.x] = running;
+}
+
+// V: type of the value travelling with each key (uint32_t or unsigned long long); PAIRS = false: keys only;
+// ROWS: hoff holds row-wise scans (k_rs_rowscan) and dtot the rows' totals, instead of one scan over the table
+template <typename V, bool PAIRS, bool SKIP, bool ROWS = false>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
                                                           const V *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
                                                           V *__restrict__ vals_out,
                                                           const unsigned long long *__restrict__ n_ptr, int64_t n_host,
                                                           int shift, uint32_t dmask,
-                                                          const uint32_t *__restrict__ hoff, int64_t n_tiles) {
+                                                          const uint32_t *__restrict__ hoff, int64_t n_tiles,
+                                                          const uint32_t *__restrict__ dtot = nullptr) {
 	__shared__ uint32_t s_key[RS_TILE];
 	__shared__ V s_val[PAIRS ? RS_TILE : 1];
 	__shared__ uint32_t s_nvalid;
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];   // per wave: running digit counts, then the wave's offset
 	__shared__ uint32_t s_dstart[256];                // first position of the digit inside the sorted tile
 	__shared__ uint32_t s_gbase[256];                 // global position of the digit's run minus s_dstart
-	__shared__ uint32_t s_wsum[MSX_BLOCK / 64];
+	__shared__ uint32_t s_wsum[MSX_BLOCK / 64], s_gsum[MSX_BLOCK / 64];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t tile = blockIdx.x;
 	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
@@ -173,14 +215,24 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 			const uint32_t t = __shfl_up(inc, o, 64);
 			if (lane >= o) inc += t;
 		}
-		if (lane == 63) s_wsum[w] = inc;
+		// (ROWS: the same scan over the digits' global totals gives the position where each digit's run begins)
+		const uint32_t gt = ROWS ? dtot[d] : 0u;
+		uint32_t ginc = gt;
+		if (ROWS) {
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const uint32_t t = __shfl_up(ginc, o, 64);
+				if (lane >= o) ginc += t;
+			}
+		}
+		if (lane == 63) { s_wsum[w] = inc; if (ROWS) s_gsum[w] = ginc; }
 		s_cnt[0][d] = 0; s_cnt[1][d] = c0; s_cnt[2][d] = c0 + c1; s_cnt[3][d] = c0 + c1 + c2;
 		__syncthreads();
-		uint32_t woff = 0;
-		for (int q = 0; q < w; q++) woff += s_wsum[q];
+		uint32_t woff = 0, goff = 0;
+		for (int q = 0; q < w; q++) { woff += s_wsum[q]; if (ROWS) goff += s_gsum[q]; }
 		const uint32_t ds = woff + inc - tot;
 		s_dstart[d] = ds;
-		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] - ds;
+		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] + (ROWS ? goff + ginc - gt : 0u) - ds;
 		if (d == 255) s_nvalid = ds + tot;
 	}
 	__syncthreads();
@@ -1111,7 +1163,7 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 	const unsigned nblk = (unsigned)n_waves;
 	static_assert(sizeof(V) == 8, "the value buffers hold 8-byte values");
 	msx_buf *vbuf = p->t_val64;
-	int cur = vin_buf, rc;
+	int cur = vin_buf;
 	for (int ps = 0; ps < passes; ps++) {
 		const int dst = cur ^ 1;
 		const int left = bits - 8 * ps;
@@ -1121,14 +1173,17 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 		hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin, n_ptr,
 		                   (int64_t)0, ps * 8, dmask, (uint32_t *)p->rs_hist.p, n_waves);
 		msx_time_end(ctx);
-		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->rs_hist.p, (uint32_t *)p->rs_off.p, 256 * n_waves, n_ptr,
-		                           RS_TILE, 256)))
-			return rc;
+		uint32_t *const dtot = (uint32_t *)p->rs_off.p + 256 * n_waves + 16;
+		msx_time_begin(ctx, MSX_K_SCAN);
+		msx_time_bytes(ctx, 0, 8, 256 * n_waves, n_ptr, RS_TILE, 256);   // the table in and out
+		hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)p->rs_hist.p, n_ptr,
+		                   n_waves, (uint32_t *)p->rs_off.p, dtot);
+		msx_time_end(ctx);
 		msx_time_begin(ctx, MSX_K_RS_SCATTER);
 		msx_time_bytes(ctx, 0, 24, n_ub, n_ptr);          // key + 8-byte value in and out
-		hipLaunchKernelGGL((k_rs_scatter<V, true, false>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin,
+		hipLaunchKernelGGL((k_rs_scatter<V, true, false, true>), dim3(nblk), dim3(MSX_BLOCK), 0, ctx->stream, kin,
 		                   vin, (uint32_t *)p->t_key[dst].p, (V *)vbuf[dst].p, n_ptr, (int64_t)0, ps * 8,
-		                   dmask, (const uint32_t *)p->rs_off.p, n_waves);
+		                   dmask, (const uint32_t *)p->rs_off.p, n_waves, (const uint32_t *)dtot);
 		msx_time_end(ctx);
 		kin = (const uint32_t *)p->t_key[dst].p;
 		vin = (const V *)vbuf[dst].p;
@@ -1148,16 +1203,19 @@ int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shi
 	uint32_t *kk[2] = {k0, k1};
 	int cur = 0, rc;
 	if ((rc = msx_reserve(ctx, hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
-	if ((rc = msx_reserve(ctx, off, (size_t)(256 * n_tiles + 16) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, off, (size_t)(256 * n_tiles + 16 + 256) * 4))) return rc;
+	uint32_t *const dtot = (uint32_t *)off->p + 256 * n_tiles + 16;
 	for (int ps = 0; ps < passes; ps++) {
 		const int left = bits - 8 * ps;
 		const uint32_t dmask = left >= 8 ? 255u : ((1u << left) - 1u);
 		hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)kk[cur],
 		                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (uint32_t *)hist->p, n_tiles);
-		if ((rc = msx_scan_u32(ctx, (const uint32_t *)hist->p, (uint32_t *)off->p, 256 * n_tiles))) return rc;
-		hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, false>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
+		hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
+		                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, dtot);
+		hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)kk[cur], (const uint32_t *)nullptr, kk[cur ^ 1], (uint32_t *)nullptr,
-		                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (const uint32_t *)off->p, n_tiles);
+		                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (const uint32_t *)off->p, n_tiles,
+		                   (const uint32_t *)dtot);
 		cur ^= 1;
 	}
 	*sel = cur;
@@ -1183,7 +1241,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	}
 	const int64_t n_waves = ((eub > lub ? eub : lub) + RS_TILE - 1) / RS_TILE;
 	if ((rc = msx_reserve(ctx, &p->rs_hist, (size_t)(256 * n_waves + 16) * 4))) return rc;
-	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, &p->rs_off, (size_t)(256 * n_waves + 16 + 256) * 4))) return rc;   // (+ the rows' totals)
 	const unsigned long long *tot = p->csr_tot;
 	int bits = 0;
 	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)p->n_features) bits++;
