@@ -200,8 +200,8 @@ def algorithmic_bytes_per_step(name, w):
         # writes the kept ones, the count kernel reads those and updates ui once per feature
         return 8 * ng + 8 * w["uniq"] + 8 * nf
     if name == "k_multi_compact":
-        # on the lists as accumulated: per-pool word 4, scan value 8, group_off 4 ; scratch features in, CSR out
-        return 16 * ng + 4 * L0 + 8 * E0
+        # on the lists as accumulated: per-pool word 4, group_off 4 ; scratch features in, CSR out
+        return 8 * ng + 4 * L0 + 8 * E0
     if name == "k_list_order":
         # k_list_key (m_off, m_fid in; key 4 + signature 8 out), k_dup_mark (signatures in; head, length out),
         # k_uniq_gather (head, index, offset, signature in; CSR, entry key 4 + value 8, head position out),

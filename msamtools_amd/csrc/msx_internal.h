@@ -156,6 +156,9 @@ static inline int msx_grid(msx_ctx *ctx, int64_t items, int per_block) { return 
 int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
 // exclusive u64 scan of (1 << 32 | nd) over the pools whose word is MSX_PINFO_LIST | nd (msx_count.h), 0 for the others
 int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m);
+// the same scan's chunk sums only (exclusive, chunks of MSX_PINFO_CHUNK pools; base[n_chunks] = total); *base_out lives in the scan workspace
+#define MSX_PINFO_CHUNK 2048
+int msx_scan_pinfo_chunks(msx_ctx *ctx, const uint32_t *pinfo, int64_t m, const unsigned long long **base_out);
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m);
 // exclusive u32 scan whose data length is known on the device only: min(m, mul * ceil(*n_ptr / div)) items
 int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m, const unsigned long long *n_ptr,

@@ -59,30 +59,65 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	count_block_end(A, s_key, s_val, s_c, c);
 }
 
-// csr_tot = {n_lists, n_entries} running totals of the compact CSR
+// csr_tot = {n_lists, n_entries} running totals of the compact CSR.
+// One workgroup per chunk of MSX_PINFO_CHUNK pools, eight consecutive pools per thread: the positions of a
+// pool's list and of its entries are the chunk's base (msx_scan_pinfo_chunks) plus a scan inside the
+// workgroup of (1 << 32 | nd) over the pools that hold a list.
 __global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(int64_t n_groups, const uint32_t *__restrict__ group_off,
                                                              const uint32_t *__restrict__ pinfo,
-                                                             const unsigned long long *__restrict__ mscan,
+                                                             const unsigned long long *__restrict__ chunk_base,
                                                              const int32_t *__restrict__ tmp_fid,
                                                              const unsigned long long *__restrict__ csr_tot,
-                                                             uint32_t *__restrict__ m_off, int32_t *__restrict__ m_fid) {
+                                                             uint32_t *__restrict__ m_off, int32_t *__restrict__ m_fid, int wide) {
+	__shared__ unsigned long long s_w[MSX_BLOCK / 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t g0 = (int64_t)blockIdx.x * MSX_PINFO_CHUNK + (int64_t)threadIdx.x * 8;
+	uint32_t info[8], goff[8];
+	if (g0 + 8 <= n_groups && wide) {                      // (group_off is the caller's array: 16-byte loads only if it is aligned)
+		const uint4 a = *reinterpret_cast<const uint4 *>(pinfo + g0), b = *reinterpret_cast<const uint4 *>(pinfo + g0 + 4);
+		const uint4 c = *reinterpret_cast<const uint4 *>(group_off + g0), d = *reinterpret_cast<const uint4 *>(group_off + g0 + 4);
+		info[0] = a.x; info[1] = a.y; info[2] = a.z; info[3] = a.w; info[4] = b.x; info[5] = b.y; info[6] = b.z; info[7] = b.w;
+		goff[0] = c.x; goff[1] = c.y; goff[2] = c.z; goff[3] = c.w; goff[4] = d.x; goff[5] = d.y; goff[6] = d.z; goff[7] = d.w;
+	} else {
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			info[k] = g0 + k < n_groups ? pinfo[g0 + k] : MSX_PINFO_NONE;
+			goff[k] = g0 + k < n_groups ? group_off[g0 + k] : 0u;
+		}
+	}
+	unsigned long long v[8], sum = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		v[k] = ((info[k] & MSX_PINFO_LIST) && info[k] != MSX_PINFO_NONE) ? ((1ull << 32) | (info[k] & ~MSX_PINFO_LIST)) : 0ull;
+		sum += v[k];
+	}
+	unsigned long long inc = sum;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned long long t = __shfl_up(inc, o, 64);
+		if (lane >= o) inc += t;
+	}
+	if (lane == 63) s_w[w] = inc;
+	__syncthreads();
+	unsigned long long run = chunk_base[blockIdx.x] + inc - sum;
+	for (int q = 0; q < w; q++) run += s_w[q];
 	const unsigned long long base_l = csr_tot[0], base_e = csr_tot[1];
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < n_groups; g += stride) {
-		const uint32_t info = pinfo[g];
-		if (!(info & MSX_PINFO_LIST) || info == MSX_PINFO_NONE) continue;
-		const uint32_t nd = info & ~MSX_PINFO_LIST;
-		const unsigned long long sc = mscan[g];
-		const unsigned long long li = base_l + (sc >> 32), ei = base_e + (sc & 0xffffffffull);
-		m_off[li] = (uint32_t)ei;
-		const int32_t *src = tmp_fid + group_off[g];
-		for (uint32_t k = 0; k < nd; ++k) m_fid[ei + k] = src[k];
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		if (v[k]) {
+			const uint32_t nd = (uint32_t)v[k];
+			const unsigned long long li = base_l + (run >> 32), ei = base_e + (run & 0xffffffffull);
+			m_off[li] = (uint32_t)ei;
+			const int32_t *src = tmp_fid + goff[k];
+			for (uint32_t j = 0; j < nd; ++j) m_fid[ei + j] = src[j];
+		}
+		run += v[k];
 	}
 }
 
-__global__ void k_multi_advance(int64_t n_groups, const unsigned long long *__restrict__ mscan,
+__global__ void k_multi_advance(int64_t n_chunks, const unsigned long long *__restrict__ chunk_base,
                                 unsigned long long *csr_tot, uint32_t *m_off) {
-	const unsigned long long tot = mscan[n_groups];
+	const unsigned long long tot = chunk_base[n_chunks];
 	const unsigned long long nl = csr_tot[0] + (tot >> 32), ne = csr_tot[1] + (tot & 0xffffffffull);
 	csr_tot[0] = nl;
 	csr_tot[1] = ne;
@@ -200,7 +235,6 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	int rc;
 	if ((rc = msx_reserve(ctx, &ctx->tmp_fid, (size_t)n * 4))) return rc;
 	if (prop) {
-		if ((rc = msx_reserve(ctx, &ctx->moff, (size_t)(ng + 8) * 8))) return rc;
 		// the bounds grow by the whole batch (the host never waits for the true counts); once they near the
 		// 32-bit offsets of the store -- a file of billions of records, few of them multi-mapped -- they are
 		// folded back to what the device has really stored (one 16-byte read-back)
@@ -274,14 +308,16 @@ int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, b
 		if (rc) return rc;
 	}
 	if (prop) {
-		if ((rc = msx_scan_pinfo(ctx, (const uint32_t *)ctx->pinfo.p, (uint64_t *)ctx->moff.p, ng))) return rc;
+		const unsigned long long *chunk_base = nullptr;
+		const int64_t n_chunks = (ng + MSX_PINFO_CHUNK - 1) / MSX_PINFO_CHUNK;
+		if ((rc = msx_scan_pinfo_chunks(ctx, (const uint32_t *)ctx->pinfo.p, ng, &chunk_base))) return rc;
 		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);
-		hipLaunchKernelGGL(k_multi_compact, dim3(msx_grid(ctx, ng, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, ng,
-		                   b->group_off, (const uint32_t *)ctx->pinfo.p,
-		                   (const unsigned long long *)ctx->moff.p, (const int32_t *)ctx->tmp_fid.p,
-		                   (const unsigned long long *)p->csr_tot, (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p);
-		hipLaunchKernelGGL(k_multi_advance, dim3(1), dim3(1), 0, ctx->stream, ng,
-		                   (const unsigned long long *)ctx->moff.p, p->csr_tot, (uint32_t *)p->m_off.p);
+		hipLaunchKernelGGL(k_multi_compact, dim3((unsigned)n_chunks), dim3(MSX_BLOCK), 0, ctx->stream, ng,
+		                   b->group_off, (const uint32_t *)ctx->pinfo.p, chunk_base, (const int32_t *)ctx->tmp_fid.p,
+		                   (const unsigned long long *)p->csr_tot, (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p,
+		                   (int)(((uintptr_t)b->group_off & 15u) == 0));
+		hipLaunchKernelGGL(k_multi_advance, dim3(1), dim3(1), 0, ctx->stream, n_chunks, chunk_base, p->csr_tot,
+		                   (uint32_t *)p->m_off.p);
 		msx_time_end(ctx);
 	}
 	MSX_HIP(ctx, hipGetLastError());
