@@ -158,7 +158,8 @@ int msx_scan_u32(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m);
 int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m);
 // the same scan's chunk sums only (exclusive, chunks of MSX_PINFO_CHUNK pools; base[n_chunks] = total); *base_out lives in the scan workspace
 #define MSX_PINFO_CHUNK 2048
-int msx_scan_pinfo_chunks(msx_ctx *ctx, const uint32_t *pinfo, int64_t m, const unsigned long long **base_out);
+int msx_scan_pinfo_chunks(msx_ctx *ctx, const uint32_t *pinfo, int64_t m, const unsigned long long **base_out,
+                          const unsigned long long *n_ptr = nullptr);
 int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m);
 // exclusive u32 scan whose data length is known on the device only: min(m, mul * ceil(*n_ptr / div)) items
 int msx_scan_u32_len(msx_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t m, const unsigned long long *n_ptr,
@@ -192,8 +193,8 @@ struct msx_profile {
 	msx_buf ck_hist, ck_off;          // the same for msx_count_keys, which runs on a side lane while the store is being built
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
 	msx_buf runs, owned;              // runs of partial slots (feature, first slot, count) and the bitmap of the features that own one
-	msx_buf m_off_alt, m_fid_alt, len2;   // derived store: renumbered, duplicate lists merged
-	msx_buf head, uidx, eoff, hpos;       // dedupe scratch; hpos[u+1]-hpos[u] = weight of merged list u
+	msx_buf m_off_alt, m_fid_alt;         // derived store: renumbered, duplicate lists merged
+	msx_buf head, hpos;                   // dedupe scratch (head: one word per sorted list, msx_count.h's encoding); hpos[u+1]-hpos[u] = weight of merged list u
 	unsigned long long *d_tot = nullptr;  // device {lists, entries, general lists, short runs, long runs of partial slots} of the derived store
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
 	int key_bits = 0;                 // bits of the feature id in an entry key (the list weight sits above)

@@ -18,6 +18,7 @@
 // rounding (<= a few ulp, inside the 1e-6 relative bound of BASELINE.json).
 // Across ranks `share` is the vector to all-reduce (C1 in SURVEY.md section 2).
 #include "msx_internal.h"
+#include "msx_count.h"
 
 #include <cstdlib>
 
@@ -410,15 +411,16 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long
 	}
 }
 
-// head[i] = 1 when the list at sorted position i is not the same set as its predecessor;
-// len2[i] = its length for heads, 0 for merged duplicates (and beyond the last list).
+// hl[i] = MSX_PINFO_LIST | length when the list at sorted position i is not the same set as its predecessor
+// (a head), MSX_PINFO_NONE for a merged duplicate: the per-pool word of msx_count.h, so that the same
+// chunk-sum scan serves.
 // ssig = the signatures in sorted order (the values of the list sort): no gather is needed
 __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long *__restrict__ csr_tot, int64_t m,
                                                         const uint32_t *__restrict__ skey,
                                                         const unsigned long long *__restrict__ ssig,
                                                         const uint32_t *__restrict__ m_off,
                                                         const int32_t *__restrict__ m_fid,
-                                                        uint32_t *__restrict__ head, uint32_t *__restrict__ len2) {
+                                                        uint32_t *__restrict__ hl) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	const int lane = threadIdx.x & 63;
@@ -458,10 +460,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 				}
 			}
 		}
-		if (in) {
-			head[i] = hd;
-			len2[i] = hd ? l : 0u;
-		}
+		if (in) hl[i] = hd ? (MSX_PINFO_LIST | l) : MSX_PINFO_NONE;
 	}
 }
 
@@ -471,10 +470,12 @@ __device__ __forceinline__ unsigned long long pack_others(uint32_t o1, uint32_t 
 	return (unsigned long long)o1 | ((unsigned long long)o2 << 21) | ((unsigned long long)o3 << 42);
 }
 
+// One workgroup per chunk of MSX_PINFO_CHUNK sorted positions: the number u of a head and the offset o of its
+// entries are the chunk's base (msx_scan_pinfo_chunks over hl[]) plus a scan inside the workgroup; they go
+// through LDS so that the writing runs one list per lane, neighbours side by side.
 __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long long *__restrict__ csr_tot,
-                                                           const uint32_t *__restrict__ head,
-                                                           const uint32_t *__restrict__ uidx,
-                                                           const uint32_t *__restrict__ eoff,
+                                                           const uint32_t *__restrict__ hl,
+                                                           const unsigned long long *__restrict__ chunk_base, int64_t n_chunks,
                                                            const unsigned long long *__restrict__ ssig,
                                                            const uint32_t *__restrict__ m_off,
                                                            const int32_t *__restrict__ m_fid,
@@ -483,12 +484,53 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
                                                            unsigned long long *__restrict__ e_val,
                                                            uint32_t *__restrict__ hpos, int64_t m,
                                                            unsigned long long *__restrict__ d_tot) {
+	__shared__ unsigned long long s_w[MSX_BLOCK / 64];
+	__shared__ unsigned long long s_pos[MSX_PINFO_CHUNK];
 	const int64_t n_lists = (int64_t)csr_tot[0];
-	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < n_lists; i += stride) {
-		if (!head[i]) continue;
-		const uint32_t u = uidx[i];
-		uint32_t o = eoff[i];
+	const int64_t c0 = (int64_t)blockIdx.x * MSX_PINFO_CHUNK;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		const unsigned long long tot = chunk_base[n_chunks];
+		const uint32_t U = (uint32_t)(tot >> 32), E2 = (uint32_t)tot;
+		d_tot[0] = U;
+		d_tot[1] = E2;
+		d_tot[2] = 0;                  // general lists, counted by k_entry_weight
+		d_off[U] = E2;                 // CSR sentinel
+		hpos[U] = (uint32_t)n_lists;   // so that weight(u) = hpos[u+1] - hpos[u]
+	}
+	if (c0 >= n_lists) return;
+	{
+		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+		const int64_t i0 = c0 + (int64_t)threadIdx.x * 8;
+		unsigned long long v[8], sum = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const uint32_t x = i0 + k < n_lists ? hl[i0 + k] : MSX_PINFO_NONE;
+			v[k] = ((x & MSX_PINFO_LIST) && x != MSX_PINFO_NONE) ? ((1ull << 32) | (x & ~MSX_PINFO_LIST)) : 0ull;
+			sum += v[k];
+		}
+		unsigned long long inc = sum;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned long long t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		unsigned long long run = chunk_base[blockIdx.x] + inc - sum;
+		for (int q = 0; q < w; q++) run += s_w[q];
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			s_pos[threadIdx.x * 8 + k] = v[k] ? run : ~0ull;
+			run += v[k];
+		}
+		__syncthreads();
+	}
+	for (int r = 0; r < 8; r++) {
+		const int64_t i = c0 + r * MSX_BLOCK + threadIdx.x;
+		const unsigned long long sc = s_pos[r * MSX_BLOCK + threadIdx.x];
+		if (sc == ~0ull) continue;
+		const uint32_t u = (uint32_t)(sc >> 32);
+		uint32_t o = (uint32_t)sc;
 		const unsigned long long sg = ssig[i];
 		d_off[u] = o;
 		hpos[u] = (uint32_t)i;
@@ -534,14 +576,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 				}
 			}
 		}
-	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		const uint32_t U = uidx[m], E2 = eoff[m];
-		d_tot[0] = U;
-		d_tot[1] = E2;
-		d_tot[2] = 0;                  // general lists, counted by k_entry_weight
-		d_off[U] = E2;                 // CSR sentinel
-		hpos[U] = (uint32_t)n_lists;   // so that weight(u) = hpos[u+1] - hpos[u]
 	}
 }
 
@@ -1254,10 +1288,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if (hash_bits < 0) hash_bits = 0;
 		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap + 64))) return rc;
-		if ((rc = msx_reserve(ctx, &p->len2, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->head, (size_t)(lub + 8) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &p->uidx, (size_t)(lub + 8) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &p->eoff, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->hpos, (size_t)(lub + 8) * 4))) return rc;
 		for (int i = 0; i < 2; i++)
 			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64 + SR_STEP) * 8))) return rc;
@@ -1274,17 +1305,17 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_dup_mark, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
 		                             lub, skey, ssig, (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
-		                             (uint32_t *)p->head.p, (uint32_t *)p->len2.p));
-		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->head.p, (uint32_t *)p->uidx.p, lub, tot, 1, 1))) return rc;
-		if ((rc = msx_scan_u32_len(ctx, (const uint32_t *)p->len2.p, (uint32_t *)p->eoff.p, lub, tot, 1, 1))) return rc;
+		                             (uint32_t *)p->head.p));
+		const unsigned long long *chunk_base = nullptr;
+		const int64_t n_chunks = (lub + MSX_PINFO_CHUNK - 1) / MSX_PINFO_CHUNK;
+		if ((rc = msx_scan_pinfo_chunks(ctx, (const uint32_t *)p->head.p, lub, &chunk_base, tot))) return rc;
 		// the feature-major entries are written as the derived store is built, into the buffers the
 		// list sort is not holding its result in: key = feature, value = the list's signature or number
 		ebuf = sb ^ 1;
 		if ((rc = msx_reserve(ctx, &p->gl_idx, (size_t)(lub + 8) * 4))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
-		          hipLaunchKernelGGL(k_uniq_gather, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                             tot, (const uint32_t *)p->head.p, (const uint32_t *)p->uidx.p,
-		                             (const uint32_t *)p->eoff.p, ssig,
+		          hipLaunchKernelGGL(k_uniq_gather, dim3((unsigned)n_chunks), dim3(MSX_BLOCK), 0, ctx->stream,
+		                             tot, (const uint32_t *)p->head.p, chunk_base, n_chunks, ssig,
 		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p,
 		                             (uint32_t *)p->m_off_alt.p, (int32_t *)p->m_fid_alt.p,
 		                             (uint32_t *)p->t_key[ebuf].p, (unsigned long long *)p->t_val64[ebuf].p,

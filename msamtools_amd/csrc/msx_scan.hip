@@ -218,9 +218,11 @@ int msx_scan_inclusive_u32(msx_ctx *ctx, uint32_t *data, int64_t m) {
 }
 
 // The chunk sums of the same scan only: base[c] = (lists << 32 | entries) of the pools before chunk c, chunks of
-// MSX_PINFO_CHUNK pools, base[n_chunks] = the total.  The consumer (k_multi_compact) scans inside its chunk
-// itself -- the 8 bytes per pool of the full scan are neither written nor read.
-int msx_scan_pinfo_chunks(msx_ctx *ctx, const uint32_t *pinfo, int64_t m, const unsigned long long **base_out) {
+// MSX_PINFO_CHUNK pools, base[n_chunks] = the total.  The consumer (k_multi_compact, k_uniq_gather) scans inside
+// its chunk itself -- the 8 bytes per pool of the full scan are neither written nor read.  n_ptr: the words at
+// and beyond *n_ptr do not exist (device-side length), m is then the host's upper bound.
+int msx_scan_pinfo_chunks(msx_ctx *ctx, const uint32_t *pinfo, int64_t m, const unsigned long long **base_out,
+                          const unsigned long long *n_ptr) {
 	static_assert(MSX_PINFO_CHUNK == SCAN_CHUNK, "k_multi_compact's chunk is the scan's");
 	using T = unsigned long long;
 	int64_t nb = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -230,9 +232,9 @@ int msx_scan_pinfo_chunks(msx_ctx *ctx, const uint32_t *pinfo, int64_t m, const 
 	T *partial = (T *)ctx->scan_l1.p;
 	T *pscan = partial + ((nb + 3) & ~(int64_t)3);
 	msx_time_begin(ctx, MSX_K_SCAN);
-	msx_time_bytes(ctx, 0, 4, m);                        // 4-byte words in, 8 bytes per 2048 of them out
+	msx_time_bytes(ctx, 0, 4, m, n_ptr);                 // 4-byte words in, 8 bytes per 2048 of them out
 	hipLaunchKernelGGL((k_scan_reduce<T, true>), dim3((unsigned)nb), dim3(MSX_BLOCK), 0, ctx->stream, (const void *)pinfo, m,
-	                   ScanLen{nullptr, 1, 1}, partial);
+	                   ScanLen{n_ptr, 1, 1}, partial);
 	rc = scan_rec<T, false, false>(ctx, partial, pscan, nb, 1);
 	msx_time_end(ctx);
 	if (rc) return rc;
