@@ -182,7 +182,6 @@ struct msx_profile {
 	uint32_t *purged_local = nullptr; // device [1]
 	// multi-mapper store, list-major CSR (global->multi_mappers)
 	msx_buf m_off;                    // u32 [n_lists+1]
-	msx_buf m_key, m_sig;             // per list: sort key (u32) and signature (u64) for the merged-list store (msx_listkey.h)
 	msx_buf m_fid;                    // i32 [n_entries]
 	int64_t lists_ub = 0, entries_ub = 0;    // host upper bounds (capacity / grid sizing)
 	// feature-major view built once per finalize by a stable radix sort
@@ -210,12 +209,6 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p);            // feature-major vi
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete);   // share[f] = sum_j w_j/S_j over this rank's lists
 int msx_prop_apply_launch(msx_ctx *ctx, msx_profile *p, int k, bool fused);
 int64_t msx_share_waves(msx_ctx *ctx);
-// bits of a feature id
-static inline int msx_feature_bits(int32_t n_features) {
-	int bits = 0;
-	while (bits < 32 && ((int64_t)1 << bits) < (int64_t)n_features) bits++;
-	return bits;
-}
 int64_t msx_apply_blocks(int32_t nf);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);

@@ -9,7 +9,6 @@
 // reference's sequential order, as BASELINE.json allows).
 #include "msx_internal.h"
 #include "msx_count.h"
-#include "msx_listkey.h"
 
 #include <cstdlib>
 
@@ -69,9 +68,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(int64_t n_groups, c
                                                              const unsigned long long *__restrict__ chunk_base,
                                                              const int32_t *__restrict__ tmp_fid,
                                                              const unsigned long long *__restrict__ csr_tot,
-                                                             uint32_t *__restrict__ m_off, int32_t *__restrict__ m_fid,
-                                                             uint32_t *__restrict__ m_key, unsigned long long *__restrict__ m_sig,
-                                                             int hash_bits) {
+                                                             uint32_t *__restrict__ m_off, int32_t *__restrict__ m_fid) {
 	__shared__ unsigned long long s_w[MSX_BLOCK / 64];
 	__shared__ unsigned long long s_pos[MSX_PINFO_CHUNK];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -121,8 +118,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_multi_compact(int64_t n_groups, c
 			m_off[li] = (uint32_t)ei;
 			const int32_t *src = tmp_fid + group_off[g];
 			for (uint32_t j = 0; j < nd; ++j) m_fid[ei + j] = src[j];
-			// sort key and signature of the list for the merged-list store (msx_prop_build), while the list is at hand
-			list_key_sig(src, nd, (uint32_t)li, hash_bits, &m_key[li], &m_sig[li]);
 		}
 	}
 }
@@ -160,7 +155,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	if (ctx) msx_join(ctx);
 	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
-	                p->m_off.p, p->m_fid.p, p->m_key.p, p->m_sig.p, p->csr_tot, p->partial, p->purged_local,
+	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p, p->ck_hist.p, p->ck_off.p,
 	                p->recip.p, p->runs.p, p->owned.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p,
 	                p->head.p, p->hpos.p, p->d_tot,
@@ -261,8 +256,6 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 		p->entries_ub += n;
 		if (p->entries_ub > 0xffffff00LL) return msx_fail(ctx, MSX_ERR_ARG, "multi-mapper CSR exceeds 2^32 entries");
 		if ((rc = msx_grow_keep(ctx, &p->m_off, (size_t)(p->lists_ub + 2) * 4))) return rc;
-		if ((rc = msx_grow_keep(ctx, &p->m_key, (size_t)(p->lists_ub + 2) * 4))) return rc;
-		if ((rc = msx_grow_keep(ctx, &p->m_sig, (size_t)(p->lists_ub + 2) * 8))) return rc;
 		if ((rc = msx_grow_keep(ctx, &p->m_fid, (size_t)(p->entries_ub + 2) * 4))) return rc;
 		p->transposed_valid = false;
 	}
@@ -328,8 +321,7 @@ int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, b
 		msx_time_begin(ctx, MSX_K_MULTI_COMPACT);
 		hipLaunchKernelGGL(k_multi_compact, dim3((unsigned)n_chunks), dim3(MSX_BLOCK), 0, ctx->stream, ng,
 		                   b->group_off, (const uint32_t *)ctx->pinfo.p, chunk_base, (const int32_t *)ctx->tmp_fid.p,
-		                   (const unsigned long long *)p->csr_tot, (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p,
-		                   (uint32_t *)p->m_key.p, (unsigned long long *)p->m_sig.p, list_hash_bits(msx_feature_bits(p->n_features)));
+		                   (const unsigned long long *)p->csr_tot, (uint32_t *)p->m_off.p, (int32_t *)p->m_fid.p);
 		hipLaunchKernelGGL(k_multi_advance, dim3(1), dim3(1), 0, ctx->stream, n_chunks, chunk_base, p->csr_tot,
 		                   (uint32_t *)p->m_off.p);
 		msx_time_end(ctx);

@@ -19,7 +19,6 @@
 // Across ranks `share` is the vector to all-reduce (C1 in SURVEY.md section 2).
 #include "msx_internal.h"
 #include "msx_count.h"
-#include "msx_listkey.h"
 
 #include <cstdlib>
 
@@ -349,7 +348,68 @@ int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t 
 // locality order) and an order-independent hash of the set in the low bits, so
 // equal sets end up adjacent; adjacency is then verified exactly, set against
 // set.  The accumulated store (m_off/m_fid) is left untouched for later batches.
-// (key and signature of a list: msx_listkey.h; they are written with the list itself, by k_multi_compact)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+	x ^= x >> 16; x *= 0x7feb352du;
+	x ^= x >> 15; x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+
+// Signature of a list: sets of <= 3 features (the common case) are packed exactly --
+// three 21-bit fields in ascending order, unused fields = SIG_PAD -- so that equal
+// signatures mean equal sets and the set itself can be rebuilt from the signature;
+// anything else gets bit 63, a 31-bit hash of the set and, in the low half, the number of the
+// list (so that it can be found again after the sort), and is compared entry by entry.
+#define SIG_PAD 0x1fffffu
+#define SIG_HASHED (1ull << 63)
+
+__device__ __forceinline__ uint32_t sig_len(unsigned long long sg) {
+	return 1u + (((sg >> 21) & SIG_PAD) != SIG_PAD) + (((sg >> 42) & SIG_PAD) != SIG_PAD);
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long *__restrict__ csr_tot,
+                                                        const uint32_t *__restrict__ m_off,
+                                                        const int32_t *__restrict__ m_fid, int hash_bits,
+                                                        uint32_t *__restrict__ key,
+                                                        unsigned long long *__restrict__ sig) {
+	const int64_t n_lists = (int64_t)csr_tot[0];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
+		const uint32_t s = m_off[j], e = m_off[j + 1];
+		uint32_t mn = 0xffffffffu, h = (e - s) * 0x9e3779b9u, h2 = (e - s) * 0x85ebca6bu;
+		unsigned long long sg;
+		if (e - s <= 3u) {
+			// independent loads, then a 3-element sorting network
+			uint32_t f0 = SIG_PAD, f1 = SIG_PAD, f2 = SIG_PAD;
+			if (e - s > 0u) f0 = (uint32_t)m_fid[s];
+			if (e - s > 1u) f1 = (uint32_t)m_fid[s + 1];
+			if (e - s > 2u) f2 = (uint32_t)m_fid[s + 2];
+			const bool fits = (e - s > 0u) && f0 < SIG_PAD && (e - s < 2u || f1 < SIG_PAD) && (e - s < 3u || f2 < SIG_PAD);
+			if (e - s > 0u) { h += mix32(f0); h2 += mix32(f0 ^ 0x5bd1e995u); }
+			if (e - s > 1u) { h += mix32(f1); h2 += mix32(f1 ^ 0x5bd1e995u); }
+			if (e - s > 2u) { h += mix32(f2); h2 += mix32(f2 ^ 0x5bd1e995u); }
+			uint32_t a = f0, b = f1, c = f2, t;
+			if (a > b) { t = a; a = b; b = t; }
+			if (b > c) { t = b; b = c; c = t; }
+			if (a > b) { t = a; a = b; b = t; }
+			mn = a;
+			sg = fits ? ((unsigned long long)a | ((unsigned long long)b << 21) | ((unsigned long long)c << 42))
+			          : (SIG_HASHED | ((unsigned long long)(h2 >> 1) << 32) | (unsigned long long)(uint32_t)j);
+			if (e == s) mn = 0xffffffffu;
+		} else {
+			for (uint32_t k = s; k < e; ++k) {
+				const uint32_t f = (uint32_t)m_fid[k];
+				mn = f < mn ? f : mn;
+				h += mix32(f);                                   // commutative: a hash of the set
+				h2 += mix32(f ^ 0x5bd1e995u);
+			}
+			sg = SIG_HASHED | ((unsigned long long)(h2 >> 1) << 32) | (unsigned long long)(uint32_t)j;
+		}
+		const uint32_t hb = hash_bits > 0 ? (h & ((1u << hash_bits) - 1u)) : 0u;
+		key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
+		sig[j] = sg;                                          // travels through the sort as the value
+	}
+}
 
 // hl[i] = MSX_PINFO_LIST | length when the list at sorted position i is not the same set as its predecessor
 // (a head), MSX_PINFO_NONE for a merged duplicate: the per-pool word of msx_count.h, so that the same
@@ -1223,17 +1283,22 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	// (a) derived store: lists ordered by (smallest feature, set hash), identical sets merged
 	int ebuf = 1;
 	{
-		const int hash_bits = list_hash_bits(bits);
+		int hash_bits = 32 - bits;
+		if (hash_bits > 12) hash_bits = 12;
+		if (hash_bits < 0) hash_bits = 0;
 		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->head, (size_t)(lub + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->hpos, (size_t)(lub + 8) * 4))) return rc;
 		for (int i = 0; i < 2; i++)
 			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64 + SR_STEP) * 8))) return rc;
-		// (key and signature of every list were written with the list: the sort reads them where they lie)
-		int sb = 1;
-		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->m_key.p, (const unsigned long long *)p->m_sig.p, 1, tot + 0,
-		                           lub, bits + hash_bits, &sb)))
+		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
+		          hipLaunchKernelGGL(k_list_key, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
+		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits,
+		                             (uint32_t *)p->t_key[0].p, (unsigned long long *)p->t_val64[0].p));
+		int sb = 0;
+		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p,
+		                           (const unsigned long long *)p->t_val64[0].p, 0, tot + 0, lub, bits + hash_bits, &sb)))
 			return rc;
 		const uint32_t *skey = (const uint32_t *)p->t_key[sb].p;
 		const unsigned long long *ssig = (const unsigned long long *)p->t_val64[sb].p;
