@@ -18,6 +18,7 @@ try:
 except Exception as e:
     print("bench failed", e, open(sys.argv[1].replace(".json",".err")).read()[-1500:])
 PY
+sleep 5   # (right after the command-line runs of the default bench the device is still releasing their memory: c2 measured 25 % slower there)
 timeout 600 python bench.py --workload c2 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
