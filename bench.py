@@ -116,6 +116,7 @@ def e2e_cli(groups, refs):
         return d
 
     def run(cmd):
+        time.sleep(1.0)     # (the device is still releasing the previous process's memory right after it exits)
         t = time.perf_counter()
         r = subprocess.run(cmd, shell=True, env=env, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
         dt = time.perf_counter() - t
