@@ -1408,6 +1408,11 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 		size_t tl = strlen(hdr_text);
 		o->ubuf = (uint8_t *)malloc(BGZF_MAX);
 		o->level = mode == MSH_OUT_UBAM ? 0 : Z_DEFAULT_COMPRESSION;
+		if (mode == MSH_OUT_BAM) {           /* MSX_BGZF_LEVEL=1..9: trade file size for speed (-b is deflate-bound: level 6 by default, as htslib) */
+			const char *e = getenv("MSX_BGZF_LEVEL");
+			const int lv = e ? atoi(e) : 0;
+			if (lv >= 1 && lv <= 9) o->level = lv;
+		}
 		ks_put(&b, "BAM\1", 4);
 		put_le32(&b, (uint32_t)tl);
 		ks_put(&b, hdr_text, tl);
