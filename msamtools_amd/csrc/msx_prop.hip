@@ -975,12 +975,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 // (k_part_runs): the slots of one feature are neighbours (the keys ascend), a *run*; runs[] lists every
 // run as (feature, first slot, number of slots), and a bitmap marks the features that own one.
 #define PA_FPB 1024                    // features per streaming workgroup of k_prop_apply
-__device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, const uint32_t *chunk_beg, const uint32_t *t_key,
-                                                uint32_t fmask) {
+__device__ __forceinline__ uint32_t part_key_at(int64_t j, const uint32_t *chunk_beg, const uint32_t *t_key, uint32_t fmask) {
 	const int64_t c0 = chunk_beg[j >> 1], c1 = chunk_beg[(j >> 1) + 1];
-	// an empty chunk (its slots hold 0.0) takes the key of the entry it would begin with, so that the keys keep
-	// ascending; behind the last entry: the sentinel
-	if (c0 >= c1) return c0 < E ? (t_key[c0] & fmask) : SR_SENT;
+	if (c0 >= c1) return SR_SENT;         // idle wave
 	return t_key[(j & 1) ? c1 - 1 : c0] & fmask;
 }
 
@@ -988,11 +985,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long lo
                                                           const uint32_t *__restrict__ t_key, int bits, int64_t W,
                                                           const uint32_t *__restrict__ chunk_beg,
                                                           uint32_t *__restrict__ part_key, unsigned long long *d_tot) {
-	const int64_t E = (int64_t)csr_tot[1];
 	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < 2 * W; j += stride)
-		part_key[j] = part_key_at(j, E, chunk_beg, t_key, fmask);
+		part_key[j] = part_key_at(j, chunk_beg, t_key, fmask);
 	if (blockIdx.x == 0 && threadIdx.x == 0) { d_tot[3] = 0; d_tot[4] = 0; }   // short / long runs, counted by k_part_runs
 }
 
