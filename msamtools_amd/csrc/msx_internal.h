@@ -194,7 +194,6 @@ struct msx_profile {
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)
 	msx_buf runs, owned;              // runs of partial slots (feature, first slot, count) and the bitmap of the features that own one
 	msx_buf m_off_alt, m_fid_alt;         // derived store: renumbered, duplicate lists merged
-	msx_buf chunk_beg;                    // first entry of every k_share_reduce chunk (k_chunk_bounds)
 	msx_buf head, hpos;                   // dedupe scratch (head: one word per sorted list, msx_count.h's encoding); hpos[u+1]-hpos[u] = weight of merged list u
 	unsigned long long *d_tot = nullptr;  // device {lists, entries, general lists, short runs, long runs of partial slots} of the derived store
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs

@@ -158,7 +158,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p, p->ck_hist.p, p->ck_off.p,
 	                p->recip.p, p->runs.p, p->owned.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p,
-	                p->head.p, p->hpos.p, p->chunk_beg.p, p->d_tot,
+	                p->head.p, p->hpos.p, p->d_tot,
 	                p->t_val64[0].p, p->t_val64[1].p, p->gl_idx.p};
 	for (void *q : ptrs)
 		if (q) (void)hipFree(q);

@@ -735,35 +735,10 @@ __device__ __forceinline__ SegRow seg_row(uint32_t key, double v, bool valid, ui
 	return r;
 }
 
-// Where the chunks of the W waves begin (chunk_beg[0..W], whole steps).  Equal numbers of entries are not equal
-// work: a wave's time grows with the number of segments (features) it closes -- stores, scans that carry
-// nothing -- and the feature-sorted entries of a skewed community go from a few features with thousands of
-// entries each to thousands of features with a few (measured with wall_clock64 per wave on c3: 28 us for the
-// first quarter of the chunks, 42 for the last, the launch lasting as long as the slowest).  So the chunks are
-// cut at equal steps of  (1 - lambda) * entries passed / E  +  lambda * features passed / n_features,
-// which is monotone in the entry position: one binary search per boundary, once per build.
-#define SR_LAMBDA_DEFAULT 180          // per mille (MSX_SR_LAMBDA)
-__global__ __launch_bounds__(MSX_BLOCK) void k_chunk_bounds(const unsigned long long *__restrict__ d_tot,
-                                                            const uint32_t *__restrict__ t_key, int bits, int32_t nf, int64_t W,
-                                                            int lambda_pm, uint32_t *__restrict__ chunk_beg) {
-	const int64_t E = (int64_t)d_tot[1];
-	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
-	const int64_t w = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	if (w > W) return;
-	int64_t pos = E;
-	if (w < W && E > 0) {
-		// smallest i with cost(i) >= w / W, cost(i) = (1-l) i/E + l key[i]/nf  (compared in integers, scaled by 1000 E nf W)
-		const double target = (double)w / (double)W;
-		const double l = lambda_pm * 1e-3;
-		int64_t lo = 0, hi = E;
-		while (lo < hi) {
-			const int64_t mid = (lo + hi) >> 1;
-			const double c = (1.0 - l) * (double)mid / (double)E + l * (double)(t_key[mid] & fmask) / (double)(nf > 0 ? nf : 1);
-			if (c < target) lo = mid + 1; else hi = mid;
-		}
-		pos = lo / SR_STEP * SR_STEP;                          // (whole steps: 16-byte loads, and the pipeline's steps)
-	}
-	chunk_beg[w] = (uint32_t)pos;
+// entries per wave: the E entries in W equal chunks, rounded up to whole steps
+__device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
+	const int64_t per = (E + W - 1) / W;
+	return (per + SR_STEP - 1) / SR_STEP * SR_STEP;
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
@@ -773,8 +748,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
                                                             const double *__restrict__ a, int bits, int64_t W,
                                                             double *__restrict__ share,
                                                             double *__restrict__ part_val,
-                                                            const int32_t *__restrict__ iter_state,
-                                                            const uint32_t *__restrict__ chunk_beg) {
+                                                            const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
@@ -785,11 +759,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	// served to the others out of the Infinity Cache while they are there)
 	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
 	if (wave >= W) return;
-	const int64_t c0 = chunk_beg[wave], c1 = chunk_beg[wave + 1];
-	if (c0 >= c1) {   // idle wave: neutral slots
+	const int64_t per = sr_chunk(E, W);
+	const int64_t c0 = wave * per;
+	if (c0 >= E) {   // idle wave: neutral slots
 		if (lane < 2) part_val[2 * wave + lane] = 0.0;
 		return;
 	}
+	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
 	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	// the open segment carried from step to step (its sum so far, whether it began inside this chunk)
 	double carry = 0.0;
@@ -975,20 +951,23 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 // (k_part_runs): the slots of one feature are neighbours (the keys ascend), a *run*; runs[] lists every
 // run as (feature, first slot, number of slots), and a bitmap marks the features that own one.
 #define PA_FPB 1024                    // features per streaming workgroup of k_prop_apply
-__device__ __forceinline__ uint32_t part_key_at(int64_t j, const uint32_t *chunk_beg, const uint32_t *t_key, uint32_t fmask) {
-	const int64_t c0 = chunk_beg[j >> 1], c1 = chunk_beg[(j >> 1) + 1];
-	if (c0 >= c1) return SR_SENT;         // idle wave
-	return t_key[(j & 1) ? c1 - 1 : c0] & fmask;
+__device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t fmask) {
+	const int64_t c0 = (j >> 1) * per;
+	if (c0 >= E) return SR_SENT;          // idle wave
+	if (!(j & 1)) return t_key[c0] & fmask;
+	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
+	return t_key[c1 - 1] & fmask;
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long long *__restrict__ csr_tot,
                                                           const uint32_t *__restrict__ t_key, int bits, int64_t W,
-                                                          const uint32_t *__restrict__ chunk_beg,
                                                           uint32_t *__restrict__ part_key, unsigned long long *d_tot) {
+	const int64_t E = (int64_t)csr_tot[1];
+	const int64_t per = sr_chunk(E, W);
 	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < 2 * W; j += stride)
-		part_key[j] = part_key_at(j, chunk_beg, t_key, fmask);
+		part_key[j] = part_key_at(j, E, per, t_key, fmask);
 	if (blockIdx.x == 0 && threadIdx.x == 0) { d_tot[3] = 0; d_tot[4] = 0; }   // short / long runs, counted by k_part_runs
 }
 
@@ -1290,7 +1269,6 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	{
 		const int64_t W = msx_share_waves(ctx);
 		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * W + 8) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &p->chunk_beg, (size_t)(W + 8) * 4))) return rc;
 		if ((rc = msx_reserve(ctx, &p->part_val, (size_t)(2 * W + 8) * 8))) return rc;
 		if ((rc = msx_reserve(ctx, &p->runs, (size_t)(2 * W + 8) * sizeof(PartRun)))) return rc;
 		if ((rc = msx_reserve(ctx, &p->owned, (size_t)(p->n_features / 32 + 8) * 4))) return rc;
@@ -1363,17 +1341,9 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		const int64_t W = msx_share_waves(ctx);
 		MSX_HIP(ctx, hipMemsetAsync(p->owned.p, 0, (size_t)(p->n_features / 32 + 1) * 4, ctx->stream));
 		msx_time_begin(ctx, MSX_K_LIST_ORDER);
-		static const int lambda_pm = [] {
-			const char *e = getenv("MSX_SR_LAMBDA");           // experiments: weight of the features in a chunk's cost, per mille
-			const int v = e ? atoi(e) : -1;
-			return (v >= 0 && v <= 1000) ? v : SR_LAMBDA_DEFAULT;
-		}();
-		hipLaunchKernelGGL(k_chunk_bounds, dim3((unsigned)((W + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, p->n_features, W,
-		                   lambda_pm, (uint32_t *)p->chunk_beg.p);
 		hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, 2 * W, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W,
-		                   (const uint32_t *)p->chunk_beg.p, (uint32_t *)p->part_key.p, p->d_tot);
+		                   (uint32_t *)p->part_key.p, p->d_tot);
 		hipLaunchKernelGGL(k_part_runs, dim3((unsigned)((2 * W + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
 		msx_time_end(ctx);
@@ -1409,7 +1379,7 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
 	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
 	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
-	                             (const int32_t *)p->iter_state, (const uint32_t *)p->chunk_beg.p));
+	                             (const int32_t *)p->iter_state));
 	if (complete) {
 		const int64_t M = 2 * W;
 		const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
