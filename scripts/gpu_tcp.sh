@@ -6,13 +6,12 @@ OUT=gpurun_out/tcp
 rm -rf $OUT; mkdir -p $OUT
 ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e"
 i=0
-for set in "TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-           "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
-           "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_VOLATILE_sum" \
+# (counter sets with TA_*, TCP_GATE_EN*, TCP_*_STALL_CYCLES or TCP_TOTAL_* made rocprofv3 sit until the timeout on
+#  this pool -- 5 GPU-minutes each: only sets seen to work are listed)
+for set in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_VOLATILE_sum" \
            "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/s$i -- python3 $ARGS > $OUT/s$i.log 2>&1
+  timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/s$i -- python3 $ARGS > $OUT/s$i.log 2>&1
 done
 python3 - "$K" <<'PY'
 import csv, glob, collections, json, sys
