@@ -871,8 +871,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		for (int i = 0; i < SR_EPL; i++) {
 			const bool live = e0.k[i] != SR_SENT;
 			const bool general = (e0.lv[i] & SIG_HASHED) != 0;
-			const uint32_t o1 = (uint32_t)(e0.lv[i] & SIG_PAD), o2 = (uint32_t)((e0.lv[i] >> 21) & SIG_PAD),
-			               o3 = (uint32_t)((e0.lv[i] >> 42) & SIG_PAD);
 			const double sum = ((g0.a1[i] + g0.a2[i]) + g0.a3[i]) + g0.af[i];     // absent ones came back as +0.0
 			const double w = (double)(bits < 32 ? (e0.k[i] >> bits) : 0u);
 			x[i] = !live ? 0.0 : general ? g0.ag[i] : (sum > 0 ? w / sum : 0.0);
@@ -1378,6 +1376,8 @@ static RecipArgs recip_args(const msx_profile *p) {
 }
 
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
+	if ((size_t)p->n_features * 8 > 0xfffffff0u)                 // (the gathers of k_share_reduce address a[] with 32-bit byte offsets)
+		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing: too many features (%d)", p->n_features);
 	const int64_t W = msx_share_waves(ctx);
 	if (!p->recip_valid) {
 		MSX_TIMED(ctx, MSX_K_GENERAL_RECIP,
@@ -1467,7 +1467,10 @@ extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc
 	msx_join(ctx);
 	if (p->share_type != MSX_MULTI_SHARE_PROPORTIONAL)
 		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
-	msx_prop_iteration(ctx, p, true);         // share[] complete: the caller all-reduces it
+	{
+		const int rc = msx_prop_iteration(ctx, p, true);         // share[] complete: the caller all-reduces it
+		if (rc) return rc;
+	}
 	if (inc) *inc = p->share;
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
@@ -1539,7 +1542,7 @@ extern "C" int msx_profile_finalize_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (rc) return rc;
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331; converged iterations exit at once
-			msx_prop_iteration(ctx, p, false);
+			if ((rc = msx_prop_iteration(ctx, p, false))) return rc;
 			msx_prop_apply_launch(ctx, p, k, true);
 		}
 		msx_prop_purged_launch(ctx, p, p->counters + 3);
@@ -1556,7 +1559,7 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if ((rc = msx_profile_prop_begin(ctx, p))) return rc;      // a = U = ui/2 (+d): identical on every rank
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
-			msx_prop_iteration(ctx, p, true);     // share = this rank's part of the increment, complete
+			if ((rc = msx_prop_iteration(ctx, p, true))) return rc;     // share = this rank's part of the increment, complete
 			// (after convergence the local kernels are no-ops and leave `share` at zero on every rank;
 			// the all-reduce still runs -- every rank enqueues the same 19 -- and sums zeros)
 			if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;
