@@ -634,7 +634,7 @@ static void *bgz_reader_main(void *arg) {
 			if (k < 0) mDie("Read failed");
 			if (k == 0) { eof = 1; break; }
 			n += (size_t)k;
-			if (n >= ((size_t)1 << 20) && b->rd_wait) break;
+			if (n >= ((size_t)1 << 20) && __atomic_load_n(&b->rd_wait, __ATOMIC_RELAXED)) break;   /* (a hint: no ordering needed) */
 		}
 		pthread_mutex_lock(&b->rd_mu);
 		b->rd_len[slot] = n;
@@ -673,9 +673,9 @@ static int bgz_next_buffer(bgz_in *b, size_t *left_out) {
 		b->cur = -1;
 	}
 	slot = b->rd_head;
-	b->rd_wait = 1;
+	__atomic_store_n(&b->rd_wait, 1, __ATOMIC_RELAXED);
 	while (!b->rd_full[slot] && !b->rd_eof) pthread_cond_wait(&b->rd_cv_full, &b->rd_mu);   /* (the last buffer and rd_eof are set together) */
-	b->rd_wait = 0;
+	__atomic_store_n(&b->rd_wait, 0, __ATOMIC_RELAXED);
 	if (!b->rd_full[slot]) {             /* the reader has handed over its last buffer, and that one is behind us */
 		pthread_mutex_unlock(&b->rd_mu);
 		return 0;
@@ -1284,9 +1284,9 @@ static void chunk_write(msh_out *o, struct wchunk *c) {
 			want += c->slot_len[q];
 		}
 		while (want) {
-			if (c->mapped && o->is_pipe) {
+			if (c->mapped && __atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED)) {
 				got = vmsplice(o->fd, iv + v, (unsigned long)(niv - v), 0);
-				if (got < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { o->is_pipe = 0; continue; }   /* not here: copy */
+				if (got < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { __atomic_store_n(&o->is_pipe, 0, __ATOMIC_RELAXED); continue; }   /* not here: copy */
 			} else {
 				got = writev(o->fd, iv + v, niv - v);
 			}
@@ -1605,7 +1605,7 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 				if (!c) mDie("Out of memory");
 				c->nblk = take + extra;
 				c->slots_bytes = c->nblk * WSLOT;
-				c->mapped = o->is_pipe;
+				c->mapped = __atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED);
 				c->slots = c->mapped ? (uint8_t *)mmap(NULL, c->slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)
 				                     : (uint8_t *)malloc(c->slots_bytes);
 				c->slot_len = (uint32_t *)malloc(c->nblk * sizeof(uint32_t));
