@@ -680,8 +680,11 @@ static int rec_plausible(const uint8_t *u, size_t off, size_t len, int32_t nt) {
 	if (off + 36 > len) return 0;
 	bs = le32(u + off);
 	if (bs < 32 || bs > (64 << 20)) return 0;
-	if (chase_sloppy < 0) chase_sloppy = getenv("MSX_CHASE_SLOPPY") != NULL;
-	if (chase_sloppy) return bs < 4096;
+	{
+		int sl = __atomic_load_n(&chase_sloppy, __ATOMIC_RELAXED);      /* (every thread would compute the same value) */
+		if (sl < 0) { sl = getenv("MSX_CHASE_SLOPPY") != NULL; __atomic_store_n(&chase_sloppy, sl, __ATOMIC_RELAXED); }
+		if (sl) return bs < 4096;
+	}
 	r = u + off + 4;
 	tid = REC_TID(r); pos = REC_POS(r); mtid = le32(r + 20); mpos = le32(r + 24);
 	if (tid < -1 || tid >= nt || mtid < -1 || mtid >= nt || pos < -1 || mpos < -1) return 0;

@@ -514,8 +514,12 @@ uint32_t msh_crc32(const void *p, size_t n) {
 	const uint8_t *s = (const uint8_t *)p;
 	uLong c = crc32(0L, NULL, 0);
 #if defined(__x86_64__)
-	static int fast = -1;
-	if (fast < 0) fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("MSX_NO_PCLMUL");
+	static int fast_flag = -1;           /* (every thread would compute the same value: relaxed accesses, no lock) */
+	int fast = __atomic_load_n(&fast_flag, __ATOMIC_RELAXED);
+	if (fast < 0) {
+		fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("MSX_NO_PCLMUL");
+		__atomic_store_n(&fast_flag, fast, __ATOMIC_RELAXED);
+	}
 	if (fast && n >= 64) {
 		const size_t m = n & ~(size_t)15;
 		c = (uLong)(~crc32_fold(s, m, ~(uint32_t)c) & 0xffffffffu);
@@ -583,9 +587,13 @@ static void inflate_block(bgz_in *b, int i) {
 	 * block, and with a hundred threads those serialise inside the allocator */
 	static __thread z_stream zs;
 	static __thread int zs_ready = 0;
-	static int fast = -1;
+	static int fast_flag = -1;
+	int fast = __atomic_load_n(&fast_flag, __ATOMIC_RELAXED);
 	if (isize == 0) return;
-	if (fast < 0) fast = !getenv("MSX_NO_FAST_INFLATE");
+	if (fast < 0) {
+		fast = !getenv("MSX_NO_FAST_INFLATE");
+		__atomic_store_n(&fast_flag, fast, __ATOMIC_RELAXED);
+	}
 	/* the decoder of msh_inflate.c first (twice zlib's speed on BAM records); whatever it does not vouch for,
 	 * and whatever fails the CRC afterwards, is decoded again by zlib, whose verdict stands */
 	if (fast && msh_fast_inflate(data, dlen, out, isize) && msh_crc32(out, isize) == (uint32_t)le32(c + clen - 8)) return;
