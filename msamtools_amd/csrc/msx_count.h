@@ -67,24 +67,26 @@ __device__ __forceinline__ void pool_begin(const CountArgs &A, PoolAcc &v, uint3
 
 // one record of the stream profile sees, given its tid
 __device__ __forceinline__ void pool_visit(const CountArgs &A, PoolAcc &v, int32_t t) {
-	if (t == -1) return;                             // msam_profile.c:223-225
-	const int32_t fid = A.fmap ? A.fmap[t] : t;
-	v.nvalid++;
+	// (written with selects: the lanes of a wave are at different points of their pools, and every branch here
+	//  is an exec-mask round trip per lane group; only the fifth and later distinct features of a pool branch)
+	const bool valid = t != -1;                      // msam_profile.c:223-225
+	int32_t fid = t;
+	if (A.fmap) fid = valid ? A.fmap[t] : -1;        // (kernel argument: a uniform branch)
+	v.nvalid += valid ? 1u : 0u;
 	bool seen = (v.nd > 0 && fid == v.f0) || (v.nd > 1 && fid == v.f1) || (v.nd > 2 && fid == v.f2) ||
 	            (v.nd > 3 && fid == v.f3);
-	if (!seen && v.nd > 4)
+	if (valid && !seen && v.nd > 4)
 		for (uint32_t k = 4; k < v.nd; ++k)
 			if (v.lst[k] == fid) { seen = true; break; }
-	if (!seen) {
-		if (v.nd == 0) v.f0 = fid;
-		else if (v.nd == 1) v.f1 = fid;
-		else if (v.nd == 2) v.f2 = fid;
-		else if (v.nd == 3) v.f3 = fid;
-		// the first four stay in registers until the pool is done (pool_finish writes them out, and only
-		// for a pool with two or more -- the scratch list of any other pool is never read)
-		if (v.nd >= 4) v.lst[v.nd] = fid;
-		v.nd++;
-	}
+	const bool fresh = valid && !seen;
+	v.f0 = (fresh && v.nd == 0) ? fid : v.f0;
+	v.f1 = (fresh && v.nd == 1) ? fid : v.f1;
+	v.f2 = (fresh && v.nd == 2) ? fid : v.f2;
+	v.f3 = (fresh && v.nd == 3) ? fid : v.f3;
+	// the first four stay in registers until the pool is done (pool_finish writes them out, and only
+	// for a pool with two or more -- the scratch list of any other pool is never read)
+	if (fresh && v.nd >= 4) v.lst[v.nd] = fid;
+	v.nd += fresh ? 1u : 0u;
 }
 
 // The records of the pool at s whose bit is set in m1, then those in m2 (filter's output
