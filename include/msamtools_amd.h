@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSX_ABI_VERSION 2
+#define MSX_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSX_OK              0
@@ -94,7 +94,13 @@ typedef struct msx_batch {
 	const int32_t  *as;         /* [n] (int32_t) bam_aux2i(AS); 0 when absent    */
 	const uint32_t *group_off;  /* [n_groups+1], see above                       */
 	const uint64_t *qname_hash; /* [n] optional, not read by the kernels (shard routing) */
+	int32_t         pool_rule;  /* MSX_POOLS_PROFILE or MSX_POOLS_FILTER: which loop's rule group_off follows.
+	                               Read by the profile entry points only, see msx_profile_accumulate. */
+	int32_t         reserved_;
 } msx_batch;
+#define MSX_POOLS_PROFILE 0   /* msam_profile.c:223-232 (or any input where one pool = one QNAME run)      */
+#define MSX_POOLS_FILTER  1   /* msam_filter.c:120-125,170: a record of another name closes the pool, but only
+                                 a MAPPED record renames the read being collected                            */
 
 /* Thresholds and switches of `msamtools filter`, already validated/derived as
  * msam_filter.c:420-457 does (PPT = 10*-p or --ppt; MAX_CLIP = 100 - -z). */
@@ -187,6 +193,15 @@ int  msx_host_register(msx_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegis
 int  msx_host_unregister(msx_ctx *ctx, void *ptr);
 /* asynchronous device -> host copy on the ctx stream (host memory should be page-locked) */
 int  msx_dev_to_host_async(msx_ctx *ctx, void *host, const void *dev, size_t bytes);
+/* A marker on the ctx stream: record it behind the work that reads a host buffer (msx_stage_upload) and wait
+ * for it before the buffer is reused -- one marker per batch slot instead of a stream synchronisation per batch
+ * (the loops of msam_filter.c:119-186 / msam_profile.c:222-234 hand over record after record; here a slot's
+ * page-locked arrays go back to the decoder as soon as their copies have left). */
+typedef struct msx_event msx_event;
+int  msx_event_create(msx_ctx *ctx, msx_event **ev);
+int  msx_event_record(msx_ctx *ctx, msx_event *ev);
+int  msx_event_wait(msx_ctx *ctx, msx_event *ev);      /* host waits; returns at once if never recorded */
+void msx_event_destroy(msx_ctx *ctx, msx_event *ev);
 
 /* ---- filter: replaces mFilterFileWrapper/mFilterFile + writers ----------- */
 
@@ -232,7 +247,15 @@ int  msx_profile_reset(msx_ctx *ctx, msx_profile *p);
  * stream (the `profile` subcommand).  keep != NULL (device, [n_records], from
  * msx_filter): the stream is filter's output for this batch, in its output
  * order -- the fused `filter ... | profile -` pipe; dev->group_off are then
- * filter's pools (one pool per QNAME run).  Enqueues and returns. */
+ * filter's pools.  profile re-pools what filter writes by QNAME
+ * (msam_profile.c:223-232); with dev->pool_rule == MSX_POOLS_FILTER the device
+ * does the same: the filter loop opens a new pool at every record whose QNAME
+ * differs from the last MAPPED record's (msam_filter.c:120-125,170), so a pool
+ * that begins with an unmapped record holds -- behind it -- more alignments of
+ * the read the pool before it held (A mapped, B unmapped, A mapped: two filter
+ * pools, one insert); such a pool is counted together with its predecessor.
+ * dev->flag is needed for that.  With MSX_POOLS_PROFILE every pool is one
+ * insert.  Enqueues and returns. */
 int  msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_batch *dev,
                             const uint8_t *keep);
 

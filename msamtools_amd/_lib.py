@@ -33,7 +33,11 @@ class Batch(C.Structure):
         ("flag", C.c_void_p), ("rflags", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p),
         ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("md_off", C.c_void_p), ("md", C.c_void_p),
         ("nm", C.c_void_p), ("as_", C.c_void_p), ("group_off", C.c_void_p), ("qname_hash", C.c_void_p),
+        ("pool_rule", C.c_int32), ("reserved_", C.c_int32),
     ]
+
+
+POOLS_PROFILE, POOLS_FILTER = 0, 1
 
 
 class FilterParams(C.Structure):
@@ -88,6 +92,10 @@ SYMBOLS = {
     "msx_host_register": (C.c_int, [_P, _P, C.c_size_t]),
     "msx_host_unregister": (C.c_int, [_P, _P]),
     "msx_dev_to_host_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msx_event_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "msx_event_record": (C.c_int, [_P, _P]),
+    "msx_event_wait": (C.c_int, [_P, _P]),
+    "msx_event_destroy": (None, [_P, _P]),
     "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),
     "msx_filter_finish": (C.c_int, [_P, C.POINTER(FilterStatus)]),
     "msx_aln_stats": (C.c_int, [_P, C.POINTER(Batch), _P, _P, _P, _P, _P]),

@@ -163,9 +163,11 @@ _FIELDS = (("flag", np.uint16), ("rflags", np.uint8), ("tid", np.int32), ("pos",
            ("nm", np.int32), ("as_", np.int32), ("group_off", np.uint32))
 
 
-def host_batch_struct(rec, group_off=None):
-    """numpy SoA (attributes as in tests/samio.Records) -> (msx_batch with host pointers, keepalive)."""
+def host_batch_struct(rec, group_off=None, filter_pools=False):
+    """numpy SoA (attributes as in tests/samio.Records) -> (msx_batch with host pointers, keepalive).
+    filter_pools: group_off follow the rule of msam_filter.c:120-125,170 (msx_batch.pool_rule)."""
     b = L.Batch()
+    b.pool_rule = L.POOLS_FILTER if filter_pools else L.POOLS_PROFILE
     keep = []
     b.n_records = int(rec.flag.shape[0])
     for name, dt in _FIELDS:
@@ -192,8 +194,8 @@ class DeviceBatch:
         self.sizes = sizes
 
     @classmethod
-    def upload(cls, ctx, rec, group_off=None):
-        hb, keep = host_batch_struct(rec, group_off)
+    def upload(cls, ctx, rec, group_off=None, filter_pools=False):
+        hb, keep = host_batch_struct(rec, group_off, filter_pools)
         db = L.Batch()
         ctx.check(ctx.lib.msx_batch_upload(ctx.h, C.byref(hb), C.byref(db)))
         return cls(ctx, db)

@@ -1119,7 +1119,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	fdev_t F;
 	pthread_t th_dec, th_dev;
 	double t_start = now_s(), tw = 0, t_wait = 0;
-	size_t n_in = 0, n_out = 0;
+	size_t n_in = 0, n_out = 0, n_batches = 0;
 	pipe_init(&P, in, pools ? 1 : 0, want_stats);
 	memset(&F, 0, sizeof F);
 	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv;
@@ -1133,6 +1133,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		t_wait += t1 - t0;
 		if (s->eof) break;
 		msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
+		n_batches++;
 		n_in += s->b.n;
 		n_out += (size_t)s->n_emit;
 		tw += now_s() - t1;
@@ -1141,6 +1142,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	pthread_join(th_dec, NULL);
 	pthread_join(th_dev, NULL);
 	msh_out_close(F.out);
+	if (getenv("MSX_TIMING")) fprintf(stderr, "# batches: %zu\n", n_batches);
 	if (getenv("MSX_TIMING"))
 		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 		        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
@@ -1523,6 +1525,9 @@ int msam_profile_main(int argc, char *argv[]) {
 		msx_stage *stage = NULL;
 		double t_start = now_s(), t_dev = 0, t_wait = 0, t_ctx;
 		size_t n_in = 0;
+		msx_event *ev[PIPE_SLOTS] = {NULL};
+		int held = -1;                           /* slot whose uploads may still be in flight */
+		size_t n_batches = 0;
 		pipe_init(&P, in, 2, 0);
 		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 		ctx_open();                              /* HIP start-up runs beside the decoding of the first batch */
@@ -1547,15 +1552,24 @@ int msam_profile_main(int argc, char *argv[]) {
 				hb.cigar_off = NULL; hb.cigar = NULL; hb.md_off = NULL; hb.md = NULL;   /* profile reads tid only */
 				hb.nm = NULL; hb.as = NULL; hb.pos = NULL; hb.flag = NULL; hb.rflags = NULL;
 				MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
+				/* the slot's page-locked arrays go back to the decoder once these copies have left -- a marker per
+				 * slot, waited for one batch later, instead of a stream synchronisation per batch */
+				if (!ev[si]) MSX(msx_event_create(g_ctx, &ev[si]));
+				MSX(msx_event_record(g_ctx, ev[si]));
 				MSX(msx_profile_accumulate(g_ctx, prof, &db, NULL));
-				MSX(msx_ctx_sync(g_ctx));                 /* the slot's arrays are free again */
 				n_in += s->b.n;
+				n_batches++;
 			}
+			if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P.q_free, held); }
+			held = si;
 			t_dev += now_s() - t1;
-			pq_push(&P.q_free, si);
 		}
+		if (held >= 0) MSX(msx_event_wait(g_ctx, ev[held]));
 		pthread_join(th_dec, NULL);
+		MSX(msx_ctx_sync(g_ctx));
 		msx_stage_destroy(g_ctx, stage);
+		{ int q; for (q = 0; q < PIPE_SLOTS; q++) msx_event_destroy(g_ctx, ev[q]); }
+		if (getenv("MSX_TIMING")) fprintf(stderr, "# batches: %zu\n", n_batches);
 		if (getenv("MSX_TIMING"))
 			fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 			        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
@@ -2126,6 +2140,73 @@ static int pipetest_main(int argc, char *argv[]) {
 	}
 }
 
+/* hidden, host only: `msamtools digest <file>` prints the number of records and an order-sensitive 64-bit
+ * digest of (QNAME, FLAG, tid, pos) over the record stream:  sum over records i = 0.. of (i + 1) * g(record i)
+ * mod 2^64, g = a 64-bit mix of the three integers xor FNV-1a of the QNAME.  The tests and bench.py compute the
+ * same figure from the oracle's emit list (tests/digest.py), so that an output of tens of millions of records
+ * is compared with the oracle's -- which records, in which order -- without a text round trip. */
+static uint64_t dg_mix(uint64_t x) {
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+	x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+	x ^= x >> 33;
+	return x;
+}
+static uint64_t dg_record(const uint8_t *r) {
+	const char *q = REC_QNAME(r);
+	uint64_t h = 1469598103934665603ull;
+	const uint64_t v = (uint64_t)REC_FLAG(r) + (uint64_t)(uint32_t)REC_TID(r) * 0x9e3779b97f4a7c15ull +
+	                   (uint64_t)(uint32_t)REC_POS(r) * 0xc2b2ae3d27d4eb4full;
+	while (*q) { h ^= (uint8_t)*q++; h *= 1099511628211ull; }
+	return dg_mix(v) ^ h;
+}
+typedef struct { const rbatch *b; uint64_t first, part[MSH_POOL_MAX]; } digest_job;
+static void digest_worker(void *arg, int tid, int nth) {
+	digest_job *J = (digest_job *)arg;
+	const rbatch *b = J->b;
+	const size_t lo = b->n * (size_t)tid / (size_t)nth, hi = b->n * (size_t)(tid + 1) / (size_t)nth;
+	uint64_t s = 0;
+	size_t i;
+	for (i = lo; i < hi; i++) {
+		const uint8_t *r = RB_REC(b, i);
+		msh_rec_check(r, RB_LEN(b, i));
+		s += (J->first + (uint64_t)i + 1) * dg_record(r);
+	}
+	J->part[tid] = s;
+}
+
+static int digest_main(int argc, char *argv[]) {
+	msh_in *in;
+	uint64_t n = 0, h = 0;
+	if (argc < 2) mQuit("usage: %s digest <file>", PROGRAM);
+	in = msh_open(argv[1]);
+	if (msh_is_bam(in)) {
+		static pipe_t P;
+		pthread_t th;
+		pipe_init(&P, in, 0, 0);
+		if (pthread_create(&th, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
+		for (;;) {
+			const int si = pq_pop(&P.q_dev);
+			pslot *s = &P.slot[si];
+			digest_job J;
+			int nth = msh_threads(), t;
+			if (s->eof) break;
+			if (nth > MSH_POOL_MAX) nth = MSH_POOL_MAX;
+			J.b = &s->b; J.first = n;
+			msh_parallel(nth, digest_worker, &J);
+			for (t = 0; t < nth; t++) h += J.part[t];
+			n += s->b.n;
+			pq_push(&P.q_free, si);
+		}
+		pthread_join(th, NULL);
+	} else {
+		kstr rec = {0, 0, 0};
+		while (msh_read(in, &rec) == 0) { n++; h += n * dg_record((const uint8_t *)rec.s); }
+	}
+	printf("records=%llu digest=%016llx\n", (unsigned long long)n, (unsigned long long)h);
+	msh_close(in);
+	return 0;
+}
+
 int main(int argc, char *argv[]) {
 	g_t_main = now_s();
 	if (argc < 2) return usage(stderr);
@@ -2144,6 +2225,7 @@ int main(int argc, char *argv[]) {
 	}
 	if (strcmp(argv[1], "recode") == 0) return recode_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "pipetest") == 0) return pipetest_main(argc - 1, argv + 1);
+	if (strcmp(argv[1], "digest") == 0) return digest_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);

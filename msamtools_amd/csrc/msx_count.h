@@ -25,7 +25,22 @@ struct CountArgs {
 	//   MSX_PINFO_NONE        nothing to do
 	uint32_t *pinfo;
 	int32_t count_keys;       // unique inserts are counted afterwards by msx_count_keys, not by ui_add here
+	// msx_batch.pool_rule == MSX_POOLS_FILTER: group_off are the pools of msam_filter.c:120-125,170, and the stream
+	// profile reads is filter's output re-pooled by QNAME (msam_profile.c:223-232).  A filter pool that begins with
+	// an UNMAPPED record was opened by that record's name while prev_read kept the name of the last mapped record;
+	// the mapped records that follow in it carry that earlier name, so the pool's output belongs to the insert of
+	// the pool before it.  An insert is then a *chain*: a pool that begins with a mapped record (or pool 0) and the
+	// pools after it that begin with an unmapped one.  Chain members are left out by the per-pool kernels and
+	// counted as one pool by k_insert_chains.  chain_flag = FLAG array (null: every pool is its own insert).
+	const uint16_t *chain_flag;
 };
+
+// pool g continues the insert of pool g - 1
+__device__ __forceinline__ bool pool_follows(const CountArgs &A, int64_t g) {
+	if (!A.chain_flag || g <= 0 || g >= A.n_groups) return false;
+	const uint32_t s = A.group_off[g];
+	return s < A.group_off[g + 1] && (A.chain_flag[s] & MSX_F_UNMAP) != 0;
+}
 #define MSX_PINFO_LIST 0x80000000u
 #define MSX_PINFO_NONE 0xffffffffu
 
@@ -194,5 +209,6 @@ __device__ __forceinline__ void count_block_end(const CountArgs &A, int32_t *s_k
 int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep, CountArgs *out,
                               bool *by_part_out);
 int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, bool by_part);
+void msx_profile_count_chains(msx_ctx *ctx, const CountArgs &A);      // k_insert_chains, after the per-pool kernel
 
 #endif

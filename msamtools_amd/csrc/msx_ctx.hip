@@ -367,6 +367,7 @@ extern "C" int msx_batch_upload(msx_ctx *ctx, const msx_batch *h, msx_batch *d) 
 	size_t n_cig = (n && h->cigar_off) ? h->cigar_off[n] : 0, n_md = (n && h->md_off) ? h->md_off[n] : 0;
 	d->n_records = h->n_records;
 	d->n_groups = h->group_off ? h->n_groups : 0;
+	d->pool_rule = h->pool_rule;
 	int rc;
 #define UP(field, count, pad) \
 	if ((rc = up(ctx, h->field, (count), (pad), &d->field)) != MSX_OK) { msx_batch_free(ctx, d); return rc; }
@@ -431,6 +432,7 @@ extern "C" int msx_stage_upload(msx_ctx *ctx, msx_stage *st, const msx_batch *h,
 	const size_t n_cig = (n && h->cigar_off) ? h->cigar_off[n] : 0, n_md = (n && h->md_off) ? h->md_off[n] : 0;
 	d->n_records = h->n_records;
 	d->n_groups = h->group_off ? h->n_groups : 0;
+	d->pool_rule = h->pool_rule;
 	int rc;
 #define UP(i, field, count, pad) if ((rc = stage_up(ctx, &st->arr[i], h->field, (count), (pad), &d->field)) != MSX_OK) return rc;
 	UP(0, flag, n, 2)
@@ -495,4 +497,42 @@ extern "C" int msx_dev_to_host_async(msx_ctx *ctx, void *host, const void *dev, 
 	msx_join(ctx);
 	if (bytes) MSX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
 	return MSX_OK;
+}
+
+// ---- stream markers ------------------------------------------------------------------------------
+struct msx_event {
+	hipEvent_t ev = nullptr;
+	bool recorded = false;
+};
+
+extern "C" int msx_event_create(msx_ctx *ctx, msx_event **out) {
+	if (!ctx || !out) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	msx_event *e = new msx_event();
+	if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) {
+		delete e;
+		return msx_fail(ctx, MSX_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(hipGetLastError()));
+	}
+	*out = e;
+	return MSX_OK;
+}
+
+extern "C" int msx_event_record(msx_ctx *ctx, msx_event *e) {
+	if (!ctx || !e) return MSX_ERR_ARG;
+	MSX_HIP(ctx, hipEventRecord(e->ev, ctx->stream));
+	e->recorded = true;
+	return MSX_OK;
+}
+
+extern "C" int msx_event_wait(msx_ctx *ctx, msx_event *e) {
+	if (!ctx || !e) return MSX_ERR_ARG;
+	if (e->recorded) MSX_HIP(ctx, hipEventSynchronize(e->ev));
+	return MSX_OK;
+}
+
+extern "C" void msx_event_destroy(msx_ctx *ctx, msx_event *e) {
+	(void)ctx;
+	if (!e) return;
+	if (e->ev) (void)hipEventDestroy(e->ev);
+	delete e;
 }

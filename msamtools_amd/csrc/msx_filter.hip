@@ -68,11 +68,13 @@ __device__ __forceinline__ uint8_t bh_keep(const BhAcc &c, bool w0, bool w1, boo
 // flat path below takes it).
 __device__ __forceinline__ uint32_t bh_rec_code(const SelectArgs &A, uint32_t i) {
 	// MSX_PC_IN | MSX_PC_HAS_AS | mate bits of a record that takes part, 0 otherwise
+	// (+ MSX_PC_UNMAP for an unmapped record, pooled or not)
 	if (A.pool_is_code) return A.pool[i];                // k_aln_stats_flat has looked at FLAG and the aux bits already
 	const uint32_t fl = A.flag[i];
 	const bool pooled = A.pool ? (A.pool[i] != 0) : !(fl & MSX_F_UNMAP);
 	const bool has = (A.rflags[i] & MSX_HAS_AS) || (A.rescored && !(fl & MSX_F_UNMAP));
-	return pooled ? (MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (fl & MSX_F_MATES)) : 0u;
+	return (pooled ? (MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (fl & MSX_F_MATES)) : 0u) |
+	       ((fl & MSX_F_UNMAP) ? MSX_PC_UNMAP : 0u);
 }
 
 template <bool COUNT>
@@ -94,13 +96,17 @@ __device__ __forceinline__ void bh_pool_serial(const SelectArgs &A, const CountA
 		cnt += (k != 0);
 	}
 	if (COUNT) {
-		// the keep codes this lane just wrote, in output order
-		PoolAcc v;
-		pool_begin(P, v, s);
-		for (uint32_t pass = 1; pass <= 2; ++pass)
-			for (uint32_t i = s; i < e; ++i)
-				if (A.keep[i] == pass) pool_visit(P, v, P.tid[i]);
-		pool_finish(P, g, v, s_key, s_val, bc);
+		if (pool_follows(P, g) || pool_follows(P, g + 1)) {
+			if (P.pinfo) P.pinfo[g] = MSX_PINFO_NONE;        // member of a chain of pools: k_insert_chains counts it
+		} else {
+			// the keep codes this lane just wrote, in output order
+			PoolAcc v;
+			pool_begin(P, v, s);
+			for (uint32_t pass = 1; pass <= 2; ++pass)
+				for (uint32_t i = s; i < e; ++i)
+					if (A.keep[i] == pass) pool_visit(P, v, P.tid[i]);
+			pool_finish(P, g, v, s_key, s_val, bc);
+		}
 	}
 	// msam_filter.c:219-221: a participating record without AS is fatal
 	const uint32_t bad = c.paired ? (c.noas1 < c.noas2 ? c.noas1 : c.noas2) : c.noas0;
@@ -133,6 +139,7 @@ struct BfWave {
 	int32_t best[3][64];          // per mate class: neither bit, READ1, READ2
 	uint32_t ties[3][64], noas[3][64];
 	uint32_t pair[64], k1[64], k2[64], start[64];
+	uint32_t fum[64];             // the pool's first record is unmapped (chains of pools, msx_count.h)
 };
 
 __device__ __forceinline__ void bf_wave_sync() {
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 		L.noas[0][lane] = 0xffffffffu; L.noas[1][lane] = 0xffffffffu; L.noas[2][lane] = 0xffffffffu;
 		L.pair[lane] = 0u; L.k1[lane] = 0u; L.k2[lane] = 0u;
 		L.start[lane] = s - S;
+		if (COUNT && P.chain_flag) L.fum[lane] = 0u;
 		if (A.unique_only) { L.ties[0][lane] = 0u; L.ties[1][lane] = 0u; L.ties[2][lane] = 0u; }
 		// all of the range's records in flight before anything is looked at
 		uint32_t pc[BF_ROWS];
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 						else atomicMin(&L.noas[ci][pid], S + off);
 					}
 				}
+				if (COUNT && P.chain_flag && (c & MSX_PC_UNMAP) && off == L.start[pid]) L.fum[pid] = 1u;
 				pc[r] = c | (pid << 8);
 			}
 		}
@@ -262,10 +271,21 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 			const uint32_t bad = L.pair[lane] ? (n1 < n2 ? n1 : n2) : L.noas[0][lane];
 			if (bad != 0xffffffffu) atomicMin(&A.st->first_no_as, (unsigned long long)bad);
 			if (COUNT) {
-				PoolAcc v;
-				pool_begin(P, v, s);
-				pool_visit_masks(P, v, s, k1, k2);
-				pool_finish(P, g, v, s_key, s_val, bc);
+				// a pool that begins with an unmapped record continues the insert of the pool before it: the members
+				// of such a chain are counted together by k_insert_chains (msx_count.h)
+				bool member = false;
+				if (P.chain_flag) {
+					const bool last = ((vm >> lane) >> 1) == 0ull;                     // the tile's last pool: its successor is another wave's
+					member = (g > 0 && L.fum[lane] != 0u) || (last ? pool_follows(P, g + 1) : L.fum[(lane + 1u) & 63u] != 0u);
+				}
+				if (member) {
+					if (P.pinfo) P.pinfo[g] = MSX_PINFO_NONE;
+				} else {
+					PoolAcc v;
+					pool_begin(P, v, s);
+					pool_visit_masks(P, v, s, k1, k2);
+					pool_finish(P, g, v, s_key, s_val, bc);
+				}
 			}
 		}
 		bf_wave_sync();                                                            // the slots are reused by the next tile
@@ -486,6 +506,7 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 			hipLaunchKernelGGL(k_besthit_select<false>, dim3(msx_grid_x(ctx, ng, MSX_BLOCK, 4)), dim3(MSX_BLOCK), 0,
 			                   ctx->stream, S, P);
 		msx_time_end(ctx);
+		if (prof && ng > 0 && P.chain_flag) msx_profile_count_chains(ctx, P);
 		// three independent chains from here: counting the unique-insert keys (side lane 0, inside
 		// msx_profile_count_finish), appending the multi-mapper lists (main stream), and filter's own
 		// output order (side lane 1); all three are latency-bound and overlap well

@@ -21,6 +21,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
 		const uint32_t s = A.group_off[g], e = A.group_off[g + 1];
+		if (pool_follows(A, g) || pool_follows(A, g + 1)) {      // member of a chain of pools: k_insert_chains
+			if (A.pinfo) A.pinfo[g] = MSX_PINFO_NONE;
+			continue;
+		}
 		PoolAcc v;
 		pool_begin(A, v, s);
 		// the stream: the batch itself, or filter's output order (all pass-1 records of the
@@ -57,6 +61,44 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_insert_count(CountArgs A) {
 		pool_finish(A, g, v, s_key, s_val, c);
 	}
 	count_block_end(A, s_key, s_val, s_c, c);
+}
+
+// Chains of filter pools that are ONE insert for profile (CountArgs.chain_flag, msx_count.h): one lane per chain
+// head walks the records its pools write -- pool by pool, first-pass records, then second-pass records: the order of
+// filter's output (msam_filter.c:247-263), which is the order profile's pool holds them in (msam_profile.c:131-145
+// lists distinct features by first appearance) -- and accounts for them as one pool.  Rare by construction (a record
+// of another name, unmapped, between the alignments of one read), so no attempt at coalescing.
+__global__ __launch_bounds__(MSX_BLOCK) void k_insert_chains(CountArgs A) {
+	__shared__ uint32_t s_c[3][MSX_BLOCK / 64];
+	__shared__ int32_t s_key[UI_TBL];
+	__shared__ uint32_t s_val[UI_TBL];
+	count_block_begin(A, s_key, s_val);
+	BlockCounts c = {0u, 0u, 0u};
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t g = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; g < A.n_groups; g += stride) {
+		if (pool_follows(A, g) || !pool_follows(A, g + 1)) continue;      // not the head of a chain
+		PoolAcc v;
+		pool_begin(A, v, A.group_off[g]);
+		for (int64_t h = g;; ++h) {
+			const uint32_t s = A.group_off[h], e = A.group_off[h + 1];
+			if (!A.keep) {
+				for (uint32_t i = s; i < e; ++i) pool_visit(A, v, A.tid[i]);
+			} else {
+				for (uint32_t pass = 1; pass <= 2; ++pass)
+					for (uint32_t i = s; i < e; ++i)
+						if (A.keep[i] == pass) pool_visit(A, v, A.tid[i]);
+			}
+			if (!pool_follows(A, h + 1)) break;
+		}
+		pool_finish(A, g, v, s_key, s_val, c);
+	}
+	count_block_end(A, s_key, s_val, s_c, c);
+}
+
+void msx_profile_count_chains(msx_ctx *ctx, const CountArgs &A) {
+	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
+	hipLaunchKernelGGL(k_insert_chains, dim3(msx_grid(ctx, A.n_groups, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A);
+	msx_time_end(ctx);
 }
 
 // csr_tot = {n_lists, n_entries} running totals of the compact CSR.
@@ -271,6 +313,10 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	A.d = p->d;
 	A.counters = p->counters;
 	A.tmp_fid = (int32_t *)ctx->tmp_fid.p;
+	if (b->pool_rule == MSX_POOLS_FILTER) {
+		if (!b->flag) return msx_fail(ctx, MSX_ERR_ARG, "msx_batch.pool_rule = MSX_POOLS_FILTER needs the flag array");
+		A.chain_flag = b->flag;
+	}
 	{
 		// Staging-table size (measured on MI355X): with ~1 M features a large table is needed to
 		// catch the hot references among the cold ones (2048: 1.5 ms vs 256: 2.7 ms at 20 M pools);
@@ -343,6 +389,7 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
 	hipLaunchKernelGGL(k_insert_count, dim3(msx_grid(ctx, b->n_groups, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, A);
 	msx_time_end(ctx);
+	if (A.chain_flag) msx_profile_count_chains(ctx, A);
 	return msx_profile_count_finish(ctx, p, b, by_part);
 }
 

@@ -7,6 +7,8 @@
 // pool byte written for k_besthit_select (FilterArgs.pool_as_code): bits 6-7 are FLAG's READ1/READ2
 #define MSX_PC_IN 0x01u
 #define MSX_PC_HAS_AS 0x02u
+#define MSX_PC_UNMAP 0x04u     // FLAG & 4, whether the record is pooled or not: a pool that BEGINS with an unmapped record
+                               // continues the QNAME of the pool before it (msam_filter.c:120-125,170; msx_count.h)
 
 struct FilterArgs {
 	int64_t n;

@@ -188,10 +188,11 @@ __device__ __forceinline__ uint32_t sf_finish_record(const FilterArgs &A, uint32
 // the byte handed to k_besthit_select (FilterArgs.pool_as_code) or written as keep
 template <bool EXTRA>
 __device__ __forceinline__ uint32_t sf_pool_byte(const FilterArgs &A, uint32_t pooled, uint32_t flag, uint32_t rf) {
-	if (A.pool_as_code && pooled) {
+	if (A.pool_as_code) {
 		// msam_filter.c:223: AS is read from the record; after --rescore every mapped record has one (:167)
 		const bool has = (rf & MSX_HAS_AS) || (EXTRA && A.rescore && !(flag & MSX_F_UNMAP));
-		pooled = MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (flag & MSX_F_MATES);
+		pooled = pooled ? (MSX_PC_IN | (has ? MSX_PC_HAS_AS : 0u) | (flag & MSX_F_MATES)) : 0u;
+		pooled |= (flag & MSX_F_UNMAP) ? MSX_PC_UNMAP : 0u;
 	}
 	return pooled;
 }

@@ -1,0 +1,179 @@
+"""The command line at scale against the oracle (-m gpu): the assembled decode | device | encode pipeline --
+BGZF inflate, record chase, SoA packing, pools carried across batch cuts, kernels, emit-index gather into BGZF
+blocks, the writer thread, the pipe between two processes -- on a synthetic BAM of millions of records cut into
+twenty and more batches, 16 host threads.
+
+What is compared (msam_filter.c:206-245, msam_profile.c:858-983; the comparison rule of the reference's own
+harness, tests/functions.sh:160-163: same records in the same order, same profile):
+  * `filter -l 80 -p 95 -z 80 --besthit` output (-bu, -b, file and pipe): the records the oracle emits, in its
+    order -- as text lines (`recode`) on the 1 M-record file, as the order-sensitive digest of (QNAME, FLAG, tid,
+    pos) on the 3 M-record file (tests/digest.py = `msamtools digest`);
+  * `filter ... | profile -`, `profile` of filter's file and `profile` alone: header counts equal the oracle's,
+    every value within 1e-6 relative of orc.run_profile + profile_finish.
+"""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import digest
+import oracle_lib as orc
+from conftest import ROOT
+
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+FILT = ["filter", "-l", "80", "-p", "95", "-z", "80", "--besthit"]
+OPTS = dict(l=80, p=95, z=80, besthit=True)
+REF_LEN = 4496          # msh_cli.c: synth_main writes every @SQ with this length
+ENV = dict(MSX_THREADS="16", MSX_BATCH_BYTES="2500000", MSX_BATCH_RECORDS="160000")
+
+pytestmark = pytest.mark.gpu
+
+
+def sh(cmd, **env):
+    e = dict(os.environ, **ENV)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run(cmd, shell=True, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, (cmd, r.stderr.decode()[-2000:])
+    return r
+
+
+class Case:
+    """A synthetic name-grouped BAM (-b and -u) with the oracle's answers for it."""
+
+    def __init__(self, d, groups, refs):
+        import msamtools_amd as m
+        self.groups, self.refs, self.dir = groups, refs, str(d)
+        self.bam = {}
+        for flag in ("b", "u"):
+            p = os.path.join(self.dir, f"in_{groups}_{flag}.bam")
+            with open(p, "wb") as fh:
+                subprocess.check_call([BIN, "synth", "--groups", str(groups), "--refs", str(refs), f"-{flag}"], stdout=fh)
+            self.bam[flag] = p
+        self.hs = m.HostSynth(13579, groups, refs, 4)
+        f = orc.run_filter(self.hs, **OPTS)
+        assert f["rc"] == 0
+        self.emit = f["emit"]
+        self.digest_in = digest.synth_digest(self.hs)
+        self.digest_out = digest.synth_digest(self.hs, self.emit)
+        self.flen = np.full(refs, REF_LEN, dtype=np.uint32)
+        self.pipe = orc.run_profile(self.hs, refs, multi="proportional", sel=self.emit)
+        self.plain = orc.run_profile(self.hs, refs, multi="proportional")
+
+    def check_digest(self, path, want):
+        out = subprocess.check_output([BIN, "digest", path], env=dict(os.environ, MSX_THREADS="8")).decode().strip()
+        h, n = want
+        assert out == f"records={n} digest={h:016x}", (path, out, n, f"{h:016x}")
+
+    def check_profile(self, path, ref, batches_stderr=None):
+        text = gzip.open(path, "rt").read()
+        head = [l for l in text.split("\n") if l.startswith("#")]
+        rows = [l.split("\t") for l in text.split("\n") if l and not l.startswith("#")]
+        s = ref["stats"]
+        get = lambda key: next(l for l in head if l.startswith(key)).split(":")[1].split("(")[0].strip()
+        assert int(get("# Mapped inserts")) == s.insert_count
+        assert int(get("#   - Multiple mapped")) == s.multi_mapper_count
+        assert int(get("#   - Uniquely mapped")) == s.uniq_mapper_count
+        vals, purged, eff = orc.profile_finish(ref["abundance"], self.flen, s, unit="rel")
+        assert float(get("# Purged inserts")) == pytest.approx(purged, rel=1e-6)
+        assert float(get("# Effective inserts")) == pytest.approx(eff, rel=1e-6)
+        assert rows[0] == ["ID", "S"] and rows[1][0] == "Unknown" and len(rows) == self.refs + 2
+        assert [r[0] for r in rows[2:5]] == ["ref0000000", "ref0000001", "ref0000002"]
+        got = np.array([float(r[1]) for r in rows[1:]])
+        assert np.array_equal(got == 0, vals == 0)
+        # %.8g prints eight significant digits: 5e-8 relative on top of the 1e-6 the profile is held to
+        rel = np.abs(got - vals) / np.maximum(np.abs(vals), 1e-300)
+        assert rel.max() <= 1e-6 + 1e-7, rel.max()
+        assert abs(got.sum() - 1.0) <= 5e-6
+
+
+@pytest.fixture(scope="module")
+def big(tmp_path_factory):
+    return Case(tmp_path_factory.mktemp("scale3m"), 600_000, 3000)
+
+
+@pytest.fixture(scope="module")
+def mid(tmp_path_factory):
+    return Case(tmp_path_factory.mktemp("scale1m"), 200_000, 800)
+
+
+def n_batches(stderr):
+    for line in stderr.decode().split("\n"):
+        if line.startswith("# batches:"):
+            return int(line.split()[2])
+    return None
+
+
+def test_inputs_are_what_the_oracle_was_given(big, mid):
+    for c in (big, mid):
+        for flag in ("b", "u"):
+            c.check_digest(c.bam[flag], c.digest_in)
+
+
+def test_filter_records_as_text_lines(mid, tmp_path):
+    """1 M records, > 20 batches: every output line equals the input line the oracle selects, in its order."""
+    out = str(tmp_path / "f.bam")
+    r = sh(f"{BIN} {' '.join(FILT)} -bu {mid.bam['u']} > {out}", MSX_TIMING=1, MSX_BATCH_BYTES=1_500_000,
+           MSX_BATCH_RECORDS=110_000)
+    assert n_batches(r.stderr) >= 8, r.stderr.decode()[-800:]
+    src = subprocess.check_output([BIN, "recode", mid.bam["u"]]).decode().split("\n")[:-1]
+    got = subprocess.check_output([BIN, "recode", out]).decode().split("\n")[:-1]
+    assert len(src) == mid.hs.n_records
+    assert len(got) == len(mid.emit)
+    want = [src[i] for i in mid.emit]
+    assert got == want
+    # SAM text out of the same run equals the BAM's records
+    r = sh(f"{BIN} {' '.join(FILT)} {mid.bam['b']} > {tmp_path / 'f.sam'}")
+    assert open(tmp_path / "f.sam").read().split("\n")[:-1] == want
+
+
+@pytest.mark.parametrize("inflag,outflag", [("b", "-bu"), ("u", "-bu"), ("b", "-b"), ("u", "-b")])
+def test_filter_digest_many_batches(big, tmp_path, inflag, outflag):
+    out = str(tmp_path / "f.bam")
+    r = sh(f"{BIN} {' '.join(FILT)} {outflag} {big.bam[inflag]} > {out}", MSX_TIMING=1)
+    assert n_batches(r.stderr) >= 20, r.stderr.decode()[-800:]
+    big.check_digest(out, big.digest_out)
+
+
+def test_filter_through_pipes(big, tmp_path):
+    """stdin from a pipe (the reader thread's ring), stdout into a pipe (vmsplice hand-over)."""
+    out = str(tmp_path / "f.bam")
+    sh(f"cat {big.bam['b']} | {BIN} {' '.join(FILT)} -bu - | cat > {out}")
+    big.check_digest(out, big.digest_out)
+
+
+@pytest.mark.parametrize("inflag", ["b", "u"])
+def test_filter_pipe_profile(big, tmp_path, inflag):
+    """The reference's two-process workflow, filter's pools and profile's pools both cut across > 20 batches."""
+    p = str(tmp_path / "p.gz")
+    sh(f"{BIN} {' '.join(FILT)} -bu {big.bam[inflag]} | {BIN} profile --label S -o {p} -")
+    big.check_profile(p, big.pipe)
+
+
+def test_filter_file_then_profile(big, tmp_path):
+    f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    sh(f"{BIN} {' '.join(FILT)} -b {big.bam['u']} > {f}")
+    r = sh(f"{BIN} profile --label S -o {p} {f}", MSX_TIMING=1)
+    assert n_batches(r.stderr) >= 8
+    big.check_profile(p, big.pipe)
+
+
+@pytest.mark.parametrize("inflag", ["b", "u"])
+def test_profile_alone(big, tmp_path, inflag):
+    p = str(tmp_path / "p.gz")
+    r = sh(f"{BIN} profile --label S -o {p} {big.bam[inflag]}", MSX_TIMING=1)
+    assert n_batches(r.stderr) >= 20
+    big.check_profile(p, big.plain)
+
+
+def test_one_batch_equals_many(mid, tmp_path):
+    """The default batch size (one batch here) and 1 or 3 threads write the same records as the many-batch run
+    (BGZF block boundaries follow the batches and threads, so the decoded streams are compared)."""
+    def records(**env):
+        out = str(tmp_path / "o.bam")
+        sh(f"{BIN} {' '.join(FILT)} -bu {mid.bam['b']} > {out}", **env)
+        return subprocess.check_output([BIN, "recode", "-h", out])
+    ref = records()
+    for env in (dict(MSX_BATCH_BYTES=96 << 20, MSX_BATCH_RECORDS=3 << 20), dict(MSX_THREADS=1), dict(MSX_THREADS=3)):
+        assert records(**env) == ref
