@@ -73,7 +73,68 @@ def parse():
                     help="run the multi-GPU step (msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator) "
                          "even with one rank")
     ap.add_argument("--print-checksum", action="store_true", help="add a checksum of the abundance vector to the JSON")
+    ap.add_argument("--no-coverage", action="store_true", help="skip the coverage block (BASELINE configs[3])")
+    ap.add_argument("--no-dist-leg", action="store_true",
+                    help="skip timing the multi-GPU step over a one-rank communicator (dist_one_rank_ms_per_step)")
+    ap.add_argument("--e2e-seq-groups", type=int, default=4_000_000,
+                    help="QNAME groups of the end-to-end BAM with SEQ/QUAL (~250 B per record); 0 = skip")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="ranks print their launch environment as JSON and exit (tests of the launcher; no GPU)")
     return ap.parse_args()
+
+
+def granted_cpus():
+    """CPUs this process may really use: its affinity mask and the cgroup's CPU quota (the GPU box grants the job
+    fewer than it shows online)."""
+    import math
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            if parse:
+                q, per = parse(open(path).read())
+                if q != "max":
+                    n = min(n, max(1, math.ceil(int(q) / int(per))))
+            else:
+                q = int(open(path).read())
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0 and per > 0:
+                    n = min(n, max(1, math.ceil(q / per)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started plainly (no launcher, WORLD_SIZE unset): this process starts the N ranks itself,
+    one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, relays rank 0's JSON
+    line and exits non-zero if any rank does.  It never touches the GPU (no HIP call, no torch.cuda call): the
+    children are fresh processes, nothing is re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MSX_BENCH_RANK_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
 
 
 def cpu_model():
@@ -86,11 +147,54 @@ def cpu_model():
     return "unknown"
 
 
-def e2e_cli(groups, refs):
-    """The command line end to end on this box: a synthetic BAM of `groups` QNAME groups (BGZF level 6, records
-    without SEQ/QUAL) through `msamtools filter -l 80 -p 95 -z 80 --besthit -bu | msamtools profile -` -- the
-    reference's own two-process workflow -- and through either command alone.  Host-bound (BGZF inflate, record
-    walk, deflate); reported next to `value`, never as it (SURVEY.md 8d metric (ii))."""
+def read_profile_gz(path):
+    """(header lines, feature names, values[Unknown, features...]) of a profile written by the command line"""
+    import gzip
+    import numpy as np
+    head, names, vals = [], [], []
+    with gzip.open(path, "rt") as fh:
+        for line in fh:
+            if line.startswith("#"):
+                head.append(line.rstrip("\n"))
+                continue
+            k, _, v = line.rstrip("\n").partition("\t")
+            if k == "ID" or not v:
+                continue
+            names.append(k)
+            vals.append(float(v))
+    return head, names, np.array(vals)
+
+
+def profile_parity(path, stats, abundance, refs, ref_len):
+    """The profile file against the oracle: header counts equal, every value within 1e-6 relative (+ the 5e-8 of
+    the eight digits %.8g prints), a checksum of the values at six decimals (msam_profile.c:858-983)."""
+    import hashlib
+    import numpy as np
+    import oracle_lib as orc
+    head, names, got = read_profile_gz(path)
+
+    def field(key):
+        return next(l for l in head if l.startswith(key)).split(":")[1].split("(")[0].strip()
+    vals, purged, eff = orc.profile_finish(abundance, np.full(refs, ref_len, np.uint32), stats, unit="rel")
+    counts = (int(field("# Mapped inserts")), int(field("#   - Multiple mapped")), int(field("#   - Uniquely mapped")))
+    want_counts = (int(stats.insert_count), int(stats.multi_mapper_count), int(stats.uniq_mapper_count))
+    rel = float((np.abs(got - vals) / np.maximum(np.abs(vals), 1e-300)).max()) if got.shape == vals.shape else float("inf")
+    return {"header_counts_equal": counts == want_counts, "mapped_multiple_unique": list(counts),
+            "rows": int(got.size), "zero_pattern_equal": bool(got.shape == vals.shape and np.array_equal(got == 0, vals == 0)),
+            "max_rel_err": rel, "tolerance": 1e-6 + 1e-7,
+            "sha1_6dp": hashlib.sha1(np.round(got, 6).tobytes()).hexdigest(),
+            "sha1_6dp_oracle": hashlib.sha1(np.round(vals, 6).tobytes()).hexdigest(),
+            "ok": bool(counts == want_counts and rel <= 1e-6 + 1e-7)}
+
+
+def e2e_cli(groups, refs, expect=None, seq=False):
+    """The command line end to end on this box: a synthetic BAM of `groups` QNAME groups (BGZF level 6; records
+    without SEQ/QUAL, or ~250 B records with them: seq) through `msamtools filter -l 80 -p 95 -z 80 --besthit -bu |
+    msamtools profile -` -- the reference's own two-process workflow -- through either command alone, and through
+    the one-process form `filter --profile-out`.  Host-bound (BGZF inflate, record walk, deflate); reported next to
+    `value`, never as it (SURVEY.md 8d metric (ii)).  The outputs are kept and compared with
+    the oracle's for the same stream (expect: emit digest, stats and abundances of the oracle's pipe and of the
+    oracle's plain profile) -- which records, in which order; header counts; every value."""
     import re
     import shutil
     import subprocess
@@ -101,6 +205,7 @@ def e2e_cli(groups, refs):
     tmp = tempfile.mkdtemp(prefix="msx_e2e_", dir="/tmp")
     filt = "filter -l 80 -p 95 -z 80 --besthit -bu"
     env = dict(os.environ, MSX_TIMING="1")
+    ref_len = 4496              # msh_cli.c: synth_main
 
     def stages(err, kind):
         d = {}
@@ -123,31 +228,72 @@ def e2e_cli(groups, refs):
         if r.returncode != 0:
             raise RuntimeError(r.stderr.decode()[-500:])
         return dt, r.stderr.decode()
+
+    def digest(path):
+        out = subprocess.check_output([exe, "digest", path]).decode().split()
+        return int(out[0].split("=")[1]), out[1].split("=")[1]
     try:
         t0 = time.perf_counter()
-        subprocess.check_call(f"{exe} synth --groups {groups} --refs {refs} -b > {tmp}/in.bam", shell=True)
+        subprocess.check_call(f"{exe} synth --groups {groups} --refs {refs} {'--seq' if seq else ''} -b > {tmp}/in.bam", shell=True)
         synth_s = time.perf_counter() - t0
-        n = int(subprocess.check_output(f"{exe} synth --groups {groups} --refs {refs} -u | wc -c", shell=True))   # uncompressed size
-        size_u = n
-        n = int(subprocess.check_output(f"{exe} recode {tmp}/in.bam | wc -l", shell=True))
+        n, _ = digest(f"{tmp}/in.bam")
+        # bytes per record: a small uncompressed sample with a short header (the records do not depend on it)
+        subprocess.check_call(f"{exe} synth --groups {min(groups, 100000)} --refs 1000 {'--seq' if seq else ''} -u > {tmp}/s.bam", shell=True)
+        n_s, _ = digest(f"{tmp}/s.bam")
+        size_u = os.path.getsize(f"{tmp}/s.bam")
         dt_f, err_f = run(f"{exe} {filt} {tmp}/in.bam > {tmp}/f.bam")
         dt_p, err_p = run(f"{exe} profile --label S -o {tmp}/p1.gz {tmp}/in.bam")
         dt_fp, err_fp = run(f"{exe} {filt} {tmp}/in.bam | {exe} profile --label S -o {tmp}/p.gz -")
+        tee = None
+        try:
+            dt_t, err_t = run(f"{exe} {filt} --profile-out {tmp}/pt.gz --label S {tmp}/in.bam > {tmp}/ft.bam")
+            tee = {"M_alignments_per_s": round(n / dt_t / 1e6, 2), "seconds": round(dt_t, 3),
+                   "command": f"msamtools {filt} --profile-out p.gz --label S in.bam > f.bam", **stages(err_t, "filter")}
+        except RuntimeError as exc:
+            tee = {"error": str(exc)[:200]}
         sf, sp = stages(err_fp, "filter"), stages(err_fp, "profile")
-        return {
+        res = {
             "M_alignments_per_s": round(n / dt_fp / 1e6, 2),
             "command": f"msamtools {filt} in.bam | msamtools profile --label S -o p.gz -",
-            "seconds": round(dt_fp, 3), "records": n,
+            "seconds": round(dt_fp, 3), "records": n, "references_in_header": refs,
             "decode_s": sf.get("decode_s"), "upload_s": sf.get("upload_s"), "gpu_s": sf.get("gpu_s"), "encode_s": sf.get("encode_s"),
             "profile_decode_s": sp.get("decode_s"), "profile_upload_accumulate_s": sp.get("upload_accumulate_s"),
-            "threads": sf.get("threads"), "host_cpus_online": os.cpu_count(),
-            "bgzf_level": {"input": 6, "pipe": 0}, "bytes_per_record": round(size_u / n, 1),
+            "threads": sf.get("threads"), "host_cpus_online": os.cpu_count(), "host_cpus_granted": granted_cpus(),
+            "bgzf_level": {"input": 6, "pipe": 0}, "encoding": "SEQ/QUAL present" if seq else "lean (l_seq = 0)",
+            "bytes_per_record": round(size_u / max(1, n_s), 1),
             "input_MB": round(os.path.getsize(f"{tmp}/in.bam") / 1e6, 1),
             "filter_alone": {"M_alignments_per_s": round(n / dt_f / 1e6, 2), "seconds": round(dt_f, 3), **stages(err_f, "filter")},
             "profile_alone": {"M_alignments_per_s": round(n / dt_p / 1e6, 2), "seconds": round(dt_p, 3), **stages(err_p, "profile")},
+            "one_process_tee": tee,
             "synth_s": round(synth_s, 1),
             "note": "stage times are busy times of overlapping pipeline stages (decode | device | encode), not a sum",
         }
+        if expect is not None:
+            # ---- the outputs against the oracle's for the same stream ----
+            par = {}
+            n_out, dg = digest(f"{tmp}/f.bam")
+            par["filter_records_out"] = n_out
+            par["filter_records_oracle"] = int(expect["n_emit"])
+            if "emit_digest" in expect:
+                par["filter_digest"] = dg
+                par["filter_digest_oracle"] = f"{expect['emit_digest']:016x}"
+                par["filter_ok"] = bool(n_out == expect["n_emit"] and dg == par["filter_digest_oracle"])
+            else:
+                par["filter_ok"] = bool(n_out == expect["n_emit"])
+            if "pipe" in expect:
+                par["pipe_profile"] = profile_parity(f"{tmp}/p.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
+            if "plain" in expect:
+                par["plain_profile"] = profile_parity(f"{tmp}/p1.gz", expect["plain"]["stats"], expect["plain"]["abundance"], refs, ref_len)
+            if tee and "error" not in tee:
+                nt, dgt = digest(f"{tmp}/ft.bam")
+                par["tee_filter_ok"] = bool((nt, dgt) == (n_out, dg))
+                if "pipe" in expect:
+                    par["tee_profile"] = profile_parity(f"{tmp}/pt.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
+            par["parity_ok"] = bool(par["filter_ok"] and all(v.get("ok", True) for v in par.values() if isinstance(v, dict))
+                                    and par.get("tee_filter_ok", True))
+            res["parity"] = par
+            res["parity_ok"] = par["parity_ok"]
+        return res
     except Exception as exc:
         return {"error": str(exc)[:300]}
     finally:
@@ -220,13 +366,86 @@ def algorithmic_bytes_per_step(name, w):
     return None        # k_general_recip (a few thousand lists), k_partial_reduce: not priced
 
 
+def coverage_block(m, ctx, with_oracle):
+    """BASELINE configs[3]: per-base depth over 50 k references x 5 kb from ~50 M alignments resident in HBM
+    (msam_coverage.c:33-87): msx_coverage_accumulate + msx_coverage_finish, timed on the library's stream; priced
+    against the HBM roof on 4 B per depth cell + the record bytes read (tid, pos, cigar_off, CIGAR words)."""
+    import ctypes as C
+    import numpy as np
+    refs, tl, ngrp = 50_000, 5_000, 10_000_000
+    db = m.DeviceBatch.synth(ctx, SEED, ngrp, refs, 4)
+    try:
+        off = np.arange(refs + 1, dtype=np.int64) * tl
+        total = int(off[-1])
+        d_off, d_cov = ctx.alloc(off.nbytes), ctx.alloc(4 * total + 8)
+        ctx.to_dev(d_off, off)
+
+        def one(batch):
+            ctx.zero(d_cov, 4 * total + 8)
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off), refs, total,
+                                                      C.c_void_p(d_cov), None))
+            ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
+            ctx.sync()
+            return time.perf_counter() - t0
+        ts = [one(db) for _ in range(6)]
+        best = min(ts[1:])
+        cov = ctx.to_host(d_cov, total, np.int32)
+        sz = db.sizes
+        alg = 4 * total + 12 * db.n_records + 4 * int(sz.n_cigar)
+        # size-independent property at full size: the depths sum to the M/=/X bases of the records with a reference
+        cig = db.fetch("cigar", int(sz.n_cigar), np.uint32)
+        n_cig = np.diff(db.fetch("cigar_off", db.n_records + 1, np.uint32).astype(np.int64))
+        has_ref = np.repeat(db.fetch("tid", db.n_records, np.int32) >= 0, n_cig)
+        op, w = cig & 0xF, (cig >> 4).astype(np.int64)
+        want_sum = int(w[has_ref & ((op == 0) | (op == 7) | (op == 8))].sum())
+        blk = {
+            "workload": f"c4: coverage of {db.n_records} alignments on {refs} references x {tl} bp "
+                        f"({4 * total / 1e9:.2f} GB of int32 depths), inputs resident in HBM",
+            "ms": round(best * 1e3, 3), "G_alignments_per_s": round(db.n_records / best / 1e9, 2),
+            "algorithmic_bytes": alg, "algorithmic_GBps": round(alg / best / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+            "frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 4),
+            "depth_sum": int(cov.astype(np.int64).sum()), "depth_sum_expected": want_sum,
+            "depth_sum_ok": bool(int(cov.astype(np.int64).sum()) == want_sum and (cov >= 0).all()),
+        }
+        del cov, cig, n_cig, has_ref, op, w
+        if with_oracle:
+            import oracle_lib as orc
+            pg = 200_000                                   # every depth of a prefix of the stream against the oracle
+            small = m.DeviceBatch.synth(ctx, SEED, pg, refs, 4)
+            hs = m.HostSynth(SEED, pg, refs, 4)
+            # (the large-batch path: the binned pile-up is what the c4 batch takes)
+            one(small)
+            got = ctx.to_host(d_cov, total, np.int32)
+            t0 = time.perf_counter()
+            want = np.concatenate(orc.coverage(hs, [tl] * refs))
+            cpu_s = time.perf_counter() - t0
+            blk["parity_prefix"] = {"alignments": hs.n_records, "every_depth_equal": bool(np.array_equal(got, want))}
+            blk["cpu_oracle_M_alignments_per_s"] = round(hs.n_records / cpu_s / 1e6, 2)
+            blk["parity_ok"] = bool(blk["depth_sum_ok"] and blk["parity_prefix"]["every_depth_equal"])
+            small.free()
+        ctx.free(d_off)
+        ctx.free(d_cov)
+        return blk
+    finally:
+        db.free()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)            # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.dry_launch:
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                          "child": os.environ.get("MSX_BENCH_RANK_CHILD") == "1"}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -372,11 +591,17 @@ def main():
             per_kernel[k] = {"ms_per_step": round(v[0], 4), "launches": v[1],
                              "algorithmic_bytes_per_step": int(b) if b else None,
                              "algorithmic_GBps": round(g, 1) if g else None}
-            # a figure above the roof means the formula is wrong, not that the kernel is fast
-            assert g is None or g <= HBM_PEAK_GBS, (k, g)
+            # a figure above the roof: a small workload served from the 256 MB Infinity Cache, or a wrong formula --
+            # flagged, not fatal (a missing JSON line is a failed run to the driver)
+            if g is not None and g > HBM_PEAK_GBS:
+                per_kernel[k]["over_roof"] = True
+                print(f"[bench] warning: {k} prices at {g:.0f} GB/s algorithmic, above the {HBM_PEAK_GBS:.0f} GB/s roof",
+                      file=sys.stderr)
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
+            "traffic_source": (os.path.relpath(_PMC, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this command; "
+                               "not collected inside this run)") if TRAFFIC.get(dom) else None,
             "algorithmic_bytes_per_launch": int(dom_bytes / tms[dom][1]),
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": tms[dom][1],
             "per_kernel": per_kernel,
@@ -442,9 +667,24 @@ def main():
             par["ok"] = par["emit_equal"]
         out["parity"] = par
         del res
+        if sg == ng and not args.no_e2e and args.e2e_groups == ng:
+            # the end-to-end BAM is this very stream (same generator, seed, groups and references): what the oracle
+            # just computed is what the command line must write
+            import digest as dg
+            counts = np.diff(hs.group_off.astype(np.int64))
+            gidx = np.repeat(np.arange(counts.size, dtype=np.int64), counts)
+            em = f["emit"]
+            h, cnt = dg.stream_digest(hs.flag[em], hs.tid[em], hs.pos[em], dg.fnv_sim_names(gidx[em]))
+            del gidx
+            e2e_expect = {"n_emit": cnt, "emit_digest": h,
+                          "pipe": {"stats": p["stats"], "abundance": p["abundance"]},
+                          "plain": orc.run_profile(hs, nrefs, multi="proportional")}
+            if args.e2e_seq_groups and args.e2e_seq_groups < ng:
+                goff_s = int(hs.group_off[args.e2e_seq_groups])
+                e2e_seq_expect = {"n_emit": int(np.searchsorted(em, goff_s))}
         out["cpu_baseline"] = {
             "value": round(hs.n_records / best / 1e6, 3), "unit": "M alignments/s", "cores": 1, "kind": "port",
-            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_granted": granted_cpus(),
             "sample": f"first {sg} QNAME groups ({hs.n_records} alignments) of the same synthetic stream, "
                       f"{nrefs} references, copied back from the device batch, resident in RAM; best of 2 runs of oracle filter+profile "
                       f"({best:.2f} s each)",
@@ -455,7 +695,7 @@ def main():
         # the concatenated selection -- the "best CPU" figure
         try:
             from concurrent.futures import ThreadPoolExecutor
-            ncores = min(os.cpu_count() or 1, 64)
+            ncores = min(granted_cpus(), 64)         # what the cgroup / affinity mask grants, not what is online
             goff = hs.group_off.astype(np.int64)
             cuts = [int(goff[int(sg * i / ncores)]) for i in range(ncores + 1)]
             shards = [orc.make_records_slice(hs, hs.name_id, cuts[i], cuts[i + 1]) for i in range(ncores)
@@ -482,12 +722,51 @@ def main():
         except Exception as exc:      # never let the extra figure break the bench line
             out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
 
+    # ---- the multi-GPU step on the one GPU there is: msx_profile_finalize_dist_enqueue over a one-rank RCCL
+    # communicator -- the code path the ranks of --gpus N run, collectives included -- next to ms_per_step
+    if rank == 0 and world == 1 and not use_dist and not args.no_dist_leg and not args.no_roofline:
+        try:
+            ctx.dist_init(m.dist_unique_id(), 0, 1)
+
+            def dstep():
+                prof.reset()
+                run.enqueue_with_profile(prof)
+                prof.finalize_dist_enqueue()
+                run.finish()
+            for _ in range(2):
+                dstep()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dstep()
+            barrier()
+            dms = 1e3 * (time.perf_counter() - t0) / max(args.steps, 1)
+            ab_d, st_d = prof.fetch()
+            out["dist_one_rank_ms_per_step"] = round(dms, 4)
+            out["dist_one_rank"] = {
+                "ms_per_step": round(dms, 4), "ratio_to_plain_step": round(dms / ms_per_step, 4),
+                "iterations": int(st_d.iterations),
+                "max_rel_diff_to_plain": float((np.abs(ab_d - ab) / np.maximum(np.abs(ab), 1e-300)).max()),
+                "note": "one-rank RCCL communicator: every collective of the N-rank step is enqueued and runs"}
+        except Exception as exc:
+            out["dist_one_rank"] = {"error": str(exc)[:300]}
+
     prof.close()
     run.free()
     db.free()
+
+    # ---- BASELINE configs[3]: per-base coverage, 50 k references x 5 kb, ~50 M alignments ----
+    if rank == 0 and world == 1 and not args.no_coverage and args.workload == "c3":
+        try:
+            out["coverage"] = coverage_block(m, ctx, not args.no_cpu_baseline)
+        except Exception as exc:
+            out["coverage"] = {"error": str(exc)[:300]}
     ctx.close()
     if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
-        out["e2e"] = e2e_cli(args.e2e_groups, 100_000)
+        e2e_refs = nrefs if args.e2e_groups == ng else 100_000
+        out["e2e"] = e2e_cli(args.e2e_groups, e2e_refs, locals().get("e2e_expect"))
+        if args.e2e_seq_groups:
+            out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True)
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
         try:

@@ -372,7 +372,8 @@ int  msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p);
  * reference has no bounds check (a run past its target's end writes past that
  * target's array); here such a run is cut at the target's ends. */
 int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
-                             const int64_t *cov_off, int32_t n_targets, int32_t *cov,
+                             const int64_t *cov_off, int32_t n_targets,
+                             int64_t total_len /* = cov_off[n_targets], as the caller summed it */, int32_t *cov,
                              uint8_t *covered /* device u8[n_targets] or NULL: global->covered[tid],
                                                  set for every target that has an alignment (msam_coverage.c:45-49) */);
 int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);

@@ -497,7 +497,7 @@ def coverage(ctx, batch, target_len):
         ctx.to_dev(d_off, off)
         ctx.zero(d_cov, 4 * max(total, 1) + 8)
         ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off),
-                                                  len(target_len), C.c_void_p(d_cov), None))
+                                                  len(target_len), total, C.c_void_p(d_cov), None))
         ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
         cov = ctx.to_host(d_cov, total, np.int32)
     finally:

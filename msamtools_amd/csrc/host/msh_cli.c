@@ -1843,7 +1843,7 @@ int msam_coverage_main(int argc, char *argv[]) {
 			rb_host_view(&b, &hb, 0);
 			hb.md_off = NULL; hb.md = NULL; hb.nm = NULL; hb.as = NULL;
 			MSX(msx_batch_upload(g_ctx, &hb, &db));
-			MSX(msx_coverage_accumulate(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, (int32_t *)d_cov,
+			MSX(msx_coverage_accumulate(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
 			                            (uint8_t *)d_covered));
 			MSX(msx_ctx_sync(g_ctx));
 			msx_batch_free(g_ctx, &db);

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_tile(const uint32_t *__restri
 }
 
 extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets,
-                                       int32_t *cov, uint8_t *covered) {
+                                       int64_t total_len, int32_t *cov, uint8_t *covered) {
 	if (!ctx || !b || !cov_off || !cov) return MSX_ERR_ARG;
 	if (!b->pos || !b->tid || !b->cigar_off || !b->cigar)
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_accumulate needs tid, pos and cigar arrays");
@@ -178,11 +178,8 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 		const char *e = getenv("MSX_COV_BINNED_FROM");          // records per batch from which the binned path is used
 		return e ? atoll(e) : (int64_t)(2 << 20);
 	}();
-	int64_t total_cells = 0;                                     // the end of the depth array lives on the device
-	if (b->n_records >= binned_from && n_targets > 0) {
-		MSX_HIP(ctx, hipMemcpyAsync(&total_cells, cov_off + n_targets, 8, hipMemcpyDeviceToHost, ctx->stream));
-		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	}
+	// (total_len = cov_off[n_targets], which the caller summed itself: reading it back cost a stream synchronisation per batch)
+	const int64_t total_cells = (b->n_records >= binned_from && n_targets > 0) ? total_len : 0;
 	// an item is one word (cell << 1 | sign) and tile n_tiles marks an empty slot: depth arrays of 2^31 cells
 	// and more take the direct path
 	if (total_cells > 0 && total_cells + 2 * (int64_t)CV_TILE < ((int64_t)1 << 31)) {

@@ -24,6 +24,7 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 // ---- the part of the RCCL (NCCL 2) API used here, bound by dlsym ----------------------------
 typedef struct { char internal[128]; } msx_nccl_id;        // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
@@ -118,28 +119,58 @@ extern "C" int msx_dist_rendezvous(const char *addr, int port, int rank, int wor
 		sockaddr_in sa;
 		memset(&sa, 0, sizeof sa);
 		sa.sin_family = AF_INET;
-		sa.sin_addr.s_addr = htonl(INADDR_ANY);
 		sa.sin_port = htons((uint16_t)port);
-		if (bind(ls, (sockaddr *)&sa, sizeof sa) != 0 || listen(ls, world) != 0) {
+		// listen on the interface the ranks were told to connect to (MASTER_ADDR), not on every one
+		sa.sin_addr.s_addr = htonl(INADDR_ANY);
+		{
+			addrinfo h2, *r2 = nullptr;
+			memset(&h2, 0, sizeof h2);
+			h2.ai_family = AF_INET;
+			h2.ai_socktype = SOCK_STREAM;
+			if (getaddrinfo(addr, nullptr, &h2, &r2) == 0 && r2) {
+				sa.sin_addr = ((sockaddr_in *)r2->ai_addr)->sin_addr;
+				freeaddrinfo(r2);
+			}
+		}
+		if (bind(ls, (sockaddr *)&sa, sizeof sa) != 0) {       // (an address of another host's view of this one: any interface)
+			sa.sin_addr.s_addr = htonl(INADDR_ANY);
+			if (bind(ls, (sockaddr *)&sa, sizeof sa) != 0) {
+				int e = errno;
+				close(ls);
+				return msx_fail(nullptr, MSX_ERR_DIST, "rendezvous: cannot bind port %d: %s", port, strerror(e));
+			}
+		}
+		if (listen(ls, world + 8) != 0) {
 			int e = errno;
 			close(ls);
 			return msx_fail(nullptr, MSX_ERR_DIST, "rendezvous: cannot listen on port %d: %s", port, strerror(e));
 		}
-		timeval tv = {timeout_s > 0 ? timeout_s : 300, 0};
+		const int limit = timeout_s > 0 ? timeout_s : 300;
+		timeval tv = {limit, 0};
 		setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
-		for (int got = 1; got < world; got++) {
+		std::vector<char> seen((size_t)world, 0);
+		const time_t t_end = time(nullptr) + limit;
+		for (int got = 1; got < world;) {
 			int fd = accept(ls, nullptr, nullptr);
 			if (fd < 0) {
 				int e = errno;
+				if (e == EINTR) continue;
 				close(ls);
 				return msx_fail(nullptr, MSX_ERR_DIST, "rendezvous: %d of %d ranks connected: %s", got, world, strerror(e));
 			}
-			int32_t peer = -1;
-			int rc = recv_all(fd, &peer, 4) || send_all(fd, payload, bytes);
+			// a connection that is not a rank's (a port scanner, a stale client) must neither block the hand-over
+			// nor end it: 5 s for the hello, then on to the next connection
+			timeval tc = {5, 0};
+			setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tc, sizeof tc);
+			setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tc, sizeof tc);
+			int32_t hello[2] = {0, -1};
+			const bool ok = recv_all(fd, hello, 8) == 0 && hello[0] == 0x4d535831 /* "MSX1" */ && hello[1] > 0 &&
+			                hello[1] < world && !seen[(size_t)hello[1]] && send_all(fd, payload, bytes) == 0;
 			close(fd);
-			if (rc || peer <= 0 || peer >= world) {
+			if (ok) { seen[(size_t)hello[1]] = 1; got++; }
+			else if (time(nullptr) > t_end) {
 				close(ls);
-				return msx_fail(nullptr, MSX_ERR_DIST, "rendezvous: bad hello from a peer");
+				return msx_fail(nullptr, MSX_ERR_DIST, "rendezvous: %d of %d ranks connected in %d s", got, world, limit);
 			}
 		}
 		close(ls);
@@ -157,10 +188,12 @@ extern "C" int msx_dist_rendezvous(const char *addr, int port, int rank, int wor
 		int fd = socket(AF_INET, SOCK_STREAM, 0);
 		if (fd < 0) break;
 		if (connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
-			int32_t me = rank;
-			rc = (send_all(fd, &me, 4) || recv_all(fd, payload, bytes)) ? -2 : 0;
+			int32_t hello[2] = {0x4d535831, rank};
+			timeval tc = {30, 0};
+			setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tc, sizeof tc);
+			rc = (send_all(fd, hello, 8) || recv_all(fd, payload, bytes)) ? -2 : 0;
 			close(fd);
-			if (rc == -2) break;
+			if (rc == -2) { rc = -1; usleep(200000); }      // (rank 0 dropped us -- a duplicate, or it was busy: try again)
 		} else {
 			close(fd);
 			usleep(100000);

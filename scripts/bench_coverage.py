@@ -28,7 +28,7 @@ for it in range(6):
     ctx.zero(d_cov, 4 * total + 8)
     ctx.sync()
     t0 = time.perf_counter()
-    ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(db.b), C.c_void_p(d_off), refs, C.c_void_p(d_cov), None))
+    ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(db.b), C.c_void_p(d_off), refs, total, C.c_void_p(d_cov), None))
     ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
     ctx.sync()
     ts.append(time.perf_counter() - t0)

@@ -157,3 +157,78 @@ def test_dist_entry_points_without_a_context():
     lib = _lib.load()
     assert lib.msx_dist_world(None) == 1 and lib.msx_dist_rank(None) == 0
     assert lib.msx_dist_init_env(None) != 0
+
+
+def _stray_client(port, stop):
+    """connects to the rendezvous port, says nothing (a port scanner) or garbage, again and again"""
+    import socket
+    import time
+    k = 0
+    while not stop.is_set():
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=1) as sk:
+                if k % 2:
+                    sk.sendall(b"GET / HTTP/1.0\r\n\r\n")
+                time.sleep(0.3)
+        except OSError:
+            time.sleep(0.05)
+        k += 1
+
+
+def test_c_rendezvous_survives_stray_connections():
+    """one stray connection used to block rank 0 in recv for ever, a bad hello ended the hand-over.
+    Now a connection has 5 s to say a rank's hello and is skipped otherwise."""
+    import multiprocessing as mp
+    import threading
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000)
+    stop = threading.Event()
+    th = threading.Thread(target=_stray_client, args=(port, stop), daemon=True)
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, 2, port, q)) for r in (0, 1)]
+    procs[0].start()
+    th.start()
+    import time
+    time.sleep(1.0)                  # the stray client is talking to rank 0 when rank 1 arrives
+    procs[1].start()
+    got = sorted(q.get(timeout=90) for _ in range(2))
+    stop.set()
+    for p in procs:
+        p.join(timeout=30)
+    want = bytes((7 * i + 3) & 0xFF for i in range(128))
+    assert [(r, rc) for r, rc, _ in got] == [(0, 0), (1, 0)]
+    assert all(b == want for _, _, b in got)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launcher_starts_n_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it starts N rank processes itself, each with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line on stdout and fails if a rank fails
+    (with WORLD_SIZE unset `--gpus 8` ran ONE rank).  --dry-launch: the ranks only report their
+    environment, so this runs without a GPU; the parent never initialises one."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-launch"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    d0 = json.loads(r.stdout.decode().strip().split("\n")[-1])
+    assert (d0["rank"], d0["world"], d0["local_rank"], d0["child"]) == (0, world, 0, True)
+    others = [json.loads(l) for l in r.stderr.decode().split("\n") if l.startswith("{")]
+    assert sorted(d["rank"] for d in others) == list(range(1, world))
+    assert all(d["world"] == world and d["local_rank"] == d["rank"] and d["master"] == d0["master"] for d in others)
+    # under a launcher (WORLD_SIZE set) it is a rank, not a launcher
+    env2 = dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env2, timeout=120)
+    d = json.loads(r.stdout.decode().strip().split("\n")[-1])
+    assert (d["rank"], d["world"], d["child"]) == (1, 4, False)
+
+
+def test_bench_launcher_reports_a_failing_rank(tmp_path):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # (no GPU here: every rank fails at context creation; where there is one, an unknown workload does it)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--groups", "-5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode != 0

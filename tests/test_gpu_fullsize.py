@@ -180,7 +180,7 @@ def test_c4_coverage_full_size():
         ctx.to_dev(d_off, off)
         ctx.zero(d_cov, 4 * total + 8)
         ctx.zero(d_seen, C4_REFS)
-        ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(db.b), C.c_void_p(d_off), C4_REFS,
+        ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(db.b), C.c_void_p(d_off), C4_REFS, total,
                                                   C.c_void_p(d_cov), C.c_void_p(d_seen)))
         ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
         cov = ctx.to_host(d_cov, total, np.int32)
