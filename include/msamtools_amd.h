@@ -267,6 +267,13 @@ int  msx_filter_profile_enqueue(msx_ctx *ctx, const msx_batch *dev,
  * call on this ctx, whichever it is.  msx_profile_finalize_enqueue makes use of
  * that: it builds the sharing store, which needs neither, before it joins.) */
 
+/* One process driving several contexts (one per GPU, batches of one sample dealt round-robin; the reference is one
+ * loop over one file, msam_profile.c:222-234): adds what `src` has counted -- ui, d, {inserts, uniq, multi} and its
+ * multi-mapper lists (global->multi_mappers) -- to `dst`, which may live on another device (peer copy).  `src` is
+ * left as it is.  Afterwards msx_profile_finalize(dst) is mInsertCountToAbundanceMatrix over all the inserts.
+ * Batches must have been cut at insert boundaries (as for ranks).  Synchronises both streams. */
+int  msx_profile_merge(msx_ctx *dst_ctx, msx_profile *dst, msx_ctx *src_ctx, msx_profile *src);
+
 /* Device pointers to the accumulators, for a cross-GPU all-reduce(sum) by the
  * caller (RCCL): ui_insert_count u32[n_features], d_insert_count f64
  * [n_features] (NULL unless share_type is EQUAL), counters u32[4] =

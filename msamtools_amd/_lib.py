@@ -104,6 +104,7 @@ SYMBOLS = {
     "msx_profile_reset": (C.c_int, [_P, _P]),
     "msx_profile_accumulate": (C.c_int, [_P, _P, C.POINTER(Batch), _P]),
     "msx_filter_profile_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut), _P]),
+    "msx_profile_merge": (C.c_int, [_P, _P, _P, _P]),
     "msx_profile_accumulators": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "msx_profile_prop_begin": (C.c_int, [_P, _P]),
     "msx_profile_prop_local": (C.c_int, [_P, _P, C.POINTER(_P)]),

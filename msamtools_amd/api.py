@@ -395,6 +395,10 @@ class Profile:
         c.check(c.lib.msx_profile_accumulate(c.h, self.h, C.byref(batch.b),
                                              C.c_void_p(keep_ptr) if keep_ptr else None))
 
+    def merge(self, other):
+        """Adds what `other` (a Profile of the same sample on any context of this process) has counted."""
+        self.ctx.check(self.ctx.lib.msx_profile_merge(self.ctx.h, self.h, other.ctx.h, other.h))
+
     def accumulators(self):
         ui, d, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
         c = self.ctx

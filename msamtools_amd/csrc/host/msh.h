@@ -27,6 +27,9 @@
 /* ---- errors (mCommon.c:3-31) ---------------------------------------------- */
 void mDie(const char *fmt, ...);    /* "Fatal Error: ..." on stderr, exit 1 */
 void mQuit(const char *fmt, ...);   /* text on stderr, exit 1               */
+#include <pthread.h>
+extern pthread_t msh_main_thread;   /* set by main(): mDie on any other thread leaves with _exit */
+extern int msh_main_thread_set;
 
 /* ---- growable byte string -------------------------------------------------- */
 typedef struct {

@@ -23,7 +23,8 @@
 #define COORD_ORDER_CHECK_RECORDS 100000
 #define COORD_ORDER_MIN_RECORDS 10000
 
-static msx_ctx *g_ctx;
+/* the context the calling thread works on: one device thread per GPU, each with its own (MSX_DEVICES) */
+static __thread msx_ctx *g_ctx;
 
 /* stage timers, printed to stderr when MSX_TIMING is set */
 static double now_s(void) {
@@ -64,11 +65,42 @@ static void fast_exit(void) {
  * (msx_profile_finalize_dist_enqueue); rank 0 writes the profile. */
 static int dist_world(void) { const char *e = getenv("WORLD_SIZE"); int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }
 static int dist_rank(void) { const char *e = getenv("RANK"); return e ? atoi(e) : 0; }
+/* Running as one rank of several is something the caller asks for -- "{rank}" in the input path, or MSX_DIST=1 --
+ * never something inferred from a WORLD_SIZE that happens to be in the environment (a SLURM job, a torchrun
+ * parent): a rank that read the WHOLE file would have its counts multiplied by the number of ranks. */
+static int g_dist;
 
+static void ctx_open_dev(int id) {
+	if (msx_ctx_create(&g_ctx, id) != MSX_OK) mDie("%s", msx_last_error(NULL));
+}
 static void ctx_open(void) {
 	const char *dev = getenv("MSX_DEVICE"), *lr = getenv("LOCAL_RANK");
-	const int id = dev ? atoi(dev) : (dist_world() > 1 && lr ? atoi(lr) : 0);
-	if (msx_ctx_create(&g_ctx, id) != MSX_OK) mDie("%s", msx_last_error(NULL));
+	ctx_open_dev(dev ? atoi(dev) : (g_dist && lr ? atoi(lr) : 0));
+}
+
+/* One process, several GPUs: MSX_DEVICES="0,1,2,3" (device ids, one context and one device thread each; the decode
+ * stage deals the batches of the one input to them and the writer puts filter's output back in input order --
+ * SURVEY.md 8e).  Unset: one device (MSX_DEVICE, default 0). */
+#define MSH_MAX_DEVICES 16
+static int device_list(int *ids) {
+	const char *e = getenv("MSX_DEVICES");
+	int n = 0;
+	if (e && *e && !g_dist) {
+		const char *p = e;
+		while (*p && n < MSH_MAX_DEVICES) {
+			char *end;
+			long v = strtol(p, &end, 10);
+			if (end == p || v < 0) mDie("MSX_DEVICES: expected a comma-separated list of device ids, got '%s'", e);
+			ids[n++] = (int)v;
+			p = *end == ',' ? end + 1 : end;
+			if (*end && *end != ',') mDie("MSX_DEVICES: expected a comma-separated list of device ids, got '%s'", e);
+		}
+	}
+	if (n == 0) {
+		const char *dev = getenv("MSX_DEVICE"), *lr = getenv("LOCAL_RANK");
+		ids[n++] = dev ? atoi(dev) : (g_dist && lr ? atoi(lr) : 0);
+	}
+	return n;
 }
 
 static size_t batch_target(void) {
@@ -346,7 +378,10 @@ static void filter_help(FILE *out) {
 	        "  --rescore                 rescore alignments using MD or NM fields, in that order (default: false)\n\n"
 	        "Special filters:\n----------------\n\n"
 	        "  --besthit                 keep all highest scoring hit(s) per read (default: false)\n"
-	        "  --uniqhit                 keep only one highest scoring hit per read, only if it is unique (default: false)\n",
+	        "  --uniqhit                 keep only one highest scoring hit per read, only if it is unique (default: false)\n"
+	        "\nOne-process pipe (MI355X build):\n--------------------------------\n\n"
+	        "  --profile-out=<file>      also write the profile `msamtools profile -` would estimate from this command's output\n"
+	        "                            (needs --label; takes profile's --genome --total --mincount --unit --pandas --no-pandas --nolen --multi)\n",
 	        PROGRAM);
 }
 
@@ -405,9 +440,21 @@ typedef struct {
 	rbatch *b;
 	const uint8_t *base;
 	size_t n;
-	int mode, want_stats;
+	int mode, want_stats, unmapped_visible;
 	const char *carry_name;      /* QNAME of the last mapped / tid != -1 record of earlier batches */
 } pack_job;
+
+/* Does the record take part in the pool rule of `mode`?
+ *   1  msam_filter.c:120-125,170: every record is compared, only a MAPPED one renames the read (rule_sees = 1 always)
+ *   2  msam_profile.c:223-232: records with tid == -1 are skipped entirely
+ *   3  profile's rule over the records filter can write when pools do not shape its output (no best hit): a record
+ *      with tid == -1 is invisible to profile, an unmapped one is never written (unless -k -v, unmapped_visible) */
+static inline int rec_names_pool(const uint8_t *r, int mode, int uv) {
+	if (mode == 1) return !(REC_FLAG(r) & 4);
+	if (mode == 2) return REC_TID(r) != -1;
+	return REC_TID(r) != -1 && (uv || !(REC_FLAG(r) & 4));
+}
+static inline int rec_rule_sees(const uint8_t *r, int mode, int uv) { return mode == 1 ? 1 : rec_names_pool(r, mode, uv); }
 
 static void pack_scan(void *arg, int tid, int nth) {
 	pack_job *J = (pack_job *)arg;
@@ -420,7 +467,7 @@ static void pack_scan(void *arg, int tid, int nth) {
 		size_t j = lo;
 		while (j > 0) {
 			const uint8_t *pr = J->base + b->rec_off[j - 1] + 4;
-			if (J->mode == 1 ? !(REC_FLAG(pr) & 4) : (REC_TID(pr) != -1)) { pn = REC_QNAME(pr); break; }
+			if (rec_names_pool(pr, J->mode, J->unmapped_visible)) { pn = REC_QNAME(pr); break; }
 			j--;
 		}
 		if (!pn) pn = J->carry_name;
@@ -451,10 +498,10 @@ static void pack_scan(void *arg, int tid, int nth) {
 			b->cigar_off[i + 1] = 0;
 			b->md_off[i + 1] = 0;
 		}
-		if (J->mode == 1 || (J->mode == 2 && REC_TID(r) != -1))
+		if (J->mode != 0 && rec_rule_sees(r, J->mode, J->unmapped_visible))
 			bd = (pn && strcmp(REC_QNAME(r), pn) != 0) ? 1 : 0;
 		b->bound[i] = bd;
-		if (J->mode == 1 ? !(REC_FLAG(r) & 4) : (J->mode == 2 && REC_TID(r) != -1)) pn = REC_QNAME(r);
+		if (J->mode != 0 && rec_names_pool(r, J->mode, J->unmapped_visible)) pn = REC_QNAME(r);
 	}
 }
 
@@ -500,7 +547,7 @@ static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int 
 		b->rec_off[n] = off;
 		if (n == 0) { rd->done = 1; b->n = 0; return; }
 		/* 2. parallel: aux scan, SoA scalars, pool boundaries */
-		J.b = b; J.base = span; J.n = n; J.mode = mode; J.want_stats = want_stats;
+		J.b = b; J.base = span; J.n = n; J.mode = mode; J.want_stats = want_stats; J.unmapped_visible = 0;
 		J.carry_name = rd->have_prev ? rd->prev_read : NULL;
 		msh_parallel(msh_threads(), pack_scan, &J);
 		/* 3. where the batch ends: the last pool boundary (the open pool waits for more data) */
@@ -562,13 +609,15 @@ static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int 
 /* still copy records out of batch i while batch i+1 is being decoded; the    */
 /* bytes of the pool left open at a batch's end are carried into the next.    */
 /* ------------------------------------------------------------------------ */
-#define PIPE_SLOTS 3
+#define PIPE_SLOTS 3                    /* with one device; one more per further device */
+#define PIPE_SLOTS_MAX (PIPE_SLOTS + MSH_MAX_DEVICES)
 #define MSH_POOL_MAX 128
+#define PQ_END (-1)                     /* queue item: end of the stream (one per consumer) */
 
 typedef struct {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
-	int item[PIPE_SLOTS + 2], n;
+	int item[2 * PIPE_SLOTS_MAX + 4], n;
 } pq;
 static void pq_init(pq *q) { pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL); q->n = 0; }
 static void pq_push(pq *q, int v) {
@@ -593,7 +642,9 @@ typedef struct {
 	uint8_t *ubuf;             /* inflated BAM bytes of this batch */
 	size_t ulen, ucap;
 	int32_t *emit;             /* filter: indices of the records to write, in output order */
+	int32_t *as_out;           /* --rescore: the AS every record carries on output */
 	int64_t n_emit;
+	size_t seq;                /* number of the batch in the input: the writer's order */
 	int eof;                   /* end-of-stream marker */
 	int pinned;
 } pslot;
@@ -601,9 +652,13 @@ typedef struct {
 typedef struct {
 	msh_in *in;
 	const msh_hdr *hdr;
-	int mode, want_stats;      /* pool rule (0 none / 1 filter / 2 profile), cigar+md wanted */
+	int mode, want_stats;      /* pool rule (0 none / 1 filter / 2 profile / 3 profile's rule over what filter can write), cigar+md wanted */
+	int unmapped_visible;      /* mode 3: -k -v with a PPT >= 0 filter writes unmapped records (msam_filter.c:132-138) */
+	int cut_mapped;            /* prefer batch ends in front of a pool that begins with a MAPPED record (an insert's first pool) */
+	int n_slots, n_consumers;
+	size_t n_filled;           /* batches handed on so far */
 	size_t batch_bytes, cap_rec, cap_cig, cap_md;
-	pslot slot[PIPE_SLOTS];
+	pslot slot[PIPE_SLOTS_MAX];
 	pq q_free, q_dev, q_out;
 	/* decode state */
 	kstr carry;                /* bytes of the open pool (and of a cut record) left by the previous batch */
@@ -628,10 +683,13 @@ static void *xmalloc(size_t n) {
 	return p;
 }
 
-static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats) {
+static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_consumers) {
 	int i;
 	memset(P, 0, sizeof *P);
 	P->in = in;
+	P->n_consumers = n_consumers < 1 ? 1 : n_consumers;
+	P->n_slots = PIPE_SLOTS + P->n_consumers - 1;
+	if (P->n_slots > PIPE_SLOTS_MAX) P->n_slots = PIPE_SLOTS_MAX;
 	P->hdr = msh_header(in);
 	P->mode = mode;
 	P->want_stats = want_stats;
@@ -641,7 +699,7 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats) {
 	P->cap_cig = want_stats ? 2 * P->cap_rec : 4;
 	P->cap_md = want_stats ? 16 * P->cap_rec : 16;
 	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out);
-	for (i = 0; i < PIPE_SLOTS; i++) {
+	for (i = 0; i < P->n_slots; i++) {
 		pslot *s = &P->slot[i];
 		rbatch *b = &s->b;
 		const size_t c = P->cap_rec + 8;
@@ -913,7 +971,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 			continue;
 		}
 		/* aux scan, SoA scalars, pool boundaries */
-		J.b = b; J.base = s->ubuf; J.n = n; J.mode = P->mode; J.want_stats = P->want_stats;
+		J.b = b; J.base = s->ubuf; J.n = n; J.mode = P->mode; J.want_stats = P->want_stats; J.unmapped_visible = P->unmapped_visible;
 		J.carry_name = P->have_prev ? P->prev_read : NULL;
 		msh_parallel(msh_threads(), pack_scan, &J);
 		P->t_scan += now_s() - tq;
@@ -922,6 +980,15 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 			size_t k = n;
 			while (k > 1 && !b->bound[k - 1]) k--;
 			n_batch = k - 1;
+			if (P->cut_mapped && n_batch > 0) {
+				/* filter | profile in one process: a pool that begins with an unmapped record belongs to the insert of
+				 * the pool before it (msx_batch.pool_rule), so the batch should end in front of a pool that begins with
+				 * a mapped one; looked for in the batch's second half (a long tail of unmapped records must not make
+				 * the batch grow without bound -- cut inside it, only a QNAME that reappears behind it could notice) */
+				size_t q = k;
+				while (q - 1 > n / 2 && !(b->bound[q - 1] && !(b->flag[q - 1] & 4))) q--;
+				if (q - 1 > n / 2) n_batch = q - 1;
+			}
 			if (n_batch == 0) {          /* one pool fills the whole batch: take more bytes */
 				if (P->in_eof && tail == s->ulen) { n_batch = n; break; }
 				if (n >= P->cap_rec) mDie("A single QNAME group exceeds the batch capacity (%zu records); raise MSX_BATCH_RECORDS", P->cap_rec);
@@ -976,7 +1043,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 	P->have_first = 1;
 	for (i = n_batch; i > 0; i--) {       /* grouping state for the next batch */
 		const uint8_t *r = s->ubuf + b->rec_off[i - 1] + 4;
-		if (P->mode == 2 ? (REC_TID(r) != -1) : !(REC_FLAG(r) & 4)) {
+		if (P->mode == 0 || rec_names_pool(r, P->mode, P->unmapped_visible)) {
 			strcpy(P->prev_read, REC_QNAME(r));
 			P->have_prev = 1;
 			break;
@@ -1000,8 +1067,15 @@ static void *pipe_decode_thread(void *arg) {
 		n = pipe_fill(P, s);
 		P->t_decode += now_s() - t1;
 		s->eof = n == 0;
+		if (n == 0) {
+			/* end of the stream: one token per consumer (P->n_filled is final from here on) */
+			int c;
+			for (c = 0; c < P->n_consumers; c++) pq_push(&P->q_dev, PQ_END);
+			return NULL;
+		}
+		s->seq = P->n_filled;
+		__atomic_store_n(&P->n_filled, P->n_filled + 1, __ATOMIC_RELEASE);
 		pq_push(&P->q_dev, si);
-		if (n == 0) return NULL;
 	}
 }
 
@@ -1018,6 +1092,7 @@ static void pipe_pin_slot(pipe_t *P, pslot *s) {
 		MSX(msx_host_register(g_ctx, b->nm, c * 4));
 		MSX(msx_host_register(g_ctx, b->as, c * 4));
 		MSX(msx_host_register(g_ctx, s->emit, c * 4));
+		if (s->as_out) MSX(msx_host_register(g_ctx, s->as_out, c * 4));
 	}
 	if (P->want_stats) {
 		MSX(msx_host_register(g_ctx, b->cigar_off, (c + 1) * 4));
@@ -1047,113 +1122,500 @@ static void rescore_record(const uint8_t *r, size_t len, int32_t score, kstr *ou
 	}
 }
 
-/* ---- filter over the pipeline ----------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------ */
+/* profile                                                                    */
+/* ------------------------------------------------------------------------ */
+static void profile_help(FILE *out) {
+	fprintf(out,
+	        "Usage:\n------\n\n%s profile [-S] <bamfile> [--help] -o <file> --label=<string> [--genome=<string>] "
+	        "[--total=<int>] [--mincount=<int>] [--unit=<string>] [--pandas] [--no-pandas] [--nolen] [--multi=<string>]\n"
+	        "\nGeneral options:\n----------------\n\n"
+	        "These options specify the input/output formats of BAM/SAM files \n(same meaning as in 'samtools view'):\n"
+	        "  -S                        input is SAM (default: false)\n"
+	        "  <bamfile>                 input SAM/BAM file\n"
+	        "  --help                    print this help and exit\n\n"
+	        "Specific options:\n-----------------\n\n"
+	        "  -o <file>                 name of output file (required)\n"
+	        "  --label=<string>          label to use for the profile; typically the sample id (required)\n"
+	        "  --genome=<string>         tab-delimited genome definition file - 'genome-id<tab>seq-id' (default: none)\n"
+	        "  --total=<int>             number of high-quality inserts (mate-pairs/paired-ends) that were input to the aligner (default: unknown)\n"
+	        "  --mincount=<int>          minimum number of inserts mapped to a feature, below which the feature is counted as absent (default: 0)\n"
+	        "  --unit=<string>           unit of abundance to report {ab | rel | fpkm | tpm} (default: rel)\n"
+	        "  --pandas                  print two columns (ID, sample-label) as header compatible with python pandas (default)\n"
+	        "  --no-pandas               use legacy profile header without the ID column\n"
+	        "  --nolen                   do not normalize the abundance (only relevant for ab or rel) for sequence length (default: normalize)\n"
+	        "  --multi=<string>          how to deal with multi-mappers {all | equal | proportional | ignore} (default: proportional)\n",
+	        PROGRAM);
+}
+
+/* mPrintInsertStats / mPrintInsertStatsDouble (msam_profile.c:434-499) */
+static void print_stats_int(gzFile s, int left, const char *type, int number, int total, const char *post) {
+	int width = 7;
+	if (total > 0) width = (int)(1 + log10(total));
+	gzprintf(s, "# ");
+	if (left) gzprintf(s, "%-20s: ", type); else gzprintf(s, "%20s: ", type);
+	if (strcmp(type, "Total inserts") == 0 && number == -1) gzprintf(s, "%*s (", width, "NA");
+	else gzprintf(s, "%*d (", width, number);
+	if (total > 0) gzprintf(s, "%6.2f", 100.0 * number / total); else gzprintf(s, "%6s", "NA");
+	gzprintf(s, "%%)");
+	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
+}
+static void print_stats_dbl(gzFile s, int left, const char *type, double number, int total, const char *post) {
+	gzprintf(s, "# ");
+	if (left) gzprintf(s, "%-20s: ", type); else gzprintf(s, "%20s: ", type);
+	gzprintf(s, "%10.7g (", number);
+	if (total > 0) gzprintf(s, "%6.2f", 100.0 * number / total); else gzprintf(s, "%6s", "NA");
+	gzprintf(s, "%%)");
+	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
+}
+
+
+/* ---- what `profile` and `filter --profile-out` share: options, features, the report ------------------------ */
 typedef struct {
-	pipe_t *P;
-	const msx_filter_params *fp;
-	int pools, out_mode, argc;
-	char **argv;
-	msh_out *out;               /* created by the device stage after the preflight of the first batch */
+	const char *out, *label, *genome, *unit, *multi;
+	int n_out, n_label, n_total, n_mincount, pandas, nopandas, nolen;
+	long v_total, v_mincount;
+	/* derived (prof_opts_derive) */
+	int share_type, unit_type, length_normalize, total_inserts;
+} prof_opts;
+
+typedef struct {
+	int32_t n_features, *fmap;
+	char **name;
+	uint32_t *len;
+} prof_feat;
+
+/* msam_profile.c:712-755: --multi and --unit by prefix match, length normalisation */
+static void prof_opts_derive(prof_opts *o) {
+	int i;
+	o->total_inserts = o->n_total > 0 ? (int)o->v_total : -1;
+	o->share_type = MSX_MULTI_SHARE_PROPORTIONAL;                     /* :712-728, prefix match */
+	if (o->multi) {
+		const char *types[5] = {"", "all", "equal", "proportional", "ignore"};
+		o->share_type = -1;
+		for (i = 1; i <= 4; i++)
+			if (strncmp(o->multi, types[i], strlen(o->multi)) == 0) { o->share_type = i; break; }
+		if (o->share_type == -1) mDie("Do not understand --multi=%s", o->multi);
+	}
+	o->unit_type = 1;                                                 /* :732-748 */
+	if (o->unit) {
+		const char *types[5] = {"", "relative", "fpkm", "tpm", "abundance"};
+		o->unit_type = -1;
+		for (i = 1; i <= 4; i++)
+			if (strncmp(o->unit, types[i], strlen(o->unit)) == 0) { o->unit_type = i; break; }
+		if (o->unit_type == -1) mDie("Do not understand --unit=%s", o->unit);
+	}
+	o->length_normalize = 1;
+	if (o->unit_type == 1 || o->unit_type == 4) o->length_normalize = (o->nolen == 0);   /* :752-755 */
+}
+
+static void prof_features(const prof_opts *o, const msh_hdr *hdr, prof_feat *F) {
+	F->fmap = NULL;
+	if (o->genome) {
+		F->fmap = msh_genome_map(o->genome, hdr, &F->n_features, &F->name, &F->len);     /* :757-852 */
+	} else {
+		F->n_features = hdr->n_targets;
+		F->name = hdr->target_name;
+		F->len = hdr->target_len;
+	}
+}
+
+/* msam_profile.c:858-983 + mMatrix.c:137-179,359-376: post-processing and the text, in the reference's order.
+ * row[0] = Unknown, row[1 + i] = abundance of feature i as mInsertCountToAbundanceMatrix left it. */
+static void profile_report(const prof_opts *o, const prof_feat *F, const msx_profile_stats *st, double *row,
+                           const qn_result *qn, const char *cl) {
+	const int32_t n_features = F->n_features;
+	int total_inserts = o->total_inserts, mapped_inserts = (int)st->insert_count, i;
+	double purged_insert_equivalent = 0, purged_inserts, effective_inserts;
+	char qmsg[1024];
+	gzFile gz;
+	if (o->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		int k;
+		for (k = 1; k <= st->iterations; k++)
+			fprintf(stderr, "#     PropSharing Iteration: %2d; DELTA^2=%g%s\n", k, st->delta[k],
+			        (k == st->iterations && st->converged) ? ". CONVERGED!" : "");
+		fprintf(stderr, "# End   PropSharing!\n");
+		fprintf(stderr, "# Purged %d inserts that mapped to features without unique inserts.\n",
+		        (int)st->purged_insert_count);
+	}
+	row[0] = 0.0;
+	if (o->n_mincount > 0) {                                          /* :858-869 */
+		int mincount = (int)o->v_mincount;
+		for (i = 1; i < n_features + 1; i++)
+			if (row[i] < mincount) { purged_insert_equivalent += row[i]; row[i] = 0; }
+		fprintf(stderr, "# Purged %.7g insert-equivalents from low-abundance features based on --mincount.\n",
+		        purged_insert_equivalent);
+	}
+	if (total_inserts > 0 && total_inserts < mapped_inserts) {        /* :873-876 */
+		fprintf(stderr, "# Ignoring 'unknown' fraction, as total inserts (%d) < mapped inserts (%d)!\n", total_inserts,
+		        mapped_inserts);
+		total_inserts = -1;
+	}
+	gz = strcmp(o->out, "-") == 0 ? gzdopen(fileno(stdout), "wb") : gzopen(o->out, "wb");   /* :879-883 */
+	if (!gz) mDie("Cannot open %s for writing", o->out);
+	gzbuffer(gz, 1 << 20);
+	qn_format(qn, qmsg, sizeof qmsg);
+	gzprintf(gz, "# msamtools version: %s\n", MSH_VERSION);           /* msam_helper.c:145-148 */
+	gzprintf(gz, "# msamtools git commit: %s\n", MSH_GIT_COMMIT);
+	gzprintf(gz, "# Command line: %s\n", cl);
+	gzprintf(gz, "# %s\n", qmsg);
+	purged_inserts = st->purged_insert_count + purged_insert_equivalent;   /* :889-903 */
+	effective_inserts = mapped_inserts - purged_inserts;
+	if (o->share_type == MSX_MULTI_IGNORE) effective_inserts -= st->multi_mapper_count;
+	print_stats_int(gz, 1, "Total inserts", total_inserts, total_inserts, NULL);
+	print_stats_int(gz, 1, "Mapped inserts", mapped_inserts, total_inserts, NULL);
+	print_stats_int(gz, 0, "- Multiple mapped ", (int)st->multi_mapper_count, total_inserts, NULL);
+	print_stats_int(gz, 0, "- Uniquely mapped ", (int)st->uniq_mapper_count, total_inserts, NULL);
+	print_stats_dbl(gz, 1, "Purged inserts", purged_inserts, total_inserts,
+	                "due to ambiguous mapping or low abundance features");
+	print_stats_dbl(gz, 1, "Effective inserts", effective_inserts, total_inserts, NULL);
+	if (total_inserts <= 0) gzprintf(gz, "# Estimated seq. length for 'Unknown': NA\n");
+	if (total_inserts > 0) {                                          /* :906-934 */
+		row[0] = total_inserts - mapped_inserts + purged_inserts;
+		if (o->share_type == MSX_MULTI_IGNORE) row[0] += st->multi_mapper_count;
+		if (o->length_normalize) {
+			int count = 0;
+			uint64_t sum = 0;
+			uint32_t unknown_size;
+			for (i = 0; i < n_features; i++) { sum += F->len[i]; count++; }
+			unknown_size = (uint32_t)(sum / (uint64_t)count);
+			gzprintf(gz, "# Estimated seq. length for 'Unknown': %dbp\n", unknown_size);
+			row[0] = 1.0 * row[0] / unknown_size;
+		} else {
+			gzprintf(gz, "# Estimated seq. length for 'Unknown': NA\n");
+		}
+	}
+	if (o->length_normalize)                                          /* :937-947 */
+		for (i = 0; i < n_features; i++) row[1 + i] /= F->len[i];
+	switch (o->unit_type) {                                           /* :950-975, mMatrix.c:137-179 */
+	case 2: {
+		double d = total_inserts > 0 ? 1.0E9 / total_inserts : 1.0E9 / mapped_inserts;
+		for (i = 0; i < n_features + 1; i++) row[i] *= d;
+		break;
+	}
+	case 3:
+	case 1: {
+		double sum = 0;
+		for (i = 0; i < n_features + 1; i++) sum += row[i];
+		for (i = 0; i < n_features + 1; i++) row[i] /= sum;
+		if (o->unit_type == 3)
+			for (i = 0; i < n_features + 1; i++) row[i] *= 1.0E6;
+		break;
+	}
+	default: break;
+	}
+	if (o->nopandas == 0) gzprintf(gz, "ID\t");                       /* mMatrix.c:359-376 */
+	gzprintf(gz, "%s\n", o->label);
+	gzprintf(gz, "Unknown\t%.8g\n", row[0]);
+	{
+		/* "%s\t%.8g\n" per feature: formatted into a buffer, a million gzprintf calls cost more than the numbers */
+		kstr k = {0, 0, 0};
+		for (i = 0; i < n_features; i++) {
+			ks_printf(&k, "%s\t%.8g\n", F->name[i], row[1 + i]);
+			if (k.l > (1u << 20)) { if (gzwrite(gz, k.s, (unsigned)k.l) != (int)k.l) mDie("Write failed"); k.l = 0; }
+		}
+		if (k.l && gzwrite(gz, k.s, (unsigned)k.l) != (int)k.l) mDie("Write failed");
+		free(k.s);
+	}
+	gzclose(gz);
+}
+
+/* The inserts of one sample counted on several devices of this process (or on this rank of several): everything
+ * onto the first context, then mInsertCountToAbundanceMatrix (msam_profile.c:248-425) there.  Leaves g_ctx = ctx[0]. */
+static void profile_combine_and_finalize(msx_ctx **ctx, msx_profile **prof, int n_dev, int share_type, double *row,
+                                         msx_profile_stats *st) {
+	int k;
+	g_ctx = ctx[0];
+	for (k = 1; k < n_dev; k++)
+		if (msx_profile_merge(ctx[0], prof[0], ctx[k], prof[k]) != MSX_OK) mDie("%s", msx_last_error(ctx[0]));
+	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) fprintf(stderr, "# Start PropSharing:\n");
+	if (g_dist) {
+		/* this rank's counts are a shard's: sum them over the ranks, iterate with the increment all-reduced */
+		MSX(msx_profile_finalize_dist_enqueue(g_ctx, prof[0]));
+		MSX(msx_profile_fetch(g_ctx, prof[0], row + 1, st));
+	} else {
+		MSX(msx_profile_finalize(g_ctx, prof[0], row + 1, st));
+	}
+}
+
+/* the communicator of a rank-per-process run is made BEFORE the input is read: a rank that finishes reading minutes
+ * after another would otherwise find its peers' rendezvous timed out */
+static void dist_begin(void) {
+	if (g_dist) MSX(msx_dist_init_env(g_ctx));
+}
+
+/* ---- filter over the pipeline ----------------------------------------------------------------------- */
+typedef struct fshared fshared;
+typedef struct {
+	fshared *S;
+	int dev_id, index;
+	msx_ctx *ctx;
+	msx_profile *prof;          /* filter --profile-out: this device's part of the sample */
+	pthread_t th;
 	double t_ctx, t_upload, t_gpu, t_fetch, t_wait;
 } fdev_t;
 
+struct fshared {
+	pipe_t *P;
+	const msx_filter_params *fp;
+	int pools, out_mode, argc, n_dev, n_done;
+	char **argv;
+	msh_out *out;               /* created by the device thread that sees batch 0, after its preflight */
+	pthread_mutex_t mu;
+	qn_result qn;
+	const prof_opts *po;        /* filter --profile-out, else NULL */
+	const prof_feat *pf;
+	fdev_t dev[MSH_MAX_DEVICES];
+};
+
+/* preflight on the first records (msam_filter.c:478-482), then the header with its @PG line */
+static void filter_open_output(fshared *F, const rbatch *first) {
+	pipe_t *P = F->P;
+	qn_result qn = {QN_NOT_REQUIRED, 0, 0, 0};
+	char qmsg[1024], ds[1300], *cl;
+	kstr htext = {0, 0, 0};
+	rbatch empty;
+	memset(&empty, 0, sizeof empty);
+	if (F->pools || F->po) qn = qn_check(P->hdr, first ? first : &empty);     /* (profile checks always: msam_profile.c:708) */
+	F->qn = qn;
+	if (!F->pools) { qn_result nr = {QN_NOT_REQUIRED, 0, 0, 0}; qn_format(&nr, qmsg, sizeof qmsg); }
+	else qn_format(&qn, qmsg, sizeof qmsg);
+	cl = command_line(F->argc, F->argv);
+	snprintf(ds, sizeof ds, "git=%s; %s", MSH_GIT_COMMIT, qmsg);      /* msam_helper.c:159-164 */
+	if (P->hdr->text.l) ks_put(&htext, P->hdr->text.s, P->hdr->text.l);
+	msh_hdr_add_pg(&htext, PROGRAM, MSH_VERSION, cl, ds);
+	F->out = msh_out_open(stdout, F->out_mode, P->hdr, htext.s);
+	free(cl);
+	free(htext.s);
+}
+
 static void *filter_dev_thread(void *arg) {
-	fdev_t *F = (fdev_t *)arg;
+	fdev_t *D = (fdev_t *)arg;
+	fshared *F = D->S;
 	pipe_t *P = F->P;
 	msx_stage *stage = NULL;
-	int first = 1;
 	{
 		double t0 = now_s();
-		ctx_open();                          /* HIP start-up runs beside the decoding of the first batch */
+		ctx_open_dev(D->dev_id);             /* HIP start-up runs beside the decoding of the first batch */
+		D->ctx = g_ctx;
 		MSX(msx_stage_create(g_ctx, &stage));
-		F->t_ctx = now_s() - t0;
+		if (F->po)
+			MSX(msx_profile_create(g_ctx, &D->prof, F->pf->n_features, F->po->share_type, F->pf->fmap, P->hdr->n_targets));
+		D->t_ctx = now_s() - t0;
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
 		const int si = pq_pop(&P->q_dev);
-		pslot *s = &P->slot[si];
-		rbatch *b = &s->b;
+		pslot *s;
+		rbatch *b;
 		msx_batch hb, db;
 		msx_filter_out fo;
 		msx_filter_status st;
 		t1 = now_s();
-		F->t_wait += t1 - t0;
-		if (first) {
-			/* preflight on the first records (msam_filter.c:478-482), then the header with its @PG line */
-			qn_result qn = {QN_NOT_REQUIRED, 0, 0, 0};
-			char qmsg[1024], ds[1300], *cl;
-			kstr htext = {0, 0, 0};
-			if (F->pools && !s->eof) qn = qn_check(P->hdr, b);
-			qn_format(&qn, qmsg, sizeof qmsg);
-			cl = command_line(F->argc, F->argv);
-			snprintf(ds, sizeof ds, "git=%s; %s", MSH_GIT_COMMIT, qmsg);      /* msam_helper.c:159-164 */
-			if (P->hdr->text.l) ks_put(&htext, P->hdr->text.s, P->hdr->text.l);
-			msh_hdr_add_pg(&htext, PROGRAM, MSH_VERSION, cl, ds);
-			F->out = msh_out_open(stdout, F->out_mode, P->hdr, htext.s);
-			free(cl);
-			free(htext.s);
-			first = 0;
-			t1 = now_s();
-		}
-		if (s->eof) { pq_push(&P->q_out, si); break; }
+		D->t_wait += t1 - t0;
+		if (si == PQ_END) break;
+		s = &P->slot[si];
+		b = &s->b;
+		if (s->seq == 0) { filter_open_output(F, b); t1 = now_s(); }
 		pipe_pin_slot(P, s);
-		rb_host_view(b, &hb, F->pools);
+		rb_host_view(b, &hb, P->mode != 0);
+		hb.pool_rule = (F->pools && F->po) ? MSX_POOLS_FILTER : MSX_POOLS_PROFILE;
 		MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
-		MSX(msx_stage_outputs(g_ctx, stage, (int64_t)b->n, 0, &fo));
-		F->t_upload += now_s() - t1; t1 = now_s();
-		MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
+		MSX(msx_stage_outputs(g_ctx, stage, (int64_t)b->n, F->fp->rescore, &fo));
+		D->t_upload += now_s() - t1; t1 = now_s();
+		if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
+		else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
 		if (msx_filter_finish(g_ctx, &st) != MSX_OK) mDie("%s", msx_last_error(g_ctx));   /* the reference's own mDie texts */
-		F->t_gpu += now_s() - t1; t1 = now_s();
+		D->t_gpu += now_s() - t1; t1 = now_s();
 		s->n_emit = st.n_emit;
 		MSX(msx_dev_to_host(g_ctx, s->emit, fo.emit_idx, 4 * (size_t)st.n_emit));
-		F->t_fetch += now_s() - t1;
+		if (F->fp->rescore) MSX(msx_dev_to_host(g_ctx, s->as_out, fo.as_out, 4 * b->n));
+		D->t_fetch += now_s() - t1;
 		pq_push(&P->q_out, si);
 	}
+	MSX(msx_ctx_sync(g_ctx));
 	msx_stage_destroy(g_ctx, stage);
+	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
+	pthread_mutex_lock(&F->mu);
+	if (++F->n_done == F->n_dev) {
+		if (__atomic_load_n(&P->n_filled, __ATOMIC_ACQUIRE) == 0) filter_open_output(F, NULL);
+		pq_push(&P->q_out, PQ_END);
+	}
+	pthread_mutex_unlock(&F->mu);
 	return NULL;
 }
 
+/* the writer's side of q_out: the slot that holds batch `seq` (device threads finish in any order), or PQ_END */
+static int pq_pop_seq(pq *q, const pipe_t *P, size_t seq) {
+	int i, v = PQ_END - 1;
+	pthread_mutex_lock(&q->mu);
+	for (;;) {
+		int end = 0;
+		for (i = 0; i < q->n; i++) {
+			if (q->item[i] == PQ_END) { end = 1; continue; }
+			if (P->slot[q->item[i]].seq == seq) break;
+		}
+		if (i < q->n) {
+			v = q->item[i];
+			for (i = i + 1; i < q->n; i++) q->item[i - 1] = q->item[i];
+			q->n--;
+			break;
+		}
+		if (end) { v = PQ_END; break; }       /* (pushed after every batch: nothing more can arrive) */
+		pthread_cond_wait(&q->cv, &q->mu);
+	}
+	pthread_mutex_unlock(&q->mu);
+	return v;
+}
+
+/* --rescore: the emitted records of a batch rewritten (first AS dropped, AS:i appended: msam_filter.c:160-168),
+ * in parallel into one buffer the block writer then reads from */
+typedef struct {
+	const pslot *s;
+	int pass;
+	size_t *off;             /* [n_emit + 1] offsets into blob (each record with its 4-byte length) */
+	uint8_t *blob;
+} rescore_job;
+
+static void rescore_worker(void *arg, int tid, int nth) {
+	rescore_job *J = (rescore_job *)arg;
+	const pslot *s = J->s;
+	const rbatch *b = &s->b;
+	const size_t n = (size_t)s->n_emit, lo = n * (size_t)tid / (size_t)nth, hi = n * (size_t)(tid + 1) / (size_t)nth;
+	size_t i;
+	kstr tmp = {0, 0, 0};
+	for (i = lo; i < hi; i++) {
+		const size_t k = (size_t)s->emit[i];
+		const uint8_t *r = RB_REC(b, k);
+		const size_t len = RB_LEN(b, k);
+		const int mapped = !(b->flag[k] & 4);
+		if (J->pass == 0) {
+			size_t out_len = len;
+			if (mapped) {
+				const uint8_t *as = msh_aux_get(r, len, "AS");
+				out_len = len - (as ? 2 + msh_aux_size(as, r + len) : 0) + 7;
+			}
+			J->off[i] = 4 + out_len;
+		} else {
+			uint8_t *o = J->blob + J->off[i];
+			const uint8_t *src = r;
+			size_t l = len;
+			if (mapped) { rescore_record(r, len, s->as_out[k], &tmp); src = (const uint8_t *)tmp.s; l = tmp.l; }
+			o[0] = (uint8_t)l; o[1] = (uint8_t)(l >> 8); o[2] = (uint8_t)(l >> 16); o[3] = (uint8_t)(l >> 24);
+			memcpy(o + 4, src, l);
+		}
+	}
+	free(tmp.s);
+}
+
 static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, int want_stats, int out_mode, int argc,
-                            char *argv[]) {
+                            char *argv[], const prof_opts *po) {
 	static pipe_t P;
-	fdev_t F;
-	pthread_t th_dec, th_dev;
+	static fshared F;
+	prof_feat pf;
+	pthread_t th_dec;
 	double t_start = now_s(), tw = 0, t_wait = 0;
-	size_t n_in = 0, n_out = 0, n_batches = 0;
-	pipe_init(&P, in, pools ? 1 : 0, want_stats);
+	size_t n_in = 0, n_out = 0, n_batches = 0, seq = 0;
+	int dev_ids[MSH_MAX_DEVICES], k;
+	rescore_job RJ;
+	int32_t *ident = NULL;
+	size_t ident_cap = 0;
+	const int unmapped_written = fp->keep_unmapped && fp->ppt >= 0 && fp->invert &&
+	                             ((fp->min_length > 0) || fp->ppt != 0 || fp->max_clip < 100);   /* msam_filter.c:132-138 */
 	memset(&F, 0, sizeof F);
-	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv;
-	if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0 || pthread_create(&th_dev, NULL, filter_dev_thread, &F) != 0)
-		mDie("pthread_create failed");
-	for (;;) {                                   /* this thread is the encode stage */
+	memset(&RJ, 0, sizeof RJ);
+	memset(&pf, 0, sizeof pf);
+	F.n_dev = device_list(dev_ids);
+	/* pools: filter's own rule when best-hit selection needs them; with --profile-out and no best hit, profile's rule
+	 * over the records filter can write (filter's output does not depend on pools then) */
+	pipe_init(&P, in, pools ? 1 : (po ? 3 : 0), want_stats, F.n_dev);
+	P.unmapped_visible = unmapped_written;
+	P.cut_mapped = pools && po;
+	if (fp->rescore)
+		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
+	if (po) prof_features(po, P.hdr, &pf);
+	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv; F.po = po; F.pf = &pf;
+	pthread_mutex_init(&F.mu, NULL);
+	if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
+	for (k = 0; k < F.n_dev; k++) {
+		F.dev[k].S = &F; F.dev[k].dev_id = dev_ids[k]; F.dev[k].index = k;
+		if (pthread_create(&F.dev[k].th, NULL, filter_dev_thread, &F.dev[k]) != 0) mDie("pthread_create failed");
+	}
+	for (;;) {                                   /* this thread is the encode stage: batches in input order */
 		double t0 = now_s(), t1;
-		const int si = pq_pop(&P.q_out);
-		pslot *s = &P.slot[si];
+		const int si = pq_pop_seq(&P.q_out, &P, seq);
+		pslot *s;
 		t1 = now_s();
 		t_wait += t1 - t0;
-		if (s->eof) break;
-		msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
+		if (si == PQ_END) break;
+		s = &P.slot[si];
+		if (!fp->rescore) {
+			msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
+		} else if (s->n_emit > 0) {
+			const size_t n = (size_t)s->n_emit;
+			size_t i, tot = 0;
+			RJ.s = s;
+			RJ.off = (size_t *)realloc(RJ.off, (n + 1) * sizeof(size_t));
+			if (n > ident_cap) {
+				ident_cap = n + n / 4 + 1024;
+				ident = (int32_t *)realloc(ident, ident_cap * 4);
+				if (!ident) mDie("Out of memory");
+				for (i = 0; i < ident_cap; i++) ident[i] = (int32_t)i;
+			}
+			RJ.pass = 0;
+			msh_parallel(msh_threads(), rescore_worker, &RJ);
+			for (i = 0; i < n; i++) { const size_t z = RJ.off[i]; RJ.off[i] = tot; tot += z; }
+			RJ.off[n] = tot;
+			RJ.blob = (uint8_t *)realloc(RJ.blob, tot + 16);
+			if (!RJ.off || !RJ.blob) mDie("Out of memory");
+			RJ.pass = 1;
+			msh_parallel(msh_threads(), rescore_worker, &RJ);
+			msh_write_many(F.out, RJ.blob, RJ.off, ident, n);
+		}
 		n_batches++;
+		seq++;
 		n_in += s->b.n;
 		n_out += (size_t)s->n_emit;
 		tw += now_s() - t1;
 		pq_push(&P.q_free, si);
 	}
 	pthread_join(th_dec, NULL);
-	pthread_join(th_dev, NULL);
+	for (k = 0; k < F.n_dev; k++) pthread_join(F.dev[k].th, NULL);
 	msh_out_close(F.out);
-	if (getenv("MSX_TIMING")) fprintf(stderr, "# batches: %zu\n", n_batches);
-	if (getenv("MSX_TIMING"))
+	if (po) {
+		/* the other half of `filter ... | profile -`, without the pipe, the second decode and the second process */
+		msx_ctx *ctxs[MSH_MAX_DEVICES];
+		msx_profile *profs[MSH_MAX_DEVICES];
+		msx_profile_stats st;
+		double *row = (double *)calloc((size_t)pf.n_features + 1, sizeof(double));
+		char *cl = command_line(argc, argv);
+		for (k = 0; k < F.n_dev; k++) { ctxs[k] = F.dev[k].ctx; profs[k] = F.dev[k].prof; }
+		profile_combine_and_finalize(ctxs, profs, F.n_dev, po->share_type, row, &st);
+		profile_report(po, &pf, &st, row, &F.qn, cl);
+		free(row);
+		free(cl);
+	} else {
+		g_ctx = F.dev[0].ctx;
+	}
+	if (getenv("MSX_TIMING")) {
+		double t_ctx = 0, t_up = 0, t_gpu = 0, t_fetch = 0, t_dw = 0;
+		for (k = 0; k < F.n_dev; k++) {
+			t_ctx += F.dev[k].t_ctx; t_up += F.dev[k].t_upload; t_gpu += F.dev[k].t_gpu; t_fetch += F.dev[k].t_fetch; t_dw += F.dev[k].t_wait;
+		}
+		fprintf(stderr, "# batches: %zu\n", n_batches);
 		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 		        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
-	if (getenv("MSX_TIMING"))
 		fprintf(stderr, "# filter pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
 		        "upload %.3f, kernels %.3f, fetch %.3f (+%.3f waiting for a batch); encode+write %.3f s (+%.3f waiting); "
-		        "%zu records in, %zu out, %d threads\n",
-		        now_s() - t_start, P.t_decode, P.t_wait_free, F.t_ctx, F.t_upload, F.t_gpu, F.t_fetch, F.t_wait, tw, t_wait,
-		        n_in, n_out, msh_threads());
+		        "%zu records in, %zu out, %d threads, %d device%s\n",
+		        now_s() - t_start, P.t_decode, P.t_wait_free, t_ctx, t_up, t_gpu, t_fetch, t_dw, tw, t_wait,
+		        n_in, n_out, msh_threads(), F.n_dev, F.n_dev > 1 ? "s" : "");
+	}
 	fast_exit();
-	msx_ctx_destroy(g_ctx);
+	for (k = 0; k < F.n_dev; k++) {
+		if (F.dev[k].prof) msx_profile_destroy(F.dev[k].ctx, F.dev[k].prof);
+		msx_ctx_destroy(F.dev[k].ctx);
+	}
 	return 0;
 }
 
@@ -1162,7 +1624,16 @@ int msam_filter_main(int argc, char *argv[]) {
 	    {"help", no_argument, 0, 1000},       {"ppt", required_argument, 0, 1001},
 	    {"rescore", no_argument, 0, 1002},    {"besthit", no_argument, 0, 1003},
 	    {"uniqhit", no_argument, 0, 1004},    {"keep_unmapped", no_argument, 0, 'k'},
-	    {"invert", no_argument, 0, 'v'},      {0, 0, 0, 0}};
+	    {"invert", no_argument, 0, 'v'},
+	    /* `filter ... | profile -` in one process (additive; the reference's surface is unchanged): profile's options */
+	    {"profile-out", required_argument, 0, 1100}, {"label", required_argument, 0, 1101},
+	    {"genome", required_argument, 0, 1102},      {"total", required_argument, 0, 1103},
+	    {"mincount", required_argument, 0, 1104},    {"unit", required_argument, 0, 1105},
+	    {"pandas", no_argument, 0, 1106},            {"no-pandas", no_argument, 0, 1107},
+	    {"nolen", no_argument, 0, 1108},             {"multi", required_argument, 0, 1109},
+	    {0, 0, 0, 0}};
+	prof_opts po;
+	int tee;
 	int o_b = 0, o_u = 0, o_h = 0, o_S = 0, o_help = 0, o_k = 0, o_v = 0, o_rescore = 0, o_best = 0, o_uniq = 0;
 	int n_l = 0, n_p = 0, n_ppt = 0, n_z = 0, nerrors = 0, c;
 	long v_l = 0, v_p = 0, v_ppt = 0, v_z = 0;
@@ -1182,6 +1653,7 @@ int msam_filter_main(int argc, char *argv[]) {
 	size_t emit_cap = 0;
 
 	(void)o_S;
+	memset(&po, 0, sizeof po);
 	opterr = 0;
 	optind = 1;
 	while ((c = getopt_long(argc, argv, "buhSkvl:p:z:", lopts, NULL)) != -1) {
@@ -1200,6 +1672,16 @@ int msam_filter_main(int argc, char *argv[]) {
 		case 1002: o_rescore++; break;
 		case 1003: o_best++; break;
 		case 1004: o_uniq++; break;
+		case 1100: po.n_out++; po.out = optarg; break;
+		case 1101: po.n_label++; po.label = optarg; break;
+		case 1102: po.genome = optarg; break;
+		case 1103: po.n_total++; po.v_total = strtol(optarg, NULL, 10); break;
+		case 1104: po.n_mincount++; po.v_mincount = strtol(optarg, NULL, 10); break;
+		case 1105: po.unit = optarg; break;
+		case 1106: po.pandas++; break;
+		case 1107: po.nopandas++; break;
+		case 1108: po.nolen++; break;
+		case 1109: po.multi = optarg; break;
 		default:
 			fprintf(stderr, "%s: invalid option \"%s\"\n", PROGRAM, argv[optind - 1]);
 			nerrors++;
@@ -1226,6 +1708,16 @@ int msam_filter_main(int argc, char *argv[]) {
 	else if (n_p > 0 && n_ppt > 0) BAIL("-p cannot be combined with --ppt");
 	else if (!n_l && !n_p && !n_ppt && !o_uniq && !o_best && !n_z)
 		BAIL("--mode filter needs -l, -p, --ppt, -z, --besthit or --uniqhit");
+	tee = po.n_out > 0;
+	if (!tee && (po.n_label || po.genome || po.n_total || po.n_mincount || po.unit || po.pandas || po.nopandas || po.nolen || po.multi))
+		BAIL("--label, --genome, --total, --mincount, --unit, --pandas, --no-pandas, --nolen and --multi need --profile-out");
+	if (tee) {                                                        /* msam_profile.c:672-700 */
+		if (po.n_label != 1 || po.n_out != 1) BAIL("--profile-out requires --label");
+		if (strcmp(po.out, "-") == 0) BAIL("--profile-out cannot be '-': standard output carries the alignments");
+		if (po.pandas > 0 && po.nopandas > 0) BAIL("--pandas and --no-pandas cannot be used together");
+		if (po.n_total > 0 && po.v_total <= 0) BAIL("--total must be a positive integer");
+		if (po.n_mincount > 0 && po.v_mincount < 0) BAIL("--mincount must be a non-negative integer");
+	}
 	memset(&fp, 0, sizeof fp);
 	if (n_p > 0) {                                                    /* :420-457 */
 		if (v_p < 0 || v_p > 100) BAIL("-p must be in the range [0,100]");
@@ -1260,14 +1752,16 @@ int msam_filter_main(int argc, char *argv[]) {
 	rd.in = msh_open(infile);
 	hdr = msh_header(rd.in);
 
+	if (tee) prof_opts_derive(&po);
 	bulk = msh_is_bam(rd.in);
-	if (bulk && !fp.rescore && !getenv("MSX_SERIAL_IO")) {
+	if (bulk && !getenv("MSX_SERIAL_IO")) {
 		/* BAM in: decode | device | encode as three overlapping stages */
-		int rc = filter_pipelined(rd.in, &fp, pools, want_stats, mode, argc, argv);
+		int rc = filter_pipelined(rd.in, &fp, pools, want_stats, mode, argc, argv, tee ? &po : NULL);
 		msh_close(rd.in);
 		return rc;
 	}
-	/* SAM text in, or --rescore (records are rewritten one by one): one batch at a time */
+	if (tee) mDie("--profile-out needs BAM input (pipe SAM text through `%s recode -u`)", PROGRAM);
+	/* SAM text in (or MSX_SERIAL_IO): one batch at a time */
 	/* first batch: large enough for the preflight window */
 	{
 		size_t t1 = target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS;
@@ -1354,51 +1848,74 @@ int msam_filter_main(int argc, char *argv[]) {
 	return 0;
 }
 
-/* ------------------------------------------------------------------------ */
-/* profile                                                                    */
-/* ------------------------------------------------------------------------ */
-static void profile_help(FILE *out) {
-	fprintf(out,
-	        "Usage:\n------\n\n%s profile [-S] <bamfile> [--help] -o <file> --label=<string> [--genome=<string>] "
-	        "[--total=<int>] [--mincount=<int>] [--unit=<string>] [--pandas] [--no-pandas] [--nolen] [--multi=<string>]\n"
-	        "\nGeneral options:\n----------------\n\n"
-	        "These options specify the input/output formats of BAM/SAM files \n(same meaning as in 'samtools view'):\n"
-	        "  -S                        input is SAM (default: false)\n"
-	        "  <bamfile>                 input SAM/BAM file\n"
-	        "  --help                    print this help and exit\n\n"
-	        "Specific options:\n-----------------\n\n"
-	        "  -o <file>                 name of output file (required)\n"
-	        "  --label=<string>          label to use for the profile; typically the sample id (required)\n"
-	        "  --genome=<string>         tab-delimited genome definition file - 'genome-id<tab>seq-id' (default: none)\n"
-	        "  --total=<int>             number of high-quality inserts (mate-pairs/paired-ends) that were input to the aligner (default: unknown)\n"
-	        "  --mincount=<int>          minimum number of inserts mapped to a feature, below which the feature is counted as absent (default: 0)\n"
-	        "  --unit=<string>           unit of abundance to report {ab | rel | fpkm | tpm} (default: rel)\n"
-	        "  --pandas                  print two columns (ID, sample-label) as header compatible with python pandas (default)\n"
-	        "  --no-pandas               use legacy profile header without the ID column\n"
-	        "  --nolen                   do not normalize the abundance (only relevant for ab or rel) for sequence length (default: normalize)\n"
-	        "  --multi=<string>          how to deal with multi-mappers {all | equal | proportional | ignore} (default: proportional)\n",
-	        PROGRAM);
-}
+/* ---- profile over the pipeline: one device thread per GPU ---------------------------------------------------- */
+typedef struct pshared pshared;
+typedef struct {
+	pshared *S;
+	int dev_id;
+	msx_ctx *ctx;
+	msx_profile *prof;
+	pthread_t th;
+	double t_ctx, t_dev, t_wait;
+	size_t n_in, n_batches;
+} pdev_t;
 
-/* mPrintInsertStats / mPrintInsertStatsDouble (msam_profile.c:434-499) */
-static void print_stats_int(gzFile s, int left, const char *type, int number, int total, const char *post) {
-	int width = 7;
-	if (total > 0) width = (int)(1 + log10(total));
-	gzprintf(s, "# ");
-	if (left) gzprintf(s, "%-20s: ", type); else gzprintf(s, "%20s: ", type);
-	if (strcmp(type, "Total inserts") == 0 && number == -1) gzprintf(s, "%*s (", width, "NA");
-	else gzprintf(s, "%*d (", width, number);
-	if (total > 0) gzprintf(s, "%6.2f", 100.0 * number / total); else gzprintf(s, "%6s", "NA");
-	gzprintf(s, "%%)");
-	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
-}
-static void print_stats_dbl(gzFile s, int left, const char *type, double number, int total, const char *post) {
-	gzprintf(s, "# ");
-	if (left) gzprintf(s, "%-20s: ", type); else gzprintf(s, "%20s: ", type);
-	gzprintf(s, "%10.7g (", number);
-	if (total > 0) gzprintf(s, "%6.2f", 100.0 * number / total); else gzprintf(s, "%6s", "NA");
-	gzprintf(s, "%%)");
-	if (post) gzprintf(s, " %s\n", post); else gzprintf(s, "\n");
+struct pshared {
+	pipe_t *P;
+	const prof_opts *o;
+	const prof_feat *F;
+	qn_result qn;
+	int n_dev;
+	pdev_t dev[MSH_MAX_DEVICES];
+};
+
+static void *profile_dev_thread(void *arg) {
+	pdev_t *D = (pdev_t *)arg;
+	pshared *S = D->S;
+	pipe_t *P = S->P;
+	msx_stage *stage = NULL;
+	msx_event *ev[PIPE_SLOTS_MAX] = {NULL};
+	int held = -1, q;                          /* slot whose uploads may still be in flight */
+	double t0 = now_s();
+	ctx_open_dev(D->dev_id);                     /* HIP start-up runs beside the decoding of the first batch */
+	D->ctx = g_ctx;
+	if (D == &S->dev[0]) dist_begin();
+	MSX(msx_stage_create(g_ctx, &stage));
+	MSX(msx_profile_create(g_ctx, &D->prof, S->F->n_features, S->o->share_type, S->F->fmap, P->hdr->n_targets));   /* :855 */
+	D->t_ctx = now_s() - t0;
+	for (;;) {
+		double t1;
+		int si;
+		pslot *s;
+		msx_batch hb, db;
+		t0 = now_s();
+		si = pq_pop(&P->q_dev);
+		t1 = now_s();
+		D->t_wait += t1 - t0;
+		if (si == PQ_END) break;
+		s = &P->slot[si];
+		if (s->seq == 0) S->qn = qn_check(P->hdr, &s->b);            /* :708, always for profile */
+		pipe_pin_slot(P, s);
+		rb_host_view(&s->b, &hb, 1);
+		hb.cigar_off = NULL; hb.cigar = NULL; hb.md_off = NULL; hb.md = NULL;   /* profile reads tid only */
+		hb.nm = NULL; hb.as = NULL; hb.pos = NULL; hb.flag = NULL; hb.rflags = NULL;
+		MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
+		/* the slot's page-locked arrays go back to the decoder once these copies have left -- a marker per slot,
+		 * waited for one batch later, instead of a stream synchronisation per batch */
+		if (!ev[si]) MSX(msx_event_create(g_ctx, &ev[si]));
+		MSX(msx_event_record(g_ctx, ev[si]));
+		MSX(msx_profile_accumulate(g_ctx, D->prof, &db, NULL));
+		D->n_in += s->b.n;
+		D->n_batches++;
+		if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); }
+		held = si;
+		D->t_dev += now_s() - t1;
+	}
+	if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); }
+	MSX(msx_ctx_sync(g_ctx));
+	msx_stage_destroy(g_ctx, stage);
+	for (q = 0; q < PIPE_SLOTS_MAX; q++) msx_event_destroy(g_ctx, ev[q]);
+	return NULL;
 }
 
 int msam_profile_main(int argc, char *argv[]) {
@@ -1409,45 +1926,39 @@ int msam_profile_main(int argc, char *argv[]) {
 	    {"pandas", no_argument, 0, 1006},      {"no-pandas", no_argument, 0, 1007},
 	    {"nolen", no_argument, 0, 1008},       {"multi", required_argument, 0, 1009},
 	    {0, 0, 0, 0}};
-	const char *o_out = NULL, *o_label = NULL, *o_genome = NULL, *o_unit = NULL, *o_multi = NULL;
-	int n_out = 0, n_label = 0, n_total = 0, n_mincount = 0, o_pandas = 0, o_nopandas = 0, o_nolen = 0, o_help = 0;
-	long v_total = 0, v_mincount = 0;
-	int nerrors = 0, c, i;
-	int share_type, unit_type, length_normalize = 1, total_inserts = -1, mapped_inserts;
-	double purged_insert_equivalent = 0, purged_inserts, effective_inserts;
+	prof_opts o;
+	prof_feat F;
+	int o_help = 0, nerrors = 0, c;
 	msh_in *in;
 	const msh_hdr *hdr;
 	rbatch b;
 	qn_result qn;
-	int32_t n_features, *fmap = NULL;
-	char **feature_name;
-	uint32_t *feature_len;
-	msx_profile *prof;
+	msx_profile *prof = NULL;
 	msx_profile_stats st;
 	double *row;
 	kstr rec = {0, 0, 0};
-	char prev_read[256], qmsg[1024], *cl;
+	char prev_read[256], *cl;
 	int have_prev = 0, eof = 0, have_pending = 0, first = 1;
 	size_t target = batch_target();
-	gzFile gz;
 	static reader prof_rd;
 
+	memset(&o, 0, sizeof o);
 	opterr = 0;
 	optind = 1;
 	while ((c = getopt_long(argc, argv, "So:", lopts, NULL)) != -1) {
 		switch (c) {
 		case 'S': break;
-		case 'o': n_out++; o_out = optarg; break;
+		case 'o': o.n_out++; o.out = optarg; break;
 		case 1000: o_help++; break;
-		case 1001: n_label++; o_label = optarg; break;
-		case 1002: o_genome = optarg; break;
-		case 1003: n_total++; v_total = strtol(optarg, NULL, 10); break;
-		case 1004: n_mincount++; v_mincount = strtol(optarg, NULL, 10); break;
-		case 1005: o_unit = optarg; break;
-		case 1006: o_pandas++; break;
-		case 1007: o_nopandas++; break;
-		case 1008: o_nolen++; break;
-		case 1009: o_multi = optarg; break;
+		case 1001: o.n_label++; o.label = optarg; break;
+		case 1002: o.genome = optarg; break;
+		case 1003: o.n_total++; o.v_total = strtol(optarg, NULL, 10); break;
+		case 1004: o.n_mincount++; o.v_mincount = strtol(optarg, NULL, 10); break;
+		case 1005: o.unit = optarg; break;
+		case 1006: o.pandas++; break;
+		case 1007: o.nopandas++; break;
+		case 1008: o.nolen++; break;
+		case 1009: o.multi = optarg; break;
 		default:
 			fprintf(stdout, "%s: invalid option \"%s\"\n", PROGRAM, argv[optind - 1]);
 			nerrors++;
@@ -1455,8 +1966,8 @@ int msam_profile_main(int argc, char *argv[]) {
 	}
 	if (o_help > 0 || argc < 2) { profile_help(stdout); exit(EXIT_SUCCESS); }
 	if (argc - optind < 1) { fprintf(stdout, "%s: missing option <bamfile>\n", PROGRAM); nerrors++; }
-	if (n_out == 0) { fprintf(stdout, "%s: missing option -o <file>\n", PROGRAM); nerrors++; }
-	if (n_label == 0) { fprintf(stdout, "%s: missing option --label=<string>\n", PROGRAM); nerrors++; }
+	if (o.n_out == 0) { fprintf(stdout, "%s: missing option -o <file>\n", PROGRAM); nerrors++; }
+	if (o.n_label == 0) { fprintf(stdout, "%s: missing option --label=<string>\n", PROGRAM); nerrors++; }
 	if (nerrors > 0) {                                                /* msam_profile.c:664-668 (stdout) */
 		fprintf(stdout, "Use --help for usage instructions!\n");
 		mQuit("");
@@ -1468,116 +1979,78 @@ int msam_profile_main(int argc, char *argv[]) {
 		mQuit("");
 	}
 #define BAIL(msg) do { fprintf(stdout, "%s\n", msg); profile_help(stdout); mQuit(""); } while (0)
-	if (n_label != 1 || n_out != 1) BAIL("requires --label and -o");
-	if (o_pandas > 0 && o_nopandas > 0) BAIL("--pandas and --no-pandas cannot be used together");
-	if (n_total > 0) {
-		total_inserts = (int)v_total;
-		if (total_inserts <= 0) BAIL("--total must be a positive integer");
-	}
-	if (n_mincount > 0 && v_mincount < 0) BAIL("--mincount must be a non-negative integer");
+	if (o.n_label != 1 || o.n_out != 1) BAIL("requires --label and -o");
+	if (o.pandas > 0 && o.nopandas > 0) BAIL("--pandas and --no-pandas cannot be used together");
+	if (o.n_total > 0 && (int)o.v_total <= 0) BAIL("--total must be a positive integer");
+	if (o.n_mincount > 0 && o.v_mincount < 0) BAIL("--mincount must be a non-negative integer");
 #undef BAIL
 
 	{
-		/* "{rank}" in the path names this rank's shard */
-		const char *path = argv[optind], *ph = strstr(path, "{rank}");
-		if (ph && dist_world() > 1) {
-			static char shard[4096];
+		/* One rank of several (one process per GPU, RANK / WORLD_SIZE / MASTER_* in the environment): asked for with
+		 * "{rank}" in the input path -- replaced by the rank: every rank reads ITS shard -- or MSX_DIST=1 (tests: the
+		 * same path over a one-rank communicator).  A WORLD_SIZE that is merely present is refused, not obeyed: every
+		 * rank would read the whole file and the all-reduce would multiply every count by the number of ranks. */
+		const char *path = argv[optind], *ph = strstr(path, "{rank}"), *md = getenv("MSX_DIST");
+		static char shard[4096];
+		g_dist = (md && atoi(md) != 0) || getenv("MSX_FORCE_DIST") != NULL || (ph != NULL && dist_world() > 1);
+		if (!g_dist && dist_world() > 1 && getenv("RANK") && !(md && atoi(md) == 0))
+			mDie("WORLD_SIZE=%d is set but the input path has no \"{rank}\": as one rank of %d this command reads its own shard "
+			     "(e.g. sample.shard{rank}.bam, cut at QNAME boundaries).  Unset WORLD_SIZE or set MSX_DIST=0 to run it as an "
+			     "ordinary single process.", dist_world(), dist_world());
+		if (ph && g_dist) {
 			snprintf(shard, sizeof shard, "%.*s%d%s", (int)(ph - path), path, dist_rank(), ph + 6);
 			path = shard;
 		}
 		in = msh_open(path);
 	}
 	hdr = msh_header(in);
-
-	share_type = MSX_MULTI_SHARE_PROPORTIONAL;                        /* :712-728, prefix match */
-	if (o_multi) {
-		const char *types[5] = {"", "all", "equal", "proportional", "ignore"};
-		share_type = -1;
-		for (i = 1; i <= 4; i++)
-			if (strncmp(o_multi, types[i], strlen(o_multi)) == 0) { share_type = i; break; }
-		if (share_type == -1) mDie("Do not understand --multi=%s", o_multi);
-	}
-	unit_type = 1;                                                    /* :732-748 */
-	if (o_unit) {
-		const char *types[5] = {"", "relative", "fpkm", "tpm", "abundance"};
-		unit_type = -1;
-		for (i = 1; i <= 4; i++)
-			if (strncmp(o_unit, types[i], strlen(o_unit)) == 0) { unit_type = i; break; }
-		if (unit_type == -1) mDie("Do not understand --unit=%s", o_unit);
-	}
-	if (unit_type == 1 || unit_type == 4) length_normalize = (o_nolen == 0);   /* :752-755 */
-
-	if (o_genome) {
-		fmap = msh_genome_map(o_genome, hdr, &n_features, &feature_name, &feature_len);
-	} else {
-		n_features = hdr->n_targets;
-		feature_name = hdr->target_name;
-		feature_len = hdr->target_len;
-	}
+	prof_opts_derive(&o);
+	prof_features(&o, hdr, &F);
 
 	/* mEstimateInsertCountOnFile (:204-243): pools by QNAME over records with tid != -1 */
 	memset(&b, 0, sizeof b);
 	memset(&qn, 0, sizeof qn);
+	row = (double *)calloc((size_t)F.n_features + 1, sizeof(double));
 	if (msh_is_bam(in) && !getenv("MSX_SERIAL_IO")) {
-		/* BAM in: the decode stage runs on its own thread, this one feeds the device */
+		/* BAM in: the decode stage on its own thread feeds one device thread per GPU */
 		static pipe_t P;
+		static pshared S;
 		pthread_t th_dec;
-		msx_stage *stage = NULL;
-		double t_start = now_s(), t_dev = 0, t_wait = 0, t_ctx;
-		size_t n_in = 0;
-		msx_event *ev[PIPE_SLOTS] = {NULL};
-		int held = -1;                           /* slot whose uploads may still be in flight */
-		size_t n_batches = 0;
-		pipe_init(&P, in, 2, 0);
+		msx_ctx *ctxs[MSH_MAX_DEVICES];
+		msx_profile *profs[MSH_MAX_DEVICES];
+		int dev_ids[MSH_MAX_DEVICES], k;
+		double t_start = now_s(), t_ctx = 0, t_dev = 0, t_wait = 0;
+		size_t n_in = 0, n_batches = 0;
+		memset(&S, 0, sizeof S);
+		S.n_dev = device_list(dev_ids);
+		pipe_init(&P, in, 2, 0, S.n_dev);
+		S.P = &P; S.o = &o; S.F = &F;
 		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
-		ctx_open();                              /* HIP start-up runs beside the decoding of the first batch */
-		MSX(msx_stage_create(g_ctx, &stage));
-		t_ctx = now_s() - t_start;
-		for (;;) {
-			double t0 = now_s(), t1;
-			const int si = pq_pop(&P.q_dev);
-			pslot *s = &P.slot[si];
-			t1 = now_s();
-			t_wait += t1 - t0;
-			if (first) {
-				if (!s->eof) qn = qn_check(hdr, &s->b); else { rbatch e; memset(&e, 0, sizeof e); qn = qn_check(hdr, &e); }   /* :708, always for profile */
-				first = 0;
-				MSX(msx_profile_create(g_ctx, &prof, n_features, share_type, fmap, hdr->n_targets));   /* :855 */
-			}
-			if (s->eof) break;
-			{
-				msx_batch hb, db;
-				pipe_pin_slot(&P, s);
-				rb_host_view(&s->b, &hb, 1);
-				hb.cigar_off = NULL; hb.cigar = NULL; hb.md_off = NULL; hb.md = NULL;   /* profile reads tid only */
-				hb.nm = NULL; hb.as = NULL; hb.pos = NULL; hb.flag = NULL; hb.rflags = NULL;
-				MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
-				/* the slot's page-locked arrays go back to the decoder once these copies have left -- a marker per
-				 * slot, waited for one batch later, instead of a stream synchronisation per batch */
-				if (!ev[si]) MSX(msx_event_create(g_ctx, &ev[si]));
-				MSX(msx_event_record(g_ctx, ev[si]));
-				MSX(msx_profile_accumulate(g_ctx, prof, &db, NULL));
-				n_in += s->b.n;
-				n_batches++;
-			}
-			if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P.q_free, held); }
-			held = si;
-			t_dev += now_s() - t1;
+		for (k = 0; k < S.n_dev; k++) {
+			S.dev[k].S = &S; S.dev[k].dev_id = dev_ids[k];
+			if (pthread_create(&S.dev[k].th, NULL, profile_dev_thread, &S.dev[k]) != 0) mDie("pthread_create failed");
 		}
-		if (held >= 0) MSX(msx_event_wait(g_ctx, ev[held]));
 		pthread_join(th_dec, NULL);
-		MSX(msx_ctx_sync(g_ctx));
-		msx_stage_destroy(g_ctx, stage);
-		{ int q; for (q = 0; q < PIPE_SLOTS; q++) msx_event_destroy(g_ctx, ev[q]); }
-		if (getenv("MSX_TIMING")) fprintf(stderr, "# batches: %zu\n", n_batches);
-		if (getenv("MSX_TIMING"))
+		for (k = 0; k < S.n_dev; k++) {
+			pthread_join(S.dev[k].th, NULL);
+			ctxs[k] = S.dev[k].ctx; profs[k] = S.dev[k].prof;
+			t_ctx += S.dev[k].t_ctx; t_dev += S.dev[k].t_dev; t_wait += S.dev[k].t_wait;
+			n_in += S.dev[k].n_in; n_batches += S.dev[k].n_batches;
+		}
+		if (P.n_filled == 0) { rbatch e; memset(&e, 0, sizeof e); S.qn = qn_check(hdr, &e); }     /* an empty input is still checked (:708) */
+		qn = S.qn;
+		if (getenv("MSX_TIMING")) {
+			fprintf(stderr, "# batches: %zu\n", n_batches);
 			fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 			        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
-		if (getenv("MSX_TIMING"))
 			fprintf(stderr, "# profile pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
-			        "upload+accumulate %.3f (+%.3f waiting for a batch); %zu records, %d threads\n",
-			        now_s() - t_start, P.t_decode, P.t_wait_free, t_ctx, t_dev, t_wait, n_in, msh_threads());
-		goto accumulated;
+			        "upload+accumulate %.3f (+%.3f waiting for a batch); %zu records, %d threads, %d device%s\n",
+			        now_s() - t_start, P.t_decode, P.t_wait_free, t_ctx, t_dev, t_wait, n_in, msh_threads(), S.n_dev,
+			        S.n_dev > 1 ? "s" : "");
+		}
+		profile_combine_and_finalize(ctxs, profs, S.n_dev, o.share_type, row, &st);
+		prof = profs[0];
+		goto finalized;
 	}
 	for (;;) {
 		size_t tgt = first && target < COORD_ORDER_CHECK_RECORDS ? COORD_ORDER_CHECK_RECORDS : target;
@@ -1612,7 +2085,8 @@ batch_ready:
 			qn = qn_check(hdr, &b);                                   /* :708, always for profile */
 			first = 0;
 			ctx_open();
-			MSX(msx_profile_create(g_ctx, &prof, n_features, share_type, fmap, hdr->n_targets));   /* :855 */
+			dist_begin();
+			MSX(msx_profile_create(g_ctx, &prof, F.n_features, o.share_type, F.fmap, hdr->n_targets));   /* :855 */
 		}
 		if (b.n > 0) {
 			msx_batch hb, db;
@@ -1625,106 +2099,19 @@ batch_ready:
 		}
 		if (eof && !have_pending) break;
 	}
-
-accumulated:
 	/* mInsertCountToAbundanceMatrix (:248-425) */
-	row = (double *)calloc((size_t)n_features + 1, sizeof(double));
-	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) fprintf(stderr, "# Start PropSharing:\n");
-	if (dist_world() > 1 || getenv("MSX_FORCE_DIST")) {      /* (MSX_FORCE_DIST: the same path over a one-rank communicator, for tests) */
-		/* this rank's counts are a shard's: sum them over the ranks, iterate with the increment all-reduced */
-		MSX(msx_dist_init_env(g_ctx));
-		MSX(msx_profile_finalize_dist_enqueue(g_ctx, prof));
-		MSX(msx_profile_fetch(g_ctx, prof, row + 1, &st));
-		if (dist_rank() != 0) {               /* every rank holds the same result; rank 0 reports it */
-			msx_dist_finalize(g_ctx);
-			fast_exit();
-			return 0;
-		}
-	} else {
-		MSX(msx_profile_finalize(g_ctx, prof, row + 1, &st));
+	{
+		msx_ctx *one = g_ctx;
+		profile_combine_and_finalize(&one, &prof, 1, o.share_type, row, &st);
 	}
-	if (share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
-		int k;
-		for (k = 1; k <= st.iterations; k++)
-			fprintf(stderr, "#     PropSharing Iteration: %2d; DELTA^2=%g%s\n", k, st.delta[k],
-			        (k == st.iterations && st.converged) ? ". CONVERGED!" : "");
-		fprintf(stderr, "# End   PropSharing!\n");
-		fprintf(stderr, "# Purged %d inserts that mapped to features without unique inserts.\n",
-		        (int)st.purged_insert_count);
+finalized:
+	if (g_dist && dist_rank() != 0) {             /* every rank holds the same result; rank 0 reports it */
+		msx_dist_finalize(g_ctx);
+		fast_exit();
+		return 0;
 	}
-	mapped_inserts = (int)st.insert_count;
-	row[0] = 0.0;
-
-	if (n_mincount > 0) {                                             /* :858-869 */
-		int mincount = (int)v_mincount;
-		for (i = 1; i < n_features + 1; i++)
-			if (row[i] < mincount) { purged_insert_equivalent += row[i]; row[i] = 0; }
-		fprintf(stderr, "# Purged %.7g insert-equivalents from low-abundance features based on --mincount.\n",
-		        purged_insert_equivalent);
-	}
-	if (total_inserts > 0 && total_inserts < mapped_inserts) {        /* :873-876 */
-		fprintf(stderr, "# Ignoring 'unknown' fraction, as total inserts (%d) < mapped inserts (%d)!\n", total_inserts,
-		        mapped_inserts);
-		total_inserts = -1;
-	}
-	gz = strcmp(o_out, "-") == 0 ? gzdopen(fileno(stdout), "wb") : gzopen(o_out, "wb");   /* :879-883 */
-	if (!gz) mDie("Cannot open %s for writing", o_out);
 	cl = command_line(argc, argv);
-	qn_format(&qn, qmsg, sizeof qmsg);
-	gzprintf(gz, "# msamtools version: %s\n", MSH_VERSION);           /* msam_helper.c:145-148 */
-	gzprintf(gz, "# msamtools git commit: %s\n", MSH_GIT_COMMIT);
-	gzprintf(gz, "# Command line: %s\n", cl);
-	gzprintf(gz, "# %s\n", qmsg);
-	purged_inserts = st.purged_insert_count + purged_insert_equivalent;   /* :889-903 */
-	effective_inserts = mapped_inserts - purged_inserts;
-	if (share_type == MSX_MULTI_IGNORE) effective_inserts -= st.multi_mapper_count;
-	print_stats_int(gz, 1, "Total inserts", total_inserts, total_inserts, NULL);
-	print_stats_int(gz, 1, "Mapped inserts", mapped_inserts, total_inserts, NULL);
-	print_stats_int(gz, 0, "- Multiple mapped ", (int)st.multi_mapper_count, total_inserts, NULL);
-	print_stats_int(gz, 0, "- Uniquely mapped ", (int)st.uniq_mapper_count, total_inserts, NULL);
-	print_stats_dbl(gz, 1, "Purged inserts", purged_inserts, total_inserts,
-	                "due to ambiguous mapping or low abundance features");
-	print_stats_dbl(gz, 1, "Effective inserts", effective_inserts, total_inserts, NULL);
-	if (total_inserts <= 0) gzprintf(gz, "# Estimated seq. length for 'Unknown': NA\n");
-	if (total_inserts > 0) {                                          /* :906-934 */
-		row[0] = total_inserts - mapped_inserts + purged_inserts;
-		if (share_type == MSX_MULTI_IGNORE) row[0] += st.multi_mapper_count;
-		if (length_normalize) {
-			int count = 0;
-			uint64_t sum = 0;
-			uint32_t unknown_size;
-			for (i = 0; i < n_features; i++) { sum += feature_len[i]; count++; }
-			unknown_size = (uint32_t)(sum / (uint64_t)count);
-			gzprintf(gz, "# Estimated seq. length for 'Unknown': %dbp\n", unknown_size);
-			row[0] = 1.0 * row[0] / unknown_size;
-		} else {
-			gzprintf(gz, "# Estimated seq. length for 'Unknown': NA\n");
-		}
-	}
-	if (length_normalize)                                             /* :937-947 */
-		for (i = 0; i < n_features; i++) row[1 + i] /= feature_len[i];
-	switch (unit_type) {                                              /* :950-975, mMatrix.c:137-179 */
-	case 2: {
-		double d = total_inserts > 0 ? 1.0E9 / total_inserts : 1.0E9 / mapped_inserts;
-		for (i = 0; i < n_features + 1; i++) row[i] *= d;
-		break;
-	}
-	case 3:
-	case 1: {
-		double sum = 0;
-		for (i = 0; i < n_features + 1; i++) sum += row[i];
-		for (i = 0; i < n_features + 1; i++) row[i] /= sum;
-		if (unit_type == 3)
-			for (i = 0; i < n_features + 1; i++) row[i] *= 1.0E6;
-		break;
-	}
-	default: break;
-	}
-	if (o_nopandas == 0) gzprintf(gz, "ID\t");                        /* mMatrix.c:359-376 */
-	gzprintf(gz, "%s\n", o_label);
-	gzprintf(gz, "Unknown\t%.8g\n", row[0]);
-	for (i = 0; i < n_features; i++) gzprintf(gz, "%s\t%.8g\n", feature_name[i], row[1 + i]);
-	gzclose(gz);
+	profile_report(&o, &F, &st, row, &qn, cl);
 
 	fast_exit();
 	msx_profile_destroy(g_ctx, prof);
@@ -2071,14 +2458,16 @@ static int pipetest_main(int argc, char *argv[]) {
 	mode = atoi(argv[1]); stats = atoi(argv[2]);
 	in = msh_open(argv[3]);
 	if (!msh_is_bam(in)) mQuit("pipetest needs BAM input");
-	pipe_init(&P, in, mode, stats);
+	pipe_init(&P, in, mode, stats, 1);
 	if (pthread_create(&th, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 	for (;;) {
 		const int si = pq_pop(&P.q_dev);
-		pslot *s = &P.slot[si];
-		rbatch *b = &s->b;
+		pslot *s;
+		rbatch *b;
 		size_t i, g;
-		if (s->eof) break;
+		if (si == PQ_END) break;
+		s = &P.slot[si];
+		b = &s->b;
 		batches++;
 		for (i = 0; i < b->n; i++) {
 			const uint8_t *r = RB_REC(b, i);
@@ -2182,14 +2571,15 @@ static int digest_main(int argc, char *argv[]) {
 	if (msh_is_bam(in)) {
 		static pipe_t P;
 		pthread_t th;
-		pipe_init(&P, in, 0, 0);
+		pipe_init(&P, in, 0, 0, 1);
 		if (pthread_create(&th, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 		for (;;) {
 			const int si = pq_pop(&P.q_dev);
-			pslot *s = &P.slot[si];
+			pslot *s;
 			digest_job J;
 			int nth = msh_threads(), t;
-			if (s->eof) break;
+			if (si == PQ_END) break;
+			s = &P.slot[si];
 			if (nth > MSH_POOL_MAX) nth = MSH_POOL_MAX;
 			J.b = &s->b; J.first = n;
 			msh_parallel(nth, digest_worker, &J);
@@ -2209,6 +2599,8 @@ static int digest_main(int argc, char *argv[]) {
 
 int main(int argc, char *argv[]) {
 	g_t_main = now_s();
+	msh_main_thread = pthread_self();
+	msh_main_thread_set = 1;
 	if (argc < 2) return usage(stderr);
 	if (strcmp(argv[1], "keyorder") == 0) {
 		/* hidden, host only: names on stdin (one per line) -> the reference's key order on stdout */

@@ -21,6 +21,9 @@
 /* ------------------------------------------------------------------------ */
 /* errors, strings                                                            */
 /* ------------------------------------------------------------------------ */
+pthread_t msh_main_thread;
+int msh_main_thread_set;
+
 void mDie(const char *fmt, ...) {
 	va_list ap;
 	fflush(stdout);
@@ -29,6 +32,11 @@ void mDie(const char *fmt, ...) {
 	vfprintf(stderr, fmt, ap);
 	va_end(ap);
 	fprintf(stderr, "\n");
+	/* a fatal error raised on a worker, reader, writer or device thread: the other threads are still running (a
+	 * device thread may be inside the HIP runtime, which exit()'s handlers would tear down under it) -- leave at
+	 * once, with the diagnostic and everything written so far flushed */
+	fflush(stderr);
+	if (msh_main_thread_set && !pthread_equal(pthread_self(), msh_main_thread)) _exit(EXIT_FAILURE);
 	exit(EXIT_FAILURE);
 }
 

@@ -126,6 +126,8 @@ void msx_lane_leave(msx_ctx *ctx) {
 }
 
 void msx_join(msx_ctx *ctx) {
+	// (the head of nearly every entry point: the calling thread may have last worked on another context's device)
+	(void)hipSetDevice(ctx->device);
 	if (!ctx->forked) return;
 	msx_lane_leave(ctx);
 	for (int i = 0; i < MSX_SIDE_LANES; i++) {
@@ -480,7 +482,7 @@ extern "C" void msx_host_free(msx_ctx *ctx, void *ptr) {
 
 extern "C" int msx_host_register(msx_ctx *ctx, void *ptr, size_t bytes) {
 	if (!ctx || !ptr || !bytes) return MSX_ERR_ARG;
-	hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+	hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);    // (pinned for every device: one process may drive several contexts)
 	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_HIP, "hipHostRegister(%zu) failed: %s", bytes, hipGetErrorString(e));
 	return MSX_OK;
 }

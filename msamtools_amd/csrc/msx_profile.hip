@@ -393,6 +393,95 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 	return msx_profile_count_finish(ctx, p, b, by_part);
 }
 
+// ---- one process, several contexts: the inserts of one sample counted on several devices ----------------
+__global__ __launch_bounds__(MSX_BLOCK) void k_merge_counts(int32_t nf, const uint32_t *__restrict__ ui_src, uint32_t *__restrict__ ui,
+                                                            const double *__restrict__ d_src, double *__restrict__ d,
+                                                            const uint32_t *__restrict__ cnt_src, uint32_t *__restrict__ cnt) {
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
+		ui[i] += ui_src[i];
+		if (d) d[i] += d_src[i];
+	}
+	if (blockIdx.x == 0 && threadIdx.x < 3) cnt[threadIdx.x] += cnt_src[threadIdx.x];     // inserts, uniq, multi
+}
+
+// m_off[L + j] = off_src[j] + E for j = 0 .. n (the sentinel included), then the totals
+__global__ __launch_bounds__(MSX_BLOCK) void k_merge_offsets(int64_t n, const uint32_t *__restrict__ off_src,
+                                                             unsigned long long *csr_tot, uint32_t *__restrict__ m_off) {
+	const unsigned long long L = csr_tot[0], E = csr_tot[1];
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j <= n; j += stride) m_off[L + j] = off_src[j] + (uint32_t)E;
+}
+__global__ void k_merge_totals(unsigned long long n_lists, unsigned long long n_entries, unsigned long long *csr_tot) {
+	csr_tot[0] += n_lists;
+	csr_tot[1] += n_entries;
+}
+
+extern "C" int msx_profile_merge(msx_ctx *ctx, msx_profile *p, msx_ctx *src_ctx, msx_profile *q) {
+	if (!ctx || !p || !src_ctx || !q) return MSX_ERR_ARG;
+	if (p == q) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_merge: source and destination are the same profile");
+	if (p->n_features != q->n_features || p->share_type != q->share_type)
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_merge: the two profiles differ in features or --multi mode");
+	msx_join(ctx);
+	msx_join(src_ctx);
+	// everything the source has enqueued must have landed
+	MSX_HIP(src_ctx, hipSetDevice(src_ctx->device));
+	MSX_HIP(src_ctx, hipStreamSynchronize(src_ctx->stream));
+	unsigned long long t[2] = {0, 0};
+	MSX_HIP(src_ctx, hipMemcpy(t, q->csr_tot, 16, hipMemcpyDeviceToHost));
+	const int64_t nl = (int64_t)t[0], ne = (int64_t)t[1];
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t nf = (size_t)(p->n_features > 0 ? p->n_features : 1);
+	// staging on the destination device: ui, d, counters, offsets of the source
+	const size_t b_ui = nf * 4, b_d = q->d ? nf * 8 : 0, b_off = (size_t)(nl + 1) * 4;
+	const size_t o_d = (b_ui + 15) & ~(size_t)15, o_cnt = o_d + ((b_d + 15) & ~(size_t)15), o_off = o_cnt + 16;
+	char *stage = nullptr;
+	if (hipMalloc((void **)&stage, o_off + b_off + 16) != hipSuccess)
+		return msx_fail(ctx, MSX_ERR_NOMEM, "msx_profile_merge: staging allocation failed");
+	const bool same = ctx->device == src_ctx->device;
+	auto copy = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+		if (!bytes) return hipSuccess;
+		return same ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream)
+		            : hipMemcpyPeerAsync(dst, ctx->device, src, src_ctx->device, bytes, ctx->stream);
+	};
+	int rc = MSX_OK;
+	hipError_t e = copy(stage, q->ui, b_ui);
+	if (e == hipSuccess) e = copy(stage + o_d, q->d, b_d);
+	if (e == hipSuccess) e = copy(stage + o_cnt, q->counters, 16);
+	if (e == hipSuccess) e = copy(stage + o_off, q->m_off.p, b_off);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_merge_counts, dim3(msx_grid(ctx, p->n_features, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   p->n_features, (const uint32_t *)stage, p->ui, (const double *)(stage + o_d), p->d ? p->d : nullptr,
+		                   (const uint32_t *)(stage + o_cnt), p->counters);
+		if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL && nl > 0) {
+			// fold the destination's bounds back to what it really holds, then make room for the source's lists
+			unsigned long long mine[2] = {0, 0};
+			e = hipMemcpyAsync(mine, p->csr_tot, 16, hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			if (e == hipSuccess) {
+				p->lists_ub = (int64_t)mine[0] + nl;
+				p->entries_ub = (int64_t)mine[1] + ne;
+				if (p->entries_ub > 0xffffff00LL) rc = msx_fail(ctx, MSX_ERR_ARG, "multi-mapper CSR exceeds 2^32 entries");
+				if (!rc) rc = msx_grow_keep(ctx, &p->m_off, (size_t)(p->lists_ub + 2) * 4);
+				if (!rc) rc = msx_grow_keep(ctx, &p->m_fid, (size_t)(p->entries_ub + 2) * 4);
+				if (!rc) {
+					e = copy((int32_t *)p->m_fid.p + mine[1], q->m_fid.p, (size_t)ne * 4);
+					hipLaunchKernelGGL(k_merge_offsets, dim3(msx_grid(ctx, nl + 1, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, nl,
+					                   (const uint32_t *)(stage + o_off), p->csr_tot, (uint32_t *)p->m_off.p);
+					hipLaunchKernelGGL(k_merge_totals, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long)nl, (unsigned long long)ne,
+					                   p->csr_tot);
+					p->transposed_valid = false;
+				}
+			}
+		}
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(stage);
+	if (rc) return rc;
+	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_HIP, "msx_profile_merge failed: %s", hipGetErrorString(e));
+	return MSX_OK;
+}
+
 extern "C" int msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui, double **d, uint32_t **counters) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	msx_join(ctx);

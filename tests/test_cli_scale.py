@@ -177,3 +177,87 @@ def test_one_batch_equals_many(mid, tmp_path):
     ref = records()
     for env in (dict(MSX_BATCH_BYTES=96 << 20, MSX_BATCH_RECORDS=3 << 20), dict(MSX_THREADS=1), dict(MSX_THREADS=3)):
         assert records(**env) == ref
+
+
+# ---- one process instead of two: filter --profile-out ------------------------------------------------------------
+
+@pytest.mark.parametrize("inflag", ["b", "u"])
+def test_tee_equals_the_two_process_pipe(big, tmp_path, inflag):
+    """`filter ... --profile-out p.gz --label S` = `filter ... | profile -` without the pipe, the second decode and
+    the second process: same records on stdout, same profile (msx_filter_profile_enqueue per batch, > 20 batches)."""
+    f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam[inflag]} > {f}", MSX_TIMING=1)
+    assert n_batches(r.stderr) >= 20
+    big.check_digest(f, big.digest_out)
+    big.check_profile(p, big.pipe)
+    assert b"PropSharing Iteration" in r.stderr and b"# Purged " in r.stderr
+
+
+def test_tee_without_best_hit_and_with_uniqhit(mid, tmp_path):
+    """-l/-p/-z only (pools do not shape filter's output: the host hands over profile's pools over the records
+    filter can write) and --uniqhit, against the oracle run as the two commands."""
+    for opts, cli in ((dict(l=80, p=95, z=80), "-l 80 -p 95 -z 80"), (dict(uniqhit=True), "--uniqhit"),
+                      (dict(l=80, p=97, besthit=True), "-l 80 -p 97 --besthit")):
+        f = orc.run_filter(mid.hs, **opts)
+        ref = orc.run_profile(mid.hs, mid.refs, multi="proportional", sel=f["emit"])
+        fb, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+        sh(f"{BIN} filter {cli} -bu --profile-out {p} --label S {mid.bam['b']} > {fb}", MSX_BATCH_BYTES=1_500_000,
+           MSX_BATCH_RECORDS=110_000)
+        mid.check_digest(fb, digest.synth_digest(mid.hs, f["emit"]))
+        mid.check_profile(p, ref)
+
+
+def test_tee_options_and_refusals(mid, tmp_path):
+    p = str(tmp_path / "p.gz")
+    r = subprocess.run(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} {mid.bam['b']}", shell=True, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"--profile-out requires --label" in r.stdout
+    r = subprocess.run(f"{BIN} {' '.join(FILT)} -bu --label S {mid.bam['b']}", shell=True, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"need --profile-out" in r.stdout
+    # profile's own options travel: --multi all --unit ab --nolen --total
+    f = orc.run_filter(mid.hs, **OPTS)
+    ref = orc.run_profile(mid.hs, mid.refs, multi="all", sel=f["emit"])
+    sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S --multi all --unit ab --nolen --total 400000 {mid.bam['b']} > /dev/null")
+    vals, _, _ = orc.profile_finish(ref["abundance"], mid.flen, ref["stats"], unit="ab", nolen=True, total=400000, multi="all")
+    rows = [l.split("\t") for l in gzip.open(p, "rt").read().split("\n") if l and not l.startswith("#")]
+    got = np.array([float(x[1]) for x in rows[1:]])
+    assert np.allclose(got, vals, rtol=1e-6, atol=0)
+
+
+# ---- one process, several contexts (MSX_DEVICES): here two contexts on the one GPU -----------------------------------
+
+def test_two_contexts_filter_profile_and_tee(big, tmp_path):
+    """The decode stage deals the batches to two device threads (each its own context, stage and profile), the writer
+    puts filter's output back in input order, the profiles are merged on the first context before the sharing
+    iterations (msx_profile_merge): same files as with one context."""
+    f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    r = sh(f"{BIN} {' '.join(FILT)} -bu {big.bam['b']} > {f}", MSX_DEVICES="0,0", MSX_TIMING=1)
+    assert b"2 devices" in r.stderr
+    big.check_digest(f, big.digest_out)
+    r = sh(f"{BIN} profile --label S -o {p} {big.bam['u']}", MSX_DEVICES="0,0", MSX_TIMING=1)
+    assert b"2 devices" in r.stderr
+    big.check_profile(p, big.plain)
+    sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {f}", MSX_DEVICES="0,0,0")
+    big.check_digest(f, big.digest_out)
+    big.check_profile(p, big.pipe)
+
+
+# ---- --rescore on the pipeline ------------------------------------------------------------------------------------
+
+def test_rescore_on_the_pipeline(mid, tmp_path):
+    """--rescore (msam_filter.c:160-168: AS recomputed from MD/NM, the old AS dropped, AS:i appended) used to take the
+    one-batch-at-a-time loop; the pipeline's writer now rewrites the emitted records in parallel.  Same text as the
+    serial loop, and the AS values are the oracle's."""
+    cmd = f"{BIN} filter -l 80 -p 95 -z 80 --rescore --besthit -bu {mid.bam['b']}"
+    a, b = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    sh(f"{cmd} > {a}", MSX_BATCH_BYTES=1_500_000, MSX_BATCH_RECORDS=110_000)
+    sh(f"{cmd} > {b}", MSX_SERIAL_IO=1, MSX_BATCH_RECORDS=100_000)
+    ta = subprocess.check_output([BIN, "recode", a]).decode().split("\n")[:-1]
+    tb = subprocess.check_output([BIN, "recode", b]).decode().split("\n")[:-1]
+    assert ta == tb
+    f = orc.run_filter(mid.hs, l=80, p=95, z=80, rescore=True, besthit=True)
+    assert len(ta) == len(f["emit"])
+    got_as = [int(next(x for x in l.split("\t")[11:] if x.startswith("AS:i:"))[5:]) for l in ta]
+    assert got_as == f["as_out"][f["emit"]].tolist()
+    assert all(l.split("\t")[-1].startswith("AS:i:") for l in ta[:1000])          # appended at the end (:167)

@@ -216,3 +216,49 @@ def test_pool_rule_needs_flag(ctx, tmp_path):
     batch.b.flag = saved
     prof.close()
     batch.free()
+
+
+def test_tee_cli_counts_chains_across_batch_cuts(ctx, tmp_path):
+    """The one-process pipe of the command line (`filter --besthit --profile-out`) on a stream full of interleaved
+    unmapped names, cut into many batches: batch ends are placed in front of pools that begin with a mapped record, so
+    no chain is cut; header counts and values are the oracle's for the two commands."""
+    import gzip
+    import os
+    import subprocess
+    from conftest import ROOT
+    BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+    recs = random_stream(5, 120000)
+    sam = tmp_path / "s.sam"
+    sam.write_text(sam_text(recs))
+    rec = samio.read_sam(str(sam))[1]
+    bam = str(tmp_path / "s.bam")
+    with open(bam, "wb") as fh:
+        subprocess.check_call([BIN, "recode", "-u", str(sam)], stdout=fh)
+    opts = dict(l=30, p=95, z=80, besthit=True)
+    f, ref = oracle_pipe(rec, "proportional", **opts)
+    p = str(tmp_path / "p.gz")
+    env = dict(os.environ, MSX_BATCH_BYTES="1500000", MSX_BATCH_RECORDS="110000", MSX_THREADS="8", MSX_TIMING="1")
+    r = subprocess.run(f"{BIN} filter -l 30 -p 95 -z 80 --besthit -bu --profile-out {p} --label S {bam} > {tmp_path / 'f.bam'}",
+                       shell=True, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    nb = [int(l.split()[2]) for l in r.stderr.decode().split("\n") if l.startswith("# batches:")]
+    assert nb and nb[0] >= 3
+    out = subprocess.check_output([BIN, "recode", str(tmp_path / "f.bam")]).decode().split("\n")[:-1]
+    src = subprocess.check_output([BIN, "recode", bam]).decode().split("\n")[:-1]
+    assert out == [src[i] for i in f["emit"]]
+    text = gzip.open(p, "rt").read()
+    head = [l for l in text.split("\n") if l.startswith("#")]
+    get = lambda key: next(l for l in head if l.startswith(key)).split(":")[1].split("(")[0].strip()
+    s = ref["stats"]
+    assert (int(get("# Mapped inserts")), int(get("#   - Multiple mapped")), int(get("#   - Uniquely mapped"))) == \
+        (s.insert_count, s.multi_mapper_count, s.uniq_mapper_count)
+    vals, _, _ = orc.profile_finish(ref["abundance"], np.full(N_REF, 5000, np.uint32), s, unit="rel")
+    got = np.array([float(l.split("\t")[1]) for l in text.split("\n") if l and not l.startswith("#") and not l.startswith("ID")])
+    assert np.allclose(got, vals, rtol=1.1e-6, atol=0)
+    # the two-process pipe on the same file agrees (profile re-pools by QNAME itself)
+    p2 = str(tmp_path / "p2.gz")
+    r = subprocess.run(f"{BIN} filter -l 30 -p 95 -z 80 --besthit -bu {bam} | {BIN} profile --label S -o {p2} -", shell=True,
+                       env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    strip = lambda t: "\n".join(l for l in t.split("\n") if not l.startswith("# Command"))
+    assert strip(gzip.open(p2, "rt").read()) == strip(text)

@@ -145,6 +145,21 @@ def test_qname_preflight_rejects_bad_order(tmp_path):
     assert r.returncode == 1 and not out.exists()
 
 
+def test_profile_refuses_a_leaked_world_size(tmp_path):
+    """with WORLD_SIZE > 1 in the environment and a plain input path every rank would read the whole
+    file and the all-reduce would multiply every count.  The command refuses (before touching input or GPU) unless
+    the run is asked for as a rank ("{rank}" in the path / MSX_DIST=1) or explicitly as a single process (MSX_DIST=0)."""
+    out = tmp_path / "p.gz"
+    env = {"WORLD_SIZE": "4", "RANK": "1", "LOCAL_RANK": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29777"}
+    r = run(["profile", "-S", "--label", "x", "-o", str(out), fixture_path("profile.sam")], env=env)
+    assert r.returncode == 1 and b'has no "{rank}"' in r.stderr and b"Fatal Error" in r.stderr and not out.exists()
+    # WORLD_SIZE alone (no RANK: not a launcher's environment) is ignored, as is anything under MSX_DIST=0:
+    # both get as far as needing the GPU (or succeed where there is one)
+    for e in ({"WORLD_SIZE": "4"}, dict(env, MSX_DIST="0")):
+        r = run(["profile", "-S", "--label", "x", "-o", str(out), fixture_path("profile.sam")], env=e)
+        assert b'has no "{rank}"' not in r.stderr
+
+
 # ---- end to end on the GPU ---------------------------------------------------------------
 
 def cli_opts(opts):
