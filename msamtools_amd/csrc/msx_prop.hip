@@ -701,8 +701,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_general_recip(RecipArgs G, const 
 // entry order, whose keys (part_key, fixed for a build: k_part_index) ascend.  Single GPU:
 // k_prop_apply adds the slots that fall into its workgroup's feature range, in slot order.
 // With a collective between the halves of an iteration (msx_profile_prop_local): k_partial_reduce
-// runs a segmented sum over the slots, 64 per row, and adds each run to share[] once.
-#define PR_CHUNK 256                   // partials reduced by one wave (k_partial_reduce)
+// folds the slots into share[] run by run, in slot order, without atomics.
 #define SR_SENT 0xffffffffu
 #define SR_EPL 4                       // consecutive entries summed by one lane
 #define SR_STEP (64 * SR_EPL)          // entries per wave step
@@ -1017,40 +1016,38 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_part_runs(const uint32_t *__restr
 	if (threadIdx.x < s_n[1]) runs[M - 1 - (s_base[1] + threadIdx.x)] = s_run[1][threadIdx.x];
 }
 
-// level 2: runs of equal feature ids among the boundary partials -> one add per run
-__global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const uint32_t *__restrict__ pkey,
-                                                              const double *__restrict__ pval,
+// With a collective between the halves of an iteration share[] must be complete before it leaves the device: the
+// partial slots are folded into it run by run -- one lane per short run, one wave per long run, slots added in slot
+// order -- with plain stores: every feature owns at most one run (its slots are neighbours), so no two lanes write
+// the same word, the order of the additions is fixed and the result repeats bit for bit (the atomic adds this
+// replaces did not).  The runs are the ones k_part_runs lists for k_prop_apply<true>.
+__global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t n_slots, const unsigned long long *__restrict__ d_tot,
+                                                              const PartRun *__restrict__ runs,
+                                                              const double *__restrict__ part_val,
                                                               double *__restrict__ share,
                                                               const int32_t *__restrict__ iter_state) {
 	if (iter_state[0]) return;
 	const int lane = threadIdx.x & 63;
-	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
-	const int64_t c0 = wave * PR_CHUNK;
-	if (c0 >= M) return;
-	const int64_t c1 = (c0 + PR_CHUNK < M) ? c0 + PR_CHUNK : M;
-	double carry = 0.0;
-	bool carry_open = false;
-	uint32_t carry_key = 0;
-	for (int64_t rb = c0; rb < c1; rb += 64) {
-		const int64_t k = rb + lane;
-		const bool valid = k < c1;
-		const uint32_t key = valid ? pkey[k] : SR_SENT;
-		const double v = valid ? pval[k] : 0.0;
-		uint32_t pk = __shfl_up(key, 1, 64);
-		if (lane == 0) pk = (k > 0) ? pkey[k - 1] : ~key;
-		uint32_t nk = __shfl_down(key, 1, 64);
-		if (valid && (lane == 63 || k + 1 >= c1)) nk = (k + 1 < M) ? pkey[k + 1] : ~key;
-		const SegRow s = seg_row(key, v, valid, pk, nk, lane, carry, true);
-		if (s.tail && key != SR_SENT && s.v != 0.0) atomicAdd(&share[key], s.v);
-		const int64_t rem = c1 - rb - 1;
-		const int ll = rem < 63 ? (int)rem : 63;
-		const double cv = __shfl(s.v, ll, 64);
-		const int ct = __shfl((int)s.tail, ll, 64);
-		carry_key = __shfl(key, ll, 64);
-		carry_open = !ct;
-		carry = ct ? 0.0 : cv;
+	const int64_t r = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (r < (int64_t)d_tot[3]) {
+		const PartRun R = runs[r];
+		double sum = 0;
+		for (uint32_t q = 0; q < R.n; ++q) sum += part_val[R.first + q];
+		// += : a segment that ENDS with its chunk's last entry is stored by k_share_reduce itself and still owns the
+		// chunk's (zero) end slot.  Precondition: share[] of a feature nothing was stored to this iteration is 0 --
+		// k_prop_begin and prop_update (which zeroes what it has consumed) see to that.
+		share[R.key] += sum;
 	}
-	if (lane == 0 && carry_open && carry_key != SR_SENT && carry != 0.0) atomicAdd(&share[carry_key], carry);
+	const int64_t n_long = (int64_t)d_tot[4];
+	const int64_t n_waves = (int64_t)gridDim.x * (MSX_BLOCK / 64);
+	for (int64_t w = r >> 6; w < n_long; w += n_waves) {
+		const PartRun R = runs[n_slots - 1 - w];
+		double part = 0;
+		for (uint32_t q = (uint32_t)lane; q < R.n; q += 64u) part += part_val[R.first + q];
+		double tot = 0;
+		for (int l = 0; l < 64; l++) tot += __shfl(part, l, 64);     // every lane computes the same total
+		if (lane == 0) share[R.key] += tot;
+	}
 }
 
 // a = U + a * share, clamp, DELTA^2, convergence (msam_profile.c:368-389).  The first `nsb` workgroups
@@ -1059,7 +1056,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t M, const u
 // owns a run of partial slots instead -- the streaming workgroups leave those features (bitmap `owned`)
 // to the workgroups behind them, where one thread per run adds its slots in slot order (a fixed
 // summation order: results repeat bit for bit) and updates the feature.  Not FUSED: share[] is complete
-// (k_partial_reduce -- atomics -- and the caller's all-reduce have run).  Every workgroup leaves its sum
+// (k_partial_reduce and the caller's all-reduce have run).  Every workgroup leaves its sum
 // of diff^2 for k_prop_finish.
 __device__ __forceinline__ double prop_update(int64_t i, double sh, const double *U, double *a, double *share) {
 	const double old = a[i];
@@ -1394,11 +1391,10 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	                             (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u)));
 	if (complete) {
 		const int64_t M = 2 * W;
-		const int64_t n_waves2 = (M + PR_CHUNK - 1) / PR_CHUNK;
 		MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
-		          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((n_waves2 + 3) / 4)), dim3(MSX_BLOCK), 0,
-		                             ctx->stream, M, (const uint32_t *)p->part_key.p, (const double *)p->part_val.p,
-		                             p->share, (const int32_t *)p->iter_state));
+		          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((M + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
+		                             ctx->stream, M, (const unsigned long long *)p->d_tot, (const PartRun *)p->runs.p,
+		                             (const double *)p->part_val.p, p->share, (const int32_t *)p->iter_state));
 	}
 	return MSX_OK;
 }

@@ -120,3 +120,53 @@ def test_bench_multi_gpu_step_on_one_rank():
         assert ca[k] == cb[k], k
     assert abs(ca["abundance_sum"] - cb["abundance_sum"]) <= 1e-9 * ca["abundance_sum"]
     assert ca["abundance_sha1_6dp"] == cb["abundance_sha1_6dp"]
+
+
+@pytest.mark.parametrize("groups,refs", [(300, 7), (2000, 50), (60_000, 500), (400_000, 20_000)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_one_rank_distributed_finalize_equals_plain_and_oracle(groups, refs, fused):
+    """msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator -- counts all-reduced, the partial slots of
+    k_share_reduce folded into share[] (k_partial_reduce, run by run, no atomics), share[] all-reduced inside each of
+    the 19 iterations -- against msx_profile_finalize_enqueue on the same inserts (equal to 1e-12: the same additions
+    in another order) and against the oracle (<= 1e-6, msam_profile.c:317-410).  Small inputs matter: most waves of
+    k_share_reduce idle then and every feature's segment ends at a chunk's last entry somewhere."""
+    import msamtools_amd as m
+    ctx = m.Context(0)
+    ctx.dist_init(m.dist_unique_id(), 0, 1)
+    db = m.DeviceBatch.synth(ctx, 24680, groups, refs, 4)
+    hs = m.HostSynth(24680, groups, refs, 4)
+    out = {}
+    try:
+        for path in ("plain", "dist"):
+            prof = m.Profile(ctx, refs, "proportional")
+            if fused:
+                run = m.FilterRun(ctx, db, **OPTS)
+                run.enqueue_with_profile(prof)
+                run.finish()
+                sel = run.result().emit
+                run.free()
+            else:
+                prof.accumulate(db, None)
+                sel = None
+            if path == "dist":
+                prof.finalize_dist_enqueue()
+            else:
+                prof.finalize_enqueue()
+            ab, st = prof.fetch()
+            out[path] = (ab.copy(), (st.insert_count, st.uniq_mapper_count, st.multi_mapper_count, st.purged_insert_count,
+                                     st.iterations, st.converged))
+            prof.close()
+        ref = orc.run_profile(hs, refs, multi="proportional", sel=sel)
+    finally:
+        db.free()
+        ctx.close()
+    a, b = out["plain"][0], out["dist"][0]
+    assert out["plain"][1] == out["dist"][1]
+    assert np.array_equal(a == 0, b == 0)
+    assert (np.abs(a - b) / np.maximum(np.abs(a), 1e-300)).max() <= 1e-12
+    s = ref["stats"]
+    assert out["dist"][1] == (s.insert_count, s.uniq_mapper_count, s.multi_mapper_count, s.purged_insert_count,
+                              s.iterations, s.converged)
+    want = ref["abundance"]
+    assert np.array_equal(b == 0, want == 0)
+    assert (np.abs(b - want) / np.maximum(np.abs(want), 1e-300)).max() <= 1e-6
