@@ -203,6 +203,50 @@ int  msx_event_record(msx_ctx *ctx, msx_event *ev);
 int  msx_event_wait(msx_ctx *ctx, msx_event *ev);      /* host waits; returns at once if never recorded */
 void msx_event_destroy(msx_ctx *ctx, msx_event *ev);
 
+/* ---- the record walk on the device -------------------------------------------------
+ *
+ * mSamRead (msam_helper.c:246-268) hands the loops of msam_filter.c:119-186 and
+ * msam_profile.c:222-234 one record after another.  With msx_unpack the host does
+ * only what must be done there (read, BGZF inflate): the inflated BAM byte stream of a
+ * batch -- records with their 4-byte block_size prefixes, cut anywhere -- is uploaded
+ * as it is, and the device finds the record boundaries, reads the core fields, scans
+ * every aux block for MD / NM / AS (bam_aux_get / bam_aux2i), packs CIGAR and MD,
+ * compares QNAMEs for the pools of the chosen loop and ends the batch at its last pool
+ * boundary; the open pool and the cut record behind it stay on the device and head the
+ * next batch.  msx_unpack_finish hands out the msx_batch view (device pointers owned by
+ * the unpacker, valid until the next msx_unpack_enqueue) for the compute entry points;
+ * msx_unpack_emit returns filter's output records as one byte string (block_size
+ * prefixes included, output order), ready for BGZF framing. */
+typedef struct msx_unpack msx_unpack;
+typedef struct msx_unpack_params {
+	int32_t pool_mode;         /* 0: no pools; 1: msam_filter.c:120-125,170; 2: msam_profile.c:223-232;
+	                              3: profile's rule over the records filter can write (no best hit)      */
+	int32_t unmapped_visible;  /* mode 3: filter -k -v writes unmapped records (msam_filter.c:132-138)  */
+	int32_t want_aux;          /* MD / NM / AS wanted (rflags, nm, as)                                  */
+	int32_t want_stats;        /* CIGAR and MD arrays wanted (cigar_off, cigar, md_off, md)             */
+	int32_t n_targets;         /* header's reference count (plausibility of guessed record starts)     */
+	int32_t last;              /* no more bytes follow: every record belongs to the batch, a cut one is an error */
+	int32_t cut_mapped;        /* prefer to end the batch in front of a pool that begins with a mapped record */
+	int32_t reserved_;
+} msx_unpack_params;
+typedef struct msx_unpack_result {
+	int64_t n_records, n_groups;   /* of the batch                                                   */
+	int64_t bytes_consumed;        /* of (carried bytes + new bytes)                                  */
+	int64_t carry_bytes;           /* kept on the device for the next batch                           */
+	int64_t bad_guesses;           /* record-start guesses the chase had to repair                    */
+} msx_unpack_result;
+int  msx_unpack_create(msx_ctx *ctx, msx_unpack **u);
+void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u);
+/* bytes that precede the first msx_unpack_enqueue's (records a host-side reader has left over) and the QNAME of
+ * the last record that named a pool before them (NULL: none) */
+int  msx_unpack_seed(msx_ctx *ctx, msx_unpack *u, const uint8_t *carry, size_t n, const char *prev_name);
+int  msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n, const msx_unpack_params *prm);
+int  msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result *res, msx_batch *dev_view);
+int  msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, uint8_t *host_out,
+                     size_t host_cap, int64_t *n_bytes);
+/* record offsets of the last batch, u32[n + 1] relative to its first byte (tests, SAM-text writers) */
+int  msx_unpack_offsets(msx_ctx *ctx, msx_unpack *u, uint32_t *host, int64_t n);
+
 /* ---- filter: replaces mFilterFileWrapper/mFilterFile + writers ----------- */
 
 /* msam_filter.c:65-263 on one device batch.  Enqueues on the ctx stream and

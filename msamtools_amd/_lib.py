@@ -61,6 +61,15 @@ class ProfileStats(C.Structure):
     ]
 
 
+class UnpackParams(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("pool_mode", "unmapped_visible", "want_aux", "want_stats", "n_targets", "last",
+                                         "cut_mapped", "reserved_")]
+
+
+class UnpackResult(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_records", "n_groups", "bytes_consumed", "carry_bytes", "bad_guesses")]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_groups", C.c_int64), ("n_refs", C.c_int32),
                 ("mean_extra_hits", C.c_int32), ("first_group", C.c_int64)]
@@ -96,6 +105,13 @@ SYMBOLS = {
     "msx_event_record": (C.c_int, [_P, _P]),
     "msx_event_wait": (C.c_int, [_P, _P]),
     "msx_event_destroy": (None, [_P, _P]),
+    "msx_unpack_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "msx_unpack_destroy": (None, [_P, _P]),
+    "msx_unpack_seed": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_char_p]),
+    "msx_unpack_enqueue": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(UnpackParams)]),
+    "msx_unpack_finish": (C.c_int, [_P, _P, C.POINTER(UnpackResult), C.POINTER(Batch)]),
+    "msx_unpack_emit": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_int64)]),
+    "msx_unpack_offsets": (C.c_int, [_P, _P, _P, C.c_int64]),
     "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),
     "msx_filter_finish": (C.c_int, [_P, C.POINTER(FilterStatus)]),
     "msx_aln_stats": (C.c_int, [_P, C.POINTER(Batch), _P, _P, _P, _P, _P]),

@@ -298,6 +298,63 @@ class HostSynth:
             pass
 
 
+class Unpack:
+    """msx_unpack: the record walk on the device (inflated BAM bytes in, msx_batch view out)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.msx_unpack_create(ctx.h, C.byref(h)))
+        self.h = h
+        self._keep = None
+
+    def seed(self, carry=b"", prev_name=None):
+        buf = (C.c_uint8 * max(len(carry), 1)).from_buffer_copy(bytes(carry) or b"\0")
+        self.ctx.check(self.ctx.lib.msx_unpack_seed(self.ctx.h, self.h, buf, len(carry),
+                                                    prev_name.encode() if isinstance(prev_name, str) else prev_name))
+
+    def enqueue(self, data, pool_mode=0, want_aux=True, want_stats=True, n_targets=1 << 30, last=False, cut_mapped=False,
+                unmapped_visible=False):
+        data = bytes(data)
+        self._keep = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        prm = L.UnpackParams(pool_mode, int(unmapped_visible), int(want_aux), int(want_stats), int(n_targets), int(last),
+                             int(cut_mapped), 0)
+        self.ctx.check(self.ctx.lib.msx_unpack_enqueue(self.ctx.h, self.h, self._keep, len(data), C.byref(prm)))
+
+    def finish(self):
+        """(UnpackResult, DeviceBatch view -- owned by the unpacker: do not free)"""
+        res = L.UnpackResult()
+        b = L.Batch()
+        self.ctx.check(self.ctx.lib.msx_unpack_finish(self.ctx.h, self.h, C.byref(res), C.byref(b)))
+        view = DeviceBatch(self.ctx, b)
+        view.free = lambda: None
+        return res, view
+
+    def offsets(self, n_records):
+        out = np.zeros(n_records + 1, np.uint32)
+        self.ctx.check(self.ctx.lib.msx_unpack_offsets(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p), n_records + 1))
+        return out
+
+    def emit(self, emit_ptr, n_emit, cap):
+        out = np.zeros(max(cap, 1), np.uint8)
+        nb = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.msx_unpack_emit(self.ctx.h, self.h, C.c_void_p(emit_ptr), int(n_emit),
+                                                    out.ctypes.data_as(C.c_void_p), out.size, C.byref(nb)))
+        return out[:nb.value].tobytes()
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.msx_unpack_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+
 class FilterResult:
     def __init__(self, keep, emit, as_out, n_emit):
         self.keep, self.emit, self.as_out, self.n_emit = keep, emit, as_out, n_emit

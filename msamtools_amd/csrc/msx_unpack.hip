@@ -1,0 +1,767 @@
+// msx_unpack.hip -- the record walk of the reader loops on the device.
+//
+// mSamRead (msam_helper.c:246-268) hands the loops of msam_filter.c:119-186 / msam_profile.c:222-234 one bam1_t
+// after another; the host pipeline of this repository (csrc/host) turned that into "inflate, find the record
+// boundaries, scan every record's aux block, fill the SoA arrays, compare QNAMEs" on the host cores -- half of the
+// decode stage's time once inflate had been made fast.  Here the inflated BAM bytes of a batch are uploaded as they
+// are and everything after inflate happens on the device:
+//   k_chase_walk      record boundaries.  The block_size chain is serial; every lane takes a 16 KB segment, guesses a
+//                     record start in it (a header that looks like one, followed by two more that do) and walks its
+//                     segment; k_chase_join checks that every segment's first record is where the segment before it
+//                     ended (one wave-wide look) and repairs -- serially, rarely -- where a guess was wrong: from a
+//                     true start the chain is the true chain, so guesses only decide how parallel the walk was.
+//   k_rec_fields      one lane per record: core fields, one pass over the aux block for MD / NM / AS
+//                     (bam_aux_get: first occurrence; bam_aux2i: c C s S i I), CIGAR and MD lengths
+//   k_rec_payload     CIGAR words and MD bytes packed back to back (msx_batch.cigar / md)
+//   k_name_*          the pool rule: a record's QNAME against the QNAME of the nearest earlier record that names the
+//                     read being collected (msam_filter.c:120-125,170 / msam_profile.c:223-232) -- a prefix maximum
+//                     of record indices, then a string compare per record
+//   k_pool_*          group_off from the boundary bits, the batch's last pool boundary (the open pool and the cut
+//                     record behind it stay on the device as the next batch's first bytes), the carried name
+//   k_emit_*          filter's output records, block_size prefixes included, concatenated in output order
+// Integer / byte work, HBM-bound; no MFMA.
+#include "msx_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#define UP_SEG 16384u              // bytes per chase segment (one lane each)
+#define UP_NONE 0xffffffffu
+#define UP_TILE 2048               // records per workgroup in the name kernels (8 per thread)
+
+// device-side state of one batch
+struct up_state {
+	uint32_t n_total;              // complete records found
+	uint32_t tail_off;             // first byte not covered by them
+	uint32_t bad_segments;         // guesses the join had to repair
+	uint32_t status;               // MSX_UP_* below
+	uint32_t cut_any, cut_mapped;  // last pool boundary (record index) / last one whose record is mapped, in the batch's second half
+	uint32_t n_batch, n_groups, cut_off;
+	uint32_t has_prev;             // prev_name holds the QNAME of the last naming record of earlier batches
+	uint32_t emit_bytes;
+	uint32_t pad;
+};
+#define MSX_UP_CORRUPT 1u          // block_size < 32 on the true chain, or a record whose fields do not fit its length
+
+struct msx_unpack {
+	msx_buf raw[2];                // ping-pong: [carry][new bytes] of the current batch, the next batch's carry lands in the other
+	int cur = 0;
+	size_t carry_len = 0, n_bytes = 0;
+	msx_buf seg_first, seg_end, seg_cnt, seg_base;
+	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
+	    group_off, tile_last, cigar, md, out_len, out_off, out;
+	char *prev_name = nullptr;     // device, 256 bytes
+	up_state *d_state = nullptr, *h_state = nullptr;
+	msx_unpack_params prm = {};
+	int64_t n_total = 0, n_batch = 0, n_groups = 0;
+	bool enqueued = false;
+};
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
+	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+
+// ---------------------------------------------------------------------------
+// record boundaries
+// ---------------------------------------------------------------------------
+// does a record plausibly start at `off`?  (only guesses: a wrong one is repaired by k_chase_join)
+__device__ __forceinline__ bool up_plausible(const uint8_t *u, uint32_t off, uint32_t n, int32_t nt) {
+	if ((uint64_t)off + 36u > n) return false;
+	const uint32_t bs = ld32(u + off);
+	if (bs < 32u || bs > (64u << 20)) return false;
+	const uint8_t *r = u + off + 4;
+	const int32_t tid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4), mtid = (int32_t)ld32(r + 20), mpos = (int32_t)ld32(r + 24);
+	const int32_t ls = (int32_t)ld32(r + 16);
+	if (tid < -1 || tid >= nt || mtid < -1 || mtid >= nt || pos < -1 || mpos < -1) return false;
+	const uint32_t lq = r[8], nc = ld16(r + 12);
+	if (lq < 1u || ls < 0) return false;
+	if (32ull + lq + 4ull * nc + ((uint64_t)ls + 1) / 2 + (uint64_t)ls > (uint64_t)bs) return false;
+	if ((uint64_t)off + 4u + 32u + lq > n) return true;
+	if (r[32 + lq - 1] != 0) return false;
+	for (uint32_t k = 0; k + 1 < lq; k++)
+		if (r[32 + k] < 33 || r[32 + k] > 126) return false;
+	return true;
+}
+
+// the records that START in [off, hi): their number, and where the chain stands afterwards (>= hi, or the offset of a
+// record cut by the buffer's end, or of a block_size < 32 -- then *invalid)
+template <bool WRITE>
+__device__ __forceinline__ uint32_t up_walk(const uint8_t *u, uint32_t n, uint32_t off, uint32_t hi, uint32_t *end, bool *invalid,
+                                            uint32_t *out) {
+	uint32_t cnt = 0;
+	*invalid = false;
+	while (off < hi && (uint64_t)off + 4u <= n) {
+		const uint32_t bs = ld32(u + off);
+		if (bs < 32u) { *invalid = true; break; }
+		if ((uint64_t)off + 4u + bs > n) break;               // cut by the buffer's end
+		if (WRITE) out[cnt] = off;
+		cnt++;
+		off += 4u + bs;
+	}
+	*end = off;
+	return cnt;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_chase_walk(const uint8_t *__restrict__ u, uint32_t n, uint32_t nseg, int32_t nt,
+                                                          uint32_t *__restrict__ seg_first, uint32_t *__restrict__ seg_end,
+                                                          uint32_t *__restrict__ seg_cnt) {
+	const uint32_t k = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (k >= nseg) return;
+	const uint32_t lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
+	uint32_t first = lo;
+	if (k > 0) {
+		first = UP_NONE;
+		for (uint32_t off = lo; off < hi; off++) {
+			if (!up_plausible(u, off, n, nt)) continue;
+			const uint32_t o2 = off + 4u + ld32(u + off);
+			if ((uint64_t)o2 + 36u <= n) {
+				if (!up_plausible(u, o2, n, nt)) continue;
+				const uint32_t o3 = o2 + 4u + ld32(u + o2);
+				if ((uint64_t)o3 + 36u <= n && !up_plausible(u, o3, n, nt)) continue;
+			}
+			first = off;
+			break;
+		}
+	}
+	uint32_t end = first, cnt = 0;
+	bool inv = false;
+	if (first != UP_NONE) cnt = up_walk<false>(u, n, first, hi, &end, &inv, nullptr);
+	seg_first[k] = first;
+	seg_end[k] = end;
+	seg_cnt[k] = (first != UP_NONE && !inv) ? cnt : UP_NONE;      // (a walk that ran into a block_size < 32 started from a wrong guess)
+}
+
+// One workgroup: joints, repair, prefix over the segments' counts.  Segment k is right when it starts where segment
+// k - 1 ended -- or, for a segment no record starts in, when the chain had already passed it.
+__global__ __launch_bounds__(MSX_BLOCK) void k_chase_join(const uint8_t *__restrict__ u, uint32_t n, uint32_t nseg,
+                                                          uint32_t *__restrict__ seg_first, uint32_t *__restrict__ seg_end,
+                                                          uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_base,
+                                                          up_state *st) {
+	__shared__ uint32_t s_bad, s_w[MSX_BLOCK / 64], s_run;
+	if (threadIdx.x == 0) { s_bad = 0; s_run = 0; }
+	__syncthreads();
+	uint32_t bad = 0;
+	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += MSX_BLOCK) {
+		const uint32_t pe = seg_end[k - 1], lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
+		const bool ok = (pe < hi) ? (seg_first[k] == pe && seg_cnt[k] != UP_NONE)
+		                          : false;        // the chain jumps over this segment (a long record): repaired below (cheap)
+		bad += ok ? 0u : 1u;
+	}
+	if (seg_cnt[0] == UP_NONE && threadIdx.x == 0) bad++;
+	if (bad) atomicAdd(&s_bad, bad);
+	__syncthreads();
+	if (s_bad && threadIdx.x == 0) {
+		// serial repair: walk every segment whose start does not match from where the chain really stands
+		uint32_t pos = 0, status = 0, fixed = 0;
+		for (uint32_t k = 0; k < nseg; k++) {
+			const uint32_t lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
+			if (k > 0 && seg_first[k] == pos && seg_cnt[k] != UP_NONE && pos < hi) { pos = seg_end[k]; continue; }
+			if (k == 0 && seg_cnt[0] != UP_NONE) { pos = seg_end[0]; continue; }
+			uint32_t end = pos, cnt = 0;
+			bool inv = false;
+			if (pos < hi) cnt = up_walk<false>(u, n, pos, hi, &end, &inv, nullptr);
+			if (inv) status = MSX_UP_CORRUPT;                 // on the true chain: the data is corrupt
+			seg_first[k] = pos;
+			seg_cnt[k] = cnt;
+			seg_end[k] = end;
+			pos = end;
+			fixed++;
+			if (inv) {                                        // nothing behind it can be trusted
+				for (uint32_t q = k + 1; q < nseg; q++) { seg_first[q] = end; seg_cnt[q] = 0; seg_end[q] = end; }
+				break;
+			}
+		}
+		st->bad_segments = fixed;
+		if (status) st->status = status;
+	}
+	__syncthreads();
+	// exclusive prefix of the counts
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (uint32_t base = 0; base < nseg; base += MSX_BLOCK) {
+		const uint32_t k = base + threadIdx.x;
+		const uint32_t v = k < nseg ? seg_cnt[k] : 0u;
+		uint32_t inc = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(inc, d, 64);
+			if (lane >= d) inc += o;
+		}
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		uint32_t woff = 0, tot = 0;
+		for (int q = 0; q < MSX_BLOCK / 64; q++) { if (q < w) woff += s_w[q]; tot += s_w[q]; }
+		if (k < nseg) seg_base[k] = s_run + woff + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 0) s_run += tot;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		seg_base[nseg] = s_run;
+		st->n_total = s_run;
+		st->tail_off = nseg ? seg_end[nseg - 1] : 0u;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_chase_write(const uint8_t *__restrict__ u, uint32_t n, uint32_t nseg,
+                                                           const uint32_t *__restrict__ seg_first, const uint32_t *__restrict__ seg_cnt,
+                                                           const uint32_t *__restrict__ seg_base, uint32_t *__restrict__ rec_off,
+                                                           const up_state *st) {
+	const uint32_t k = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (k == 0) rec_off[st->n_total] = st->tail_off;
+	if (k >= nseg || seg_cnt[k] == 0u) return;
+	const uint32_t lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
+	uint32_t end;
+	bool inv;
+	(void)up_walk<true>(u, n, seg_first[k], hi, &end, &inv, rec_off + seg_base[k]);
+}
+
+// ---------------------------------------------------------------------------
+// fields
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t aux_size(const uint8_t *t, const uint8_t *end) {      // type byte + payload, as msh_aux_size
+	switch (*t) {
+	case 'A': case 'c': case 'C': return 2;
+	case 's': case 'S': return 3;
+	case 'i': case 'I': case 'f': return 5;
+	case 'Z': case 'H': {
+		const uint8_t *p = t + 1;
+		while (p < end && *p) p++;
+		return (uint32_t)(p - t) + 1u;
+	}
+	case 'B': {
+		if (t + 6 > end) return (uint32_t)(end - t);
+		const uint32_t cnt = ld32(t + 2);
+		uint32_t es = 1;
+		switch (t[1]) { case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: break; }
+		const uint64_t sz = 6ull + (uint64_t)cnt * es;
+		return sz > (uint64_t)(end - t) ? (uint32_t)(end - t) : (uint32_t)sz;
+	}
+	default: return (uint32_t)(end - t);      // unknown type: nothing behind it can be parsed
+	}
+}
+
+__device__ __forceinline__ int32_t aux2i(const uint8_t *t) {       // bam_aux2i, truncated to int32 as the reference does
+	switch (*t) {
+	case 'c': return (int8_t)t[1];
+	case 'C': return t[1];
+	case 's': return (int16_t)ld16(t + 1);
+	case 'S': return (int32_t)ld16(t + 1);
+	case 'i': case 'I': return (int32_t)ld32(t + 1);
+	default: return 0;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restrict__ u, uint32_t n_rec,
+                                                          const uint32_t *__restrict__ rec_off, int want_aux, int want_stats,
+                                                          uint16_t *__restrict__ flag, uint8_t *__restrict__ rflags,
+                                                          int32_t *__restrict__ tid, int32_t *__restrict__ pos,
+                                                          int32_t *__restrict__ nm, int32_t *__restrict__ as,
+                                                          uint32_t *__restrict__ cig_cnt, uint32_t *__restrict__ md_len,
+                                                          uint32_t *__restrict__ md_src, up_state *st) {
+	const uint32_t i = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (i >= n_rec) return;
+	const uint32_t o = rec_off[i], len = rec_off[i + 1] - o - 4u;
+	const uint8_t *r = u + o + 4;
+	const uint32_t lq = r[8], nc = ld16(r + 12), fl = ld16(r + 14);
+	const int32_t ls = (int32_t)ld32(r + 16);
+	const uint64_t aux0 = 32ull + lq + 4ull * nc + (ls >= 0 ? ((uint64_t)ls + 1) / 2 + (uint64_t)ls : 0ull);
+	// msh_rec_check: the fields the record announces fit its length, the name is terminated
+	if (ls < 0 || lq < 1u || aux0 > len || r[32 + lq - 1] != 0) {
+		st->status = MSX_UP_CORRUPT;
+		flag[i] = 4; rflags[i] = 0; tid[i] = -1; pos[i] = 0; nm[i] = 0; as[i] = 0; cig_cnt[i] = 0; md_len[i] = 0; md_src[i] = 0;
+		return;
+	}
+	flag[i] = (uint16_t)fl;
+	tid[i] = (int32_t)ld32(r);
+	pos[i] = (int32_t)ld32(r + 4);
+	uint32_t rf = 0, ml = 0, msrc = 0;
+	int32_t vnm = 0, vas = 0;
+	if (want_aux) {
+		const uint8_t *p = r + aux0, *end = r + len;
+		bool md = false, hnm = false, has = false;
+		while (p + 3 <= end) {
+			const uint32_t sz = aux_size(p + 2, end);
+			if (p[0] == 'M' && p[1] == 'D' && !md) {
+				md = true;
+				if (p[2] == 'Z') { ml = sz - 2u; msrc = (uint32_t)(p + 3 - u); if (p + 2 + sz > end || p[2 + sz - 1] != 0) ml = sz - 1u; }
+			} else if (p[0] == 'N' && p[1] == 'M' && !hnm) { hnm = true; vnm = aux2i(p + 2); }
+			else if (p[0] == 'A' && p[1] == 'S' && !has) { has = true; vas = aux2i(p + 2); }
+			p += 2 + sz;
+		}
+		rf = (md ? MSX_HAS_MD : 0u) | (hnm ? MSX_HAS_NM : 0u) | (has ? MSX_HAS_AS : 0u);
+	}
+	rflags[i] = (uint8_t)rf;
+	nm[i] = vnm;
+	as[i] = vas;
+	cig_cnt[i] = want_stats ? nc : 0u;
+	md_len[i] = want_stats ? ml : 0u;
+	md_src[i] = msrc;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_rec_payload(const uint8_t *__restrict__ u, uint32_t n_rec,
+                                                           const uint32_t *__restrict__ rec_off,
+                                                           const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ md_off,
+                                                           const uint32_t *__restrict__ md_src, uint32_t *__restrict__ cigar,
+                                                           uint8_t *__restrict__ md) {
+	const uint32_t i = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (i >= n_rec) return;
+	const uint32_t c0 = cigar_off[i], nc = cigar_off[i + 1] - c0;
+	if (nc) {
+		const uint8_t *r = u + rec_off[i] + 4;
+		const uint8_t *cg = r + 32 + r[8];
+		for (uint32_t k = 0; k < nc; k++) cigar[c0 + k] = ld32(cg + 4 * k);
+	}
+	const uint32_t m0 = md_off[i], ml = md_off[i + 1] - m0;
+	if (ml) {
+		const uint8_t *src = u + md_src[i];
+		for (uint32_t k = 0; k < ml; k++) md[m0 + k] = src[k];
+	}
+}
+
+// ---------------------------------------------------------------------------
+// pools
+// ---------------------------------------------------------------------------
+// mode 1  msam_filter.c:120-125,170: every record is compared, a MAPPED one names the read
+// mode 2  msam_profile.c:223-232: records with tid == -1 are skipped entirely
+// mode 3  profile's rule over the records filter can write when pools do not shape its output
+__device__ __forceinline__ bool names_pool(int mode, int uv, uint32_t fl, int32_t t) {
+	if (mode == 1) return !(fl & 4u);
+	if (mode == 2) return t != -1;
+	return t != -1 && (uv || !(fl & 4u));
+}
+__device__ __forceinline__ bool rule_sees(int mode, int uv, uint32_t fl, int32_t t) { return mode == 1 ? true : names_pool(mode, uv, fl, t); }
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_name_tile_last(uint32_t n_rec, int mode, int uv, const uint16_t *__restrict__ flag,
+                                                              const int32_t *__restrict__ tid, int32_t *__restrict__ tile_last) {
+	__shared__ int32_t s_m;
+	if (threadIdx.x == 0) s_m = -1;
+	__syncthreads();
+	const uint32_t base = blockIdx.x * UP_TILE;
+	int32_t m = -1;
+	for (uint32_t q = threadIdx.x; q < UP_TILE; q += MSX_BLOCK) {
+		const uint32_t i = base + q;
+		if (i < n_rec && names_pool(mode, uv, flag[i], tid[i])) m = (int32_t)i > m ? (int32_t)i : m;
+	}
+	for (int d = 32; d > 0; d >>= 1) { const int32_t o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+	if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(&s_m, m);
+	__syncthreads();
+	if (threadIdx.x == 0) tile_last[blockIdx.x] = s_m;
+}
+
+// exclusive prefix maximum over the tiles (one workgroup; a batch has a few thousand tiles)
+__global__ __launch_bounds__(MSX_BLOCK) void k_name_tile_scan(uint32_t n_tiles, int32_t *__restrict__ tile_last) {
+	__shared__ int32_t s_w[MSX_BLOCK / 64], s_run;
+	if (threadIdx.x == 0) s_run = -1;
+	__syncthreads();
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (uint32_t base = 0; base < n_tiles; base += MSX_BLOCK) {
+		const uint32_t k = base + threadIdx.x;
+		const int32_t v = k < n_tiles ? tile_last[k] : -1;
+		int32_t inc = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int32_t o = __shfl_up(inc, d, 64);
+			if (lane >= d) inc = o > inc ? o : inc;
+		}
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		int32_t pre = s_run;
+		for (int q = 0; q < w; q++) pre = s_w[q] > pre ? s_w[q] : pre;
+		int32_t ex = __shfl_up(inc, 1, 64);
+		if (lane == 0) ex = -1;
+		ex = ex > pre ? ex : pre;
+		int32_t tot = s_run;
+		for (int q = 0; q < MSX_BLOCK / 64; q++) tot = s_w[q] > tot ? s_w[q] : tot;
+		__syncthreads();
+		if (k < n_tiles) tile_last[k] = ex;
+		if (threadIdx.x == 0) s_run = tot;
+		__syncthreads();
+	}
+}
+
+__device__ __forceinline__ bool name_differs(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb) {
+	if (la != lb) return true;
+	for (uint32_t k = 0; k < la; k++)
+		if (a[k] != b[k]) return true;
+	return false;
+}
+
+// bd[i]: record i opens a pool; pidx[i]: the nearest earlier naming record (-1: none in this batch), for i = 0 .. n_rec.
+// Also the batch's last boundary, and the last one in its second half whose record is mapped (cut_mapped).
+__global__ __launch_bounds__(MSX_BLOCK) void k_name_bounds(const uint8_t *__restrict__ u, uint32_t n_rec, int mode, int uv,
+                                                           const uint32_t *__restrict__ rec_off, const uint16_t *__restrict__ flag,
+                                                           const int32_t *__restrict__ tid, const int32_t *__restrict__ tile_carry,
+                                                           const char *__restrict__ prev_name, uint8_t *__restrict__ bd,
+                                                           int32_t *__restrict__ pidx, uint32_t *__restrict__ gflag, up_state *st) {
+	__shared__ int32_t s_w[MSX_BLOCK / 64];
+	__shared__ uint32_t s_cut[2];
+	if (threadIdx.x < 2) s_cut[threadIdx.x] = 0;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t i0 = blockIdx.x * UP_TILE + threadIdx.x * 8u;
+	uint32_t fl[8];
+	int32_t t[8], own[8];
+	int32_t m = -1;
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		const uint32_t i = i0 + q;
+		fl[q] = 4u; t[q] = -1; own[q] = -1;
+		if (i < n_rec) {
+			fl[q] = flag[i]; t[q] = tid[i];
+			if (names_pool(mode, uv, fl[q], t[q])) own[q] = (int32_t)i;
+		}
+		m = own[q] > m ? own[q] : m;
+	}
+	int32_t inc = m;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int32_t o = __shfl_up(inc, d, 64);
+		if (lane >= d) inc = o > inc ? o : inc;
+	}
+	if (lane == 63) s_w[w] = inc;
+	__syncthreads();
+	int32_t run = tile_carry[blockIdx.x];
+	for (int q = 0; q < w; q++) run = s_w[q] > run ? s_w[q] : run;
+	int32_t ex = __shfl_up(inc, 1, 64);
+	if (lane == 0) ex = -1;
+	run = ex > run ? ex : run;                       // nearest naming record before this thread's first record
+	const bool has_prev = st->has_prev != 0;
+	uint32_t cut_any = 0, cut_map = 0;
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		const uint32_t i = i0 + q;
+		if (i <= n_rec) pidx[i] = run;
+		if (i < n_rec) {
+			bool b = false;
+			if (mode != 0 && rule_sees(mode, uv, fl[q], t[q])) {
+				const uint8_t *r = u + rec_off[i] + 4;
+				if (run >= 0) {
+					const uint8_t *p = u + rec_off[run] + 4;
+					b = name_differs(r + 32, r[8], p + 32, p[8]);
+				} else if (has_prev) {
+					uint32_t lp = 0;
+					while (lp < 255u && prev_name[lp]) lp++;
+					b = name_differs(r + 32, r[8], (const uint8_t *)prev_name, lp + 1u);
+				}
+			}
+			bd[i] = b ? 1 : 0;
+			gflag[i] = (b || i == 0u) ? 1u : 0u;
+			if (b && i > 0u) {
+				cut_any = i;
+				if (!(fl[q] & 4u) && i > n_rec / 2u) cut_map = i;
+			}
+		}
+		run = own[q] > run ? own[q] : run;
+	}
+	__syncthreads();
+	if (cut_any) atomicMax(&s_cut[0], cut_any);
+	if (cut_map) atomicMax(&s_cut[1], cut_map);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_cut[0]) atomicMax(&st->cut_any, s_cut[0]);
+		if (s_cut[1]) atomicMax(&st->cut_mapped, s_cut[1]);
+	}
+}
+
+// where the batch ends, its pools, and the name carried into the next one
+__global__ void k_pool_cut(uint32_t n_rec, int mode, int last, int cut_mapped, const uint32_t *__restrict__ rec_off,
+                           const uint32_t *__restrict__ gpos, const int32_t *__restrict__ pidx, const uint8_t *__restrict__ u,
+                           char *__restrict__ prev_name, up_state *st) {
+	uint32_t nb = n_rec;
+	if (!last && mode != 0) nb = (cut_mapped && st->cut_mapped) ? st->cut_mapped : st->cut_any;   // 0: one pool fills the batch, nothing is final yet
+	if (!last && mode == 0) nb = n_rec;
+	st->n_batch = nb;
+	st->n_groups = mode != 0 ? gpos[nb] : 0u;
+	st->cut_off = rec_off[nb];
+	const int32_t p = pidx[nb];
+	if (p >= 0) {
+		const uint8_t *r = u + rec_off[p] + 4;
+		const uint32_t lq = r[8];
+		for (uint32_t k = 0; k < lq && k < 255u; k++) prev_name[k] = (char)r[32 + k];
+		prev_name[lq < 255u ? lq : 255u] = 0;
+		st->has_prev = 1;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_pool_offsets(uint32_t n_rec, const uint32_t *__restrict__ gflag,
+                                                            const uint32_t *__restrict__ gpos, uint32_t *__restrict__ group_off,
+                                                            const up_state *st) {
+	const uint32_t i = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	const uint32_t nb = st->n_batch;
+	if (i == 0) group_off[st->n_groups] = nb;
+	if (i < nb && gflag[i]) group_off[gpos[i]] = i;
+}
+
+// ---------------------------------------------------------------------------
+// filter's output: the emitted records, block_size prefixes included, back to back
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MSX_BLOCK) void k_emit_len(uint32_t n_emit, const int32_t *__restrict__ emit,
+                                                        const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ out_len) {
+	const uint32_t k = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (k < n_emit) { const uint32_t i = (uint32_t)emit[k]; out_len[k] = rec_off[i + 1] - rec_off[i]; }
+}
+
+// one wave per 16 consecutive output records; the lanes copy a record's bytes side by side
+#define EM_PER_WAVE 16
+__global__ __launch_bounds__(MSX_BLOCK) void k_emit_copy(const uint8_t *__restrict__ u, uint32_t n_emit, const int32_t *__restrict__ emit,
+                                                         const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ out_off,
+                                                         uint8_t *__restrict__ out, up_state *st) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = (blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
+	if (wave == 0 && lane == 0) st->emit_bytes = out_off[n_emit];
+	const uint32_t k0 = wave * EM_PER_WAVE;
+	for (uint32_t q = 0; q < EM_PER_WAVE; q++) {
+		const uint32_t k = k0 + q;
+		if (k >= n_emit) return;
+		const uint32_t i = (uint32_t)emit[k], s = rec_off[i], len = rec_off[i + 1] - s, d = out_off[k];
+		for (uint32_t b = lane; b < len; b += 64u) out[d + b] = u[s + b];
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+extern "C" int msx_unpack_create(msx_ctx *ctx, msx_unpack **out) {
+	if (!ctx || !out) return MSX_ERR_ARG;
+	*out = nullptr;
+	msx_join(ctx);
+	msx_unpack *u = new msx_unpack();
+	if (hipMalloc((void **)&u->prev_name, 256) != hipSuccess || hipMalloc((void **)&u->d_state, sizeof(up_state)) != hipSuccess ||
+	    hipHostMalloc((void **)&u->h_state, sizeof(up_state), hipHostMallocDefault) != hipSuccess) {
+		msx_unpack_destroy(ctx, u);
+		return msx_fail(ctx, MSX_ERR_NOMEM, "msx_unpack_create: allocation failed");
+	}
+	(void)hipMemsetAsync(u->prev_name, 0, 256, ctx->stream);
+	(void)hipMemsetAsync(u->d_state, 0, sizeof(up_state), ctx->stream);
+	*out = u;
+	return MSX_OK;
+}
+
+extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
+	if (!u) return;
+	if (ctx && ctx->stream) { msx_join(ctx); (void)hipStreamSynchronize(ctx->stream); }
+	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
+	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
+	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
+	                   &u->out_off, &u->out};
+	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+	if (u->prev_name) (void)hipFree(u->prev_name);
+	if (u->d_state) (void)hipFree(u->d_state);
+	if (u->h_state) (void)hipHostFree(u->h_state);
+	delete u;
+}
+
+// grow a buffer keeping its first `keep` bytes
+static int grow_keep_n(msx_ctx *ctx, msx_buf *b, size_t bytes, size_t keep) {
+	if (bytes <= b->cap && b->p) return MSX_OK;
+	const size_t want = bytes + bytes / 4 + 4096;
+	void *np = nullptr;
+	if (hipMalloc(&np, want) != hipSuccess) return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed", want);
+	if (b->p) {
+		if (keep) (void)hipMemcpyAsync(np, b->p, keep, hipMemcpyDeviceToDevice, ctx->stream);
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipFree(b->p);
+	}
+	b->p = np;
+	b->cap = want;
+	return MSX_OK;
+}
+
+extern "C" int msx_unpack_seed(msx_ctx *ctx, msx_unpack *u, const uint8_t *carry, size_t n, const char *prev_name) {
+	if (!ctx || !u) return MSX_ERR_ARG;
+	msx_join(ctx);
+	int rc = grow_keep_n(ctx, &u->raw[u->cur], n + 64, 0);
+	if (rc) return rc;
+	if (n) MSX_HIP(ctx, hipMemcpyAsync(u->raw[u->cur].p, carry, n, hipMemcpyHostToDevice, ctx->stream));
+	u->carry_len = n;
+	up_state z;
+	memset(&z, 0, sizeof z);
+	char nm[256];
+	memset(nm, 0, sizeof nm);
+	if (prev_name) { strncpy(nm, prev_name, 255); z.has_prev = 1; }
+	MSX_HIP(ctx, hipMemcpyAsync(u->prev_name, nm, 256, hipMemcpyHostToDevice, ctx->stream));
+	MSX_HIP(ctx, hipMemcpyAsync(u->d_state, &z, sizeof z, hipMemcpyHostToDevice, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));       // (nm and z live on this stack)
+	return MSX_OK;
+}
+
+#define UP_RES(field, bytes) if ((rc = msx_reserve(ctx, &u->field, (bytes)))) return rc
+
+extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n_new, const msx_unpack_params *prm) {
+	if (!ctx || !u || !prm || (!host_bytes && n_new)) return MSX_ERR_ARG;
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t n = u->carry_len + n_new;
+	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue: more than 4 GiB in one batch");
+	int rc;
+	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 64, u->carry_len))) return rc;
+	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, host_bytes, n_new, hipMemcpyHostToDevice, ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(raw + n, 0, 64, ctx->stream));
+	u->n_bytes = n;
+	u->prm = *prm;
+	u->enqueued = true;
+	// the state of this batch (has_prev and prev_name carry over)
+	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 8, ctx->stream));
+	const uint32_t nseg = (uint32_t)((n + UP_SEG - 1) / UP_SEG);
+	const size_t cap = n / 36 + 16;               // records: a record is at least 37 bytes with its block_size
+	UP_RES(seg_first, (size_t)(nseg + 2) * 4); UP_RES(seg_end, (size_t)(nseg + 2) * 4);
+	UP_RES(seg_cnt, (size_t)(nseg + 2) * 4); UP_RES(seg_base, (size_t)(nseg + 2) * 4);
+	UP_RES(rec_off, (cap + 2) * 4);
+	if (nseg == 0) return MSX_OK;
+	hipLaunchKernelGGL(k_chase_walk, dim3((nseg + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, raw, (uint32_t)n, nseg,
+	                   prm->n_targets, (uint32_t *)u->seg_first.p, (uint32_t *)u->seg_end.p, (uint32_t *)u->seg_cnt.p);
+	hipLaunchKernelGGL(k_chase_join, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, raw, (uint32_t)n, nseg, (uint32_t *)u->seg_first.p,
+	                   (uint32_t *)u->seg_end.p, (uint32_t *)u->seg_cnt.p, (uint32_t *)u->seg_base.p, u->d_state);
+	hipLaunchKernelGGL(k_chase_write, dim3((nseg + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, raw, (uint32_t)n, nseg,
+	                   (const uint32_t *)u->seg_first.p, (const uint32_t *)u->seg_cnt.p, (const uint32_t *)u->seg_base.p,
+	                   (uint32_t *)u->rec_off.p, (const up_state *)u->d_state);
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+static int up_fetch_state(msx_ctx *ctx, msx_unpack *u) {
+	MSX_HIP(ctx, hipMemcpyAsync(u->h_state, u->d_state, sizeof(up_state), hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}
+
+extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result *res, msx_batch *dev) {
+	if (!ctx || !u || !res || !dev) return MSX_ERR_ARG;
+	if (!u->enqueued) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_finish without msx_unpack_enqueue");
+	u->enqueued = false;
+	msx_join(ctx);
+	memset(res, 0, sizeof *res);
+	memset(dev, 0, sizeof *dev);
+	const msx_unpack_params &P = u->prm;
+	const size_t n = u->n_bytes;
+	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	int rc;
+	if (n > 0) {
+		if ((rc = up_fetch_state(ctx, u))) return rc;               // sync 1: how many records
+		if (u->h_state->status == MSX_UP_CORRUPT) return msx_fail(ctx, MSX_ERR_ARG, "Corrupt BAM record");
+	} else {
+		memset(u->h_state, 0, sizeof(up_state));
+	}
+	const uint32_t nr = n ? u->h_state->n_total : 0u;
+	u->n_total = nr;
+	res->bad_guesses = n ? u->h_state->bad_segments : 0;
+	if (P.last && n && u->h_state->tail_off != (uint32_t)n) return msx_fail(ctx, MSX_ERR_ARG, "Truncated BAM record");
+	if (nr == 0) {
+		// nothing complete yet (or nothing at all): everything stays as the carry
+		res->carry_bytes = (int64_t)n;
+		u->carry_len = n;
+		return MSX_OK;
+	}
+	const size_t c = (size_t)nr + 8;
+	UP_RES(flag, c * 2); UP_RES(rflags, c); UP_RES(tid, c * 4); UP_RES(pos, c * 4); UP_RES(nm, c * 4); UP_RES(as, c * 4);
+	UP_RES(cig_cnt, c * 4); UP_RES(cigar_off, (c + 1) * 4); UP_RES(md_len, c * 4); UP_RES(md_off, (c + 1) * 4); UP_RES(md_src, c * 4);
+	UP_RES(bd, c); UP_RES(pidx, (c + 1) * 4); UP_RES(gflag, c * 4); UP_RES(gpos, (c + 1) * 4); UP_RES(group_off, (c + 1) * 4);
+	const uint32_t n_tiles = (nr + 1 + UP_TILE - 1) / UP_TILE;
+	UP_RES(tile_last, (size_t)(n_tiles + 2) * 4);
+	const unsigned gr = (nr + MSX_BLOCK - 1) / MSX_BLOCK;
+	const uint32_t *rec_off = (const uint32_t *)u->rec_off.p;
+	hipLaunchKernelGGL(k_rec_fields, dim3(gr), dim3(MSX_BLOCK), 0, ctx->stream, raw, nr, rec_off, P.want_aux, P.want_stats,
+	                   (uint16_t *)u->flag.p, (uint8_t *)u->rflags.p, (int32_t *)u->tid.p, (int32_t *)u->pos.p, (int32_t *)u->nm.p,
+	                   (int32_t *)u->as.p, (uint32_t *)u->cig_cnt.p, (uint32_t *)u->md_len.p, (uint32_t *)u->md_src.p, u->d_state);
+	if (P.want_stats) {
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->cig_cnt.p, (uint32_t *)u->cigar_off.p, nr))) return rc;
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->md_len.p, (uint32_t *)u->md_off.p, nr))) return rc;
+		// (the payload arrays are bounded by the bytes they come from)
+		UP_RES(cigar, n + 64);
+		UP_RES(md, n + 64);
+		hipLaunchKernelGGL(k_rec_payload, dim3(gr), dim3(MSX_BLOCK), 0, ctx->stream, raw, nr, rec_off, (const uint32_t *)u->cigar_off.p,
+		                   (const uint32_t *)u->md_off.p, (const uint32_t *)u->md_src.p, (uint32_t *)u->cigar.p, (uint8_t *)u->md.p);
+	}
+	if (P.pool_mode != 0) {
+		hipLaunchKernelGGL(k_name_tile_last, dim3(n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, nr, P.pool_mode, P.unmapped_visible,
+		                   (const uint16_t *)u->flag.p, (const int32_t *)u->tid.p, (int32_t *)u->tile_last.p);
+		hipLaunchKernelGGL(k_name_tile_scan, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, n_tiles, (int32_t *)u->tile_last.p);
+		hipLaunchKernelGGL(k_name_bounds, dim3(n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, raw, nr, P.pool_mode, P.unmapped_visible, rec_off,
+		                   (const uint16_t *)u->flag.p, (const int32_t *)u->tid.p, (const int32_t *)u->tile_last.p,
+		                   (const char *)u->prev_name, (uint8_t *)u->bd.p, (int32_t *)u->pidx.p, (uint32_t *)u->gflag.p, u->d_state);
+		if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->gflag.p, (uint32_t *)u->gpos.p, nr))) return rc;
+	} else {
+		MSX_HIP(ctx, hipMemsetAsync(u->pidx.p, 0xff, (c + 1) * 4, ctx->stream));
+	}
+	hipLaunchKernelGGL(k_pool_cut, dim3(1), dim3(1), 0, ctx->stream, nr, P.pool_mode, P.last, P.cut_mapped, rec_off,
+	                   (const uint32_t *)u->gpos.p, (const int32_t *)u->pidx.p, raw, u->prev_name, u->d_state);
+	if (P.pool_mode != 0)
+		hipLaunchKernelGGL(k_pool_offsets, dim3(gr), dim3(MSX_BLOCK), 0, ctx->stream, nr, (const uint32_t *)u->gflag.p,
+		                   (const uint32_t *)u->gpos.p, (uint32_t *)u->group_off.p, (const up_state *)u->d_state);
+	MSX_HIP(ctx, hipGetLastError());
+	if ((rc = up_fetch_state(ctx, u))) return rc;                   // sync 2: where the batch ends
+	if (u->h_state->status == MSX_UP_CORRUPT) return msx_fail(ctx, MSX_ERR_ARG, "Corrupt BAM record");
+	const up_state &S = *u->h_state;
+	u->n_batch = S.n_batch;
+	u->n_groups = S.n_groups;
+	res->n_records = S.n_batch;
+	res->n_groups = S.n_groups;
+	res->bytes_consumed = S.cut_off;
+	res->carry_bytes = (int64_t)n - (int64_t)S.cut_off;
+	// the bytes behind the batch become the head of the next one (in the other buffer: this one stays valid for
+	// msx_unpack_emit_enqueue and for the views handed out below)
+	{
+		const int nxt = u->cur ^ 1;
+		const size_t cl = n - S.cut_off;
+		if ((rc = grow_keep_n(ctx, &u->raw[nxt], cl + 64, 0))) return rc;
+		if (cl) MSX_HIP(ctx, hipMemcpyAsync(u->raw[nxt].p, raw + S.cut_off, cl, hipMemcpyDeviceToDevice, ctx->stream));
+		u->carry_len = cl;
+		u->cur = nxt;
+	}
+	dev->n_records = S.n_batch;
+	dev->n_groups = P.pool_mode != 0 ? (int64_t)S.n_groups : 0;
+	dev->flag = (const uint16_t *)u->flag.p; dev->rflags = (const uint8_t *)u->rflags.p;
+	dev->tid = (const int32_t *)u->tid.p; dev->pos = (const int32_t *)u->pos.p;
+	dev->nm = (const int32_t *)u->nm.p; dev->as = (const int32_t *)u->as.p;
+	if (P.want_stats) {
+		dev->cigar_off = (const uint32_t *)u->cigar_off.p; dev->cigar = (const uint32_t *)u->cigar.p;
+		dev->md_off = (const uint32_t *)u->md_off.p; dev->md = (const uint8_t *)u->md.p;
+	}
+	if (P.pool_mode != 0) dev->group_off = (const uint32_t *)u->group_off.p;
+	dev->pool_rule = P.pool_mode == 1 ? MSX_POOLS_FILTER : MSX_POOLS_PROFILE;
+	return MSX_OK;
+}
+
+extern "C" int msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, uint8_t *host_out,
+                               size_t host_cap, int64_t *n_bytes) {
+	if (!ctx || !u || !n_bytes || (n_emit > 0 && (!emit_idx_dev || !host_out))) return MSX_ERR_ARG;
+	msx_join(ctx);
+	*n_bytes = 0;
+	if (n_emit <= 0) return MSX_OK;
+	if (n_emit > u->n_batch) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: more records than the batch holds");
+	int rc;
+	const uint32_t ne = (uint32_t)n_emit;
+	// the batch's bytes are in the buffer the carry was NOT copied into
+	const uint8_t *raw = (const uint8_t *)u->raw[u->cur ^ 1].p;
+	UP_RES(out_len, ((size_t)ne + 8) * 4);
+	UP_RES(out_off, ((size_t)ne + 8) * 4);
+	UP_RES(out, u->n_bytes + 64);
+	hipLaunchKernelGGL(k_emit_len, dim3((ne + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, ne, emit_idx_dev,
+	                   (const uint32_t *)u->rec_off.p, (uint32_t *)u->out_len.p);
+	if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->out_len.p, (uint32_t *)u->out_off.p, ne))) return rc;
+	const uint32_t n_waves = (ne + EM_PER_WAVE - 1) / EM_PER_WAVE;
+	hipLaunchKernelGGL(k_emit_copy, dim3((n_waves + 3) / 4), dim3(MSX_BLOCK), 0, ctx->stream, raw, ne, emit_idx_dev,
+	                   (const uint32_t *)u->rec_off.p, (const uint32_t *)u->out_off.p, (uint8_t *)u->out.p, u->d_state);
+	MSX_HIP(ctx, hipGetLastError());
+	if ((rc = up_fetch_state(ctx, u))) return rc;                   // sync: how many bytes
+	const size_t tb = u->h_state->emit_bytes;
+	if (tb > host_cap) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: output buffer too small (%zu > %zu)", tb, host_cap);
+	MSX_HIP(ctx, hipMemcpyAsync(host_out, u->out.p, tb, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*n_bytes = (int64_t)tb;
+	return MSX_OK;
+}
+
+// for tests: the record offsets of the batch (u32 [n_records + 1], relative to the batch's first byte)
+extern "C" int msx_unpack_offsets(msx_ctx *ctx, msx_unpack *u, uint32_t *host, int64_t n) {
+	if (!ctx || !u || !host) return MSX_ERR_ARG;
+	msx_join(ctx);
+	if (n > u->n_total + 1) n = u->n_total + 1;
+	if (n > 0) {
+		MSX_HIP(ctx, hipMemcpyAsync(host, u->rec_off.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return MSX_OK;
+}
