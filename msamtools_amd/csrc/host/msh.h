@@ -107,6 +107,8 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 void msh_write(msh_out *o, const uint8_t *rec, size_t len);
 /* records base + rec_off[idx[k]] (+4 = past the block_size prefix), k = 0..n-1; multi-threaded */
 void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, const int32_t *idx, size_t n);
+/* a ready-made record stream ([block_size | record] back to back, as msx_unpack_emit returns it) */
+void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n);
 void msh_out_close(msh_out *o);
 
 /* SAM text <-> BAM record */

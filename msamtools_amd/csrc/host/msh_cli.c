@@ -613,6 +613,7 @@ static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int 
 #define PIPE_SLOTS_MAX (PIPE_SLOTS + MSH_MAX_DEVICES)
 #define MSH_POOL_MAX 128
 #define PQ_END (-1)                     /* queue item: end of the stream (one per consumer) */
+#define BGZF_INFLATE_MAX ((size_t)1024 * 65536)   /* msh_inflate_append appends at most one batch of blocks (msh_io.c: BGZF_BATCH x BGZF_MAX) */
 
 typedef struct {
 	pthread_mutex_t mu;
@@ -647,6 +648,14 @@ typedef struct {
 	size_t seq;                /* number of the batch in the input: the writer's order */
 	int eof;                   /* end-of-stream marker */
 	int pinned;
+	/* device unpack (msx_unpack): the slot carries inflated bytes only, cut anywhere */
+	int raw, last;             /* raw: ubuf[0, ulen) is all there is; last: nothing follows */
+	int has_seed, seed_has_name;
+	kstr seed;                 /* what the host-side reader left over in front of the first raw slot */
+	char seed_name[256];
+	uint8_t *ubuf_reg;         /* ubuf as page-locked by the device thread (never moved afterwards) */
+	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit), page-locked */
+	size_t ocap, olen;
 } pslot;
 
 typedef struct {
@@ -656,6 +665,8 @@ typedef struct {
 	int unmapped_visible;      /* mode 3: -k -v with a PPT >= 0 filter writes unmapped records (msam_filter.c:132-138) */
 	int cut_mapped;            /* prefer batch ends in front of a pool that begins with a MAPPED record (an insert's first pool) */
 	int n_slots, n_consumers;
+	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
+	int raw_started, raw_done;
 	size_t n_filled;           /* batches handed on so far */
 	size_t batch_bytes, cap_rec, cap_cig, cap_md;
 	pslot slot[PIPE_SLOTS_MAX];
@@ -1064,7 +1075,45 @@ static void *pipe_decode_thread(void *arg) {
 		size_t n;
 		t1 = now_s();
 		P->t_wait_free += t1 - t0;
-		n = pipe_fill(P, s);
+		s->raw = 0;
+		if (P->raw_mode && P->n_filled >= 1) {
+			/* device unpack: inflate only.  The first raw slot takes along what batch 0's host-side cut left over. */
+			double tq = now_s();
+			if (P->raw_done || (!P->raw_started && P->in_eof && P->carry.l == 0)) {
+				n = 0;
+			} else {
+				s->raw = 1;
+				s->ulen = 0;
+				s->has_seed = 0;
+				if (!P->raw_started) {
+					P->raw_started = 1;
+					s->has_seed = 1;
+					s->seed.l = 0;
+					if (P->carry.l) ks_put(&s->seed, P->carry.s, P->carry.l);
+					P->carry.l = 0;
+					s->seed_has_name = P->have_prev;
+					if (P->have_prev) strcpy(s->seed_name, P->prev_read);
+				}
+				if (!s->ubuf_reg && s->ucap < P->batch_bytes + BGZF_INFLATE_MAX + 64) {      /* sized once, before it is page-locked */
+					s->ucap = P->batch_bytes + BGZF_INFLATE_MAX + 64;
+					s->ubuf = (uint8_t *)realloc(s->ubuf, s->ucap);
+					if (!s->ubuf) mDie("Out of memory");
+				}
+				for (;;) {
+					/* (a page-locked buffer must not move: stop short of its end rather than let it be reallocated) */
+					const size_t room = (size_t)BGZF_INFLATE_MAX + 64;
+					if (P->in_eof || s->ulen >= P->batch_bytes) break;
+					if (s->ubuf_reg && s->ulen + room > s->ucap) break;
+					if (!msh_inflate_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
+				}
+				s->last = P->in_eof;
+				if (s->last) P->raw_done = 1;
+				n = 1;                       /* (a slot: possibly without bytes, its `last` flag flushes the device's carry) */
+			}
+			P->t_inflate += now_s() - tq;
+		} else {
+			n = pipe_fill(P, s);
+		}
 		P->t_decode += now_s() - t1;
 		s->eof = n == 0;
 		if (n == 0) {
@@ -1394,6 +1443,7 @@ static void *filter_dev_thread(void *arg) {
 	fshared *F = D->S;
 	pipe_t *P = F->P;
 	msx_stage *stage = NULL;
+	msx_unpack *unpack = NULL;
 	{
 		double t0 = now_s();
 		ctx_open_dev(D->dev_id);             /* HIP start-up runs beside the decoding of the first batch */
@@ -1416,6 +1466,42 @@ static void *filter_dev_thread(void *arg) {
 		if (si == PQ_END) break;
 		s = &P->slot[si];
 		b = &s->b;
+		if (s->raw) {
+			/* the record walk on the device: inflated bytes up, filter's output records back */
+			msx_unpack_params up;
+			msx_unpack_result ur;
+			int64_t nb = 0;
+			if (!unpack) MSX(msx_unpack_create(g_ctx, &unpack));
+			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
+			if (!s->ubuf_reg && s->ubuf && !getenv("MSX_NO_PIN")) { MSX(msx_host_register(g_ctx, s->ubuf, s->ucap)); s->ubuf_reg = s->ubuf; }
+			memset(&up, 0, sizeof up);
+			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
+			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
+			MSX(msx_unpack_enqueue(g_ctx, unpack, s->ubuf, s->ulen, &up));
+			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+			D->t_upload += now_s() - t1; t1 = now_s();
+			b->n = (size_t)ur.n_records;
+			s->n_emit = 0;
+			s->olen = 0;
+			if (ur.n_records > 0) {
+				MSX(msx_stage_outputs(g_ctx, stage, ur.n_records, 0, &fo));
+				if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
+				else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
+				if (msx_filter_finish(g_ctx, &st) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+				D->t_gpu += now_s() - t1; t1 = now_s();
+				s->n_emit = st.n_emit;
+				if ((size_t)ur.bytes_consumed + 64 > s->ocap) {
+					if (s->obuf) msx_host_free(g_ctx, s->obuf);
+					s->ocap = (size_t)ur.bytes_consumed + (size_t)ur.bytes_consumed / 4 + ((size_t)16 << 20);
+					MSX(msx_host_alloc(g_ctx, (void **)&s->obuf, s->ocap));
+				}
+				MSX(msx_unpack_emit(g_ctx, unpack, fo.emit_idx, st.n_emit, s->obuf, s->ocap, &nb));
+				s->olen = (size_t)nb;
+				D->t_fetch += now_s() - t1;
+			}
+			pq_push(&P->q_out, si);
+			continue;
+		}
 		if (s->seq == 0) { filter_open_output(F, b); t1 = now_s(); }
 		pipe_pin_slot(P, s);
 		rb_host_view(b, &hb, P->mode != 0);
@@ -1435,6 +1521,7 @@ static void *filter_dev_thread(void *arg) {
 	}
 	MSX(msx_ctx_sync(g_ctx));
 	msx_stage_destroy(g_ctx, stage);
+	msx_unpack_destroy(g_ctx, unpack);
 	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
 	pthread_mutex_lock(&F->mu);
 	if (++F->n_done == F->n_dev) {
@@ -1531,6 +1618,10 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	pipe_init(&P, in, pools ? 1 : (po ? 3 : 0), want_stats, F.n_dev);
 	P.unmapped_visible = unmapped_written;
 	P.cut_mapped = pools && po;
+	/* From the second batch on the record walk runs on the device (msx_unpack): one context, records written as they
+	 * are (no --rescore), BAM out.  The first batch takes the host-side walk: the preflight reads its records.
+	 * MSX_HOST_UNPACK=1 keeps every batch on the host. */
+	P.raw_mode = F.n_dev == 1 && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) && !getenv("MSX_HOST_UNPACK");
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
 	if (po) prof_features(po, P.hdr, &pf);
@@ -1549,7 +1640,9 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		t_wait += t1 - t0;
 		if (si == PQ_END) break;
 		s = &P.slot[si];
-		if (!fp->rescore) {
+		if (s->raw) {
+			msh_write_stream(F.out, s->obuf, s->olen);
+		} else if (!fp->rescore) {
 			msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
 		} else if (s->n_emit > 0) {
 			const size_t n = (size_t)s->n_emit;
@@ -1874,6 +1967,7 @@ static void *profile_dev_thread(void *arg) {
 	pshared *S = D->S;
 	pipe_t *P = S->P;
 	msx_stage *stage = NULL;
+	msx_unpack *unpack = NULL;
 	msx_event *ev[PIPE_SLOTS_MAX] = {NULL};
 	int held = -1, q;                          /* slot whose uploads may still be in flight */
 	double t0 = now_s();
@@ -1894,6 +1988,24 @@ static void *profile_dev_thread(void *arg) {
 		D->t_wait += t1 - t0;
 		if (si == PQ_END) break;
 		s = &P->slot[si];
+		if (s->raw) {
+			msx_unpack_params up;
+			msx_unpack_result ur;
+			if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); held = -1; }
+			if (!unpack) MSX(msx_unpack_create(g_ctx, &unpack));
+			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
+			if (!s->ubuf_reg && s->ubuf && !getenv("MSX_NO_PIN")) { MSX(msx_host_register(g_ctx, s->ubuf, s->ucap)); s->ubuf_reg = s->ubuf; }
+			memset(&up, 0, sizeof up);
+			up.pool_mode = 2; up.n_targets = P->hdr->n_targets; up.last = s->last;
+			MSX(msx_unpack_enqueue(g_ctx, unpack, s->ubuf, s->ulen, &up));
+			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));   /* (synchronises: the slot's bytes have left) */
+			if (ur.n_records > 0) MSX(msx_profile_accumulate(g_ctx, D->prof, &db, NULL));
+			D->n_in += (size_t)ur.n_records;
+			D->n_batches++;
+			pq_push(&P->q_free, si);
+			D->t_dev += now_s() - t1;
+			continue;
+		}
 		if (s->seq == 0) S->qn = qn_check(P->hdr, &s->b);            /* :708, always for profile */
 		pipe_pin_slot(P, s);
 		rb_host_view(&s->b, &hb, 1);
@@ -1914,6 +2026,7 @@ static void *profile_dev_thread(void *arg) {
 	if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); }
 	MSX(msx_ctx_sync(g_ctx));
 	msx_stage_destroy(g_ctx, stage);
+	msx_unpack_destroy(g_ctx, unpack);
 	for (q = 0; q < PIPE_SLOTS_MAX; q++) msx_event_destroy(g_ctx, ev[q]);
 	return NULL;
 }
@@ -2024,6 +2137,7 @@ int msam_profile_main(int argc, char *argv[]) {
 		memset(&S, 0, sizeof S);
 		S.n_dev = device_list(dev_ids);
 		pipe_init(&P, in, 2, 0, S.n_dev);
+		P.raw_mode = S.n_dev == 1 && !getenv("MSX_HOST_UNPACK");       /* the record walk of every batch but the first on the device */
 		S.P = &P; S.o = &o; S.F = &F;
 		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 		for (k = 0; k < S.n_dev; k++) {

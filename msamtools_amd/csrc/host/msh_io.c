@@ -1656,6 +1656,100 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 	}
 }
 
+/* The same for a ready-made record stream (records with their block_size prefixes, back to back -- what
+ * msx_unpack_emit returns): payloads of BGZF_PAYLOAD bytes cut where they fall (a record may straddle two blocks, as
+ * the format allows), blocks built by all threads, written in order by the writer thread. */
+typedef struct {
+	msh_out *o;
+	const uint8_t *bytes;
+	size_t nblk;
+	uint8_t *slots;
+	uint32_t *slot_len;
+} sjob;
+
+static void wstream_worker(void *arg, int tid, int nth) {
+	sjob *w = (sjob *)arg;
+	const int stored = w->o->level == 0;
+	size_t k;
+	for (k = (size_t)tid; k < w->nblk; k += (size_t)nth) {
+		uint8_t *slot = w->slots + k * WSLOT;
+		const uint8_t *src = w->bytes + k * BGZF_PAYLOAD;
+		const uint32_t n = BGZF_PAYLOAD;
+		if (stored) {
+			memcpy(slot + 18 + 5, src, n);
+			slot[18] = 1; slot[19] = (uint8_t)n; slot[20] = (uint8_t)(n >> 8); slot[21] = (uint8_t)~n; slot[22] = (uint8_t)(~n >> 8);
+			bgzf_finish(slot, 5 + n, msh_crc32(src, n), n);
+			w->slot_len[k] = 18 + 5 + n + 8;
+		} else {
+			w->slot_len[k] = bgzf_compress(slot, src, n, w->o->level);
+		}
+	}
+}
+
+void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n) {
+	const int nth = msh_threads();
+	size_t nb, done;
+	if (n == 0) return;
+	if (o->mode != MSH_OUT_BAM && o->mode != MSH_OUT_UBAM) {          /* text: record by record */
+		size_t p = 0;
+		while (p + 4 <= n) {
+			const size_t len = (size_t)(uint32_t)le32(bytes + p);
+			msh_write(o, bytes + p + 4, len);
+			p += 4 + len;
+		}
+		return;
+	}
+	uint8_t *carry = NULL;
+	uint32_t carry_len = 0;
+	if (o->ulen) {                           /* top up the block the previous call left open */
+		const size_t room = BGZF_PAYLOAD - o->ulen, k = n < room ? n : room;
+		memcpy(o->ubuf + o->ulen, bytes, k);
+		o->ulen += (uint32_t)k;
+		bytes += k;
+		n -= k;
+		if (o->ulen == BGZF_PAYLOAD) {       /* full: it travels as block 0 of this call's first chunk */
+			if (!(carry = (uint8_t *)malloc(BGZF_MAX + 1024))) mDie("Out of memory");
+			carry_len = bgzf_compress(carry, o->ubuf, o->ulen, o->level);
+			o->ulen = 0;
+		}
+	}
+	nb = n / BGZF_PAYLOAD;
+	if (nb == 0 && carry) {
+		out_bytes(o, carry, carry_len);
+		free(carry);
+		carry = NULL;
+	}
+	for (done = 0; done < nb;) {
+		struct wchunk *c = (struct wchunk *)calloc(1, sizeof(*c));
+		sjob w;
+		const size_t extra = carry ? 1 : 0;
+		const size_t take = nb - done < WCHUNK_BLOCKS - extra ? nb - done : WCHUNK_BLOCKS - extra;
+		if (!c) mDie("Out of memory");
+		c->nblk = take + extra;
+		c->slots_bytes = c->nblk * WSLOT;
+		c->mapped = __atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED);
+		c->slots = c->mapped ? (uint8_t *)mmap(NULL, c->slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)
+		                     : (uint8_t *)malloc(c->slots_bytes);
+		c->slot_len = (uint32_t *)malloc(c->nblk * sizeof(uint32_t));
+		if (!c->slots || c->slots == (uint8_t *)MAP_FAILED || !c->slot_len) mDie("Out of memory");
+		if (carry) {
+			memcpy(c->slots, carry, carry_len);
+			c->slot_len[0] = carry_len;
+			free(carry);
+			carry = NULL;
+		}
+		w.o = o; w.bytes = bytes + done * BGZF_PAYLOAD; w.nblk = take; w.slots = c->slots + extra * WSLOT; w.slot_len = c->slot_len + extra;
+		msh_parallel(nth < (int)take ? nth : (int)take, wstream_worker, &w);
+		writer_put(o, c);
+		done += take;
+	}
+	if (n > nb * BGZF_PAYLOAD) {             /* the rest waits in the open block */
+		const size_t rest = n - nb * BGZF_PAYLOAD;
+		memcpy(o->ubuf, bytes + nb * BGZF_PAYLOAD, rest);
+		o->ulen = (uint32_t)rest;
+	}
+}
+
 void msh_out_close(msh_out *o) {
 	if (!o) return;
 	if (o->mode == MSH_OUT_BAM || o->mode == MSH_OUT_UBAM) {

@@ -261,3 +261,24 @@ def test_rescore_on_the_pipeline(mid, tmp_path):
     got_as = [int(next(x for x in l.split("\t")[11:] if x.startswith("AS:i:"))[5:]) for l in ta]
     assert got_as == f["as_out"][f["emit"]].tolist()
     assert all(l.split("\t")[-1].startswith("AS:i:") for l in ta[:1000])          # appended at the end (:167)
+
+
+# ---- the record walk on the device (msx_unpack) against the host-side walk ----------------------------------------
+
+def test_device_unpack_equals_host_unpack(big, tmp_path):
+    """From the second batch on the pipeline uploads the inflated bytes and the device finds the records, scans the aux
+    blocks, packs the SoA arrays, compares QNAMEs and cuts the batch (msx_unpack); MSX_HOST_UNPACK=1 keeps the host-side
+    walk for every batch.  Same records out (both equal the oracle's), same profile; > 20 batches each."""
+    for env in (dict(), dict(MSX_HOST_UNPACK=1)):
+        f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+        r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {f}", MSX_TIMING=1, **env)
+        assert n_batches(r.stderr) >= 20
+        big.check_digest(f, big.digest_out)
+        big.check_profile(p, big.pipe)
+        r = sh(f"{BIN} profile --label S -o {p} {big.bam['b']}", MSX_TIMING=1, **env)
+        assert n_batches(r.stderr) >= 20
+        big.check_profile(p, big.plain)
+    # compressed output takes the same stream writer (payloads cut where they fall, deflated in parallel)
+    f = str(tmp_path / "fb.bam")
+    sh(f"{BIN} {' '.join(FILT)} -b {big.bam['u']} > {f}")
+    big.check_digest(f, big.digest_out)
