@@ -550,6 +550,16 @@ uint32_t msh_crc32(const void *p, size_t n) {
 /* ------------------------------------------------------------------------ */
 #define BGZF_MAX 65536
 #define BGZF_BATCH 1024
+/* blocks inflated per call: MSX_INFLATE_BLOCKS lowers it (tests: many small batches through the pipeline) */
+static int bgzf_batch_blocks(void) {
+	static int v = 0;
+	if (!v) {
+		const char *e = getenv("MSX_INFLATE_BLOCKS");
+		const long n = e ? strtol(e, NULL, 10) : 0;
+		v = (n >= 1 && n < BGZF_BATCH) ? (int)n : BGZF_BATCH;
+	}
+	return v;
+}
 #define RD_NBUF 3
 #define RD_HEAD (BGZF_MAX + 1024)    /* headroom in front of a ring buffer's data: the tail of the block its predecessor cut */
 
@@ -712,7 +722,7 @@ static size_t bgz_read_blocks(bgz_in *b) {
 	b->nblk = 0;
 	if (b->eof) return 0;
 	b->uoff[0] = 0;
-	while (b->nblk < BGZF_BATCH) {
+	while (b->nblk < bgzf_batch_blocks()) {
 		uint32_t bsize, isize;
 		const uint8_t *blk;
 		if (b->map) {
@@ -1275,16 +1285,46 @@ struct msh_out {
 	int level;
 };
 #define BGZF_PAYLOAD 0xff00
+#define WCHUNK_BLOCKS 2048          /* blocks per chunk handed to the writer thread */
+#define WSLOT (BGZF_MAX + 1024)     /* bytes reserved per block in a chunk */
 
 static uint32_t bgzf_compress(uint8_t *out, const uint8_t *in, uint32_t n, int level);
 
 /* a chunk of finished BGZF blocks on its way out */
 struct wchunk {
 	uint8_t *slots;          /* nblk blocks, WSLOT apart */
-	size_t slots_bytes, nblk;
+	size_t slots_bytes, slots_cap, nblk;
 	uint32_t *slot_len;
 	int mapped;              /* slots is an anonymous mapping of its own (vmsplice) rather than heap memory */
 };
+
+/* Slot arrays of file output are reused: a fresh 136 MB allocation per chunk meant a page fault (and a zeroed page) for
+ * every 4 KB written.  (Pipe output keeps its fresh mappings: handed-over pages must never be written again.) */
+static struct { uint8_t *buf[4]; size_t bytes[4]; int n; pthread_mutex_t mu; } slot_pool = {{0}, {0}, 0, PTHREAD_MUTEX_INITIALIZER};
+static uint8_t *slots_get(size_t bytes, size_t *got) {
+	uint8_t *p = NULL;
+	int i;
+	pthread_mutex_lock(&slot_pool.mu);
+	for (i = 0; i < slot_pool.n; i++)
+		if (slot_pool.bytes[i] >= bytes) {
+			p = slot_pool.buf[i]; *got = slot_pool.bytes[i];
+			slot_pool.buf[i] = slot_pool.buf[slot_pool.n - 1]; slot_pool.bytes[i] = slot_pool.bytes[slot_pool.n - 1];
+			slot_pool.n--;
+			break;
+		}
+	pthread_mutex_unlock(&slot_pool.mu);
+	if (!p) {
+		*got = bytes < (size_t)WCHUNK_BLOCKS * WSLOT ? (size_t)WCHUNK_BLOCKS * WSLOT : bytes;
+		p = (uint8_t *)malloc(*got);
+	}
+	return p;
+}
+static void slots_put(uint8_t *p, size_t bytes) {
+	pthread_mutex_lock(&slot_pool.mu);
+	if (slot_pool.n < 4) { slot_pool.buf[slot_pool.n] = p; slot_pool.bytes[slot_pool.n] = bytes; slot_pool.n++; p = NULL; }
+	pthread_mutex_unlock(&slot_pool.mu);
+	free(p);
+}
 
 static void chunk_write(msh_out *o, struct wchunk *c) {
 	size_t q;
@@ -1313,7 +1353,7 @@ static void chunk_write(msh_out *o, struct wchunk *c) {
 			if (got > 0) { iv[v].iov_base = (uint8_t *)iv[v].iov_base + got; iv[v].iov_len -= (size_t)got; }
 		}
 	}
-	if (c->mapped) munmap(c->slots, c->slots_bytes); else free(c->slots);
+	if (c->mapped) munmap(c->slots, c->slots_bytes); else slots_put(c->slots, c->slots_cap);
 	free(c->slot_len);
 	free(c);
 }
@@ -1467,7 +1507,6 @@ void msh_write(msh_out *o, const uint8_t *rec, size_t len) {
  * block_size, as in the BAM stream) for k = 0..n-1.  BAM: the records are packed
  * greedily into BGZF blocks (whole records per block), blocks are deflated in
  * parallel and written in order.  SAM: lines are formatted in parallel. */
-#define WCHUNK_BLOCKS 2048
 #define WCHUNK_LINES 262144
 
 typedef struct {
@@ -1484,7 +1523,6 @@ typedef struct {
 	size_t lo, hi;
 	kstr *lines;            /* one per thread */
 } wjob;
-#define WSLOT (BGZF_MAX + 1024)
 
 static const uint8_t BGZF_HEAD[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
 
@@ -1623,7 +1661,7 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 				c->slots_bytes = c->nblk * WSLOT;
 				c->mapped = __atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED);
 				c->slots = c->mapped ? (uint8_t *)mmap(NULL, c->slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)
-				                     : (uint8_t *)malloc(c->slots_bytes);
+				                     : slots_get(c->slots_bytes, &c->slots_cap);
 				c->slot_len = (uint32_t *)malloc(c->nblk * sizeof(uint32_t));
 				if (!c->slots || c->slots == (uint8_t *)MAP_FAILED || !c->slot_len) mDie("Out of memory");
 				if (carry) {
@@ -1729,7 +1767,7 @@ void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n) {
 		c->slots_bytes = c->nblk * WSLOT;
 		c->mapped = __atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED);
 		c->slots = c->mapped ? (uint8_t *)mmap(NULL, c->slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)
-		                     : (uint8_t *)malloc(c->slots_bytes);
+		                     : slots_get(c->slots_bytes, &c->slots_cap);
 		c->slot_len = (uint32_t *)malloc(c->nblk * sizeof(uint32_t));
 		if (!c->slots || c->slots == (uint8_t *)MAP_FAILED || !c->slot_len) mDie("Out of memory");
 		if (carry) {

@@ -26,7 +26,7 @@ BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
 FILT = ["filter", "-l", "80", "-p", "95", "-z", "80", "--besthit"]
 OPTS = dict(l=80, p=95, z=80, besthit=True)
 REF_LEN = 4496          # msh_cli.c: synth_main writes every @SQ with this length
-ENV = dict(MSX_THREADS="16", MSX_BATCH_BYTES="2500000", MSX_BATCH_RECORDS="160000")
+ENV = dict(MSX_THREADS="16", MSX_BATCH_BYTES="2500000", MSX_BATCH_RECORDS="160000", MSX_INFLATE_BLOCKS="24")
 
 pytestmark = pytest.mark.gpu
 

@@ -237,7 +237,7 @@ def test_tee_cli_counts_chains_across_batch_cuts(ctx, tmp_path):
     opts = dict(l=30, p=95, z=80, besthit=True)
     f, ref = oracle_pipe(rec, "proportional", **opts)
     p = str(tmp_path / "p.gz")
-    env = dict(os.environ, MSX_BATCH_BYTES="1500000", MSX_BATCH_RECORDS="110000", MSX_THREADS="8", MSX_TIMING="1")
+    env = dict(os.environ, MSX_BATCH_BYTES="1500000", MSX_BATCH_RECORDS="110000", MSX_THREADS="8", MSX_TIMING="1", MSX_INFLATE_BLOCKS="8")
     r = subprocess.run(f"{BIN} filter -l 30 -p 95 -z 80 --besthit -bu --profile-out {p} --label S {bam} > {tmp_path / 'f.bam'}",
                        shell=True, env=env, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-1000:]
