@@ -670,7 +670,7 @@ typedef struct {
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
 	int raw_started, raw_done;
 	size_t n_filled;           /* batches handed on so far */
-	size_t batch_bytes, cap_rec, cap_cig, cap_md;
+	size_t batch_bytes, batch_bytes_cfg, cap_rec, cap_cig, cap_md;
 	pslot slot[PIPE_SLOTS_MAX];
 	pq q_free, q_dev, q_out;
 	/* decode state */
@@ -706,7 +706,7 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	P->hdr = msh_header(in);
 	P->mode = mode;
 	P->want_stats = want_stats;
-	P->batch_bytes = env_size("MSX_BATCH_BYTES", (size_t)96 << 20);
+	P->batch_bytes = P->batch_bytes_cfg = env_size("MSX_BATCH_BYTES", (size_t)96 << 20);
 	P->cap_rec = env_size("MSX_BATCH_RECORDS", (size_t)3 << 20);
 	if (P->cap_rec < COORD_ORDER_CHECK_RECORDS + 1024) P->cap_rec = COORD_ORDER_CHECK_RECORDS + 1024;
 	P->cap_cig = want_stats ? 2 * P->cap_rec : 4;
@@ -1096,15 +1096,16 @@ static void *pipe_decode_thread(void *arg) {
 					s->seed_has_name = P->have_prev;
 					if (P->have_prev) strcpy(s->seed_name, P->prev_read);
 				}
-				if (!s->ubuf_reg && s->ucap < P->batch_bytes + BGZF_INFLATE_MAX + 64) {      /* sized once, before it is page-locked */
-					s->ucap = P->batch_bytes + BGZF_INFLATE_MAX + 64;
+				/* (batch 0 may have grown batch_bytes to reach the preflight window; the configured size holds from here on) */
+				if (!s->ubuf_reg && s->ucap < P->batch_bytes_cfg + BGZF_INFLATE_MAX + 64) {      /* sized once, before it is page-locked */
+					s->ucap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 64;
 					s->ubuf = (uint8_t *)realloc(s->ubuf, s->ucap);
 					if (!s->ubuf) mDie("Out of memory");
 				}
 				for (;;) {
 					/* (a page-locked buffer must not move: stop short of its end rather than let it be reallocated) */
 					const size_t room = (size_t)BGZF_INFLATE_MAX + 64;
-					if (P->in_eof || s->ulen >= P->batch_bytes) break;
+					if (P->in_eof || s->ulen >= P->batch_bytes_cfg) break;
 					if (s->ubuf_reg && s->ulen + room > s->ucap) break;
 					if (!msh_inflate_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
 				}
