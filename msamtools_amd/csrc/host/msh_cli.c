@@ -655,7 +655,9 @@ typedef struct {
 	int has_seed, seed_has_name;
 	kstr seed;                 /* what the host-side reader left over in front of the first raw slot */
 	char seed_name[256];
-	uint8_t *ubuf_reg;         /* ubuf as page-locked by the device thread (never moved afterwards) */
+	uint8_t *rbuf;             /* raw slots: the inflated bytes, in a buffer of fixed size (page-locked by the device thread) */
+	size_t rcap, rlen;
+	int rbuf_reg;
 	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit), page-locked */
 	size_t ocap, olen;
 } pslot;
@@ -733,6 +735,17 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 		b->group_cap = c + 1; b->group_off = (uint32_t *)xmalloc(b->group_cap * 4);
 		s->emit = (int32_t *)xmalloc(c * 4);
 		pq_push(&P->q_free, i);
+	}
+}
+
+/* device unpack: every slot gets a buffer of fixed size for the inflated bytes (page-locked by the device thread) */
+static void pipe_enable_raw(pipe_t *P) {
+	int i;
+	P->raw_mode = 1;
+	for (i = 0; i < P->n_slots; i++) {
+		pslot *s = &P->slot[i];
+		s->rcap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 4096;
+		if (posix_memalign((void **)&s->rbuf, 4096, s->rcap) != 0) mDie("Out of memory");
 	}
 }
 
@@ -1085,7 +1098,7 @@ static void *pipe_decode_thread(void *arg) {
 				n = 0;
 			} else {
 				s->raw = 1;
-				s->ulen = 0;
+				s->rlen = 0;
 				s->has_seed = 0;
 				if (!P->raw_started) {
 					P->raw_started = 1;
@@ -1096,19 +1109,11 @@ static void *pipe_decode_thread(void *arg) {
 					s->seed_has_name = P->have_prev;
 					if (P->have_prev) strcpy(s->seed_name, P->prev_read);
 				}
-				/* (batch 0 may have grown batch_bytes to reach the preflight window; the configured size holds from here on) */
-				if (!s->ubuf_reg && s->ucap < P->batch_bytes_cfg + BGZF_INFLATE_MAX + 64) {      /* sized once, before it is page-locked */
-					s->ucap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 64;
-					s->ubuf = (uint8_t *)realloc(s->ubuf, s->ucap);
-					if (!s->ubuf) mDie("Out of memory");
-				}
-				for (;;) {
-					/* (a page-locked buffer must not move: stop short of its end rather than let it be reallocated) */
-					const size_t room = (size_t)BGZF_INFLATE_MAX + 64;
-					if (P->in_eof || s->ulen >= P->batch_bytes_cfg) break;
-					if (s->ubuf_reg && s->ulen + room > s->ucap) break;
-					if (!msh_inflate_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
-				}
+				/* (batch 0 may have grown batch_bytes to reach the preflight window; the configured size holds from here
+				 * on.  The buffer is page-locked and must not move: msh_inflate_append appends one batch of blocks at most,
+				 * so there is always room for the next call) */
+				while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + BGZF_INFLATE_MAX + 64 <= s->rcap)
+					if (!msh_inflate_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
 				s->last = P->in_eof;
 				if (s->last) P->raw_done = 1;
 				n = 1;                       /* (a slot: possibly without bytes, its `last` flag flushes the device's carry) */
@@ -1517,6 +1522,18 @@ static void *filter_dev_thread(void *arg) {
 		if (F->po)
 			MSX(msx_profile_create(g_ctx, &D->prof, F->pf->n_features, F->po->share_type, F->pf->fmap, P->hdr->n_targets));
 		D->t_ctx = now_s() - t0;
+		if (P->raw_mode) {
+			/* page-locking the slots' byte buffers and the output buffers takes tens of milliseconds each: done now,
+			 * while the first batch is still being decoded */
+			int q;
+			MSX(msx_unpack_create(g_ctx, &unpack));
+			for (q = 0; q < P->n_slots; q++) {
+				pslot *sl = &P->slot[q];
+				if (!getenv("MSX_NO_PIN")) { MSX(msx_host_register(g_ctx, sl->rbuf, sl->rcap)); sl->rbuf_reg = 1; }
+				sl->ocap = sl->rcap;
+				MSX(msx_host_alloc(g_ctx, (void **)&sl->obuf, sl->ocap));
+			}
+		}
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
@@ -1538,11 +1555,10 @@ static void *filter_dev_thread(void *arg) {
 			int64_t nb = 0;
 			if (!unpack) MSX(msx_unpack_create(g_ctx, &unpack));
 			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
-			if (!s->ubuf_reg && s->ubuf && !getenv("MSX_NO_PIN")) { MSX(msx_host_register(g_ctx, s->ubuf, s->ucap)); s->ubuf_reg = s->ubuf; }
 			memset(&up, 0, sizeof up);
 			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
-			MSX(msx_unpack_enqueue(g_ctx, unpack, s->ubuf, s->ulen, &up));
+			MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, &up));
 			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
 			D->t_upload += now_s() - t1; t1 = now_s();
 			b->n = (size_t)ur.n_records;
@@ -1686,7 +1702,8 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	/* From the second batch on the record walk runs on the device (msx_unpack): one context, records written as they
 	 * are (no --rescore), BAM out.  The first batch takes the host-side walk: the preflight reads its records.
 	 * MSX_HOST_UNPACK=1 keeps every batch on the host. */
-	P.raw_mode = F.n_dev == 1 && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) && !getenv("MSX_HOST_UNPACK");
+	if (F.n_dev == 1 && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) && !getenv("MSX_HOST_UNPACK"))
+		pipe_enable_raw(&P);
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
 	if (po) prof_features(po, P.hdr, &pf);
@@ -2042,6 +2059,10 @@ static void *profile_dev_thread(void *arg) {
 	MSX(msx_stage_create(g_ctx, &stage));
 	MSX(msx_profile_create(g_ctx, &D->prof, S->F->n_features, S->o->share_type, S->F->fmap, P->hdr->n_targets));   /* :855 */
 	D->t_ctx = now_s() - t0;
+	if (P->raw_mode && !getenv("MSX_NO_PIN")) {
+		MSX(msx_unpack_create(g_ctx, &unpack));
+		for (q = 0; q < P->n_slots; q++) { MSX(msx_host_register(g_ctx, P->slot[q].rbuf, P->slot[q].rcap)); P->slot[q].rbuf_reg = 1; }
+	}
 	for (;;) {
 		double t1;
 		int si;
@@ -2059,10 +2080,9 @@ static void *profile_dev_thread(void *arg) {
 			if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); held = -1; }
 			if (!unpack) MSX(msx_unpack_create(g_ctx, &unpack));
 			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
-			if (!s->ubuf_reg && s->ubuf && !getenv("MSX_NO_PIN")) { MSX(msx_host_register(g_ctx, s->ubuf, s->ucap)); s->ubuf_reg = s->ubuf; }
 			memset(&up, 0, sizeof up);
 			up.pool_mode = 2; up.n_targets = P->hdr->n_targets; up.last = s->last;
-			MSX(msx_unpack_enqueue(g_ctx, unpack, s->ubuf, s->ulen, &up));
+			MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, &up));
 			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));   /* (synchronises: the slot's bytes have left) */
 			if (ur.n_records > 0) MSX(msx_profile_accumulate(g_ctx, D->prof, &db, NULL));
 			D->n_in += (size_t)ur.n_records;
@@ -2202,7 +2222,7 @@ int msam_profile_main(int argc, char *argv[]) {
 		memset(&S, 0, sizeof S);
 		S.n_dev = device_list(dev_ids);
 		pipe_init(&P, in, 2, 0, S.n_dev);
-		P.raw_mode = S.n_dev == 1 && !getenv("MSX_HOST_UNPACK");       /* the record walk of every batch but the first on the device */
+		if (S.n_dev == 1 && !getenv("MSX_HOST_UNPACK")) pipe_enable_raw(&P);   /* the record walk of every batch but the first on the device */
 		S.P = &P; S.o = &o; S.F = &F;
 		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 		for (k = 0; k < S.n_dev; k++) {

@@ -5,11 +5,11 @@
 // boundaries, scan every record's aux block, fill the SoA arrays, compare QNAMEs" on the host cores -- half of the
 // decode stage's time once inflate had been made fast.  Here the inflated BAM bytes of a batch are uploaded as they
 // are and everything after inflate happens on the device:
-//   k_chase_walk      record boundaries.  The block_size chain is serial; every lane takes a 16 KB segment, guesses a
+//   k_chase_walk      record boundaries.  The block_size chain is serial; every lane takes a 4 KB segment, guesses a
 //                     record start in it (a header that looks like one, followed by two more that do) and walks its
-//                     segment; k_chase_join checks that every segment's first record is where the segment before it
-//                     ended (one wave-wide look) and repairs -- serially, rarely -- where a guess was wrong: from a
-//                     true start the chain is the true chain, so guesses only decide how parallel the walk was.
+//                     segment; k_chase_check counts the segments that do not begin where the segment before them
+//                     ended, k_chase_fix repairs those -- serially, rarely: from a true start the chain is the true
+//                     chain, so guesses only decide how parallel the walk was.
 //   k_rec_fields      one lane per record: core fields, one pass over the aux block for MD / NM / AS
 //                     (bam_aux_get: first occurrence; bam_aux2i: c C s S i I), CIGAR and MD lengths
 //   k_rec_payload     CIGAR words and MD bytes packed back to back (msx_batch.cigar / md)
@@ -25,7 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#define UP_SEG 16384u              // bytes per chase segment (one lane each)
+#define UP_SEG 4096u               // bytes per chase segment (one lane each: ~55 records of 71 bytes)
 #define UP_NONE 0xffffffffu
 #define UP_TILE 2048               // records per workgroup in the name kernels (8 per thread)
 
@@ -57,15 +57,18 @@ struct msx_unpack {
 	bool enqueued = false;
 };
 
-__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
-	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
-}
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+// (global memory takes unaligned dword / qword loads on this target: one instruction instead of four byte loads)
+typedef uint32_t __attribute__((aligned(1))) u32_u;
+typedef uint16_t __attribute__((aligned(1))) u16_u;
+typedef unsigned long long __attribute__((aligned(1))) u64_u;
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return *reinterpret_cast<const u32_u *>(p); }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return *reinterpret_cast<const u16_u *>(p); }
+__device__ __forceinline__ unsigned long long ld64(const uint8_t *p) { return *reinterpret_cast<const u64_u *>(p); }
 
 // ---------------------------------------------------------------------------
 // record boundaries
 // ---------------------------------------------------------------------------
-// does a record plausibly start at `off`?  (only guesses: a wrong one is repaired by k_chase_join)
+// does a record plausibly start at `off`?  (only guesses: a wrong one is repaired by k_chase_fix)
 __device__ __forceinline__ bool up_plausible(const uint8_t *u, uint32_t off, uint32_t n, int32_t nt) {
 	if ((uint64_t)off + 36u > n) return false;
 	const uint32_t bs = ld32(u + off);
@@ -132,75 +135,54 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_chase_walk(const uint8_t *__restr
 	seg_cnt[k] = (first != UP_NONE && !inv) ? cnt : UP_NONE;      // (a walk that ran into a block_size < 32 started from a wrong guess)
 }
 
-// One workgroup: joints, repair, prefix over the segments' counts.  Segment k is right when it starts where segment
-// k - 1 ended -- or, for a segment no record starts in, when the chain had already passed it.
-__global__ __launch_bounds__(MSX_BLOCK) void k_chase_join(const uint8_t *__restrict__ u, uint32_t n, uint32_t nseg,
-                                                          uint32_t *__restrict__ seg_first, uint32_t *__restrict__ seg_end,
-                                                          uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_base,
-                                                          up_state *st) {
-	__shared__ uint32_t s_bad, s_w[MSX_BLOCK / 64], s_run;
-	if (threadIdx.x == 0) { s_bad = 0; s_run = 0; }
-	__syncthreads();
-	uint32_t bad = 0;
-	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += MSX_BLOCK) {
-		const uint32_t pe = seg_end[k - 1], lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
-		const bool ok = (pe < hi) ? (seg_first[k] == pe && seg_cnt[k] != UP_NONE)
-		                          : false;        // the chain jumps over this segment (a long record): repaired below (cheap)
-		bad += ok ? 0u : 1u;
-	}
-	if (seg_cnt[0] == UP_NONE && threadIdx.x == 0) bad++;
-	if (bad) atomicAdd(&s_bad, bad);
-	__syncthreads();
-	if (s_bad && threadIdx.x == 0) {
-		// serial repair: walk every segment whose start does not match from where the chain really stands
-		uint32_t pos = 0, status = 0, fixed = 0;
-		for (uint32_t k = 0; k < nseg; k++) {
-			const uint32_t lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
-			if (k > 0 && seg_first[k] == pos && seg_cnt[k] != UP_NONE && pos < hi) { pos = seg_end[k]; continue; }
-			if (k == 0 && seg_cnt[0] != UP_NONE) { pos = seg_end[0]; continue; }
-			uint32_t end = pos, cnt = 0;
-			bool inv = false;
-			if (pos < hi) cnt = up_walk<false>(u, n, pos, hi, &end, &inv, nullptr);
-			if (inv) status = MSX_UP_CORRUPT;                 // on the true chain: the data is corrupt
-			seg_first[k] = pos;
-			seg_cnt[k] = cnt;
-			seg_end[k] = end;
-			pos = end;
-			fixed++;
-			if (inv) {                                        // nothing behind it can be trusted
-				for (uint32_t q = k + 1; q < nseg; q++) { seg_first[q] = end; seg_cnt[q] = 0; seg_end[q] = end; }
-				break;
-			}
+// Segment k is right when it starts where segment k - 1 ended.  k_chase_check counts the segments that are not
+// (wrong guesses, segments a long record jumps over); k_chase_fix -- one lane, and nothing to do in the usual case --
+// walks those from where the chain really stands; the counts are then scanned into positions.
+__global__ __launch_bounds__(MSX_BLOCK) void k_chase_check(uint32_t n, uint32_t nseg, const uint32_t *__restrict__ seg_first,
+                                                           const uint32_t *__restrict__ seg_end, uint32_t *__restrict__ seg_cnt,
+                                                           up_state *st) {
+	const uint32_t k = blockIdx.x * MSX_BLOCK + threadIdx.x;
+	bool bad = false;
+	if (k < nseg) {
+		if (k == 0) bad = seg_cnt[0] == UP_NONE;
+		else {
+			const uint32_t pe = seg_end[k - 1], lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
+			bad = !(pe < hi && seg_first[k] == pe && seg_cnt[k] != UP_NONE);
 		}
-		st->bad_segments = fixed;
-		if (status) st->status = status;
 	}
-	__syncthreads();
-	// exclusive prefix of the counts
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	for (uint32_t base = 0; base < nseg; base += MSX_BLOCK) {
-		const uint32_t k = base + threadIdx.x;
-		const uint32_t v = k < nseg ? seg_cnt[k] : 0u;
-		uint32_t inc = v;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t o = __shfl_up(inc, d, 64);
-			if (lane >= d) inc += o;
+	const unsigned long long m = __ballot(bad);
+	if (m && (threadIdx.x & 63) == 0) atomicAdd(&st->bad_segments, (uint32_t)__popcll(m));
+}
+
+__global__ void k_chase_fix(const uint8_t *__restrict__ u, uint32_t n, uint32_t nseg, uint32_t *__restrict__ seg_first,
+                            uint32_t *__restrict__ seg_end, uint32_t *__restrict__ seg_cnt, up_state *st) {
+	if (st->bad_segments == 0) return;
+	uint32_t pos = 0, status = 0, fixed = 0;
+	for (uint32_t k = 0; k < nseg; k++) {
+		const uint32_t lo = k * UP_SEG, hi = (lo + UP_SEG < n) ? lo + UP_SEG : n;
+		if (k > 0 && seg_first[k] == pos && seg_cnt[k] != UP_NONE && pos < hi) { pos = seg_end[k]; continue; }
+		if (k == 0 && seg_cnt[0] != UP_NONE) { pos = seg_end[0]; continue; }
+		uint32_t end = pos, cnt = 0;
+		bool inv = false;
+		if (pos < hi) cnt = up_walk<false>(u, n, pos, hi, &end, &inv, nullptr);
+		if (inv) status = MSX_UP_CORRUPT;                 // on the true chain: the data is corrupt
+		seg_first[k] = pos;
+		seg_cnt[k] = cnt;
+		seg_end[k] = end;
+		pos = end;
+		fixed++;
+		if (inv) {                                        // nothing behind it can be trusted
+			for (uint32_t q = k + 1; q < nseg; q++) { seg_first[q] = end; seg_cnt[q] = 0; seg_end[q] = end; }
+			break;
 		}
-		if (lane == 63) s_w[w] = inc;
-		__syncthreads();
-		uint32_t woff = 0, tot = 0;
-		for (int q = 0; q < MSX_BLOCK / 64; q++) { if (q < w) woff += s_w[q]; tot += s_w[q]; }
-		if (k < nseg) seg_base[k] = s_run + woff + inc - v;
-		__syncthreads();
-		if (threadIdx.x == 0) s_run += tot;
-		__syncthreads();
 	}
-	if (threadIdx.x == 0) {
-		seg_base[nseg] = s_run;
-		st->n_total = s_run;
-		st->tail_off = nseg ? seg_end[nseg - 1] : 0u;
-	}
+	st->bad_segments = fixed;
+	if (status) st->status = status;
+}
+
+__global__ void k_chase_total(uint32_t nseg, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_end, up_state *st) {
+	st->n_total = seg_base[nseg];
+	st->tail_off = nseg ? seg_end[nseg - 1] : 0u;
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_chase_write(const uint8_t *__restrict__ u, uint32_t n, uint32_t nseg,
@@ -380,15 +362,23 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_name_tile_scan(uint32_t n_tiles, 
 	}
 }
 
-__device__ __forceinline__ bool name_differs(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb) {
+// names differ?  (la, lb include the terminating NUL; eight bytes at a time -- the reads may run past a name's end
+// into the record's own CIGAR / the next record: the buffer is padded by 64 bytes)
+__device__ __forceinline__ bool name_differs8(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb) {
 	if (la != lb) return true;
-	for (uint32_t k = 0; k < la; k++)
-		if (a[k] != b[k]) return true;
+	uint32_t k = 0;
+	for (; k + 8u <= la; k += 8u)
+		if (ld64(a + k) != ld64(b + k)) return true;
+	if (k < la) {
+		const unsigned long long m = ~0ull >> (8u * (8u - (la - k)));
+		if ((ld64(a + k) ^ ld64(b + k)) & m) return true;
+	}
 	return false;
 }
 
 // bd[i]: record i opens a pool; pidx[i]: the nearest earlier naming record (-1: none in this batch), for i = 0 .. n_rec.
 // Also the batch's last boundary, and the last one in its second half whose record is mapped (cut_mapped).
+// One record per lane, a tile in UP_TILE / MSX_BLOCK rows; the running maximum goes from row to row.
 __global__ __launch_bounds__(MSX_BLOCK) void k_name_bounds(const uint8_t *__restrict__ u, uint32_t n_rec, int mode, int uv,
                                                            const uint32_t *__restrict__ rec_off, const uint16_t *__restrict__ flag,
                                                            const int32_t *__restrict__ tid, const int32_t *__restrict__ tile_carry,
@@ -396,64 +386,61 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_name_bounds(const uint8_t *__rest
                                                            int32_t *__restrict__ pidx, uint32_t *__restrict__ gflag, up_state *st) {
 	__shared__ int32_t s_w[MSX_BLOCK / 64];
 	__shared__ uint32_t s_cut[2];
+	__shared__ uint8_t s_prev[256];
+	__shared__ uint32_t s_plen;
 	if (threadIdx.x < 2) s_cut[threadIdx.x] = 0;
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const uint32_t i0 = blockIdx.x * UP_TILE + threadIdx.x * 8u;
-	uint32_t fl[8];
-	int32_t t[8], own[8];
-	int32_t m = -1;
-#pragma unroll
-	for (int q = 0; q < 8; q++) {
-		const uint32_t i = i0 + q;
-		fl[q] = 4u; t[q] = -1; own[q] = -1;
-		if (i < n_rec) {
-			fl[q] = flag[i]; t[q] = tid[i];
-			if (names_pool(mode, uv, fl[q], t[q])) own[q] = (int32_t)i;
-		}
-		m = own[q] > m ? own[q] : m;
-	}
-	int32_t inc = m;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const int32_t o = __shfl_up(inc, d, 64);
-		if (lane >= d) inc = o > inc ? o : inc;
-	}
-	if (lane == 63) s_w[w] = inc;
-	__syncthreads();
-	int32_t run = tile_carry[blockIdx.x];
-	for (int q = 0; q < w; q++) run = s_w[q] > run ? s_w[q] : run;
-	int32_t ex = __shfl_up(inc, 1, 64);
-	if (lane == 0) ex = -1;
-	run = ex > run ? ex : run;                       // nearest naming record before this thread's first record
 	const bool has_prev = st->has_prev != 0;
+	s_prev[threadIdx.x] = has_prev ? (uint8_t)prev_name[threadIdx.x] : 0;
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t lp = 0; while (lp < 255u && s_prev[lp]) lp++; s_plen = lp + 1u; }
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	int32_t carry = tile_carry[blockIdx.x];
 	uint32_t cut_any = 0, cut_map = 0;
+	for (uint32_t row = 0; row < UP_TILE / MSX_BLOCK; row++) {
+		const uint32_t i = blockIdx.x * UP_TILE + row * MSX_BLOCK + threadIdx.x;
+		uint32_t fl = 4u;
+		int32_t t = -1, own = -1;
+		if (i < n_rec) {
+			fl = flag[i]; t = tid[i];
+			if (names_pool(mode, uv, fl, t)) own = (int32_t)i;
+		}
+		int32_t inc = own;
 #pragma unroll
-	for (int q = 0; q < 8; q++) {
-		const uint32_t i = i0 + q;
+		for (int d = 1; d < 64; d <<= 1) {
+			const int32_t o = __shfl_up(inc, d, 64);
+			if (lane >= d) inc = o > inc ? o : inc;
+		}
+		__syncthreads();                                 // (s_w of the previous row has been read)
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		int32_t run = carry, tot = carry;
+		for (int q = 0; q < MSX_BLOCK / 64; q++) { if (q < w) run = s_w[q] > run ? s_w[q] : run; tot = s_w[q] > tot ? s_w[q] : tot; }
+		int32_t ex = __shfl_up(inc, 1, 64);
+		if (lane == 0) ex = -1;
+		run = ex > run ? ex : run;                        // nearest naming record before record i
+		carry = tot;
 		if (i <= n_rec) pidx[i] = run;
 		if (i < n_rec) {
 			bool b = false;
-			if (mode != 0 && rule_sees(mode, uv, fl[q], t[q])) {
+			if (mode != 0 && rule_sees(mode, uv, fl, t)) {
 				const uint8_t *r = u + rec_off[i] + 4;
 				if (run >= 0) {
 					const uint8_t *p = u + rec_off[run] + 4;
-					b = name_differs(r + 32, r[8], p + 32, p[8]);
+					b = name_differs8(r + 32, r[8], p + 32, p[8]);
 				} else if (has_prev) {
-					uint32_t lp = 0;
-					while (lp < 255u && prev_name[lp]) lp++;
-					b = name_differs(r + 32, r[8], (const uint8_t *)prev_name, lp + 1u);
+					const uint32_t la = r[8];
+					b = la != s_plen;
+					for (uint32_t k = 0; !b && k < la; k++) b = r[32 + k] != s_prev[k];
 				}
 			}
 			bd[i] = b ? 1 : 0;
 			gflag[i] = (b || i == 0u) ? 1u : 0u;
 			if (b && i > 0u) {
 				cut_any = i;
-				if (!(fl[q] & 4u) && i > n_rec / 2u) cut_map = i;
+				if (!(fl & 4u) && i > n_rec / 2u) cut_map = i;
 			}
 		}
-		run = own[q] > run ? own[q] : run;
 	}
-	__syncthreads();
 	if (cut_any) atomicMax(&s_cut[0], cut_any);
 	if (cut_map) atomicMax(&s_cut[1], cut_map);
 	__syncthreads();
@@ -612,8 +599,13 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 	if (nseg == 0) return MSX_OK;
 	hipLaunchKernelGGL(k_chase_walk, dim3((nseg + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, raw, (uint32_t)n, nseg,
 	                   prm->n_targets, (uint32_t *)u->seg_first.p, (uint32_t *)u->seg_end.p, (uint32_t *)u->seg_cnt.p);
-	hipLaunchKernelGGL(k_chase_join, dim3(1), dim3(MSX_BLOCK), 0, ctx->stream, raw, (uint32_t)n, nseg, (uint32_t *)u->seg_first.p,
-	                   (uint32_t *)u->seg_end.p, (uint32_t *)u->seg_cnt.p, (uint32_t *)u->seg_base.p, u->d_state);
+	hipLaunchKernelGGL(k_chase_check, dim3((nseg + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, (uint32_t)n, nseg,
+	                   (const uint32_t *)u->seg_first.p, (const uint32_t *)u->seg_end.p, (uint32_t *)u->seg_cnt.p, u->d_state);
+	hipLaunchKernelGGL(k_chase_fix, dim3(1), dim3(1), 0, ctx->stream, raw, (uint32_t)n, nseg, (uint32_t *)u->seg_first.p,
+	                   (uint32_t *)u->seg_end.p, (uint32_t *)u->seg_cnt.p, u->d_state);
+	if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->seg_cnt.p, (uint32_t *)u->seg_base.p, nseg))) return rc;
+	hipLaunchKernelGGL(k_chase_total, dim3(1), dim3(1), 0, ctx->stream, nseg, (const uint32_t *)u->seg_base.p,
+	                   (const uint32_t *)u->seg_end.p, u->d_state);
 	hipLaunchKernelGGL(k_chase_write, dim3((nseg + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, raw, (uint32_t)n, nseg,
 	                   (const uint32_t *)u->seg_first.p, (const uint32_t *)u->seg_cnt.p, (const uint32_t *)u->seg_base.p,
 	                   (uint32_t *)u->rec_off.p, (const up_state *)u->d_state);
