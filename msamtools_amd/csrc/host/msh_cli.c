@@ -655,9 +655,9 @@ typedef struct {
 	int has_seed, seed_has_name;
 	kstr seed;                 /* what the host-side reader left over in front of the first raw slot */
 	char seed_name[256];
-	uint8_t *rbuf;             /* raw slots: the inflated bytes, in a buffer of fixed size (page-locked by the device thread) */
+	uint8_t *rbuf;             /* raw slots: the inflated bytes, in a buffer of fixed size (page-locked by pin_thread) */
 	size_t rcap, rlen;
-	int rbuf_reg;
+	int pin_ready;             /* rbuf is page-locked and obuf allocated (pin_mu) */
 	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit), page-locked */
 	size_t ocap, olen;
 } pslot;
@@ -671,6 +671,12 @@ typedef struct {
 	int n_slots, n_consumers;
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
 	int raw_started, raw_done;
+	int pin_obuf;              /* filter: the slots also get an output buffer */
+	int pin_started;
+	msx_ctx *pin_ctx;
+	pthread_t pin_th;
+	pthread_mutex_t pin_mu;
+	pthread_cond_t pin_cv;
 	size_t n_filled;           /* batches handed on so far */
 	size_t batch_bytes, batch_bytes_cfg, cap_rec, cap_cig, cap_md;
 	pslot slot[PIPE_SLOTS_MAX];
@@ -738,7 +744,43 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	}
 }
 
-/* device unpack: every slot gets a buffer of fixed size for the inflated bytes (page-locked by the device thread) */
+/* Page-locking a slot's byte buffer and allocating its page-locked output buffer takes tens of milliseconds per
+ * slot -- on a thread of its own, in the order the decode stage will use the slots for raw batches (1, 2, ..., 0), so
+ * that neither the first batch nor HIP start-up waits for it; the device thread waits for the one slot it is about to use. */
+static void *pin_thread(void *arg) {
+	pipe_t *P = (pipe_t *)arg;
+	int k;
+	g_ctx = P->pin_ctx;
+	for (k = 1; k <= P->n_slots; k++) {
+		pslot *s = &P->slot[k % P->n_slots];
+		if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, s->rbuf, s->rcap));
+		if (P->pin_obuf) {
+			s->ocap = s->rcap;
+			MSX(msx_host_alloc(g_ctx, (void **)&s->obuf, s->ocap));
+		}
+		pthread_mutex_lock(&P->pin_mu);
+		s->pin_ready = 1;
+		pthread_cond_broadcast(&P->pin_cv);
+		pthread_mutex_unlock(&P->pin_mu);
+	}
+	return NULL;
+}
+static void pin_start(pipe_t *P, int with_obuf) {
+	if (P->pin_started) return;
+	P->pin_started = 1;
+	P->pin_ctx = g_ctx;
+	P->pin_obuf = with_obuf;
+	pthread_mutex_init(&P->pin_mu, NULL);
+	pthread_cond_init(&P->pin_cv, NULL);
+	if (pthread_create(&P->pin_th, NULL, pin_thread, P) != 0) mDie("pthread_create failed");
+}
+static void pin_wait(pipe_t *P, pslot *s) {
+	pthread_mutex_lock(&P->pin_mu);
+	while (!s->pin_ready) pthread_cond_wait(&P->pin_cv, &P->pin_mu);
+	pthread_mutex_unlock(&P->pin_mu);
+}
+
+/* device unpack: every slot gets a buffer of fixed size for the inflated bytes (page-locked by pin_thread) */
 static void pipe_enable_raw(pipe_t *P) {
 	int i;
 	P->raw_mode = 1;
@@ -1522,18 +1564,7 @@ static void *filter_dev_thread(void *arg) {
 		if (F->po)
 			MSX(msx_profile_create(g_ctx, &D->prof, F->pf->n_features, F->po->share_type, F->pf->fmap, P->hdr->n_targets));
 		D->t_ctx = now_s() - t0;
-		if (P->raw_mode) {
-			/* page-locking the slots' byte buffers and the output buffers takes tens of milliseconds each: done now,
-			 * while the first batch is still being decoded */
-			int q;
-			MSX(msx_unpack_create(g_ctx, &unpack));
-			for (q = 0; q < P->n_slots; q++) {
-				pslot *sl = &P->slot[q];
-				if (!getenv("MSX_NO_PIN")) { MSX(msx_host_register(g_ctx, sl->rbuf, sl->rcap)); sl->rbuf_reg = 1; }
-				sl->ocap = sl->rcap;
-				MSX(msx_host_alloc(g_ctx, (void **)&sl->obuf, sl->ocap));
-			}
-		}
+		if (P->raw_mode) MSX(msx_unpack_create(g_ctx, &unpack));
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
@@ -1553,7 +1584,8 @@ static void *filter_dev_thread(void *arg) {
 			msx_unpack_params up;
 			msx_unpack_result ur;
 			int64_t nb = 0;
-			if (!unpack) MSX(msx_unpack_create(g_ctx, &unpack));
+			pin_start(P, 1);
+			pin_wait(P, s);
 			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
 			memset(&up, 0, sizeof up);
 			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
@@ -1583,6 +1615,8 @@ static void *filter_dev_thread(void *arg) {
 			pq_push(&P->q_out, si);
 			continue;
 		}
+		/* more batches follow batch 0: their buffers are page-locked while this one is processed */
+		if (s->seq == 0 && P->raw_mode && !__atomic_load_n(&P->in_eof, __ATOMIC_RELAXED)) pin_start(P, 1);
 		if (s->seq == 0) { filter_open_output(F, b); t1 = now_s(); }
 		pipe_pin_slot(P, s);
 		rb_host_view(b, &hb, P->mode != 0);
@@ -1601,6 +1635,7 @@ static void *filter_dev_thread(void *arg) {
 		pq_push(&P->q_out, si);
 	}
 	MSX(msx_ctx_sync(g_ctx));
+	if (P->pin_started) pthread_join(P->pin_th, NULL);
 	msx_stage_destroy(g_ctx, stage);
 	msx_unpack_destroy(g_ctx, unpack);
 	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
@@ -2059,10 +2094,7 @@ static void *profile_dev_thread(void *arg) {
 	MSX(msx_stage_create(g_ctx, &stage));
 	MSX(msx_profile_create(g_ctx, &D->prof, S->F->n_features, S->o->share_type, S->F->fmap, P->hdr->n_targets));   /* :855 */
 	D->t_ctx = now_s() - t0;
-	if (P->raw_mode && !getenv("MSX_NO_PIN")) {
-		MSX(msx_unpack_create(g_ctx, &unpack));
-		for (q = 0; q < P->n_slots; q++) { MSX(msx_host_register(g_ctx, P->slot[q].rbuf, P->slot[q].rcap)); P->slot[q].rbuf_reg = 1; }
-	}
+	if (P->raw_mode) MSX(msx_unpack_create(g_ctx, &unpack));
 	for (;;) {
 		double t1;
 		int si;
@@ -2078,7 +2110,8 @@ static void *profile_dev_thread(void *arg) {
 			msx_unpack_params up;
 			msx_unpack_result ur;
 			if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); held = -1; }
-			if (!unpack) MSX(msx_unpack_create(g_ctx, &unpack));
+			pin_start(P, 0);
+			pin_wait(P, s);
 			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
 			memset(&up, 0, sizeof up);
 			up.pool_mode = 2; up.n_targets = P->hdr->n_targets; up.last = s->last;
@@ -2091,6 +2124,7 @@ static void *profile_dev_thread(void *arg) {
 			D->t_dev += now_s() - t1;
 			continue;
 		}
+		if (s->seq == 0 && P->raw_mode && !__atomic_load_n(&P->in_eof, __ATOMIC_RELAXED)) pin_start(P, 0);
 		if (s->seq == 0) S->qn = qn_check(P->hdr, &s->b);            /* :708, always for profile */
 		pipe_pin_slot(P, s);
 		rb_host_view(&s->b, &hb, 1);
@@ -2110,6 +2144,7 @@ static void *profile_dev_thread(void *arg) {
 	}
 	if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); }
 	MSX(msx_ctx_sync(g_ctx));
+	if (P->pin_started) pthread_join(P->pin_th, NULL);
 	msx_stage_destroy(g_ctx, stage);
 	msx_unpack_destroy(g_ctx, unpack);
 	for (q = 0; q < PIPE_SLOTS_MAX; q++) msx_event_destroy(g_ctx, ev[q]);

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r3e
 rm -rf $OUT; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_cli_scale.py tests/test_gpu_chains.py tests/test_host_cli.py tests/test_validation_community.py tests/test_gpu_unpack.py -m gpu -q -x > $OUT/new_tests.log 2>&1; echo "rc=$?" >> $OUT/new_tests.log
+timeout 1500 python -m pytest tests/test_cli_scale.py tests/test_gpu_chains.py tests/test_gpu_unpack.py -m gpu -q -x > $OUT/new_tests.log 2>&1; echo "rc=$?" >> $OUT/new_tests.log
 tail -40 $OUT/new_tests.log
 B=msamtools_amd/bin/msamtools
 $B synth --groups 20000000 --refs 1000000 -b > /tmp/in.bam
