@@ -671,6 +671,9 @@ typedef struct {
 	int n_slots, n_consumers;
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
 	int raw_started, raw_done;
+	int first_state, first_slot;   /* 0: batch 0 not decoded yet; 1: it is, in slot first_slot; 2: the input holds no record (first_mu) */
+	pthread_mutex_t first_mu;
+	pthread_cond_t first_cv;
 	int pin_obuf;              /* filter: the slots also get an output buffer */
 	int pin_started;
 	msx_ctx *pin_ctx;
@@ -720,6 +723,8 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	P->cap_cig = want_stats ? 2 * P->cap_rec : 4;
 	P->cap_md = want_stats ? 16 * P->cap_rec : 16;
 	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out);
+	pthread_mutex_init(&P->first_mu, NULL);
+	pthread_cond_init(&P->first_cv, NULL);
 	for (i = 0; i < P->n_slots; i++) {
 		pslot *s = &P->slot[i];
 		rbatch *b = &s->b;
@@ -1166,6 +1171,13 @@ static void *pipe_decode_thread(void *arg) {
 		}
 		P->t_decode += now_s() - t1;
 		s->eof = n == 0;
+		if (n == 0 || P->n_filled == 0) {
+			/* whoever opens the output (preflight on batch 0's records, header) need not wait for the device stage */
+			pthread_mutex_lock(&P->first_mu);
+			if (P->first_state == 0) { P->first_state = n == 0 ? 2 : 1; P->first_slot = si; }
+			pthread_cond_broadcast(&P->first_cv);
+			pthread_mutex_unlock(&P->first_mu);
+		}
 		if (n == 0) {
 			/* end of the stream: one token per consumer (P->n_filled is final from here on) */
 			int c;
@@ -1617,7 +1629,6 @@ static void *filter_dev_thread(void *arg) {
 		}
 		/* more batches follow batch 0: their buffers are page-locked while this one is processed */
 		if (s->seq == 0 && P->raw_mode && !__atomic_load_n(&P->in_eof, __ATOMIC_RELAXED)) pin_start(P, 1);
-		if (s->seq == 0) { filter_open_output(F, b); t1 = now_s(); }
 		pipe_pin_slot(P, s);
 		rb_host_view(b, &hb, P->mode != 0);
 		hb.pool_rule = (F->pools && F->po) ? MSX_POOLS_FILTER : MSX_POOLS_PROFILE;
@@ -1640,10 +1651,7 @@ static void *filter_dev_thread(void *arg) {
 	msx_unpack_destroy(g_ctx, unpack);
 	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
 	pthread_mutex_lock(&F->mu);
-	if (++F->n_done == F->n_dev) {
-		if (__atomic_load_n(&P->n_filled, __ATOMIC_ACQUIRE) == 0) filter_open_output(F, NULL);
-		pq_push(&P->q_out, PQ_END);
-	}
+	if (++F->n_done == F->n_dev) pq_push(&P->q_out, PQ_END);
 	pthread_mutex_unlock(&F->mu);
 	return NULL;
 }
@@ -1748,6 +1756,14 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	for (k = 0; k < F.n_dev; k++) {
 		F.dev[k].S = &F; F.dev[k].dev_id = dev_ids[k]; F.dev[k].index = k;
 		if (pthread_create(&F.dev[k].th, NULL, filter_dev_thread, &F.dev[k]) != 0) mDie("pthread_create failed");
+	}
+	{
+		/* the preflight on batch 0's records (msam_filter.c:478-482) and the header, here -- beside the device
+		 * stage's start-up and its work on batch 0, not in front of it (a million @SQ lines are 45 MB of header) */
+		pthread_mutex_lock(&P.first_mu);
+		while (P.first_state == 0) pthread_cond_wait(&P.first_cv, &P.first_mu);
+		pthread_mutex_unlock(&P.first_mu);
+		filter_open_output(&F, P.first_state == 1 ? &P.slot[P.first_slot].b : NULL);
 	}
 	for (;;) {                                   /* this thread is the encode stage: batches in input order */
 		double t0 = now_s(), t1;

@@ -35,8 +35,8 @@ void mDie(const char *fmt, ...) {
 	/* a fatal error raised on a worker, reader, writer or device thread: the other threads are still running (a
 	 * device thread may be inside the HIP runtime, which exit()'s handlers would tear down under it) -- leave at
 	 * once, with the diagnostic and everything written so far flushed */
-	fflush(stderr);
-	if (msh_main_thread_set && !pthread_equal(pthread_self(), msh_main_thread)) _exit(EXIT_FAILURE);
+	fflush(NULL);
+	if (msh_main_thread_set) _exit(EXIT_FAILURE);       /* (the command line: device, reader or writer threads may be running) */
 	exit(EXIT_FAILURE);
 }
 
