@@ -712,7 +712,8 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	memset(P, 0, sizeof *P);
 	P->in = in;
 	P->n_consumers = n_consumers < 1 ? 1 : n_consumers;
-	P->n_slots = PIPE_SLOTS + P->n_consumers - 1;
+	P->n_slots = (int)env_size("MSX_SLOTS", PIPE_SLOTS) + P->n_consumers - 1;
+	if (P->n_slots < 2) P->n_slots = 2;
 	if (P->n_slots > PIPE_SLOTS_MAX) P->n_slots = PIPE_SLOTS_MAX;
 	P->hdr = msh_header(in);
 	P->mode = mode;
@@ -1194,7 +1195,9 @@ static void *pipe_decode_thread(void *arg) {
 static void pipe_pin_slot(pipe_t *P, pslot *s) {
 	rbatch *b = &s->b;
 	const size_t c = b->cap;
-	if (s->pinned || getenv("MSX_NO_PIN")) return;
+	/* (device unpack: only batch 0 takes the host-side walk -- page-locking 170 MB of arrays for one upload costs more
+	 * than the upload saves) */
+	if (s->pinned || P->raw_mode || getenv("MSX_NO_PIN")) return;
 	s->pinned = 1;
 	MSX(msx_host_register(g_ctx, b->flag, c * 2));
 	MSX(msx_host_register(g_ctx, b->rflags, c));
