@@ -106,7 +106,7 @@ def parse_profile_text(text):
 
 class Community:
     def __init__(self, seed=1, n_species=3, strains=(3, 2, 2), chrom_len=(14000, 22000), n_shared=36, n_within=4,
-                 sharing=True):
+                 sharing=True, copies=(1, 3)):
         rng = np.random.RandomState(seed)
         self.rng = rng
         self.genomes = []      # dict(name, species, strain, seq)
@@ -125,7 +125,7 @@ class Community:
                 piece = self.genomes[donor]["seq"][ds:ds + L]
                 within = k >= n_shared
                 others = [donor] if within else [g for g in range(len(self.genomes)) if g != donor]
-                for _ in range(int(rng.randint(1, 3))):
+                for _ in range(int(rng.randint(copies[0], copies[1]))):
                     g = int(rng.choice(others))
                     s = int(rng.randint(0, len(self.genomes[g]["seq"]) - L))
                     if within and abs(s - ds) < L:
@@ -161,8 +161,11 @@ class Community:
     def feature_of(self, level):
         return [g[level] for g in self.genomes]
 
-    def write(self, path, n_inserts, shared_fraction=0.25, single_mate_fraction=0.06, seed=2, exclude_cross=False):
-        """Writes the SAM; returns dict(source=[genome index per insert], targets=[set of genome indices])."""
+    def write(self, path, n_inserts, shared_fraction=0.25, single_mate_fraction=0.06, seed=2, exclude_cross=False,
+              weighted_shared=False):
+        """Writes the SAM; returns dict(source=[genome index per insert], targets=[set of genome indices]).
+        weighted_shared: the inserts drawn from shared loci take their source genome in proportion to abundance x
+        locus length as well (an absent genome is then never a source), instead of uniformly over the planted copies."""
         rng = np.random.RandomState(seed)
         lens = np.array([len(g["seq"]) for g in self.genomes], dtype=float)
         w = self.abundance * lens
@@ -172,6 +175,10 @@ class Community:
         plan = np.repeat(np.arange(len(w)), [alloc[i] for i in range(len(w))])
         rng.shuffle(plan)
         src, tgt = [], []
+        site_p = None
+        if weighted_shared and self.shared_sites:
+            site_p = np.array([self.abundance[g] * L for g, _, L in self.shared_sites], dtype=float)
+            site_p = site_p / site_p.sum() if site_p.sum() > 0 else None
         with open(path, "w") as f:
             f.write("@HD\tVN:1.6\tSO:queryname\n")
             for g in self.genomes:
@@ -179,7 +186,8 @@ class Community:
             i = 0
             while i < n_inserts:
                 if self.shared_sites and rng.rand() < shared_fraction:
-                    gi, s0, L = self.shared_sites[int(rng.randint(len(self.shared_sites)))]
+                    k_site = int(rng.choice(len(self.shared_sites), p=site_p)) if site_p is not None else int(rng.randint(len(self.shared_sites)))
+                    gi, s0, L = self.shared_sites[k_site]
                     start = s0 + int(rng.randint(0, L - INSERT + 1))
                 else:
                     gi = int(plan[i])
@@ -227,3 +235,16 @@ def bray_curtis(truth, est):
     l1 = sum(abs(truth[k] - est.get(k, 0.0)) for k in keys)
     den = sum(truth.values()) + sum(est.get(k, 0.0) for k in keys)
     return l1 / den if den > 0 else 0.0
+
+
+def realised_rel(comm, truth, level):
+    """Relative cell abundance per feature as the simulation realised it: source inserts per base of the feature."""
+    cnt, length = defaultdict(float), defaultdict(float)
+    for g in comm.genomes:
+        length[g[level]] += len(g["seq"])
+        cnt[g[level]] += 0.0
+    for gi in truth["source"]:
+        cnt[comm.genomes[gi][level]] += 1.0
+    dens = {k: cnt[k] / length[k] for k in cnt}
+    tot = sum(dens.values())
+    return {k: v / tot for k, v in dens.items()}
