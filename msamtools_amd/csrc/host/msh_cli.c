@@ -672,6 +672,7 @@ typedef struct {
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
 	int raw_started, raw_done;
 	int first_state, first_slot;   /* 0: batch 0 not decoded yet; 1: it is, in slot first_slot; 2: the input holds no record (first_mu) */
+	int out_opened;                /* the preflight has passed and the output is open (first_mu) */
 	pthread_mutex_t first_mu;
 	pthread_cond_t first_cv;
 	int pin_obuf;              /* filter: the slots also get an output buffer */
@@ -694,6 +695,12 @@ typedef struct {
 	double t_decode, t_wait_free;
 	double t_inflate, t_chase, t_scan, t_serial, t_copy;    /* inside t_decode */
 } pipe_t;
+
+/* the next stretch of BAM record bytes of the input, whatever its format: inflated BGZF blocks, or SAM text parsed
+ * into records (the reference reads both through sam_read1: msam_helper.c:246-268; its validation harness feeds .sam) */
+static size_t pipe_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
+	return msh_is_bam(in) ? msh_inflate_append(in, buf, len, cap) : msh_sam_append(in, buf, len, cap);
+}
 
 static size_t env_size(const char *name, size_t dflt) {
 	const char *e = getenv(name);
@@ -1029,7 +1036,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		size_t want = P->batch_bytes;
 		double tq = now_s(), tq2;
 		while (!P->in_eof && s->ulen < want)
-			if (!msh_inflate_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
+			if (!pipe_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
 		tq2 = now_s(); P->t_inflate += tq2 - tq; tq = tq2;
 		if (s->ulen == 0) return 0;
 		n = chase_records(P, b, s->ubuf, s->ulen, P->cap_rec, &tail);
@@ -1161,7 +1168,7 @@ static void *pipe_decode_thread(void *arg) {
 				 * on.  The buffer is page-locked and must not move: msh_inflate_append appends one batch of blocks at most,
 				 * so there is always room for the next call) */
 				while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + BGZF_INFLATE_MAX + 64 <= s->rcap)
-					if (!msh_inflate_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
+					if (!pipe_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
 				s->last = P->in_eof;
 				if (s->last) P->raw_done = 1;
 				n = 1;                       /* (a slot: possibly without bytes, its `last` flag flushes the device's carry) */
@@ -1573,7 +1580,14 @@ static void *filter_dev_thread(void *arg) {
 	msx_unpack *unpack = NULL;
 	{
 		double t0 = now_s();
-		ctx_open_dev(D->dev_id);             /* HIP start-up runs beside the decoding of the first batch */
+		/* HIP start-up runs beside the decoding of the first batch.  Should it fail, the input's own faults are
+		 * reported first (the preflight runs on the writer thread; the reference checks the input before anything else) */
+		if (msx_ctx_create(&g_ctx, D->dev_id) != MSX_OK) {
+			pthread_mutex_lock(&P->first_mu);
+			while (!P->out_opened) pthread_cond_wait(&P->first_cv, &P->first_mu);
+			pthread_mutex_unlock(&P->first_mu);
+			mDie("%s", msx_last_error(NULL));
+		}
 		D->ctx = g_ctx;
 		MSX(msx_stage_create(g_ctx, &stage));
 		if (F->po)
@@ -1767,6 +1781,10 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		while (P.first_state == 0) pthread_cond_wait(&P.first_cv, &P.first_mu);
 		pthread_mutex_unlock(&P.first_mu);
 		filter_open_output(&F, P.first_state == 1 ? &P.slot[P.first_slot].b : NULL);
+		pthread_mutex_lock(&P.first_mu);
+		P.out_opened = 1;
+		pthread_cond_broadcast(&P.first_cv);
+		pthread_mutex_unlock(&P.first_mu);
 	}
 	for (;;) {                                   /* this thread is the encode stage: batches in input order */
 		double t0 = now_s(), t1;
@@ -1983,14 +2001,14 @@ int msam_filter_main(int argc, char *argv[]) {
 
 	if (tee) prof_opts_derive(&po);
 	bulk = msh_is_bam(rd.in);
-	if (bulk && !getenv("MSX_SERIAL_IO")) {
-		/* BAM in: decode | device | encode as three overlapping stages */
+	if (!getenv("MSX_SERIAL_IO")) {
+		/* BAM or SAM text in: decode | device | encode as three overlapping stages */
 		int rc = filter_pipelined(rd.in, &fp, pools, want_stats, mode, argc, argv, tee ? &po : NULL);
 		msh_close(rd.in);
 		return rc;
 	}
-	if (tee) mDie("--profile-out needs BAM input (pipe SAM text through `%s recode -u`)", PROGRAM);
-	/* SAM text in (or MSX_SERIAL_IO): one batch at a time */
+	if (tee) mDie("--profile-out is not available with MSX_SERIAL_IO");
+	/* MSX_SERIAL_IO (tests: the record-at-a-time reader as a second opinion): one batch at a time */
 	/* first batch: large enough for the preflight window */
 	{
 		size_t t1 = target > COORD_ORDER_CHECK_RECORDS ? target : COORD_ORDER_CHECK_RECORDS;
@@ -2263,8 +2281,8 @@ int msam_profile_main(int argc, char *argv[]) {
 	memset(&b, 0, sizeof b);
 	memset(&qn, 0, sizeof qn);
 	row = (double *)calloc((size_t)F.n_features + 1, sizeof(double));
-	if (msh_is_bam(in) && !getenv("MSX_SERIAL_IO")) {
-		/* BAM in: the decode stage on its own thread feeds one device thread per GPU */
+	if (!getenv("MSX_SERIAL_IO")) {
+		/* BAM or SAM text in: the decode stage on its own thread feeds one device thread per GPU */
 		static pipe_t P;
 		static pshared S;
 		pthread_t th_dec;

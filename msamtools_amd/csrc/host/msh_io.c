@@ -1069,6 +1069,10 @@ struct msh_in {
 	size_t line_cap;
 	kstr pending;        /* first record line, read while scanning the header */
 	int has_pending;
+	/* SAM text through the pipelined reader (msh_sam_append) */
+	char *tbuf;
+	size_t tcap, tlen;   /* tbuf[0, tlen): text read but not parsed yet (an incomplete last line) */
+	int text_eof;
 };
 
 int msh_is_bam(const msh_in *in) { return in->is_bam; }
@@ -1116,6 +1120,105 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 		msh_parallel(msh_threads() < b->nblk ? msh_threads() : b->nblk, inflate_worker, b);
 	}
 	*len += total;
+	return total;
+}
+
+/* SAM text for the pipelined reader: the next chunk of lines, parsed on all threads into BAM records
+ * ([block_size | record] back to back, in input order) and appended to *buf.  A chunk is SAM_CHUNK bytes of text: at
+ * most twice that in BAM bytes (a record's binary form exceeds its text by the fixed core at most).  Returns the number
+ * of bytes appended, 0 at the end of the input. */
+#define SAM_CHUNK ((size_t)16 << 20)
+typedef struct {
+	const msh_hdr *h;
+	char *text;
+	size_t lo[MSH_MAX_THREADS + 1];       /* line-aligned ranges of the chunk, one per thread */
+	kstr out[MSH_MAX_THREADS];
+} sam_job;
+
+static void sam_worker(void *arg, int tid, int nth) {
+	sam_job *J = (sam_job *)arg;
+	char *p = J->text + J->lo[tid], *end = J->text + J->lo[tid + 1];
+	kstr rec = {0, 0, 0}, *o = &J->out[tid];
+	(void)nth;
+	o->l = 0;
+	while (p < end) {
+		char *nl = (char *)memchr(p, '\n', (size_t)(end - p));
+		char *stop = nl ? nl : end;
+		size_t n = (size_t)(stop - p);
+		*stop = 0;
+		while (n > 0 && p[n - 1] == '\r') p[--n] = 0;
+		if (n > 0) {
+			uint8_t b4[4];
+			msh_sam_parse(J->h, p, &rec);
+			b4[0] = (uint8_t)rec.l; b4[1] = (uint8_t)(rec.l >> 8); b4[2] = (uint8_t)(rec.l >> 16); b4[3] = (uint8_t)(rec.l >> 24);
+			ks_put(o, b4, 4);
+			ks_put(o, rec.s, rec.l);
+		}
+		p = stop + 1;
+	}
+	free(rec.s);
+}
+
+size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
+	static sam_job J;
+	size_t end, total = 0;
+	int nth = msh_threads(), t;
+	if (in->is_bam) mDie("msh_sam_append on BAM input");
+	for (;;) {
+		if (in->tcap < in->tlen + SAM_CHUNK + 2) {
+			in->tcap = in->tlen + SAM_CHUNK + 2;
+			in->tbuf = (char *)realloc(in->tbuf, in->tcap);
+			if (!in->tbuf) mDie("Out of memory");
+		}
+		if (in->has_pending) {                 /* the first record line, read while the header was scanned */
+			in->has_pending = 0;
+			memcpy(in->tbuf + in->tlen, in->pending.s, in->pending.l);
+			in->tlen += in->pending.l;
+			in->tbuf[in->tlen++] = '\n';
+		}
+		if (!in->text_eof) {
+			const size_t got = fread(in->tbuf + in->tlen, 1, SAM_CHUNK, in->fp);
+			in->tlen += got;
+			if (got < SAM_CHUNK) in->text_eof = 1;
+		}
+		if (in->tlen == 0) return 0;
+		/* the chunk ends behind its last newline; at the end of the input the rest is a line as well */
+		end = in->tlen;
+		if (!in->text_eof) {
+			while (end > 0 && in->tbuf[end - 1] != '\n') end--;
+			if (end == 0) continue;            /* one line longer than the chunk: read on */
+		}
+		break;
+	}
+	if (nth > MSH_MAX_THREADS) nth = MSH_MAX_THREADS;
+	if ((size_t)nth > end / 65536 + 1) nth = (int)(end / 65536 + 1);
+	J.h = &in->hdr;
+	J.text = in->tbuf;
+	J.lo[0] = 0;
+	for (t = 1; t < nth; t++) {
+		size_t q = end * (size_t)t / (size_t)nth;
+		if (q < J.lo[t - 1]) q = J.lo[t - 1];
+		while (q < end && q > 0 && in->tbuf[q - 1] != '\n') q++;
+		J.lo[t] = q;
+	}
+	J.lo[nth] = end;
+	if (end == in->tlen) { in->tbuf[end] = 0; }      /* (room for the terminator of an unterminated last line) */
+	msh_parallel(nth, sam_worker, &J);
+	for (t = 0; t < nth; t++) total += J.out[t].l;
+	if (*len + total + 64 > *cap) {
+		size_t nc = *cap ? *cap : ((size_t)16 << 20);
+		while (nc < *len + total + 64) nc += nc >> 1;
+		*buf = (uint8_t *)realloc(*buf, nc);
+		if (!*buf) mDie("Out of memory");
+		*cap = nc;
+	}
+	for (t = 0; t < nth; t++) {
+		memcpy(*buf + *len, J.out[t].s, J.out[t].l);
+		*len += J.out[t].l;
+	}
+	memmove(in->tbuf, in->tbuf + end, in->tlen - end);
+	in->tlen -= end;
+	if (total == 0 && (in->tlen > 0 || !in->text_eof)) return msh_sam_append(in, buf, len, cap);   /* (a chunk of empty lines) */
 	return total;
 }
 

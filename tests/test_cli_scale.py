@@ -282,3 +282,29 @@ def test_device_unpack_equals_host_unpack(big, tmp_path):
     f = str(tmp_path / "fb.bam")
     sh(f"{BIN} {' '.join(FILT)} -b {big.bam['u']} > {f}")
     big.check_digest(f, big.digest_out)
+
+
+# ---- SAM text in (the reference's validation harness feeds .sam: validate_profiles.py:735-751) ----------------------
+
+def test_sam_text_input_takes_the_pipeline(mid, tmp_path):
+    """SAM text is parsed into BAM records on all threads by the decode stage and takes the same pipeline (device
+    unpack from the second batch on): same records out, same profiles -- filter, profile, the one-process pipe, and
+    text out of text in."""
+    sam = str(tmp_path / "in.sam")
+    with open(sam, "wb") as fh:
+        subprocess.check_call([BIN, "recode", "-h", mid.bam["b"]], stdout=fh)
+    assert os.path.getsize(sam) > 100_000_000
+    f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    r = sh(f"{BIN} {' '.join(FILT)} -S -bu --profile-out {p} --label S {sam} > {f}", MSX_TIMING=1, MSX_BATCH_BYTES=4_000_000)
+    assert n_batches(r.stderr) >= 5
+    mid.check_digest(f, mid.digest_out)
+    mid.check_profile(p, mid.pipe)
+    r = sh(f"cat {sam} | {BIN} profile -S --label S -o {p} -", MSX_TIMING=1, MSX_BATCH_BYTES=4_000_000)
+    assert n_batches(r.stderr) >= 5
+    mid.check_profile(p, mid.plain)
+    # text in, text out: the lines the oracle selects
+    out = sh(f"{BIN} {' '.join(FILT)} -S {sam}", MSX_BATCH_BYTES=4_000_000).stdout.decode().split("\n")[:-1]
+    src = [l for l in open(sam).read().split("\n") if l and not l.startswith("@")]
+    assert out == [src[i] for i in mid.emit]
+    # and the record-at-a-time reader agrees (MSX_SERIAL_IO)
+    assert sh(f"{BIN} {' '.join(FILT)} -S {sam}", MSX_SERIAL_IO=1).stdout.decode().split("\n")[:-1] == out
