@@ -1127,7 +1127,17 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
  * ([block_size | record] back to back, in input order) and appended to *buf.  A chunk is SAM_CHUNK bytes of text: at
  * most twice that in BAM bytes (a record's binary form exceeds its text by the fixed core at most).  Returns the number
  * of bytes appended, 0 at the end of the input. */
-#define SAM_CHUNK ((size_t)16 << 20)
+#define SAM_CHUNK_MAX ((size_t)16 << 20)
+static size_t sam_chunk_bytes(void) {           /* MSX_SAM_CHUNK lowers it (tests: many small batches) */
+	static size_t v = 0;
+	if (!v) {
+		const char *e = getenv("MSX_SAM_CHUNK");
+		const long long n = e ? strtoll(e, NULL, 10) : 0;
+		v = (n >= 4096 && (size_t)n < SAM_CHUNK_MAX) ? (size_t)n : SAM_CHUNK_MAX;
+	}
+	return v;
+}
+#define SAM_CHUNK sam_chunk_bytes()
 typedef struct {
 	const msh_hdr *h;
 	char *text;
