@@ -466,16 +466,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_dup_mark(const unsigned long long
 
 // unique list u (sorted position i, a head): offsets, entries, and the sorted position itself
 // (weights are differences of consecutive head positions)
-// An entry's key: class in the two low bits, the feature id above them, the list's weight above that.  The class says
-// how many OTHER features the entry's list has -- 0: one, 1: two, 2: three -- or, 3, that the list is a general one
-// (recip[] is gathered).  Sorting by (feature, class) keeps a feature's entries together and, inside a feature, the
-// entries of one class: a wave of k_share_reduce that walks a long segment then sees one class only and skips the
-// gathers that class does not need (a third of the entries of the IGC-scale workload need the second other feature,
-// an eighth the third) -- the gather instructions are what that kernel's time goes to.
-#define EK_CLASS_BITS 2
-#define EK_GENERAL 3u
-__device__ __forceinline__ uint32_t ek_make(uint32_t feature, uint32_t cls) { return (feature << EK_CLASS_BITS) | cls; }
-
 __device__ __forceinline__ unsigned long long pack_others(uint32_t o1, uint32_t o2, uint32_t o3) {
 	return (unsigned long long)o1 | ((unsigned long long)o2 << 21) | ((unsigned long long)o3 << 42);
 }
@@ -550,11 +540,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 			// the set is in the signature (ascending feature order)
 			const uint32_t a = (uint32_t)(sg & SIG_PAD), b = (uint32_t)((sg >> 21) & SIG_PAD),
 			               c = (uint32_t)((sg >> 42) & SIG_PAD);
-			// (a list of one feature cannot occur: such an insert is uniquely mapped)
-			const uint32_t cls = (c != SIG_PAD) ? 1u : 0u;
-			d_fid[o] = (int32_t)a; e_key[o] = ek_make(a, cls); e_val[o] = pack_others(b, c, SIG_PAD); o++;
-			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_key[o] = ek_make(b, cls); e_val[o] = pack_others(a, c, SIG_PAD); o++; }
-			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_key[o] = ek_make(c, cls); e_val[o] = pack_others(a, b, SIG_PAD); }
+			d_fid[o] = (int32_t)a; e_key[o] = a; e_val[o] = pack_others(b, c, SIG_PAD); o++;
+			if (b != SIG_PAD) { d_fid[o] = (int32_t)b; e_key[o] = b; e_val[o] = pack_others(a, c, SIG_PAD); o++; }
+			if (c != SIG_PAD) { d_fid[o] = (int32_t)c; e_key[o] = c; e_val[o] = pack_others(a, b, SIG_PAD); }
 		} else {
 			const uint32_t j = (uint32_t)sg;
 			const uint32_t s = m_off[j], e = m_off[j + 1];
@@ -580,11 +568,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_uniq_gather(const unsigned long l
 					const uint32_t o1 = (x == q0) ? q1 : q0;
 					const uint32_t o2 = (x == q0 || x == q1) ? q2 : q1;
 					const uint32_t o3 = (x == q3) ? q2 : q3;
-					d_fid[o] = (int32_t)x; e_key[o] = ek_make(x, 2u); e_val[o] = pack_others(o1, o2, o3); o++;
+					d_fid[o] = (int32_t)x; e_key[o] = x; e_val[o] = pack_others(o1, o2, o3); o++;
 				}
 			} else {
 				for (uint32_t k = s; k < e; ++k) {
-					d_fid[o] = m_fid[k]; e_key[o] = ek_make((uint32_t)m_fid[k], EK_GENERAL); e_val[o] = SIG_HASHED | u; o++;
+					d_fid[o] = m_fid[k]; e_key[o] = (uint32_t)m_fid[k]; e_val[o] = SIG_HASHED | u; o++;
 				}
 			}
 		}
@@ -617,12 +605,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_entry_weight(unsigned long long *
 			const uint32_t w = hpos[u + 1] - hpos[u];
 			const bool hashed = (e_val[s] & SIG_HASHED) != 0;
 			// (w + 1: the all-ones key is the sentinel of k_share_reduce)
-			// (`bits` counts the feature and the class bits)
 			const bool fits = bits < 32 && (((unsigned long long)w + 1ull) >> (32 - bits)) == 0ull;
 			if (!hashed && fits) {
 				for (uint32_t o = s; o < e; ++o) e_key[o] |= w << bits;
 			} else {
-				for (uint32_t o = s; o < e; ++o) { e_key[o] |= EK_GENERAL; e_val[o] = SIG_HASHED | (unsigned long long)u; }
+				for (uint32_t o = s; o < e; ++o) e_val[o] = SIG_HASHED | (unsigned long long)u;
 				s_gl[atomicAdd(&s_n, 1u)] = (uint32_t)u;     // (<= 256 per round: flushed below before it can overflow)
 			}
 		}
@@ -779,8 +766,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		return;
 	}
 	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
-	// key = [weight | feature | class]: `bits` counts feature and class bits; a feature id is (key & kmask) >> EK_CLASS_BITS
-	const uint32_t kmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
+	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	// the open segment carried from step to step (its sum so far, whether it began inside this chunk)
 	double carry = 0.0;
 	bool carry_started = false, carry_open = false;
@@ -815,7 +801,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 #pragma unroll
 		for (int i = 0; i < SR_EPL; i++)
 			if (r0 + i >= c1) { k[i] = SR_SENT; lv[i] = 0ull; }
-		after = (lane == 63 && base + SR_STEP < E) ? ((after & kmask) >> EK_CLASS_BITS) : SR_SENT;
+		after = (lane == 63 && base + SR_STEP < E) ? (after & fmask) : SR_SENT;
 	};
 	// The operands of each entry's term w/S.  A list of <= 4 features travels with its entries (the other
 	// features in the value, weight above the feature id in the key): S is summed from a[] -- 8 MB that
@@ -836,24 +822,19 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		return d;
 	};
 	const uint32_t NONE = 0xffffffffu;                            // (beyond any buffer)
-	// The class of an entry (two low key bits) says which operands exist; an operand slot no lane of the wave needs is not
-	// fetched at all (wave-uniform branch): inside a long segment the entries are ordered by class, so whole steps need
-	// neither the second nor the third other feature nor recip[].
 	auto gather_step = [&](const uint32_t *k, const unsigned long long *lv, double *af, double *ag, double *a1, double *a2, double *a3) {
 #pragma unroll
 		for (int i = 0; i < SR_EPL; i++) {
 			const bool live = k[i] != SR_SENT;
-			const uint32_t cls = k[i] & 3u;
-			const bool general = live && cls == EK_GENERAL;
+			const bool general = live && (lv[i] & SIG_HASHED) != 0;
 			const bool exact = live && !general;
 			const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
 			               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-			af[i] = bload(rs_a, exact ? ((k[i] & kmask) >> EK_CLASS_BITS) * 8u : NONE);
-			a1[i] = bload(rs_a, exact ? o1 * 8u : NONE);
-			a2[i] = 0.0; a3[i] = 0.0; ag[i] = 0.0;
-			if (__ballot(exact && cls >= 1u) != 0ull) a2[i] = bload(rs_a, (exact && cls >= 1u) ? o2 * 8u : NONE);
-			if (__ballot(exact && cls == 2u) != 0ull) a3[i] = bload(rs_a, (exact && cls == 2u) ? o3 * 8u : NONE);
-			if (__ballot(general) != 0ull) ag[i] = bload(rs_r, general ? (uint32_t)lv[i] * 8u : NONE);
+			af[i] = bload(rs_a, exact ? (k[i] & fmask) * 8u : NONE);
+			ag[i] = bload(rs_r, general ? (uint32_t)lv[i] * 8u : NONE);
+			a1[i] = bload(rs_a, (exact && o1 != SIG_PAD) ? o1 * 8u : NONE);
+			a2[i] = bload(rs_a, (exact && o2 != SIG_PAD) ? o2 * 8u : NONE);
+			a3[i] = bload(rs_a, (exact && o3 != SIG_PAD) ? o3 * 8u : NONE);
 		}
 	};
 	// A three-stage pipeline over the steps of the chunk: while step i is summed, the gathers of step i+1 and
@@ -871,7 +852,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	mask_step(c0, e0.k, e0.lv, e0.after);
 	gather_step(e0.k, e0.lv, g0.af, g0.ag, g0.a1, g0.a2, g0.a3);
 	uint32_t before = 0;
-	if (lane == 0 && c0 > 0) before = (t_key[c0 - 1] & kmask) >> EK_CLASS_BITS;
+	if (lane == 0 && c0 > 0) before = t_key[c0 - 1] & fmask;
 	for (int64_t step = 0; step < n_steps; step++) {
 		const int64_t base = c0 + step * SR_STEP;
 		// (beyond the chunk's last step the same step is fetched again and not used)
@@ -888,11 +869,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 #pragma unroll
 		for (int i = 0; i < SR_EPL; i++) {
 			const bool live = e0.k[i] != SR_SENT;
-			const bool general = (e0.k[i] & 3u) == EK_GENERAL;
+			const bool general = (e0.lv[i] & SIG_HASHED) != 0;
 			const double sum = ((g0.a1[i] + g0.a2[i]) + g0.a3[i]) + g0.af[i];     // absent ones came back as +0.0
 			const double w = (double)(bits < 32 ? (e0.k[i] >> bits) : 0u);
 			x[i] = !live ? 0.0 : general ? g0.ag[i] : (sum > 0 ? w / sum : 0.0);
-			k[i] = live ? ((e0.k[i] & kmask) >> EK_CLASS_BITS) : e0.k[i];         // from here on: the feature id
+			k[i] = live ? (e0.k[i] & fmask) : e0.k[i];                            // from here on: the feature id
 		}
 		e0 = e1; e1 = e2; g0 = g1;
 		b1 = b2;
@@ -978,12 +959,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 // (k_part_runs): the slots of one feature are neighbours (the keys ascend), a *run*; runs[] lists every
 // run as (feature, first slot, number of slots), and a bitmap marks the features that own one.
 #define PA_FPB 1024                    // features per streaming workgroup of k_prop_apply
-__device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t kmask) {
+__device__ __forceinline__ uint32_t part_key_at(int64_t j, int64_t E, int64_t per, const uint32_t *t_key, uint32_t fmask) {
 	const int64_t c0 = (j >> 1) * per;
 	if (c0 >= E) return SR_SENT;          // idle wave
-	if (!(j & 1)) return (t_key[c0] & kmask) >> EK_CLASS_BITS;
+	if (!(j & 1)) return t_key[c0] & fmask;
 	const int64_t c1 = (c0 + per < E) ? c0 + per : E;
-	return (t_key[c1 - 1] & kmask) >> EK_CLASS_BITS;
+	return t_key[c1 - 1] & fmask;
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long long *__restrict__ csr_tot,
@@ -991,10 +972,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_part_index(const unsigned long lo
                                                           uint32_t *__restrict__ part_key, unsigned long long *d_tot) {
 	const int64_t E = (int64_t)csr_tot[1];
 	const int64_t per = sr_chunk(E, W);
-	const uint32_t kmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
+	const uint32_t fmask = bits < 32 ? ((1u << bits) - 1u) : 0xffffffffu;
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < 2 * W; j += stride)
-		part_key[j] = part_key_at(j, E, per, t_key, kmask);
+		part_key[j] = part_key_at(j, E, per, t_key, fmask);
 	if (blockIdx.x == 0 && threadIdx.x == 0) { d_tot[3] = 0; d_tot[4] = 0; }   // short / long runs, counted by k_part_runs
 }
 
@@ -1311,10 +1292,6 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		int hash_bits = 32 - bits;
 		if (hash_bits > 12) hash_bits = 12;
 		if (hash_bits < 0) hash_bits = 0;
-		if (const char *e = getenv("MSX_LIST_HASH_BITS")) {       // experiments: fewer key bits = fewer radix passes, fewer merges
-			const int v = atoi(e);
-			if (v >= 0 && v < hash_bits) hash_bits = v;
-		}
 		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->head, (size_t)(lub + 8) * 4))) return rc;
@@ -1352,17 +1329,17 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_entry_weight, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                             p->d_tot, (const uint32_t *)p->m_off_alt.p,
-		                             (const uint32_t *)p->hpos.p, bits + EK_CLASS_BITS, (uint32_t *)p->t_key[ebuf].p,
+		                             (const uint32_t *)p->hpos.p, bits, (uint32_t *)p->t_key[ebuf].p,
 		                             (unsigned long long *)p->t_val64[ebuf].p, (uint32_t *)p->gl_idx.p));
 	}
 	tot = p->d_tot;      // everything below works on the derived store
-	p->key_bits = bits + EK_CLASS_BITS;       // feature + class bits of an entry key; the weight sits above
+	p->key_bits = bits;
 
 	// (b) feature-major view: (feature, list) pairs sorted by feature
 	int cur = ebuf;     // (a single feature: the list-major order is already feature-major)
-	if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[ebuf].p,
-	                           (const unsigned long long *)p->t_val64[ebuf].p, ebuf, tot + 1, eub, bits + EK_CLASS_BITS,
-	                           &cur)))
+	if (bits > 0 && (rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[ebuf].p,
+	                                       (const unsigned long long *)p->t_val64[ebuf].p, ebuf, tot + 1, eub, bits,
+	                                       &cur)))
 		return rc;
 	p->sorted_buf = cur;
 	// (c) keys of the partial slots, their runs, and the features that own one
@@ -1371,7 +1348,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		MSX_HIP(ctx, hipMemsetAsync(p->owned.p, 0, (size_t)(p->n_features / 32 + 1) * 4, ctx->stream));
 		msx_time_begin(ctx, MSX_K_LIST_ORDER);
 		hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, 2 * W, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits + EK_CLASS_BITS, W,
+		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W,
 		                   (uint32_t *)p->part_key.p, p->d_tot);
 		hipLaunchKernelGGL(k_part_runs, dim3((unsigned)((2 * W + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
