@@ -74,6 +74,8 @@ def parse():
                          "even with one rank")
     ap.add_argument("--print-checksum", action="store_true", help="add a checksum of the abundance vector to the JSON")
     ap.add_argument("--no-coverage", action="store_true", help="skip the coverage block (BASELINE configs[3])")
+    ap.add_argument("--no-dist-parity", action="store_true",
+                    help="N ranks: skip comparing the distributed result with one context doing all N shards")
     ap.add_argument("--no-dist-leg", action="store_true",
                     help="skip timing the multi-GPU step over a one-rank communicator (dist_one_rank_ms_per_step)")
     ap.add_argument("--e2e-seq-groups", type=int, default=4_000_000,
@@ -725,6 +727,38 @@ def main():
                                           f"threads, then one profile pass ({bestn:.2f} s)"}
         except Exception as exc:      # never let the extra figure break the bench line
             out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
+
+    # ---- N ranks: the distributed result against ONE context doing all N shards (rank 0, after the timed region) ----
+    if use_dist and not args.no_dist_parity:
+        par = None
+        if rank == 0:
+            try:
+                prof1 = m.Profile(ctx, nrefs, "proportional")
+                recs = 0
+                for r in range(world):
+                    db_r = db if r == 0 else m.DeviceBatch.synth(ctx, SEED, ng, nrefs, 4, first_group=r * ng)
+                    run_r = run if r == 0 else m.FilterRun(ctx, db_r, **FILTER_OPTS)
+                    run_r.enqueue_with_profile(prof1)
+                    run_r.finish()
+                    recs += db_r.n_records
+                    if r:
+                        run_r.free()
+                        db_r.free()
+                prof1.finalize_enqueue()              # no collective: everything is on this device
+                ab1, st1 = prof1.fetch()
+                same = lambda a, b: all(int(getattr(a, k)) == int(getattr(b, k)) for k in
+                                        ("insert_count", "uniq_mapper_count", "multi_mapper_count", "purged_insert_count",
+                                         "iterations", "converged"))
+                rel = float((np.abs(ab - ab1) / np.maximum(np.abs(ab1), 1e-300)).max())
+                par = {"checked": f"{world} ranks x {n} alignments against one context accumulating all {world} shards",
+                       "records_equal": bool(recs == total_records), "counters_and_iterations_equal": bool(same(pst, st1)),
+                       "zero_pattern_equal": bool(np.array_equal(ab == 0, ab1 == 0)), "max_rel_diff": rel,
+                       "tolerance": 1e-9, "ok": bool(recs == total_records and same(pst, st1) and rel <= 1e-9)}
+                prof1.close()
+            except Exception as exc:
+                par = {"error": str(exc)[:300]}
+            out["dist_parity"] = par
+        barrier()                                      # the other ranks keep their communicator until rank 0 is done
 
     # ---- the multi-GPU step on the one GPU there is: msx_profile_finalize_dist_enqueue over a one-rank RCCL
     # communicator -- the code path the ranks of --gpus N run, collectives included -- next to ms_per_step

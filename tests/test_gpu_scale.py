@@ -120,6 +120,9 @@ def test_bench_multi_gpu_step_on_one_rank():
         assert ca[k] == cb[k], k
     assert abs(ca["abundance_sum"] - cb["abundance_sum"]) <= 1e-9 * ca["abundance_sum"]
     assert ca["abundance_sha1_6dp"] == cb["abundance_sha1_6dp"]
+    # the self-check the N-rank line carries: the distributed result against one context accumulating every shard
+    assert b["dist_parity"]["ok"] is True and b["dist_parity"]["max_rel_diff"] <= 1e-9, b["dist_parity"]
+    assert "dist_parity" not in a
 
 
 @pytest.mark.parametrize("groups,refs", [(300, 7), (2000, 50), (60_000, 500), (400_000, 20_000)])
