@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
 # filled from profiles/ when measured for the default workload; None = not measured.
 TRAFFIC = {}
-_PMC = os.path.join(ROOT, "profiles", "round2", "pmc_traffic_c3.json")
+_PMC = os.path.join(ROOT, "profiles", "round3", "pmc_traffic_c3.json")
 
 
 def load_traffic(workload, ng, nrefs):
