@@ -91,6 +91,7 @@ const uint8_t *msh_span(msh_in *in, size_t *len);     /* unconsumed bytes; inval
 void msh_span_consume(msh_in *in, size_t n);
 /* pipelined reader: inflate the next batch of blocks onto the end of a caller-owned buffer; 0 at EOF */
 size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
+void msh_inflate_limit(int blocks);      /* at most this many BGZF blocks per msh_inflate_append call (0: the default batch) */
 /* the same for SAM text: the next chunk of lines parsed on all threads into BAM records; at most MSH_SAM_APPEND_MAX bytes */
 size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
 #define MSH_SAM_APPEND_MAX ((size_t)48 << 20)

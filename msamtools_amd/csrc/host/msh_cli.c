@@ -719,7 +719,7 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	memset(P, 0, sizeof *P);
 	P->in = in;
 	P->n_consumers = n_consumers < 1 ? 1 : n_consumers;
-	P->n_slots = (int)env_size("MSX_SLOTS", PIPE_SLOTS) + P->n_consumers - 1;
+	P->n_slots = (int)env_size("MSX_SLOTS", PIPE_SLOTS + 1) + P->n_consumers - 1;
 	if (P->n_slots < 2) P->n_slots = 2;
 	if (P->n_slots > PIPE_SLOTS_MAX) P->n_slots = PIPE_SLOTS_MAX;
 	P->hdr = msh_header(in);
@@ -1032,6 +1032,13 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		s->ulen = P->carry.l;
 		P->carry.l = 0;
 	}
+	/* device unpack: batch 0 -- the one batch walked on the host, for the preflight -- is kept to the preflight window
+	 * (it is decoded, uploaded from pageable memory and filtered while everything else waits for it) */
+	if (P->raw_mode && !P->have_first && P->batch_bytes == P->batch_bytes_cfg) {
+		P->batch_bytes = (size_t)12 << 20;
+		if (P->batch_bytes > P->batch_bytes_cfg) P->batch_bytes = P->batch_bytes_cfg;
+		msh_inflate_limit(192);
+	}
 	for (;;) {
 		size_t want = P->batch_bytes;
 		double tq = now_s(), tq2;
@@ -1122,6 +1129,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 	b->n = n_batch;
 	b->base = s->ubuf;
 	P->have_first = 1;
+	msh_inflate_limit(0);
 	for (i = n_batch; i > 0; i--) {       /* grouping state for the next batch */
 		const uint8_t *r = s->ubuf + b->rec_off[i - 1] + 4;
 		if (P->mode == 0 || rec_names_pool(r, P->mode, P->unmapped_visible)) {

@@ -551,6 +551,7 @@ uint32_t msh_crc32(const void *p, size_t n) {
 #define BGZF_MAX 65536
 #define BGZF_BATCH 1024
 /* blocks inflated per call: MSX_INFLATE_BLOCKS lowers it (tests: many small batches through the pipeline) */
+static int bgzf_blocks_limit;          /* msh_inflate_limit: a caller's own, temporary limit (0: none) */
 static int bgzf_batch_blocks(void) {
 	static int v = 0;
 	if (!v) {
@@ -558,8 +559,9 @@ static int bgzf_batch_blocks(void) {
 		const long n = e ? strtol(e, NULL, 10) : 0;
 		v = (n >= 1 && n < BGZF_BATCH) ? (int)n : BGZF_BATCH;
 	}
-	return v;
+	return (bgzf_blocks_limit > 0 && bgzf_blocks_limit < v) ? bgzf_blocks_limit : v;
 }
+void msh_inflate_limit(int blocks) { bgzf_blocks_limit = blocks; }
 #define RD_NBUF 3
 #define RD_HEAD (BGZF_MAX + 1024)    /* headroom in front of a ring buffer's data: the tail of the block its predecessor cut */
 
