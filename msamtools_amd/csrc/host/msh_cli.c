@@ -458,6 +458,20 @@ static inline int rec_names_pool(const uint8_t *r, int mode, int uv) {
 }
 static inline int rec_rule_sees(const uint8_t *r, int mode, int uv) { return mode == 1 ? 1 : rec_names_pool(r, mode, uv); }
 
+/* QNAMEs of two records of the batch differ?  The earlier one may lie in another thread's range and not have been
+ * through msh_rec_check yet: nothing is read beyond what the records' own lengths allow (a corrupt record is reported
+ * by the thread that owns it; here it only must not send a string compare past the buffer). */
+static int rec_name_differs(const rbatch *b, const uint8_t *base, size_t i, const uint8_t *r, const char *pn_rec, size_t pn_len_max) {
+	const size_t len = b->rec_off[i + 1] - b->rec_off[i] - 4;
+	const size_t lq = REC_LQNAME(r);
+	size_t lp = 0;
+	(void)base;
+	if (32 + lq > len || lq == 0) return 1;
+	while (lp < pn_len_max && pn_rec[lp]) lp++;
+	if (lp + 1 != lq) return 1;
+	return memcmp(REC_QNAME(r), pn_rec, lp) != 0;
+}
+
 static void pack_scan(void *arg, int tid, int nth) {
 	pack_job *J = (pack_job *)arg;
 	rbatch *b = J->b;
@@ -465,11 +479,17 @@ static void pack_scan(void *arg, int tid, int nth) {
 	/* QNAME of the nearest earlier record that counts for the pool rule (mapped for filter, tid != -1 for
 	 * profile): found once by walking back from this thread's first record, then carried forward */
 	const char *pn = NULL;
+	size_t pn_max = 255;          /* bytes that may be read at pn */
 	if (J->mode != 0) {
 		size_t j = lo;
 		while (j > 0) {
 			const uint8_t *pr = J->base + b->rec_off[j - 1] + 4;
-			if (rec_names_pool(pr, J->mode, J->unmapped_visible)) { pn = REC_QNAME(pr); break; }
+			const size_t plen = b->rec_off[j] - b->rec_off[j - 1] - 4;
+			if (plen >= 32 && rec_names_pool(pr, J->mode, J->unmapped_visible)) {
+				pn = REC_QNAME(pr);
+				pn_max = plen - 32 < 255 ? plen - 32 : 255;
+				break;
+			}
 			j--;
 		}
 		if (!pn) pn = J->carry_name;
@@ -501,9 +521,9 @@ static void pack_scan(void *arg, int tid, int nth) {
 			b->md_off[i + 1] = 0;
 		}
 		if (J->mode != 0 && rec_rule_sees(r, J->mode, J->unmapped_visible))
-			bd = (pn && strcmp(REC_QNAME(r), pn) != 0) ? 1 : 0;
+			bd = (pn && rec_name_differs(b, J->base, i, r, pn, pn_max)) ? 1 : 0;
 		b->bound[i] = bd;
-		if (J->mode != 0 && rec_names_pool(r, J->mode, J->unmapped_visible)) pn = REC_QNAME(r);
+		if (J->mode != 0 && rec_names_pool(r, J->mode, J->unmapped_visible)) { pn = REC_QNAME(r); pn_max = len - 32 < 255 ? len - 32 : 255; }
 	}
 }
 

@@ -581,7 +581,7 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 	const size_t n = u->carry_len + n_new;
 	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue: more than 4 GiB in one batch");
 	int rc;
-	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 64, u->carry_len))) return rc;
+	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;     // (a corrupt record's name length may point 255 bytes past the data)
 	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
 	if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, host_bytes, n_new, hipMemcpyHostToDevice, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(raw + n, 0, 64, ctx->stream));
@@ -697,7 +697,7 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	{
 		const int nxt = u->cur ^ 1;
 		const size_t cl = n - S.cut_off;
-		if ((rc = grow_keep_n(ctx, &u->raw[nxt], cl + 64, 0))) return rc;
+		if ((rc = grow_keep_n(ctx, &u->raw[nxt], cl + 1024, 0))) return rc;
 		if (cl) MSX_HIP(ctx, hipMemcpyAsync(u->raw[nxt].p, raw + S.cut_off, cl, hipMemcpyDeviceToDevice, ctx->stream));
 		u->carry_len = cl;
 		u->cur = nxt;
