@@ -369,7 +369,7 @@ __device__ __forceinline__ uint32_t sig_len(unsigned long long sg) {
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long *__restrict__ csr_tot,
                                                         const uint32_t *__restrict__ m_off,
-                                                        const int32_t *__restrict__ m_fid, int hash_bits,
+                                                        const int32_t *__restrict__ m_fid, int hash_bits, int coarse, int fbits,
                                                         uint32_t *__restrict__ key,
                                                         unsigned long long *__restrict__ sig) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
@@ -406,7 +406,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long
 			sg = SIG_HASHED | ((unsigned long long)(h2 >> 1) << 32) | (unsigned long long)(uint32_t)j;
 		}
 		const uint32_t hb = hash_bits > 0 ? (h & ((1u << hash_bits) - 1u)) : 0u;
-		key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
+		// hash_bits < 0: the whole key is a hash of the set (-hash_bits bits of it): no order by smallest feature, but
+		// equal sets meet whatever else shares their smallest feature
+		if (hash_bits < 0) {
+			// (experiment) -hash_bits key bits in all: the top `coarse` bits of the smallest feature, a hash of the set below
+			const int kb = -hash_bits, hbits = kb - coarse;
+			const uint32_t hh = mix32(h ^ (h2 * 0x9e3779b9u)) >> (32 - hbits);
+			const uint32_t top = coarse > 0 ? ((mn == 0xffffffffu ? 0u : mn) >> (fbits > coarse ? fbits - coarse : 0)) : 0u;
+			key[j] = (top << hbits) | hh;
+		} else {
+			key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
+		}
 		sig[j] = sg;                                          // travels through the sort as the value
 	}
 }
@@ -1292,6 +1302,13 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		int hash_bits = 32 - bits;
 		if (hash_bits > 12) hash_bits = 12;
 		if (hash_bits < 0) hash_bits = 0;
+		int key_bits_total = bits + hash_bits;
+		if (const char *e = getenv("MSX_LIST_KEY_HASH")) {        // experiment: the sort key is a hash of the set alone, this many bits
+			const int v = atoi(e);
+			if (v >= 8 && v <= 32) { hash_bits = -v; key_bits_total = v; }
+		}
+		int coarse = 0;
+		if (const char *e = getenv("MSX_LIST_KEY_COARSE")) { const int v = atoi(e); if (v >= 0 && v < key_bits_total - 4) coarse = v; }
 		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->head, (size_t)(lub + 8) * 4))) return rc;
@@ -1300,11 +1317,11 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 			if ((rc = msx_reserve(ctx, &p->t_val64[i], (size_t)(eub + 64 + SR_STEP) * 8))) return rc;
 		MSX_TIMED(ctx, MSX_K_LIST_ORDER,
 		          hipLaunchKernelGGL(k_list_key, dim3(msx_grid(ctx, lub, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, tot,
-		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits,
+		                             (const uint32_t *)p->m_off.p, (const int32_t *)p->m_fid.p, hash_bits, coarse, bits,
 		                             (uint32_t *)p->t_key[0].p, (unsigned long long *)p->t_val64[0].p));
 		int sb = 0;
 		if ((rc = radix_sort_pairs(ctx, p, (const uint32_t *)p->t_key[0].p,
-		                           (const unsigned long long *)p->t_val64[0].p, 0, tot + 0, lub, bits + hash_bits, &sb)))
+		                           (const unsigned long long *)p->t_val64[0].p, 0, tot + 0, lub, key_bits_total, &sb)))
 			return rc;
 		const uint32_t *skey = (const uint32_t *)p->t_key[sb].p;
 		const unsigned long long *ssig = (const unsigned long long *)p->t_val64[sb].p;

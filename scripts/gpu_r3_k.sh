@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r3k
 rm -rf $OUT; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_prop_edges.py tests/test_gpu_scale.py tests/test_gpu_fullsize.py tests/test_gpu_chains.py -m gpu -q -x > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log
+timeout 900 python -m pytest tests/test_gpu_prop_edges.py tests/test_gpu_fuzz.py -m gpu -q -x > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log
 tail -5 $OUT/pytest.log
 run_bench() {
   name=$1; shift
@@ -19,4 +19,4 @@ except Exception as e:
 PY
 }
 run_bench base X=1
-for e in "$@"; do run_bench "$(echo $e | tr '=' '_')" "$e"; done
+for e in "$@"; do run_bench "$(echo $e | tr '=,' '__')" $(echo $e | tr ',' ' '); done

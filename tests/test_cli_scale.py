@@ -310,3 +310,52 @@ def test_sam_text_input_takes_the_pipeline(mid, tmp_path):
     # and the record-at-a-time reader agrees (MSX_SERIAL_IO)
     assert sh(f"{BIN} {' '.join(FILT)} -S {sam}", MSX_SERIAL_IO=1).stdout.decode().split("\n")[:-1] == out
     del os.environ["MSX_SAM_CHUNK"]
+
+
+# ---- damaged record streams through the device-side walk -----------------------------------------------------------
+
+def bgzf_blocks(data, level=1):
+    """BGZF framing (SAMv1 4.1) of a byte string, in Python: blocks of <= 0xff00 payload bytes + the EOF block"""
+    import struct
+    import zlib
+    out = bytearray()
+    for i in range(0, len(data), 0xff00):
+        chunk = data[i:i + 0xff00]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25)
+        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    return bytes(out)
+
+
+def test_truncated_and_corrupt_record_streams_are_fatal(mid, tmp_path):
+    """A BAM whose record stream ends inside a record, or holds a block_size < 32, dies with the host reader's own
+    diagnostics when the batch is walked on the device as well (several batches, so the damage lies in a raw one)."""
+    import gzip
+    import struct
+    raw = gzip.open(mid.bam["u"], "rb").read()
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(bgzf_blocks(raw[:len(raw) - 7]))
+    env = dict(os.environ, **ENV)
+    r = subprocess.run(f"{BIN} {' '.join(FILT)} -bu {cut} > /dev/null", shell=True, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Fatal Error: Truncated BAM record" in r.stderr, r.stderr[-300:]
+    r = subprocess.run(f"{BIN} profile --label S -o {tmp_path / 'p.gz'} {cut}", shell=True, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Truncated BAM record" in r.stderr
+    # a record length of 5 two thirds into the stream (found by walking the records from the header's end)
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 8 + struct.unpack_from("<i", raw, p)[0]
+    target = 2 * len(raw) // 3
+    while p < target:
+        p += 4 + struct.unpack_from("<i", raw, p)[0]
+    bad = bytearray(raw)
+    bad[p:p + 4] = struct.pack("<i", 5)
+    badf = tmp_path / "bad.bam"
+    badf.write_bytes(bgzf_blocks(bytes(bad)))
+    for extra in ({}, {"MSX_HOST_UNPACK": "1"}):
+        r = subprocess.run(f"{BIN} {' '.join(FILT)} -bu {badf} > /dev/null", shell=True, env=dict(env, **extra), stderr=subprocess.PIPE)
+        assert r.returncode == 1 and b"Fatal Error: Corrupt BAM record" in r.stderr, r.stderr[-300:]
