@@ -2756,7 +2756,6 @@ static int pipetest_main(int argc, char *argv[]) {
 	if (argc < 4) mQuit("usage: %s pipetest <mode> <stats> <bam>", PROGRAM);
 	mode = atoi(argv[1]); stats = atoi(argv[2]);
 	in = msh_open(argv[3]);
-	if (!msh_is_bam(in)) mQuit("pipetest needs BAM input");
 	pipe_init(&P, in, mode, stats, 1);
 	if (pthread_create(&th, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 	for (;;) {
@@ -2896,6 +2895,40 @@ static int digest_main(int argc, char *argv[]) {
 	return 0;
 }
 
+/* hidden, host only: `msamtools restream [-b|-u] <file>` decodes the input through the pipeline's decode stage and
+ * writes every batch with msh_write_stream -- the writer of device-unpacked batches: a ready-made record stream, cut
+ * into BGZF payloads where they fall -- so that this writer is tested without a GPU. */
+static int restream_main(int argc, char *argv[]) {
+	static pipe_t P;
+	pthread_t th;
+	int mode = MSH_OUT_UBAM, i;
+	const char *path = NULL;
+	msh_in *in;
+	msh_out *out;
+	for (i = 1; i < argc; i++) {
+		if (strcmp(argv[i], "-b") == 0) mode = MSH_OUT_BAM;
+		else if (strcmp(argv[i], "-u") == 0) mode = MSH_OUT_UBAM;
+		else path = argv[i];
+	}
+	if (!path) mQuit("usage: %s restream [-b|-u] <file>", PROGRAM);
+	in = msh_open(path);
+	out = msh_out_open(stdout, mode, msh_header(in), msh_header(in)->text.s ? msh_header(in)->text.s : "");
+	pipe_init(&P, in, 0, 0, 1);
+	if (pthread_create(&th, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
+	for (;;) {
+		const int si = pq_pop(&P.q_dev);
+		pslot *s;
+		if (si == PQ_END) break;
+		s = &P.slot[si];
+		if (s->b.n) msh_write_stream(out, s->b.base + s->b.rec_off[0], s->b.rec_off[s->b.n] - s->b.rec_off[0]);
+		pq_push(&P.q_free, si);
+	}
+	pthread_join(th, NULL);
+	msh_out_close(out);
+	msh_close(in);
+	return 0;
+}
+
 int main(int argc, char *argv[]) {
 	g_t_main = now_s();
 	msh_main_thread = pthread_self();
@@ -2917,6 +2950,7 @@ int main(int argc, char *argv[]) {
 	if (strcmp(argv[1], "recode") == 0) return recode_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "pipetest") == 0) return pipetest_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "digest") == 0) return digest_main(argc - 1, argv + 1);
+	if (strcmp(argv[1], "restream") == 0) return restream_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);

@@ -1177,8 +1177,9 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 	int nth = msh_threads(), t;
 	if (in->is_bam) mDie("msh_sam_append on BAM input");
 	for (;;) {
-		if (in->tcap < in->tlen + SAM_CHUNK + 2) {
-			in->tcap = in->tlen + SAM_CHUNK + 2;
+		const size_t need = in->tlen + (in->has_pending ? in->pending.l + 1 : 0) + SAM_CHUNK + 2;
+		if (in->tcap < need) {
+			in->tcap = need;
 			in->tbuf = (char *)realloc(in->tbuf, in->tcap);
 			if (!in->tbuf) mDie("Out of memory");
 		}

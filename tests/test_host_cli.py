@@ -425,6 +425,42 @@ def test_pipeline_decode_equals_record_reader(synth_bams, mode, stats):
         assert rc == 0, text
 
 
+def test_pipeline_decode_of_sam_text_equals_record_reader(synth_bams, tmp_path):
+    """SAM text through the decode stage (msh_sam_append: chunks of lines parsed into BAM records on all threads) against
+    the line-at-a-time reader: same records, same SoA fields, same pools, for chunks that cut lines anywhere."""
+    sam = str(tmp_path / "in.sam")
+    with open(sam, "wb") as fh:
+        subprocess.check_call([BIN, "recode", "-h", synth_bams["u"]], stdout=fh)
+    for mode, stats in ((1, 1), (2, 0)):
+        for env in (dict(MSX_SAM_CHUNK=70_001, MSX_BATCH_BYTES=300_000, MSX_BATCH_RECORDS=110_000, MSX_THREADS=5),
+                    dict(MSX_SAM_CHUNK=1_000_000, MSX_THREADS=16), dict(MSX_THREADS=1)):
+            rc, text = _pipetest(sam, mode, stats, **env)
+            assert rc == 0, text
+    # CRLF line ends and a last line without a newline
+    body = open(sam, "rb").read().replace(b"\n", b"\r\n")[:-2]
+    open(sam, "wb").write(body)
+    rc, text = _pipetest(sam, 1, 1, MSX_SAM_CHUNK=50_000, MSX_THREADS=4)
+    assert rc == 0, text
+
+
+@pytest.mark.parametrize("flag", ["-u", "-b"])
+def test_stream_writer_roundtrip(synth_bams, tmp_path, flag):
+    """msh_write_stream -- the writer of device-unpacked batches: a ready-made record stream cut into BGZF payloads where
+    they fall, records straddling blocks -- through a file and through a pipe (vmsplice), several batches: the records
+    read back are the input's, in order (`msamtools digest`)."""
+    want = subprocess.check_output([BIN, "digest", synth_bams["u"]])
+    env = dict(os.environ, MSX_BATCH_BYTES="3000000", MSX_INFLATE_BLOCKS="16", MSX_THREADS="6")
+    out = str(tmp_path / "o.bam")
+    with open(out, "wb") as fh:
+        subprocess.check_call([BIN, "restream", flag, synth_bams["b"]], stdout=fh, env=env)
+    assert subprocess.check_output([BIN, "digest", out]) == want
+    subprocess.check_call(f"{BIN} restream {flag} {synth_bams['u']} | cat > {out}", shell=True, env=env)
+    assert subprocess.check_output([BIN, "digest", out]) == want
+    # an independent reader agrees on the BGZF framing (python gzip + struct)
+    hdr, rec = samio.read_bam(out)
+    assert rec.n == int(want.split()[0].split(b"=")[1])
+
+
 def test_pipeline_chase_repairs_wrong_guesses(synth_bams):
     """With MSX_CHASE_SLOPPY nearly every guessed record start is wrong: the stitcher must still
     deliver the true chain."""
