@@ -242,6 +242,9 @@ void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u);
 int  msx_unpack_seed(msx_ctx *ctx, msx_unpack *u, const uint8_t *carry, size_t n, const char *prev_name);
 int  msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n, const msx_unpack_params *prm);
 int  msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result *res, msx_batch *dev_view);
+/* optional: after msx_unpack_finish, send the bytes of the NEXT msx_unpack_enqueue ahead (a copy stream of their own),
+ * so that they travel while the current batch is filtered and its output fetched; the next enqueue names the same bytes */
+int  msx_unpack_prefetch(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n);
 int  msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, uint8_t *host_out,
                      size_t host_cap, int64_t *n_bytes);
 /* record offsets of the last batch, u32[n + 1] relative to its first byte (tests, SAM-text writers) */

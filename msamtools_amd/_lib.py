@@ -110,6 +110,7 @@ SYMBOLS = {
     "msx_unpack_seed": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_char_p]),
     "msx_unpack_enqueue": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(UnpackParams)]),
     "msx_unpack_finish": (C.c_int, [_P, _P, C.POINTER(UnpackResult), C.POINTER(Batch)]),
+    "msx_unpack_prefetch": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msx_unpack_emit": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_int64)]),
     "msx_unpack_offsets": (C.c_int, [_P, _P, _P, C.c_int64]),
     "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),

@@ -313,10 +313,21 @@ class Unpack:
         self.ctx.check(self.ctx.lib.msx_unpack_seed(self.ctx.h, self.h, buf, len(carry),
                                                     prev_name.encode() if isinstance(prev_name, str) else prev_name))
 
+    def prefetch(self, data):
+        """send the bytes of the next enqueue ahead (msx_unpack_prefetch); pass the same `data` to enqueue"""
+        data = bytes(data)
+        self._pre = (data, (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0"))
+        self.ctx.check(self.ctx.lib.msx_unpack_prefetch(self.ctx.h, self.h, self._pre[1], len(data)))
+
     def enqueue(self, data, pool_mode=0, want_aux=True, want_stats=True, n_targets=1 << 30, last=False, cut_mapped=False,
                 unmapped_visible=False):
         data = bytes(data)
-        self._keep = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        pre = getattr(self, "_pre", None)
+        if pre is not None and pre[0] == data:
+            self._keep = pre[1]              # the buffer already on its way
+        else:
+            self._keep = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        self._pre = None
         prm = L.UnpackParams(pool_mode, int(unmapped_visible), int(want_aux), int(want_stats), int(n_targets), int(last),
                              int(cut_mapped), 0)
         self.ctx.check(self.ctx.lib.msx_unpack_enqueue(self.ctx.h, self.h, self._keep, len(data), C.byref(prm)))

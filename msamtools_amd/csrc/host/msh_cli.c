@@ -660,6 +660,19 @@ static int pq_pop(pq *q) {
 	return v;
 }
 
+#define PQ_NONE (-2)                    /* pq_try_pop: the queue is empty */
+static int pq_try_pop(pq *q) {
+	int v = PQ_NONE, i;
+	pthread_mutex_lock(&q->mu);
+	if (q->n > 0) {
+		v = q->item[0];
+		for (i = 1; i < q->n; i++) q->item[i - 1] = q->item[i];
+		q->n--;
+	}
+	pthread_mutex_unlock(&q->mu);
+	return v;
+}
+
 typedef struct {
 	rbatch b;                  /* fixed-capacity SoA (page-locked by the device stage) + rec_off; b.base = ubuf */
 	uint8_t *ubuf;             /* inflated BAM bytes of this batch */
@@ -1606,6 +1619,7 @@ static void *filter_dev_thread(void *arg) {
 	pipe_t *P = F->P;
 	msx_stage *stage = NULL;
 	msx_unpack *unpack = NULL;
+	int pending = PQ_NONE;             /* a slot taken off the queue ahead of its turn (its bytes are being sent up) */
 	{
 		double t0 = now_s();
 		/* HIP start-up runs beside the decoding of the first batch.  Should it fail, the input's own faults are
@@ -1625,12 +1639,13 @@ static void *filter_dev_thread(void *arg) {
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
-		const int si = pq_pop(&P->q_dev);
+		const int si = pending != PQ_NONE ? pending : pq_pop(&P->q_dev);
 		pslot *s;
 		rbatch *b;
 		msx_batch hb, db;
 		msx_filter_out fo;
 		msx_filter_status st;
+		pending = PQ_NONE;
 		t1 = now_s();
 		D->t_wait += t1 - t0;
 		if (si == PQ_END) break;
@@ -1649,6 +1664,15 @@ static void *filter_dev_thread(void *arg) {
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
 			MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, &up));
 			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+			/* the next batch, if it is decoded already, starts its way up now -- behind the bytes this batch carried
+			 * over -- and travels while this one is filtered and its output gathered and fetched */
+			if (F->n_dev == 1) {
+				pending = pq_try_pop(&P->q_dev);
+				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed) {
+					pin_wait(P, &P->slot[pending]);
+					MSX(msx_unpack_prefetch(g_ctx, unpack, P->slot[pending].rbuf, P->slot[pending].rlen));
+				}
+			}
 			D->t_upload += now_s() - t1; t1 = now_s();
 			b->n = (size_t)ur.n_records;
 			s->n_emit = 0;

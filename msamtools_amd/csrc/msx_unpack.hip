@@ -55,6 +55,11 @@ struct msx_unpack {
 	msx_unpack_params prm = {};
 	int64_t n_total = 0, n_batch = 0, n_groups = 0;
 	bool enqueued = false;
+	// msx_unpack_prefetch: the next batch's bytes on their way up (a stream of its own) while the current batch is filtered
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t copy_done = nullptr;
+	const uint8_t *pre_host = nullptr;
+	size_t pre_n = 0;
 };
 
 // (global memory takes unaligned dword / qword loads on this target: one instruction instead of four byte loads)
@@ -520,6 +525,11 @@ extern "C" int msx_unpack_create(msx_ctx *ctx, msx_unpack **out) {
 	}
 	(void)hipMemsetAsync(u->prev_name, 0, 256, ctx->stream);
 	(void)hipMemsetAsync(u->d_state, 0, sizeof(up_state), ctx->stream);
+	if (hipStreamCreateWithFlags(&u->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&u->copy_done, hipEventDisableTiming) != hipSuccess) {
+		msx_unpack_destroy(ctx, u);
+		return msx_fail(ctx, MSX_ERR_HIP, "msx_unpack_create: stream setup failed");
+	}
 	*out = u;
 	return MSX_OK;
 }
@@ -532,6 +542,8 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
 	                   &u->out_off, &u->out};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
+	if (u->copy_done) (void)hipEventDestroy(u->copy_done);
 	if (u->prev_name) (void)hipFree(u->prev_name);
 	if (u->d_state) (void)hipFree(u->d_state);
 	if (u->h_state) (void)hipHostFree(u->h_state);
@@ -574,6 +586,25 @@ extern "C" int msx_unpack_seed(msx_ctx *ctx, msx_unpack *u, const uint8_t *carry
 
 #define UP_RES(field, bytes) if ((rc = msx_reserve(ctx, &u->field, (bytes)))) return rc
 
+// The bytes of the NEXT msx_unpack_enqueue, sent ahead on a stream of their own: called after msx_unpack_finish of the
+// current batch (the carry's length is known then), they travel while the current batch is filtered and its output is
+// gathered and downloaded.  The following msx_unpack_enqueue must name the same bytes.
+extern "C" int msx_unpack_prefetch(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n_new) {
+	if (!ctx || !u || (!host_bytes && n_new)) return MSX_ERR_ARG;
+	if (u->enqueued) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_prefetch between msx_unpack_enqueue and msx_unpack_finish");
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t n = u->carry_len + n_new;
+	if (n > 0xfffffff0ull - 64 || n_new == 0) return MSX_OK;             // (msx_unpack_enqueue will say so / nothing to send)
+	int rc;
+	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;
+	MSX_HIP(ctx, hipMemcpyAsync((uint8_t *)u->raw[u->cur].p + u->carry_len, host_bytes, n_new, hipMemcpyHostToDevice, u->copy_stream));
+	MSX_HIP(ctx, hipEventRecord(u->copy_done, u->copy_stream));
+	u->pre_host = host_bytes;
+	u->pre_n = n_new;
+	return MSX_OK;
+}
+
 extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n_new, const msx_unpack_params *prm) {
 	if (!ctx || !u || !prm || (!host_bytes && n_new)) return MSX_ERR_ARG;
 	msx_join(ctx);
@@ -581,9 +612,17 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 	const size_t n = u->carry_len + n_new;
 	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue: more than 4 GiB in one batch");
 	int rc;
+	const bool sent = u->pre_n != 0 && u->pre_host == host_bytes && u->pre_n == n_new;
+	if (u->pre_n != 0 && !sent) {
+		MSX_HIP(ctx, hipStreamSynchronize(u->copy_stream));
+		u->pre_n = 0;
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue: other bytes than msx_unpack_prefetch sent ahead");
+	}
+	u->pre_n = 0;
 	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;     // (a corrupt record's name length may point 255 bytes past the data)
 	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
-	if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, host_bytes, n_new, hipMemcpyHostToDevice, ctx->stream));
+	if (sent) MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->copy_done, 0));
+	else if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, host_bytes, n_new, hipMemcpyHostToDevice, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(raw + n, 0, 64, ctx->stream));
 	u->n_bytes = n;
 	u->prm = *prm;

@@ -51,7 +51,7 @@ def offsets_of(stream):
     return np.asarray(off, dtype=np.int64)
 
 
-def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False, want_stats=True):
+def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False, want_stats=True, prefetch=False):
     """feeds the stream in chunks, checks every batch against `rec`; returns the list of (first record, n, groups)"""
     import msamtools_amd as m
     pools = {0: None, 1: m.filter_pools(rec), 2: m.profile_pools(rec)}[pool_mode]
@@ -68,6 +68,8 @@ def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False
             last = pos >= len(stream)
             up.enqueue(chunk, pool_mode=pool_mode, n_targets=n_ref, last=last, cut_mapped=cut_mapped, want_stats=want_stats)
             res, view = up.finish()
+            if prefetch and not last:        # the next chunk goes up while this batch is looked at
+                up.prefetch(stream[pos:pos + chunk_sizes[k % len(chunk_sizes)]])
             fed += len(chunk)
             n = int(res.n_records)
             # the batch covers whole records from where the previous one ended, and the carry is the rest of what was fed
@@ -126,6 +128,20 @@ def test_synthetic_stream_in_ragged_chunks(ctx, synth, pool_mode):
     stream, n_ref, rec = synth
     batches = run_chunks(ctx, stream, n_ref, rec, [3_000_001, 777_777, 5_000_000, 123_456, 64], pool_mode)
     assert len(batches) >= 8
+
+
+def test_prefetched_chunks(ctx, synth):
+    """msx_unpack_prefetch: the next chunk's bytes sent ahead on the copy stream, behind the carry"""
+    stream, n_ref, rec = synth
+    batches = run_chunks(ctx, stream, n_ref, rec, [3_000_001, 777_777, 5_000_000, 123_456], 1, prefetch=True)
+    assert len(batches) >= 8
+    import msamtools_amd as m
+    up = m.Unpack(ctx)
+    up.seed()
+    up.prefetch(stream[:1000])
+    with pytest.raises(m.MsxError, match="other bytes"):
+        up.enqueue(stream[:2000], pool_mode=1, n_targets=n_ref)
+    up.close()
 
 
 def test_whole_stream_at_once_and_tiny_chunks(ctx, synth):
