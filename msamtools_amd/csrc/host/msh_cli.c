@@ -1620,6 +1620,7 @@ static void *filter_dev_thread(void *arg) {
 	msx_stage *stage = NULL;
 	msx_unpack *unpack = NULL;
 	int pending = PQ_NONE;             /* a slot taken off the queue ahead of its turn (its bytes are being sent up) */
+	const int prefetch_on = getenv("MSX_PREFETCH") != NULL;
 	{
 		double t0 = now_s();
 		/* HIP start-up runs beside the decoding of the first batch.  Should it fail, the input's own faults are
@@ -1664,9 +1665,12 @@ static void *filter_dev_thread(void *arg) {
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
 			MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, &up));
 			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
-			/* the next batch, if it is decoded already, starts its way up now -- behind the bytes this batch carried
-			 * over -- and travels while this one is filtered and its output gathered and fetched */
-			if (F->n_dev == 1) {
+			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
+			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
+			 * default: measured, it changes nothing (upload 0.35-0.40 s of the 100 M-record run either way) -- uploads
+			 * and downloads that run at once slow each other down (scripts/micro/pcie_rate.hip: 57 GB/s one way, 16 GB/s
+			 * each when both directions are busy) and the download is what the upload would hide behind. */
+			if (F->n_dev == 1 && prefetch_on) {
 				pending = pq_try_pop(&P->q_dev);
 				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed) {
 					pin_wait(P, &P->slot[pending]);
