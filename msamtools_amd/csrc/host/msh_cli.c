@@ -1667,9 +1667,11 @@ static void *filter_dev_thread(void *arg) {
 			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
 			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
 			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
-			 * default: measured, it changes nothing (upload 0.35-0.40 s of the 100 M-record run either way) -- uploads
-			 * and downloads that run at once slow each other down (scripts/micro/pcie_rate.hip: 57 GB/s one way, 16 GB/s
-			 * each when both directions are busy) and the download is what the upload would hide behind. */
+			 * default: measured, it changes nothing (upload phase 0.35-0.40 s of the 100 M-record run either way).  The
+			 * copies are not what that phase spends its time on (rocprofv3: 2.3 ms of upload per 130 MB batch at 56 GB/s,
+			 * 48 GB/s each way when both directions are busy -- scripts/micro/pcie_rate.hip -- in a phase of 6.5 ms):
+			 * the device thread synchronises five times per batch and has to be scheduled again each time on a host whose
+			 * granted CPUs are all busy inflating. */
 			if (F->n_dev == 1 && prefetch_on) {
 				pending = pq_try_pop(&P->q_dev);
 				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed) {
