@@ -693,6 +693,8 @@ typedef struct {
 	int pin_ready;             /* rbuf is page-locked and obuf allocated (pin_mu) */
 	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit), page-locked */
 	size_t ocap, olen;
+	int fatal;                 /* the batch holds a record the reference dies at: fatal_msg, after the pools before it */
+	char fatal_msg[512];
 } pslot;
 
 typedef struct {
@@ -1613,6 +1615,23 @@ static void filter_open_output(fshared *F, const rbatch *first) {
 	free(htext.s);
 }
 
+/* A record the reference's loop dies at (no MD and no NM where statistics are needed: msam_filter.c:150-152; a
+ * participating record without AS: :219-221).  The reference has by then written every pool it had completed; the batch
+ * API reports the error for the whole batch.  So the batch is filtered once more, cut in front of the pool that holds the
+ * offending record, that output goes to the writer, and the writer -- when it reaches this batch, every earlier one
+ * written -- dies with the reference's message.  (Not reproduced: a paired pool whose READ1 pass the reference had
+ * already written when its READ2 pass met the record without AS.)
+ * Returns the number of records in front of the offending pool, *g = the number of pools. */
+static int64_t fatal_prefix(const uint32_t *group_off, int64_t n_groups, int64_t err_record, int64_t *g) {
+	int64_t lo = 0, hi = n_groups;            /* the last pool that starts at or before err_record */
+	while (lo + 1 < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if ((int64_t)group_off[mid] <= err_record) lo = mid; else hi = mid;
+	}
+	*g = lo;
+	return (int64_t)group_off[lo];
+}
+
 static void *filter_dev_thread(void *arg) {
 	fdev_t *D = (fdev_t *)arg;
 	fshared *F = D->S;
@@ -1652,6 +1671,7 @@ static void *filter_dev_thread(void *arg) {
 		if (si == PQ_END) break;
 		s = &P->slot[si];
 		b = &s->b;
+		s->fatal = 0;
 		if (s->raw) {
 			/* the record walk on the device: inflated bytes up, filter's output records back */
 			msx_unpack_params up;
@@ -1687,7 +1707,23 @@ static void *filter_dev_thread(void *arg) {
 				MSX(msx_stage_outputs(g_ctx, stage, ur.n_records, 0, &fo));
 				if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
 				else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
-				if (msx_filter_finish(g_ctx, &st) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+				if (msx_filter_finish(g_ctx, &st) != MSX_OK) {
+					s->fatal = 1;
+					snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
+					st.n_emit = 0;
+					if (P->mode == 1 && st.err_record >= 0 && ur.n_groups > 0) {
+						uint32_t *go = (uint32_t *)xmalloc(((size_t)ur.n_groups + 1) * 4);
+						int64_t g = 0, npre;
+						MSX(msx_dev_to_host(g_ctx, go, db.group_off, ((size_t)ur.n_groups + 1) * 4));
+						npre = fatal_prefix(go, ur.n_groups, st.err_record, &g);
+						free(go);
+						if (npre > 0) {
+							db.n_records = npre; db.n_groups = g;
+							MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
+							if (msx_filter_finish(g_ctx, &st) != MSX_OK) st.n_emit = 0;
+						}
+					}
+				}
 				D->t_gpu += now_s() - t1; t1 = now_s();
 				s->n_emit = st.n_emit;
 				if ((size_t)ur.bytes_consumed + 64 > s->ocap) {
@@ -1712,7 +1748,20 @@ static void *filter_dev_thread(void *arg) {
 		D->t_upload += now_s() - t1; t1 = now_s();
 		if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
 		else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
-		if (msx_filter_finish(g_ctx, &st) != MSX_OK) mDie("%s", msx_last_error(g_ctx));   /* the reference's own mDie texts */
+		if (msx_filter_finish(g_ctx, &st) != MSX_OK) {          /* the reference's own mDie texts; see fatal_prefix */
+			s->fatal = 1;
+			snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
+			st.n_emit = 0;
+			if (P->mode == 1 && st.err_record >= 0 && b->n_groups > 0) {
+				int64_t g = 0;
+				const int64_t npre = fatal_prefix(b->group_off, (int64_t)b->n_groups, st.err_record, &g);
+				if (npre > 0) {
+					db.n_records = npre; db.n_groups = g;
+					MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
+					if (msx_filter_finish(g_ctx, &st) != MSX_OK) st.n_emit = 0;
+				}
+			}
+		}
 		D->t_gpu += now_s() - t1; t1 = now_s();
 		s->n_emit = st.n_emit;
 		MSX(msx_dev_to_host(g_ctx, s->emit, fo.emit_idx, 4 * (size_t)st.n_emit));
@@ -1876,6 +1925,10 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 			RJ.pass = 1;
 			msh_parallel(msh_threads(), rescore_worker, &RJ);
 			msh_write_many(F.out, RJ.blob, RJ.off, ident, n);
+		}
+		if (s->fatal) {                      /* every earlier batch and the pools in front of the record are written */
+			msh_out_drain(F.out);
+			mDie("%s", s->fatal_msg);
 		}
 		n_batches++;
 		seq++;

@@ -1904,6 +1904,14 @@ void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n) {
 	}
 }
 
+/* everything handed over so far is in the descriptor; the open block is NOT written (a fatal error follows: the
+ * reference dies with its last buffer unwritten too) */
+void msh_out_drain(msh_out *o) {
+	if (!o) return;
+	writer_drain(o);
+	fflush(o->fp);
+}
+
 void msh_out_close(msh_out *o) {
 	if (!o) return;
 	if (o->mode == MSH_OUT_BAM || o->mode == MSH_OUT_UBAM) {

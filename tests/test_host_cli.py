@@ -510,9 +510,10 @@ def test_cli_profile_over_a_one_rank_communicator(tmp_path, synth_bams):
 @pytest.mark.gpu
 def test_cli_fatal_record_leaves_no_partial_batch(tmp_path):
     """A record with neither MD nor NM is fatal for -p (msam_filter.c:150-152).  The reference dies AT that
-    record, after having written the pools before it; here the error is reported for the batch the record
-    is in, so nothing of that batch is written (the stated difference).  Same message,
-    same exit status."""
+    record, after having written the pools before it.  Without best-hit selection the batches carry no filter
+    pools, the error is reported for the batch the record is in and nothing of that batch is written (DESIGN.md
+    section 1: the stated difference; with --besthit / --uniqhit the pools before the record are written, next test).
+    Same message, same exit status."""
     sam = tmp_path / "bad.sam"
     good = "r{0}\t0\tchr1\t{1}\t255\t50M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:50\tAS:i:50\n"
     with open(sam, "w") as fh:
@@ -532,6 +533,62 @@ def test_cli_fatal_record_leaves_no_partial_batch(tmp_path):
     bam.write_bytes(run(["recode", "-b", str(sam)]).stdout)
     r = run(["filter", "-p", "95", str(bam)])
     assert r.returncode == 1 and r.stdout == b"" and b"Either NM or MD must be present" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_fatal_record_after_the_pools_before_it(tmp_path, synth_bams):
+    """With best-hit pools the reference has written every pool it completed when its loop dies at a record
+    (msam_filter.c:150-152 no MD/NM, :219-221 no AS).  So does the command line: the batch is filtered again in front
+    of the offending pool, every earlier batch and those pools are written, then the reference's message, exit 1."""
+    sam = tmp_path / "bad.sam"
+    good = "r{0}\t0\tchr1\t{1}\t255\t50M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:50\tAS:i:50\n"
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:chr1\tLN:100000\n")
+        for i in range(3):
+            fh.write(good.format(i, 100 + i))
+        fh.write("r3\t0\tchr1\t200\t255\t50M\t*\t0\t0\t*\t*\tAS:i:50\n")          # no MD, no NM
+        fh.write(good.format(4, 300))
+    r = run(["filter", "-S", "-p", "95", "--besthit", str(sam)])
+    assert r.returncode == 1 and b"Either NM or MD must be present" in r.stderr
+    assert [l.split("\t")[0] for l in r.stdout.decode().split("\n") if l] == ["r0", "r1", "r2"]
+    # no AS on a participating record (the pool's writer dies): the pools before it are out
+    text = open(sam).read().replace("r3\t0\tchr1\t200\t255\t50M\t*\t0\t0\t*\t*\tAS:i:50", "r3\t0\tchr1\t200\t255\t50M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:50")
+    open(sam, "w").write(text)
+    r = run(["filter", "-S", "--besthit", str(sam)])
+    assert r.returncode == 1 and b"Required field AS not found" in r.stderr
+    assert [l.split("\t")[0] for l in r.stdout.decode().split("\n") if l] == ["r0", "r1", "r2"]
+    # many batches, the offending record late in the file: every earlier batch is written (in order), then the pools
+    # of its own batch in front of it -- device-side walk and host-side walk alike
+    src = subprocess.check_output([BIN, "recode", synth_bams["u"]]).decode().split("\n")[:-1]
+    k = next(i for i in range(len(src) * 3 // 4, len(src)) if src[i].split("\t")[0] != src[i - 1].split("\t")[0])
+    f = src[k].split("\t")
+    src[k] = "\t".join(x for x in f if not x.startswith(("MD:", "NM:")))
+    hdr = subprocess.check_output([BIN, "recode", "-h", synth_bams["u"]]).decode().split("\n")
+    hdr = [l for l in hdr if l.startswith("@")]
+    bad_sam = tmp_path / "late.sam"
+    bad_sam.write_text("\n".join(hdr + src) + "\n")
+    bad_bam = tmp_path / "late.bam"
+    bad_bam.write_bytes(run(["recode", "-u", str(bad_sam)]).stdout)
+    import oracle_lib as orc
+    _, rec = samio.read_sam(str(bad_sam))
+    want = orc.run_filter(rec, l=80, p=95, z=80, besthit=True)
+    assert want["rc"] != 0 and want["err_record"] == k
+    # what the oracle emits from the records in front of the offending one (its pool starts there: k is a name change)
+    class Cut:
+        pass
+    cut = Cut()
+    for a in ("flag", "rflags", "tid", "pos", "nm", "as_"):
+        setattr(cut, a, getattr(rec, a)[:k])
+    cut.cigar_off, cut.md_off, cut.cigar, cut.md = rec.cigar_off[:k + 1], rec.md_off[:k + 1], rec.cigar, rec.md
+    cut.qname_off, cut.qname = rec.qname_off[:k + 1], rec.qname
+    pre = orc.run_filter(cut, l=80, p=95, z=80, besthit=True)
+    assert pre["rc"] == 0
+    for env in ({}, {"MSX_HOST_UNPACK": "1"}):
+        e = dict(MSX_BATCH_BYTES="1500000", MSX_BATCH_RECORDS="110000", MSX_INFLATE_BLOCKS="8", MSX_THREADS="8", **env)
+        r = run(["filter", "-l", "80", "-p", "95", "-z", "80", "--besthit", str(bad_bam)], env=e)
+        assert r.returncode == 1 and b"Either NM or MD must be present" in r.stderr
+        got = r.stdout.decode().split("\n")[:-1]
+        assert got == [src[i] for i in pre["emit"]], (len(got), len(pre["emit"]))
 
 
 @pytest.mark.gpu
