@@ -713,7 +713,9 @@ typedef struct {
 	int pin_obuf;              /* filter: the slots also get an output buffer */
 	int pin_started;
 	msx_ctx *pin_ctx;
-	pthread_t pin_th;
+	pthread_t pin_th[PIPE_SLOTS_MAX];
+	int n_pin;
+	struct pin_arg_s { void *P; int first, step; } pin_args[PIPE_SLOTS_MAX];
 	pthread_mutex_t pin_mu;
 	pthread_cond_t pin_cv;
 	size_t n_filled;           /* batches handed on so far */
@@ -796,10 +798,11 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
  * slot -- on a thread of its own, in the order the decode stage will use the slots for raw batches (1, 2, ..., 0), so
  * that neither the first batch nor HIP start-up waits for it; the device thread waits for the one slot it is about to use. */
 static void *pin_thread(void *arg) {
-	pipe_t *P = (pipe_t *)arg;
+	struct pin_arg_s *A = (struct pin_arg_s *)arg;
+	pipe_t *P = (pipe_t *)A->P;
 	int k;
 	g_ctx = P->pin_ctx;
-	for (k = 1; k <= P->n_slots; k++) {
+	for (k = 1 + A->first; k <= P->n_slots; k += A->step) {
 		pslot *s = &P->slot[k % P->n_slots];
 		if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, s->rbuf, s->rcap));
 		if (P->pin_obuf) {
@@ -814,13 +817,25 @@ static void *pin_thread(void *arg) {
 	return NULL;
 }
 static void pin_start(pipe_t *P, int with_obuf) {
+	int t;
 	if (P->pin_started) return;
 	P->pin_started = 1;
 	P->pin_ctx = g_ctx;
 	P->pin_obuf = with_obuf;
+	P->n_pin = getenv("MSX_PIN_THREADS") ? atoi(getenv("MSX_PIN_THREADS")) : 1;
+	if (P->n_pin < 1) P->n_pin = 1;
+	if (P->n_pin > P->n_slots) P->n_pin = P->n_slots;
 	pthread_mutex_init(&P->pin_mu, NULL);
 	pthread_cond_init(&P->pin_cv, NULL);
-	if (pthread_create(&P->pin_th, NULL, pin_thread, P) != 0) mDie("pthread_create failed");
+	for (t = 0; t < P->n_pin; t++) {
+		P->pin_args[t].P = P; P->pin_args[t].first = t; P->pin_args[t].step = P->n_pin;
+		if (pthread_create(&P->pin_th[t], NULL, pin_thread, &P->pin_args[t]) != 0) mDie("pthread_create failed");
+	}
+}
+static void pin_join(pipe_t *P) {
+	int t;
+	if (!P->pin_started) return;
+	for (t = 0; t < P->n_pin; t++) pthread_join(P->pin_th[t], NULL);
 }
 static void pin_wait(pipe_t *P, pslot *s) {
 	pthread_mutex_lock(&P->pin_mu);
@@ -1579,6 +1594,7 @@ typedef struct {
 	msx_profile *prof;          /* filter --profile-out: this device's part of the sample */
 	pthread_t th;
 	double t_ctx, t_upload, t_gpu, t_fetch, t_wait;
+	size_t n_prefetched;
 } fdev_t;
 
 struct fshared {
@@ -1697,6 +1713,7 @@ static void *filter_dev_thread(void *arg) {
 				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed) {
 					pin_wait(P, &P->slot[pending]);
 					MSX(msx_unpack_prefetch(g_ctx, unpack, P->slot[pending].rbuf, P->slot[pending].rlen));
+					D->n_prefetched++;
 				}
 			}
 			D->t_upload += now_s() - t1; t1 = now_s();
@@ -1770,7 +1787,7 @@ static void *filter_dev_thread(void *arg) {
 		pq_push(&P->q_out, si);
 	}
 	MSX(msx_ctx_sync(g_ctx));
-	if (P->pin_started) pthread_join(P->pin_th, NULL);
+	pin_join(P);
 	msx_stage_destroy(g_ctx, stage);
 	msx_unpack_destroy(g_ctx, unpack);
 	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
@@ -1960,7 +1977,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		for (k = 0; k < F.n_dev; k++) {
 			t_ctx += F.dev[k].t_ctx; t_up += F.dev[k].t_upload; t_gpu += F.dev[k].t_gpu; t_fetch += F.dev[k].t_fetch; t_dw += F.dev[k].t_wait;
 		}
-		fprintf(stderr, "# batches: %zu\n", n_batches);
+		fprintf(stderr, "# batches: %zu (%zu sent ahead)\n", n_batches, F.dev[0].n_prefetched);
 		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 		        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 		fprintf(stderr, "# filter pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
@@ -2292,7 +2309,7 @@ static void *profile_dev_thread(void *arg) {
 	}
 	if (held >= 0) { MSX(msx_event_wait(g_ctx, ev[held])); pq_push(&P->q_free, held); }
 	MSX(msx_ctx_sync(g_ctx));
-	if (P->pin_started) pthread_join(P->pin_th, NULL);
+	pin_join(P);
 	msx_stage_destroy(g_ctx, stage);
 	msx_unpack_destroy(g_ctx, unpack);
 	for (q = 0; q < PIPE_SLOTS_MAX; q++) msx_event_destroy(g_ctx, ev[q]);

@@ -73,6 +73,12 @@ extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
 		int v = atoi(e);
 		if (v >= 1 && v <= 64) ctx->blocks_per_cu = v;
 	}
+	if (const char *e = getenv("MSX_SCHED")) {       // how the host waits for the device: spin | yield | block (HIP's default: auto)
+		const unsigned f = !strcmp(e, "spin") ? hipDeviceScheduleSpin : !strcmp(e, "yield") ? hipDeviceScheduleYield
+		                 : !strcmp(e, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+		(void)hipSetDevice(device_id);
+		(void)hipSetDeviceFlags(f);
+	}
 	if (hipSetDevice(device_id) != hipSuccess ||
 	    hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipMalloc((void **)&ctx->d_status, sizeof(msx_dev_status)) != hipSuccess ||
