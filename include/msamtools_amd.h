@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSX_ABI_VERSION 3
+#define MSX_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSX_OK              0
@@ -46,6 +46,7 @@ extern "C" {
 #define MSX_ERR_NOMEM     (-12) /* device or host allocation failed              */
 #define MSX_ERR_NO_DEVICE (-13) /* no usable gfx950 device: there is NO CPU fallback */
 #define MSX_ERR_DIST      (-14) /* RCCL / rendezvous failure                      */
+#define MSX_ERR_INFLATE   (-15) /* a BGZF block the device inflater refused: inflate the batch on the host */
 
 /* ---- per-record aux presence bits (msx_batch.rflags) --------------------- */
 #define MSX_HAS_MD 1u   /* bam_aux_get(b,"MD") != NULL (msam_filter.c:146)      */
@@ -249,6 +250,32 @@ int  msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, i
                      size_t host_cap, int64_t *n_bytes);
 /* record offsets of the last batch, u32[n + 1] relative to its first byte (tests, SAM-text writers) */
 int  msx_unpack_offsets(msx_ctx *ctx, msx_unpack *u, uint32_t *host, int64_t n);
+
+/* ---- BGZF inflate on the device ------------------------------------------------------
+ *
+ * mSamRead (msam_helper.c:246-268) reads through htslib's BGZF layer (sam_read1 -> bgzf_read ->
+ * inflate of one <= 64 KB raw DEFLATE stream per block, CRC-32 and ISIZE in the trailer).  Blocks are
+ * independent: the host only walks the block headers (BSIZE chain) and hands the compressed payloads
+ * over as they are; one wave per block inflates them and a second kernel checks every CRC-32.
+ * A block the device does not vouch for (status != 0: a code without a table entry, a distance before
+ * the start of the block, lengths that do not add up, CRC mismatch) is the caller's to inflate again
+ * on the host, whose decoder produces the diagnostics. */
+typedef struct msx_bgzf_block {
+	uint64_t in_off;           /* first byte of the block's DEFLATE stream in the compressed buffer      */
+	uint64_t out_off;          /* where its bytes go in the output buffer (running sum of out_len)        */
+	uint32_t in_len;           /* BSIZE + 1 - 12 - XLEN - 8                                               */
+	uint32_t out_len;          /* ISIZE (<= 65536)                                                        */
+	uint32_t crc32;            /* of the inflated bytes (trailer)                                         */
+	uint32_t reserved_;
+} msx_bgzf_block;
+/* device pointers throughout; d_status: u32[n_blocks]; waits for the result and reports how many blocks were refused */
+int  msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks,
+                      int64_t n_blocks, void *d_out, uint32_t *d_status, int64_t *n_refused);
+/* msx_unpack_enqueue with the batch's new bytes still compressed (host pointers: the payloads, back to back or not,
+ * and their table; out_off counts from the batch's first NEW byte).  msx_unpack_finish returns MSX_ERR_INFLATE if a
+ * block was refused: nothing has been consumed then, and the same batch can be handed to msx_unpack_enqueue inflated. */
+int  msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
+                             const msx_bgzf_block *host_blocks, int64_t n_blocks, const msx_unpack_params *prm);
 
 /* ---- filter: replaces mFilterFileWrapper/mFilterFile + writers ----------- */
 

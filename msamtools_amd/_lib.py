@@ -66,6 +66,11 @@ class UnpackParams(C.Structure):
                                          "cut_mapped", "reserved_")]
 
 
+class BgzfBlock(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("out_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32),
+                ("crc32", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
 class UnpackResult(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_records", "n_groups", "bytes_consumed", "carry_bytes", "bad_guesses")]
 
@@ -113,6 +118,8 @@ SYMBOLS = {
     "msx_unpack_prefetch": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msx_unpack_emit": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_int64)]),
     "msx_unpack_offsets": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "msx_bgzf_inflate": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int64, _P, _P, _P]),
+    "msx_unpack_enqueue_bgzf": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_int64, _P]),
     "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),
     "msx_filter_finish": (C.c_int, [_P, C.POINTER(FilterStatus)]),
     "msx_aln_stats": (C.c_int, [_P, C.POINTER(Batch), _P, _P, _P, _P, _P]),

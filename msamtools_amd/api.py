@@ -298,6 +298,48 @@ class HostSynth:
             pass
 
 
+def bgzf_blocks(payloads, datas=None, crcs=None, gap=0):
+    """(compressed buffer, BgzfBlock array, total inflated length) for raw DEFLATE payloads laid out back to back
+    (`gap` bytes of filler between them); out_len / crc32 from `datas` (the expected bytes) unless given"""
+    import zlib
+    n = len(payloads)
+    arr = (L.BgzfBlock * max(n, 1))()
+    comp = bytearray()
+    uo = 0
+    for i, pl in enumerate(payloads):
+        comp += b"\xa5" * gap
+        arr[i].in_off = len(comp)
+        arr[i].in_len = len(pl)
+        arr[i].out_off = uo
+        arr[i].out_len = len(datas[i])
+        arr[i].crc32 = (crcs[i] if crcs is not None else zlib.crc32(datas[i])) & 0xffffffff
+        comp += pl
+        uo += len(datas[i])
+    return bytes(comp), arr, uo
+
+
+def bgzf_inflate(ctx, comp, blocks, n_blocks, total_out):
+    """msx_bgzf_inflate on host data: (output bytes, status u32[n_blocks], blocks refused)"""
+    comp = bytes(comp)
+    d_comp = ctx.alloc(len(comp) + 16)
+    d_blk = ctx.alloc(C.sizeof(L.BgzfBlock) * max(n_blocks, 1))
+    d_out = ctx.alloc(total_out + 64)
+    d_st = ctx.alloc(4 * max(n_blocks, 1))
+    try:
+        ctx.to_dev(d_comp, np.frombuffer(comp + b"\0" * 16, np.uint8))
+        ctx.to_dev(d_blk, np.frombuffer(bytes(blocks), np.uint8))
+        ctx.zero(d_out, total_out + 64)
+        refused = C.c_int64(-1)
+        ctx.check(ctx.lib.msx_bgzf_inflate(ctx.h, C.c_void_p(d_comp), len(comp), C.c_void_p(d_blk), n_blocks,
+                                           C.c_void_p(d_out), C.c_void_p(d_st), C.byref(refused)))
+        out = ctx.to_host(d_out, total_out + 64, np.uint8)
+        st = ctx.to_host(d_st, max(n_blocks, 1), np.uint32)[:n_blocks]
+        return out, st, refused.value
+    finally:
+        for p in (d_comp, d_blk, d_out, d_st):
+            ctx.free(p)
+
+
 class Unpack:
     """msx_unpack: the record walk on the device (inflated BAM bytes in, msx_batch view out)."""
 

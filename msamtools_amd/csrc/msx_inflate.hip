@@ -1,0 +1,602 @@
+// msx_inflate.hip -- BGZF blocks inflated on the device.
+//
+// mSamRead (msam_helper.c:246-268) reads through htslib's BGZF layer: every 64 KB block of a BAM file is a raw DEFLATE
+// stream (RFC 1951) with its inflated length and CRC-32 in the trailer.  With the record walk on the device
+// (msx_unpack.hip) the command line was bound by inflate on the host cores; here the compressed blocks are uploaded as
+// they are (a sixth of the bytes) and inflated where their records are used.
+//
+// One wave per block.  DEFLATE is serial inside a block -- every code's position depends on the code before it -- so
+// the decode loop runs on wave-uniform values (bit buffer, table entries through readfirstlane: the scalar unit does
+// the arithmetic), and the lanes do together what can be done together: building the Huffman tables of a dynamic
+// block (code assignment by ballots, table fill one symbol per lane), copying a match (one byte per lane), staging
+// the compressed bytes into LDS a kilobyte ahead, writing the output back.  The chip runs thousands of blocks at a
+// time; what a block costs is latency, so everything the loop touches lives in LDS:
+//   ll / dt       primary decode tables indexed by the next 10 / 9 bits (bit-reversed codes); longer codes are rare
+//                 symbols and take the canonical route (limit per length, sorted symbols)
+//   in            the compressed stream, two halves of 1 KB; the half behind the read position is refilled from
+//                 registers that were loaded a kilobyte earlier
+//   ring          the last 8 KB of output.  Matches within reach (distance <= 7.5 KB -- records repeat their
+//                 neighbours) are LDS-to-LDS copies; farther ones read what has been written back to global memory
+//                 (behind a workgroup-scope fence: the wave reads its own earlier stores).  Every 2 KB the ring's new
+//                 bytes go out as aligned 16-byte vectors.
+// A block the decoder does not vouch for -- a code without a table entry, a distance before the start, lengths that
+// do not add up, a CRC mismatch -- is marked in status[] and left to the caller (the command line inflates such a
+// batch on the host, whose decoder and zlib produce the reference diagnostics).  No loop is unbounded: every
+// iteration consumes input bits, and running past the block's last bit ends the block.
+// k_bgzf_crc checks the CRC-32 of every block's output: 64 slices per block, one per lane, table-driven, joined by
+// multiplication with x^(8 * length) mod P.
+// Integer / byte work; no MFMA.
+#include "msx_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#define IF_LL_ROOT 10
+#define IF_D_ROOT 9
+#define IF_RING 8192u
+#define IF_RMASK (IF_RING - 1u)
+#define IF_FLUSH 2048u
+#define IF_NEAR (IF_RING - 512u)
+#define IF_IN_DW 512u
+#define IF_IN_HALF 256u
+
+// table entry: bits 0-3 code length, 4-7 kind, 8-11 extra bits, 16-31 payload (literal / base)
+#define IF_LIT 1u
+#define IF_BASE 2u
+#define IF_EOB 3u
+#define IF_LONG 4u
+
+// status of a block
+#define IF_OK 0u
+#define IF_BAD_TYPE 1u
+#define IF_BAD_CODE 2u
+#define IF_BAD_DIST 3u
+#define IF_OUT_OVER 4u
+#define IF_IN_OVER 5u
+#define IF_LEN_MISMATCH 6u
+#define IF_BAD_STORED 7u
+#define IF_BAD_CRC 8u
+#define IF_BAD_LENS 9u
+
+struct IfShared {
+	uint32_t ll[1 << IF_LL_ROOT];
+	uint32_t dt[1 << IF_D_ROOT];
+	uint32_t in[IF_IN_DW];
+	__attribute__((aligned(16))) uint8_t ring[IF_RING];
+	uint32_t pre[128];                 // the code-length code: 7 bits
+	uint32_t lim[2][16], first[2][16]; // per code length, left-aligned to 15 bits: end and start of its codes
+	uint16_t off[2][16];               // first place of a length's symbols in sorted[]
+	uint16_t sorted[2][320];
+	uint8_t lens[352];
+	uint8_t pl[32];
+};
+
+#define IFU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+
+// the order in which a dynamic block sends the lengths of its code-length code (RFC 1951, 3.2.7), five bits each
+constexpr uint64_t if_pack_order(int from, int to) {
+	constexpr int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+	uint64_t v = 0;
+	for (int i = from; i < to; i++) v |= (uint64_t)order[i] << (5 * (i - from));
+	return v;
+}
+#define IF_ORDER_LO if_pack_order(0, 12)
+#define IF_ORDER_HI if_pack_order(12, 19)
+
+__device__ __forceinline__ uint32_t if_ll_entry(uint32_t sym) {
+	if (sym < 256u) return (IF_LIT << 4) | (sym << 16);
+	if (sym == 256u) return IF_EOB << 4;
+	if (sym > 285u) return 0u;
+	const uint32_t c = sym - 257u;
+	if (c < 8u) return (IF_BASE << 4) | ((3u + c) << 16);
+	if (c == 28u) return (IF_BASE << 4) | (258u << 16);
+	const uint32_t ex = (c >> 2) - 1u;
+	return (IF_BASE << 4) | (ex << 8) | ((3u + ((4u + (c & 3u)) << ex)) << 16);
+}
+__device__ __forceinline__ uint32_t if_d_entry(uint32_t sym) {
+	if (sym > 29u) return 0u;
+	if (sym < 4u) return (IF_BASE << 4) | ((1u + sym) << 16);
+	const uint32_t ex = (sym >> 1) - 1u;
+	return (IF_BASE << 4) | (ex << 8) | ((1u + ((2u + (sym & 1u)) << ex)) << 16);
+}
+
+// the state of one block's decoder: wave-uniform
+struct IfState {
+	uint64_t buf;
+	int32_t cnt;
+	uint32_t ip;          // next dword of the stream (index from the aligned base)
+	uint32_t cross;       // dword index at which the next half of `in` is refilled
+	uint32_t pos, flushed;
+	uint32_t status;
+};
+
+struct IfIn {
+	const uint32_t *g;    // aligned base of the stream
+	uint32_t n_bytes;     // bytes that may be read from g
+	uint4 ahead;          // this lane's 16 bytes of the chunk after the two staged ones
+};
+
+// word d of the stream where the buffer ends inside or in front of it
+__device__ __forceinline__ uint32_t if_edge_word(const IfIn &I, uint32_t d) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
+	uint32_t v = 0u;
+	for (uint32_t k = 0; k < 4u; k++)
+		if (4u * d + k < I.n_bytes) v |= (uint32_t)p[4u * d + k] << (8u * k);
+	return v;
+}
+__device__ __forceinline__ uint4 if_load_chunk(const IfIn &I, uint32_t chunk, uint32_t lane) {
+	const uint32_t d = chunk * IF_IN_HALF + lane * 4u;
+	uint4 v;
+	if (4u * d + 16u <= I.n_bytes) {
+		v = *reinterpret_cast<const uint4 *>(I.g + d);
+	} else {
+		v.x = if_edge_word(I, d);
+		v.y = if_edge_word(I, d + 1u);
+		v.z = if_edge_word(I, d + 2u);
+		v.w = if_edge_word(I, d + 3u);
+	}
+	return v;
+}
+__device__ __forceinline__ void if_store_chunk(IfShared &S, uint32_t chunk, uint32_t lane, const uint4 &v) {
+	*reinterpret_cast<uint4 *>(&S.in[(chunk & 1u) * IF_IN_HALF + lane * 4u]) = v;
+}
+
+// (re)position the reader at byte `byte_off` of the stream
+__device__ __forceinline__ void if_seek(IfShared &S, IfState &T, IfIn &I, uint32_t byte_off, uint32_t lane) {
+	const uint32_t dw = byte_off >> 2;
+	const uint32_t c0 = dw / IF_IN_HALF;
+	if_store_chunk(S, c0, lane, if_load_chunk(I, c0, lane));
+	if_store_chunk(S, c0 + 1u, lane, if_load_chunk(I, c0 + 1u, lane));
+	I.ahead = if_load_chunk(I, c0 + 2u, lane);
+	T.cross = (c0 + 1u) * IF_IN_HALF;
+	T.ip = dw;
+	T.buf = 0;
+	T.cnt = 0;
+	// two words, then the bytes in front of byte_off go
+	T.buf = (uint64_t)IFU(S.in[T.ip & (IF_IN_DW - 1u)]);
+	T.ip++;
+	if (T.ip == T.cross) {       // (dw was the last word of its chunk)
+		if_store_chunk(S, (T.ip / IF_IN_HALF) + 1u, lane, I.ahead);
+		I.ahead = if_load_chunk(I, (T.ip / IF_IN_HALF) + 2u, lane);
+		T.cross += IF_IN_HALF;
+	}
+	T.buf |= (uint64_t)IFU(S.in[T.ip & (IF_IN_DW - 1u)]) << 32;
+	T.ip++;
+	T.cnt = 64;
+	const uint32_t skip = (byte_off & 3u) * 8u;
+	T.buf >>= skip;
+	T.cnt -= (int32_t)skip;
+}
+
+__device__ __forceinline__ void if_refill(IfShared &S, IfState &T, IfIn &I, uint32_t lane) {
+	if (T.cnt <= 32) {
+		if (T.ip == T.cross) {
+			// the chunk behind the read position is done with: the chunk two ahead takes its half, the one three ahead
+			// starts travelling
+			const uint32_t k = T.ip / IF_IN_HALF;
+			if_store_chunk(S, k + 1u, lane, I.ahead);
+			I.ahead = if_load_chunk(I, k + 2u, lane);
+			T.cross += IF_IN_HALF;
+		}
+		T.buf |= (uint64_t)IFU(S.in[T.ip & (IF_IN_DW - 1u)]) << T.cnt;
+		T.cnt += 32;
+		T.ip++;
+	}
+}
+#define IF_PEEK(T, n) ((uint32_t)((T).buf & ((1ull << (n)) - 1ull)))
+#define IF_DROP(T, n) do { (T).buf >>= (n); (T).cnt -= (int32_t)(n); } while (0)
+// bits of the stream consumed so far (from the aligned base)
+#define IF_BITPOS(T) ((uint64_t)(T).ip * 32ull - (uint64_t)(T).cnt)
+
+// write the ring's bytes [T.flushed, upto) of the output back.  Ring index and global address agree modulo 16.
+__device__ __forceinline__ void if_flush(IfShared &S, IfState &T, uint8_t *og, uint32_t upto, uint32_t lane) {
+	const uintptr_t base = (uintptr_t)og & ~(uintptr_t)15;          // ring index 0 modulo IF_RING
+	const uintptr_t lo = (uintptr_t)og + T.flushed, hi = (uintptr_t)og + upto;
+	const uintptr_t a = lo & ~(uintptr_t)15;
+	for (uintptr_t va = a + 16u * lane; va < hi; va += 16u * 64u) {
+		const uint32_t ri = (uint32_t)(va - base) & IF_RMASK;
+		if (va >= lo && va + 16u <= hi) {
+			*reinterpret_cast<uint4 *>(va) = *reinterpret_cast<const uint4 *>(&S.ring[ri]);
+		} else {
+			for (uint32_t k = 0; k < 16u; k++)
+				if (va + k >= lo && va + k < hi) *reinterpret_cast<uint8_t *>(va + k) = S.ring[ri + k];
+		}
+	}
+	T.flushed = upto;
+}
+
+// Canonical Huffman code of S.lens[base, base + nsym) into a primary table of `root` bits and the per-length arrays
+// of the canonical route.  which: 0 literal/length, 1 distance.  Returns 0 if the lengths are refused.
+__device__ __forceinline__ uint32_t if_build(IfShared &S, uint32_t which, uint32_t base, uint32_t nsym, uint32_t lane) {
+	uint32_t *tab = which ? S.dt : S.ll;
+	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
+	const uint32_t tsize = 1u << root;
+	for (uint32_t k = lane; k < tsize; k += 64u) tab[k] = 0u;
+	uint32_t L[5], code[5];
+#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const uint32_t s = lane + 64u * j;
+		L[j] = s < nsym ? (uint32_t)S.lens[base + s] : 0u;
+		code[j] = 0u;
+	}
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	uint32_t nxt = 0u, offs = 0u, n_codes = 0u;
+	int32_t left = 1;
+	for (uint32_t len = 1; len <= 15u; len++) {
+		uint32_t cnt = 0u;
+#pragma unroll
+		for (int j = 0; j < 5; j++) {
+			const unsigned long long b = __ballot(L[j] == len);
+			if (L[j] == len) code[j] = nxt + cnt + (uint32_t)__popcll(b & lt);
+			cnt += (uint32_t)__popcll(b);
+		}
+		left = left * 2 - (int32_t)cnt;
+		if (left < 0) return 0u;
+		if (lane == 0) {
+			S.first[which][len] = nxt << (15u - len);
+			S.lim[which][len] = (nxt + cnt) << (15u - len);
+			S.off[which][len] = (uint16_t)offs;
+		}
+		// sorted[]: the symbols of this length in symbol order
+#pragma unroll
+		for (int j = 0; j < 5; j++)
+			if (L[j] == len) S.sorted[which][offs + (code[j] - nxt)] = (uint16_t)(lane + 64u * j);
+		offs += cnt;
+		n_codes += cnt;
+		nxt = (nxt + cnt) << 1;
+	}
+	if (left > 0 && !(which == 1u && n_codes <= 1u)) return 0u;   // incomplete: only a distance code of one symbol (or none) is
+#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const uint32_t s = lane + 64u * j, l = L[j];
+		if (l == 0u) continue;
+		const uint32_t rev = __brev(code[j]) >> (32u - l);
+		if (l <= root) {
+			const uint32_t e = (which ? if_d_entry(s) : if_ll_entry(s)) | l;
+			for (uint32_t k = rev; k < tsize; k += 1u << l) tab[k] = e;
+		} else {
+			tab[rev & (tsize - 1u)] = IF_LONG << 4;
+		}
+	}
+	return 1u;
+}
+
+// a code longer than the primary table's index: the canonical route.  Returns the entry (with its length), 0 if none.
+__device__ __forceinline__ uint32_t if_long(IfShared &S, uint32_t which, uint32_t bits15) {
+	const uint32_t c15 = __brev(bits15) >> 17;
+	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
+	for (uint32_t len = root + 1u; len <= 15u; len++) {
+		const uint32_t lim = IFU(S.lim[which][len]);
+		if (c15 < lim) {
+			const uint32_t first = IFU(S.first[which][len]);
+			if (c15 < first) return 0u;
+			const uint32_t sym = IFU(S.sorted[which][IFU(S.off[which][len]) + ((c15 - first) >> (15u - len))]);
+			const uint32_t e = which ? if_d_entry(sym) : if_ll_entry(sym);
+			return e ? (e | len) : 0u;
+		}
+	}
+	return 0u;
+}
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, size_t comp_len,
+                                                     const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
+	__shared__ IfShared S;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t bi = blockIdx.x;
+	if (bi >= n_blocks) return;
+	const msx_bgzf_block B = blk[bi];
+	uint8_t *og = out + B.out_off;
+	const uint32_t out_len = B.out_len;
+	if (out_len == 0u) {
+		if (lane == 0) status[bi] = IF_OK;
+		return;
+	}
+	IfIn I;
+	{
+		const uintptr_t p = (uintptr_t)(comp + B.in_off);
+		I.g = reinterpret_cast<const uint32_t *>(p & ~(uintptr_t)3);
+		const size_t from = (size_t)((const uint8_t *)I.g - comp);
+		const size_t avail = comp_len > from ? comp_len - from : 0u;
+		I.n_bytes = avail > 0xfffffff0u ? 0xfffffff0u : (uint32_t)avail;
+	}
+	const uint32_t skew = (uint32_t)((uintptr_t)(comp + B.in_off) & 3u);
+	const uint64_t end_bit = ((uint64_t)skew + B.in_len) * 8ull;
+	const uint32_t rshift = (uint32_t)((uintptr_t)og & 15u);
+	IfState T;
+	T.pos = 0u; T.flushed = 0u; T.status = IF_OK;
+	if_seek(S, T, I, skew, lane);
+#define IF_RI(q) (((q) + rshift) & IF_RMASK)
+#define IF_FAIL(code) do { T.status = (code); goto done; } while (0)
+	for (;;) {
+		if_refill(S, T, I, lane);
+		const uint32_t last = IF_PEEK(T, 1);
+		const uint32_t type = (uint32_t)(T.buf >> 1) & 3u;
+		IF_DROP(T, 3);
+		if (IF_BITPOS(T) > end_bit) IF_FAIL(IF_IN_OVER);
+		if (type == 3u) IF_FAIL(IF_BAD_TYPE);
+		if (type == 0u) {
+			// stored: to the next byte boundary, LEN, NLEN, bytes (through the ring: a later block may refer to them)
+			IF_DROP(T, (uint32_t)T.cnt & 7u);
+			if_refill(S, T, I, lane);
+			const uint32_t len = IF_PEEK(T, 16);
+			IF_DROP(T, 16);
+			const uint32_t nlen = IF_PEEK(T, 16);
+			IF_DROP(T, 16);
+			const uint64_t bp = IF_BITPOS(T) >> 3;
+			if ((len ^ 0xffffu) != nlen) IF_FAIL(IF_BAD_STORED);
+			if ((bp + len) * 8ull > end_bit) IF_FAIL(IF_IN_OVER);
+			if (len > out_len - T.pos) IF_FAIL(IF_OUT_OVER);
+			const uint8_t *src = reinterpret_cast<const uint8_t *>(I.g) + bp;
+			for (uint32_t done_b = 0; done_b < len;) {
+				const uint32_t piece = len - done_b < 1024u ? len - done_b : 1024u;
+				for (uint32_t i = lane; i < piece; i += 64u) S.ring[IF_RI(T.pos + i)] = src[done_b + i];
+				T.pos += piece;
+				done_b += piece;
+				if (T.pos - T.flushed >= IF_FLUSH) {
+					const uint32_t upto = (uint32_t)((((uintptr_t)og + T.pos) & ~(uintptr_t)15) - (uintptr_t)og);
+					if_flush(S, T, og, upto, lane);
+				}
+			}
+			if_seek(S, T, I, (uint32_t)(bp + len), lane);
+			if (last) break;
+			continue;
+		}
+		uint32_t hlit, hdist;
+		if (type == 1u) {
+			hlit = 288u; hdist = 32u;
+			for (uint32_t s = lane; s < 320u; s += 64u)
+				S.lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 5u);
+		} else {
+			hlit = IF_PEEK(T, 5) + 257u; IF_DROP(T, 5);
+			hdist = IF_PEEK(T, 5) + 1u; IF_DROP(T, 5);
+			const uint32_t hclen = IF_PEEK(T, 4) + 4u; IF_DROP(T, 4);
+			if (hlit > 286u || hdist > 30u) IF_FAIL(IF_BAD_LENS);
+			if (lane < 19u) S.pl[lane] = 0;
+			for (uint32_t i = 0; i < hclen; i++) {
+				if_refill(S, T, I, lane);
+				const uint32_t o = (uint32_t)((i < 12u ? IF_ORDER_LO >> (5u * i) : IF_ORDER_HI >> (5u * (i - 12u))) & 31ull);
+				if (lane == 0) S.pl[o] = (uint8_t)IF_PEEK(T, 3);
+				IF_DROP(T, 3);
+			}
+			if (IF_BITPOS(T) > end_bit) IF_FAIL(IF_IN_OVER);
+			// the code-length code into a direct table of 7 bits
+			{
+				const uint32_t Lp = lane < 19u ? (uint32_t)S.pl[lane] : 0u;
+				uint32_t code = 0u, nxt = 0u;
+				int32_t left = 1;
+				const unsigned long long lt = (1ull << lane) - 1ull;
+				for (uint32_t len = 1; len <= 7u; len++) {
+					const unsigned long long b = __ballot(Lp == len);
+					const uint32_t cnt = (uint32_t)__popcll(b);
+					if (Lp == len) code = nxt + (uint32_t)__popcll(b & lt);
+					left = left * 2 - (int32_t)cnt;
+					nxt = (nxt + cnt) << 1;
+					if (left < 0) break;
+				}
+				if (left != 0) IF_FAIL(IF_BAD_LENS);
+				S.pre[lane] = 0u; S.pre[lane + 64u] = 0u;
+				if (Lp) {
+					const uint32_t rev = __brev(code) >> (32u - Lp);
+					for (uint32_t k = rev; k < 128u; k += 1u << Lp) S.pre[k] = Lp | (lane << 8) | 0x10000u;
+				}
+			}
+			const uint32_t total = hlit + hdist;
+			uint32_t n = 0u, prev = 0u;
+			while (n < total) {
+				if_refill(S, T, I, lane);
+				const uint32_t e = IFU(S.pre[IF_PEEK(T, 7)]);
+				if (!e) IF_FAIL(IF_BAD_CODE);
+				IF_DROP(T, e & 0xffu);
+				const uint32_t sym = (e >> 8) & 0xffu;
+				if (sym < 16u) {
+					if (lane == 0) S.lens[n] = (uint8_t)sym;
+					prev = sym;
+					n++;
+				} else {
+					uint32_t rep, v = 0u;
+					if (sym == 16u) {
+						if (n == 0u) IF_FAIL(IF_BAD_LENS);
+						v = prev;
+						rep = 3u + IF_PEEK(T, 2); IF_DROP(T, 2);
+					} else if (sym == 17u) {
+						rep = 3u + IF_PEEK(T, 3); IF_DROP(T, 3);
+						prev = 0u;
+					} else {
+						rep = 11u + IF_PEEK(T, 7); IF_DROP(T, 7);
+						prev = 0u;
+					}
+					if (n + rep > total) IF_FAIL(IF_BAD_LENS);
+					for (uint32_t i = lane; i < rep; i += 64u) S.lens[n + i] = (uint8_t)v;
+					n += rep;
+				}
+				if (IF_BITPOS(T) > end_bit) IF_FAIL(IF_IN_OVER);
+			}
+			if (S.lens[256] == 0) IF_FAIL(IF_BAD_LENS);       // a block must be able to end
+		}
+		if (!if_build(S, 0u, 0u, hlit, lane)) IF_FAIL(IF_BAD_LENS);
+		if (!if_build(S, 1u, hlit, hdist, lane)) IF_FAIL(IF_BAD_LENS);
+		// ---- the symbols of the block ----
+		for (;;) {
+			if_refill(S, T, I, lane);
+			uint32_t e = IFU(S.ll[IF_PEEK(T, IF_LL_ROOT)]);
+			if (((e >> 4) & 15u) == IF_LONG) e = if_long(S, 0u, IF_PEEK(T, 15));
+			const uint32_t kind = (e >> 4) & 15u;
+			if (kind == 0u) IF_FAIL(IF_BAD_CODE);
+			IF_DROP(T, e & 15u);
+			if (kind == IF_LIT) {
+				if (T.pos >= out_len) IF_FAIL(IF_OUT_OVER);
+				if (lane == 0) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
+				T.pos++;
+			} else if (kind == IF_EOB) {
+				break;
+			} else {
+				const uint32_t xl = (e >> 8) & 15u;
+				const uint32_t len = (e >> 16) + IF_PEEK(T, xl);
+				IF_DROP(T, xl);
+				if_refill(S, T, I, lane);
+				uint32_t d = IFU(S.dt[IF_PEEK(T, IF_D_ROOT)]);
+				if (((d >> 4) & 15u) == IF_LONG) d = if_long(S, 1u, IF_PEEK(T, 15));
+				if (((d >> 4) & 15u) != IF_BASE) IF_FAIL(IF_BAD_CODE);
+				IF_DROP(T, d & 15u);
+				const uint32_t xd = (d >> 8) & 15u;
+				const uint32_t dist = (d >> 16) + IF_PEEK(T, xd);
+				IF_DROP(T, xd);
+				if (dist > T.pos) IF_FAIL(IF_BAD_DIST);
+				if (len > out_len - T.pos) IF_FAIL(IF_OUT_OVER);
+				const uint32_t from = T.pos - dist;
+				if (dist <= IF_NEAR) {
+					if (dist >= 64u || dist >= len) {
+						// a round's sources lie in front of the round: earlier rounds (LDS keeps a wave's order) or earlier symbols
+						for (uint32_t b = 0; b < len; b += 64u) {
+							const uint32_t i = b + lane;
+							if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + i)];
+						}
+					} else {
+						// the match overlaps itself: byte i repeats byte i mod dist
+						const float rf = 1.0f / (float)dist;
+						for (uint32_t b = 0; b < len; b += 64u) {
+							const uint32_t i = b + lane;
+							const uint32_t q = (uint32_t)(((float)i + 0.5f) * rf);
+							if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + (i - q * dist))];
+						}
+					}
+				} else {
+					// out of the ring's reach: those bytes were written back at least IF_NEAR - IF_FLUSH - 258 bytes ago
+					// (the wave waits for its own stores, then reads past the vector L1)
+					__builtin_amdgcn_s_waitcnt(0);
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+					for (uint32_t b = 0; b < len; b += 64u) {
+						const uint32_t i = b + lane;
+						if (i < len)
+							S.ring[IF_RI(T.pos + i)] = __hip_atomic_load(og + from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+				T.pos += len;
+			}
+			if (IF_BITPOS(T) > end_bit) IF_FAIL(IF_IN_OVER);
+			if (T.pos - T.flushed >= IF_FLUSH) {
+				const uint32_t upto = (uint32_t)((((uintptr_t)og + T.pos) & ~(uintptr_t)15) - (uintptr_t)og);
+				if_flush(S, T, og, upto, lane);
+			}
+		}
+		if (last) break;
+	}
+	if (T.pos != out_len) T.status = IF_LEN_MISMATCH;
+done:
+	if (T.status == IF_OK) if_flush(S, T, og, T.pos, lane);
+	if (lane == 0) status[bi] = T.status;
+#undef IF_RI
+#undef IF_FAIL
+}
+
+// ---------------------------------------------------------------------------
+// CRC-32 (the gzip polynomial, reflected) of every block's output
+// ---------------------------------------------------------------------------
+#define CRC_POLY 0xedb88320u
+// a * b mod P; bit 31 is the coefficient of x^0
+__device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
+	uint32_t r = 0u;
+	for (int k = 0; k < 32; k++) {
+		if (a & (0x80000000u >> k)) r ^= b;
+		b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+	}
+	return r;
+}
+// x^(8 n) mod P
+__device__ __forceinline__ uint32_t crc_xpow8(uint32_t n) {
+	uint32_t r = 0x80000000u, p = 0x00800000u;       // 1, x^8
+	while (n) {
+		if (n & 1u) r = crc_mul(r, p);
+		p = crc_mul(p, p);
+		n >>= 1;
+	}
+	return r;
+}
+
+__global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
+                                                 const uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                 uint32_t *__restrict__ n_bad) {
+	__shared__ uint32_t tab[256];
+	const uint32_t lane = threadIdx.x, bi = blockIdx.x;
+	if (bi >= n_blocks) return;
+	const uint32_t st = status[bi];
+	if (st != IF_OK) {
+		if (lane == 0) atomicAdd(n_bad, 1u);
+		return;
+	}
+	for (uint32_t k = lane; k < 256u; k += 64u) {
+		uint32_t c = k;
+		for (int j = 0; j < 8; j++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+		tab[k] = c;
+	}
+	__syncthreads();
+	const msx_bgzf_block B = blk[bi];
+	const uint32_t n = B.out_len;
+	if (n == 0u) {
+		if (lane == 0 && B.crc32 != 0u) { status[bi] = IF_BAD_CRC; atomicAdd(n_bad, 1u); }
+		return;
+	}
+	// 64 slices of `per` bytes, aligned to the END of the block: the slices to the right of any lane are full, so joining
+	// state(A || B) = state(A) * x^(8 |B|) + state(B) needs one multiplier per step.  The lane that holds byte 0 starts from
+	// the register's initial value (all ones); lanes in front of it hold nothing and contribute 0.
+	const uint32_t per = ((n + 63u) / 64u + 3u) & ~3u;
+	const int64_t lo_s = (int64_t)n - (int64_t)(64u - lane) * per;
+	const uint32_t lo = lo_s > 0 ? (uint32_t)lo_s : 0u;
+	const int64_t hi_s = lo_s + per;
+	const uint32_t hi = hi_s > 0 ? (uint32_t)hi_s : 0u;
+	const uint8_t *p = out + B.out_off;
+	uint32_t s = (hi > 0u && lo == 0u) ? 0xffffffffu : 0u;
+	uint32_t i = lo;
+	for (; i + 4u <= hi; i += 4u) {
+		const uint32_t w = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(p + i);
+		s = tab[(s ^ w) & 0xffu] ^ (s >> 8);
+		s = tab[(s ^ (w >> 8)) & 0xffu] ^ (s >> 8);
+		s = tab[(s ^ (w >> 16)) & 0xffu] ^ (s >> 8);
+		s = tab[(s ^ (w >> 24)) & 0xffu] ^ (s >> 8);
+	}
+	for (; i < hi; i++) s = tab[(s ^ p[i]) & 0xffu] ^ (s >> 8);
+	uint32_t X = crc_xpow8(per);
+	for (uint32_t step = 1; step < 64u; step <<= 1) {
+		const uint32_t os = (uint32_t)__shfl_down((int)s, step);
+		if ((lane & (2u * step - 1u)) == 0u) s = crc_mul(s, X) ^ os;
+		X = crc_mul(X, X);
+	}
+	if (lane == 0) {
+		const uint32_t crc = ~s;
+		if (crc != B.crc32) { status[bi] = IF_BAD_CRC; atomicAdd(n_bad, 1u); }
+	}
+}
+
+// ---------------------------------------------------------------------------
+// ABI
+// ---------------------------------------------------------------------------
+int msx_bgzf_inflate_launch(msx_ctx *ctx, const uint8_t *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks, int64_t n_blocks,
+                            uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
+	if (n_blocks <= 0) return MSX_OK;
+	hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_comp, comp_len, d_blocks,
+	                   (uint32_t)n_blocks, d_out, d_status);
+	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_blocks, (uint32_t)n_blocks,
+	                   (const uint8_t *)d_out, d_status, d_n_bad);
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks,
+                                int64_t n_blocks, void *d_out, uint32_t *d_status, int64_t *n_refused) {
+	if (!ctx || (n_blocks > 0 && (!d_comp || !d_blocks || !d_out || !d_status))) return MSX_ERR_ARG;
+	if (n_blocks < 0 || n_blocks > 0x7fffffff) return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_inflate: block count");
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	if ((rc = msx_reserve(ctx, &ctx->scan_l3, 64))) return rc;
+	uint32_t *d_bad = (uint32_t *)ctx->scan_l3.p;
+	MSX_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+	if ((rc = msx_bgzf_inflate_launch(ctx, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad)))
+		return rc;
+	uint32_t bad = 0;
+	MSX_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n_refused) *n_refused = bad;
+	return MSX_OK;
+}

@@ -117,6 +117,9 @@ void msx_lane_enter(msx_ctx *ctx, int lane);
 void msx_lane_leave(msx_ctx *ctx);
 void msx_join(msx_ctx *ctx);
 int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes);
+// msx_inflate.hip: inflate + CRC check of n_blocks BGZF blocks on ctx->stream; *d_n_bad (zeroed by the caller) counts the refused
+int msx_bgzf_inflate_launch(msx_ctx *ctx, const uint8_t *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks, int64_t n_blocks,
+                            uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad);
 extern thread_local std::string msx_tls_err;
 
 #define MSX_HIP(ctx, call)                                                              \

@@ -37,9 +37,9 @@ struct up_state {
 	uint32_t status;               // MSX_UP_* below
 	uint32_t cut_any, cut_mapped;  // last pool boundary (record index) / last one whose record is mapped, in the batch's second half
 	uint32_t n_batch, n_groups, cut_off;
+	uint32_t inflate_bad;          // msx_unpack_enqueue_bgzf: blocks the device inflater refused
 	uint32_t has_prev;             // prev_name holds the QNAME of the last naming record of earlier batches
 	uint32_t emit_bytes;
-	uint32_t pad;
 };
 #define MSX_UP_CORRUPT 1u          // block_size < 32 on the true chain, or a record whose fields do not fit its length
 
@@ -48,6 +48,8 @@ struct msx_unpack {
 	int cur = 0;
 	size_t carry_len = 0, n_bytes = 0;
 	msx_buf seg_first, seg_end, seg_cnt, seg_base;
+	msx_buf comp, blk, blk_status;  // msx_unpack_enqueue_bgzf: the compressed payloads, their table, the inflater's verdicts
+	bool bgzf = false;              // the current batch came in compressed
 	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
 	    group_off, tile_last, cigar, md, out_len, out_off, out;
 	char *prev_name = nullptr;     // device, 256 bytes
@@ -540,7 +542,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
-	                   &u->out_off, &u->out};
+	                   &u->out_off, &u->out, &u->comp, &u->blk, &u->blk_status};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
 	if (u->copy_done) (void)hipEventDestroy(u->copy_done);
@@ -605,6 +607,8 @@ extern "C" int msx_unpack_prefetch(msx_ctx *ctx, msx_unpack *u, const uint8_t *h
 	return MSX_OK;
 }
 
+static int up_enqueue_walk(msx_ctx *ctx, msx_unpack *u, size_t n, const msx_unpack_params *prm);
+
 extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n_new, const msx_unpack_params *prm) {
 	if (!ctx || !u || !prm || (!host_bytes && n_new)) return MSX_ERR_ARG;
 	msx_join(ctx);
@@ -621,15 +625,23 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 	u->pre_n = 0;
 	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;     // (a corrupt record's name length may point 255 bytes past the data)
 	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	// the state of this batch (has_prev and prev_name carry over)
+	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 4, ctx->stream));
 	if (sent) MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->copy_done, 0));
 	else if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, host_bytes, n_new, hipMemcpyHostToDevice, ctx->stream));
+	u->bgzf = false;
+	return up_enqueue_walk(ctx, u, n, prm);
+}
+
+// the batch's bytes are (or will be, in stream order) in raw[cur][0, n): find the records
+static int up_enqueue_walk(msx_ctx *ctx, msx_unpack *u, size_t n, const msx_unpack_params *prm) {
+	int rc;
+	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
 	MSX_HIP(ctx, hipMemsetAsync(raw + n, 0, 64, ctx->stream));
 	u->n_bytes = n;
 	u->prm = *prm;
 	u->enqueued = true;
-	// the state of this batch (has_prev and prev_name carry over)
-	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
-	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 8, ctx->stream));
 	const uint32_t nseg = (uint32_t)((n + UP_SEG - 1) / UP_SEG);
 	const size_t cap = n / 36 + 16;               // records: a record is at least 37 bytes with its block_size
 	UP_RES(seg_first, (size_t)(nseg + 2) * 4); UP_RES(seg_end, (size_t)(nseg + 2) * 4);
@@ -652,6 +664,43 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 	return MSX_OK;
 }
 
+// The batch's new bytes arrive compressed: BGZF payloads and their table (msx_bgzf_block, out_off from the batch's first
+// new byte).  They are inflated behind the carry, where msx_unpack_enqueue would have copied them.
+extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
+                                       const msx_bgzf_block *host_blocks, int64_t n_blocks, const msx_unpack_params *prm) {
+	if (!ctx || !u || !prm || n_blocks < 0 || (n_blocks > 0 && (!host_comp || !host_blocks))) return MSX_ERR_ARG;
+	if (u->pre_n != 0) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf after msx_unpack_prefetch");
+	if (n_blocks > (1 << 24)) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: too many blocks");
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	size_t n_new = 0;
+	for (int64_t i = 0; i < n_blocks; i++) {
+		const msx_bgzf_block &b = host_blocks[i];
+		if (b.out_off != n_new || b.out_len > 65536u || b.in_off > comp_len || b.in_len > comp_len - b.in_off)
+			return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: block %lld of the table is inconsistent", (long long)i);
+		n_new += b.out_len;
+	}
+	const size_t n = u->carry_len + n_new;
+	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: more than 4 GiB in one batch");
+	int rc;
+	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;
+	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 4, ctx->stream));
+	if (n_blocks > 0) {
+		UP_RES(comp, comp_len + 64);
+		UP_RES(blk, (size_t)n_blocks * sizeof(msx_bgzf_block));
+		UP_RES(blk_status, (size_t)n_blocks * 4);
+		MSX_HIP(ctx, hipMemcpyAsync(u->comp.p, host_comp, comp_len, hipMemcpyHostToDevice, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(u->blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, ctx->stream));
+		if ((rc = msx_bgzf_inflate_launch(ctx, (const uint8_t *)u->comp.p, comp_len, (const msx_bgzf_block *)u->blk.p, n_blocks,
+		                                  raw + u->carry_len, (uint32_t *)u->blk_status.p, &u->d_state->inflate_bad)))
+			return rc;
+	}
+	u->bgzf = true;
+	return up_enqueue_walk(ctx, u, n, prm);
+}
+
 static int up_fetch_state(msx_ctx *ctx, msx_unpack *u) {
 	MSX_HIP(ctx, hipMemcpyAsync(u->h_state, u->d_state, sizeof(up_state), hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -671,6 +720,8 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	int rc;
 	if (n > 0) {
 		if ((rc = up_fetch_state(ctx, u))) return rc;               // sync 1: how many records
+		if (u->bgzf && u->h_state->inflate_bad)                      // (nothing consumed: the carry stands where it stood)
+			return msx_fail(ctx, MSX_ERR_INFLATE, "%u BGZF block(s) of the batch refused by the device inflater", u->h_state->inflate_bad);
 		if (u->h_state->status == MSX_UP_CORRUPT) return msx_fail(ctx, MSX_ERR_ARG, "Corrupt BAM record");
 	} else {
 		memset(u->h_state, 0, sizeof(up_state));

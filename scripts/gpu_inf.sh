@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout 600 python -m pytest tests/test_gpu_inflate.py -x -q 2>&1 | tail -30

@@ -1,0 +1,141 @@
+"""BGZF inflate on the device (msx_inflate.hip) against zlib: the reference reads through htslib's BGZF layer
+(msam_helper.c:246-268); every block is one raw DEFLATE stream whose CRC-32 and length are in the trailer."""
+import zlib
+
+import numpy as np
+import pytest
+
+import msamtools_amd as m
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_at=(), flush_mode=zlib.Z_FULL_FLUSH, mem=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+    out, last = b"", 0
+    for f in flush_at:
+        out += co.compress(data[last:f]) + co.flush(flush_mode)
+        last = f
+    return out + co.compress(data[last:]) + co.flush()
+
+
+def bam_like(rng, n_bytes):
+    """records that repeat their neighbours, the way name-sorted BAM does"""
+    out = bytearray()
+    k = 0
+    while len(out) < n_bytes:
+        name = b"sim%08d" % k
+        for h in range(int(rng.integers(1, 9))):
+            core = rng.integers(0, 256, 12, dtype=np.uint8).tobytes()
+            out += (60 + len(name)).to_bytes(4, "little") + core + name + b"\0" + bytes([100 << 4 & 255, 6, 0, 0])
+            out += b"NMC" + bytes([int(rng.integers(0, 4))]) + b"ASC" + bytes([int(rng.integers(90, 101))]) + b"MDZ100\0"
+        k += 1
+    return bytes(out[:n_bytes])
+
+
+def cases():
+    rng = np.random.default_rng(20251003)
+    c = []
+    c.append(("empty", b"", {}))
+    c.append(("one byte", b"A", {}))
+    c.append(("zeros", bytes(65280), {}))
+    c.append(("ones level 1", b"\x01" * 65536, dict(level=1)))
+    for per in (2, 3, 5, 7, 16, 31, 63, 64, 65, 127, 300):
+        unit = rng.integers(0, 256, per, dtype=np.uint8).tobytes()
+        c.append((f"period {per}", (unit * (65280 // per + 1))[:65280], {}))
+    c.append(("random (stored or nearly)", rng.integers(0, 256, 65280, dtype=np.uint8).tobytes(), {}))
+    c.append(("random level 0", rng.integers(0, 256, 65280, dtype=np.uint8).tobytes(), dict(level=0)))
+    c.append(("random nibbles, huffman only", rng.integers(0, 16, 65280, dtype=np.uint8).tobytes(), dict(strategy=zlib.Z_HUFFMAN_ONLY)))
+    c.append(("skewed bytes (long codes)", (rng.geometric(0.08, 65280) % 256).astype(np.uint8).tobytes(), {}))
+    c.append(("very skewed bytes (15-bit codes)", np.minimum(rng.geometric(0.5, 65280) * 3 + rng.integers(0, 200, 65280) * (rng.random(65280) < 0.002), 255).astype(np.uint8).tobytes(), dict(strategy=zlib.Z_HUFFMAN_ONLY)))
+    for lvl in (1, 4, 6, 9):
+        c.append((f"bam-like level {lvl}", bam_like(rng, 65280), dict(level=lvl)))
+    c.append(("bam-like fixed codes", bam_like(rng, 65280), dict(strategy=zlib.Z_FIXED)))
+    c.append(("bam-like rle", bam_like(rng, 65280), dict(strategy=zlib.Z_RLE)))
+    c.append(("short fixed", b"hello hello hello hello", dict(strategy=zlib.Z_FIXED)))
+    far = rng.integers(0, 256, 20000, dtype=np.uint8).tobytes()
+    c.append(("far matches (20 KB back)", far + far + far[:25280], dict(level=9)))
+    c.append(("far matches (32 KB back)", far[:16000] + bytes(16768) + far[:16000] + bytes(16000), dict(level=9)))
+    mix = bam_like(rng, 30000) + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes() + bam_like(rng, 30280)
+    c.append(("several blocks (full flush)", mix, dict(flush_at=(10000, 30000, 35000))))
+    c.append(("several blocks (sync flush)", mix, dict(flush_at=(1, 2, 40000), flush_mode=zlib.Z_SYNC_FLUSH)))
+    c.append(("small hash (memLevel 1: many blocks)", bam_like(rng, 65280), dict(mem=1)))
+    c.append(("stored pieces", rng.integers(0, 256, 65280, dtype=np.uint8).tobytes(), dict(level=0, flush_at=(100, 101, 30000))))
+    c.append(("text", (b"the quick brown fox jumps over the lazy dog. " * 2000)[:65280], {}))
+    c.append(("max block", bam_like(rng, 65536), {}))
+    return c
+
+
+def test_every_case_inflates_to_what_zlib_made_it_from(ctx):
+    cs = cases()
+    datas = [d for _, d, _ in cs]
+    payloads = [raw_deflate(d, **kw) for _, d, kw in cs]
+    for pl, d in zip(payloads, datas):
+        assert zlib.decompress(pl, -15) == d
+    for gap in (0, 1, 2, 3, 7):            # every alignment of the streams
+        comp, blocks, total = m.bgzf_blocks(payloads, datas, gap=gap)
+        out, st, refused = m.bgzf_inflate(ctx, comp, blocks, len(cs), total)
+        bad = [(cs[i][0], int(st[i])) for i in range(len(cs)) if st[i] != 0]
+        assert not bad and refused == 0, bad
+        o = 0
+        for (name, d, _) in cs:
+            got = out[o:o + len(d)].tobytes()
+            if got != d:
+                first = next(k for k in range(len(d)) if got[k] != d[k])
+                raise AssertionError(f"{name} (gap {gap}): first difference at byte {first} of {len(d)}")
+            o += len(d)
+        assert not out[total:].any()           # nothing written behind the last block
+
+
+def test_many_blocks_of_a_bam_like_stream(ctx):
+    rng = np.random.default_rng(7)
+    stream = bam_like(rng, 3_000_000)
+    datas = [stream[i:i + 65280] for i in range(0, len(stream), 65280)]
+    payloads = [raw_deflate(d, level=(1, 6, 9)[i % 3]) for i, d in enumerate(datas)]
+    comp, blocks, total = m.bgzf_blocks(payloads, datas)
+    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, len(datas), total)
+    assert refused == 0 and not st.any()
+    assert out[:total].tobytes() == stream
+
+
+def test_damaged_blocks_are_refused_and_nothing_hangs(ctx):
+    rng = np.random.default_rng(99)
+    datas = [bam_like(rng, 40000) for _ in range(64)]
+    good = [raw_deflate(d) for d in datas]
+    payloads = []
+    for i, pl in enumerate(good):
+        b = bytearray(pl)
+        if i % 4 == 1:
+            for k in rng.integers(0, len(b), 3):
+                b[int(k)] ^= 1 << int(rng.integers(0, 8))
+        elif i % 4 == 2:
+            b = b[:len(b) // 2]                                   # cut short
+        elif i % 4 == 3:
+            b = bytearray(rng.integers(0, 256, len(b), dtype=np.uint8).tobytes())   # noise
+        payloads.append(bytes(b))
+    comp, blocks, total = m.bgzf_blocks(payloads, datas)
+    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, len(datas), total)
+    o = 0
+    for i, d in enumerate(datas):
+        if i % 4 == 0:
+            assert st[i] == 0 and out[o:o + len(d)].tobytes() == d
+        else:
+            # a damaged stream either fails to decode or fails its CRC (zlib agrees that it is not the original)
+            assert st[i] != 0, i
+        o += len(d)
+    assert refused == int((st != 0).sum())
+    # a wrong CRC in the trailer alone
+    comp, blocks, total = m.bgzf_blocks(good[:4], datas[:4], crcs=[zlib.crc32(d) ^ (i == 2) for i, d in enumerate(datas[:4])])
+    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, 4, total)
+    assert list(st) == [0, 0, 8, 0] and refused == 1
+    # a wrong length in the trailer
+    comp, blocks, total = m.bgzf_blocks(good[:2], [datas[0], datas[1][:-5]], crcs=[zlib.crc32(datas[0]), zlib.crc32(datas[1])])
+    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, 2, total)
+    assert st[0] == 0 and st[1] != 0
