@@ -690,6 +690,10 @@ typedef struct {
 	char seed_name[256];
 	uint8_t *rbuf;             /* raw slots: the inflated bytes, in a buffer of fixed size (page-locked by pin_thread) */
 	size_t rcap, rlen;
+	/* device inflate (msx_unpack_enqueue_bgzf): rbuf holds the blocks' DEFLATE payloads instead, blk their table */
+	int comp, n_blk;
+	msx_bgzf_block *blk;
+	size_t inflated;           /* bytes the table's blocks inflate to */
 	int pin_ready;             /* rbuf is page-locked and obuf allocated (pin_mu) */
 	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit), page-locked */
 	size_t ocap, olen;
@@ -705,6 +709,9 @@ typedef struct {
 	int cut_mapped;            /* prefer batch ends in front of a pool that begins with a MAPPED record (an insert's first pool) */
 	int n_slots, n_consumers;
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
+	size_t n_host_inflated;        /* batches the device inflater refused */
+	int comp_mode, comp_blocks;    /* ... and inflated there as well: the decode stage only copies the blocks' payloads */
+	size_t ocap_cfg;
 	int raw_started, raw_done;
 	int first_state, first_slot;   /* 0: batch 0 not decoded yet; 1: it is, in slot first_slot; 2: the input holds no record (first_mu) */
 	int out_opened;                /* the preflight has passed and the output is open (first_mu) */
@@ -806,7 +813,7 @@ static void *pin_thread(void *arg) {
 		pslot *s = &P->slot[k % P->n_slots];
 		if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, s->rbuf, s->rcap));
 		if (P->pin_obuf) {
-			s->ocap = s->rcap;
+			s->ocap = P->ocap_cfg;
 			MSX(msx_host_alloc(g_ctx, (void **)&s->obuf, s->ocap));
 		}
 		pthread_mutex_lock(&P->pin_mu);
@@ -843,13 +850,53 @@ static void pin_wait(pipe_t *P, pslot *s) {
 	pthread_mutex_unlock(&P->pin_mu);
 }
 
+/* a raw slot's bytes to the device and the record walk over them.  Compressed slots are inflated there; a batch with a
+ * block the device inflater refuses is inflated here instead -- by the reader's own decoder and zlib, whose diagnostics
+ * are the command's -- and handed over inflated. */
+static void unpack_slot(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up, msx_unpack_result *ur, msx_batch *db) {
+	int rc;
+	if (!s->comp) {
+		MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, up));
+		if (msx_unpack_finish(g_ctx, unpack, ur, db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+		return;
+	}
+	MSX(msx_unpack_enqueue_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk, up));
+	rc = msx_unpack_finish(g_ctx, unpack, ur, db);
+	if (rc == MSX_ERR_INFLATE) {
+		static __thread uint8_t *fb = NULL;
+		static __thread size_t fb_cap = 0;
+		if (fb_cap < s->inflated + 64) { fb_cap = s->inflated + 64; fb = (uint8_t *)realloc(fb, fb_cap); if (!fb) mDie("Out of memory"); }
+		msh_inflate_table(s->rbuf, s->blk, s->n_blk, fb);
+		__atomic_add_fetch(&P->n_host_inflated, 1, __ATOMIC_RELAXED);
+		MSX(msx_unpack_enqueue(g_ctx, unpack, fb, s->inflated, up));
+		rc = msx_unpack_finish(g_ctx, unpack, ur, db);
+	}
+	if (rc != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+}
+
 /* device unpack: every slot gets a buffer of fixed size for the inflated bytes (page-locked by pin_thread) */
 static void pipe_enable_raw(pipe_t *P) {
 	int i;
 	P->raw_mode = 1;
+	/* BAM input: the blocks stay compressed until they are on the device (MSX_HOST_INFLATE=1: inflate here).  A batch is
+	 * as many blocks as the device inflates at a time -- one wave per block, eight per compute unit (msx_inflate.hip) --
+	 * or what fits the slot's buffer, whichever comes first. */
+	P->comp_mode = msh_is_bam(P->in) && !getenv("MSX_HOST_INFLATE");
+	/* (MSX_BATCH_BYTES, the inflated size of a batch, translates into blocks) */
+	P->comp_blocks = (int)env_size("MSX_COMP_BLOCKS", getenv("MSX_BATCH_BYTES") ? P->batch_bytes_cfg / 65280 : 2048);
+	if (P->comp_blocks < 1) P->comp_blocks = 1;
+	if (P->comp_blocks > (1 << 16)) P->comp_blocks = 1 << 16;
 	for (i = 0; i < P->n_slots; i++) {
 		pslot *s = &P->slot[i];
-		s->rcap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 4096;
+		if (P->comp_mode) {
+			s->rcap = env_size("MSX_COMP_BYTES", (size_t)64 << 20);
+			if (s->rcap < ((size_t)2 << 20)) s->rcap = (size_t)2 << 20;
+			s->blk = (msx_bgzf_block *)xmalloc((size_t)P->comp_blocks * sizeof(msx_bgzf_block));
+			P->ocap_cfg = (size_t)P->comp_blocks * 65536 + 4096;
+		} else {
+			s->rcap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 4096;
+			P->ocap_cfg = s->rcap;
+		}
 		if (posix_memalign((void **)&s->rbuf, 4096, s->rcap) != 0) mDie("Out of memory");
 	}
 }
@@ -1225,6 +1272,13 @@ static void *pipe_decode_thread(void *arg) {
 				/* (batch 0 may have grown batch_bytes to reach the preflight window; the configured size holds from here
 				 * on.  The buffer is page-locked and must not move: msh_inflate_append appends one batch of blocks at most,
 				 * so there is always room for the next call) */
+				s->comp = P->comp_mode;
+				s->n_blk = 0;
+				s->inflated = 0;
+				if (P->comp_mode) {
+					while (!P->in_eof && s->n_blk < P->comp_blocks && (s->rcap - s->rlen) / (65536 + 1024) > 0)
+						if (!msh_raw_append(P->in, s->rbuf, s->rcap, &s->rlen, s->blk, &s->n_blk, P->comp_blocks, &s->inflated)) P->in_eof = 1;
+				} else
 				while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + BGZF_INFLATE_MAX + 64 <= s->rcap)
 					if (!pipe_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
 				s->last = P->in_eof;
@@ -1699,8 +1753,7 @@ static void *filter_dev_thread(void *arg) {
 			memset(&up, 0, sizeof up);
 			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
-			MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, &up));
-			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+			unpack_slot(P, s, unpack, &up, &ur, &db);
 			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
 			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
 			 * default: measured, it changes nothing (upload phase 0.35-0.40 s of the 100 M-record run either way).  The
@@ -1710,7 +1763,7 @@ static void *filter_dev_thread(void *arg) {
 			 * granted CPUs are all busy inflating. */
 			if (F->n_dev == 1 && prefetch_on) {
 				pending = pq_try_pop(&P->q_dev);
-				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed) {
+				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed && !P->slot[pending].comp) {
 					pin_wait(P, &P->slot[pending]);
 					MSX(msx_unpack_prefetch(g_ctx, unpack, P->slot[pending].rbuf, P->slot[pending].rlen));
 					D->n_prefetched++;
@@ -1977,7 +2030,9 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		for (k = 0; k < F.n_dev; k++) {
 			t_ctx += F.dev[k].t_ctx; t_up += F.dev[k].t_upload; t_gpu += F.dev[k].t_gpu; t_fetch += F.dev[k].t_fetch; t_dw += F.dev[k].t_wait;
 		}
-		fprintf(stderr, "# batches: %zu (%zu sent ahead)\n", n_batches, F.dev[0].n_prefetched);
+		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, F.dev[0].n_prefetched,
+		        P.comp_mode ? "; BGZF blocks inflated on the device" : "");
+		if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
 		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 		        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 		fprintf(stderr, "# filter pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
@@ -2280,8 +2335,7 @@ static void *profile_dev_thread(void *arg) {
 			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
 			memset(&up, 0, sizeof up);
 			up.pool_mode = 2; up.n_targets = P->hdr->n_targets; up.last = s->last;
-			MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, &up));
-			if (msx_unpack_finish(g_ctx, unpack, &ur, &db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));   /* (synchronises: the slot's bytes have left) */
+			unpack_slot(P, s, unpack, &up, &ur, &db);                     /* (synchronises: the slot's bytes have left) */
 			if (ur.n_records > 0) MSX(msx_profile_accumulate(g_ctx, D->prof, &db, NULL));
 			D->n_in += (size_t)ur.n_records;
 			D->n_batches++;
@@ -2439,7 +2493,8 @@ int msam_profile_main(int argc, char *argv[]) {
 		if (P.n_filled == 0) { rbatch e; memset(&e, 0, sizeof e); S.qn = qn_check(hdr, &e); }     /* an empty input is still checked (:708) */
 		qn = S.qn;
 		if (getenv("MSX_TIMING")) {
-			fprintf(stderr, "# batches: %zu\n", n_batches);
+			fprintf(stderr, "# batches: %zu%s\n", n_batches, P.comp_mode ? "; BGZF blocks inflated on the device" : "");
+			if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
 			fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 			        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 			fprintf(stderr, "# profile pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "

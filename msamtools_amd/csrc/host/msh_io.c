@@ -595,14 +595,8 @@ typedef struct {
 	size_t span_beg, span_end, span_cap;
 } bgz_in;
 
-static void inflate_block(bgz_in *b, int i) {
-	const uint8_t *c = b->cptr[i];
-	size_t clen = b->coff[i + 1] - b->coff[i];
-	uint32_t xlen = le16(c + 10);
-	const uint8_t *data = c + 12 + xlen;
-	size_t dlen = clen - 12 - xlen - 8;
-	uint32_t isize = (uint32_t)(b->uoff[i + 1] - b->uoff[i]);
-	uint8_t *out = b->dst + b->uoff[i];
+/* one block's DEFLATE stream into `out` (isize bytes expected, CRC-32 `crc`) */
+static void inflate_payload(const uint8_t *data, size_t dlen, uint8_t *out, uint32_t isize, uint32_t crc) {
 	/* one stream per thread, reset between blocks: initialising one per block means an allocation per
 	 * block, and with a hundred threads those serialise inside the allocator */
 	static __thread z_stream zs;
@@ -616,7 +610,7 @@ static void inflate_block(bgz_in *b, int i) {
 	}
 	/* the decoder of msh_inflate.c first (twice zlib's speed on BAM records); whatever it does not vouch for,
 	 * and whatever fails the CRC afterwards, is decoded again by zlib, whose verdict stands */
-	if (fast && msh_fast_inflate(data, dlen, out, isize) && msh_crc32(out, isize) == (uint32_t)le32(c + clen - 8)) return;
+	if (fast && msh_fast_inflate(data, dlen, out, isize) && msh_crc32(out, isize) == crc) return;
 	if (!zs_ready) {
 		memset(&zs, 0, sizeof zs);
 		if (inflateInit2(&zs, -15) != Z_OK) mDie("zlib inflateInit2 failed");
@@ -629,8 +623,15 @@ static void inflate_block(bgz_in *b, int i) {
 	zs.next_out = out;
 	zs.avail_out = isize;
 	if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize) mDie("Corrupt BGZF block (inflate failed)");
-	if (msh_crc32(out, isize) != (uint32_t)le32(c + clen - 8))
-		mDie("Corrupt BGZF block (CRC mismatch)");
+	if (msh_crc32(out, isize) != crc) mDie("Corrupt BGZF block (CRC mismatch)");
+}
+
+static void inflate_block(bgz_in *b, int i) {
+	const uint8_t *c = b->cptr[i];
+	size_t clen = b->coff[i + 1] - b->coff[i];
+	uint32_t xlen = le16(c + 10);
+	inflate_payload(c + 12 + xlen, clen - 12 - xlen - 8, b->dst + b->uoff[i], (uint32_t)(b->uoff[i + 1] - b->uoff[i]),
+	                (uint32_t)le32(c + clen - 8));
 }
 
 static void inflate_worker(void *arg, int tid, int nth) {
@@ -1123,6 +1124,76 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 	}
 	*len += total;
 	return total;
+}
+
+/* The device inflater's feed (msx_unpack_enqueue_bgzf): the DEFLATE payloads of the next blocks, copied back to back
+ * behind buf[0, *len), and their table behind blk[0, *n) -- at most max_blocks in the table, at most cap bytes in the
+ * buffer.  Returns the number of blocks appended: 0 at the end of the input, or when nothing more fits. */
+typedef struct { bgz_in *b; uint8_t *dst; const size_t *poff; } rawcopy_job;
+static void rawcopy_worker(void *arg, int tid, int nth) {
+	rawcopy_job *J = (rawcopy_job *)arg;
+	bgz_in *b = J->b;
+	int i;
+	for (i = tid; i < b->nblk; i += nth) {
+		const uint8_t *c = b->cptr[i];
+		const uint32_t xlen = le16(c + 10);
+		memcpy(J->dst + J->poff[i], c + 12 + xlen, J->poff[i + 1] - J->poff[i]);
+	}
+}
+int msh_raw_append(msh_in *in, uint8_t *buf, size_t cap, size_t *len, msx_bgzf_block *blk, int *n, int max_blocks, size_t *out_total) {
+	bgz_in *b = &in->bz;
+	static size_t poff[BGZF_BATCH + 1];
+	rawcopy_job J;
+	size_t room = cap > *len ? (cap - *len) / (BGZF_MAX + 1024) : 0;
+	int want = max_blocks - *n, i, added = 0, save = bgzf_blocks_limit;
+	if (b->span_end != b->span_beg) mDie("msh_raw_append: inflated bytes pending");
+	if ((size_t)want > room) want = (int)room;
+	if (want <= 0) return 0;
+	bgzf_blocks_limit = want;
+	(void)bgz_read_blocks(b);
+	bgzf_blocks_limit = save;
+	if (b->nblk == 0) return 0;
+	poff[0] = 0;
+	for (i = 0; i < b->nblk; i++) {
+		const size_t clen = b->coff[i + 1] - b->coff[i];
+		const uint32_t xlen = le16(b->cptr[i] + 10);
+		poff[i + 1] = poff[i] + (clen - 12 - xlen - 8);
+	}
+	J.b = b; J.dst = buf + *len; J.poff = poff;
+	msh_parallel(msh_threads() < b->nblk ? msh_threads() : b->nblk, rawcopy_worker, &J);
+	for (i = 0; i < b->nblk; i++) {
+		const uint8_t *c = b->cptr[i];
+		const size_t clen = b->coff[i + 1] - b->coff[i];
+		const uint32_t isize = (uint32_t)(b->uoff[i + 1] - b->uoff[i]);
+		msx_bgzf_block *q;
+		if (isize == 0) continue;                 /* (an empty block -- the end-of-file marker -- has nothing to say) */
+		q = &blk[*n];
+		q->in_off = *len + poff[i];
+		q->in_len = (uint32_t)(poff[i + 1] - poff[i]);
+		q->out_off = *out_total;
+		q->out_len = isize;
+		q->crc32 = (uint32_t)le32(c + clen - 8);
+		q->reserved_ = 0;
+		*out_total += isize;
+		(*n)++;
+		added++;
+	}
+	*len += poff[b->nblk];
+	return added ? added : msh_raw_append(in, buf, cap, len, blk, n, max_blocks, out_total);   /* (only empty blocks: read on) */
+}
+
+/* what the device refused: the blocks of a table inflated here, with this reader's diagnostics */
+typedef struct { const uint8_t *comp; const msx_bgzf_block *blk; int n; uint8_t *out; } tabinf_job;
+static void tabinf_worker(void *arg, int tid, int nth) {
+	tabinf_job *J = (tabinf_job *)arg;
+	int i;
+	for (i = tid; i < J->n; i += nth)
+		inflate_payload(J->comp + J->blk[i].in_off, J->blk[i].in_len, J->out + J->blk[i].out_off, J->blk[i].out_len, J->blk[i].crc32);
+}
+void msh_inflate_table(const uint8_t *comp, const msx_bgzf_block *blk, int n, uint8_t *out) {
+	tabinf_job J;
+	J.comp = comp; J.blk = blk; J.n = n; J.out = out;
+	if (n > 0) msh_parallel(msh_threads() < n ? msh_threads() : n, tabinf_worker, &J);
 }
 
 /* SAM text for the pipelined reader: the next chunk of lines, parsed on all threads into BAM records

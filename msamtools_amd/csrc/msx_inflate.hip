@@ -28,6 +28,7 @@
 // Integer / byte work; no MFMA.
 #include "msx_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -71,6 +72,9 @@ struct IfShared {
 	uint8_t pl[32];
 };
 
+#ifndef IF_FAR_LOAD
+#define IF_FAR_LOAD(p) (*(const uint8_t *)(p))
+#endif
 #define IFU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 // the order in which a dynamic block sends the lengths of its code-length code (RFC 1951, 3.2.7), five bits each
@@ -141,8 +145,21 @@ __device__ __forceinline__ void if_store_chunk(IfShared &S, uint32_t chunk, uint
 	*reinterpret_cast<uint4 *>(&S.in[(chunk & 1u) * IF_IN_HALF + lane * 4u]) = v;
 }
 
-// (re)position the reader at byte `byte_off` of the stream
-__device__ __forceinline__ void if_seek(IfShared &S, IfState &T, IfIn &I, uint32_t byte_off, uint32_t lane) {
+// one word of the stream taken: when the read position enters the next chunk, the chunk behind it is done with -- the
+// chunk two ahead takes its half (out of the registers it has been travelling in), the one three ahead starts travelling
+__device__ __forceinline__ void if_advance(IfShared &S, IfState &T, IfIn &I, uint32_t lane) {
+	T.ip++;
+	if (T.ip == T.cross) {
+		const uint32_t k = T.ip / IF_IN_HALF;
+		if_store_chunk(S, k + 1u, lane, I.ahead);
+		I.ahead = if_load_chunk(I, k + 2u, lane);
+		T.cross += IF_IN_HALF;
+	}
+}
+
+// (re)position the reader at byte `byte_off` of the stream.  w: the word at T.ip, read ahead of its use (an LDS read
+// waited for only where the next LDS result is waited for anyway)
+__device__ __forceinline__ void if_seek(IfShared &S, IfState &T, IfIn &I, uint32_t &w, uint32_t byte_off, uint32_t lane) {
 	const uint32_t dw = byte_off >> 2;
 	const uint32_t c0 = dw / IF_IN_HALF;
 	if_store_chunk(S, c0, lane, if_load_chunk(I, c0, lane));
@@ -150,37 +167,23 @@ __device__ __forceinline__ void if_seek(IfShared &S, IfState &T, IfIn &I, uint32
 	I.ahead = if_load_chunk(I, c0 + 2u, lane);
 	T.cross = (c0 + 1u) * IF_IN_HALF;
 	T.ip = dw;
-	T.buf = 0;
-	T.cnt = 0;
 	// two words, then the bytes in front of byte_off go
 	T.buf = (uint64_t)IFU(S.in[T.ip & (IF_IN_DW - 1u)]);
-	T.ip++;
-	if (T.ip == T.cross) {       // (dw was the last word of its chunk)
-		if_store_chunk(S, (T.ip / IF_IN_HALF) + 1u, lane, I.ahead);
-		I.ahead = if_load_chunk(I, (T.ip / IF_IN_HALF) + 2u, lane);
-		T.cross += IF_IN_HALF;
-	}
+	if_advance(S, T, I, lane);
 	T.buf |= (uint64_t)IFU(S.in[T.ip & (IF_IN_DW - 1u)]) << 32;
-	T.ip++;
-	T.cnt = 64;
+	if_advance(S, T, I, lane);
+	w = S.in[T.ip & (IF_IN_DW - 1u)];
 	const uint32_t skip = (byte_off & 3u) * 8u;
 	T.buf >>= skip;
-	T.cnt -= (int32_t)skip;
+	T.cnt = 64 - (int32_t)skip;
 }
 
-__device__ __forceinline__ void if_refill(IfShared &S, IfState &T, IfIn &I, uint32_t lane) {
+__device__ __forceinline__ void if_refill(IfShared &S, IfState &T, IfIn &I, uint32_t &w, uint32_t lane) {
 	if (T.cnt <= 32) {
-		if (T.ip == T.cross) {
-			// the chunk behind the read position is done with: the chunk two ahead takes its half, the one three ahead
-			// starts travelling
-			const uint32_t k = T.ip / IF_IN_HALF;
-			if_store_chunk(S, k + 1u, lane, I.ahead);
-			I.ahead = if_load_chunk(I, k + 2u, lane);
-			T.cross += IF_IN_HALF;
-		}
-		T.buf |= (uint64_t)IFU(S.in[T.ip & (IF_IN_DW - 1u)]) << T.cnt;
+		T.buf |= (uint64_t)IFU(w) << T.cnt;
 		T.cnt += 32;
-		T.ip++;
+		if_advance(S, T, I, lane);
+		w = S.in[T.ip & (IF_IN_DW - 1u)];
 	}
 }
 #define IF_PEEK(T, n) ((uint32_t)((T).buf & ((1ull << (n)) - 1ull)))
@@ -278,10 +281,13 @@ __device__ __forceinline__ uint32_t if_long(IfShared &S, uint32_t which, uint32_
 	return 0u;
 }
 
+template <int DBG>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, size_t comp_len,
                                                      const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
-                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                     uint32_t *__restrict__ stats) {
 	__shared__ IfShared S;
+	uint32_t n_lit = 0u, n_match = 0u, n_far = 0u, n_dyn = 0u;      // (MSX_INFLATE_STATS: what the blocks are made of)
 	const uint32_t lane = threadIdx.x;
 	const uint32_t bi = blockIdx.x;
 	if (bi >= n_blocks) return;
@@ -305,11 +311,12 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 	const uint32_t rshift = (uint32_t)((uintptr_t)og & 15u);
 	IfState T;
 	T.pos = 0u; T.flushed = 0u; T.status = IF_OK;
-	if_seek(S, T, I, skew, lane);
+	uint32_t w;
+	if_seek(S, T, I, w, skew, lane);
 #define IF_RI(q) (((q) + rshift) & IF_RMASK)
 #define IF_FAIL(code) do { T.status = (code); goto done; } while (0)
 	for (;;) {
-		if_refill(S, T, I, lane);
+		if_refill(S, T, I, w, lane);
 		const uint32_t last = IF_PEEK(T, 1);
 		const uint32_t type = (uint32_t)(T.buf >> 1) & 3u;
 		IF_DROP(T, 3);
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 		if (type == 0u) {
 			// stored: to the next byte boundary, LEN, NLEN, bytes (through the ring: a later block may refer to them)
 			IF_DROP(T, (uint32_t)T.cnt & 7u);
-			if_refill(S, T, I, lane);
+			if_refill(S, T, I, w, lane);
 			const uint32_t len = IF_PEEK(T, 16);
 			IF_DROP(T, 16);
 			const uint32_t nlen = IF_PEEK(T, 16);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 					if_flush(S, T, og, upto, lane);
 				}
 			}
-			if_seek(S, T, I, (uint32_t)(bp + len), lane);
+			if_seek(S, T, I, w, (uint32_t)(bp + len), lane);
 			if (last) break;
 			continue;
 		}
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			if (hlit > 286u || hdist > 30u) IF_FAIL(IF_BAD_LENS);
 			if (lane < 19u) S.pl[lane] = 0;
 			for (uint32_t i = 0; i < hclen; i++) {
-				if_refill(S, T, I, lane);
+				if_refill(S, T, I, w, lane);
 				const uint32_t o = (uint32_t)((i < 12u ? IF_ORDER_LO >> (5u * i) : IF_ORDER_HI >> (5u * (i - 12u))) & 31ull);
 				if (lane == 0) S.pl[o] = (uint8_t)IF_PEEK(T, 3);
 				IF_DROP(T, 3);
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			const uint32_t total = hlit + hdist;
 			uint32_t n = 0u, prev = 0u;
 			while (n < total) {
-				if_refill(S, T, I, lane);
+				if_refill(S, T, I, w, lane);
 				const uint32_t e = IFU(S.pre[IF_PEEK(T, 7)]);
 				if (!e) IF_FAIL(IF_BAD_CODE);
 				IF_DROP(T, e & 0xffu);
@@ -414,27 +421,34 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			}
 			if (S.lens[256] == 0) IF_FAIL(IF_BAD_LENS);       // a block must be able to end
 		}
+		n_dyn++;
 		if (!if_build(S, 0u, 0u, hlit, lane)) IF_FAIL(IF_BAD_LENS);
 		if (!if_build(S, 1u, hlit, hdist, lane)) IF_FAIL(IF_BAD_LENS);
 		// ---- the symbols of the block ----
+		// The table entry of the NEXT symbol is asked for as soon as its bits are known -- before a literal is stored, before
+		// a match is copied -- and waited for at the top of the loop.
+		if_refill(S, T, I, w, lane);
+		uint32_t ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
 		for (;;) {
-			if_refill(S, T, I, lane);
-			uint32_t e = IFU(S.ll[IF_PEEK(T, IF_LL_ROOT)]);
+			uint32_t e = IFU(ev);
 			if (((e >> 4) & 15u) == IF_LONG) e = if_long(S, 0u, IF_PEEK(T, 15));
 			const uint32_t kind = (e >> 4) & 15u;
 			if (kind == 0u) IF_FAIL(IF_BAD_CODE);
 			IF_DROP(T, e & 15u);
 			if (kind == IF_LIT) {
 				if (T.pos >= out_len) IF_FAIL(IF_OUT_OVER);
-				if (lane == 0) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
+				if_refill(S, T, I, w, lane);
+				ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
+				if (lane == 0 && DBG != 3) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
 				T.pos++;
+				n_lit++;
 			} else if (kind == IF_EOB) {
 				break;
 			} else {
 				const uint32_t xl = (e >> 8) & 15u;
 				const uint32_t len = (e >> 16) + IF_PEEK(T, xl);
 				IF_DROP(T, xl);
-				if_refill(S, T, I, lane);
+				if_refill(S, T, I, w, lane);
 				uint32_t d = IFU(S.dt[IF_PEEK(T, IF_D_ROOT)]);
 				if (((d >> 4) & 15u) == IF_LONG) d = if_long(S, 1u, IF_PEEK(T, 15));
 				if (((d >> 4) & 15u) != IF_BASE) IF_FAIL(IF_BAD_CODE);
@@ -444,8 +458,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 				IF_DROP(T, xd);
 				if (dist > T.pos) IF_FAIL(IF_BAD_DIST);
 				if (len > out_len - T.pos) IF_FAIL(IF_OUT_OVER);
+				if_refill(S, T, I, w, lane);
+				ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
 				const uint32_t from = T.pos - dist;
-				if (dist <= IF_NEAR) {
+				if (DBG == 2) {
+				} else if (dist <= IF_NEAR || DBG == 1) {
 					if (dist >= 64u || dist >= len) {
 						// a round's sources lie in front of the round: earlier rounds (LDS keeps a wave's order) or earlier symbols
 						for (uint32_t b = 0; b < len; b += 64u) {
@@ -462,17 +479,17 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 						}
 					}
 				} else {
-					// out of the ring's reach: those bytes were written back at least IF_NEAR - IF_FLUSH - 258 bytes ago
-					// (the wave waits for its own stores, then reads past the vector L1)
-					__builtin_amdgcn_s_waitcnt(0);
+					// out of the ring's reach: those bytes were written back at least IF_NEAR - IF_FLUSH - 258 bytes ago (the
+					// wave reads its own stores: workgroup scope)
+					n_far++;
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 					for (uint32_t b = 0; b < len; b += 64u) {
 						const uint32_t i = b + lane;
-						if (i < len)
-							S.ring[IF_RI(T.pos + i)] = __hip_atomic_load(og + from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (i < len) S.ring[IF_RI(T.pos + i)] = IF_FAR_LOAD(og + from + i);
 					}
 				}
 				T.pos += len;
+				n_match++;
 			}
 			if (IF_BITPOS(T) > end_bit) IF_FAIL(IF_IN_OVER);
 			if (T.pos - T.flushed >= IF_FLUSH) {
@@ -486,6 +503,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 done:
 	if (T.status == IF_OK) if_flush(S, T, og, T.pos, lane);
 	if (lane == 0) status[bi] = T.status;
+	if (stats && lane == 0) {
+		atomicAdd(&stats[0], n_lit); atomicAdd(&stats[1], n_match); atomicAdd(&stats[2], n_far); atomicAdd(&stats[3], n_dyn);
+	}
 #undef IF_RI
 #undef IF_FAIL
 }
@@ -571,11 +591,16 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restric
 // ---------------------------------------------------------------------------
 // ABI
 // ---------------------------------------------------------------------------
+static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate only): device counters
+
 int msx_bgzf_inflate_launch(msx_ctx *ctx, const uint8_t *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks, int64_t n_blocks,
                             uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
 	if (n_blocks <= 0) return MSX_OK;
-	hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_comp, comp_len, d_blocks,
-	                   (uint32_t)n_blocks, d_out, d_status);
+	static int dbg = -1;
+	if (dbg < 0) dbg = getenv("MSX_INFLATE_DBG") ? atoi(getenv("MSX_INFLATE_DBG")) : 0;
+#define IF_LAUNCH(D) hipLaunchKernelGGL(k_bgzf_inflate<D>, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_comp, comp_len, d_blocks, \
+	                   (uint32_t)n_blocks, d_out, d_status, if_stats)
+	if (dbg == 1) IF_LAUNCH(1); else if (dbg == 2) IF_LAUNCH(2); else if (dbg == 3) IF_LAUNCH(3); else IF_LAUNCH(0);
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
 	MSX_HIP(ctx, hipGetLastError());
@@ -592,8 +617,18 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 	if ((rc = msx_reserve(ctx, &ctx->scan_l3, 64))) return rc;
 	uint32_t *d_bad = (uint32_t *)ctx->scan_l3.p;
 	MSX_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-	if ((rc = msx_bgzf_inflate_launch(ctx, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad)))
-		return rc;
+	const bool want_stats = getenv("MSX_INFLATE_STATS") != nullptr;
+	if (want_stats) { if_stats = d_bad + 4; MSX_HIP(ctx, hipMemsetAsync(if_stats, 0, 16, ctx->stream)); }
+	rc = msx_bgzf_inflate_launch(ctx, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad);
+	if_stats = nullptr;
+	if (rc) return rc;
+	if (want_stats) {
+		uint32_t h[4];
+		MSX_HIP(ctx, hipMemcpyAsync(h, d_bad + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		fprintf(stderr, "# inflate: %lld blocks: %u literals, %u matches (%u beyond the ring), %u coded deflate blocks\n",
+		        (long long)n_blocks, h[0], h[1], h[2], h[3]);
+	}
 	uint32_t bad = 0;
 	MSX_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
