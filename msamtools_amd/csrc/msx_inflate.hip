@@ -44,8 +44,8 @@
 // table entry: bits 0-3 code length, 4-7 kind, 8-11 extra bits, 16-31 payload (literal / base)
 #define IF_LIT 1u
 #define IF_BASE 2u
-#define IF_EOB 3u
-#define IF_LONG 4u
+#define IF_EOB 4u
+#define IF_LONG 8u
 
 // status of a block
 #define IF_OK 0u
@@ -121,11 +121,10 @@ struct IfIn {
 };
 
 // word d of the stream where the buffer ends inside or in front of it
-__device__ __forceinline__ uint32_t if_edge_word(const IfIn &I, uint32_t d) {
-	const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
+__device__ __noinline__ uint32_t if_edge_word(const uint8_t *p, uint32_t n_bytes, uint32_t d) {
 	uint32_t v = 0u;
 	for (uint32_t k = 0; k < 4u; k++)
-		if (4u * d + k < I.n_bytes) v |= (uint32_t)p[4u * d + k] << (8u * k);
+		if (4u * d + k < n_bytes) v |= (uint32_t)p[4u * d + k] << (8u * k);
 	return v;
 }
 __device__ __forceinline__ uint4 if_load_chunk(const IfIn &I, uint32_t chunk, uint32_t lane) {
@@ -134,10 +133,11 @@ __device__ __forceinline__ uint4 if_load_chunk(const IfIn &I, uint32_t chunk, ui
 	if (4u * d + 16u <= I.n_bytes) {
 		v = *reinterpret_cast<const uint4 *>(I.g + d);
 	} else {
-		v.x = if_edge_word(I, d);
-		v.y = if_edge_word(I, d + 1u);
-		v.z = if_edge_word(I, d + 2u);
-		v.w = if_edge_word(I, d + 3u);
+		const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
+		v.x = if_edge_word(p, I.n_bytes, d);
+		v.y = if_edge_word(p, I.n_bytes, d + 1u);
+		v.z = if_edge_word(p, I.n_bytes, d + 2u);
+		v.w = if_edge_word(p, I.n_bytes, d + 3u);
 	}
 	return v;
 }
@@ -430,6 +430,86 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 		if_refill(S, T, I, w, lane);
 		uint32_t ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
 		for (;;) {
+			// ---- the fast loop: symbols whose codes the primary tables hold, while neither a write-back nor a refill of
+			// the input ring is due (a symbol takes two words at most).  Anything else -- a long literal/length code, the
+			// end of the block, the output's end, a chunk boundary -- leaves it in front of the symbol for the general step
+			// below; only errors leave it inside a symbol.
+			{
+				uint32_t err = 0u;
+				for (;;) {
+					const uint32_t lim = T.flushed + IF_FLUSH < out_len ? T.flushed + IF_FLUSH : out_len;
+					if (T.pos >= lim || T.ip + 2u >= T.cross) break;
+					const uint32_t e = IFU(ev);
+					if (e & (IF_LIT << 4)) {
+						IF_DROP(T, e & 15u);
+						if (T.cnt <= 32) {
+							T.buf |= (uint64_t)IFU(w) << T.cnt;
+							T.cnt += 32;
+							T.ip++;
+							w = S.in[T.ip & (IF_IN_DW - 1u)];
+						}
+						ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
+						if (lane == 0) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
+						T.pos++;
+						n_lit++;
+						continue;
+					}
+					if (((e >> 4) & 15u) != IF_BASE) break;
+					IF_DROP(T, e & 15u);
+					const uint32_t xl = (e >> 8) & 15u;
+					const uint32_t len = (e >> 16) + IF_PEEK(T, xl);
+					IF_DROP(T, xl);
+					if (T.cnt <= 32) {
+						T.buf |= (uint64_t)IFU(w) << T.cnt;
+						T.cnt += 32;
+						T.ip++;
+						w = S.in[T.ip & (IF_IN_DW - 1u)];
+					}
+					uint32_t d = IFU(S.dt[IF_PEEK(T, IF_D_ROOT)]);
+					if (((d >> 4) & 15u) == IF_LONG) d = if_long(S, 1u, IF_PEEK(T, 15));
+					if (((d >> 4) & 15u) != IF_BASE) { err = IF_BAD_CODE; break; }
+					IF_DROP(T, d & 15u);
+					const uint32_t xd = (d >> 8) & 15u;
+					const uint32_t dist = (d >> 16) + IF_PEEK(T, xd);
+					IF_DROP(T, xd);
+					if (dist > T.pos) { err = IF_BAD_DIST; break; }
+					if (len > out_len - T.pos) { err = IF_OUT_OVER; break; }
+					if (T.cnt <= 32) {
+						T.buf |= (uint64_t)IFU(w) << T.cnt;
+						T.cnt += 32;
+						T.ip++;
+						w = S.in[T.ip & (IF_IN_DW - 1u)];
+					}
+					ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
+					const uint32_t from = T.pos - dist;
+					if (dist <= IF_NEAR) {
+						if (dist >= 64u || dist >= len) {
+							for (uint32_t b = 0; b < len; b += 64u) {
+								const uint32_t i = b + lane;
+								if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + i)];
+							}
+						} else {
+							const float rf = 1.0f / (float)dist;
+							for (uint32_t b = 0; b < len; b += 64u) {
+								const uint32_t i = b + lane;
+								const uint32_t q = (uint32_t)(((float)i + 0.5f) * rf);
+								if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + (i - q * dist))];
+							}
+						}
+					} else {
+						n_far++;
+						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+						for (uint32_t b = 0; b < len; b += 64u) {
+							const uint32_t i = b + lane;
+							if (i < len) S.ring[IF_RI(T.pos + i)] = IF_FAR_LOAD(og + from + i);
+						}
+					}
+					T.pos += len;
+					n_match++;
+				}
+				if (err) IF_FAIL(err);
+			}
+			// ---- the general step: one symbol, whatever it takes ----
 			uint32_t e = IFU(ev);
 			if (((e >> 4) & 15u) == IF_LONG) e = if_long(S, 0u, IF_PEEK(T, 15));
 			const uint32_t kind = (e >> 4) & 15u;
