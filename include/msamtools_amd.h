@@ -248,6 +248,11 @@ int  msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result *res, msx_
 int  msx_unpack_prefetch(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n);
 int  msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, uint8_t *host_out,
                      size_t host_cap, int64_t *n_bytes);
+/* msx_unpack_emit in two steps: gather on the device (*n_bytes: how long the byte string is -- the caller's buffer can be
+ * sized now), then fetch; with `done` the bytes travel on a copy stream of their own while the next batch is enqueued:
+ * msx_event_wait(done) before host_out is read. */
+int  msx_unpack_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int64_t *n_bytes);
+int  msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_out, size_t host_cap, msx_event *done);
 /* record offsets of the last batch, u32[n + 1] relative to its first byte (tests, SAM-text writers) */
 int  msx_unpack_offsets(msx_ctx *ctx, msx_unpack *u, uint32_t *host, int64_t n);
 
@@ -276,6 +281,10 @@ int  msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_len, const m
  * block was refused: nothing has been consumed then, and the same batch can be handed to msx_unpack_enqueue inflated. */
 int  msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
                              const msx_bgzf_block *host_blocks, int64_t n_blocks, const msx_unpack_params *prm);
+/* optional, at any time: upload and inflate the blocks of the NEXT msx_unpack_enqueue_bgzf on a stream of their own, while
+ * the current batch is walked, filtered and fetched (the next enqueue names the same buffer, length and block count) */
+int  msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
+                              const msx_bgzf_block *host_blocks, int64_t n_blocks);
 
 /* ---- filter: replaces mFilterFileWrapper/mFilterFile + writers ----------- */
 

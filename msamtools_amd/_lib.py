@@ -120,6 +120,9 @@ SYMBOLS = {
     "msx_unpack_offsets": (C.c_int, [_P, _P, _P, C.c_int64]),
     "msx_bgzf_inflate": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int64, _P, _P, _P]),
     "msx_unpack_enqueue_bgzf": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_int64, _P]),
+    "msx_unpack_emit_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "msx_unpack_emit_fetch": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "msx_unpack_prefetch_bgzf": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_int64]),
     "msx_filter_enqueue": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(FilterParams), C.POINTER(FilterOut)]),
     "msx_filter_finish": (C.c_int, [_P, C.POINTER(FilterStatus)]),
     "msx_aln_stats": (C.c_int, [_P, C.POINTER(Batch), _P, _P, _P, _P, _P]),

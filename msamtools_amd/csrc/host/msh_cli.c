@@ -695,7 +695,9 @@ typedef struct {
 	msx_bgzf_block *blk;
 	size_t inflated;           /* bytes the table's blocks inflate to */
 	int pin_ready;             /* rbuf is page-locked and obuf allocated (pin_mu) */
-	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit), page-locked */
+	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit_async), page-locked */
+	msx_event *ev_out;         /* ... are there once this has been waited for */
+	msx_ctx *ev_ctx;
 	size_t ocap, olen;
 	int fatal;                 /* the batch holds a record the reference dies at: fatal_msg, after the pools before it */
 	char fatal_msg[512];
@@ -710,6 +712,7 @@ typedef struct {
 	int n_slots, n_consumers;
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
 	size_t n_host_inflated;        /* batches the device inflater refused */
+	size_t n_ahead;                /* batches whose blocks were sent and inflated ahead (msx_unpack_prefetch_bgzf) */
 	int comp_mode, comp_blocks;    /* ... and inflated there as well: the decode stage only copies the blocks' payloads */
 	size_t ocap_cfg;
 	int raw_started, raw_done;
@@ -829,7 +832,7 @@ static void pin_start(pipe_t *P, int with_obuf) {
 	P->pin_started = 1;
 	P->pin_ctx = g_ctx;
 	P->pin_obuf = with_obuf;
-	P->n_pin = getenv("MSX_PIN_THREADS") ? atoi(getenv("MSX_PIN_THREADS")) : 1;
+	P->n_pin = getenv("MSX_PIN_THREADS") ? atoi(getenv("MSX_PIN_THREADS")) : (P->comp_mode ? 2 : 1);
 	if (P->n_pin < 1) P->n_pin = 1;
 	if (P->n_pin > P->n_slots) P->n_pin = P->n_slots;
 	pthread_mutex_init(&P->pin_mu, NULL);
@@ -853,16 +856,27 @@ static void pin_wait(pipe_t *P, pslot *s) {
 /* a raw slot's bytes to the device and the record walk over them.  Compressed slots are inflated there; a batch with a
  * block the device inflater refuses is inflated here instead -- by the reader's own decoder and zlib, whose diagnostics
  * are the command's -- and handed over inflated. */
-static void unpack_slot(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up, msx_unpack_result *ur, msx_batch *db) {
-	int rc;
-	if (!s->comp) {
-		MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, up));
-		if (msx_unpack_finish(g_ctx, unpack, ur, db) != MSX_OK) mDie("%s", msx_last_error(g_ctx));
-		return;
+static void unpack_slot_enqueue(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up) {
+	(void)P;
+	if (!s->comp) MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, up));
+	else MSX(msx_unpack_enqueue_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk, up));
+}
+/* the batch behind this one, if the decode stage has it ready: its blocks start their way up and are inflated beside the
+ * work on this batch.  Returns the slot taken off the queue (the caller's next one), PQ_NONE if there was none. */
+static int unpack_slot_ahead(pipe_t *P, msx_unpack *unpack) {
+	int nx;
+	if (!P->comp_mode || getenv("MSX_NO_INFLATE_AHEAD")) return PQ_NONE;
+	nx = pq_try_pop(&P->q_dev);
+	if (nx >= 0 && P->slot[nx].raw && P->slot[nx].comp && P->slot[nx].n_blk > 0) {
+		pin_wait(P, &P->slot[nx]);
+		__atomic_add_fetch(&P->n_ahead, 1, __ATOMIC_RELAXED);
+		MSX(msx_unpack_prefetch_bgzf(g_ctx, unpack, P->slot[nx].rbuf, P->slot[nx].rlen, P->slot[nx].blk, P->slot[nx].n_blk));
 	}
-	MSX(msx_unpack_enqueue_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk, up));
-	rc = msx_unpack_finish(g_ctx, unpack, ur, db);
-	if (rc == MSX_ERR_INFLATE) {
+	return nx;
+}
+static void unpack_slot_finish(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up, msx_unpack_result *ur, msx_batch *db) {
+	int rc = msx_unpack_finish(g_ctx, unpack, ur, db);
+	if (rc == MSX_ERR_INFLATE && s->comp) {
 		static __thread uint8_t *fb = NULL;
 		static __thread size_t fb_cap = 0;
 		if (fb_cap < s->inflated + 64) { fb_cap = s->inflated + 64; fb = (uint8_t *)realloc(fb, fb_cap); if (!fb) mDie("Out of memory"); }
@@ -889,10 +903,12 @@ static void pipe_enable_raw(pipe_t *P) {
 	for (i = 0; i < P->n_slots; i++) {
 		pslot *s = &P->slot[i];
 		if (P->comp_mode) {
-			s->rcap = env_size("MSX_COMP_BYTES", (size_t)64 << 20);
+			s->rcap = env_size("MSX_COMP_BYTES", (size_t)40 << 20);
 			if (s->rcap < ((size_t)2 << 20)) s->rcap = (size_t)2 << 20;
 			s->blk = (msx_bgzf_block *)xmalloc((size_t)P->comp_blocks * sizeof(msx_bgzf_block));
-			P->ocap_cfg = (size_t)P->comp_blocks * 65536 + 4096;
+			/* (the output buffer starts at half of what the blocks inflate to -- page-locking is paid per byte, at start-up --
+			 * and is replaced by a larger one when a batch keeps more: filter_dev_thread) */
+			P->ocap_cfg = (size_t)P->comp_blocks * 32768 + ((size_t)8 << 20);
 		} else {
 			s->rcap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 4096;
 			P->ocap_cfg = s->rcap;
@@ -1753,7 +1769,9 @@ static void *filter_dev_thread(void *arg) {
 			memset(&up, 0, sizeof up);
 			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
-			unpack_slot(P, s, unpack, &up, &ur, &db);
+			unpack_slot_enqueue(P, s, unpack, &up);
+			if (F->n_dev == 1) pending = unpack_slot_ahead(P, unpack);
+			unpack_slot_finish(P, s, unpack, &up, &ur, &db);
 			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
 			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
 			 * default: measured, it changes nothing (upload phase 0.35-0.40 s of the 100 M-record run either way).  The
@@ -1761,7 +1779,7 @@ static void *filter_dev_thread(void *arg) {
 			 * 48 GB/s each way when both directions are busy -- scripts/micro/pcie_rate.hip -- in a phase of 6.5 ms):
 			 * the device thread synchronises five times per batch and has to be scheduled again each time on a host whose
 			 * granted CPUs are all busy inflating. */
-			if (F->n_dev == 1 && prefetch_on) {
+			if (F->n_dev == 1 && prefetch_on && !P->comp_mode) {
 				pending = pq_try_pop(&P->q_dev);
 				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed && !P->slot[pending].comp) {
 					pin_wait(P, &P->slot[pending]);
@@ -1796,12 +1814,17 @@ static void *filter_dev_thread(void *arg) {
 				}
 				D->t_gpu += now_s() - t1; t1 = now_s();
 				s->n_emit = st.n_emit;
-				if ((size_t)ur.bytes_consumed + 64 > s->ocap) {
+				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
+				 * while the next batch is worked on: the writer waits for s->ev_out */
+				MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
+				if ((size_t)nb + 64 > s->ocap) {
 					if (s->obuf) msx_host_free(g_ctx, s->obuf);
-					s->ocap = (size_t)ur.bytes_consumed + (size_t)ur.bytes_consumed / 4 + ((size_t)16 << 20);
+					s->ocap = (size_t)nb + (size_t)nb / 4 + ((size_t)4 << 20);
 					MSX(msx_host_alloc(g_ctx, (void **)&s->obuf, s->ocap));
 				}
-				MSX(msx_unpack_emit(g_ctx, unpack, fo.emit_idx, st.n_emit, s->obuf, s->ocap, &nb));
+				if (!s->ev_out) MSX(msx_event_create(g_ctx, &s->ev_out));
+				MSX(msx_unpack_emit_fetch(g_ctx, unpack, s->obuf, s->ocap, s->ev_out));
+				s->ev_ctx = g_ctx;
 				s->olen = (size_t)nb;
 				D->t_fetch += now_s() - t1;
 			}
@@ -1972,6 +1995,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		if (si == PQ_END) break;
 		s = &P.slot[si];
 		if (s->raw) {
+			if (s->ev_out && s->olen) { if (msx_event_wait(s->ev_ctx, s->ev_out) != MSX_OK) mDie("%s", msx_last_error(s->ev_ctx)); }
 			msh_write_stream(F.out, s->obuf, s->olen);
 		} else if (!fp->rescore) {
 			msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
@@ -2030,7 +2054,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		for (k = 0; k < F.n_dev; k++) {
 			t_ctx += F.dev[k].t_ctx; t_up += F.dev[k].t_upload; t_gpu += F.dev[k].t_gpu; t_fetch += F.dev[k].t_fetch; t_dw += F.dev[k].t_wait;
 		}
-		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, F.dev[0].n_prefetched,
+		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.comp_mode ? P.n_ahead : F.dev[0].n_prefetched,
 		        P.comp_mode ? "; BGZF blocks inflated on the device" : "");
 		if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
 		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
@@ -2306,7 +2330,7 @@ static void *profile_dev_thread(void *arg) {
 	msx_stage *stage = NULL;
 	msx_unpack *unpack = NULL;
 	msx_event *ev[PIPE_SLOTS_MAX] = {NULL};
-	int held = -1, q;                          /* slot whose uploads may still be in flight */
+	int held = -1, q, pending = PQ_NONE;       /* held: slot whose uploads may still be in flight; pending: slot taken off the queue ahead */
 	double t0 = now_s();
 	ctx_open_dev(D->dev_id);                     /* HIP start-up runs beside the decoding of the first batch */
 	D->ctx = g_ctx;
@@ -2321,7 +2345,8 @@ static void *profile_dev_thread(void *arg) {
 		pslot *s;
 		msx_batch hb, db;
 		t0 = now_s();
-		si = pq_pop(&P->q_dev);
+		si = pending != PQ_NONE ? pending : pq_pop(&P->q_dev);
+		pending = PQ_NONE;
 		t1 = now_s();
 		D->t_wait += t1 - t0;
 		if (si == PQ_END) break;
@@ -2335,7 +2360,9 @@ static void *profile_dev_thread(void *arg) {
 			if (s->has_seed) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)s->seed.s, s->seed.l, s->seed_has_name ? s->seed_name : NULL));
 			memset(&up, 0, sizeof up);
 			up.pool_mode = 2; up.n_targets = P->hdr->n_targets; up.last = s->last;
-			unpack_slot(P, s, unpack, &up, &ur, &db);                     /* (synchronises: the slot's bytes have left) */
+			unpack_slot_enqueue(P, s, unpack, &up);
+			if (S->n_dev == 1) pending = unpack_slot_ahead(P, unpack);
+			unpack_slot_finish(P, s, unpack, &up, &ur, &db);              /* (synchronises: the slot's bytes have left) */
 			if (ur.n_records > 0) MSX(msx_profile_accumulate(g_ctx, D->prof, &db, NULL));
 			D->n_in += (size_t)ur.n_records;
 			D->n_batches++;
@@ -2493,7 +2520,7 @@ int msam_profile_main(int argc, char *argv[]) {
 		if (P.n_filled == 0) { rbatch e; memset(&e, 0, sizeof e); S.qn = qn_check(hdr, &e); }     /* an empty input is still checked (:708) */
 		qn = S.qn;
 		if (getenv("MSX_TIMING")) {
-			fprintf(stderr, "# batches: %zu%s\n", n_batches, P.comp_mode ? "; BGZF blocks inflated on the device" : "");
+			fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.n_ahead, P.comp_mode ? "; BGZF blocks inflated on the device" : "");
 			if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
 			fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 			        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);

@@ -508,11 +508,6 @@ extern "C" int msx_dev_to_host_async(msx_ctx *ctx, void *host, const void *dev, 
 }
 
 // ---- stream markers ------------------------------------------------------------------------------
-struct msx_event {
-	hipEvent_t ev = nullptr;
-	bool recorded = false;
-};
-
 extern "C" int msx_event_create(msx_ctx *ctx, msx_event **out) {
 	if (!ctx || !out) return MSX_ERR_ARG;
 	MSX_HIP(ctx, hipSetDevice(ctx->device));

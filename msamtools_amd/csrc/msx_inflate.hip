@@ -32,14 +32,20 @@
 #include <cstdlib>
 #include <cstring>
 
+// LDS per block: 4 KB + 1 KB + 1 KB + 4 KB + 1.3 KB = 11.3 KB, fourteen blocks per compute unit
 #define IF_LL_ROOT 10
-#define IF_D_ROOT 9
-#define IF_RING 8192u
+#define IF_D_ROOT 8
+#ifndef IF_RING
+#define IF_RING 4096u
+#endif
 #define IF_RMASK (IF_RING - 1u)
-#define IF_FLUSH 2048u
+#define IF_FLUSH (IF_RING / 4u)
 #define IF_NEAR (IF_RING - 512u)
-#define IF_IN_DW 512u
-#define IF_IN_HALF 256u
+#ifndef IF_IN_HALF
+#define IF_IN_HALF 128u              // words per half of the input ring: 64 lanes x 2
+#endif
+#define IF_IN_DW (2u * IF_IN_HALF)
+#define IF_LANE_DW (IF_IN_HALF / 64u)
 
 // table entry: bits 0-3 code length, 4-7 kind, 8-11 extra bits, 16-31 payload (literal / base)
 #define IF_LIT 1u
@@ -64,13 +70,16 @@ struct IfShared {
 	uint32_t dt[1 << IF_D_ROOT];
 	uint32_t in[IF_IN_DW];
 	__attribute__((aligned(16))) uint8_t ring[IF_RING];
-	uint32_t pre[128];                 // the code-length code: 7 bits
 	uint32_t lim[2][16], first[2][16]; // per code length, left-aligned to 15 bits: end and start of its codes
 	uint16_t off[2][16];               // first place of a length's symbols in sorted[]
-	uint16_t sorted[2][320];
+	union {
+		uint16_t sorted[320];          // [0, 288) literal/length symbols by code, [288, 320) distance symbols
+		uint32_t pre[128];             // the code-length code (7 bits): done with before sorted[] is written
+	};
 	uint8_t lens[352];
 	uint8_t pl[32];
 };
+#define IF_SORTED(S, which) ((S).sorted + ((which) ? 288 : 0))
 
 #ifndef IF_FAR_LOAD
 #define IF_FAR_LOAD(p) (*(const uint8_t *)(p))
@@ -114,10 +123,11 @@ struct IfState {
 	uint32_t status;
 };
 
+struct __attribute__((aligned(4 * IF_LANE_DW))) if_vec { uint32_t v[IF_LANE_DW]; };   // a lane's share of a chunk of the input ring
 struct IfIn {
 	const uint32_t *g;    // aligned base of the stream
 	uint32_t n_bytes;     // bytes that may be read from g
-	uint4 ahead;          // this lane's 16 bytes of the chunk after the two staged ones
+	if_vec ahead;         // this lane's words of the chunk after the two staged ones
 };
 
 // word d of the stream where the buffer ends inside or in front of it
@@ -127,22 +137,20 @@ __device__ __noinline__ uint32_t if_edge_word(const uint8_t *p, uint32_t n_bytes
 		if (4u * d + k < n_bytes) v |= (uint32_t)p[4u * d + k] << (8u * k);
 	return v;
 }
-__device__ __forceinline__ uint4 if_load_chunk(const IfIn &I, uint32_t chunk, uint32_t lane) {
-	const uint32_t d = chunk * IF_IN_HALF + lane * 4u;
-	uint4 v;
-	if (4u * d + 16u <= I.n_bytes) {
-		v = *reinterpret_cast<const uint4 *>(I.g + d);
+__device__ __forceinline__ if_vec if_load_chunk(const IfIn &I, uint32_t chunk, uint32_t lane) {
+	const uint32_t d = chunk * IF_IN_HALF + lane * IF_LANE_DW;
+	if_vec v;
+	if (4u * d + 4u * IF_LANE_DW <= I.n_bytes) {
+		v = *reinterpret_cast<const if_vec *>(I.g + d);
 	} else {
 		const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
-		v.x = if_edge_word(p, I.n_bytes, d);
-		v.y = if_edge_word(p, I.n_bytes, d + 1u);
-		v.z = if_edge_word(p, I.n_bytes, d + 2u);
-		v.w = if_edge_word(p, I.n_bytes, d + 3u);
+#pragma unroll
+		for (uint32_t k = 0; k < IF_LANE_DW; k++) v.v[k] = if_edge_word(p, I.n_bytes, d + k);
 	}
 	return v;
 }
-__device__ __forceinline__ void if_store_chunk(IfShared &S, uint32_t chunk, uint32_t lane, const uint4 &v) {
-	*reinterpret_cast<uint4 *>(&S.in[(chunk & 1u) * IF_IN_HALF + lane * 4u]) = v;
+__device__ __forceinline__ void if_store_chunk(IfShared &S, uint32_t chunk, uint32_t lane, const if_vec &v) {
+	*reinterpret_cast<if_vec *>(&S.in[(chunk & 1u) * IF_IN_HALF + lane * IF_LANE_DW]) = v;
 }
 
 // one word of the stream taken: when the read position enters the next chunk, the chunk behind it is done with -- the
@@ -243,7 +251,7 @@ __device__ __forceinline__ uint32_t if_build(IfShared &S, uint32_t which, uint32
 		// sorted[]: the symbols of this length in symbol order
 #pragma unroll
 		for (int j = 0; j < 5; j++)
-			if (L[j] == len) S.sorted[which][offs + (code[j] - nxt)] = (uint16_t)(lane + 64u * j);
+			if (L[j] == len) IF_SORTED(S, which)[offs + (code[j] - nxt)] = (uint16_t)(lane + 64u * j);
 		offs += cnt;
 		n_codes += cnt;
 		nxt = (nxt + cnt) << 1;
@@ -273,7 +281,7 @@ __device__ __forceinline__ uint32_t if_long(IfShared &S, uint32_t which, uint32_
 		if (c15 < lim) {
 			const uint32_t first = IFU(S.first[which][len]);
 			if (c15 < first) return 0u;
-			const uint32_t sym = IFU(S.sorted[which][IFU(S.off[which][len]) + ((c15 - first) >> (15u - len))]);
+			const uint32_t sym = IFU(IF_SORTED(S, which)[IFU(S.off[which][len]) + ((c15 - first) >> (15u - len))]);
 			const uint32_t e = which ? if_d_entry(sym) : if_ll_entry(sym);
 			return e ? (e | len) : 0u;
 		}
@@ -285,18 +293,22 @@ template <int DBG>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, size_t comp_len,
                                                      const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
-                                                     uint32_t *__restrict__ stats) {
+                                                     uint32_t *__restrict__ ticket, uint32_t *__restrict__ stats) {
 	__shared__ IfShared S;
-	uint32_t n_lit = 0u, n_match = 0u, n_far = 0u, n_dyn = 0u;      // (MSX_INFLATE_STATS: what the blocks are made of)
 	const uint32_t lane = threadIdx.x;
-	const uint32_t bi = blockIdx.x;
+	// the launch holds as many waves as are to run at a time; each takes block after block
+	for (;;) {
+	uint32_t n_lit = 0u, n_match = 0u, n_far = 0u, n_dyn = 0u;      // (MSX_INFLATE_STATS: what the blocks are made of)
+	uint32_t bi = 0u;
+	if (lane == 0) bi = atomicAdd(ticket, 1u);
+	bi = IFU(bi);
 	if (bi >= n_blocks) return;
 	const msx_bgzf_block B = blk[bi];
 	uint8_t *og = out + B.out_off;
 	const uint32_t out_len = B.out_len;
 	if (out_len == 0u) {
 		if (lane == 0) status[bi] = IF_OK;
-		return;
+		continue;
 	}
 	IfIn I;
 	{
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			if (len > out_len - T.pos) IF_FAIL(IF_OUT_OVER);
 			const uint8_t *src = reinterpret_cast<const uint8_t *>(I.g) + bp;
 			for (uint32_t done_b = 0; done_b < len;) {
-				const uint32_t piece = len - done_b < 1024u ? len - done_b : 1024u;
+				const uint32_t piece = len - done_b < IF_FLUSH ? len - done_b : IF_FLUSH;
 				for (uint32_t i = lane; i < piece; i += 64u) S.ring[IF_RI(T.pos + i)] = src[done_b + i];
 				T.pos += piece;
 				done_b += piece;
@@ -586,6 +598,7 @@ done:
 	if (stats && lane == 0) {
 		atomicAdd(&stats[0], n_lit); atomicAdd(&stats[1], n_match); atomicAdd(&stats[2], n_far); atomicAdd(&stats[3], n_dyn);
 	}
+	}
 #undef IF_RI
 #undef IF_FAIL
 }
@@ -671,17 +684,26 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restric
 // ---------------------------------------------------------------------------
 // ABI
 // ---------------------------------------------------------------------------
+#define IF_PER_CU 14                      // waves per compute unit: what its LDS holds
 static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate only): device counters
 
-int msx_bgzf_inflate_launch(msx_ctx *ctx, const uint8_t *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks, int64_t n_blocks,
-                            uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
+int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
+                            const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
 	if (n_blocks <= 0) return MSX_OK;
-	static int dbg = -1;
-	if (dbg < 0) dbg = getenv("MSX_INFLATE_DBG") ? atoi(getenv("MSX_INFLATE_DBG")) : 0;
-#define IF_LAUNCH(D) hipLaunchKernelGGL(k_bgzf_inflate<D>, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_comp, comp_len, d_blocks, \
-	                   (uint32_t)n_blocks, d_out, d_status, if_stats)
+	static int dbg = -1, per_cu_env = 0;
+	if (dbg < 0) {
+		dbg = getenv("MSX_INFLATE_DBG") ? atoi(getenv("MSX_INFLATE_DBG")) : 0;
+		per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
+	}
+	int per_cu = per_cu_env > 0 ? per_cu_env : waves_per_cu > 0 ? waves_per_cu : IF_PER_CU;
+	if (per_cu > IF_PER_CU) per_cu = IF_PER_CU;
+	int64_t grid = (int64_t)per_cu * ctx->num_cu;
+	if (grid > n_blocks) grid = n_blocks;
+	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 4, stream));      // the ticket
+#define IF_LAUNCH(D) hipLaunchKernelGGL(k_bgzf_inflate<D>, dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
+	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 1, if_stats)
 	if (dbg == 1) IF_LAUNCH(1); else if (dbg == 2) IF_LAUNCH(2); else if (dbg == 3) IF_LAUNCH(3); else IF_LAUNCH(0);
-	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_blocks, (uint32_t)n_blocks,
+	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
@@ -699,7 +721,7 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 	MSX_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
 	const bool want_stats = getenv("MSX_INFLATE_STATS") != nullptr;
 	if (want_stats) { if_stats = d_bad + 4; MSX_HIP(ctx, hipMemsetAsync(if_stats, 0, 16, ctx->stream)); }
-	rc = msx_bgzf_inflate_launch(ctx, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad);
+	rc = msx_bgzf_inflate_launch(ctx, ctx->stream, 0, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad);
 	if_stats = nullptr;
 	if (rc) return rc;
 	if (want_stats) {

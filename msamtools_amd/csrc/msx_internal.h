@@ -109,6 +109,11 @@ struct msx_ctx {
 	std::vector<hipEvent_t> event_pool;
 };
 
+struct msx_event {
+	hipEvent_t ev = nullptr;
+	bool recorded = false;
+};
+
 int msx_fail(msx_ctx *ctx, int code, const char *fmt, ...);
 // fork / join around independent chains (no-ops returning false when timing is on or lanes are off):
 //   if (msx_fork(ctx)) ...; msx_lane_enter(ctx, i); <launches>; msx_lane_leave(ctx); ...; msx_join(ctx);
@@ -117,9 +122,9 @@ void msx_lane_enter(msx_ctx *ctx, int lane);
 void msx_lane_leave(msx_ctx *ctx);
 void msx_join(msx_ctx *ctx);
 int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes);
-// msx_inflate.hip: inflate + CRC check of n_blocks BGZF blocks on ctx->stream; *d_n_bad (zeroed by the caller) counts the refused
-int msx_bgzf_inflate_launch(msx_ctx *ctx, const uint8_t *d_comp, size_t comp_len, const msx_bgzf_block *d_blocks, int64_t n_blocks,
-                            uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad);
+// msx_inflate.hip: inflate + CRC check of n_blocks BGZF blocks on `stream`, waves_per_cu waves per compute unit (0: all the LDS holds); d_n_bad[0] (zeroed by the caller) counts the refused, d_n_bad[1] is the launch's ticket counter
+int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
+                            const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad);
 extern thread_local std::string msx_tls_err;
 
 #define MSX_HIP(ctx, call)                                                              \

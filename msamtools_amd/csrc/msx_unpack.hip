@@ -38,6 +38,7 @@ struct up_state {
 	uint32_t cut_any, cut_mapped;  // last pool boundary (record index) / last one whose record is mapped, in the batch's second half
 	uint32_t n_batch, n_groups, cut_off;
 	uint32_t inflate_bad;          // msx_unpack_enqueue_bgzf: blocks the device inflater refused
+	uint32_t inflate_ticket;       // ... and the counter its waves draw their blocks from (msx_bgzf_inflate_launch: d_n_bad[1])
 	uint32_t has_prev;             // prev_name holds the QNAME of the last naming record of earlier batches
 	uint32_t emit_bytes;
 };
@@ -50,6 +51,16 @@ struct msx_unpack {
 	msx_buf seg_first, seg_end, seg_cnt, seg_base;
 	msx_buf comp, blk, blk_status;  // msx_unpack_enqueue_bgzf: the compressed payloads, their table, the inflater's verdicts
 	bool bgzf = false;              // the current batch came in compressed
+	// msx_unpack_prefetch_bgzf: the NEXT batch uploaded and inflated on a stream of its own while the current one is walked,
+	// filtered and fetched -- into a staging buffer (the carry it will follow is not known yet); msx_unpack_enqueue_bgzf
+	// then copies it behind the carry
+	hipStream_t inf_stream = nullptr;
+	hipEvent_t inf_done = nullptr, stage_free = nullptr;
+	msx_buf pre_comp, pre_blk, pre_status, pre_out, pre_cnt;
+	const uint8_t *pre_key = nullptr;
+	size_t pre_comp_len = 0, pre_total = 0;
+	int64_t pre_nblk = 0;
+	bool pre_bgzf = false, stage_used = false;
 	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
 	    group_off, tile_last, cigar, md, out_len, out_off, out;
 	char *prev_name = nullptr;     // device, 256 bytes
@@ -60,6 +71,9 @@ struct msx_unpack {
 	// msx_unpack_prefetch: the next batch's bytes on their way up (a stream of its own) while the current batch is filtered
 	hipStream_t copy_stream = nullptr;
 	hipEvent_t copy_done = nullptr;
+	hipEvent_t out_copied = nullptr;   // msx_unpack_emit_async: the gather buffer has been read
+	bool out_busy = false;
+	size_t gathered = 0;               // msx_unpack_emit_gather: bytes in `out`
 	const uint8_t *pre_host = nullptr;
 	size_t pre_n = 0;
 };
@@ -528,7 +542,8 @@ extern "C" int msx_unpack_create(msx_ctx *ctx, msx_unpack **out) {
 	(void)hipMemsetAsync(u->prev_name, 0, 256, ctx->stream);
 	(void)hipMemsetAsync(u->d_state, 0, sizeof(up_state), ctx->stream);
 	if (hipStreamCreateWithFlags(&u->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-	    hipEventCreateWithFlags(&u->copy_done, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&u->copy_done, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&u->out_copied, hipEventDisableTiming) != hipSuccess) {
 		msx_unpack_destroy(ctx, u);
 		return msx_fail(ctx, MSX_ERR_HIP, "msx_unpack_create: stream setup failed");
 	}
@@ -539,13 +554,19 @@ extern "C" int msx_unpack_create(msx_ctx *ctx, msx_unpack **out) {
 extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (!u) return;
 	if (ctx && ctx->stream) { msx_join(ctx); (void)hipStreamSynchronize(ctx->stream); }
+	if (u->inf_stream) (void)hipStreamSynchronize(u->inf_stream);
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
-	                   &u->out_off, &u->out, &u->comp, &u->blk, &u->blk_status};
+	                   &u->out_off, &u->out, &u->comp, &u->blk, &u->blk_status, &u->pre_comp, &u->pre_blk,
+	                   &u->pre_status, &u->pre_out, &u->pre_cnt};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
+	if (u->inf_stream) { (void)hipStreamSynchronize(u->inf_stream); (void)hipStreamDestroy(u->inf_stream); }
+	if (u->inf_done) (void)hipEventDestroy(u->inf_done);
+	if (u->stage_free) (void)hipEventDestroy(u->stage_free);
 	if (u->copy_done) (void)hipEventDestroy(u->copy_done);
+	if (u->out_copied) (void)hipEventDestroy(u->out_copied);
 	if (u->prev_name) (void)hipFree(u->prev_name);
 	if (u->d_state) (void)hipFree(u->d_state);
 	if (u->h_state) (void)hipHostFree(u->h_state);
@@ -664,36 +685,106 @@ static int up_enqueue_walk(msx_ctx *ctx, msx_unpack *u, size_t n, const msx_unpa
 	return MSX_OK;
 }
 
+static int up_check_table(msx_ctx *ctx, const msx_bgzf_block *host_blocks, int64_t n_blocks, size_t comp_len, size_t *n_new_out) {
+	size_t n_new = 0;
+	for (int64_t i = 0; i < n_blocks; i++) {
+		const msx_bgzf_block &b = host_blocks[i];
+		if (b.out_off != n_new || b.out_len > 65536u || b.in_off > comp_len || b.in_len > comp_len - b.in_off)
+			return msx_fail(ctx, MSX_ERR_ARG, "BGZF block %lld of the table is inconsistent", (long long)i);
+		n_new += b.out_len;
+	}
+	*n_new_out = n_new;
+	return MSX_OK;
+}
+
+// The bytes of the NEXT msx_unpack_enqueue_bgzf, sent ahead and inflated on a stream of their own.  May be called at any
+// time (also between msx_unpack_enqueue* and msx_unpack_finish of the current batch): nothing here depends on the carry.
+extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
+                                        const msx_bgzf_block *host_blocks, int64_t n_blocks) {
+	if (!ctx || !u || n_blocks <= 0 || !host_comp || !host_blocks) return MSX_ERR_ARG;
+	if (u->pre_bgzf) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_prefetch_bgzf: one batch is on its way already");
+	if (n_blocks > (1 << 24)) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_prefetch_bgzf: too many blocks");
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	size_t n_new = 0;
+	if ((rc = up_check_table(ctx, host_blocks, n_blocks, comp_len, &n_new))) return rc;
+	if (!u->inf_stream) {
+		int lo = 0, hi = 0;
+		MSX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));           // (lo: the least urgent)
+		MSX_HIP(ctx, hipStreamCreateWithPriority(&u->inf_stream, hipStreamNonBlocking, lo));
+		MSX_HIP(ctx, hipEventCreateWithFlags(&u->inf_done, hipEventDisableTiming));
+		MSX_HIP(ctx, hipEventCreateWithFlags(&u->stage_free, hipEventDisableTiming));
+	}
+	// (the buffers may be in use by the copy of the batch before: grown only behind that copy)
+	if (u->stage_used) MSX_HIP(ctx, hipStreamWaitEvent(u->inf_stream, u->stage_free, 0));
+	if (u->pre_comp.cap < comp_len + 64 || u->pre_blk.cap < (size_t)n_blocks * sizeof(msx_bgzf_block) ||
+	    u->pre_status.cap < (size_t)n_blocks * 4 || u->pre_out.cap < n_new + 64) {
+		if (u->stage_used) MSX_HIP(ctx, hipEventSynchronize(u->stage_free));
+		MSX_HIP(ctx, hipStreamSynchronize(u->inf_stream));
+	}
+	UP_RES(pre_comp, comp_len + 64);
+	UP_RES(pre_blk, (size_t)n_blocks * sizeof(msx_bgzf_block));
+	UP_RES(pre_status, (size_t)n_blocks * 4);
+	UP_RES(pre_out, n_new + 64);
+	UP_RES(pre_cnt, 64);
+	MSX_HIP(ctx, hipMemsetAsync(u->pre_cnt.p, 0, 8, u->inf_stream));
+	MSX_HIP(ctx, hipMemcpyAsync(u->pre_comp.p, host_comp, comp_len, hipMemcpyHostToDevice, u->inf_stream));
+	MSX_HIP(ctx, hipMemcpyAsync(u->pre_blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, u->inf_stream));
+	// (eight waves per compute unit: the batch beside it needs LDS too -- k_besthit_select waited a whole inflate kernel for
+	// its share when ten were resident -- and the command line's batches of 2048 blocks are eight per compute unit anyway)
+	if ((rc = msx_bgzf_inflate_launch(ctx, u->inf_stream, 8, (const uint8_t *)u->pre_comp.p, comp_len, (const msx_bgzf_block *)u->pre_blk.p,
+	                                  n_blocks, (uint8_t *)u->pre_out.p, (uint32_t *)u->pre_status.p, (uint32_t *)u->pre_cnt.p)))
+		return rc;
+	MSX_HIP(ctx, hipEventRecord(u->inf_done, u->inf_stream));
+	u->pre_bgzf = true;
+	u->pre_key = host_comp;
+	u->pre_comp_len = comp_len;
+	u->pre_nblk = n_blocks;
+	u->pre_total = n_new;
+	return MSX_OK;
+}
+
 // The batch's new bytes arrive compressed: BGZF payloads and their table (msx_bgzf_block, out_off from the batch's first
 // new byte).  They are inflated behind the carry, where msx_unpack_enqueue would have copied them.
 extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
                                        const msx_bgzf_block *host_blocks, int64_t n_blocks, const msx_unpack_params *prm) {
 	if (!ctx || !u || !prm || n_blocks < 0 || (n_blocks > 0 && (!host_comp || !host_blocks))) return MSX_ERR_ARG;
 	if (u->pre_n != 0) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf after msx_unpack_prefetch");
+	if (u->enqueued) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf between msx_unpack_enqueue and msx_unpack_finish");
 	if (n_blocks > (1 << 24)) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: too many blocks");
 	msx_join(ctx);
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
 	size_t n_new = 0;
-	for (int64_t i = 0; i < n_blocks; i++) {
-		const msx_bgzf_block &b = host_blocks[i];
-		if (b.out_off != n_new || b.out_len > 65536u || b.in_off > comp_len || b.in_len > comp_len - b.in_off)
-			return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: block %lld of the table is inconsistent", (long long)i);
-		n_new += b.out_len;
+	const bool sent = u->pre_bgzf && u->pre_key == host_comp && u->pre_comp_len == comp_len && u->pre_nblk == n_blocks;
+	if (u->pre_bgzf && !sent) {
+		MSX_HIP(ctx, hipStreamSynchronize(u->inf_stream));
+		u->pre_bgzf = false;
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: other blocks than msx_unpack_prefetch_bgzf sent ahead");
 	}
+	if (sent) n_new = u->pre_total;
+	else if ((rc = up_check_table(ctx, host_blocks, n_blocks, comp_len, &n_new))) return rc;
 	const size_t n = u->carry_len + n_new;
 	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: more than 4 GiB in one batch");
-	int rc;
 	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;
 	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
 	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 4, ctx->stream));
-	if (n_blocks > 0) {
+	if (sent) {
+		// inflated already, in the staging buffer: behind the carry with it, and the verdict into this batch's state
+		u->pre_bgzf = false;
+		MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->inf_done, 0));
+		if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, u->pre_out.p, n_new, hipMemcpyDeviceToDevice, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(&u->d_state->inflate_bad, u->pre_cnt.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+		MSX_HIP(ctx, hipEventRecord(u->stage_free, ctx->stream));
+		u->stage_used = true;
+	} else if (n_blocks > 0) {
 		UP_RES(comp, comp_len + 64);
 		UP_RES(blk, (size_t)n_blocks * sizeof(msx_bgzf_block));
 		UP_RES(blk_status, (size_t)n_blocks * 4);
 		MSX_HIP(ctx, hipMemcpyAsync(u->comp.p, host_comp, comp_len, hipMemcpyHostToDevice, ctx->stream));
 		MSX_HIP(ctx, hipMemcpyAsync(u->blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, ctx->stream));
-		if ((rc = msx_bgzf_inflate_launch(ctx, (const uint8_t *)u->comp.p, comp_len, (const msx_bgzf_block *)u->blk.p, n_blocks,
+		if ((rc = msx_bgzf_inflate_launch(ctx, ctx->stream, 0, (const uint8_t *)u->comp.p, comp_len, (const msx_bgzf_block *)u->blk.p, n_blocks,
 		                                  raw + u->carry_len, (uint32_t *)u->blk_status.p, &u->d_state->inflate_bad)))
 			return rc;
 	}
@@ -806,12 +897,16 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	return MSX_OK;
 }
 
-extern "C" int msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, uint8_t *host_out,
-                               size_t host_cap, int64_t *n_bytes) {
-	if (!ctx || !u || !n_bytes || (n_emit > 0 && (!emit_idx_dev || !host_out))) return MSX_ERR_ARG;
+// Filter's output records gathered into one byte string on the device (block_size prefixes included, output order);
+// *n_bytes tells how long it is.  msx_unpack_emit_fetch brings it down.
+extern "C" int msx_unpack_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int64_t *n_bytes) {
+	if (!ctx || !u || !n_bytes || (n_emit > 0 && !emit_idx_dev)) return MSX_ERR_ARG;
 	msx_join(ctx);
 	*n_bytes = 0;
+	u->gathered = 0;
 	if (n_emit <= 0) return MSX_OK;
+	// (the gather buffer may still be on its way down for the batch before)
+	if (u->out_busy) { MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->out_copied, 0)); u->out_busy = false; }
 	if (n_emit > u->n_batch) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: more records than the batch holds");
 	int rc;
 	const uint32_t ne = (uint32_t)n_emit;
@@ -828,12 +923,39 @@ extern "C" int msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_
 	                   (const uint32_t *)u->rec_off.p, (const uint32_t *)u->out_off.p, (uint8_t *)u->out.p, u->d_state);
 	MSX_HIP(ctx, hipGetLastError());
 	if ((rc = up_fetch_state(ctx, u))) return rc;                   // sync: how many bytes
-	const size_t tb = u->h_state->emit_bytes;
-	if (tb > host_cap) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: output buffer too small (%zu > %zu)", tb, host_cap);
-	MSX_HIP(ctx, hipMemcpyAsync(host_out, u->out.p, tb, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*n_bytes = (int64_t)tb;
+	u->gathered = u->h_state->emit_bytes;
+	*n_bytes = (int64_t)u->gathered;
 	return MSX_OK;
+}
+
+// The gathered bytes to the host.  done == NULL: waits for them.  Otherwise they travel on a copy stream of their own while
+// the caller goes on with the next batch; msx_event_wait(done) before host_out is read.
+extern "C" int msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_out, size_t host_cap, msx_event *done) {
+	if (!ctx || !u || (u->gathered && !host_out)) return MSX_ERR_ARG;
+	if (done) done->recorded = false;
+	const size_t tb = u->gathered;
+	if (tb == 0) return MSX_OK;
+	if (tb > host_cap) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: output buffer too small (%zu > %zu)", tb, host_cap);
+	if (!done) {
+		MSX_HIP(ctx, hipMemcpyAsync(host_out, u->out.p, tb, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		return MSX_OK;
+	}
+	// (the kernels that wrote u->out have been waited for by msx_unpack_emit_gather)
+	MSX_HIP(ctx, hipMemcpyAsync(host_out, u->out.p, tb, hipMemcpyDeviceToHost, u->copy_stream));
+	MSX_HIP(ctx, hipEventRecord(u->out_copied, u->copy_stream));
+	MSX_HIP(ctx, hipEventRecord(done->ev, u->copy_stream));
+	u->out_busy = true;
+	done->recorded = true;
+	return MSX_OK;
+}
+
+extern "C" int msx_unpack_emit(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, uint8_t *host_out,
+                               size_t host_cap, int64_t *n_bytes) {
+	if (n_emit > 0 && !host_out) return MSX_ERR_ARG;
+	int rc = msx_unpack_emit_gather(ctx, u, emit_idx_dev, n_emit, n_bytes);
+	if (rc) return rc;
+	return msx_unpack_emit_fetch(ctx, u, host_out, host_cap, nullptr);
 }
 
 // for tests: the record offsets of the batch (u32 [n_records + 1], relative to the batch's first byte)

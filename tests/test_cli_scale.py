@@ -101,7 +101,7 @@ def mid(tmp_path_factory):
 def n_batches(stderr):
     for line in stderr.decode().split("\n"):
         if line.startswith("# batches:"):
-            return int(line.split()[2])
+            return int(line.split()[2].rstrip(";"))
     return None
 
 
