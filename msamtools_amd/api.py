@@ -374,6 +374,27 @@ class Unpack:
                              int(cut_mapped), 0)
         self.ctx.check(self.ctx.lib.msx_unpack_enqueue(self.ctx.h, self.h, self._keep, len(data), C.byref(prm)))
 
+    def _prm(self, pool_mode, want_aux, want_stats, n_targets, last, cut_mapped, unmapped_visible):
+        return L.UnpackParams(pool_mode, int(unmapped_visible), int(want_aux), int(want_stats), int(n_targets), int(last),
+                              int(cut_mapped), 0)
+
+    def prefetch_bgzf(self, comp, blocks, n_blocks):
+        """msx_unpack_prefetch_bgzf; pass the object this returns to enqueue_bgzf"""
+        buf = (C.c_uint8 * max(len(comp), 1)).from_buffer_copy(bytes(comp) or b"\0")
+        self.ctx.check(self.ctx.lib.msx_unpack_prefetch_bgzf(self.ctx.h, self.h, buf, len(comp), blocks, n_blocks))
+        return (buf, len(comp), blocks, n_blocks)
+
+    def enqueue_bgzf(self, comp, blocks=None, n_blocks=None, pool_mode=0, want_aux=True, want_stats=True, n_targets=1 << 30,
+                     last=False, cut_mapped=False, unmapped_visible=False):
+        """the batch's new bytes as BGZF payloads (api.bgzf_blocks); `comp` may be what prefetch_bgzf returned"""
+        if isinstance(comp, tuple):
+            buf, n, blocks, n_blocks = comp
+        else:
+            buf, n = (C.c_uint8 * max(len(comp), 1)).from_buffer_copy(bytes(comp) or b"\0"), len(comp)
+        self._keep = (buf, blocks)
+        prm = self._prm(pool_mode, want_aux, want_stats, n_targets, last, cut_mapped, unmapped_visible)
+        self.ctx.check(self.ctx.lib.msx_unpack_enqueue_bgzf(self.ctx.h, self.h, buf, n, blocks, n_blocks, C.byref(prm)))
+
     def finish(self):
         """(UnpackResult, DeviceBatch view -- owned by the unpacker: do not free)"""
         res = L.UnpackResult()

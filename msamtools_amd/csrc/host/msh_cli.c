@@ -1772,6 +1772,7 @@ static void *filter_dev_thread(void *arg) {
 			unpack_slot_enqueue(P, s, unpack, &up);
 			if (F->n_dev == 1) pending = unpack_slot_ahead(P, unpack);
 			unpack_slot_finish(P, s, unpack, &up, &ur, &db);
+			if (F->n_dev == 1 && pending == PQ_NONE) pending = unpack_slot_ahead(P, unpack);   /* (not decoded yet a moment ago?) */
 			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
 			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
 			 * default: measured, it changes nothing (upload phase 0.35-0.40 s of the 100 M-record run either way).  The
@@ -1814,6 +1815,7 @@ static void *filter_dev_thread(void *arg) {
 				}
 				D->t_gpu += now_s() - t1; t1 = now_s();
 				s->n_emit = st.n_emit;
+				if (F->n_dev == 1 && pending == PQ_NONE) pending = unpack_slot_ahead(P, unpack);
 				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
 				 * while the next batch is worked on: the writer waits for s->ev_out */
 				MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));

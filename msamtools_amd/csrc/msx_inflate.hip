@@ -681,6 +681,11 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restric
 	}
 }
 
+__global__ void k_bgzf_refuse(uint32_t n_blocks, uint32_t every, uint32_t *__restrict__ status, uint32_t *__restrict__ n_bad) {
+	for (uint32_t i = threadIdx.x * every; i < n_blocks; i += 64u * every)
+		if (status[i] == IF_OK) { status[i] = IF_BAD_CODE; atomicAdd(n_bad, 1u); }
+}
+
 // ---------------------------------------------------------------------------
 // ABI
 // ---------------------------------------------------------------------------
@@ -705,6 +710,10 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 	if (dbg == 1) IF_LAUNCH(1); else if (dbg == 2) IF_LAUNCH(2); else if (dbg == 3) IF_LAUNCH(3); else IF_LAUNCH(0);
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
+	// MSX_INFLATE_REFUSE=<n> (tests): every n-th block is reported as refused, whatever the decoder made of it
+	static int refuse = -1;
+	if (refuse < 0) refuse = getenv("MSX_INFLATE_REFUSE") ? atoi(getenv("MSX_INFLATE_REFUSE")) : 0;
+	if (refuse > 0) hipLaunchKernelGGL(k_bgzf_refuse, dim3(1), dim3(64), 0, stream, (uint32_t)n_blocks, (uint32_t)refuse, d_status, d_n_bad);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }

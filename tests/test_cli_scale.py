@@ -136,6 +136,27 @@ def test_filter_digest_many_batches(big, tmp_path, inflag, outflag):
     big.check_digest(out, big.digest_out)
 
 
+@pytest.mark.parametrize("env", [dict(MSX_INFLATE_REFUSE=7), dict(MSX_HOST_INFLATE=1), dict(MSX_NO_INFLATE_AHEAD=1),
+                                 dict(MSX_INFLATE_WAVES=3)])
+def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
+    """BGZF blocks are inflated on the device (msx_inflate.hip); batches with a block the device refuses (here: every 7th
+    block, by a test switch) are inflated on the host instead; MSX_HOST_INFLATE=1 inflates everything there.  Same output."""
+    out, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {out}", MSX_TIMING=1, **env)
+    assert n_batches(r.stderr) >= 20
+    err = r.stderr.decode()
+    if "MSX_INFLATE_REFUSE" in env:
+        assert "inflated on the host (blocks the device refused)" in err
+    elif "MSX_HOST_INFLATE" in env:
+        assert "inflated on the device" not in err
+    else:
+        assert "inflated on the device" in err and "refused" not in err
+    big.check_digest(out, big.digest_out)
+    big.check_profile(p, big.pipe)
+    r = sh(f"{BIN} profile --label S -o {p} {big.bam['b']}", MSX_TIMING=1, **env)
+    big.check_profile(p, big.plain)
+
+
 def test_filter_through_pipes(big, tmp_path):
     """stdin from a pipe (the reader thread's ring), stdout into a pipe (vmsplice hand-over)."""
     out = str(tmp_path / "f.bam")

@@ -51,9 +51,26 @@ def offsets_of(stream):
     return np.asarray(off, dtype=np.int64)
 
 
-def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False, want_stats=True, prefetch=False):
-    """feeds the stream in chunks, checks every batch against `rec`; returns the list of (first record, n, groups)"""
+def as_blocks(chunk, level=6, piece=65280):
+    """the chunk as BGZF payloads: (compressed buffer, table, number of blocks)"""
+    import zlib
     import msamtools_amd as m
+    datas = [chunk[i:i + piece] for i in range(0, len(chunk), piece)]
+    payloads = []
+    for d in datas:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payloads.append(co.compress(d) + co.flush())
+    comp, blocks, total = m.bgzf_blocks(payloads, datas)
+    assert total == len(chunk)
+    return comp, blocks, len(datas)
+
+
+def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False, want_stats=True, prefetch=False, feed="plain"):
+    """feeds the stream in chunks, checks every batch against `rec`; returns the list of (first record, n, groups).
+    feed: "plain" inflated bytes (msx_unpack_enqueue); "bgzf" the chunk as compressed blocks (msx_unpack_enqueue_bgzf);
+    "bgzf_ahead" the same with the next chunk's blocks sent and inflated ahead (msx_unpack_prefetch_bgzf)"""
+    import msamtools_amd as m
+    ahead = None
     pools = {0: None, 1: m.filter_pools(rec), 2: m.profile_pools(rec)}[pool_mode]
     off = offsets_of(stream)
     up = m.Unpack(ctx)
@@ -66,7 +83,19 @@ def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False
             chunk = stream[pos:pos + sz]
             pos += len(chunk)
             last = pos >= len(stream)
-            up.enqueue(chunk, pool_mode=pool_mode, n_targets=n_ref, last=last, cut_mapped=cut_mapped, want_stats=want_stats)
+            kw = dict(pool_mode=pool_mode, n_targets=n_ref, last=last, cut_mapped=cut_mapped, want_stats=want_stats)
+            if feed == "plain" or len(chunk) == 0:
+                up.enqueue(chunk, **kw)
+            else:
+                if ahead is not None:
+                    up.enqueue_bgzf(ahead, **kw)
+                else:
+                    up.enqueue_bgzf(*as_blocks(chunk, level=(1, 6, 9)[k % 3]), **kw)
+                ahead = None
+                if feed == "bgzf_ahead" and not last:     # between enqueue and finish: nothing of it depends on the carry
+                    nxt = stream[pos:pos + chunk_sizes[k % len(chunk_sizes)]]
+                    if len(nxt):
+                        ahead = up.prefetch_bgzf(*as_blocks(nxt, level=(1, 6, 9)[(k + 1) % 3]))
             res, view = up.finish()
             if prefetch and not last:        # the next chunk goes up while this batch is looked at
                 up.prefetch(stream[pos:pos + chunk_sizes[k % len(chunk_sizes)]])
@@ -141,6 +170,61 @@ def test_prefetched_chunks(ctx, synth):
     up.prefetch(stream[:1000])
     with pytest.raises(m.MsxError, match="other bytes"):
         up.enqueue(stream[:2000], pool_mode=1, n_targets=n_ref)
+    up.close()
+
+
+@pytest.mark.parametrize("feed", ["bgzf", "bgzf_ahead"])
+@pytest.mark.parametrize("pool_mode", [1, 2])
+def test_chunks_that_arrive_compressed(ctx, synth, feed, pool_mode):
+    """msx_unpack_enqueue_bgzf / msx_unpack_prefetch_bgzf: the same batches as from inflated bytes"""
+    stream, n_ref, rec = synth
+    sizes = [3_000_001, 777_777, 5_000_000, 123_456, 64]
+    plain = run_chunks(ctx, stream, n_ref, rec, sizes, pool_mode)
+    assert run_chunks(ctx, stream, n_ref, rec, sizes, pool_mode, feed=feed) == plain
+
+
+def test_a_refused_block_leaves_the_carry_alone(ctx, synth):
+    """a damaged block: msx_unpack_finish says MSX_ERR_INFLATE and has consumed nothing -- the same chunk handed over
+    inflated (what the command line does with such a batch) continues the stream"""
+    import msamtools_amd as m
+    stream, n_ref, rec = synth
+    off = offsets_of(stream)
+    up = m.Unpack(ctx)
+    up.seed()
+    a, b = stream[:2_000_000], stream[2_000_000:4_500_000]
+    up.enqueue_bgzf(*as_blocks(a), pool_mode=1, n_targets=n_ref)
+    r1, _ = up.finish()
+    comp, blocks, nb = as_blocks(b)
+    bad = bytearray(comp)
+    for q in range(blocks[3].in_off + 40, blocks[3].in_off + 60):
+        bad[q] ^= 0x5a
+    up.enqueue_bgzf(bytes(bad), blocks, nb, pool_mode=1, n_targets=n_ref)
+    with pytest.raises(m.MsxError, match="refused by the device inflater") as ei:
+        up.finish()
+    assert ei.value.code == -15
+    up.enqueue(b, pool_mode=1, n_targets=n_ref)
+    r2, view = up.finish()
+    n1, n2 = int(r1.n_records), int(r2.n_records)
+    assert n1 > 0 and n2 > 0
+    assert off[n1] == r1.bytes_consumed and off[n1 + n2] - off[n1] == r2.bytes_consumed
+    assert np.array_equal(view.fetch("flag", n2, np.uint16), rec.flag[n1:n1 + n2])
+    # sent ahead and damaged: the verdict arrives with the batch it belongs to
+    c = stream[4_500_000:6_000_000]
+    comp, blocks, nb = as_blocks(c)
+    bad = bytearray(comp)
+    bad[blocks[1].in_off + 30] ^= 0xff
+    h = up.prefetch_bgzf(bytes(bad), blocks, nb)
+    up.enqueue_bgzf(h, pool_mode=1, n_targets=n_ref)
+    with pytest.raises(m.MsxError, match="refused by the device inflater"):
+        up.finish()
+    up.enqueue(c, pool_mode=1, n_targets=n_ref)
+    r3, view = up.finish()
+    n3 = int(r3.n_records)
+    assert np.array_equal(view.fetch("tid", n3, np.int32), rec.tid[n1 + n2:n1 + n2 + n3])
+    # other blocks than the ones sent ahead
+    h = up.prefetch_bgzf(*as_blocks(c[:100_000]))
+    with pytest.raises(m.MsxError, match="other blocks"):
+        up.enqueue_bgzf(*as_blocks(c[:200_000]), pool_mode=1, n_targets=n_ref)
     up.close()
 
 
