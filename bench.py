@@ -189,7 +189,62 @@ def profile_parity(path, stats, abundance, refs, ref_len):
             "ok": bool(counts == want_counts and rel <= 1e-6 + 1e-7)}
 
 
-def e2e_cli(groups, refs, expect=None, seq=False):
+def inflate_probe(m, ctx, path, n_blocks=8192):
+    """msx_bgzf_inflate (msx_inflate.hip) on the first blocks of a BAM file: rate, the device's own CRC verdicts, and a
+    sample of the blocks against zlib."""
+    import ctypes as C
+    import struct
+    import zlib
+    import numpy as np
+    from msamtools_amd import _lib as L
+    raw = open(path, "rb").read(n_blocks * 70000)
+    blocks, pos = [], 0
+    while pos + 18 <= len(raw) and len(blocks) < n_blocks:
+        xlen = struct.unpack_from("<H", raw, pos + 10)[0]
+        bsize = struct.unpack_from("<H", raw, pos + 16)[0] + 1
+        if pos + bsize > len(raw):
+            break
+        crc, isize = struct.unpack_from("<II", raw, pos + bsize - 8)
+        blocks.append((pos + 12 + xlen, bsize - 12 - xlen - 8, isize, crc))
+        pos += bsize
+    n = len(blocks)
+    arr = (L.BgzfBlock * n)()
+    uo = 0
+    for i, (io, il, ol, crc) in enumerate(blocks):
+        arr[i].in_off, arr[i].in_len, arr[i].out_off, arr[i].out_len, arr[i].crc32 = io, il, uo, ol, crc
+        uo += ol
+    d_comp, d_blk, d_out, d_st = ctx.alloc(pos + 64), ctx.alloc(32 * n), ctx.alloc(uo + 64), ctx.alloc(4 * n)
+    try:
+        ctx.to_dev(d_comp, np.frombuffer(raw[:pos], np.uint8))
+        ctx.to_dev(d_blk, np.frombuffer(bytes(arr), np.uint8))
+        ref = C.c_int64()
+        ts = []
+        for _ in range(5):
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.msx_bgzf_inflate(ctx.h, C.c_void_p(d_comp), pos, C.c_void_p(d_blk), n, C.c_void_p(d_out), C.c_void_p(d_st),
+                                               C.byref(ref)))
+            ts.append(time.perf_counter() - t0)
+        best = min(ts[1:])
+        out = ctx.to_host(d_out, uo, np.uint8)
+        sample = list(range(0, n, max(1, n // 256)))
+        t0 = time.perf_counter()
+        ok = all(zlib.decompress(raw[blocks[i][0]:blocks[i][0] + blocks[i][1]], -15) == out[arr[i].out_off:arr[i].out_off + arr[i].out_len].tobytes()
+                 for i in sample)
+        zs = time.perf_counter() - t0
+        zbytes = sum(blocks[i][2] for i in sample)
+        return {"blocks": n, "compressed_MB": round(pos / 1e6, 1), "inflated_MB": round(uo / 1e6, 1), "ms": round(best * 1e3, 3),
+                "GBps_inflated": round(uo / best / 1e9, 1), "blocks_refused": int(ref.value),
+                "sample_equals_zlib": bool(ok), "sample_blocks": len(sample),
+                "zlib_one_core_GBps": round(zbytes / zs / 1e9, 2),
+                "frac_of_hbm_peak": round((pos + uo) / best / 8e12, 4),
+                "bound": "not memory: one wave per block decodes serially -- scalar issue and LDS latency (DESIGN.md section 5)"}
+    finally:
+        for q in (d_comp, d_blk, d_out, d_st):
+            ctx.free(q)
+
+
+def e2e_cli(groups, refs, expect=None, seq=False, probe=None):
     """The command line end to end on this box: a synthetic BAM of `groups` QNAME groups (BGZF level 6; records
     without SEQ/QUAL, or ~250 B records with them: seq) through `msamtools filter -l 80 -p 95 -z 80 --besthit -bu |
     msamtools profile -` -- the reference's own two-process workflow -- through either command alone, and through
@@ -255,6 +310,14 @@ def e2e_cli(groups, refs, expect=None, seq=False):
             dt_n, err_n = run(f"{exe} {filt} --profile-out {tmp}/pn.gz --label S {tmp}/in.bam > /dev/null")
             tee["alignments_discarded"] = {"M_alignments_per_s": round(n / dt_n / 1e6, 2), "seconds": round(dt_n, 3),
                                            "note": "stdout to /dev/null (filter's BAM is formed and framed, not stored)"}
+            # A/B: the same command with BGZF inflate on the host cores instead of the device (MSX_HOST_INFLATE=1)
+            env["MSX_HOST_INFLATE"] = "1"
+            try:
+                dt_h, err_h = run(f"{exe} {filt} --profile-out {tmp}/ph.gz --label S {tmp}/in.bam > {tmp}/fh.bam")
+            finally:
+                del env["MSX_HOST_INFLATE"]
+            tee["host_inflate"] = {"M_alignments_per_s": round(n / dt_h / 1e6, 2), "seconds": round(dt_h, 3), **stages(err_h, "filter")}
+            os.remove(f"{tmp}/fh.bam")
         except RuntimeError as exc:
             tee = {"error": str(exc)[:200]}
         sf, sp = stages(err_fp, "filter"), stages(err_fp, "profile")
@@ -274,6 +337,11 @@ def e2e_cli(groups, refs, expect=None, seq=False):
             "synth_s": round(synth_s, 1),
             "note": "stage times are busy times of overlapping pipeline stages (decode | device | encode), not a sum",
         }
+        if probe is not None:
+            try:
+                res["inflate"] = probe(f"{tmp}/in.bam")
+            except Exception as exc:
+                res["inflate"] = {"error": str(exc)[:200]}
         if expect is not None:
             # ---- the outputs against the oracle's for the same stream ----
             par = {}
@@ -802,9 +870,15 @@ def main():
     ctx.close()
     if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
         e2e_refs = nrefs if args.e2e_groups == ng else 100_000
-        out["e2e"] = e2e_cli(args.e2e_groups, e2e_refs, locals().get("e2e_expect"))
+        def probe(path):          # (a context of its own, after the command lines have had the device to themselves)
+            c = m.Context(0)
+            try:
+                return inflate_probe(m, c, path)
+            finally:
+                c.close()
+        out["e2e"] = e2e_cli(args.e2e_groups, e2e_refs, locals().get("e2e_expect"), probe=probe)
         if args.e2e_seq_groups:
-            out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True)
+            out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True, probe=probe)
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
         try:

@@ -5,9 +5,19 @@ import zlib
 import numpy as np
 import pytest
 
-import msamtools_amd as m
-
 pytestmark = pytest.mark.gpu
+
+
+class _Lazy:
+    """(the library is loaded when a test first needs it, not while the test files are being collected: another test
+    file imports torch during collection, and torch's own copy of the ROCm runtime must not be the second one in)"""
+
+    def __getattr__(self, name):
+        import msamtools_amd
+        return getattr(msamtools_amd, name)
+
+
+m = _Lazy()
 
 
 @pytest.fixture(scope="module")
