@@ -17,6 +17,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """Test files must not load the library while they are being collected: tests/test_gpu_two_ranks.py asks torch for
+    the device count during collection, and a process that loads /opt/rocm's runtime first (through the library) and
+    torch's bundled copy second ends up with two HSA runtimes -- RCCL then fails to initialise (seen as
+    "pfn_hsa_system_get_info failed" / "no ROCm-capable device is detected" in every in-process RCCL test)."""
+    if "msamtools_amd" in sys.modules:
+        raise pytest.UsageError("a test module imported msamtools_amd during collection (import it inside tests and fixtures)")
+
+
 @pytest.fixture(scope="session")
 def expectations():
     import json

@@ -8,21 +8,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-class _Lazy:
+def M():
     """(the library is loaded when a test first needs it, not while the test files are being collected: another test
-    file imports torch during collection, and torch's own copy of the ROCm runtime must not be the second one in)"""
-
-    def __getattr__(self, name):
-        import msamtools_amd
-        return getattr(msamtools_amd, name)
-
-
-m = _Lazy()
+    file imports torch during collection, and torch's bundled copy of the ROCm runtime must not be the second one in)"""
+    import msamtools_amd
+    return msamtools_amd
 
 
 @pytest.fixture(scope="module")
 def ctx():
-    c = m.Context(0)
+    c = M().Context(0)
     yield c
     c.close()
 
@@ -90,8 +85,8 @@ def test_every_case_inflates_to_what_zlib_made_it_from(ctx):
     for pl, d in zip(payloads, datas):
         assert zlib.decompress(pl, -15) == d
     for gap in (0, 1, 2, 3, 7):            # every alignment of the streams
-        comp, blocks, total = m.bgzf_blocks(payloads, datas, gap=gap)
-        out, st, refused = m.bgzf_inflate(ctx, comp, blocks, len(cs), total)
+        comp, blocks, total = M().bgzf_blocks(payloads, datas, gap=gap)
+        out, st, refused = M().bgzf_inflate(ctx, comp, blocks, len(cs), total)
         bad = [(cs[i][0], int(st[i])) for i in range(len(cs)) if st[i] != 0]
         assert not bad and refused == 0, bad
         o = 0
@@ -109,8 +104,8 @@ def test_many_blocks_of_a_bam_like_stream(ctx):
     stream = bam_like(rng, 3_000_000)
     datas = [stream[i:i + 65280] for i in range(0, len(stream), 65280)]
     payloads = [raw_deflate(d, level=(1, 6, 9)[i % 3]) for i, d in enumerate(datas)]
-    comp, blocks, total = m.bgzf_blocks(payloads, datas)
-    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, len(datas), total)
+    comp, blocks, total = M().bgzf_blocks(payloads, datas)
+    out, st, refused = M().bgzf_inflate(ctx, comp, blocks, len(datas), total)
     assert refused == 0 and not st.any()
     assert out[:total].tobytes() == stream
 
@@ -130,8 +125,8 @@ def test_damaged_blocks_are_refused_and_nothing_hangs(ctx):
         elif i % 4 == 3:
             b = bytearray(rng.integers(0, 256, len(b), dtype=np.uint8).tobytes())   # noise
         payloads.append(bytes(b))
-    comp, blocks, total = m.bgzf_blocks(payloads, datas)
-    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, len(datas), total)
+    comp, blocks, total = M().bgzf_blocks(payloads, datas)
+    out, st, refused = M().bgzf_inflate(ctx, comp, blocks, len(datas), total)
     o = 0
     for i, d in enumerate(datas):
         if i % 4 == 0:
@@ -142,10 +137,10 @@ def test_damaged_blocks_are_refused_and_nothing_hangs(ctx):
         o += len(d)
     assert refused == int((st != 0).sum())
     # a wrong CRC in the trailer alone
-    comp, blocks, total = m.bgzf_blocks(good[:4], datas[:4], crcs=[zlib.crc32(d) ^ (i == 2) for i, d in enumerate(datas[:4])])
-    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, 4, total)
+    comp, blocks, total = M().bgzf_blocks(good[:4], datas[:4], crcs=[zlib.crc32(d) ^ (i == 2) for i, d in enumerate(datas[:4])])
+    out, st, refused = M().bgzf_inflate(ctx, comp, blocks, 4, total)
     assert list(st) == [0, 0, 8, 0] and refused == 1
     # a wrong length in the trailer
-    comp, blocks, total = m.bgzf_blocks(good[:2], [datas[0], datas[1][:-5]], crcs=[zlib.crc32(datas[0]), zlib.crc32(datas[1])])
-    out, st, refused = m.bgzf_inflate(ctx, comp, blocks, 2, total)
+    comp, blocks, total = M().bgzf_blocks(good[:2], [datas[0], datas[1][:-5]], crcs=[zlib.crc32(datas[0]), zlib.crc32(datas[1])])
+    out, st, refused = M().bgzf_inflate(ctx, comp, blocks, 2, total)
     assert st[0] == 0 and st[1] != 0
