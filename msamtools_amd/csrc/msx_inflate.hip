@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			}
 			if (S.lens[256] == 0) IF_FAIL(IF_BAD_LENS);       // a block must be able to end
 		}
-		n_dyn++;
+		if (DBG == 4) n_dyn++;
 		if (!if_build(S, 0u, 0u, hlit, lane)) IF_FAIL(IF_BAD_LENS);
 		if (!if_build(S, 1u, hlit, hdist, lane)) IF_FAIL(IF_BAD_LENS);
 		// ---- the symbols of the block ----
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 						ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
 						if (lane == 0) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
 						T.pos++;
-						n_lit++;
+						if (DBG == 4) n_lit++;
 						continue;
 					}
 					if (((e >> 4) & 15u) != IF_BASE) break;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 							}
 						}
 					} else {
-						n_far++;
+						if (DBG == 4) n_far++;
 						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 						for (uint32_t b = 0; b < len; b += 64u) {
 							const uint32_t i = b + lane;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 						}
 					}
 					T.pos += len;
-					n_match++;
+					if (DBG == 4) n_match++;
 				}
 				if (err) IF_FAIL(err);
 			}
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 				ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
 				if (lane == 0 && DBG != 3) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
 				T.pos++;
-				n_lit++;
+				if (DBG == 4) n_lit++;
 			} else if (kind == IF_EOB) {
 				break;
 			} else {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 				} else {
 					// out of the ring's reach: those bytes were written back at least IF_NEAR - IF_FLUSH - 258 bytes ago (the
 					// wave reads its own stores: workgroup scope)
-					n_far++;
+					if (DBG == 4) n_far++;
 					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 					for (uint32_t b = 0; b < len; b += 64u) {
 						const uint32_t i = b + lane;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 					}
 				}
 				T.pos += len;
-				n_match++;
+				if (DBG == 4) n_match++;
 			}
 			if (IF_BITPOS(T) > end_bit) IF_FAIL(IF_IN_OVER);
 			if (T.pos - T.flushed >= IF_FLUSH) {
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 done:
 	if (T.status == IF_OK) if_flush(S, T, og, T.pos, lane);
 	if (lane == 0) status[bi] = T.status;
-	if (stats && lane == 0) {
+	if (DBG == 4 && stats && lane == 0) {
 		atomicAdd(&stats[0], n_lit); atomicAdd(&stats[1], n_match); atomicAdd(&stats[2], n_far); atomicAdd(&stats[3], n_dyn);
 	}
 	}
@@ -608,7 +608,7 @@ done:
 // ---------------------------------------------------------------------------
 #define CRC_POLY 0xedb88320u
 // a * b mod P; bit 31 is the coefficient of x^0
-__device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
+__host__ __device__ constexpr uint32_t crc_mul(uint32_t a, uint32_t b) {
 	uint32_t r = 0u;
 	for (int k = 0; k < 32; k++) {
 		if (a & (0x80000000u >> k)) r ^= b;
@@ -617,7 +617,7 @@ __device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
 	return r;
 }
 // x^(8 n) mod P
-__device__ __forceinline__ uint32_t crc_xpow8(uint32_t n) {
+__host__ __device__ constexpr uint32_t crc_xpow8(uint32_t n) {
 	uint32_t r = 0x80000000u, p = 0x00800000u;       // 1, x^8
 	while (n) {
 		if (n & 1u) r = crc_mul(r, p);
@@ -626,7 +626,16 @@ __device__ __forceinline__ uint32_t crc_xpow8(uint32_t n) {
 	}
 	return r;
 }
+#define CRC_SLICE 64u                                 // bytes per lane and pass
+#define CRC_PASS (64u * CRC_SLICE)                    // bytes per pass of a wave
 
+// One wave per block, in passes of 4 KB: every lane takes 64 consecutive bytes (a pass reads 4 KB of consecutive
+// memory: every fetched line is used whole while it is in the L1) and runs them through the table.  The register is
+// linear in what has been fed: state(A || B) = state(A) * x^(8 |B|) + state(B).  Slices are aligned to the END of the
+// block, so that everything to the right of a slice is full slices: a lane chains its own slices of successive passes
+// with one constant (x^(8 * 4096), Horner), moves its sum over the (63 - lane) slices to its right at the end, and the
+// lanes' results are added up.  What is short or empty is the front of the first pass, and a state of 0 contributes
+// nothing.  The lane that holds byte 0 starts from the register's initial value (all ones).
 __global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
                                                  const uint8_t *__restrict__ out, uint32_t *__restrict__ status,
                                                  uint32_t *__restrict__ n_bad) {
@@ -650,33 +659,33 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restric
 		if (lane == 0 && B.crc32 != 0u) { status[bi] = IF_BAD_CRC; atomicAdd(n_bad, 1u); }
 		return;
 	}
-	// 64 slices of `per` bytes, aligned to the END of the block: the slices to the right of any lane are full, so joining
-	// state(A || B) = state(A) * x^(8 |B|) + state(B) needs one multiplier per step.  The lane that holds byte 0 starts from
-	// the register's initial value (all ones); lanes in front of it hold nothing and contribute 0.
-	const uint32_t per = ((n + 63u) / 64u + 3u) & ~3u;
-	const int64_t lo_s = (int64_t)n - (int64_t)(64u - lane) * per;
-	const uint32_t lo = lo_s > 0 ? (uint32_t)lo_s : 0u;
-	const int64_t hi_s = lo_s + per;
-	const uint32_t hi = hi_s > 0 ? (uint32_t)hi_s : 0u;
+	constexpr uint32_t X_PASS = crc_xpow8(CRC_PASS);
 	const uint8_t *p = out + B.out_off;
-	uint32_t s = (hi > 0u && lo == 0u) ? 0xffffffffu : 0u;
-	uint32_t i = lo;
-	for (; i + 4u <= hi; i += 4u) {
-		const uint32_t w = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(p + i);
-		s = tab[(s ^ w) & 0xffu] ^ (s >> 8);
-		s = tab[(s ^ (w >> 8)) & 0xffu] ^ (s >> 8);
-		s = tab[(s ^ (w >> 16)) & 0xffu] ^ (s >> 8);
-		s = tab[(s ^ (w >> 24)) & 0xffu] ^ (s >> 8);
+	const uint32_t n_pass = (n + CRC_PASS - 1u) / CRC_PASS;
+	uint32_t acc = 0u;                               // this lane's slices of all passes: Horner over the passes
+	for (uint32_t q = 0; q < n_pass; q++) {
+		// this pass ends (n_pass - 1 - q) passes in front of the block's end
+		const int64_t pass_end = (int64_t)n - (int64_t)(n_pass - 1u - q) * CRC_PASS;
+		const int64_t lo_s = pass_end - (int64_t)(64u - lane) * CRC_SLICE;
+		const uint32_t hi = (uint32_t)(lo_s + CRC_SLICE > 0 ? lo_s + CRC_SLICE : 0);
+		const uint32_t lo = lo_s > 0 ? (uint32_t)lo_s : 0u;
+		uint32_t s = (hi > 0u && lo == 0u) ? 0xffffffffu : 0u;
+		uint32_t i = lo;
+		for (; i + 4u <= hi; i += 4u) {
+			const uint32_t w = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(p + i);
+			s = tab[(s ^ w) & 0xffu] ^ (s >> 8);
+			s = tab[(s ^ (w >> 8)) & 0xffu] ^ (s >> 8);
+			s = tab[(s ^ (w >> 16)) & 0xffu] ^ (s >> 8);
+			s = tab[(s ^ (w >> 24)) & 0xffu] ^ (s >> 8);
+		}
+		for (; i < hi; i++) s = tab[(s ^ p[i]) & 0xffu] ^ (s >> 8);
+		acc = crc_mul(acc, X_PASS) ^ s;
 	}
-	for (; i < hi; i++) s = tab[(s ^ p[i]) & 0xffu] ^ (s >> 8);
-	uint32_t X = crc_xpow8(per);
-	for (uint32_t step = 1; step < 64u; step <<= 1) {
-		const uint32_t os = (uint32_t)__shfl_down((int)s, step);
-		if ((lane & (2u * step - 1u)) == 0u) s = crc_mul(s, X) ^ os;
-		X = crc_mul(X, X);
-	}
+	// the lanes' sums, each moved over the 64-byte slices to its right, added up
+	uint32_t t = crc_mul(acc, crc_xpow8(CRC_SLICE * (63u - lane)));
+	for (uint32_t step = 32u; step >= 1u; step >>= 1) t ^= (uint32_t)__shfl_xor((int)t, step);
 	if (lane == 0) {
-		const uint32_t crc = ~s;
+		const uint32_t crc = ~t;
 		if (crc != B.crc32) { status[bi] = IF_BAD_CRC; atomicAdd(n_bad, 1u); }
 	}
 }
@@ -707,7 +716,7 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 4, stream));      // the ticket
 #define IF_LAUNCH(D) hipLaunchKernelGGL(k_bgzf_inflate<D>, dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
 	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 1, if_stats)
-	if (dbg == 1) IF_LAUNCH(1); else if (dbg == 2) IF_LAUNCH(2); else if (dbg == 3) IF_LAUNCH(3); else IF_LAUNCH(0);
+	if (if_stats) IF_LAUNCH(4); else if (dbg == 1) IF_LAUNCH(1); else if (dbg == 2) IF_LAUNCH(2); else if (dbg == 3) IF_LAUNCH(3); else IF_LAUNCH(0);
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
 	// MSX_INFLATE_REFUSE=<n> (tests): every n-th block is reported as refused, whatever the decoder made of it
