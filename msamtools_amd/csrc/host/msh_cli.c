@@ -633,6 +633,8 @@ static void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int 
 /* ------------------------------------------------------------------------ */
 #define PIPE_SLOTS 3                    /* with one device; one more per further device */
 #define PIPE_SLOTS_MAX (PIPE_SLOTS + MSH_MAX_DEVICES)
+#define PIPE_OBUFS 4                    /* page-locked output buffers of the device-unpack path */
+#define PIPE_SLOTS_COMP 6               /* slots when the batches arrive compressed (a slot is 40 MB of payloads then) */
 #define MSH_POOL_MAX 128
 #define PQ_END (-1)                     /* queue item: end of the stream (one per consumer) */
 #define BGZF_INFLATE_MAX ((size_t)1024 * 65536)   /* msh_inflate_append appends at most one batch of blocks (msh_io.c: BGZF_BATCH x BGZF_MAX) */
@@ -695,7 +697,8 @@ typedef struct {
 	msx_bgzf_block *blk;
 	size_t inflated;           /* bytes the table's blocks inflate to */
 	int pin_ready;             /* rbuf is page-locked and obuf allocated (pin_mu) */
-	uint8_t *obuf;             /* filter's output records of the batch (msx_unpack_emit_async), page-locked */
+	int ob;                    /* the output buffer this batch holds (pipe_t.ob[]), -1: none */
+	uint8_t *obuf;             /* = P->ob[ob]: filter's output records of the batch (msx_unpack_emit_fetch), page-locked */
 	msx_event *ev_out;         /* ... are there once this has been waited for */
 	msx_ctx *ev_ctx;
 	size_t ocap, olen;
@@ -715,6 +718,11 @@ typedef struct {
 	size_t n_ahead;                /* batches whose blocks were sent and inflated ahead (msx_unpack_prefetch_bgzf) */
 	int comp_mode, comp_blocks;    /* ... and inflated there as well: the decode stage only copies the blocks' payloads */
 	size_t ocap_cfg;
+	/* output buffers are a pool of their own: a slot is the decode stage's unit (a buffer of compressed blocks), and the
+	 * decoder must not run out of slots because the writer still holds the outputs of earlier batches */
+	uint8_t *ob[PIPE_OBUFS];
+	size_t ob_cap[PIPE_OBUFS];
+	pq q_ob;
 	int raw_started, raw_done;
 	int first_state, first_slot;   /* 0: batch 0 not decoded yet; 1: it is, in slot first_slot; 2: the input holds no record (first_mu) */
 	int out_opened;                /* the preflight has passed and the output is open (first_mu) */
@@ -777,7 +785,8 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	if (P->cap_rec < COORD_ORDER_CHECK_RECORDS + 1024) P->cap_rec = COORD_ORDER_CHECK_RECORDS + 1024;
 	P->cap_cig = want_stats ? 2 * P->cap_rec : 4;
 	P->cap_md = want_stats ? 16 * P->cap_rec : 16;
-	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out);
+	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out); pq_init(&P->q_ob);
+	for (i = 0; i < PIPE_SLOTS_MAX; i++) P->slot[i].ob = -1;
 	pthread_mutex_init(&P->first_mu, NULL);
 	pthread_cond_init(&P->first_cv, NULL);
 	for (i = 0; i < P->n_slots; i++) {
@@ -812,17 +821,25 @@ static void *pin_thread(void *arg) {
 	pipe_t *P = (pipe_t *)A->P;
 	int k;
 	g_ctx = P->pin_ctx;
+	int j = A->first;
 	for (k = 1 + A->first; k <= P->n_slots; k += A->step) {
 		pslot *s = &P->slot[k % P->n_slots];
 		if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, s->rbuf, s->rcap));
-		if (P->pin_obuf) {
-			s->ocap = P->ocap_cfg;
-			MSX(msx_host_alloc(g_ctx, (void **)&s->obuf, s->ocap));
-		}
 		pthread_mutex_lock(&P->pin_mu);
 		s->pin_ready = 1;
 		pthread_cond_broadcast(&P->pin_cv);
 		pthread_mutex_unlock(&P->pin_mu);
+		if (P->pin_obuf && j < PIPE_OBUFS) {          /* (an output buffer for every input buffer, while there are any) */
+			P->ob_cap[j] = P->ocap_cfg;
+			MSX(msx_host_alloc(g_ctx, (void **)&P->ob[j], P->ob_cap[j]));
+			pq_push(&P->q_ob, j);
+			j += A->step;
+		}
+	}
+	for (; P->pin_obuf && j < PIPE_OBUFS; j += A->step) {
+		P->ob_cap[j] = P->ocap_cfg;
+		MSX(msx_host_alloc(g_ctx, (void **)&P->ob[j], P->ob_cap[j]));
+		pq_push(&P->q_ob, j);
 	}
 	return NULL;
 }
@@ -900,6 +917,10 @@ static void pipe_enable_raw(pipe_t *P) {
 	P->comp_blocks = (int)env_size("MSX_COMP_BLOCKS", getenv("MSX_BATCH_BYTES") ? P->batch_bytes_cfg / 65280 : 2048);
 	if (P->comp_blocks < 1) P->comp_blocks = 1;
 	if (P->comp_blocks > (1 << 16)) P->comp_blocks = 1 << 16;
+	/* compressed batches need nothing of a slot but its buffer of payloads: two more of them (batch 0, walked on the host,
+	 * has taken its slot -- one of the first -- by the time these are used) */
+	if (P->comp_mode && !getenv("MSX_SLOTS") && P->n_consumers == 1)
+		while (P->n_slots < PIPE_SLOTS_COMP && P->n_slots < PIPE_SLOTS_MAX) pq_push(&P->q_free, P->n_slots++);
 	for (i = 0; i < P->n_slots; i++) {
 		pslot *s = &P->slot[i];
 		if (P->comp_mode) {
@@ -1487,7 +1508,11 @@ static void gz_member(const kstr *in, kstr *out) {
 	z_stream zs;
 	size_t bound;
 	memset(&zs, 0, sizeof zs);
-	if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("deflateInit2 failed");
+	/* level 4 rather than gzip's 6: the million-line profile of the bench compresses in 25 ms instead of 59 per thread and
+	 * comes out 5 % larger (7.1 MB instead of 6.8); MSX_GZ_LEVEL=6 for the reference's level */
+	static int level = 0;
+	if (!level) { const char *e = getenv("MSX_GZ_LEVEL"); level = e && atoi(e) >= 1 && atoi(e) <= 9 ? atoi(e) : 4; }
+	if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) mDie("deflateInit2 failed");
 	bound = deflateBound(&zs, (uLong)in->l) + 64;
 	out->l = 0;
 	ks_reserve(out, bound);
@@ -1665,6 +1690,8 @@ typedef struct {
 	pthread_t th;
 	double t_ctx, t_upload, t_gpu, t_fetch, t_wait;
 	size_t n_prefetched;
+	double t_end[64];            /* MSX_TIMING: when the first batches left this stage */
+	int n_end;
 } fdev_t;
 
 struct fshared {
@@ -1677,6 +1704,10 @@ struct fshared {
 	qn_result qn;
 	const prof_opts *po;        /* filter --profile-out, else NULL */
 	const prof_feat *pf;
+	/* one device: its thread finalizes and writes the profile as soon as the last batch is accumulated, beside the
+	 * writer's last batches (profile_done); not when a batch held a record the reference dies at (any_fatal) */
+	int profile_done, any_fatal;
+	double t_finalized, t_reported;
 	fdev_t dev[MSH_MAX_DEVICES];
 };
 
@@ -1798,6 +1829,7 @@ static void *filter_dev_thread(void *arg) {
 				else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
 				if (msx_filter_finish(g_ctx, &st) != MSX_OK) {
 					s->fatal = 1;
+					F->any_fatal = 1;
 					snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
 					st.n_emit = 0;
 					if (P->mode == 1 && st.err_record >= 0 && ur.n_groups > 0) {
@@ -1819,10 +1851,15 @@ static void *filter_dev_thread(void *arg) {
 				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
 				 * while the next batch is worked on: the writer waits for s->ev_out */
 				MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
-				if ((size_t)nb + 64 > s->ocap) {
-					if (s->obuf) msx_host_free(g_ctx, s->obuf);
-					s->ocap = (size_t)nb + (size_t)nb / 4 + ((size_t)4 << 20);
-					MSX(msx_host_alloc(g_ctx, (void **)&s->obuf, s->ocap));
+				if (nb > 0) {
+					s->ob = pq_pop(&P->q_ob);                /* (waits for the writer when all of them are on their way out) */
+					if ((size_t)nb + 64 > P->ob_cap[s->ob]) {
+						if (P->ob[s->ob]) msx_host_free(g_ctx, P->ob[s->ob]);
+						P->ob_cap[s->ob] = (size_t)nb + (size_t)nb / 4 + ((size_t)4 << 20);
+						MSX(msx_host_alloc(g_ctx, (void **)&P->ob[s->ob], P->ob_cap[s->ob]));
+					}
+					s->obuf = P->ob[s->ob];
+					s->ocap = P->ob_cap[s->ob];
 				}
 				if (!s->ev_out) MSX(msx_event_create(g_ctx, &s->ev_out));
 				MSX(msx_unpack_emit_fetch(g_ctx, unpack, s->obuf, s->ocap, s->ev_out));
@@ -1830,6 +1867,7 @@ static void *filter_dev_thread(void *arg) {
 				s->olen = (size_t)nb;
 				D->t_fetch += now_s() - t1;
 			}
+			if (D->n_end < 64) D->t_end[D->n_end++] = now_s();
 			pq_push(&P->q_out, si);
 			continue;
 		}
@@ -1845,6 +1883,7 @@ static void *filter_dev_thread(void *arg) {
 		else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
 		if (msx_filter_finish(g_ctx, &st) != MSX_OK) {          /* the reference's own mDie texts; see fatal_prefix */
 			s->fatal = 1;
+			F->any_fatal = 1;
 			snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
 			st.n_emit = 0;
 			if (P->mode == 1 && st.err_record >= 0 && b->n_groups > 0) {
@@ -1865,13 +1904,31 @@ static void *filter_dev_thread(void *arg) {
 		pq_push(&P->q_out, si);
 	}
 	MSX(msx_ctx_sync(g_ctx));
-	pin_join(P);
-	msx_stage_destroy(g_ctx, stage);
-	msx_unpack_destroy(g_ctx, unpack);
 	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
 	pthread_mutex_lock(&F->mu);
 	if (++F->n_done == F->n_dev) pq_push(&P->q_out, PQ_END);
 	pthread_mutex_unlock(&F->mu);
+	if (F->po && F->n_dev == 1 && !F->any_fatal && D->prof && __atomic_load_n(&P->n_filled, __ATOMIC_ACQUIRE) > 0) {
+		msx_ctx *ctxs[1] = {g_ctx};
+		msx_profile *profs[1] = {D->prof};
+		msx_profile_stats pst;
+		double *row = (double *)calloc((size_t)F->pf->n_features + 1, sizeof(double));
+		char *cl = command_line(F->argc, F->argv);
+		/* (the preflight's verdict is part of the report: the writer thread has it once the output is open) */
+		pthread_mutex_lock(&P->first_mu);
+		while (!P->out_opened) pthread_cond_wait(&P->first_cv, &P->first_mu);
+		pthread_mutex_unlock(&P->first_mu);
+		profile_combine_and_finalize(ctxs, profs, 1, F->po->share_type, row, &pst);
+		F->t_finalized = now_s();
+		profile_report(F->po, F->pf, &pst, row, &F->qn, cl);
+		F->t_reported = now_s();
+		free(row);
+		free(cl);
+		F->profile_done = 1;
+	}
+	pin_join(P);
+	msx_stage_destroy(g_ctx, stage);
+	msx_unpack_destroy(g_ctx, unpack);
 	return NULL;
 }
 
@@ -1944,7 +2001,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	static fshared F;
 	prof_feat pf;
 	pthread_t th_dec;
-	double t_start = now_s(), tw = 0, t_wait = 0;
+	double t_start = now_s(), tw = 0, t_wait = 0, t_tail[4] = {0, 0, 0, 0};
 	size_t n_in = 0, n_out = 0, n_batches = 0, seq = 0;
 	int dev_ids[MSH_MAX_DEVICES], k;
 	rescore_job RJ;
@@ -1999,6 +2056,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		if (s->raw) {
 			if (s->ev_out && s->olen) { if (msx_event_wait(s->ev_ctx, s->ev_out) != MSX_OK) mDie("%s", msx_last_error(s->ev_ctx)); }
 			msh_write_stream(F.out, s->obuf, s->olen);
+			if (s->ob >= 0) { pq_push(&P.q_ob, s->ob); s->ob = -1; }
 		} else if (!fp->rescore) {
 			msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
 		} else if (s->n_emit > 0) {
@@ -2033,10 +2091,15 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		tw += now_s() - t1;
 		pq_push(&P.q_free, si);
 	}
+	t_tail[0] = now_s();
 	pthread_join(th_dec, NULL);
 	for (k = 0; k < F.n_dev; k++) pthread_join(F.dev[k].th, NULL);
 	msh_out_close(F.out);
-	if (po) {
+	t_tail[1] = now_s();
+	if (po && F.profile_done) {
+		t_tail[2] = F.t_finalized; t_tail[3] = F.t_reported;
+		g_ctx = F.dev[0].ctx;
+	} else if (po) {
 		/* the other half of `filter ... | profile -`, without the pipe, the second decode and the second process */
 		msx_ctx *ctxs[MSH_MAX_DEVICES];
 		msx_profile *profs[MSH_MAX_DEVICES];
@@ -2045,7 +2108,9 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		char *cl = command_line(argc, argv);
 		for (k = 0; k < F.n_dev; k++) { ctxs[k] = F.dev[k].ctx; profs[k] = F.dev[k].prof; }
 		profile_combine_and_finalize(ctxs, profs, F.n_dev, po->share_type, row, &st);
+		t_tail[2] = now_s();
 		profile_report(po, &pf, &st, row, &F.qn, cl);
+		t_tail[3] = now_s();
 		free(row);
 		free(cl);
 	} else {
@@ -2059,6 +2124,13 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.comp_mode ? P.n_ahead : F.dev[0].n_prefetched,
 		        P.comp_mode ? "; BGZF blocks inflated on the device" : "");
 		if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
+		if (F.dev[0].n_end) {
+			int q;
+			fprintf(stderr, "# device stage, batches done at (ms):");
+			for (q = 0; q < F.dev[0].n_end; q++) fprintf(stderr, " %.0f", (F.dev[0].t_end[q] - t_start) * 1e3);
+			fprintf(stderr, "; writer done %.0f, output closed %.0f, profile finalized %.0f, written %.0f\n", (t_tail[0] - t_start) * 1e3,
+			        (t_tail[1] - t_start) * 1e3, (t_tail[2] - t_start) * 1e3, (t_tail[3] - t_start) * 1e3);
+		}
 		fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 		        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 		fprintf(stderr, "# filter pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
