@@ -16,6 +16,7 @@
 #include <fcntl.h>
 #include <getopt.h>
 #include <pthread.h>
+#include <sys/mman.h>
 #include <math.h>
 #include <time.h>
 #include <unistd.h>
@@ -728,8 +729,8 @@ typedef struct {
 	int out_opened;                /* the preflight has passed and the output is open (first_mu) */
 	pthread_mutex_t first_mu;
 	pthread_cond_t first_cv;
-	int pin_obuf;              /* filter: the slots also get an output buffer */
-	int pin_started;
+	int with_obuf;             /* filter: there are output buffers as well */
+	int pin_started, pin_quit;
 	msx_ctx *pin_ctx;
 	pthread_t pin_th[PIPE_SLOTS_MAX];
 	int n_pin;
@@ -813,6 +814,28 @@ static void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_con
 	}
 }
 
+/* An I/O buffer of the device-unpack path: anonymous memory advised for huge pages.  Page-locking costs next to nothing
+ * once the pages exist (0.4 ms for 80 MB, scripts/micro/pin_rate.hip) -- what takes the time is faulting them in, and
+ * that needs no HIP call and holds no lock of the runtime: io_populate does it (MADV_POPULATE_WRITE: contents untouched,
+ * so a buffer the decode stage is already filling may be populated) on the pin threads while HIP is starting up. */
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+static uint8_t *io_alloc(size_t bytes) {
+	const size_t al = (size_t)2 << 20, len = (bytes + al - 1) / al * al + al;
+	uint8_t *m = (uint8_t *)mmap(NULL, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0), *p;
+	if (m == MAP_FAILED) mDie("Out of memory");
+	p = (uint8_t *)(((uintptr_t)m + al - 1) / al * al);
+#ifdef MADV_HUGEPAGE
+	(void)madvise(p, len - (size_t)(p - m), MADV_HUGEPAGE);
+#endif
+	return p;                              /* (never unmapped: the buffers live as long as the process) */
+}
+static void io_populate(uint8_t *p, size_t bytes) {
+	if (getenv("MSX_NO_POPULATE")) return;
+	(void)madvise(p, bytes, MADV_POPULATE_WRITE);      /* (EINVAL on kernels before 5.14: page-locking faults the pages in then) */
+}
+
 /* Page-locking a slot's byte buffer and allocating its page-locked output buffer takes tens of milliseconds per
  * slot -- on a thread of its own, in the order the decode stage will use the slots for raw batches (1, 2, ..., 0), so
  * that neither the first batch nor HIP start-up waits for it; the device thread waits for the one slot it is about to use. */
@@ -820,36 +843,47 @@ static void *pin_thread(void *arg) {
 	struct pin_arg_s *A = (struct pin_arg_s *)arg;
 	pipe_t *P = (pipe_t *)A->P;
 	int k;
-	g_ctx = P->pin_ctx;
-	int j = A->first;
-	for (k = 1 + A->first; k <= P->n_slots; k += A->step) {
-		pslot *s = &P->slot[k % P->n_slots];
-		if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, s->rbuf, s->rcap));
-		pthread_mutex_lock(&P->pin_mu);
-		s->pin_ready = 1;
-		pthread_cond_broadcast(&P->pin_cv);
-		pthread_mutex_unlock(&P->pin_mu);
-		if (P->pin_obuf && j < PIPE_OBUFS) {          /* (an output buffer for every input buffer, while there are any) */
-			P->ob_cap[j] = P->ocap_cfg;
-			MSX(msx_host_alloc(g_ctx, (void **)&P->ob[j], P->ob_cap[j]));
-			pq_push(&P->q_ob, j);
-			j += A->step;
-		}
+	int j;
+	/* phase 1, no HIP involved (runs from pipe_enable_raw on, beside HIP start-up): the pages */
+	for (k = 1 + A->first, j = A->first; k <= P->n_slots || j < PIPE_OBUFS; k += A->step, j += A->step) {
+		if (k <= P->n_slots) io_populate(P->slot[k % P->n_slots].rbuf, P->slot[k % P->n_slots].rcap);
+		if (P->with_obuf && j < PIPE_OBUFS) io_populate(P->ob[j], P->ob_cap[j]);
 	}
-	for (; P->pin_obuf && j < PIPE_OBUFS; j += A->step) {
-		P->ob_cap[j] = P->ocap_cfg;
-		MSX(msx_host_alloc(g_ctx, (void **)&P->ob[j], P->ob_cap[j]));
-		pq_push(&P->q_ob, j);
+	/* phase 2, once a context exists: page-lock them, in the order they will be needed */
+	pthread_mutex_lock(&P->pin_mu);
+	while (!P->pin_ctx && !P->pin_quit) pthread_cond_wait(&P->pin_cv, &P->pin_mu);
+	pthread_mutex_unlock(&P->pin_mu);
+	if (!P->pin_ctx) return NULL;
+	g_ctx = P->pin_ctx;
+	for (k = 1 + A->first, j = A->first; k <= P->n_slots || j < PIPE_OBUFS; k += A->step, j += A->step) {
+		if (k <= P->n_slots) {
+			pslot *s = &P->slot[k % P->n_slots];
+			if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, s->rbuf, s->rcap));
+			pthread_mutex_lock(&P->pin_mu);
+			s->pin_ready = 1;
+			pthread_cond_broadcast(&P->pin_cv);
+			pthread_mutex_unlock(&P->pin_mu);
+		}
+		if (P->with_obuf && j < PIPE_OBUFS) {
+			if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, P->ob[j], P->ob_cap[j]));
+			pq_push(&P->q_ob, j);
+		}
 	}
 	return NULL;
 }
+/* the threads are started by pipe_enable_raw (they populate the buffers); the device thread hands them its context here */
 static void pin_start(pipe_t *P, int with_obuf) {
-	int t;
-	if (P->pin_started) return;
-	P->pin_started = 1;
+	(void)with_obuf;
+	if (!P->pin_started || P->pin_ctx) return;
+	pthread_mutex_lock(&P->pin_mu);
 	P->pin_ctx = g_ctx;
-	P->pin_obuf = with_obuf;
-	P->n_pin = getenv("MSX_PIN_THREADS") ? atoi(getenv("MSX_PIN_THREADS")) : (P->comp_mode ? 2 : 1);
+	pthread_cond_broadcast(&P->pin_cv);
+	pthread_mutex_unlock(&P->pin_mu);
+}
+static void pin_spawn(pipe_t *P) {
+	int t;
+	P->pin_started = 1;
+	P->n_pin = getenv("MSX_PIN_THREADS") ? atoi(getenv("MSX_PIN_THREADS")) : 2;
 	if (P->n_pin < 1) P->n_pin = 1;
 	if (P->n_pin > P->n_slots) P->n_pin = P->n_slots;
 	pthread_mutex_init(&P->pin_mu, NULL);
@@ -862,6 +896,10 @@ static void pin_start(pipe_t *P, int with_obuf) {
 static void pin_join(pipe_t *P) {
 	int t;
 	if (!P->pin_started) return;
+	pthread_mutex_lock(&P->pin_mu);
+	P->pin_quit = 1;                                  /* (threads that were never given a context) */
+	pthread_cond_broadcast(&P->pin_cv);
+	pthread_mutex_unlock(&P->pin_mu);
 	for (t = 0; t < P->n_pin; t++) pthread_join(P->pin_th[t], NULL);
 }
 static void pin_wait(pipe_t *P, pslot *s) {
@@ -906,9 +944,10 @@ static void unpack_slot_finish(pipe_t *P, pslot *s, msx_unpack *unpack, const ms
 }
 
 /* device unpack: every slot gets a buffer of fixed size for the inflated bytes (page-locked by pin_thread) */
-static void pipe_enable_raw(pipe_t *P) {
+static void pipe_enable_raw(pipe_t *P, int with_obuf) {
 	int i;
 	P->raw_mode = 1;
+	P->with_obuf = with_obuf;
 	/* BAM input: the blocks stay compressed until they are on the device (MSX_HOST_INFLATE=1: inflate here).  A batch is
 	 * as many blocks as the device inflates at a time -- one wave per block, eight per compute unit (msx_inflate.hip) --
 	 * or what fits the slot's buffer, whichever comes first. */
@@ -934,8 +973,13 @@ static void pipe_enable_raw(pipe_t *P) {
 			s->rcap = P->batch_bytes_cfg + BGZF_INFLATE_MAX + 4096;
 			P->ocap_cfg = s->rcap;
 		}
-		if (posix_memalign((void **)&s->rbuf, 4096, s->rcap) != 0) mDie("Out of memory");
+		s->rbuf = io_alloc(s->rcap);
 	}
+	for (i = 0; with_obuf && i < PIPE_OBUFS; i++) {
+		P->ob_cap[i] = P->ocap_cfg;
+		P->ob[i] = io_alloc(P->ob_cap[i]);
+	}
+	pin_spawn(P);
 }
 
 /* ---- record boundaries: a speculative parallel chase -------------------------------------------
@@ -1350,10 +1394,10 @@ static void *pipe_decode_thread(void *arg) {
 /* page-lock the slot's SoA arrays once (they never move): uploads become asynchronous DMA */
 static void pipe_pin_slot(pipe_t *P, pslot *s) {
 	rbatch *b = &s->b;
-	const size_t c = b->cap;
-	/* (device unpack: only batch 0 takes the host-side walk -- page-locking 170 MB of arrays for one upload costs more
-	 * than the upload saves) */
-	if (s->pinned || P->raw_mode || getenv("MSX_NO_PIN")) return;
+	/* (device unpack: only batch 0 takes the host-side walk -- of its arrays just what it uses is page-locked: 170 MB for
+	 * one upload would cost more than the upload saves, and from pageable memory the dozen copies took 77 ms) */
+	const size_t c = P->raw_mode ? b->n + 8 : b->cap;
+	if (s->pinned || getenv("MSX_NO_PIN")) return;
 	s->pinned = 1;
 	MSX(msx_host_register(g_ctx, b->flag, c * 2));
 	MSX(msx_host_register(g_ctx, b->rflags, c));
@@ -1367,10 +1411,10 @@ static void pipe_pin_slot(pipe_t *P, pslot *s) {
 	if (P->want_stats) {
 		MSX(msx_host_register(g_ctx, b->cigar_off, (c + 1) * 4));
 		MSX(msx_host_register(g_ctx, b->md_off, (c + 1) * 4));
-		MSX(msx_host_register(g_ctx, b->cigar, b->cigar_cap * 4));
-		MSX(msx_host_register(g_ctx, b->md, b->md_cap));
+		MSX(msx_host_register(g_ctx, b->cigar, P->raw_mode ? ((size_t)b->cigar_off[b->n] + 8) * 4 : b->cigar_cap * 4));
+		MSX(msx_host_register(g_ctx, b->md, P->raw_mode ? (size_t)b->md_off[b->n] + 64 : b->md_cap));
 	}
-	if (P->mode != 0) MSX(msx_host_register(g_ctx, b->group_off, b->group_cap * 4));
+	if (P->mode != 0) MSX(msx_host_register(g_ctx, b->group_off, P->raw_mode ? (b->n_groups + 8) * 4 : b->group_cap * 4));
 }
 
 /* --rescore: drop the first AS and append AS:i (msam_filter.c:162-167) */
@@ -1690,6 +1734,7 @@ typedef struct {
 	pthread_t th;
 	double t_ctx, t_upload, t_gpu, t_fetch, t_wait;
 	size_t n_prefetched;
+	double t_ctx_end;
 	double t_end[64];            /* MSX_TIMING: when the first batches left this stage */
 	int n_end;
 } fdev_t;
@@ -1772,7 +1817,8 @@ static void *filter_dev_thread(void *arg) {
 		if (F->po)
 			MSX(msx_profile_create(g_ctx, &D->prof, F->pf->n_features, F->po->share_type, F->pf->fmap, P->hdr->n_targets));
 		D->t_ctx = now_s() - t0;
-		if (P->raw_mode) MSX(msx_unpack_create(g_ctx, &unpack));
+		D->t_ctx_end = now_s();
+		if (P->raw_mode) { MSX(msx_unpack_create(g_ctx, &unpack)); pin_start(P, 1); }
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
@@ -1853,10 +1899,11 @@ static void *filter_dev_thread(void *arg) {
 				MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
 				if (nb > 0) {
 					s->ob = pq_pop(&P->q_ob);                /* (waits for the writer when all of them are on their way out) */
-					if ((size_t)nb + 64 > P->ob_cap[s->ob]) {
-						if (P->ob[s->ob]) msx_host_free(g_ctx, P->ob[s->ob]);
+					if ((size_t)nb + 64 > P->ob_cap[s->ob]) {          /* (the old one stays mapped and page-locked: rare) */
 						P->ob_cap[s->ob] = (size_t)nb + (size_t)nb / 4 + ((size_t)4 << 20);
-						MSX(msx_host_alloc(g_ctx, (void **)&P->ob[s->ob], P->ob_cap[s->ob]));
+						P->ob[s->ob] = io_alloc(P->ob_cap[s->ob]);
+						io_populate(P->ob[s->ob], P->ob_cap[s->ob]);
+						MSX(msx_host_register(g_ctx, P->ob[s->ob], P->ob_cap[s->ob]));
 					}
 					s->obuf = P->ob[s->ob];
 					s->ocap = P->ob_cap[s->ob];
@@ -1871,13 +1918,16 @@ static void *filter_dev_thread(void *arg) {
 			pq_push(&P->q_out, si);
 			continue;
 		}
-		/* more batches follow batch 0: their buffers are page-locked while this one is processed */
-		if (s->seq == 0 && P->raw_mode && !__atomic_load_n(&P->in_eof, __ATOMIC_RELAXED)) pin_start(P, 1);
 		pipe_pin_slot(P, s);
 		rb_host_view(b, &hb, P->mode != 0);
 		hb.pool_rule = (F->pools && F->po) ? MSX_POOLS_FILTER : MSX_POOLS_PROFILE;
 		MSX(msx_stage_upload(g_ctx, stage, &hb, &db));
 		MSX(msx_stage_outputs(g_ctx, stage, (int64_t)b->n, F->fp->rescore, &fo));
+		/* (the I/O buffers of the batches behind batch 0 were populated while HIP started up; page-locking them now is a
+		 * matter of a millisecond -- it used to be tens, holding the runtime's lock, with this batch's allocations and
+		 * copies in line behind it: 77 ms for a 12 MB batch) */
+		if (s->seq == 0 && P->raw_mode) pin_start(P, 1);
+		if (s->seq == 0 && getenv("MSX_TIMING")) fprintf(stderr, "# batch 0: popped +%.0f ms after the context, uploaded +%.0f\n", (t1 - (t0 - 0)) * 0 + (t1 - D->t_ctx_end) * 1e3, (now_s() - D->t_ctx_end) * 1e3);
 		D->t_upload += now_s() - t1; t1 = now_s();
 		if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
 		else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
@@ -1896,11 +1946,13 @@ static void *filter_dev_thread(void *arg) {
 				}
 			}
 		}
+		if (s->seq == 0 && getenv("MSX_TIMING")) fprintf(stderr, "# batch 0: kernels done +%.0f ms after the context\n", (now_s() - D->t_ctx_end) * 1e3);
 		D->t_gpu += now_s() - t1; t1 = now_s();
 		s->n_emit = st.n_emit;
 		MSX(msx_dev_to_host(g_ctx, s->emit, fo.emit_idx, 4 * (size_t)st.n_emit));
 		if (F->fp->rescore) MSX(msx_dev_to_host(g_ctx, s->as_out, fo.as_out, 4 * b->n));
 		D->t_fetch += now_s() - t1;
+		if (D->n_end < 64) D->t_end[D->n_end++] = now_s();
 		pq_push(&P->q_out, si);
 	}
 	MSX(msx_ctx_sync(g_ctx));
@@ -2022,7 +2074,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	 * are (no --rescore), BAM out.  The first batch takes the host-side walk: the preflight reads its records.
 	 * MSX_HOST_UNPACK=1 keeps every batch on the host. */
 	if (F.n_dev == 1 && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) && !getenv("MSX_HOST_UNPACK"))
-		pipe_enable_raw(&P);
+		pipe_enable_raw(&P, 1);
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
 	if (po) prof_features(po, P.hdr, &pf);
@@ -2412,7 +2464,7 @@ static void *profile_dev_thread(void *arg) {
 	MSX(msx_stage_create(g_ctx, &stage));
 	MSX(msx_profile_create(g_ctx, &D->prof, S->F->n_features, S->o->share_type, S->F->fmap, P->hdr->n_targets));   /* :855 */
 	D->t_ctx = now_s() - t0;
-	if (P->raw_mode) MSX(msx_unpack_create(g_ctx, &unpack));
+	if (P->raw_mode) { MSX(msx_unpack_create(g_ctx, &unpack)); pin_start(P, 0); }
 	for (;;) {
 		double t1;
 		int si;
@@ -2577,7 +2629,7 @@ int msam_profile_main(int argc, char *argv[]) {
 		memset(&S, 0, sizeof S);
 		S.n_dev = device_list(dev_ids);
 		pipe_init(&P, in, 2, 0, S.n_dev);
-		if (S.n_dev == 1 && !getenv("MSX_HOST_UNPACK")) pipe_enable_raw(&P);   /* the record walk of every batch but the first on the device */
+		if (S.n_dev == 1 && !getenv("MSX_HOST_UNPACK")) pipe_enable_raw(&P, 0);   /* the record walk of every batch but the first on the device */
 		S.P = &P; S.o = &o; S.F = &F;
 		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 		for (k = 0; k < S.n_dev; k++) {
