@@ -144,3 +144,37 @@ def test_damaged_blocks_are_refused_and_nothing_hangs(ctx):
     comp, blocks, total = M().bgzf_blocks(good[:2], [datas[0], datas[1][:-5]], crcs=[zlib.crc32(datas[0]), zlib.crc32(datas[1])])
     out, st, refused = M().bgzf_inflate(ctx, comp, blocks, 2, total)
     assert st[0] == 0 and st[1] != 0
+
+
+def test_random_streams_of_random_lengths(ctx):
+    """400 blocks: length 1 .. 65536, data from five generators, every zlib level, strategy and memLevel at random"""
+    rng = np.random.default_rng(424242)
+    datas, payloads = [], []
+    for k in range(400):
+        n = int(rng.integers(1, 65537)) if k % 7 else int(rng.integers(1, 300))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            d = bam_like(rng, n)
+        elif kind == 1:
+            d = rng.integers(0, int(rng.integers(2, 257)), n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            unit = rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8).tobytes()
+            d = (unit * (n // len(unit) + 1))[:n]
+        elif kind == 3:
+            base = bam_like(rng, max(n // 3, 1))
+            d = (base + rng.integers(0, 256, max(n // 3, 1), dtype=np.uint8).tobytes() + base)[:n]
+        else:
+            d = np.minimum(rng.geometric(float(rng.uniform(0.02, 0.9)), n), 255).astype(np.uint8).tobytes()
+        d = d.ljust(n, b"\0")[:n]
+        flush_at = tuple(sorted(int(x) for x in rng.integers(0, n + 1, int(rng.integers(0, 3))))) if rng.random() < 0.3 else ()
+        pl = raw_deflate(d, level=int(rng.integers(0, 10)),
+                         strategy=[zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 5))],
+                         flush_at=flush_at, flush_mode=[zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH][int(rng.integers(0, 2))],
+                         mem=int(rng.integers(1, 10)))
+        assert zlib.decompress(pl, -15) == d
+        datas.append(d)
+        payloads.append(pl)
+    comp, blocks, total = M().bgzf_blocks(payloads, datas, gap=int(rng.integers(0, 5)))
+    out, st, refused = M().bgzf_inflate(ctx, comp, blocks, len(datas), total)
+    assert refused == 0 and not st.any(), [(i, int(v)) for i, v in enumerate(st) if v][:5]
+    assert out[:total].tobytes() == b"".join(datas)
