@@ -78,7 +78,7 @@ def parse():
                     help="N ranks: skip comparing the distributed result with one context doing all N shards")
     ap.add_argument("--no-dist-leg", action="store_true",
                     help="skip timing the multi-GPU step over a one-rank communicator (dist_one_rank_ms_per_step)")
-    ap.add_argument("--e2e-seq-groups", type=int, default=4_000_000,
+    ap.add_argument("--e2e-seq-groups", type=int, default=10_000_000,
                     help="QNAME groups of the end-to-end BAM with SEQ/QUAL (~250 B per record); 0 = skip")
     ap.add_argument("--dry-launch", action="store_true",
                     help="ranks print their launch environment as JSON and exit (tests of the launcher; no GPU)")
