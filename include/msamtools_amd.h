@@ -281,8 +281,9 @@ int  msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_len, const m
  * block was refused: nothing has been consumed then, and the same batch can be handed to msx_unpack_enqueue inflated. */
 int  msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
                              const msx_bgzf_block *host_blocks, int64_t n_blocks, const msx_unpack_params *prm);
-/* optional, at any time: upload and inflate the blocks of the NEXT msx_unpack_enqueue_bgzf on a stream of their own, while
- * the current batch is walked, filtered and fetched (the next enqueue names the same buffer, length and block count) */
+/* optional, at any time: upload and inflate the blocks of a coming msx_unpack_enqueue_bgzf on streams of their own, while
+ * the current batch is walked, filtered and fetched.  Up to two batches may be on their way; they must be enqueued in
+ * the order they were sent (each enqueue names the same buffer, length and block count as its prefetch). */
 int  msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
                               const msx_bgzf_block *host_blocks, int64_t n_blocks);
 

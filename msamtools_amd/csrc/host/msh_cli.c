@@ -916,18 +916,34 @@ static void unpack_slot_enqueue(pipe_t *P, pslot *s, msx_unpack *unpack, const m
 	if (!s->comp) MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, up));
 	else MSX(msx_unpack_enqueue_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk, up));
 }
-/* the batch behind this one, if the decode stage has it ready: its blocks start their way up and are inflated beside the
- * work on this batch.  Returns the slot taken off the queue (the caller's next one), PQ_NONE if there was none. */
-static int unpack_slot_ahead(pipe_t *P, msx_unpack *unpack) {
-	int nx;
-	if (!P->comp_mode || getenv("MSX_NO_INFLATE_AHEAD")) return PQ_NONE;
-	nx = pq_try_pop(&P->q_dev);
-	if (nx >= 0 && P->slot[nx].raw && P->slot[nx].comp && P->slot[nx].n_blk > 0) {
-		pin_wait(P, &P->slot[nx]);
-		__atomic_add_fetch(&P->n_ahead, 1, __ATOMIC_RELAXED);
-		MSX(msx_unpack_prefetch_bgzf(g_ctx, unpack, P->slot[nx].rbuf, P->slot[nx].rlen, P->slot[nx].blk, P->slot[nx].n_blk));
+/* The batches behind this one, as far as the decode stage has them ready (two at most): their blocks start their way up
+ * and are inflated beside the work on this batch.  `ahead` is the caller's queue of slots taken off q_dev ahead of their
+ * turn (in order; an end-of-stream token or a slot that cannot be sent ahead closes it). */
+typedef struct { int item[2], n, closed; } ahead_q;
+static void unpack_slots_ahead(pipe_t *P, msx_unpack *unpack, ahead_q *A) {
+	static int depth = 0;
+	if (!depth) { const char *e = getenv("MSX_INFLATE_AHEAD"); depth = e && atoi(e) == 2 ? 2 : 1; }
+	if (!P->comp_mode || getenv("MSX_NO_INFLATE_AHEAD")) return;
+	while (A->n < depth && !A->closed) {
+		const int nx = pq_try_pop(&P->q_dev);
+		if (nx == PQ_NONE) return;
+		A->item[A->n++] = nx;
+		if (nx >= 0 && P->slot[nx].raw && P->slot[nx].comp && P->slot[nx].n_blk > 0) {
+			pin_wait(P, &P->slot[nx]);
+			__atomic_add_fetch(&P->n_ahead, 1, __ATOMIC_RELAXED);
+			MSX(msx_unpack_prefetch_bgzf(g_ctx, unpack, P->slot[nx].rbuf, P->slot[nx].rlen, P->slot[nx].blk, P->slot[nx].n_blk));
+		} else {
+			A->closed = 1;               /* (what follows it must not overtake it on the device) */
+		}
 	}
-	return nx;
+}
+static int ahead_pop(ahead_q *A) {
+	int v;
+	if (A->n == 0) return PQ_NONE;
+	v = A->item[0];
+	A->item[0] = A->item[1];
+	if (--A->n == 0) A->closed = 0;
+	return v;
 }
 static void unpack_slot_finish(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up, msx_unpack_result *ur, msx_batch *db) {
 	int rc = msx_unpack_finish(g_ctx, unpack, ur, db);
@@ -1801,6 +1817,7 @@ static void *filter_dev_thread(void *arg) {
 	msx_stage *stage = NULL;
 	msx_unpack *unpack = NULL;
 	int pending = PQ_NONE;             /* a slot taken off the queue ahead of its turn (its bytes are being sent up) */
+	ahead_q ahead = {{PQ_NONE, PQ_NONE}, 0, 0};
 	const int prefetch_on = getenv("MSX_PREFETCH") != NULL;
 	{
 		double t0 = now_s();
@@ -1822,7 +1839,7 @@ static void *filter_dev_thread(void *arg) {
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
-		const int si = pending != PQ_NONE ? pending : pq_pop(&P->q_dev);
+		const int si = pending != PQ_NONE ? pending : ahead.n ? ahead_pop(&ahead) : pq_pop(&P->q_dev);
 		pslot *s;
 		rbatch *b;
 		msx_batch hb, db;
@@ -1847,9 +1864,9 @@ static void *filter_dev_thread(void *arg) {
 			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
 			unpack_slot_enqueue(P, s, unpack, &up);
-			if (F->n_dev == 1) pending = unpack_slot_ahead(P, unpack);
+			if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
 			unpack_slot_finish(P, s, unpack, &up, &ur, &db);
-			if (F->n_dev == 1 && pending == PQ_NONE) pending = unpack_slot_ahead(P, unpack);   /* (not decoded yet a moment ago?) */
+			if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);        /* (not decoded yet a moment ago?) */
 			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
 			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
 			 * default: measured, it changes nothing (upload phase 0.35-0.40 s of the 100 M-record run either way).  The
@@ -1893,7 +1910,7 @@ static void *filter_dev_thread(void *arg) {
 				}
 				D->t_gpu += now_s() - t1; t1 = now_s();
 				s->n_emit = st.n_emit;
-				if (F->n_dev == 1 && pending == PQ_NONE) pending = unpack_slot_ahead(P, unpack);
+				if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
 				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
 				 * while the next batch is worked on: the writer waits for s->ev_out */
 				MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
@@ -2456,7 +2473,8 @@ static void *profile_dev_thread(void *arg) {
 	msx_stage *stage = NULL;
 	msx_unpack *unpack = NULL;
 	msx_event *ev[PIPE_SLOTS_MAX] = {NULL};
-	int held = -1, q, pending = PQ_NONE;       /* held: slot whose uploads may still be in flight; pending: slot taken off the queue ahead */
+	int held = -1, q;                          /* held: slot whose uploads may still be in flight */
+	ahead_q ahead = {{PQ_NONE, PQ_NONE}, 0, 0};  /* slots taken off the queue ahead of their turn */
 	double t0 = now_s();
 	ctx_open_dev(D->dev_id);                     /* HIP start-up runs beside the decoding of the first batch */
 	D->ctx = g_ctx;
@@ -2471,8 +2489,7 @@ static void *profile_dev_thread(void *arg) {
 		pslot *s;
 		msx_batch hb, db;
 		t0 = now_s();
-		si = pending != PQ_NONE ? pending : pq_pop(&P->q_dev);
-		pending = PQ_NONE;
+		si = ahead.n ? ahead_pop(&ahead) : pq_pop(&P->q_dev);
 		t1 = now_s();
 		D->t_wait += t1 - t0;
 		if (si == PQ_END) break;
@@ -2487,7 +2504,7 @@ static void *profile_dev_thread(void *arg) {
 			memset(&up, 0, sizeof up);
 			up.pool_mode = 2; up.n_targets = P->hdr->n_targets; up.last = s->last;
 			unpack_slot_enqueue(P, s, unpack, &up);
-			if (S->n_dev == 1) pending = unpack_slot_ahead(P, unpack);
+			if (S->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
 			unpack_slot_finish(P, s, unpack, &up, &ur, &db);              /* (synchronises: the slot's bytes have left) */
 			if (ur.n_records > 0) MSX(msx_profile_accumulate(g_ctx, D->prof, &db, NULL));
 			D->n_in += (size_t)ur.n_records;

@@ -51,16 +51,20 @@ struct msx_unpack {
 	msx_buf seg_first, seg_end, seg_cnt, seg_base;
 	msx_buf comp, blk, blk_status;  // msx_unpack_enqueue_bgzf: the compressed payloads, their table, the inflater's verdicts
 	bool bgzf = false;              // the current batch came in compressed
-	// msx_unpack_prefetch_bgzf: the NEXT batch uploaded and inflated on a stream of its own while the current one is walked,
-	// filtered and fetched -- into a staging buffer (the carry it will follow is not known yet); msx_unpack_enqueue_bgzf
-	// then copies it behind the carry
-	hipStream_t inf_stream = nullptr;
-	hipEvent_t inf_done = nullptr, stage_free = nullptr;
-	msx_buf pre_comp, pre_blk, pre_status, pre_out, pre_cnt;
-	const uint8_t *pre_key = nullptr;
-	size_t pre_comp_len = 0, pre_total = 0;
-	int64_t pre_nblk = 0;
-	bool pre_bgzf = false, stage_used = false;
+	// msx_unpack_prefetch_bgzf: the NEXT batches (up to two) uploaded and inflated on streams of their own while the current
+	// one is walked, filtered and fetched -- into staging buffers (the carry a batch will follow is not known yet);
+	// msx_unpack_enqueue_bgzf then copies the oldest behind the carry.  Two sets: the upload of batch k+2 travels while batch
+	// k+1 is being inflated, and the inflater never waits for the host.
+	struct pre_set {
+		msx_buf comp, blk, status, out, cnt;
+		hipEvent_t h2d_done = nullptr, inf_done = nullptr, freed = nullptr;
+		const uint8_t *key = nullptr;
+		size_t comp_len = 0, total = 0;
+		int64_t nblk = 0;
+		bool used = false;              // `freed` has been recorded at least once
+	} pre[2];
+	int ahead_head = 0, ahead_n = 0;   // the oldest pending set, how many are pending
+	hipStream_t inf_stream = nullptr, h2d_stream = nullptr;
 	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
 	    group_off, tile_last, cigar, md, out_len, out_off, out;
 	char *prev_name = nullptr;     // device, 256 bytes
@@ -71,7 +75,7 @@ struct msx_unpack {
 	// msx_unpack_prefetch: the next batch's bytes on their way up (a stream of its own) while the current batch is filtered
 	hipStream_t copy_stream = nullptr;
 	hipEvent_t copy_done = nullptr;
-	hipEvent_t out_copied = nullptr;   // msx_unpack_emit_async: the gather buffer has been read
+	hipEvent_t out_copied = nullptr;   // msx_unpack_emit_fetch: the gather buffer has been read
 	bool out_busy = false;
 	size_t gathered = 0;               // msx_unpack_emit_gather: bytes in `out`
 	const uint8_t *pre_host = nullptr;
@@ -554,17 +558,23 @@ extern "C" int msx_unpack_create(msx_ctx *ctx, msx_unpack **out) {
 extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (!u) return;
 	if (ctx && ctx->stream) { msx_join(ctx); (void)hipStreamSynchronize(ctx->stream); }
+	if (u->h2d_stream) (void)hipStreamSynchronize(u->h2d_stream);
 	if (u->inf_stream) (void)hipStreamSynchronize(u->inf_stream);
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
-	                   &u->out_off, &u->out, &u->comp, &u->blk, &u->blk_status, &u->pre_comp, &u->pre_blk,
-	                   &u->pre_status, &u->pre_out, &u->pre_cnt};
+	                   &u->out_off, &u->out, &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
+	                   &u->pre[0].status, &u->pre[0].out, &u->pre[0].cnt, &u->pre[1].comp, &u->pre[1].blk, &u->pre[1].status,
+	                   &u->pre[1].out, &u->pre[1].cnt};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
 	if (u->inf_stream) { (void)hipStreamSynchronize(u->inf_stream); (void)hipStreamDestroy(u->inf_stream); }
-	if (u->inf_done) (void)hipEventDestroy(u->inf_done);
-	if (u->stage_free) (void)hipEventDestroy(u->stage_free);
+	if (u->h2d_stream) { (void)hipStreamSynchronize(u->h2d_stream); (void)hipStreamDestroy(u->h2d_stream); }
+	for (auto &ps : u->pre) {
+		if (ps.h2d_done) (void)hipEventDestroy(ps.h2d_done);
+		if (ps.inf_done) (void)hipEventDestroy(ps.inf_done);
+		if (ps.freed) (void)hipEventDestroy(ps.freed);
+	}
 	if (u->copy_done) (void)hipEventDestroy(u->copy_done);
 	if (u->out_copied) (void)hipEventDestroy(u->out_copied);
 	if (u->prev_name) (void)hipFree(u->prev_name);
@@ -697,12 +707,13 @@ static int up_check_table(msx_ctx *ctx, const msx_bgzf_block *host_blocks, int64
 	return MSX_OK;
 }
 
-// The bytes of the NEXT msx_unpack_enqueue_bgzf, sent ahead and inflated on a stream of their own.  May be called at any
+// The bytes of a coming msx_unpack_enqueue_bgzf, sent ahead and inflated on streams of their own.  May be called at any
 // time (also between msx_unpack_enqueue* and msx_unpack_finish of the current batch): nothing here depends on the carry.
+// Up to two batches may be on their way; they are consumed in the order they were sent.
 extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
                                         const msx_bgzf_block *host_blocks, int64_t n_blocks) {
 	if (!ctx || !u || n_blocks <= 0 || !host_comp || !host_blocks) return MSX_ERR_ARG;
-	if (u->pre_bgzf) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_prefetch_bgzf: one batch is on its way already");
+	if (u->ahead_n >= 2) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_prefetch_bgzf: two batches are on their way already");
 	if (n_blocks > (1 << 24)) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_prefetch_bgzf: too many blocks");
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	int rc;
@@ -712,35 +723,46 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 		int lo = 0, hi = 0;
 		MSX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));           // (lo: the least urgent)
 		MSX_HIP(ctx, hipStreamCreateWithPriority(&u->inf_stream, hipStreamNonBlocking, lo));
-		MSX_HIP(ctx, hipEventCreateWithFlags(&u->inf_done, hipEventDisableTiming));
-		MSX_HIP(ctx, hipEventCreateWithFlags(&u->stage_free, hipEventDisableTiming));
+		MSX_HIP(ctx, hipStreamCreateWithFlags(&u->h2d_stream, hipStreamNonBlocking));
+		for (auto &ps : u->pre) {
+			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.h2d_done, hipEventDisableTiming));
+			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.inf_done, hipEventDisableTiming));
+			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.freed, hipEventDisableTiming));
+		}
 	}
-	// (the buffers may be in use by the copy of the batch before: grown only behind that copy)
-	if (u->stage_used) MSX_HIP(ctx, hipStreamWaitEvent(u->inf_stream, u->stage_free, 0));
-	if (u->pre_comp.cap < comp_len + 64 || u->pre_blk.cap < (size_t)n_blocks * sizeof(msx_bgzf_block) ||
-	    u->pre_status.cap < (size_t)n_blocks * 4 || u->pre_out.cap < n_new + 64) {
-		if (u->stage_used) MSX_HIP(ctx, hipEventSynchronize(u->stage_free));
+	msx_unpack::pre_set &ps = u->pre[(u->ahead_head + u->ahead_n) & 1];
+	// (the set may still be read by the copy of the batch that used it last: its upload waits for that copy; buffers are
+	// grown only when nothing of the set is in flight any more)
+	if (ps.used) MSX_HIP(ctx, hipStreamWaitEvent(u->h2d_stream, ps.freed, 0));
+	if (ps.comp.cap < comp_len + 64 || ps.blk.cap < (size_t)n_blocks * sizeof(msx_bgzf_block) || ps.status.cap < (size_t)n_blocks * 4 ||
+	    ps.out.cap < n_new + 64 || ps.cnt.cap < 64) {
+		if (ps.used) MSX_HIP(ctx, hipEventSynchronize(ps.freed));
+		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
 		MSX_HIP(ctx, hipStreamSynchronize(u->inf_stream));
 	}
-	UP_RES(pre_comp, comp_len + 64);
-	UP_RES(pre_blk, (size_t)n_blocks * sizeof(msx_bgzf_block));
-	UP_RES(pre_status, (size_t)n_blocks * 4);
-	UP_RES(pre_out, n_new + 64);
-	UP_RES(pre_cnt, 64);
-	MSX_HIP(ctx, hipMemsetAsync(u->pre_cnt.p, 0, 8, u->inf_stream));
-	MSX_HIP(ctx, hipMemcpyAsync(u->pre_comp.p, host_comp, comp_len, hipMemcpyHostToDevice, u->inf_stream));
-	MSX_HIP(ctx, hipMemcpyAsync(u->pre_blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, u->inf_stream));
+	if ((rc = msx_reserve(ctx, &ps.comp, comp_len + 64))) return rc;
+	if ((rc = msx_reserve(ctx, &ps.blk, (size_t)n_blocks * sizeof(msx_bgzf_block)))) return rc;
+	if ((rc = msx_reserve(ctx, &ps.status, (size_t)n_blocks * 4))) return rc;
+	if ((rc = msx_reserve(ctx, &ps.out, n_new + 64))) return rc;
+	if ((rc = msx_reserve(ctx, &ps.cnt, 64))) return rc;
+	// the upload on a stream of its own (it travels while the batch before is being inflated) ...
+	MSX_HIP(ctx, hipMemcpyAsync(ps.comp.p, host_comp, comp_len, hipMemcpyHostToDevice, u->h2d_stream));
+	MSX_HIP(ctx, hipMemcpyAsync(ps.blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, u->h2d_stream));
+	MSX_HIP(ctx, hipEventRecord(ps.h2d_done, u->h2d_stream));
+	// ... the inflater behind it, and behind the inflater of the batch before.
 	// (eight waves per compute unit: the batch beside it needs LDS too -- k_besthit_select waited a whole inflate kernel for
 	// its share when ten were resident -- and the command line's batches of 2048 blocks are eight per compute unit anyway)
-	if ((rc = msx_bgzf_inflate_launch(ctx, u->inf_stream, 8, (const uint8_t *)u->pre_comp.p, comp_len, (const msx_bgzf_block *)u->pre_blk.p,
-	                                  n_blocks, (uint8_t *)u->pre_out.p, (uint32_t *)u->pre_status.p, (uint32_t *)u->pre_cnt.p)))
+	MSX_HIP(ctx, hipStreamWaitEvent(u->inf_stream, ps.h2d_done, 0));
+	MSX_HIP(ctx, hipMemsetAsync(ps.cnt.p, 0, 8, u->inf_stream));
+	if ((rc = msx_bgzf_inflate_launch(ctx, u->inf_stream, 8, (const uint8_t *)ps.comp.p, comp_len, (const msx_bgzf_block *)ps.blk.p,
+	                                  n_blocks, (uint8_t *)ps.out.p, (uint32_t *)ps.status.p, (uint32_t *)ps.cnt.p)))
 		return rc;
-	MSX_HIP(ctx, hipEventRecord(u->inf_done, u->inf_stream));
-	u->pre_bgzf = true;
-	u->pre_key = host_comp;
-	u->pre_comp_len = comp_len;
-	u->pre_nblk = n_blocks;
-	u->pre_total = n_new;
+	MSX_HIP(ctx, hipEventRecord(ps.inf_done, u->inf_stream));
+	ps.key = host_comp;
+	ps.comp_len = comp_len;
+	ps.nblk = n_blocks;
+	ps.total = n_new;
+	u->ahead_n++;
 	return MSX_OK;
 }
 
@@ -756,13 +778,15 @@ extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	int rc;
 	size_t n_new = 0;
-	const bool sent = u->pre_bgzf && u->pre_key == host_comp && u->pre_comp_len == comp_len && u->pre_nblk == n_blocks;
-	if (u->pre_bgzf && !sent) {
+	msx_unpack::pre_set &ps = u->pre[u->ahead_head];
+	const bool sent = u->ahead_n > 0 && ps.key == host_comp && ps.comp_len == comp_len && ps.nblk == n_blocks;
+	if (u->ahead_n > 0 && !sent) {
+		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
 		MSX_HIP(ctx, hipStreamSynchronize(u->inf_stream));
-		u->pre_bgzf = false;
+		u->ahead_n = 0;
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: other blocks than msx_unpack_prefetch_bgzf sent ahead");
 	}
-	if (sent) n_new = u->pre_total;
+	if (sent) n_new = ps.total;
 	else if ((rc = up_check_table(ctx, host_blocks, n_blocks, comp_len, &n_new))) return rc;
 	const size_t n = u->carry_len + n_new;
 	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: more than 4 GiB in one batch");
@@ -772,12 +796,13 @@ extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_
 	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 4, ctx->stream));
 	if (sent) {
 		// inflated already, in the staging buffer: behind the carry with it, and the verdict into this batch's state
-		u->pre_bgzf = false;
-		MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->inf_done, 0));
-		if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, u->pre_out.p, n_new, hipMemcpyDeviceToDevice, ctx->stream));
-		MSX_HIP(ctx, hipMemcpyAsync(&u->d_state->inflate_bad, u->pre_cnt.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
-		MSX_HIP(ctx, hipEventRecord(u->stage_free, ctx->stream));
-		u->stage_used = true;
+		MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ps.inf_done, 0));
+		if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, ps.out.p, n_new, hipMemcpyDeviceToDevice, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(&u->d_state->inflate_bad, ps.cnt.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+		MSX_HIP(ctx, hipEventRecord(ps.freed, ctx->stream));
+		ps.used = true;
+		u->ahead_head ^= 1;
+		u->ahead_n--;
 	} else if (n_blocks > 0) {
 		UP_RES(comp, comp_len + 64);
 		UP_RES(blk, (size_t)n_blocks * sizeof(msx_bgzf_block));

@@ -70,7 +70,7 @@ def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False
     feed: "plain" inflated bytes (msx_unpack_enqueue); "bgzf" the chunk as compressed blocks (msx_unpack_enqueue_bgzf);
     "bgzf_ahead" the same with the next chunk's blocks sent and inflated ahead (msx_unpack_prefetch_bgzf)"""
     import msamtools_amd as m
-    ahead = None
+    ahead = []            # (chunk length, handle) of the chunks sent ahead, oldest first: two at most
     pools = {0: None, 1: m.filter_pools(rec), 2: m.profile_pools(rec)}[pool_mode]
     off = offsets_of(stream)
     up = m.Unpack(ctx)
@@ -83,19 +83,23 @@ def run_chunks(ctx, stream, n_ref, rec, chunk_sizes, pool_mode, cut_mapped=False
             chunk = stream[pos:pos + sz]
             pos += len(chunk)
             last = pos >= len(stream)
+            apos = pos + sum(n for n, _ in ahead[1:]) if ahead else pos     # where the chunks not yet sent ahead begin
             kw = dict(pool_mode=pool_mode, n_targets=n_ref, last=last, cut_mapped=cut_mapped, want_stats=want_stats)
             if feed == "plain" or len(chunk) == 0:
                 up.enqueue(chunk, **kw)
             else:
-                if ahead is not None:
-                    up.enqueue_bgzf(ahead, **kw)
+                if ahead:
+                    n0, h = ahead.pop(0)
+                    assert n0 == len(chunk)
+                    up.enqueue_bgzf(h, **kw)
                 else:
                     up.enqueue_bgzf(*as_blocks(chunk, level=(1, 6, 9)[k % 3]), **kw)
-                ahead = None
-                if feed == "bgzf_ahead" and not last:     # between enqueue and finish: nothing of it depends on the carry
-                    nxt = stream[pos:pos + chunk_sizes[k % len(chunk_sizes)]]
-                    if len(nxt):
-                        ahead = up.prefetch_bgzf(*as_blocks(nxt, level=(1, 6, 9)[(k + 1) % 3]))
+                if feed == "bgzf_ahead":                  # between enqueue and finish: nothing of it depends on the carry
+                    while len(ahead) < 2 and apos < len(stream):
+                        j = k + len(ahead)
+                        nxt = stream[apos:apos + chunk_sizes[j % len(chunk_sizes)]]
+                        ahead.append((len(nxt), up.prefetch_bgzf(*as_blocks(nxt, level=(1, 6, 9)[(j + 1) % 3]))))
+                        apos += len(nxt)
             res, view = up.finish()
             if prefetch and not last:        # the next chunk goes up while this batch is looked at
                 up.prefetch(stream[pos:pos + chunk_sizes[k % len(chunk_sizes)]])
