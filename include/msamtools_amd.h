@@ -468,6 +468,10 @@ int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
                              uint8_t *covered /* device u8[n_targets] or NULL: global->covered[tid],
                                                  set for every target that has an alignment (msam_coverage.c:45-49) */);
 int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);
+/* after msx_coverage_finish: per target, the number of positions with a depth other than 0 and the sum of the depths --
+ * what mWriteCoverageSummaryToStream (msam_coverage.c:188-219) divides by the target's length; host arrays of n_targets */
+int  msx_coverage_summary(msx_ctx *ctx, const int32_t *cov, const int64_t *cov_off, int32_t n_targets,
+                          int64_t *touched_host, int64_t *sum_host);
 
 /* ---- synthetic workloads (bench.py / tests) -------- */
 

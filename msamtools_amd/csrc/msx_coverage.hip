@@ -223,3 +223,42 @@ extern "C" int msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
 	return msx_scan_inclusive_u32(ctx, (uint32_t *)cov, total_len);
 }
+
+// mWriteCoverageSummaryToStream (msam_coverage.c:188-219) prints, per target, the fraction of positions with a depth
+// other than 0 and the mean depth: two sums over the target's cells.  One wave per target; the sums leave the device,
+// the depths need not (a million references of 4.5 kb are 18 GB of them).
+__global__ __launch_bounds__(64) void k_coverage_summary(const int32_t *__restrict__ cov, const int64_t *__restrict__ off,
+                                                         int32_t n_targets, int64_t *__restrict__ touched, int64_t *__restrict__ sum) {
+	const int32_t t = (int32_t)blockIdx.x;
+	if (t >= n_targets) return;
+	const int64_t lo = off[t], hi = off[t + 1];
+	int64_t a = 0, b = 0;
+	for (int64_t i = lo + threadIdx.x; i < hi; i += 64) {
+		const int32_t v = cov[i];
+		a += v != 0;
+		b += v;
+	}
+	for (int step = 32; step >= 1; step >>= 1) {
+		a += __shfl_xor(a, step);
+		b += __shfl_xor(b, step);
+	}
+	if (threadIdx.x == 0) { touched[t] = a; sum[t] = b; }
+}
+
+extern "C" int msx_coverage_summary(msx_ctx *ctx, const int32_t *cov, const int64_t *cov_off, int32_t n_targets,
+                                    int64_t *touched_host, int64_t *sum_host) {
+	if (!ctx || !cov || !cov_off || n_targets < 0 || !touched_host || !sum_host) return MSX_ERR_ARG;
+	msx_join(ctx);
+	if (n_targets == 0) return MSX_OK;
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	const size_t bytes = (size_t)n_targets * 8;
+	if ((rc = msx_reserve(ctx, &ctx->cv_start, 2 * bytes))) return rc;
+	int64_t *d_t = (int64_t *)ctx->cv_start.p, *d_s = d_t + n_targets;
+	hipLaunchKernelGGL(k_coverage_summary, dim3((unsigned)n_targets), dim3(64), 0, ctx->stream, cov, cov_off, n_targets, d_t, d_s);
+	MSX_HIP(ctx, hipGetLastError());
+	MSX_HIP(ctx, hipMemcpyAsync(touched_host, d_t, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipMemcpyAsync(sum_host, d_s, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}

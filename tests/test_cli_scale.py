@@ -157,6 +157,37 @@ def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
     big.check_profile(p, big.plain)
 
 
+def test_coverage_through_the_pipeline(mid, tmp_path):
+    """`coverage` on a many-batch BAM: the pipeline of filter and profile (batches as compressed blocks, inflated and
+    walked on the device) against the oracle's pile-up (msam_coverage.c:33-87), and against the serial reader."""
+    cov = orc.coverage(mid.hs, [REF_LEN] * mid.refs)
+    want = []
+    for t, c in enumerate(cov):
+        if not c.any() and not ((mid.hs.tid == t).any()):
+            want.append(f"ref{t:07d}\t0\t0")
+        else:
+            want.append(f"ref{t:07d}\t{(c != 0).sum() / REF_LEN:.8f}\t{c.sum() / REF_LEN:.2f}")
+    outs = {}
+    for name, env in (("device", {}), ("host inflate", dict(MSX_HOST_INFLATE=1)), ("host walk", dict(MSX_HOST_UNPACK=1)),
+                      ("serial", dict(MSX_SERIAL_IO=1))):
+        o = str(tmp_path / "c.gz")
+        sh(f"{BIN} coverage --summary -o {o} {mid.bam['b']}", MSX_BATCH_BYTES=1_500_000, MSX_BATCH_RECORDS=110_000, **env)
+        outs[name] = gzip.open(o, "rt").read().split("\n")[:-1]
+    assert outs["device"] == want
+    for name in outs:
+        assert outs[name] == outs["device"], name
+    # per-position text of a few targets
+    o = str(tmp_path / "t.gz")
+    sh(f"{BIN} coverage -w 17 -o {o} {mid.bam['u']}", MSX_BATCH_BYTES=1_500_000, MSX_BATCH_RECORDS=110_000)
+    text = gzip.open(o, "rt").read()
+    blocks = text.split(">")[1:]
+    assert len(blocks) == mid.refs
+    for t in (0, 1, mid.refs // 2, mid.refs - 1):
+        head, body = blocks[t].split("\n", 1)
+        assert head == f"ref{t:07d}"
+        assert np.array_equal(np.array(body.split(), dtype=np.int64), cov[t].astype(np.int64))
+
+
 def test_filter_through_pipes(big, tmp_path):
     """stdin from a pipe (the reader thread's ring), stdout into a pipe (vmsplice hand-over)."""
     out = str(tmp_path / "f.bam")
