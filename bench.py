@@ -244,6 +244,54 @@ def inflate_probe(m, ctx, path, n_blocks=8192):
             ctx.free(q)
 
 
+def coverage_cli(groups=10_000_000, refs=50_000):
+    """`msamtools coverage` end to end on a c4-like BAM file (BASELINE configs[3]: 50 k references, ~50 M alignments;
+    BGZF level 6): --summary and the per-position text, each also through the serial record-at-a-time reader
+    (MSX_SERIAL_IO=1) as a cross-check of the outputs (the pile-up itself is checked against the oracle in the
+    `coverage` block above and, through the command line, in tests/test_cli_scale.py)."""
+    import gzip
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+    if not os.path.exists(exe):
+        return {"error": "msamtools_amd/bin/msamtools not built"}
+    tmp = tempfile.mkdtemp(prefix="msx_cov_", dir="/tmp")
+
+    def md5(path):
+        h = hashlib.md5()
+        with gzip.open(path, "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    def run(cmd, **env):
+        time.sleep(1.0)
+        t = time.perf_counter()
+        r = subprocess.run(cmd, shell=True, env=dict(os.environ, **env), stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr.decode()[-300:])
+        return time.perf_counter() - t
+    try:
+        subprocess.check_call(f"{exe} synth --groups {groups} --refs {refs} -b > {tmp}/in.bam", shell=True)
+        n = int(subprocess.check_output([exe, "digest", f"{tmp}/in.bam"]).decode().split()[0].split("=")[1])
+        dt_s = run(f"{exe} coverage --summary -o {tmp}/s.gz {tmp}/in.bam")
+        dt_t = run(f"{exe} coverage -o {tmp}/t.gz {tmp}/in.bam")
+        dt_s1 = run(f"{exe} coverage --summary -o {tmp}/s1.gz {tmp}/in.bam", MSX_SERIAL_IO="1")
+        res = {"records": n, "references": refs, "positions": refs * 4496,
+               "summary": {"seconds": round(dt_s, 3), "M_alignments_per_s": round(n / dt_s / 1e6, 1)},
+               "per_position_text": {"seconds": round(dt_t, 3), "M_alignments_per_s": round(n / dt_t / 1e6, 1),
+                                     "gz_MB": round(os.path.getsize(f"{tmp}/t.gz") / 1e6, 1)},
+               "summary_serial_reader": {"seconds": round(dt_s1, 3)},
+               "outputs_equal_serial_reader": md5(f"{tmp}/s.gz") == md5(f"{tmp}/s1.gz")}
+        return res
+    except Exception as exc:
+        return {"error": str(exc)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def e2e_cli(groups, refs, expect=None, seq=False, probe=None):
     """The command line end to end on this box: a synthetic BAM of `groups` QNAME groups (BGZF level 6; records
     without SEQ/QUAL, or ~250 B records with them: seq) through `msamtools filter -l 80 -p 95 -z 80 --besthit -bu |
@@ -879,6 +927,8 @@ def main():
         out["e2e"] = e2e_cli(args.e2e_groups, e2e_refs, locals().get("e2e_expect"), probe=probe)
         if args.e2e_seq_groups:
             out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True, probe=probe)
+        if isinstance(out.get("coverage"), dict) and "error" not in out["coverage"]:
+            out["coverage"]["cli"] = coverage_cli()
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
         try:
