@@ -569,6 +569,7 @@ typedef struct {
 	FILE *fp;
 	const uint8_t *map;                  /* a regular file is mapped: blocks are inflated straight out of the page cache */
 	size_t map_len, map_pos;
+	size_t map_released;                 /* pages of the mapping in front of this offset have been given back */
 	/* otherwise (a pipe): a thread of its own keeps draining the descriptor with read(2) into a ring of raw
 	 * buffers -- the writer at the other end never waits for this process to finish parsing a batch -- and
 	 * the blocks are parsed in place.  A block cut by a buffer's end is completed in the headroom in front of
@@ -799,6 +800,18 @@ static size_t bgz_read_blocks(bgz_in *b) {
 		b->uoff[b->nblk] = total;
 	}
 	return total;
+}
+
+/* The blocks in front of the read position have been inflated or copied: their pages of the mapping are given back now
+ * (the page cache keeps them; the process's page tables do not: a 1.6 GB mapping is 400 000 entries to tear down when
+ * the process ends, and the decode stage has time to spare). */
+static void bgz_release_consumed(bgz_in *b) {
+	const size_t pg = 4096, lo = (b->map_released + pg - 1) / pg * pg, hi = b->map_pos / pg * pg;
+	if (!b->map || hi <= lo || hi - lo < ((size_t)8 << 20)) return;
+#ifdef MADV_DONTNEED
+	(void)madvise((void *)(b->map + lo), hi - lo, MADV_DONTNEED);
+#endif
+	b->map_released = hi;
 }
 
 /* read the next batch of raw blocks and append their inflated bytes to the span; 0 at EOF */
@@ -1121,6 +1134,7 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 	} else {
 		b->dst = *buf + *len;
 		msh_parallel(msh_threads() < b->nblk ? msh_threads() : b->nblk, inflate_worker, b);
+		bgz_release_consumed(b);
 	}
 	*len += total;
 	return total;
@@ -1161,6 +1175,7 @@ int msh_raw_append(msh_in *in, uint8_t *buf, size_t cap, size_t *len, msx_bgzf_b
 	}
 	J.b = b; J.dst = buf + *len; J.poff = poff;
 	msh_parallel(msh_threads() < b->nblk ? msh_threads() : b->nblk, rawcopy_worker, &J);
+	bgz_release_consumed(b);
 	for (i = 0; i < b->nblk; i++) {
 		const uint8_t *c = b->cptr[i];
 		const size_t clen = b->coff[i + 1] - b->coff[i];
@@ -1501,8 +1516,16 @@ static uint8_t *slots_get(size_t bytes, size_t *got) {
 		}
 	pthread_mutex_unlock(&slot_pool.mu);
 	if (!p) {
+		/* anonymous memory advised for huge pages: a 136 MB array touched once per 4 KB page is 35 000 faults to fill and
+		 * as many pages to give back when the process ends */
+		const size_t al = (size_t)2 << 20;
 		*got = bytes < (size_t)WCHUNK_BLOCKS * WSLOT ? (size_t)WCHUNK_BLOCKS * WSLOT : bytes;
-		p = (uint8_t *)malloc(*got);
+		*got = (*got + al - 1) / al * al;
+		p = (uint8_t *)mmap(NULL, *got, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (p == (uint8_t *)MAP_FAILED) return NULL;
+#ifdef MADV_HUGEPAGE
+		(void)madvise(p, *got, MADV_HUGEPAGE);
+#endif
 	}
 	return p;
 }
@@ -1510,7 +1533,7 @@ static void slots_put(uint8_t *p, size_t bytes) {
 	pthread_mutex_lock(&slot_pool.mu);
 	if (slot_pool.n < 4) { slot_pool.buf[slot_pool.n] = p; slot_pool.bytes[slot_pool.n] = bytes; slot_pool.n++; p = NULL; }
 	pthread_mutex_unlock(&slot_pool.mu);
-	free(p);
+	if (p) munmap(p, bytes);
 }
 
 static void chunk_write(msh_out *o, struct wchunk *c) {
