@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 				if (T.pos >= out_len) IF_FAIL(IF_OUT_OVER);
 				if_refill(S, T, I, w, lane);
 				ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
-				if (lane == 0 && DBG != 3) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
+				if (lane == 0) S.ring[IF_RI(T.pos)] = (uint8_t)(e >> 16);
 				T.pos++;
 				if (DBG == 4) n_lit++;
 			} else if (kind == IF_EOB) {
@@ -553,8 +553,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 				if_refill(S, T, I, w, lane);
 				ev = S.ll[IF_PEEK(T, IF_LL_ROOT)];
 				const uint32_t from = T.pos - dist;
-				if (DBG == 2) {
-				} else if (dist <= IF_NEAR || DBG == 1) {
+				if (dist <= IF_NEAR) {
 					if (dist >= 64u || dist >= len) {
 						// a round's sources lie in front of the round: earlier rounds (LDS keeps a wave's order) or earlier symbols
 						for (uint32_t b = 0; b < len; b += 64u) {
@@ -704,11 +703,8 @@ static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate
 int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
                             const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
 	if (n_blocks <= 0) return MSX_OK;
-	static int dbg = -1, per_cu_env = 0;
-	if (dbg < 0) {
-		dbg = getenv("MSX_INFLATE_DBG") ? atoi(getenv("MSX_INFLATE_DBG")) : 0;
-		per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
-	}
+	static int per_cu_env = -1;
+	if (per_cu_env < 0) per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
 	int per_cu = per_cu_env > 0 ? per_cu_env : waves_per_cu > 0 ? waves_per_cu : IF_PER_CU;
 	if (per_cu > IF_PER_CU) per_cu = IF_PER_CU;
 	int64_t grid = (int64_t)per_cu * ctx->num_cu;
@@ -716,7 +712,7 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 4, stream));      // the ticket
 #define IF_LAUNCH(D) hipLaunchKernelGGL(k_bgzf_inflate<D>, dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
 	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 1, if_stats)
-	if (if_stats) IF_LAUNCH(4); else if (dbg == 1) IF_LAUNCH(1); else if (dbg == 2) IF_LAUNCH(2); else if (dbg == 3) IF_LAUNCH(3); else IF_LAUNCH(0);
+	if (if_stats) IF_LAUNCH(4); else IF_LAUNCH(0);          // (4: the same kernel counting its symbols, MSX_INFLATE_STATS)
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
 	// MSX_INFLATE_REFUSE=<n> (tests): every n-th block is reported as refused, whatever the decoder made of it
