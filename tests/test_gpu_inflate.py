@@ -178,3 +178,117 @@ def test_random_streams_of_random_lengths(ctx):
     out, st, refused = M().bgzf_inflate(ctx, comp, blocks, len(datas), total)
     assert refused == 0 and not st.any(), [(i, int(v)) for i, v in enumerate(st) if v][:5]
     assert out[:total].tobytes() == b"".join(datas)
+
+
+class BitWriter:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, v, nbits):                 # LSB first (header fields, extra bits)
+        self.acc |= v << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, c, nbits):                # a Huffman code: most significant bit first
+        self.put(int(format(c, f"0{nbits}b")[::-1], 2), nbits)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+        return bytes(self.out)
+
+
+def canonical(lens):
+    """code of every symbol with a length (RFC 1951, 3.2.2)"""
+    codes, code = {}, 0
+    for l in range(1, 16):
+        for s, sl in enumerate(lens):
+            if sl == l:
+                codes[s] = (code, l)
+                code += 1
+        code <<= 1
+    return codes
+
+
+def dynamic_block(symbols, ll_lens, d_lens, last=True):
+    """one dynamic-Huffman block from explicit code lengths (each length sent as itself: no run-length codes);
+    symbols: ints (literal / end of block) or (length symbol, extra bits value, distance symbol, extra bits value)"""
+    w = BitWriter()
+    w.put(1 if last else 0, 1)
+    w.put(2, 2)
+    hlit, hdist = max(257, len(ll_lens)), max(1, len(d_lens))
+    ll = list(ll_lens) + [0] * (hlit - len(ll_lens))
+    dl = list(d_lens) + [0] * (hdist - len(d_lens))
+    w.put(hlit - 257, 5)
+    w.put(hdist - 1, 5)
+    # the code-length code: every length 0..15 gets a 4-bit code (16 symbols of length 4: complete), 16-18 unused
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = [4] * 16 + [0, 0, 0]
+    w.put(19 - 4, 4)
+    for o in order:
+        w.put(cl[o], 3)
+    clc = canonical(cl)
+    for l in ll + dl:
+        w.code(*clc[l])
+    llc, dc = canonical(ll), canonical(dl)
+    lext = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+    dext = [0, 0, 0, 0] + [b for b in range(1, 14) for _ in (0, 1)]
+    for sym in symbols:
+        if isinstance(sym, tuple):
+            ls, lx, ds, dx = sym
+            w.code(*llc[ls])
+            w.put(lx, lext[ls - 257])
+            w.code(*dc[ds])
+            w.put(dx, dext[ds])
+        else:
+            w.code(*llc[sym])
+    return w.done()
+
+
+def test_code_sets_zlib_never_writes(ctx):
+    """Streams other encoders produce (htslib is often built with libdeflate): a block without any distance code, a
+    distance code of a single symbol (incomplete: RFC 1951 allows exactly this), 15-bit literal codes next to 1-bit ones.
+    zlib inflates them; so must the device -- or refuse, never mis-decode."""
+    cases = []
+    # 1. literals only, no distance code at all (HDIST = 1, its length 0)
+    ll = [0] * 257
+    for c in b"ACGT":
+        ll[c] = 3
+    ll[ord("N")] = 3
+    ll[256] = 3
+    ll[ord("\n")] = 3
+    ll[ord("x")] = 3                      # eight codes of length 3: complete
+    text = (b"ACGTNx\n" * 700)[:4321]
+    cases.append((dynamic_block(list(text) + [256], ll, [0]), text))
+    # 2. one distance symbol of length 1 (distance 1): runs
+    ll = [0] * 286
+    ll[ord("a")] = 2
+    ll[ord("b")] = 2
+    ll[256] = 2
+    ll[285] = 2                           # length 258
+    syms = [ord("a"), (285, 0, 0, 0), ord("b"), (285, 0, 0, 0), (285, 0, 0, 0), 256]
+    cases.append((dynamic_block(syms, ll, [1]), b"a" * 259 + b"b" * 517))
+    # 3. a very skewed literal code: lengths 1, 2, ..., 14, 15, 15
+    ll = [0] * 257
+    order = list(b"etaoinshrdlucmw") + [256]
+    for k, c in enumerate(order):
+        ll[c] = min(k + 1, 15)
+    rng = np.random.default_rng(3)
+    text = bytes(order[min(int(g) - 1, 14)] for g in rng.geometric(0.5, 20000))
+    cases.append((dynamic_block(list(text) + [256], ll, [0]), text))
+    datas = [d for _, d in cases]
+    payloads = [pl for pl, _ in cases]
+    for pl, d in cases:
+        assert zlib.decompress(pl, -15) == d
+    comp, blocks, total = M().bgzf_blocks(payloads, datas)
+    out, st, refused = M().bgzf_inflate(ctx, comp, blocks, len(datas), total)
+    o = 0
+    for i, d in enumerate(datas):
+        if st[i] == 0:
+            assert out[o:o + len(d)].tobytes() == d, i
+        o += len(d)
+    assert refused == int((st != 0).sum())
+    assert not st.any(), list(st)          # all three are within what the device decodes itself
