@@ -196,7 +196,10 @@ struct msx_profile {
 	msx_buf t_key[2];                 // ping-pong keys of the radix sorts (list keys, then entry keys)
 	msx_buf t_val64[2];               // ping-pong 64-bit values travelling with them: set signatures (msx_prop.hip)
 	msx_buf gl_idx;                   // u32 [general lists]: numbers of the lists k_general_recip handles
-	msx_buf recip;                    // f64 [n_lists]: w/S of the general lists
+	msx_buf recip;                    // f64: a[] (n_features, padded to 8) and behind it recip[n_lists], w/S of the general lists
+	bool a_in_recip = false;          // msx_prop_build has moved a[] into `recip` (one buffer descriptor for both)
+	double *recip_ptr = nullptr;
+	uint32_t recip_at = 0;            // bytes from a[] to recip[]
 	msx_buf rs_hist, rs_off;          // radix-sort histograms
 	msx_buf ck_hist, ck_off;          // the same for msx_count_keys, which runs on a side lane while the store is being built
 	msx_buf part_key, part_val;       // boundary partials of k_share_reduce (2 per wave)

@@ -196,7 +196,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	if (!p) return;
 	if (ctx) msx_join(ctx);
 	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a, p->share, p->delta, p->iter_state,
+	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a_in_recip ? nullptr : (void *)p->a, p->share, p->delta, p->iter_state,
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p, p->ck_hist.p, p->ck_off.p,
 	                p->recip.p, p->runs.p, p->owned.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p,

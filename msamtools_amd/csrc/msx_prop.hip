@@ -753,12 +753,11 @@ __device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
-                                                            const double *__restrict__ recip,
                                                             const double *__restrict__ a, int bits, int64_t W,
                                                             double *__restrict__ share,
                                                             double *__restrict__ part_val,
                                                             const int32_t *__restrict__ iter_state,
-                                                            uint32_t a_bytes, uint32_t recip_bytes) {
+                                                            uint32_t a_bytes, uint32_t recip_at) {
 	if (iter_state[0]) return;
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
@@ -823,8 +822,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	// (measured slower: fetching an index only when it differs from the previous entry's -- a lane's
 	// entries mostly share their feature -- 67 us against 55; a[] of the 512 features from the step's
 	// first one on staged in LDS, in-window gathers as ds_read_b64 -- 65 us against 53)
+	// recip[] of the general lists lives behind a[] in the same allocation (recip_at bytes in): one descriptor, and the
+	// gather of a general entry's w/S takes the place of the gather of its own feature -- a fifth instruction per
+	// entry for 0.6 % of the entries cost 3 us per launch
 	const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)a, 0, (int)a_bytes, 0x00020000);
-	const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)recip, 0, (int)recip_bytes, 0x00020000);
 	auto bload = [](decltype(rs_a) rs, uint32_t byte_off) {
 		const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)byte_off, 0, 0);
 		double d;
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		return d;
 	};
 	const uint32_t NONE = 0xffffffffu;                            // (beyond any buffer)
-	auto gather_step = [&](const uint32_t *k, const unsigned long long *lv, double *af, double *ag, double *a1, double *a2, double *a3) {
+	auto gather_step = [&](const uint32_t *k, const unsigned long long *lv, double *af, double *a1, double *a2, double *a3) {
 #pragma unroll
 		for (int i = 0; i < SR_EPL; i++) {
 			const bool live = k[i] != SR_SENT;
@@ -840,8 +841,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 			const bool exact = live && !general;
 			const uint32_t o1 = (uint32_t)(lv[i] & SIG_PAD), o2 = (uint32_t)((lv[i] >> 21) & SIG_PAD),
 			               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
-			af[i] = bload(rs_a, exact ? (k[i] & fmask) * 8u : NONE);
-			ag[i] = bload(rs_r, general ? (uint32_t)lv[i] * 8u : NONE);
+			af[i] = bload(rs_a, exact ? (k[i] & fmask) * 8u : general ? recip_at + (uint32_t)lv[i] * 8u : NONE);
 			a1[i] = bload(rs_a, (exact && o1 != SIG_PAD) ? o1 * 8u : NONE);
 			a2[i] = bload(rs_a, (exact && o2 != SIG_PAD) ? o2 * 8u : NONE);
 			a3[i] = bload(rs_a, (exact && o3 != SIG_PAD) ? o3 * 8u : NONE);
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	// the entries of step i+2 are in flight -- the two round trips of a step (entries, then what they point
 	// at) were what the kernel waited for, with the vector ALUs busy 30 % of the time.
 	struct Ent { uint32_t k[SR_EPL]; unsigned long long lv[SR_EPL]; uint32_t after; };
-	struct Ops { double af[SR_EPL], ag[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL]; };
+	struct Ops { double af[SR_EPL], a1[SR_EPL], a2[SR_EPL], a3[SR_EPL]; };
 	Ent e0, e1, e2;
 	Ops g0, g1;
 	const int64_t n_steps = (c1 - c0 + SR_STEP - 1) / SR_STEP;
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	load_step(c0, e0.k, e0.lv, e0.after);
 	load_step(b1, e1.k, e1.lv, e1.after);
 	mask_step(c0, e0.k, e0.lv, e0.after);
-	gather_step(e0.k, e0.lv, g0.af, g0.ag, g0.a1, g0.a2, g0.a3);
+	gather_step(e0.k, e0.lv, g0.af, g0.a1, g0.a2, g0.a3);
 	uint32_t before = 0;
 	if (lane == 0 && c0 > 0) before = t_key[c0 - 1] & fmask;
 	for (int64_t step = 0; step < n_steps; step++) {
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 		const int64_t b2 = base + 2 * SR_STEP < last_base ? base + 2 * SR_STEP : last_base;
 		load_step(b2, e2.k, e2.lv, e2.after);
 		mask_step(b1, e1.k, e1.lv, e1.after);
-		gather_step(e1.k, e1.lv, g1.af, g1.ag, g1.a1, g1.a2, g1.a3);
+		gather_step(e1.k, e1.lv, g1.af, g1.a1, g1.a2, g1.a3);
 		uint32_t k[SR_EPL];
 		const uint32_t after = e0.after;
 		// ((o1 + o2) + o3) + own.  (The entries of one list add the same numbers in different orders: their S
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 			const bool general = (e0.lv[i] & SIG_HASHED) != 0;
 			const double sum = ((g0.a1[i] + g0.a2[i]) + g0.a3[i]) + g0.af[i];     // absent ones came back as +0.0
 			const double w = (double)(bits < 32 ? (e0.k[i] >> bits) : 0u);
-			x[i] = !live ? 0.0 : general ? g0.ag[i] : (sum > 0 ? w / sum : 0.0);
+			x[i] = !live ? 0.0 : general ? g0.af[i] : (sum > 0 ? w / sum : 0.0);      // (general: af is recip[u])
 			k[i] = live ? (e0.k[i] & fmask) : e0.k[i];                            // from here on: the feature id
 		}
 		e0 = e1; e1 = e2; g0 = g1;
@@ -1281,7 +1281,19 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	for (int i = 0; i < 2; i++) {
 		if ((rc = msx_reserve(ctx, &p->t_key[i], (size_t)(eub + 64 + SR_STEP) * 4))) return rc;
 	}
-	if ((rc = msx_reserve(ctx, &p->recip, (size_t)(lub + 8) * 8))) return rc;
+	// a[] and recip[] in one allocation (k_share_reduce reaches both through one buffer descriptor); a[]'s contents are
+	// dead here: k_prop_begin writes them.  32-bit byte offsets: both together must stay below 4 GB.
+	{
+		const size_t nf_pad = ((size_t)(p->n_features > 0 ? p->n_features : 1) + 7) / 8 * 8;
+		const size_t bytes = (nf_pad + (size_t)lub + 8) * 8;
+		if (bytes >= 0xfffffff0ull) return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing: %lld features and %lld lists exceed the 4 GB the sharing kernel addresses", (long long)p->n_features, (long long)lub);
+		if ((rc = msx_reserve(ctx, &p->recip, bytes))) return rc;
+		if (!p->a_in_recip && p->a) (void)hipFree(p->a);
+		p->a = (double *)p->recip.p;
+		p->a_in_recip = true;
+		p->recip_ptr = p->a + nf_pad;
+		p->recip_at = (uint32_t)(nf_pad * 8);
+	}
 	{
 		const int64_t W = msx_share_waves(ctx);
 		if ((rc = msx_reserve(ctx, &p->part_key, (size_t)(2 * W + 8) * 4))) return rc;
@@ -1386,7 +1398,7 @@ static int recip_grid(msx_ctx *ctx, const msx_profile *p) {
 
 static RecipArgs recip_args(const msx_profile *p) {
 	return RecipArgs{(const unsigned long long *)p->d_tot, (const uint32_t *)p->m_off_alt.p, (const int32_t *)p->m_fid_alt.p,
-	                 (const uint32_t *)p->hpos.p, (const uint32_t *)p->gl_idx.p, (const double *)p->a, (double *)p->recip.p};
+	                 (const uint32_t *)p->hpos.p, (const uint32_t *)p->gl_idx.p, (const double *)p->a, p->recip_ptr};
 }
 
 int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
@@ -1402,10 +1414,10 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
 	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
-	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->recip.p,
+	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p,
 	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
-	                             (const int32_t *)p->iter_state, (uint32_t)((size_t)p->n_features * 8),
-	                             (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u)));
+	                             (const int32_t *)p->iter_state, (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u),
+	                             p->recip_at));
 	if (complete) {
 		const int64_t M = 2 * W;
 		MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
