@@ -621,8 +621,9 @@ class Profile:
             pass
 
 
-def coverage(ctx, batch, target_len):
-    """Per-base depth per target (msam_coverage.c:33-87) for one device batch."""
+def coverage(ctx, batch, target_len, summary=False):
+    """Per-base depth per target (msam_coverage.c:33-87) for one device batch; summary=True: also (touched positions,
+    depth sum) per target as the device takes them (msx_coverage_summary, msam_coverage.c:188-219)."""
     off = np.zeros(len(target_len) + 1, np.int64)
     off[1:] = np.cumsum(np.asarray(target_len, dtype=np.int64))
     total = int(off[-1])
@@ -635,7 +636,13 @@ def coverage(ctx, batch, target_len):
                                                   len(target_len), total, C.c_void_p(d_cov), None))
         ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
         cov = ctx.to_host(d_cov, total, np.int32)
+        if summary:
+            touched = np.zeros(max(len(target_len), 1), np.int64)
+            dsum = np.zeros(max(len(target_len), 1), np.int64)
+            ctx.check(ctx.lib.msx_coverage_summary(ctx.h, C.c_void_p(d_cov), C.c_void_p(d_off), len(target_len),
+                                                   touched.ctypes.data_as(C.c_void_p), dsum.ctypes.data_as(C.c_void_p)))
     finally:
         ctx.free(d_off)
         ctx.free(d_cov)
-    return [cov[off[i]:off[i + 1]] for i in range(len(target_len))]
+    per = [cov[off[i]:off[i + 1]] for i in range(len(target_len))]
+    return (per, touched[:len(target_len)], dsum[:len(target_len)]) if summary else per

@@ -548,8 +548,11 @@ def test_synth_coverage_parity(ctx, synth):
     import msamtools_amd as m
     hs, db = synth
     tlen = [5000] * 2000
-    cov = m.coverage(ctx, db, tlen)
+    cov, touched, dsum = m.coverage(ctx, db, tlen, summary=True)
     want = orc.coverage(hs, tlen)
     for t in range(len(tlen)):
         assert (cov[t] == want[t]).all(), t
     assert sum(int(c.sum()) for c in cov) > 0
+    # msx_coverage_summary: the two sums mWriteCoverageSummaryToStream divides by the target's length (msam_coverage.c:188-219)
+    assert touched.tolist() == [int((w != 0).sum()) for w in want]
+    assert dsum.tolist() == [int(w.astype(np.int64).sum()) for w in want]
