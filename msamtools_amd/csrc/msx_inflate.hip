@@ -9,22 +9,24 @@
 // the decode loop runs on wave-uniform values (bit buffer, table entries through readfirstlane: the scalar unit does
 // the arithmetic), and the lanes do together what can be done together: building the Huffman tables of a dynamic
 // block (code assignment by ballots, table fill one symbol per lane), copying a match (one byte per lane), staging
-// the compressed bytes into LDS a kilobyte ahead, writing the output back.  The chip runs thousands of blocks at a
-// time; what a block costs is latency, so everything the loop touches lives in LDS:
-//   ll / dt       primary decode tables indexed by the next 10 / 9 bits (bit-reversed codes); longer codes are rare
+// the compressed bytes into LDS half a kilobyte ahead, writing the output back.  The launch is persistent: as many
+// waves as are to be resident draw block numbers from a ticket.  What a block costs is latency and scalar issue, so
+// everything the loop touches lives in LDS, 11.3 KB per wave (fourteen waves per compute unit):
+//   ll / dt       primary decode tables indexed by the next 10 / 8 bits (bit-reversed codes); longer codes are rare
 //                 symbols and take the canonical route (limit per length, sorted symbols)
-//   in            the compressed stream, two halves of 1 KB; the half behind the read position is refilled from
-//                 registers that were loaded a kilobyte earlier
-//   ring          the last 8 KB of output.  Matches within reach (distance <= 7.5 KB -- records repeat their
-//                 neighbours) are LDS-to-LDS copies; farther ones read what has been written back to global memory
-//                 (behind a workgroup-scope fence: the wave reads its own earlier stores).  Every 2 KB the ring's new
-//                 bytes go out as aligned 16-byte vectors.
+//   in            the compressed stream, two halves of 512 bytes; the half behind the read position is refilled from
+//                 registers that were loaded a half earlier
+//   ring          the last 4 KB of output.  Matches within reach (distance <= 3.5 KB) are LDS-to-LDS copies; farther
+//                 ones read what has been written back to global memory (behind a workgroup-scope fence: the wave
+//                 reads its own earlier stores).  Every kilobyte the ring's new bytes go out as aligned 16-byte vectors.
+// A fast loop decodes the symbols whose codes the primary tables hold, between write-backs and input refills; anything
+// else leaves it in front of the symbol for a general step.
 // A block the decoder does not vouch for -- a code without a table entry, a distance before the start, lengths that
 // do not add up, a CRC mismatch -- is marked in status[] and left to the caller (the command line inflates such a
 // batch on the host, whose decoder and zlib produce the reference diagnostics).  No loop is unbounded: every
-// iteration consumes input bits, and running past the block's last bit ends the block.
-// k_bgzf_crc checks the CRC-32 of every block's output: 64 slices per block, one per lane, table-driven, joined by
-// multiplication with x^(8 * length) mod P.
+// iteration consumes input bits or produces output bytes, and running past the block's last bit ends the block.
+// k_bgzf_crc checks the CRC-32 of every block's output: passes of 4 KB, 64 bytes per lane, table-driven, the lanes'
+// states joined by multiplication with x^(8 * length) mod P.
 // Integer / byte work; no MFMA.
 #include "msx_internal.h"
 
