@@ -716,6 +716,8 @@ typedef struct {
 	int n_slots, n_consumers;
 	int raw_mode;              /* batches after the first are unpacked on the device: the decode stage only inflates */
 	size_t n_host_inflated;        /* batches the device inflater refused */
+	size_t n_comp_done;            /* compressed batches the device stage is through with */
+	int comp_given_up;             /* (decode thread) the input's blocks are inflated on the host from here on */
 	size_t n_ahead;                /* batches whose blocks were sent and inflated ahead (msx_unpack_prefetch_bgzf) */
 	int comp_mode, comp_blocks;    /* ... and inflated there as well: the decode stage only copies the blocks' payloads */
 	size_t ocap_cfg;
@@ -947,6 +949,7 @@ static int ahead_pop(ahead_q *A) {
 }
 static void unpack_slot_finish(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up, msx_unpack_result *ur, msx_batch *db) {
 	int rc = msx_unpack_finish(g_ctx, unpack, ur, db);
+	if (s->comp) __atomic_add_fetch(&P->n_comp_done, 1, __ATOMIC_RELAXED);
 	if (rc == MSX_ERR_INFLATE && s->comp) {
 		static __thread uint8_t *fb = NULL;
 		static __thread size_t fb_cap = 0;
@@ -1369,10 +1372,24 @@ static void *pipe_decode_thread(void *arg) {
 				/* (batch 0 may have grown batch_bytes to reach the preflight window; the configured size holds from here
 				 * on.  The buffer is page-locked and must not move: msh_inflate_append appends one batch of blocks at most,
 				 * so there is always room for the next call) */
-				s->comp = P->comp_mode;
+				/* an input whose blocks the device inflater keeps refusing (the first three batches, every one of them: an
+				 * encoder whose streams it does not decode) is inflated here from then on -- in batches the slots' buffers
+				 * hold -- instead of being tried on the device and inflated here batch by batch */
+				if (P->comp_mode && !P->comp_given_up) {
+					const size_t refused = __atomic_load_n(&P->n_host_inflated, __ATOMIC_RELAXED);
+					/* (+ 1: the batch the device stage is inflating here right now has been counted as done, not yet as refused) */
+					if (refused >= 3 && refused + 1 >= __atomic_load_n(&P->n_comp_done, __ATOMIC_RELAXED)) P->comp_given_up = 1;
+				}
+				s->comp = P->comp_mode && !P->comp_given_up;
 				s->n_blk = 0;
 				s->inflated = 0;
-				if (P->comp_mode) {
+				if (P->comp_mode && P->comp_given_up) {
+					const size_t per = P->batch_bytes_cfg / 65536 + 1 < 128 ? P->batch_bytes_cfg / 65536 + 1 : 128;
+					msh_inflate_limit((int)per);
+					while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + (per + 1) * 65536 + 64 <= s->rcap)
+						if (!pipe_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
+					msh_inflate_limit(0);
+				} else if (P->comp_mode) {
 					while (!P->in_eof && s->n_blk < P->comp_blocks && (s->rcap - s->rlen) / (65536 + 1024) > 0)
 						if (!msh_raw_append(P->in, s->rbuf, s->rcap, &s->rlen, s->blk, &s->n_blk, P->comp_blocks, &s->inflated)) P->in_eof = 1;
 				} else

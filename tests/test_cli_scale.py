@@ -136,8 +136,8 @@ def test_filter_digest_many_batches(big, tmp_path, inflag, outflag):
     big.check_digest(out, big.digest_out)
 
 
-@pytest.mark.parametrize("env", [dict(MSX_INFLATE_REFUSE=7), dict(MSX_HOST_INFLATE=1), dict(MSX_NO_INFLATE_AHEAD=1),
-                                 dict(MSX_INFLATE_WAVES=3)])
+@pytest.mark.parametrize("env", [dict(MSX_INFLATE_REFUSE=7), dict(MSX_INFLATE_REFUSE=1), dict(MSX_HOST_INFLATE=1),
+                                 dict(MSX_NO_INFLATE_AHEAD=1), dict(MSX_INFLATE_AHEAD=2), dict(MSX_INFLATE_WAVES=3)])
 def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
     """BGZF blocks are inflated on the device (msx_inflate.hip); batches with a block the device refuses (here: every 7th
     block, by a test switch) are inflated on the host instead; MSX_HOST_INFLATE=1 inflates everything there.  Same output."""
@@ -147,6 +147,9 @@ def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
     err = r.stderr.decode()
     if "MSX_INFLATE_REFUSE" in env:
         assert "inflated on the host (blocks the device refused)" in err
+        # every batch holds refused blocks: after the first few the device is no longer asked (the slots in flight still are)
+        tried = int(err.split(" batches inflated on the host")[0].split("# ")[-1])
+        assert 3 <= tried <= 12, tried
     elif "MSX_HOST_INFLATE" in env:
         assert "inflated on the device" not in err
     else:
