@@ -3415,6 +3415,52 @@ static int restream_main(int argc, char *argv[]) {
 	return 0;
 }
 
+/* `msamtools rawtest [--blocks N] <file.bam>` (hidden, host only): the decode stage's feed of the device inflater --
+ * msh_raw_append: block headers walked, DEFLATE payloads copied, table written -- checked without a device: every batch's
+ * table is inflated by msh_inflate_table, and the length and CRC-32 of the whole record stream (everything behind the
+ * BAM header) are printed for the test-suite to compare with an independent decompression. */
+static int rawtest_main(int argc, char *argv[]) {
+	const char *path = NULL;
+	int max_blocks = 64, i;
+	msh_in *in;
+	uint8_t *comp, *out = NULL, *head = NULL;
+	size_t cap = (size_t)8 << 20, out_cap = 0, hl = 0, hc = 0, total = 0, batches = 0, blocks = 0;
+	msx_bgzf_block *blk;
+	uLong crc = crc32(0L, NULL, 0);
+	for (i = 1; i < argc; i++) {
+		if (strcmp(argv[i], "--blocks") == 0 && i + 1 < argc) max_blocks = atoi(argv[++i]);
+		else path = argv[i];
+	}
+	if (!path || max_blocks < 1) mQuit("usage: %s rawtest [--blocks N] <file.bam>", PROGRAM);
+	in = msh_open(path);
+	if (!msh_is_bam(in)) mQuit("rawtest: BAM input only");
+	/* what msh_open has inflated beyond the header comes first (one call: the span's live bytes, or the next batch) */
+	msh_inflate_limit(2);
+	if (msh_inflate_append(in, &head, &hl, &hc)) { crc = crc32(crc, head, (uInt)hl); total += hl; }
+	msh_inflate_limit(0);
+	comp = (uint8_t *)xmalloc(cap);
+	blk = (msx_bgzf_block *)xmalloc((size_t)max_blocks * sizeof *blk);
+	for (;;) {
+		size_t len = 0, inflated = 0;
+		int n = 0;
+		while (n < max_blocks && (cap - len) / (65536 + 1024) > 0)
+			if (!msh_raw_append(in, comp, cap, &len, blk, &n, max_blocks, &inflated)) break;
+		if (n == 0) break;
+		if (inflated + 64 > out_cap) { out_cap = inflated + 64; out = (uint8_t *)realloc(out, out_cap); if (!out) mDie("Out of memory"); }
+		msh_inflate_table(comp, blk, n, out);
+		for (i = 0; i < n; i++)
+			if (blk[i].out_off != (i ? blk[i - 1].out_off + blk[i - 1].out_len : 0) || blk[i].in_off + blk[i].in_len > len)
+				mDie("rawtest: inconsistent table");
+		{ size_t q = 0; while (q < inflated) { const size_t k = inflated - q > 0x40000000u ? 0x40000000u : inflated - q; crc = crc32(crc, out + q, (uInt)k); q += k; } }
+		total += inflated;
+		batches++;
+		blocks += (size_t)n;
+	}
+	printf("bytes=%zu crc32=%08lx batches=%zu blocks=%zu\n", total, (unsigned long)crc, batches, blocks);
+	msh_close(in);
+	return 0;
+}
+
 int main(int argc, char *argv[]) {
 	g_t_main = now_s();
 	msh_main_thread = pthread_self();
@@ -3437,6 +3483,7 @@ int main(int argc, char *argv[]) {
 	if (strcmp(argv[1], "pipetest") == 0) return pipetest_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "digest") == 0) return digest_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "restream") == 0) return restream_main(argc - 1, argv + 1);
+	if (strcmp(argv[1], "rawtest") == 0) return rawtest_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "synth") == 0) return synth_main(argc - 1, argv + 1);
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);

@@ -443,6 +443,29 @@ def test_pipeline_decode_of_sam_text_equals_record_reader(synth_bams, tmp_path):
     assert rc == 0, text
 
 
+
+@pytest.mark.parametrize("flag", ["b", "u"])
+@pytest.mark.parametrize("blocks", [1, 7, 64, 4096])
+def test_block_feed_of_the_device_inflater(synth_bams, flag, blocks):
+    """msh_raw_append (block headers walked, DEFLATE payloads copied, table written) + msh_inflate_table, without a
+    device (`msamtools rawtest`): the record stream they reproduce against Python's own decompression of the file."""
+    import gzip
+    import struct
+    import zlib
+    raw = gzip.open(synth_bams[flag], "rb").read()
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 8 + struct.unpack_from("<i", raw, p)[0]
+    out = subprocess.check_output([BIN, "rawtest", "--blocks", str(blocks), synth_bams[flag]],
+                                  env=dict(os.environ, MSX_THREADS="5", MSX_INFLATE_BLOCKS="8")).decode().split()
+    got = dict(kv.split("=") for kv in out)
+    assert int(got["bytes"]) == len(raw) - p
+    assert int(got["crc32"], 16) == zlib.crc32(raw[p:])
+    assert int(got["batches"]) >= (2 if blocks < 64 else 1)
+
 @pytest.mark.parametrize("flag", ["-u", "-b"])
 def test_stream_writer_roundtrip(synth_bams, tmp_path, flag):
     """msh_write_stream -- the writer of device-unpacked batches: a ready-made record stream cut into BGZF payloads where
