@@ -2209,7 +2209,8 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		}
 		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.comp_mode ? P.n_ahead : F.dev[0].n_prefetched,
 		        P.comp_mode ? "; BGZF blocks inflated on the device" : "");
-		if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
+		if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)%s\n", P.n_host_inflated,
+		                               P.comp_given_up ? "; the device was not asked any more after that" : "");
 		if (F.dev[0].n_end) {
 			int q;
 			fprintf(stderr, "# device stage, batches done at (ms):");
@@ -2681,7 +2682,8 @@ int msam_profile_main(int argc, char *argv[]) {
 		qn = S.qn;
 		if (getenv("MSX_TIMING")) {
 			fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.n_ahead, P.comp_mode ? "; BGZF blocks inflated on the device" : "");
-			if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)\n", P.n_host_inflated);
+			if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)%s\n", P.n_host_inflated,
+		                               P.comp_given_up ? "; the device was not asked any more after that" : "");
 			fprintf(stderr, "# decode stage: inflate %.3f, record chase %.3f, aux scan %.3f, offsets+pools (serial) %.3f, payload copy %.3f s\n",
 			        P.t_inflate, P.t_chase, P.t_scan, P.t_serial, P.t_copy);
 			fprintf(stderr, "# profile pipeline: wall %.3f s; decode %.3f s (+%.3f waiting for a free slot); device: start-up %.3f, "
