@@ -340,6 +340,38 @@ def bgzf_inflate(ctx, comp, blocks, n_blocks, total_out):
             ctx.free(p)
 
 
+def bgzf_deflate(ctx, data, level=0):
+    """msx_bgzf_deflate on host data: (bytes of finished BGZF blocks, number of blocks)"""
+    data = bytes(data)
+    cap = int(ctx.lib.msx_bgzf_bound(len(data), level)) + 64
+    d_in = ctx.alloc(len(data) + 64)
+    d_out = ctx.alloc(cap)
+    try:
+        ctx.to_dev(d_in, np.frombuffer(data + b"\0" * 64, np.uint8))
+        n_out, n_blk = C.c_int64(-1), C.c_int64(-1)
+        ctx.check(ctx.lib.msx_bgzf_deflate(ctx.h, C.c_void_p(d_in), len(data), level, C.c_void_p(d_out), cap,
+                                           C.byref(n_out), C.byref(n_blk)))
+        out = ctx.to_host(d_out, max(n_out.value, 1), np.uint8)[:n_out.value].tobytes()
+        return out, n_blk.value
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+
+
+def bgzf_split(stream):
+    """the BGZF blocks of a byte string: [(payload bytes, isize, crc32)], checking every header on the way"""
+    out, p = [], 0
+    while p < len(stream):
+        h = stream[p:p + 18]
+        assert len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[10:12] == b"\x06\x00" and h[12:16] == b"BC\x02\x00", (p, h)
+        total = int.from_bytes(h[16:18], "little") + 1
+        blk = stream[p:p + total]
+        assert len(blk) == total, (p, total, len(blk))
+        out.append((blk[18:-8], int.from_bytes(blk[-4:], "little"), int.from_bytes(blk[-8:-4], "little")))
+        p += total
+    return out
+
+
 class Unpack:
     """msx_unpack: the record walk on the device (inflated BAM bytes in, msx_batch view out)."""
 
@@ -415,6 +447,15 @@ class Unpack:
         self.ctx.check(self.ctx.lib.msx_unpack_emit(self.ctx.h, self.h, C.c_void_p(emit_ptr), int(n_emit),
                                                     out.ctypes.data_as(C.c_void_p), out.size, C.byref(nb)))
         return out[:nb.value].tobytes()
+
+    def emit_bgzf(self, emit_ptr, n_emit, cap, level=0):
+        """filter's output as finished BGZF blocks (msx_unpack_emit_gather_bgzf + fetch)"""
+        nb, nblk = C.c_int64(0), C.c_int64(0)
+        self.ctx.check(self.ctx.lib.msx_unpack_emit_gather_bgzf(self.ctx.h, self.h, C.c_void_p(emit_ptr), int(n_emit), level,
+                                                               C.byref(nb), C.byref(nblk)))
+        out = np.zeros(max(nb.value, 1), np.uint8)
+        self.ctx.check(self.ctx.lib.msx_unpack_emit_fetch(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p), out.size, None))
+        return out[:nb.value].tobytes(), nblk.value
 
     def close(self):
         if self.h:

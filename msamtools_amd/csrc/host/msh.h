@@ -115,6 +115,8 @@ void msh_write(msh_out *o, const uint8_t *rec, size_t len);
 void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, const int32_t *idx, size_t n);
 /* a ready-made record stream ([block_size | record] back to back, as msx_unpack_emit returns it) */
 void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n);
+/* finished BGZF blocks, back to back (framed on the device): written as they are */
+void msh_write_framed(msh_out *o, const uint8_t *blocks, size_t n);
 void msh_out_drain(msh_out *o);     /* before dying: what was handed to the writer is written out */
 void msh_out_close(msh_out *o);
 

@@ -703,6 +703,7 @@ typedef struct {
 	msx_event *ev_out;         /* ... are there once this has been waited for */
 	msx_ctx *ev_ctx;
 	size_t ocap, olen;
+	int framed;                /* obuf holds finished BGZF blocks (msx_unpack_emit_gather_bgzf), not a bare record stream */
 	int fatal;                 /* the batch holds a record the reference dies at: fatal_msg, after the pools before it */
 	char fatal_msg[512];
 } pslot;
@@ -1785,6 +1786,7 @@ struct fshared {
 	/* one device: its thread finalizes and writes the profile as soon as the last batch is accumulated, beside the
 	 * writer's last batches (profile_done); not when a batch held a record the reference dies at (any_fatal) */
 	int profile_done, any_fatal;
+	int dev_frame;              /* -bu: the device hands down finished (stored) BGZF blocks, msx_unpack_emit_gather_bgzf */
 	double t_finalized, t_reported;
 	fdev_t dev[MSH_MAX_DEVICES];
 };
@@ -1930,7 +1932,9 @@ static void *filter_dev_thread(void *arg) {
 				if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
 				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
 				 * while the next batch is worked on: the writer waits for s->ev_out */
-				MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
+				s->framed = F->dev_frame;
+				if (F->dev_frame) MSX(msx_unpack_emit_gather_bgzf(g_ctx, unpack, fo.emit_idx, st.n_emit, 0, &nb, NULL));
+				else MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
 				if (nb > 0) {
 					s->ob = pq_pop(&P->q_ob);                /* (waits for the writer when all of them are on their way out) */
 					if ((size_t)nb + 64 > P->ob_cap[s->ob]) {          /* (the old one stays mapped and page-locked: rare) */
@@ -2112,6 +2116,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
 	if (po) prof_features(po, P.hdr, &pf);
+	F.dev_frame = out_mode == MSH_OUT_UBAM && !getenv("MSX_HOST_FRAME");
 	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv; F.po = po; F.pf = &pf;
 	pthread_mutex_init(&F.mu, NULL);
 	if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
@@ -2141,7 +2146,8 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		s = &P.slot[si];
 		if (s->raw) {
 			if (s->ev_out && s->olen) { if (msx_event_wait(s->ev_ctx, s->ev_out) != MSX_OK) mDie("%s", msx_last_error(s->ev_ctx)); }
-			msh_write_stream(F.out, s->obuf, s->olen);
+			if (s->framed) msh_write_framed(F.out, s->obuf, s->olen);
+			else msh_write_stream(F.out, s->obuf, s->olen);
 			if (s->ob >= 0) { pq_push(&P.q_ob, s->ob); s->ob = -1; }
 		} else if (!fp->rescore) {
 			msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);

@@ -1485,6 +1485,10 @@ struct msh_out {
 	uint8_t *ubuf;       /* BGZF payload being filled */
 	uint32_t ulen;
 	int level;
+	/* msh_write_framed: finished blocks written from where they are.  A regular file opened without O_APPEND takes
+	 * them as pwrite()s of disjoint ranges from several threads (par_threads > 1), the descriptor's offset moved behind
+	 * them afterwards */
+	int par_threads;     /* -1: not looked at yet */
 };
 #define BGZF_PAYLOAD 0xff00
 #define WCHUNK_BLOCKS 2048          /* blocks per chunk handed to the writer thread */
@@ -1498,6 +1502,7 @@ struct wchunk {
 	size_t slots_bytes, slots_cap, nblk;
 	uint32_t *slot_len;
 	int mapped;              /* slots is an anonymous mapping of its own (vmsplice) rather than heap memory */
+	size_t flat_len;         /* != 0: slots holds flat_len bytes of finished blocks back to back (msh_write_framed) */
 };
 
 /* Slot arrays of file output are reused: a fresh 136 MB allocation per chunk meant a page fault (and a zeroed page) for
@@ -1538,6 +1543,27 @@ static void slots_put(uint8_t *p, size_t bytes) {
 
 static void chunk_write(msh_out *o, struct wchunk *c) {
 	size_t q;
+	if (c->flat_len) {                   /* one run of bytes (a pipe: handed over by reference, like the slots below) */
+		uint8_t *p = c->slots;
+		size_t want = c->flat_len;
+		while (want) {
+			struct iovec iv;
+			ssize_t got;
+			iv.iov_base = p; iv.iov_len = want;
+			if (c->mapped && __atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED)) {
+				got = vmsplice(o->fd, &iv, 1, 0);
+				if (got < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { __atomic_store_n(&o->is_pipe, 0, __ATOMIC_RELAXED); continue; }
+			} else {
+				got = write(o->fd, p, want);
+			}
+			if (got < 0 && errno == EINTR) continue;
+			if (got <= 0) mDie("Write failed");
+			p += got; want -= (size_t)got;
+		}
+		munmap(c->slots, c->slots_bytes);
+		free(c);
+		return;
+	}
 	/* the chunk's blocks in order, up to 512 of them per system call */
 	for (q = 0; q < c->nblk;) {
 		struct iovec iv[512];
@@ -1655,6 +1681,7 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 	o->mode = mode;
 	o->hdr = h;
 	o->fd = -1;
+	o->par_threads = -1;
 	setvbuf(fp, NULL, _IOFBF, 1 << 20);
 	if (mode == MSH_OUT_BAM || mode == MSH_OUT_UBAM) {
 		fflush(fp);
@@ -1995,6 +2022,76 @@ void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n) {
 		const size_t rest = n - nb * BGZF_PAYLOAD;
 		memcpy(o->ubuf, bytes + nb * BGZF_PAYLOAD, rest);
 		o->ulen = (uint32_t)rest;
+	}
+}
+
+/* Finished BGZF blocks, back to back, as the device framed them (msx_unpack_emit_gather_bgzf): nothing is copied or
+ * summed here.  The block a host-side writer call left open goes out first, as a short block of its own.
+ * Regular file: written from where they are -- by MSX_WRITE_THREADS threads as pwrite()s of disjoint ranges when the
+ * descriptor allows it (no O_APPEND, seekable).  Pipe: the bytes are copied once, by all threads, into a fresh
+ * mapping that is handed over by reference (the caller's buffer is page-locked and reused, so it cannot be). */
+typedef struct { int fd; const uint8_t *src; uint8_t *dst; size_t n; off_t off; } fjob;
+static void framed_pwrite_worker(void *arg, int tid, int nth) {
+	const fjob *j = (const fjob *)arg;
+	const size_t al = (size_t)1 << 20;
+	size_t per = (j->n / (size_t)nth + al - 1) / al * al, lo = per * (size_t)tid, hi = lo + per < j->n ? lo + per : j->n;
+	while (lo < hi) {
+		ssize_t k = pwrite(j->fd, j->src + lo, hi - lo, j->off + (off_t)lo);
+		if (k < 0 && errno == EINTR) continue;
+		if (k <= 0) mDie("Write failed");
+		lo += (size_t)k;
+	}
+}
+static void framed_copy_worker(void *arg, int tid, int nth) {
+	const fjob *j = (const fjob *)arg;
+	const size_t lo = j->n * (size_t)tid / (size_t)nth, hi = j->n * (size_t)(tid + 1) / (size_t)nth;
+	memcpy(j->dst + lo, j->src + lo, hi - lo);
+}
+
+void msh_write_framed(msh_out *o, const uint8_t *blocks, size_t n) {
+	fjob J;
+	if (n == 0) return;
+	if (o->mode != MSH_OUT_BAM && o->mode != MSH_OUT_UBAM) mDie("msh_write_framed: not a BAM output");
+	if (o->ulen) bgz_flush_block(o);
+	writer_drain(o);
+	if (o->par_threads < 0) {
+		const char *e = getenv("MSX_WRITE_THREADS");
+		struct stat st;
+		const int fl = fcntl(o->fd, F_GETFL);
+		o->par_threads = 1;
+		if (fstat(o->fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND) && lseek(o->fd, 0, SEEK_CUR) >= 0)
+			o->par_threads = e ? atoi(e) : 1;
+		if (o->par_threads < 1) o->par_threads = 1;
+		if (o->par_threads > msh_threads()) o->par_threads = msh_threads();
+	}
+	memset(&J, 0, sizeof J);
+	J.fd = o->fd; J.src = blocks; J.n = n;
+	if (__atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED)) {
+		struct wchunk *c = (struct wchunk *)calloc(1, sizeof(*c));
+		int nth = msh_threads();
+		if (!c) mDie("Out of memory");
+		c->slots_bytes = (n + 4095) & ~(size_t)4095;
+		c->slots = (uint8_t *)mmap(NULL, c->slots_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (c->slots == (uint8_t *)MAP_FAILED) mDie("Out of memory");
+		c->mapped = 1;
+		c->flat_len = n;
+		J.dst = c->slots;
+		if ((size_t)nth > n / 65536 + 1) nth = (int)(n / 65536 + 1);
+		msh_parallel(nth, framed_copy_worker, &J);
+		writer_put(o, c);
+		return;
+	}
+	if (o->par_threads > 1 && n >= ((size_t)8 << 20)) {
+		J.off = lseek(o->fd, 0, SEEK_CUR);
+		msh_parallel(o->par_threads, framed_pwrite_worker, &J);
+		if (lseek(o->fd, J.off + (off_t)n, SEEK_SET) < 0) mDie("Write failed");
+		return;
+	}
+	while (n) {
+		ssize_t k = write(o->fd, blocks, n);
+		if (k < 0 && errno == EINTR) continue;
+		if (k <= 0) mDie("Write failed");
+		blocks += k; n -= (size_t)k;
 	}
 }
 

@@ -125,6 +125,10 @@ int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes);
 // msx_inflate.hip: inflate + CRC check of n_blocks BGZF blocks on `stream`, waves_per_cu waves per compute unit (0: all the LDS holds); d_n_bad[0] (zeroed by the caller) counts the refused, d_n_bad[1] is the launch's ticket counter
 int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
                             const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad);
+// msx_deflate.hip: the byte string in[0 .. total) -- total = *d_total (a device word) if given, else n_cap -- framed as stored BGZF
+// blocks: block k at k * (0xff00 + 31), all full but the last; the launch is sized by n_cap
+int msx_bgzf_store_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out);
+extern "C" int64_t msx_bgzf_bound(int64_t n_bytes, int level);
 extern thread_local std::string msx_tls_err;
 
 #define MSX_HIP(ctx, call)                                                              \

@@ -66,7 +66,7 @@ struct msx_unpack {
 	int ahead_head = 0, ahead_n = 0;   // the oldest pending set, how many are pending
 	hipStream_t inf_stream = nullptr, h2d_stream = nullptr;
 	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
-	    group_off, tile_last, cigar, md, out_len, out_off, out;
+	    group_off, tile_last, cigar, md, out_len, out_off, out, framed;
 	char *prev_name = nullptr;     // device, 256 bytes
 	up_state *d_state = nullptr, *h_state = nullptr;
 	msx_unpack_params prm = {};
@@ -77,7 +77,8 @@ struct msx_unpack {
 	hipEvent_t copy_done = nullptr;
 	hipEvent_t out_copied = nullptr;   // msx_unpack_emit_fetch: the gather buffer has been read
 	bool out_busy = false;
-	size_t gathered = 0;               // msx_unpack_emit_gather: bytes in `out`
+	size_t gathered = 0;               // msx_unpack_emit_gather: bytes in `out` (msx_unpack_emit_gather_bgzf: in `framed`)
+	const void *fetch_src = nullptr;   // what msx_unpack_emit_fetch brings down
 	const uint8_t *pre_host = nullptr;
 	size_t pre_n = 0;
 };
@@ -563,7 +564,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
-	                   &u->out_off, &u->out, &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
+	                   &u->out_off, &u->out, &u->framed, &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
 	                   &u->pre[0].status, &u->pre[0].out, &u->pre[0].cnt, &u->pre[1].comp, &u->pre[1].blk, &u->pre[1].status,
 	                   &u->pre[1].out, &u->pre[1].cnt};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
@@ -924,11 +925,10 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 
 // Filter's output records gathered into one byte string on the device (block_size prefixes included, output order);
 // *n_bytes tells how long it is.  msx_unpack_emit_fetch brings it down.
-extern "C" int msx_unpack_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int64_t *n_bytes) {
-	if (!ctx || !u || !n_bytes || (n_emit > 0 && !emit_idx_dev)) return MSX_ERR_ARG;
+static int up_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level) {
 	msx_join(ctx);
-	*n_bytes = 0;
 	u->gathered = 0;
+	u->fetch_src = nullptr;
 	if (n_emit <= 0) return MSX_OK;
 	// (the gather buffer may still be on its way down for the batch before)
 	if (u->out_busy) { MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->out_copied, 0)); u->out_busy = false; }
@@ -947,9 +947,45 @@ extern "C" int msx_unpack_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t
 	hipLaunchKernelGGL(k_emit_copy, dim3((n_waves + 3) / 4), dim3(MSX_BLOCK), 0, ctx->stream, raw, ne, emit_idx_dev,
 	                   (const uint32_t *)u->rec_off.p, (const uint32_t *)u->out_off.p, (uint8_t *)u->out.p, u->d_state);
 	MSX_HIP(ctx, hipGetLastError());
+	if (level == 0) {
+		// -u: framed on the device as stored blocks; the launch is sized by the batch's bytes, the kernel reads how many
+		// were emitted (out_off[n_emit]) where the scan has left it
+		UP_RES(framed, (size_t)msx_bgzf_bound((int64_t)u->n_bytes + 64, 0) + 64);
+		if ((rc = msx_bgzf_store_launch(ctx, ctx->stream, (const uint8_t *)u->out.p, (const uint32_t *)u->out_off.p + ne, u->n_bytes,
+		                                (uint8_t *)u->framed.p)))
+			return rc;
+	}
 	if ((rc = up_fetch_state(ctx, u))) return rc;                   // sync: how many bytes
+	return MSX_OK;
+}
+
+extern "C" int msx_unpack_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int64_t *n_bytes) {
+	if (!ctx || !u || !n_bytes || (n_emit > 0 && !emit_idx_dev)) return MSX_ERR_ARG;
+	*n_bytes = 0;
+	int rc = up_emit_gather(ctx, u, emit_idx_dev, n_emit, -1);
+	if (rc || n_emit <= 0) return rc;
 	u->gathered = u->h_state->emit_bytes;
+	u->fetch_src = u->out.p;
 	*n_bytes = (int64_t)u->gathered;
+	return MSX_OK;
+}
+
+// The same, and the byte string cut into BGZF blocks on the device (msx_deflate.hip): what comes down is what goes into
+// the file.  level 0: stored blocks (filter -bu).  *n_bytes: bytes of finished blocks, *n_blocks: how many; the blocks of
+// one call are full except the last.
+extern "C" int msx_unpack_emit_gather_bgzf(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level,
+                                           int64_t *n_bytes, int64_t *n_blocks) {
+	if (!ctx || !u || !n_bytes || (n_emit > 0 && !emit_idx_dev)) return MSX_ERR_ARG;
+	if (level != 0) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit_gather_bgzf: level %d", level);
+	*n_bytes = 0;
+	if (n_blocks) *n_blocks = 0;
+	int rc = up_emit_gather(ctx, u, emit_idx_dev, n_emit, level);
+	if (rc || n_emit <= 0) return rc;
+	const int64_t raw_bytes = (int64_t)u->h_state->emit_bytes;
+	u->gathered = (size_t)msx_bgzf_bound(raw_bytes, 0);
+	u->fetch_src = u->framed.p;
+	*n_bytes = (int64_t)u->gathered;
+	if (n_blocks) *n_blocks = (raw_bytes + 0xff00 - 1) / 0xff00;
 	return MSX_OK;
 }
 
@@ -962,12 +998,12 @@ extern "C" int msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_
 	if (tb == 0) return MSX_OK;
 	if (tb > host_cap) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: output buffer too small (%zu > %zu)", tb, host_cap);
 	if (!done) {
-		MSX_HIP(ctx, hipMemcpyAsync(host_out, u->out.p, tb, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(host_out, u->fetch_src, tb, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		return MSX_OK;
 	}
 	// (the kernels that wrote u->out have been waited for by msx_unpack_emit_gather)
-	MSX_HIP(ctx, hipMemcpyAsync(host_out, u->out.p, tb, hipMemcpyDeviceToHost, u->copy_stream));
+	MSX_HIP(ctx, hipMemcpyAsync(host_out, u->fetch_src, tb, hipMemcpyDeviceToHost, u->copy_stream));
 	MSX_HIP(ctx, hipEventRecord(u->out_copied, u->copy_stream));
 	MSX_HIP(ctx, hipEventRecord(done->ev, u->copy_stream));
 	u->out_busy = true;

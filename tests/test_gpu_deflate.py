@@ -1,0 +1,128 @@
+"""BGZF blocks written on the device (msx_deflate.hip): the reference writes through htslib's BGZF layer
+(sam_write1 -> bgzf_write, msam_helper.c:270-272; "wbu" / "wb": msam_filter.c:464-470).  Which bytes a writer puts into
+its blocks is not pinned by the reference (its tests compare records: tests/functions.sh:160-163); the rule is that
+every block is a valid gzip member with a BC field, that zlib and this repository's own inflater decode the blocks to
+the input, byte for byte, and that CRC-32 / ISIZE / BSIZE are right."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PAYLOAD = 0xff00
+
+
+def M():
+    import msamtools_amd
+    return msamtools_amd
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = M().Context(0)
+    yield c
+    c.close()
+
+
+def bam_like(rng, n_bytes, seq=False):
+    """records that repeat their neighbours, the way name-sorted BAM does"""
+    out = bytearray()
+    k = 0
+    while len(out) < n_bytes:
+        name = b"sim%08d" % k
+        for h in range(int(rng.integers(1, 9))):
+            core = rng.integers(0, 256, 12, dtype=np.uint8).tobytes()
+            out += (60 + len(name)).to_bytes(4, "little") + core + name + b"\0" + bytes([100 << 4 & 255, 6, 0, 0])
+            if seq:
+                out += rng.integers(0, 256, 50, dtype=np.uint8).tobytes() + bytes(rng.integers(30, 42, 100, dtype=np.uint8))
+            out += b"NMC" + bytes([int(rng.integers(0, 4))]) + b"ASC" + bytes([int(rng.integers(90, 101))]) + b"MDZ100\0"
+        k += 1
+    return bytes(out[:n_bytes])
+
+
+def check_stream(ctx, data, stream, n_blk, level):
+    m = M()
+    blocks = m.bgzf_split(stream)
+    assert len(blocks) == n_blk == (len(data) + PAYLOAD - 1) // PAYLOAD
+    # whole-stream check by an independent reader: a BGZF file is a multi-member gzip file
+    assert gzip.decompress(stream) == data if data else stream == b""
+    pos = 0
+    payloads, datas = [], []
+    for i, (pl, isize, crc) in enumerate(blocks):
+        want = data[pos:pos + isize]
+        assert isize == (PAYLOAD if i + 1 < len(blocks) else len(data) - pos)
+        assert crc == zlib.crc32(want)
+        assert zlib.decompress(pl, -15) == want
+        if level == 0:
+            assert len(pl) == 5 + isize and pl[0] == 1
+        payloads.append(pl)
+        datas.append(want)
+        pos += isize
+    assert pos == len(data)
+    # ... and by the device's own inflater (msx_inflate.hip)
+    if blocks:
+        comp, tab, total = m.bgzf_blocks(payloads, datas)
+        out, st, refused = m.bgzf_inflate(ctx, comp, tab, len(payloads), total)
+        assert refused == 0 and not st.any() and out[:total].tobytes() == data
+
+
+SIZES = [0, 1, 15, 16, 17, 4095, 4096, 4097, PAYLOAD - 1, PAYLOAD, PAYLOAD + 1, 2 * PAYLOAD, 3 * PAYLOAD + 17, 1_000_003]
+
+
+@pytest.mark.parametrize("level", [0])
+def test_blocks_decode_to_the_input(ctx, level):
+    rng = np.random.default_rng(41)
+    for n in SIZES:
+        for kind in ("random", "bam", "zeros"):
+            data = (rng.integers(0, 256, n, dtype=np.uint8).tobytes() if kind == "random" else
+                    bam_like(rng, n) if kind == "bam" else bytes(n))
+            stream, n_blk = M().bgzf_deflate(ctx, data, level)
+            check_stream(ctx, data, stream, n_blk, level)
+
+
+@pytest.mark.parametrize("level", [0])
+def test_large_input(ctx, level):
+    rng = np.random.default_rng(7)
+    data = bam_like(rng, 40_000_000, seq=True)
+    stream, n_blk = M().bgzf_deflate(ctx, data, level)
+    assert n_blk == (len(data) + PAYLOAD - 1) // PAYLOAD
+    assert gzip.decompress(stream) == data
+    if level == 0:
+        assert len(stream) == len(data) + 31 * n_blk
+
+
+@pytest.mark.parametrize("level", [0])
+def test_emit_as_finished_blocks(ctx, level):
+    """filter's output records of an unpacked batch, gathered and framed in one call: the blocks hold exactly the
+    record stream msx_unpack_emit returns"""
+    import struct
+    m = M()
+    rng = np.random.default_rng(3)
+    recs = []
+    for k in range(30000):
+        name = b"r%07d\0" % (k // 3)
+        body = struct.pack("<iiBBHHHIiii", 0, 10 + k, len(name), 30, 4680, 1, 0, 0, -1, -1, 0) + name + struct.pack("<I", 100 << 4)
+        body += b"NMC\1ASC\x60MDZ" + (b"%d" % int(rng.integers(1, 100))) + b"\0"
+        recs.append(struct.pack("<I", len(body)) + body)
+    stream = b"".join(recs)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    up = m.Unpack(ctx)
+    up.seed()
+    up.enqueue(stream, pool_mode=1, n_targets=5, last=True)
+    res, view = up.finish()
+    n = int(res.n_records)
+    assert n == len(recs)
+    emit = np.sort(rng.choice(n, size=n // 2, replace=False)).astype(np.int32)
+    d = ctx.alloc(4 * emit.size)
+    ctx.to_dev(d, emit)
+    want = b"".join(stream[int(off[i]):int(off[i + 1])] for i in emit)
+    assert up.emit(d, emit.size, len(stream)) == want
+    blocks, n_blk = up.emit_bgzf(d, emit.size, len(stream), level)
+    check_stream(ctx, want, blocks, n_blk, level)
+    # nothing emitted: no bytes, no blocks
+    blocks, n_blk = up.emit_bgzf(d, 0, len(stream), level)
+    assert blocks == b"" and n_blk == 0
+    ctx.free(d)
+    up.close()
