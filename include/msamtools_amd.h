@@ -256,8 +256,9 @@ int  msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_out, size_
 /* msx_unpack_emit_gather with the BGZF layer of the writer on the device as well (mSamWrite -> sam_write1 -> bgzf_write:
  * msam_helper.c:270-272; "wbu" / "wb": msam_filter.c:464-470): the gathered byte string is cut into payloads of 0xff00
  * bytes and every payload becomes a finished BGZF block -- header with BSIZE, DEFLATE stream, CRC-32, ISIZE -- so that what
- * msx_unpack_emit_fetch brings down is what goes into the file, byte for byte.  level 0: stored blocks (-bu).
- * *n_bytes: bytes of finished blocks; *n_blocks: how many (all full but the last). */
+ * msx_unpack_emit_fetch brings down is what goes into the file, byte for byte.  level 0: stored blocks (-bu); level >= 1:
+ * DEFLATE with dynamic Huffman codes (-b; one encoder, the level is not a dial).
+ * *n_bytes: bytes of finished blocks; *n_blocks: how many (payloads all full but the last). */
 int  msx_unpack_emit_gather_bgzf(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level,
                                  int64_t *n_bytes, int64_t *n_blocks);
 /* record offsets of the last batch, u32[n + 1] relative to its first byte (tests, SAM-text writers) */
@@ -298,7 +299,9 @@ int  msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_c
  *
  * The other direction (bgzf_write under sam_write1, msam_helper.c:270-272): n_bytes of device memory cut into payloads of
  * 0xff00 bytes, each framed as one BGZF block in d_out, back to back.  level 0: stored blocks (what htslib writes for
- * "wbu", msam_filter.c:464-470).  msx_bgzf_bound: bytes d_out must hold.  Waits for the result. */
+ * "wbu", msam_filter.c:464-470); level >= 1: raw DEFLATE ("wb"), LZ77 + dynamic Huffman codes per block -- the bytes differ
+ * from zlib's, the records do not (the reference's tests compare records: tests/functions.sh:160-163).
+ * msx_bgzf_bound: bytes d_out must hold.  Waits for the result. */
 int64_t msx_bgzf_bound(int64_t n_bytes, int level);
 int  msx_bgzf_deflate(msx_ctx *ctx, const void *d_in, size_t n_bytes, int level, void *d_out, size_t out_cap,
                       int64_t *n_out, int64_t *n_blocks);

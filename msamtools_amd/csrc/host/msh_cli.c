@@ -1786,7 +1786,7 @@ struct fshared {
 	/* one device: its thread finalizes and writes the profile as soon as the last batch is accumulated, beside the
 	 * writer's last batches (profile_done); not when a batch held a record the reference dies at (any_fatal) */
 	int profile_done, any_fatal;
-	int dev_frame;              /* -bu: the device hands down finished (stored) BGZF blocks, msx_unpack_emit_gather_bgzf */
+	int dev_frame, dev_level;   /* -bu / -b: the device hands down finished BGZF blocks (stored / deflated), msx_unpack_emit_gather_bgzf */
 	double t_finalized, t_reported;
 	fdev_t dev[MSH_MAX_DEVICES];
 };
@@ -1933,7 +1933,7 @@ static void *filter_dev_thread(void *arg) {
 				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
 				 * while the next batch is worked on: the writer waits for s->ev_out */
 				s->framed = F->dev_frame;
-				if (F->dev_frame) MSX(msx_unpack_emit_gather_bgzf(g_ctx, unpack, fo.emit_idx, st.n_emit, 0, &nb, NULL));
+				if (F->dev_frame) MSX(msx_unpack_emit_gather_bgzf(g_ctx, unpack, fo.emit_idx, st.n_emit, F->dev_level, &nb, NULL));
 				else MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
 				if (nb > 0) {
 					s->ob = pq_pop(&P->q_ob);                /* (waits for the writer when all of them are on their way out) */
@@ -2116,7 +2116,10 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
 	if (po) prof_features(po, P.hdr, &pf);
-	F.dev_frame = out_mode == MSH_OUT_UBAM && !getenv("MSX_HOST_FRAME");
+	/* the BGZF layer of the output on the device: stored blocks for -bu, DEFLATE for -b (MSX_HOST_FRAME=1: frame / zlib-deflate
+	 * on the host cores, as round 3 did; MSX_HOST_DEFLATE=1: only -b's deflate) */
+	F.dev_frame = (out_mode == MSH_OUT_UBAM || (out_mode == MSH_OUT_BAM && !getenv("MSX_HOST_DEFLATE"))) && !getenv("MSX_HOST_FRAME");
+	F.dev_level = out_mode == MSH_OUT_UBAM ? 0 : 6;
 	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv; F.po = po; F.pf = &pf;
 	pthread_mutex_init(&F.mu, NULL);
 	if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");

@@ -216,6 +216,309 @@ extern "C" int msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *b, const i
 	return MSX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// A whole sample in one batch: depths written once (msx_coverage_depths).
+//
+// The streamed path above keeps a difference array in global memory -- zeroed by the caller, marked batch after
+// batch, summed in place at the end: the 1 GB array of the c4 workload is touched three times and the marks arrive
+// as atomic adds.  When the batch IS the sample the depths of a tile can be finished where its marks are gathered:
+//   k_cov_emit2     a record's first run as two items in its own slots -- item = sign << S | cell: the sign sits ABOVE
+//                   the tile number, so the sort leaves all +1 marks by tile, then all -1 marks by tile, and the
+//                   running depth at a tile's first cell is (+1 marks in front of the tile) - (-1 marks in front of
+//                   it): two positions in the sorted array, no pass over the marks; further runs of a record (after
+//                   a D or N) go to one of 64 overflow lists (one LDS-staged append per workgroup, so no same-address
+//                   traffic); the first radix pass's digit counts of the workgroup's 4096 items are left in the
+//                   sort's table on the way (one read of the items saved)
+//   radix sort      by (sign, tile), keys only
+//   k_cov_starts2   where every (sign, tile) begins
+//   k_cov_heavy_*   tiles with more marks than a workgroup should walk alone (hot references of a skewed community)
+//                   are pre-reduced: every chunk of the sorted array that touches such a tile adds its LDS image to
+//                   the tile's image in a side buffer (atomic adds of consecutive cells)
+//   k_cov_depths    one workgroup per 8 K-cell tile: marks into an LDS image (or the side buffer's), inclusive scan,
+//                   + the tile's incoming depth, written out as 16-byte vectors -- the depth array's only touch.
+// Integer work, HBM-bound: no MFMA.
+// ---------------------------------------------------------------------------
+#define CV2_REC 2048                    // records per workgroup of k_cov_emit2 (= MSX_SORT_TILE / 2)
+#define CV2_LISTS 64                    // overflow lists
+#define CV2_STAGE 2048                  // overflow items a workgroup can stage
+#define CV2_HEAVY 32768u                // marks of one sign in a tile from which the tile is pre-reduced
+#define CV2_HEAVY_CAP 2048              // side-buffer slots
+struct cv2_state {
+	uint32_t list_n[CV2_LISTS];         // items in every overflow list
+	uint32_t overflow;                  // a list or a stage was too small: the caller takes the streamed path
+	uint32_t n_heavy;
+};
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit2(int64_t n, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
+                                                         const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
+                                                         const int64_t *__restrict__ cov_off, uint8_t *__restrict__ covered,
+                                                         uint32_t *__restrict__ items, int sign_shift, int64_t list_base, uint32_t list_cap,
+                                                         cv2_state *__restrict__ st, uint32_t *__restrict__ hist, int64_t hist_tiles, int hist_shift) {
+	__shared__ uint32_t s_extra[CV2_STAGE];
+	__shared__ uint32_t s_n, s_base;
+	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (threadIdx.x == 0) s_n = 0;
+	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
+	__syncthreads();
+	const uint32_t sgn = 1u << sign_shift;
+	for (int q = 0; q < CV2_REC / MSX_BLOCK; q++) {
+		const int64_t i = (int64_t)blockIdx.x * CV2_REC + (int64_t)q * MSX_BLOCK + threadIdx.x;
+		if (i >= n) break;
+		uint2 it = make_uint2(0xffffffffu, 0xffffffffu);
+		const int32_t t = tid[i];
+		if (t >= 0) {                                        // msam_coverage.c:42
+			if (covered) covered[t] = 1;                     // :45-49
+			const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
+			int64_t p = pos[i];
+			const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
+			int64_t run_start = -1;
+			bool first = true;
+			auto mark = [&](int64_t s, int64_t e) {
+				if (s < 0) s = 0;
+				if (e > t_len) e = t_len;
+				if (e <= s) return;
+				const uint32_t a = (uint32_t)(t_beg + s), b = (uint32_t)(t_beg + e) | sgn;
+				if (first) {
+					first = false;
+					it = make_uint2(a, b);
+				} else {
+					const uint32_t k = atomicAdd(&s_n, 2u);
+					if (k + 2u <= CV2_STAGE) { s_extra[k] = a; s_extra[k + 1u] = b; }
+				}
+			};
+			for (uint32_t k = ks; k < ke; ++k) {
+				const uint32_t op = cigar[k] & 0xf, wd = cigar[k] >> 4;
+				if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
+					if (run_start < 0) run_start = p;
+					p += wd;
+				} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
+					if (run_start >= 0 && wd > 0) { mark(run_start, p); run_start = -1; }
+					p += wd;
+				}
+			}
+			if (run_start >= 0) mark(run_start, p);
+		}
+		reinterpret_cast<uint2 *>(items)[i] = it;
+		// the first radix pass's digits of the two items (an empty slot counts too: it is a key like any other)
+		atomicAdd(&s_cnt[w][(it.x >> hist_shift) & 255u], 1u);
+		atomicAdd(&s_cnt[w][(it.y >> hist_shift) & 255u], 1u);
+	}
+	__syncthreads();
+	{
+		const int d = threadIdx.x;
+		hist[(int64_t)d * hist_tiles + blockIdx.x] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
+	}
+	const uint32_t ne = s_n;
+	if (ne == 0) return;
+	if (ne > CV2_STAGE) { if (threadIdx.x == 0) st->overflow = 1; return; }
+	const uint32_t li = blockIdx.x & (CV2_LISTS - 1);
+	if (threadIdx.x == 0) s_base = atomicAdd(&st->list_n[li], ne);
+	__syncthreads();
+	const uint32_t b0 = s_base;
+	if (b0 + ne > list_cap) { if (threadIdx.x == 0) st->overflow = 1; return; }
+	for (uint32_t k = threadIdx.x; k < ne; k += MSX_BLOCK) items[list_base + (int64_t)li * list_cap + b0 + k] = s_extra[k];
+}
+
+// the unused part of every overflow list: empty slots
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_fill_lists(uint32_t *__restrict__ items, int64_t list_base, uint32_t list_cap,
+                                                              const cv2_state *__restrict__ st) {
+	const uint32_t li = blockIdx.y;
+	const uint32_t used = st->list_n[li] < list_cap ? st->list_n[li] : list_cap;
+	for (uint32_t k = used + blockIdx.x * MSX_BLOCK + threadIdx.x; k < list_cap; k += gridDim.x * MSX_BLOCK)
+		items[list_base + (int64_t)li * list_cap + k] = 0xffffffffu;
+}
+
+// start[s * (n_tiles + 1) + t]: first sorted item at or behind (sign s, tile t); t = n_tiles: where sign s ends
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts2(const uint32_t *__restrict__ ikey, int64_t n_items, int64_t n_tiles, int sign_shift,
+                                                           uint32_t *__restrict__ start) {
+	const int64_t q = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (q >= 2 * (n_tiles + 1)) return;
+	const uint32_t s = q >= n_tiles + 1 ? 1u : 0u;
+	const int64_t t = q - (int64_t)s * (n_tiles + 1);
+	const uint64_t want = ((uint64_t)s << sign_shift) + ((uint64_t)t << CV_TILE_SHIFT);     // (t = n_tiles of sign 1 passes 32 bits: every real item is below)
+	int64_t lo = 0, hi = n_items;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if ((uint64_t)ikey[mid] < want) lo = mid + 1; else hi = mid;
+	}
+	start[q] = (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list(const uint32_t *__restrict__ start, int64_t n_tiles, int32_t *__restrict__ slot_of,
+                                                              cv2_state *__restrict__ st) {
+	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (t >= n_tiles) return;
+	const uint32_t np = start[t + 1] - start[t], nm = start[n_tiles + 1 + t + 1] - start[n_tiles + 1 + t];
+	int32_t slot = -1;
+	if (np > CV2_HEAVY || nm > CV2_HEAVY) {
+		const uint32_t k = atomicAdd(&st->n_heavy, 1u);
+		if (k < CV2_HEAVY_CAP) slot = (int32_t)k; else st->overflow = 1;
+	}
+	slot_of[t] = slot;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_zero(int32_t *__restrict__ side, const cv2_state *__restrict__ st) {
+	if (blockIdx.x >= st->n_heavy || blockIdx.x >= CV2_HEAVY_CAP) return;
+	int4 *p = reinterpret_cast<int4 *>(side + (size_t)blockIdx.x * CV_TILE);
+	for (uint32_t q = threadIdx.x; q < CV_TILE / 4; q += MSX_BLOCK) p[q] = make_int4(0, 0, 0, 0);
+}
+
+// every chunk of the sorted items: the part that belongs to pre-reduced tiles is added to their side images
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add(const uint32_t *__restrict__ items, const uint32_t *__restrict__ start, int64_t n_tiles,
+                                                             int sign_shift, const int32_t *__restrict__ slot_of, int32_t *__restrict__ side,
+                                                             const cv2_state *__restrict__ st) {
+	__shared__ int32_t s_d[CV_TILE];
+	if (st->n_heavy == 0) return;
+	const int64_t n = (int64_t)start[2 * n_tiles + 1];       // where the -1 marks end: the empty slots sort behind
+	const int64_t lo_c = (int64_t)blockIdx.x * CV_CHUNK;
+	if (lo_c >= n) return;
+	const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
+	const uint32_t smask = (1u << sign_shift) - 1u;
+	// the (sign, tile) pairs this chunk touches: walk them by their starts
+	int64_t a = lo_c;
+	while (a < hi_c) {
+		const uint32_t v0 = items[a], s = v0 >> sign_shift, t = (v0 & smask) >> CV_TILE_SHIFT;
+		const int64_t e_t = (int64_t)start[(int64_t)s * (n_tiles + 1) + t + 1];
+		const int64_t b = e_t < hi_c ? e_t : hi_c;
+		const int32_t slot = slot_of[t];
+		if (slot >= 0) {                                         // (workgroup-uniform)
+			for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) s_d[q] = 0;
+			__syncthreads();
+			for (int64_t q = a + threadIdx.x; q < b; q += MSX_BLOCK) atomicAdd(&s_d[items[q] & (CV_TILE - 1)], s ? -1 : 1);
+			__syncthreads();
+			int32_t *img = side + (size_t)slot * CV_TILE;
+			for (uint32_t q = threadIdx.x; q < CV_TILE; q += MSX_BLOCK) {
+				const int32_t d = s_d[q];
+				if (__ballot(d != 0) != 0ull) atomicAdd(&img[q], d);
+			}
+			__syncthreads();
+		}
+		a = b > a ? b : a + 1;
+	}
+}
+
+// one workgroup per tile: the tile's marks as an LDS image, its inclusive sum + the depth the tile starts from
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths(const uint32_t *__restrict__ items, const uint32_t *__restrict__ start, int64_t n_tiles,
+                                                          const int32_t *__restrict__ slot_of, const int32_t *__restrict__ side,
+                                                          int64_t total_cells, int32_t *__restrict__ cov) {
+	__shared__ int32_t s_d[CV_TILE];
+	__shared__ int32_t s_w[MSX_BLOCK / 64];
+	const int64_t t = blockIdx.x;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t ps = start[t], pe = start[t + 1], ms = start[n_tiles + 1 + t], me = start[n_tiles + 1 + t + 1];
+	const int32_t carry = (int32_t)(ps - start[0]) - (int32_t)(ms - start[n_tiles + 1]);
+	const int32_t slot = slot_of[t];
+	if (slot >= 0) {
+		const int4 *img = reinterpret_cast<const int4 *>(side + (size_t)slot * CV_TILE);
+		for (uint32_t q = threadIdx.x; q < CV_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = img[q];
+	} else {
+		for (uint32_t q = threadIdx.x; q < CV_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = make_int4(0, 0, 0, 0);
+		__syncthreads();
+		for (uint32_t q = ps + threadIdx.x; q < pe; q += MSX_BLOCK) atomicAdd(&s_d[items[q] & (CV_TILE - 1)], 1);
+		for (uint32_t q = ms + threadIdx.x; q < me; q += MSX_BLOCK) atomicAdd(&s_d[items[q] & (CV_TILE - 1)], -1);
+	}
+	__syncthreads();
+	const int64_t c0 = t << CV_TILE_SHIFT;
+	int32_t running = carry;
+	for (uint32_t base = 0; base < CV_TILE; base += MSX_BLOCK * 4) {
+		const uint32_t q = base + threadIdx.x * 4u;
+		int4 v = *reinterpret_cast<const int4 *>(&s_d[q]);
+		v.y += v.x; v.z += v.y; v.w += v.z;
+		int32_t inc = v.w;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int32_t u = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += u;
+		}
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		int32_t woff = 0, tot = 0;
+		for (int k = 0; k < MSX_BLOCK / 64; k++) { if (k < w) woff += s_w[k]; tot += s_w[k]; }
+		const int32_t add = running + woff + inc - v.w;
+		v.x += add; v.y += add; v.z += add; v.w += add;
+		const int64_t c = c0 + q;
+		if (c + 4 <= total_cells + 1) *reinterpret_cast<int4 *>(&cov[c]) = v;
+		else {
+			if (c <= total_cells) cov[c] = v.x;
+			if (c + 1 <= total_cells) cov[c + 1] = v.y;
+			if (c + 2 <= total_cells) cov[c + 2] = v.z;
+		}
+		running += tot;
+		__syncthreads();
+	}
+}
+
+extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
+                                   int32_t *cov, uint8_t *covered) {
+	if (!ctx || !b || !cov_off || !cov || total_len < 0) return MSX_ERR_ARG;
+	if (!b->pos || !b->tid || !b->cigar_off || !b->cigar)
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_depths needs tid, pos and cigar arrays");
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	const int64_t n = b->n_records;
+	const int64_t n_tiles = (total_len + 1 + CV_TILE - 1) >> CV_TILE_SHIFT;
+	int tile_bits = 1;
+	while (((int64_t)1 << tile_bits) < n_tiles + 1) tile_bits++;
+	const int sign_shift = CV_TILE_SHIFT + tile_bits;          // item = sign << sign_shift | cell; an empty slot: all ones
+	// what this path is for: a batch that is large against the depth array, items of one word.  Everything else takes
+	// the streamed path (zero, accumulate, finish) -- as does a batch whose overflow lists run full.
+	bool fused = n >= (1 << 16) && n_targets > 0 && sign_shift <= 30 && 2 * n < ((int64_t)1 << 31) && !getenv("MSX_COV_STREAMED");
+	if (fused) {
+		const int64_t n_wg = (n + CV2_REC - 1) / CV2_REC;
+		const int64_t own = n_wg * MSX_SORT_TILE;                  // the records' own slots, rounded up to whole sort tiles
+		const uint32_t list_cap = (uint32_t)(((n / 8 + CV2_LISTS - 1) / CV2_LISTS + 1023) & ~(int64_t)1023);
+		const int64_t n_items = own + (int64_t)CV2_LISTS * list_cap;
+		for (int q = 0; q < 2; q++)
+			if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(n_items + 64) * 4))) return rc;
+		if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * (n_tiles + 1) + n_tiles + 64) * 4 + sizeof(cv2_state) + 64))) return rc;
+		if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
+		int64_t sort_tiles = 0;
+		if ((rc = msx_sort_keys32_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
+		uint32_t *start = (uint32_t *)ctx->cv_start.p;
+		int32_t *slot_of = (int32_t *)(start + 2 * (n_tiles + 1));
+		cv2_state *st = (cv2_state *)(((uintptr_t)(slot_of + n_tiles) + 63) & ~(uintptr_t)63);
+		uint32_t *items = (uint32_t *)ctx->cv_key[0].p;
+		MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
+		msx_time_begin(ctx, MSX_K_COVERAGE);
+		if (own > 2 * n)             // (the last workgroup's tile is not full: its tail holds empty slots)
+			MSX_HIP(ctx, hipMemsetAsync(items + 2 * n, 0xff, (size_t)(own - 2 * n) * 4, ctx->stream));
+		hipLaunchKernelGGL(k_cov_emit2, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar,
+		                   cov_off, covered, items, sign_shift, own, list_cap, st, (uint32_t *)ctx->cv_hist.p, sort_tiles, CV_TILE_SHIFT);
+		hipLaunchKernelGGL(k_cov_fill_lists, dim3(16, CV2_LISTS), dim3(MSX_BLOCK), 0, ctx->stream, items, own, list_cap, st);
+		int sel = 0;
+		// (the last workgroup's histogram counted only the records it has: the tail's empty slots are added by ... nothing --
+		//  so that tile is counted by the sort itself)
+		const int64_t counted = (own > 2 * n) ? n_wg - 1 : n_wg;
+		if ((rc = msx_sort_keys32(ctx, items, (uint32_t *)ctx->cv_key[1].p, n_items, CV_TILE_SHIFT, tile_bits + 1, &ctx->cv_hist, &ctx->cv_off,
+		                          &sel, counted)))
+			return rc;
+		const uint32_t *sorted = (const uint32_t *)ctx->cv_key[sel].p;
+		hipLaunchKernelGGL(k_cov_starts2, dim3((unsigned)((2 * (n_tiles + 1) + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   sorted, n_items, n_tiles, sign_shift, start);
+		hipLaunchKernelGGL(k_cov_heavy_list, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		                   (const uint32_t *)start, n_tiles, slot_of, st);
+		hipLaunchKernelGGL(k_cov_heavy_zero, dim3(CV2_HEAVY_CAP), dim3(MSX_BLOCK), 0, ctx->stream, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
+		hipLaunchKernelGGL(k_cov_heavy_add, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream, sorted,
+		                   (const uint32_t *)start, n_tiles, sign_shift, (const int32_t *)slot_of, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
+		hipLaunchKernelGGL(k_cov_depths, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, sorted, (const uint32_t *)start, n_tiles,
+		                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov);
+		msx_time_end(ctx);
+		MSX_HIP(ctx, hipGetLastError());
+		cv2_state h;
+		MSX_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (!h.overflow) return MSX_OK;
+	}
+	// the streamed path on one batch
+	MSX_HIP(ctx, hipMemsetAsync(cov, 0, (size_t)(total_len + 1) * 4, ctx->stream));
+	if ((rc = msx_coverage_accumulate(ctx, b, cov_off, n_targets, total_len, cov, covered))) return rc;
+	if ((rc = msx_coverage_finish(ctx, cov, total_len))) return rc;
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}
+
 extern "C" int msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len) {
 	if (!ctx || !cov || total_len < 0) return MSX_ERR_ARG;
 	msx_join(ctx);

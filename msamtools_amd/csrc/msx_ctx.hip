@@ -163,7 +163,8 @@ extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 	for (auto &ev : ctx->event_pool) (void)hipEventDestroy(ev);
 	msx_buf *bufs[] = {&ctx->pool_code, &ctx->gcount, &ctx->gbase, &ctx->scan_l1, &ctx->scan_l2,
 	                   &ctx->scan_l3, &ctx->pinfo, &ctx->moff, &ctx->tmp_fid, &ctx->ukey2,
-	                   &ctx->cv_key[0], &ctx->cv_key[1], &ctx->cv_hist, &ctx->cv_off, &ctx->cv_start};
+	                   &ctx->cv_key[0], &ctx->cv_key[1], &ctx->cv_hist, &ctx->cv_off, &ctx->cv_start, &ctx->cv_side, &ctx->df_slots, &ctx->df_size,
+	                   &ctx->df_tok};
 	for (auto *b : bufs) free_buf(b);
 	if (ctx->d_status) (void)hipFree(ctx->d_status);
 	if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -31,7 +31,7 @@ typedef struct {
 } df_opts;
 
 static inline df_opts df_default_opts(void) {
-	df_opts o = {8192u, 64u, 12, 1, 1, 1, 0};
+	df_opts o = {8192u, 64u, 11, 1, 1, 1, 0};
 	return o;
 }
 
@@ -181,9 +181,14 @@ static inline uint32_t df_tokens(const uint8_t *in, uint32_t n, const df_opts *O
 					if (l >= 4 && (l > bl || (l == bl && p - (c - 1) < bd))) { bl = l; bd = p - (c - 1); }
 				}
 			}
-			if (O->use_rep && p >= 1 && in[p] == in[p - 1]) {
-				const uint32_t l = df_match_len(in, p - 1, p, maxl);
-				if (l >= 3 && l >= bl) { bl = l; bd = 1; }
+			if (O->use_rep && p + 4 <= n) {          /* the nearest of the distances 1..8 whose next 4 bytes repeat (runs, short periods) */
+				uint32_t d;
+				for (d = 1; d <= 8u && d <= p; d++)
+					if (df_ld32(in + p - d) == df_ld32(in + p)) {
+						const uint32_t l = df_match_len(in, p - d, p, maxl);
+						if (l >= bl) { bl = l; bd = d; }
+						break;
+					}
 			}
 			ml[i] = bl; md[i] = bd;
 		}

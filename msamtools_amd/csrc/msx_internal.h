@@ -98,7 +98,8 @@ struct msx_ctx {
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
 	// workspace, grown on demand and kept
 	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, pinfo, moff, tmp_fid, ukey2;
-	msx_buf cv_key[2], cv_hist, cv_off, cv_start;   // coverage: binned pile-up items
+	msx_buf cv_key[2], cv_hist, cv_off, cv_start, cv_side;   // coverage: binned pile-up items; images of pre-reduced tiles
+	msx_buf df_slots, df_size, df_tok;              // msx_deflate.hip: block slots, sizes + offsets, token scratch of the resident waves
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;
@@ -129,6 +130,8 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 // blocks: block k at k * (0xff00 + 31), all full but the last; the launch is sized by n_cap
 int msx_bgzf_store_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out);
 extern "C" int64_t msx_bgzf_bound(int64_t n_bytes, int level);
+// ... deflated (level >= 1) into BGZF blocks back to back in d_out, on ctx->stream; *d_out_total (device) = the stream's length
+int msx_bgzf_deflate_launch(msx_ctx *ctx, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out, uint32_t *d_out_total);
 extern thread_local std::string msx_tls_err;
 
 #define MSX_HIP(ctx, call)                                                              \
@@ -227,8 +230,10 @@ int64_t msx_share_waves(msx_ctx *ctx);
 int64_t msx_apply_blocks(int32_t nf);
 int msx_prop_purged_launch(msx_ctx *ctx, msx_profile *p, uint32_t *out_dev);
 int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
+#define MSX_SORT_TILE 4096      // keys per workgroup tile of a radix pass (msx_prop.hip: RS_TILE)
+int msx_sort_keys32_reserve(msx_ctx *ctx, int64_t n, msx_buf *hist, msx_buf *off, int64_t *n_tiles_out);
 int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shift0, int bits, msx_buf *hist, msx_buf *off,
-                    int *sel);
+                    int *sel, int64_t counted_tiles = 0);
 // msx_dist.hip: in-place all-reduce(sum) on the ctx stream; no-ops without a communicator
 int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p);
 int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count);

@@ -59,10 +59,10 @@ template <bool SKIP>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restrict__ keys,
                                                        const unsigned long long *__restrict__ n_ptr, int64_t n_host,
                                                        int shift, uint32_t dmask, uint32_t *__restrict__ hist,
-                                                       int64_t n_tiles) {
+                                                       int64_t n_tiles, int64_t tile0 = 0) {
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int64_t tile = blockIdx.x;
+	const int64_t tile = blockIdx.x + tile0;      // (tile0: the tiles in front have their counts already, msx_sort_keys32)
 	const int64_t E = n_ptr ? (int64_t)*n_ptr : n_host;
 	const int64_t base = tile * RS_TILE;
 	// The launch is sized for the host's upper bound of the element count.  With a device-side
@@ -1245,21 +1245,33 @@ static int radix_sort_pairs(msx_ctx *ctx, msx_profile *p, const uint32_t *kin, c
 
 // Stable LSD radix sort of 32-bit keys on bits [shift0, shift0 + bits), for callers outside the profile
 // (msx_coverage.hip): n keys (host count), ping-pong between k0 and k1; *sel tells which one holds the
-// result.  hist / off: workspace, grown here.
-int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shift0, int bits, msx_buf *hist, msx_buf *off,
-                    int *sel) {
-	const int passes = (bits + 7) / 8;
+// result.  hist / off: workspace, grown by msx_sort_keys32_reserve (which also tells the number of tiles and the
+// table's address: a caller that produces the keys itself, tile by tile of MSX_SORT_TILE keys, can leave the first
+// pass's digit counts of its tiles in the table -- hist[digit * n_tiles + tile] -- and name them as `counted_tiles`).
+int msx_sort_keys32_reserve(msx_ctx *ctx, int64_t n, msx_buf *hist, msx_buf *off, int64_t *n_tiles_out) {
 	const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
-	uint32_t *kk[2] = {k0, k1};
-	int cur = 0, rc;
+	int rc;
 	if ((rc = msx_reserve(ctx, hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
 	if ((rc = msx_reserve(ctx, off, (size_t)(256 * n_tiles + 16 + 256) * 4))) return rc;
+	if (n_tiles_out) *n_tiles_out = n_tiles;
+	return MSX_OK;
+}
+
+int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shift0, int bits, msx_buf *hist, msx_buf *off,
+                    int *sel, int64_t counted_tiles) {
+	const int passes = (bits + 7) / 8;
+	int64_t n_tiles = 0;
+	uint32_t *kk[2] = {k0, k1};
+	int cur = 0, rc;
+	if ((rc = msx_sort_keys32_reserve(ctx, n, hist, off, &n_tiles))) return rc;
 	uint32_t *const dtot = (uint32_t *)off->p + 256 * n_tiles + 16;
 	for (int ps = 0; ps < passes; ps++) {
 		const int left = bits - 8 * ps;
 		const uint32_t dmask = left >= 8 ? 255u : ((1u << left) - 1u);
-		hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)kk[cur],
-		                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (uint32_t *)hist->p, n_tiles);
+		const int64_t t0 = ps == 0 ? counted_tiles : 0;
+		if (n_tiles > t0)
+			hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)(n_tiles - t0)), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)kk[cur],
+			                   (const unsigned long long *)nullptr, n, shift0 + ps * 8, dmask, (uint32_t *)hist->p, n_tiles, t0);
 		hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
 		                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, dtot);
 		hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,

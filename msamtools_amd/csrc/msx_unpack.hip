@@ -40,7 +40,8 @@ struct up_state {
 	uint32_t inflate_bad;          // msx_unpack_enqueue_bgzf: blocks the device inflater refused
 	uint32_t inflate_ticket;       // ... and the counter its waves draw their blocks from (msx_bgzf_inflate_launch: d_n_bad[1])
 	uint32_t has_prev;             // prev_name holds the QNAME of the last naming record of earlier batches
-	uint32_t emit_bytes;
+	uint32_t emit_bytes;           // what msx_unpack_emit_fetch brings down (the record stream, or the BGZF blocks made of it)
+	uint32_t emit_raw;             // bytes of the record stream
 };
 #define MSX_UP_CORRUPT 1u          // block_size < 32 on the true chain, or a record whose fields do not fit its length
 
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_emit_copy(const uint8_t *__restri
                                                          uint8_t *__restrict__ out, up_state *st) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
-	if (wave == 0 && lane == 0) st->emit_bytes = out_off[n_emit];
+	if (wave == 0 && lane == 0) st->emit_bytes = st->emit_raw = out_off[n_emit];
 	const uint32_t k0 = wave * EM_PER_WAVE;
 	for (uint32_t q = 0; q < EM_PER_WAVE; q++) {
 		const uint32_t k = k0 + q;
@@ -954,6 +955,12 @@ static int up_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_d
 		if ((rc = msx_bgzf_store_launch(ctx, ctx->stream, (const uint8_t *)u->out.p, (const uint32_t *)u->out_off.p + ne, u->n_bytes,
 		                                (uint8_t *)u->framed.p)))
 			return rc;
+	} else if (level > 0) {
+		// -b: deflated on the device, the blocks moved back to back; the stream's length lands in the state
+		UP_RES(framed, (size_t)msx_bgzf_bound((int64_t)u->n_bytes + 64, level) + 64);
+		if ((rc = msx_bgzf_deflate_launch(ctx, (const uint8_t *)u->out.p, (const uint32_t *)u->out_off.p + ne, u->n_bytes,
+		                                  (uint8_t *)u->framed.p, &u->d_state->emit_bytes)))
+			return rc;
 	}
 	if ((rc = up_fetch_state(ctx, u))) return rc;                   // sync: how many bytes
 	return MSX_OK;
@@ -971,18 +978,18 @@ extern "C" int msx_unpack_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t
 }
 
 // The same, and the byte string cut into BGZF blocks on the device (msx_deflate.hip): what comes down is what goes into
-// the file.  level 0: stored blocks (filter -bu).  *n_bytes: bytes of finished blocks, *n_blocks: how many; the blocks of
+// the file.  level 0: stored blocks (filter -bu); level >= 1: DEFLATE (filter -b).  *n_bytes: bytes of finished blocks, *n_blocks: how many; the blocks of
 // one call are full except the last.
 extern "C" int msx_unpack_emit_gather_bgzf(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level,
                                            int64_t *n_bytes, int64_t *n_blocks) {
 	if (!ctx || !u || !n_bytes || (n_emit > 0 && !emit_idx_dev)) return MSX_ERR_ARG;
-	if (level != 0) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit_gather_bgzf: level %d", level);
+	if (level < 0 || level > 9) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit_gather_bgzf: level %d", level);
 	*n_bytes = 0;
 	if (n_blocks) *n_blocks = 0;
 	int rc = up_emit_gather(ctx, u, emit_idx_dev, n_emit, level);
 	if (rc || n_emit <= 0) return rc;
-	const int64_t raw_bytes = (int64_t)u->h_state->emit_bytes;
-	u->gathered = (size_t)msx_bgzf_bound(raw_bytes, 0);
+	const int64_t raw_bytes = (int64_t)u->h_state->emit_raw;
+	u->gathered = level == 0 ? (size_t)msx_bgzf_bound(raw_bytes, 0) : (size_t)u->h_state->emit_bytes;
 	u->fetch_src = u->framed.p;
 	*n_bytes = (int64_t)u->gathered;
 	if (n_blocks) *n_blocks = (raw_bytes + 0xff00 - 1) / 0xff00;

@@ -58,7 +58,7 @@ PY
           t0=$(date +%s.%N)
           env MSX_TIMING=1 $e $EXE filter -l 80 -p 95 -z 80 --besthit ${E2E_MODE:--bu} --profile-out $T/p.gz --label S $T/in.bam > $T/f.bam 2> $OUT/e2e_${k}_err.log
           t1=$(date +%s.%N)
-          echo "[$e] $(echo "$t1 - $t0" | bc) s | $(grep 'filter pipeline' $OUT/e2e_${k}_err.log | cut -c1-400)"
+          echo "[$e] $(python3 -c "print(round($t1-$t0,3))") s | $(grep 'filter pipeline' $OUT/e2e_${k}_err.log | cut -c1-400)"
         done
         $DEV digest $T/f.bam; ls -l $T/f.bam | awk '{print $5}'
       done 2>&1 | tee $OUT/e2e_$k.log

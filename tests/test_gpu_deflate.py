@@ -68,10 +68,29 @@ def check_stream(ctx, data, stream, n_blk, level):
         assert refused == 0 and not st.any() and out[:total].tobytes() == data
 
 
+def twin(tmp_path):
+    """the host twin of the encoder (tests/c/deflate_twin.c over msamtools_amd/csrc/msx_deflate_model.h)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "deflate_twin")
+    if not os.path.exists(exe):
+        subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(root, "tests", "c", "deflate_twin.c"), "-lz"])
+
+    def run(data):
+        src, dst = str(tmp_path / "twin_in"), str(tmp_path / "twin_out")
+        with open(src, "wb") as fh:
+            fh.write(data)
+        subprocess.check_call([exe, src, dst], stdout=subprocess.DEVNULL)
+        with open(dst, "rb") as fh:
+            return fh.read()
+    return run
+
+
 SIZES = [0, 1, 15, 16, 17, 4095, 4096, 4097, PAYLOAD - 1, PAYLOAD, PAYLOAD + 1, 2 * PAYLOAD, 3 * PAYLOAD + 17, 1_000_003]
 
 
-@pytest.mark.parametrize("level", [0])
+@pytest.mark.parametrize("level", [0, 6])
 def test_blocks_decode_to_the_input(ctx, level):
     rng = np.random.default_rng(41)
     for n in SIZES:
@@ -82,7 +101,7 @@ def test_blocks_decode_to_the_input(ctx, level):
             check_stream(ctx, data, stream, n_blk, level)
 
 
-@pytest.mark.parametrize("level", [0])
+@pytest.mark.parametrize("level", [0, 6])
 def test_large_input(ctx, level):
     rng = np.random.default_rng(7)
     data = bam_like(rng, 40_000_000, seq=True)
@@ -93,7 +112,7 @@ def test_large_input(ctx, level):
         assert len(stream) == len(data) + 31 * n_blk
 
 
-@pytest.mark.parametrize("level", [0])
+@pytest.mark.parametrize("level", [0, 6])
 def test_emit_as_finished_blocks(ctx, level):
     """filter's output records of an unpacked batch, gathered and framed in one call: the blocks hold exactly the
     record stream msx_unpack_emit returns"""
@@ -126,3 +145,43 @@ def test_emit_as_finished_blocks(ctx, level):
     assert blocks == b"" and n_blk == 0
     ctx.free(d)
     up.close()
+
+
+def test_the_kernel_writes_the_twins_bytes(ctx, tmp_path):
+    """the device encoder against its one-position-at-a-time restatement on the host: the same blocks, bit for bit --
+    matches, lazy decisions, trees, headers (what the lanes do side by side is what the model does in order)"""
+    rng = np.random.default_rng(99)
+    run = twin(tmp_path)
+    cases = {
+        "bam-like": bam_like(rng, 6 * PAYLOAD + 1234),
+        "bam-like with seq/qual": bam_like(rng, 4 * PAYLOAD + 77, seq=True),
+        "random (stored)": rng.integers(0, 256, 2 * PAYLOAD + 5, dtype=np.uint8).tobytes(),
+        "nibbles (literals only)": rng.integers(0, 16, PAYLOAD + 999, dtype=np.uint8).tobytes(),
+        "zeros": bytes(3 * PAYLOAD),
+        "period 4": (b"\x12\x23\x34\x45" * 40000)[:2 * PAYLOAD + 3],
+        "period 300": (rng.integers(0, 256, 300, dtype=np.uint8).tobytes() * 500)[:PAYLOAD + 1],
+        "tiny": b"abcabcabcabcabcabc",
+        "one byte": b"Q",
+        "text": (b"the quick brown fox jumps over the lazy dog; " * 3000)[:PAYLOAD * 2 - 1],
+        "skewed (long codes)": bytes(np.minimum(rng.geometric(0.35, 3 * PAYLOAD), 255).astype(np.uint8)),
+    }
+    for name, data in cases.items():
+        got, n_blk = M().bgzf_deflate(ctx, data, 6)
+        want = run(data)
+        assert len(got) == len(want), (name, len(got), len(want))
+        if got != want:
+            first = next(i for i in range(len(got)) if got[i] != want[i])
+            raise AssertionError(f"{name}: first difference at byte {first} of {len(got)}")
+
+
+def test_ratio_next_to_zlib(ctx):
+    """compressed size within 15 % of zlib level 6 on name-grouped BAM records (the reference's writer is htslib at level 6:
+    msam_filter.c:464-470); output bytes are not pinned, record identity is"""
+    rng = np.random.default_rng(5)
+    data = bam_like(rng, 60 * PAYLOAD)
+    got, n_blk = M().bgzf_deflate(ctx, data, 6)
+    z = 0
+    for i in range(0, len(data), PAYLOAD):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        z += len(co.compress(data[i:i + PAYLOAD]) + co.flush()) + 26
+    assert len(got) <= 1.15 * z, (len(got), z)
