@@ -292,7 +292,7 @@ def coverage_cli(groups=10_000_000, refs=50_000):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def e2e_cli(groups, refs, expect=None, seq=False, probe=None):
+def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0, cpu_records=0, out_flag="-bu"):
     """The command line end to end on this box: a synthetic BAM of `groups` QNAME groups (BGZF level 6; records
     without SEQ/QUAL, or ~250 B records with them: seq) through `msamtools filter -l 80 -p 95 -z 80 --besthit -bu |
     msamtools profile -` -- the reference's own two-process workflow -- through either command alone, and through
@@ -308,7 +308,7 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None):
     if not os.path.exists(exe):
         return {"error": "msamtools_amd/bin/msamtools not built"}
     tmp = tempfile.mkdtemp(prefix="msx_e2e_", dir="/tmp")
-    filt = "filter -l 80 -p 95 -z 80 --besthit -bu"
+    filt = f"filter -l 80 -p 95 -z 80 --besthit {out_flag}"
     env = dict(os.environ, MSX_TIMING="1")
     ref_len = 4496              # msh_cli.c: synth_main
 
@@ -385,6 +385,75 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None):
             "synth_s": round(synth_s, 1),
             "note": "stage times are busy times of overlapping pipeline stages (decode | device | encode), not a sum",
         }
+        # ---- compressed output (the reference's -b: htslib deflate at level 6, msam_filter.c:464-470) ----
+        # device DEFLATE (msx_deflate.hip) against zlib level 6 on the granted cores (MSX_HOST_DEFLATE=1, round 3's path): time,
+        # size, the same records in the same order, every block readable by the host inflater + zlib (digest) and by the
+        # device inflater (profile of the compressed output: its counts are those of the one-process form)
+        if out_flag == "-bu":
+            try:
+                fb = filt.replace("-bu", "-b")
+                dt_b, err_b = run(f"{exe} {fb} --profile-out {tmp}/pb.gz --label S {tmp}/in.bam > {tmp}/fb.bam")
+                dt_b = min(dt_b, run(f"{exe} {fb} --profile-out {tmp}/pb.gz --label S {tmp}/in.bam > {tmp}/fb.bam")[0])
+                nb_, dgb = digest(f"{tmp}/fb.bam")
+                size_dev = os.path.getsize(f"{tmp}/fb.bam")
+                env["MSX_HOST_DEFLATE"] = "1"
+                try:
+                    dt_z, err_z = run(f"{exe} {fb} --profile-out {tmp}/pz.gz --label S {tmp}/in.bam > {tmp}/fz.bam")
+                finally:
+                    del env["MSX_HOST_DEFLATE"]
+                nz_, dgz = digest(f"{tmp}/fz.bam")
+                size_z = os.path.getsize(f"{tmp}/fz.bam")
+                dt_pb, err_pb = run(f"{exe} profile --label S -o {tmp}/pbb.gz {tmp}/fb.bam")
+                comp = {"command": f"msamtools {fb} --profile-out p.gz --label S in.bam > f.bam",
+                        "M_alignments_per_s": round(n / dt_b / 1e6, 2), "seconds": round(dt_b, 3), **stages(err_b, "filter"),
+                        "output_MB": round(size_dev / 1e6, 1),
+                        "zlib_level6_on_host": {"M_alignments_per_s": round(n / dt_z / 1e6, 2), "seconds": round(dt_z, 3),
+                                                "output_MB": round(size_z / 1e6, 1), **stages(err_z, "filter")},
+                        "size_ratio_to_zlib6": round(size_dev / max(size_z, 1), 4),
+                        "records_and_order_equal_to_zlib_output": bool((nb_, dgb) == (nz_, dgz)),
+                        "read_back_through_device_inflater": "BGZF blocks inflated on the device" in err_pb,
+                        "_digest": (nb_, dgb)}
+                res["compressed_out"] = comp
+                for f in ("fz.bam", "pz.gz"):
+                    os.remove(f"{tmp}/{f}")
+            except Exception as exc:
+                res["compressed_out"] = {"error": str(exc)[:300]}
+        # ---- the pipeline's own rate: a second, smaller file, and what the additional records cost ----
+        # (a whole-process figure carries ~0.35 s of start-up -- HIP, page-locking, process start and exit -- whatever the
+        #  file's size; the marginal rate between two sizes is what a longer file would run at)
+        if marginal_groups and tee and "error" not in tee:
+            try:
+                subprocess.check_call(f"{exe} synth --groups {marginal_groups} --refs {refs} {'--seq' if seq else ''} -b > {tmp}/in2.bam", shell=True)
+                n2, _ = digest(f"{tmp}/in2.bam")
+                cmd2 = f"{exe} {filt} --profile-out {tmp}/pt2.gz --label S {tmp}/in2.bam > {tmp}/ft2.bam"
+                dt2 = min(run(cmd2)[0], run(cmd2)[0])
+                dt1 = min(dt_t, run(f"{exe} {filt} --profile-out {tmp}/pt.gz --label S {tmp}/in.bam > {tmp}/ft.bam")[0])
+                tee["marginal"] = {"records_small": n2, "seconds_small": round(dt2, 3), "records_large": n, "seconds_large": round(dt1, 3),
+                                   "marginal_M_alignments_per_s": round((n - n2) / max(dt1 - dt2, 1e-9) / 1e6, 1),
+                                   "note": "delta records / delta seconds of the one-process form between the two files (best of two runs each)"}
+                os.remove(f"{tmp}/in2.bam")
+            except Exception as exc:
+                tee["marginal"] = {"error": str(exc)[:200]}
+        # ---- the reference's execution model on this box's host cores, same file (CPU-1 / CPU-N) ----
+        cpu = os.path.join(ROOT, "oracle", "msx_cpu_e2e")
+        if cpu_records and os.path.exists(cpu):
+            try:
+                def cpu_run(threads, level):
+                    out = subprocess.check_output([cpu, f"{tmp}/in.bam", str(cpu_records), str(threads), f"{tmp}/cpu.bam", str(level)])
+                    d = json.loads(out.decode())
+                    os.remove(f"{tmp}/cpu.bam")
+                    return d
+                g = granted_cpus()
+                res["cpu_baseline_e2e"] = {
+                    "kind": "port", "what": "oracle/msx_cpu_e2e.c: zlib inflate + CRC, record walk, one aux scan per record (decode); orc_filter "
+                    "--besthit + orc_profile proportional (compute); gather + BGZF blocks + write (encode) on a prefix of the same file, "
+                    "1 M-reference header included; one thread = the reference's execution model",
+                    "sample": f"the first {cpu_records} records of the e2e BAM (whole QNAME groups)",
+                    "cpu_1_thread_bu": cpu_run(1, 0), "cpu_1_thread_b_level6": cpu_run(1, 6),
+                    f"cpu_{g}_threads_bu": cpu_run(g, 0), f"cpu_{g}_threads_b_level6": cpu_run(g, 6),
+                }
+            except Exception as exc:
+                res["cpu_baseline_e2e"] = {"error": str(exc)[:300]}
         if probe is not None:
             try:
                 res["inflate"] = probe(f"{tmp}/in.bam")
@@ -411,10 +480,22 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None):
                 par["tee_filter_ok"] = bool((nt, dgt) == (n_out, dg))
                 if "pipe" in expect:
                     par["tee_profile"] = profile_parity(f"{tmp}/pt.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
-            par["parity_ok"] = bool(par["filter_ok"] and all(v.get("ok", True) for v in par.values() if isinstance(v, dict))
+            co = res.get("compressed_out")
+            if isinstance(co, dict) and "_digest" in co:
+                nb_, dgb = co.pop("_digest")
+                par["compressed_filter_ok"] = bool((nb_, dgb) == (n_out, dg) and co["records_and_order_equal_to_zlib_output"])
+                if "pipe" in expect:
+                    par["compressed_tee_profile"] = profile_parity(f"{tmp}/pb.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
+                    par["profile_of_compressed_output"] = profile_parity(f"{tmp}/pbb.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
+                co["parity_ok"] = bool(par["compressed_filter_ok"] and par.get("compressed_tee_profile", {}).get("ok", True)
+                                       and par.get("profile_of_compressed_output", {}).get("ok", True) and co["read_back_through_device_inflater"])
+            par["parity_ok"] = bool(par["filter_ok"] and par.get("compressed_filter_ok", True)
+                                    and all(v.get("ok", True) for v in par.values() if isinstance(v, dict))
                                     and par.get("tee_filter_ok", True))
             res["parity"] = par
             res["parity_ok"] = par["parity_ok"]
+        if isinstance(res.get("compressed_out"), dict):
+            res["compressed_out"].pop("_digest", None)
         return res
     except Exception as exc:
         return {"error": str(exc)[:300]}
@@ -490,8 +571,9 @@ def algorithmic_bytes_per_step(name, w):
 
 def coverage_block(m, ctx, with_oracle):
     """BASELINE configs[3]: per-base depth over 50 k references x 5 kb from ~50 M alignments resident in HBM
-    (msam_coverage.c:33-87): msx_coverage_accumulate + msx_coverage_finish, timed on the library's stream; priced
-    against the HBM roof on 4 B per depth cell + the record bytes read (tid, pos, cigar_off, CIGAR words)."""
+    (msam_coverage.c:33-87): msx_coverage_depths (the batch is the sample; round 3 timed zero-less accumulate + finish,
+    kept beside it as `streamed_form_ms`), wall time around the call; priced against the HBM roof on 4 B per depth cell +
+    the record bytes read (tid, pos, cigar_off, CIGAR words)."""
     import ctypes as C
     import numpy as np
     refs, tl, ngrp = 50_000, 5_000, 10_000_000
@@ -502,15 +584,22 @@ def coverage_block(m, ctx, with_oracle):
         d_off, d_cov = ctx.alloc(off.nbytes), ctx.alloc(4 * total + 8)
         ctx.to_dev(d_off, off)
 
-        def one(batch):
-            ctx.zero(d_cov, 4 * total + 8)
+        def one(batch, streamed=False):
+            if streamed:          # round 2/3's form: the caller's zeroed difference array, marks, in-place prefix sum (what the command line streams batches into)
+                ctx.zero(d_cov, 4 * total + 8)
+                ctx.sync()
+                t0 = time.perf_counter()
+                ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off), refs, total,
+                                                          C.c_void_p(d_cov), None))
+                ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
+                ctx.sync()
+                return time.perf_counter() - t0
             ctx.sync()
-            t0 = time.perf_counter()
-            ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off), refs, total,
-                                                      C.c_void_p(d_cov), None))
-            ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
-            ctx.sync()
+            t0 = time.perf_counter()              # the whole-sample form: nothing to zero, depths written once
+            ctx.check(ctx.lib.msx_coverage_depths(ctx.h, C.byref(batch.b), C.c_void_p(d_off), refs, total, C.c_void_p(d_cov), None))
             return time.perf_counter() - t0
+        ts_s = [one(db, streamed=True) for _ in range(4)]
+        cov_s = ctx.to_host(d_cov, total, np.int32)
         ts = [one(db) for _ in range(6)]
         best = min(ts[1:])
         cov = ctx.to_host(d_cov, total, np.int32)
@@ -530,8 +619,9 @@ def coverage_block(m, ctx, with_oracle):
             "frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 4),
             "depth_sum": int(cov.astype(np.int64).sum()), "depth_sum_expected": want_sum,
             "depth_sum_ok": bool(int(cov.astype(np.int64).sum()) == want_sum and (cov >= 0).all()),
+            "streamed_form_ms": round(min(ts_s[1:]) * 1e3, 3), "equal_to_streamed_form": bool(np.array_equal(cov, cov_s)),
         }
-        del cov, cig, n_cig, has_ref, op, w
+        del cov, cov_s, cig, n_cig, has_ref, op, w
         if with_oracle:
             import oracle_lib as orc
             pg = 200_000                                   # every depth of a prefix of the stream against the oracle
@@ -545,7 +635,7 @@ def coverage_block(m, ctx, with_oracle):
             cpu_s = time.perf_counter() - t0
             blk["parity_prefix"] = {"alignments": hs.n_records, "every_depth_equal": bool(np.array_equal(got, want))}
             blk["cpu_oracle_M_alignments_per_s"] = round(hs.n_records / cpu_s / 1e6, 2)
-            blk["parity_ok"] = bool(blk["depth_sum_ok"] and blk["parity_prefix"]["every_depth_equal"])
+            blk["parity_ok"] = bool(blk["depth_sum_ok"] and blk["parity_prefix"]["every_depth_equal"] and blk["equal_to_streamed_form"])
             small.free()
         ctx.free(d_off)
         ctx.free(d_cov)
@@ -924,9 +1014,11 @@ def main():
                 return inflate_probe(m, c, path)
             finally:
                 c.close()
-        out["e2e"] = e2e_cli(args.e2e_groups, e2e_refs, locals().get("e2e_expect"), probe=probe)
+        out["e2e"] = e2e_cli(args.e2e_groups, e2e_refs, locals().get("e2e_expect"), probe=probe, marginal_groups=args.e2e_groups // 4,
+                             cpu_records=2_000_000)
         if args.e2e_seq_groups:
-            out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True, probe=probe)
+            out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True, probe=probe,
+                                     marginal_groups=args.e2e_seq_groups // 4)
         if isinstance(out.get("coverage"), dict) and "error" not in out["coverage"]:
             out["coverage"]["cli"] = coverage_cli()
     if rank == 0:

@@ -487,6 +487,12 @@ int  msx_coverage_accumulate(msx_ctx *ctx, const msx_batch *dev,
                              uint8_t *covered /* device u8[n_targets] or NULL: global->covered[tid],
                                                  set for every target that has an alignment (msam_coverage.c:45-49) */);
 int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);
+/* A whole sample in one batch (the loop of msam_coverage.c:293-301 over one file that fits the device): per-base depths
+ * straight into cov[0 .. total_len] -- the caller need not zero it, no msx_coverage_finish follows.  Same result as
+ * zero + msx_coverage_accumulate + msx_coverage_finish; the depth array is written once instead of touched three times
+ * (marks sorted by tile, every tile's depths finished where its marks are gathered).  Waits for the result. */
+int  msx_coverage_depths(msx_ctx *ctx, const msx_batch *dev, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
+                         int32_t *cov, uint8_t *covered);
 /* after msx_coverage_finish: per target, the number of positions with a depth other than 0 and the sum of the depths --
  * what mWriteCoverageSummaryToStream (msam_coverage.c:188-219) divides by the target's length; host arrays of n_targets */
 int  msx_coverage_summary(msx_ctx *ctx, const int32_t *cov, const int64_t *cov_off, int32_t n_targets,

@@ -662,9 +662,10 @@ class Profile:
             pass
 
 
-def coverage(ctx, batch, target_len, summary=False):
+def coverage(ctx, batch, target_len, summary=False, whole_sample=False):
     """Per-base depth per target (msam_coverage.c:33-87) for one device batch; summary=True: also (touched positions,
-    depth sum) per target as the device takes them (msx_coverage_summary, msam_coverage.c:188-219)."""
+    depth sum) per target as the device takes them (msx_coverage_summary, msam_coverage.c:188-219);
+    whole_sample=True: msx_coverage_depths (the batch is the sample: depths written once, no zeroing, no finish)."""
     off = np.zeros(len(target_len) + 1, np.int64)
     off[1:] = np.cumsum(np.asarray(target_len, dtype=np.int64))
     total = int(off[-1])
@@ -672,10 +673,15 @@ def coverage(ctx, batch, target_len, summary=False):
     d_cov = ctx.alloc(4 * max(total, 1) + 8)
     try:
         ctx.to_dev(d_off, off)
-        ctx.zero(d_cov, 4 * max(total, 1) + 8)
-        ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off),
-                                                  len(target_len), total, C.c_void_p(d_cov), None))
-        ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
+        if whole_sample:
+            ctx.to_dev(d_cov, np.full(max(total, 1) + 2, 0x5a5a5a5a, np.uint32))      # (garbage: the call must not rely on zeros)
+            ctx.check(ctx.lib.msx_coverage_depths(ctx.h, C.byref(batch.b), C.c_void_p(d_off), len(target_len), total,
+                                                  C.c_void_p(d_cov), None))
+        else:
+            ctx.zero(d_cov, 4 * max(total, 1) + 8)
+            ctx.check(ctx.lib.msx_coverage_accumulate(ctx.h, C.byref(batch.b), C.c_void_p(d_off),
+                                                      len(target_len), total, C.c_void_p(d_cov), None))
+            ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
         cov = ctx.to_host(d_cov, total, np.int32)
         if summary:
             touched = np.zeros(max(len(target_len), 1), np.int64)

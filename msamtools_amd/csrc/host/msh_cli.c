@@ -1385,11 +1385,16 @@ static void *pipe_decode_thread(void *arg) {
 				s->n_blk = 0;
 				s->inflated = 0;
 				if (P->comp_mode && P->comp_given_up) {
-					const size_t per = P->batch_bytes_cfg / 65536 + 1 < 128 ? P->batch_bytes_cfg / 65536 + 1 : 128;
+					/* blocks per call: what the batch size asks for, and no more than the slot's buffer holds (a small
+					 * MSX_COMP_BYTES: without this the loop below never ran and the slot went out empty, for ever) */
+					size_t per = P->batch_bytes_cfg / 65536 + 1 < 128 ? P->batch_bytes_cfg / 65536 + 1 : 128;
+					const size_t before = s->rlen;
+					if (s->rcap / 65536 < per + 2) per = s->rcap / 65536 > 2 ? s->rcap / 65536 - 2 : 1;
 					msh_inflate_limit((int)per);
 					while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + (per + 1) * 65536 + 64 <= s->rcap)
 						if (!pipe_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
 					msh_inflate_limit(0);
+					if (s->rlen == before && !P->in_eof) mDie("The batch buffers are too small for a BGZF block (MSX_COMP_BYTES)");
 				} else if (P->comp_mode) {
 					while (!P->in_eof && s->n_blk < P->comp_blocks && (s->rcap - s->rlen) / (65536 + 1024) > 0)
 						if (!msh_raw_append(P->in, s->rbuf, s->rcap, &s->rlen, s->blk, &s->n_blk, P->comp_blocks, &s->inflated)) P->in_eof = 1;

@@ -346,12 +346,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts2(const uint32_t *__res
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list(const uint32_t *__restrict__ start, int64_t n_tiles, int32_t *__restrict__ slot_of,
-                                                              cv2_state *__restrict__ st) {
+                                                              cv2_state *__restrict__ st, uint32_t heavy_from) {
 	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (t >= n_tiles) return;
 	const uint32_t np = start[t + 1] - start[t], nm = start[n_tiles + 1 + t + 1] - start[n_tiles + 1 + t];
 	int32_t slot = -1;
-	if (np > CV2_HEAVY || nm > CV2_HEAVY) {
+	if (np > heavy_from || nm > heavy_from) {
 		const uint32_t k = atomicAdd(&st->n_heavy, 1u);
 		if (k < CV2_HEAVY_CAP) slot = (int32_t)k; else st->overflow = 1;
 	}
@@ -495,10 +495,11 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		                          &sel, counted)))
 			return rc;
 		const uint32_t *sorted = (const uint32_t *)ctx->cv_key[sel].p;
+		static const uint32_t heavy_from = getenv("MSX_COV_HEAVY") ? (uint32_t)atoll(getenv("MSX_COV_HEAVY")) : CV2_HEAVY;
 		hipLaunchKernelGGL(k_cov_starts2, dim3((unsigned)((2 * (n_tiles + 1) + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   sorted, n_items, n_tiles, sign_shift, start);
 		hipLaunchKernelGGL(k_cov_heavy_list, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-		                   (const uint32_t *)start, n_tiles, slot_of, st);
+		                   (const uint32_t *)start, n_tiles, slot_of, st, heavy_from);
 		hipLaunchKernelGGL(k_cov_heavy_zero, dim3(CV2_HEAVY_CAP), dim3(MSX_BLOCK), 0, ctx->stream, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
 		hipLaunchKernelGGL(k_cov_heavy_add, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream, sorted,
 		                   (const uint32_t *)start, n_tiles, sign_shift, (const int32_t *)slot_of, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);

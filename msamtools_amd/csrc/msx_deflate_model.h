@@ -167,28 +167,30 @@ static inline uint32_t df_tokens(const uint8_t *in, uint32_t n, const df_opts *O
 		for (i = 0; i < cnt; i++) {                  /* every lane: the candidates as the tables stood before the step */
 			const uint32_t p = p0 + i, maxl = n - p < DF_MAXMATCH ? n - p : DF_MAXMATCH;
 			uint32_t bl = 0, bd = 0;
+			/* candidates in a fixed order -- the near distances, the 4-byte table, the 8-byte table -- a later one must be
+			 * strictly longer (so that the kernel can drop it after one look at the bytes around the best length so far) */
+			if (O->use_rep && p + 4 <= n) {          /* the nearest of the distances 1..8 whose next 4 bytes repeat (runs, short periods) */
+				uint32_t d;
+				for (d = 1; d <= 8u && d <= p; d++)
+					if (df_ld32(in + p - d) == df_ld32(in + p)) {
+						bl = df_match_len(in, p - d, p, maxl);
+						bd = d;
+						break;
+					}
+			}
 			if (p + 4 <= n) {
 				const uint32_t c = h4[(df_ld32(in + p) * DF_MUL4) >> (32 - O->hash_bits)];
 				if (c && p - (c - 1) <= O->window) {
 					const uint32_t l = df_match_len(in, c - 1, p, maxl);
-					if (l >= 4) { bl = l; bd = p - (c - 1); }
+					if (l >= 4 && l > bl) { bl = l; bd = p - (c - 1); }
 				}
 			}
 			if (O->use_h8 && p + 8 <= n) {
 				const uint32_t c = h8[(uint32_t)((df_ld64(in + p) * DF_MUL8) >> (64 - O->hash_bits))];
 				if (c && p - (c - 1) <= O->window) {
 					const uint32_t l = df_match_len(in, c - 1, p, maxl);
-					if (l >= 4 && (l > bl || (l == bl && p - (c - 1) < bd))) { bl = l; bd = p - (c - 1); }
+					if (l >= 4 && l > bl) { bl = l; bd = p - (c - 1); }
 				}
-			}
-			if (O->use_rep && p + 4 <= n) {          /* the nearest of the distances 1..8 whose next 4 bytes repeat (runs, short periods) */
-				uint32_t d;
-				for (d = 1; d <= 8u && d <= p; d++)
-					if (df_ld32(in + p - d) == df_ld32(in + p)) {
-						const uint32_t l = df_match_len(in, p - d, p, maxl);
-						if (l >= bl) { bl = l; bd = d; }
-						break;
-					}
 			}
 			ml[i] = bl; md[i] = bd;
 		}

@@ -555,6 +555,12 @@ extern "C" int msx_filter_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_fi
 extern "C" int msx_filter_profile_enqueue(msx_ctx *ctx, const msx_batch *b, const msx_filter_params *p,
                                           const msx_filter_out *out, msx_profile *prof) {
 	if (!prof) return msx_fail(ctx, MSX_ERR_ARG, "msx_filter_profile_enqueue: null profile");
+	// The chain rule that joins filter's pools into profile's inserts (k_insert_chains) rests on unmapped records never
+	// being written.  -k -v with thresholds writes them (msam_filter.c:132-138), and one with a name and an RNAME of its
+	// own would split a read's alignments into two inserts for the pipe.  The reference's command line never gets there
+	// (--invert cannot be combined with --besthit or --uniqhit, msam_filter.c:398-402); neither does this entry point.
+	if (p && p->invert && (p->besthit || p->uniqhit) && b && b->pool_rule == MSX_POOLS_FILTER)
+		return msx_fail(ctx, MSX_ERR_ARG, "--invert cannot be combined with --besthit or --uniqhit");
 	return filter_enqueue_impl(ctx, b, p, out, prof);
 }
 

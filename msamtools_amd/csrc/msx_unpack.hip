@@ -228,26 +228,33 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_chase_write(const uint8_t *__rest
 // ---------------------------------------------------------------------------
 // fields
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t aux_size(const uint8_t *t, const uint8_t *end) {      // type byte + payload, as msh_aux_size
+// *bad: the field does not fit the record (a fixed-size value cut by its end, a string without its NUL, an array longer
+// than what is left, an unknown type) -- msh_aux_size and htslib refuse such a record
+__device__ __forceinline__ uint32_t aux_size(const uint8_t *t, const uint8_t *end, bool *bad) {      // type byte + payload, as msh_aux_size
+	uint32_t fs = 0;
 	switch (*t) {
-	case 'A': case 'c': case 'C': return 2;
-	case 's': case 'S': return 3;
-	case 'i': case 'I': case 'f': return 5;
+	case 'A': case 'c': case 'C': fs = 2; break;
+	case 's': case 'S': fs = 3; break;
+	case 'i': case 'I': case 'f': fs = 5; break;
 	case 'Z': case 'H': {
 		const uint8_t *p = t + 1;
 		while (p < end && *p) p++;
+		if (p >= end) *bad = true;
 		return (uint32_t)(p - t) + 1u;
 	}
 	case 'B': {
-		if (t + 6 > end) return (uint32_t)(end - t);
+		if (t + 6 > end) { *bad = true; return (uint32_t)(end - t); }
 		const uint32_t cnt = ld32(t + 2);
-		uint32_t es = 1;
-		switch (t[1]) { case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: break; }
+		uint32_t es = 0;
+		switch (t[1]) { case 'c': case 'C': es = 1; break; case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: break; }
 		const uint64_t sz = 6ull + (uint64_t)cnt * es;
-		return sz > (uint64_t)(end - t) ? (uint32_t)(end - t) : (uint32_t)sz;
+		if (es == 0 || sz > (uint64_t)(end - t)) { *bad = true; return (uint32_t)(end - t); }
+		return (uint32_t)sz;
 	}
-	default: return (uint32_t)(end - t);      // unknown type: nothing behind it can be parsed
+	default: *bad = true; return (uint32_t)(end - t);      // unknown type: nothing behind it can be parsed
 	}
+	if (t + fs > end) { *bad = true; return (uint32_t)(end - t); }
+	return fs;
 }
 
 __device__ __forceinline__ int32_t aux2i(const uint8_t *t) {       // bam_aux2i, truncated to int32 as the reference does
@@ -289,15 +296,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restr
 	if (want_aux) {
 		const uint8_t *p = r + aux0, *end = r + len;
 		bool md = false, hnm = false, has = false;
-		while (p + 3 <= end) {
-			const uint32_t sz = aux_size(p + 2, end);
+		bool bad = false;
+		while (p + 3 <= end && !bad) {
+			const uint32_t sz = aux_size(p + 2, end, &bad);
+			if (bad) break;                              // (nothing of a field that does not fit is used)
 			if (p[0] == 'M' && p[1] == 'D' && !md) {
 				md = true;
-				if (p[2] == 'Z') { ml = sz - 2u; msrc = (uint32_t)(p + 3 - u); if (p + 2 + sz > end || p[2 + sz - 1] != 0) ml = sz - 1u; }
+				if (p[2] == 'Z') { ml = sz - 2u; msrc = (uint32_t)(p + 3 - u); }      // type byte and NUL are not part of the string
 			} else if (p[0] == 'N' && p[1] == 'M' && !hnm) { hnm = true; vnm = aux2i(p + 2); }
 			else if (p[0] == 'A' && p[1] == 'S' && !has) { has = true; vas = aux2i(p + 2); }
 			p += 2 + sz;
 		}
+		if (bad) st->status = MSX_UP_CORRUPT;
 		rf = (md ? MSX_HAS_MD : 0u) | (hnm ? MSX_HAS_NM : 0u) | (has ? MSX_HAS_AS : 0u);
 	}
 	rflags[i] = (uint8_t)rf;

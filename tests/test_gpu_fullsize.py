@@ -185,6 +185,15 @@ def test_c4_coverage_full_size():
         ctx.check(ctx.lib.msx_coverage_finish(ctx.h, C.c_void_p(d_cov), total))
         cov = ctx.to_host(d_cov, total, np.int32)
         seen = ctx.to_host(d_seen, C4_REFS, np.uint8)
+        # the whole-sample form (msx_coverage_depths: no zeroing, depths written once) on the same batch
+        ctx.to_dev(d_cov, np.full(total + 2, 0x5a5a5a5a, np.uint32))
+        ctx.zero(d_seen, C4_REFS)
+        ctx.check(ctx.lib.msx_coverage_depths(ctx.h, C.byref(db.b), C.c_void_p(d_off), C4_REFS, total, C.c_void_p(d_cov),
+                                              C.c_void_p(d_seen)))
+        cov2 = ctx.to_host(d_cov, total, np.int32)
+        seen2 = ctx.to_host(d_seen, C4_REFS, np.uint8)
+        assert np.array_equal(cov, cov2) and np.array_equal(seen, seen2)
+        del cov2
         ctx.free(d_off), ctx.free(d_cov), ctx.free(d_seen)
 
         hs = HostCopy(db)

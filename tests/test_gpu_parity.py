@@ -556,3 +556,19 @@ def test_synth_coverage_parity(ctx, synth):
     # msx_coverage_summary: the two sums mWriteCoverageSummaryToStream divides by the target's length (msam_coverage.c:188-219)
     assert touched.tolist() == [int((w != 0).sum()) for w in want]
     assert dsum.tolist() == [int(w.astype(np.int64).sum()) for w in want]
+
+
+@pytest.mark.parametrize("n_groups,n_refs,tl", [(40000, 2000, 5000), (300000, 300, 5000), (200000, 4, 5000), (30000, 50000, 5000)])
+def test_whole_sample_coverage_parity(ctx, n_groups, n_refs, tl):
+    """msx_coverage_depths (marks sorted by (sign, tile), every tile's depths finished where its marks are gathered; hot
+    tiles pre-reduced; runs behind a D / N through the overflow lists) equals the oracle's per-base counting and the
+    streamed path -- few references: every tile is a hot one; many short ones: tiles span dozens of targets"""
+    import msamtools_amd as m
+    hs = m.HostSynth(4242, n_groups, n_refs, 4)
+    db = m.DeviceBatch.synth(ctx, 4242, n_groups, n_refs, 4)
+    tlen = [tl] * n_refs
+    got = m.coverage(ctx, db, tlen, whole_sample=True)
+    want = orc.coverage(hs, tlen)
+    for t in range(n_refs):
+        assert (got[t] == want[t]).all(), t
+    db.free()
