@@ -255,8 +255,9 @@ def coverage_cli(groups=10_000_000, refs=50_000):
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-    if not os.path.exists(exe):
-        return {"error": "msamtools_amd/bin/msamtools not built"}
+    dev = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")      # synth / digest: generator and self-tests, not in the product binary
+    if not os.path.exists(exe) or not os.path.exists(dev):
+        return {"error": "msamtools_amd/bin/msamtools or msamtools-dev not built"}
     tmp = tempfile.mkdtemp(prefix="msx_cov_", dir="/tmp")
 
     def md5(path):
@@ -274,8 +275,8 @@ def coverage_cli(groups=10_000_000, refs=50_000):
             raise RuntimeError(r.stderr.decode()[-300:])
         return time.perf_counter() - t
     try:
-        subprocess.check_call(f"{exe} synth --groups {groups} --refs {refs} -b > {tmp}/in.bam", shell=True)
-        n = int(subprocess.check_output([exe, "digest", f"{tmp}/in.bam"]).decode().split()[0].split("=")[1])
+        subprocess.check_call(f"{dev} synth --groups {groups} --refs {refs} -b > {tmp}/in.bam", shell=True)
+        n = int(subprocess.check_output([dev, "digest", f"{tmp}/in.bam"]).decode().split()[0].split("=")[1])
         dt_s = run(f"{exe} coverage --summary -o {tmp}/s.gz {tmp}/in.bam")
         dt_t = run(f"{exe} coverage -o {tmp}/t.gz {tmp}/in.bam")
         dt_s1 = run(f"{exe} coverage --summary -o {tmp}/s1.gz {tmp}/in.bam", MSX_SERIAL_IO="1")
@@ -305,12 +306,13 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0,
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-    if not os.path.exists(exe):
-        return {"error": "msamtools_amd/bin/msamtools not built"}
+    dev = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
+    if not os.path.exists(exe) or not os.path.exists(dev):
+        return {"error": "msamtools_amd/bin/msamtools or msamtools-dev not built"}
     tmp = tempfile.mkdtemp(prefix="msx_e2e_", dir="/tmp")
     filt = f"filter -l 80 -p 95 -z 80 --besthit {out_flag}"
     env = dict(os.environ, MSX_TIMING="1")
-    ref_len = 4496              # msh_cli.c: synth_main
+    ref_len = 4496              # msh_dev.c: synth_main
 
     def stages(err, kind):
         d = {}
@@ -335,15 +337,15 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0,
         return dt, r.stderr.decode()
 
     def digest(path):
-        out = subprocess.check_output([exe, "digest", path]).decode().split()
+        out = subprocess.check_output([dev, "digest", path]).decode().split()
         return int(out[0].split("=")[1]), out[1].split("=")[1]
     try:
         t0 = time.perf_counter()
-        subprocess.check_call(f"{exe} synth --groups {groups} --refs {refs} {'--seq' if seq else ''} -b > {tmp}/in.bam", shell=True)
+        subprocess.check_call(f"{dev} synth --groups {groups} --refs {refs} {'--seq' if seq else ''} -b > {tmp}/in.bam", shell=True)
         synth_s = time.perf_counter() - t0
         n, _ = digest(f"{tmp}/in.bam")
         # bytes per record: a small uncompressed sample with a short header (the records do not depend on it)
-        subprocess.check_call(f"{exe} synth --groups {min(groups, 100000)} --refs 1000 {'--seq' if seq else ''} -u > {tmp}/s.bam", shell=True)
+        subprocess.check_call(f"{dev} synth --groups {min(groups, 100000)} --refs 1000 {'--seq' if seq else ''} -u > {tmp}/s.bam", shell=True)
         n_s, _ = digest(f"{tmp}/s.bam")
         size_u = os.path.getsize(f"{tmp}/s.bam")
         dt_f, err_f = run(f"{exe} {filt} {tmp}/in.bam > {tmp}/f.bam")
@@ -423,7 +425,7 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0,
         #  file's size; the marginal rate between two sizes is what a longer file would run at)
         if marginal_groups and tee and "error" not in tee:
             try:
-                subprocess.check_call(f"{exe} synth --groups {marginal_groups} --refs {refs} {'--seq' if seq else ''} -b > {tmp}/in2.bam", shell=True)
+                subprocess.check_call(f"{dev} synth --groups {marginal_groups} --refs {refs} {'--seq' if seq else ''} -b > {tmp}/in2.bam", shell=True)
                 n2, _ = digest(f"{tmp}/in2.bam")
                 cmd2 = f"{exe} {filt} --profile-out {tmp}/pt2.gz --label S {tmp}/in2.bam > {tmp}/ft2.bam"
                 dt2 = min(run(cmd2)[0], run(cmd2)[0])

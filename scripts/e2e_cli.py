@@ -14,6 +14,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+D = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
 FILT = "filter -l 80 -p 95 -z 80 --besthit"
 
 
@@ -62,10 +63,10 @@ def run(ngrp=10_000_000, refs=100_000, tmp="/tmp/msx_e2e", levels=("u", "b"), ve
     res = {"host_cores": os.cpu_count(), "groups": ngrp, "refs": refs, "runs": []}
     try:
         for flag in levels:
-            dt, _ = timed(f"{B} synth --groups {ngrp} --refs {refs} -{flag} > {tmp}/in_{flag}.bam")
+            dt, _ = timed(f"{D} synth --groups {ngrp} --refs {refs} -{flag} > {tmp}/in_{flag}.bam")
             res[f"synth_{flag}_s"] = round(dt, 2)
             res[f"size_{flag}_MB"] = round(os.path.getsize(f"{tmp}/in_{flag}.bam") / 1e6, 1)
-        n = int(subprocess.check_output(f"{B} recode {tmp}/in_{levels[0]}.bam | wc -l", shell=True))
+        n = int(subprocess.check_output(f"{D} recode {tmp}/in_{levels[0]}.bam | wc -l", shell=True))
         res["records"] = n
         res["bytes_per_record"] = round(res[f"size_{levels[0]}_MB"] * 1e6 / n, 1) if levels[0] == "u" else None
         env = {"MSX_TIMING": "1"}

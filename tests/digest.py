@@ -1,4 +1,4 @@
-"""The record-stream digest of `msamtools digest` (msh_cli.c: digest_main), computed with numpy from SoA fields.
+"""The record-stream digest of `msamtools digest` (msh_dev.c: digest_main), computed with numpy from SoA fields.
 
 digest = sum over the records i = 0.. of (i + 1) * g(record i) mod 2^64,
 g = mix64(flag + u32(tid) * K1 + u32(pos) * K2) xor FNV-1a(QNAME).  Order-sensitive (the weights), so "the same
@@ -25,7 +25,7 @@ def _mix(x):
 
 
 def fnv_sim_names(group_index):
-    """FNV-1a of the QNAMEs `sim%08d` (msamtools synth, msh_cli.c: synth_worker) of the given group indices."""
+    """FNV-1a of the QNAMEs `sim%08d` (msamtools synth, msh_dev.c: synth_worker) of the given group indices."""
     g = np.asarray(group_index, dtype=np.int64)
     out = np.empty(g.shape, dtype=np.uint64)
     width = np.full(g.shape, 8, dtype=np.int64)                 # %08d: at least eight digits

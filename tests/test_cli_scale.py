@@ -23,9 +23,10 @@ import oracle_lib as orc
 from conftest import ROOT
 
 BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
 FILT = ["filter", "-l", "80", "-p", "95", "-z", "80", "--besthit"]
 OPTS = dict(l=80, p=95, z=80, besthit=True)
-REF_LEN = 4496          # msh_cli.c: synth_main writes every @SQ with this length
+REF_LEN = 4496          # msh_dev.c: synth_main writes every @SQ with this length
 ENV = dict(MSX_THREADS="16", MSX_BATCH_BYTES="2500000", MSX_BATCH_RECORDS="160000", MSX_INFLATE_BLOCKS="24")
 
 pytestmark = pytest.mark.gpu
@@ -49,7 +50,7 @@ class Case:
         for flag in ("b", "u"):
             p = os.path.join(self.dir, f"in_{groups}_{flag}.bam")
             with open(p, "wb") as fh:
-                subprocess.check_call([BIN, "synth", "--groups", str(groups), "--refs", str(refs), f"-{flag}"], stdout=fh)
+                subprocess.check_call([DEV, "synth", "--groups", str(groups), "--refs", str(refs), f"-{flag}"], stdout=fh)
             self.bam[flag] = p
         self.hs = m.HostSynth(13579, groups, refs, 4)
         f = orc.run_filter(self.hs, **OPTS)
@@ -62,7 +63,7 @@ class Case:
         self.plain = orc.run_profile(self.hs, refs, multi="proportional")
 
     def check_digest(self, path, want):
-        out = subprocess.check_output([BIN, "digest", path], env=dict(os.environ, MSX_THREADS="8")).decode().strip()
+        out = subprocess.check_output([DEV, "digest", path], env=dict(os.environ, MSX_THREADS="8")).decode().strip()
         h, n = want
         assert out == f"records={n} digest={h:016x}", (path, out, n, f"{h:016x}")
 
@@ -117,8 +118,8 @@ def test_filter_records_as_text_lines(mid, tmp_path):
     r = sh(f"{BIN} {' '.join(FILT)} -bu {mid.bam['u']} > {out}", MSX_TIMING=1, MSX_BATCH_BYTES=1_500_000,
            MSX_BATCH_RECORDS=110_000)
     assert n_batches(r.stderr) >= 8, r.stderr.decode()[-800:]
-    src = subprocess.check_output([BIN, "recode", mid.bam["u"]]).decode().split("\n")[:-1]
-    got = subprocess.check_output([BIN, "recode", out]).decode().split("\n")[:-1]
+    src = subprocess.check_output([DEV, "recode", mid.bam["u"]]).decode().split("\n")[:-1]
+    got = subprocess.check_output([DEV, "recode", out]).decode().split("\n")[:-1]
     assert len(src) == mid.hs.n_records
     assert len(got) == len(mid.emit)
     want = [src[i] for i in mid.emit]
@@ -228,7 +229,7 @@ def test_one_batch_equals_many(mid, tmp_path):
     def records(**env):
         out = str(tmp_path / "o.bam")
         sh(f"{BIN} {' '.join(FILT)} -bu {mid.bam['b']} > {out}", **env)
-        return subprocess.check_output([BIN, "recode", "-h", out])
+        return subprocess.check_output([DEV, "recode", "-h", out])
     ref = records()
     for env in (dict(MSX_BATCH_BYTES=96 << 20, MSX_BATCH_RECORDS=3 << 20), dict(MSX_THREADS=1), dict(MSX_THREADS=3)):
         assert records(**env) == ref
@@ -308,8 +309,8 @@ def test_rescore_on_the_pipeline(mid, tmp_path):
     a, b = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
     sh(f"{cmd} > {a}", MSX_BATCH_BYTES=1_500_000, MSX_BATCH_RECORDS=110_000)
     sh(f"{cmd} > {b}", MSX_SERIAL_IO=1, MSX_BATCH_RECORDS=100_000)
-    ta = subprocess.check_output([BIN, "recode", a]).decode().split("\n")[:-1]
-    tb = subprocess.check_output([BIN, "recode", b]).decode().split("\n")[:-1]
+    ta = subprocess.check_output([DEV, "recode", a]).decode().split("\n")[:-1]
+    tb = subprocess.check_output([DEV, "recode", b]).decode().split("\n")[:-1]
     assert ta == tb
     f = orc.run_filter(mid.hs, l=80, p=95, z=80, rescore=True, besthit=True)
     assert len(ta) == len(f["emit"])
@@ -347,7 +348,7 @@ def test_sam_text_input_takes_the_pipeline(mid, tmp_path):
     text out of text in."""
     sam = str(tmp_path / "in.sam")
     with open(sam, "wb") as fh:
-        subprocess.check_call([BIN, "recode", "-h", mid.bam["b"]], stdout=fh)
+        subprocess.check_call([DEV, "recode", "-h", mid.bam["b"]], stdout=fh)
     assert os.path.getsize(sam) > 50_000_000
     f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
     os.environ["MSX_SAM_CHUNK"] = "1000000"

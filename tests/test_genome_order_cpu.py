@@ -17,6 +17,7 @@ from conftest import GOLDEN, ROOT
 
 VEC = json.load(open(os.path.join(GOLDEN, "genome_order_vectors.json")))["vectors"]
 BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
 
 
 def oracle_order(names):
@@ -39,7 +40,7 @@ def test_host_key_order_matches_reference_vectors(v):
     if not os.path.exists(BIN):
         pytest.skip("host binary not built")
     inp = b"".join(s.encode("latin-1") + b"\n" for s in v["insert"])
-    out = subprocess.run([BIN, "keyorder"], input=inp, capture_output=True, check=True).stdout
+    out = subprocess.run([DEV, "keyorder"], input=inp, capture_output=True, check=True).stdout
     assert out.split(b"\n")[:-1] == [s.encode("latin-1") for s in v["keys"]]
 
 

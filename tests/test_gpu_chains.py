@@ -227,13 +227,14 @@ def test_tee_cli_counts_chains_across_batch_cuts(ctx, tmp_path):
     import subprocess
     from conftest import ROOT
     BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+    DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
     recs = random_stream(5, 120000)
     sam = tmp_path / "s.sam"
     sam.write_text(sam_text(recs))
     rec = samio.read_sam(str(sam))[1]
     bam = str(tmp_path / "s.bam")
     with open(bam, "wb") as fh:
-        subprocess.check_call([BIN, "recode", "-u", str(sam)], stdout=fh)
+        subprocess.check_call([DEV, "recode", "-u", str(sam)], stdout=fh)
     opts = dict(l=30, p=95, z=80, besthit=True)
     f, ref = oracle_pipe(rec, "proportional", **opts)
     p = str(tmp_path / "p.gz")
@@ -243,8 +244,8 @@ def test_tee_cli_counts_chains_across_batch_cuts(ctx, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-1000:]
     nb = [int(l.split()[2]) for l in r.stderr.decode().split("\n") if l.startswith("# batches:")]
     assert nb and nb[0] >= 3
-    out = subprocess.check_output([BIN, "recode", str(tmp_path / "f.bam")]).decode().split("\n")[:-1]
-    src = subprocess.check_output([BIN, "recode", bam]).decode().split("\n")[:-1]
+    out = subprocess.check_output([DEV, "recode", str(tmp_path / "f.bam")]).decode().split("\n")[:-1]
+    src = subprocess.check_output([DEV, "recode", bam]).decode().split("\n")[:-1]
     assert out == [src[i] for i in f["emit"]]
     text = gzip.open(p, "rt").read()
     head = [l for l in text.split("\n") if l.startswith("#")]

@@ -19,6 +19,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
 
 
 @pytest.fixture(scope="module")
@@ -151,7 +152,7 @@ def synth(tmp_path_factory):
     d = tmp_path_factory.mktemp("unpack")
     p = str(d / "s.bam")
     with open(p, "wb") as fh:
-        subprocess.check_call([BIN, "synth", "--groups", "150000", "--refs", "700", "-u"], stdout=fh)
+        subprocess.check_call([DEV, "synth", "--groups", "150000", "--refs", "700", "-u"], stdout=fh)
     stream, n_ref = record_stream(p)
     return stream, n_ref, samio.read_bam(p)[1]
 
@@ -279,7 +280,7 @@ def odd_sam(tmp_path):
     p.write_text("\n".join(lines) + "\n")
     bam = str(tmp_path / "odd.bam")
     with open(bam, "wb") as fh:
-        subprocess.check_call([BIN, "recode", "-b", str(p)], stdout=fh)
+        subprocess.check_call([DEV, "recode", "-b", str(p)], stdout=fh)
     return bam
 
 

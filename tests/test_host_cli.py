@@ -19,6 +19,7 @@ import samio
 from conftest import GOLDEN, ROOT, fixture_path
 
 BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
 EXP = json.load(open(os.path.join(GOLDEN, "reference_expectations.json")))
 
 
@@ -31,7 +32,8 @@ def built():
 def run(args, stdin=None, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    return subprocess.run([BIN] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    exe = DEV if args and args[0] in ("synth", "digest", "recode", "pipetest", "restream", "rawtest", "keyorder") else BIN
+    return subprocess.run([exe] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
 
 
 def body(path):
@@ -396,7 +398,7 @@ def test_cli_profile_genome_errors(tmp_path):
 # ---- the pipelined BAM reader (decode stage only: no GPU needed) ---------------------------------------
 def _pipetest(path, mode, stats, **env):
     e = dict(os.environ, **{k: str(v) for k, v in env.items()})
-    r = subprocess.run([BIN, "pipetest", str(mode), str(stats), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    r = subprocess.run([DEV, "pipetest", str(mode), str(stats), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=e, timeout=300)
     return r.returncode, r.stdout.decode() + r.stderr.decode()
 
@@ -408,7 +410,7 @@ def synth_bams(tmp_path_factory):
     for flag in ("b", "u"):
         p = str(d / f"in_{flag}.bam")
         with open(p, "wb") as fh:
-            subprocess.check_call([BIN, "synth", "--groups", "60000", "--refs", "500", f"-{flag}"], stdout=fh)
+            subprocess.check_call([DEV, "synth", "--groups", "60000", "--refs", "500", f"-{flag}"], stdout=fh)
         out[flag] = p
     return out
 
@@ -430,7 +432,7 @@ def test_pipeline_decode_of_sam_text_equals_record_reader(synth_bams, tmp_path):
     the line-at-a-time reader: same records, same SoA fields, same pools, for chunks that cut lines anywhere."""
     sam = str(tmp_path / "in.sam")
     with open(sam, "wb") as fh:
-        subprocess.check_call([BIN, "recode", "-h", synth_bams["u"]], stdout=fh)
+        subprocess.check_call([DEV, "recode", "-h", synth_bams["u"]], stdout=fh)
     for mode, stats in ((1, 1), (2, 0)):
         for env in (dict(MSX_SAM_CHUNK=70_001, MSX_BATCH_BYTES=300_000, MSX_BATCH_RECORDS=110_000, MSX_THREADS=5),
                     dict(MSX_SAM_CHUNK=1_000_000, MSX_THREADS=16), dict(MSX_THREADS=1)):
@@ -459,7 +461,7 @@ def test_block_feed_of_the_device_inflater(synth_bams, flag, blocks):
     p += 4
     for _ in range(n_ref):
         p += 8 + struct.unpack_from("<i", raw, p)[0]
-    out = subprocess.check_output([BIN, "rawtest", "--blocks", str(blocks), synth_bams[flag]],
+    out = subprocess.check_output([DEV, "rawtest", "--blocks", str(blocks), synth_bams[flag]],
                                   env=dict(os.environ, MSX_THREADS="5", MSX_INFLATE_BLOCKS="8")).decode().split()
     got = dict(kv.split("=") for kv in out)
     assert int(got["bytes"]) == len(raw) - p
@@ -471,14 +473,14 @@ def test_stream_writer_roundtrip(synth_bams, tmp_path, flag):
     """msh_write_stream -- the writer of device-unpacked batches: a ready-made record stream cut into BGZF payloads where
     they fall, records straddling blocks -- through a file and through a pipe (vmsplice), several batches: the records
     read back are the input's, in order (`msamtools digest`)."""
-    want = subprocess.check_output([BIN, "digest", synth_bams["u"]])
+    want = subprocess.check_output([DEV, "digest", synth_bams["u"]])
     env = dict(os.environ, MSX_BATCH_BYTES="3000000", MSX_INFLATE_BLOCKS="16", MSX_THREADS="6")
     out = str(tmp_path / "o.bam")
     with open(out, "wb") as fh:
-        subprocess.check_call([BIN, "restream", flag, synth_bams["b"]], stdout=fh, env=env)
-    assert subprocess.check_output([BIN, "digest", out]) == want
-    subprocess.check_call(f"{BIN} restream {flag} {synth_bams['u']} | cat > {out}", shell=True, env=env)
-    assert subprocess.check_output([BIN, "digest", out]) == want
+        subprocess.check_call([DEV, "restream", flag, synth_bams["b"]], stdout=fh, env=env)
+    assert subprocess.check_output([DEV, "digest", out]) == want
+    subprocess.check_call(f"{DEV} restream {flag} {synth_bams['u']} | cat > {out}", shell=True, env=env)
+    assert subprocess.check_output([DEV, "digest", out]) == want
     # an independent reader agrees on the BGZF framing (python gzip + struct)
     hdr, rec = samio.read_bam(out)
     assert rec.n == int(want.split()[0].split(b"=")[1])
@@ -503,7 +505,7 @@ def test_pipeline_long_unmapped_stretch_is_linear(tmp_path):
             fh.write(f"u{i:07d}\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n")
     bam = tmp_path / "tail.bam"
     with open(bam, "wb") as fh:
-        subprocess.check_call([BIN, "recode", "-u", str(sam)], stdout=fh)
+        subprocess.check_call([DEV, "recode", "-u", str(sam)], stdout=fh)
     t0 = time.time()
     rc, text = _pipetest(str(bam), 1, 1, MSX_THREADS=4)
     assert rc == 0, text
@@ -582,11 +584,11 @@ def test_cli_fatal_record_after_the_pools_before_it(tmp_path, synth_bams):
     assert [l.split("\t")[0] for l in r.stdout.decode().split("\n") if l] == ["r0", "r1", "r2"]
     # many batches, the offending record late in the file: every earlier batch is written (in order), then the pools
     # of its own batch in front of it -- device-side walk and host-side walk alike
-    src = subprocess.check_output([BIN, "recode", synth_bams["u"]]).decode().split("\n")[:-1]
+    src = subprocess.check_output([DEV, "recode", synth_bams["u"]]).decode().split("\n")[:-1]
     k = next(i for i in range(len(src) * 3 // 4, len(src)) if src[i].split("\t")[0] != src[i - 1].split("\t")[0])
     f = src[k].split("\t")
     src[k] = "\t".join(x for x in f if not x.startswith(("MD:", "NM:")))
-    hdr = subprocess.check_output([BIN, "recode", "-h", synth_bams["u"]]).decode().split("\n")
+    hdr = subprocess.check_output([DEV, "recode", "-h", synth_bams["u"]]).decode().split("\n")
     hdr = [l for l in hdr if l.startswith("@")]
     bad_sam = tmp_path / "late.sam"
     bad_sam.write_text("\n".join(hdr + src) + "\n")
@@ -635,3 +637,11 @@ def test_cli_coverage_binned_path_equals_atomic_path(tmp_path, synth_bams):
         for i in range(0, len(v), 4):
             want.append(" ".join(str(x) for x in v[i:i + 4]))
     assert gzip.open(out, "rt").read().split("\n")[:-1] == want
+
+
+def test_product_binary_carries_only_the_reference_commands():
+    """generator and I/O self-tests live in msamtools-dev (msh_dev.c); `msamtools` dispatches what msamtools.c:31-49 does"""
+    for c in ("synth", "recode", "digest", "pipetest", "restream", "rawtest", "keyorder"):
+        r = subprocess.run([BIN, c], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and b"unrecognized command" in r.stderr, c
+    assert subprocess.run([DEV, "filter"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1

@@ -14,6 +14,7 @@ import pytest
 from conftest import ROOT
 
 BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
 EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
@@ -28,7 +29,7 @@ def _block(data):
 def test_damaged_records_are_fatal_errors_not_overreads(tmp_path):
     src = tmp_path / "in.bam"
     with open(src, "wb") as fh:
-        subprocess.check_call([BIN, "synth", "--groups", "800", "--refs", "50", "-b"], stdout=fh)
+        subprocess.check_call([DEV, "synth", "--groups", "800", "--refs", "50", "-b"], stdout=fh)
     raw = gzip.open(src).read()
     l_text = struct.unpack_from("<i", raw, 4)[0]
     n_ref = struct.unpack_from("<i", raw, 8 + l_text)[0]
@@ -56,7 +57,7 @@ def test_damaged_records_are_fatal_errors_not_overreads(tmp_path):
             for i in range(0, len(d), 60000):
                 fh.write(_block(bytes(d[i:i + 60000])))
             fh.write(EOF_BLOCK)
-        for cmd in ([BIN, "recode", str(bam)], [BIN, "pipetest", "1", "1", str(bam)]):
+        for cmd in ([DEV, "recode", str(bam)], [DEV, "pipetest", "1", "1", str(bam)]):
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120,
                                env=dict(os.environ, MSX_THREADS="4", MSX_BATCH_BYTES="300000"))
             err = r.stderr.decode(errors="replace").strip()

@@ -22,6 +22,7 @@ import samio
 from conftest import ROOT
 
 BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
 MODES = {"all": "all", "equal": "equal", "ignore": "ignore", "prop": "proportional"}
 N = 3000
 
