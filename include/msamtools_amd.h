@@ -467,8 +467,10 @@ int  msx_dist_sum_i64(msx_ctx *ctx, int64_t *value);
 int  msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p);
 /* mInsertCountToAbundanceMatrix over all ranks' shards: msx_profile_allreduce_counts, then
  * msx_profile_finalize_enqueue's device work with `share` all-reduced inside every iteration and the
- * purged count summed at the end; nothing waits for the host.  Identical results on every rank
- * (fetch them with msx_profile_fetch).  With one rank it IS msx_profile_finalize_enqueue. */
+ * purged count summed at the end.  Identical results on every rank (fetch them with msx_profile_fetch).  Without a
+ * communicator it IS msx_profile_finalize_enqueue.  With one, the loop looks at the convergence flag (msam_profile.c:383)
+ * every MSX_DIST_POLL iterations (default 4) -- a 4-byte copy and a wait for the stream -- and stops enqueueing
+ * collectives once it is set; MSX_DIST_POLL=0: all 19 iterations are enqueued and nothing waits for the host. */
 int  msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p);
 
 /* ---- coverage: replaces mUpdateCoverageForAlignment (msam_coverage.c:33-87) */

@@ -213,12 +213,14 @@ void *filter_dev_thread(void *arg) {
 					F->any_fatal = 1;
 					snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
 					st.n_emit = 0;
-					if (P->mode == 1 && st.err_record >= 0 && ur.n_groups > 0) {
-						uint32_t *go = (uint32_t *)xmalloc(((size_t)ur.n_groups + 1) * 4);
-						int64_t g = 0, npre;
-						MSX(msx_dev_to_host(g_ctx, go, db.group_off, ((size_t)ur.n_groups + 1) * 4));
-						npre = fatal_prefix(go, ur.n_groups, st.err_record, &g);
-						free(go);
+					if (st.err_record >= 0) {
+						int64_t g = 0, npre = st.err_record;           /* (no pools in the batch: cut at the record itself) */
+						if (P->mode != 0 && ur.n_groups > 0) {
+							uint32_t *go = (uint32_t *)xmalloc(((size_t)ur.n_groups + 1) * 4);
+							MSX(msx_dev_to_host(g_ctx, go, db.group_off, ((size_t)ur.n_groups + 1) * 4));
+							npre = fatal_prefix(go, ur.n_groups, st.err_record, &g);
+							free(go);
+						}
 						if (npre > 0) {
 							db.n_records = npre; db.n_groups = g;
 							MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
@@ -273,9 +275,10 @@ void *filter_dev_thread(void *arg) {
 			F->any_fatal = 1;
 			snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
 			st.n_emit = 0;
-			if (P->mode == 1 && st.err_record >= 0 && b->n_groups > 0) {
+			if (st.err_record >= 0) {
 				int64_t g = 0;
-				const int64_t npre = fatal_prefix(b->group_off, (int64_t)b->n_groups, st.err_record, &g);
+				const int64_t npre = (P->mode != 0 && b->n_groups > 0) ? fatal_prefix(b->group_off, (int64_t)b->n_groups, st.err_record, &g)
+				                                                       : st.err_record;
 				if (npre > 0) {
 					db.n_records = npre; db.n_groups = g;
 					MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));

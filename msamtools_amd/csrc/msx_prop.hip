@@ -1595,12 +1595,24 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (rc) return rc;
 	if ((rc = msx_profile_prop_begin(ctx, p))) return rc;      // a = U = ui/2 (+d): identical on every rank
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
+		// After convergence the local kernels are no-ops and leave `share` at zero on every rank, but a collective that
+		// has been enqueued runs: 8 MB of zeros per remaining iteration.  So the loop looks at the convergence flag every
+		// `poll` iterations (MSX_DIST_POLL, default 4; 0: never -- enqueue all 19 and return without waiting): one small
+		// copy and one wait for the stream, and every rank -- they hold the same all-reduced numbers, hence the same flag
+		// (:383) -- stops enqueueing at the same k.  The price is a drained stream every fourth iteration (~20 us), the
+		// gain every all-reduce behind the last look (c3 converges at k = 15: three of nineteen).
+		const char *pe = getenv("MSX_DIST_POLL");
+		const int poll = (ctx->dist && pe) ? atoi(pe) : (ctx->dist ? 4 : 0);
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
 			if ((rc = msx_prop_iteration(ctx, p, true))) return rc;     // share = this rank's part of the increment, complete
-			// (after convergence the local kernels are no-ops and leave `share` at zero on every rank;
-			// the all-reduce still runs -- every rank enqueues the same 19 -- and sums zeros)
 			if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;
 			msx_prop_apply_launch(ctx, p, k, false);   // same numbers, same decision (:383) everywhere
+			if (poll > 0 && k % poll == 0 && k < 19) {
+				int32_t done = 0;
+				MSX_HIP(ctx, hipMemcpyAsync(&done, p->iter_state, 4, hipMemcpyDeviceToHost, ctx->stream));
+				MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+				if (done) break;
+			}
 		}
 		msx_prop_purged_launch(ctx, p, p->counters + 3);       // this rank's multi-mappers whose sum is 0
 		if ((rc = msx_dist_allreduce_u32(ctx, p->counters + 3, 1))) return rc;

@@ -292,3 +292,35 @@ def test_code_sets_zlib_never_writes(ctx):
         o += len(d)
     assert refused == int((st != 0).sum())
     assert not st.any(), list(st)          # all three are within what the device decodes itself
+
+
+def test_blocks_written_by_libdeflate():
+    """Streams from another encoder: libdeflate (what htslib and samtools deflate with in most builds) at levels 1, 6 and
+    12 -- block splits, code lengths and match shapes zlib never chooses.  The compressed bytes are committed data
+    (tests/golden/libdeflate_blocks.bin, made by tests/golden/make_libdeflate_blocks.py in the build container); the
+    inputs are regenerated from that script's seed.  Every stream must inflate on the device to its input, CRC included."""
+    import importlib.util
+    import json
+    import os
+    m = M()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_libdeflate_blocks", os.path.join(here, "make_libdeflate_blocks.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    inputs = gen.inputs()
+    blob = open(os.path.join(here, "libdeflate_blocks.bin"), "rb").read()
+    index = json.load(open(os.path.join(here, "libdeflate_blocks.json")))["blocks"]
+    assert len(index) == 21 and {b["level"] for b in index} == {1, 6, 12}
+    payloads = [blob[b["offset"]:b["offset"] + b["length"]] for b in index]
+    datas = [inputs[b["name"]] for b in index]
+    for b, pl, d in zip(index, payloads, datas):
+        assert len(d) == b["isize"] and zlib.crc32(d) == b["crc32"] and zlib.decompress(pl, -15) == d      # the fixture itself
+    c = m.Context(0)
+    try:
+        comp, tab, total = m.bgzf_blocks(payloads, datas)
+        out, st, refused = m.bgzf_inflate(c, comp, tab, len(payloads), total)
+        bad = [(index[i]["name"], index[i]["level"], int(st[i])) for i in range(len(index)) if st[i]]
+        assert refused == 0 and not bad, bad
+        assert out[:total].tobytes() == b"".join(datas)
+    finally:
+        c.close()

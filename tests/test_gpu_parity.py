@@ -531,6 +531,56 @@ def test_ragged_inputs(ctx):
         assert_profile_close(ab, st, ref)
 
 
+def test_extreme_scores_and_mate_bits(ctx):
+    """Corners no reference fixture pins (source-derived, msam_filter.c:192-263): AS = INT32_MIN alone in a pool (the
+    reference writes it: best_count goes 0 -> 1 through the score == best_score branch, :225-229), tied, and beside
+    larger scores; AS of BAM type I above 2^31 (bam_aux2i's int64 truncated to int32_t: a negative score); paired pools
+    whose records carry both mate bits, neither, or a mix -- kernel against the oracle, --besthit and --uniqhit, and
+    the inserts profile counts from what is written."""
+    import msamtools_amd as m
+    lo = -(1 << 31)
+    b = samio._Builder()
+    cig = [(100 << 4) | 0]
+
+    def pool(name, scores, flags=None, tids=None):
+        for i, sc in enumerate(scores):
+            fl = flags[i] if flags else (0 if i == 0 else 256)
+            b.add(name, fl, tids[i] if tids else i % 7, 10 * i, cig, b"100", None, sc)
+    pool(b"min_alone", [lo])
+    pool(b"min_tied", [lo, lo, lo])
+    pool(b"min_and_more", [lo, lo + 1, 5, lo])
+    pool(b"min_vs_zero", [0, lo])
+    pool(b"big_I", [0x80000005 - (1 << 32), 0xfffffff0 - (1 << 32), 0x7fffffff])       # type I values as int32
+    pool(b"max_tied", [0x7fffffff, 0x7fffffff, lo])
+    pool(b"both_bits", [50, 60, 60, 40], flags=[0xC1, 0xC1 | 256, 0xC1 | 256, 0xC1 | 256])
+    pool(b"both_and_one", [50, 60, 70, 70, lo], flags=[0xC1, 0x41 | 256, 0x81 | 256, 0xC1 | 256, 0x81 | 256])
+    pool(b"neither_bit_paired", [30, 30, 20], flags=[0x01, 0x01 | 256, 0x01 | 256])
+    pool(b"unpaired_with_mate_bits", [30, 31, 31], flags=[0x40, 0x80 | 256, 0xC0 | 256])
+    pool(b"min_paired", [lo, lo, lo, 3], flags=[0x41, 0x81 | 256, 0x41 | 256, 0x81 | 256], tids=[1, 1, 2, 3])
+    rec = b.build()
+    for opts in (dict(besthit=True), dict(uniqhit=True), dict(l=50, besthit=True), dict(p=90, uniqhit=True)):
+        got = gpu_filter(ctx, rec, **opts)
+        want = orc.run_filter(rec, **opts)
+        assert want["rc"] == 0
+        assert got.emit.tolist() == want["emit"].tolist(), opts
+    # the inserts of `filter --besthit | profile`, fused call against the oracle run as the two commands
+    goff = m.filter_pools(rec)
+    batch = m.DeviceBatch.upload(ctx, rec, goff, filter_pools=True)
+    run = m.FilterRun(ctx, batch, besthit=True)
+    prof = m.Profile(ctx, 7, "proportional")
+    run.enqueue_with_profile(prof)
+    run.finish()
+    sel = run.result().emit
+    ab, st = prof.finalize()
+    ref = orc.run_profile(rec, 7, multi="proportional", sel=sel)
+    assert (st.insert_count, st.uniq_mapper_count, st.multi_mapper_count) == \
+        (ref["stats"].insert_count, ref["stats"].uniq_mapper_count, ref["stats"].multi_mapper_count)
+    assert_profile_close(ab, st, ref)
+    prof.close()
+    run.free()
+    batch.free()
+
+
 def test_int32_wraparound_matches_oracle(ctx):
     """Alignments > 2.1 Mbp overflow the reference's int32 threshold products; the kernel wraps like the oracle."""
     import msamtools_amd as m
