@@ -40,15 +40,30 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
 # filled from profiles/ when measured for the default workload; None = not measured.
 TRAFFIC = {}
-_PMC = os.path.join(ROOT, "profiles", "round3", "pmc_traffic_c3.json")
+_PMC = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_traffic_c3.json") for r in ("round4", "round3")) if os.path.exists(p)),
+            os.path.join(ROOT, "profiles", "round4", "pmc_traffic_c3.json"))
+TRAFFIC_STALE = []          # kernel sources that have changed since the PMC passes were collected
 
 
 def load_traffic(workload, ng, nrefs):
-    """PMC-measured HBM bytes per launch; only valid for the workload they were collected on (c3 defaults)."""
+    """PMC-measured HBM bytes per launch; only valid for the workload they were collected on (c3 defaults).  The file
+    records a hash of every kernel source it was collected on: when one has changed since, the line says so
+    (roofline.traffic_stale_sources) and a warning goes to stderr -- the figure describes an earlier kernel."""
     if workload == "c3" and (ng, nrefs) == WORKLOADS["c3"][:2] and os.path.exists(_PMC):
         try:
-            for k, v in json.load(open(_PMC))["kernels"].items():
+            doc = json.load(open(_PMC))
+            for k, v in doc["kernels"].items():
                 TRAFFIC[k] = int(v["hbm_bytes_per_launch"])
+            import hashlib
+            for f, h in doc.get("source_sha16", {}).items():
+                q = os.path.join(ROOT, "msamtools_amd", "csrc", f)
+                if not os.path.exists(q) or hashlib.sha256(open(q, "rb").read()).hexdigest()[:16] != h:
+                    TRAFFIC_STALE.append(f)
+            if "source_sha16" not in doc:
+                TRAFFIC_STALE.append("(no source hashes in the file: collected before round 4)")
+            if TRAFFIC_STALE:
+                print(f"bench.py: warning: {os.path.relpath(_PMC, ROOT)} was collected on other versions of {', '.join(TRAFFIC_STALE)}",
+                      file=sys.stderr)
         except Exception:
             pass
 SEED = 13579
@@ -816,6 +831,7 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
             "traffic_source": (os.path.relpath(_PMC, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this command; "
                                "not collected inside this run)") if TRAFFIC.get(dom) else None,
+            "traffic_stale_sources": TRAFFIC_STALE or None,
             "algorithmic_bytes_per_launch": int(dom_bytes / tms[dom][1]),
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": tms[dom][1],
             "per_kernel": per_kernel,

@@ -241,6 +241,11 @@ void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u);
 /* bytes that precede the first msx_unpack_enqueue's (records a host-side reader has left over) and the QNAME of
  * the last record that named a pool before them (NULL: none) */
 int  msx_unpack_seed(msx_ctx *ctx, msx_unpack *u, const uint8_t *carry, size_t n, const char *prev_name);
+/* the other direction: what the last msx_unpack_finish left for the next batch (the open pool, the cut record, the last naming
+ * QNAME), to the host -- for msx_unpack_seed of another unpacker: one input (the loop of msam_filter.c:119-186 reads ONE
+ * stream) dealt batch by batch to several GPUs keeps inflate and walk on the devices, this hand-over alone is serial.
+ * host == NULL or cap < *n: only the size is told. */
+int  msx_unpack_carry(msx_ctx *ctx, msx_unpack *u, uint8_t *host, size_t cap, size_t *n, char name[256], int *has_name);
 int  msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_bytes, size_t n, const msx_unpack_params *prm);
 int  msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result *res, msx_batch *dev_view);
 /* optional: after msx_unpack_finish, send the bytes of the NEXT msx_unpack_enqueue ahead (a copy stream of their own),

@@ -113,6 +113,7 @@ SYMBOLS = {
     "msx_unpack_create": (C.c_int, [_P, C.POINTER(_P)]),
     "msx_unpack_destroy": (None, [_P, _P]),
     "msx_unpack_seed": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_char_p]),
+    "msx_unpack_carry": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.POINTER(C.c_int)]),
     "msx_unpack_enqueue": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(UnpackParams)]),
     "msx_unpack_finish": (C.c_int, [_P, _P, C.POINTER(UnpackResult), C.POINTER(Batch)]),
     "msx_unpack_prefetch": (C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -118,7 +118,8 @@ typedef struct {
 	int pin_ready;             /* rbuf is page-locked and obuf allocated (pin_mu) */
 	int ob;                    /* the output buffer this batch holds (pipe_t.ob[]), -1: none */
 	uint8_t *obuf;             /* = P->ob[ob]: filter's output records of the batch (msx_unpack_emit_fetch), page-locked */
-	msx_event *ev_out;         /* ... are there once this has been waited for */
+	msx_event *ev_out;         /* ... are there once this has been waited for (= ev_out_by[the context that worked on the batch]) */
+	msx_event *ev_out_by[MSH_MAX_DEVICES];
 	msx_ctx *ev_ctx;
 	size_t ocap, olen;
 	int framed;                /* obuf holds finished BGZF blocks (msx_unpack_emit_gather_bgzf), not a bare record stream */
@@ -146,6 +147,15 @@ typedef struct {
 	size_t ob_cap[PIPE_OBUFS];
 	pq q_ob;
 	int raw_started, raw_done;
+	/* several contexts: the stream's carry behind raw batch seq - 1, handed from the context that finished it to the one
+	 * that walks batch `baton_seq` (msx_unpack_carry -> msx_unpack_seed) */
+	pthread_mutex_t baton_mu;
+	pthread_cond_t baton_cv;
+	size_t baton_seq;             /* the raw batch whose predecessor's carry is in baton */
+	int baton_fresh;              /* ... and has not been taken: the first raw batch is seeded by the decode stage instead */
+	kstr baton;
+	char baton_name[256];
+	int baton_has_name;
 	int first_state, first_slot;   /* 0: batch 0 not decoded yet; 1: it is, in slot first_slot; 2: the input holds no record (first_mu) */
 	int out_opened;                /* the preflight has passed and the output is open (first_mu) */
 	pthread_mutex_t first_mu;

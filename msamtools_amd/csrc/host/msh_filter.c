@@ -247,7 +247,9 @@ void *filter_dev_thread(void *arg) {
 					s->obuf = P->ob[s->ob];
 					s->ocap = P->ob_cap[s->ob];
 				}
-				if (!s->ev_out) MSX(msx_event_create(g_ctx, &s->ev_out));
+				/* (an event belongs to the device it was made on: one per slot and context) */
+				if (!s->ev_out_by[D->index]) MSX(msx_event_create(g_ctx, &s->ev_out_by[D->index]));
+				s->ev_out = s->ev_out_by[D->index];
 				MSX(msx_unpack_emit_fetch(g_ctx, unpack, s->obuf, s->ocap, s->ev_out));
 				s->ev_ctx = g_ctx;
 				s->olen = (size_t)nb;
@@ -413,7 +415,11 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	/* From the second batch on the record walk runs on the device (msx_unpack): one context, records written as they
 	 * are (no --rescore), BAM out.  The first batch takes the host-side walk: the preflight reads its records.
 	 * MSX_HOST_UNPACK=1 keeps every batch on the host. */
-	if (F.n_dev == 1 && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) && !getenv("MSX_HOST_UNPACK"))
+	/* Several contexts (MSX_DEVICES) keep both: every context inflates and walks its batches, the stream's carry travels
+	 * from the context that finished batch k to the one that walks batch k + 1 (unpack_slot_enqueue; MSX_MULTI_HOST_WALK=1:
+	 * round 3's form, inflate and walk on the host for every batch). */
+	if ((F.n_dev == 1 || !getenv("MSX_MULTI_HOST_WALK")) && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) &&
+	    !getenv("MSX_HOST_UNPACK"))
 		pipe_enable_raw(&P, 1);
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);

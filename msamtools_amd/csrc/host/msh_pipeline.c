@@ -294,6 +294,9 @@ void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_consumers)
 	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out); pq_init(&P->q_ob);
 	for (i = 0; i < PIPE_SLOTS_MAX; i++) P->slot[i].ob = -1;
 	pthread_mutex_init(&P->first_mu, NULL);
+	pthread_mutex_init(&P->baton_mu, NULL);
+	pthread_cond_init(&P->baton_cv, NULL);
+	P->baton_seq = (size_t)-1;
 	pthread_cond_init(&P->first_cv, NULL);
 	for (i = 0; i < P->n_slots; i++) {
 		pslot *s = &P->slot[i];
@@ -417,9 +420,31 @@ void pin_wait(pipe_t *P, pslot *s) {
  * block the device inflater refuses is inflated here instead -- by the reader's own decoder and zlib, whose diagnostics
  * are the command's -- and handed over inflated. */
 void unpack_slot_enqueue(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up) {
-	(void)P;
+	if (P->n_consumers > 1) {
+		/* Several contexts share the one stream: this batch's blocks go up and are inflated at once (a stream of their
+		 * own), its walk waits for the carry of the batch before it -- which another context may still be walking. */
+		if (s->comp && s->n_blk > 0) MSX(msx_unpack_prefetch_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk));
+		pthread_mutex_lock(&P->baton_mu);
+		while (P->baton_seq != s->seq) pthread_cond_wait(&P->baton_cv, &P->baton_mu);
+		if (P->baton_fresh) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)P->baton.s, P->baton.l, P->baton_has_name ? P->baton_name : NULL));
+		pthread_mutex_unlock(&P->baton_mu);
+	}
 	if (!s->comp) MSX(msx_unpack_enqueue(g_ctx, unpack, s->rbuf, s->rlen, up));
 	else MSX(msx_unpack_enqueue_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk, up));
+}
+/* (several contexts) the walk of batch s is done: its carry to whoever walks the next batch */
+static void baton_pass(pipe_t *P, pslot *s, msx_unpack *unpack) {
+	size_t n = 0;
+	MSX(msx_unpack_carry(g_ctx, unpack, NULL, 0, &n, NULL, NULL));
+	pthread_mutex_lock(&P->baton_mu);
+	P->baton.l = 0;
+	ks_reserve(&P->baton, n + 1);
+	MSX(msx_unpack_carry(g_ctx, unpack, (uint8_t *)P->baton.s, n, &n, P->baton_name, &P->baton_has_name));
+	P->baton.l = n;
+	P->baton_seq = s->seq + 1;
+	P->baton_fresh = 1;
+	pthread_cond_broadcast(&P->baton_cv);
+	pthread_mutex_unlock(&P->baton_mu);
 }
 void unpack_slots_ahead(pipe_t *P, msx_unpack *unpack, ahead_q *A) {
 	static int depth = 0;
@@ -459,6 +484,7 @@ void unpack_slot_finish(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpac
 		rc = msx_unpack_finish(g_ctx, unpack, ur, db);
 	}
 	if (rc != MSX_OK) mDie("%s", msx_last_error(g_ctx));
+	if (P->n_consumers > 1) baton_pass(P, s, unpack);
 }
 
 /* device unpack: every slot gets a buffer of fixed size for the inflated bytes (page-locked by pin_thread) */
@@ -923,6 +949,13 @@ void *pipe_decode_thread(void *arg) {
 			return NULL;
 		}
 		s->seq = P->n_filled;
+		if (s->raw && s->has_seed) {          /* the first raw batch is seeded from batch 0's leftovers, not from a baton */
+			pthread_mutex_lock(&P->baton_mu);
+			P->baton_seq = s->seq;
+			P->baton_fresh = 0;
+			pthread_cond_broadcast(&P->baton_cv);
+			pthread_mutex_unlock(&P->baton_mu);
+		}
 		__atomic_store_n(&P->n_filled, P->n_filled + 1, __ATOMIC_RELEASE);
 		pq_push(&P->q_dev, si);
 	}

@@ -476,7 +476,7 @@ int msam_profile_main(int argc, char *argv[]) {
 		memset(&S, 0, sizeof S);
 		S.n_dev = device_list(dev_ids);
 		pipe_init(&P, in, 2, 0, S.n_dev);
-		if (S.n_dev == 1 && !getenv("MSX_HOST_UNPACK")) pipe_enable_raw(&P, 0);   /* the record walk of every batch but the first on the device */
+		if ((S.n_dev == 1 || !getenv("MSX_MULTI_HOST_WALK")) && !getenv("MSX_HOST_UNPACK")) pipe_enable_raw(&P, 0);   /* the record walk of every batch but the first on the device */
 		S.P = &P; S.o = &o; S.F = &F;
 		if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
 		for (k = 0; k < S.n_dev; k++) {

@@ -750,6 +750,10 @@ __device__ __forceinline__ int64_t sr_chunk(int64_t E, int64_t W) {
 	return (per + SR_STEP - 1) / SR_STEP * SR_STEP;
 }
 
+// NG: operand gathers issued for the "other features" of an entry (3 = all of them: the kernel; 1 and 2 exist to PRICE a
+// class-major entry order -- a region of entries with one / two other features would issue exactly that many -- and give
+// wrong sums on the real store: MSX_SR_GATHERS)
+template <int NG>
 __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long long *__restrict__ csr_tot,
                                                             const uint32_t *__restrict__ t_key,
                                                             const unsigned long long *__restrict__ t_val,
@@ -843,8 +847,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 			               o3 = (uint32_t)((lv[i] >> 42) & SIG_PAD);
 			af[i] = bload(rs_a, exact ? (k[i] & fmask) * 8u : general ? recip_at + (uint32_t)lv[i] * 8u : NONE);
 			a1[i] = bload(rs_a, (exact && o1 != SIG_PAD) ? o1 * 8u : NONE);
-			a2[i] = bload(rs_a, (exact && o2 != SIG_PAD) ? o2 * 8u : NONE);
-			a3[i] = bload(rs_a, (exact && o3 != SIG_PAD) ? o3 * 8u : NONE);
+			a2[i] = NG >= 2 ? bload(rs_a, (exact && o2 != SIG_PAD) ? o2 * 8u : NONE) : 0.0;
+			a3[i] = NG >= 3 ? bload(rs_a, (exact && o3 != SIG_PAD) ? o3 * 8u : NONE) : 0.0;
 		}
 	};
 	// A three-stage pipeline over the steps of the chunk: while step i is summed, the gathers of step i+1 and
@@ -1186,6 +1190,21 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long l
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// MSX_SR_CLASSES=1: how many entries of the derived store have 0 / 1 / 2 / 3 other features in their value, how many
+// belong to general lists (what a class-major order would have to work with)
+__global__ __launch_bounds__(MSX_BLOCK) void k_sr_classes(const unsigned long long *__restrict__ csr_tot, const unsigned long long *__restrict__ t_val,
+                                                          unsigned long long *__restrict__ out) {
+	const int64_t E = (int64_t)csr_tot[1];
+	unsigned long long c[5] = {0, 0, 0, 0, 0};
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < E; i += (int64_t)gridDim.x * MSX_BLOCK) {
+		const unsigned long long v = t_val[i];
+		if (v & SIG_HASHED) { c[4]++; continue; }
+		const int n = ((v & SIG_PAD) != SIG_PAD) + (((v >> 21) & SIG_PAD) != SIG_PAD) + (((v >> 42) & SIG_PAD) != SIG_PAD);
+		c[n]++;
+	}
+	for (int k = 0; k < 5; k++) if (c[k]) atomicAdd(&out[k], c[k]);
+}
+
 // waves of one k_share_reduce launch: what the chip holds at once
 int64_t msx_share_waves(msx_ctx *ctx) {
 	static const int wps = [] {
@@ -1394,6 +1413,16 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		hipLaunchKernelGGL(k_part_runs, dim3((unsigned)((2 * W + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
 		msx_time_end(ctx);
+		if (getenv("MSX_SR_CLASSES")) {
+			unsigned long long h[5] = {0, 0, 0, 0, 0}, *d = (unsigned long long *)p->part_val.p;      // (not in use yet)
+			MSX_HIP(ctx, hipMemsetAsync(d, 0, 40, ctx->stream));
+			hipLaunchKernelGGL(k_sr_classes, dim3(1024), dim3(MSX_BLOCK), 0, ctx->stream, (const unsigned long long *)p->d_tot,
+			                   (const unsigned long long *)p->t_val64[cur].p, d);
+			MSX_HIP(ctx, hipMemcpyAsync(h, d, 40, hipMemcpyDeviceToHost, ctx->stream));
+			MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			fprintf(stderr, "# derived store: entries with 0 / 1 / 2 / 3 other features: %llu / %llu / %llu / %llu, of general lists: %llu\n",
+			        h[0], h[1], h[2], h[3], h[4]);
+		}
 	}
 	p->transposed_valid = true;
 	MSX_HIP(ctx, hipGetLastError());
@@ -1423,13 +1452,17 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 		                             recip_args(p), (const int32_t *)p->iter_state));
 		p->recip_valid = true;
 	}
-	MSX_TIMED(ctx, MSX_K_SHARE_REDUCE,
-	          hipLaunchKernelGGL(k_share_reduce, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                             (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,
-	                             (const unsigned long long *)p->t_val64[p->sorted_buf].p,
-	                             (const double *)p->a, p->key_bits, W, p->share, (double *)p->part_val.p,
-	                             (const int32_t *)p->iter_state, (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u),
-	                             p->recip_at));
+	static const int ng = [] { const char *e = getenv("MSX_SR_GATHERS"); const int v = e ? atoi(e) : 3; return (v >= 1 && v <= 3) ? v : 3; }();
+#define SR_LAUNCH(NG_)                                                                                                          \
+	hipLaunchKernelGGL(k_share_reduce<NG_>, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,                      \
+	                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,                        \
+	                   (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->a, p->key_bits, W, p->share,  \
+	                   (double *)p->part_val.p, (const int32_t *)p->iter_state,                                                  \
+	                   (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u), p->recip_at)
+	msx_time_begin(ctx, MSX_K_SHARE_REDUCE);
+	if (ng == 3) SR_LAUNCH(3); else if (ng == 2) SR_LAUNCH(2); else SR_LAUNCH(1);
+	msx_time_end(ctx);
+#undef SR_LAUNCH
 	if (complete) {
 		const int64_t M = 2 * W;
 		MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,

@@ -629,6 +629,26 @@ extern "C" int msx_unpack_seed(msx_ctx *ctx, msx_unpack *u, const uint8_t *carry
 	return MSX_OK;
 }
 
+// What msx_unpack_finish left for the next batch -- the bytes of the open pool and the cut record, the QNAME of the last
+// naming record -- brought to the host, for msx_unpack_seed of ANOTHER unpacker (another context, another GPU): one input
+// dealt batch by batch to several devices keeps inflate and walk on the devices, only this hand-over is serial.
+// host == NULL or cap too small: *n tells the size, nothing is copied.
+extern "C" int msx_unpack_carry(msx_ctx *ctx, msx_unpack *u, uint8_t *host, size_t cap, size_t *n, char name[256], int *has_name) {
+	if (!ctx || !u || !n) return MSX_ERR_ARG;
+	if (u->enqueued) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_carry between msx_unpack_enqueue and msx_unpack_finish");
+	msx_join(ctx);
+	*n = u->carry_len;
+	if (has_name) *has_name = 0;
+	if (!host || cap < u->carry_len) return MSX_OK;
+	if (u->carry_len) MSX_HIP(ctx, hipMemcpyAsync(host, u->raw[u->cur].p, u->carry_len, hipMemcpyDeviceToHost, ctx->stream));
+	up_state z;
+	MSX_HIP(ctx, hipMemcpyAsync(&z, u->d_state, sizeof z, hipMemcpyDeviceToHost, ctx->stream));
+	if (name) MSX_HIP(ctx, hipMemcpyAsync(name, u->prev_name, 256, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (has_name) *has_name = z.has_prev != 0;
+	return MSX_OK;
+}
+
 #define UP_RES(field, bytes) if ((rc = msx_reserve(ctx, &u->field, (bytes)))) return rc
 
 // The bytes of the NEXT msx_unpack_enqueue, sent ahead on a stream of their own: called after msx_unpack_finish of the

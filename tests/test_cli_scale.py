@@ -284,17 +284,28 @@ def test_tee_options_and_refusals(mid, tmp_path):
 # ---- one process, several contexts (MSX_DEVICES): here two contexts on the one GPU -----------------------------------
 
 def test_two_contexts_filter_profile_and_tee(big, tmp_path):
-    """The decode stage deals the batches to two device threads (each its own context, stage and profile), the writer
-    puts filter's output back in input order, the profiles are merged on the first context before the sharing
-    iterations (msx_profile_merge): same files as with one context."""
+    """The decode stage deals the batches to two device threads (each its own context, stage, unpacker and profile), the
+    writer puts filter's output back in input order, the profiles are merged on the first context before the sharing
+    iterations (msx_profile_merge): same files as with one context.  Every context inflates and walks its own batches
+    on the device; the stream's carry (open pool, cut record, last naming QNAME) travels from the context that finished
+    batch k to the one that walks batch k + 1 (msx_unpack_carry -> msx_unpack_seed)."""
     f, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
     r = sh(f"{BIN} {' '.join(FILT)} -bu {big.bam['b']} > {f}", MSX_DEVICES="0,0", MSX_TIMING=1)
-    assert b"2 devices" in r.stderr
+    assert b"2 devices" in r.stderr and b"BGZF blocks inflated on the device" in r.stderr
     big.check_digest(f, big.digest_out)
     r = sh(f"{BIN} profile --label S -o {p} {big.bam['u']}", MSX_DEVICES="0,0", MSX_TIMING=1)
-    assert b"2 devices" in r.stderr
+    assert b"2 devices" in r.stderr and b"BGZF blocks inflated on the device" in r.stderr
     big.check_profile(p, big.plain)
-    sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {f}", MSX_DEVICES="0,0,0")
+    r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {f}", MSX_DEVICES="0,0,0", MSX_TIMING=1)
+    assert b"3 devices" in r.stderr and b"BGZF blocks inflated on the device" in r.stderr
+    big.check_digest(f, big.digest_out)
+    big.check_profile(p, big.pipe)
+    # compressed output (the device DEFLATE encoder on every context), and round 3's form: inflate and walk on the host
+    sh(f"{BIN} {' '.join(FILT)} -b --profile-out {p} --label S {big.bam['b']} > {f}", MSX_DEVICES="0,0")
+    big.check_digest(f, big.digest_out)
+    big.check_profile(p, big.pipe)
+    r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {f}", MSX_DEVICES="0,0", MSX_MULTI_HOST_WALK=1, MSX_TIMING=1)
+    assert b"BGZF blocks inflated on the device" not in r.stderr
     big.check_digest(f, big.digest_out)
     big.check_profile(p, big.pipe)
 
