@@ -247,6 +247,7 @@ struct cv2_state {
 	uint32_t list_n[CV2_LISTS];         // items in every overflow list
 	uint32_t overflow;                  // a list or a stage was too small: the caller takes the streamed path
 	uint32_t n_heavy;
+	uint32_t n_hchunks;                 // chunks of the sorted items that touch a pre-reduced tile
 };
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit2(int64_t n, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
@@ -358,21 +359,45 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list(const uint32_t *__
 	slot_of[t] = slot;
 }
 
+// the chunks of the sorted array that hold marks of a pre-reduced tile.  Such a tile has more marks of one sign than a
+// chunk holds, so inside a chunk it can only be the tile of the chunk's first or of its last item: one look at each.
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_chunks(const uint32_t *__restrict__ items, const uint32_t *__restrict__ start, int64_t n_tiles,
+                                                                int sign_shift, const int32_t *__restrict__ slot_of, cv2_state *__restrict__ st,
+                                                                uint32_t *__restrict__ chunk_list) {
+	const int64_t n = (int64_t)start[2 * n_tiles + 1];
+	const int64_t c = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	const int64_t lo = c * CV_CHUNK;
+	bool hit = false;
+	if (st->n_heavy != 0 && lo < n) {
+		const int64_t hi = lo + CV_CHUNK < n ? lo + CV_CHUNK : n;
+		const uint32_t smask = (1u << sign_shift) - 1u;
+		hit = slot_of[(items[lo] & smask) >> CV_TILE_SHIFT] >= 0 || slot_of[(items[hi - 1] & smask) >> CV_TILE_SHIFT] >= 0;
+	}
+	const unsigned long long m = __ballot(hit);
+	if (m) {                                                 // one append per wave
+		const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
+		uint32_t base = 0;
+		if (lane == lead) base = atomicAdd(&st->n_hchunks, (uint32_t)__popcll(m));
+		base = (uint32_t)__shfl((int)base, lead, 64);
+		if (hit) chunk_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)c;
+	}
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_zero(int32_t *__restrict__ side, const cv2_state *__restrict__ st) {
 	if (blockIdx.x >= st->n_heavy || blockIdx.x >= CV2_HEAVY_CAP) return;
 	int4 *p = reinterpret_cast<int4 *>(side + (size_t)blockIdx.x * CV_TILE);
 	for (uint32_t q = threadIdx.x; q < CV_TILE / 4; q += MSX_BLOCK) p[q] = make_int4(0, 0, 0, 0);
 }
 
-// every chunk of the sorted items: the part that belongs to pre-reduced tiles is added to their side images
+// the listed chunks of the sorted items: the part that belongs to pre-reduced tiles is added to their side images
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add(const uint32_t *__restrict__ items, const uint32_t *__restrict__ start, int64_t n_tiles,
                                                              int sign_shift, const int32_t *__restrict__ slot_of, int32_t *__restrict__ side,
-                                                             const cv2_state *__restrict__ st) {
+                                                             const cv2_state *__restrict__ st, const uint32_t *__restrict__ chunk_list) {
 	__shared__ int32_t s_d[CV_TILE];
-	if (st->n_heavy == 0) return;
 	const int64_t n = (int64_t)start[2 * n_tiles + 1];       // where the -1 marks end: the empty slots sort behind
-	const int64_t lo_c = (int64_t)blockIdx.x * CV_CHUNK;
-	if (lo_c >= n) return;
+	for (uint32_t ci = blockIdx.x; ci < st->n_hchunks; ci += gridDim.x) {
+	const int64_t lo_c = (int64_t)chunk_list[ci] * CV_CHUNK;
+	if (lo_c >= n) continue;
 	const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
 	const uint32_t smask = (1u << sign_shift) - 1u;
 	// the (sign, tile) pairs this chunk touches: walk them by their starts
@@ -395,6 +420,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add(const uint32_t *__r
 			__syncthreads();
 		}
 		a = b > a ? b : a + 1;
+	}
 	}
 }
 
@@ -472,7 +498,10 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		const int64_t n_items = own + (int64_t)CV2_LISTS * list_cap;
 		for (int q = 0; q < 2; q++)
 			if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(n_items + 64) * 4))) return rc;
-		if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * (n_tiles + 1) + n_tiles + 64) * 4 + sizeof(cv2_state) + 64))) return rc;
+		const int64_t n_chunks = (n_items + CV_CHUNK - 1) / CV_CHUNK;
+		if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * (n_tiles + 1) + n_tiles + 64) * 4 + sizeof(cv2_state) + 64 +
+		                                                (size_t)(n_chunks / 32 + 2 + n_chunks + 64) * 4)))
+			return rc;
 		if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
 		int64_t sort_tiles = 0;
 		if ((rc = msx_sort_keys32_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
@@ -480,6 +509,7 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		int32_t *slot_of = (int32_t *)(start + 2 * (n_tiles + 1));
 		cv2_state *st = (cv2_state *)(((uintptr_t)(slot_of + n_tiles) + 63) & ~(uintptr_t)63);
 		uint32_t *items = (uint32_t *)ctx->cv_key[0].p;
+		uint32_t *chunk_list = (uint32_t *)(st + 1);
 		MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
 		msx_time_begin(ctx, MSX_K_COVERAGE);
 		if (own > 2 * n)             // (the last workgroup's tile is not full: its tail holds empty slots)
@@ -500,9 +530,12 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		                   sorted, n_items, n_tiles, sign_shift, start);
 		hipLaunchKernelGGL(k_cov_heavy_list, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)start, n_tiles, slot_of, st, heavy_from);
+		hipLaunchKernelGGL(k_cov_heavy_chunks, dim3((unsigned)((n_chunks + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, sorted,
+		                   (const uint32_t *)start, n_tiles, sign_shift, (const int32_t *)slot_of, st, chunk_list);
 		hipLaunchKernelGGL(k_cov_heavy_zero, dim3(CV2_HEAVY_CAP), dim3(MSX_BLOCK), 0, ctx->stream, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
-		hipLaunchKernelGGL(k_cov_heavy_add, dim3((unsigned)((n_items + CV_CHUNK - 1) / CV_CHUNK)), dim3(MSX_BLOCK), 0, ctx->stream, sorted,
-		                   (const uint32_t *)start, n_tiles, sign_shift, (const int32_t *)slot_of, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
+		hipLaunchKernelGGL(k_cov_heavy_add, dim3((unsigned)(n_chunks < 1024 ? n_chunks : 1024)), dim3(MSX_BLOCK), 0, ctx->stream, sorted,
+		                   (const uint32_t *)start, n_tiles, sign_shift, (const int32_t *)slot_of, (int32_t *)ctx->cv_side.p, (const cv2_state *)st,
+		                   (const uint32_t *)chunk_list);
 		hipLaunchKernelGGL(k_cov_depths, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, sorted, (const uint32_t *)start, n_tiles,
 		                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov);
 		msx_time_end(ctx);

@@ -141,10 +141,6 @@ __device__ __forceinline__ uint32_t df_wave_max(uint32_t x) {
 	for (int s = 32; s >= 1; s >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)x, s); x = o > x ? o : x; }
 	return x;
 }
-__device__ __forceinline__ uint64_t df_range(uint32_t a, uint32_t b) {   // bits [a, b), b <= 64
-	const uint64_t hi = b >= 64u ? ~0ull : ((1ull << b) - 1ull);
-	return a >= 64u ? 0ull : hi & ~((1ull << a) - 1ull);
-}
 // the dword at byte position pos of the ring (any alignment); the ring's first 8 dwords are repeated behind its end, so
 // that up to 5 consecutive dwords can be read from any index without wrapping
 __device__ __forceinline__ uint32_t df_ring32(const uint32_t *ring, uint32_t pos) {
@@ -440,21 +436,26 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 			const uint32_t h4i = (W2 * DF_MUL4) >> (32 - DF_HBITS);
 			const uint32_t h8i = (uint32_t)((((uint64_t)W3 << 32 | W2) * DF_MUL8) >> (64 - DF_HBITS));
 			const uint32_t c4 = has4 ? S.lz.h4[h4i] : 0u, c8 = has8 ? S.lz.h8[h8i] : 0u;
-			if (has4) atomicMax(&S.lz.h4[h4i], p + 1u);
-			if (has8) atomicMax(&S.lz.h8[h8i], p + 1u);
+			// the nearest of the distances 1..8 whose 4 bytes repeat (runs, short periods: what the tables of earlier steps
+			// cannot show a position).  Such a position stays out of the tables: inside a run every position would enter
+			// with the same keys, and the tables would remember the nearest repeat instead of the run's start in an
+			// earlier record, from where the long match goes on behind the run's end.
+			uint32_t nd = 0;
+			if (has4) {
+				const uint64_t A = (uint64_t)W2 << 32 | W1, B = (uint64_t)W1 << 32 | W0;
+#pragma unroll
+				for (uint32_t d = 8; d >= 5u; d--) if ((uint32_t)(B >> (8u * (8u - d))) == W2 && d <= p) nd = d;
+#pragma unroll
+				for (uint32_t d = 4; d >= 1u; d--) if ((uint32_t)(A >> (8u * (4u - d))) == W2 && d <= p) nd = d;
+			}
+			if (has4 && !nd) atomicMax(&S.lz.h4[h4i], p + 1u);
+			if (has8 && !nd) atomicMax(&S.lz.h8[h8i], p + 1u);
 			uint32_t bl = 0, bd = 0;
 			const bool need = active && p >= next_free;
 			DF_T(1);
 			if (__ballot(need)) {
 				const uint32_t maxl = (n - p) < DF_MAXMATCH ? (n - p) : DF_MAXMATCH;
-				uint32_t nd = 0;
-				if (need && has4) {                                // the nearest of the distances 1..8 whose 4 bytes repeat
-					const uint64_t A = (uint64_t)W2 << 32 | W1, B = (uint64_t)W1 << 32 | W0;
-#pragma unroll
-					for (uint32_t d = 8; d >= 5u; d--) if ((uint32_t)(B >> (8u * (8u - d))) == W2 && d <= p) nd = d;
-#pragma unroll
-					for (uint32_t d = 4; d >= 1u; d--) if ((uint32_t)(A >> (8u * (4u - d))) == W2 && d <= p) nd = d;
-				}
+				if (!need) nd = 0;
 				const uint32_t a4 = c4 - 1u, a8 = c8 - 1u;
 				const bool v4 = need && c4 != 0u && p - a4 <= DF_WINDOW;
 				const bool v8 = need && c8 != 0u && p - a8 <= DF_WINDOW && !(v4 && c8 == c4);
@@ -471,34 +472,31 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 				uint32_t cur = q0, l = 0;
 				bool quick = false, act = need && cur != NONE;
 				while (__ballot(act)) {
-					if (act) {
+					if (act) {                                   // (one masked region; inside it selects, no branches)
 						const uint32_t off = quick ? bl - 15u : l;
 						uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
 						df_ring128(S.lz.ring, cur + off, a0, a1, a2, a3);
 						df_ring128(S.lz.ring, p + off, b0, b1, b2, b3);
 						const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
 						const bool diff = (x0 | x1 | x2 | x3) != 0u;
-						bool fin = false;
-						uint32_t len = 0;
-						if (quick) {
-							if (diff) fin = true;                              // cannot be longer than the best so far
-							else { quick = false; l = 0; }                     // may be: measure it
-						} else if (diff) {
-							len = l + (x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
-							           : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : 12u + ((uint32_t)__builtin_ctz(x3) >> 3));
-							fin = true;
-						} else {
-							l += 16u;
-							if (l >= maxl) { len = maxl; fin = true; }
-						}
-						if (fin) {
-							if (len > maxl) len = maxl;
-							if (len >= 4u && len > bl) { bl = len; bd = p - cur; }
-							cur = q1; q1 = q2; q2 = NONE;
-							l = 0;
-							quick = bl >= 16u;
-							act = cur != NONE && bl < maxl;
-						}
+						// where the first differing byte sits (diff) -- __builtin_ctz of 0 is not asked for: | 1u << 31 keeps it defined
+						const uint32_t f0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, f1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3),
+						               f2 = 8u + ((uint32_t)__builtin_ctz(x2 | 0x80000000u) >> 3), f3 = 12u + ((uint32_t)__builtin_ctz(x3 | 0x80000000u) >> 3);
+						const uint32_t fd = x0 ? f0 : x1 ? f1 : x2 ? f2 : f3;
+						const uint32_t l16 = l + 16u;
+						const bool end = !diff && l16 >= maxl;            // (measuring) ran into the longest a match may be
+						const bool fin = quick ? diff : (diff || end);    // quick: a difference drops the candidate; none: measure it from 0
+						uint32_t len = quick ? 0u : (diff ? l + fd : maxl);
+						len = len > maxl ? maxl : len;
+						const bool take = fin && len >= 4u && len > bl;
+						bd = take ? p - cur : bd;
+						bl = take ? len : bl;
+						l = (quick || fin) ? 0u : l16;
+						cur = fin ? q1 : cur;
+						q1 = fin ? q2 : q1;
+						q2 = fin ? NONE : q2;
+						quick = fin && bl >= 16u;
+						act = fin ? (cur != NONE && bl < maxl) : true;
 					}
 				}
 				if (!need) bl = 0;
@@ -511,11 +509,12 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 			const uint64_t Mmask = __ballot(M);
 			uint32_t cur = next_free > p0 ? next_free - p0 : 0u;
 			uint64_t tokmask = 0;
+			const uint64_t upto_cnt = (2ull << (cnt - 1u)) - 1ull;          // bits [0, cnt)
 			while (cur < cnt) {
-				const uint64_t mm = Mmask >> cur;
-				if (!mm) { tokmask |= df_range(cur, cnt); cur = cnt; break; }
-				const uint32_t j = cur + (uint32_t)__builtin_ctzll(mm);
-				tokmask |= df_range(cur, j + 1u);
+				const uint64_t from_cur = ~0ull << cur, mm = Mmask & from_cur;
+				if (!mm) { tokmask |= upto_cnt & from_cur; cur = cnt; break; }       // literals to the step's end
+				const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+				tokmask |= ((2ull << j) - 1ull) & from_cur;                          // literals [cur, j), the match at j
 				cur = j + (uint32_t)__builtin_amdgcn_readlane((int)bl, (int)j);
 			}
 			next_free = p0 + cur;

@@ -196,6 +196,14 @@ static inline uint32_t df_tokens(const uint8_t *in, uint32_t n, const df_opts *O
 		}
 		for (i = 0; i < cnt; i++) {                  /* insert: the highest position of the step wins a slot */
 			const uint32_t p = p0 + i;
+			uint32_t d, near = 0;
+			/* a position that repeats at a near distance stays out of the tables: inside runs and short periods every
+			 * position would enter with the same keys, and what the tables then remember is the nearest repeat -- not the
+			 * start of the run in an earlier record, from where the long match goes on behind the run's end */
+			if (O->use_rep && p + 4 <= n)
+				for (d = 1; d <= 8u && d <= p; d++)
+					if (df_ld32(in + p - d) == df_ld32(in + p)) { near = 1; break; }
+			if (near) continue;
 			if (p + 4 <= n) h4[(df_ld32(in + p) * DF_MUL4) >> (32 - O->hash_bits)] = p + 1;
 			if (O->use_h8 && p + 8 <= n) h8[(uint32_t)((df_ld64(in + p) * DF_MUL8) >> (64 - O->hash_bits))] = p + 1;
 		}
