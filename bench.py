@@ -917,7 +917,9 @@ def main():
             "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_granted": granted_cpus(),
             "sample": f"first {sg} QNAME groups ({hs.n_records} alignments) of the same synthetic stream, "
                       f"{nrefs} references, copied back from the device batch, resident in RAM; best of 2 runs of oracle filter+profile "
-                      f"({best:.2f} s each)",
+                      f"({best:.2f} s each).  COMPUTE ONLY: pre-parsed SoA arrays in, no BGZF inflate, no record walk, no output written "
+                      f"-- comparable with `value` (kernel-only), not with the command line; the end-to-end CPU figure with its "
+                      f"decode / compute / encode split is e2e.cpu_baseline_e2e",
         }
 
         # the same oracle with every host core: filter (the per-record walk + best hit, the bulk of the
@@ -947,8 +949,9 @@ def main():
                     bestn = dt if bestn is None else min(bestn, dt)
             out["cpu_baseline_all_cores"] = {
                 "value": round(hs.n_records / bestn / 1e6, 2), "unit": "M alignments/s", "cores": len(shards),
-                "kind": "port", "sample": f"same sample; filter on {len(shards)} pool-aligned shards in parallel "
-                                          f"threads, then one profile pass ({bestn:.2f} s)"}
+                "kind": "port", "sample": f"same sample, compute only; ONLY filter runs on {len(shards)} pool-aligned shards in parallel "
+                                          f"threads -- the profile (insert counting + the proportional iterations) is one serial pass "
+                                          f"behind them ({bestn:.2f} s in all)"}
         except Exception as exc:      # never let the extra figure break the bench line
             out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
 

@@ -291,7 +291,7 @@ __device__ __forceinline__ uint32_t if_long(IfShared &S, uint32_t which, uint32_
 	return 0u;
 }
 
-template <int DBG>
+template <int DBG, bool VEC>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, size_t comp_len,
                                                      const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
@@ -448,6 +448,91 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			// the input ring is due (a symbol takes two words at most).  Anything else -- a long literal/length code, the
 			// end of the block, the output's end, a chunk boundary -- leaves it in front of the symbol for the general step
 			// below; only errors leave it inside a symbol.
+			if (VEC && T.cross > T.ip + 2u) {
+				// ---- the same loop on the VECTOR unit (round 4).  The bit buffer, its count and the read position are wave-
+				// uniform values, so the compiler keeps them in scalar registers and the scalar unit does the arithmetic: 55
+				// scalar instructions per symbol, and a compute unit has ONE scalar unit for all its waves -- it saturates at
+				// 12 of the 14 waves the LDS holds (profiles/round3/inflate_summary.json).  Here the same values live in vector
+				// registers (laundered through v_mov so that no analysis moves them back): shifts, masks and the refill are
+				// VALU instructions -- four SIMDs per compute unit issue them side by side -- the refill is a select instead of a
+				// branch, and only what a branch or a copy loop needs crosses to the scalar side (one v_readfirstlane of the
+				// table entry per symbol, two more for a match's length and distance).  The loop runs for as many symbols as
+				// cannot reach the input ring's next refill (a symbol takes two words at most), so the read position needs no
+				// test; a symbol the primary tables do not hold, or an error, puts the state back in front of the symbol and
+				// leaves it to the scalar loops below.
+#define IF_TO_V(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
+#define IF_VREFILL() do { const bool take_ = vcnt <= 32; vb |= take_ ? (uint64_t)w << vcnt : 0ull; vcnt += take_ ? 32 : 0;     \
+				                  vip += take_ ? 1u : 0u; w = S.in[vip & (IF_IN_DW - 1u)]; } while (0)
+				uint32_t vlo, vhi, vip, vc_;
+				IF_TO_V(vlo, (uint32_t)T.buf); IF_TO_V(vhi, (uint32_t)(T.buf >> 32)); IF_TO_V(vc_, (uint32_t)T.cnt); IF_TO_V(vip, T.ip);
+				uint64_t vb = (uint64_t)vhi << 32 | vlo;
+				int32_t vcnt = (int32_t)vc_;
+				const uint32_t lim = T.flushed + IF_FLUSH < out_len ? T.flushed + IF_FLUSH : out_len;
+				for (uint32_t budget = (T.cross - T.ip - 2u) / 2u; budget != 0u && T.pos < lim; budget--) {
+					const uint32_t e = ev, es = IFU(e);
+					if (es & (IF_LIT << 4)) {
+						const uint32_t n = e & 15u;
+						vb >>= n; vcnt -= (int32_t)n;
+						IF_VREFILL();
+						ev = S.ll[(uint32_t)vb & ((1u << IF_LL_ROOT) - 1u)];
+						S.ring[IF_RI(T.pos)] = (uint8_t)(es >> 16);          // (every lane the same byte to the same place)
+						T.pos++;
+						if (DBG == 4) n_lit++;
+						continue;
+					}
+					if (((es >> 4) & 15u) != IF_BASE) break;
+					const uint64_t vb0 = vb;
+					const int32_t vcnt0 = vcnt;
+					const uint32_t vip0 = vip, w0 = w;
+					uint32_t n = e & 15u;
+					vb >>= n; vcnt -= (int32_t)n;
+					const uint32_t xl = (e >> 8) & 15u;
+					const uint32_t vlen = (e >> 16) + ((uint32_t)vb & ((1u << xl) - 1u));
+					vb >>= xl; vcnt -= (int32_t)xl;
+					IF_VREFILL();
+					const uint32_t d = S.dt[(uint32_t)vb & ((1u << IF_D_ROOT) - 1u)];
+					if (((IFU(d) >> 4) & 15u) != IF_BASE) { vb = vb0; vcnt = vcnt0; vip = vip0; w = w0; break; }
+					n = d & 15u;
+					vb >>= n; vcnt -= (int32_t)n;
+					const uint32_t xd = (d >> 8) & 15u;
+					const uint32_t vdist = (d >> 16) + ((uint32_t)vb & ((1u << xd) - 1u));
+					vb >>= xd; vcnt -= (int32_t)xd;
+					const uint32_t len = IFU(vlen), dist = IFU(vdist);
+					if (dist > T.pos || len > out_len - T.pos) { vb = vb0; vcnt = vcnt0; vip = vip0; w = w0; break; }
+					IF_VREFILL();
+					ev = S.ll[(uint32_t)vb & ((1u << IF_LL_ROOT) - 1u)];
+					const uint32_t from = T.pos - dist;
+					if (dist <= IF_NEAR) {
+						if (dist >= 64u || dist >= len) {
+							for (uint32_t b = 0; b < len; b += 64u) {
+								const uint32_t i = b + lane;
+								if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + i)];
+							}
+						} else {
+							const float rf = 1.0f / (float)dist;
+							for (uint32_t b = 0; b < len; b += 64u) {
+								const uint32_t i = b + lane;
+								const uint32_t q = (uint32_t)(((float)i + 0.5f) * rf);
+								if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + (i - q * dist))];
+							}
+						}
+					} else {
+						if (DBG == 4) n_far++;
+						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+						for (uint32_t b = 0; b < len; b += 64u) {
+							const uint32_t i = b + lane;
+							if (i < len) S.ring[IF_RI(T.pos + i)] = IF_FAR_LOAD(og + from + i);
+						}
+					}
+					T.pos += len;
+					if (DBG == 4) n_match++;
+				}
+				T.buf = (uint64_t)IFU((uint32_t)(vb >> 32)) << 32 | (uint64_t)IFU((uint32_t)vb);
+				T.cnt = (int32_t)IFU((uint32_t)vcnt);
+				T.ip = IFU(vip);
+#undef IF_VREFILL
+#undef IF_TO_V
+			}
 			{
 				uint32_t err = 0u;
 				for (;;) {
@@ -654,9 +739,14 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 	int64_t grid = (int64_t)per_cu * ctx->num_cu;
 	if (grid > n_blocks) grid = n_blocks;
 	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 4, stream));      // the ticket
-#define IF_LAUNCH(D) hipLaunchKernelGGL(k_bgzf_inflate<D>, dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
+	// MSX_INFLATE_VEC=1: the decode loop's bit buffer on the vector unit (round 4's experiment: measured SLOWER, 45.1 against
+	// 50.1 GB/s on lean records, 101 against 108 with SEQ/QUAL -- DESIGN.md section 3; kept as an A/B switch, off by default)
+	static int vec = -1;
+	if (vec < 0) vec = getenv("MSX_INFLATE_VEC") ? atoi(getenv("MSX_INFLATE_VEC")) != 0 : 0;
+#define IF_LAUNCH(D, V) hipLaunchKernelGGL((k_bgzf_inflate<D, V>), dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
 	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 1, if_stats)
-	if (if_stats) IF_LAUNCH(4); else IF_LAUNCH(0);          // (4: the same kernel counting its symbols, MSX_INFLATE_STATS)
+	if (if_stats) { if (vec) IF_LAUNCH(4, true); else IF_LAUNCH(4, false); }      // (4: the same kernel counting its symbols, MSX_INFLATE_STATS)
+	else { if (vec) IF_LAUNCH(0, true); else IF_LAUNCH(0, false); }
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
 	// MSX_INFLATE_REFUSE=<n> (tests): every n-th block is reported as refused, whatever the decoder made of it
