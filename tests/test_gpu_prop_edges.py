@@ -156,7 +156,7 @@ def test_merged_store_stays_close_to_the_distinct_sets(groups, refs):
     the smallest feature and 12 hash bits, so two different sets that collide on it interleave (A, B, A) and some
     merges are missed.  Results do not depend on it (every surviving list keeps its weight), the size of the derived
     store and with it the cost of an iteration does.  Measured on MI355X: 1.03-1.17 x the number of distinct sets
-    (scripts/dbg_merge.py); guarded here at 1.25 x, and the sum of the weights must be the number of lists."""
+    (scripts/archive/dbg_merge.py); guarded here at 1.25 x, and the sum of the weights must be the number of lists."""
     import msamtools_amd as m
     ctx = m.Context(0)
     db = m.DeviceBatch.synth(ctx, 13579, groups, refs, 4)
