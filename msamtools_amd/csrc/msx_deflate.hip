@@ -288,19 +288,23 @@ __device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uin
 		}
 		if (lane == 0) S.hf.cnt[0] = 0;
 		__syncthreads();
-		uint32_t overflow = df_wave_sum(over);
-		if (overflow) {                                    // zlib trees.c gen_bitlen: lengths above the limit
+		const uint32_t overflow = df_wave_sum(over);
+		if (overflow) {
+			// Leaves deeper than the limit go up to it: the code is then over-subscribed by `excess` units of 2^-maxbits
+			// (Kraft sum).  zlib's step (trees.c gen_bitlen: a leaf of the deepest level below the limit that has one goes
+			// down a level and takes a leaf of the limit's level along as its sibling) takes exactly one unit away -- the
+			// number of steps comes from the Kraft sum, not from the number of leaves moved (msx_deflate_model.h).
 			if (lane == 0) {
-				uint32_t c = S.hf.cnt[maxbits] + overflow;
-				int ov = (int)overflow;
-				S.hf.cnt[maxbits] = c;
-				while (ov > 0) {
+				S.hf.cnt[maxbits] += overflow;
+				long excess = -(1L << maxbits);
+				for (uint32_t b = 1; b <= maxbits; b++) excess += (long)S.hf.cnt[b] << (maxbits - b);
+				while (excess > 0) {
 					uint32_t bits = maxbits - 1u;
 					while (S.hf.cnt[bits] == 0u) bits--;
 					S.hf.cnt[bits]--;
 					S.hf.cnt[bits + 1u] += 2u;
 					S.hf.cnt[maxbits]--;
-					ov -= 2;
+					excess--;
 				}
 			}
 			__syncthreads();

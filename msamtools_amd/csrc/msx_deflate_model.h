@@ -99,20 +99,29 @@ static inline void df_huff_lengths(const uint32_t *freq_in, int n, int maxbits, 
 	}
 	/* A[r] = depth of the r-th rarest symbol (non-increasing in r) */
 	{
-		int cnt[40], overflow = 0, bits;
+		int cnt[40], bits;
+		long excess;
 		memset(cnt, 0, sizeof cnt);
 		for (i = 0; i < m; i++) {
 			int d = (int)A[i];
-			if (d > maxbits) { d = maxbits; overflow++; }
+			if (d > maxbits) d = maxbits;
 			cnt[d]++;
 		}
-		while (overflow > 0) {               /* zlib trees.c gen_bitlen: move a leaf down from the deepest level that has one */
+		/* Leaves deeper than the limit were moved up to it: the code is over-subscribed by `excess` units of
+		 * 2^-maxbits (Kraft sum).  zlib's step (trees.c gen_bitlen) -- a leaf of the deepest level below the limit that has
+		 * one goes down a level and takes a leaf of the limit's level along as its sibling -- takes exactly one unit away.
+		 * (zlib counts the steps from the nodes it clamps on its way down the tree; counted from the leaves' true depths
+		 * the number must come from the Kraft sum: leaves two and more levels too deep weigh more than half a unit each --
+		 * the first version counted them as a half and wrote over-subscribed 7-bit code-length codes.) */
+		excess = -(1L << maxbits);
+		for (bits = 1; bits <= maxbits; bits++) excess += (long)cnt[bits] << (maxbits - bits);
+		while (excess > 0) {
 			bits = maxbits - 1;
 			while (cnt[bits] == 0) bits--;
 			cnt[bits]--;
 			cnt[bits + 1] += 2;
 			cnt[maxbits]--;
-			overflow -= 2;
+			excess--;
 		}
 		i = 0;
 		for (bits = maxbits; bits >= 1; bits--)

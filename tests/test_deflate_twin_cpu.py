@@ -55,3 +55,19 @@ def test_twin_blocks_decode_and_stay_near_zlib(tmp_path):
             assert len(stream) <= 1.15 * z, (len(stream), z)
         if name == "random":
             assert int(out[3]) >= 1                     # the full block is stored (the 17-byte tail is shorter with fixed codes)
+
+
+def test_length_limited_codes_are_complete(tmp_path):
+    """the tree builder's repair of codes deeper than their limit (15 bits; 7 for the code-length code): complete prefix
+    codes under Fibonacci, power-of-two and one-giant frequency vectors (tests/c/huff_lengths_test.c), and the block of
+    filter's output on which the first version wrote an over-subscribed code-length code (bench.py's digest check found
+    it; committed as data: tests/golden/deflate_block_clcode_overflow.bin)"""
+    exe = str(tmp_path / "huff_lengths_test")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "c", "huff_lengths_test.c")])
+    assert subprocess.check_output([exe]).decode().strip() == "ok"
+    twin = str(tmp_path / "deflate_twin")
+    subprocess.check_call(["gcc", "-O2", "-o", twin, os.path.join(ROOT, "tests", "c", "deflate_twin.c"), "-lz"])
+    blk = os.path.join(ROOT, "tests", "golden", "deflate_block_clcode_overflow.bin")
+    out = str(tmp_path / "o")
+    subprocess.check_call([twin, blk, out], stdout=subprocess.DEVNULL)            # (the twin inflates what it wrote with zlib)
+    assert gzip.decompress(open(out, "rb").read()) == open(blk, "rb").read()

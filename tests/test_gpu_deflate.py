@@ -4,6 +4,7 @@ its blocks is not pinned by the reference (its tests compare records: tests/func
 every block is a valid gzip member with a BC field, that zlib and this repository's own inflater decode the blocks to
 the input, byte for byte, and that CRC-32 / ISIZE / BSIZE are right."""
 import gzip
+import os
 import zlib
 
 import numpy as np
@@ -147,6 +148,15 @@ def test_emit_as_finished_blocks(ctx, level):
     up.close()
 
 
+def fibonacci_bytes(rng):
+    fib = [1, 1]
+    while sum(fib) + fib[-1] + fib[-2] < PAYLOAD:
+        fib.append(fib[-1] + fib[-2])
+    data = np.concatenate([np.full(f, i, np.uint8) for i, f in enumerate(fib)])
+    rng.shuffle(data)
+    return data.tobytes() * 2
+
+
 def test_the_kernel_writes_the_twins_bytes(ctx, tmp_path):
     """the device encoder against its one-position-at-a-time restatement on the host: the same blocks, bit for bit --
     matches, lazy decisions, trees, headers (what the lanes do side by side is what the model does in order)"""
@@ -164,6 +174,11 @@ def test_the_kernel_writes_the_twins_bytes(ctx, tmp_path):
         "one byte": b"Q",
         "text": (b"the quick brown fox jumps over the lazy dog; " * 3000)[:PAYLOAD * 2 - 1],
         "skewed (long codes)": bytes(np.minimum(rng.geometric(0.35, 3 * PAYLOAD), 255).astype(np.uint8)),
+        # codes deeper than their limit: Fibonacci literal frequencies (literal/length code past 15 bits), and the block of
+        # filter's output whose code-length code goes past 7 (the repair counts Kraft units: msx_deflate_model.h)
+        "fibonacci literals": fibonacci_bytes(rng),
+        "code-length code past its limit": open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                             "deflate_block_clcode_overflow.bin"), "rb").read(),
     }
     for name, data in cases.items():
         got, n_blk = M().bgzf_deflate(ctx, data, 6)
