@@ -474,7 +474,7 @@ int  msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p);
  * msx_profile_finalize_enqueue's device work with `share` all-reduced inside every iteration and the
  * purged count summed at the end.  Identical results on every rank (fetch them with msx_profile_fetch).  Without a
  * communicator it IS msx_profile_finalize_enqueue.  With one, the loop looks at the convergence flag (msam_profile.c:383)
- * every MSX_DIST_POLL iterations (default 4) -- a 4-byte copy and a wait for the stream -- and stops enqueueing
+ * every MSX_DIST_POLL iterations (default 8) -- a 4-byte copy and a wait for the stream -- and stops enqueueing
  * collectives once it is set; MSX_DIST_POLL=0: all 19 iterations are enqueued and nothing waits for the host. */
 int  msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p);
 

@@ -1630,12 +1630,15 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 	if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL) {
 		// After convergence the local kernels are no-ops and leave `share` at zero on every rank, but a collective that
 		// has been enqueued runs: 8 MB of zeros per remaining iteration.  So the loop looks at the convergence flag every
-		// `poll` iterations (MSX_DIST_POLL, default 4; 0: never -- enqueue all 19 and return without waiting): one small
+		// `poll` iterations (MSX_DIST_POLL, default 8; 0: never -- enqueue all 19 and return without waiting): one small
 		// copy and one wait for the stream, and every rank -- they hold the same all-reduced numbers, hence the same flag
-		// (:383) -- stops enqueueing at the same k.  The price is a drained stream every fourth iteration (~20 us), the
-		// gain every all-reduce behind the last look (c3 converges at k = 15: three of nineteen).
+		// (:383) -- stops enqueueing at the same k.  The price is a drained stream per look (~22 us: 4.22 against 4.13 ms
+		// for the one-rank c3 step at poll = 4), the gain every all-reduce behind the look that sees the flag.  The c3
+		// batch itself runs all 19 iterations (DELTA^2 has not reached 1e-10 by then), so there the looks are pure cost --
+		// hence two of them by default, not four; a sample that converges at k = 15 (the e2e file's 2 M-record prefix
+		// does) saves the all-reduces of k = 17..19.
 		const char *pe = getenv("MSX_DIST_POLL");
-		const int poll = (ctx->dist && pe) ? atoi(pe) : (ctx->dist ? 4 : 0);
+		const int poll = (ctx->dist && pe) ? atoi(pe) : (ctx->dist ? 8 : 0);
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
 			if ((rc = msx_prop_iteration(ctx, p, true))) return rc;     // share = this rank's part of the increment, complete
 			if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;

@@ -127,14 +127,14 @@ def test_bench_multi_gpu_step_on_one_rank():
 
 @pytest.mark.parametrize("groups,refs", [(300, 7), (2000, 50), (60_000, 500), (400_000, 20_000)])
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("poll", ["0", "4", "1"])
+@pytest.mark.parametrize("poll", ["0", "8", "1"])
 def test_one_rank_distributed_finalize_equals_plain_and_oracle(groups, refs, fused, poll, monkeypatch):
     """msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator -- counts all-reduced, the partial slots of
     k_share_reduce folded into share[] (k_partial_reduce, run by run, no atomics), share[] all-reduced inside each of
     the 19 iterations -- against msx_profile_finalize_enqueue on the same inserts (equal to 1e-12: the same additions
     in another order) and against the oracle (<= 1e-6, msam_profile.c:317-410).  Small inputs matter: most waves of
     k_share_reduce idle then and every feature's segment ends at a chunk's last entry somewhere.
-    poll: MSX_DIST_POLL -- never look at the convergence flag (all 19 iterations enqueued), every 4th iteration (the
+    poll: MSX_DIST_POLL -- never look at the convergence flag (all 19 iterations enqueued), every 8th iteration (the
     default), every iteration: the same numbers, the same iteration count either way."""
     import msamtools_amd as m
     monkeypatch.setenv("MSX_DIST_POLL", poll)
