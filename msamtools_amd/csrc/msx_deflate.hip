@@ -632,6 +632,17 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 			extra = df_wave_sum(extra);
 			bits_dyn = df_wave_sum(dyn) + extra + 3u + 5u + 5u + 4u + 3u * hclen;
 			bits_fix = df_wave_sum(fix) + extra + 3u;
+			// A belt beside the braces: the three codes must be complete prefix codes (Kraft sum exactly 1) -- an inflater
+			// refuses anything else.  Should the tree builder ever hand out lengths that are not, the block is written with
+			// the fixed codes or stored instead (both always valid), never with a header no reader accepts.
+			uint32_t kl = 0, kd = 0, kc = 0;
+			for (uint32_t k = 0; k < 5u; k++) {
+				const uint32_t i = lane + 64u * k;
+				if (i < 286u && S.hf.ll[i]) kl += 1u << (15u - S.hf.ll[i]);
+			}
+			if (lane < 30u && S.hf.ll[DF_LL + lane]) kd = 1u << (15u - S.hf.ll[DF_LL + lane]);
+			if (lane < 19u && S.hf.cl[lane]) kc = 1u << (7u - S.hf.cl[lane]);
+			if (df_wave_sum(kl) != (1u << 15) || df_wave_sum(kd) != (1u << 15) || df_wave_sum(kc) != (1u << 7)) bits_dyn = 0xffffffffu;
 		}
 		DF_T(7);
 		const uint32_t bits_stored = 8u * (5u + n);

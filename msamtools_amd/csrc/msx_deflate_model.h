@@ -303,6 +303,15 @@ static inline uint32_t df_block(const uint8_t *in, uint32_t n, uint8_t *out, con
 	bits_dyn += 2 * (uint64_t)clf[16] + 3 * (uint64_t)clf[17] + 7 * (uint64_t)clf[18];
 	for (i = 0; i < DF_NLL; i++) bits_dyn += (uint64_t)lf[i] * ll[i];
 	for (i = 0; i < DF_ND; i++) bits_dyn += (uint64_t)dq[i] * ll[DF_NLL + i];
+	{
+		/* the three codes must be complete (Kraft sum exactly 1); should they ever not be, the block is written with the
+		 * fixed codes or stored -- as the kernel does */
+		uint64_t kl = 0, kd = 0, kc = 0;
+		for (i = 0; i < DF_NLL; i++) if (ll[i]) kl += 1ull << (15 - ll[i]);
+		for (i = 0; i < DF_ND; i++) if (ll[DF_NLL + i]) kd += 1ull << (15 - ll[DF_NLL + i]);
+		for (i = 0; i < DF_NCL; i++) if (cl[i]) kc += 1ull << (7 - cl[i]);
+		if (kl != 1ull << 15 || kd != 1ull << 15 || kc != 1ull << 7) bits_dyn = 0xffffffffull;
+	}
 	bits_fix = 3 + extra;
 	for (i = 0; i < DF_NLL; i++) bits_fix += (uint64_t)lf[i] * (i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
 	for (i = 0; i < DF_ND; i++) bits_fix += (uint64_t)dq[i] * 5;
