@@ -266,6 +266,12 @@ int  msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_out, size_
  * *n_bytes: bytes of finished blocks; *n_blocks: how many (payloads all full but the last). */
 int  msx_unpack_emit_gather_bgzf(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level,
                                  int64_t *n_bytes, int64_t *n_blocks);
+/* The same in two steps (level >= 1), so that the encoder runs BESIDE the next batch instead of in front of it: _enqueue gathers
+ * the batch's records and hands them to the encoder on a stream of its own, then returns; _complete -- once per _enqueue, in
+ * the same order, any time later -- waits for that batch's blocks, tells their size and makes them what the next
+ * msx_unpack_emit_fetch brings down.  At most two batches between _enqueue and the end of their fetch. */
+int  msx_unpack_emit_bgzf_enqueue(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level);
+int  msx_unpack_emit_bgzf_complete(msx_ctx *ctx, msx_unpack *u, int64_t *n_bytes, int64_t *n_blocks);
 /* record offsets of the last batch, u32[n + 1] relative to its first byte (tests, SAM-text writers) */
 int  msx_unpack_offsets(msx_ctx *ctx, msx_unpack *u, uint32_t *host, int64_t n);
 

@@ -124,6 +124,8 @@ SYMBOLS = {
     "msx_unpack_emit_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "msx_unpack_emit_fetch": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "msx_unpack_emit_gather_bgzf": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    "msx_unpack_emit_bgzf_enqueue": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
+    "msx_unpack_emit_bgzf_complete": (C.c_int, [_P, _P, _P, _P]),
     "msx_bgzf_bound": (C.c_int64, [C.c_int64, C.c_int]),
     "msx_bgzf_deflate": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P, C.c_size_t, _P, _P]),
     "msx_unpack_prefetch_bgzf": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_int64]),

@@ -457,6 +457,18 @@ class Unpack:
         self.ctx.check(self.ctx.lib.msx_unpack_emit_fetch(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p), out.size, None))
         return out[:nb.value].tobytes(), nblk.value
 
+    def emit_bgzf_enqueue(self, emit_ptr, n_emit, level=6):
+        """hand the batch's output records to the encoder on its own stream (msx_unpack_emit_bgzf_enqueue)"""
+        self.ctx.check(self.ctx.lib.msx_unpack_emit_bgzf_enqueue(self.ctx.h, self.h, C.c_void_p(emit_ptr), int(n_emit), level))
+
+    def emit_bgzf_complete(self):
+        """the oldest enqueued batch's blocks (msx_unpack_emit_bgzf_complete + fetch): (bytes, number of blocks)"""
+        nb, nblk = C.c_int64(0), C.c_int64(0)
+        self.ctx.check(self.ctx.lib.msx_unpack_emit_bgzf_complete(self.ctx.h, self.h, C.byref(nb), C.byref(nblk)))
+        out = np.zeros(max(nb.value, 1), np.uint8)
+        self.ctx.check(self.ctx.lib.msx_unpack_emit_fetch(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p), out.size, None))
+        return out[:nb.value].tobytes(), nblk.value
+
     def close(self):
         if self.h:
             self.ctx.lib.msx_unpack_destroy(self.ctx.h, self.h)

@@ -145,7 +145,13 @@ typedef struct {
 	 * decoder must not run out of slots because the writer still holds the outputs of earlier batches */
 	uint8_t *ob[PIPE_OBUFS];
 	size_t ob_cap[PIPE_OBUFS];
-	pq q_ob;
+	/* batch seq takes buffer seq % PIPE_OBUFS, and waits for it: handed out first come, first served, several device threads
+	 * could take every buffer for batches BEHIND the one the writer is waiting for, whose thread then finds none -- seen
+	 * once as a hang of the two-context test.  By batch number the buffer a batch waits for is held by a batch PIPE_OBUFS
+	 * in front of it, which the writer reaches first. */
+	pthread_mutex_t ob_mu;
+	pthread_cond_t ob_cv;
+	int ob_state[PIPE_OBUFS];      /* 0: not page-locked yet, 1: free, 2: holds a batch's output */
 	int raw_started, raw_done;
 	/* several contexts: the stream's carry behind raw batch seq - 1, handed from the context that finished it to the one
 	 * that walks batch `baton_seq` (msx_unpack_carry -> msx_unpack_seed) */
@@ -239,6 +245,8 @@ void io_populate(uint8_t *p, size_t bytes);
 void pin_start(pipe_t *P, int with_obuf);
 void pin_join(pipe_t *P);
 void pin_wait(pipe_t *P, pslot *s);
+int ob_acquire(pipe_t *P, size_t seq);
+void ob_release(pipe_t *P, int i);
 void unpack_slot_enqueue(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up);
 void unpack_slots_ahead(pipe_t *P, msx_unpack *unpack, ahead_q *A);
 int ahead_pop(ahead_q *A);

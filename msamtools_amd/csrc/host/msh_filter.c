@@ -86,6 +86,7 @@ struct fshared {
 	 * writer's last batches (profile_done); not when a batch held a record the reference dies at (any_fatal) */
 	int profile_done, any_fatal;
 	int dev_frame, dev_level;   /* -bu / -b: the device hands down finished BGZF blocks (stored / deflated), msx_unpack_emit_gather_bgzf */
+	int dev_overlap;            /* -b: the encoder on a stream of its own beside the next batch (msx_unpack_emit_bgzf_enqueue / _complete) */
 	double t_finalized, t_reported;
 	fdev_t dev[MSH_MAX_DEVICES];
 };
@@ -128,6 +129,41 @@ static int64_t fatal_prefix(const uint32_t *group_off, int64_t n_groups, int64_t
 	return (int64_t)group_off[lo];
 }
 
+/* the gathered output of a device-unpacked batch (records, or finished BGZF blocks) on its way to the host: an output buffer
+ * of the pool -- a larger one if this batch keeps more than any before it --, the copy on the unpacker's copy stream, the
+ * event the writer waits for */
+static void filter_emit_fetch(fdev_t *D, msx_unpack *unpack, pslot *s, int64_t nb) {
+	pipe_t *P = D->S->P;
+	if (nb > 0) {
+		s->ob = ob_acquire(P, s->seq);           /* (the buffer of this batch's number: waits for the writer to have written the batch PIPE_OBUFS before it) */
+		if ((size_t)nb + 64 > P->ob_cap[s->ob]) {          /* (the old one stays mapped and page-locked: rare) */
+			P->ob_cap[s->ob] = (size_t)nb + (size_t)nb / 4 + ((size_t)4 << 20);
+			P->ob[s->ob] = io_alloc(P->ob_cap[s->ob]);
+			io_populate(P->ob[s->ob], P->ob_cap[s->ob]);
+			MSX(msx_host_register(g_ctx, P->ob[s->ob], P->ob_cap[s->ob]));
+		}
+		s->obuf = P->ob[s->ob];
+		s->ocap = P->ob_cap[s->ob];
+	}
+	/* (an event belongs to the device it was made on: one per slot and context) */
+	if (!s->ev_out_by[D->index]) MSX(msx_event_create(g_ctx, &s->ev_out_by[D->index]));
+	s->ev_out = s->ev_out_by[D->index];
+	MSX(msx_unpack_emit_fetch(g_ctx, unpack, s->obuf, s->ocap, s->ev_out));
+	s->ev_ctx = g_ctx;
+	s->olen = (size_t)nb;
+}
+/* (-b, the encoder beside the next batch) the oldest batch handed to the encoder: wait for its blocks, send them down, pass
+ * the batch on to the writer */
+static void filter_emit_down(fdev_t *D, msx_unpack *unpack, int si) {
+	pipe_t *P = D->S->P;
+	const double t0 = now_s();
+	int64_t nb = 0;
+	MSX(msx_unpack_emit_bgzf_complete(g_ctx, unpack, &nb, NULL));
+	filter_emit_fetch(D, unpack, &P->slot[si], nb);
+	D->t_fetch += now_s() - t0;
+	pq_push(&P->q_out, si);
+}
+
 void *filter_dev_thread(void *arg) {
 	fdev_t *D = (fdev_t *)arg;
 	fshared *F = D->S;
@@ -135,6 +171,7 @@ void *filter_dev_thread(void *arg) {
 	msx_stage *stage = NULL;
 	msx_unpack *unpack = NULL;
 	int pending = PQ_NONE;             /* a slot taken off the queue ahead of its turn (its bytes are being sent up) */
+	int held = -1;                     /* (-b) the batch whose records the encoder is working on */
 	ahead_q ahead = {{PQ_NONE, PQ_NONE}, 0, 0};
 	const int prefetch_on = getenv("MSX_PREFETCH") != NULL;
 	{
@@ -234,25 +271,19 @@ void *filter_dev_thread(void *arg) {
 				/* gather on the device, make room here if this batch keeps more than any before it, and let the bytes travel
 				 * while the next batch is worked on: the writer waits for s->ev_out */
 				s->framed = F->dev_frame;
+				if (F->dev_overlap) {
+					/* -b: the encoder runs on a stream of its own beside the NEXT batch's walk and filter.  This batch is
+					 * handed to it; the batch before, whose blocks are done by now, goes down and on to the writer. */
+					MSX(msx_unpack_emit_bgzf_enqueue(g_ctx, unpack, fo.emit_idx, st.n_emit, F->dev_level));
+					D->t_fetch += now_s() - t1;
+					if (held >= 0) filter_emit_down(D, unpack, held);
+					held = si;
+					if (D->n_end < 64) D->t_end[D->n_end++] = now_s();
+					continue;
+				}
 				if (F->dev_frame) MSX(msx_unpack_emit_gather_bgzf(g_ctx, unpack, fo.emit_idx, st.n_emit, F->dev_level, &nb, NULL));
 				else MSX(msx_unpack_emit_gather(g_ctx, unpack, fo.emit_idx, st.n_emit, &nb));
-				if (nb > 0) {
-					s->ob = pq_pop(&P->q_ob);                /* (waits for the writer when all of them are on their way out) */
-					if ((size_t)nb + 64 > P->ob_cap[s->ob]) {          /* (the old one stays mapped and page-locked: rare) */
-						P->ob_cap[s->ob] = (size_t)nb + (size_t)nb / 4 + ((size_t)4 << 20);
-						P->ob[s->ob] = io_alloc(P->ob_cap[s->ob]);
-						io_populate(P->ob[s->ob], P->ob_cap[s->ob]);
-						MSX(msx_host_register(g_ctx, P->ob[s->ob], P->ob_cap[s->ob]));
-					}
-					s->obuf = P->ob[s->ob];
-					s->ocap = P->ob_cap[s->ob];
-				}
-				/* (an event belongs to the device it was made on: one per slot and context) */
-				if (!s->ev_out_by[D->index]) MSX(msx_event_create(g_ctx, &s->ev_out_by[D->index]));
-				s->ev_out = s->ev_out_by[D->index];
-				MSX(msx_unpack_emit_fetch(g_ctx, unpack, s->obuf, s->ocap, s->ev_out));
-				s->ev_ctx = g_ctx;
-				s->olen = (size_t)nb;
+				filter_emit_fetch(D, unpack, s, nb);
 				D->t_fetch += now_s() - t1;
 			}
 			if (D->n_end < 64) D->t_end[D->n_end++] = now_s();
@@ -297,6 +328,7 @@ void *filter_dev_thread(void *arg) {
 		if (D->n_end < 64) D->t_end[D->n_end++] = now_s();
 		pq_push(&P->q_out, si);
 	}
+	if (held >= 0) filter_emit_down(D, unpack, held);
 	MSX(msx_ctx_sync(g_ctx));
 	/* the last device thread to finish closes the writer's queue (and opens the output of an empty input) */
 	pthread_mutex_lock(&F->mu);
@@ -428,6 +460,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	 * on the host cores, as round 3 did; MSX_HOST_DEFLATE=1: only -b's deflate) */
 	F.dev_frame = (out_mode == MSH_OUT_UBAM || (out_mode == MSH_OUT_BAM && !getenv("MSX_HOST_DEFLATE"))) && !getenv("MSX_HOST_FRAME");
 	F.dev_level = out_mode == MSH_OUT_UBAM ? 0 : 6;
+	F.dev_overlap = F.dev_frame && F.dev_level > 0 && !getenv("MSX_DEFLATE_SYNC");     /* (MSX_DEFLATE_SYNC=1: one batch after the other) */
 	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv; F.po = po; F.pf = &pf;
 	pthread_mutex_init(&F.mu, NULL);
 	if (pthread_create(&th_dec, NULL, pipe_decode_thread, &P) != 0) mDie("pthread_create failed");
@@ -459,7 +492,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 			if (s->ev_out && s->olen) { if (msx_event_wait(s->ev_ctx, s->ev_out) != MSX_OK) mDie("%s", msx_last_error(s->ev_ctx)); }
 			if (s->framed) msh_write_framed(F.out, s->obuf, s->olen);
 			else msh_write_stream(F.out, s->obuf, s->olen);
-			if (s->ob >= 0) { pq_push(&P.q_ob, s->ob); s->ob = -1; }
+			if (s->ob >= 0) { ob_release(&P, s->ob); s->ob = -1; }
 		} else if (!fp->rescore) {
 			msh_write_many(F.out, s->b.base, s->b.rec_off, s->emit, (size_t)s->n_emit);
 		} else if (s->n_emit > 0) {

@@ -291,7 +291,9 @@ void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_consumers)
 	if (P->cap_rec < COORD_ORDER_CHECK_RECORDS + 1024) P->cap_rec = COORD_ORDER_CHECK_RECORDS + 1024;
 	P->cap_cig = want_stats ? 2 * P->cap_rec : 4;
 	P->cap_md = want_stats ? 16 * P->cap_rec : 16;
-	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out); pq_init(&P->q_ob);
+	pq_init(&P->q_free); pq_init(&P->q_dev); pq_init(&P->q_out);
+	pthread_mutex_init(&P->ob_mu, NULL);
+	pthread_cond_init(&P->ob_cv, NULL);
 	for (i = 0; i < PIPE_SLOTS_MAX; i++) P->slot[i].ob = -1;
 	pthread_mutex_init(&P->first_mu, NULL);
 	pthread_mutex_init(&P->baton_mu, NULL);
@@ -374,7 +376,7 @@ static void *pin_thread(void *arg) {
 		}
 		if (P->with_obuf && j < PIPE_OBUFS) {
 			if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, P->ob[j], P->ob_cap[j]));
-			pq_push(&P->q_ob, j);
+			ob_release(P, j);
 		}
 	}
 	return NULL;
@@ -409,6 +411,20 @@ void pin_join(pipe_t *P) {
 	pthread_cond_broadcast(&P->pin_cv);
 	pthread_mutex_unlock(&P->pin_mu);
 	for (t = 0; t < P->n_pin; t++) pthread_join(P->pin_th[t], NULL);
+}
+int ob_acquire(pipe_t *P, size_t seq) {
+	const int i = (int)(seq % PIPE_OBUFS);
+	pthread_mutex_lock(&P->ob_mu);
+	while (P->ob_state[i] != 1) pthread_cond_wait(&P->ob_cv, &P->ob_mu);
+	P->ob_state[i] = 2;
+	pthread_mutex_unlock(&P->ob_mu);
+	return i;
+}
+void ob_release(pipe_t *P, int i) {
+	pthread_mutex_lock(&P->ob_mu);
+	P->ob_state[i] = 1;
+	pthread_cond_broadcast(&P->ob_cv);
+	pthread_mutex_unlock(&P->ob_mu);
 }
 void pin_wait(pipe_t *P, pslot *s) {
 	pthread_mutex_lock(&P->pin_mu);

@@ -772,9 +772,31 @@ extern "C" int64_t msx_bgzf_bound(int64_t n_bytes, int level) {
 	return n_bytes + nblk * (int64_t)BZ_STORED_FRAME;
 }
 
+// exclusive sums of the blocks' sizes (one workgroup: a batch is a thousand blocks; 65 536 of them take 256 rounds)
+__global__ __launch_bounds__(MSX_BLOCK) void k_bgzf_offsets(const uint32_t *__restrict__ bsize, uint32_t *__restrict__ boff, uint32_t n) {
+	__shared__ uint32_t s_w[MSX_BLOCK / 64];
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < n; base += MSX_BLOCK) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < n ? bsize[i] : 0u;
+		const uint32_t inc = df_wave_incl_scan(v);
+		if (lane == 63u) s_w[w] = inc;
+		__syncthreads();
+		uint32_t woff = 0, tot = 0;
+		for (uint32_t q = 0; q < MSX_BLOCK / 64; q++) { if (q < w) woff += s_w[q]; tot += s_w[q]; }
+		if (i < n) boff[i] = running + woff + inc - v;
+		running += tot;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) boff[n] = running;
+}
+
 // Deflates (level >= 1) the byte string in[0 .. total) -- total = *d_total (a device word) if given, else n_cap -- into
-// BGZF blocks, back to back in d_out; *d_out_total (device) receives the stream's length.  Enqueued on ctx->stream.
-int msx_bgzf_deflate_launch(msx_ctx *ctx, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out, uint32_t *d_out_total) {
+// BGZF blocks, back to back in d_out; *d_out_total (device) receives the stream's length.  Enqueued on `stream` (every
+// kernel its own: nothing of the context's scan workspace is touched, so the stream may run beside the context's).
+int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out,
+                            uint32_t *d_out_total) {
 	if (n_cap == 0) return MSX_OK;
 	const size_t nblk = (n_cap + BZ_PAYLOAD - 1) / BZ_PAYLOAD;
 	int rc;
@@ -784,20 +806,19 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, const uint8_t *d_in, const uint32_t *d
 	if ((rc = msx_reserve(ctx, &ctx->df_size, (nblk + 16) * 8 + 256))) return rc;
 	if ((rc = msx_reserve(ctx, &ctx->df_tok, waves * (size_t)DF_TOKCAP * 4 + 64))) return rc;
 	uint32_t *bsize = (uint32_t *)ctx->df_size.p, *boff = bsize + nblk + 8, *misc = boff + nblk + 4;
-	MSX_HIP(ctx, hipMemsetAsync(bsize, 0, (nblk + 16) * 8 + 192, ctx->stream));
+	MSX_HIP(ctx, hipMemsetAsync(bsize, 0, (nblk + 16) * 8 + 192, stream));
 	static int want_kinds = -1;
 	if (want_kinds < 0) want_kinds = getenv("MSX_DEFLATE_STATS") != nullptr;
-	hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)waves), dim3(64), 0, ctx->stream, d_in, d_total, (uint32_t)n_cap,
+	hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)waves), dim3(64), 0, stream, d_in, d_total, (uint32_t)n_cap,
 	                   (uint8_t *)ctx->df_slots.p, bsize, (uint32_t *)ctx->df_tok.p, misc, want_kinds ? misc + 4 : nullptr);
-	MSX_HIP(ctx, hipGetLastError());
-	if ((rc = msx_scan_u32(ctx, bsize, boff, (int64_t)nblk))) return rc;
-	hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->df_slots.p, bsize, boff, d_total,
+	hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(MSX_BLOCK), 0, stream, (const uint32_t *)bsize, boff, (uint32_t)nblk);
+	hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nblk), dim3(64), 0, stream, (const uint8_t *)ctx->df_slots.p, bsize, boff, d_total,
 	                   (uint32_t)n_cap, d_out, d_out_total);
 	MSX_HIP(ctx, hipGetLastError());
 	if (want_kinds) {
 		uint32_t h[4 + 2 * 10];
-		MSX_HIP(ctx, hipMemcpyAsync(h, misc + 4, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(h, misc + 4, sizeof h, hipMemcpyDeviceToHost, stream));
+		MSX_HIP(ctx, hipStreamSynchronize(stream));
 		const unsigned long long *t = reinterpret_cast<const unsigned long long *>(h + 4);
 		const double nb = (double)(h[0] + h[1] + h[2] ? h[0] + h[1] + h[2] : 1);
 		fprintf(stderr, "# deflate: %zu blocks at most: %u stored, %u with the fixed codes, %u with codes of their own; clocks per block: ring+keys %.0f, "
@@ -828,7 +849,7 @@ extern "C" int msx_bgzf_deflate(msx_ctx *ctx, const void *d_in, size_t n_bytes, 
 	} else {
 		if ((rc = msx_reserve(ctx, &ctx->scan_l3, 64))) return rc;
 		uint32_t *d_tot = (uint32_t *)ctx->scan_l3.p + 8, h_tot = 0;
-		if ((rc = msx_bgzf_deflate_launch(ctx, (const uint8_t *)d_in, nullptr, n_bytes, (uint8_t *)d_out, d_tot))) return rc;
+		if ((rc = msx_bgzf_deflate_launch(ctx, ctx->stream, (const uint8_t *)d_in, nullptr, n_bytes, (uint8_t *)d_out, d_tot))) return rc;
 		MSX_HIP(ctx, hipMemcpyAsync(&h_tot, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		*n_out = h_tot;

@@ -80,6 +80,17 @@ struct msx_unpack {
 	bool out_busy = false;
 	size_t gathered = 0;               // msx_unpack_emit_gather: bytes in `out` (msx_unpack_emit_gather_bgzf: in `framed`)
 	const void *fetch_src = nullptr;   // what msx_unpack_emit_fetch brings down
+	// msx_unpack_emit_bgzf_enqueue / _complete: the encoder on a stream of its own, two batches in flight.  Batch k's
+	// gathered records (eo[k & 1]) are deflated into ef[k & 1] while batch k + 1 is walked and filtered on the context's
+	// stream; sizes come back through a pinned pair per parity.
+	msx_buf eo[2], ef[2];
+	hipStream_t df_stream = nullptr;
+	hipEvent_t ev_gathered = nullptr, ev_deflated[2] = {nullptr, nullptr}, ev_fetched[2] = {nullptr, nullptr};
+	bool deflated_used[2] = {false, false}, fetched_used[2] = {false, false};
+	uint32_t *d_emit = nullptr, *h_emit = nullptr;      // [4]: {bytes of blocks, bytes of records} per parity
+	uint64_t eseq_in = 0, eseq_out = 0;                 // batches enqueued / completed
+	int64_t e_nemit[2] = {0, 0};
+	int fetch_par = -1;                                 // the parity msx_unpack_emit_fetch is bringing down (-1: the plain path)
 	const uint8_t *pre_host = nullptr;
 	size_t pre_n = 0;
 };
@@ -529,10 +540,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_emit_len(uint32_t n_emit, const i
 #define EM_PER_WAVE 16
 __global__ __launch_bounds__(MSX_BLOCK) void k_emit_copy(const uint8_t *__restrict__ u, uint32_t n_emit, const int32_t *__restrict__ emit,
                                                          const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ out_off,
-                                                         uint8_t *__restrict__ out, up_state *st) {
+                                                         uint8_t *__restrict__ out, up_state *st, uint32_t *__restrict__ tot_out = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
-	if (wave == 0 && lane == 0) st->emit_bytes = st->emit_raw = out_off[n_emit];
+	if (wave == 0 && lane == 0) {
+		if (tot_out) *tot_out = out_off[n_emit];          // (the overlapped path: the state is the next batch's by the time it is read)
+		else st->emit_bytes = st->emit_raw = out_off[n_emit];
+	}
 	const uint32_t k0 = wave * EM_PER_WAVE;
 	for (uint32_t q = 0; q < EM_PER_WAVE; q++) {
 		const uint32_t k = k0 + q;
@@ -572,10 +586,12 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (ctx && ctx->stream) { msx_join(ctx); (void)hipStreamSynchronize(ctx->stream); }
 	if (u->h2d_stream) (void)hipStreamSynchronize(u->h2d_stream);
 	if (u->inf_stream) (void)hipStreamSynchronize(u->inf_stream);
+	if (u->df_stream) (void)hipStreamSynchronize(u->df_stream);
+	if (u->copy_stream) (void)hipStreamSynchronize(u->copy_stream);
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
-	                   &u->out_off, &u->out, &u->framed, &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
+	                   &u->out_off, &u->out, &u->framed, &u->eo[0], &u->eo[1], &u->ef[0], &u->ef[1], &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
 	                   &u->pre[0].status, &u->pre[0].out, &u->pre[0].cnt, &u->pre[1].comp, &u->pre[1].blk, &u->pre[1].status,
 	                   &u->pre[1].out, &u->pre[1].cnt};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
@@ -589,6 +605,14 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	}
 	if (u->copy_done) (void)hipEventDestroy(u->copy_done);
 	if (u->out_copied) (void)hipEventDestroy(u->out_copied);
+	if (u->df_stream) (void)hipStreamDestroy(u->df_stream);
+	if (u->ev_gathered) (void)hipEventDestroy(u->ev_gathered);
+	for (int q = 0; q < 2; q++) {
+		if (u->ev_deflated[q]) (void)hipEventDestroy(u->ev_deflated[q]);
+		if (u->ev_fetched[q]) (void)hipEventDestroy(u->ev_fetched[q]);
+	}
+	if (u->d_emit) (void)hipFree(u->d_emit);
+	if (u->h_emit) (void)hipHostFree(u->h_emit);
 	if (u->prev_name) (void)hipFree(u->prev_name);
 	if (u->d_state) (void)hipFree(u->d_state);
 	if (u->h_state) (void)hipHostFree(u->h_state);
@@ -960,6 +984,7 @@ static int up_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_d
 	msx_join(ctx);
 	u->gathered = 0;
 	u->fetch_src = nullptr;
+	u->fetch_par = -1;
 	if (n_emit <= 0) return MSX_OK;
 	// (the gather buffer may still be on its way down for the batch before)
 	if (u->out_busy) { MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->out_copied, 0)); u->out_busy = false; }
@@ -988,7 +1013,7 @@ static int up_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_d
 	} else if (level > 0) {
 		// -b: deflated on the device, the blocks moved back to back; the stream's length lands in the state
 		UP_RES(framed, (size_t)msx_bgzf_bound((int64_t)u->n_bytes + 64, level) + 64);
-		if ((rc = msx_bgzf_deflate_launch(ctx, (const uint8_t *)u->out.p, (const uint32_t *)u->out_off.p + ne, u->n_bytes,
+		if ((rc = msx_bgzf_deflate_launch(ctx, ctx->stream, (const uint8_t *)u->out.p, (const uint32_t *)u->out_off.p + ne, u->n_bytes,
 		                                  (uint8_t *)u->framed.p, &u->d_state->emit_bytes)))
 			return rc;
 	}
@@ -1026,6 +1051,80 @@ extern "C" int msx_unpack_emit_gather_bgzf(msx_ctx *ctx, msx_unpack *u, const in
 	return MSX_OK;
 }
 
+// The same in two steps that need not follow each other at once (level >= 1: filter -b).  _enqueue gathers batch k's records
+// on the context's stream and hands them to the encoder on a stream of its own, then returns; the caller goes on with batch
+// k + 1 (walk, filter) while batch k is being deflated.  _complete -- called once per _enqueue, in the same order -- waits for the
+// oldest batch's blocks, tells their size and makes them what the next msx_unpack_emit_fetch brings down.  Two batches may be
+// in flight (one being deflated, one whose blocks are travelling to the host).
+extern "C" int msx_unpack_emit_bgzf_enqueue(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level) {
+	if (!ctx || !u || (n_emit > 0 && !emit_idx_dev)) return MSX_ERR_ARG;
+	if (level < 1 || level > 9) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit_bgzf_enqueue: level %d", level);
+	if (u->eseq_in - u->eseq_out >= 2) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit_bgzf_enqueue: two batches are in flight already");
+	msx_join(ctx);
+	int rc;
+	if (!u->df_stream) {
+		if (hipStreamCreateWithFlags(&u->df_stream, hipStreamNonBlocking) != hipSuccess ||
+		    hipEventCreateWithFlags(&u->ev_gathered, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&u->ev_deflated[0], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&u->ev_deflated[1], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&u->ev_fetched[0], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&u->ev_fetched[1], hipEventDisableTiming) != hipSuccess ||
+		    hipMalloc((void **)&u->d_emit, 16) != hipSuccess || hipHostMalloc((void **)&u->h_emit, 16, hipHostMallocDefault) != hipSuccess)
+			return msx_fail(ctx, MSX_ERR_HIP, "msx_unpack_emit_bgzf_enqueue: stream setup failed");
+	}
+	const int par = (int)(u->eseq_in & 1u);
+	u->eseq_in++;
+	u->e_nemit[par] = n_emit > 0 ? n_emit : 0;
+	if (n_emit <= 0) return MSX_OK;
+	if (n_emit > u->n_batch) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: more records than the batch holds");
+	const uint32_t ne = (uint32_t)n_emit;
+	const uint8_t *raw = (const uint8_t *)u->raw[u->cur ^ 1].p;
+	// (this parity's record buffer was read by the encoder two batches ago)
+	if (u->deflated_used[par]) MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->ev_deflated[par], 0));
+	UP_RES(out_len, ((size_t)ne + 8) * 4);
+	UP_RES(out_off, ((size_t)ne + 8) * 4);
+	UP_RES(eo[par], u->n_bytes + 64);
+	hipLaunchKernelGGL(k_emit_len, dim3((ne + MSX_BLOCK - 1) / MSX_BLOCK), dim3(MSX_BLOCK), 0, ctx->stream, ne, emit_idx_dev,
+	                   (const uint32_t *)u->rec_off.p, (uint32_t *)u->out_len.p);
+	if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->out_len.p, (uint32_t *)u->out_off.p, ne))) return rc;
+	const uint32_t n_waves = (ne + EM_PER_WAVE - 1) / EM_PER_WAVE;
+	hipLaunchKernelGGL(k_emit_copy, dim3((n_waves + 3) / 4), dim3(MSX_BLOCK), 0, ctx->stream, raw, ne, emit_idx_dev,
+	                   (const uint32_t *)u->rec_off.p, (const uint32_t *)u->out_off.p, (uint8_t *)u->eo[par].p, u->d_state, u->d_emit + 2 * par + 1);
+	MSX_HIP(ctx, hipGetLastError());
+	MSX_HIP(ctx, hipEventRecord(u->ev_gathered, ctx->stream));
+	// the encoder's stream: behind the gather, and behind the journey of the blocks this parity held before
+	MSX_HIP(ctx, hipStreamWaitEvent(u->df_stream, u->ev_gathered, 0));
+	if (u->fetched_used[par]) MSX_HIP(ctx, hipStreamWaitEvent(u->df_stream, u->ev_fetched[par], 0));
+	UP_RES(ef[par], (size_t)msx_bgzf_bound((int64_t)u->n_bytes + 64, level) + 64);
+	if ((rc = msx_bgzf_deflate_launch(ctx, u->df_stream, (const uint8_t *)u->eo[par].p, u->d_emit + 2 * par + 1, u->n_bytes, (uint8_t *)u->ef[par].p,
+	                                  u->d_emit + 2 * par)))
+		return rc;
+	MSX_HIP(ctx, hipMemcpyAsync(u->h_emit + 2 * par, u->d_emit + 2 * par, 8, hipMemcpyDeviceToHost, u->df_stream));
+	MSX_HIP(ctx, hipEventRecord(u->ev_deflated[par], u->df_stream));
+	u->deflated_used[par] = true;
+	return MSX_OK;
+}
+
+extern "C" int msx_unpack_emit_bgzf_complete(msx_ctx *ctx, msx_unpack *u, int64_t *n_bytes, int64_t *n_blocks) {
+	if (!ctx || !u || !n_bytes) return MSX_ERR_ARG;
+	if (u->eseq_out >= u->eseq_in) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit_bgzf_complete without msx_unpack_emit_bgzf_enqueue");
+	const int par = (int)(u->eseq_out & 1u);
+	u->eseq_out++;
+	*n_bytes = 0;
+	if (n_blocks) *n_blocks = 0;
+	u->gathered = 0;
+	u->fetch_src = nullptr;
+	u->fetch_par = par;
+	if (u->e_nemit[par] <= 0) return MSX_OK;
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	MSX_HIP(ctx, hipEventSynchronize(u->ev_deflated[par]));
+	u->gathered = u->h_emit[2 * par];
+	u->fetch_src = u->ef[par].p;
+	*n_bytes = (int64_t)u->gathered;
+	if (n_blocks) *n_blocks = ((int64_t)u->h_emit[2 * par + 1] + 0xff00 - 1) / 0xff00;
+	return MSX_OK;
+}
+
 // The gathered bytes to the host.  done == NULL: waits for them.  Otherwise they travel on a copy stream of their own while
 // the caller goes on with the next batch; msx_event_wait(done) before host_out is read.
 extern "C" int msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_out, size_t host_cap, msx_event *done) {
@@ -1041,9 +1140,14 @@ extern "C" int msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_
 	}
 	// (the kernels that wrote u->out have been waited for by msx_unpack_emit_gather)
 	MSX_HIP(ctx, hipMemcpyAsync(host_out, u->fetch_src, tb, hipMemcpyDeviceToHost, u->copy_stream));
-	MSX_HIP(ctx, hipEventRecord(u->out_copied, u->copy_stream));
+	if (u->fetch_par >= 0) {                  // the overlapped path: the encoder's next use of this parity's buffer waits for this
+		MSX_HIP(ctx, hipEventRecord(u->ev_fetched[u->fetch_par], u->copy_stream));
+		u->fetched_used[u->fetch_par] = true;
+	} else {
+		MSX_HIP(ctx, hipEventRecord(u->out_copied, u->copy_stream));
+		u->out_busy = true;
+	}
 	MSX_HIP(ctx, hipEventRecord(done->ev, u->copy_stream));
-	u->out_busy = true;
 	done->recorded = true;
 	return MSX_OK;
 }

@@ -35,8 +35,11 @@ pytestmark = pytest.mark.gpu
 def sh(cmd, **env):
     e = dict(os.environ, **ENV)
     e.update({k: str(v) for k, v in env.items()})
-    r = subprocess.run(cmd, shell=True, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 0, (cmd, r.stderr.decode()[-2000:])
+    # (a command line that hangs must fail its test, not hold the GPU box until the harness gives up: round 4 lost forty
+    #  minutes to a deadlock between device threads over output buffers)
+    r = subprocess.run(f"timeout 180 {cmd}" if "|" not in cmd else f"timeout 180 bash -c {cmd!r}", shell=True, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, (cmd, r.returncode, r.stderr.decode()[-2000:])
     return r
 
 
@@ -308,6 +311,12 @@ def test_two_contexts_filter_profile_and_tee(big, tmp_path):
     assert b"BGZF blocks inflated on the device" not in r.stderr
     big.check_digest(f, big.digest_out)
     big.check_profile(p, big.pipe)
+    # device threads finish batches in any order while the writer takes them in input order: again and again, with few
+    # buffers to go round (a hang here was a deadlock over output buffers handed out first come, first served)
+    for rep in range(6):
+        sh(f"{BIN} {' '.join(FILT)} {'-b' if rep % 2 else '-bu'} {big.bam['b']} > {f}", MSX_DEVICES="0,0,0" if rep % 3 else "0,0",
+           MSX_BATCH_BYTES=1_200_000)
+        big.check_digest(f, big.digest_out)
 
 
 # ---- --rescore on the pipeline ------------------------------------------------------------------------------------

@@ -200,3 +200,52 @@ def test_ratio_next_to_zlib(ctx):
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
         z += len(co.compress(data[i:i + PAYLOAD]) + co.flush()) + 26
     assert len(got) <= 1.15 * z, (len(got), z)
+
+
+def test_encoder_beside_the_next_batch(ctx):
+    """msx_unpack_emit_bgzf_enqueue / _complete: batch k is deflated on a stream of its own while batch k + 1 is walked and
+    gathered; two batches in flight, completed in order -- the same blocks as the one-call form gives, batch by batch"""
+    import struct
+    m = M()
+    rng = np.random.default_rng(17)
+
+    def records(n, tag):
+        recs = []
+        for k in range(n):
+            name = b"%s%07d\0" % (tag, k // 3)
+            body = struct.pack("<iiBBHHHIiii", 0, 10 + k, len(name), 30, 4680, 1, 0, 0, -1, -1, 0) + name + struct.pack("<I", 100 << 4)
+            body += b"NMC\1ASC\x60MDZ" + (b"%d" % int(rng.integers(1, 100))) + b"\0"
+            recs.append(struct.pack("<I", len(body)) + body)
+        return recs
+    batches = [records(30000, b"a"), records(5000, b"b"), records(41000, b"c"), records(1, b"d"), records(20000, b"e")]
+    up = m.Unpack(ctx)
+    up.seed()
+    want, dptrs, pending, got = [], [], [], []
+    for i, recs in enumerate(batches):
+        stream = b"".join(recs)
+        off = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+        up.enqueue(stream, pool_mode=0, n_targets=5, last=True)
+        res, view = up.finish()
+        n = int(res.n_records)
+        assert n == len(recs)
+        emit = np.sort(rng.choice(n, size=max(1, n // 2), replace=False)).astype(np.int32) if i != 3 else np.zeros(0, np.int32)
+        d = ctx.alloc(4 * max(emit.size, 1))
+        if emit.size:
+            ctx.to_dev(d, emit)
+        dptrs.append(d)
+        want.append(b"".join(stream[int(off[j]):int(off[j + 1])] for j in emit))
+        up.emit_bgzf_enqueue(d, emit.size, 6)
+        pending.append(i)
+        if len(pending) == 2:                       # two in flight: complete the older one
+            got.append(up.emit_bgzf_complete())
+            pending.pop(0)
+    while pending:
+        got.append(up.emit_bgzf_complete())
+        pending.pop(0)
+    for i, (blocks, n_blk) in enumerate(got):
+        assert (gzip.decompress(blocks) if blocks else b"") == want[i], i
+        one, _ = m.bgzf_deflate(ctx, want[i], 6)
+        assert blocks == one, i                     # the same encoder, the same bytes
+    for d in dptrs:
+        ctx.free(d)
+    up.close()
