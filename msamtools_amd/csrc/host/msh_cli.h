@@ -145,13 +145,13 @@ typedef struct {
 	 * decoder must not run out of slots because the writer still holds the outputs of earlier batches */
 	uint8_t *ob[PIPE_OBUFS];
 	size_t ob_cap[PIPE_OBUFS];
-	/* batch seq takes buffer seq % PIPE_OBUFS, and waits for it: handed out first come, first served, several device threads
-	 * could take every buffer for batches BEHIND the one the writer is waiting for, whose thread then finds none -- seen
-	 * once as a hang of the two-context test.  By batch number the buffer a batch waits for is held by a batch PIPE_OBUFS
-	 * in front of it, which the writer reaches first. */
+	/* batch seq takes buffer seq % PIPE_OBUFS, and only once it is among the PIPE_OBUFS batches the writer takes next: handed
+	 * out first come, first served, several device threads could take every buffer for batches BEHIND the one the writer is
+	 * waiting for, whose thread then finds none (a hang of the three-context test) */
 	pthread_mutex_t ob_mu;
 	pthread_cond_t ob_cv;
 	int ob_state[PIPE_OBUFS];      /* 0: not page-locked yet, 1: free, 2: holds a batch's output */
+	size_t ob_written;             /* batches the writer is done with */
 	int raw_started, raw_done;
 	/* several contexts: the stream's carry behind raw batch seq - 1, handed from the context that finished it to the one
 	 * that walks batch `baton_seq` (msx_unpack_carry -> msx_unpack_seed) */
@@ -167,7 +167,7 @@ typedef struct {
 	pthread_mutex_t first_mu;
 	pthread_cond_t first_cv;
 	int with_obuf;             /* filter: there are output buffers as well */
-	int pin_started, pin_quit;
+	int pin_started, pin_quit, pin_joined;       /* pin_joined: 1 while one thread joins them, 2 once joined */
 	msx_ctx *pin_ctx;
 	pthread_t pin_th[PIPE_SLOTS_MAX];
 	int n_pin;
@@ -245,8 +245,11 @@ void io_populate(uint8_t *p, size_t bytes);
 void pin_start(pipe_t *P, int with_obuf);
 void pin_join(pipe_t *P);
 void pin_wait(pipe_t *P, pslot *s);
+int msh_trace_on(void);
+#define MSH_TRACE(...) do { if (msh_trace_on()) { fprintf(stderr, "# trace %.3f: ", now_s()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 int ob_acquire(pipe_t *P, size_t seq);
 void ob_release(pipe_t *P, int i);
+void ob_written(pipe_t *P, size_t seq);
 void unpack_slot_enqueue(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpack_params *up);
 void unpack_slots_ahead(pipe_t *P, msx_unpack *unpack, ahead_q *A);
 int ahead_pop(ahead_q *A);

@@ -194,12 +194,23 @@ void *filter_dev_thread(void *arg) {
 	}
 	for (;;) {
 		double t0 = now_s(), t1;
-		const int si = pending != PQ_NONE ? pending : ahead.n ? ahead_pop(&ahead) : pq_pop(&P->q_dev);
+		int si;
 		pslot *s;
 		rbatch *b;
 		msx_batch hb, db;
 		msx_filter_out fo;
 		msx_filter_status st;
+		if (pending != PQ_NONE) si = pending;
+		else if (ahead.n) si = ahead_pop(&ahead);
+		else if (held < 0) si = pq_pop(&P->q_dev);
+		else if ((si = pq_try_pop(&P->q_dev)) == PQ_NONE) {
+			/* nothing to work on beside the encoder: its batch goes on now.  (Waiting here with a batch in hand would also
+			 * stall several contexts for good: the writer wants that batch first, and the decoder has no slot left to
+			 * make the batch this thread waits for.) */
+			filter_emit_down(D, unpack, held);
+			held = -1;
+			si = pq_pop(&P->q_dev);
+		}
 		pending = PQ_NONE;
 		t1 = now_s();
 		D->t_wait += t1 - t0;
@@ -207,6 +218,7 @@ void *filter_dev_thread(void *arg) {
 		s = &P->slot[si];
 		b = &s->b;
 		s->fatal = 0;
+		MSH_TRACE("device thread %d takes batch %zu (slot %d)", D->index, s->seq, si);
 		if (s->raw) {
 			/* the record walk on the device: inflated bytes up, filter's output records back */
 			msx_unpack_params up;
@@ -287,6 +299,7 @@ void *filter_dev_thread(void *arg) {
 				D->t_fetch += now_s() - t1;
 			}
 			if (D->n_end < 64) D->t_end[D->n_end++] = now_s();
+			MSH_TRACE("device thread %d hands batch %zu to the writer (%zu bytes)", D->index, s->seq, s->olen);
 			pq_push(&P->q_out, si);
 			continue;
 		}
@@ -484,6 +497,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		double t0 = now_s(), t1;
 		const int si = pq_pop_seq(&P.q_out, &P, seq);
 		pslot *s;
+		MSH_TRACE("writer has batch %zu (slot %d)", seq, si);
 		t1 = now_s();
 		t_wait += t1 - t0;
 		if (si == PQ_END) break;
@@ -520,6 +534,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 			msh_out_drain(F.out);
 			mDie("%s", s->fatal_msg);
 		}
+		ob_written(&P, seq);
 		n_batches++;
 		seq++;
 		n_in += s->b.n;

@@ -386,8 +386,10 @@ void pin_start(pipe_t *P, int with_obuf) {
 	(void)with_obuf;
 	if (!P->pin_started || P->pin_ctx) return;
 	pthread_mutex_lock(&P->pin_mu);
-	P->pin_ctx = g_ctx;
-	pthread_cond_broadcast(&P->pin_cv);
+	if (!P->pin_ctx) {                               /* (the first context to come, of several) */
+		P->pin_ctx = g_ctx;
+		pthread_cond_broadcast(&P->pin_cv);
+	}
 	pthread_mutex_unlock(&P->pin_mu);
 }
 static void pin_spawn(pipe_t *P) {
@@ -407,22 +409,45 @@ void pin_join(pipe_t *P) {
 	int t;
 	if (!P->pin_started) return;
 	pthread_mutex_lock(&P->pin_mu);
+	/* (every device thread calls this; a thread is joined once -- four contexts joining the same threads hung one run in 48) */
+	while (P->pin_joined == 1) pthread_cond_wait(&P->pin_cv, &P->pin_mu);
+	if (P->pin_joined == 2) { pthread_mutex_unlock(&P->pin_mu); return; }
+	P->pin_joined = 1;
 	P->pin_quit = 1;                                  /* (threads that were never given a context) */
 	pthread_cond_broadcast(&P->pin_cv);
 	pthread_mutex_unlock(&P->pin_mu);
 	for (t = 0; t < P->n_pin; t++) pthread_join(P->pin_th[t], NULL);
+	pthread_mutex_lock(&P->pin_mu);
+	P->pin_joined = 2;
+	pthread_cond_broadcast(&P->pin_cv);
+	pthread_mutex_unlock(&P->pin_mu);
 }
+/* MSX_TRACE=1: one line per hand-over between the pipeline's threads (who waits for what), for hangs */
+int msh_trace_on(void) { static int on = -1; if (on < 0) on = getenv("MSX_TRACE") != NULL; return on; }
+#define TRACE(...) do { if (msh_trace_on()) { fprintf(stderr, "# trace %.3f: ", now_s()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 int ob_acquire(pipe_t *P, size_t seq) {
 	const int i = (int)(seq % PIPE_OBUFS);
+	TRACE("batch %zu wants output buffer %d (state %d, %zu batches written)", seq, i, P->ob_state[i], P->ob_written);
 	pthread_mutex_lock(&P->ob_mu);
-	while (P->ob_state[i] != 1) pthread_cond_wait(&P->ob_cv, &P->ob_mu);
+	/* only the PIPE_OBUFS batches the writer will take next may hold a buffer: each of them has a buffer number of its
+	 * own, so the batch the writer is waiting for always finds its buffer free (a batch further behind that came first
+	 * would otherwise sit on it: seen as a hang with three contexts) */
+	while (P->ob_state[i] != 1 || seq >= P->ob_written + PIPE_OBUFS) pthread_cond_wait(&P->ob_cv, &P->ob_mu);
 	P->ob_state[i] = 2;
 	pthread_mutex_unlock(&P->ob_mu);
 	return i;
 }
 void ob_release(pipe_t *P, int i) {
+	TRACE("output buffer %d released", i);
 	pthread_mutex_lock(&P->ob_mu);
 	P->ob_state[i] = 1;
+	pthread_cond_broadcast(&P->ob_cv);
+	pthread_mutex_unlock(&P->ob_mu);
+}
+/* the writer is done with batch seq (whether it held a buffer or not) */
+void ob_written(pipe_t *P, size_t seq) {
+	pthread_mutex_lock(&P->ob_mu);
+	P->ob_written = seq + 1;
 	pthread_cond_broadcast(&P->ob_cv);
 	pthread_mutex_unlock(&P->ob_mu);
 }
@@ -440,8 +465,10 @@ void unpack_slot_enqueue(pipe_t *P, pslot *s, msx_unpack *unpack, const msx_unpa
 		/* Several contexts share the one stream: this batch's blocks go up and are inflated at once (a stream of their
 		 * own), its walk waits for the carry of the batch before it -- which another context may still be walking. */
 		if (s->comp && s->n_blk > 0) MSX(msx_unpack_prefetch_bgzf(g_ctx, unpack, s->rbuf, s->rlen, s->blk, s->n_blk));
+		TRACE("batch %zu waits for the carry (baton at %zu)", s->seq, P->baton_seq);
 		pthread_mutex_lock(&P->baton_mu);
 		while (P->baton_seq != s->seq) pthread_cond_wait(&P->baton_cv, &P->baton_mu);
+		TRACE("batch %zu has the carry (%zu bytes, fresh %d)", s->seq, P->baton.l, P->baton_fresh);
 		if (P->baton_fresh) MSX(msx_unpack_seed(g_ctx, unpack, (const uint8_t *)P->baton.s, P->baton.l, P->baton_has_name ? P->baton_name : NULL));
 		pthread_mutex_unlock(&P->baton_mu);
 	}
@@ -459,6 +486,7 @@ static void baton_pass(pipe_t *P, pslot *s, msx_unpack *unpack) {
 	P->baton.l = n;
 	P->baton_seq = s->seq + 1;
 	P->baton_fresh = 1;
+	TRACE("batch %zu passes the carry on (%zu bytes)", s->seq, n);
 	pthread_cond_broadcast(&P->baton_cv);
 	pthread_mutex_unlock(&P->baton_mu);
 }
@@ -965,6 +993,7 @@ void *pipe_decode_thread(void *arg) {
 			return NULL;
 		}
 		s->seq = P->n_filled;
+		TRACE("decode: batch %zu ready (slot %d, raw %d, comp %d, %d blocks, last %d)", s->seq, si, s->raw, s->comp, s->n_blk, s->last);
 		if (s->raw && s->has_seed) {          /* the first raw batch is seeded from batch 0's leftovers, not from a baton */
 			pthread_mutex_lock(&P->baton_mu);
 			P->baton_seq = s->seq;

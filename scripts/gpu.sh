@@ -22,7 +22,7 @@ for step in "$@"; do
   echo "== step $k: $step"
   case $kind in
     tests)
-      eval "timeout 2400 python -m pytest -m gpu -x -q --durations=5 ${arg:-tests}" > $OUT/pytest_$k.log 2>&1; echo "rc=$?" >> $OUT/pytest_$k.log
+      eval "timeout 1200 python -m pytest --timeout=300 -m gpu -x -q --durations=5 ${arg:-tests}" > $OUT/pytest_$k.log 2>&1; echo "rc=$?" >> $OUT/pytest_$k.log
       tail -12 $OUT/pytest_$k.log ;;
     bench)
       timeout 1500 python bench.py $arg > $OUT/bench_$k.json 2> $OUT/bench_$k.err; echo "rc=$?"
