@@ -15,9 +15,16 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 EXE=msamtools_amd/bin/msamtools
 DEV=msamtools_amd/bin/msamtools-dev
 [ -x $DEV ] || DEV=$EXE
+# a box whose GPU does not answer (or one a hung command has wedged) costs GPU-minutes and nothing else: stop at once
+healthy() {
+  timeout 180 python3 -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float(x.sum()) == 1 << 20" > $OUT/health.log 2>&1 && return 0
+  echo "GPU health check failed:"; tail -3 $OUT/health.log; return 1
+}
+healthy || exit 1
 k=0
 for step in "$@"; do
   k=$((k+1))
+  if [ $k -gt 1 ]; then healthy || exit 1; fi
   kind=${step%%=*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*=}
   echo "== step $k: $step"
   case $kind in
@@ -25,7 +32,7 @@ for step in "$@"; do
       eval "timeout 1200 python -m pytest --timeout=300 -m gpu -x -q --durations=5 ${arg:-tests}" > $OUT/pytest_$k.log 2>&1; echo "rc=$?" >> $OUT/pytest_$k.log
       tail -12 $OUT/pytest_$k.log ;;
     bench)
-      timeout 1500 python bench.py $arg > $OUT/bench_$k.json 2> $OUT/bench_$k.err; echo "rc=$?"
+      timeout 1200 python bench.py $arg > $OUT/bench_$k.json 2> $OUT/bench_$k.err; echo "rc=$?"
       python3 - $OUT/bench_$k.json <<'PY'
 import json, sys
 try:

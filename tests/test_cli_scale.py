@@ -312,11 +312,14 @@ def test_two_contexts_filter_profile_and_tee(big, tmp_path):
     big.check_digest(f, big.digest_out)
     big.check_profile(p, big.pipe)
     # device threads finish batches in any order while the writer takes them in input order: again and again, with few
-    # buffers to go round (a hang here was a deadlock over output buffers handed out first come, first served)
-    for rep in range(6):
-        sh(f"{BIN} {' '.join(FILT)} {'-b' if rep % 2 else '-bu'} {big.bam['b']} > {f}", MSX_DEVICES="0,0,0" if rep % 3 else "0,0",
-           MSX_BATCH_BYTES=1_200_000)
+    # buffers to go round.  Three hangs were found here: output buffers handed out first come, first served (then by batch
+    # number, but to a later batch of the same number first); a thread waiting for its next batch with the writer's next
+    # one still in its hands (-b, the encoder beside the next batch); every context joining the same helper threads.
+    for rep in range(12):
+        sh(f"{BIN} {' '.join(FILT)} {'-b' if rep % 2 else '-bu'} --profile-out {p} --label S {big.bam['b']} > {f}",
+           MSX_DEVICES=("0,0", "0,0,0", "0,0,0,0")[rep % 3], MSX_BATCH_BYTES=1_200_000)
         big.check_digest(f, big.digest_out)
+    big.check_profile(p, big.pipe)
 
 
 # ---- --rescore on the pipeline ------------------------------------------------------------------------------------
