@@ -475,6 +475,320 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths(const uint32_t *__rest
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same, one word per run (round 4, second form): an item is the PIECE of a run inside one 4 K-cell tile,
+//   key = (tile & 255) << 24 | cell in tile << 12 | (length - 1),   sup = tile >> 8   (an 8-bit value beside the key)
+// -- 28 bits of cell address and 12 of length do not fit one word, so the top byte of the tile number travels as a byte
+// of its own through the two radix passes (first the key's top byte, then that byte: msx_sort_k32v8) and 5 bytes move per
+// run where the first form moves 8 (a +1 and a -1 mark).  A run that crosses a tile boundary is cut there (the further
+// pieces go to the overflow lists, like the runs behind a D or N): every tile then holds every piece that covers it,
+// the depth at its first cell included, and no depth is carried from tile to tile.  Up to 255 * 2^20 cells (the byte 255
+// marks an empty slot, which sorts behind everything); larger samples take the first form.
+#define CV3_TILE_SHIFT 12
+#define CV3_TILE (1u << CV3_TILE_SHIFT)
+#define CV3_REC MSX_SORT_TILE           // records per workgroup of k_cov_emit3: one sort tile of own slots
+#define CV3_STAGE 2048
+#define CV3_MAX_TILES (255 * 256)
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit3(int64_t n, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
+                                                         const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
+                                                         const int64_t *__restrict__ cov_off, uint8_t *__restrict__ covered,
+                                                         uint32_t *__restrict__ items, uint8_t *__restrict__ sups, int64_t list_base,
+                                                         uint32_t list_cap, cv2_state *__restrict__ st, uint32_t *__restrict__ hist,
+                                                         int64_t hist_tiles) {
+	__shared__ uint32_t s_extra[CV3_STAGE];
+	__shared__ uint8_t s_esup[CV3_STAGE];
+	__shared__ uint32_t s_n, s_base;
+	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (threadIdx.x == 0) s_n = 0;
+	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
+	__syncthreads();
+	for (int q = 0; q < CV3_REC / MSX_BLOCK; q++) {
+		const int64_t i = (int64_t)blockIdx.x * CV3_REC + (int64_t)q * MSX_BLOCK + threadIdx.x;
+		if (i >= n) break;
+		uint32_t key = 0xffffffffu, sup = 0xffu;
+		const int32_t t = tid[i];
+		if (t >= 0) {                                        // msam_coverage.c:42
+			if (covered) covered[t] = 1;                     // :45-49
+			const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
+			int64_t p = pos[i];
+			const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
+			int64_t run_start = -1;
+			bool first = true;
+			auto mark = [&](int64_t s, int64_t e) {
+				if (s < 0) s = 0;
+				if (e > t_len) e = t_len;
+				if (e <= s) return;
+				uint32_t a = (uint32_t)(t_beg + s);
+				const uint32_t b = (uint32_t)(t_beg + e);
+				while (a < b) {                                  // piece by piece, tile by tile
+					const uint32_t tile_end = (a | (CV3_TILE - 1u)) + 1u, pe = b < tile_end ? b : tile_end;
+					const uint32_t k1 = ((a >> CV3_TILE_SHIFT) & 255u) << 24 | (a & (CV3_TILE - 1u)) << 12 | (pe - a - 1u);
+					const uint32_t s1 = a >> (CV3_TILE_SHIFT + 8);
+					if (first) {
+						first = false;
+						key = k1; sup = s1;
+					} else {
+						const uint32_t k = atomicAdd(&s_n, 1u);
+						if (k < CV3_STAGE) { s_extra[k] = k1; s_esup[k] = (uint8_t)s1; }
+					}
+					a = pe;
+				}
+			};
+			for (uint32_t k = ks; k < ke; ++k) {
+				const uint32_t op = cigar[k] & 0xf, wd = cigar[k] >> 4;
+				if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
+					if (run_start < 0) run_start = p;
+					p += wd;
+				} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
+					if (run_start >= 0 && wd > 0) { mark(run_start, p); run_start = -1; }
+					p += wd;
+				}
+			}
+			if (run_start >= 0) mark(run_start, p);
+		}
+		items[i] = key;
+		sups[i] = (uint8_t)sup;
+		atomicAdd(&s_cnt[w][key >> 24], 1u);                 // the first radix pass's digit (an empty slot is a key like any other)
+	}
+	__syncthreads();
+	{
+		const int d = threadIdx.x;
+		hist[(int64_t)d * hist_tiles + blockIdx.x] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
+	}
+	const uint32_t ne = s_n;
+	if (ne == 0) return;
+	if (ne > CV3_STAGE) { if (threadIdx.x == 0) st->overflow = 1; return; }
+	const uint32_t li = blockIdx.x & (CV2_LISTS - 1);
+	if (threadIdx.x == 0) s_base = atomicAdd(&st->list_n[li], ne);
+	__syncthreads();
+	const uint32_t b0 = s_base;
+	if (b0 + ne > list_cap) { if (threadIdx.x == 0) st->overflow = 1; return; }
+	for (uint32_t k = threadIdx.x; k < ne; k += MSX_BLOCK) {
+		items[list_base + (int64_t)li * list_cap + b0 + k] = s_extra[k];
+		sups[list_base + (int64_t)li * list_cap + b0 + k] = s_esup[k];
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_fill_lists3(uint32_t *__restrict__ items, uint8_t *__restrict__ sups, int64_t list_base,
+                                                               uint32_t list_cap, const cv2_state *__restrict__ st) {
+	const uint32_t li = blockIdx.y;
+	const uint32_t used = st->list_n[li] < list_cap ? st->list_n[li] : list_cap;
+	for (uint32_t k = used + blockIdx.x * MSX_BLOCK + threadIdx.x; k < list_cap; k += gridDim.x * MSX_BLOCK) {
+		items[list_base + (int64_t)li * list_cap + k] = 0xffffffffu;
+		sups[list_base + (int64_t)li * list_cap + k] = 0xffu;
+	}
+}
+
+__device__ __forceinline__ uint32_t cv3_tile_at(const uint32_t *items, const uint8_t *sups, int64_t q) {
+	return (uint32_t)sups[q] << 8 | items[q] >> 24;
+}
+
+// start[t]: first sorted item of tile t or a later one, t = 0 .. n_tiles (start[n_tiles]: where the items end)
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts3(const uint32_t *__restrict__ items, const uint8_t *__restrict__ sups, int64_t n_items,
+                                                           int64_t n_tiles, uint32_t *__restrict__ start) {
+	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (t > n_tiles) return;
+	int64_t lo = 0, hi = n_items;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if ((int64_t)cv3_tile_at(items, sups, mid) < t) lo = mid + 1; else hi = mid;
+	}
+	start[t] = (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list3(const uint32_t *__restrict__ start, int64_t n_tiles, int32_t *__restrict__ slot_of,
+                                                               cv2_state *__restrict__ st, uint32_t heavy_from) {
+	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (t >= n_tiles) return;
+	int32_t slot = -1;
+	if (start[t + 1] - start[t] > heavy_from) {
+		const uint32_t k = atomicAdd(&st->n_heavy, 1u);
+		if (k < CV2_HEAVY_CAP) slot = (int32_t)k; else st->overflow = 1;
+	}
+	slot_of[t] = slot;
+}
+
+// (a pre-reduced tile has more items than a chunk holds: inside a chunk it is the tile of the first or of the last item)
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_chunks3(const uint32_t *__restrict__ items, const uint8_t *__restrict__ sups,
+                                                                 const uint32_t *__restrict__ start, int64_t n_tiles,
+                                                                 const int32_t *__restrict__ slot_of, cv2_state *__restrict__ st,
+                                                                 uint32_t *__restrict__ chunk_list) {
+	const int64_t n = (int64_t)start[n_tiles];
+	const int64_t c = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	const int64_t lo = c * CV_CHUNK;
+	bool hit = false;
+	if (st->n_heavy != 0 && lo < n) {
+		const int64_t hi = lo + CV_CHUNK < n ? lo + CV_CHUNK : n;
+		hit = slot_of[cv3_tile_at(items, sups, lo)] >= 0 || slot_of[cv3_tile_at(items, sups, hi - 1)] >= 0;
+	}
+	const unsigned long long m = __ballot(hit);
+	if (m) {                                                 // one append per wave
+		const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
+		uint32_t base = 0;
+		if (lane == lead) base = atomicAdd(&st->n_hchunks, (uint32_t)__popcll(m));
+		base = (uint32_t)__shfl((int)base, lead, 64);
+		if (hit) chunk_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)c;
+	}
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_zero3(int32_t *__restrict__ side, const cv2_state *__restrict__ st) {
+	if (blockIdx.x >= st->n_heavy || blockIdx.x >= CV2_HEAVY_CAP) return;
+	int4 *p = reinterpret_cast<int4 *>(side + (size_t)blockIdx.x * CV3_TILE);
+	for (uint32_t q = threadIdx.x; q < CV3_TILE / 4; q += MSX_BLOCK) p[q] = make_int4(0, 0, 0, 0);
+}
+
+// an item's two marks in a tile's image: +1 where the piece begins, -1 behind its last cell if that is inside the tile
+__device__ __forceinline__ void cv3_mark(int32_t *s_d, uint32_t v) {
+	const uint32_t c = (v >> 12) & (CV3_TILE - 1u), e = c + (v & 4095u) + 1u;
+	atomicAdd(&s_d[c], 1);
+	if (e < CV3_TILE) atomicAdd(&s_d[e], -1);
+}
+
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__restrict__ items, const uint8_t *__restrict__ sups,
+                                                              const uint32_t *__restrict__ start, int64_t n_tiles,
+                                                              const int32_t *__restrict__ slot_of, int32_t *__restrict__ side,
+                                                              const cv2_state *__restrict__ st, const uint32_t *__restrict__ chunk_list) {
+	__shared__ int32_t s_d[CV3_TILE];
+	const int64_t n = (int64_t)start[n_tiles];
+	for (uint32_t ci = blockIdx.x; ci < st->n_hchunks; ci += gridDim.x) {
+		const int64_t lo_c = (int64_t)chunk_list[ci] * CV_CHUNK;
+		if (lo_c >= n) continue;
+		const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
+		int64_t a = lo_c;
+		while (a < hi_c) {                                       // the tiles this chunk touches, by their starts
+			const uint32_t t = cv3_tile_at(items, sups, a);
+			const int64_t e_t = (int64_t)start[t + 1];
+			const int64_t b = e_t < hi_c ? e_t : hi_c;
+			const int32_t slot = slot_of[t];
+			if (slot >= 0) {                                     // (workgroup-uniform)
+				for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) s_d[q] = 0;
+				__syncthreads();
+				for (int64_t q = a + threadIdx.x; q < b; q += MSX_BLOCK) cv3_mark(s_d, items[q]);
+				__syncthreads();
+				int32_t *img = side + (size_t)slot * CV3_TILE;
+				for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) {
+					const int32_t d = s_d[q];
+					if (__ballot(d != 0) != 0ull) atomicAdd(&img[q], d);
+				}
+				__syncthreads();
+			}
+			a = b > a ? b : a + 1;
+		}
+	}
+}
+
+// one workgroup per tile: the pieces' marks as an LDS image (or the pre-reduced image), its inclusive sum, 16-byte stores
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ start,
+                                                           const int32_t *__restrict__ slot_of, const int32_t *__restrict__ side,
+                                                           int64_t total_cells, int32_t *__restrict__ cov) {
+	__shared__ int32_t s_d[CV3_TILE];
+	__shared__ int32_t s_w[MSX_BLOCK / 64];
+	const int64_t t = blockIdx.x;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t ps = start[t], pe = start[t + 1];
+	const int32_t slot = slot_of[t];
+	if (slot >= 0) {
+		const int4 *img = reinterpret_cast<const int4 *>(side + (size_t)slot * CV3_TILE);
+		for (uint32_t q = threadIdx.x; q < CV3_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = img[q];
+	} else {
+		for (uint32_t q = threadIdx.x; q < CV3_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = make_int4(0, 0, 0, 0);
+		__syncthreads();
+		for (uint32_t q = ps + threadIdx.x; q < pe; q += MSX_BLOCK) cv3_mark(s_d, items[q]);
+	}
+	__syncthreads();
+	const int64_t c0 = t << CV3_TILE_SHIFT;
+	int32_t running = 0;
+	for (uint32_t base = 0; base < CV3_TILE; base += MSX_BLOCK * 4) {
+		const uint32_t q = base + threadIdx.x * 4u;
+		int4 v = *reinterpret_cast<const int4 *>(&s_d[q]);
+		v.y += v.x; v.z += v.y; v.w += v.z;
+		int32_t inc = v.w;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int32_t u = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += u;
+		}
+		if (lane == 63) s_w[w] = inc;
+		__syncthreads();
+		int32_t woff = 0, tot = 0;
+		for (int k = 0; k < MSX_BLOCK / 64; k++) { if (k < w) woff += s_w[k]; tot += s_w[k]; }
+		const int32_t add = running + woff + inc - v.w;
+		v.x += add; v.y += add; v.z += add; v.w += add;
+		const int64_t c = c0 + q;
+		if (c + 4 <= total_cells + 1) *reinterpret_cast<int4 *>(&cov[c]) = v;
+		else {
+			if (c <= total_cells) cov[c] = v.x;
+			if (c + 1 <= total_cells) cov[c + 1] = v.y;
+			if (c + 2 <= total_cells) cov[c + 2] = v.z;
+		}
+		running += tot;
+		__syncthreads();
+	}
+}
+
+// returns MSX_OK with *done = 1 when the depths are written, *done = 0 when this form does not apply (or its lists ran full)
+static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len, int32_t *cov,
+                             uint8_t *covered, int *done) {
+	*done = 0;
+	const int64_t n = b->n_records;
+	const int64_t n_tiles = (total_len + 1 + CV3_TILE - 1) >> CV3_TILE_SHIFT;
+	if (n < (1 << 16) || n_targets <= 0 || n_tiles > CV3_MAX_TILES || n >= ((int64_t)1 << 31) - (1 << 24) || getenv("MSX_COV_MARKS") ||
+	    getenv("MSX_COV_STREAMED"))
+		return MSX_OK;
+	int rc;
+	const int64_t n_wg = (n + CV3_REC - 1) / CV3_REC;
+	const int64_t own = n_wg * MSX_SORT_TILE;
+	const uint32_t list_cap = (uint32_t)(((n / 8 + CV2_LISTS - 1) / CV2_LISTS + 1023) & ~(int64_t)1023);
+	const int64_t n_items = own + (int64_t)CV2_LISTS * list_cap;
+	for (int q = 0; q < 2; q++)
+		if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(n_items + 64) * 5))) return rc;
+	const int64_t n_chunks = (n_items + CV_CHUNK - 1) / CV_CHUNK;
+	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)((n_tiles + 1) + n_tiles + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(n_chunks + 64) * 4)))
+		return rc;
+	if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
+	int64_t sort_tiles = 0;
+	if ((rc = msx_sort_keys32_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
+	uint32_t *start = (uint32_t *)ctx->cv_start.p;
+	int32_t *slot_of = (int32_t *)(start + (n_tiles + 1));
+	cv2_state *st = (cv2_state *)(((uintptr_t)(slot_of + n_tiles) + 63) & ~(uintptr_t)63);
+	uint32_t *chunk_list = (uint32_t *)(st + 1);
+	uint32_t *items = (uint32_t *)ctx->cv_key[0].p, *items1 = (uint32_t *)ctx->cv_key[1].p;
+	uint8_t *sups = (uint8_t *)(items + n_items + 64), *sups1 = (uint8_t *)(items1 + n_items + 64);
+	MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
+	msx_time_begin(ctx, MSX_K_COVERAGE);
+	if (own > n) {               // (the last workgroup's tile is not full: its tail holds empty slots)
+		MSX_HIP(ctx, hipMemsetAsync(items + n, 0xff, (size_t)(own - n) * 4, ctx->stream));
+		MSX_HIP(ctx, hipMemsetAsync(sups + n, 0xff, (size_t)(own - n), ctx->stream));
+	}
+	hipLaunchKernelGGL(k_cov_emit3, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar, cov_off,
+	                   covered, items, sups, own, list_cap, st, (uint32_t *)ctx->cv_hist.p, sort_tiles);
+	hipLaunchKernelGGL(k_cov_fill_lists3, dim3(16, CV2_LISTS), dim3(MSX_BLOCK), 0, ctx->stream, items, sups, own, list_cap, st);
+	const int64_t counted = (own > n) ? n_wg - 1 : n_wg;      // (the last workgroup counted only the records it has)
+	if ((rc = msx_sort_k32v8(ctx, items, sups, items1, sups1, n_items, 24, &ctx->cv_hist, &ctx->cv_off, counted, nullptr))) return rc;
+	static const uint32_t heavy_from = getenv("MSX_COV_HEAVY") ? (uint32_t)atoll(getenv("MSX_COV_HEAVY")) : CV2_HEAVY;
+	hipLaunchKernelGGL(k_cov_starts3, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)items, (const uint8_t *)sups, n_items, n_tiles, start);
+	hipLaunchKernelGGL(k_cov_heavy_list3, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)start, n_tiles, slot_of, st, heavy_from);
+	hipLaunchKernelGGL(k_cov_heavy_chunks3, dim3((unsigned)((n_chunks + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)items, (const uint8_t *)sups, (const uint32_t *)start, n_tiles, (const int32_t *)slot_of, st, chunk_list);
+	hipLaunchKernelGGL(k_cov_heavy_zero3, dim3(CV2_HEAVY_CAP), dim3(MSX_BLOCK), 0, ctx->stream, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
+	hipLaunchKernelGGL(k_cov_heavy_add3, dim3((unsigned)(n_chunks < 1024 ? n_chunks : 1024)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)items, (const uint8_t *)sups, (const uint32_t *)start, n_tiles, (const int32_t *)slot_of,
+	                   (int32_t *)ctx->cv_side.p, (const cv2_state *)st, (const uint32_t *)chunk_list);
+	hipLaunchKernelGGL(k_cov_depths3, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items, (const uint32_t *)start,
+	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov);
+	msx_time_end(ctx);
+	MSX_HIP(ctx, hipGetLastError());
+	cv2_state h;
+	MSX_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*done = !h.overflow;
+	return MSX_OK;
+}
+
 extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
                                    int32_t *cov, uint8_t *covered) {
 	if (!ctx || !b || !cov_off || !cov || total_len < 0) return MSX_ERR_ARG;
@@ -490,6 +804,11 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 	const int sign_shift = CV_TILE_SHIFT + tile_bits;          // item = sign << sign_shift | cell; an empty slot: all ones
 	// what this path is for: a batch that is large against the depth array, items of one word.  Everything else takes
 	// the streamed path (zero, accumulate, finish) -- as does a batch whose overflow lists run full.
+	{
+		int done = 0;
+		if ((rc = cov_depths_pieces(ctx, b, cov_off, n_targets, total_len, cov, covered, &done))) return rc;
+		if (done) return MSX_OK;
+	}
 	bool fused = n >= (1 << 16) && n_targets > 0 && sign_shift <= 30 && 2 * n < ((int64_t)1 << 31) && !getenv("MSX_COV_STREAMED");
 	if (fused) {
 		const int64_t n_wg = (n + CV2_REC - 1) / CV2_REC;

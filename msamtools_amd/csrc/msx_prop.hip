@@ -104,6 +104,31 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
+// the same table from 8-bit values that are digits themselves (msx_sort_k32v8's second pass): 16 of them per load
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist8(const uint8_t *__restrict__ vals, int64_t n, uint32_t *__restrict__ hist, int64_t n_tiles) {
+	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t tile = blockIdx.x, base = tile * RS_TILE;
+	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
+	if (base + RS_TILE <= n) {
+		const uint4 v = reinterpret_cast<const uint4 *>(vals + base)[threadIdx.x];
+		const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+#pragma unroll
+			for (int b = 0; b < 4; b++) hist_add(s_cnt[w], (x[q] >> (8 * b)) & 255u, true);
+	} else {
+		for (int q = 0; q < RS_EPT; q++) {
+			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
+			const bool ok = k < n;
+			hist_add(s_cnt[w], ok ? (uint32_t)vals[k] : 0u, ok);
+		}
+	}
+	__syncthreads();
+	const int d = threadIdx.x;
+	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
+}
+
 // Between the two: the per-tile digit counts become positions.  hist[] is laid out digit-major, so the
 // tiles of one digit are a contiguous row: k_rs_rowscan scans every row by itself (256 workgroups, none
 // waiting for another) and leaves the rows' totals in dtot[256]; the scatter kernel adds the exclusive
@@ -146,7 +171,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_rowscan(const uint32_t *__rest
 
 // V: type of the value travelling with each key (uint32_t or unsigned long long); PAIRS = false: keys only;
 // ROWS: hoff holds row-wise scans (k_rs_rowscan) and dtot the rows' totals, instead of one scan over the table
-template <typename V, bool PAIRS, bool SKIP, bool ROWS = false>
+// DV: the digit is the value itself (an 8-bit value that travels with the key: msx_sort_k32v8), not bits of the key
+template <typename V, bool PAIRS, bool SKIP, bool ROWS = false, bool DV = false>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
                                                           const V *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]));
-		const uint32_t d = (key[r] >> shift) & dmask;
+		const uint32_t d = DV ? ((uint32_t)val[r] & dmask) : ((key[r] >> shift) & dmask);
 		unsigned long long m = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < 8; b++) {
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		if ((wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]))) {
-			const uint32_t d = (key[r] >> shift) & dmask;
+			const uint32_t d = DV ? ((uint32_t)val[r] & dmask) : ((key[r] >> shift) & dmask);
 			const uint32_t p = s_dstart[d] + s_cnt[w][d] + pos[r];
 			s_key[p] = key[r];
 			if (PAIRS) s_val[p] = val[r];
@@ -255,7 +281,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
 		if (p < n_out) {
 			const uint32_t k = s_key[p];
-			const uint32_t dst = s_gbase[(k >> shift) & dmask] + p;
+			const uint32_t dst = s_gbase[DV ? ((uint32_t)s_val[PAIRS ? p : 0] & dmask) : ((k >> shift) & dmask)] + p;
 			keys_out[dst] = k;
 			if (PAIRS) vals_out[dst] = s_val[p];
 		}
@@ -1300,6 +1326,35 @@ int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shi
 		cur ^= 1;
 	}
 	*sel = cur;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+// (key, 8-bit value) pairs in the order (value, key bits [shift, shift + 8)): two stable passes, the first on the key's
+// bits (its counts for the first `counted_tiles` tiles already in the table, as with msx_sort_keys32), the second on the
+// value.  The result is back in k0 / v0; *dtot_out: the device table of the 256 values' totals (where each value's run
+// begins is its exclusive sum).
+int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, uint8_t *v0, uint32_t *k1, uint8_t *v1, int64_t n, int shift, msx_buf *hist, msx_buf *off,
+                   int64_t counted_tiles, const uint32_t **dtot_out) {
+	int64_t n_tiles = 0;
+	int rc;
+	if ((rc = msx_sort_keys32_reserve(ctx, n, hist, off, &n_tiles))) return rc;
+	uint32_t *const dtot = (uint32_t *)off->p + 256 * n_tiles + 16;
+	if (n_tiles > counted_tiles)
+		hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)(n_tiles - counted_tiles)), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)k0,
+		                   (const unsigned long long *)nullptr, n, shift, 255u, (uint32_t *)hist->p, n_tiles, counted_tiles);
+	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
+	                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, dtot);
+	hipLaunchKernelGGL((k_rs_scatter<uint8_t, true, false, true, false>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)k0, (const uint8_t *)v0, k1, v1, (const unsigned long long *)nullptr, n, shift, 255u,
+	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)dtot);
+	hipLaunchKernelGGL(k_rs_hist8, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint8_t *)v1, n, (uint32_t *)hist->p, n_tiles);
+	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
+	                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, dtot);
+	hipLaunchKernelGGL((k_rs_scatter<uint8_t, true, false, true, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)k1, (const uint8_t *)v1, k0, v0, (const unsigned long long *)nullptr, n, 0, 255u,
+	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)dtot);
+	if (dtot_out) *dtot_out = dtot;
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }

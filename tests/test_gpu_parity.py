@@ -617,8 +617,51 @@ def test_whole_sample_coverage_parity(ctx, n_groups, n_refs, tl):
     hs = m.HostSynth(4242, n_groups, n_refs, 4)
     db = m.DeviceBatch.synth(ctx, 4242, n_groups, n_refs, 4)
     tlen = [tl] * n_refs
-    got = m.coverage(ctx, db, tlen, whole_sample=True)
     want = orc.coverage(hs, tlen)
-    for t in range(n_refs):
-        assert (got[t] == want[t]).all(), t
+    # the form with one word per run piece (4 K-cell tiles, the tile's top byte beside the key), then the form with a +1
+    # and a -1 mark per run (MSX_COV_MARKS=1: what samples beyond 255 * 2^20 cells take)
+    for env in (None, "MSX_COV_MARKS"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            got = m.coverage(ctx, db, tlen, whole_sample=True)
+        finally:
+            if env:
+                del os.environ[env]
+        for t in range(n_refs):
+            assert (got[t] == want[t]).all(), (env, t)
+    db.free()
+
+
+def test_whole_sample_coverage_long_runs(ctx):
+    """Runs longer than a tile (a contig aligned end to end: cut into one piece per 4 K-cell tile, all but the first through
+    the overflow lists) and runs behind long N skips -- both whole-sample forms and the streamed path against the oracle's
+    per-base counting.  (Every run stays inside its target: beyond it the reference writes outside its array,
+    msam_coverage.c:66-70, and so does the oracle.)"""
+    import msamtools_amd as m
+    hs = m.HostSynth(777, 20000, 40, 4)
+    assert hs.n_records >= 1 << 16                     # (below that msx_coverage_depths takes the streamed path)
+    cig = hs.cigar
+    first = hs.cigar_off[:-1]
+    nops = np.diff(hs.cigar_off)
+    r = np.arange(hs.n_records)
+    long_m = first[(r % 211 == 0)]
+    cig[long_m] = (cig[long_m] & 15) | (9000 << 4)                      # 9000M: three tiles
+    very = first[(r % 4099 == 0)]
+    cig[very] = (cig[very] & 15) | (20000 << 4)                         # five or six tiles
+    skip = first[(nops == 3) & (r % 7 == 0)] + 1
+    cig[skip] = 3 | (6000 << 4)                                         # xM 6000N yM
+    tlen = [30000] * 40
+    want = orc.coverage(hs, tlen)
+    db = m.DeviceBatch.upload(ctx, hs)
+    for env in (None, "MSX_COV_MARKS", "MSX_COV_STREAMED"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            got = m.coverage(ctx, db, tlen, whole_sample=True)
+        finally:
+            if env:
+                del os.environ[env]
+        for t in range(40):
+            assert (got[t] == want[t]).all(), (env, t, np.flatnonzero(got[t] != want[t])[:5])
     db.free()
