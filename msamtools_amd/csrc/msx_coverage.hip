@@ -478,9 +478,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths(const uint32_t *__rest
 // ---------------------------------------------------------------------------------------------------------------------
 // The same, one word per run (round 4, second form): an item is the PIECE of a run inside one 4 K-cell tile,
 //   key = (tile & 255) << 24 | cell in tile << 12 | (length - 1),   sup = tile >> 8   (an 8-bit value beside the key)
-// -- 28 bits of cell address and 12 of length do not fit one word, so the top byte of the tile number travels as a byte
-// of its own through the two radix passes (first the key's top byte, then that byte: msx_sort_k32v8) and 5 bytes move per
-// run where the first form moves 8 (a +1 and a -1 mark).  A run that crosses a tile boundary is cut there (the further
+// -- 28 bits of cell address and 12 of length do not fit one word, so the top byte of the tile number is a byte of its
+// own beside the key: the first radix pass orders by that byte and drops it (from then on the position tells it: every
+// byte value's run begins at a whole sort tile), the second orders every such run by the key's top byte
+// (msx_sort_k32v8); 5 + 4 bytes move per run where the first form moves 8 + 8 (a +1 and a -1 mark, two passes).
+// A run that crosses a tile boundary is cut there (the further
 // pieces go to the overflow lists, like the runs behind a D or N): every tile then holds every piece that covers it,
 // the depth at its first cell included, and no depth is carried from tile to tile.  Up to 255 * 2^20 cells (the byte 255
 // marks an empty slot, which sorts behind everything); larger samples take the first form.
@@ -489,10 +491,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths(const uint32_t *__rest
 #define CV3_REC MSX_SORT_TILE           // records per workgroup of k_cov_emit3: one sort tile of own slots
 #define CV3_STAGE 2048
 #define CV3_MAX_TILES (255 * 256)
+#define CV3_FLIGHT 4                    // records a thread of k_cov_emit3 has in flight (8: 86 registers, 5 waves per SIMD, 467 us against 381)
+#define CV3_PICK(a) (u == 0 ? a[0] : u == 1 ? a[1] : u == 2 ? a[2] : a[3])
+
+// (first cell, length) of every target in one 8-byte word: the record loop gathers it once per record
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_targets3(const int64_t *__restrict__ cov_off, int32_t n_targets, uint2 *__restrict__ targets) {
+	const int32_t t = (int32_t)(blockIdx.x * MSX_BLOCK + threadIdx.x);
+	if (t < n_targets) targets[t] = make_uint2((uint32_t)cov_off[t], (uint32_t)(cov_off[t + 1] - cov_off[t]));
+}
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit3(int64_t n, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
                                                          const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
-                                                         const int64_t *__restrict__ cov_off, uint8_t *__restrict__ covered,
+                                                         const uint2 *__restrict__ targets, uint8_t *__restrict__ covered,
                                                          uint32_t *__restrict__ items, uint8_t *__restrict__ sups, int64_t list_base,
                                                          uint32_t list_cap, cv2_state *__restrict__ st, uint32_t *__restrict__ hist,
                                                          int64_t hist_tiles) {
@@ -504,53 +514,83 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit3(int64_t n, const int32_
 	if (threadIdx.x == 0) s_n = 0;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	__syncthreads();
-	for (int q = 0; q < CV3_REC / MSX_BLOCK; q++) {
-		const int64_t i = (int64_t)blockIdx.x * CV3_REC + (int64_t)q * MSX_BLOCK + threadIdx.x;
-		if (i >= n) break;
-		uint32_t key = 0xffffffffu, sup = 0xffu;
-		const int32_t t = tid[i];
-		if (t >= 0) {                                        // msam_coverage.c:42
-			if (covered) covered[t] = 1;                     // :45-49
-			const int64_t t_beg = cov_off[t], t_len = cov_off[t + 1] - t_beg;
-			int64_t p = pos[i];
-			const uint32_t ks = cigar_off[i], ke = cigar_off[i + 1];
-			int64_t run_start = -1;
-			bool first = true;
-			auto mark = [&](int64_t s, int64_t e) {
-				if (s < 0) s = 0;
-				if (e > t_len) e = t_len;
-				if (e <= s) return;
-				uint32_t a = (uint32_t)(t_beg + s);
-				const uint32_t b = (uint32_t)(t_beg + e);
-				while (a < b) {                                  // piece by piece, tile by tile
-					const uint32_t tile_end = (a | (CV3_TILE - 1u)) + 1u, pe = b < tile_end ? b : tile_end;
-					const uint32_t k1 = ((a >> CV3_TILE_SHIFT) & 255u) << 24 | (a & (CV3_TILE - 1u)) << 12 | (pe - a - 1u);
-					const uint32_t s1 = a >> (CV3_TILE_SHIFT + 8);
-					if (first) {
-						first = false;
-						key = k1; sup = s1;
-					} else {
-						const uint32_t k = atomicAdd(&s_n, 1u);
-						if (k < CV3_STAGE) { s_extra[k] = k1; s_esup[k] = (uint8_t)s1; }
-					}
-					a = pe;
-				}
-			};
-			for (uint32_t k = ks; k < ke; ++k) {
-				const uint32_t op = cigar[k] & 0xf, wd = cigar[k] >> 4;
-				if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
-					if (run_start < 0) run_start = p;
-					p += wd;
-				} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
-					if (run_start >= 0 && wd > 0) { mark(run_start, p); run_start = -1; }
-					p += wd;
-				}
-			}
-			if (run_start >= 0) mark(run_start, p);
+	// Four records per thread at a time: their fields (straight-line loads, indices clamped instead of branches), then what
+	// those point at (the target's first cell and length, the first CIGAR word), then ONE copy of the walk run four times
+	// over values picked out of the four -- with one record after the other every load of the chain was exposed and a wave
+	// spent 9 K cycles per record; with the walk written out four times the code no longer fit and it got slower.
+	for (int q0 = 0; q0 < CV3_REC / MSX_BLOCK; q0 += CV3_FLIGHT) {
+		const int64_t i0 = (int64_t)blockIdx.x * CV3_REC + (int64_t)q0 * MSX_BLOCK + threadIdx.x;
+		if (i0 >= n) break;
+		int32_t t4[CV3_FLIGHT], p4[CV3_FLIGHT];
+		uint32_t ks4[CV3_FLIGHT], ke4[CV3_FLIGHT], c04[CV3_FLIGHT];
+		uint2 tt4[CV3_FLIGHT];
+#pragma unroll
+		for (int u = 0; u < CV3_FLIGHT; u++) {
+			const int64_t i = i0 + (int64_t)u * MSX_BLOCK, ic = i < n ? i : n - 1;
+			t4[u] = tid[ic];
+			p4[u] = pos[ic];
+			ks4[u] = cigar_off[ic];
+			ke4[u] = cigar_off[ic + 1];
 		}
-		items[i] = key;
-		sups[i] = (uint8_t)sup;
-		atomicAdd(&s_cnt[w][key >> 24], 1u);                 // the first radix pass's digit (an empty slot is a key like any other)
+#pragma unroll
+		for (int u = 0; u < CV3_FLIGHT; u++) {
+			if (i0 + (int64_t)u * MSX_BLOCK >= n) t4[u] = -1;
+			tt4[u] = targets[t4[u] >= 0 ? t4[u] : 0];
+			c04[u] = cigar[ke4[u] > ks4[u] ? ks4[u] : 0u];
+		}
+#pragma nounroll
+		for (int u = 0; u < CV3_FLIGHT; u++) {
+			const int64_t i = i0 + (int64_t)u * MSX_BLOCK;
+			if (i >= n) break;
+			const int32_t t = CV3_PICK(t4);
+			uint32_t key = 0xffffffffu, sup = 0xffu;
+			if (t >= 0) {                                        // msam_coverage.c:42
+				if (covered) covered[t] = 1;                     // :45-49
+				const uint2 tt = CV3_PICK(tt4);    // (first cell, length)
+				const int64_t t_beg = tt.x, t_len = tt.y;
+				int64_t p = CV3_PICK(p4);
+				const uint32_t ks = CV3_PICK(ks4);
+				const uint32_t ke = CV3_PICK(ke4);
+				const uint32_t c0 = CV3_PICK(c04);
+				int64_t run_start = -1;
+				bool first = true;
+				auto mark = [&](int64_t s, int64_t e) {
+					if (s < 0) s = 0;
+					if (e > t_len) e = t_len;
+					if (e <= s) return;
+					uint32_t a = (uint32_t)(t_beg + s);
+					const uint32_t b = (uint32_t)(t_beg + e);
+					while (a < b) {                                  // piece by piece, tile by tile
+						const uint32_t tile_end = (a | (CV3_TILE - 1u)) + 1u, pe = b < tile_end ? b : tile_end;
+						const uint32_t k1 = ((a >> CV3_TILE_SHIFT) & 255u) << 24 | (a & (CV3_TILE - 1u)) << 12 | (pe - a - 1u);
+						const uint32_t s1 = a >> (CV3_TILE_SHIFT + 8);
+						if (first) {
+							first = false;
+							key = k1; sup = s1;
+						} else {
+							const uint32_t k = atomicAdd(&s_n, 1u);
+							if (k < CV3_STAGE) { s_extra[k] = k1; s_esup[k] = (uint8_t)s1; }
+						}
+						a = pe;
+					}
+				};
+				for (uint32_t k = ks; k < ke; ++k) {
+					const uint32_t cw = k == ks ? c0 : cigar[k];
+					const uint32_t op = cw & 0xf, wd = cw >> 4;
+					if (op == MSX_OP_MATCH || op == MSX_OP_EQUAL || op == MSX_OP_DIFF) {   // :63-74
+						if (run_start < 0) run_start = p;
+						p += wd;
+					} else if (op == MSX_OP_DEL || op == MSX_OP_REF_SKIP) {                // :75-78
+						if (run_start >= 0 && wd > 0) { mark(run_start, p); run_start = -1; }
+						p += wd;
+					}
+				}
+				if (run_start >= 0) mark(run_start, p);
+			}
+			items[i] = key;
+			sups[i] = (uint8_t)sup;
+			atomicAdd(&s_cnt[w][sup], 1u);                       // the first radix pass's digit (an empty slot is a key like any other)
+		}
 	}
 	__syncthreads();
 	{
@@ -581,21 +621,28 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_fill_lists3(uint32_t *__restr
 	}
 }
 
-__device__ __forceinline__ uint32_t cv3_tile_at(const uint32_t *items, const uint8_t *sups, int64_t q) {
-	return (uint32_t)sups[q] << 8 | items[q] >> 24;
+// lay[0 .. 256): where each top byte's bucket begins in the sorted items, lay[256 .. 512): how many items it holds
+__device__ __forceinline__ uint32_t cv3_bucket_at(const uint32_t *lay, uint32_t q) {
+	uint32_t lo = 0, hi = 256;                               // the last bucket that begins at or before q
+	while (lo + 1 < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (lay[mid] <= q) lo = mid; else hi = mid;
+	}
+	return lo;
 }
 
-// start[t]: first sorted item of tile t or a later one, t = 0 .. n_tiles (start[n_tiles]: where the items end)
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts3(const uint32_t *__restrict__ items, const uint8_t *__restrict__ sups, int64_t n_items,
-                                                           int64_t n_tiles, uint32_t *__restrict__ start) {
-	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	if (t > n_tiles) return;
-	int64_t lo = 0, hi = n_items;
+// start[2 t], start[2 t + 1]: the sorted items of tile t
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay, int64_t n_tiles,
+                                                           uint32_t *__restrict__ start) {
+	const int64_t q = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
+	if (q >= 2 * n_tiles) return;
+	const uint32_t t = (uint32_t)(q >> 1), sup = t >> 8, want = (t & 255u) + (uint32_t)(q & 1);
+	uint32_t lo = lay[sup], hi = lo + lay[256 + sup];
 	while (lo < hi) {
-		const int64_t mid = (lo + hi) >> 1;
-		if ((int64_t)cv3_tile_at(items, sups, mid) < t) lo = mid + 1; else hi = mid;
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		if ((items[mid] >> 24) < want) lo = mid + 1; else hi = mid;
 	}
-	start[t] = (uint32_t)lo;
+	start[q] = lo;
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list3(const uint32_t *__restrict__ start, int64_t n_tiles, int32_t *__restrict__ slot_of,
@@ -603,25 +650,27 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list3(const uint32_t *_
 	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (t >= n_tiles) return;
 	int32_t slot = -1;
-	if (start[t + 1] - start[t] > heavy_from) {
+	if (start[2 * t + 1] - start[2 * t] > heavy_from) {
 		const uint32_t k = atomicAdd(&st->n_heavy, 1u);
 		if (k < CV2_HEAVY_CAP) slot = (int32_t)k; else st->overflow = 1;
 	}
 	slot_of[t] = slot;
 }
 
-// (a pre-reduced tile has more items than a chunk holds: inside a chunk it is the tile of the first or of the last item)
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_chunks3(const uint32_t *__restrict__ items, const uint8_t *__restrict__ sups,
-                                                                 const uint32_t *__restrict__ start, int64_t n_tiles,
-                                                                 const int32_t *__restrict__ slot_of, cv2_state *__restrict__ st,
-                                                                 uint32_t *__restrict__ chunk_list) {
-	const int64_t n = (int64_t)start[n_tiles];
+// (a pre-reduced tile has more items than a chunk holds: inside a chunk it is the tile of the first or of the last item;
+//  an empty slot at the end of a bucket reads as that bucket's tile 255, which does no harm)
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_chunks3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay,
+                                                                 int64_t n_tiles, const int32_t *__restrict__ slot_of,
+                                                                 cv2_state *__restrict__ st, uint32_t *__restrict__ chunk_list) {
+	const int64_t n = (int64_t)lay[255];                     // (bucket 255: the empty slots)
 	const int64_t c = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	const int64_t lo = c * CV_CHUNK;
 	bool hit = false;
 	if (st->n_heavy != 0 && lo < n) {
 		const int64_t hi = lo + CV_CHUNK < n ? lo + CV_CHUNK : n;
-		hit = slot_of[cv3_tile_at(items, sups, lo)] >= 0 || slot_of[cv3_tile_at(items, sups, hi - 1)] >= 0;
+		const int64_t ta = (int64_t)(cv3_bucket_at(lay, (uint32_t)lo) << 8 | items[lo] >> 24);
+		const int64_t tb = (int64_t)(cv3_bucket_at(lay, (uint32_t)(hi - 1)) << 8 | items[hi - 1] >> 24);
+		hit = (ta < n_tiles && slot_of[ta] >= 0) || (tb < n_tiles && slot_of[tb] >= 0);
 	}
 	const unsigned long long m = __ballot(hit);
 	if (m) {                                                 // one append per wave
@@ -640,28 +689,38 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_zero3(int32_t *__restri
 }
 
 // an item's two marks in a tile's image: +1 where the piece begins, -1 behind its last cell if that is inside the tile
+// (all ones: an empty slot -- no piece reaches beyond its tile, so no piece reads like that)
 __device__ __forceinline__ void cv3_mark(int32_t *s_d, uint32_t v) {
+	if (v == 0xffffffffu) return;
 	const uint32_t c = (v >> 12) & (CV3_TILE - 1u), e = c + (v & 4095u) + 1u;
 	atomicAdd(&s_d[c], 1);
 	if (e < CV3_TILE) atomicAdd(&s_d[e], -1);
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__restrict__ items, const uint8_t *__restrict__ sups,
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay,
                                                               const uint32_t *__restrict__ start, int64_t n_tiles,
                                                               const int32_t *__restrict__ slot_of, int32_t *__restrict__ side,
                                                               const cv2_state *__restrict__ st, const uint32_t *__restrict__ chunk_list) {
 	__shared__ int32_t s_d[CV3_TILE];
-	const int64_t n = (int64_t)start[n_tiles];
+	const int64_t n = (int64_t)lay[255];
 	for (uint32_t ci = blockIdx.x; ci < st->n_hchunks; ci += gridDim.x) {
 		const int64_t lo_c = (int64_t)chunk_list[ci] * CV_CHUNK;
 		if (lo_c >= n) continue;
 		const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
 		int64_t a = lo_c;
-		while (a < hi_c) {                                       // the tiles this chunk touches, by their starts
-			const uint32_t t = cv3_tile_at(items, sups, a);
-			const int64_t e_t = (int64_t)start[t + 1];
+		while (a < hi_c) {                                       // the tiles this chunk touches, by their ends
+			const uint32_t sup = cv3_bucket_at(lay, (uint32_t)a);
+			const int64_t bucket_end = (int64_t)lay[sup] + lay[256 + sup];
+			if (a >= bucket_end) {                               // the empty slots behind a bucket's items: on to the next bucket
+				uint32_t nx = sup + 1;
+				while (nx < 255 && lay[256 + nx] == 0) nx++;
+				a = (int64_t)lay[nx];
+				continue;
+			}
+			const uint32_t t = sup << 8 | items[a] >> 24;
+			const int64_t e_t = (int64_t)start[2 * (int64_t)t + 1];
 			const int64_t b = e_t < hi_c ? e_t : hi_c;
-			const int32_t slot = slot_of[t];
+			const int32_t slot = (int64_t)t < n_tiles ? slot_of[t] : -1;
 			if (slot >= 0) {                                     // (workgroup-uniform)
 				for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) s_d[q] = 0;
 				__syncthreads();
@@ -687,7 +746,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths3(const uint32_t *__res
 	__shared__ int32_t s_w[MSX_BLOCK / 64];
 	const int64_t t = blockIdx.x;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const uint32_t ps = start[t], pe = start[t + 1];
+	const uint32_t ps = start[2 * t], pe = start[2 * t + 1];
 	const int32_t slot = slot_of[t];
 	if (slot >= 0) {
 		const int4 *img = reinterpret_cast<const int4 *>(side + (size_t)slot * CV3_TILE);
@@ -742,41 +801,48 @@ static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *co
 	const int64_t own = n_wg * MSX_SORT_TILE;
 	const uint32_t list_cap = (uint32_t)(((n / 8 + CV2_LISTS - 1) / CV2_LISTS + 1023) & ~(int64_t)1023);
 	const int64_t n_items = own + (int64_t)CV2_LISTS * list_cap;
-	for (int q = 0; q < 2; q++)
-		if ((rc = msx_reserve(ctx, &ctx->cv_key[q], (size_t)(n_items + 64) * 5))) return rc;
-	const int64_t n_chunks = (n_items + CV_CHUNK - 1) / CV_CHUNK;
-	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)((n_tiles + 1) + n_tiles + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(n_chunks + 64) * 4)))
+	const int64_t n_ub = msx_sort_k32v8_bound(n_items);       // (every bucket of the sorted items begins at a whole sort tile)
+	// cv_key[0]: the items and their top bytes, later the sorted items; cv_key[1]: the items between the passes
+	if ((rc = msx_reserve(ctx, &ctx->cv_key[0], (size_t)(n_ub + 64) * 4 + (size_t)n_items + 64))) return rc;
+	if ((rc = msx_reserve(ctx, &ctx->cv_key[1], (size_t)(n_ub + 64) * 4))) return rc;
+	const int64_t n_chunks = (n_ub + CV_CHUNK - 1) / CV_CHUNK;
+	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * n_tiles + n_tiles + 512 + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(n_chunks + 64) * 4 +
+	                                                (size_t)n_targets * 8 + 64)))
 		return rc;
 	if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
 	int64_t sort_tiles = 0;
-	if ((rc = msx_sort_keys32_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
+	if ((rc = msx_sort_k32v8_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
 	uint32_t *start = (uint32_t *)ctx->cv_start.p;
-	int32_t *slot_of = (int32_t *)(start + (n_tiles + 1));
-	cv2_state *st = (cv2_state *)(((uintptr_t)(slot_of + n_tiles) + 63) & ~(uintptr_t)63);
+	int32_t *slot_of = (int32_t *)(start + 2 * n_tiles);
+	uint32_t *lay = (uint32_t *)(slot_of + n_tiles);
+	cv2_state *st = (cv2_state *)(((uintptr_t)(lay + 512) + 63) & ~(uintptr_t)63);
 	uint32_t *chunk_list = (uint32_t *)(st + 1);
+	uint2 *targets = (uint2 *)(((uintptr_t)(chunk_list + n_chunks + 64) + 15) & ~(uintptr_t)15);
 	uint32_t *items = (uint32_t *)ctx->cv_key[0].p, *items1 = (uint32_t *)ctx->cv_key[1].p;
-	uint8_t *sups = (uint8_t *)(items + n_items + 64), *sups1 = (uint8_t *)(items1 + n_items + 64);
+	uint8_t *sups = (uint8_t *)(items + n_ub + 64);
 	MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
 	msx_time_begin(ctx, MSX_K_COVERAGE);
 	if (own > n) {               // (the last workgroup's tile is not full: its tail holds empty slots)
 		MSX_HIP(ctx, hipMemsetAsync(items + n, 0xff, (size_t)(own - n) * 4, ctx->stream));
 		MSX_HIP(ctx, hipMemsetAsync(sups + n, 0xff, (size_t)(own - n), ctx->stream));
 	}
-	hipLaunchKernelGGL(k_cov_emit3, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar, cov_off,
-	                   covered, items, sups, own, list_cap, st, (uint32_t *)ctx->cv_hist.p, sort_tiles);
+	hipLaunchKernelGGL(k_cov_targets3, dim3((unsigned)((n_targets + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, cov_off, n_targets,
+	                   targets);
+	hipLaunchKernelGGL(k_cov_emit3, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar,
+	                   (const uint2 *)targets, covered, items, sups, own, list_cap, st, (uint32_t *)ctx->cv_hist.p, sort_tiles);
 	hipLaunchKernelGGL(k_cov_fill_lists3, dim3(16, CV2_LISTS), dim3(MSX_BLOCK), 0, ctx->stream, items, sups, own, list_cap, st);
 	const int64_t counted = (own > n) ? n_wg - 1 : n_wg;      // (the last workgroup counted only the records it has)
-	if ((rc = msx_sort_k32v8(ctx, items, sups, items1, sups1, n_items, 24, &ctx->cv_hist, &ctx->cv_off, counted, nullptr))) return rc;
+	if ((rc = msx_sort_k32v8(ctx, items, sups, items1, n_items, 24, &ctx->cv_hist, &ctx->cv_off, counted, 255, lay))) return rc;
 	static const uint32_t heavy_from = getenv("MSX_COV_HEAVY") ? (uint32_t)atoll(getenv("MSX_COV_HEAVY")) : CV2_HEAVY;
-	hipLaunchKernelGGL(k_cov_starts3, dim3((unsigned)((n_tiles + 1 + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)items, (const uint8_t *)sups, n_items, n_tiles, start);
+	hipLaunchKernelGGL(k_cov_starts3, dim3((unsigned)((2 * n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)items, (const uint32_t *)lay, n_tiles, start);
 	hipLaunchKernelGGL(k_cov_heavy_list3, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                   (const uint32_t *)start, n_tiles, slot_of, st, heavy_from);
 	hipLaunchKernelGGL(k_cov_heavy_chunks3, dim3((unsigned)((n_chunks + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)items, (const uint8_t *)sups, (const uint32_t *)start, n_tiles, (const int32_t *)slot_of, st, chunk_list);
+	                   (const uint32_t *)items, (const uint32_t *)lay, n_tiles, (const int32_t *)slot_of, st, chunk_list);
 	hipLaunchKernelGGL(k_cov_heavy_zero3, dim3(CV2_HEAVY_CAP), dim3(MSX_BLOCK), 0, ctx->stream, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
 	hipLaunchKernelGGL(k_cov_heavy_add3, dim3((unsigned)(n_chunks < 1024 ? n_chunks : 1024)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)items, (const uint8_t *)sups, (const uint32_t *)start, n_tiles, (const int32_t *)slot_of,
+	                   (const uint32_t *)items, (const uint32_t *)lay, (const uint32_t *)start, n_tiles, (const int32_t *)slot_of,
 	                   (int32_t *)ctx->cv_side.p, (const cv2_state *)st, (const uint32_t *)chunk_list);
 	hipLaunchKernelGGL(k_cov_depths3, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items, (const uint32_t *)start,
 	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov);

@@ -236,8 +236,10 @@ int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes);
 int msx_sort_keys32_reserve(msx_ctx *ctx, int64_t n, msx_buf *hist, msx_buf *off, int64_t *n_tiles_out);
 int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shift0, int bits, msx_buf *hist, msx_buf *off,
                     int *sel, int64_t counted_tiles = 0);
-int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, uint8_t *v0, uint32_t *k1, uint8_t *v1, int64_t n, int shift, msx_buf *hist, msx_buf *off,
-                   int64_t counted_tiles, const uint32_t **dtot_out);
+int64_t msx_sort_k32v8_bound(int64_t n);
+int msx_sort_k32v8_reserve(msx_ctx *ctx, int64_t n, msx_buf *hist, msx_buf *off, int64_t *n_tiles_out);
+int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, const uint8_t *v0, uint32_t *k1, int64_t n, int shift, msx_buf *hist, msx_buf *off,
+                   int64_t counted_tiles, int skip_bucket, uint32_t *lay);
 // msx_dist.hip: in-place all-reduce(sum) on the ctx stream; no-ops without a communicator
 int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p);
 int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count);

@@ -104,11 +104,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
-// the same table from 8-bit values that are digits themselves (msx_sort_k32v8's second pass): 16 of them per load
-__global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist8(const uint8_t *__restrict__ vals, int64_t n, uint32_t *__restrict__ hist, int64_t n_tiles) {
+// the digit counts of 8-bit values that are digits themselves (msx_sort_k32v8's first pass): 16 of them per load
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist8(const uint8_t *__restrict__ vals, int64_t n, uint32_t *__restrict__ hist, int64_t n_tiles,
+                                                        int64_t tile0) {
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int64_t tile = blockIdx.x, base = tile * RS_TILE;
+	const int64_t tile = blockIdx.x + tile0, base = tile * RS_TILE;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	if (base + RS_TILE <= n) {
 		const uint4 v = reinterpret_cast<const uint4 *>(vals + base)[threadIdx.x];
@@ -127,6 +128,35 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist8(const uint8_t *__restric
 	__syncthreads();
 	const int d = threadIdx.x;
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
+}
+
+// msx_sort_k32v8 between its passes: the slots between a bucket's keys and the next bucket's first tile, and everything
+// behind the last bucket up to n_ub, become empty keys (all ones); lay[d] = where bucket d begins, lay[256 + d] = its keys
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_bucket_pad(const uint32_t *__restrict__ btot, uint32_t *__restrict__ keys, int64_t n_ub,
+                                                             uint32_t *__restrict__ lay) {
+	__shared__ uint32_t s_wsum[MSX_BLOCK / 64];
+	__shared__ uint32_t s_lo, s_hi;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, d = threadIdx.x;
+	const uint32_t cnt = btot[d], padded = (cnt + RS_TILE - 1) & ~(uint32_t)(RS_TILE - 1);
+	uint32_t inc = padded;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(inc, o, 64);
+		if (lane >= o) inc += t;
+	}
+	if (lane == 63) s_wsum[w] = inc;
+	__syncthreads();
+	for (int q = 0; q < w; q++) inc += s_wsum[q];
+	if (blockIdx.x == 0) { lay[d] = inc - padded; lay[256 + d] = cnt; }
+	if (d == (int)blockIdx.x) { s_lo = inc - padded + cnt; s_hi = inc; }
+	if (blockIdx.x >= 256 && d == 255) {                     // the tail, a slice per workgroup
+		const uint32_t parts = gridDim.x - 256, part = blockIdx.x - 256, len = (uint32_t)n_ub - inc;
+		const uint32_t per = ((len + parts - 1) / parts + 3u) & ~3u;
+		s_lo = inc + (part * per < len ? part * per : len);
+		s_hi = inc + ((part + 1) * per < len ? (part + 1) * per : len);
+	}
+	__syncthreads();
+	for (uint32_t q = s_lo + threadIdx.x; q < s_hi; q += MSX_BLOCK) keys[q] = 0xffffffffu;
 }
 
 // Between the two: the per-tile digit counts become positions.  hist[] is laid out digit-major, so the
@@ -171,8 +201,15 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_rowscan(const uint32_t *__rest
 
 // V: type of the value travelling with each key (uint32_t or unsigned long long); PAIRS = false: keys only;
 // ROWS: hoff holds row-wise scans (k_rs_rowscan) and dtot the rows' totals, instead of one scan over the table
-// DV: the digit is the value itself (an 8-bit value that travels with the key: msx_sort_k32v8), not bits of the key
-template <typename V, bool PAIRS, bool SKIP, bool ROWS = false, bool DV = false>
+// The last three serve msx_sort_k32v8 (keys with an 8-bit value beside them, ordered by (value, key digit)):
+// DV: the digit is the value itself, and only the keys are written -- each value's run (a BUCKET) begins at a whole
+//     tile, its length rounded up (the slots in between are filled by k_rs_bucket_pad), so the bucket is known from
+//     the position from then on;
+// SEG: the pass inside the buckets: a tile lies in one bucket (btot[]: the buckets' lengths), and its digit runs go
+//     to  bucket start + (the bucket's keys of smaller digits) + (the digit's keys in the bucket's earlier tiles) --
+//     all three from the row-wise scans of the digit counts (hoff) at the bucket's first tile, this tile and the next
+//     bucket's first tile.  Tiles behind the last bucket and the tiles of bucket `skip_bucket` have nothing to do.
+template <typename V, bool PAIRS, bool SKIP, bool ROWS = false, bool DV = false, bool SEG = false>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
                                                           const V *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
@@ -180,7 +217,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
                                                           const unsigned long long *__restrict__ n_ptr, int64_t n_host,
                                                           int shift, uint32_t dmask,
                                                           const uint32_t *__restrict__ hoff, int64_t n_tiles,
-                                                          const uint32_t *__restrict__ dtot = nullptr) {
+                                                          const uint32_t *__restrict__ dtot = nullptr,
+                                                          const uint32_t *__restrict__ btot = nullptr, int skip_bucket = -1) {
 	__shared__ uint32_t s_key[RS_TILE];
 	__shared__ V s_val[PAIRS ? RS_TILE : 1];
 	__shared__ uint32_t s_nvalid;
@@ -195,18 +233,49 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	if (base >= E) return;
 	if (n_ptr) n_tiles = (E + RS_TILE - 1) / RS_TILE;      // the table's stride, as k_rs_hist laid it out
 	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
+	__shared__ uint32_t s_bfirst, s_bnext;            // SEG: the bucket's first tile, the next bucket's first tile
+	if (SEG) {
+		// which bucket is this tile in?  (thread d: bucket d)
+		const int d = threadIdx.x;
+		const uint32_t bp = (btot[d] + RS_TILE - 1) / RS_TILE;
+		uint32_t binc = bp;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(binc, o, 64);
+			if (lane >= o) binc += t;
+		}
+		if (lane == 63) s_wsum[w] = binc;
+		if (d == 0) s_bfirst = 0xffffffffu;
+		__syncthreads();
+		for (int q = 0; q < w; q++) binc += s_wsum[q];
+		if ((uint32_t)tile >= binc - bp && (uint32_t)tile < binc && d != skip_bucket) { s_bfirst = binc - bp; s_bnext = binc; }
+		__syncthreads();
+		if (s_bfirst == 0xffffffffu) return;
+	}
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	// 1. all loads up front; wave w owns elements [w*RS_EPT*64, (w+1)*RS_EPT*64) of the tile
 	uint32_t key[RS_EPT];
 	V val[RS_EPT];
 	const uint32_t wbase = (uint32_t)w * (RS_EPT * 64) + (uint32_t)lane;
+	// (DV: the tile's 8-bit values as one 16-byte load per thread, handed to their rows through LDS -- sixteen one-byte
+	//  loads per thread cost as many memory instructions as the keys)
+	__shared__ uint4 s_v8[(DV && sizeof(V) == 1) ? RS_TILE / 16 : 1];
+	const bool v8 = DV && sizeof(V) == 1 && n_here == RS_TILE;
+	if (v8) s_v8[threadIdx.x] = reinterpret_cast<const uint4 *>(vals_in + base)[threadIdx.x];
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const uint32_t i = wbase + (uint32_t)r * 64u;
 		key[r] = SKIP ? RS_NOKEY : 0u; val[r] = 0;
 		if (i < n_here) {
 			key[r] = keys_in[base + i];
-			if (PAIRS) val[r] = vals_in[base + i];
+			if (PAIRS && !v8) val[r] = vals_in[base + i];
+		}
+	}
+	if (DV && sizeof(V) == 1) {
+		__syncthreads();
+		if (v8) {
+#pragma unroll
+			for (int r = 0; r < RS_EPT; r++) val[r] = (V) reinterpret_cast<const uint8_t *>(s_v8)[wbase + (uint32_t)r * 64u];
 		}
 	}
 	// 2. rank inside the wave
@@ -242,8 +311,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 			const uint32_t t = __shfl_up(inc, o, 64);
 			if (lane >= o) inc += t;
 		}
-		// (ROWS: the same scan over the digits' global totals gives the position where each digit's run begins)
-		const uint32_t gt = ROWS ? dtot[d] : 0u;
+		// (ROWS: the same scan over the digits' global totals gives the position where each digit's run begins;
+		//  SEG: over the digits' totals inside the bucket)
+		uint32_t p_first = 0;
+		if (SEG) p_first = hoff[(int64_t)d * n_tiles + s_bfirst];
+		const uint32_t gt = SEG ? ((s_bnext < (uint32_t)n_tiles ? hoff[(int64_t)d * n_tiles + s_bnext] : dtot[d]) - p_first)
+		                        : ROWS ? (DV ? ((dtot[d] + RS_TILE - 1) & ~(uint32_t)(RS_TILE - 1)) : dtot[d]) : 0u;
 		uint32_t ginc = gt;
 		if (ROWS) {
 #pragma unroll
@@ -260,6 +333,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		const uint32_t ds = woff + inc - tot;
 		s_dstart[d] = ds;
 		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] + (ROWS ? goff + ginc - gt : 0u) - ds;
+		if (SEG) s_gbase[d] += s_bfirst * RS_TILE - p_first;
 		if (d == 255) s_nvalid = ds + tot;
 	}
 	__syncthreads();
@@ -283,7 +357,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 			const uint32_t k = s_key[p];
 			const uint32_t dst = s_gbase[DV ? ((uint32_t)s_val[PAIRS ? p : 0] & dmask) : ((k >> shift) & dmask)] + p;
 			keys_out[dst] = k;
-			if (PAIRS) vals_out[dst] = s_val[p];
+			if (PAIRS && !DV) vals_out[dst] = s_val[p];
 		}
 	}
 }
@@ -1297,7 +1371,7 @@ int msx_sort_keys32_reserve(msx_ctx *ctx, int64_t n, msx_buf *hist, msx_buf *off
 	const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
 	int rc;
 	if ((rc = msx_reserve(ctx, hist, (size_t)(256 * n_tiles + 16) * 4))) return rc;
-	if ((rc = msx_reserve(ctx, off, (size_t)(256 * n_tiles + 16 + 256) * 4))) return rc;
+	if ((rc = msx_reserve(ctx, off, (size_t)(256 * n_tiles + 16 + 512) * 4))) return rc;
 	if (n_tiles_out) *n_tiles_out = n_tiles;
 	return MSX_OK;
 }
@@ -1330,31 +1404,42 @@ int msx_sort_keys32(msx_ctx *ctx, uint32_t *k0, uint32_t *k1, int64_t n, int shi
 	return MSX_OK;
 }
 
-// (key, 8-bit value) pairs in the order (value, key bits [shift, shift + 8)): two stable passes, the first on the key's
-// bits (its counts for the first `counted_tiles` tiles already in the table, as with msx_sort_keys32), the second on the
-// value.  The result is back in k0 / v0; *dtot_out: the device table of the 256 values' totals (where each value's run
-// begins is its exclusive sum).
-int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, uint8_t *v0, uint32_t *k1, uint8_t *v1, int64_t n, int shift, msx_buf *hist, msx_buf *off,
-                   int64_t counted_tiles, const uint32_t **dtot_out) {
-	int64_t n_tiles = 0;
+// Keys with an 8-bit value beside them, into the order (value, key bits [shift, shift + 8)), the value dropped on the way:
+// pass 1 by the value (its digit counts for the first `counted_tiles` tiles already in hist[digit * n_tiles + tile], as
+// with msx_sort_keys32) writes the keys only, every value's run -- a bucket -- beginning at a whole tile; pass 2 orders
+// each bucket by the key's digit.  k0 (n keys) -> k1 -> k0: both hold msx_sort_k32v8_bound(n) keys.  lay (device,
+// 512 words): where bucket v begins in the result, and how many keys it has (empty slots, all ones, fill the rest of
+// its last tile).  Bucket `skip_bucket` is left unordered (the caller's empty slots).
+int64_t msx_sort_k32v8_bound(int64_t n) { return ((n + RS_TILE - 1) / RS_TILE + 256) * RS_TILE; }
+// (the workspace, before the caller leaves its counts in it; *n_tiles_out: the stride of the first pass's table)
+int msx_sort_k32v8_reserve(msx_ctx *ctx, int64_t n, msx_buf *hist, msx_buf *off, int64_t *n_tiles_out) {
+	if (n_tiles_out) *n_tiles_out = (n + RS_TILE - 1) / RS_TILE;
+	return msx_sort_keys32_reserve(ctx, msx_sort_k32v8_bound(n), hist, off, nullptr);
+}
+int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, const uint8_t *v0, uint32_t *k1, int64_t n, int shift, msx_buf *hist, msx_buf *off,
+                   int64_t counted_tiles, int skip_bucket, uint32_t *lay) {
 	int rc;
-	if ((rc = msx_sort_keys32_reserve(ctx, n, hist, off, &n_tiles))) return rc;
-	uint32_t *const dtot = (uint32_t *)off->p + 256 * n_tiles + 16;
+	const int64_t n_ub = msx_sort_k32v8_bound(n), tiles_ub = n_ub / RS_TILE, n_tiles = (n + RS_TILE - 1) / RS_TILE;
+	if ((rc = msx_sort_k32v8_reserve(ctx, n, hist, off, nullptr))) return rc;
+	uint32_t *const dtot = (uint32_t *)off->p + 256 * tiles_ub + 16, *const btot = dtot + 256;
+	// pass 1 (the table's stride: n_tiles; the caller's counts are laid out for it -- msx_sort_keys32_reserve(n) told it so)
 	if (n_tiles > counted_tiles)
-		hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)(n_tiles - counted_tiles)), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)k0,
-		                   (const unsigned long long *)nullptr, n, shift, 255u, (uint32_t *)hist->p, n_tiles, counted_tiles);
+		hipLaunchKernelGGL(k_rs_hist8, dim3((unsigned)(n_tiles - counted_tiles)), dim3(MSX_BLOCK), 0, ctx->stream, v0, n, (uint32_t *)hist->p,
+		                   n_tiles, counted_tiles);
 	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
-	                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, dtot);
-	hipLaunchKernelGGL((k_rs_scatter<uint8_t, true, false, true, false>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)k0, (const uint8_t *)v0, k1, v1, (const unsigned long long *)nullptr, n, shift, 255u,
-	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)dtot);
-	hipLaunchKernelGGL(k_rs_hist8, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint8_t *)v1, n, (uint32_t *)hist->p, n_tiles);
-	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
-	                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, dtot);
+	                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, btot);
 	hipLaunchKernelGGL((k_rs_scatter<uint8_t, true, false, true, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)k1, (const uint8_t *)v1, k0, v0, (const unsigned long long *)nullptr, n, 0, 255u,
-	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)dtot);
-	if (dtot_out) *dtot_out = dtot;
+	                   (const uint32_t *)k0, v0, k1, (uint8_t *)nullptr, (const unsigned long long *)nullptr, n, 0, 255u,
+	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)btot);
+	hipLaunchKernelGGL(k_rs_bucket_pad, dim3(256 + 64), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)btot, k1, n_ub, lay);
+	// pass 2
+	hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)tiles_ub), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)k1,
+	                   (const unsigned long long *)nullptr, n_ub, shift, 255u, (uint32_t *)hist->p, tiles_ub, (int64_t)0);
+	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
+	                   (const unsigned long long *)nullptr, tiles_ub, (uint32_t *)off->p, dtot);
+	hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, false, true, false, true>), dim3((unsigned)tiles_ub), dim3(MSX_BLOCK), 0, ctx->stream,
+	                   (const uint32_t *)k1, (const uint32_t *)nullptr, k0, (uint32_t *)nullptr, (const unsigned long long *)nullptr, n_ub,
+	                   shift, 255u, (const uint32_t *)off->p, tiles_ub, (const uint32_t *)dtot, (const uint32_t *)btot, skip_bucket);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }

@@ -71,11 +71,11 @@ PY
       done 2>&1 | tee $OUT/e2e_$k.log
       rm -rf $T ;;
     stats)
-      rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$k -o s -- $arg > $OUT/stats_$k.log 2>&1; echo "rc=$?"
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$k -o s -- $arg > $OUT/stats_$k.log 2>&1; echo "rc=$?"
       f=$(find $OUT/stats_$k -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/stats_${k}_kernel_stats.csv && head -25 "$f" ;;
     pmc)
       ctr=${arg%%=*}; cmd=${arg#*=}
-      rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$k -o p -- $cmd > $OUT/pmc_$k.log 2>&1; echo "rc=$?"
+      timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$k -o p -- $cmd > $OUT/pmc_$k.log 2>&1; echo "rc=$?"
       f=$(find $OUT/pmc_$k -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python3 scripts/pmc_sum.py "$f" | tee $OUT/pmc_${k}_${ctr// /_}.txt ;;
     sh)
       bash -c "$arg" 2>&1 | tee $OUT/sh_$k.log | tail -40 ;;
