@@ -637,7 +637,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts3(const uint32_t *__res
 	const int64_t q = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (q >= 2 * n_tiles) return;
 	const uint32_t t = (uint32_t)(q >> 1), sup = t >> 8, want = (t & 255u) + (uint32_t)(q & 1);
-	uint32_t lo = lay[sup], hi = lo + lay[256 + sup];
+	// (up to the bucket's last whole sort tile: the passes are not stable, so the empty slots that fill it -- all ones, digit
+	//  255 -- lie anywhere among the items of the bucket's tile 255; k_cov_depths3 skips them)
+	uint32_t lo = lay[sup], hi = lo + ((lay[256 + sup] + MSX_SORT_TILE - 1u) & ~(uint32_t)(MSX_SORT_TILE - 1u));
 	while (lo < hi) {
 		const uint32_t mid = lo + ((hi - lo) >> 1);
 		if ((items[mid] >> 24) < want) lo = mid + 1; else hi = mid;
@@ -657,8 +659,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list3(const uint32_t *_
 	slot_of[t] = slot;
 }
 
-// (a pre-reduced tile has more items than a chunk holds: inside a chunk it is the tile of the first or of the last item;
-//  an empty slot at the end of a bucket reads as that bucket's tile 255, which does no harm)
+// (a pre-reduced tile has more items than a chunk holds: inside a chunk it is the tile of the first or of the last item)
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_chunks3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay,
                                                                  int64_t n_tiles, const int32_t *__restrict__ slot_of,
                                                                  cv2_state *__restrict__ st, uint32_t *__restrict__ chunk_list) {
@@ -710,14 +711,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__
 		int64_t a = lo_c;
 		while (a < hi_c) {                                       // the tiles this chunk touches, by their ends
 			const uint32_t sup = cv3_bucket_at(lay, (uint32_t)a);
-			const int64_t bucket_end = (int64_t)lay[sup] + lay[256 + sup];
-			if (a >= bucket_end) {                               // the empty slots behind a bucket's items: on to the next bucket
-				uint32_t nx = sup + 1;
-				while (nx < 255 && lay[256 + nx] == 0) nx++;
-				a = (int64_t)lay[nx];
-				continue;
-			}
-			const uint32_t t = sup << 8 | items[a] >> 24;
+			const uint32_t t = sup << 8 | items[a] >> 24;        // (an empty slot: tile 255 of its bucket, whose items it lies among)
 			const int64_t e_t = (int64_t)start[2 * (int64_t)t + 1];
 			const int64_t b = e_t < hi_c ? e_t : hi_c;
 			const int32_t slot = (int64_t)t < n_tiles ? slot_of[t] : -1;

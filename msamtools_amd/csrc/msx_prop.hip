@@ -130,6 +130,134 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist8(const uint8_t *__restric
 	hist[(int64_t)d * n_tiles + tile] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
+// The two passes of msx_sort_k32v8 need not be stable (what is ordered are marks that are added up), so a key's place
+// inside its digit's run of the tile is whatever an LDS counter hands out: one atomic with return per key instead of the
+// eight ballots and their mask arithmetic per row of 64 -- k_rs_scatter issues ~120 vector instructions per row and is
+// bound by that, not by memory.  When most of a row holds one digit (a hot reference: its bucket, its tile) those lanes
+// are counted by a ballot and one add.
+//   DV : the digit is the 8-bit value beside the key; keys only are written, every value's run (a BUCKET) beginning at a
+//        whole tile (the slots in between: k_rs_bucket_pad);
+//   SEG: the pass inside the buckets, by key bits [shift, shift + 8): a tile lies in one bucket (btot[]: the buckets'
+//        lengths); its digit runs go to  bucket start + (the bucket's keys of smaller digits) + (the digit's keys in the
+//        bucket's earlier tiles) -- all from the row-wise scans of the digit counts (hoff) at the bucket's first tile,
+//        at this tile and at the next bucket's first tile.  Tiles behind the last bucket and those of bucket
+//        `skip_bucket` have nothing to do.
+template <bool DV, bool SEG>
+__global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__restrict__ keys_in, const uint8_t *__restrict__ vals_in,
+                                                              uint32_t *__restrict__ keys_out, int64_t n, int shift,
+                                                              const uint32_t *__restrict__ hoff, int64_t n_tiles,
+                                                              const uint32_t *__restrict__ dtot, const uint32_t *__restrict__ btot,
+                                                              int skip_bucket) {
+	__shared__ uint32_t s_key[RS_TILE];
+	__shared__ uint8_t s_dig[DV ? RS_TILE : 1];       // DV: the digit of the key at each place of the ordered tile
+	__shared__ uint4 s_v8[DV ? RS_TILE / 16 : 1];
+	__shared__ uint32_t s_cnt[256], s_dstart[256], s_gbase[256];
+	__shared__ uint32_t s_wsum[MSX_BLOCK / 64], s_gsum[MSX_BLOCK / 64], s_bfirst, s_bnext;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t tile = blockIdx.x, base = tile * RS_TILE;
+	if (base >= n) return;
+	const uint32_t n_here = (uint32_t)((n - base) < (int64_t)RS_TILE ? (n - base) : (int64_t)RS_TILE);
+	if (SEG) {                                        // which bucket is this tile in?  (thread d: bucket d)
+		const int d = threadIdx.x;
+		const uint32_t bp = (btot[d] + RS_TILE - 1) / RS_TILE;
+		uint32_t binc = bp;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(binc, o, 64);
+			if (lane >= o) binc += t;
+		}
+		if (lane == 63) s_wsum[w] = binc;
+		if (d == 0) s_bfirst = 0xffffffffu;
+		__syncthreads();
+		for (int q = 0; q < w; q++) binc += s_wsum[q];
+		if ((uint32_t)tile >= binc - bp && (uint32_t)tile < binc && d != skip_bucket) { s_bfirst = binc - bp; s_bnext = binc; }
+		__syncthreads();
+		if (s_bfirst == 0xffffffffu) return;
+	}
+	s_cnt[threadIdx.x] = 0;
+	uint32_t key[RS_EPT];
+	const uint32_t wbase = (uint32_t)w * (RS_EPT * 64) + (uint32_t)lane;
+	const bool v8 = DV && n_here == RS_TILE;          // the tile's values as one 16-byte load per thread, handed to their rows through LDS
+	if (v8) s_v8[threadIdx.x] = reinterpret_cast<const uint4 *>(vals_in + base)[threadIdx.x];
+#pragma unroll
+	for (int r = 0; r < RS_EPT; r++) {
+		const uint32_t i = wbase + (uint32_t)r * 64u;
+		key[r] = i < n_here ? keys_in[base + i] : 0u;
+	}
+	__syncthreads();
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	uint32_t pos[RS_EPT], dig[RS_EPT];
+#pragma unroll
+	for (int r = 0; r < RS_EPT; r++) {
+		const uint32_t i = wbase + (uint32_t)r * 64u;
+		const bool valid = i < n_here;
+		uint32_t d;
+		if (DV) d = v8 ? (uint32_t) reinterpret_cast<const uint8_t *>(s_v8)[i] : (valid ? (uint32_t)vals_in[base + i] : 0u);
+		else d = (key[r] >> shift) & 255u;
+		dig[r] = d;
+		const unsigned long long act = __ballot(valid);
+		uint32_t p = 0;
+		if (act) {
+			const int lead = __ffsll((long long)act) - 1;
+			const uint32_t d0 = (uint32_t)__shfl((int)d, lead, 64);
+			const unsigned long long same = __ballot(valid && d == d0);
+			uint32_t b0 = 0;
+			if (lane == lead) b0 = atomicAdd(&s_cnt[d0], (uint32_t)__popcll(same));
+			b0 = (uint32_t)__shfl((int)b0, lead, 64);
+			if (valid && d == d0) p = b0 + (uint32_t)__popcll(same & lt);
+			else if (valid) p = atomicAdd(&s_cnt[d], 1u);
+		}
+		pos[r] = p;
+	}
+	__syncthreads();
+	{
+		const int d = threadIdx.x;
+		const uint32_t tot = s_cnt[d];
+		uint32_t inc = tot;                                // inclusive scan over the 256 digits: where each begins in the tile
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		// ... and in the output: over the digits' padded totals (DV), or over their totals inside the bucket (SEG)
+		uint32_t p_first = 0;
+		if (SEG) p_first = hoff[(int64_t)d * n_tiles + s_bfirst];
+		const uint32_t gt = SEG ? ((s_bnext < (uint32_t)n_tiles ? hoff[(int64_t)d * n_tiles + s_bnext] : dtot[d]) - p_first)
+		                        : ((dtot[d] + RS_TILE - 1) & ~(uint32_t)(RS_TILE - 1));
+		uint32_t ginc = gt;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(ginc, o, 64);
+			if (lane >= o) ginc += t;
+		}
+		if (lane == 63) { s_wsum[w] = inc; s_gsum[w] = ginc; }
+		__syncthreads();
+		uint32_t woff = 0, goff = 0;
+		for (int q = 0; q < w; q++) { woff += s_wsum[q]; goff += s_gsum[q]; }
+		const uint32_t ds = woff + inc - tot;
+		s_dstart[d] = ds;
+		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] + goff + ginc - gt - ds + (SEG ? s_bfirst * RS_TILE - p_first : 0u);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < RS_EPT; r++) {
+		if (wbase + (uint32_t)r * 64u < n_here) {
+			const uint32_t p = s_dstart[dig[r]] + pos[r];
+			s_key[p] = key[r];
+			if (DV) s_dig[p] = (uint8_t)dig[r];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < RS_EPT; q++) {
+		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
+		if (p < n_here) {
+			const uint32_t k = s_key[p];
+			keys_out[s_gbase[DV ? (uint32_t)s_dig[p] : ((k >> shift) & 255u)] + p] = k;
+		}
+	}
+}
+
 // msx_sort_k32v8 between its passes: the slots between a bucket's keys and the next bucket's first tile, and everything
 // behind the last bucket up to n_ub, become empty keys (all ones); lay[d] = where bucket d begins, lay[256 + d] = its keys
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_bucket_pad(const uint32_t *__restrict__ btot, uint32_t *__restrict__ keys, int64_t n_ub,
@@ -201,15 +329,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_rowscan(const uint32_t *__rest
 
 // V: type of the value travelling with each key (uint32_t or unsigned long long); PAIRS = false: keys only;
 // ROWS: hoff holds row-wise scans (k_rs_rowscan) and dtot the rows' totals, instead of one scan over the table
-// The last three serve msx_sort_k32v8 (keys with an 8-bit value beside them, ordered by (value, key digit)):
-// DV: the digit is the value itself, and only the keys are written -- each value's run (a BUCKET) begins at a whole
-//     tile, its length rounded up (the slots in between are filled by k_rs_bucket_pad), so the bucket is known from
-//     the position from then on;
-// SEG: the pass inside the buckets: a tile lies in one bucket (btot[]: the buckets' lengths), and its digit runs go
-//     to  bucket start + (the bucket's keys of smaller digits) + (the digit's keys in the bucket's earlier tiles) --
-//     all three from the row-wise scans of the digit counts (hoff) at the bucket's first tile, this tile and the next
-//     bucket's first tile.  Tiles behind the last bucket and the tiles of bucket `skip_bucket` have nothing to do.
-template <typename V, bool PAIRS, bool SKIP, bool ROWS = false, bool DV = false, bool SEG = false>
+template <typename V, bool PAIRS, bool SKIP, bool ROWS = false>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
                                                           const V *__restrict__ vals_in,
                                                           uint32_t *__restrict__ keys_out,
@@ -217,8 +337,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
                                                           const unsigned long long *__restrict__ n_ptr, int64_t n_host,
                                                           int shift, uint32_t dmask,
                                                           const uint32_t *__restrict__ hoff, int64_t n_tiles,
-                                                          const uint32_t *__restrict__ dtot = nullptr,
-                                                          const uint32_t *__restrict__ btot = nullptr, int skip_bucket = -1) {
+                                                          const uint32_t *__restrict__ dtot = nullptr) {
 	__shared__ uint32_t s_key[RS_TILE];
 	__shared__ V s_val[PAIRS ? RS_TILE : 1];
 	__shared__ uint32_t s_nvalid;
@@ -233,49 +352,18 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	if (base >= E) return;
 	if (n_ptr) n_tiles = (E + RS_TILE - 1) / RS_TILE;      // the table's stride, as k_rs_hist laid it out
 	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
-	__shared__ uint32_t s_bfirst, s_bnext;            // SEG: the bucket's first tile, the next bucket's first tile
-	if (SEG) {
-		// which bucket is this tile in?  (thread d: bucket d)
-		const int d = threadIdx.x;
-		const uint32_t bp = (btot[d] + RS_TILE - 1) / RS_TILE;
-		uint32_t binc = bp;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t t = __shfl_up(binc, o, 64);
-			if (lane >= o) binc += t;
-		}
-		if (lane == 63) s_wsum[w] = binc;
-		if (d == 0) s_bfirst = 0xffffffffu;
-		__syncthreads();
-		for (int q = 0; q < w; q++) binc += s_wsum[q];
-		if ((uint32_t)tile >= binc - bp && (uint32_t)tile < binc && d != skip_bucket) { s_bfirst = binc - bp; s_bnext = binc; }
-		__syncthreads();
-		if (s_bfirst == 0xffffffffu) return;
-	}
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
 	// 1. all loads up front; wave w owns elements [w*RS_EPT*64, (w+1)*RS_EPT*64) of the tile
 	uint32_t key[RS_EPT];
 	V val[RS_EPT];
 	const uint32_t wbase = (uint32_t)w * (RS_EPT * 64) + (uint32_t)lane;
-	// (DV: the tile's 8-bit values as one 16-byte load per thread, handed to their rows through LDS -- sixteen one-byte
-	//  loads per thread cost as many memory instructions as the keys)
-	__shared__ uint4 s_v8[(DV && sizeof(V) == 1) ? RS_TILE / 16 : 1];
-	const bool v8 = DV && sizeof(V) == 1 && n_here == RS_TILE;
-	if (v8) s_v8[threadIdx.x] = reinterpret_cast<const uint4 *>(vals_in + base)[threadIdx.x];
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const uint32_t i = wbase + (uint32_t)r * 64u;
 		key[r] = SKIP ? RS_NOKEY : 0u; val[r] = 0;
 		if (i < n_here) {
 			key[r] = keys_in[base + i];
-			if (PAIRS && !v8) val[r] = vals_in[base + i];
-		}
-	}
-	if (DV && sizeof(V) == 1) {
-		__syncthreads();
-		if (v8) {
-#pragma unroll
-			for (int r = 0; r < RS_EPT; r++) val[r] = (V) reinterpret_cast<const uint8_t *>(s_v8)[wbase + (uint32_t)r * 64u];
+			if (PAIRS) val[r] = vals_in[base + i];
 		}
 	}
 	// 2. rank inside the wave
@@ -284,7 +372,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]));
-		const uint32_t d = DV ? ((uint32_t)val[r] & dmask) : ((key[r] >> shift) & dmask);
+		const uint32_t d = (key[r] >> shift) & dmask;
 		unsigned long long m = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < 8; b++) {
@@ -311,12 +399,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 			const uint32_t t = __shfl_up(inc, o, 64);
 			if (lane >= o) inc += t;
 		}
-		// (ROWS: the same scan over the digits' global totals gives the position where each digit's run begins;
-		//  SEG: over the digits' totals inside the bucket)
-		uint32_t p_first = 0;
-		if (SEG) p_first = hoff[(int64_t)d * n_tiles + s_bfirst];
-		const uint32_t gt = SEG ? ((s_bnext < (uint32_t)n_tiles ? hoff[(int64_t)d * n_tiles + s_bnext] : dtot[d]) - p_first)
-		                        : ROWS ? (DV ? ((dtot[d] + RS_TILE - 1) & ~(uint32_t)(RS_TILE - 1)) : dtot[d]) : 0u;
+		// (ROWS: the same scan over the digits' global totals gives the position where each digit's run begins)
+		const uint32_t gt = ROWS ? dtot[d] : 0u;
 		uint32_t ginc = gt;
 		if (ROWS) {
 #pragma unroll
@@ -333,7 +417,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		const uint32_t ds = woff + inc - tot;
 		s_dstart[d] = ds;
 		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] + (ROWS ? goff + ginc - gt : 0u) - ds;
-		if (SEG) s_gbase[d] += s_bfirst * RS_TILE - p_first;
 		if (d == 255) s_nvalid = ds + tot;
 	}
 	__syncthreads();
@@ -341,7 +424,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		if ((wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]))) {
-			const uint32_t d = DV ? ((uint32_t)val[r] & dmask) : ((key[r] >> shift) & dmask);
+			const uint32_t d = (key[r] >> shift) & dmask;
 			const uint32_t p = s_dstart[d] + s_cnt[w][d] + pos[r];
 			s_key[p] = key[r];
 			if (PAIRS) s_val[p] = val[r];
@@ -355,9 +438,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
 		if (p < n_out) {
 			const uint32_t k = s_key[p];
-			const uint32_t dst = s_gbase[DV ? ((uint32_t)s_val[PAIRS ? p : 0] & dmask) : ((k >> shift) & dmask)] + p;
+			const uint32_t dst = s_gbase[(k >> shift) & dmask] + p;
 			keys_out[dst] = k;
-			if (PAIRS && !DV) vals_out[dst] = s_val[p];
+			if (PAIRS) vals_out[dst] = s_val[p];
 		}
 	}
 }
@@ -1428,18 +1511,17 @@ int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, const uint8_t *v0, uint32_t *k1, 
 		                   n_tiles, counted_tiles);
 	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
 	                   (const unsigned long long *)nullptr, n_tiles, (uint32_t *)off->p, btot);
-	hipLaunchKernelGGL((k_rs_scatter<uint8_t, true, false, true, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)k0, v0, k1, (uint8_t *)nullptr, (const unsigned long long *)nullptr, n, 0, 255u,
-	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)btot);
+	hipLaunchKernelGGL((k_rs_scatter_any<true, false>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)k0, v0, k1, n, 0,
+	                   (const uint32_t *)off->p, n_tiles, (const uint32_t *)btot, (const uint32_t *)nullptr, -1);
 	hipLaunchKernelGGL(k_rs_bucket_pad, dim3(256 + 64), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)btot, k1, n_ub, lay);
 	// pass 2
 	hipLaunchKernelGGL(k_rs_hist<false>, dim3((unsigned)tiles_ub), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)k1,
 	                   (const unsigned long long *)nullptr, n_ub, shift, 255u, (uint32_t *)hist->p, tiles_ub, (int64_t)0);
 	hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)hist->p,
 	                   (const unsigned long long *)nullptr, tiles_ub, (uint32_t *)off->p, dtot);
-	hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, false, true, false, true>), dim3((unsigned)tiles_ub), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)k1, (const uint32_t *)nullptr, k0, (uint32_t *)nullptr, (const unsigned long long *)nullptr, n_ub,
-	                   shift, 255u, (const uint32_t *)off->p, tiles_ub, (const uint32_t *)dtot, (const uint32_t *)btot, skip_bucket);
+	hipLaunchKernelGGL((k_rs_scatter_any<false, true>), dim3((unsigned)tiles_ub), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)k1,
+	                   (const uint8_t *)nullptr, k0, n_ub, shift, (const uint32_t *)off->p, tiles_ub, (const uint32_t *)dtot,
+	                   (const uint32_t *)btot, skip_bucket);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
