@@ -503,7 +503,10 @@ int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);
 /* A whole sample in one batch (the loop of msam_coverage.c:293-301 over one file that fits the device): per-base depths
  * straight into cov[0 .. total_len] -- the caller need not zero it, no msx_coverage_finish follows.  Same result as
  * zero + msx_coverage_accumulate + msx_coverage_finish; the depth array is written once instead of touched three times
- * (marks sorted by tile, every tile's depths finished where its marks are gathered).  Waits for the result. */
+ * (the runs, cut at tile boundaries, sorted by tile; every tile's depths finished where its pieces are gathered).  Runs
+ * are expected to lie inside their targets (beyond a target's end the reference writes outside its array,
+ * msam_coverage.c:66-70; here such a run is cut at the end).  Batches under 65 536 records, and batches whose overflow
+ * lists run full (most records with several long runs), take the streamed path inside the call.  Waits for the result. */
 int  msx_coverage_depths(msx_ctx *ctx, const msx_batch *dev, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
                          int32_t *cov, uint8_t *covered);
 /* after msx_coverage_finish: per target, the number of positions with a depth other than 0 and the sum of the depths --

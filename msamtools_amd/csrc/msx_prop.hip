@@ -342,6 +342,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	__shared__ V s_val[PAIRS ? RS_TILE : 1];
 	__shared__ uint32_t s_nvalid;
 	__shared__ uint32_t s_cnt[MSX_BLOCK / 64][256];   // per wave: running digit counts, then the wave's offset
+	__shared__ unsigned long long s_mask[MSX_BLOCK / 64][256];   // per wave and digit: the lanes of the current row that hold it
 	__shared__ uint32_t s_dstart[256];                // first position of the digit inside the sorted tile
 	__shared__ uint32_t s_gbase[256];                 // global position of the digit's run minus s_dstart
 	__shared__ uint32_t s_wsum[MSX_BLOCK / 64], s_gsum[MSX_BLOCK / 64];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	if (base >= E) return;
 	if (n_ptr) n_tiles = (E + RS_TILE - 1) / RS_TILE;      // the table's stride, as k_rs_hist laid it out
 	const uint32_t n_here = (uint32_t)((E - base) < (int64_t)RS_TILE ? (E - base) : (int64_t)RS_TILE);
-	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
+	for (int q = 0; q < 4; q++) { s_cnt[w][lane + 64 * q] = 0; s_mask[w][lane + 64 * q] = 0ull; }
 	// 1. all loads up front; wave w owns elements [w*RS_EPT*64, (w+1)*RS_EPT*64) of the tile
 	uint32_t key[RS_EPT];
 	V val[RS_EPT];
@@ -373,12 +374,22 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter(const uint32_t *__rest
 	for (int r = 0; r < RS_EPT; r++) {
 		const bool valid = (wbase + (uint32_t)r * 64u < n_here) && (!SKIP || !RS_SKIPPED(key[r]));
 		const uint32_t d = (key[r] >> shift) & dmask;
-		unsigned long long m = __ballot(valid);
-#pragma unroll
-		for (int b = 0; b < 8; b++) {
-			const bool bit = (d >> b) & 1u;
-			const unsigned long long bal = __ballot(bit);
-			m &= bit ? bal : ~bal;
+		// m: the lanes of this row that hold the same digit.  The lanes that share the first valid lane's digit know it
+		// from one ballot; the others OR their lane bit into an LDS word per digit and read the word back (the wave's
+		// LDS operations complete in order), the lowest lane of each clears it for the next row.  (Eight ballots and
+		// the mask arithmetic per row were ~50 of the kernel's ~120 vector instructions per row, and the kernel is
+		// bound by what it issues.)
+		unsigned long long m = 0;
+		{
+			const unsigned long long act = __ballot(valid);
+			const uint32_t d0 = (uint32_t)__shfl((int)d, act ? __ffsll((long long)act) - 1 : 0, 64);
+			const unsigned long long same = __ballot(valid && d == d0);
+			if (valid && d == d0) m = same;
+			else if (valid) {
+				__hip_atomic_fetch_or(&s_mask[w][d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				m = __hip_atomic_load(&s_mask[w][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if ((m & lt) == 0ull) __hip_atomic_store(&s_mask[w][d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
 		}
 		const uint32_t rank = (uint32_t)__popcll(m & lt);
 		const uint32_t cnt = (uint32_t)__popcll(m);
