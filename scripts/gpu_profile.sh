@@ -7,13 +7,13 @@ OUT=gpurun_out/${1:-prof}
 rm -rf $OUT; mkdir -p $OUT
 stats() {   # name, program args...
   local n=$1; shift
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$n -- "$@" > $OUT/$n.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$n -- "$@" > $OUT/$n.log 2>&1
   find $OUT/$n -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${n}_kernel_stats.csv
   head -12 $OUT/${n}_kernel_stats.csv | cut -c1-160
 }
 pmc() {     # name, counters, program args...
   local n=$1 c=$2; shift; shift
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$n -- "$@" > $OUT/$n.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$n -- "$@" > $OUT/$n.log 2>&1
   find $OUT/$n -name "*counter_collection.csv" | head -1 | xargs -I{} python3 scripts/pmc_sum.py {} > $OUT/${n}.json
 }
 STEP="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e --no-coverage --no-dist-leg"
@@ -24,6 +24,7 @@ pmc c3_write WRITE_SIZE python3 $STEP1
 stats cov python3 scripts/bench_coverage.py 10000000 4 depths
 pmc cov_fetch FETCH_SIZE python3 scripts/bench_coverage.py 10000000 2 depths
 pmc cov_write WRITE_SIZE python3 scripts/bench_coverage.py 10000000 2 depths
+pmc cov_c4_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" python3 scripts/bench_coverage.py 10000000 2 depths
 stats deflate python3 scripts/bench_deflate.py 400000
 pmc deflate_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python3 scripts/bench_deflate.py 400000
 python3 - $OUT <<'PY'
