@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSX_ABI_VERSION 5
+#define MSX_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSX_OK              0
@@ -114,6 +114,12 @@ typedef struct msx_filter_params {
 	int32_t keep_unmapped;  /* -k                                              */
 	int32_t besthit;        /* --besthit                                       */
 	int32_t uniqhit;        /* --uniqhit                                       */
+	int32_t fatal_pool_partial;
+	/* 0 in normal use.  1: a best-hit pool that holds a participating record without AS keeps what the reference had
+	 * written of it when it died there (msam_filter.c:219-221 inside :247-263): the READ1 winners if only the READ2 pass
+	 * meets such a record, nothing otherwise.  The call still fails with MSX_ERR_NO_AS; msx_filter_status.n_emit and
+	 * emit_idx are valid all the same -- the caller that has cut the batch behind the offending pool writes them and
+	 * then dies with the reference's message. */
 } msx_filter_params;
 
 /* Device output buffers of one filter call, caller-allocated (device memory).

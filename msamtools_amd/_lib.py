@@ -42,7 +42,8 @@ POOLS_PROFILE, POOLS_FILTER = 0, 1
 
 class FilterParams(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
-                ("min_length", "ppt", "max_clip", "rescore", "invert", "keep_unmapped", "besthit", "uniqhit")]
+                ("min_length", "ppt", "max_clip", "rescore", "invert", "keep_unmapped", "besthit", "uniqhit",
+                 "fatal_pool_partial")]
 
 
 class FilterOut(C.Structure):

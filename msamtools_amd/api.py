@@ -16,7 +16,7 @@ from . import _lib as L
 
 
 def filter_params(l=0, p=None, ppt=None, z=None, rescore=False, invert=False,
-                  keep_unmapped=False, besthit=False, uniqhit=False):
+                  keep_unmapped=False, besthit=False, uniqhit=False, fatal_pool_partial=False):
     """CLI options -> msx_filter_params, validated as msam_filter.c:398-457 does."""
     if invert and (besthit or uniqhit):
         raise ValueError("--invert cannot be combined with --besthit or --uniqhit")
@@ -44,6 +44,7 @@ def filter_params(l=0, p=None, ppt=None, z=None, rescore=False, invert=False,
         raise ValueError("-l must be a non-negative integer")
     fp.rescore, fp.invert, fp.keep_unmapped = int(bool(rescore)), int(bool(invert)), int(bool(keep_unmapped))
     fp.besthit, fp.uniqhit = int(bool(besthit)), int(bool(uniqhit))
+    fp.fatal_pool_partial = int(bool(fatal_pool_partial))
     return fp
 
 

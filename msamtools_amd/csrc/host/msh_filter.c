@@ -116,8 +116,10 @@ static void filter_open_output(fshared *F, const rbatch *first) {
  * participating record without AS: :219-221).  The reference has by then written every pool it had completed; the batch
  * API reports the error for the whole batch.  So the batch is filtered once more, cut in front of the pool that holds the
  * offending record, that output goes to the writer, and the writer -- when it reaches this batch, every earlier one
- * written -- dies with the reference's message.  (Not reproduced: a paired pool whose READ1 pass the reference had
- * already written when its READ2 pass met the record without AS.)
+ * written -- dies with the reference's message.  A record without AS is met when its pool is written
+ * (msam_filter.c:219-221), and a paired pool is written READ1 pass first (:247-263): the batch is then cut BEHIND that pool
+ * and filtered with msx_filter_params.fatal_pool_partial, which keeps of it what the reference had written -- the READ1
+ * winners when only the READ2 pass meets such a record (fatal_refilter).
  * Returns the number of records in front of the offending pool, *g = the number of pools. */
 static int64_t fatal_prefix(const uint32_t *group_off, int64_t n_groups, int64_t err_record, int64_t *g) {
 	int64_t lo = 0, hi = n_groups;            /* the last pool that starts at or before err_record */
@@ -127,6 +129,62 @@ static int64_t fatal_prefix(const uint32_t *group_off, int64_t n_groups, int64_t
 	}
 	*g = lo;
 	return (int64_t)group_off[lo];
+}
+
+/* Plain filters carry no pools in their batches.  The reference holds the records it has kept since its last name change
+ * in an open pool -- a record's name is compared with the last MAPPED record's (msam_filter.c:120-125,170), unmapped ones do
+ * not move that name on (:132-138) -- and dies with them unwritten.  Where that pool begins, from the batch's records up to
+ * the offending one (BAM records with their length words, one after the other).  (A pool that was opened in the batch
+ * before cannot be taken back: those records are out.) */
+static int64_t open_pool_start(const uint8_t *recs, int64_t err) {
+	const uint8_t *p = recs, *prev = NULL;
+	int64_t i, start = 0;
+	for (i = 0; i <= err; i++) {
+		const uint32_t len = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+		const uint8_t *r = p + 4;
+		if (prev && (r[8] != prev[8] || memcmp(r + 32, prev + 32, r[8]) != 0)) start = i;      /* written before record i is looked at */
+		if (!(r[14] & 4)) prev = r;
+		p += 4 + (size_t)len;
+	}
+	return start;
+}
+
+/* the batch once more, cut where the reference died (see fatal_prefix); db / fo as the first pass left them.  recs: the
+ * batch's records on the host, or NULL with the unpacker that holds them on the device.  Leaves the number of records to
+ * write in st->n_emit. */
+static void fatal_refilter(const msx_filter_params *fp, int no_as, int has_pools, const uint32_t *group_off, int64_t n_groups,
+                           const uint8_t *recs, msx_unpack *unpack, msx_batch *db, msx_filter_out *fo, msx_filter_status *st) {
+	const int64_t err = st->err_record;
+	msx_filter_params cut = *fp;
+	int64_t g = 0, npre = err;
+	st->n_emit = 0;
+	if (err < 0) return;
+	if (has_pools && n_groups > 0) {
+		npre = fatal_prefix(group_off, n_groups, err, &g);
+		if (no_as) {                           /* the offending pool stays in, judged as far as the reference got */
+			npre = (int64_t)group_off[g + 1];
+			g = g + 1;
+			cut.fatal_pool_partial = 1;
+		}
+	} else if (recs) {
+		npre = open_pool_start(recs, err);
+	} else if (unpack) {                       /* the records in front of it, down from the device (a dying command can afford it) */
+		int32_t *idx = (int32_t *)xmalloc(((size_t)err + 1) * 4);
+		uint8_t *buf;
+		int64_t i, nb = 0;
+		for (i = 0; i <= err; i++) idx[i] = (int32_t)i;
+		MSX(msx_host_to_dev(g_ctx, fo->emit_idx, idx, ((size_t)err + 1) * 4));
+		MSX(msx_unpack_emit_gather(g_ctx, unpack, fo->emit_idx, err + 1, &nb));
+		buf = (uint8_t *)xmalloc((size_t)nb + 64);
+		MSX(msx_unpack_emit_fetch(g_ctx, unpack, buf, (size_t)nb + 64, NULL));
+		npre = open_pool_start(buf, err);
+		free(buf);
+		free(idx);
+	}
+	if (npre <= 0) return;
+	db->n_records = npre; db->n_groups = g;
+	MSX(msx_filter_enqueue(g_ctx, db, &cut, fo));
+	if (msx_filter_finish(g_ctx, st) != MSX_OK && !cut.fatal_pool_partial) st->n_emit = 0;
 }
 
 /* the gathered output of a device-unpacked batch (records, or finished BGZF blocks) on its way to the host: an output buffer
@@ -257,25 +315,18 @@ void *filter_dev_thread(void *arg) {
 				MSX(msx_stage_outputs(g_ctx, stage, ur.n_records, 0, &fo));
 				if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
 				else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
-				if (msx_filter_finish(g_ctx, &st) != MSX_OK) {
+				int frc;
+				if ((frc = msx_filter_finish(g_ctx, &st)) != MSX_OK) {
+					uint32_t *go = NULL;
 					s->fatal = 1;
 					F->any_fatal = 1;
 					snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
-					st.n_emit = 0;
-					if (st.err_record >= 0) {
-						int64_t g = 0, npre = st.err_record;           /* (no pools in the batch: cut at the record itself) */
-						if (P->mode != 0 && ur.n_groups > 0) {
-							uint32_t *go = (uint32_t *)xmalloc(((size_t)ur.n_groups + 1) * 4);
-							MSX(msx_dev_to_host(g_ctx, go, db.group_off, ((size_t)ur.n_groups + 1) * 4));
-							npre = fatal_prefix(go, ur.n_groups, st.err_record, &g);
-							free(go);
-						}
-						if (npre > 0) {
-							db.n_records = npre; db.n_groups = g;
-							MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
-							if (msx_filter_finish(g_ctx, &st) != MSX_OK) st.n_emit = 0;
-						}
+					if (P->mode != 0 && ur.n_groups > 0 && st.err_record >= 0) {
+						go = (uint32_t *)xmalloc(((size_t)ur.n_groups + 1) * 4);
+						MSX(msx_dev_to_host(g_ctx, go, db.group_off, ((size_t)ur.n_groups + 1) * 4));
 					}
+					fatal_refilter(F->fp, frc == MSX_ERR_NO_AS, P->mode != 0, go, ur.n_groups, NULL, unpack, &db, &fo, &st);
+					free(go);
 				}
 				D->t_gpu += now_s() - t1; t1 = now_s();
 				s->n_emit = st.n_emit;
@@ -316,20 +367,13 @@ void *filter_dev_thread(void *arg) {
 		D->t_upload += now_s() - t1; t1 = now_s();
 		if (D->prof) MSX(msx_filter_profile_enqueue(g_ctx, &db, F->fp, &fo, D->prof));
 		else MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
-		if (msx_filter_finish(g_ctx, &st) != MSX_OK) {          /* the reference's own mDie texts; see fatal_prefix */
-			s->fatal = 1;
-			F->any_fatal = 1;
-			snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
-			st.n_emit = 0;
-			if (st.err_record >= 0) {
-				int64_t g = 0;
-				const int64_t npre = (P->mode != 0 && b->n_groups > 0) ? fatal_prefix(b->group_off, (int64_t)b->n_groups, st.err_record, &g)
-				                                                       : st.err_record;
-				if (npre > 0) {
-					db.n_records = npre; db.n_groups = g;
-					MSX(msx_filter_enqueue(g_ctx, &db, F->fp, &fo));
-					if (msx_filter_finish(g_ctx, &st) != MSX_OK) st.n_emit = 0;
-				}
+		{
+			int frc;
+			if ((frc = msx_filter_finish(g_ctx, &st)) != MSX_OK) {          /* the reference's own mDie texts; see fatal_prefix */
+				s->fatal = 1;
+				F->any_fatal = 1;
+				snprintf(s->fatal_msg, sizeof s->fatal_msg, "%s", msx_last_error(g_ctx));
+				fatal_refilter(F->fp, frc == MSX_ERR_NO_AS, P->mode != 0, b->group_off, (int64_t)b->n_groups, b->base + b->rec_off[0], NULL, &db, &fo, &st);
 			}
 		}
 		if (s->seq == 0 && getenv("MSX_TIMING")) fprintf(stderr, "# batch 0: kernels done +%.0f ms after the context\n", (now_s() - D->t_ctx_end) * 1e3);

@@ -26,6 +26,7 @@ struct SelectArgs {
 	const int32_t *as;        // AS to compare (as_out after --rescore)
 	int32_t rescored;         // every mapped pooled record has AS (msam_filter.c:167)
 	int32_t unique_only;      // --uniqhit
+	int32_t partial;          // msx_filter_params.fatal_pool_partial
 	uint8_t *keep;            // [n]
 	uint32_t *gcount;         // [n_groups] records written per pool
 	msx_dev_status *st;
@@ -86,9 +87,14 @@ __device__ __forceinline__ void bh_pool_serial(const SelectArgs &A, const CountA
 		const uint32_t pc = bh_rec_code(A, i);
 		bh_count(c, i, pc & MSX_F_MATES, (pc & MSX_PC_IN) != 0, (pc & MSX_PC_HAS_AS) != 0, A.as[i]);
 	}
-	const bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);
-	const bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
-	const bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
+	bool w0 = !c.paired && c.n0 > 0 && (!A.unique_only || c.n0 == 1);
+	bool w1 = c.paired && c.n1 > 0 && (!A.unique_only || c.n1 == 1);
+	bool w2 = c.paired && c.n2 > 0 && (!A.unique_only || c.n2 == 1);
+	if (A.partial) {            // what the reference had written when it died in this pool: a pass that meets no record without AS
+		w0 = w0 && c.noas0 == 0xffffffffu;
+		w1 = w1 && c.noas1 == 0xffffffffu;
+		w2 = w2 && c.noas1 == 0xffffffffu && c.noas2 == 0xffffffffu;
+	}
 	for (uint32_t i = s; i < e; ++i) {
 		const uint32_t pc = bh_rec_code(A, i);
 		const uint8_t k = bh_keep(c, w0, w1, w2, pc & MSX_F_MATES, (pc & MSX_PC_IN) != 0, (pc & MSX_PC_HAS_AS) != 0, A.as[i]);
@@ -243,6 +249,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_besthit_select(SelectArgs A, Coun
 				// a paired pool is judged per mate (READ1, READ2), an unpaired one as a whole
 				const bool judged = L.pair[pid] ? (ci != 0u) : (ci == 0u);
 				win = judged && sc[r] == L.best[ci][pid];
+				// (wave-uniform switch) the pool the reference died in: a pass that met a record without AS wrote nothing,
+				// and the READ2 pass comes after the READ1 pass
+				if (A.partial && (L.noas[ci][pid] != 0xffffffffu || (ci == 2u && L.noas[1][pid] != 0xffffffffu))) win = false;
 			}
 			if (A.unique_only && win) atomicAdd(&L.ties[ci][pid], 1u);
 			pc[r] = (c & ~(uint32_t)MSX_PC_IN) | (win ? MSX_PC_IN : 0u);          // bit 0 from here on: winner
@@ -492,6 +501,7 @@ static int filter_enqueue_impl(msx_ctx *ctx, const msx_batch *b, const msx_filte
 		S.as = p->rescore ? out->as_out : b->as;
 		S.rescored = p->rescore;
 		S.unique_only = p->uniqhit ? 1 : 0;   // msam_filter.c:88-91: --uniqhit wins
+		S.partial = p->fatal_pool_partial ? 1 : 0;
 		S.keep = out->keep;
 		S.gcount = (uint32_t *)ctx->gcount.p;
 		S.st = ctx->d_status;

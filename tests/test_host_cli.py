@@ -563,6 +563,43 @@ def test_cli_fatal_record_writes_what_precedes_it(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_fatal_record_leaves_its_open_pool_unwritten(tmp_path):
+    """Plain -l/-p/-z: the reference keeps the records of the current QNAME in an open pool and writes it at the next name
+    change (msam_filter.c:120-125); the name it compares with is the last MAPPED record's (:170), an unmapped record does
+    not move it on (:132-138).  A record without MD and NM kills it with that pool unwritten (:150-152).  The command line
+    cuts the batch where that pool began -- against the oracle's output up to its error, SAM and BAM, device-side and
+    host-side walk."""
+    import oracle_lib as orc
+    good = "{0}\t{1}\tchr1\t{2}\t255\t50M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:50\tAS:i:50\n"
+    bad = "{0}\t{1}\tchr1\t{2}\t255\t50M\t*\t0\t0\t*\t*\tAS:i:50\n"
+    unm = "{0}\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n"
+    cases = {
+        "same_name_in_front": [good.format("a", 0, 100), good.format("b", 0, 110), good.format("c", 0, 120), good.format("c", 16, 130),
+                               bad.format("c", 0, 140), good.format("d", 0, 150)],
+        "new_name": [good.format("a", 0, 100), good.format("b", 0, 110), bad.format("c", 0, 140), good.format("d", 0, 150)],
+        "unmapped_in_between": [good.format("a", 0, 100), good.format("b", 0, 110), unm.format("b"), good.format("b", 0, 115),
+                                unm.format("x"), bad.format("b", 0, 140)],
+        "first_record": [bad.format("a", 0, 100), good.format("b", 0, 110)],
+    }
+    for label, lines in cases.items():
+        sam = tmp_path / f"{label}.sam"
+        sam.write_text("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:chr1\tLN:100000\n" + "".join(lines))
+        _, rec = samio.read_sam(str(sam))
+        want = orc.run_filter(rec, p=95)
+        assert want["rc"] != 0
+        expect = "".join(lines[i] for i in want["emit"])
+        r = run(["filter", "-S", "-p", "95", str(sam)])
+        assert r.returncode == 1 and b"Either NM or MD must be present" in r.stderr, (label, r.stderr)
+        assert r.stdout.decode() == expect, (label, want["emit"])
+        bam = tmp_path / f"{label}.bam"
+        bam.write_bytes(run(["recode", "-b", str(sam)]).stdout)
+        for env in ({}, {"MSX_HOST_UNPACK": "1"}):
+            r = run(["filter", "-p", "95", str(bam)], env=env)
+            assert r.returncode == 1 and b"Either NM or MD must be present" in r.stderr
+            assert r.stdout.decode() == expect, (label, env)
+
+
+@pytest.mark.gpu
 def test_cli_fatal_record_after_the_pools_before_it(tmp_path, synth_bams):
     """With best-hit pools the reference has written every pool it completed when its loop dies at a record
     (msam_filter.c:150-152 no MD/NM, :219-221 no AS).  So does the command line: the batch is filtered again in front
@@ -616,6 +653,45 @@ def test_cli_fatal_record_after_the_pools_before_it(tmp_path, synth_bams):
         assert r.returncode == 1 and b"Either NM or MD must be present" in r.stderr
         got = r.stdout.decode().split("\n")[:-1]
         assert got == [src[i] for i in pre["emit"]], (len(got), len(pre["emit"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--besthit", "--uniqhit"])
+def test_cli_fatal_pool_written_as_far_as_the_reference_got(tmp_path, mode):
+    """A paired pool is written READ1 pass first, then READ2 pass (msam_filter.c:247-263); a record without AS is met by the
+    pass of its mate class (:219-221).  So when only READ2 records lack AS the reference has written the pool's READ1
+    winners by the time it dies; when a READ1 record lacks AS, or the pool is unpaired, nothing of the pool.  Every
+    arrangement against the oracle's output up to its error (it restates the writer pass by pass)."""
+    import oracle_lib as orc
+    rec_t = "{name}\t{flag}\tchr1\t{pos}\t255\t50M\t*\t0\t0\t*\t*\tNM:i:0\tMD:Z:50{as_}\n"
+    def pool(name, rows):          # rows: (flag, AS or None)
+        return [rec_t.format(name=name, flag=f, pos=100 + 10 * i, as_="" if a is None else f"\tAS:i:{a}") for i, (f, a) in enumerate(rows)]
+    R1, R2 = 0x41, 0x81
+    cases = {
+        "read2_lacks_as": [(R1, 40), (R1, 50), (R2, 30), (R2, None), (R1, 50)],          # both READ1 winners out, then death
+        "read2_lacks_as_first_in_pool": [(R2, None), (R1, 45), (R2, 60)],
+        "read1_lacks_as": [(R1, 40), (R2, 50), (R1, None), (R2, 50)],                   # dies in the READ1 pass: nothing of the pool
+        "both_lack_as": [(R2, None), (R1, None), (R1, 50)],
+        "unpaired_lacks_as": [(0, 50), (0, None), (0, 50)],
+        "read1_tie_read2_lacks_as": [(R1, 50), (R1, 50), (R2, None)],                   # --uniqhit: the tie writes nothing, then death
+    }
+    for label, rows in cases.items():
+        sam = tmp_path / f"{label}.sam"
+        lines = pool("a0", [(R1, 50), (R2, 50)]) + pool("a1", [(0, 50)]) + pool("bad", rows) + pool("z9", [(0, 50)])
+        sam.write_text("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:chr1\tLN:100000\n" + "".join(lines))
+        _, rec = samio.read_sam(str(sam))
+        want = orc.run_filter(rec, **{mode[2:]: True})
+        assert want["rc"] != 0
+        r = run(["filter", "-S", mode, str(sam)])
+        assert r.returncode == 1 and b"Required field AS not found" in r.stderr, (label, r.stderr)
+        assert r.stdout.decode() == "".join(lines[i] for i in want["emit"]), (label, mode, want["emit"])
+        # the same through the BAM pipeline, device-side walk and host-side walk (SAM text out)
+        bam = tmp_path / f"{label}.bam"
+        bam.write_bytes(run(["recode", "-b", str(sam)]).stdout)
+        for env in ({}, {"MSX_HOST_UNPACK": "1"}):
+            r = run(["filter", mode, str(bam)], env=env)
+            assert r.returncode == 1 and b"Required field AS not found" in r.stderr
+            assert r.stdout.decode() == "".join(lines[i] for i in want["emit"]), (label, mode, env)
 
 
 @pytest.mark.gpu
