@@ -1,5 +1,6 @@
 #!/bin/bash
-# debug: the command line with several contexts, traced, under timeout (a hang shows in the last trace lines)
+# stress: the command line with 1-4 contexts on one GPU, -bu and -b, traced (MSX_TRACE), each run under timeout -- a hang shows in
+# the last trace lines; REPS and DEVS choose how many and which (three deadlocks of round 4 were found with this)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/dbgmulti
 D=msamtools_amd/bin/msamtools-dev; B=msamtools_amd/bin/msamtools
 $D synth --groups 600000 --refs 3000 -b > /tmp/in.bam
