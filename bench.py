@@ -617,6 +617,14 @@ def coverage_block(m, ctx, with_oracle):
             return time.perf_counter() - t0
         ts_s = [one(db, streamed=True) for _ in range(4)]
         cov_s = ctx.to_host(d_cov, total, np.int32)
+        # the first whole-sample form (a +1 and a -1 mark per run, two 8-bit passes over them): what samples beyond
+        # 255 * 2^20 cells take, and the figure the second form is held against
+        os.environ["MSX_COV_MARKS"] = "1"
+        try:
+            ts_m = [one(db) for _ in range(4)]
+            cov_m = ctx.to_host(d_cov, total, np.int32)
+        finally:
+            del os.environ["MSX_COV_MARKS"]
         ts = [one(db) for _ in range(6)]
         best = min(ts[1:])
         cov = ctx.to_host(d_cov, total, np.int32)
@@ -636,9 +644,11 @@ def coverage_block(m, ctx, with_oracle):
             "frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 4),
             "depth_sum": int(cov.astype(np.int64).sum()), "depth_sum_expected": want_sum,
             "depth_sum_ok": bool(int(cov.astype(np.int64).sum()) == want_sum and (cov >= 0).all()),
+            "form": "one word per run piece: 4 K-cell tiles, the tile's top byte dropped by the first of two radix passes",
             "streamed_form_ms": round(min(ts_s[1:]) * 1e3, 3), "equal_to_streamed_form": bool(np.array_equal(cov, cov_s)),
+            "marks_form_ms": round(min(ts_m[1:]) * 1e3, 3), "equal_to_marks_form": bool(np.array_equal(cov, cov_m)),
         }
-        del cov, cov_s, cig, n_cig, has_ref, op, w
+        del cov, cov_s, cov_m, cig, n_cig, has_ref, op, w
         if with_oracle:
             import oracle_lib as orc
             pg = 200_000                                   # every depth of a prefix of the stream against the oracle
@@ -652,7 +662,8 @@ def coverage_block(m, ctx, with_oracle):
             cpu_s = time.perf_counter() - t0
             blk["parity_prefix"] = {"alignments": hs.n_records, "every_depth_equal": bool(np.array_equal(got, want))}
             blk["cpu_oracle_M_alignments_per_s"] = round(hs.n_records / cpu_s / 1e6, 2)
-            blk["parity_ok"] = bool(blk["depth_sum_ok"] and blk["parity_prefix"]["every_depth_equal"] and blk["equal_to_streamed_form"])
+            blk["parity_ok"] = bool(blk["depth_sum_ok"] and blk["parity_prefix"]["every_depth_equal"] and blk["equal_to_streamed_form"] and
+                                     blk["equal_to_marks_form"])
             small.free()
         ctx.free(d_off)
         ctx.free(d_cov)
