@@ -665,3 +665,45 @@ def test_whole_sample_coverage_long_runs(ctx):
         for t in range(40):
             assert (got[t] == want[t]).all(), (env, t, np.flatnonzero(got[t] != want[t])[:5])
     db.free()
+
+
+@pytest.mark.parametrize("seed,n_refs,tl", [(1, 7, 40000), (2, 300, 3000), (3, 20000, 700)])
+def test_whole_sample_coverage_fuzz(ctx, seed, n_refs, tl):
+    """Random CIGARs (every operation code, 1-9 operations, zero-length ones among them), random targets (unmapped records
+    too) and positions such that every run stays inside its target: both whole-sample forms and the streamed path
+    against the oracle's per-base counting (msam_coverage.c:33-87)."""
+    import msamtools_amd as m
+    rng = np.random.default_rng(seed)
+    hs = m.HostSynth(99 + seed, 16000, max(n_refs, 4), 4)
+    n = hs.n_records
+    assert n >= 1 << 16
+    nops = rng.integers(1, 10, n)
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(nops)
+    ops = rng.choice(np.arange(9), size=int(off[-1]), p=[0.45, 0.1, 0.12, 0.08, 0.08, 0.03, 0.02, 0.06, 0.06]).astype(np.uint32)
+    wd = rng.integers(0, 60, int(off[-1])).astype(np.uint32)
+    wd[rng.random(wd.size) < 0.02] = rng.integers(300, 1500, int((rng.random(wd.size) < 0.02).sum()) or 1)[0]
+    ref_span = lambda: np.add.reduceat(np.where(np.isin(ops, [0, 2, 3, 7, 8]), wd, 0).astype(np.int64), off[:-1].astype(np.int64))
+    for i in np.flatnonzero(ref_span() > tl - 1):      # a record longer than its target: all soft clips but one 10M
+        ops[off[i]:off[i + 1]] = 4
+        ops[off[i]], wd[off[i]] = 0, 10
+    span = ref_span()
+    tid = rng.integers(-1, n_refs, n).astype(np.int32)
+    pos = (rng.random(n) * (tl - span)).astype(np.int32)
+    assert ((pos + span) <= tl).all()
+    hs.cigar_off, hs.cigar = off, (wd << 4 | ops).astype(np.uint32)
+    hs.tid, hs.pos = tid, pos
+    tlen = [tl] * n_refs
+    want = orc.coverage(hs, tlen)
+    db = m.DeviceBatch.upload(ctx, hs)
+    for env in (None, "MSX_COV_MARKS", "MSX_COV_STREAMED"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            got = m.coverage(ctx, db, tlen, whole_sample=True)
+        finally:
+            if env:
+                del os.environ[env]
+        for t in range(n_refs):
+            assert (got[t] == want[t]).all(), (env, t, np.flatnonzero(got[t] != want[t])[:5])
+    db.free()
