@@ -94,6 +94,7 @@ SYMBOLS = {
     "msx_ctx_destroy": (None, [_P]),
     "msx_last_error": (C.c_char_p, [_P]),
     "msx_abi_version": (C.c_int, []),
+    "msx_runtime_warmup": (C.c_int, [C.c_int]),
     "msx_ctx_stream": (_P, [_P]),
     "msx_ctx_sync": (C.c_int, [_P]),
     "msx_batch_upload": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Batch)]),

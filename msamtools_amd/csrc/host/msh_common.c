@@ -52,6 +52,27 @@ int dist_rank(void) { const char *e = getenv("RANK"); return e ? atoi(e) : 0; }
  * parent): a rank that read the WHOLE file would have its counts multiplied by the number of ranks. */
 int g_dist;
 
+/* The HIP runtime starts up (60-90 ms) on a thread of its own from the moment the options are known to be good, beside
+ * the opening of the input and the parsing of its header (a million @SQ lines: 70 ms) -- the device threads' msx_ctx_create
+ * then finds it up.  Nothing waits for this thread: a failure is reported by the msx_ctx_create that follows, and every way
+ * out of the command from here on is _exit (mDie, fast_exit), which does not run the runtime's exit handlers under it.
+ * MSX_NO_WARMUP=1: as before. */
+static void *warmup_thread(void *arg) {
+	(void)msx_runtime_warmup((int)(intptr_t)arg);
+	return NULL;
+}
+void runtime_warmup_start(void) {
+	int ids[MSH_MAX_DEVICES];
+	pthread_t th;
+	pthread_attr_t at;
+	if (getenv("MSX_NO_WARMUP")) return;
+	(void)device_list(ids);
+	pthread_attr_init(&at);
+	pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+	(void)pthread_create(&th, &at, warmup_thread, (void *)(intptr_t)ids[0]);
+	pthread_attr_destroy(&at);
+}
+
 void ctx_open_dev(int id) {
 	if (msx_ctx_create(&g_ctx, id) != MSX_OK) mDie("%s", msx_last_error(NULL));
 }

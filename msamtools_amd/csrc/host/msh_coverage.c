@@ -138,6 +138,7 @@ int msam_coverage_main(int argc, char *argv[]) {
 	out_fd = strcmp(o_out, "-") == 0 ? fileno(stdout) : open(o_out, O_WRONLY | O_CREAT | O_TRUNC, 0666);   /* :348-353 */
 	if (out_fd < 0) mDie("Cannot open %s for writing", o_out);
 
+	runtime_warmup_start();
 	in = msh_open(argv[optind]);
 	hdr = msh_header(in);
 	/* BAM input goes through the pipeline of filter and profile: a decode thread hands over batches (the first one walked

@@ -773,6 +773,7 @@ int msam_filter_main(int argc, char *argv[]) {
 	infile = argv[optind];
 	memset(&rd, 0, sizeof rd);
 	memset(&b, 0, sizeof b);
+	runtime_warmup_start();
 	rd.in = msh_open(infile);
 	hdr = msh_header(rd.in);
 

@@ -453,6 +453,7 @@ int msam_profile_main(int argc, char *argv[]) {
 			snprintf(shard, sizeof shard, "%.*s%d%s", (int)(ph - path), path, dist_rank(), ph + 6);
 			path = shard;
 		}
+		runtime_warmup_start();
 		in = msh_open(path);
 	}
 	hdr = msh_header(in);

@@ -47,6 +47,18 @@ extern "C" const char *msx_last_error(const msx_ctx *ctx) {
 	return ctx ? ctx->err.c_str() : msx_tls_err.c_str();
 }
 
+extern "C" int msx_runtime_warmup(int device_id) {
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return msx_fail(nullptr, MSX_ERR_NO_DEVICE, "no HIP device available (%s); libmsamtools_amd has no CPU fallback",
+		                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+	if (device_id < 0 || device_id >= ndev) return msx_fail(nullptr, MSX_ERR_ARG, "device %d out of range (0..%d)", device_id, ndev - 1);
+	if (hipSetDevice(device_id) != hipSuccess || hipFree(nullptr) != hipSuccess)      // (hipFree(0): the primary context, now)
+		return msx_fail(nullptr, MSX_ERR_HIP, "runtime start-up failed: %s", hipGetErrorString(hipGetLastError()));
+	return MSX_OK;
+}
+
 extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
 	if (!out) return msx_fail(nullptr, MSX_ERR_ARG, "msx_ctx_create: null output pointer");
 	*out = nullptr;
