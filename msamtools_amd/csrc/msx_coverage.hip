@@ -626,15 +626,6 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_fill_lists3(uint32_t *__restr
 }
 
 // lay[0 .. 256): where each top byte's bucket begins in the sorted items, lay[256 .. 512): how many items it holds
-__device__ __forceinline__ uint32_t cv3_bucket_at(const uint32_t *lay, uint32_t q) {
-	uint32_t lo = 0, hi = 256;                               // the last bucket that begins at or before q
-	while (lo + 1 < hi) {
-		const uint32_t mid = (lo + hi) >> 1;
-		if (lay[mid] <= q) lo = mid; else hi = mid;
-	}
-	return lo;
-}
-
 // start[2 t], start[2 t + 1]: the sorted items of tile t
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay, int64_t n_tiles,
                                                            uint32_t *__restrict__ start) {
@@ -651,40 +642,32 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_starts3(const uint32_t *__res
 	start[q] = lo;
 }
 
+// A tile with more items than a workgroup should walk alone is pre-reduced by several: its items in UNITS of CV3_UNIT, each
+// unit one workgroup's share (k_cov_heavy_add3).  (Round 4's first cut listed the 8 K-item chunks of the sorted array that
+// touch such a tile and flushed an image per chunk: 4096 atomics per 8192 items; units of 32 K flush a quarter of that.)
+#define CV3_UNIT 32768u
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list3(const uint32_t *__restrict__ start, int64_t n_tiles, int32_t *__restrict__ slot_of,
-                                                               cv2_state *__restrict__ st, uint32_t heavy_from) {
+                                                               cv2_state *__restrict__ st, uint32_t heavy_from, uint4 *__restrict__ units,
+                                                               uint32_t unit_cap) {
 	const int64_t t = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (t >= n_tiles) return;
 	int32_t slot = -1;
-	if (start[2 * t + 1] - start[2 * t] > heavy_from) {
+	const uint32_t lo = start[2 * t], hi = start[2 * t + 1];
+	if (hi - lo > heavy_from) {
 		const uint32_t k = atomicAdd(&st->n_heavy, 1u);
-		if (k < CV2_HEAVY_CAP) slot = (int32_t)k; else st->overflow = 1;
+		const uint32_t nu = (hi - lo + CV3_UNIT - 1u) / CV3_UNIT;
+		const uint32_t ub = atomicAdd(&st->n_hchunks, nu);
+		if (k < CV2_HEAVY_CAP && ub + nu <= unit_cap) {
+			slot = (int32_t)k;
+			for (uint32_t u = 0; u < nu; u++) {
+				const uint32_t a = lo + u * CV3_UNIT;
+				units[ub + u] = make_uint4((uint32_t)k, a, hi - a < CV3_UNIT ? hi : a + CV3_UNIT, 0u);
+			}
+		} else {
+			st->overflow = 1;
+		}
 	}
 	slot_of[t] = slot;
-}
-
-// (a pre-reduced tile has more items than a chunk holds: inside a chunk it is the tile of the first or of the last item)
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_chunks3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay,
-                                                                 int64_t n_tiles, const int32_t *__restrict__ slot_of,
-                                                                 cv2_state *__restrict__ st, uint32_t *__restrict__ chunk_list) {
-	const int64_t n = (int64_t)lay[255];                     // (bucket 255: the empty slots)
-	const int64_t c = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	const int64_t lo = c * CV_CHUNK;
-	bool hit = false;
-	if (st->n_heavy != 0 && lo < n) {
-		const int64_t hi = lo + CV_CHUNK < n ? lo + CV_CHUNK : n;
-		const int64_t ta = (int64_t)(cv3_bucket_at(lay, (uint32_t)lo) << 8 | items[lo] >> 24);
-		const int64_t tb = (int64_t)(cv3_bucket_at(lay, (uint32_t)(hi - 1)) << 8 | items[hi - 1] >> 24);
-		hit = (ta < n_tiles && slot_of[ta] >= 0) || (tb < n_tiles && slot_of[tb] >= 0);
-	}
-	const unsigned long long m = __ballot(hit);
-	if (m) {                                                 // one append per wave
-		const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
-		uint32_t base = 0;
-		if (lane == lead) base = atomicAdd(&st->n_hchunks, (uint32_t)__popcll(m));
-		base = (uint32_t)__shfl((int)base, lead, 64);
-		if (hit) chunk_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)c;
-	}
 }
 
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_zero3(int32_t *__restrict__ side, const cv2_state *__restrict__ st) {
@@ -702,37 +685,34 @@ __device__ __forceinline__ void cv3_mark(int32_t *s_d, uint32_t v) {
 	if (e < CV3_TILE) atomicAdd(&s_d[e], -1);
 }
 
-__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ lay,
-                                                              const uint32_t *__restrict__ start, int64_t n_tiles,
-                                                              const int32_t *__restrict__ slot_of, int32_t *__restrict__ side,
-                                                              const cv2_state *__restrict__ st, const uint32_t *__restrict__ chunk_list) {
+__global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__restrict__ items, int32_t *__restrict__ side,
+                                                              const cv2_state *__restrict__ st, const uint4 *__restrict__ units,
+                                                              uint32_t unit_cap) {
 	__shared__ int32_t s_d[CV3_TILE];
-	const int64_t n = (int64_t)lay[255];
-	for (uint32_t ci = blockIdx.x; ci < st->n_hchunks; ci += gridDim.x) {
-		const int64_t lo_c = (int64_t)chunk_list[ci] * CV_CHUNK;
-		if (lo_c >= n) continue;
-		const int64_t hi_c = lo_c + CV_CHUNK < n ? lo_c + CV_CHUNK : n;
-		int64_t a = lo_c;
-		while (a < hi_c) {                                       // the tiles this chunk touches, by their ends
-			const uint32_t sup = cv3_bucket_at(lay, (uint32_t)a);
-			const uint32_t t = sup << 8 | items[a] >> 24;        // (an empty slot: tile 255 of its bucket, whose items it lies among)
-			const int64_t e_t = (int64_t)start[2 * (int64_t)t + 1];
-			const int64_t b = e_t < hi_c ? e_t : hi_c;
-			const int32_t slot = (int64_t)t < n_tiles ? slot_of[t] : -1;
-			if (slot >= 0) {                                     // (workgroup-uniform)
-				for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) s_d[q] = 0;
-				__syncthreads();
-				for (int64_t q = a + threadIdx.x; q < b; q += MSX_BLOCK) cv3_mark(s_d, items[q]);
-				__syncthreads();
-				int32_t *img = side + (size_t)slot * CV3_TILE;
-				for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) {
-					const int32_t d = s_d[q];
-					if (__ballot(d != 0) != 0ull) atomicAdd(&img[q], d);
-				}
-				__syncthreads();
+	const uint32_t n_units = st->n_hchunks < unit_cap ? st->n_hchunks : unit_cap;
+	for (uint32_t ui = blockIdx.x; ui < n_units; ui += gridDim.x) {
+		const uint4 u = units[ui];                               // (image slot, first item, behind the last item)
+		for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) s_d[q] = 0;
+		__syncthreads();
+		{
+			// eight items per thread in flight, then their marks (one after the other the loads were the whole of the time)
+			uint32_t q = u.y + threadIdx.x;
+			for (; q + 7u * MSX_BLOCK < u.z; q += 8u * MSX_BLOCK) {
+				uint32_t v[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) v[j] = items[q + (uint32_t)j * MSX_BLOCK];
+#pragma unroll
+				for (int j = 0; j < 8; j++) cv3_mark(s_d, v[j]);
 			}
-			a = b > a ? b : a + 1;
+			for (; q < u.z; q += MSX_BLOCK) cv3_mark(s_d, items[q]);
 		}
+		__syncthreads();
+		int32_t *img = side + (size_t)u.x * CV3_TILE;
+		for (uint32_t q = threadIdx.x; q < CV3_TILE; q += MSX_BLOCK) {
+			const int32_t d = s_d[q];
+			if (__ballot(d != 0) != 0ull) atomicAdd(&img[q], d);
+		}
+		__syncthreads();
 	}
 }
 
@@ -813,8 +793,8 @@ static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *co
 	// cv_key[0]: the items and their top bytes, later the sorted items; cv_key[1]: the items between the passes
 	if ((rc = msx_reserve(ctx, &ctx->cv_key[0], (size_t)(n_ub + 64) * 4 + (size_t)n_items + 64))) return rc;
 	if ((rc = msx_reserve(ctx, &ctx->cv_key[1], (size_t)(n_ub + 64) * 4))) return rc;
-	const int64_t n_chunks = (n_ub + CV_CHUNK - 1) / CV_CHUNK;
-	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * n_tiles + n_tiles + 512 + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(n_chunks + 64) * 4 +
+	const uint32_t unit_cap = (uint32_t)(n_ub / CV3_UNIT + CV2_HEAVY_CAP + 64);      // (a tile's last unit may be short)
+	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * n_tiles + n_tiles + 512 + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(unit_cap + 8) * 16 +
 	                                                (size_t)n_targets * 8 + 64)))
 		return rc;
 	if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
@@ -824,8 +804,8 @@ static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *co
 	int32_t *slot_of = (int32_t *)(start + 2 * n_tiles);
 	uint32_t *lay = (uint32_t *)(slot_of + n_tiles);
 	cv2_state *st = (cv2_state *)(((uintptr_t)(lay + 512) + 63) & ~(uintptr_t)63);
-	uint32_t *chunk_list = (uint32_t *)(st + 1);
-	uint2 *targets = (uint2 *)(((uintptr_t)(chunk_list + n_chunks + 64) + 15) & ~(uintptr_t)15);
+	uint4 *units = (uint4 *)(((uintptr_t)(st + 1) + 15) & ~(uintptr_t)15);
+	uint2 *targets = (uint2 *)(units + unit_cap + 4);
 	uint32_t *items = (uint32_t *)ctx->cv_key[0].p, *items1 = (uint32_t *)ctx->cv_key[1].p;
 	uint8_t *sups = (uint8_t *)(items + n_ub + 64);
 	MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
@@ -845,13 +825,10 @@ static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *co
 	hipLaunchKernelGGL(k_cov_starts3, dim3((unsigned)((2 * n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                   (const uint32_t *)items, (const uint32_t *)lay, n_tiles, start);
 	hipLaunchKernelGGL(k_cov_heavy_list3, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)start, n_tiles, slot_of, st, heavy_from);
-	hipLaunchKernelGGL(k_cov_heavy_chunks3, dim3((unsigned)((n_chunks + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)items, (const uint32_t *)lay, n_tiles, (const int32_t *)slot_of, st, chunk_list);
+	                   (const uint32_t *)start, n_tiles, slot_of, st, heavy_from, units, unit_cap);
 	hipLaunchKernelGGL(k_cov_heavy_zero3, dim3(CV2_HEAVY_CAP), dim3(MSX_BLOCK), 0, ctx->stream, (int32_t *)ctx->cv_side.p, (const cv2_state *)st);
-	hipLaunchKernelGGL(k_cov_heavy_add3, dim3((unsigned)(n_chunks < 1024 ? n_chunks : 1024)), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   (const uint32_t *)items, (const uint32_t *)lay, (const uint32_t *)start, n_tiles, (const int32_t *)slot_of,
-	                   (int32_t *)ctx->cv_side.p, (const cv2_state *)st, (const uint32_t *)chunk_list);
+	hipLaunchKernelGGL(k_cov_heavy_add3, dim3(unit_cap < 2048u ? unit_cap : 2048u), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items,
+	                   (int32_t *)ctx->cv_side.p, (const cv2_state *)st, (const uint4 *)units, unit_cap);
 	hipLaunchKernelGGL(k_cov_depths3, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items, (const uint32_t *)start,
 	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov, getenv("MSX_COV_NO_NT") ? 0 : 1);
 	msx_time_end(ctx);
