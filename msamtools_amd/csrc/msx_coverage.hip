@@ -735,7 +735,15 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths3(const uint32_t *__res
 	} else {
 		for (uint32_t q = threadIdx.x; q < CV3_TILE / 4; q += MSX_BLOCK) reinterpret_cast<int4 *>(s_d)[q] = make_int4(0, 0, 0, 0);
 		__syncthreads();
-		for (uint32_t q = ps + threadIdx.x; q < pe; q += MSX_BLOCK) cv3_mark(s_d, items[q]);
+		uint32_t q = ps + threadIdx.x;
+		for (; q + 3u * MSX_BLOCK < pe; q += 4u * MSX_BLOCK) {      // (four loads in flight)
+			uint32_t v[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) v[j] = items[q + (uint32_t)j * MSX_BLOCK];
+#pragma unroll
+			for (int j = 0; j < 4; j++) cv3_mark(s_d, v[j]);
+		}
+		for (; q < pe; q += MSX_BLOCK) cv3_mark(s_d, items[q]);
 	}
 	__syncthreads();
 	const int64_t c0 = t << CV3_TILE_SHIFT;
