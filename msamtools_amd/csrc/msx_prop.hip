@@ -568,16 +568,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long
                                                         unsigned long long *__restrict__ sig) {
 	const int64_t n_lists = (int64_t)csr_tot[0];
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
-	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += stride) {
-		const uint32_t s = m_off[j], e = m_off[j + 1];
+	// one list: its bounds and (up to three features) its features have been fetched by the caller
+	auto one = [&](int64_t j, uint32_t s, uint32_t e, uint32_t p0, uint32_t p1, uint32_t p2) {
 		uint32_t mn = 0xffffffffu, h = (e - s) * 0x9e3779b9u, h2 = (e - s) * 0x85ebca6bu;
 		unsigned long long sg;
 		if (e - s <= 3u) {
-			// independent loads, then a 3-element sorting network
-			uint32_t f0 = SIG_PAD, f1 = SIG_PAD, f2 = SIG_PAD;
-			if (e - s > 0u) f0 = (uint32_t)m_fid[s];
-			if (e - s > 1u) f1 = (uint32_t)m_fid[s + 1];
-			if (e - s > 2u) f2 = (uint32_t)m_fid[s + 2];
+			// a 3-element sorting network
+			const uint32_t f0 = e - s > 0u ? p0 : SIG_PAD, f1 = e - s > 1u ? p1 : SIG_PAD, f2 = e - s > 2u ? p2 : SIG_PAD;
 			const bool fits = (e - s > 0u) && f0 < SIG_PAD && (e - s < 2u || f1 < SIG_PAD) && (e - s < 3u || f2 < SIG_PAD);
 			if (e - s > 0u) { h += mix32(f0); h2 += mix32(f0 ^ 0x5bd1e995u); }
 			if (e - s > 1u) { h += mix32(f1); h2 += mix32(f1 ^ 0x5bd1e995u); }
@@ -612,6 +609,28 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_list_key(const unsigned long long
 			key[j] = hash_bits > 0 ? ((mn << hash_bits) | hb) : mn;
 		}
 		sig[j] = sg;                                          // travels through the sort as the value
+	};
+	// two lists per thread at a time: both lists' bounds, then both lists' features, then the arithmetic (a list after the
+	// other left the two dependent round trips of each exposed)
+	for (int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; j < n_lists; j += 2 * stride) {
+		const int64_t j2 = j + stride;
+		const bool two = j2 < n_lists;
+		const uint32_t s0 = m_off[j], e0 = m_off[j + 1];
+		uint32_t s1 = 0, e1 = 0;
+		if (two) { s1 = m_off[j2]; e1 = m_off[j2 + 1]; }
+		uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+		if (e0 - s0 <= 3u) {
+			if (e0 - s0 > 0u) a0 = (uint32_t)m_fid[s0];
+			if (e0 - s0 > 1u) a1 = (uint32_t)m_fid[s0 + 1];
+			if (e0 - s0 > 2u) a2 = (uint32_t)m_fid[s0 + 2];
+		}
+		if (two && e1 - s1 <= 3u) {
+			if (e1 - s1 > 0u) b0 = (uint32_t)m_fid[s1];
+			if (e1 - s1 > 1u) b1 = (uint32_t)m_fid[s1 + 1];
+			if (e1 - s1 > 2u) b2 = (uint32_t)m_fid[s1 + 2];
+		}
+		one(j, s0, e0, a0, a1, a2);
+		if (two) one(j2, s1, e1, b0, b1, b2);
 	}
 }
 
