@@ -72,7 +72,21 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist(const uint32_t *__restric
 	if (base >= E) return;
 	if (n_ptr) n_tiles = (E + RS_TILE - 1) / RS_TILE;
 	for (int q = 0; q < 4; q++) s_cnt[w][lane + 64 * q] = 0;
-	if (SKIP) {
+	if (SKIP && base + RS_TILE <= E) {
+		// (all of the thread's keys asked for before any is counted: a load per iteration under its bounds check left
+		//  sixteen round trips in a row)
+		const uint4 *kv = reinterpret_cast<const uint4 *>(keys + base);
+		uint4 v[RS_EPT / 4];
+#pragma unroll
+		for (int q = 0; q < RS_EPT / 4; q++) v[q] = kv[q * MSX_BLOCK + threadIdx.x];
+#pragma unroll
+		for (int q = 0; q < RS_EPT / 4; q++) {
+			if (!RS_SKIPPED(v[q].x)) atomicAdd(&s_cnt[w][(v[q].x >> shift) & dmask], 1u);
+			if (!RS_SKIPPED(v[q].y)) atomicAdd(&s_cnt[w][(v[q].y >> shift) & dmask], 1u);
+			if (!RS_SKIPPED(v[q].z)) atomicAdd(&s_cnt[w][(v[q].z >> shift) & dmask], 1u);
+			if (!RS_SKIPPED(v[q].w)) atomicAdd(&s_cnt[w][(v[q].w >> shift) & dmask], 1u);
+		}
+	} else if (SKIP) {
 		for (int q = 0; q < RS_EPT; q++) {
 			const int64_t k = base + q * MSX_BLOCK + threadIdx.x;
 			if (k < E) {
