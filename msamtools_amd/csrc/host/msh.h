@@ -141,5 +141,6 @@ int32_t *msh_genome_map(const char *path, const msh_hdr *h, int32_t *n_features,
 int msam_filter_main(int argc, char *argv[]);
 int msam_profile_main(int argc, char *argv[]);
 int msam_coverage_main(int argc, char *argv[]);
+int msam_summary_main(int argc, char *argv[]);
 
 #endif

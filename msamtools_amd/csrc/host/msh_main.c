@@ -1,5 +1,5 @@
 /*
- * msh_main.c -- the program's entry: command dispatch as msamtools.c:8-49 (filter, profile, coverage, help).
+ * msh_main.c -- the program's entry: command dispatch as msamtools.c:8-49 (filter, profile, coverage, summary, help).
  */
 #include "msh_cli.h"
 
@@ -22,6 +22,9 @@ int usage(FILE *out) {
 	fprintf(out, " -- Coverage\n");
 	fprintf(out, "     coverage       estimate per-base or per-sequence read coverage of each reference sequence\n");
 	fprintf(out, "\n");
+	fprintf(out, " -- Summary\n");
+	fprintf(out, "     summary        summarize alignment statistics per read in a table format\n");
+	fprintf(out, "\n");
 	return 1;
 }
 
@@ -33,6 +36,7 @@ int main(int argc, char *argv[]) {
 	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "coverage") == 0) return msam_coverage_main(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "summary") == 0) return msam_summary_main(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "help") == 0) { usage(stdout); return 0; }
 	fprintf(stderr, "[msamtools] unrecognized command '%s'\n", argv[1]);
 	usage(stderr);

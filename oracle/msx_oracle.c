@@ -738,3 +738,132 @@ int32_t orc_key_order(const char *const *names, int32_t n, int32_t *order) {
 	free(keys.item);
 	return nk;
 }
+
+/* ------------------------------------------------------------------------- */
+/* summary: mBamVector.c:135-236, msam_summary.c:19-135                       */
+/* ------------------------------------------------------------------------- */
+void orc_ext_summary_record(const uint32_t *cigar, uint32_t n_cigar, const char *md, int has_md, orc_ext_summary *out) {
+	int32_t alen = 0, qlen = 0, qclip = 0, match = 0, mismatch = 0, gapopen = 0, gapextend = 0;
+	uint32_t k;
+	for (k = 0; k < n_cigar; ++k) {                          /* :155-196 */
+		int op = (int)(cigar[k] & 0xf);
+		int w = (int)(cigar[k] >> 4);
+		switch (op) {
+		case OP_MATCH: case OP_EQUAL: case OP_DIFF:
+			match += w; qlen += w; alen += w;
+			break;
+		case OP_INS:
+			qlen += w; gapopen++; gapextend += (w - 1); alen += w;
+			break;
+		case OP_DEL:
+			gapopen++; gapextend += (w - 1); alen += w;
+			break;
+		case OP_HARD_CLIP: case OP_SOFT_CLIP:
+			qclip += w; qlen += w;
+			break;
+		default:                                             /* N, P, anything else */
+			break;
+		}
+	}
+	if (has_md) {                                            /* :200-219: kstrtok(md, "^0123456789") */
+		/* a token is a maximal run of bytes outside the separator set; it counts when it does not begin the string and
+		 * the byte in front of it is not '^' -- every byte of it (the loop at :214-216 is the inner one here) */
+		size_t i = 0, n = strlen(md);
+		while (i < n) {
+			size_t j;
+			if (md[i] == '^' || (md[i] >= '0' && md[i] <= '9')) { i++; continue; }
+			j = i;
+			while (j < n && !(md[j] == '^' || (md[j] >= '0' && md[j] <= '9'))) j++;
+			if (i > 0 && md[i - 1] != '^') mismatch += (int32_t)(j - i);
+			i = j;
+		}
+		match -= mismatch;                                   /* :218 */
+	}
+	out->match = match; out->mismatch = mismatch; out->gapopen = gapopen; out->gapextend = gapextend;
+	out->query_length = qlen; out->query_clip = qclip; out->length = alen;
+	out->edit = mismatch + qclip + gapopen + gapextend;      /* :228 */
+}
+
+/* htslib bam_endpos: pos + bam_cigar2rlen (M, D, N, =, X consume the reference), a length of 0 counts as 1 */
+static int64_t ext_endpos(const orc_records *r, int64_t i) {
+	int64_t rlen = 0;
+	uint32_t k;
+	if (!(r->flag[i] & F_UNMAP))
+		for (k = r->cigar_off[i]; k < r->cigar_off[i + 1]; k++) {
+			int op = (int)(r->cigar[k] & 0xf);
+			if (op == OP_MATCH || op == OP_DEL || op == OP_REF_SKIP || op == OP_EQUAL || op == OP_DIFF) rlen += r->cigar[k] >> 4;
+		}
+	if (rlen == 0) rlen = 1;
+	return (int64_t)r->pos[i] + rlen;
+}
+
+/* the records mSummarizeAlignments / ...Stats look at (msam_summary.c:56-66, :98-108) */
+static int summary_takes(const orc_records *r, const uint32_t *target_len, uint32_t edge, int64_t i) {
+	int64_t start, end;
+	if (r->flag[i] & F_UNMAP) return 0;
+	if (r->flag[i] & 0x100) return 0;                        /* BAM_FSECONDARY */
+	start = r->pos[i];
+	end = ext_endpos(r, i);
+	if (start < (int64_t)edge || (int64_t)target_len[r->tid[i]] - end < (int64_t)edge) return 0;
+	return 1;
+}
+
+static void summary_of(const orc_records *r, int64_t i, orc_ext_summary *a) {
+	char *md = NULL;
+	int has_md = (r->rflags[i] & ORC_HAS_MD) != 0;
+	if (has_md) {
+		uint32_t l = r->md_off[i + 1] - r->md_off[i];
+		md = (char *)malloc((size_t)l + 1);
+		memcpy(md, r->md + r->md_off[i], l);
+		md[l] = 0;
+	}
+	orc_ext_summary_record(r->cigar + r->cigar_off[i], r->cigar_off[i + 1] - r->cigar_off[i], md, has_md, a);
+	free(md);
+}
+
+int64_t orc_summary_table(const orc_records *r, const uint32_t *target_len, uint32_t edge, int64_t *sel, int32_t *vals) {
+	int64_t i, n = 0;
+	for (i = 0; i < r->n; i++) {
+		orc_ext_summary a;
+		if (!summary_takes(r, target_len, edge, i)) continue;
+		summary_of(r, i, &a);
+		sel[n] = i;
+		vals[4 * n] = a.query_length;
+		vals[4 * n + 1] = a.length + a.query_clip;           /* glocal_len :70 */
+		vals[4 * n + 2] = a.match;
+		vals[4 * n + 3] = a.edit;
+		n++;
+	}
+	return n;
+}
+
+void orc_summary_stats(const orc_records *r, const uint32_t *target_len, uint32_t edge, int stats_type, int64_t *dist) {
+	int64_t i;
+	memset(dist, 0, 4097 * sizeof(int64_t));
+	for (i = 0; i < r->n; i++) {
+		orc_ext_summary a;
+		uint32_t stats[4];
+		int idx;
+		if (!summary_takes(r, target_len, edge, i)) continue;
+		summary_of(r, i, &a);
+		stats[0] = (uint32_t)a.match;                        /* :110-113 */
+		stats[1] = (uint32_t)(a.query_length - a.match);
+		stats[2] = (uint32_t)a.edit;
+		stats[3] = (uint32_t)(a.match - a.edit);
+		idx = (int)stats[stats_type];                        /* :120-122 */
+		if (idx > 4096) idx = 4096;
+		if (idx < 0) idx = 0;
+		dist[idx]++;
+	}
+}
+
+int64_t orc_summary_count(const orc_records *r) {
+	int64_t i, prev = -1, count = 0;
+	for (i = 0; i < r->n; i++) {
+		if (r->flag[i] & F_UNMAP) continue;                  /* :30 */
+		/* prev_read starts as "": a first mapped record with an empty name would not count (:21, :32) */
+		if (prev < 0 ? (r->qname_off ? r->qname_off[i + 1] > r->qname_off[i] : 1) : !same_name(r, i, prev)) count++;
+		prev = i;
+	}
+	return count;
+}

@@ -168,4 +168,27 @@ int32_t orc_key_order(const char *const *names, int32_t n, int32_t *order);
 #ifdef __cplusplus
 }
 #endif
+
+/* --- `summary` (msam_summary.c, mBamVector.c:135-236) ------------------------ */
+
+/* bam_get_extended_summary (mBamVector.c:135-236): the summary subcommand's own record walk.  MD only -- NM is never
+ * looked at -- and the MD count is the inner loop's (one per mismatching base). */
+typedef struct {
+	int32_t match, mismatch, gapopen, gapextend, query_length, query_clip, length, edit;
+} orc_ext_summary;
+void orc_ext_summary_record(const uint32_t *cigar, uint32_t n_cigar, const char *md, int has_md, orc_ext_summary *out);
+
+/* mSummarizeAlignments (msam_summary.c:42-74): for every record the table prints -- mapped, not secondary, not within
+ * `edge` bases of either end of its target (bam_endpos: pos + reference length of the CIGAR, + 1 when that is 0) --
+ * its number in sel[] and {query_length, glocal_len, match, edit} in vals[4 * k ..]; returns how many.
+ * target_len[tid] as the header gives it. */
+int64_t orc_summary_table(const orc_records *r, const uint32_t *target_len, uint32_t edge, int64_t *sel, int32_t *vals);
+
+/* mSummarizeAlignmentsStats (msam_summary.c:76-135): dist[0 .. 4096] of the chosen statistic
+ * (0 mapped, 1 unmapped, 2 edit, 3 score; values above 4096 counted at 4096, "negative" ones at 0). */
+void orc_summary_stats(const orc_records *r, const uint32_t *target_len, uint32_t edge, int stats_type, int64_t *dist);
+
+/* mCountInserts (msam_summary.c:19-40): mapped records whose QNAME differs from the previous mapped record's */
+int64_t orc_summary_count(const orc_records *r);
+
 #endif

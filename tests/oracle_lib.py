@@ -194,3 +194,48 @@ def make_records_slice(rec, name_id, lo, hi):
     v.nm = rec.nm[lo:hi]
     v.as_ = rec.as_[lo:hi]
     return v
+
+
+def summary_table(rec, target_len, edge=0):
+    """msamtools summary's per-alignment table (msam_summary.c:42-74): (record numbers, [query_length, glocal_len, match,
+    edit] per row)."""
+    r, keep = make_records(rec)
+    tl = np.ascontiguousarray(target_len, dtype=np.uint32)
+    sel = np.zeros(max(r.n, 1), np.int64)
+    vals = np.zeros(4 * max(r.n, 1), np.int32)
+    f = lib().orc_summary_table
+    f.restype = C.c_int64
+    n = f(C.byref(r), _p(tl), C.c_uint32(edge), _p(sel), _p(vals))
+    return sel[:n].copy(), vals[:4 * n].reshape(n, 4).copy()
+
+
+def summary_lines(rec, names, target_names, target_len, edge=0):
+    """The table as the text the reference prints (msam_summary.c:71)."""
+    sel, v = summary_table(rec, target_len, edge)
+    out = []
+    for k, i in enumerate(sel):
+        ql, gl, m, e = (int(x) for x in v[k])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ident = float(np.float64(100.0) - np.float64(100.0) * np.float64(e) / np.float64(gl))
+        out.append("%s\t%d\t%s\t%d\t%d\t%.1f" % (names[i], ql, target_names[rec.tid[i]], gl, m, ident))
+    return out
+
+
+def summary_stats(rec, target_len, which, edge=0):
+    """--stats {mapped|unmapped|edit|score}: the distribution as the reference prints it (msam_summary.c:76-135)."""
+    r, keep = make_records(rec)
+    tl = np.ascontiguousarray(target_len, dtype=np.uint32)
+    dist = np.zeros(4097, np.int64)
+    lib().orc_summary_stats(C.byref(r), _p(tl), C.c_uint32(edge), C.c_int(("mapped", "unmapped", "edit", "score").index(which)), _p(dist))
+    out = ["%d\t%d" % (i, dist[i]) for i in range(4096) if dist[i] > 0]
+    if dist[4096] > 0:
+        out.append("4096+\t%d" % dist[4096])
+    return out
+
+
+def summary_count(rec, name_id=None):
+    """--count: QNAME groups among the mapped records (msam_summary.c:19-40)."""
+    r, keep = make_records(rec, name_id)
+    f = lib().orc_summary_count
+    f.restype = C.c_int64
+    return int(f(C.byref(r)))

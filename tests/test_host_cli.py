@@ -723,3 +723,74 @@ def test_product_binary_carries_only_the_reference_commands():
         r = subprocess.run([BIN, c], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1 and b"unrecognized command" in r.stderr, c
     assert subprocess.run([DEV, "filter"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
+
+
+# ---- `summary` (msam_summary.c) ----------------------------------------------------------------------------------------
+
+def test_summary_count_and_option_errors_need_no_gpu():
+    """--count reads names and flags only (mCountInserts, msam_summary.c:19-40); the option conflicts are refused before the
+    input is opened, with the reference's lines on stdout (:222-242), an unknown --stats mode with its mDie text (:266)."""
+    for case in EXP["summary"]["cases"]:
+        if "-c" in case["args"]:
+            r = run(["summary", "-S"] + case["args"] + [fixture_path(case["fixture"])])
+            assert r.returncode == 0 and r.stdout.decode().split("\n")[:-1] == case["stdout"], case["src"]
+            assert r.stderr == b""
+    fx = fixture_path("summary.sam")
+    r = run(["summary", "-S", "-e", "-1", fx])
+    assert r.returncode == 1 and r.stdout.decode().startswith("-e must be a positive integer\n")
+    r = run(["summary", "-S", "--stats", "edit", "-c", fx])
+    assert r.returncode == 1 and r.stdout.decode().startswith("--stats cannot be combined with --count\n")
+    r = run(["summary", "-S", "-e", "3", "-c", fx])
+    assert r.returncode == 1 and r.stdout.decode().startswith("-e cannot be combined with --count\n")
+    r = run(["summary", "-S", "--stats", "median", fx])
+    assert r.returncode == 1 and r.stderr.decode().strip().endswith("Fatal Error: Do not understand median as mode")
+    r = run(["summary", "--help"])
+    assert r.returncode == 0 and b"qname,aligned_qlen,target_name,glocal_align_len,matches,percent_identity" in r.stdout
+    assert b"summary        summarize alignment statistics per read in a table format" in run(["help"]).stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXP["summary"]["cases"], ids=[c["name"] for c in EXP["summary"]["cases"]])
+def test_cli_summary_golden(case):
+    """test_summary.sh through the command line: the table, --edge, the four --stats distributions, --count, M against =/X."""
+    r = run(["summary", "-S"] + case["args"] + [fixture_path(case["fixture"])])
+    assert r.returncode == 0, r.stderr.decode()
+    got = r.stdout.decode().split("\n")[:-1]
+    if "stdout" in case:
+        assert got == case["stdout"], case["src"]
+    for x in case.get("contains", []):
+        assert any(x in l for l in got), case["src"]
+    for x in case.get("not_contains", []):
+        assert not any(x in l for l in got), case["src"]
+    if case.get("stderr_empty"):
+        assert r.stderr == b""
+
+
+@pytest.mark.gpu
+def test_cli_summary_equals_the_oracle(tmp_path, synth_bams):
+    """Every fixture (records without MD, with NM only, soft and hard clips, I / D / N, unmapped and secondary ones) and a
+    300 000-record BAM through `summary` -- table, --edge, every --stats mode, --count -- against the oracle's restatement of
+    msam_summary.c and bam_get_extended_summary (mBamVector.c:135-236); BAM input takes the bulk reader, SAM the text one."""
+    import oracle_lib as orc
+    sams = [fixture_path(f) for f in ("summary.sam", "summary_count.sam", "summary_edge.sam", "filter.sam", "cigar_eqx.sam", "besthit.sam",
+                                      "profile.sam", "integration.sam", "coverage.sam", "long_qname.sam")]
+    big_sam = tmp_path / "big.sam"
+    big_sam.write_bytes(run(["recode", "-h", synth_bams["b"]]).stdout)
+    for path in sams + [str(big_sam)]:
+        hdr, rec = samio.read_sam(path)
+        names = [rec.name(i) for i in range(rec.n)]
+        inputs = [path]
+        if path == str(big_sam):
+            inputs.append(synth_bams["b"])                     # the same records as BAM
+        for inp in inputs:
+            for edge in (0, 7):
+                e = ["-e", str(edge)] if edge else []
+                r = run(["summary"] + e + [inp])
+                assert r.returncode == 0, (inp, r.stderr.decode()[-500:])
+                assert r.stdout.decode().split("\n")[:-1] == orc.summary_lines(rec, names, hdr.target_name, hdr.target_len, edge), (inp, edge)
+                for which in ("mapped", "unmapped", "edit", "score"):
+                    r = run(["summary", "--stats", which] + e + [inp])
+                    assert r.returncode == 0
+                    assert r.stdout.decode().split("\n")[:-1] == orc.summary_stats(rec, hdr.target_len, which, edge), (inp, which, edge)
+            r = run(["summary", "-c", inp])
+            assert r.returncode == 0 and r.stdout.decode().strip() == str(orc.summary_count(rec)), inp

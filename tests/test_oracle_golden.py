@@ -169,3 +169,29 @@ def test_unmapped_flushes_pool_without_renaming():
               names=["a", "b", "a", "c"], as_=[10, 0, 20, 5])
     out = orc.run_filter(rec, besthit=True)
     assert out["emit"].tolist() == [0, 2, 3]     # {a0} and {a2} are separate pools
+
+
+def oracle_summary_stdout(fixture, args):
+    """What `msamtools summary -S <args> <fixture>` prints, from the oracle."""
+    hdr, rec = samio.read_sam(fixture_path(fixture))
+    names = [rec.name(i) for i in range(rec.n)]
+    edge = int(args[args.index("-e") + 1]) if "-e" in args else 0
+    if "-c" in args:
+        return [str(orc.summary_count(rec))]
+    if "--stats" in args:
+        return orc.summary_stats(rec, hdr.target_len, args[args.index("--stats") + 1], edge)
+    return orc.summary_lines(rec, names, hdr.target_name, hdr.target_len, edge)
+
+
+@pytest.mark.parametrize("case", EXP["summary"]["cases"], ids=[c["name"] for c in EXP["summary"]["cases"]])
+def test_summary_golden(case):
+    """test_summary.sh: the per-alignment table, --edge, the four --stats distributions, --count (also with 251-byte QNAMEs),
+    M against =/X CIGARs -- the oracle's restatement of msam_summary.c / bam_get_extended_summary against the exact
+    output the reference's own test holds."""
+    got = oracle_summary_stdout(case["fixture"], case["args"])
+    if "stdout" in case:
+        assert got == case["stdout"], case["src"]
+    for x in case.get("contains", []):
+        assert any(x in l for l in got), case["src"]
+    for x in case.get("not_contains", []):
+        assert not any(l.startswith(x) or x in l for l in got), case["src"]
