@@ -156,7 +156,9 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_hist8(const uint8_t *__restric
 //        bucket's earlier tiles) -- all from the row-wise scans of the digit counts (hoff) at the bucket's first tile,
 //        at this tile and at the next bucket's first tile.  Tiles behind the last bucket and those of bucket
 //        `skip_bucket` have nothing to do.
-template <bool DV, bool SEG>
+//   SKIPK: keys only, keys with bit 31 set are not part of the input (msx_count_keys: the per-pool word of msx_count.h), hoff
+//        holds one scan over the whole table (digit-major), no dtot / btot
+template <bool DV, bool SEG, bool SKIPK = false>
 __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__restrict__ keys_in, const uint8_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ keys_out, int64_t n, int shift,
                                                               const uint32_t *__restrict__ hoff, int64_t n_tiles,
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__
 	__shared__ uint8_t s_dig[DV ? RS_TILE : 1];       // DV: the digit of the key at each place of the ordered tile
 	__shared__ uint4 s_v8[DV ? RS_TILE / 16 : 1];
 	__shared__ uint32_t s_cnt[256], s_dstart[256], s_gbase[256];
-	__shared__ uint32_t s_wsum[MSX_BLOCK / 64], s_gsum[MSX_BLOCK / 64], s_bfirst, s_bnext;
+	__shared__ uint32_t s_wsum[MSX_BLOCK / 64], s_gsum[MSX_BLOCK / 64], s_bfirst, s_bnext, s_nvalid;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int64_t tile = blockIdx.x, base = tile * RS_TILE;
 	if (base >= n) return;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
 		const uint32_t i = wbase + (uint32_t)r * 64u;
-		const bool valid = i < n_here;
+		const bool valid = i < n_here && !(SKIPK && RS_SKIPPED(key[r]));
 		uint32_t d;
 		if (DV) d = v8 ? (uint32_t) reinterpret_cast<const uint8_t *>(s_v8)[i] : (valid ? (uint32_t)vals_in[base + i] : 0u);
 		else d = (key[r] >> shift) & 255u;
@@ -236,7 +238,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__
 		// ... and in the output: over the digits' padded totals (DV), or over their totals inside the bucket (SEG)
 		uint32_t p_first = 0;
 		if (SEG) p_first = hoff[(int64_t)d * n_tiles + s_bfirst];
-		const uint32_t gt = SEG ? ((s_bnext < (uint32_t)n_tiles ? hoff[(int64_t)d * n_tiles + s_bnext] : dtot[d]) - p_first)
+		const uint32_t gt = SKIPK ? 0u
+		                  : SEG ? ((s_bnext < (uint32_t)n_tiles ? hoff[(int64_t)d * n_tiles + s_bnext] : dtot[d]) - p_first)
 		                        : ((dtot[d] + RS_TILE - 1) & ~(uint32_t)(RS_TILE - 1));
 		uint32_t ginc = gt;
 #pragma unroll
@@ -251,11 +254,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__
 		const uint32_t ds = woff + inc - tot;
 		s_dstart[d] = ds;
 		s_gbase[d] = hoff[(int64_t)d * n_tiles + tile] + goff + ginc - gt - ds + (SEG ? s_bfirst * RS_TILE - p_first : 0u);
+		if (d == 255) s_nvalid = ds + tot;
 	}
 	__syncthreads();
 #pragma unroll
 	for (int r = 0; r < RS_EPT; r++) {
-		if (wbase + (uint32_t)r * 64u < n_here) {
+		if (wbase + (uint32_t)r * 64u < n_here && !(SKIPK && RS_SKIPPED(key[r]))) {
 			const uint32_t p = s_dstart[dig[r]] + pos[r];
 			s_key[p] = key[r];
 			if (DV) s_dig[p] = (uint8_t)dig[r];
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rs_scatter_any(const uint32_t *__
 #pragma unroll
 	for (int q = 0; q < RS_EPT; q++) {
 		const uint32_t p = (uint32_t)q * MSX_BLOCK + threadIdx.x;
-		if (p < n_here) {
+		if (p < (SKIPK ? s_nvalid : n_here)) {
 			const uint32_t k = s_key[p];
 			keys_out[s_gbase[DV ? (uint32_t)s_dig[p] : ((k >> shift) & 255u)] + p] = k;
 		}
@@ -535,9 +539,10 @@ int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t 
 	                             n_tiles));
 	if ((rc = msx_scan_u32(ctx, (const uint32_t *)p->ck_hist.p, (uint32_t *)p->ck_off.p, 256 * n_tiles))) return rc;
 	msx_time_begin(ctx, MSX_K_INSERT_COUNT);
-	hipLaunchKernelGGL((k_rs_scatter<uint32_t, false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream,
-	                   keys, (const uint32_t *)nullptr, key2, (uint32_t *)nullptr, (const unsigned long long *)nullptr,
-	                   n, shift, 255u, (const uint32_t *)p->ck_off.p, n_tiles);
+	// (the partition need not be stable -- what follows counts -- so a key's place comes from an LDS counter: k_rs_scatter_any)
+	hipLaunchKernelGGL((k_rs_scatter_any<false, false, true>), dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, keys,
+	                   (const uint8_t *)nullptr, key2, n, shift, (const uint32_t *)p->ck_off.p, n_tiles, (const uint32_t *)nullptr,
+	                   (const uint32_t *)nullptr, -1);
 	hipLaunchKernelGGL(k_part_count, dim3(PC_SPLIT, 256), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)key2,
 	                   (const uint32_t *)p->ck_off.p, n_tiles, shift, p->n_features, add, p->ui);
 	msx_time_end(ctx);
