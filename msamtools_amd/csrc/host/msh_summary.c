@@ -184,6 +184,8 @@ int msam_summary_main(int argc, char *argv[]) {
 					if (b.flag[i] & 4) continue;                                  /* :56-57, :98-99 */
 					if (b.flag[i] & 0x100) continue;                              /* :59-60 secondary */
 					tid = b.tid[i];
+					if (tid < 0 || tid >= hdr->n_targets)      /* (the reference reads target_len[tid] here whatever tid is) */
+						mDie("Mapped record '%s' names no reference sequence", (const char *)RB_REC(&b, i) + 32);
 					start = b.pos[i];
 					end = record_endpos(&b, i);
 					if (start < (int64_t)edge || (int64_t)hdr->target_len[tid] - end < (int64_t)edge) continue;    /* :62-63 */
