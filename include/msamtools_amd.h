@@ -324,7 +324,10 @@ int  msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_c
  * 0xff00 bytes, each framed as one BGZF block in d_out, back to back.  level 0: stored blocks (what htslib writes for
  * "wbu", msam_filter.c:464-470); level >= 1: raw DEFLATE ("wb"), LZ77 + dynamic Huffman codes per block -- the bytes differ
  * from zlib's, the records do not (the reference's tests compare records: tests/functions.sh:160-163).
- * msx_bgzf_bound: bytes d_out must hold.  Waits for the result. */
+ * msx_bgzf_bound: bytes d_out must hold.  Waits for the result.  One call takes at most what keeps msx_bgzf_bound below
+ * 2^32 for level >= 1 (block offsets are 32-bit words on the device; MSX_ERR_ARG beyond), 0xfff00000 bytes for level 0.
+ * The encoder has ONE set of scratch per context: its launches -- this call on the context's stream, the unpacker's
+ * emit calls on the stream they name -- are ordered one behind the other whatever streams they run on. */
 int64_t msx_bgzf_bound(int64_t n_bytes, int level);
 int  msx_bgzf_deflate(msx_ctx *ctx, const void *d_in, size_t n_bytes, int level, void *d_out, size_t out_cap,
                       int64_t *n_out, int64_t *n_blocks);

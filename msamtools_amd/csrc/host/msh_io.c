@@ -2030,11 +2030,12 @@ void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n) {
  * Regular file: written from where they are -- by MSX_WRITE_THREADS threads as pwrite()s of disjoint ranges when the
  * descriptor allows it (no O_APPEND, seekable).  Pipe: the bytes are copied once, by all threads, into a fresh
  * mapping that is handed over by reference (the caller's buffer is page-locked and reused, so it cannot be). */
+#include "msh_split.h"
 typedef struct { int fd; const uint8_t *src; uint8_t *dst; size_t n; off_t off; } fjob;
 static void framed_pwrite_worker(void *arg, int tid, int nth) {
 	const fjob *j = (const fjob *)arg;
-	const size_t al = (size_t)1 << 20;
-	size_t per = (j->n / (size_t)nth + al - 1) / al * al, lo = per * (size_t)tid, hi = lo + per < j->n ? lo + per : j->n;
+	size_t lo, hi;
+	msh_split_aligned(j->n, nth, tid, (size_t)1 << 20, &lo, &hi);
 	while (lo < hi) {
 		ssize_t k = pwrite(j->fd, j->src + lo, hi - lo, j->off + (off_t)lo);
 		if (k < 0 && errno == EINTR) continue;

@@ -168,6 +168,8 @@ extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 		free_buf(&l.scan_l1); free_buf(&l.scan_l2); free_buf(&l.scan_l3);
 	}
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+	if (ctx->df_used && ctx->df_last) (void)hipStreamSynchronize(ctx->df_last);
+	if (ctx->df_done) (void)hipEventDestroy(ctx->df_done);
 	for (auto &t : ctx->timed) {
 		(void)hipEventDestroy(t.a);
 		(void)hipEventDestroy(t.b);

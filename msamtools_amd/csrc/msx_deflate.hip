@@ -802,9 +802,22 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	int rc;
 	size_t waves = (size_t)ctx->num_cu * 4;
 	if (waves > nblk) waves = nblk;
-	if ((rc = msx_reserve(ctx, &ctx->df_slots, nblk * (size_t)DF_SLOT + 64))) return rc;
-	if ((rc = msx_reserve(ctx, &ctx->df_size, (nblk + 16) * 8 + 256))) return rc;
-	if ((rc = msx_reserve(ctx, &ctx->df_tok, waves * (size_t)DF_TOKCAP * 4 + 64))) return rc;
+	// One set of scratch per context (slots, sizes with the ticket, token scratch), launches on whatever stream the caller
+	// names: the launch is ordered behind the previous one's last kernel when that ran on another stream, and the stream
+	// that last used the scratch is drained before any of it is freed to grow (msx_reserve drains ctx->stream only).
+	const size_t need_slots = nblk * (size_t)DF_SLOT + 64, need_size = (nblk + 16) * 8 + 256, need_tok = waves * (size_t)DF_TOKCAP * 4 + 64;
+	if (ctx->df_used && ctx->df_last != stream) {
+		const bool grows = need_slots > ctx->df_slots.cap || need_size > ctx->df_size.cap || need_tok > ctx->df_tok.cap;
+		if (grows) MSX_HIP(ctx, hipStreamSynchronize(ctx->df_last));
+		else MSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->df_done, 0));
+	} else if (ctx->df_used && stream != ctx->stream &&
+	           (need_slots > ctx->df_slots.cap || need_size > ctx->df_size.cap || need_tok > ctx->df_tok.cap)) {
+		MSX_HIP(ctx, hipStreamSynchronize(stream));
+	}
+	if ((rc = msx_reserve(ctx, &ctx->df_slots, need_slots))) return rc;
+	if ((rc = msx_reserve(ctx, &ctx->df_size, need_size))) return rc;
+	if ((rc = msx_reserve(ctx, &ctx->df_tok, need_tok))) return rc;
+	if (!ctx->df_done) MSX_HIP(ctx, hipEventCreateWithFlags(&ctx->df_done, hipEventDisableTiming));
 	uint32_t *bsize = (uint32_t *)ctx->df_size.p, *boff = bsize + nblk + 8, *misc = boff + nblk + 4;
 	MSX_HIP(ctx, hipMemsetAsync(bsize, 0, (nblk + 16) * 8 + 192, stream));
 	static int want_kinds = -1;
@@ -815,6 +828,9 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nblk), dim3(64), 0, stream, (const uint8_t *)ctx->df_slots.p, bsize, boff, d_total,
 	                   (uint32_t)n_cap, d_out, d_out_total);
 	MSX_HIP(ctx, hipGetLastError());
+	MSX_HIP(ctx, hipEventRecord(ctx->df_done, stream));
+	ctx->df_last = stream;
+	ctx->df_used = true;
 	if (want_kinds) {
 		uint32_t h[4 + 2 * 10];
 		MSX_HIP(ctx, hipMemcpyAsync(h, misc + 4, sizeof h, hipMemcpyDeviceToHost, stream));
@@ -831,7 +847,10 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 extern "C" int msx_bgzf_deflate(msx_ctx *ctx, const void *d_in, size_t n_bytes, int level, void *d_out, size_t out_cap,
                                 int64_t *n_out, int64_t *n_blocks) {
 	if (!ctx || !n_out || (n_bytes > 0 && (!d_in || !d_out))) return MSX_ERR_ARG;
-	if (n_bytes > 0xfff00000ull) return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_deflate: more than 4 GB in one call");
+	// block offsets and the stream's length are 32-bit words on the device: what must stay below 2^32 is the OUTPUT's bound
+	// (every block stored: n + 31 per 0xff00 bytes), not the input
+	if (n_bytes > 0xfff00000ull || (level > 0 && (uint64_t)msx_bgzf_bound((int64_t)n_bytes, level) >= (1ull << 32)))
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_deflate: more than 4 GB in one call");
 	if (level < 0 || level > 9) return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_deflate: level %d", level);
 	msx_join(ctx);
 	MSX_HIP(ctx, hipSetDevice(ctx->device));

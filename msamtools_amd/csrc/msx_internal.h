@@ -100,6 +100,9 @@ struct msx_ctx {
 	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, pinfo, moff, tmp_fid, ukey2;
 	msx_buf cv_key[2], cv_hist, cv_off, cv_start, cv_side;   // coverage: binned pile-up items; images of pre-reduced tiles
 	msx_buf df_slots, df_size, df_tok;              // msx_deflate.hip: block slots, sizes + offsets, token scratch of the resident waves
+	hipStream_t df_last = nullptr;     // the stream the encoder's scratch was last used on (ONE set per context: a launch on
+	hipEvent_t df_done = nullptr;      // another stream waits for df_done first; growing the scratch drains df_last)
+	bool df_used = false;
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;

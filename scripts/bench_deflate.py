@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """k_bgzf_deflate alone on the records of a synthetic BAM (MSX_DEFLATE_STATS=1 prints the clocks per phase and block).
-usage: bench_deflate.py [groups] [--seq]"""
+usage: bench_deflate.py FILE.bam        -- a BAM written beforehand (`msamtools-dev synth ... -u > FILE.bam`); no child process
+       bench_deflate.py [groups] [--seq] -- synthesises the file itself through a child process: NOT under rocprofv3 (the
+                                           profiler's preloaded library has initialised the GPU in every child, and a child
+                                           that execs is what the pool forbids) -- the script refuses that combination."""
 import gzip
 import os
 import subprocess
@@ -18,10 +21,15 @@ import msamtools_amd as m
 
 groups = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200000
 seq = "--seq" in sys.argv
-exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
-if not os.path.exists(exe):
-    exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-raw = gzip.decompress(subprocess.check_output(f"{exe} synth --groups {groups} --refs 1000 {'--seq' if seq else ''} -u", shell=True))
+path = sys.argv[1] if len(sys.argv) > 1 and os.path.isfile(sys.argv[1]) else None
+if path:
+    raw = gzip.decompress(open(path, "rb").read())
+else:
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")):
+        sys.exit("bench_deflate.py: under rocprofv3 give it a file (msamtools-dev synth ... -u > f.bam); it starts no child there")
+    exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
+    args = [exe, "synth", "--groups", str(groups), "--refs", "1000", "-u"] + (["--seq"] if seq else [])
+    raw = gzip.decompress(subprocess.run(args, stdout=subprocess.PIPE, check=True).stdout)
 data = raw[len(raw) // 8:]
 data = data[:len(data) // 0xff00 * 0xff00]
 ctx = m.Context(0)
