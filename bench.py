@@ -625,6 +625,25 @@ def coverage_block(m, ctx, with_oracle):
             cov_m = ctx.to_host(d_cov, total, np.int32)
         finally:
             del os.environ["MSX_COV_MARKS"]
+        # the command's form (round 5): the same stream in batches of the command line's size, resident in HBM; every batch's
+        # pieces kept on the device (msx_coverage_collect: one emit kernel and one 76-byte read of its overflow flag per
+        # batch), sorted and summed once (msx_coverage_collect_finish)
+        per = 370_000
+        parts = [m.DeviceBatch.synth(ctx, SEED, min(per, ngrp - g0), refs, 4, first_group=g0) for g0 in range(0, ngrp, per)]
+
+        def collected():
+            ctx.sync()
+            t0 = time.perf_counter()
+            for part in parts:
+                ctx.check(ctx.lib.msx_coverage_collect(ctx.h, C.byref(part.b), C.c_void_p(d_off), refs, total, C.c_void_p(d_cov), None))
+            n_str = C.c_int64(-1)
+            ctx.check(ctx.lib.msx_coverage_collect_finish(ctx.h, C.c_void_p(d_cov), total, C.byref(n_str)))
+            ctx.sync()
+            return time.perf_counter() - t0, int(n_str.value)
+        ts_c = [collected() for _ in range(4)]
+        cov_c = ctx.to_host(d_cov, total, np.int32)
+        for part in parts:
+            part.free()
         ts = [one(db) for _ in range(6)]
         best = min(ts[1:])
         cov = ctx.to_host(d_cov, total, np.int32)
@@ -647,8 +666,13 @@ def coverage_block(m, ctx, with_oracle):
             "form": "one word per run piece: 4 K-cell tiles, the tile's top byte dropped by the first of two radix passes",
             "streamed_form_ms": round(min(ts_s[1:]) * 1e3, 3), "equal_to_streamed_form": bool(np.array_equal(cov, cov_s)),
             "marks_form_ms": round(min(ts_m[1:]) * 1e3, 3), "equal_to_marks_form": bool(np.array_equal(cov, cov_m)),
+            "collected_form": {
+                "what": "msx_coverage_collect per batch + msx_coverage_collect_finish: what `msamtools coverage` calls (msh_coverage.c) -- "
+                        "the kernels of `ms` with the emit kernel run per batch and the host reading each batch's overflow flag",
+                "batches": len(parts), "ms": round(min(t for t, _ in ts_c[1:]) * 1e3, 3), "batches_streamed": ts_c[-1][1],
+                "equal": bool(np.array_equal(cov, cov_c))},
         }
-        del cov, cov_s, cov_m, cig, n_cig, has_ref, op, w
+        del cov, cov_s, cov_m, cov_c, cig, n_cig, has_ref, op, w
         if with_oracle:
             import oracle_lib as orc
             pg = 200_000                                   # every depth of a prefix of the stream against the oracle
@@ -663,7 +687,7 @@ def coverage_block(m, ctx, with_oracle):
             blk["parity_prefix"] = {"alignments": hs.n_records, "every_depth_equal": bool(np.array_equal(got, want))}
             blk["cpu_oracle_M_alignments_per_s"] = round(hs.n_records / cpu_s / 1e6, 2)
             blk["parity_ok"] = bool(blk["depth_sum_ok"] and blk["parity_prefix"]["every_depth_equal"] and blk["equal_to_streamed_form"] and
-                                     blk["equal_to_marks_form"])
+                                     blk["equal_to_marks_form"] and blk["collected_form"]["equal"])
             small.free()
         ctx.free(d_off)
         ctx.free(d_cov)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSX_ABI_VERSION 6
+#define MSX_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------- */
 #define MSX_OK              0
@@ -524,6 +524,18 @@ int  msx_coverage_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len);
  * lists run full (most records with several long runs), take the streamed path inside the call.  Waits for the result. */
 int  msx_coverage_depths(msx_ctx *ctx, const msx_batch *dev, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
                          int32_t *cov, uint8_t *covered);
+/* A whole sample, batch after batch (the loop of msam_coverage.c:293-301 as the command line runs it): msx_coverage_collect
+ * in the place of msx_coverage_accumulate, msx_coverage_collect_finish in the place of msx_coverage_finish.  The batches'
+ * pieces stay on the device (5 bytes per record) and the finish sorts and sums them once, writing cov[0 .. total_len] once:
+ * msx_coverage_depths without the batch having to be the sample.  cov need NOT be zeroed and holds nothing until the finish.
+ * What the one-word-per-piece form does not take goes the streamed way inside the same calls and the results are added:
+ * samples of more than 255 x 2^20 cells (every batch), a batch whose overflow lists ran full, batches beyond 2^31 items.
+ * One sample at a time per context; every call names the same cov / total_len.  *n_batches_streamed (or NULL): how many
+ * batches took the streamed way.  msx_coverage_collect waits for the batch's pieces (the batch's arrays may be given back
+ * when it returns); the finish enqueues and returns -- the depths are on the context's stream. */
+int  msx_coverage_collect(msx_ctx *ctx, const msx_batch *dev, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
+                          int32_t *cov, uint8_t *covered);
+int  msx_coverage_collect_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len, int64_t *n_batches_streamed);
 /* after msx_coverage_finish: per target, the number of positions with a depth other than 0 and the sum of the depths --
  * what mWriteCoverageSummaryToStream (msam_coverage.c:188-219) divides by the target's length; host arrays of n_targets */
 int  msx_coverage_summary(msx_ctx *ctx, const int32_t *cov, const int64_t *cov_off, int32_t n_targets,

@@ -10,9 +10,10 @@ from ._lib import MsxError
 
 _lib.load()
 
-from .api import (Context, DeviceBatch, FilterRun, HostSynth, Profile, Unpack, aln_stats,  # noqa: E402
-                  bgzf_blocks, bgzf_deflate, bgzf_inflate, bgzf_split, coverage, dist_unique_id, filter_params, run_filter)
+from .api import (Context, DeviceBatch, FilterRun, HostSynth, Profile, RecordSlice, Unpack, aln_stats,  # noqa: E402
+                  bgzf_blocks, bgzf_deflate, bgzf_inflate, bgzf_split, coverage, coverage_collected, dist_unique_id, filter_params,
+                  run_filter)
 from .grouping import filter_pools, profile_pools  # noqa: E402
 
 __all__ = ["Context", "DeviceBatch", "FilterRun", "HostSynth", "Profile", "Unpack", "MsxError", "aln_stats",
-           "bgzf_blocks", "bgzf_deflate", "bgzf_inflate", "bgzf_split", "coverage", "dist_unique_id", "filter_params", "run_filter", "filter_pools", "profile_pools"]
+           "bgzf_blocks", "bgzf_deflate", "bgzf_inflate", "bgzf_split", "coverage", "coverage_collected", "RecordSlice", "dist_unique_id", "filter_params", "run_filter", "filter_pools", "profile_pools"]

@@ -157,6 +157,8 @@ SYMBOLS = {
     "msx_coverage_accumulate": (C.c_int, [_P, C.POINTER(Batch), _P, C.c_int32, C.c_int64, _P, _P]),
     "msx_coverage_finish": (C.c_int, [_P, _P, C.c_int64]),
     "msx_coverage_depths": (C.c_int, [_P, C.POINTER(Batch), _P, C.c_int32, C.c_int64, _P, _P]),
+    "msx_coverage_collect": (C.c_int, [_P, C.POINTER(Batch), _P, C.c_int32, C.c_int64, _P, _P]),
+    "msx_coverage_collect_finish": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "msx_coverage_summary": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "msx_synth_device": (C.c_int, [_P, C.POINTER(SynthParams), C.POINTER(Batch), C.POINTER(SynthSizes)]),
     "msx_synth_host": (C.c_int, [C.POINTER(SynthParams), C.POINTER(Batch), C.POINTER(SynthSizes)]),

@@ -675,6 +675,50 @@ class Profile:
             pass
 
 
+class RecordSlice:
+    """Records [lo, hi) of a host SoA (tests/samio.Records, HostSynth) as a batch of their own: the coverage fields."""
+
+    def __init__(self, rec, lo, hi):
+        self.flag = rec.flag[lo:hi]
+        self.tid = rec.tid[lo:hi]
+        self.pos = rec.pos[lo:hi]
+        co = np.asarray(rec.cigar_off[lo:hi + 1], dtype=np.int64)
+        self.cigar_off = (co - co[0]).astype(np.uint32)
+        self.cigar = rec.cigar[int(co[0]):int(co[-1])]
+        self.n_records = hi - lo
+
+
+def coverage_collected(ctx, batches, target_len, covered=False):
+    """A sample that arrives batch after batch (the command line's loop): msx_coverage_collect per device batch, then
+    msx_coverage_collect_finish.  Returns (depths per target, batches that took the streamed way[, covered flags])."""
+    off = np.zeros(len(target_len) + 1, np.int64)
+    off[1:] = np.cumsum(np.asarray(target_len, dtype=np.int64))
+    total = int(off[-1])
+    d_off = ctx.alloc(off.nbytes)
+    d_cov = ctx.alloc(4 * max(total, 1) + 8)
+    d_flag = ctx.alloc(len(target_len) + 8) if covered else None
+    try:
+        ctx.to_dev(d_off, off)
+        ctx.to_dev(d_cov, np.full(max(total, 1) + 2, 0x5a5a5a5a, np.uint32))      # (garbage: the calls must not rely on zeros)
+        if covered:
+            ctx.zero(d_flag, len(target_len) + 8)
+        for b in batches:
+            ctx.check(ctx.lib.msx_coverage_collect(ctx.h, C.byref(b.b), C.c_void_p(d_off), len(target_len), total, C.c_void_p(d_cov),
+                                                   C.c_void_p(d_flag) if covered else None))
+        n_streamed = C.c_int64(-1)
+        ctx.check(ctx.lib.msx_coverage_collect_finish(ctx.h, C.c_void_p(d_cov), total, C.byref(n_streamed)))
+        ctx.sync()
+        cov = ctx.to_host(d_cov, total, np.int32)
+        flags = ctx.to_host(d_flag, len(target_len), np.uint8) if covered else None
+    finally:
+        ctx.free(d_off)
+        ctx.free(d_cov)
+        if covered:
+            ctx.free(d_flag)
+    per = [cov[off[i]:off[i + 1]] for i in range(len(target_len))]
+    return (per, int(n_streamed.value), flags) if covered else (per, int(n_streamed.value))
+
+
 def coverage(ctx, batch, target_len, summary=False, whole_sample=False):
     """Per-base depth per target (msam_coverage.c:33-87) for one device batch; summary=True: also (touched positions,
     depth sum) per target as the device takes them (msx_coverage_summary, msam_coverage.c:188-219);

@@ -106,6 +106,7 @@ int msam_coverage_main(int argc, char *argv[]) {
 	int piped = 0;
 	int64_t *cs_touched = NULL, *cs_sum = NULL;
 	double t_cov[4] = {0, 0, 0, 0}, t_cov0 = now_s();
+	int64_t n_streamed = 0;
 
 	opterr = 0;
 	optind = 1;
@@ -159,7 +160,9 @@ int msam_coverage_main(int argc, char *argv[]) {
 	MSX(msx_dev_alloc(g_ctx, &d_cov, 4 * (size_t)total + 8));
 	MSX(msx_dev_alloc(g_ctx, &d_covered, (size_t)hdr->n_targets + 8));
 	MSX(msx_host_to_dev(g_ctx, d_off, off, sizeof(int64_t) * ((size_t)hdr->n_targets + 1)));
-	MSX(msx_dev_zero(g_ctx, d_cov, 4 * (size_t)total + 8));
+	/* (the depth array is not zeroed here: msx_coverage_collect keeps the batches' pieces on the device and
+	 *  msx_coverage_collect_finish writes every cell once -- for what goes the streamed way the library zeroes it when the first
+	 *  such batch comes; MSX_COV_STREAMED=1: zero, marks, prefix sum for every batch, as in rounds 2-4) */
 	MSX(msx_dev_zero(g_ctx, d_covered, (size_t)hdr->n_targets + 8));
 
 	/* mEstimateCoverageOnFile (:106-139): every alignment adds 1, pools do not matter */
@@ -188,13 +191,13 @@ int msam_coverage_main(int argc, char *argv[]) {
 				unpack_slots_ahead(&P, unpack, &ahead);
 				unpack_slot_finish(&P, s, unpack, &up, &ur, &db);
 				if (ur.n_records > 0)
-					MSX(msx_coverage_accumulate(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
+					MSX(msx_coverage_collect(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
 					                            (uint8_t *)d_covered));
 			} else if (s->b.n > 0) {
 				rb_host_view(&s->b, &hb, 0);
 				hb.md_off = NULL; hb.md = NULL; hb.nm = NULL; hb.as = NULL;
 				MSX(msx_batch_upload(g_ctx, &hb, &db));
-				MSX(msx_coverage_accumulate(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
+				MSX(msx_coverage_collect(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
 				                            (uint8_t *)d_covered));
 				MSX(msx_ctx_sync(g_ctx));
 				msx_batch_free(g_ctx, &db);
@@ -219,7 +222,7 @@ int msam_coverage_main(int argc, char *argv[]) {
 			rb_host_view(&b, &hb, 0);
 			hb.md_off = NULL; hb.md = NULL; hb.nm = NULL; hb.as = NULL;
 			MSX(msx_batch_upload(g_ctx, &hb, &db));
-			MSX(msx_coverage_accumulate(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
+			MSX(msx_coverage_collect(g_ctx, &db, (const int64_t *)d_off, hdr->n_targets, total, (int32_t *)d_cov,
 			                            (uint8_t *)d_covered));
 			MSX(msx_ctx_sync(g_ctx));
 			msx_batch_free(g_ctx, &db);
@@ -227,7 +230,7 @@ int msam_coverage_main(int argc, char *argv[]) {
 		if (rd.done) break;
 	}
 	t_cov[1] = now_s();
-	MSX(msx_coverage_finish(g_ctx, (int32_t *)d_cov, total));
+	MSX(msx_coverage_collect_finish(g_ctx, (int32_t *)d_cov, total, &n_streamed));
 	MSX(msx_ctx_sync(g_ctx));
 	t_cov[2] = now_s();
 	covered = (uint8_t *)malloc((size_t)hdr->n_targets + 1);
@@ -291,9 +294,9 @@ int msam_coverage_main(int argc, char *argv[]) {
 		if (out_fd != fileno(stdout) && close(out_fd) != 0) mDie("Write failed");
 	}
 	if (getenv("MSX_TIMING"))
-		fprintf(stderr, "# coverage: input and device set up %.3f s, records through %.3f, prefix sums %.3f, depths to the host %.3f, "
-		        "report %.3f (%lld cells)\n", t_cov[0] - t_cov0, t_cov[1] - t_cov[0], t_cov[2] - t_cov[1], t_cov[3] - t_cov[2],
-		        now_s() - t_cov[3], (long long)total);
+		fprintf(stderr, "# coverage: input and device set up %.3f s, records through %.3f, depths from the pieces %.3f, depths to the host %.3f, "
+		        "report %.3f (%lld cells; %lld batches piled up the streamed way)\n", t_cov[0] - t_cov0, t_cov[1] - t_cov[0],
+		        t_cov[2] - t_cov[1], t_cov[3] - t_cov[2], now_s() - t_cov[3], (long long)total, (long long)n_streamed);
 	msx_dev_free(g_ctx, d_off);
 	msx_dev_free(g_ctx, d_cov);
 	msx_dev_free(g_ctx, d_covered);

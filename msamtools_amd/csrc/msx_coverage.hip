@@ -524,7 +524,16 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit3(int64_t n, const int32_
 	// spent 9 K cycles per record; with the walk written out four times the code no longer fit and it got slower.
 	for (int q0 = 0; q0 < CV3_REC / MSX_BLOCK; q0 += CV3_FLIGHT) {
 		const int64_t i0 = (int64_t)blockIdx.x * CV3_REC + (int64_t)q0 * MSX_BLOCK + threadIdx.x;
-		if (i0 >= n) break;
+		if (i0 >= n) {            // (the last workgroup's slots behind the records: empty keys, counted like any other)
+#pragma unroll
+			for (int u = 0; u < CV3_FLIGHT; u++) {
+				const int64_t i = i0 + (int64_t)u * MSX_BLOCK;
+				items[i] = 0xffffffffu;
+				sups[i] = 0xffu;
+				atomicAdd(&s_cnt[w][255], 1u);
+			}
+			continue;
+		}
 		int32_t t4[CV3_FLIGHT], p4[CV3_FLIGHT];
 		uint32_t ks4[CV3_FLIGHT], ke4[CV3_FLIGHT], c04[CV3_FLIGHT];
 		uint2 tt4[CV3_FLIGHT];
@@ -545,8 +554,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit3(int64_t n, const int32_
 #pragma nounroll
 		for (int u = 0; u < CV3_FLIGHT; u++) {
 			const int64_t i = i0 + (int64_t)u * MSX_BLOCK;
-			if (i >= n) break;
-			const int32_t t = CV3_PICK(t4);
+			const int32_t t = CV3_PICK(t4);                      // (-1 behind the last record: an empty slot)
 			uint32_t key = 0xffffffffu, sup = 0xffu;
 			if (t >= 0) {                                        // msam_coverage.c:42
 				if (covered) covered[t] = 1;                     // :45-49
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_emit3(int64_t n, const int32_
 		}
 	}
 	__syncthreads();
-	{
+	if (hist) {      // (msx_coverage_collect appends batch after batch: the table's stride is not known yet, the sort counts)
 		const int d = threadIdx.x;
 		hist[(int64_t)d * hist_tiles + blockIdx.x] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 	}
@@ -664,7 +672,11 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_list3(const uint32_t *_
 				units[ub + u] = make_uint4((uint32_t)k, a, hi - a < CV3_UNIT ? hi : a + CV3_UNIT, 0u);
 			}
 		} else {
+			// no image slot (or no room in the unit list) for this tile: its workgroup of k_cov_depths3 walks the items alone --
+			// slower, as exact.  The unit numbers drawn above must not stay unwritten: k_cov_heavy_add3 walks the list up to
+			// n_hchunks, so they become units without items.
 			st->overflow = 1;
+			for (uint32_t u = 0; u < nu && ub + u < unit_cap; u++) units[ub + u] = make_uint4(0u, 0u, 0u, 0u);
 		}
 	}
 	slot_of[t] = slot;
@@ -722,7 +734,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_heavy_add3(const uint32_t *__
 // what they write is read by the next kernel)
 __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths3(const uint32_t *__restrict__ items, const uint32_t *__restrict__ start,
                                                            const int32_t *__restrict__ slot_of, const int32_t *__restrict__ side,
-                                                           int64_t total_cells, int32_t *__restrict__ cov, int nt) {
+                                                           int64_t total_cells, int32_t *__restrict__ cov, int nt, int acc) {
+	// acc: cov[] already holds depths (of the batches msx_coverage_collect had to pile up the streamed way) -- added to
 	__shared__ int32_t s_d[CV3_TILE];
 	__shared__ int32_t s_w[MSX_BLOCK / 64];
 	const int64_t t = blockIdx.x;
@@ -765,6 +778,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths3(const uint32_t *__res
 		const int32_t add = running + woff + inc - v.w;
 		v.x += add; v.y += add; v.z += add; v.w += add;
 		const int64_t c = c0 + q;
+		if (acc) {
+			if (c <= total_cells) v.x += cov[c];
+			if (c + 1 <= total_cells) v.y += cov[c + 1];
+			if (c + 2 <= total_cells) v.z += cov[c + 2];
+			if (c + 3 <= total_cells) v.w += cov[c + 3];
+		}
 		if (c + 4 <= total_cells + 1) {
 			if (nt) {
 				typedef int v4i __attribute__((ext_vector_type(4)));
@@ -783,51 +802,26 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_cov_depths3(const uint32_t *__res
 	}
 }
 
-// returns MSX_OK with *done = 1 when the depths are written, *done = 0 when this form does not apply (or its lists ran full)
-static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len, int32_t *cov,
-                             uint8_t *covered, int *done) {
-	*done = 0;
-	const int64_t n = b->n_records;
-	const int64_t n_tiles = (total_len + 1 + CV3_TILE - 1) >> CV3_TILE_SHIFT;
-	if (n < (1 << 16) || n_targets <= 0 || n_tiles > CV3_MAX_TILES || n >= ((int64_t)1 << 31) - (1 << 24) || getenv("MSX_COV_MARKS") ||
-	    getenv("MSX_COV_STREAMED"))
-		return MSX_OK;
+// From the items of a sample (own slots and overflow lists, empty slots all ones / 0xff) to its depths: the two passes, where
+// every tile's items lie, the pre-reduction of the hot tiles, the depth kernel.  items: msx_sort_k32v8_bound(n_items) + 64
+// words (the sorted items end up there), items1 as many; counted: sort tiles whose first-pass digit counts the emit kernel
+// left in cv_hist (stride = the sort tiles of n_items).  acc: cov[] holds depths already, add to them.  *heavy_overflow: a
+// hot tile had to be walked by one workgroup (no image slot left) -- the depths are right all the same.
+static int cov_pieces_finish(msx_ctx *ctx, uint32_t *items, const uint8_t *sups, uint32_t *items1, int64_t n_items, int64_t counted,
+                             int64_t total_len, int32_t *cov, int acc, int *heavy_overflow) {
 	int rc;
-	const int64_t n_wg = (n + CV3_REC - 1) / CV3_REC;
-	const int64_t own = n_wg * MSX_SORT_TILE;
-	const uint32_t list_cap = (uint32_t)(((n / 8 + CV2_LISTS - 1) / CV2_LISTS + 1023) & ~(int64_t)1023);
-	const int64_t n_items = own + (int64_t)CV2_LISTS * list_cap;
-	const int64_t n_ub = msx_sort_k32v8_bound(n_items);       // (every bucket of the sorted items begins at a whole sort tile)
-	// cv_key[0]: the items and their top bytes, later the sorted items; cv_key[1]: the items between the passes
-	if ((rc = msx_reserve(ctx, &ctx->cv_key[0], (size_t)(n_ub + 64) * 4 + (size_t)n_items + 64))) return rc;
-	if ((rc = msx_reserve(ctx, &ctx->cv_key[1], (size_t)(n_ub + 64) * 4))) return rc;
+	const int64_t n_tiles = (total_len + 1 + CV3_TILE - 1) >> CV3_TILE_SHIFT;
+	const int64_t n_ub = msx_sort_k32v8_bound(n_items);
 	const uint32_t unit_cap = (uint32_t)(n_ub / CV3_UNIT + CV2_HEAVY_CAP + 64);      // (a tile's last unit may be short)
-	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * n_tiles + n_tiles + 512 + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(unit_cap + 8) * 16 +
-	                                                (size_t)n_targets * 8 + 64)))
+	if ((rc = msx_reserve(ctx, &ctx->cv_start, (size_t)(2 * n_tiles + n_tiles + 512 + 64) * 4 + sizeof(cv2_state) + 64 + (size_t)(unit_cap + 8) * 16 + 64)))
 		return rc;
 	if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
-	int64_t sort_tiles = 0;
-	if ((rc = msx_sort_k32v8_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
 	uint32_t *start = (uint32_t *)ctx->cv_start.p;
 	int32_t *slot_of = (int32_t *)(start + 2 * n_tiles);
 	uint32_t *lay = (uint32_t *)(slot_of + n_tiles);
 	cv2_state *st = (cv2_state *)(((uintptr_t)(lay + 512) + 63) & ~(uintptr_t)63);
 	uint4 *units = (uint4 *)(((uintptr_t)(st + 1) + 15) & ~(uintptr_t)15);
-	uint2 *targets = (uint2 *)(units + unit_cap + 4);
-	uint32_t *items = (uint32_t *)ctx->cv_key[0].p, *items1 = (uint32_t *)ctx->cv_key[1].p;
-	uint8_t *sups = (uint8_t *)(items + n_ub + 64);
 	MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
-	msx_time_begin(ctx, MSX_K_COVERAGE);
-	if (own > n) {               // (the last workgroup's tile is not full: its tail holds empty slots)
-		MSX_HIP(ctx, hipMemsetAsync(items + n, 0xff, (size_t)(own - n) * 4, ctx->stream));
-		MSX_HIP(ctx, hipMemsetAsync(sups + n, 0xff, (size_t)(own - n), ctx->stream));
-	}
-	hipLaunchKernelGGL(k_cov_targets3, dim3((unsigned)((n_targets + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, cov_off, n_targets,
-	                   targets);
-	hipLaunchKernelGGL(k_cov_emit3, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar,
-	                   (const uint2 *)targets, covered, items, sups, own, list_cap, st, (uint32_t *)ctx->cv_hist.p, sort_tiles);
-	hipLaunchKernelGGL(k_cov_fill_lists3, dim3(16, CV2_LISTS), dim3(MSX_BLOCK), 0, ctx->stream, items, sups, own, list_cap, st);
-	const int64_t counted = (own > n) ? n_wg - 1 : n_wg;      // (the last workgroup counted only the records it has)
 	if ((rc = msx_sort_k32v8(ctx, items, sups, items1, n_items, 24, &ctx->cv_hist, &ctx->cv_off, counted, 255, lay))) return rc;
 	static const uint32_t heavy_from = getenv("MSX_COV_HEAVY") ? (uint32_t)atoll(getenv("MSX_COV_HEAVY")) : CV2_HEAVY;
 	hipLaunchKernelGGL(k_cov_starts3, dim3((unsigned)((2 * n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
@@ -838,14 +832,197 @@ static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *co
 	hipLaunchKernelGGL(k_cov_heavy_add3, dim3(unit_cap < 2048u ? unit_cap : 2048u), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items,
 	                   (int32_t *)ctx->cv_side.p, (const cv2_state *)st, (const uint4 *)units, unit_cap);
 	hipLaunchKernelGGL(k_cov_depths3, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items, (const uint32_t *)start,
-	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov, getenv("MSX_COV_NO_NT") ? 0 : 1);
-	msx_time_end(ctx);
+	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov, (getenv("MSX_COV_NO_NT") || acc) ? 0 : 1, acc);
 	MSX_HIP(ctx, hipGetLastError());
+	if (heavy_overflow) {
+		cv2_state h;
+		MSX_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		*heavy_overflow = (int)h.overflow;
+	}
+	return MSX_OK;
+}
+
+// the items of n records into items[0 ..) / sups[0 ..): own slots (whole sort tiles), then CV2_LISTS overflow lists of
+// list_cap; *n_items_out what that comes to.  hist (or null) / hist_tiles: the first pass's digit counts left for the sort.
+static inline void cov_pieces_geometry(int64_t n, int64_t *n_wg, int64_t *own, uint32_t *list_cap, int64_t *n_items) {
+	*n_wg = (n + CV3_REC - 1) / CV3_REC;
+	*own = *n_wg * MSX_SORT_TILE;
+	*list_cap = (uint32_t)(((n / 8 + CV2_LISTS - 1) / CV2_LISTS + 1024) & ~(int64_t)1023);     // (a kilobyte of items at least)
+	*n_items = *own + (int64_t)CV2_LISTS * *list_cap;
+}
+static int cov_pieces_emit(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, uint8_t *covered, uint32_t *items,
+                           uint8_t *sups, cv2_state *st, uint32_t *hist, int64_t hist_tiles, bool targets_ready) {
+	int rc;
+	const int64_t n = b->n_records;
+	int64_t n_wg, own, n_items;
+	uint32_t list_cap;
+	cov_pieces_geometry(n, &n_wg, &own, &list_cap, &n_items);
+	if ((rc = msx_reserve(ctx, &ctx->cv_targets, (size_t)n_targets * 8 + 64))) return rc;
+	uint2 *targets = (uint2 *)ctx->cv_targets.p;
+	MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
+	// (the last workgroup's tile need not be full: the emit kernel fills the slots behind the records with empty keys)
+	if (!targets_ready)
+		hipLaunchKernelGGL(k_cov_targets3, dim3((unsigned)((n_targets + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, cov_off,
+		                   n_targets, targets);
+	hipLaunchKernelGGL(k_cov_emit3, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar,
+	                   (const uint2 *)targets, covered, items, sups, own, list_cap, st, hist, hist_tiles);
+	hipLaunchKernelGGL(k_cov_fill_lists3, dim3(16, CV2_LISTS), dim3(MSX_BLOCK), 0, ctx->stream, items, sups, own, list_cap, st);
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+// returns MSX_OK with *done = 1 when the depths are written, *done = 0 when this form does not apply (or its lists ran full)
+static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len, int32_t *cov,
+                             uint8_t *covered, int *done) {
+	*done = 0;
+	const int64_t n = b->n_records;
+	const int64_t n_tiles = (total_len + 1 + CV3_TILE - 1) >> CV3_TILE_SHIFT;
+	if (n < (1 << 16) || n_targets <= 0 || n_tiles > CV3_MAX_TILES || n >= ((int64_t)1 << 31) - (1 << 24) || getenv("MSX_COV_MARKS") ||
+	    getenv("MSX_COV_STREAMED"))
+		return MSX_OK;
+	int rc;
+	int64_t n_wg, own, n_items;
+	uint32_t list_cap;
+	cov_pieces_geometry(n, &n_wg, &own, &list_cap, &n_items);
+	const int64_t n_ub = msx_sort_k32v8_bound(n_items);       // (every bucket of the sorted items begins at a whole sort tile)
+	// cv_key[0]: the items and their top bytes, later the sorted items; cv_key[1]: the items between the passes
+	if ((rc = msx_reserve(ctx, &ctx->cv_key[0], (size_t)(n_ub + 64) * 4 + (size_t)n_items + 64 + sizeof(cv2_state) + 64))) return rc;
+	if ((rc = msx_reserve(ctx, &ctx->cv_key[1], (size_t)(n_ub + 64) * 4))) return rc;
+	int64_t sort_tiles = 0;
+	if ((rc = msx_sort_k32v8_reserve(ctx, n_items, &ctx->cv_hist, &ctx->cv_off, &sort_tiles))) return rc;
+	uint32_t *items = (uint32_t *)ctx->cv_key[0].p, *items1 = (uint32_t *)ctx->cv_key[1].p;
+	uint8_t *sups = (uint8_t *)(items + n_ub + 64);
+	cv2_state *st = (cv2_state *)(((uintptr_t)(sups + n_items + 64) + 63) & ~(uintptr_t)63);      // (the emit kernel's: list fill, overflow)
+	msx_time_begin(ctx, MSX_K_COVERAGE);
+	if ((rc = cov_pieces_emit(ctx, b, cov_off, n_targets, covered, items, sups, st, (uint32_t *)ctx->cv_hist.p, sort_tiles, false))) return rc;
+	const int64_t counted = n_wg;                              // (every workgroup left the digit counts of its whole tile)
+	// (queued behind the emit kernel; its flag is read with the finish's: a batch whose lists ran full is piled up again the streamed way)
 	cv2_state h;
 	MSX_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*done = !h.overflow;
+	int heavy = 0;
+	rc = cov_pieces_finish(ctx, items, sups, items1, n_items, counted, total_len, cov, 0, &heavy);
+	msx_time_end(ctx);
+	if (rc) return rc;
+	*done = !h.overflow && !heavy;
 	return MSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for a sample that arrives batch after batch (the command line; round 5): msx_coverage_collect puts a batch's
+// pieces behind those of the batches before it -- 5 bytes per record stay on the device, a 50 M-read sample keeps 300 MB --
+// and msx_coverage_collect_finish sorts and sums them once, writing the depth array once: what msx_coverage_depths does
+// for one batch, without the batch having to be the sample.  What this form does not take goes the streamed way inside
+// the same two calls: a sample of more than 255 x 2^20 cells (every batch), a batch whose overflow lists ran full or
+// that would take the items beyond 2^31 (that batch: marks in cov[], zeroed then; the finish sums them and ADDS the tiles'
+// depths to them).
+// ---------------------------------------------------------------------------------------------------------------------
+static int cov_grow_keep(msx_ctx *ctx, msx_buf *b, size_t keep_bytes, size_t want_bytes) {
+	if (want_bytes <= b->cap && b->p) return MSX_OK;
+	size_t cap = 2 * want_bytes + 4096;                  // (doubling: a sample's batches arrive without its size being known)
+	void *np = nullptr;
+	hipError_t e = hipMalloc(&np, cap);
+	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+	if (b->p) {
+		if (keep_bytes) MSX_HIP(ctx, hipMemcpyAsync(np, b->p, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		(void)hipFree(b->p);
+	}
+	b->p = np;
+	b->cap = cap;
+	return MSX_OK;
+}
+
+extern "C" int msx_coverage_collect(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len,
+                                    int32_t *cov, uint8_t *covered) {
+	if (!ctx || !b || !cov_off || !cov || total_len < 0) return MSX_ERR_ARG;
+	if (!b->pos || !b->tid || !b->cigar_off || !b->cigar)
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_collect needs tid, pos and cigar arrays");
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	msx_cov_collect &C = ctx->cvc;
+	int rc;
+	if (!C.active) {
+		const int64_t n_tiles = (total_len + 1 + CV3_TILE - 1) >> CV3_TILE_SHIFT;
+		C = msx_cov_collect();
+		C.active = true;
+		C.total_len = total_len;
+		C.n_targets = n_targets;
+		C.cov = cov;
+		C.pieces = n_targets > 0 && n_tiles <= CV3_MAX_TILES && !getenv("MSX_COV_MARKS") && !getenv("MSX_COV_STREAMED");
+	} else if (C.total_len != total_len || C.n_targets != n_targets || C.cov != cov) {
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_collect: another depth array than the one the sample began with");
+	}
+	const int64_t n = b->n_records;
+	if (n <= 0) return MSX_OK;
+	bool streamed = !C.pieces;
+	if (!streamed) {
+		int64_t n_wg, own, n_items;
+		uint32_t list_cap;
+		cov_pieces_geometry(n, &n_wg, &own, &list_cap, &n_items);
+		if (C.n_items + n_items >= ((int64_t)1 << 31) - (1 << 24)) streamed = true;       // (the sort's positions are 32-bit words)
+		else {
+			const size_t at = (size_t)C.n_items, need = at + (size_t)n_items;
+			if ((rc = cov_grow_keep(ctx, &ctx->cvc_items, at * 4, need * 4 + 256))) return rc;
+			if ((rc = cov_grow_keep(ctx, &ctx->cvc_sups, at, need + 256))) return rc;
+			if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
+			cv2_state *st = (cv2_state *)ctx->cv_side.p;            // (the emit kernel's state: the side images are the finish's)
+			msx_time_begin(ctx, MSX_K_COVERAGE);
+			if ((rc = cov_pieces_emit(ctx, b, cov_off, n_targets, covered, (uint32_t *)ctx->cvc_items.p + at, (uint8_t *)ctx->cvc_sups.p + at, st,
+			                          nullptr, 0, C.targets_ready)))
+				return rc;
+			msx_time_end(ctx);
+			C.targets_ready = true;
+			// the one thing the host must know before the batch's arrays may be given back: did its pieces fit (a page-locked word)
+			if (!ctx->cvc_flag) MSX_HIP(ctx, hipHostMalloc((void **)&ctx->cvc_flag, 64, hipHostMallocDefault));
+			MSX_HIP(ctx, hipMemcpyAsync(ctx->cvc_flag, &st->overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+			MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			if (getenv("MSX_COV_DEBUG")) {
+				cv2_state h;
+				MSX_HIP(ctx, hipMemcpy(&h, st, sizeof h, hipMemcpyDeviceToHost));
+				uint32_t mx = 0;
+				for (int q = 0; q < CV2_LISTS; q++) mx = h.list_n[q] > mx ? h.list_n[q] : mx;
+				fprintf(stderr, "# collect: batch of %lld records at item %lld (+%lld), lists of %u (fullest %u), overflow %u\n", (long long)n,
+				        (long long)C.n_items, (long long)n_items, list_cap, mx, h.overflow);
+			}
+			if (!*ctx->cvc_flag) { C.n_items += n_items; C.n_batches++; return MSX_OK; }
+			streamed = true;                                        // (its items are not kept: the next batch writes over them)
+		}
+	}
+	if (!C.cov_zeroed) {
+		MSX_HIP(ctx, hipMemsetAsync(cov, 0, (size_t)(total_len + 1) * 4, ctx->stream));
+		C.cov_zeroed = true;
+	}
+	C.n_streamed++;
+	return msx_coverage_accumulate(ctx, b, cov_off, n_targets, total_len, cov, covered);
+}
+
+extern "C" int msx_coverage_collect_finish(msx_ctx *ctx, int32_t *cov, int64_t total_len, int64_t *n_batches_streamed) {
+	if (!ctx || !cov || total_len < 0) return MSX_ERR_ARG;
+	msx_join(ctx);
+	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	msx_cov_collect &C = ctx->cvc;
+	if (C.active && (C.cov != cov || C.total_len != total_len))
+		return msx_fail(ctx, MSX_ERR_ARG, "msx_coverage_collect_finish: another depth array than the one the sample began with");
+	int rc = MSX_OK;
+	const bool marks = C.active && C.cov_zeroed;
+	if (n_batches_streamed) *n_batches_streamed = C.active ? C.n_streamed : 0;
+	if (marks) rc = msx_coverage_finish(ctx, cov, total_len);               // the streamed batches' marks -> depths
+	if (!rc && C.active && C.n_items > 0) {
+		const int64_t n_ub = msx_sort_k32v8_bound(C.n_items);
+		if (!(rc = cov_grow_keep(ctx, &ctx->cvc_items, (size_t)C.n_items * 4, (size_t)(n_ub + 64) * 4)) &&
+		    !(rc = msx_reserve(ctx, &ctx->cv_key[1], (size_t)(n_ub + 64) * 4)) &&
+		    !(rc = msx_sort_k32v8_reserve(ctx, C.n_items, &ctx->cv_hist, &ctx->cv_off, nullptr))) {
+			msx_time_begin(ctx, MSX_K_COVERAGE);
+			rc = cov_pieces_finish(ctx, (uint32_t *)ctx->cvc_items.p, (const uint8_t *)ctx->cvc_sups.p, (uint32_t *)ctx->cv_key[1].p, C.n_items, 0,
+			                       total_len, cov, marks ? 1 : 0, nullptr);
+			msx_time_end(ctx);
+		}
+	} else if (!rc && !marks && total_len >= 0) {
+		MSX_HIP(ctx, hipMemsetAsync(cov, 0, (size_t)(total_len + 1) * 4, ctx->stream));       // a sample without a record
+	}
+	C = msx_cov_collect();             // (the items' buffers stay with the context: the next sample writes over them)
+	return rc;
 }
 
 extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64_t *cov_off, int32_t n_targets, int64_t total_len,

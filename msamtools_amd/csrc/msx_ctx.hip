@@ -170,6 +170,7 @@ extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->df_used && ctx->df_last) (void)hipStreamSynchronize(ctx->df_last);
 	if (ctx->df_done) (void)hipEventDestroy(ctx->df_done);
+	if (ctx->cvc_flag) (void)hipHostFree(ctx->cvc_flag);
 	for (auto &t : ctx->timed) {
 		(void)hipEventDestroy(t.a);
 		(void)hipEventDestroy(t.b);
@@ -177,7 +178,7 @@ extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 	for (auto &ev : ctx->event_pool) (void)hipEventDestroy(ev);
 	msx_buf *bufs[] = {&ctx->pool_code, &ctx->gcount, &ctx->gbase, &ctx->scan_l1, &ctx->scan_l2,
 	                   &ctx->scan_l3, &ctx->pinfo, &ctx->moff, &ctx->tmp_fid, &ctx->ukey2,
-	                   &ctx->cv_key[0], &ctx->cv_key[1], &ctx->cv_hist, &ctx->cv_off, &ctx->cv_start, &ctx->cv_side, &ctx->df_slots, &ctx->df_size,
+	                   &ctx->cv_key[0], &ctx->cv_key[1], &ctx->cv_hist, &ctx->cv_off, &ctx->cv_start, &ctx->cv_side, &ctx->cv_targets, &ctx->cvc_items, &ctx->cvc_sups, &ctx->df_slots, &ctx->df_size,
 	                   &ctx->df_tok};
 	for (auto *b : bufs) free_buf(b);
 	if (ctx->d_status) (void)hipFree(ctx->d_status);

@@ -61,6 +61,19 @@ struct msx_buf {
 	size_t cap = 0;
 };
 
+// msx_coverage_collect: a sample's coverage items gathered batch after batch (msx_coverage.hip)
+struct msx_cov_collect {
+	bool active = false;
+	bool pieces = false;            // the sample takes the one-word-per-piece form (else every batch is piled up the streamed way)
+	bool cov_zeroed = false;        // cov[] holds marks of streamed batches (zeroed when the first of them came)
+	bool targets_ready = false;
+	int64_t n_items = 0;            // items kept so far (own slots and overflow lists of every batch, empty slots included)
+	int64_t n_batches = 0, n_streamed = 0;
+	int64_t total_len = 0;
+	int32_t n_targets = 0;
+	int32_t *cov = nullptr;
+};
+
 struct msx_timed {
 	int kid;
 	hipEvent_t a, b;
@@ -99,6 +112,9 @@ struct msx_ctx {
 	// workspace, grown on demand and kept
 	msx_buf pool_code, gcount, gbase, scan_l1, scan_l2, scan_l3, pinfo, moff, tmp_fid, ukey2;
 	msx_buf cv_key[2], cv_hist, cv_off, cv_start, cv_side;   // coverage: binned pile-up items; images of pre-reduced tiles
+	msx_buf cv_targets, cvc_items, cvc_sups;                 // (first cell, length) per target; msx_coverage_collect's items
+	msx_cov_collect cvc;
+	uint32_t *cvc_flag = nullptr;      // page-locked: a batch's overflow flag on its way to the host
 	msx_buf df_slots, df_size, df_tok;              // msx_deflate.hip: block slots, sizes + offsets, token scratch of the resident waves
 	hipStream_t df_last = nullptr;     // the stream the encoder's scratch was last used on (ONE set per context: a launch on
 	hipEvent_t df_done = nullptr;      // another stream waits for df_done first; growing the scratch drains df_last)

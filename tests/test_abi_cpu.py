@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version():
     from msamtools_amd import _lib
-    assert _lib.load().msx_abi_version() == 6
+    assert _lib.load().msx_abi_version() == 7
 
 
 def test_library_carries_gfx950_code_object():

@@ -194,6 +194,27 @@ def test_c4_coverage_full_size():
         seen2 = ctx.to_host(d_seen, C4_REFS, np.uint8)
         assert np.array_equal(cov, cov2) and np.array_equal(seen, seen2)
         del cov2
+        # the command line's form: the sample batch after batch (msx_coverage_collect: the batches' pieces stay on the device,
+        # msx_coverage_collect_finish sorts and sums them once) -- the same stream cut into seven uneven batches
+        ctx.to_dev(d_cov, np.full(total + 2, 0x5a5a5a5a, np.uint32))
+        ctx.zero(d_seen, C4_REFS)
+        cuts = [0, 1_000_000, 1_000_017, 3_500_000, 3_500_000 + 9_000, 6_000_000, 9_999_999, C4_GROUPS]
+        n_rec = 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = m.DeviceBatch.synth(ctx, SEED, hi - lo, C4_REFS, 4, first_group=lo)
+            n_rec += part.n_records
+            ctx.check(ctx.lib.msx_coverage_collect(ctx.h, C.byref(part.b), C.c_void_p(d_off), C4_REFS, total, C.c_void_p(d_cov),
+                                                   C.c_void_p(d_seen)))
+            part.free()
+        assert n_rec == db.n_records
+        n_streamed = C.c_int64(-1)
+        ctx.check(ctx.lib.msx_coverage_collect_finish(ctx.h, C.c_void_p(d_cov), total, C.byref(n_streamed)))
+        ctx.sync()
+        assert n_streamed.value == 0
+        cov3 = ctx.to_host(d_cov, total, np.int32)
+        seen3 = ctx.to_host(d_seen, C4_REFS, np.uint8)
+        assert np.array_equal(cov, cov3) and np.array_equal(seen, seen3)
+        del cov3
         ctx.free(d_off), ctx.free(d_cov), ctx.free(d_seen)
 
         hs = HostCopy(db)

@@ -707,3 +707,82 @@ def test_whole_sample_coverage_fuzz(ctx, seed, n_refs, tl):
         for t in range(n_refs):
             assert (got[t] == want[t]).all(), (env, t, np.flatnonzero(got[t] != want[t])[:5])
     db.free()
+
+
+def _cov_fuzz_records(hs, seed, n_refs, tl):
+    """hs with random CIGARs (every operation code, 1-9 operations), random targets and positions, runs inside their targets"""
+    rng = np.random.default_rng(seed)
+    n = hs.n_records
+    nops = rng.integers(1, 10, n)
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(nops)
+    ops = rng.choice(np.arange(9), size=int(off[-1]), p=[0.45, 0.1, 0.12, 0.08, 0.08, 0.03, 0.02, 0.06, 0.06]).astype(np.uint32)
+    wd = rng.integers(0, 60, int(off[-1])).astype(np.uint32)
+    ref_span = lambda: np.add.reduceat(np.where(np.isin(ops, [0, 2, 3, 7, 8]), wd, 0).astype(np.int64), off[:-1].astype(np.int64))
+    for i in np.flatnonzero(ref_span() > tl - 1):
+        ops[off[i]:off[i + 1]] = 4
+        ops[off[i]], wd[off[i]] = 0, 10
+    span = ref_span()
+    hs.cigar_off, hs.cigar = off, (wd << 4 | ops).astype(np.uint32)
+    hs.tid = rng.integers(-1, n_refs, n).astype(np.int32)
+    hs.pos = (rng.random(n) * (tl - span)).astype(np.int32)
+    return hs
+
+
+@pytest.mark.parametrize("n_groups,n_refs,tl,cuts", [
+    (60000, 2000, 5000, [0.0, 0.31, 0.31, 0.32, 0.77, 1.0]),        # an empty batch, a small one
+    (300000, 6, 5000, [0.0, 0.05, 0.5, 0.52, 1.0]),                 # every tile a hot one
+    (20000, 50000, 5000, [0.0, 0.001, 0.002, 0.6, 1.0])])           # tiny batches (far below a sort tile), many targets
+def test_collected_coverage_parity(ctx, n_groups, n_refs, tl, cuts):
+    """msx_coverage_collect / msx_coverage_collect_finish -- the command line's form of the whole-sample pile-up: the batches'
+    pieces kept on the device, sorted and summed once -- against the oracle's per-base counting (msam_coverage.c:33-87),
+    the covered flags (:45-49) included; no batch takes the streamed way."""
+    import msamtools_amd as m
+    hs = m.HostSynth(515, n_groups, n_refs, 4)
+    tlen = [tl] * n_refs
+    want = orc.coverage(hs, tlen)
+    n = hs.n_records
+    edges = [int(round(c * n)) for c in cuts]
+    parts = [m.DeviceBatch.upload(ctx, m.RecordSlice(hs, lo, hi)) for lo, hi in zip(edges[:-1], edges[1:])]
+    try:
+        got, n_streamed, flags = m.coverage_collected(ctx, parts, tlen, covered=True)
+    finally:
+        for p in parts:
+            p.free()
+    assert n_streamed == 0
+    for t in range(n_refs):
+        assert (got[t] == want[t]).all(), (t, np.flatnonzero(got[t] != want[t])[:5])
+    assert np.array_equal(flags != 0, np.bincount(hs.tid[hs.tid >= 0], minlength=n_refs) > 0)
+    # a second sample on the same context starts from nothing
+    again, n_streamed = m.coverage_collected(ctx, [], tlen)
+    assert n_streamed == 0 and all(int(a.sum()) == 0 and (a == 0).all() for a in again)
+
+
+def test_collected_coverage_with_batches_that_go_the_streamed_way(ctx):
+    """A batch whose overflow lists run full (most records with several runs behind D / N operations) is piled up the streamed
+    way inside msx_coverage_collect -- marks in the depth array, zeroed then -- and the finish adds the other batches'
+    tile depths to its prefix sums: plain batch, such a batch, plain batch; and the whole sample the streamed way
+    (MSX_COV_STREAMED=1: what a sample of more than 255 x 2^20 cells takes)."""
+    import msamtools_amd as m
+    n_refs, tl = 300, 5000                                  # (the synthetic positions stay below 5000: msx_synth.h)
+    a = m.HostSynth(31, 30000, n_refs, 4)
+    b = _cov_fuzz_records(m.HostSynth(32, 16000, n_refs, 4), 7, n_refs, tl)
+    c = m.HostSynth(33, 9000, n_refs, 4)
+    tlen = [tl] * n_refs
+    want = [x + y + z for x, y, z in zip(orc.coverage(a, tlen), orc.coverage(b, tlen), orc.coverage(c, tlen))]
+    for env, min_streamed in ((None, 1), ("MSX_COV_STREAMED", 3)):
+        parts = [m.DeviceBatch.upload(ctx, m.RecordSlice(x, 0, x.n_records)) for x in (a, b, c)]
+        if env:
+            os.environ[env] = "1"
+        try:
+            got, n_streamed = m.coverage_collected(ctx, parts, tlen)
+        finally:
+            if env:
+                del os.environ[env]
+            for p in parts:
+                p.free()
+        assert n_streamed >= min_streamed, (env, n_streamed)
+        if env is None:
+            assert n_streamed < 3
+        for t in range(n_refs):
+            assert (got[t] == want[t]).all(), (env, t, np.flatnonzero(got[t] != want[t])[:5])
