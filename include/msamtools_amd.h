@@ -274,7 +274,10 @@ int  msx_unpack_emit_fetch(msx_ctx *ctx, msx_unpack *u, uint8_t *host_out, size_
  * msam_helper.c:270-272; "wbu" / "wb": msam_filter.c:464-470): the gathered byte string is cut into payloads of 0xff00
  * bytes and every payload becomes a finished BGZF block -- header with BSIZE, DEFLATE stream, CRC-32, ISIZE -- so that what
  * msx_unpack_emit_fetch brings down is what goes into the file, byte for byte.  level 0: stored blocks (-bu); level >= 1:
- * DEFLATE with dynamic Huffman codes (-b; one encoder, the level is not a dial).
+ * DEFLATE with dynamic Huffman codes (-b).  One encoder; what the level dials is its window and table sizes -- the LDS a wave
+ * takes, hence the waves a compute unit keeps resident: 7-9 window 8 KB, tables of 2048 + 2048 entries (22 GB/s, 1.08 of zlib
+ * -6's size on BAM records); 4-6 window 2.5 KB, 1024 + 2048 (40 GB/s, 1.085; -b asks for 6, htslib's default); 1-3 window
+ * 2.5 KB, 1024 + 1024 (44 GB/s, 1.09).
  * *n_bytes: bytes of finished blocks; *n_blocks: how many (payloads all full but the last). */
 int  msx_unpack_emit_gather_bgzf(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_dev, int64_t n_emit, int level,
                                  int64_t *n_bytes, int64_t *n_blocks);
@@ -322,7 +325,8 @@ int  msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_c
  *
  * The other direction (bgzf_write under sam_write1, msam_helper.c:270-272): n_bytes of device memory cut into payloads of
  * 0xff00 bytes, each framed as one BGZF block in d_out, back to back.  level 0: stored blocks (what htslib writes for
- * "wbu", msam_filter.c:464-470); level >= 1: raw DEFLATE ("wb"), LZ77 + dynamic Huffman codes per block -- the bytes differ
+ * "wbu", msam_filter.c:464-470); level >= 1: raw DEFLATE ("wb"), LZ77 + dynamic Huffman codes per block (levels 1-3 / 4-6 /
+ * 7-9: three sizes of window and tables, see msx_unpack_emit_gather_bgzf) -- the bytes differ
  * from zlib's, the records do not (the reference's tests compare records: tests/functions.sh:160-163).
  * msx_bgzf_bound: bytes d_out must hold.  Waits for the result.  One call takes at most what keeps msx_bgzf_bound below
  * 2^32 for level >= 1 (block offsets are 32-bit words on the device; MSX_ERR_ARG beyond), 0xfff00000 bytes for level 0.

@@ -516,7 +516,9 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	/* the BGZF layer of the output on the device: stored blocks for -bu, DEFLATE for -b (MSX_HOST_FRAME=1: frame / zlib-deflate
 	 * on the host cores, as round 3 did; MSX_HOST_DEFLATE=1: only -b's deflate) */
 	F.dev_frame = (out_mode == MSH_OUT_UBAM || (out_mode == MSH_OUT_BAM && !getenv("MSX_HOST_DEFLATE"))) && !getenv("MSX_HOST_FRAME");
-	F.dev_level = out_mode == MSH_OUT_UBAM ? 0 : 6;
+	F.dev_level = out_mode == MSH_OUT_UBAM ? 0 : 6;           /* ("wb": htslib's default level; MSX_BGZF_LEVEL=1..9 as for the host's zlib) */
+	if (F.dev_level && getenv("MSX_BGZF_LEVEL") && atoi(getenv("MSX_BGZF_LEVEL")) >= 1 && atoi(getenv("MSX_BGZF_LEVEL")) <= 9)
+		F.dev_level = atoi(getenv("MSX_BGZF_LEVEL"));
 	F.dev_overlap = F.dev_frame && F.dev_level > 0 && !getenv("MSX_DEFLATE_SYNC");     /* (MSX_DEFLATE_SYNC=1: one batch after the other) */
 	F.P = &P; F.fp = fp; F.pools = pools; F.out_mode = out_mode; F.argc = argc; F.argv = argv; F.po = po; F.pf = &pf;
 	pthread_mutex_init(&F.mu, NULL);

@@ -95,9 +95,6 @@ int msx_bgzf_store_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in,
 // LDS: 32 KB ring + tables in pass 1, reused by the coder; 34 KB per wave -> 4 waves per compute unit.
 #define DF_SLOT (BZ_PAYLOAD + 1024u)  // bytes reserved per block while it is being built
 #define DF_OUT0 32u                   // a slot's DEFLATE stream starts here (16-byte aligned); the block itself at DF_OUT0 - 18
-#define DF_RMASK 4095u                // the ring, in dwords
-#define DF_WINDOW 8192u
-#define DF_HBITS 11
 #define DF_AHEAD 336u                 // bytes a step reads beyond its first position (63 + 258 + 8, rounded up)
 #define DF_TOKCAP (BZ_PAYLOAD + 64u)  // tokens per block, at most (+ end of block)
 #define DF_MAXMATCH 258u
@@ -106,23 +103,31 @@ int msx_bgzf_store_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in,
 #define DF_TOK_MATCH 0x80000000u
 #define DF_LL 288                     // literal/length lengths live at ll[0..288), distance lengths at ll[288..320)
 
+// the coder's working set (pass 2; it takes the place of the ring and the tables of pass 1)
+struct df_hf {
+	uint32_t stage[512];          // coded bits on their way out: two halves of 1 KB
+	uint32_t crc_tab[256];
+	uint32_t key[320];            // ranking keys
+	uint32_t W[320];              // weights of the ranked symbols
+	uint32_t inode[320];          // weights of the internal nodes, then their depths
+	uint32_t cnt[336];            // internal nodes per depth / leaves per length
+	uint32_t lcode[288], dcode[32], ccode[20];   // code | length << 16
+	uint16_t par[320];            // parent of an internal node, then jump pointers
+	uint16_t order[320];          // rank -> symbol
+	uint16_t seq[336];            // both trees' lengths, run-length coded: symbol | extra << 8
+	uint8_t ll[320];
+	uint8_t cl[32];
+};
+// GEOMETRY of pass 1 (template parameters of the kernel): RING_DW dwords of input ring (a power of two; it must hold the
+// window, a step, what a step reads ahead and the kilobyte the ring is filled by: 4 * RING_DW >= WINDOW + 64 + DF_AHEAD + 1024),
+// HB4 / HB8 bits of hash for the two tables, WINDOW = the largest distance.  The kernel is a latency chain per wave (every LDS
+// round trip exposed, the vector ALUs a third busy at one wave per SIMD), so what a launch achieves follows the waves a
+// compute unit keeps resident, and that is the LDS a wave takes: msx_bgzf_deflate_launch lists the geometries.
+template <int RING_DW, int HB4, int HB8>
 struct df_lds {
 	union {
-		struct { uint32_t ring[4096 + 8]; uint32_t h4[1u << DF_HBITS]; uint32_t h8[1u << DF_HBITS]; } lz;   // (ring: its first 8 dwords once more behind the end)
-		struct {
-			uint32_t stage[512];          // coded bits on their way out: two halves of 1 KB
-			uint32_t crc_tab[256];
-			uint32_t key[320];            // ranking keys
-			uint32_t W[320];              // weights of the ranked symbols
-			uint32_t inode[320];          // weights of the internal nodes, then their depths
-			uint32_t cnt[336];            // internal nodes per depth / leaves per length
-			uint32_t lcode[288], dcode[32], ccode[20];   // code | length << 16
-			uint16_t par[320];            // parent of an internal node, then jump pointers
-			uint16_t order[320];          // rank -> symbol
-			uint16_t seq[336];            // both trees' lengths, run-length coded: symbol | extra << 8
-			uint8_t ll[320];
-			uint8_t cl[32];
-		} hf;
+		struct { uint32_t ring[RING_DW + 8]; uint32_t h4[1u << HB4]; uint32_t h8[1u << HB8]; } lz;   // (ring: its first 8 dwords once more behind the end)
+		df_hf hf;
 	};
 	uint32_t lf[288], dq[32], clf[32];
 };
@@ -141,35 +146,15 @@ __device__ __forceinline__ uint32_t df_wave_max(uint32_t x) {
 	for (int s = 32; s >= 1; s >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)x, s); x = o > x ? o : x; }
 	return x;
 }
-// the dword at byte position pos of the ring (any alignment); the ring's first 8 dwords are repeated behind its end, so
-// that up to 5 consecutive dwords can be read from any index without wrapping
-__device__ __forceinline__ uint32_t df_ring32(const uint32_t *ring, uint32_t pos) {
-	const uint32_t i = (pos >> 2) & DF_RMASK;
-	return __builtin_amdgcn_alignbyte(ring[i + 1u], ring[i], pos & 3u);
-}
+// (the ring's first 8 dwords are repeated behind its end, so that up to 5 consecutive dwords can be read from any index
+//  without wrapping)
 // 16 bytes from byte position pos
+template <uint32_t RMASK>
 __device__ __forceinline__ void df_ring128(const uint32_t *ring, uint32_t pos, uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3) {
-	const uint32_t i = (pos >> 2) & DF_RMASK, sh = pos & 3u;
+	const uint32_t i = (pos >> 2) & RMASK, sh = pos & 3u;
 	const uint32_t r0 = ring[i], r1 = ring[i + 1u], r2 = ring[i + 2u], r3 = ring[i + 3u], r4 = ring[i + 4u];
 	a0 = __builtin_amdgcn_alignbyte(r1, r0, sh); a1 = __builtin_amdgcn_alignbyte(r2, r1, sh);
 	a2 = __builtin_amdgcn_alignbyte(r3, r2, sh); a3 = __builtin_amdgcn_alignbyte(r4, r3, sh);
-}
-// length of the match of position c with position p (< maxl): 16 bytes per round trip to the LDS
-__device__ __forceinline__ uint32_t df_mlen(const uint32_t *ring, uint32_t c, uint32_t p, uint32_t maxl) {
-	uint32_t l = 0;
-	while (l < maxl) {
-		uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-		df_ring128(ring, c + l, a0, a1, a2, a3);
-		df_ring128(ring, p + l, b0, b1, b2, b3);
-		const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
-		if (x0 | x1 | x2 | x3) {
-			l += x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
-			     : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
-			break;
-		}
-		l += 16u;
-	}
-	return l < maxl ? l : maxl;
 }
 __device__ __forceinline__ uint32_t df_len_sym(uint32_t len) {
 	const uint32_t l = len - 3u;
@@ -187,7 +172,7 @@ __device__ __forceinline__ uint32_t df_dist_sym(uint32_t dist) {
 
 // Code lengths (<= maxbits) for freq[0..n), n <= 320, into len[] (LDS bytes, zero for unused symbols); at least two
 // symbols get a code.  Every lane calls it; the wave works together.
-__device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uint32_t maxbits, uint8_t *len, uint32_t lane) {
+__device__ void df_huff_lengths(df_hf &H, const uint32_t *freq, uint32_t n, uint32_t maxbits, uint8_t *len, uint32_t lane) {
 	// used symbols; force two (the lowest unused ones, weight 1)
 	uint32_t own_f[5], own_k[5], r[5];
 	uint32_t used = 0;
@@ -206,44 +191,44 @@ __device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uin
 		const uint32_t i = lane + 64u * k;
 		if (i < n && (i == force0 || i == force1)) own_f[k] = 1u;
 		own_k[k] = own_f[k] ? (own_f[k] << 9 | i) : 0xffffffffu;
-		if (i < 320u) S.hf.key[i] = own_k[k];
+		if (i < 320u) H.key[i] = own_k[k];
 		if (i < n) len[i] = 0;
 		r[k] = 0;
 	}
 	__syncthreads();
 	// rank by (weight, symbol): every lane counts, for its symbols, the used keys below its own
 	for (uint32_t j = 0; j < n; j++) {
-		const uint32_t kj = S.hf.key[j];
+		const uint32_t kj = H.key[j];
 		for (uint32_t k = 0; k < 5u; k++) r[k] += kj < own_k[k];
 	}
 	for (uint32_t k = 0; k < 5u; k++)
-		if (own_f[k]) { S.hf.W[r[k]] = own_f[k]; S.hf.order[r[k]] = (uint16_t)(lane + 64u * k); }
-	for (uint32_t i = lane; i < 336u; i += 64u) S.hf.cnt[i] = 0;
+		if (own_f[k]) { H.W[r[k]] = own_f[k]; H.order[r[k]] = (uint16_t)(lane + 64u * k); }
+	for (uint32_t i = lane; i < 336u; i += 64u) H.cnt[i] = 0;
 	__syncthreads();
 	// the two-queue construction on the ranked weights (ties: the leaf first, as Moffat & Katajainen's in-place form
 	// does): internal node `next` = the two lightest of (leaves from `leaf` on, internal nodes from `root` on).
 	// Wave-uniform and serial: one dependent LDS read per pick.
 	{
 		uint32_t leaf = 0, root = 0;
-		uint32_t wl = S.hf.W[0], wi = 0;                 // the heads of the two queues (wi valid while root < next)
+		uint32_t wl = H.W[0], wi = 0;                 // the heads of the two queues (wi valid while root < next)
 		for (uint32_t next = 0; next + 1u < m; next++) {
 			uint32_t sum = 0;
 			for (int pick = 0; pick < 2; pick++) {
 				if (leaf < m && (root >= next || wl <= wi)) {
 					sum += wl;
 					leaf++;
-					if (leaf < m) wl = S.hf.W[leaf];
+					if (leaf < m) wl = H.W[leaf];
 				} else {
 					sum += wi;
-					if (lane == 0) S.hf.par[root] = (uint16_t)next;
+					if (lane == 0) H.par[root] = (uint16_t)next;
 					root++;
-					if (root < next) wi = S.hf.inode[root];
+					if (root < next) wi = H.inode[root];
 				}
 			}
-			if (lane == 0) S.hf.inode[next] = sum;
+			if (lane == 0) H.inode[next] = sum;
 			if (root == next) wi = sum;                      // the queue of internal nodes was empty: this one heads it
 		}
-		if (lane == 0) S.hf.par[m - 2u] = (uint16_t)(m - 2u);   // the root
+		if (lane == 0) H.par[m - 2u] = (uint16_t)(m - 2u);   // the root
 	}
 	__syncthreads();
 	// depths of the internal nodes by pointer jumping (a node's parent has a higher number; <= 9 doublings for 319 nodes)
@@ -253,40 +238,40 @@ __device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uin
 		for (uint32_t k = 0; k < 5u; k++) {
 			const uint32_t i = lane + 64u * k;
 			d[k] = (i < ni && i != ni - 1u) ? 1u : 0u;
-			q[k] = i < ni ? S.hf.par[i] : 0u;
+			q[k] = i < ni ? H.par[i] : 0u;
 		}
-		for (uint32_t k = 0; k < 5u; k++) { const uint32_t i = lane + 64u * k; if (i < ni) S.hf.inode[i] = d[k]; }
+		for (uint32_t k = 0; k < 5u; k++) { const uint32_t i = lane + 64u * k; if (i < ni) H.inode[i] = d[k]; }
 		__syncthreads();
 		for (int round = 0; round < 9; round++) {
 			uint32_t dq_[5], pq[5];
 			for (uint32_t k = 0; k < 5u; k++) {
 				const uint32_t i = lane + 64u * k;
-				dq_[k] = i < ni ? S.hf.inode[q[k]] : 0u;
-				pq[k] = i < ni ? S.hf.par[q[k]] : 0u;
+				dq_[k] = i < ni ? H.inode[q[k]] : 0u;
+				pq[k] = i < ni ? H.par[q[k]] : 0u;
 			}
 			__syncthreads();
 			for (uint32_t k = 0; k < 5u; k++) {
 				const uint32_t i = lane + 64u * k;
-				if (i < ni) { d[k] += dq_[k]; q[k] = pq[k]; S.hf.inode[i] = d[k]; S.hf.par[i] = (uint16_t)q[k]; }
+				if (i < ni) { d[k] += dq_[k]; q[k] = pq[k]; H.inode[i] = d[k]; H.par[i] = (uint16_t)q[k]; }
 			}
 			__syncthreads();
 		}
 		// leaves at depth d + 1 = 2 * (internal nodes at depth d) - (internal nodes at depth d + 1)
-		for (uint32_t k = 0; k < 5u; k++) { const uint32_t i = lane + 64u * k; if (i < ni) atomicAdd(&S.hf.cnt[d[k]], 1u); }
+		for (uint32_t k = 0; k < 5u; k++) { const uint32_t i = lane + 64u * k; if (i < ni) atomicAdd(&H.cnt[d[k]], 1u); }
 		__syncthreads();
 		uint32_t lv[5];
 		for (uint32_t k = 0; k < 5u; k++) {
 			const uint32_t dd = lane + 64u * k;              // depth dd -> leaves at dd + 1
-			lv[k] = dd < 320u ? 2u * S.hf.cnt[dd] - S.hf.cnt[dd + 1u] : 0u;
+			lv[k] = dd < 320u ? 2u * H.cnt[dd] - H.cnt[dd + 1u] : 0u;
 		}
 		__syncthreads();
 		uint32_t over = 0;
 		for (uint32_t k = 0; k < 5u; k++) {
 			const uint32_t dd = lane + 64u * k;
-			if (dd < 320u) S.hf.cnt[dd + 1u] = lv[k];
+			if (dd < 320u) H.cnt[dd + 1u] = lv[k];
 			if (dd + 1u > maxbits) over += lv[k];
 		}
-		if (lane == 0) S.hf.cnt[0] = 0;
+		if (lane == 0) H.cnt[0] = 0;
 		__syncthreads();
 		const uint32_t overflow = df_wave_sum(over);
 		if (overflow) {
@@ -295,15 +280,15 @@ __device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uin
 			// down a level and takes a leaf of the limit's level along as its sibling) takes exactly one unit away -- the
 			// number of steps comes from the Kraft sum, not from the number of leaves moved (msx_deflate_model.h).
 			if (lane == 0) {
-				S.hf.cnt[maxbits] += overflow;
+				H.cnt[maxbits] += overflow;
 				long excess = -(1L << maxbits);
-				for (uint32_t b = 1; b <= maxbits; b++) excess += (long)S.hf.cnt[b] << (maxbits - b);
+				for (uint32_t b = 1; b <= maxbits; b++) excess += (long)H.cnt[b] << (maxbits - b);
 				while (excess > 0) {
 					uint32_t bits = maxbits - 1u;
-					while (S.hf.cnt[bits] == 0u) bits--;
-					S.hf.cnt[bits]--;
-					S.hf.cnt[bits + 1u] += 2u;
-					S.hf.cnt[maxbits]--;
+					while (H.cnt[bits] == 0u) bits--;
+					H.cnt[bits]--;
+					H.cnt[bits + 1u] += 2u;
+					H.cnt[maxbits]--;
 					excess--;
 				}
 			}
@@ -315,7 +300,7 @@ __device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uin
 		uint32_t got[5] = {0, 0, 0, 0, 0};
 		uint32_t cum = 0;
 		for (uint32_t bits = maxbits; bits >= 1u; bits--) {
-			const uint32_t c = S.hf.cnt[bits];
+			const uint32_t c = H.cnt[bits];
 			for (uint32_t k = 0; k < 5u; k++) {
 				const uint32_t rr = lane + 64u * k;
 				if (rr >= cum && rr < cum + c) got[k] = bits;
@@ -324,14 +309,14 @@ __device__ void df_huff_lengths(df_lds &S, const uint32_t *freq, uint32_t n, uin
 		}
 		for (uint32_t k = 0; k < 5u; k++) {
 			const uint32_t rr = lane + 64u * k;
-			if (rr < m) len[S.hf.order[rr]] = (uint8_t)got[k];
+			if (rr < m) len[H.order[rr]] = (uint8_t)got[k];
 		}
 	}
 	__syncthreads();
 }
 
 // canonical codes (RFC 1951 3.2.2) of len[0..n), bit-reversed for an LSB-first writer: out[i] = code | length << 16
-__device__ void df_huff_codes(df_lds &S, const uint8_t *len, uint32_t n, uint32_t *out, uint32_t lane) {
+__device__ void df_huff_codes(df_hf &H, const uint8_t *len, uint32_t n, uint32_t *out, uint32_t lane) {
 	uint32_t l[5], base[5];
 	for (uint32_t k = 0; k < 5u; k++) { const uint32_t i = lane + 64u * k; l[k] = i < n ? len[i] : 0u; base[k] = 0; }
 	// per length: how many symbols, and every symbol's number among those of its length (symbol order)
@@ -355,21 +340,21 @@ __device__ void df_huff_codes(df_lds &S, const uint8_t *len, uint32_t n, uint32_
 
 // 64 (value, bit count <= 48) pairs appended to the coded stream: offsets by a wave scan, bits OR-ed into the staging
 // area, every kilobyte that is complete written out (outp + 16-byte aligned offsets) and cleared
-__device__ __forceinline__ void df_emit(df_lds &S, uint64_t acc, uint32_t nb, uint32_t &bitpos, uint32_t &flushed, uint8_t *outp, uint32_t lane) {
+__device__ __forceinline__ void df_emit(df_hf &H, uint64_t acc, uint32_t nb, uint32_t &bitpos, uint32_t &flushed, uint8_t *outp, uint32_t lane) {
 	const uint32_t incl = df_wave_incl_scan(nb);
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 	if (nb) {
 		const uint32_t B = bitpos + incl - nb, w = B >> 5, s = B & 31u;
 		const uint64_t lo = acc << s;
-		atomicOr(&S.hf.stage[w & 511u], (uint32_t)lo);
-		if ((uint32_t)(lo >> 32)) atomicOr(&S.hf.stage[(w + 1u) & 511u], (uint32_t)(lo >> 32));
-		if (s > 16u) { const uint32_t hi = (uint32_t)(acc >> (64u - s)); if (hi) atomicOr(&S.hf.stage[(w + 2u) & 511u], hi); }
+		atomicOr(&H.stage[w & 511u], (uint32_t)lo);
+		if ((uint32_t)(lo >> 32)) atomicOr(&H.stage[(w + 1u) & 511u], (uint32_t)(lo >> 32));
+		if (s > 16u) { const uint32_t hi = (uint32_t)(acc >> (64u - s)); if (hi) atomicOr(&H.stage[(w + 2u) & 511u], hi); }
 	}
 	bitpos += total;
 	__syncthreads();
 	while (bitpos - flushed >= 8192u) {
 		const uint32_t half = (flushed >> 13) & 1u;
-		uint4 *sp = reinterpret_cast<uint4 *>(&S.hf.stage[half * 256u + lane * 4u]);
+		uint4 *sp = reinterpret_cast<uint4 *>(&H.stage[half * 256u + lane * 4u]);
 		*reinterpret_cast<uint4 *>(outp + (flushed >> 3) + lane * 16u) = *sp;
 		*sp = make_uint4(0, 0, 0, 0);
 		flushed += 8192u;
@@ -377,7 +362,8 @@ __device__ __forceinline__ void df_emit(df_lds &S, uint64_t acc, uint32_t nb, ui
 	}
 }
 
-__global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__ in, const uint32_t *__restrict__ d_total, uint32_t n_total,
+template <int RING_DW, int HB4, int HB8, int WINDOW, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_bgzf_deflate(const uint8_t *__restrict__ in, const uint32_t *__restrict__ d_total, uint32_t n_total,
                                                      uint8_t *__restrict__ slots, uint32_t *__restrict__ bsize, uint32_t *__restrict__ tok_all,
                                                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ kinds) {
 	// MSX_DEFLATE_STATS: kinds[0..2] count the blocks written stored / with the fixed codes / with codes of their own; behind them
@@ -386,7 +372,9 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 	unsigned long long t_mark = 0, t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DF_T0() do { if (prof) t_mark = __builtin_readcyclecounter(); } while (0)
 #define DF_T(i) do { if (prof) { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[i] += now_ - t_mark; t_mark = now_; } } while (0)
-	__shared__ df_lds S;
+	static_assert(4 * RING_DW >= WINDOW + 64 + (int)DF_AHEAD + 1024, "the ring holds window, step, look-ahead and a kilobyte of fill");
+	constexpr uint32_t DF_RMASK = (uint32_t)RING_DW - 1u;
+	__shared__ df_lds<RING_DW, HB4, HB8> S;
 	__shared__ uint32_t s_bi;
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = d_total ? *d_total : n_total;
@@ -405,7 +393,7 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 		uint8_t *slot = slots + (size_t)bi * DF_SLOT;
 		// ---- pass 1: tokens and their histogram ----
 		DF_T0();
-		for (uint32_t i = lane * 4u; i < 2u * (1u << DF_HBITS); i += 256u)
+		for (uint32_t i = lane * 4u; i < (1u << HB4) + (1u << HB8); i += 256u)
 			*reinterpret_cast<uint4 *>(&S.lz.h4[i]) = make_uint4(0, 0, 0, 0);     // (h8 follows h4)
 		for (uint32_t i = lane; i < 288u; i += 64u) S.lf[i] = 0;
 		if (lane < 32u) { S.dq[lane] = 0; S.clf[lane] = 0; }
@@ -423,7 +411,7 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 				}
 				const uint32_t ri = (off >> 2) & DF_RMASK;
 				*reinterpret_cast<uint4 *>(&S.lz.ring[ri]) = v;
-				if (ri < 8u) *reinterpret_cast<uint4 *>(&S.lz.ring[4096u + ri]) = v;      // (lanes 0 and 1 of the chunk that wraps)
+				if (ri < 8u) *reinterpret_cast<uint4 *>(&S.lz.ring[(uint32_t)RING_DW + ri]) = v;      // (lanes 0 and 1 of the chunk that wraps)
 				filled += 1024u;
 			}
 			__syncthreads();
@@ -437,8 +425,8 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 			const uint32_t r0 = S.lz.ring[qm], r1 = S.lz.ring[qm + 1u], r2 = S.lz.ring[qm + 2u], r3 = S.lz.ring[qm + 3u], r4 = S.lz.ring[qm + 4u];
 			const uint32_t W0 = __builtin_amdgcn_alignbyte(r1, r0, sh), W1 = __builtin_amdgcn_alignbyte(r2, r1, sh),
 			               W2 = __builtin_amdgcn_alignbyte(r3, r2, sh), W3 = __builtin_amdgcn_alignbyte(r4, r3, sh);
-			const uint32_t h4i = (W2 * DF_MUL4) >> (32 - DF_HBITS);
-			const uint32_t h8i = (uint32_t)((((uint64_t)W3 << 32 | W2) * DF_MUL8) >> (64 - DF_HBITS));
+			const uint32_t h4i = (W2 * DF_MUL4) >> (32 - HB4);
+			const uint32_t h8i = (uint32_t)((((uint64_t)W3 << 32 | W2) * DF_MUL8) >> (64 - HB8));
 			const uint32_t c4 = has4 ? S.lz.h4[h4i] : 0u, c8 = has8 ? S.lz.h8[h8i] : 0u;
 			// the nearest of the distances 1..8 whose 4 bytes repeat (runs, short periods: what the tables of earlier steps
 			// cannot show a position).  Such a position stays out of the tables: inside a run every position would enter
@@ -461,8 +449,8 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 				const uint32_t maxl = (n - p) < DF_MAXMATCH ? (n - p) : DF_MAXMATCH;
 				if (!need) nd = 0;
 				const uint32_t a4 = c4 - 1u, a8 = c8 - 1u;
-				const bool v4 = need && c4 != 0u && p - a4 <= DF_WINDOW;
-				const bool v8 = need && c8 != 0u && p - a8 <= DF_WINDOW && !(v4 && c8 == c4);
+				const bool v4 = need && c4 != 0u && p - a4 <= (uint32_t)WINDOW;
+				const bool v8 = need && c8 != 0u && p - a8 <= (uint32_t)WINDOW && !(v4 && c8 == c4);
 				// The candidates in a fixed order -- near, 4-byte table, 8-byte table; a later one must be strictly longer.
 				// One loop for all of them: every trip compares 16 bytes of each lane's current candidate, a lane that has
 				// finished one moves on to its next (the wave then waits for the lane with the most bytes to compare in all,
@@ -479,8 +467,8 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 					if (act) {                                   // (one masked region; inside it selects, no branches)
 						const uint32_t off = quick ? bl - 15u : l;
 						uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-						df_ring128(S.lz.ring, cur + off, a0, a1, a2, a3);
-						df_ring128(S.lz.ring, p + off, b0, b1, b2, b3);
+						df_ring128<DF_RMASK>(S.lz.ring, cur + off, a0, a1, a2, a3);
+						df_ring128<DF_RMASK>(S.lz.ring, p + off, b0, b1, b2, b3);
 						const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
 						const bool diff = (x0 | x1 | x2 | x3) != 0u;
 						// where the first differing byte sits (diff) -- __builtin_ctz of 0 is not asked for: | 1u << 31 keeps it defined
@@ -549,8 +537,8 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 		const uint32_t crc = n ? crc_wave(src, n, S.hf.crc_tab, lane) : 0u;
 		DF_T(4);
 		// ---- the two trees, the code-length code, what each way of writing the block costs ----
-		df_huff_lengths(S, S.lf, 286u, 15u, S.hf.ll, lane);
-		df_huff_lengths(S, S.dq, 30u, 15u, S.hf.ll + DF_LL, lane);
+		df_huff_lengths(S.hf, S.lf, 286u, 15u, S.hf.ll, lane);
+		df_huff_lengths(S.hf, S.dq, 30u, 15u, S.hf.ll + DF_LL, lane);
 		DF_T(5);
 		uint32_t hlit, hdist;
 		{
@@ -601,7 +589,7 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 		}
 		__syncthreads();
 		DF_T(6);
-		df_huff_lengths(S, S.clf, 19u, 7u, S.hf.cl, lane);
+		df_huff_lengths(S.hf, S.clf, 19u, 7u, S.hf.cl, lane);
 		const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 		uint32_t hclen;
 		{
@@ -670,15 +658,15 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 			uint32_t bitpos = 0, flushed = 0;
 			uint8_t *outp = slot + DF_OUT0;
 			if (kind == 2u) {
-				df_huff_codes(S, S.hf.ll, 286u, S.hf.lcode, lane);
-				df_huff_codes(S, S.hf.ll + DF_LL, 30u, S.hf.dcode, lane);
-				df_huff_codes(S, S.hf.cl, 19u, S.hf.ccode, lane);
+				df_huff_codes(S.hf, S.hf.ll, 286u, S.hf.lcode, lane);
+				df_huff_codes(S.hf, S.hf.ll + DF_LL, 30u, S.hf.dcode, lane);
+				df_huff_codes(S.hf, S.hf.cl, 19u, S.hf.ccode, lane);
 				// BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then the code-length code's lengths in their fixed order
 				uint64_t acc = 0;
 				uint32_t nb = 0;
 				if (lane == 0) { acc = 1u | 2u << 1 | (hlit - 257u) << 3 | (hdist - 1u) << 8 | (uint64_t)(hclen - 4u) << 13; nb = 17u; }
 				else if (lane <= hclen) { acc = S.hf.cl[cl_order[lane - 1u]]; nb = 3u; }
-				df_emit(S, acc, nb, bitpos, flushed, outp, lane);
+				df_emit(S.hf, acc, nb, bitpos, flushed, outp, lane);
 				for (uint32_t g = 0; g < ns; g += 64u) {
 					acc = 0; nb = 0;
 					if (g + lane < ns) {
@@ -687,7 +675,7 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 						acc |= (uint64_t)(e >> 8) << nb;
 						nb += sy == 16u ? 2u : sy == 17u ? 3u : sy == 18u ? 7u : 0u;
 					}
-					df_emit(S, acc, nb, bitpos, flushed, outp, lane);
+					df_emit(S.hf, acc, nb, bitpos, flushed, outp, lane);
 				}
 			} else {
 				// the fixed codes (RFC 1951 3.2.6), bit-reversed
@@ -701,7 +689,7 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 				}
 				if (lane < 30u) S.hf.dcode[lane] = (__brev(lane) >> 27) | 5u << 16;
 				__syncthreads();
-				df_emit(S, 1u | 1u << 1, lane == 0 ? 3u : 0u, bitpos, flushed, outp, lane);
+				df_emit(S.hf, 1u | 1u << 1, lane == 0 ? 3u : 0u, bitpos, flushed, outp, lane);
 			}
 			for (uint32_t g = 0; g < nt; g += 64u) {
 				uint64_t acc = 0;
@@ -721,7 +709,7 @@ __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *__restrict__
 						acc = lc & 0xffffu; nb = lc >> 16;
 					}
 				}
-				df_emit(S, acc, nb, bitpos, flushed, outp, lane);
+				df_emit(S.hf, acc, nb, bitpos, flushed, outp, lane);
 			}
 			// what is left in the staging area: whole dwords by the lanes, the last bytes by lane 0
 			nbytes = (bitpos + 7u) >> 3;
@@ -796,11 +784,37 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_bgzf_offsets(const uint32_t *__re
 // BGZF blocks, back to back in d_out; *d_out_total (device) receives the stream's length.  Enqueued on `stream` (every
 // kernel its own: nothing of the context's scan workspace is touched, so the stream may run beside the context's).
 int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out,
-                            uint32_t *d_out_total) {
+                            uint32_t *d_out_total, int level) {
 	if (n_cap == 0) return MSX_OK;
 	const size_t nblk = (n_cap + BZ_PAYLOAD - 1) / BZ_PAYLOAD;
 	int rc;
-	size_t waves = (size_t)ctx->num_cu * 4;
+	// The geometry of pass 1, <ring dwords, bits of the 4-byte table, bits of the 8-byte table, window>, by LEVEL -- what the level
+	// dials is the LDS a wave takes, hence the waves a compute unit keeps resident, hence the rate (round 5; measured on 250 MB of
+	// lean records / 290 MB with SEQ/QUAL, profiles/round5/deflate_geometries.log):
+	//   levels 7-9: <4096, 11, 11, 8192>  34 KB, 4 waves per compute unit  22 GB/s   1.078 / 1.119 of zlib -6's size   (round 4)
+	//   levels 4-6: <1024, 10, 11, 2560>  18 KB, 9 waves                    40 GB/s   1.085 / 1.128          (-b: htslib's default 6)
+	//   levels 1-3: <1024, 10, 10, 2560>  14 KB, 11 waves                   44 GB/s   1.091 / 1.133
+	// MSX_DEFLATE_GEOM=0..5 overrides the level (0, 4, 3 are the three above; 1 = <2048, 11, 11, 6144>, 2 = <2048, 10, 10, 6144>,
+	// 5 = <1024, 11, 11, 2560>: measured, not mapped).  The host twin follows: df_opts_for_level (msx_deflate_model.h).
+	static int geom_env = -2, per_cu[6] = {0, 0, 0, 0, 0, 0};
+	if (geom_env == -2) {
+		geom_env = getenv("MSX_DEFLATE_GEOM") ? atoi(getenv("MSX_DEFLATE_GEOM")) : -1;
+		if (geom_env < -1 || geom_env > 5) geom_env = -1;
+	}
+	const int geom = geom_env >= 0 ? geom_env : level >= 7 ? 0 : level >= 4 ? 4 : 3;
+	if (!per_cu[geom]) {
+		int nb = 0;
+		hipError_t e = geom == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bgzf_deflate<1024, 11, 11, 2560, 2>, 64, 0)
+		             : geom == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bgzf_deflate<1024, 10, 11, 2560, 3>, 64, 0)
+		             : geom == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bgzf_deflate<1024, 10, 10, 2560, 3>, 64, 0)
+		             : geom == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bgzf_deflate<2048, 10, 10, 6144, 2>, 64, 0)
+		             : geom == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bgzf_deflate<2048, 11, 11, 6144, 2>, 64, 0)
+		                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bgzf_deflate<4096, 11, 11, 8192, 1>, 64, 0);
+		per_cu[geom] = (e == hipSuccess && nb > 0) ? nb : 4;
+		if (getenv("MSX_DEFLATE_WAVES")) per_cu[geom] = atoi(getenv("MSX_DEFLATE_WAVES"));
+		if (getenv("MSX_DEFLATE_STATS")) fprintf(stderr, "# deflate: geometry %d, %d waves per compute unit\n", geom, per_cu[geom]);
+	}
+	size_t waves = (size_t)ctx->num_cu * (size_t)per_cu[geom];
 	if (waves > nblk) waves = nblk;
 	// One set of scratch per context (slots, sizes with the ticket, token scratch), launches on whatever stream the caller
 	// names: the launch is ordered behind the previous one's last kernel when that ran on another stream, and the stream
@@ -822,8 +836,16 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	MSX_HIP(ctx, hipMemsetAsync(bsize, 0, (nblk + 16) * 8 + 192, stream));
 	static int want_kinds = -1;
 	if (want_kinds < 0) want_kinds = getenv("MSX_DEFLATE_STATS") != nullptr;
-	hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)waves), dim3(64), 0, stream, d_in, d_total, (uint32_t)n_cap,
-	                   (uint8_t *)ctx->df_slots.p, bsize, (uint32_t *)ctx->df_tok.p, misc, want_kinds ? misc + 4 : nullptr);
+#define DF_LAUNCH(R, H4, H8, W, E) hipLaunchKernelGGL((k_bgzf_deflate<R, H4, H8, W, E>), dim3((unsigned)waves), dim3(64), 0, stream, d_in, d_total, \
+	                   (uint32_t)n_cap, (uint8_t *)ctx->df_slots.p, bsize, (uint32_t *)ctx->df_tok.p, misc, want_kinds ? misc + 4 : nullptr)
+	switch (geom) {
+	case 5: DF_LAUNCH(1024, 11, 11, 2560, 2); break;
+	case 4: DF_LAUNCH(1024, 10, 11, 2560, 3); break;
+	case 3: DF_LAUNCH(1024, 10, 10, 2560, 3); break;
+	case 2: DF_LAUNCH(2048, 10, 10, 6144, 2); break;
+	case 1: DF_LAUNCH(2048, 11, 11, 6144, 2); break;
+	default: DF_LAUNCH(4096, 11, 11, 8192, 1); break;
+	}
 	hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(MSX_BLOCK), 0, stream, (const uint32_t *)bsize, boff, (uint32_t)nblk);
 	hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nblk), dim3(64), 0, stream, (const uint8_t *)ctx->df_slots.p, bsize, boff, d_total,
 	                   (uint32_t)n_cap, d_out, d_out_total);
@@ -868,7 +890,7 @@ extern "C" int msx_bgzf_deflate(msx_ctx *ctx, const void *d_in, size_t n_bytes, 
 	} else {
 		if ((rc = msx_reserve(ctx, &ctx->scan_l3, 64))) return rc;
 		uint32_t *d_tot = (uint32_t *)ctx->scan_l3.p + 8, h_tot = 0;
-		if ((rc = msx_bgzf_deflate_launch(ctx, ctx->stream, (const uint8_t *)d_in, nullptr, n_bytes, (uint8_t *)d_out, d_tot))) return rc;
+		if ((rc = msx_bgzf_deflate_launch(ctx, ctx->stream, (const uint8_t *)d_in, nullptr, n_bytes, (uint8_t *)d_out, d_tot, level))) return rc;
 		MSX_HIP(ctx, hipMemcpyAsync(&h_tot, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		*n_out = h_tot;

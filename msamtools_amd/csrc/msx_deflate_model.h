@@ -23,17 +23,23 @@
 typedef struct {
 	uint32_t window;     /* largest distance looked at (<= 32768) */
 	uint32_t step;       /* positions resolved side by side (64 on the device) */
-	int hash_bits;       /* log2 of the table sizes */
+	int hash_bits;       /* log2 of the 4-byte table's size */
 	int use_h8;          /* second table keyed by the next 8 bytes */
 	int use_rep;         /* the match at distance 1 (runs) */
 	int lazy;            /* one-step lazy evaluation inside a step */
 	int fixed_only;      /* fixed Huffman codes only (first milestone; no header, no tree) */
+	int hash_bits8;      /* log2 of the 8-byte table's size */
 } df_opts;
 
-static inline df_opts df_default_opts(void) {
-	df_opts o = {8192u, 64u, 11, 1, 1, 1, 0};
+/* What the level dials on the device is the geometry of pass 1 -- window, table sizes: the LDS a wave takes, hence the waves a
+ * compute unit keeps resident (msx_bgzf_deflate_launch): levels 7-9 <window 8192, tables 11 / 11 bits> (round 4's encoder),
+ * 4-6 <2560, 10 / 11> (what -b asks for: htslib's default level is 6), 1-3 <2560, 10 / 10>. */
+static inline df_opts df_opts_for_level(int level) {
+	df_opts o = {8192u, 64u, 11, 1, 1, 1, 0, 11};
+	if (level <= 6) { o.window = 2560u; o.hash_bits = 10; o.hash_bits8 = level >= 4 ? 11 : 10; }
 	return o;
 }
+static inline df_opts df_default_opts(void) { return df_opts_for_level(6); }
 
 /* ---- RFC 1951 tables ---------------------------------------------------------------------------------------------- */
 static const uint16_t df_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -166,8 +172,7 @@ static inline uint32_t df_match_len(const uint8_t *in, uint32_t c, uint32_t p, u
 
 /* tokens of in[0..n) -> tok[], returns their number; lf/df: symbol frequencies (end-of-block included) */
 static inline uint32_t df_tokens(const uint8_t *in, uint32_t n, const df_opts *O, uint32_t *tok, uint32_t *lf, uint32_t *dfq) {
-	const uint32_t HS = 1u << O->hash_bits;
-	uint32_t *h4 = (uint32_t *)calloc(HS, 4), *h8 = (uint32_t *)calloc(HS, 4);
+	uint32_t *h4 = (uint32_t *)calloc((size_t)1 << O->hash_bits, 4), *h8 = (uint32_t *)calloc((size_t)1 << O->hash_bits8, 4);
 	uint32_t ml[1024], md[1024], nt = 0, next_free = 0, p0, i;
 	memset(lf, 0, 4 * DF_NLL);
 	memset(dfq, 0, 4 * DF_ND);
@@ -195,7 +200,7 @@ static inline uint32_t df_tokens(const uint8_t *in, uint32_t n, const df_opts *O
 				}
 			}
 			if (O->use_h8 && p + 8 <= n) {
-				const uint32_t c = h8[(uint32_t)((df_ld64(in + p) * DF_MUL8) >> (64 - O->hash_bits))];
+				const uint32_t c = h8[(uint32_t)((df_ld64(in + p) * DF_MUL8) >> (64 - O->hash_bits8))];
 				if (c && p - (c - 1) <= O->window) {
 					const uint32_t l = df_match_len(in, c - 1, p, maxl);
 					if (l >= 4 && l > bl) { bl = l; bd = p - (c - 1); }
@@ -214,7 +219,7 @@ static inline uint32_t df_tokens(const uint8_t *in, uint32_t n, const df_opts *O
 					if (df_ld32(in + p - d) == df_ld32(in + p)) { near = 1; break; }
 			if (near) continue;
 			if (p + 4 <= n) h4[(df_ld32(in + p) * DF_MUL4) >> (32 - O->hash_bits)] = p + 1;
-			if (O->use_h8 && p + 8 <= n) h8[(uint32_t)((df_ld64(in + p) * DF_MUL8) >> (64 - O->hash_bits))] = p + 1;
+			if (O->use_h8 && p + 8 <= n) h8[(uint32_t)((df_ld64(in + p) * DF_MUL8) >> (64 - O->hash_bits8))] = p + 1;
 		}
 		for (i = 0; i < cnt; i++) {                  /* resolve in order */
 			const uint32_t p = p0 + i;

@@ -152,7 +152,7 @@ extern "C" int64_t msx_bgzf_bound(int64_t n_bytes, int level);
 // ... deflated (level >= 1) into BGZF blocks back to back in d_out, on `stream` (no use of the context's scan workspace: the
 // stream may run beside the context's own); *d_out_total (device) = the stream's length
 int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in, const uint32_t *d_total, size_t n_cap, uint8_t *d_out,
-                            uint32_t *d_out_total);
+                            uint32_t *d_out_total, int level);
 extern thread_local std::string msx_tls_err;
 
 #define MSX_HIP(ctx, call)                                                              \

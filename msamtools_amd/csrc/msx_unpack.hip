@@ -1014,7 +1014,7 @@ static int up_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_d
 		// -b: deflated on the device, the blocks moved back to back; the stream's length lands in the state
 		UP_RES(framed, (size_t)msx_bgzf_bound((int64_t)u->n_bytes + 64, level) + 64);
 		if ((rc = msx_bgzf_deflate_launch(ctx, ctx->stream, (const uint8_t *)u->out.p, (const uint32_t *)u->out_off.p + ne, u->n_bytes,
-		                                  (uint8_t *)u->framed.p, &u->d_state->emit_bytes)))
+		                                  (uint8_t *)u->framed.p, &u->d_state->emit_bytes, level)))
 			return rc;
 	}
 	if ((rc = up_fetch_state(ctx, u))) return rc;                   // sync: how many bytes
@@ -1097,7 +1097,7 @@ extern "C" int msx_unpack_emit_bgzf_enqueue(msx_ctx *ctx, msx_unpack *u, const i
 	if (u->fetched_used[par]) MSX_HIP(ctx, hipStreamWaitEvent(u->df_stream, u->ev_fetched[par], 0));
 	UP_RES(ef[par], (size_t)msx_bgzf_bound((int64_t)u->n_bytes + 64, level) + 64);
 	if ((rc = msx_bgzf_deflate_launch(ctx, u->df_stream, (const uint8_t *)u->eo[par].p, u->d_emit + 2 * par + 1, u->n_bytes, (uint8_t *)u->ef[par].p,
-	                                  u->d_emit + 2 * par)))
+	                                  u->d_emit + 2 * par, level)))
 		return rc;
 	MSX_HIP(ctx, hipMemcpyAsync(u->h_emit + 2 * par, u->d_emit + 2 * par, 8, hipMemcpyDeviceToHost, u->df_stream));
 	MSX_HIP(ctx, hipEventRecord(u->ev_deflated[par], u->df_stream));

@@ -19,7 +19,8 @@
  *   pass 2  the dynamic-block header (code lengths run-length coded with symbols 16/17/18) and the tokens as bits.
  *           If a stored block is shorter, the block is stored instead.
  *
- * usage: deflate_twin [-w window] [-8 0|1] [-l 0|1] [-r 0|1] [-s step] [-f] <in> [<out.bgzf>]
+ * usage: deflate_twin [-L level] [-w window] [-b bits] [-B bits] [-8 0|1] [-l 0|1] [-r 0|1] [-s step] [-f] <in> [<out.bgzf>]
+ *        -L: the geometry the device takes for that level (default 6: msx_deflate_model.h df_opts_for_level)
  *        prints input bytes, output bytes, blocks; with <out> writes the BGZF blocks (no EOF block)
  * gcc -O2 -o deflate_twin deflate_twin.c -lz */
 #include <stdint.h>
@@ -41,6 +42,8 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[k], "-r") && k + 1 < argc) O.use_rep = atoi(argv[++k]);
 		else if (!strcmp(argv[k], "-s") && k + 1 < argc) O.step = (uint32_t)atoi(argv[++k]);
 		else if (!strcmp(argv[k], "-b") && k + 1 < argc) O.hash_bits = atoi(argv[++k]);
+		else if (!strcmp(argv[k], "-B") && k + 1 < argc) O.hash_bits8 = atoi(argv[++k]);
+		else if (!strcmp(argv[k], "-L") && k + 1 < argc) O = df_opts_for_level(atoi(argv[++k]));     /* (first: later options adjust it) */
 		else if (!strcmp(argv[k], "-f")) O.fixed_only = 1;
 		else if (!in_path) in_path = argv[k];
 		else out_path = argv[k];

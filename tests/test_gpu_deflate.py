@@ -78,11 +78,11 @@ def twin(tmp_path):
     if not os.path.exists(exe):
         subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(root, "tests", "c", "deflate_twin.c"), "-lz"])
 
-    def run(data):
+    def run(data, level=6):
         src, dst = str(tmp_path / "twin_in"), str(tmp_path / "twin_out")
         with open(src, "wb") as fh:
             fh.write(data)
-        subprocess.check_call([exe, src, dst], stdout=subprocess.DEVNULL)
+        subprocess.check_call([exe, "-L", str(level), src, dst], stdout=subprocess.DEVNULL)
         with open(dst, "rb") as fh:
             return fh.read()
     return run
@@ -91,7 +91,7 @@ def twin(tmp_path):
 SIZES = [0, 1, 15, 16, 17, 4095, 4096, 4097, PAYLOAD - 1, PAYLOAD, PAYLOAD + 1, 2 * PAYLOAD, 3 * PAYLOAD + 17, 1_000_003]
 
 
-@pytest.mark.parametrize("level", [0, 6])
+@pytest.mark.parametrize("level", [0, 6, 1, 9])
 def test_blocks_decode_to_the_input(ctx, level):
     rng = np.random.default_rng(41)
     for n in SIZES:
@@ -157,9 +157,11 @@ def fibonacci_bytes(rng):
     return data.tobytes() * 2
 
 
-def test_the_kernel_writes_the_twins_bytes(ctx, tmp_path):
+@pytest.mark.parametrize("level", [6, 9, 2])
+def test_the_kernel_writes_the_twins_bytes(ctx, tmp_path, level):
     """the device encoder against its one-position-at-a-time restatement on the host: the same blocks, bit for bit --
-    matches, lazy decisions, trees, headers (what the lanes do side by side is what the model does in order)"""
+    matches, lazy decisions, trees, headers (what the lanes do side by side is what the model does in order); at the three
+    geometries the level dials (window and table sizes: msx_bgzf_deflate_launch, df_opts_for_level)"""
     rng = np.random.default_rng(99)
     run = twin(tmp_path)
     cases = {
@@ -181,8 +183,8 @@ def test_the_kernel_writes_the_twins_bytes(ctx, tmp_path):
                                                              "deflate_block_clcode_overflow.bin"), "rb").read(),
     }
     for name, data in cases.items():
-        got, n_blk = M().bgzf_deflate(ctx, data, 6)
-        want = run(data)
+        got, n_blk = M().bgzf_deflate(ctx, data, level)
+        want = run(data, level)
         assert len(got) == len(want), (name, len(got), len(want))
         if got != want:
             first = next(i for i in range(len(got)) if got[i] != want[i])
