@@ -91,6 +91,7 @@ const uint8_t *msh_span(msh_in *in, size_t *len);     /* unconsumed bytes; inval
 void msh_span_consume(msh_in *in, size_t n);
 /* pipelined reader: inflate the next batch of blocks onto the end of a caller-owned buffer; 0 at EOF */
 size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
+void msh_release_input(msh_in *in);   /* at the end of the input: the mapping's pages leave the page tables */
 int msh_raw_append(msh_in *in, uint8_t *buf, size_t cap, size_t *len, msx_bgzf_block *blk, int *n, int max_blocks, size_t *out_total);
 void msh_inflate_table(const uint8_t *comp, const msx_bgzf_block *blk, int n, uint8_t *out);
 void msh_inflate_limit(int blocks);      /* at most this many BGZF blocks per msh_inflate_append call (0: the default batch) */

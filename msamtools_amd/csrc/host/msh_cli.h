@@ -240,6 +240,7 @@ void pq_push(pq *q, int v);
 int pq_pop(pq *q);
 int pq_try_pop(pq *q);
 void *xmalloc(size_t n);
+void mem_report(const char *tag);   /* MSX_TIMING=2 */
 void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_consumers);
 uint8_t *io_alloc(size_t bytes);
 void io_populate(uint8_t *p, size_t bytes);

@@ -25,6 +25,27 @@ double t_decode, t_upload, t_gpu, t_fetch, t_write;
  * orderly shutdown (leak checks). */
 double g_t_main;     /* now_s() at the head of main (MSX_TIMING) */
 
+/* MSX_TIMING=2: the mappings that hold more than 32 MB, at the checkpoints that call this (what the kernel has to take apart
+ * when the process ends is part of the command's wall time) */
+void mem_report(const char *tag) {
+	const char *e = getenv("MSX_TIMING");
+	FILE *f;
+	char line[256], head[256] = "";
+	long rss = 0, ahp = 0;
+	if (!e || atoi(e) < 2 || !(f = fopen("/proc/self/smaps", "r"))) return;
+	fprintf(stderr, "# mappings at %s:\n", tag);
+	while (fgets(line, sizeof line, f)) {
+		if (!strstr(line, " kB") && strchr(line, '-') && ((line[0] >= '0' && line[0] <= '9') || (line[0] >= 'a' && line[0] <= 'f'))) {
+			if (rss > 32768) fprintf(stderr, "#   %ld MB resident (%ld MB in huge pages): %s", rss >> 10, ahp >> 10, head);
+			snprintf(head, sizeof head, "%s", line);
+			rss = ahp = 0;
+		} else if (!strncmp(line, "Rss:", 4)) rss = atol(line + 4);
+		else if (!strncmp(line, "AnonHugePages:", 14)) ahp = atol(line + 14);
+	}
+	if (rss > 32768) fprintf(stderr, "#   %ld MB resident (%ld MB in huge pages): %s", rss >> 10, ahp >> 10, head);
+	fclose(f);
+}
+
 void fast_exit(void) {
 	if (getenv("MSX_TIMING")) {
 		/* what the stage timers do not see: from exec to main (loader, static initialisers) and, after this line,
@@ -33,6 +54,23 @@ void fast_exit(void) {
 		double cpu = 0;
 		if (clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts) == 0) cpu = (double)ts.tv_sec + ts.tv_nsec * 1e-9;
 		fprintf(stderr, "# process: %.3f s from main to exit, %.3f s of CPU time in all threads\n", now_s() - g_t_main, cpu);
+		{   /* what the kernel will have to take apart */
+			FILE *f = fopen("/proc/self/status", "r");
+			char line[256];
+			if (f) {
+				fprintf(stderr, "# process memory at exit:");
+				while (fgets(line, sizeof line, f))
+					if (!strncmp(line, "VmHWM", 5) || !strncmp(line, "VmRSS", 5) || !strncmp(line, "RssAnon", 7) || !strncmp(line, "RssFile", 7) ||
+					    !strncmp(line, "RssShmem", 8) || !strncmp(line, "VmPTE", 5) || !strncmp(line, "Threads", 7)) {
+						line[strcspn(line, "\n")] = 0;
+						for (char *q = line; *q; q++) if (*q == '\t') *q = ' ';
+						fprintf(stderr, " %s;", line);
+					}
+				fprintf(stderr, "\n");
+				fclose(f);
+			}
+			if (atoi(getenv("MSX_TIMING")) >= 2) mem_report("exit");
+		}
 	}
 	if (getenv("MSX_CLEAN_EXIT")) return;
 	fflush(stdout);

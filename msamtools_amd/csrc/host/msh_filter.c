@@ -277,6 +277,7 @@ void *filter_dev_thread(void *arg) {
 		b = &s->b;
 		s->fatal = 0;
 		MSH_TRACE("device thread %d takes batch %zu (slot %d)", D->index, s->seq, si);
+		if (s->seq <= 2) mem_report(s->seq == 0 ? "device thread takes batch 0" : s->seq == 1 ? "device thread takes batch 1" : "device thread takes batch 2");
 		if (s->raw) {
 			/* the record walk on the device: inflated bytes up, filter's output records back */
 			msx_unpack_params up;
@@ -498,7 +499,9 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	F.n_dev = device_list(dev_ids);
 	/* pools: filter's own rule when best-hit selection needs them; with --profile-out and no best hit, profile's rule
 	 * over the records filter can write (filter's output does not depend on pools then) */
+	mem_report("header read");
 	pipe_init(&P, in, pools ? 1 : (po ? 3 : 0), want_stats, F.n_dev);
+	mem_report("pipeline initialised");
 	P.unmapped_visible = unmapped_written;
 	P.cut_mapped = pools && po;
 	/* From the second batch on the record walk runs on the device (msx_unpack): one context, records written as they
@@ -589,6 +592,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		pq_push(&P.q_free, si);
 	}
 	t_tail[0] = now_s();
+	mem_report("writer done");
 	pthread_join(th_dec, NULL);
 	for (k = 0; k < F.n_dev; k++) pthread_join(F.dev[k].th, NULL);
 	msh_out_close(F.out);
@@ -638,9 +642,16 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		        n_in, n_out, msh_threads(), F.n_dev, F.n_dev > 1 ? "s" : "");
 	}
 	fast_exit();
-	for (k = 0; k < F.n_dev; k++) {
-		if (F.dev[k].prof) msx_profile_destroy(F.dev[k].ctx, F.dev[k].prof);
-		msx_ctx_destroy(F.dev[k].ctx);
+	{   /* MSX_CLEAN_EXIT=1: an orderly shutdown (leak checks), timed piece by piece under MSX_TIMING */
+		double tq = now_s();
+		for (k = 0; k < F.n_dev; k++) {
+			if (F.dev[k].prof) msx_profile_destroy(F.dev[k].ctx, F.dev[k].prof);
+			if (getenv("MSX_TIMING")) { fprintf(stderr, "# clean exit: profile destroyed after %.3f s\n", now_s() - tq); tq = now_s(); }
+			msx_ctx_destroy(F.dev[k].ctx);
+			if (getenv("MSX_TIMING")) { fprintf(stderr, "# clean exit: context destroyed after %.3f s\n", now_s() - tq); tq = now_s(); }
+		}
+		msh_close(in);
+		if (getenv("MSX_TIMING")) fprintf(stderr, "# clean exit: input closed after %.3f s; main returns %.3f s after it began\n", now_s() - tq, now_s() - g_t_main);
 	}
 	return 0;
 }

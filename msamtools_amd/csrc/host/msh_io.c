@@ -1102,6 +1102,17 @@ static int span_need(msh_in *in, size_t n) {
 
 int msh_span_fill(msh_in *in) { return bgz_fill(&in->bz); }
 
+/* the input has been read to its end: whatever of the mapping is still in the page tables goes now, on the caller's thread --
+ * not when the process ends, where taking the mapping apart is part of the command's wall time */
+void msh_release_input(msh_in *in) {
+	bgz_in *b = &in->bz;
+#ifdef MADV_DONTNEED
+	if (b->map && b->map_len) (void)madvise((void *)b->map, b->map_len, MADV_DONTNEED);
+#endif
+	b->map_released = b->map_len;
+}
+
+
 const uint8_t *msh_span(msh_in *in, size_t *len) {
 	*len = in->bz.span_end - in->bz.span_beg;
 	return in->bz.span + in->bz.span_beg;

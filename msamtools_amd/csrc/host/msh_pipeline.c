@@ -987,6 +987,7 @@ void *pipe_decode_thread(void *arg) {
 			pthread_mutex_unlock(&P->first_mu);
 		}
 		if (n == 0) {
+			msh_release_input(P->in);
 			/* end of the stream: one token per consumer (P->n_filled is final from here on) */
 			int c;
 			for (c = 0; c < P->n_consumers; c++) pq_push(&P->q_dev, PQ_END);
