@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/<NAME>/ (scripts/gpu_profile.sh) -> profiles/round4/: the files the docs cite, in the shapes they have there.
-usage: collect_profiles.py [NAME]"""
+"""gpurun_out/<NAME>/ (scripts/gpu_profile.sh) -> profiles/round<R>/: the files the docs cite, in the shapes they have there.
+usage: collect_profiles.py [NAME] [ROUND]"""
 import json
 import os
 import shutil
@@ -8,7 +8,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r4final")
-dst = os.path.join(ROOT, "profiles", "round4")
+dst = os.path.join(ROOT, "profiles", "round" + (sys.argv[2] if len(sys.argv) > 2 else "5"))
+os.makedirs(dst, exist_ok=True)
+for seed in ("cov_c4_sq.json", "inflate_vec.json"):      # (the two files that are updated in place start from the round before's)
+    if not os.path.exists(os.path.join(dst, seed)):
+        shutil.copy(os.path.join(ROOT, "profiles", "round4", seed), os.path.join(dst, seed))
 for a, b in (("c3_kernel_stats.csv", "c3_kernel_stats.csv"), ("pmc_traffic_c3.json", "pmc_traffic_c3.json"),
              ("cov_kernel_stats.csv", "cov_c4_kernel_stats.csv"), ("cov_c4_pmc.json", "cov_c4_pmc.json"),
              ("deflate_kernel_stats.csv", "deflate_kernel_stats.csv"), ("deflate_sq.json", "deflate_sq_counters.json")):
