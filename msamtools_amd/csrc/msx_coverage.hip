@@ -968,11 +968,12 @@ extern "C" int msx_coverage_collect(msx_ctx *ctx, const msx_batch *b, const int6
 			if ((rc = msx_reserve(ctx, &ctx->cv_side, (size_t)CV2_HEAVY_CAP * CV_TILE * 4))) return rc;
 			cv2_state *st = (cv2_state *)ctx->cv_side.p;            // (the emit kernel's state: the side images are the finish's)
 			msx_time_begin(ctx, MSX_K_COVERAGE);
+			// (the targets' table is written again for every batch -- n_targets words, microseconds -- rather than trusted to have
+			//  survived whatever else the context was asked for in between: msx_coverage_depths uses the same buffer)
 			if ((rc = cov_pieces_emit(ctx, b, cov_off, n_targets, covered, (uint32_t *)ctx->cvc_items.p + at, (uint8_t *)ctx->cvc_sups.p + at, st,
-			                          nullptr, 0, C.targets_ready)))
+			                          nullptr, 0, false)))
 				return rc;
 			msx_time_end(ctx);
-			C.targets_ready = true;
 			// the one thing the host must know before the batch's arrays may be given back: did its pieces fit (a page-locked word)
 			if (!ctx->cvc_flag) MSX_HIP(ctx, hipHostMalloc((void **)&ctx->cvc_flag, 64, hipHostMallocDefault));
 			MSX_HIP(ctx, hipMemcpyAsync(ctx->cvc_flag, &st->overflow, 4, hipMemcpyDeviceToHost, ctx->stream));

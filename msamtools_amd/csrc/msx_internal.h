@@ -66,7 +66,6 @@ struct msx_cov_collect {
 	bool active = false;
 	bool pieces = false;            // the sample takes the one-word-per-piece form (else every batch is piled up the streamed way)
 	bool cov_zeroed = false;        // cov[] holds marks of streamed batches (zeroed when the first of them came)
-	bool targets_ready = false;
 	int64_t n_items = 0;            // items kept so far (own slots and overflow lists of every batch, empty slots included)
 	int64_t n_batches = 0, n_streamed = 0;
 	int64_t total_len = 0;
