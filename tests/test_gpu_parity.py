@@ -786,3 +786,31 @@ def test_collected_coverage_with_batches_that_go_the_streamed_way(ctx):
             assert n_streamed < 3
         for t in range(n_refs):
             assert (got[t] == want[t]).all(), (env, t, np.flatnonzero(got[t] != want[t])[:5])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_collected_coverage_random_cuts(ctx, seed):
+    """The same records under random partitions into batches (1 to 40 batches, empty ones among them, random CIGARs with runs
+    behind D / N operations): msx_coverage_collect + _finish give the depths of the one call, whatever the cuts and whichever
+    batches went the streamed way."""
+    import msamtools_amd as m
+    rng = np.random.default_rng(1000 + seed)
+    n_refs, tl = 500, 5000
+    hs = m.HostSynth(60 + seed, 24000, n_refs, 4)
+    if seed % 2 == 0:
+        hs = _cov_fuzz_records(hs, seed, n_refs, tl)
+    tlen = [tl] * n_refs
+    whole = m.DeviceBatch.upload(ctx, m.RecordSlice(hs, 0, hs.n_records))
+    want = m.coverage(ctx, whole, tlen, whole_sample=True)
+    whole.free()
+    for trial in range(3):
+        k = int(rng.integers(1, 41))
+        edges = np.sort(np.concatenate([[0, hs.n_records], rng.integers(0, hs.n_records + 1, k - 1)])).tolist()
+        parts = [m.DeviceBatch.upload(ctx, m.RecordSlice(hs, lo, hi)) for lo, hi in zip(edges[:-1], edges[1:])]
+        try:
+            got, n_streamed = m.coverage_collected(ctx, parts, tlen)
+        finally:
+            for p in parts:
+                p.free()
+        for t in range(n_refs):
+            assert (got[t] == want[t]).all(), (seed, trial, k, n_streamed, t)
