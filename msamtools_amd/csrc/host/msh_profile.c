@@ -3,6 +3,7 @@
  * pipeline, post-processing and the text report (mMatrix.c:359-376), shared with `filter --profile-out`.
  */
 #include "msh_cli.h"
+#include "msh_fmt.h"
 
 /* ------------------------------------------------------------------------ */
 /* profile                                                                    */
@@ -123,7 +124,18 @@ static void report_worker(void *arg, int tid, int nth) {
 	const int32_t lo = (int32_t)((int64_t)J->n * tid / nth), hi = (int32_t)((int64_t)J->n * (tid + 1) / nth);
 	kstr *k = &J->text[tid];
 	int32_t i;
-	for (i = lo; i < hi; i++) ks_printf(k, "%s\t%.8g\n", J->F->name[i], J->row[1 + i]);
+	/* "%s\t%.8g\n" per feature (mMatrix.c:359-376), the number by msh_fmt_g8: printf's bytes at a third of its time */
+	for (i = lo; i < hi; i++) {
+		const char *nm = J->F->name[i];
+		const size_t nl = strlen(nm);
+		ks_reserve(k, nl + 40);
+		memcpy(k->s + k->l, nm, nl);
+		k->l += nl;
+		k->s[k->l++] = '\t';
+		k->l += (size_t)msh_fmt_g8(J->row[1 + i], k->s + k->l);
+		k->s[k->l++] = '\n';
+		k->s[k->l] = 0;
+	}
 	gz_member(k, &J->gz[tid]);
 }
 
@@ -231,6 +243,7 @@ void profile_report(const prof_opts *o, const prof_feat *F, const msx_profile_st
 		if (nth > MSH_POOL_MAX) nth = MSH_POOL_MAX;
 		if (n_features < 4096 || getenv("MSX_GZ_SINGLE")) nth = 1;
 		memset(&J, 0, sizeof J);
+		msh_fmt_init();
 		J.F = F; J.row = row; J.n = n_features;
 		if (nth == 1) {
 			/* one member, head and features together */
