@@ -1155,3 +1155,10 @@ extern "C" int msx_coverage_summary(msx_ctx *ctx, const int32_t *cov, const int6
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MSX_OK;
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_coverage(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_coverage_pileup));
+}

@@ -56,6 +56,11 @@ extern "C" int msx_runtime_warmup(int device_id) {
 	if (device_id < 0 || device_id >= ndev) return msx_fail(nullptr, MSX_ERR_ARG, "device %d out of range (0..%d)", device_id, ndev - 1);
 	if (hipSetDevice(device_id) != hipSuccess || hipFree(nullptr) != hipSuccess)      // (hipFree(0): the primary context, now)
 		return msx_fail(nullptr, MSX_ERR_HIP, "runtime start-up failed: %s", hipGetErrorString(hipGetLastError()));
+	if (!getenv("MSX_NO_MODULE_WARMUP")) {
+		msx_touch_unpack(); msx_touch_inflate(); msx_touch_stats(); msx_touch_filter(); msx_touch_scan(); msx_touch_profile();
+		msx_touch_deflate(); msx_touch_prop(); msx_touch_coverage();
+		(void)hipGetLastError();
+	}
 	return MSX_OK;
 }
 

@@ -898,3 +898,10 @@ extern "C" int msx_bgzf_deflate(msx_ctx *ctx, const void *d_in, size_t n_bytes, 
 	if (n_blocks) *n_blocks = nblk;
 	return MSX_OK;
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_deflate(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_store));
+}

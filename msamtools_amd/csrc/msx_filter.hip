@@ -628,3 +628,10 @@ extern "C" int msx_aln_stats(msx_ctx *ctx, const msx_batch *b, int32_t *length, 
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MSX_OK;
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_filter(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_besthit_select<true>));
+}

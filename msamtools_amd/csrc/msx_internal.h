@@ -265,4 +265,15 @@ int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count);
 int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add);
 #define MSX_COUNT_KEYS_MAX_FEATURES (256 * 8192)
 
+// (msx_runtime_warmup) every translation unit's code object loaded ahead of its first launch
+void msx_touch_scan(void);
+void msx_touch_filter(void);
+void msx_touch_stats(void);
+void msx_touch_profile(void);
+void msx_touch_prop(void);
+void msx_touch_coverage(void);
+void msx_touch_unpack(void);
+void msx_touch_inflate(void);
+void msx_touch_deflate(void);
+
 #endif

@@ -519,3 +519,10 @@ extern "C" int msx_profile_shared_size(msx_ctx *ctx, msx_profile *p, int64_t *n_
 	if (n_entries) *n_entries = (int64_t)t[1];
 	return MSX_OK;
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_profile(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_insert_count));
+}

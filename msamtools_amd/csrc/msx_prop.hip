@@ -1958,3 +1958,10 @@ extern "C" int msx_profile_finalize(msx_ctx *ctx, msx_profile *p, double *abunda
 	if (rc) return rc;
 	return msx_profile_fetch(ctx, p, abundance_host, stats);
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_prop(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_rs_rowscan));
+}

@@ -321,3 +321,10 @@ void msx_launch_aln_stats_flat(msx_ctx *ctx, const FilterArgs &A, int grid) {
 	else
 		hipLaunchKernelGGL(k_aln_stats_flat<false>, dim3(grid), dim3(MSX_BLOCK), 0, ctx->stream, A);
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_stats(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_aln_stats_flat<false>));
+}

@@ -1171,3 +1171,10 @@ extern "C" int msx_unpack_offsets(msx_ctx *ctx, msx_unpack *u, uint32_t *host, i
 	}
 	return MSX_OK;
 }
+
+// msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
+// module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
+void msx_touch_unpack(void) {
+	hipFuncAttributes attr;
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_chase_walk));
+}
