@@ -897,14 +897,18 @@ static int cov_depths_pieces(msx_ctx *ctx, const msx_batch *b, const int64_t *co
 	msx_time_begin(ctx, MSX_K_COVERAGE);
 	if ((rc = cov_pieces_emit(ctx, b, cov_off, n_targets, covered, items, sups, st, (uint32_t *)ctx->cv_hist.p, sort_tiles, false))) return rc;
 	const int64_t counted = n_wg;                              // (every workgroup left the digit counts of its whole tile)
-	// (queued behind the emit kernel; its flag is read with the finish's: a batch whose lists ran full is piled up again the streamed way)
-	cv2_state h;
-	MSX_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+	// Did the pieces fit?  A batch whose lists ran full is piled up again the other ways -- and must not go on here: what the
+	// workgroups that found no room left unwritten is whatever the buffers held before (the passes take any keys, but nothing
+	// behind them is meant to read a stale word as an item).  The copy waits for the emit kernel; the finish is enqueued after it.
+	if (!ctx->cvc_flag) MSX_HIP(ctx, hipHostMalloc((void **)&ctx->cvc_flag, 64, hipHostMallocDefault));
+	MSX_HIP(ctx, hipMemcpyAsync(ctx->cvc_flag, &st->overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (*ctx->cvc_flag) { msx_time_end(ctx); return MSX_OK; }
 	int heavy = 0;
 	rc = cov_pieces_finish(ctx, items, sups, items1, n_items, counted, total_len, cov, 0, &heavy);
 	msx_time_end(ctx);
 	if (rc) return rc;
-	*done = !h.overflow && !heavy;
+	*done = !heavy;
 	return MSX_OK;
 }
 
@@ -1073,6 +1077,14 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		hipLaunchKernelGGL(k_cov_emit2, dim3((unsigned)n_wg), dim3(MSX_BLOCK), 0, ctx->stream, n, b->tid, b->pos, b->cigar_off, b->cigar,
 		                   cov_off, covered, items, sign_shift, own, list_cap, st, (uint32_t *)ctx->cv_hist.p, sort_tiles, CV_TILE_SHIFT);
 		hipLaunchKernelGGL(k_cov_fill_lists, dim3(16, CV2_LISTS), dim3(MSX_BLOCK), 0, ctx->stream, items, own, list_cap, st);
+		// (as in the pieces form: lists that ran full leave stale words behind -- keys the sort does not order on their upper bits,
+		//  so that k_cov_starts2's searches return anything; found by a test that came after large batches had used the buffers)
+		if (!ctx->cvc_flag) MSX_HIP(ctx, hipHostMalloc((void **)&ctx->cvc_flag, 64, hipHostMallocDefault));
+		MSX_HIP(ctx, hipMemcpyAsync(ctx->cvc_flag, &st->overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		fused = *ctx->cvc_flag == 0u;
+		if (!fused) msx_time_end(ctx);
+		if (fused) {
 		int sel = 0;
 		// (the last workgroup's histogram counted only the records it has: the tail's empty slots are added by ... nothing --
 		//  so that tile is counted by the sort itself)
@@ -1100,6 +1112,7 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		MSX_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		if (!h.overflow) return MSX_OK;
+		}
 	}
 	// the streamed path on one batch
 	MSX_HIP(ctx, hipMemsetAsync(cov, 0, (size_t)(total_len + 1) * 4, ctx->stream));
