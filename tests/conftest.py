@@ -17,6 +17,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """MSX_TEST_ORDER=reverse | <seed>: the collected tests in reverse, or shuffled by the seed -- the contexts and their
+    workspace are shared by the tests of a file, so an order nobody wrote down finds what depends on it (round 5: a path
+    that read what an earlier, larger batch had left in a buffer)."""
+    order = os.environ.get("MSX_TEST_ORDER")
+    if not order:
+        return
+    if order == "reverse":
+        items.reverse()
+    else:
+        import random
+        random.Random(int(order)).shuffle(items)
+
+
 def pytest_collection_finish(session):
     """Test files must not load the library while they are being collected: tests/test_gpu_two_ranks.py asks torch for
     the device count during collection, and a process that loads /opt/rocm's runtime first (through the library) and
