@@ -157,7 +157,9 @@ typedef struct msx_profile_stats {
 /* The HIP runtime's own start-up (driver open, device enumeration, the device's primary context: 60-90 ms) without a
  * msx_ctx: a caller that has host-side work to do before it needs the device -- the command line parses a header of a
  * million @SQ lines first (msam_helper.c:153-164 reads it before anything else) -- starts this on a helper thread at
- * once; the msx_ctx_create that follows finds the runtime up.  Returns MSX_OK or what msx_ctx_create would fail with. */
+ * once; the msx_ctx_create that follows finds the runtime up.  Since round 5 it also has the library's code objects loaded
+ * onto the device (the runtime loads a module when one of its kernels is first asked for: a few milliseconds each, otherwise paid
+ * by a command's first batches; MSX_NO_MODULE_WARMUP=1: as before).  Returns MSX_OK or what msx_ctx_create would fail with. */
 int  msx_runtime_warmup(int device_id);
 
 /* Binds one GPU (one ctx per GPU / per rank).  Fails with MSX_ERR_NO_DEVICE if
