@@ -794,9 +794,8 @@ int msam_filter_main(int argc, char *argv[]) {
 	bulk = msh_is_bam(rd.in);
 	if (!getenv("MSX_SERIAL_IO")) {
 		/* BAM or SAM text in: decode | device | encode as three overlapping stages */
-		int rc = filter_pipelined(rd.in, &fp, pools, want_stats, mode, argc, argv, tee ? &po : NULL);
-		msh_close(rd.in);
-		return rc;
+		/* (under MSX_CLEAN_EXIT it closes the input itself, timed; otherwise the process has ended in there) */
+		return filter_pipelined(rd.in, &fp, pools, want_stats, mode, argc, argv, tee ? &po : NULL);
 	}
 	if (tee) mDie("--profile-out is not available with MSX_SERIAL_IO");
 	/* MSX_SERIAL_IO (tests: the record-at-a-time reader as a second opinion): one batch at a time */

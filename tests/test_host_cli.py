@@ -212,6 +212,23 @@ def test_cli_filter_bam_in_bam_out(tmp_path):
     assert run(["recode", str(tmp_path / "u.bam")]).stdout.decode().split("\n")[:-1] == got
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cmd", ["filter", "filter_tee", "profile", "coverage", "summary"])
+def test_cli_orderly_shutdown(tmp_path, synth_bams, cmd):
+    """MSX_CLEAN_EXIT=1 (the leak-check / profiler mode: handles destroyed, input closed, main returns instead of _exit)
+    ends with status 0 and the same output as the default quick exit, for every command."""
+    args = {"filter": ["filter", "-bu", "-l", "80", "-p", "95", "-z", "80", "--besthit", synth_bams["b"]],
+            "filter_tee": ["filter", "-bu", "-l", "80", "-p", "95", "-z", "80", "--besthit", "--profile-out", str(tmp_path / "p.gz"),
+                           "--label", "S", synth_bams["b"]],
+            "profile": ["profile", "--label", "S", "--multi", "prop", "-o", str(tmp_path / "o.gz"), synth_bams["b"]],
+            "coverage": ["coverage", "--summary", "-o", str(tmp_path / "c.gz"), synth_bams["b"]],
+            "summary": ["summary", synth_bams["b"]]}[cmd]
+    a = run(args)
+    b = run(args, env={"MSX_CLEAN_EXIT": "1", "MSX_TIMING": "1"})
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr.decode()[-400:], b.stderr.decode()[-800:])
+    assert a.stdout == b.stdout
+
+
 def read_profile(path):
     text = gzip.open(path, "rt").read()
     head = [l for l in text.split("\n") if l.startswith("#")]
