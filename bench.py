@@ -320,6 +320,8 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0,
     import shutil
     import subprocess
     import tempfile
+
+    import numpy as np
     exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
     dev = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
     if not os.path.exists(exe) or not os.path.exists(dev):
@@ -495,19 +497,31 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0,
                 par["filter_ok"] = bool(n_out == expect["n_emit"] and dg == par["filter_digest_oracle"])
             else:
                 par["filter_ok"] = bool(n_out == expect["n_emit"])
+            full_want = None
+            if "emit" in expect:
+                # every byte of every record: the output's whole-record digest against the input's records at the oracle's emit
+                # list, in its order (msamtools-dev digest --full [--select]; tests/test_digest_cpu.py)
+                np.asarray(expect["emit"]).astype("<u4").tofile(f"{tmp}/emit.u32")
+                full_want = subprocess.check_output([dev, "digest", "--full", "--select", f"{tmp}/emit.u32", f"{tmp}/in.bam"]).decode().strip()
+                full = lambda path: subprocess.check_output([dev, "digest", "--full", path]).decode().strip()
+                par["filter_bytes_equal_selected_input"] = bool(full(f"{tmp}/f.bam") == full_want)
+                par["filter_ok"] = bool(par["filter_ok"] and par["filter_bytes_equal_selected_input"])
             if "pipe" in expect:
                 par["pipe_profile"] = profile_parity(f"{tmp}/p.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
             if "plain" in expect:
                 par["plain_profile"] = profile_parity(f"{tmp}/p1.gz", expect["plain"]["stats"], expect["plain"]["abundance"], refs, ref_len)
             if tee and "error" not in tee:
                 nt, dgt = digest(f"{tmp}/ft.bam")
-                par["tee_filter_ok"] = bool((nt, dgt) == (n_out, dg))
+                par["tee_filter_ok"] = bool((nt, dgt) == (n_out, dg) and (full_want is None or full(f"{tmp}/ft.bam") == full_want))
                 if "pipe" in expect:
                     par["tee_profile"] = profile_parity(f"{tmp}/pt.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
             co = res.get("compressed_out")
             if isinstance(co, dict) and "_digest" in co:
                 nb_, dgb = co.pop("_digest")
-                par["compressed_filter_ok"] = bool((nb_, dgb) == (n_out, dg) and co["records_and_order_equal_to_zlib_output"])
+                par["compressed_filter_ok"] = bool((nb_, dgb) == (n_out, dg) and co["records_and_order_equal_to_zlib_output"]
+                                                   and (full_want is None or full(f"{tmp}/fb.bam") == full_want))
+                if full_want is not None:
+                    co["bytes_equal_selected_input"] = bool(full(f"{tmp}/fb.bam") == full_want)
                 if "pipe" in expect:
                     par["compressed_tee_profile"] = profile_parity(f"{tmp}/pb.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
                     par["profile_of_compressed_output"] = profile_parity(f"{tmp}/pbb.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, ref_len)
@@ -951,12 +965,13 @@ def main():
             em = f["emit"]
             h, cnt = dg.stream_digest(hs.flag[em], hs.tid[em], hs.pos[em], dg.fnv_sim_names(gidx[em]))
             del gidx
-            e2e_expect = {"n_emit": cnt, "emit_digest": h,
+            e2e_expect = {"n_emit": cnt, "emit_digest": h, "emit": em,
                           "pipe": {"stats": p["stats"], "abundance": p["abundance"]},
                           "plain": orc.run_profile(hs, nrefs, multi="proportional")}
             if args.e2e_seq_groups and args.e2e_seq_groups < ng:
                 goff_s = int(hs.group_off[args.e2e_seq_groups])
                 e2e_seq_expect = {"n_emit": int(np.searchsorted(em, goff_s))}
+                e2e_seq_expect["emit"] = em[:e2e_seq_expect["n_emit"]]       # (pools are independent: the prefix's emit list is the list's prefix)
         out["cpu_baseline"] = {
             "value": round(hs.n_records / best / 1e6, 3), "unit": "M alignments/s", "cores": 1, "kind": "port",
             "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_granted": granted_cpus(),

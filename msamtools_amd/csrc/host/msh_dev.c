@@ -250,26 +250,90 @@ static uint64_t dg_record(const uint8_t *r) {
 	while (*q) { h ^= (uint8_t)*q++; h *= 1099511628211ull; }
 	return dg_mix(v) ^ h;
 }
-typedef struct { const rbatch *b; uint64_t first, part[MSH_POOL_MAX]; } digest_job;
+/* --full: every byte of the record (block_size bytes: fixed fields, QNAME, CIGAR, SEQ, QUAL, aux) -- what byte-for-byte
+ * equality of filter's output with the input records it selects means at a size no text comparison goes to */
+static uint64_t dg_record_full(const uint8_t *r, size_t len) {
+	uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)len;
+	size_t i = 0;
+	for (; i + 8 <= len; i += 8) {
+		uint64_t w;
+		memcpy(&w, r + i, 8);
+		h = (h ^ w) * 0xff51afd7ed558ccdull;
+		h = (h << 29) | (h >> 35);
+	}
+	if (i < len) {
+		uint64_t w = 0;
+		memcpy(&w, r + i, len - i);
+		h = (h ^ w) * 0xff51afd7ed558ccdull;
+	}
+	return dg_mix(h);
+}
+typedef struct {
+	const rbatch *b;
+	uint64_t first, part[MSH_POOL_MAX], cnt[MSH_POOL_MAX];
+	int full;
+	const uint32_t *rank;      /* --select: rank[i] = 1 + the place of input record i in the selection, 0 = not selected */
+	size_t n_rank;
+} digest_job;
 static void digest_worker(void *arg, int tid, int nth) {
 	digest_job *J = (digest_job *)arg;
 	const rbatch *b = J->b;
 	const size_t lo = b->n * (size_t)tid / (size_t)nth, hi = b->n * (size_t)(tid + 1) / (size_t)nth;
-	uint64_t s = 0;
+	uint64_t s = 0, c = 0;
 	size_t i;
 	for (i = lo; i < hi; i++) {
 		const uint8_t *r = RB_REC(b, i);
+		uint64_t place = J->first + (uint64_t)i + 1;
 		msh_rec_check(r, RB_LEN(b, i));
-		s += (J->first + (uint64_t)i + 1) * dg_record(r);
+		if (J->rank) {
+			const uint64_t g = J->first + (uint64_t)i;
+			if (g >= J->n_rank || J->rank[g] == 0) continue;
+			place = J->rank[g];
+		}
+		c++;
+		s += place * (J->full ? dg_record_full(r, RB_LEN(b, i)) : dg_record(r));
 	}
 	J->part[tid] = s;
+	J->cnt[tid] = c;
 }
 
+/* digest [--full] [--select idx.u32] <file>: --select reads little-endian uint32 record indices (the oracle's emit list, in
+ * emit order) and digests the selected records as if they had been written in that order -- the figure filter's output file
+ * must give */
 int digest_main(int argc, char *argv[]) {
 	msh_in *in;
-	uint64_t n = 0, h = 0;
-	if (argc < 2) mQuit("usage: %s digest <file>", PROGRAM);
-	in = msh_open(argv[1]);
+	uint64_t n = 0, h = 0, n_sel = 0;
+	int full = 0, a = 1;
+	const char *select = NULL;
+	uint32_t *rank = NULL;
+	size_t n_rank = 0;
+	for (; a < argc - 1; a++) {
+		if (strcmp(argv[a], "--full") == 0) full = 1;
+		else if (strcmp(argv[a], "--select") == 0 && a + 1 < argc - 1) select = argv[++a];
+		else break;
+	}
+	if (a != argc - 1) mQuit("usage: %s digest [--full] [--select idx.u32] <file>", PROGRAM);
+	if (select) {
+		FILE *f = fopen(select, "rb");
+		uint32_t *idx;
+		size_t k, m;
+		long sz;
+		if (!f) mDie("Cannot open %s for reading", select);
+		fseek(f, 0, SEEK_END); sz = ftell(f); fseek(f, 0, SEEK_SET);
+		m = (size_t)sz / 4;
+		idx = (uint32_t *)xmalloc((m + 1) * 4);
+		if (fread(idx, 4, m, f) != m) mDie("Cannot read %s", select);
+		fclose(f);
+		for (k = 0; k < m; k++) if ((size_t)idx[k] + 1 > n_rank) n_rank = (size_t)idx[k] + 1;
+		rank = (uint32_t *)calloc(n_rank + 1, 4);
+		if (!rank) mDie("out of memory");
+		for (k = 0; k < m; k++) {
+			if (rank[idx[k]]) mDie("%s: record %u selected twice", select, idx[k]);
+			rank[idx[k]] = (uint32_t)(k + 1);
+		}
+		free(idx);
+	}
+	in = msh_open(argv[a]);
 	if (msh_is_bam(in)) {
 		static pipe_t P;
 		pthread_t th;
@@ -283,18 +347,27 @@ int digest_main(int argc, char *argv[]) {
 			if (si == PQ_END) break;
 			s = &P.slot[si];
 			if (nth > MSH_POOL_MAX) nth = MSH_POOL_MAX;
-			J.b = &s->b; J.first = n;
+			J.b = &s->b; J.first = n; J.full = full; J.rank = rank; J.n_rank = n_rank;
 			msh_parallel(nth, digest_worker, &J);
-			for (t = 0; t < nth; t++) h += J.part[t];
+			for (t = 0; t < nth; t++) { h += J.part[t]; n_sel += J.cnt[t]; }
 			n += s->b.n;
 			pq_push(&P.q_free, si);
 		}
 		pthread_join(th, NULL);
 	} else {
 		kstr rec = {0, 0, 0};
-		while (msh_read(in, &rec) == 0) { n++; h += n * dg_record((const uint8_t *)rec.s); }
+		while (msh_read(in, &rec) == 0) {
+			uint64_t place = ++n;
+			if (rank) {
+				if (n - 1 >= n_rank || rank[n - 1] == 0) continue;
+				place = rank[n - 1];
+			}
+			n_sel++;
+			h += place * (full ? dg_record_full((const uint8_t *)rec.s, rec.l) : dg_record((const uint8_t *)rec.s));
+		}
 	}
-	printf("records=%llu digest=%016llx\n", (unsigned long long)n, (unsigned long long)h);
+	printf("records=%llu digest=%016llx\n", (unsigned long long)(rank ? n_sel : n), (unsigned long long)h);
+	free(rank);
 	msh_close(in);
 	return 0;
 }

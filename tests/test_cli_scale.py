@@ -61,14 +61,27 @@ class Case:
         self.emit = f["emit"]
         self.digest_in = digest.synth_digest(self.hs)
         self.digest_out = digest.synth_digest(self.hs, self.emit)
+        self.full_out = {}
         self.flen = np.full(refs, REF_LEN, dtype=np.uint32)
         self.pipe = orc.run_profile(self.hs, refs, multi="proportional", sel=self.emit)
         self.plain = orc.run_profile(self.hs, refs, multi="proportional")
 
-    def check_digest(self, path, want):
-        out = subprocess.check_output([DEV, "digest", path], env=dict(os.environ, MSX_THREADS="8")).decode().strip()
+    def check_digest(self, path, want, src=None):
+        env = dict(os.environ, MSX_THREADS="8")
+        out = subprocess.check_output([DEV, "digest", path], env=env).decode().strip()
         h, n = want
         assert out == f"records={n} digest={h:016x}", (path, out, n, f"{h:016x}")
+        if want is self.digest_out:
+            # filter's output holds the selected input records byte for byte (msam_filter.c:232-244 writes the pooled
+            # bam1_t as read): the digest over EVERY byte of every record, against the input's records at the oracle's
+            # emit list (msamtools-dev digest --full --select; tests/test_digest_cpu.py)
+            src = src or self.bam["u"]
+            if src not in self.full_out:
+                idx = os.path.join(self.dir, "emit.u32")
+                np.asarray(self.emit).astype("<u4").tofile(idx)
+                self.full_out[src] = subprocess.check_output([DEV, "digest", "--full", "--select", idx, src], env=env).decode().strip()
+                assert self.full_out[src].startswith(f"records={n} ")
+            assert subprocess.check_output([DEV, "digest", "--full", path], env=env).decode().strip() == self.full_out[src], path
 
     def check_profile(self, path, ref, batches_stderr=None):
         text = gzip.open(path, "rt").read()
@@ -377,7 +390,7 @@ def test_sam_text_input_takes_the_pipeline(mid, tmp_path):
     os.environ["MSX_SAM_CHUNK"] = "1000000"
     r = sh(f"{BIN} {' '.join(FILT)} -S -bu --profile-out {p} --label S {sam} > {f}", MSX_TIMING=1, MSX_BATCH_BYTES=4_000_000)
     assert n_batches(r.stderr) >= 5
-    mid.check_digest(f, mid.digest_out)
+    mid.check_digest(f, mid.digest_out, src=sam)        # (records as the line-at-a-time reader parses them: integer aux types by value)
     mid.check_profile(p, mid.pipe)
     r = sh(f"cat {sam} | {BIN} profile -S --label S -o {p} -", MSX_TIMING=1, MSX_BATCH_BYTES=4_000_000)
     assert n_batches(r.stderr) >= 5

@@ -1,0 +1,72 @@
+"""`msamtools-dev digest --full [--select idx.u32]` (msh_dev.c): the whole-record digest the scale tests and bench.py hold
+filter's output to -- every byte of every selected record, in the selection's order -- against a file assembled in
+Python from the same records (no GPU)."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_cli_scale import bgzf_blocks
+
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(DEV):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "msamtools_amd", "csrc", "host")])
+
+
+def digest(*args):
+    out = subprocess.check_output([DEV, "digest", *args], env=dict(os.environ, MSX_THREADS="4", MSX_BATCH_RECORDS="9000")).decode().split()
+    return int(out[0].split("=")[1]), out[1].split("=")[1]
+
+
+def records_of(raw):
+    p = 8 + struct.unpack_from("<i", raw, 4)[0]
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 8 + struct.unpack_from("<i", raw, p)[0]
+    head, recs = raw[:p], []
+    while p < len(raw):
+        l = 4 + struct.unpack_from("<i", raw, p)[0]
+        recs.append(raw[p:p + l])
+        p += l
+    return head, recs
+
+
+@pytest.mark.parametrize("seq", [False, True])
+def test_selected_full_digest_equals_the_digest_of_the_selection_written_out(tmp_path, seq):
+    src = str(tmp_path / "in.bam")
+    with open(src, "wb") as fh:
+        subprocess.check_call([DEV, "synth", "--groups", "8000", "--refs", "300", "-b"] + (["--seq"] if seq else []), stdout=fh)
+    head, recs = records_of(gzip.open(src, "rb").read())
+    rng = np.random.default_rng(5)
+    keep = np.flatnonzero(rng.random(len(recs)) < 0.4)
+    # filter's order is not the input's inside a pool (READ1 winners before READ2 winners): swap some neighbours
+    sel = keep.copy()
+    for k in range(0, len(sel) - 1, 7):
+        sel[k], sel[k + 1] = sel[k + 1], sel[k]
+    idx = str(tmp_path / "sel.u32")
+    sel.astype("<u4").tofile(idx)
+    out = str(tmp_path / "out.bam")
+    open(out, "wb").write(bgzf_blocks(head + b"".join(recs[i] for i in sel)))
+    for mode in (["--full"], []):
+        want = digest(*mode, out)
+        assert want[0] == len(sel)
+        assert digest(*mode, "--select", idx, src) == want
+        sel2 = sel.copy()
+        sel2[3], sel2[10] = sel2[10], sel2[3]              # another order: another digest
+        sel2.astype("<u4").tofile(idx + "2")
+        assert digest(*mode, "--select", idx + "2", src) != want
+    # one byte of one record's tail (aux / QUAL) changed: the plain digest does not see it, the full one does
+    bad = bytearray(head + b"".join(recs[i] for i in sel))
+    bad[len(bad) - 1] ^= 1              # (the last aux value byte)
+    open(out, "wb").write(bgzf_blocks(bytes(bad)))
+    assert digest(out) == digest("--select", idx, src)
+    assert digest("--full", out) != digest("--full", "--select", idx, src)
