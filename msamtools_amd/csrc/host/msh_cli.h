@@ -224,6 +224,7 @@ void ctx_open_dev(int id);
 void ctx_open(void);
 int device_list(int *ids);
 void runtime_warmup_start(void);    /* the HIP runtime's start-up on a thread of its own, beside the opening of the input */
+void runtime_warmup_join(void);     /* before main() returns (not needed before _exit): see msh_common.c */
 size_t batch_target(void);
 char *command_line(int argc, char *argv[]);
 void rb_reserve(rbatch *b);

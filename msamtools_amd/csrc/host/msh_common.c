@@ -72,7 +72,7 @@ void fast_exit(void) {
 			if (atoi(getenv("MSX_TIMING")) >= 2) mem_report("exit");
 		}
 	}
-	if (getenv("MSX_CLEAN_EXIT")) return;
+	if (getenv("MSX_CLEAN_EXIT")) { runtime_warmup_join(); return; }
 	fflush(stdout);
 	fflush(stderr);
 	_exit(0);
@@ -92,23 +92,28 @@ int g_dist;
 
 /* The HIP runtime starts up (60-90 ms) on a thread of its own from the moment the options are known to be good, beside
  * the opening of the input and the parsing of its header (a million @SQ lines: 70 ms) -- the device threads' msx_ctx_create
- * then finds it up.  Nothing waits for this thread: a failure is reported by the msx_ctx_create that follows, and every way
- * out of the command from here on is _exit (mDie, fast_exit), which does not run the runtime's exit handlers under it.
+ * then finds it up.  Nothing on the way THROUGH the command waits for this thread: a failure is reported by the
+ * msx_ctx_create that follows, and the usual way out is _exit (mDie, fast_exit), which does not run the runtime's exit
+ * handlers under it.  Where main() RETURNS instead (MSX_CLEAN_EXIT=1; `coverage`), the thread is joined first
+ * (runtime_warmup_join): the runtime's exit handlers unload the code objects, and a warm-up still asking for a kernel's
+ * attributes at that moment aborts the process ("Cannot find Symbol ...": seen on a small `profile` under MSX_CLEAN_EXIT).
  * MSX_NO_WARMUP=1: as before. */
+static pthread_t g_warm_th;
+static int g_warm_started;
 static void *warmup_thread(void *arg) {
 	(void)msx_runtime_warmup((int)(intptr_t)arg);
 	return NULL;
 }
 void runtime_warmup_start(void) {
 	int ids[MSH_MAX_DEVICES];
-	pthread_t th;
-	pthread_attr_t at;
-	if (getenv("MSX_NO_WARMUP")) return;
+	if (getenv("MSX_NO_WARMUP") || g_warm_started) return;
 	(void)device_list(ids);
-	pthread_attr_init(&at);
-	pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
-	(void)pthread_create(&th, &at, warmup_thread, (void *)(intptr_t)ids[0]);
-	pthread_attr_destroy(&at);
+	if (pthread_create(&g_warm_th, NULL, warmup_thread, (void *)(intptr_t)ids[0]) == 0) g_warm_started = 1;
+}
+void runtime_warmup_join(void) {
+	if (!g_warm_started) return;
+	g_warm_started = 0;
+	pthread_join(g_warm_th, NULL);
 }
 
 void ctx_open_dev(int id) {

@@ -33,11 +33,18 @@ int main(int argc, char *argv[]) {
 	msh_main_thread = pthread_self();
 	msh_main_thread_set = 1;
 	if (argc < 2) return usage(stderr);
-	if (strcmp(argv[1], "filter") == 0) return msam_filter_main(argc - 1, argv + 1);
-	else if (strcmp(argv[1], "profile") == 0) return msam_profile_main(argc - 1, argv + 1);
-	else if (strcmp(argv[1], "coverage") == 0) return msam_coverage_main(argc - 1, argv + 1);
-	else if (strcmp(argv[1], "summary") == 0) return msam_summary_main(argc - 1, argv + 1);
-	else if (strcmp(argv[1], "help") == 0) { usage(stdout); return 0; }
+	{
+		int (*cmd)(int, char **) = strcmp(argv[1], "filter") == 0 ? msam_filter_main : strcmp(argv[1], "profile") == 0 ? msam_profile_main :
+		                           strcmp(argv[1], "coverage") == 0 ? msam_coverage_main : strcmp(argv[1], "summary") == 0 ? msam_summary_main : NULL;
+		if (cmd) {
+			/* (a command that comes back here instead of leaving through _exit has the runtime's exit handlers ahead of it:
+			 *  the warm-up thread must not be inside the runtime then -- msh_common.c) */
+			const int rc = cmd(argc - 1, argv + 1);
+			runtime_warmup_join();
+			return rc;
+		}
+	}
+	if (strcmp(argv[1], "help") == 0) { usage(stdout); return 0; }
 	fprintf(stderr, "[msamtools] unrecognized command '%s'\n", argv[1]);
 	usage(stderr);
 	return 1;

@@ -22,8 +22,8 @@ import digest
 import oracle_lib as orc
 from conftest import ROOT
 
-BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools" + os.environ.get("MSX_BIN_SUFFIX", ""))
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev" + os.environ.get("MSX_BIN_SUFFIX", ""))       # generator and I/O self-tests (msh_dev.c)
 FILT = ["filter", "-l", "80", "-p", "95", "-z", "80", "--besthit"]
 OPTS = dict(l=80, p=95, z=80, besthit=True)
 REF_LEN = 4496          # msh_dev.c: synth_main writes every @SQ with this length

@@ -226,8 +226,8 @@ def test_tee_cli_counts_chains_across_batch_cuts(ctx, tmp_path):
     import os
     import subprocess
     from conftest import ROOT
-    BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-    DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
+    BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools" + os.environ.get("MSX_BIN_SUFFIX", ""))
+    DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev" + os.environ.get("MSX_BIN_SUFFIX", ""))       # generator and I/O self-tests (msh_dev.c)
     recs = random_stream(5, 120000)
     sam = tmp_path / "s.sam"
     sam.write_text(sam_text(recs))

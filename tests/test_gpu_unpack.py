@@ -18,8 +18,8 @@ import samio
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
-BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools" + os.environ.get("MSX_BIN_SUFFIX", ""))
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev" + os.environ.get("MSX_BIN_SUFFIX", ""))       # generator and I/O self-tests (msh_dev.c)
 
 
 @pytest.fixture(scope="module")

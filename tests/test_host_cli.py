@@ -18,8 +18,8 @@ import pytest
 import samio
 from conftest import GOLDEN, ROOT, fixture_path
 
-BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools" + os.environ.get("MSX_BIN_SUFFIX", ""))
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev" + os.environ.get("MSX_BIN_SUFFIX", ""))       # generator and I/O self-tests (msh_dev.c)
 EXP = json.load(open(os.path.join(GOLDEN, "reference_expectations.json")))
 
 

@@ -13,8 +13,8 @@ import pytest
 
 from conftest import ROOT
 
-BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools" + os.environ.get("MSX_BIN_SUFFIX", ""))
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev" + os.environ.get("MSX_BIN_SUFFIX", ""))       # generator and I/O self-tests (msh_dev.c)
 EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 

@@ -21,8 +21,8 @@ import oracle_lib as orc
 import samio
 from conftest import ROOT
 
-BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
-DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")       # generator and I/O self-tests (msh_dev.c)
+BIN = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools" + os.environ.get("MSX_BIN_SUFFIX", ""))
+DEV = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev" + os.environ.get("MSX_BIN_SUFFIX", ""))       # generator and I/O self-tests (msh_dev.c)
 MODES = {"all": "all", "equal": "equal", "ignore": "ignore", "prop": "proportional"}
 N = 3000
 
