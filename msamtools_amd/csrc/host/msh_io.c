@@ -164,11 +164,55 @@ char *msh_hdr_sort_order(const msh_hdr *h) {
 	return NULL;
 }
 
+/* name -> tid for SAM text in (sam_hdr_name2tid: htslib keeps a hash of the @SQ names).  A one-entry cache per thread in
+ * front of an open-addressing table built on first use, under a lock, for the header it is first asked about (a process
+ * reads one input); any other header takes the linear probe.  The first @SQ line of a name wins, as the probe's order has it.
+ * (Round 5: the cache used to be one static word shared by the parsing threads -- a data race ThreadSanitizer reported --
+ * in front of the linear probe alone: O(references) per record whose reference differs from the one before.) */
+static struct {
+	pthread_mutex_t mu;
+	const msh_hdr *owner;     /* published last, with release order: readers that see it see the table */
+	int32_t *slot;            /* tid + 1, 0 = empty */
+	uint32_t mask;
+} g_n2t = {PTHREAD_MUTEX_INITIALIZER, NULL, NULL, 0};
+static uint32_t n2t_hash(const char *s) {
+	uint32_t h = 2166136261u;
+	while (*s) { h ^= (uint8_t)*s++; h *= 16777619u; }
+	return h ^ (h >> 15);
+}
+static void n2t_build(const msh_hdr *h) {
+	pthread_mutex_lock(&g_n2t.mu);
+	if (!g_n2t.owner) {
+		uint32_t cap = 16;
+		int32_t i;
+		while (cap < 2u * (uint32_t)h->n_targets) cap <<= 1;
+		g_n2t.slot = (int32_t *)calloc(cap, sizeof(int32_t));
+		if (!g_n2t.slot) mDie("out of memory");
+		g_n2t.mask = cap - 1;
+		for (i = 0; i < h->n_targets; i++) {
+			uint32_t k = n2t_hash(h->target_name[i]) & g_n2t.mask;
+			while (g_n2t.slot[k] && strcmp(h->target_name[g_n2t.slot[k] - 1], h->target_name[i]) != 0) k = (k + 1) & g_n2t.mask;
+			if (!g_n2t.slot[k]) g_n2t.slot[k] = i + 1;
+		}
+		__atomic_store_n(&g_n2t.owner, h, __ATOMIC_RELEASE);
+	}
+	pthread_mutex_unlock(&g_n2t.mu);
+}
 int32_t msh_hdr_name2tid(const msh_hdr *h, const char *name) {
-	/* linear probe with a one-entry cache is enough for the SAM-text path (fixtures, pipes) */
-	static int32_t last = 0;
+	static __thread int32_t last = 0;
+	const msh_hdr *owner;
 	int32_t i;
 	if (last < h->n_targets && strcmp(h->target_name[last], name) == 0) return last;
+	owner = __atomic_load_n(&g_n2t.owner, __ATOMIC_ACQUIRE);
+	if (!owner && h->n_targets > 8) { n2t_build(h); owner = __atomic_load_n(&g_n2t.owner, __ATOMIC_ACQUIRE); }
+	if (owner == h) {
+		uint32_t k = n2t_hash(name) & g_n2t.mask;
+		while (g_n2t.slot[k]) {
+			if (strcmp(h->target_name[g_n2t.slot[k] - 1], name) == 0) return last = g_n2t.slot[k] - 1;
+			k = (k + 1) & g_n2t.mask;
+		}
+		return -1;
+	}
 	for (i = 0; i < h->n_targets; i++)
 		if (strcmp(h->target_name[i], name) == 0) { last = i; return i; }
 	return -1;
@@ -1461,6 +1505,13 @@ void msh_close(msh_in *in) {
 	int i;
 	if (!in) return;
 	if (in->fp && in->fp != stdin) fclose(in->fp);
+	if (__atomic_load_n(&g_n2t.owner, __ATOMIC_ACQUIRE) == &in->hdr) {      /* (no thread parses this input any more) */
+		pthread_mutex_lock(&g_n2t.mu);
+		free(g_n2t.slot);
+		g_n2t.slot = NULL;
+		__atomic_store_n(&g_n2t.owner, (const msh_hdr *)NULL, __ATOMIC_RELEASE);
+		pthread_mutex_unlock(&g_n2t.mu);
+	}
 	for (i = 0; i < in->hdr.n_targets; i++) free(in->hdr.target_name[i]);
 	free(in->hdr.target_name);
 	free(in->hdr.target_len);

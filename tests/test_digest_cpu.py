@@ -70,3 +70,22 @@ def test_selected_full_digest_equals_the_digest_of_the_selection_written_out(tmp
     open(out, "wb").write(bgzf_blocks(bytes(bad)))
     assert digest(out) == digest("--select", idx, src)
     assert digest("--full", out) != digest("--full", "--select", idx, src)
+
+
+def test_sam_text_with_many_references_is_not_a_linear_probe_per_record(tmp_path):
+    """SAM text names its references; htslib resolves them through a hash (sam_hdr_name2tid).  200 k @SQ lines and a
+    million records whose reference changes from one to the next: the name index (msh_hdr_name2tid) -- the linear probe it
+    replaced took 40 s here, the index half a second.  Same records as the BAM they were written from."""
+    import time
+    bam, sam = str(tmp_path / "m.bam"), str(tmp_path / "m.sam")
+    with open(bam, "wb") as fh:
+        subprocess.check_call([DEV, "synth", "--groups", "200000", "--refs", "200000", "-b"], stdout=fh)
+    with open(sam, "wb") as fh:
+        subprocess.check_call([DEV, "recode", "-h", bam], stdout=fh)
+    t0 = time.time()
+    got = subprocess.run([DEV, "digest", sam], stdout=subprocess.PIPE, timeout=20).stdout.decode()
+    assert got == subprocess.check_output([DEV, "digest", bam]).decode()
+    assert time.time() - t0 < 20
+    # and through the decode stage's parallel parser
+    out = subprocess.check_output([DEV, "pipetest", "1", "1", sam], env=dict(os.environ, MSX_THREADS="8")).decode().split("\n")
+    assert out[0].split()[1:5] == out[1].split()[1:5]
