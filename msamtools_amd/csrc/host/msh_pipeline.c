@@ -423,7 +423,12 @@ void pin_join(pipe_t *P) {
 	pthread_mutex_unlock(&P->pin_mu);
 }
 /* MSX_TRACE=1: one line per hand-over between the pipeline's threads (who waits for what), for hangs */
-int msh_trace_on(void) { static int on = -1; if (on < 0) on = getenv("MSX_TRACE") != NULL; return on; }
+int msh_trace_on(void) {
+	static int on = -1;          /* (every thread would store the same value: relaxed atomics keep the sanitizer's books straight) */
+	int v = __atomic_load_n(&on, __ATOMIC_RELAXED);
+	if (v < 0) { v = getenv("MSX_TRACE") != NULL; __atomic_store_n(&on, v, __ATOMIC_RELAXED); }
+	return v;
+}
 #define TRACE(...) do { if (msh_trace_on()) { fprintf(stderr, "# trace %.3f: ", now_s()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 int ob_acquire(pipe_t *P, size_t seq) {
 	const int i = (int)(seq % PIPE_OBUFS);
