@@ -11,7 +11,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsamtools_amd.so")
+# (MSX_LIB_PATH: another build of the same library -- scripts/build_asan_lib.sh puts one with its host code under
+#  AddressSanitizer into build/asanlib; there is no other implementation to point it at)
+LIB_PATH = os.environ.get("MSX_LIB_PATH") or os.path.join(_HERE, "libmsamtools_amd.so")
 
 MSX_OK = 0
 ERR_NO_MD_NM, ERR_NO_AS, ERR_NO_FILTER, ERR_SHARE_TYPE = 1, 2, 3, 4
