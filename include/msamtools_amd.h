@@ -168,6 +168,14 @@ int  msx_ctx_create(msx_ctx **ctx, int device_id);
 void msx_ctx_destroy(msx_ctx *ctx);
 const char *msx_last_error(const msx_ctx *ctx);  /* ctx may be NULL: last create error */
 int  msx_abi_version(void);
+/* Test aid (no counterpart in the reference).  With MSX_GUARD=1 in the environment every device allocation the library makes
+ * carries 512 guard bytes in front and behind; an allocation whose guards a kernel has written into aborts the process when it
+ * is freed, and this call looks at all live ones now: the number of damaged guard bytes (each reported on stderr), 0 if all
+ * are intact, -1 if the guard is off. */
+int64_t msx_debug_guard_check(void);
+/* ... and the guard checking itself: a kernel writes one byte behind (front = 0) or in front of (front = 1) a small allocation;
+ * returns the damaged guard bytes found (1), -1 if the guard is off. */
+int64_t msx_debug_guard_selftest(int front);
 /* The HIP stream all work of this ctx is enqueued on (a hipStream_t), so the
  * caller can record events on it or make other streams wait for it.  One
  * exception to "all work": msx_filter_profile_enqueue leaves two chains running

@@ -96,6 +96,8 @@ SYMBOLS = {
     "msx_ctx_destroy": (None, [_P]),
     "msx_last_error": (C.c_char_p, [_P]),
     "msx_abi_version": (C.c_int, []),
+    "msx_debug_guard_check": (C.c_int64, []),
+    "msx_debug_guard_selftest": (C.c_int64, [C.c_int]),
     "msx_runtime_warmup": (C.c_int, [C.c_int]),
     "msx_ctx_stream": (_P, [_P]),
     "msx_ctx_sync": (C.c_int, [_P]),

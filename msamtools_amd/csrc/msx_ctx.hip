@@ -20,6 +20,7 @@ int msx_fail(msx_ctx *ctx, int code, const char *fmt, ...) {
 int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes) {
 	if (bytes <= b->cap && b->p) return MSX_OK;
 	size_t want = bytes + bytes / 8 + 256;   // slack so streaming batches settle quickly
+	if (msx_guard_on()) want = bytes ? bytes : 16;            // (MSX_GUARD: the guard sits right behind the request)
 	if (b->p) {
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		MSX_HIP(ctx, hipFree(b->p));

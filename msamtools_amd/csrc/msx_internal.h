@@ -13,6 +13,20 @@
 
 #include "../../include/msamtools_amd.h"
 
+// MSX_GUARD=1 (tests; device-side AddressSanitizer is not to be had on this pool): every device allocation of the library gets
+// 512 guard bytes in front and behind, filled with 0xC3 and looked at again when the allocation is freed and whenever
+// msx_debug_guard_check is called -- a kernel that writes past the end (or before the start) of what it was given aborts the
+// process with the allocation's size and the first damaged byte instead of spoiling a neighbour.  With the guard on,
+// msx_reserve hands out exactly what was asked for (no slack), so "past the end" means past the request.  Reads are not seen
+// (MSX_POISON covers unwritten words).  Every translation unit allocates through these two names (msx_ctx.hip has the bodies).
+hipError_t msx_guard_malloc(void **p, size_t n);
+hipError_t msx_guard_free(void *p);
+bool msx_guard_on();
+#ifndef MSX_GUARD_IMPL
+#define hipMalloc(p, n) msx_guard_malloc((void **)(p), (n))
+#define hipFree(p) msx_guard_free((void *)(p))
+#endif
+
 #define MSX_BLOCK 256          // 4 wave64 per workgroup
 #define MSX_WAVE 64
 

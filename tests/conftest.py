@@ -49,3 +49,14 @@ def expectations():
 
 def fixture_path(name):
     return os.path.join(FIXTURES, name)
+
+
+@pytest.fixture(autouse=True)
+def _device_guard_bytes(request):
+    """MSX_GUARD=1: after every GPU test the guard bytes around the library's live device allocations must be intact
+    (include/msamtools_amd.h: msx_debug_guard_check; freed allocations were checked when they were freed)."""
+    yield
+    if os.environ.get("MSX_GUARD") and request.node.get_closest_marker("gpu"):
+        import msamtools_amd._lib as L
+        bad = L.load().msx_debug_guard_check()
+        assert bad <= 0, f"{bad} guard byte(s) around device allocations overwritten (stderr has the allocations)"
