@@ -420,7 +420,9 @@ int  msx_profile_merge(msx_ctx *dst_ctx, msx_profile *dst, msx_ctx *src_ctx, msx
 /* Device pointers to the accumulators, for a cross-GPU all-reduce(sum) by the
  * caller (RCCL): ui_insert_count u32[n_features], d_insert_count f64
  * [n_features] (NULL unless share_type is EQUAL), counters u32[4] =
- * {insert_count, uniq_mapper_count, multi_mapper_count, purged_insert_count}. */
+ * {insert_count, uniq_mapper_count, multi_mapper_count, purged_insert_count}.
+ * (EQUAL: the shares counted so far are complete in d[] when this returns -- they are gathered as exact integers and
+ * folded in here; accumulate again and ask again before reading d[] again.) */
 int  msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui,
                               double **d, uint32_t **counters);
 

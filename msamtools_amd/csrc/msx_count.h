@@ -6,6 +6,9 @@
 
 #include "msx_internal.h"
 
+#define MSX_EQ_L 5354228880ull        // lcm(1..24); 2^64 / (L / 3) = 1.0e10 additions before a word could wrap: more than uint32 inserts
+#define MSX_EQ_KMAX 24u
+
 struct CountArgs {
 	int64_t n_groups;
 	int64_t n_records;
@@ -16,6 +19,12 @@ struct CountArgs {
 	int32_t share_type;
 	uint32_t *ui;
 	double *d;
+	// --multi equal: the 1/k of a pool with k <= MSX_EQ_KMAX distinct features is added as the INTEGER MSX_EQ_L / k into dq[]
+	// (MSX_EQ_L = lcm(1..24): exact, and integer atomics do not care about their order); msx_profile_fold_equal turns
+	// dq[] into d[] with one division per feature before anything reads d[].  Floating-point atomics in arrival order gave
+	// sums whose last bits changed from run to run (tests/test_gpu_determinism.py); pools of more than 24 distinct
+	// features still take that route.
+	unsigned long long *dq;
 	uint32_t *counters;       // {inserts, uniq, multi, purged}
 	int32_t *tmp_fid;         // [n_records] scratch: a multi-mapped pool g's distinct features at tmp_fid[group_off[g]..]
 	uint32_t tbl_mask;        // LDS staging table size - 1 (power of two, <= UI_TBL)
@@ -160,8 +169,13 @@ __device__ __forceinline__ void pool_finish(const CountArgs &A, int64_t g, const
 					ui_add(s_key, s_val, A.ui, v.f0, 1u, A.tbl_mask);
 					ui_add(s_key, s_val, A.ui, v.f1, 1u, A.tbl_mask);
 				} else {                                  // :175-182
-					const double share = 1.0 / (double)v.nd;
-					for (uint32_t k = 0; k < v.nd; ++k) atomicAdd(&A.d[v.lst[k]], share);
+					if (A.dq && v.nd <= MSX_EQ_KMAX) {
+						const unsigned long long q = MSX_EQ_L / (unsigned long long)v.nd;
+						for (uint32_t k = 0; k < v.nd; ++k) atomicAdd(&A.dq[v.lst[k]], q);
+					} else {
+						const double share = 1.0 / (double)v.nd;
+						for (uint32_t k = 0; k < v.nd; ++k) atomicAdd(&A.d[v.lst[k]], share);
+					}
 				}
 				break;
 			case MSX_MULTI_SHARE_PROPORTIONAL:            // :107-121, :184-186
@@ -209,6 +223,9 @@ __device__ __forceinline__ void count_block_end(const CountArgs &A, int32_t *s_k
 int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, const uint8_t *keep, CountArgs *out,
                               bool *by_part_out);
 int msx_profile_count_finish(msx_ctx *ctx, msx_profile *p, const msx_batch *b, bool by_part);
+// --multi equal: d[] += dq[] / MSX_EQ_L, dq[] = 0 (a no-op when nothing was added since the last fold); on ctx->stream, behind
+// msx_join -- every reader of d[] calls it first (accumulators, merge, all-reduce of the counts, prop_begin)
+int msx_profile_fold_equal(msx_ctx *ctx, msx_profile *p);
 void msx_profile_count_chains(msx_ctx *ctx, const CountArgs &A);      // k_insert_chains, after the per-pool kernel
 
 #endif

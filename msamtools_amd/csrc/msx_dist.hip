@@ -12,6 +12,7 @@
 // librccl is opened at run time (dlopen), only when a distributed context is initialised:
 // the single-GPU command line neither links nor loads it.
 #include "msx_internal.h"
+#include "msx_count.h"
 
 #include <arpa/inet.h>
 #include <dlfcn.h>
@@ -311,6 +312,7 @@ extern "C" int msx_dist_sum_i64(msx_ctx *ctx, int64_t *value) {
 extern "C" int msx_profile_allreduce_counts(msx_ctx *ctx, msx_profile *p) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	msx_join(ctx);
+	{ int frc = msx_profile_fold_equal(ctx, p); if (frc) return frc; }        // (--multi equal: d[] complete before it travels)
 	msx_dist *d = ctx->dist;
 	if (!d) return MSX_OK;          // (a one-rank communicator still runs the collective: the same code path)
 	MSX_HIP(ctx, hipSetDevice(ctx->device));

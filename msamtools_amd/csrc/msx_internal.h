@@ -221,6 +221,8 @@ struct msx_profile {
 	int32_t *fmap = nullptr;          // device [n_targets] or null
 	uint32_t *ui = nullptr;           // [n_features] global->ui_insert_count
 	double *d = nullptr;              // [n_features] global->d_insert_count (EQUAL)
+	unsigned long long *dq = nullptr; // [n_features] (EQUAL) the 1/k shares not yet folded into d[], in units of 1/MSX_EQ_L (msx_count.h)
+	bool dq_dirty = false;            // dq[] holds something: msx_profile_fold_equal before d[] is read
 	uint32_t *counters = nullptr;     // [4] {inserts, uniq, multi, purged}
 	double *U = nullptr, *a = nullptr;   // [n_features] U(i), a(i,k)
 	double *share = nullptr;          // [n_features] sum over multi-mappers of 1/S (all-reduced across ranks)

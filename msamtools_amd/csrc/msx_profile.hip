@@ -197,7 +197,7 @@ extern "C" void msx_profile_destroy(msx_ctx *ctx, msx_profile *p) {
 	if (!p) return;
 	if (ctx) msx_join(ctx);
 	if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-	void *ptrs[] = {p->fmap, p->ui, p->d, p->counters, p->U, p->a_in_recip ? nullptr : (void *)p->a, p->share, p->delta, p->iter_state,
+	void *ptrs[] = {p->fmap, p->ui, p->d, p->dq, p->counters, p->U, p->a_in_recip ? nullptr : (void *)p->a, p->share, p->delta, p->iter_state,
 	                p->m_off.p, p->m_fid.p, p->csr_tot, p->partial, p->purged_local,
 	                p->t_key[0].p, p->t_key[1].p, p->rs_hist.p, p->rs_off.p, p->ck_hist.p, p->ck_off.p,
 	                p->recip.p, p->runs.p, p->owned.p, p->part_key.p, p->part_val.p, p->m_off_alt.p, p->m_fid_alt.p,
@@ -232,7 +232,8 @@ extern "C" int msx_profile_create(msx_ctx *ctx, msx_profile **out, int32_t n_fea
 	          hipMalloc((void **)&p->d_tot, 8 * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->partial, (size_t)(msx_apply_blocks(n_features) + 2 * msx_share_waves(ctx) / MSX_BLOCK + 16) * 8) == hipSuccess &&
 	          hipMalloc((void **)&p->purged_local, 4) == hipSuccess;
-	if (ok && share_type == MSX_MULTI_SHARE_EQUAL) ok = hipMalloc((void **)&p->d, nf * 8) == hipSuccess;
+	if (ok && share_type == MSX_MULTI_SHARE_EQUAL)
+		ok = hipMalloc((void **)&p->d, nf * 8) == hipSuccess && hipMalloc((void **)&p->dq, nf * 8) == hipSuccess;
 	if (ok && fmap && n_targets > 0) {
 		ok = hipMalloc((void **)&p->fmap, (size_t)n_targets * 4) == hipSuccess &&
 		     hipMemcpy(p->fmap, fmap, (size_t)n_targets * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -260,6 +261,8 @@ extern "C" int msx_profile_reset(msx_ctx *ctx, msx_profile *p) {
 	const size_t nf = (size_t)(p->n_features > 0 ? p->n_features : 1);
 	MSX_HIP(ctx, hipMemsetAsync(p->ui, 0, nf * 4, ctx->stream));
 	if (p->d) MSX_HIP(ctx, hipMemsetAsync(p->d, 0, nf * 8, ctx->stream));
+	if (p->dq) MSX_HIP(ctx, hipMemsetAsync(p->dq, 0, nf * 8, ctx->stream));
+	p->dq_dirty = false;
 	MSX_HIP(ctx, hipMemsetAsync(p->counters, 0, 16, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->csr_tot, 0, 16, ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(p->d_tot, 0, 64, ctx->stream));
@@ -312,6 +315,8 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 	A.share_type = p->share_type;
 	A.ui = p->ui;
 	A.d = p->d;
+	A.dq = p->dq;
+	if (p->dq) p->dq_dirty = true;
 	A.counters = p->counters;
 	A.tmp_fid = (int32_t *)ctx->tmp_fid.p;
 	if (b->pool_rule == MSX_POOLS_FILTER) {
@@ -395,6 +400,23 @@ extern "C" int msx_profile_accumulate(msx_ctx *ctx, msx_profile *p, const msx_ba
 }
 
 // ---- one process, several contexts: the inserts of one sample counted on several devices ----------------
+// --multi equal: what the pools added to dq[] in units of 1/MSX_EQ_L becomes part of d[] (msx_count.h)
+__global__ __launch_bounds__(MSX_BLOCK) void k_fold_equal(int32_t nf, unsigned long long *__restrict__ dq, double *__restrict__ d) {
+	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
+	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
+		const unsigned long long q = dq[i];
+		if (q) { d[i] += (double)q / (double)MSX_EQ_L; dq[i] = 0; }
+	}
+}
+int msx_profile_fold_equal(msx_ctx *ctx, msx_profile *p) {
+	if (!p->dq || !p->dq_dirty) return MSX_OK;
+	hipLaunchKernelGGL(k_fold_equal, dim3(msx_grid(ctx, p->n_features, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream, p->n_features,
+	                   p->dq, p->d);
+	p->dq_dirty = false;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
 __global__ __launch_bounds__(MSX_BLOCK) void k_merge_counts(int32_t nf, const uint32_t *__restrict__ ui_src, uint32_t *__restrict__ ui,
                                                             const double *__restrict__ d_src, double *__restrict__ d,
                                                             const uint32_t *__restrict__ cnt_src, uint32_t *__restrict__ cnt) {
@@ -427,11 +449,13 @@ extern "C" int msx_profile_merge(msx_ctx *ctx, msx_profile *p, msx_ctx *src_ctx,
 	msx_join(src_ctx);
 	// everything the source has enqueued must have landed
 	MSX_HIP(src_ctx, hipSetDevice(src_ctx->device));
+	{ int frc = msx_profile_fold_equal(src_ctx, q); if (frc) return frc; }     // (--multi equal: d[] of both sides complete)
 	MSX_HIP(src_ctx, hipStreamSynchronize(src_ctx->stream));
 	unsigned long long t[2] = {0, 0};
 	MSX_HIP(src_ctx, hipMemcpy(t, q->csr_tot, 16, hipMemcpyDeviceToHost));
 	const int64_t nl = (int64_t)t[0], ne = (int64_t)t[1];
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
+	{ int frc = msx_profile_fold_equal(ctx, p); if (frc) return frc; }
 	const size_t nf = (size_t)(p->n_features > 0 ? p->n_features : 1);
 	// staging on the destination device: ui, d, counters, offsets of the source
 	const size_t b_ui = nf * 4, b_d = q->d ? nf * 8 : 0, b_off = (size_t)(nl + 1) * 4;
@@ -486,6 +510,7 @@ extern "C" int msx_profile_merge(msx_ctx *ctx, msx_profile *p, msx_ctx *src_ctx,
 extern "C" int msx_profile_accumulators(msx_ctx *ctx, msx_profile *p, uint32_t **ui, double **d, uint32_t **counters) {
 	if (!ctx || !p) return MSX_ERR_ARG;
 	msx_join(ctx);
+	{ int frc = msx_profile_fold_equal(ctx, p); if (frc) return frc; }
 	if (ui) *ui = p->ui;
 	if (d) *d = p->d;
 	if (counters) *counters = p->counters;

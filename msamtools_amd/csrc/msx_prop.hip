@@ -1230,36 +1230,57 @@ struct PartRun {
 };
 
 // runs of up to PA_SHORT slots go to runs[0 .. d_tot[3]), longer ones (a hot reference cut by hundreds of
-// chunk boundaries) to the far end of the same array, runs[cap - 1 - i] for i < d_tot[4]
+// chunk boundaries) to the far end of the same array, runs[cap - 1 - i] for i < d_tot[4].
+// ONE workgroup walks the slots in index order and places every run by ballot ranks: the lists come out in slot order, the
+// same for every build of the same store.  (Until round 5 the runs were appended through atomic counters, a workgroup per
+// 256 slots: which lane of k_prop_apply met which run then varied from build to build, and with it the order in which the
+// diff^2 of those features entered DELTA^2 -- its last bits differed from run to run while every abundance repeated bit for
+// bit; tests/test_gpu_determinism.py.  The slots number two per wave of k_share_reduce -- 6144 -- so one workgroup is enough.)
 #define PA_SHORT 8                     // slots one lane adds by itself
-__global__ __launch_bounds__(MSX_BLOCK) void k_part_runs(const uint32_t *__restrict__ part_key, int64_t M,
-                                                         PartRun *__restrict__ runs, uint32_t *__restrict__ owned,
-                                                         unsigned long long *d_tot) {
-	__shared__ uint32_t s_n[2], s_base[2];
-	__shared__ PartRun s_run[2][MSX_BLOCK];
-	if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+#define PR_BLOCK 1024
+__global__ __launch_bounds__(PR_BLOCK) void k_part_runs(const uint32_t *__restrict__ part_key, int64_t M,
+                                                        PartRun *__restrict__ runs, uint32_t *__restrict__ owned,
+                                                        unsigned long long *d_tot) {
+	__shared__ uint32_t s_cnt[2][PR_BLOCK / 64];
+	__shared__ uint32_t s_base[2];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
 	__syncthreads();
-	const int64_t j = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	if (j < M) {
-		const uint32_t key = part_key[j];
-		if (key != SR_SENT && (j == 0 || part_key[j - 1] != key)) {
-			int64_t lo = j + 1, hi = M;                 // first slot beyond the run (keys ascend)
-			while (lo < hi) {
-				const int64_t mid = (lo + hi) >> 1;
-				if (part_key[mid] <= key) lo = mid + 1; else hi = mid;
+	for (int64_t j0 = 0; j0 < M; j0 += PR_BLOCK) {
+		const int64_t j = j0 + threadIdx.x;
+		bool head = false;
+		PartRun r = {0u, 0u, 0u, 0u};
+		if (j < M) {
+			const uint32_t key = part_key[j];
+			if (key != SR_SENT && (j == 0 || part_key[j - 1] != key)) {
+				int64_t lo = j + 1, hi = M;                 // first slot beyond the run (keys ascend)
+				while (lo < hi) {
+					const int64_t mid = (lo + hi) >> 1;
+					if (part_key[mid] <= key) lo = mid + 1; else hi = mid;
+				}
+				head = true;
+				r.key = key; r.first = (uint32_t)j; r.n = (uint32_t)(lo - j);
+				atomicOr(&owned[key >> 5], 1u << (key & 31u));      // (a bitmap: order-free)
 			}
-			const PartRun r = {key, (uint32_t)j, (uint32_t)(lo - j), 0u};
-			const int big = r.n > PA_SHORT ? 1 : 0;
-			s_run[big][atomicAdd(&s_n[big], 1u)] = r;
-			atomicOr(&owned[key >> 5], 1u << (key & 31u));
 		}
+		const bool big = head && r.n > PA_SHORT, small = head && !big;
+		const unsigned long long bs = __ballot(small), bb = __ballot(big);
+		if (lane == 0) { s_cnt[0][w] = (uint32_t)__popcll(bs); s_cnt[1][w] = (uint32_t)__popcll(bb); }
+		__syncthreads();
+		uint32_t o0 = s_base[0], o1 = s_base[1];
+		for (int k = 0; k < w; k++) { o0 += s_cnt[0][k]; o1 += s_cnt[1][k]; }
+		if (small) runs[o0 + (uint32_t)__popcll(bs & below)] = r;
+		if (big) runs[M - 1 - (int64_t)(o1 + (uint32_t)__popcll(bb & below))] = r;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t t0 = 0, t1 = 0;
+			for (int k = 0; k < PR_BLOCK / 64; k++) { t0 += s_cnt[0][k]; t1 += s_cnt[1][k]; }
+			s_base[0] += t0; s_base[1] += t1;
+		}
+		__syncthreads();
 	}
-	__syncthreads();
-	if (threadIdx.x < 2 && s_n[threadIdx.x])
-		s_base[threadIdx.x] = (uint32_t)atomicAdd(&d_tot[3 + threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
-	__syncthreads();
-	if (threadIdx.x < s_n[0]) runs[s_base[0] + threadIdx.x] = s_run[0][threadIdx.x];
-	if (threadIdx.x < s_n[1]) runs[M - 1 - (s_base[1] + threadIdx.x)] = s_run[1][threadIdx.x];
+	if (threadIdx.x == 0) { d_tot[3] = s_base[0]; d_tot[4] = s_base[1]; }
 }
 
 // With a collective between the halves of an iteration share[] must be complete before it leaves the device: the
@@ -1681,7 +1702,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, 2 * W, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W,
 		                   (uint32_t *)p->part_key.p, p->d_tot);
-		hipLaunchKernelGGL(k_part_runs, dim3((unsigned)((2 * W + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
+		hipLaunchKernelGGL(k_part_runs, dim3(1), dim3(PR_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
 		msx_time_end(ctx);
 		if (getenv("MSX_SR_CLASSES")) {
@@ -1788,6 +1809,7 @@ extern "C" int msx_profile_prop_begin(msx_ctx *ctx, msx_profile *p) {
 		if (rc) { msx_join(ctx); return rc; }
 	}
 	msx_join(ctx);
+	{ int frc = msx_profile_fold_equal(ctx, p); if (frc) return frc; }        // (--multi equal: msx_count.h)
 	const int32_t nf = p->n_features;
 	msx_time_begin(ctx, MSX_K_PROP_APPLY);
 	hipLaunchKernelGGL(k_prop_begin, dim3(nf_grid(ctx, nf)), dim3(MSX_BLOCK), 0, ctx->stream, nf,
