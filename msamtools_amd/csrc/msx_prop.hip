@@ -1238,49 +1238,79 @@ struct PartRun {
 // bit; tests/test_gpu_determinism.py.  The slots number two per wave of k_share_reduce -- 6144 -- so one workgroup is enough.)
 #define PA_SHORT 8                     // slots one lane adds by itself
 #define PR_BLOCK 1024
+#define PR_PER_MAX 16                  // consecutive slots per thread: 16 K slots = 8192 waves of k_share_reduce, more than the chip holds
 __global__ __launch_bounds__(PR_BLOCK) void k_part_runs(const uint32_t *__restrict__ part_key, int64_t M,
                                                         PartRun *__restrict__ runs, uint32_t *__restrict__ owned,
                                                         unsigned long long *d_tot) {
+	__shared__ int64_t s_min[PR_BLOCK / 64];
 	__shared__ uint32_t s_cnt[2][PR_BLOCK / 64];
-	__shared__ uint32_t s_base[2];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const unsigned long long below = (1ull << lane) - 1ull;
-	if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
-	__syncthreads();
-	for (int64_t j0 = 0; j0 < M; j0 += PR_BLOCK) {
-		const int64_t j = j0 + threadIdx.x;
-		bool head = false;
-		PartRun r = {0u, 0u, 0u, 0u};
-		if (j < M) {
-			const uint32_t key = part_key[j];
-			if (key != SR_SENT && (j == 0 || part_key[j - 1] != key)) {
-				int64_t lo = j + 1, hi = M;                 // first slot beyond the run (keys ascend)
-				while (lo < hi) {
-					const int64_t mid = (lo + hi) >> 1;
-					if (part_key[mid] <= key) lo = mid + 1; else hi = mid;
-				}
-				head = true;
-				r.key = key; r.first = (uint32_t)j; r.n = (uint32_t)(lo - j);
-				atomicOr(&owned[key >> 5], 1u << (key & 31u));      // (a bitmap: order-free)
-			}
-		}
-		const bool big = head && r.n > PA_SHORT, small = head && !big;
-		const unsigned long long bs = __ballot(small), bb = __ballot(big);
-		if (lane == 0) { s_cnt[0][w] = (uint32_t)__popcll(bs); s_cnt[1][w] = (uint32_t)__popcll(bb); }
-		__syncthreads();
-		uint32_t o0 = s_base[0], o1 = s_base[1];
-		for (int k = 0; k < w; k++) { o0 += s_cnt[0][k]; o1 += s_cnt[1][k]; }
-		if (small) runs[o0 + (uint32_t)__popcll(bs & below)] = r;
-		if (big) runs[M - 1 - (int64_t)(o1 + (uint32_t)__popcll(bb & below))] = r;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			uint32_t t0 = 0, t1 = 0;
-			for (int k = 0; k < PR_BLOCK / 64; k++) { t0 += s_cnt[0][k]; t1 += s_cnt[1][k]; }
-			s_base[0] += t0; s_base[1] += t1;
-		}
-		__syncthreads();
+	const int per = (int)((M + PR_BLOCK - 1) / PR_BLOCK);          // <= PR_PER_MAX (checked by the host)
+	const int64_t jb = (int64_t)threadIdx.x * per;
+	// a run ends where the next one begins: the boundaries (slots whose key differs from the slot before; the idle waves'
+	// sentinel keys at the far end are one more "run", not listed) -- no searching
+	uint32_t key[PR_PER_MAX + 1];
+#pragma unroll
+	for (int i = 0; i <= PR_PER_MAX; i++) {
+		const int64_t q = jb - 1 + i;
+		key[i] = (i <= per && q >= 0 && q < M) ? part_key[q] : SR_SENT;
 	}
-	if (threadIdx.x == 0) { d_tot[3] = s_base[0]; d_tot[4] = s_base[1]; }
+	bool bnd[PR_PER_MAX];
+	int64_t first = M;                                             // the first boundary among this thread's slots
+#pragma unroll
+	for (int i = PR_PER_MAX - 1; i >= 0; i--) {
+		const int64_t j = jb + i;
+		bnd[i] = i < per && j < M && (j == 0 || key[i] != key[i + 1]);
+		if (bnd[i]) first = j;
+	}
+	int64_t x = first;                                             // suffix minimum over the wave (inclusive)
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int64_t o = __shfl_down(x, d, 64);
+		if (lane + d < 64 && o < x) x = o;
+	}
+	if (lane == 0) s_min[w] = x;
+	__syncthreads();
+	int64_t nextb = __shfl_down(x, 1, 64);                         // the first boundary behind this thread's slots
+	if (lane == 63) nextb = M;
+	for (int k = w + 1; k < PR_BLOCK / 64; k++) if (s_min[k] < nextb) nextb = s_min[k];
+	uint32_t len[PR_PER_MAX];
+	uint32_t ns = 0, nb = 0;
+#pragma unroll
+	for (int i = PR_PER_MAX - 1; i >= 0; i--) {
+		len[i] = 0;
+		if (bnd[i]) {
+			const int64_t j = jb + i;
+			if (key[i + 1] != SR_SENT) {
+				len[i] = (uint32_t)(nextb - j);
+				if (len[i] > PA_SHORT) nb++; else ns++;
+				atomicOr(&owned[key[i + 1] >> 5], 1u << (key[i + 1] & 31u));      // (a bitmap: order-free)
+			}
+			nextb = j;
+		}
+	}
+	// exclusive ranks of this thread's short and long runs among all of them, in slot order
+	uint32_t xs = ns, xb = nb;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t os = __shfl_up(xs, d, 64), ob = __shfl_up(xb, d, 64);
+		if (lane >= d) { xs += os; xb += ob; }
+	}
+	if (lane == 63) { s_cnt[0][w] = xs; s_cnt[1][w] = xb; }
+	__syncthreads();
+	uint32_t o0 = xs - ns, o1 = xb - nb;
+	for (int k = 0; k < w; k++) { o0 += s_cnt[0][k]; o1 += s_cnt[1][k]; }
+#pragma unroll
+	for (int i = 0; i < PR_PER_MAX; i++)
+		if (len[i]) {
+			const PartRun r = {key[i + 1], (uint32_t)(jb + i), len[i], 0u};
+			if (r.n > PA_SHORT) runs[M - 1 - (int64_t)(o1++)] = r; else runs[o0++] = r;
+		}
+	if (threadIdx.x == 0) {
+		uint32_t t0 = 0, t1 = 0;
+		for (int k = 0; k < PR_BLOCK / 64; k++) { t0 += s_cnt[0][k]; t1 += s_cnt[1][k]; }
+		d_tot[3] = t0; d_tot[4] = t1;
+	}
 }
 
 // With a collective between the halves of an iteration share[] must be complete before it leaves the device: the
@@ -1702,6 +1732,8 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, 2 * W, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W,
 		                   (uint32_t *)p->part_key.p, p->d_tot);
+		if (2 * W > (int64_t)PR_BLOCK * PR_PER_MAX)
+			return msx_fail(ctx, MSX_ERR_ARG, "k_share_reduce with %lld waves: k_part_runs lists at most %d partial slots", (long long)W, PR_BLOCK * PR_PER_MAX);
 		hipLaunchKernelGGL(k_part_runs, dim3(1), dim3(PR_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
 		msx_time_end(ctx);
