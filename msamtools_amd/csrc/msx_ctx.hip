@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 thread_local std::string msx_tls_err;
 
@@ -52,6 +53,26 @@ extern "C" const char *msx_last_error(const msx_ctx *ctx) {
 	return ctx ? ctx->err.c_str() : msx_tls_err.c_str();
 }
 
+// Every code object of the library onto the device, once per process and device, under one lock -- and msx_ctx_create does
+// not return before it has happened.  The runtime loads a code object when one of its kernels is first asked for; two threads
+// asking at once is what it does not take: the warm-up thread's hipFuncGetAttributes beside a device thread's first launch
+// aborted the process now and then on inputs small enough for the two to meet ("Cannot find Symbol with name: k_status_init",
+// hip_global.cpp; seen twice in some four hundred runs of the command-line tests), and two device threads of a several-context
+// run could have met the same way.  With every module loaded before any context exists, no launch loads one.
+// MSX_NO_MODULE_WARMUP=1: as before round 5 (modules loaded by the first launches).
+static void msx_modules_load(int device_id) {
+	static std::mutex mu;
+	static bool ready[64];
+	std::lock_guard<std::mutex> lk(mu);
+	if (device_id < 0 || device_id >= 64 || ready[device_id]) return;
+	if (!getenv("MSX_NO_MODULE_WARMUP")) {
+		msx_touch_unpack(); msx_touch_inflate(); msx_touch_stats(); msx_touch_filter(); msx_touch_scan(); msx_touch_profile();
+		msx_touch_deflate(); msx_touch_prop(); msx_touch_coverage();
+		(void)hipGetLastError();
+	}
+	ready[device_id] = true;
+}
+
 extern "C" int msx_runtime_warmup(int device_id) {
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);
@@ -61,11 +82,7 @@ extern "C" int msx_runtime_warmup(int device_id) {
 	if (device_id < 0 || device_id >= ndev) return msx_fail(nullptr, MSX_ERR_ARG, "device %d out of range (0..%d)", device_id, ndev - 1);
 	if (hipSetDevice(device_id) != hipSuccess || hipFree(nullptr) != hipSuccess)      // (hipFree(0): the primary context, now)
 		return msx_fail(nullptr, MSX_ERR_HIP, "runtime start-up failed: %s", hipGetErrorString(hipGetLastError()));
-	if (!getenv("MSX_NO_MODULE_WARMUP")) {
-		msx_touch_unpack(); msx_touch_inflate(); msx_touch_stats(); msx_touch_filter(); msx_touch_scan(); msx_touch_profile();
-		msx_touch_deflate(); msx_touch_prop(); msx_touch_coverage();
-		(void)hipGetLastError();
-	}
+	msx_modules_load(device_id);
 	return MSX_OK;
 }
 
@@ -111,6 +128,7 @@ extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
 		return rc;
 	}
 	ctx->main_stream = ctx->stream;
+	msx_modules_load(device_id);          // (waits for a warm-up thread that is in the middle of it; does it if nobody has)
 	{
 		const char *ser = getenv("MSX_SERIAL");
 		bool ok = !(ser && atoi(ser) != 0) && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
