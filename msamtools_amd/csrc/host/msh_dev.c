@@ -365,6 +365,7 @@ int digest_main(int argc, char *argv[]) {
 			n_sel++;
 			h += place * (full ? dg_record_full((const uint8_t *)rec.s, rec.l) : dg_record((const uint8_t *)rec.s));
 		}
+		free(rec.s);
 	}
 	printf("records=%llu digest=%016llx\n", (unsigned long long)(rank ? n_sel : n), (unsigned long long)h);
 	free(rank);

@@ -627,6 +627,7 @@ typedef struct {
 	int rd_full[RD_NBUF];
 	int rd_head, rd_eof, rd_wait, rd_started;
 	size_t rd_prefill;
+	const uint8_t *rd_pre;               /* the rd_prefill bytes msh_open read to tell BAM from compressed SAM text */
 	pthread_t rd_thr;
 	pthread_mutex_t rd_mu;
 	pthread_cond_t rd_cv_full, rd_cv_free;
@@ -698,7 +699,7 @@ static void *bgz_reader_main(void *arg) {
 		while (b->rd_full[slot]) pthread_cond_wait(&b->rd_cv_free, &b->rd_mu);
 		pthread_mutex_unlock(&b->rd_mu);
 		if (b->rd_prefill) {             /* the bytes msh_open looked at */
-			b->rd_buf[slot][RD_HEAD] = 0x1f; b->rd_buf[slot][RD_HEAD + 1] = 0x8b;
+			memcpy(b->rd_buf[slot] + RD_HEAD, b->rd_pre, b->rd_prefill);
 			n = b->rd_prefill;
 			b->rd_prefill = 0;
 		}
@@ -1133,6 +1134,14 @@ struct msh_in {
 	char *tbuf;
 	size_t tcap, tlen;   /* tbuf[0, tlen): text read but not parsed yet (an incomplete last line) */
 	int text_eof;
+	/* gzip / bgzip-compressed SAM text (htslib's sam_open reads it like any other SAM): a thread inflates the stream into a
+	 * pipe, fp is the pipe's reading end and everything downstream sees plain text */
+	uint8_t *pre;        /* what msh_open read ahead of a gzip stream (at most PRE_MAX bytes) */
+	size_t npre;
+	FILE *gz_src;        /* the compressed stream itself */
+	int gz_wfd;
+	pthread_t gz_thr;
+	int gz_started;
 };
 
 int msh_is_bam(const msh_in *in) { return in->is_bam; }
@@ -1376,6 +1385,80 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 	return total;
 }
 
+#define PRE_MAX 65536
+/* the first bytes a gzip stream inflates to (at most n_out), from its first n_in bytes; returns how many came out */
+static size_t gz_peek(const uint8_t *in_bytes, size_t n_in, uint8_t *out, size_t n_out) {
+	z_stream zs;
+	size_t got = 0;
+	memset(&zs, 0, sizeof zs);
+	if (inflateInit2(&zs, 15 + 32) != Z_OK) return 0;
+	zs.next_in = (Bytef *)in_bytes; zs.avail_in = (uInt)n_in;
+	zs.next_out = out; zs.avail_out = (uInt)n_out;
+	for (;;) {
+		const int rc = inflate(&zs, Z_SYNC_FLUSH);
+		got = n_out - zs.avail_out;
+		if (rc == Z_STREAM_END && got < n_out && zs.avail_in > 0) {      /* an empty member in front (BGZF allows them) */
+			if (inflateReset(&zs) != Z_OK) break;
+			continue;
+		}
+		break;
+	}
+	inflateEnd(&zs);
+	return got;
+}
+
+static void gz_write_all(int fd, const uint8_t *p, size_t n) {
+	while (n) {
+		const ssize_t k = write(fd, p, n);
+		if (k < 0 && errno == EINTR) continue;
+		if (k <= 0) mDie("Write failed");            /* (the reading end is this process's own: it never goes away first) */
+		p += k; n -= (size_t)k;
+	}
+}
+
+/* compressed SAM text: every gzip member of the stream (plain gzip has one, bgzip one per block), inflated into the pipe */
+static void *gz_text_main(void *arg) {
+	msh_in *in = (msh_in *)arg;
+	const int fd = fileno(in->gz_src);
+	const size_t ICAP = (size_t)1 << 20, OCAP = (size_t)4 << 20;
+	uint8_t *ibuf = (uint8_t *)malloc(ICAP), *obuf = (uint8_t *)malloc(OCAP);
+	z_stream zs;
+	int at_member_start = 1, eof = 0;
+	if (!ibuf || !obuf) mDie("Out of memory");
+	memset(&zs, 0, sizeof zs);
+	if (inflateInit2(&zs, 15 + 32) != Z_OK) mDie("inflateInit2 failed");
+	zs.next_in = in->pre; zs.avail_in = (uInt)in->npre;
+	for (;;) {
+		if (zs.avail_in == 0 && !eof) {
+			ssize_t k;
+			do k = read(fd, ibuf, ICAP); while (k < 0 && errno == EINTR);
+			if (k < 0) mDie("Read failed");
+			if (k == 0) eof = 1;
+			zs.next_in = ibuf; zs.avail_in = (uInt)k;
+		}
+		if (zs.avail_in == 0 && eof) {
+			if (!at_member_start) mDie("Truncated gzip stream in SAM input");
+			break;
+		}
+		zs.next_out = obuf; zs.avail_out = (uInt)OCAP;
+		{
+			const int rc = inflate(&zs, Z_NO_FLUSH);
+			if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) mDie("Corrupt gzip stream in SAM input (%s)", zs.msg ? zs.msg : "zlib error");
+			at_member_start = 0;
+			gz_write_all(in->gz_wfd, obuf, OCAP - zs.avail_out);
+			if (rc == Z_STREAM_END) {                    /* the next member, if any */
+				if (inflateReset(&zs) != Z_OK) mDie("inflateReset failed");
+				at_member_start = 1;
+			}
+		}
+	}
+	inflateEnd(&zs);
+	free(ibuf);
+	free(obuf);
+	close(in->gz_wfd);
+	return NULL;
+}
+
 msh_in *msh_open(const char *path) {
 	msh_in *in = (msh_in *)calloc(1, sizeof(*in));
 	int c0, c1;
@@ -1400,6 +1483,36 @@ msh_in *msh_open(const char *path) {
 		if (!in->is_bam) {
 			if (c1 != EOF) ungetc(c1, in->fp);
 			if (c0 != EOF) ungetc(c0, in->fp);   /* two-byte pushback works on glibc full-buffered streams */
+		} else {
+			/* a gzip stream: BAM (BGZF whose first bytes inflate to "BAM\1") or compressed SAM text, which htslib's sam_open
+			 * reads like any other SAM (msam_helper.c:203-215 opens with "r" / "rb" and lets it detect the format) */
+			uint8_t head[4];
+			in->pre = (uint8_t *)malloc(PRE_MAX);
+			if (!in->pre) mDie("Out of memory");
+			in->pre[0] = 0x1f; in->pre[1] = 0x8b;
+			in->npre = 2;
+			while (in->npre < PRE_MAX) {
+				ssize_t k = read(fileno(in->fp), in->pre + in->npre, PRE_MAX - in->npre);
+				if (k < 0 && errno == EINTR) continue;
+				if (k <= 0) break;
+				in->npre += (size_t)k;
+			}
+			const size_t nh = gz_peek(in->pre, in->npre, head, 4);
+			if (nh >= 1 && !(nh == 4 && memcmp(head, "BAM\1", 4) == 0)) {
+				int pfd[2];
+				if (pipe(pfd) != 0) mDie("pipe failed");
+#ifdef F_SETPIPE_SZ
+				(void)fcntl(pfd[1], F_SETPIPE_SZ, 1 << 20);
+#endif
+				in->is_bam = 0;
+				in->gz_src = in->fp;
+				in->gz_wfd = pfd[1];
+				in->fp = fdopen(pfd[0], "rb");
+				if (!in->fp) mDie("fdopen failed");
+				setvbuf(in->fp, NULL, _IOFBF, (size_t)4 << 20);
+				if (pthread_create(&in->gz_thr, NULL, gz_text_main, in) != 0) mDie("pthread_create failed");
+				in->gz_started = 1;
+			}
 		}
 	}
 	if (in->is_bam) {
@@ -1423,7 +1536,8 @@ msh_in *msh_open(const char *path) {
 			in->bz.ccap = (size_t)BGZF_BATCH * (BGZF_MAX + 1024);
 			in->bz.fd = fileno(in->fp);
 			in->bz.cur = -1;
-			in->bz.rd_prefill = 2;                              /* the two bytes looked at above */
+			in->bz.rd_prefill = in->npre;                       /* the bytes looked at above */
+			in->bz.rd_pre = in->pre;
 #ifdef F_SETPIPE_SZ
 			(void)fcntl(fileno(in->fp), F_SETPIPE_SZ, 1 << 20);      /* a pipe from `msamtools filter -bu`: fewer, larger reads */
 #endif
@@ -1504,6 +1618,17 @@ int msh_read(msh_in *in, kstr *rec) {
 void msh_close(msh_in *in) {
 	int i;
 	if (!in) return;
+	if (in->gz_started) {
+		/* an input read to its end: the decompressor has closed its side and returns.  One left earlier still has text to
+		 * hand over: neither end of its pipe is closed under it (a write into a closed pipe is a signal) -- the process is on
+		 * its way out in that case */
+		if (in->text_eof || feof(in->fp)) {
+			pthread_join(in->gz_thr, NULL);
+			if (in->gz_src && in->gz_src != stdin) fclose(in->gz_src);
+		} else {
+			in->fp = NULL;
+		}
+	}
 	if (in->fp && in->fp != stdin) fclose(in->fp);
 	if (__atomic_load_n(&g_n2t.owner, __ATOMIC_ACQUIRE) == &in->hdr) {      /* (no thread parses this input any more) */
 		pthread_mutex_lock(&g_n2t.mu);
@@ -1525,6 +1650,7 @@ void msh_close(msh_in *in) {
 	free(in->bz.span);
 	free(in->line);
 	free(in->pending.s);
+	free(in->pre);
 	free(in);
 }
 

@@ -89,3 +89,40 @@ def test_sam_text_with_many_references_is_not_a_linear_probe_per_record(tmp_path
     # and through the decode stage's parallel parser
     out = subprocess.check_output([DEV, "pipetest", "1", "1", sam], env=dict(os.environ, MSX_THREADS="8")).decode().split("\n")
     assert out[0].split()[1:5] == out[1].split()[1:5]
+
+
+def test_compressed_sam_text_is_read_like_sam_text(tmp_path):
+    """htslib's sam_open detects the format: gzip- and bgzip-compressed SAM text are read like plain SAM (the reference opens
+    with "r" / "rb" and leaves the rest to it, msam_helper.c:203-215).  A decompressor thread feeds the text readers: one gzip
+    member, one member per BGZF block, several members back to back, from a file and from a pipe -- every byte of every record
+    as from the plain text; a stream cut inside a member or damaged is fatal, not a shorter input."""
+    import gzip as gz
+    bam, sam = str(tmp_path / "a.bam"), str(tmp_path / "a.sam")
+    with open(bam, "wb") as fh:
+        subprocess.check_call([DEV, "synth", "--groups", "5000", "--refs", "60", "-b", "--seq"], stdout=fh)
+    with open(sam, "wb") as fh:
+        subprocess.check_call([DEV, "recode", "-h", bam], stdout=fh)
+    text = open(sam, "rb").read()
+    want = digest("--full", sam)
+    forms = {"one_member.sam.gz": gz.compress(text, 6), "bgzip.sam.gz": bgzf_blocks(text),
+             "three_members.sam.gz": gz.compress(text[:1000], 1) + gz.compress(text[1000:70001], 9) + gz.compress(text[70001:], 6)}
+    for name, data in forms.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        assert digest("--full", path) == want, name
+        out = subprocess.run(f"cat {path} | {DEV} digest --full /dev/stdin", shell=True, stdout=subprocess.PIPE).stdout.decode().split()
+        assert (int(out[0].split("=")[1]), out[1].split("=")[1]) == want, name
+        # the decode stage's parallel parser on the same stream
+        o = subprocess.check_output([DEV, "pipetest", "1", "1", path], env=dict(os.environ, MSX_THREADS="6", MSX_SAM_CHUNK="50000")).decode().split("\n")
+        assert o[0].split()[1:5] == o[1].split()[1:5], name
+    # BAM is still BAM (a QNAME or header that begins with 'B' does not make text of it, nor the reverse)
+    assert digest(bam)[0] == want[0]
+    cut = str(tmp_path / "cut.sam.gz")
+    open(cut, "wb").write(forms["one_member.sam.gz"][:-3000])
+    r = subprocess.run([DEV, "digest", cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"gzip stream" in r.stderr
+    bad = bytearray(forms["one_member.sam.gz"])
+    bad[len(bad) // 2] ^= 0x55
+    open(cut, "wb").write(bytes(bad))
+    r = subprocess.run([DEV, "digest", cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0

@@ -229,6 +229,35 @@ def test_cli_orderly_shutdown(tmp_path, synth_bams, cmd):
     assert a.stdout == b.stdout
 
 
+@pytest.mark.gpu
+def test_cli_reads_compressed_sam_text(tmp_path, synth_bams):
+    """`filter` and `profile` on gzip- and bgzip-compressed SAM text, named or on stdin, with -S and without (htslib detects
+    the format either way: validate_profiles.py:735-751 feeds .sam without -S): what the plain text gives."""
+    import gzip as gz
+    sam = str(tmp_path / "in.sam")
+    with open(sam, "wb") as fh:
+        fh.write(run(["recode", "-h", synth_bams["b"]]).stdout)
+    text = open(sam, "rb").read()
+    gzp, bgz = str(tmp_path / "in.sam.gz"), str(tmp_path / "in.bgz.sam.gz")
+    open(gzp, "wb").write(gz.compress(text, 5))
+    from test_cli_scale import bgzf_blocks
+    open(bgz, "wb").write(bgzf_blocks(text))
+    filt = ["filter", "-l", "80", "-p", "95", "-z", "80", "--besthit"]
+    want = run(filt + ["-S", sam])
+    assert want.returncode == 0 and len(want.stdout) > 10000
+    for path in (gzp, bgz):
+        for s_flag in (["-S"], []):
+            r = run(filt + s_flag + [path], env={"MSX_SAM_CHUNK": "300000"})
+            assert r.returncode == 0 and r.stdout == want.stdout, (path, s_flag, r.stderr.decode()[-300:])
+        r = run(filt + ["-S", "-"], stdin=open(path, "rb").read())
+        assert r.returncode == 0 and r.stdout == want.stdout, path
+    a, b = str(tmp_path / "a.gz"), str(tmp_path / "b.gz")
+    assert run(["profile", "-S", "--label", "S", "-o", a, sam]).returncode == 0
+    assert run(["profile", "--label", "S", "-o", b, "-"], stdin=open(gzp, "rb").read()).returncode == 0
+    text_of = lambda p: [l for l in gzip.open(p, "rt").read().split("\n") if not l.startswith("# Command")]
+    assert text_of(a) == text_of(b)
+
+
 def read_profile(path):
     text = gzip.open(path, "rt").read()
     head = [l for l in text.split("\n") if l.startswith("#")]
