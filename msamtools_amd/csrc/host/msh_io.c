@@ -1483,6 +1483,15 @@ msh_in *msh_open(const char *path) {
 		if (!in->is_bam) {
 			if (c1 != EOF) ungetc(c1, in->fp);
 			if (c0 != EOF) ungetc(c0, in->fp);   /* two-byte pushback works on glibc full-buffered streams */
+			if (c0 == 'C' && c1 == 'R') {
+				/* htslib would read CRAM here (given the reference sequences); this reader has BAM and SAM text only -- said,
+				 * instead of a complaint about the fields of a "SAM line" (a CRAM file begins "CRAM", then a binary version) */
+				int c[5], k, nc = 0;
+				while (nc < 5 && (c[nc] = getc(in->fp)) != EOF) nc++;
+				if (nc == 5 && c[2] == 'A' && c[3] == 'M' && c[4] >= 1 && c[4] <= 4)
+					mDie("%s is a CRAM file: CRAM input is not supported (samtools view -b makes BAM of it)", path);
+				for (k = nc - 1; k >= 0; k--) ungetc(c[k], in->fp);
+			}
 		} else {
 			/* a gzip stream: BAM (BGZF whose first bytes inflate to "BAM\1") or compressed SAM text, which htslib's sam_open
 			 * reads like any other SAM (msam_helper.c:203-215 opens with "r" / "rb" and lets it detect the format) */

@@ -126,3 +126,16 @@ def test_compressed_sam_text_is_read_like_sam_text(tmp_path):
     open(cut, "wb").write(bytes(bad))
     r = subprocess.run([DEV, "digest", cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0
+
+
+def test_cram_is_named_not_misparsed(tmp_path):
+    """htslib reads CRAM; this reader does not, and says so (a QNAME that begins "CR" is still a QNAME)."""
+    cram = tmp_path / "x.cram"
+    cram.write_bytes(b"CRAM\x03\x00" + bytes(200))
+    r = subprocess.run([DEV, "digest", str(cram)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"CRAM input is not supported" in r.stderr
+    sam = tmp_path / "cr.sam"
+    sam.write_text("CRR1\t0\t*\t0\t0\t*\t*\t0\t0\t*\t*\n")
+    assert digest(str(sam))[0] == 1
+    out = subprocess.run(f"cat {sam} | {DEV} digest /dev/stdin", shell=True, stdout=subprocess.PIPE).stdout.decode()
+    assert out.startswith("records=1 ")
