@@ -1142,8 +1142,11 @@ struct msh_in {
 	int gz_wfd;
 	pthread_t gz_thr;
 	int gz_started;
+	int gz_err;          /* the decompressor gave up: gz_errmsg says why (set before it closes the pipe) */
+	char gz_errmsg[200];
 };
 
+static void gz_text_check(msh_in *in);
 int msh_is_bam(const msh_in *in) { return in->is_bam; }
 
 /* ensure at least n unconsumed bytes in the span (BAM); returns 0 if EOF comes first */
@@ -1342,7 +1345,7 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 		if (!in->text_eof) {
 			const size_t got = fread(in->tbuf + in->tlen, 1, SAM_CHUNK, in->fp);
 			in->tlen += got;
-			if (got < SAM_CHUNK) in->text_eof = 1;
+			if (got < SAM_CHUNK) { in->text_eof = 1; gz_text_check(in); }
 		}
 		if (in->tlen == 0) return 0;
 		/* the chunk ends behind its last newline; at the end of the input the rest is a line as well */
@@ -1432,25 +1435,35 @@ static void *gz_text_main(void *arg) {
 		if (zs.avail_in == 0 && !eof) {
 			ssize_t k;
 			do k = read(fd, ibuf, ICAP); while (k < 0 && errno == EINTR);
-			if (k < 0) mDie("Read failed");
+			if (k < 0) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Read failed"); goto fail; }
 			if (k == 0) eof = 1;
 			zs.next_in = ibuf; zs.avail_in = (uInt)k;
 		}
 		if (zs.avail_in == 0 && eof) {
-			if (!at_member_start) mDie("Truncated gzip stream in SAM input");
+			if (!at_member_start) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Truncated gzip stream in SAM input"); goto fail; }
 			break;
 		}
 		zs.next_out = obuf; zs.avail_out = (uInt)OCAP;
 		{
 			const int rc = inflate(&zs, Z_NO_FLUSH);
-			if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) mDie("Corrupt gzip stream in SAM input (%s)", zs.msg ? zs.msg : "zlib error");
+			if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
+				snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Corrupt gzip stream in SAM input (%s)", zs.msg ? zs.msg : "zlib error");
+				goto fail;
+			}
 			at_member_start = 0;
 			gz_write_all(in->gz_wfd, obuf, OCAP - zs.avail_out);
 			if (rc == Z_STREAM_END) {                    /* the next member, if any */
-				if (inflateReset(&zs) != Z_OK) mDie("inflateReset failed");
+				if (inflateReset(&zs) != Z_OK) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "inflateReset failed"); goto fail; }
 				at_member_start = 1;
 			}
 		}
+	}
+	if (0) {
+fail:
+		/* Not mDie from here: it flushes every stream, and the reader sits inside a read of the pipe's stream with that
+		 * stream's lock held, waiting for bytes this thread would never send -- a deadlock (found by the damaged-input test).
+		 * The reason is left for the reader, which sees the end of the pipe next and dies with it (gz_text_check). */
+		__atomic_store_n(&in->gz_err, 1, __ATOMIC_RELEASE);
 	}
 	inflateEnd(&zs);
 	free(ibuf);
@@ -1458,6 +1471,12 @@ static void *gz_text_main(void *arg) {
 	close(in->gz_wfd);
 	return NULL;
 }
+
+/* at the end of the text: was it the stream's end, or the decompressor's? */
+static void gz_text_check(msh_in *in) {
+	if (in->gz_started && __atomic_load_n(&in->gz_err, __ATOMIC_ACQUIRE)) mDie("%s", in->gz_errmsg);
+}
+
 
 msh_in *msh_open(const char *path) {
 	msh_in *in = (msh_in *)calloc(1, sizeof(*in));
@@ -1582,6 +1601,7 @@ msh_in *msh_open(const char *path) {
 			ks_put(&in->hdr.text, in->line, (size_t)n);
 			if (in->line[n - 1] != '\n') ks_putc(&in->hdr.text, '\n');
 		}
+		if (n <= 0) gz_text_check(in);
 		hdr_targets_from_text(&in->hdr);
 	}
 	return in;
@@ -1613,7 +1633,7 @@ int msh_read(msh_in *in, kstr *rec) {
 				n = (ssize_t)in->pending.l;
 			} else {
 				n = getline(&in->line, &in->line_cap, in->fp);
-				if (n <= 0) return -1;
+				if (n <= 0) { gz_text_check(in); return -1; }
 				ln = in->line;
 			}
 			while (n > 0 && (ln[n - 1] == '\n' || ln[n - 1] == '\r')) ln[--n] = 0;

@@ -66,3 +66,33 @@ def test_damaged_records_are_fatal_errors_not_overreads(tmp_path):
                 assert err.startswith("Fatal Error: "), err[-300:]
                 seen.add(err.split("(")[0][:40])
     assert any("Corrupt BAM record" in s for s in seen) and any("Truncated BAM record" in s for s in seen), seen
+
+
+def test_damaged_compressed_sam_text_ends_the_run(tmp_path):
+    """gzip-compressed SAM text cut anywhere or with a byte flipped: the run ends -- a fatal error or, where the damage leaves a
+    valid stream of valid lines, a result -- within seconds, never a hang between the decompressor thread and the reader and
+    never a signal (the thread writes into a pipe the reader owns)."""
+    import gzip as gz
+    bam, sam = tmp_path / "a.bam", tmp_path / "a.sam"
+    with open(bam, "wb") as fh:
+        subprocess.check_call([DEV, "synth", "--groups", "1500", "--refs", "30", "-b"], stdout=fh)
+    with open(sam, "wb") as fh:
+        subprocess.check_call([DEV, "recode", "-h", str(bam)], stdout=fh)
+    text = open(sam, "rb").read()
+    members = gz.compress(text[:len(text) // 2], 6) + gz.compress(text[len(text) // 2:], 6)
+    rng = random.Random(77)
+    outcomes = set()
+    for it in range(40):
+        d = bytearray(members)
+        if it % 2:
+            d = d[:rng.randrange(20, len(d))]
+        else:
+            d[rng.randrange(12, len(d))] ^= 1 << rng.randrange(8)
+        path = tmp_path / "m.sam.gz"
+        path.write_bytes(bytes(d))
+        for cmd in ([DEV, "digest", str(path)], [DEV, "pipetest", "1", "1", str(path)]):
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=20,
+                               env=dict(os.environ, MSX_THREADS="4", MSX_SAM_CHUNK="20000"))
+            assert r.returncode in (0, 1), (it, cmd[1], r.returncode, r.stderr[-300:])
+            outcomes.add(r.returncode)
+    assert 1 in outcomes
