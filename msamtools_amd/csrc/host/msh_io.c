@@ -34,8 +34,10 @@ void mDie(const char *fmt, ...) {
 	fprintf(stderr, "\n");
 	/* a fatal error raised on a worker, reader, writer or device thread: the other threads are still running (a
 	 * device thread may be inside the HIP runtime, which exit()'s handlers would tear down under it) -- leave at
-	 * once, with the diagnostic and everything written so far flushed */
-	fflush(NULL);
+	 * once, with the diagnostic and everything written so far flushed.  The only output streams are stdout (flushed above)
+	 * and stderr; NOT fflush(NULL): that locks every open stream in turn, the input's among them, and a reader sitting in a
+	 * read of a pipe holds its stream's lock for as long as the other end is silent -- the error would wait with it */
+	fflush(stderr);
 	if (msh_main_thread_set) _exit(EXIT_FAILURE);       /* (the command line: device, reader or writer threads may be running) */
 	exit(EXIT_FAILURE);
 }

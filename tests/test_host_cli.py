@@ -258,6 +258,32 @@ def test_cli_reads_compressed_sam_text(tmp_path, synth_bams):
     assert text_of(a) == text_of(b)
 
 
+@pytest.mark.gpu
+def test_cli_fatal_error_does_not_wait_for_a_silent_producer(tmp_path):
+    """A fatal record found on the device while the reader sits in a read of a pipe whose other end has gone silent: the
+    command dies with the reference's message at once (msam_filter.c:150-152).  mDie used to fflush(NULL) -- which locks every
+    stream, the input's too, and that lock is held for as long as the read waits -- so the error waited for the producer."""
+    import time
+    text = tmp_path / "in.sam"                 # sent in one go (the silence must begin before the device has seen batch 0)
+    text.write_text("@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:r1\tLN:1000\n" +
+                    "".join(f"q{i:07d}\t0\tr1\t10\t255\t10M\t*\t0\t0\t*\t*\tAS:i:5\n" for i in range(200000)))
+    script = tmp_path / "slow.sh"
+    script.write_text(f"#!/bin/bash\ncat {text}\nsleep 25\n")
+    prod = subprocess.Popen(["bash", str(script)], stdout=subprocess.PIPE)
+    t0 = time.time()
+    cons = subprocess.Popen([BIN, "filter", "-S", "-p", "95", "-"], stdin=prod.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, MSX_SAM_CHUNK="1000000", MSX_BATCH_BYTES="2000000"))    # (a batch is cut by bytes: 96 MB by default)
+    prod.stdout.close()
+    try:
+        _, err = cons.communicate(timeout=120)
+        took = time.time() - t0
+    finally:
+        prod.kill()
+        prod.wait()
+    assert cons.returncode == 1 and b"Fatal Error" in err, err[-300:]
+    assert took < 15, took                                   # (the producer would have gone on sleeping until 25 s)
+
+
 def read_profile(path):
     text = gzip.open(path, "rt").read()
     head = [l for l in text.split("\n") if l.startswith("#")]
