@@ -1556,9 +1556,15 @@ msh_in *msh_open(const char *path) {
 			    !getenv("MSX_NO_MMAP")) {
 				void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(in->fp), 0);
 				if (m != MAP_FAILED) {
+					static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+					                                      0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 					in->bz.map = (const uint8_t *)m;
 					in->bz.map_len = (size_t)sb.st_size;
 					(void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+					/* htslib looks for the BGZF end-of-file marker of a seekable BAM when it reads the header and warns if it is
+					 * missing (the reference's stderr then carries this line); the records are read all the same */
+					if (sb.st_size < 28 || memcmp(in->bz.map + sb.st_size - 28, eof_block, 28) != 0)
+						fprintf(stderr, "[W::bam_hdr_read] EOF marker is absent. The input is probably truncated\n");
 				}
 			}
 		}

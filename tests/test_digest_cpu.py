@@ -139,3 +139,20 @@ def test_cram_is_named_not_misparsed(tmp_path):
     assert digest(str(sam))[0] == 1
     out = subprocess.run(f"cat {sam} | {DEV} digest /dev/stdin", shell=True, stdout=subprocess.PIPE).stdout.decode()
     assert out.startswith("records=1 ")
+
+
+def test_missing_eof_marker_is_htslibs_warning(tmp_path):
+    """A seekable BAM without the BGZF end-of-file block: htslib warns when it reads the header and reads on (bgzf_check_EOF in
+    bam_hdr_read); so does this reader, with that line; a pipe is not looked at."""
+    bam = tmp_path / "a.bam"
+    with open(bam, "wb") as fh:
+        subprocess.check_call([DEV, "synth", "--groups", "500", "--refs", "20", "-b"], stdout=fh)
+    whole = bam.read_bytes()
+    cut = tmp_path / "noeof.bam"
+    cut.write_bytes(whole[:-28])
+    a = subprocess.run([DEV, "digest", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([DEV, "digest", str(cut)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout
+    assert a.stderr == b"" and b.stderr == b"[W::bam_hdr_read] EOF marker is absent. The input is probably truncated\n"
+    c = subprocess.run(f"cat {cut} | {DEV} digest /dev/stdin", shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.stdout == a.stdout and c.stderr == b""
