@@ -207,7 +207,9 @@ extern "C" void msx_ctx_destroy(msx_ctx *ctx) {
 	msx_buf *bufs[] = {&ctx->pool_code, &ctx->gcount, &ctx->gbase, &ctx->scan_l1, &ctx->scan_l2,
 	                   &ctx->scan_l3, &ctx->pinfo, &ctx->moff, &ctx->tmp_fid, &ctx->ukey2,
 	                   &ctx->cv_key[0], &ctx->cv_key[1], &ctx->cv_hist, &ctx->cv_off, &ctx->cv_start, &ctx->cv_side, &ctx->cv_targets, &ctx->cvc_items, &ctx->cvc_sups, &ctx->df_slots, &ctx->df_size,
-	                   &ctx->df_tok};
+	                   &ctx->df_tok,
+	                   &ctx->inf[0].matches, &ctx->inf[0].retry, &ctx->inf[1].matches, &ctx->inf[1].retry, &ctx->inf[2].matches, &ctx->inf[2].retry,
+	                   &ctx->inf[3].matches, &ctx->inf[3].retry};
 	for (auto *b : bufs) free_buf(b);
 	if (ctx->d_status) (void)hipFree(ctx->d_status);
 	if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -220,7 +220,8 @@ __device__ __forceinline__ void if_flush(IfShared &S, IfState &T, uint8_t *og, u
 
 // Canonical Huffman code of S.lens[base, base + nsym) into a primary table of `root` bits and the per-length arrays
 // of the canonical route.  which: 0 literal/length, 1 distance.  Returns 0 if the lengths are refused.
-__device__ __forceinline__ uint32_t if_build(IfShared &S, uint32_t which, uint32_t base, uint32_t nsym, uint32_t lane) {
+template <class SH>
+__device__ __forceinline__ uint32_t if_build(SH &S, uint32_t which, uint32_t base, uint32_t nsym, uint32_t lane) {
 	uint32_t *tab = which ? S.dt : S.ll;
 	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
 	const uint32_t tsize = 1u << root;
@@ -275,7 +276,8 @@ __device__ __forceinline__ uint32_t if_build(IfShared &S, uint32_t which, uint32
 }
 
 // a code longer than the primary table's index: the canonical route.  Returns the entry (with its length), 0 if none.
-__device__ __forceinline__ uint32_t if_long(IfShared &S, uint32_t which, uint32_t bits15) {
+template <class SH>
+__device__ __forceinline__ uint32_t if_long(SH &S, uint32_t which, uint32_t bits15) {
 	const uint32_t c15 = __brev(bits15) >> 17;
 	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
 	for (uint32_t len = root + 1u; len <= 15u; len++) {
@@ -291,13 +293,16 @@ __device__ __forceinline__ uint32_t if_long(IfShared &S, uint32_t which, uint32_
 	return 0u;
 }
 
-template <int DBG, bool VEC>
+template <int DBG>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, size_t comp_len,
                                                      const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
-                                                     uint32_t *__restrict__ ticket, uint32_t *__restrict__ stats) {
+                                                     uint32_t *__restrict__ ticket, uint32_t *__restrict__ stats,
+                                                     const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n) {
 	__shared__ IfShared S;
 	const uint32_t lane = threadIdx.x;
+	// list: only the blocks k_bgzf_inflate_par handed back (list_n of them, written by that kernel)
+	if (list) n_blocks = IFU(*list_n);
 	// the launch holds as many waves as are to run at a time; each takes block after block
 	for (;;) {
 	uint32_t n_lit = 0u, n_match = 0u, n_far = 0u, n_dyn = 0u;      // (MSX_INFLATE_STATS: what the blocks are made of)
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 	if (lane == 0) bi = atomicAdd(ticket, 1u);
 	bi = IFU(bi);
 	if (bi >= n_blocks) return;
+	if (list) bi = IFU(list[bi]);
 	const msx_bgzf_block B = blk[bi];
 	uint8_t *og = out + B.out_off;
 	const uint32_t out_len = B.out_len;
@@ -448,91 +454,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 			// the input ring is due (a symbol takes two words at most).  Anything else -- a long literal/length code, the
 			// end of the block, the output's end, a chunk boundary -- leaves it in front of the symbol for the general step
 			// below; only errors leave it inside a symbol.
-			if (VEC && T.cross > T.ip + 2u) {
-				// ---- the same loop on the VECTOR unit (round 4).  The bit buffer, its count and the read position are wave-
-				// uniform values, so the compiler keeps them in scalar registers and the scalar unit does the arithmetic: 55
-				// scalar instructions per symbol, and a compute unit has ONE scalar unit for all its waves -- it saturates at
-				// 12 of the 14 waves the LDS holds (profiles/round3/inflate_summary.json).  Here the same values live in vector
-				// registers (laundered through v_mov so that no analysis moves them back): shifts, masks and the refill are
-				// VALU instructions -- four SIMDs per compute unit issue them side by side -- the refill is a select instead of a
-				// branch, and only what a branch or a copy loop needs crosses to the scalar side (one v_readfirstlane of the
-				// table entry per symbol, two more for a match's length and distance).  The loop runs for as many symbols as
-				// cannot reach the input ring's next refill (a symbol takes two words at most), so the read position needs no
-				// test; a symbol the primary tables do not hold, or an error, puts the state back in front of the symbol and
-				// leaves it to the scalar loops below.
-#define IF_TO_V(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
-#define IF_VREFILL() do { const bool take_ = vcnt <= 32; vb |= take_ ? (uint64_t)w << vcnt : 0ull; vcnt += take_ ? 32 : 0;     \
-				                  vip += take_ ? 1u : 0u; w = S.in[vip & (IF_IN_DW - 1u)]; } while (0)
-				uint32_t vlo, vhi, vip, vc_;
-				IF_TO_V(vlo, (uint32_t)T.buf); IF_TO_V(vhi, (uint32_t)(T.buf >> 32)); IF_TO_V(vc_, (uint32_t)T.cnt); IF_TO_V(vip, T.ip);
-				uint64_t vb = (uint64_t)vhi << 32 | vlo;
-				int32_t vcnt = (int32_t)vc_;
-				const uint32_t lim = T.flushed + IF_FLUSH < out_len ? T.flushed + IF_FLUSH : out_len;
-				for (uint32_t budget = (T.cross - T.ip - 2u) / 2u; budget != 0u && T.pos < lim; budget--) {
-					const uint32_t e = ev, es = IFU(e);
-					if (es & (IF_LIT << 4)) {
-						const uint32_t n = e & 15u;
-						vb >>= n; vcnt -= (int32_t)n;
-						IF_VREFILL();
-						ev = S.ll[(uint32_t)vb & ((1u << IF_LL_ROOT) - 1u)];
-						S.ring[IF_RI(T.pos)] = (uint8_t)(es >> 16);          // (every lane the same byte to the same place)
-						T.pos++;
-						if (DBG == 4) n_lit++;
-						continue;
-					}
-					if (((es >> 4) & 15u) != IF_BASE) break;
-					const uint64_t vb0 = vb;
-					const int32_t vcnt0 = vcnt;
-					const uint32_t vip0 = vip, w0 = w;
-					uint32_t n = e & 15u;
-					vb >>= n; vcnt -= (int32_t)n;
-					const uint32_t xl = (e >> 8) & 15u;
-					const uint32_t vlen = (e >> 16) + ((uint32_t)vb & ((1u << xl) - 1u));
-					vb >>= xl; vcnt -= (int32_t)xl;
-					IF_VREFILL();
-					const uint32_t d = S.dt[(uint32_t)vb & ((1u << IF_D_ROOT) - 1u)];
-					if (((IFU(d) >> 4) & 15u) != IF_BASE) { vb = vb0; vcnt = vcnt0; vip = vip0; w = w0; break; }
-					n = d & 15u;
-					vb >>= n; vcnt -= (int32_t)n;
-					const uint32_t xd = (d >> 8) & 15u;
-					const uint32_t vdist = (d >> 16) + ((uint32_t)vb & ((1u << xd) - 1u));
-					vb >>= xd; vcnt -= (int32_t)xd;
-					const uint32_t len = IFU(vlen), dist = IFU(vdist);
-					if (dist > T.pos || len > out_len - T.pos) { vb = vb0; vcnt = vcnt0; vip = vip0; w = w0; break; }
-					IF_VREFILL();
-					ev = S.ll[(uint32_t)vb & ((1u << IF_LL_ROOT) - 1u)];
-					const uint32_t from = T.pos - dist;
-					if (dist <= IF_NEAR) {
-						if (dist >= 64u || dist >= len) {
-							for (uint32_t b = 0; b < len; b += 64u) {
-								const uint32_t i = b + lane;
-								if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + i)];
-							}
-						} else {
-							const float rf = 1.0f / (float)dist;
-							for (uint32_t b = 0; b < len; b += 64u) {
-								const uint32_t i = b + lane;
-								const uint32_t q = (uint32_t)(((float)i + 0.5f) * rf);
-								if (i < len) S.ring[IF_RI(T.pos + i)] = S.ring[IF_RI(from + (i - q * dist))];
-							}
-						}
-					} else {
-						if (DBG == 4) n_far++;
-						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-						for (uint32_t b = 0; b < len; b += 64u) {
-							const uint32_t i = b + lane;
-							if (i < len) S.ring[IF_RI(T.pos + i)] = IF_FAR_LOAD(og + from + i);
-						}
-					}
-					T.pos += len;
-					if (DBG == 4) n_match++;
-				}
-				T.buf = (uint64_t)IFU((uint32_t)(vb >> 32)) << 32 | (uint64_t)IFU((uint32_t)vb);
-				T.cnt = (int32_t)IFU((uint32_t)vcnt);
-				T.ip = IFU(vip);
-#undef IF_VREFILL
-#undef IF_TO_V
-			}
 			{
 				uint32_t err = 0u;
 				for (;;) {
@@ -689,6 +610,493 @@ done:
 #undef IF_FAIL
 }
 
+
+// ---------------------------------------------------------------------------
+// The lane-parallel inflater (round 6)
+// ---------------------------------------------------------------------------
+// One wave per block, one symbol after the other, is a latency chain: a batch of the command line takes what ONE block
+// takes (3.5 ms per 64 KB), and the compute unit's scalar unit is busy with 55 instructions per symbol.  But Huffman decoding
+// self-synchronises: a decoder started at a wrong bit decodes garbage for a few symbols and then falls onto a true code
+// boundary, from where it IS the true chain.  So a deflate block's symbols are decoded by 256 lanes at once (the algorithm,
+// its passes and what it refuses are restated one lane after the other in msx_inflate_par_model.h, which the CPU tests run
+// against zlib):
+//   a workgroup of four waves per BGZF block; the block's WHOLE output lives in LDS (64 KB: every distance a match can have
+//   is an LDS address -- no ring, no far matches, no fences), two blocks per compute unit;
+//   segment   8 KB of the stream staged in LDS (skewed by one word per 32 so that lanes a whole number of words apart do not
+//             share a bank); lane L owns the tokens that begin in bits [seg + L * sub, seg + (L + 1) * sub), sub = 256;
+//   pass A    every lane walks its range from its first bit (lane 0: from the true position), counting bytes and matches;
+//   pass B    rounds: a lane whose left neighbour ended elsewhere than it started walks again from there; lanes behind the
+//             first one that stopped (end of block, no code, payload's end) sit out.  No change: converged.  Eight rounds
+//             without convergence (long tokens, few per lane: a BAM header's text): four times the bits per lane, again;
+//   pass C    exclusive sums of the counts place every lane in the output; the lanes walk a last time, literals go straight
+//             to their bytes in LDS, matches -- position, length, distance, 8 bytes -- to a list in global memory;
+//   resolve   256 matches at a time, one per thread: a match whose source reaches into the outputs of earlier matches of the
+//             window waits until exactly those are done (two binary searches over the window's positions, done bits by
+//             ballot), everything else copies at once, eight bytes in flight per thread (a self-overlapping match reads
+//             byte i mod distance: independent of its own stores);
+//   then the next segment, or the next deflate block's header (parsed by wave 0 on wave-uniform values, as the serial kernel
+//   does; the two tables built by waves 0 and 1 side by side), and at the end the block goes out as 16-byte vectors.
+// Whatever is wrong on the true chain hands the block to the serial kernel (IF_RETRY: a list of block numbers, a second
+// launch over it), whose verdict stands as before.
+#define IP_THREADS 256u
+#define IP_SEG_DW 2048u
+#define IP_SEG_BITS (IP_SEG_DW * 32u)
+#define IP_SUB0 256u
+#define IP_MAX_ROUNDS 8u
+#define IP_SKEW(d) ((d) + ((d) >> 5))
+#define IP_MATCH_CAP 21848u              // matches of one segment: at most a third of a block's bytes
+#define IF_RETRY 10u
+
+enum { IP_OK = 0u, IP_EOB = 1u, IP_BAD = 2u, IP_PAST = 3u, IP_DEAD = 4u };
+
+struct IpShared {
+	__attribute__((aligned(16))) uint8_t out[65536 + 16];
+	uint32_t ll[1 << IF_LL_ROOT];
+	uint32_t dt[1 << IF_D_ROOT];
+	uint32_t seg[IP_SKEW(IP_SEG_DW + 8u) + 1u];   // the staged stream; during resolve: the window's positions and ends
+	uint32_t lim[2][16], first[2][16];
+	uint16_t off[2][16];
+	union {
+		uint16_t sorted[320];
+		uint32_t pre[128];
+	};
+	uint8_t lens[352];
+	uint8_t pl[32];
+	uint32_t lend[IP_THREADS];             // a lane's end (24 bits) and state, for its right neighbour
+	uint32_t xw[16];                       // the waves' words: first stopped lane, sums, header fields
+	unsigned long long dmask[4];           // resolve: the waves' done bits
+};
+
+// a code longer than the primary table's index, per lane (if_long with nothing wave-uniform)
+__device__ __forceinline__ uint32_t ip_long(IpShared &S, uint32_t which, uint32_t bits15) {
+	const uint32_t c15 = __brev(bits15) >> 17;
+	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
+	for (uint32_t len = root + 1u; len <= 15u; len++) {
+		if (c15 < S.lim[which][len]) {
+			const uint32_t first = S.first[which][len];
+			if (c15 < first) return 0u;
+			const uint32_t sym = IF_SORTED(S, which)[S.off[which][len] + ((c15 - first) >> (15u - len))];
+			const uint32_t e = which ? if_d_entry(sym) : if_ll_entry(sym);
+			return e ? (e | len) : 0u;
+		}
+	}
+	return 0u;
+}
+
+struct IpLane { uint32_t end, nb, nm, st; };
+
+// A lane's walk (msx_inflate_par_model.h: ip_walk): tokens from bit `start` while they begin in front of `limit`.  Bit
+// positions count from the block's aligned base; seg[0] is word win_dw0 of it.  EMIT: pass C.
+template <bool EMIT>
+__device__ __forceinline__ IpLane ip_walk(IpShared &S, uint32_t start, uint32_t limit, uint32_t win_dw0, uint32_t end_bit,
+                                          uint32_t base, uint32_t rshift, uint2 *__restrict__ ml, uint32_t &bad_dist) {
+	uint32_t ip = (start >> 5) - win_dw0;
+	uint64_t buf = (uint64_t)S.seg[IP_SKEW(ip)] | (uint64_t)S.seg[IP_SKEW(ip + 1u)] << 32;
+	ip += 2u;
+	buf >>= (start & 31u);
+	int32_t cnt = 64 - (int32_t)(start & 31u);
+	IpLane r;
+	r.st = IP_OK; r.nb = 0u; r.nm = 0u;
+#define IP_AT() ((win_dw0 + ip) * 32u - (uint32_t)cnt)
+#define IP_REFILL() do { if (cnt <= 32) { buf |= (uint64_t)S.seg[IP_SKEW(ip)] << cnt; cnt += 32; ip++; } } while (0)
+#define IP_DROP(n) do { buf >>= (n); cnt -= (int32_t)(n); } while (0)
+	for (;;) {
+		const uint32_t at = IP_AT();
+		if (at >= limit) break;
+		if (at >= end_bit) { r.st = IP_PAST; break; }
+		IP_REFILL();
+		uint32_t e = S.ll[(uint32_t)buf & ((1u << IF_LL_ROOT) - 1u)];
+		if (((e >> 4) & 15u) == IF_LONG) e = ip_long(S, 0u, (uint32_t)buf & 0x7fffu);
+		const uint32_t kind = (e >> 4) & 15u;
+		if (kind == 0u) { r.st = IP_BAD; break; }
+		IP_DROP(e & 15u);
+		if (kind == IF_LIT) {
+			if (EMIT) S.out[rshift + base + r.nb] = (uint8_t)(e >> 16);
+			r.nb++;
+		} else if (kind == IF_EOB) {
+			r.st = IP_EOB;
+			break;
+		} else {
+			const uint32_t xl = (e >> 8) & 15u;
+			const uint32_t len = (e >> 16) + ((uint32_t)buf & ((1u << xl) - 1u));
+			IP_DROP(xl);
+			IP_REFILL();
+			uint32_t d = S.dt[(uint32_t)buf & ((1u << IF_D_ROOT) - 1u)];
+			if (((d >> 4) & 15u) == IF_LONG) d = ip_long(S, 1u, (uint32_t)buf & 0x7fffu);
+			if (((d >> 4) & 15u) != IF_BASE) { r.st = IP_BAD; break; }
+			IP_DROP(d & 15u);
+			const uint32_t xd = (d >> 8) & 15u;
+			const uint32_t dist = (d >> 16) + ((uint32_t)buf & ((1u << xd) - 1u));
+			IP_DROP(xd);
+			if (EMIT) {
+				const uint32_t p = base + r.nb;
+				if (dist > p) bad_dist = 1u;
+				ml[r.nm] = make_uint2(p | (len << 16), dist);
+			}
+			r.nm++;
+			r.nb += len;
+		}
+		if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
+	}
+	r.end = IP_AT();
+#undef IP_AT
+#undef IP_REFILL
+#undef IP_DROP
+	return r;
+}
+
+// the next IP_SEG_DW + 8 words of the stream from word w0 into seg[] (what lies behind the readable bytes: zeros)
+__device__ __forceinline__ void ip_stage(IpShared &S, const IfIn &I, uint32_t w0, uint32_t tid) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
+	for (uint32_t k = tid; k < IP_SEG_DW + 8u; k += IP_THREADS) {
+		const uint32_t d = w0 + k;
+		uint32_t v;
+		if (4u * (uint64_t)d + 4u <= I.n_bytes) v = I.g[d];
+		else v = if_edge_word(p, I.n_bytes, d);
+		S.seg[IP_SKEW(k)] = v;
+	}
+}
+
+__device__ __forceinline__ uint32_t ip_wave_incl(uint32_t v, uint32_t lane) {
+#pragma unroll
+	for (uint32_t d = 1u; d < 64u; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+		if (lane >= d) v += o;
+	}
+	return v;
+}
+
+__global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *__restrict__ comp, size_t comp_len,
+                                                                 const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
+                                                                 uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                                 uint32_t *__restrict__ ticket, uint2 *__restrict__ match_scratch,
+                                                                 uint32_t *__restrict__ retry_list, uint32_t *__restrict__ retry_n) {
+	__shared__ IpShared S;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	uint2 *const ml = match_scratch + (size_t)blockIdx.x * IP_MATCH_CAP;
+	uint32_t *const wpos = S.seg;                      // resolve: the window's match positions ...
+	uint32_t *const wend = S.seg + IP_THREADS + 1u;    // ... and ends (the staged stream is done with by then)
+	for (;;) {
+		if (tid == 0) S.xw[15] = atomicAdd(ticket, 1u);
+		__syncthreads();
+		const uint32_t bi = S.xw[15];
+		__syncthreads();
+		if (bi >= n_blocks) return;
+		const msx_bgzf_block B = blk[bi];
+		uint8_t *og = out + B.out_off;
+		const uint32_t out_len = B.out_len;
+		if (out_len == 0u) {
+			if (tid == 0) status[bi] = IF_OK;
+			continue;
+		}
+		IfIn I;
+		{
+			const uintptr_t p = (uintptr_t)(comp + B.in_off);
+			I.g = reinterpret_cast<const uint32_t *>(p & ~(uintptr_t)3);
+			const size_t from = (size_t)((const uint8_t *)I.g - comp);
+			const size_t avail = comp_len > from ? comp_len - from : 0u;
+			I.n_bytes = avail > 0xfffffff0u ? 0xfffffff0u : (uint32_t)avail;
+		}
+		const uint32_t skew = (uint32_t)((uintptr_t)(comp + B.in_off) & 3u);
+		const uint32_t end_bit = (skew + B.in_len) * 8u;
+		const uint32_t rshift = (uint32_t)((uintptr_t)og & 15u);
+		uint32_t at = skew * 8u;            // the stream's read position (bits from the aligned base): workgroup-uniform
+		uint32_t pos = 0u;                  // bytes produced
+		uint32_t fail = 0u;
+		bool last_block = false;
+		if (out_len > 65536u || B.in_len > 0x100000u) fail = IF_OUT_OVER;      // (not a BGZF block: the serial kernel's)
+		while (!fail && !last_block) {
+			// ---- a deflate block's header: wave 0, wave-uniform, off the staged stream ----
+			uint32_t win_dw0 = at >> 5;
+			ip_stage(S, I, win_dw0, tid);
+			__syncthreads();
+			if (wave == 0u) {
+				uint32_t hip_ = (at >> 5) - win_dw0;
+				uint64_t hb = (uint64_t)IFU(S.seg[IP_SKEW(hip_)]) | (uint64_t)IFU(S.seg[IP_SKEW(hip_ + 1u)]) << 32;
+				hip_ += 2u;
+				hb >>= (at & 31u);
+				int32_t hc = 64 - (int32_t)(at & 31u);
+#define IH_AT() ((win_dw0 + hip_) * 32u - (uint32_t)hc)
+#define IH_REFILL() do { if (hc <= 32) { hb |= (uint64_t)IFU(S.seg[IP_SKEW(hip_)]) << hc; hc += 32; hip_++; } } while (0)
+#define IH_PEEK(n) ((uint32_t)(hb & ((1ull << (n)) - 1ull)))
+#define IH_DROP(n) do { hb >>= (n); hc -= (int32_t)(n); } while (0)
+				uint32_t herr = 0u, hlit = 288u, hdist = 32u, stored_len = 0u;
+				const uint32_t lastb = IH_PEEK(1);
+				const uint32_t type = (uint32_t)(hb >> 1) & 3u;
+				IH_DROP(3);
+				do {
+					if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
+					if (type == 3u) { herr = IF_BAD_TYPE; break; }
+					if (type == 0u) {
+						IH_DROP((uint32_t)hc & 7u);
+						IH_REFILL();
+						stored_len = IH_PEEK(16);
+						IH_DROP(16);
+						const uint32_t nlen = IH_PEEK(16);
+						IH_DROP(16);
+						if ((stored_len ^ 0xffffu) != nlen) { herr = IF_BAD_STORED; break; }
+						if ((uint64_t)IH_AT() + 8ull * stored_len > end_bit) { herr = IF_IN_OVER; break; }
+						if (stored_len > out_len - pos) { herr = IF_OUT_OVER; break; }
+						break;
+					}
+					if (type == 1u) {
+						for (uint32_t s = lane; s < 320u; s += 64u)
+							S.lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 5u);
+						break;
+					}
+					IH_REFILL();
+					hlit = IH_PEEK(5) + 257u; IH_DROP(5);
+					hdist = IH_PEEK(5) + 1u; IH_DROP(5);
+					const uint32_t hclen = IH_PEEK(4) + 4u; IH_DROP(4);
+					if (hlit > 286u || hdist > 30u) { herr = IF_BAD_LENS; break; }
+					if (lane < 19u) S.pl[lane] = 0;
+					for (uint32_t i = 0; i < hclen; i++) {
+						IH_REFILL();
+						const uint32_t o = (uint32_t)((i < 12u ? IF_ORDER_LO >> (5u * i) : IF_ORDER_HI >> (5u * (i - 12u))) & 31ull);
+						if (lane == 0) S.pl[o] = (uint8_t)IH_PEEK(3);
+						IH_DROP(3);
+					}
+					if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
+					{
+						const uint32_t Lp = lane < 19u ? (uint32_t)S.pl[lane] : 0u;
+						uint32_t code = 0u, nxt = 0u;
+						int32_t left = 1;
+						const unsigned long long lt = (1ull << lane) - 1ull;
+						for (uint32_t len = 1; len <= 7u; len++) {
+							const unsigned long long b = __ballot(Lp == len);
+							const uint32_t cnt = (uint32_t)__popcll(b);
+							if (Lp == len) code = nxt + (uint32_t)__popcll(b & lt);
+							left = left * 2 - (int32_t)cnt;
+							nxt = (nxt + cnt) << 1;
+							if (left < 0) break;
+						}
+						if (left != 0) { herr = IF_BAD_LENS; break; }
+						S.pre[lane] = 0u; S.pre[lane + 64u] = 0u;
+						if (Lp) {
+							const uint32_t rev = __brev(code) >> (32u - Lp);
+							for (uint32_t k = rev; k < 128u; k += 1u << Lp) S.pre[k] = Lp | (lane << 8) | 0x10000u;
+						}
+					}
+					const uint32_t total = hlit + hdist;
+					uint32_t n = 0u, prev = 0u;
+					while (n < total) {
+						IH_REFILL();
+						const uint32_t e = IFU(S.pre[IH_PEEK(7)]);
+						if (!e) { herr = IF_BAD_CODE; break; }
+						IH_DROP(e & 0xffu);
+						const uint32_t sym = (e >> 8) & 0xffu;
+						if (sym < 16u) {
+							if (lane == 0) S.lens[n] = (uint8_t)sym;
+							prev = sym;
+							n++;
+						} else {
+							uint32_t rep, v = 0u;
+							if (sym == 16u) {
+								if (n == 0u) { herr = IF_BAD_LENS; break; }
+								v = prev;
+								rep = 3u + IH_PEEK(2); IH_DROP(2);
+							} else if (sym == 17u) {
+								rep = 3u + IH_PEEK(3); IH_DROP(3);
+								prev = 0u;
+							} else {
+								rep = 11u + IH_PEEK(7); IH_DROP(7);
+								prev = 0u;
+							}
+							if (n + rep > total) { herr = IF_BAD_LENS; break; }
+							for (uint32_t i = lane; i < rep; i += 64u) S.lens[n + i] = (uint8_t)v;
+							n += rep;
+						}
+						if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
+					}
+					if (!herr && S.lens[256] == 0) herr = IF_BAD_LENS;
+				} while (0);
+				if (lane == 0) {
+					S.xw[8] = herr; S.xw[9] = type; S.xw[10] = lastb; S.xw[11] = hlit; S.xw[12] = hdist;
+					S.xw[13] = IH_AT(); S.xw[14] = stored_len;
+				}
+#undef IH_AT
+#undef IH_REFILL
+#undef IH_PEEK
+#undef IH_DROP
+			}
+			__syncthreads();
+			if (S.xw[8]) { fail = S.xw[8]; break; }
+			const uint32_t type = S.xw[9], hlit = S.xw[11], hdist = S.xw[12];
+			last_block = S.xw[10] != 0u;
+			at = S.xw[13];
+			if (type == 0u) {
+				const uint32_t len = S.xw[14];
+				const uint8_t *src = reinterpret_cast<const uint8_t *>(I.g) + (at >> 3);
+				for (uint32_t i = tid; i < len; i += IP_THREADS) S.out[rshift + pos + i] = src[i];
+				pos += len;
+				at += 8u * len;
+				__syncthreads();
+				continue;
+			}
+			// the two tables side by side
+			uint32_t ok = 1u;
+			if (wave == 0u) ok = if_build(S, 0u, 0u, hlit, lane);
+			else if (wave == 1u) ok = if_build(S, 1u, hlit, hdist, lane);
+			if (__syncthreads_or(!ok)) { fail = IF_BAD_LENS; break; }
+			// ---- the block's symbols, segment by segment ----
+			uint32_t sub = IP_SUB0;
+			for (;;) {
+				const uint32_t seg0 = at;
+				uint32_t nl, used = 0u, limit = 0u;
+				IpLane r;
+				uint32_t dummy = 0u;
+				for (;;) {
+					// lanes of the segment: what the staged window holds behind seg0 (the last lane's range may be short)
+					const uint32_t win_end = win_dw0 * 32u + IP_SEG_BITS;
+					nl = (win_end - seg0 + sub - 1u) / sub;
+					if (nl > IP_THREADS) nl = IP_THREADS;
+					// pass A
+					used = seg0 + tid * sub;
+					limit = used + sub < win_end ? used + sub : win_end;
+					r.st = IP_DEAD; r.end = 0u; r.nb = 0u; r.nm = 0u;
+					if (tid < nl && (tid == 0u || used < end_bit)) r = ip_walk<false>(S, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+					// pass B
+					bool converged = false;
+					for (uint32_t rounds = 0u; rounds < IP_MAX_ROUNDS || nl == 1u; rounds++) {
+						S.lend[tid] = r.end | (r.st << 24);
+						const unsigned long long bal = __ballot(tid < nl && r.st != IP_OK);
+						if (lane == 0u) S.xw[wave] = bal ? 64u * wave + (uint32_t)__ffsll((unsigned long long)bal) - 1u : 0xffffu;
+						__syncthreads();
+						const uint32_t stop = min(min(S.xw[0], S.xw[1]), min(S.xw[2], S.xw[3]));
+						bool ch = false;
+						if (tid >= 1u && tid < nl && tid <= stop) {
+							const uint32_t ns = S.lend[tid - 1u] & 0xffffffu;
+							if (ns != used) { used = ns; ch = true; }
+						}
+						if (!__syncthreads_or(ch)) { converged = true; break; }
+						if (ch) r = ip_walk<false>(S, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+					}
+					if (converged) break;
+					sub *= 4u;
+				}
+				// the true chain's lanes: up to the first that stopped
+				const uint32_t stop = min(min(S.xw[0], S.xw[1]), min(S.xw[2], S.xw[3]));
+				const uint32_t lastl = stop < nl ? stop : nl - 1u;
+				const uint32_t le = S.lend[lastl];
+				const uint32_t st_last = le >> 24;
+				if (st_last != IP_OK && st_last != IP_EOB) { fail = st_last == IP_PAST ? IF_IN_OVER : IF_BAD_CODE; break; }
+				// exclusive sums of bytes and matches over the lanes of the chain
+				const uint32_t my_nb = tid <= lastl ? r.nb : 0u, my_nm = tid <= lastl ? r.nm : 0u;
+				const uint32_t inb = ip_wave_incl(my_nb, lane), inm = ip_wave_incl(my_nm, lane);
+				__syncthreads();                        // (lend / xw read above)
+				if (lane == 63u) { S.xw[wave] = inb; S.xw[4u + wave] = inm; }
+				__syncthreads();
+				uint32_t base = pos + inb - my_nb, mbase = inm - my_nm;
+				for (uint32_t w = 0; w < wave; w++) { base += S.xw[w]; mbase += S.xw[4u + w]; }
+				const uint32_t total = S.xw[0] + S.xw[1] + S.xw[2] + S.xw[3];
+				const uint32_t mtot = S.xw[4] + S.xw[5] + S.xw[6] + S.xw[7];
+				if (total > out_len - pos) { fail = IF_OUT_OVER; break; }
+				// pass C
+				uint32_t bad_dist = 0u;
+				if (tid <= lastl && r.st != IP_DEAD) (void)ip_walk<true>(S, used, limit, win_dw0, end_bit, base, rshift, ml + mbase, bad_dist);
+				if (__syncthreads_or(bad_dist != 0u)) { fail = IF_BAD_DIST; break; }
+				// resolve: a window of 256 matches at a time, one per thread
+				for (uint32_t w0 = 0u; w0 < mtot; w0 += IP_THREADS) {
+					const bool have = w0 + tid < mtot;
+					uint2 m = make_uint2(0u, 1u);
+					if (have) m = ml[w0 + tid];
+					const uint32_t p = m.x & 0xffffu, l = m.x >> 16, d = m.y;
+					const uint32_t from = p - d, send = from + (l < d ? l : d);
+					wpos[tid] = have ? p : 0x7fffffffu;
+					wend[tid] = p + l;
+					__syncthreads();
+					// the earlier matches of the window this one reads from: [a0, b]
+					uint32_t a0 = 0u, b = 0u;
+					bool dep = false;
+					if (have && tid > 0u && send > wpos[0]) {
+						// b: the last j < tid with wpos[j] < send;  a0: the last j with wpos[j] <= from (0 if none)
+						uint32_t lo = 0u, hi = tid;                      // first j in [0, tid) with wpos[j] >= send
+						while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (wpos[mid] < send) lo = mid + 1u; else hi = mid; }
+						b = lo - 1u;                                      // (lo >= 1: wpos[0] < send)
+						lo = 0u; hi = tid;                               // first j with wpos[j] > from
+						while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (wpos[mid] <= from) lo = mid + 1u; else hi = mid; }
+						a0 = lo ? lo - 1u : 0u;
+						if (wend[a0] <= from) a0++;                      // that match ends in front of the source: literals in between
+						dep = a0 <= b;
+					}
+					bool done = !have;
+					for (uint32_t guard = 0u;; guard++) {
+						if (guard > IP_THREADS) { fail = IF_BAD_CODE; break; }      // (cannot happen: the lowest open match is always ready)
+						const unsigned long long dm = __ballot(done);
+						if (lane == 0u) S.dmask[wave] = dm;
+						__syncthreads();
+						bool ready = !done;
+						if (ready && dep) {
+							for (uint32_t w = a0 >> 6; w <= (b >> 6); w++) {
+								const uint32_t f = w == (a0 >> 6) ? (a0 & 63u) : 0u, t = w == (b >> 6) ? (b & 63u) : 63u;
+								const unsigned long long need = (t == 63u ? ~0ull : ((1ull << (t + 1u)) - 1ull)) & ~((1ull << f) - 1ull);
+								if ((S.dmask[w] & need) != need) ready = false;
+							}
+						}
+						if (ready) {
+							uint8_t *o = S.out + rshift;
+							if (d >= l) {
+								for (uint32_t i = 0u; i < l; i += 8u) {
+									uint8_t v[8];
+#pragma unroll
+									for (uint32_t j = 0; j < 8u; j++) v[j] = i + j < l ? o[from + i + j] : (uint8_t)0;
+#pragma unroll
+									for (uint32_t j = 0; j < 8u; j++) if (i + j < l) o[p + i + j] = v[j];
+								}
+							} else {
+								const float rf = 1.0f / (float)d;
+								for (uint32_t i = 0u; i < l; i += 8u) {
+									uint8_t v[8];
+#pragma unroll
+									for (uint32_t j = 0; j < 8u; j++) {
+										const uint32_t q = (uint32_t)(((float)(i + j) + 0.5f) * rf);
+										v[j] = i + j < l ? o[from + (i + j - q * d)] : (uint8_t)0;
+									}
+#pragma unroll
+									for (uint32_t j = 0; j < 8u; j++) if (i + j < l) o[p + i + j] = v[j];
+								}
+							}
+							done = true;
+						}
+						if (!__syncthreads_or(!done)) break;
+					}
+				}
+				if (fail) break;
+				pos += total;
+				if ((le & 0xffffffu) <= at) { fail = IF_BAD_CODE; break; }              // (cannot happen: a segment consumes bits)
+				at = le & 0xffffffu;
+				if (st_last == IP_EOB) break;
+				// the next segment of the same deflate block
+				__syncthreads();
+				win_dw0 = at >> 5;
+				ip_stage(S, I, win_dw0, tid);
+				__syncthreads();
+			}
+			__syncthreads();
+		}
+		if (!fail && pos != out_len) fail = IF_LEN_MISMATCH;
+		__syncthreads();
+		if (!fail) {
+			// the block goes out: 16-byte vectors where the global address allows, bytes at the edges
+			const uintptr_t lo = (uintptr_t)og, hi = (uintptr_t)og + out_len;
+			const uintptr_t a = lo & ~(uintptr_t)15;
+			for (uintptr_t va = a + 16u * tid; va < hi; va += 16u * IP_THREADS) {
+				const uint32_t ri = (uint32_t)(va - a);
+				if (va >= lo && va + 16u <= hi) {
+					*reinterpret_cast<uint4 *>(va) = *reinterpret_cast<const uint4 *>(&S.out[ri]);
+				} else {
+					for (uint32_t k = 0; k < 16u; k++)
+						if (va + k >= lo && va + k < hi) *reinterpret_cast<uint8_t *>(va + k) = S.out[ri + k];
+				}
+			}
+			if (tid == 0) status[bi] = IF_OK;
+		} else if (tid == 0) {
+			status[bi] = IF_RETRY;
+			retry_list[atomicAdd(retry_n, 1u)] = bi;
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------
 // CRC-32 (the gzip polynomial, reflected) of every block's output
 // ---------------------------------------------------------------------------
@@ -718,41 +1126,72 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const msx_bgzf_block *__restric
 	if (lane == 0 && crc != B.crc32) { status[bi] = IF_BAD_CRC; atomicAdd(n_bad, 1u); }
 }
 
+#ifdef MSX_DEBUG_SWITCHES
 __global__ void k_bgzf_refuse(uint32_t n_blocks, uint32_t every, uint32_t *__restrict__ status, uint32_t *__restrict__ n_bad) {
 	for (uint32_t i = threadIdx.x * every; i < n_blocks; i += 64u * every)
 		if (status[i] == IF_OK) { status[i] = IF_BAD_CODE; atomicAdd(n_bad, 1u); }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // ABI
 // ---------------------------------------------------------------------------
-#define IF_PER_CU 14                      // waves per compute unit: what its LDS holds
+#define IF_PER_CU 14                      // serial kernel: waves per compute unit, what its LDS holds
+#define IP_PER_CU 2                       // lane-parallel kernel: workgroups per compute unit (80 KB of LDS each)
 static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate only): device counters
 
+// d_n_bad: [0] the refused blocks (zeroed by the caller), [1] the lane-parallel launch's ticket, [2] the number of blocks it
+// handed back, [3] the serial launch's ticket
 int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
                             const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
 	if (n_blocks <= 0) return MSX_OK;
-	static int per_cu_env = -1;
-	if (per_cu_env < 0) per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
+	// MSX_INFLATE_SERIAL=1: round 3's kernel for every block (one wave per block, one symbol after the other) -- the A/B of
+	// scripts/bench_inflate.py and the fallback's own test
+	const char *so_ = getenv("MSX_INFLATE_SERIAL");              // (read per launch: the tests switch it)
+	const int serial_only = so_ ? atoi(so_) : 0;
+	static const int per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
 	int per_cu = per_cu_env > 0 ? per_cu_env : waves_per_cu > 0 ? waves_per_cu : IF_PER_CU;
 	if (per_cu > IF_PER_CU) per_cu = IF_PER_CU;
 	int64_t grid = (int64_t)per_cu * ctx->num_cu;
 	if (grid > n_blocks) grid = n_blocks;
-	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 4, stream));      // the ticket
-	// MSX_INFLATE_VEC=1: the decode loop's bit buffer on the vector unit (round 4's experiment: measured SLOWER, 45.1 against
-	// 50.1 GB/s on lean records, 101 against 108 with SEQ/QUAL -- DESIGN.md section 3; kept as an A/B switch, off by default)
-	static int vec = -1;
-	if (vec < 0) vec = getenv("MSX_INFLATE_VEC") ? atoi(getenv("MSX_INFLATE_VEC")) != 0 : 0;
-#define IF_LAUNCH(D, V) hipLaunchKernelGGL((k_bgzf_inflate<D, V>), dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
-	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 1, if_stats)
-	if (if_stats) { if (vec) IF_LAUNCH(4, true); else IF_LAUNCH(4, false); }      // (4: the same kernel counting its symbols, MSX_INFLATE_STATS)
-	else { if (vec) IF_LAUNCH(0, true); else IF_LAUNCH(0, false); }
+	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 12, stream));      // tickets and the hand-back count
+	if (serial_only || if_stats) {
+#define IF_LAUNCH(D, L, LN) hipLaunchKernelGGL((k_bgzf_inflate<D>), dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
+	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 3, if_stats, (const uint32_t *)(L), (const uint32_t *)(LN))
+		if (if_stats) IF_LAUNCH(4, nullptr, nullptr);                // (4: the same kernel counting its symbols, MSX_INFLATE_STATS)
+		else IF_LAUNCH(0, nullptr, nullptr);
+	} else {
+		// the set of this stream
+		msx_ctx::inf_set *is = nullptr;
+		for (auto &c : ctx->inf) if (c.used && c.stream == stream) is = &c;
+		if (!is) for (auto &c : ctx->inf) if (!c.used) { is = &c; c.used = true; c.stream = stream; break; }
+		if (!is) return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_inflate_launch: more than four streams inflate on one context");
+		int64_t pgrid = (int64_t)IP_PER_CU * ctx->num_cu;
+		if (pgrid > n_blocks) pgrid = n_blocks;
+		const size_t want_m = (size_t)IP_PER_CU * ctx->num_cu * IP_MATCH_CAP * sizeof(uint2);
+		const size_t want_r = ((size_t)n_blocks + 64) * 4;
+		if (is->matches.cap < want_m || is->retry.cap < want_r) {
+			MSX_HIP(ctx, hipStreamSynchronize(stream));             // (an earlier launch of this stream may still read them)
+			int rc;
+			if ((rc = msx_reserve(ctx, &is->matches, want_m))) return rc;
+			if ((rc = msx_reserve(ctx, &is->retry, want_r < (1u << 18) ? (1u << 18) : want_r))) return rc;
+		}
+		hipLaunchKernelGGL(k_bgzf_inflate_par, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+		                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2);
+		// what it handed back: the serial kernel over that list (a launch that finds the list empty returns at once)
+		int64_t sgrid = grid < 4 * ctx->num_cu ? grid : 4 * ctx->num_cu;
+		grid = sgrid;
+		IF_LAUNCH(0, is->retry.p, d_n_bad + 2);
+#undef IF_LAUNCH
+	}
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
-	// MSX_INFLATE_REFUSE=<n> (tests): every n-th block is reported as refused, whatever the decoder made of it
-	static int refuse = -1;
-	if (refuse < 0) refuse = getenv("MSX_INFLATE_REFUSE") ? atoi(getenv("MSX_INFLATE_REFUSE")) : 0;
+#ifdef MSX_DEBUG_SWITCHES
+	// MSX_INFLATE_REFUSE=<n> (libmsamtools_amd_dbg.so only; tests): every n-th block is reported as refused, whatever the
+	// decoder made of it
+	static const int refuse = getenv("MSX_INFLATE_REFUSE") ? atoi(getenv("MSX_INFLATE_REFUSE")) : 0;
 	if (refuse > 0) hipLaunchKernelGGL(k_bgzf_refuse, dim3(1), dim3(64), 0, stream, (uint32_t)n_blocks, (uint32_t)refuse, d_status, d_n_bad);
+#endif
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
@@ -767,22 +1206,24 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 	if ((rc = msx_reserve(ctx, &ctx->scan_l3, 64))) return rc;
 	uint32_t *d_bad = (uint32_t *)ctx->scan_l3.p;
 	MSX_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-	const bool want_stats = getenv("MSX_INFLATE_STATS") != nullptr;
-	if (want_stats) { if_stats = d_bad + 4; MSX_HIP(ctx, hipMemsetAsync(if_stats, 0, 16, ctx->stream)); }
+	const int stats_mode = getenv("MSX_INFLATE_STATS") ? atoi(getenv("MSX_INFLATE_STATS")) : 0;   // 1: symbol counts (serial kernel); 2: blocks handed back
+	const bool want_stats = stats_mode == 1;
+	if (want_stats) { if_stats = d_bad + 8; MSX_HIP(ctx, hipMemsetAsync(if_stats, 0, 16, ctx->stream)); }
 	rc = msx_bgzf_inflate_launch(ctx, ctx->stream, 0, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad);
 	if_stats = nullptr;
 	if (rc) return rc;
 	if (want_stats) {
 		uint32_t h[4];
-		MSX_HIP(ctx, hipMemcpyAsync(h, d_bad + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipMemcpyAsync(h, d_bad + 8, 16, hipMemcpyDeviceToHost, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		fprintf(stderr, "# inflate: %lld blocks: %u literals, %u matches (%u beyond the ring), %u coded deflate blocks\n",
 		        (long long)n_blocks, h[0], h[1], h[2], h[3]);
 	}
-	uint32_t bad = 0;
-	MSX_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+	uint32_t bad[4] = {0, 0, 0, 0};
+	MSX_HIP(ctx, hipMemcpyAsync(bad, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));
 	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (n_refused) *n_refused = bad;
+	if (stats_mode == 2) fprintf(stderr, "# inflate: %lld blocks, %u handed back to the serial kernel, %u refused\n", (long long)n_blocks, bad[2], bad[0]);
+	if (n_refused) *n_refused = bad[0];
 	return MSX_OK;
 }
 
@@ -791,4 +1232,5 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 void msx_touch_inflate(void) {
 	hipFuncAttributes attr;
 	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_crc));
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_par));
 }

@@ -132,6 +132,10 @@ struct msx_ctx {
 	hipStream_t df_last = nullptr;     // the stream the encoder's scratch was last used on (ONE set per context: a launch on
 	hipEvent_t df_done = nullptr;      // another stream waits for df_done first; growing the scratch drains df_last)
 	bool df_used = false;
+	// msx_inflate.hip: the lane-parallel inflater's match lists (one per resident workgroup) and the list of blocks it hands
+	// back to the serial kernel -- one set per stream that launches it (launches on one stream follow each other; the command
+	// line inflates the batch sent ahead on a stream of its own beside the main one)
+	struct inf_set { hipStream_t stream = nullptr; msx_buf matches, retry; bool used = false; } inf[4];
 	msx_dev_status *d_status = nullptr;
 	msx_dev_status *h_status = nullptr;  // pinned
 	bool filter_pending = false;

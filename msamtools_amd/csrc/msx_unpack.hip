@@ -38,7 +38,9 @@ struct up_state {
 	uint32_t cut_any, cut_mapped;  // last pool boundary (record index) / last one whose record is mapped, in the batch's second half
 	uint32_t n_batch, n_groups, cut_off;
 	uint32_t inflate_bad;          // msx_unpack_enqueue_bgzf: blocks the device inflater refused
-	uint32_t inflate_ticket;       // ... and the counter its waves draw their blocks from (msx_bgzf_inflate_launch: d_n_bad[1])
+	uint32_t inflate_ticket;       // ... and the counter its workgroups draw their blocks from (msx_bgzf_inflate_launch: d_n_bad[1])
+	uint32_t inflate_back;         // blocks the lane-parallel kernel handed back to the serial one (d_n_bad[2]) ...
+	uint32_t inflate_ticket2;      // ... and that launch's ticket (d_n_bad[3])
 	uint32_t has_prev;             // prev_name holds the QNAME of the last naming record of earlier batches
 	uint32_t emit_bytes;           // what msx_unpack_emit_fetch brings down (the record stream, or the BGZF blocks made of it)
 	uint32_t emit_raw;             // bytes of the record stream

@@ -22,6 +22,17 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True, params=["lanes", "serial"])
+def kernel(request, monkeypatch):
+    """every test twice: the lane-parallel kernel (k_bgzf_inflate_par: 256 lanes per deflate block, what it hands back goes
+    to the serial one) and the serial kernel alone (MSX_INFLATE_SERIAL=1: one wave per block, round 3's)"""
+    if request.param == "serial":
+        monkeypatch.setenv("MSX_INFLATE_SERIAL", "1")
+    else:
+        monkeypatch.delenv("MSX_INFLATE_SERIAL", raising=False)
+    return request.param
+
+
 def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_at=(), flush_mode=zlib.Z_FULL_FLUSH, mem=8):
     co = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
     out, last = b"", 0
