@@ -927,7 +927,7 @@ static int cov_grow_keep(msx_ctx *ctx, msx_buf *b, size_t keep_bytes, size_t wan
 	void *np = nullptr;
 	hipError_t e = hipMalloc(&np, cap);
 	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-	if (getenv("MSX_POISON")) MSX_HIP(ctx, hipMemsetAsync(np, 0xa5, cap, ctx->stream));        // (tests: msx_reserve)
+	if (msx_poison_on()) MSX_HIP(ctx, hipMemsetAsync(np, 0xa5, cap, ctx->stream));        // (tests: msx_reserve)
 	if (b->p) {
 		if (keep_bytes) MSX_HIP(ctx, hipMemcpyAsync(np, b->p, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));

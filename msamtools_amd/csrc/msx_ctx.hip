@@ -34,10 +34,7 @@ int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes) {
 		return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
 	}
 	b->cap = want;
-	// MSX_POISON=1 (tests): fresh workspace holds 0xa5 bytes, not the zeros a new allocation tends to hold -- a kernel that reads
-	// a word nobody wrote then reads garbage here too, not only after another batch has used the buffer
-	static const int poison = getenv("MSX_POISON") ? atoi(getenv("MSX_POISON")) : 0;
-	if (poison) { MSX_HIP(ctx, hipMemsetAsync(b->p, 0xa5, want, ctx->stream)); MSX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+	if (msx_poison_on()) { MSX_HIP(ctx, hipMemsetAsync(b->p, 0xa5, want, ctx->stream)); MSX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
 	return MSX_OK;
 }
 
@@ -347,7 +344,7 @@ extern "C" int msx_dev_alloc(msx_ctx *ctx, void **ptr, size_t bytes) {
 	hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
 	if (e != hipSuccess)
 		return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-	if (getenv("MSX_POISON")) { MSX_HIP(ctx, hipMemsetAsync(*ptr, 0xa5, bytes ? bytes : 16, ctx->stream)); MSX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }   // (tests: msx_reserve)
+	if (msx_poison_on()) { MSX_HIP(ctx, hipMemsetAsync(*ptr, 0xa5, bytes ? bytes : 16, ctx->stream)); MSX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }   // (tests: msx_reserve)
 	return MSX_OK;
 }
 

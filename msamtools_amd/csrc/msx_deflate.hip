@@ -14,6 +14,8 @@
 // valid gzip member that zlib, htslib and this repository's own inflater decode to the same record stream.
 // Integer / byte work, HBM-bound (stored) -- no MFMA.
 #include "msx_internal.h"
+
+#include <mutex>
 #include "msx_crc.h"
 
 #define BZ_PAYLOAD 0xff00u          // bytes of BAM stream per block (htslib's BGZF_BLOCK_SIZE)
@@ -796,11 +798,15 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	//   levels 1-3: <1024, 10, 10, 2560>  14 KB, 11 waves                   44 GB/s   1.091 / 1.133
 	// MSX_DEFLATE_GEOM=0..5 overrides the level (0, 4, 3 are the three above; 1 = <2048, 11, 11, 6144>, 2 = <2048, 10, 10, 6144>,
 	// 5 = <1024, 11, 11, 2560>: measured, not mapped).  The host twin follows: df_opts_for_level (msx_deflate_model.h).
-	static int geom_env = -2, per_cu[6] = {0, 0, 0, 0, 0, 0};
-	if (geom_env == -2) {
-		geom_env = getenv("MSX_DEFLATE_GEOM") ? atoi(getenv("MSX_DEFLATE_GEOM")) : -1;
-		if (geom_env < -1 || geom_env > 5) geom_env = -1;
-	}
+	// (several device threads of one process launch the encoder at once: the lazily filled tables are filled under a lock)
+	static std::mutex geom_mu;
+	static int per_cu[6] = {0, 0, 0, 0, 0, 0};
+	int geom_env = -1;
+#ifdef MSX_DEBUG_SWITCHES
+	geom_env = getenv("MSX_DEFLATE_GEOM") ? atoi(getenv("MSX_DEFLATE_GEOM")) : -1;     // (libmsamtools_amd_dbg.so only)
+	if (geom_env < -1 || geom_env > 5) geom_env = -1;
+#endif
+	std::lock_guard<std::mutex> geom_lock(geom_mu);
 	const int geom = geom_env >= 0 ? geom_env : level >= 7 ? 0 : level >= 4 ? 4 : 3;
 	if (!per_cu[geom]) {
 		int nb = 0;
@@ -834,8 +840,7 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	if (!ctx->df_done) MSX_HIP(ctx, hipEventCreateWithFlags(&ctx->df_done, hipEventDisableTiming));
 	uint32_t *bsize = (uint32_t *)ctx->df_size.p, *boff = bsize + nblk + 8, *misc = boff + nblk + 4;
 	MSX_HIP(ctx, hipMemsetAsync(bsize, 0, (nblk + 16) * 8 + 192, stream));
-	static int want_kinds = -1;
-	if (want_kinds < 0) want_kinds = getenv("MSX_DEFLATE_STATS") != nullptr;
+	const int want_kinds = getenv("MSX_DEFLATE_STATS") != nullptr;
 #define DF_LAUNCH(R, H4, H8, W, E) hipLaunchKernelGGL((k_bgzf_deflate<R, H4, H8, W, E>), dim3((unsigned)waves), dim3(64), 0, stream, d_in, d_total, \
 	                   (uint32_t)n_cap, (uint8_t *)ctx->df_slots.p, bsize, (uint32_t *)ctx->df_tok.p, misc, want_kinds ? misc + 4 : nullptr)
 	switch (geom) {

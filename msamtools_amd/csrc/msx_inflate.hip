@@ -220,7 +220,12 @@ __device__ __forceinline__ void if_flush(IfShared &S, IfState &T, uint8_t *og, u
 
 // Canonical Huffman code of S.lens[base, base + nsym) into a primary table of `root` bits and the per-length arrays
 // of the canonical route.  which: 0 literal/length, 1 distance.  Returns 0 if the lengths are refused.
-template <class SH>
+// a literal/length entry in 16 bits (the lane-parallel kernel's sorted[]: what a long code decodes to, ready to use):
+// payload (9 bits) | extra bits << 9 | kind << 12
+__device__ __forceinline__ uint32_t if_pack16(uint32_t e) { return (e >> 16) | (((e >> 8) & 7u) << 9) | (((e >> 4) & 15u) << 12); }
+__device__ __forceinline__ uint32_t if_unpack16(uint32_t p) { return ((p & 0x1ffu) << 16) | (((p >> 9) & 7u) << 8) | ((p >> 12) << 4); }
+
+template <bool PACK = false, class SH>
 __device__ __forceinline__ uint32_t if_build(SH &S, uint32_t which, uint32_t base, uint32_t nsym, uint32_t lane) {
 	uint32_t *tab = which ? S.dt : S.ll;
 	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
@@ -254,7 +259,7 @@ __device__ __forceinline__ uint32_t if_build(SH &S, uint32_t which, uint32_t bas
 		// sorted[]: the symbols of this length in symbol order
 #pragma unroll
 		for (int j = 0; j < 5; j++)
-			if (L[j] == len) IF_SORTED(S, which)[offs + (code[j] - nxt)] = (uint16_t)(lane + 64u * j);
+			if (L[j] == len) IF_SORTED(S, which)[offs + (code[j] - nxt)] = (uint16_t)((PACK && which == 0u) ? if_pack16(if_ll_entry(lane + 64u * j)) : lane + 64u * j);
 		offs += cnt;
 		n_codes += cnt;
 		nxt = (nxt + cnt) << 1;
@@ -644,7 +649,9 @@ done:
 #define IP_SUB0 256u
 #define IP_MAX_ROUNDS 8u
 #define IP_SKEW(d) ((d) + ((d) >> 5))
-#define IP_MATCH_CAP 21848u              // matches of one segment: at most a third of a block's bytes
+#define IP_PIECE 16u                     // a match goes to the list in pieces of at most 16 bytes
+#define IP_MATCH_CAP 26000u              // pieces of one segment: a third of a block's bytes (matches) + a sixteenth (their further pieces)
+#define IP_HANDBACK_SUB 4096u            // a segment that needs this many bits per lane to converge goes to the serial kernel
 #define IF_RETRY 10u
 
 enum { IP_OK = 0u, IP_EOB = 1u, IP_BAD = 2u, IP_PAST = 3u, IP_DEAD = 4u };
@@ -665,83 +672,136 @@ struct IpShared {
 	uint32_t lend[IP_THREADS];             // a lane's end (24 bits) and state, for its right neighbour
 	uint32_t xw[16];                       // the waves' words: first stopped lane, sums, header fields
 	unsigned long long dmask[4];           // resolve: the waves' done bits
+	uint32_t rfail;                        // resolve: a wave gave up waiting (cannot happen; the block is handed back)
 };
 
-// a code longer than the primary table's index, per lane (if_long with nothing wave-uniform)
-__device__ __forceinline__ uint32_t ip_long(IpShared &S, uint32_t which, uint32_t bits15) {
-	const uint32_t c15 = __brev(bits15) >> 17;
-	const uint32_t root = which ? IF_D_ROOT : IF_LL_ROOT;
-	for (uint32_t len = root + 1u; len <= 15u; len++) {
-		if (c15 < S.lim[which][len]) {
-			const uint32_t first = S.first[which][len];
-			if (c15 < first) return 0u;
-			const uint32_t sym = IF_SORTED(S, which)[S.off[which][len] + ((c15 - first) >> (15u - len))];
-			const uint32_t e = which ? if_d_entry(sym) : if_ll_entry(sym);
-			return e ? (e | len) : 0u;
-		}
-	}
-	return 0u;
-}
+// codes longer than the primary tables' index, without a loop: the per-length limits (left-aligned to 15 bits, ascending)
+// and K[len] = off[len] - (first[len] >> (15 - len)), wave-uniform, read once per deflate block.  A code c (15 bits,
+// left-aligned) has the first length whose limit exceeds it, and its symbol is sorted[K[len] + (c >> (15 - len))].
+struct IpLong { uint32_t lim0[5]; int32_t k0[5]; uint32_t lim1[7]; int32_t k1[7]; };
 
-struct IpLane { uint32_t end, nb, nm, st; };
+struct IpLane { uint32_t end, nb, nm, st, trips; };
+
+// a distance symbol's entry, without a branch (if_d_entry)
+__device__ __forceinline__ uint32_t ip_d_entry(uint32_t s) {
+	const uint32_t h = s >> 1, ex = (h > 1u ? h : 1u) - 1u;
+	const uint32_t b = s < 2u ? 1u + s : 1u + ((2u + (s & 1u)) << ex);
+	return s > 29u ? 0u : ((IF_BASE << 4) | (ex << 8) | (b << 16));
+}
 
 // A lane's walk (msx_inflate_par_model.h: ip_walk): tokens from bit `start` while they begin in front of `limit`.  Bit
 // positions count from the block's aligned base; seg[0] is word win_dw0 of it.  EMIT: pass C.
+// What an iteration costs is its chain of dependent LDS reads and the instructions around them (the first version --
+// refill, literal/length table, the long route's loop, refill, distance table, every step its own branch -- took 2300
+// clocks per token; the second, one table read per iteration but a branch per case, compiled to 450 instructions and 44
+// branches per iteration and was no faster).  So: the stream's next word travels in a register, asked for an iteration
+// before it is needed; an iteration reads ONE table entry -- a literal/length code (mode 0) or a distance code (mode 1) --
+// and consumes it with the same arithmetic either way (code length, extra bits, base + extra); a code longer than the
+// primary table's index finds its place in sorted[] from register-held limits (mode | 2) and reads its entry there in the
+// next iteration; both of those rare paths sit behind wave-uniform branches.
 template <bool EMIT>
-__device__ __forceinline__ IpLane ip_walk(IpShared &S, uint32_t start, uint32_t limit, uint32_t win_dw0, uint32_t end_bit,
+__device__ __forceinline__ IpLane ip_walk(IpShared &S, const IpLong &Q, uint32_t start, uint32_t limit, uint32_t win_dw0, uint32_t end_bit,
                                           uint32_t base, uint32_t rshift, uint2 *__restrict__ ml, uint32_t &bad_dist) {
 	uint32_t ip = (start >> 5) - win_dw0;
 	uint64_t buf = (uint64_t)S.seg[IP_SKEW(ip)] | (uint64_t)S.seg[IP_SKEW(ip + 1u)] << 32;
 	ip += 2u;
+	uint32_t w = S.seg[IP_SKEW(ip)];
 	buf >>= (start & 31u);
 	int32_t cnt = 64 - (int32_t)(start & 31u);
 	IpLane r;
-	r.st = IP_OK; r.nb = 0u; r.nm = 0u;
+	r.st = IP_OK; r.nb = 0u; r.nm = 0u; r.trips = 0u;
+	uint32_t mode = 0u, mlen = 0u, sidx = 0u, slen = 0u;
+	const uint32_t *tab = S.ll;            // (dt follows ll in IpShared: one array of 1024 + 256 entries)
 #define IP_AT() ((win_dw0 + ip) * 32u - (uint32_t)cnt)
-#define IP_REFILL() do { if (cnt <= 32) { buf |= (uint64_t)S.seg[IP_SKEW(ip)] << cnt; cnt += 32; ip++; } } while (0)
-#define IP_DROP(n) do { buf >>= (n); cnt -= (int32_t)(n); } while (0)
 	for (;;) {
-		const uint32_t at = IP_AT();
-		if (at >= limit) break;
-		if (at >= end_bit) { r.st = IP_PAST; break; }
-		IP_REFILL();
-		uint32_t e = S.ll[(uint32_t)buf & ((1u << IF_LL_ROOT) - 1u)];
-		if (((e >> 4) & 15u) == IF_LONG) e = ip_long(S, 0u, (uint32_t)buf & 0x7fffu);
-		const uint32_t kind = (e >> 4) & 15u;
-		if (kind == 0u) { r.st = IP_BAD; break; }
-		IP_DROP(e & 15u);
-		if (kind == IF_LIT) {
-			if (EMIT) S.out[rshift + base + r.nb] = (uint8_t)(e >> 16);
-			r.nb++;
-		} else if (kind == IF_EOB) {
-			r.st = IP_EOB;
-			break;
-		} else {
-			const uint32_t xl = (e >> 8) & 15u;
-			const uint32_t len = (e >> 16) + ((uint32_t)buf & ((1u << xl) - 1u));
-			IP_DROP(xl);
-			IP_REFILL();
-			uint32_t d = S.dt[(uint32_t)buf & ((1u << IF_D_ROOT) - 1u)];
-			if (((d >> 4) & 15u) == IF_LONG) d = ip_long(S, 1u, (uint32_t)buf & 0x7fffu);
-			if (((d >> 4) & 15u) != IF_BASE) { r.st = IP_BAD; break; }
-			IP_DROP(d & 15u);
-			const uint32_t xd = (d >> 8) & 15u;
-			const uint32_t dist = (d >> 16) + ((uint32_t)buf & ((1u << xd) - 1u));
-			IP_DROP(xd);
-			if (EMIT) {
-				const uint32_t p = base + r.nb;
-				if (dist > p) bad_dist = 1u;
-				ml[r.nm] = make_uint2(p | (len << 16), dist);
-			}
-			r.nm++;
-			r.nb += len;
+		r.trips++;
+		if (mode == 0u) {
+			const uint32_t at = IP_AT();
+			if (at >= limit) break;
+			if (at >= end_bit) { r.st = IP_PAST; break; }
 		}
-		if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
+		{
+			const bool take = cnt <= 32;
+			const uint64_t in = (uint64_t)w << ((uint32_t)cnt & 63u);
+			buf |= take ? in : 0ull;
+			cnt += take ? 32 : 0;
+			ip += take ? 1u : 0u;
+			w = S.seg[IP_SKEW(ip)];
+		}
+		const uint32_t bits = (uint32_t)buf;
+		uint32_t e = tab[(mode & 1u) ? (1u << IF_LL_ROOT) + (bits & ((1u << IF_D_ROOT) - 1u)) : (bits & ((1u << IF_LL_ROOT) - 1u))];
+		if (__ballot(mode >= 2u)) {
+			// (a long code's entry: what sorted[] holds at the place computed an iteration ago)
+			const uint32_t sv = IF_SORTED(S, mode & 1u)[sidx];
+			const uint32_t el = (mode & 1u) ? ip_d_entry(sv) : if_unpack16(sv);
+			if (mode >= 2u) e = ((el >> 4) & 15u) ? (el | slen) : 0u;
+		}
+		bool skip = false;
+		if (__ballot(mode < 2u && ((e >> 4) & 15u) == IF_LONG)) {
+			const uint32_t c15 = __brev(bits & 0x7fffu) >> 17;
+			const uint32_t n0 = (uint32_t)(c15 >= Q.lim0[0]) + (uint32_t)(c15 >= Q.lim0[1]) + (uint32_t)(c15 >= Q.lim0[2]) + (uint32_t)(c15 >= Q.lim0[3]);
+			const uint32_t n1 = (uint32_t)(c15 >= Q.lim1[0]) + (uint32_t)(c15 >= Q.lim1[1]) + (uint32_t)(c15 >= Q.lim1[2]) + (uint32_t)(c15 >= Q.lim1[3]) +
+			                    (uint32_t)(c15 >= Q.lim1[4]) + (uint32_t)(c15 >= Q.lim1[5]);
+			const int32_t k0 = n0 == 0u ? Q.k0[0] : n0 == 1u ? Q.k0[1] : n0 == 2u ? Q.k0[2] : n0 == 3u ? Q.k0[3] : Q.k0[4];
+			const int32_t k1 = n1 == 0u ? Q.k1[0] : n1 == 1u ? Q.k1[1] : n1 == 2u ? Q.k1[2] : n1 == 3u ? Q.k1[3] : n1 == 4u ? Q.k1[4] : n1 == 5u ? Q.k1[5] : Q.k1[6];
+			if (mode < 2u && ((e >> 4) & 15u) == IF_LONG) {
+				const bool d = mode != 0u;
+				if (c15 >= (d ? Q.lim1[6] : Q.lim0[4])) { r.st = IP_BAD; break; }
+				slen = d ? IF_D_ROOT + 1u + n1 : IF_LL_ROOT + 1u + n0;
+				sidx = (uint32_t)((d ? k1 : k0) + (int32_t)(c15 >> (15u - slen)));
+				mode |= 2u;
+				skip = true;
+			}
+		}
+		if (skip) continue;
+		mode &= 1u;
+		// the entry consumed: code, extra bits, value
+		const uint32_t kind = (e >> 4) & 15u, x = (e >> 8) & 15u;
+		buf >>= (e & 15u);
+		const uint32_t val = (e >> 16) + ((uint32_t)buf & ((1u << x) - 1u));
+		buf >>= x;
+		cnt -= (int32_t)((e & 15u) + x);
+		if (mode == 0u) {
+			if (kind == IF_LIT) {
+				if (EMIT) S.out[rshift + base + r.nb] = (uint8_t)val;
+				r.nb++;
+				if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
+			} else if (kind == IF_BASE) {
+				mlen = val;
+				mode = 1u;
+			} else {
+				r.st = kind == IF_EOB ? IP_EOB : IP_BAD;
+				break;
+			}
+		} else {
+			if (kind != IF_BASE) { r.st = IP_BAD; break; }
+			if (EMIT) {
+				// the match as pieces of at most 16 bytes: {position | length - 1 << 16 | phase << 20, source | period << 16}.  A piece
+				// of a match that does not overlap itself reads `length` bytes from `source`; one that does (distance < length) reads
+				// byte (phase + i) mod period from the period in front of the match -- never what the match itself writes.
+				const uint32_t p = base + r.nb, dist = val;
+				if (dist > p) bad_dist = 1u;
+				uint32_t k = 0u;
+				if (dist >= mlen) {
+					for (uint32_t o = 0u; o < mlen; o += IP_PIECE, k++) {
+						const uint32_t pl = mlen - o < IP_PIECE ? mlen - o : IP_PIECE;
+						ml[r.nm + k] = make_uint2((p + o) | ((pl - 1u) << 16), (p + o - dist) & 0xffffu);
+					}
+				} else {
+					for (uint32_t o = 0u; o < mlen; o += IP_PIECE, k++) {
+						const uint32_t pl = mlen - o < IP_PIECE ? mlen - o : IP_PIECE;
+						ml[r.nm + k] = make_uint2((p + o) | ((pl - 1u) << 16) | ((o % dist) << 20), ((p - dist) & 0xffffu) | (dist << 16));
+					}
+				}
+			}
+			r.nm += (mlen + IP_PIECE - 1u) / IP_PIECE;
+			r.nb += mlen;
+			mode = 0u;
+			if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
+		}
 	}
 	r.end = IP_AT();
 #undef IP_AT
-#undef IP_REFILL
-#undef IP_DROP
 	return r;
 }
 
@@ -766,22 +826,31 @@ __device__ __forceinline__ uint32_t ip_wave_incl(uint32_t v, uint32_t lane) {
 	return v;
 }
 
+// (PH: MSX_INFLATE_STATS=3 -- thread 0's clock at the phase boundaries, summed over the blocks into stats[8..])
+#define IP_PH(k) do { if (PH) { const long long now_ = clock64(); if (tid == 0) ph[k] += (unsigned long long)(now_ - t_ph); t_ph = now_; } } while (0)
+template <bool PH>
 __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *__restrict__ comp, size_t comp_len,
                                                                  const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
                                                                  uint8_t *__restrict__ out, uint32_t *__restrict__ status,
                                                                  uint32_t *__restrict__ ticket, uint2 *__restrict__ match_scratch,
-                                                                 uint32_t *__restrict__ retry_list, uint32_t *__restrict__ retry_n) {
+                                                                 uint32_t *__restrict__ retry_list, uint32_t *__restrict__ retry_n,
+                                                                 unsigned long long *__restrict__ stats) {
 	__shared__ IpShared S;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	long long t_ph = PH ? clock64() : 0;
 	uint2 *const ml = match_scratch + (size_t)blockIdx.x * IP_MATCH_CAP;
 	uint32_t *const wpos = S.seg;                      // resolve: the window's match positions ...
 	uint32_t *const wend = S.seg + IP_THREADS + 1u;    // ... and ends (the staged stream is done with by then)
 	for (;;) {
-		if (tid == 0) S.xw[15] = atomicAdd(ticket, 1u);
+		if (tid == 0) { S.xw[15] = atomicAdd(ticket, 1u); S.rfail = 0u; }
 		__syncthreads();
 		const uint32_t bi = S.xw[15];
 		__syncthreads();
-		if (bi >= n_blocks) return;
+		if (bi >= n_blocks) {
+			if (PH && tid == 0) for (int k = 0; k < 16; k++) atomicAdd(&stats[k], ph[k]);
+			return;
+		}
 		const msx_bgzf_block B = blk[bi];
 		uint8_t *og = out + B.out_off;
 		const uint32_t out_len = B.out_len;
@@ -799,6 +868,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 		}
 		const uint32_t skew = (uint32_t)((uintptr_t)(comp + B.in_off) & 3u);
 		const uint32_t end_bit = (skew + B.in_len) * 8u;
+		IP_PH(0);
 		const uint32_t rshift = (uint32_t)((uintptr_t)og & 15u);
 		uint32_t at = skew * 8u;            // the stream's read position (bits from the aligned base): workgroup-uniform
 		uint32_t pos = 0u;                  // bytes produced
@@ -810,14 +880,21 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 			uint32_t win_dw0 = at >> 5;
 			ip_stage(S, I, win_dw0, tid);
 			__syncthreads();
+			IP_PH(1);
 			if (wave == 0u) {
-				uint32_t hip_ = (at >> 5) - win_dw0;
-				uint64_t hb = (uint64_t)IFU(S.seg[IP_SKEW(hip_)]) | (uint64_t)IFU(S.seg[IP_SKEW(hip_ + 1u)]) << 32;
+				// the stream's words in a register, 64 at a time (lane i: word hbase + i), fetched by v_readlane: a dynamic
+				// header's ~150 code-length symbols were two LDS round trips each (stream word, table entry: 115 K clocks per
+				// block); its table is held the same way (pre0 / pre1 below)
+				uint32_t hip_ = 0u, hbase = 0u;
+				uint32_t hw = S.seg[IP_SKEW(lane)];
+				uint64_t hb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, 0) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, 1) << 32;
 				hip_ += 2u;
 				hb >>= (at & 31u);
 				int32_t hc = 64 - (int32_t)(at & 31u);
 #define IH_AT() ((win_dw0 + hip_) * 32u - (uint32_t)hc)
-#define IH_REFILL() do { if (hc <= 32) { hb |= (uint64_t)IFU(S.seg[IP_SKEW(hip_)]) << hc; hc += 32; hip_++; } } while (0)
+#define IH_REFILL() do { if (hc <= 32) {                                                                     \
+					if (hip_ - hbase >= 64u) { hbase += 64u; hw = S.seg[IP_SKEW(hbase + lane)]; }                    \
+					hb |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, (int)(hip_ - hbase)) << hc; hc += 32; hip_++; } } while (0)
 #define IH_PEEK(n) ((uint32_t)(hb & ((1ull << (n)) - 1ull)))
 #define IH_DROP(n) do { hb >>= (n); hc -= (int32_t)(n); } while (0)
 				uint32_t herr = 0u, hlit = 288u, hdist = 32u, stored_len = 0u;
@@ -878,10 +955,13 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 						}
 					}
 					const uint32_t total = hlit + hdist;
+					const uint32_t pre0 = S.pre[lane], pre1 = S.pre[lane + 64u];
 					uint32_t n = 0u, prev = 0u;
 					while (n < total) {
 						IH_REFILL();
-						const uint32_t e = IFU(S.pre[IH_PEEK(7)]);
+						const uint32_t pk = IH_PEEK(7);
+						const uint32_t e = pk < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)pre0, (int)pk)
+						                            : (uint32_t)__builtin_amdgcn_readlane((int)pre1, (int)(pk - 64u));
 						if (!e) { herr = IF_BAD_CODE; break; }
 						IH_DROP(e & 0xffu);
 						const uint32_t sym = (e >> 8) & 0xffu;
@@ -920,6 +1000,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 #undef IH_DROP
 			}
 			__syncthreads();
+			IP_PH(2);
 			if (S.xw[8]) { fail = S.xw[8]; break; }
 			const uint32_t type = S.xw[9], hlit = S.xw[11], hdist = S.xw[12];
 			last_block = S.xw[10] != 0u;
@@ -935,9 +1016,23 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 			}
 			// the two tables side by side
 			uint32_t ok = 1u;
-			if (wave == 0u) ok = if_build(S, 0u, 0u, hlit, lane);
-			else if (wave == 1u) ok = if_build(S, 1u, hlit, hdist, lane);
+			if (wave == 0u) ok = if_build<true>(S, 0u, 0u, hlit, lane);
+			else if (wave == 1u) ok = if_build<true>(S, 1u, hlit, hdist, lane);
 			if (__syncthreads_or(!ok)) { fail = IF_BAD_LENS; break; }
+			IpLong Q;
+#pragma unroll
+			for (uint32_t k = 0; k < 5u; k++) {
+				const uint32_t len = IF_LL_ROOT + 1u + k;
+				Q.lim0[k] = IFU(S.lim[0][len]);
+				Q.k0[k] = (int32_t)IFU(S.off[0][len]) - (int32_t)(IFU(S.first[0][len]) >> (15u - len));
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 7u; k++) {
+				const uint32_t len = IF_D_ROOT + 1u + k;
+				Q.lim1[k] = IFU(S.lim[1][len]);
+				Q.k1[k] = (int32_t)IFU(S.off[1][len]) - (int32_t)(IFU(S.first[1][len]) >> (15u - len));
+			}
+			IP_PH(3);
 			// ---- the block's symbols, segment by segment ----
 			uint32_t sub = IP_SUB0;
 			for (;;) {
@@ -953,8 +1048,15 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 					// pass A
 					used = seg0 + tid * sub;
 					limit = used + sub < win_end ? used + sub : win_end;
-					r.st = IP_DEAD; r.end = 0u; r.nb = 0u; r.nm = 0u;
-					if (tid < nl && (tid == 0u || used < end_bit)) r = ip_walk<false>(S, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+					r.st = IP_DEAD; r.end = 0u; r.nb = 0u; r.nm = 0u; r.trips = 0u;
+					if (tid < nl && (tid == 0u || used < end_bit)) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+					if (PH) {
+						uint32_t tmax = r.trips, tsum = r.trips;
+						for (uint32_t d = 32u; d >= 1u; d >>= 1) { tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, d)); tsum += (uint32_t)__shfl_xor((int)tsum, d); }
+						if (tid == 0) { ph[12] += tmax; ph[13] += tsum; ph[14]++; }
+						__syncthreads();
+					}
+					IP_PH(4);
 					// pass B
 					bool converged = false;
 					for (uint32_t rounds = 0u; rounds < IP_MAX_ROUNDS || nl == 1u; rounds++) {
@@ -969,11 +1071,15 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 							if (ns != used) { used = ns; ch = true; }
 						}
 						if (!__syncthreads_or(ch)) { converged = true; break; }
-						if (ch) r = ip_walk<false>(S, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+						if (ch) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+						if (PH && tid == 0) ph[10]++;
 					}
+					IP_PH(5);
 					if (converged) break;
 					sub *= 4u;
+					if (sub >= IP_HANDBACK_SUB) { fail = IF_RETRY; break; }      // lanes this long are no faster than the serial kernel's one
 				}
+				if (fail) break;
 				// the true chain's lanes: up to the first that stopped
 				const uint32_t stop = min(min(S.xw[0], S.xw[1]), min(S.xw[2], S.xw[3]));
 				const uint32_t lastl = stop < nl ? stop : nl - 1u;
@@ -991,76 +1097,86 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 				const uint32_t total = S.xw[0] + S.xw[1] + S.xw[2] + S.xw[3];
 				const uint32_t mtot = S.xw[4] + S.xw[5] + S.xw[6] + S.xw[7];
 				if (total > out_len - pos) { fail = IF_OUT_OVER; break; }
+				IP_PH(6);
 				// pass C
 				uint32_t bad_dist = 0u;
-				if (tid <= lastl && r.st != IP_DEAD) (void)ip_walk<true>(S, used, limit, win_dw0, end_bit, base, rshift, ml + mbase, bad_dist);
+				if (tid <= lastl && r.st != IP_DEAD) (void)ip_walk<true>(S, Q, used, limit, win_dw0, end_bit, base, rshift, ml + mbase, bad_dist);
 				if (__syncthreads_or(bad_dist != 0u)) { fail = IF_BAD_DIST; break; }
-				// resolve: a window of 256 matches at a time, one per thread
+				IP_PH(7);
+				// resolve: a window of 256 pieces at a time, one per thread.  No workgroup barrier inside a window: every wave
+				// keeps the done bits of its own pieces in a register pair, publishes them in LDS when they change and polls
+				// the words of the waves in front of it (a piece depends on earlier pieces only); a wave leaves the window when
+				// its own pieces are done.  LDS keeps a wave's operations in order, so whoever sees a done bit sees the bytes.
 				for (uint32_t w0 = 0u; w0 < mtot; w0 += IP_THREADS) {
 					const bool have = w0 + tid < mtot;
-					uint2 m = make_uint2(0u, 1u);
+					uint2 m = make_uint2(0u, 0u);
 					if (have) m = ml[w0 + tid];
-					const uint32_t p = m.x & 0xffffu, l = m.x >> 16, d = m.y;
-					const uint32_t from = p - d, send = from + (l < d ? l : d);
+					const uint32_t p = m.x & 0xffffu, l = ((m.x >> 16) & 15u) + 1u, ph0 = m.x >> 20, from = m.y & 0xffffu, per = m.y >> 16;
+					const uint32_t send = from + (per ? per : l);                  // the source bytes end here (a period: at the match's start)
 					wpos[tid] = have ? p : 0x7fffffffu;
 					wend[tid] = p + l;
+					unsigned long long mine = __ballot(!have);
+					if (lane == 0u) __hip_atomic_store(&S.dmask[wave], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					__syncthreads();
-					// the earlier matches of the window this one reads from: [a0, b]
+					// the earlier pieces of the window this one reads from: [a0, b]
 					uint32_t a0 = 0u, b = 0u;
 					bool dep = false;
 					if (have && tid > 0u && send > wpos[0]) {
-						// b: the last j < tid with wpos[j] < send;  a0: the last j with wpos[j] <= from (0 if none)
 						uint32_t lo = 0u, hi = tid;                      // first j in [0, tid) with wpos[j] >= send
 						while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (wpos[mid] < send) lo = mid + 1u; else hi = mid; }
 						b = lo - 1u;                                      // (lo >= 1: wpos[0] < send)
 						lo = 0u; hi = tid;                               // first j with wpos[j] > from
 						while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (wpos[mid] <= from) lo = mid + 1u; else hi = mid; }
 						a0 = lo ? lo - 1u : 0u;
-						if (wend[a0] <= from) a0++;                      // that match ends in front of the source: literals in between
+						if (wend[a0] <= from) a0++;                      // that piece ends in front of the source: literals in between
 						dep = a0 <= b;
 					}
 					bool done = !have;
-					for (uint32_t guard = 0u;; guard++) {
-						if (guard > IP_THREADS) { fail = IF_BAD_CODE; break; }      // (cannot happen: the lowest open match is always ready)
-						const unsigned long long dm = __ballot(done);
-						if (lane == 0u) S.dmask[wave] = dm;
-						__syncthreads();
+					uint8_t *const o = S.out + rshift;
+					for (uint32_t spins = 0u; mine != ~0ull; spins++) {
+						if (spins > (1u << 20)) { if (lane == 0u) S.rfail = 1u; break; }      // (cannot happen: the lowest open piece is always ready)
 						bool ready = !done;
 						if (ready && dep) {
 							for (uint32_t w = a0 >> 6; w <= (b >> 6); w++) {
+								const unsigned long long dm = w == wave ? mine : __hip_atomic_load(&S.dmask[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 								const uint32_t f = w == (a0 >> 6) ? (a0 & 63u) : 0u, t = w == (b >> 6) ? (b & 63u) : 63u;
 								const unsigned long long need = (t == 63u ? ~0ull : ((1ull << (t + 1u)) - 1ull)) & ~((1ull << f) - 1ull);
-								if ((S.dmask[w] & need) != need) ready = false;
+								if ((dm & need) != need) ready = false;
 							}
 						}
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 						if (ready) {
-							uint8_t *o = S.out + rshift;
-							if (d >= l) {
-								for (uint32_t i = 0u; i < l; i += 8u) {
-									uint8_t v[8];
+							uint8_t v[IP_PIECE];
+							if (per == 0u) {
 #pragma unroll
-									for (uint32_t j = 0; j < 8u; j++) v[j] = i + j < l ? o[from + i + j] : (uint8_t)0;
-#pragma unroll
-									for (uint32_t j = 0; j < 8u; j++) if (i + j < l) o[p + i + j] = v[j];
-								}
+								for (uint32_t j = 0; j < IP_PIECE; j++) v[j] = j < l ? o[from + j] : (uint8_t)0;
 							} else {
-								const float rf = 1.0f / (float)d;
-								for (uint32_t i = 0u; i < l; i += 8u) {
-									uint8_t v[8];
+								const float rf = 1.0f / (float)per;
 #pragma unroll
-									for (uint32_t j = 0; j < 8u; j++) {
-										const uint32_t q = (uint32_t)(((float)(i + j) + 0.5f) * rf);
-										v[j] = i + j < l ? o[from + (i + j - q * d)] : (uint8_t)0;
-									}
-#pragma unroll
-									for (uint32_t j = 0; j < 8u; j++) if (i + j < l) o[p + i + j] = v[j];
+								for (uint32_t j = 0; j < IP_PIECE; j++) {
+									const uint32_t x = ph0 + j;
+									const uint32_t q = (uint32_t)(((float)x + 0.5f) * rf);
+									v[j] = j < l ? o[from + (x - q * per)] : (uint8_t)0;
 								}
 							}
+#pragma unroll
+							for (uint32_t j = 0; j < IP_PIECE; j++) if (j < l) o[p + j] = v[j];
 							done = true;
 						}
-						if (!__syncthreads_or(!done)) break;
+						const unsigned long long now = __ballot(done);
+						if (now != mine) {
+							mine = now;
+							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+							if (lane == 0u) __hip_atomic_store(&S.dmask[wave], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						} else {
+							__builtin_amdgcn_s_sleep(1);
+						}
 					}
+					__syncthreads();
+					if (PH && tid == 0) ph[11]++;
 				}
+				if (S.rfail) fail = IF_RETRY;
+				IP_PH(8);
 				if (fail) break;
 				pos += total;
 				if ((le & 0xffffffu) <= at) { fail = IF_BAD_CODE; break; }              // (cannot happen: a segment consumes bits)
@@ -1094,6 +1210,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 			status[bi] = IF_RETRY;
 			retry_list[atomicAdd(retry_n, 1u)] = bi;
 		}
+		IP_PH(9);
 	}
 }
 
@@ -1139,16 +1256,19 @@ __global__ void k_bgzf_refuse(uint32_t n_blocks, uint32_t every, uint32_t *__res
 #define IF_PER_CU 14                      // serial kernel: waves per compute unit, what its LDS holds
 #define IP_PER_CU 2                       // lane-parallel kernel: workgroups per compute unit (80 KB of LDS each)
 static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate only): device counters
+static unsigned long long *ip_phase_stats = nullptr;      // MSX_INFLATE_STATS=3: the lane-parallel kernel's clocks per phase
 
 // d_n_bad: [0] the refused blocks (zeroed by the caller), [1] the lane-parallel launch's ticket, [2] the number of blocks it
 // handed back, [3] the serial launch's ticket
 int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
                             const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
 	if (n_blocks <= 0) return MSX_OK;
-	// MSX_INFLATE_SERIAL=1: round 3's kernel for every block (one wave per block, one symbol after the other) -- the A/B of
-	// scripts/bench_inflate.py and the fallback's own test
-	const char *so_ = getenv("MSX_INFLATE_SERIAL");              // (read per launch: the tests switch it)
-	const int serial_only = so_ ? atoi(so_) : 0;
+	// MSX_INFLATE_LANES=1: the lane-parallel kernel (round 6) for every block, what it hands back to the serial one.  Off by
+	// default: measured on 8192 blocks it inflates lean records at 47.8 GB/s against the serial kernel's 50.2 and records
+	// with SEQ/QUAL at 75 against 108 (profiles/round6/inflate_lanes.md has the clocks per phase and why) -- every block
+	// equal to zlib's either way.  Read per launch: the tests switch it.
+	const char *so_ = getenv("MSX_INFLATE_LANES");
+	const int serial_only = !(so_ && atoi(so_) != 0);
 	static const int per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
 	int per_cu = per_cu_env > 0 ? per_cu_env : waves_per_cu > 0 ? waves_per_cu : IF_PER_CU;
 	if (per_cu > IF_PER_CU) per_cu = IF_PER_CU;
@@ -1176,8 +1296,12 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 			if ((rc = msx_reserve(ctx, &is->matches, want_m))) return rc;
 			if ((rc = msx_reserve(ctx, &is->retry, want_r < (1u << 18) ? (1u << 18) : want_r))) return rc;
 		}
-		hipLaunchKernelGGL(k_bgzf_inflate_par, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
-		                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2);
+		if (ip_phase_stats)
+			hipLaunchKernelGGL(k_bgzf_inflate_par<true>, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+			                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, ip_phase_stats);
+		else
+			hipLaunchKernelGGL(k_bgzf_inflate_par<false>, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+			                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, (unsigned long long *)nullptr);
 		// what it handed back: the serial kernel over that list (a launch that finds the list empty returns at once)
 		int64_t sgrid = grid < 4 * ctx->num_cu ? grid : 4 * ctx->num_cu;
 		grid = sgrid;
@@ -1209,9 +1333,26 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 	const int stats_mode = getenv("MSX_INFLATE_STATS") ? atoi(getenv("MSX_INFLATE_STATS")) : 0;   // 1: symbol counts (serial kernel); 2: blocks handed back
 	const bool want_stats = stats_mode == 1;
 	if (want_stats) { if_stats = d_bad + 8; MSX_HIP(ctx, hipMemsetAsync(if_stats, 0, 16, ctx->stream)); }
+	if (stats_mode == 3) {
+		if ((rc = msx_reserve(ctx, &ctx->scan_l2, 256))) return rc;
+		ip_phase_stats = (unsigned long long *)ctx->scan_l2.p;
+		MSX_HIP(ctx, hipMemsetAsync(ip_phase_stats, 0, 128, ctx->stream));
+	}
 	rc = msx_bgzf_inflate_launch(ctx, ctx->stream, 0, (const uint8_t *)d_comp, comp_len, d_blocks, n_blocks, (uint8_t *)d_out, d_status, d_bad);
 	if_stats = nullptr;
-	if (rc) return rc;
+	if (rc) { ip_phase_stats = nullptr; return rc; }
+	if (ip_phase_stats) {
+		unsigned long long h[16];
+		MSX_HIP(ctx, hipMemcpyAsync(h, ip_phase_stats, 128, hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ip_phase_stats = nullptr;
+		static const char *names[10] = {"ticket", "stage", "header", "tables", "pass A", "pass B", "sums", "pass C", "resolve", "write-back"};
+		fprintf(stderr, "# inflate phases, clocks per block (thread 0):");
+		for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.0f", names[k], (double)h[k] / (double)n_blocks);
+		fprintf(stderr, "; pass-B rounds %.2f, resolve windows %.2f per block; pass A of wave 0: %.1f loop trips per walk (the slowest lane), %.1f the average lane, %.2f walks per block\n",
+		        (double)h[10] / (double)n_blocks, (double)h[11] / (double)n_blocks, (double)h[12] / (double)(h[14] ? h[14] : 1),
+		        (double)h[13] / 64.0 / (double)(h[14] ? h[14] : 1), (double)h[14] / (double)n_blocks);
+	}
 	if (want_stats) {
 		uint32_t h[4];
 		MSX_HIP(ctx, hipMemcpyAsync(h, d_bad + 8, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1232,5 +1373,5 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 void msx_touch_inflate(void) {
 	hipFuncAttributes attr;
 	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_crc));
-	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_par));
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_par<false>));
 }

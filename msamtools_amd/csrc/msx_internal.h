@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -159,6 +160,10 @@ void msx_lane_enter(msx_ctx *ctx, int lane);
 void msx_lane_leave(msx_ctx *ctx);
 void msx_join(msx_ctx *ctx);
 int msx_reserve(msx_ctx *ctx, msx_buf *b, size_t bytes);
+// MSX_POISON=1 (tests): fresh workspace holds 0xa5 bytes, not the zeros a new allocation tends to hold -- a kernel that reads a
+// word nobody wrote then reads garbage here too.  Read the same way by every allocator, at every call (a test may switch it on
+// in the middle of a process).
+static inline bool msx_poison_on() { const char *e = getenv("MSX_POISON"); return e && atoi(e) != 0; }
 // msx_inflate.hip: inflate + CRC check of n_blocks BGZF blocks on `stream`, waves_per_cu waves per compute unit (0: all the LDS holds); d_n_bad[0] (zeroed by the caller) counts the refused, d_n_bad[1] is the launch's ticket counter
 int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
                             const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad);

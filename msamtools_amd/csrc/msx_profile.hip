@@ -182,7 +182,7 @@ int msx_grow_keep(msx_ctx *ctx, msx_buf *b, size_t bytes) {
 	void *np = nullptr;
 	hipError_t e = hipMalloc(&np, want);
 	if (e != hipSuccess) return msx_fail(ctx, MSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-	if (getenv("MSX_POISON")) MSX_HIP(ctx, hipMemsetAsync(np, 0xa5, want, ctx->stream));      // (tests: msx_reserve)
+	if (msx_poison_on()) MSX_HIP(ctx, hipMemsetAsync(np, 0xa5, want, ctx->stream));      // (tests: msx_reserve)
 	if (b->p) {
 		MSX_HIP(ctx, hipMemcpyAsync(np, b->p, b->cap, hipMemcpyDeviceToDevice, ctx->stream));
 		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -590,6 +590,13 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (u->inf_stream) (void)hipStreamSynchronize(u->inf_stream);
 	if (u->df_stream) (void)hipStreamSynchronize(u->df_stream);
 	if (u->copy_stream) (void)hipStreamSynchronize(u->copy_stream);
+	// what the context remembers of this unpacker's streams must not outlive them: the encoder's scratch was last used on
+	// df_stream (drained just above: nothing of it is in flight), the inflater keeps a scratch set per launching stream
+	if (ctx) {
+		if (u->df_stream && ctx->df_last == u->df_stream) { ctx->df_last = nullptr; ctx->df_used = false; }
+		for (auto &c : ctx->inf)
+			if (c.used && u->inf_stream && c.stream == u->inf_stream) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
+	}
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6: the lane-parallel inflater -- its tests (both kernels), then rate and every block against zlib on a lean and a
-# SEQ/QUAL file: gpurun -- 'bash scripts/r6_inflate.sh NAME [blocks]'
+# round 6: the lane-parallel inflater -- its tests (both kernels), then rate, clocks per phase and every block against zlib on a
+# lean and a SEQ/QUAL file and on a header's blocks: gpurun -- 'bash scripts/r6_inflate.sh NAME [blocks]'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 NAME=${1:-r6_inflate}; NB=${2:-8192}
 OUT=gpurun_out/$NAME; rm -rf $OUT; mkdir -p $OUT
@@ -9,7 +9,10 @@ timeout 900 python -m pytest tests/test_gpu_inflate.py -x -q -m gpu --timeout=24
 tail -5 $OUT/pytest.log
 $DEV synth --groups 1800000 --refs 100000 -b > /tmp/lean.bam
 $DEV synth --groups 500000 --refs 100000 --seq -b > /tmp/seq.bam
-ls -l /tmp/lean.bam /tmp/seq.bam
-MSX_INFLATE_STATS=2 timeout 600 python scripts/bench_inflate.py /tmp/lean.bam $NB --skip-bytes 3000000 --json $OUT/lean.json 2>&1 | tee $OUT/lean.log | tail -4
-MSX_INFLATE_STATS=2 timeout 600 python scripts/bench_inflate.py /tmp/seq.bam $NB --skip-bytes 3000000 --json $OUT/seq.json 2>&1 | tee $OUT/seq.log | tail -4
+for f in lean seq; do
+  MSX_INFLATE_STATS=3 timeout 600 python scripts/bench_inflate.py /tmp/$f.bam $NB --skip-bytes 3000000 2>&1 | grep phases | head -1 | tee $OUT/$f.phases.log
+  MSX_INFLATE_STATS=2 timeout 600 python scripts/bench_inflate.py /tmp/$f.bam $NB --skip-bytes 3000000 --json $OUT/$f.json 2>&1 | tee $OUT/$f.log | grep -v "^#\|handed back to the serial kernel, 0 refused" | tail -3
+  grep "handed back" $OUT/$f.log | sort | uniq -c | tail -2
+done
+MSX_INFLATE_STATS=3 timeout 600 python scripts/bench_inflate.py /tmp/lean.bam 64 2>&1 | grep phases | head -1 | tee $OUT/header.phases.log
 MSX_INFLATE_STATS=2 timeout 600 python scripts/bench_inflate.py /tmp/lean.bam 64 --json $OUT/header.json 2>&1 | tee $OUT/header.log | tail -4

@@ -58,7 +58,8 @@ int main(int argc, char **argv) {
 	size_t N = 65536, bad = 0, cases = 0, rejected = 0;
 	unsigned char *src = malloc(N), *comp = malloc(2 * N + 1024);
 	srand(4242);
-	for (size_t t = 0; t < 1500; t++) {
+	const size_t n_cases = getenv("IP_TWIN_CASES") ? (size_t)atol(getenv("IP_TWIN_CASES")) : 1500;
+	for (size_t t = 0; t < n_cases; t++) {
 		size_t n = (t % 7 == 0) ? N - (size_t)(rand() % 300) : 1 + (size_t)rand() % N, i, clen;
 		int kind = rand() % 6, level = 1 + rand() % 9, mem = rand() % 4 == 0 ? 1 + rand() % 8 : 8;
 		int strat = (rand() % 5 == 0) ? Z_FIXED : (rand() % 7 == 0 ? Z_HUFFMAN_ONLY : (rand() % 9 == 0 ? Z_RLE : Z_DEFAULT_STRATEGY));

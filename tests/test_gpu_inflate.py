@@ -24,12 +24,12 @@ def ctx():
 
 @pytest.fixture(autouse=True, params=["lanes", "serial"])
 def kernel(request, monkeypatch):
-    """every test twice: the lane-parallel kernel (k_bgzf_inflate_par: 256 lanes per deflate block, what it hands back goes
-    to the serial one) and the serial kernel alone (MSX_INFLATE_SERIAL=1: one wave per block, round 3's)"""
-    if request.param == "serial":
-        monkeypatch.setenv("MSX_INFLATE_SERIAL", "1")
+    """every test twice: the lane-parallel kernel (MSX_INFLATE_LANES=1, k_bgzf_inflate_par: 256 lanes per deflate block, what
+    it hands back goes to the serial one) and the serial kernel alone (one wave per block: the default)"""
+    if request.param == "lanes":
+        monkeypatch.setenv("MSX_INFLATE_LANES", "1")
     else:
-        monkeypatch.delenv("MSX_INFLATE_SERIAL", raising=False)
+        monkeypatch.delenv("MSX_INFLATE_LANES", raising=False)
     return request.param
 
 
