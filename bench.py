@@ -93,8 +93,9 @@ def parse():
                     help="N ranks: skip comparing the distributed result with one context doing all N shards")
     ap.add_argument("--no-dist-leg", action="store_true",
                     help="skip timing the multi-GPU step over a one-rank communicator (dist_one_rank_ms_per_step)")
-    ap.add_argument("--e2e-seq-groups", type=int, default=10_000_000,
-                    help="QNAME groups of the end-to-end BAM with SEQ/QUAL (~250 B per record); 0 = skip")
+    ap.add_argument("--e2e-seq-groups", type=int, default=20_000_000,
+                    help="QNAME groups of the end-to-end BAM with SEQ/QUAL (~221 B per record); the default is BASELINE configs[2]'s "
+                         "size (100 M records, 22 GB of BAM inflated) as for the lean file; 0 = skip")
     ap.add_argument("--dry-launch", action="store_true",
                     help="ranks print their launch environment as JSON and exit (tests of the launcher; no GPU)")
     return ap.parse_args()
@@ -233,27 +234,38 @@ def inflate_probe(m, ctx, path, n_blocks=8192):
         ctx.to_dev(d_comp, np.frombuffer(raw[:pos], np.uint8))
         ctx.to_dev(d_blk, np.frombuffer(bytes(arr), np.uint8))
         ref = C.c_int64()
-        ts = []
-        for _ in range(5):
-            ctx.sync()
-            t0 = time.perf_counter()
-            ctx.check(ctx.lib.msx_bgzf_inflate(ctx.h, C.c_void_p(d_comp), pos, C.c_void_p(d_blk), n, C.c_void_p(d_out), C.c_void_p(d_st),
-                                               C.byref(ref)))
-            ts.append(time.perf_counter() - t0)
-        best = min(ts[1:])
-        out = ctx.to_host(d_out, uo, np.uint8)
-        sample = list(range(0, n, max(1, n // 256)))
+
+        def timed():
+            ts = []
+            for _ in range(5):
+                ctx.sync()
+                t0 = time.perf_counter()
+                ctx.check(ctx.lib.msx_bgzf_inflate(ctx.h, C.c_void_p(d_comp), pos, C.c_void_p(d_blk), n, C.c_void_p(d_out), C.c_void_p(d_st),
+                                                   C.byref(ref)))
+                ts.append(time.perf_counter() - t0)
+            return min(ts[1:]), int(ref.value), ctx.to_host(d_out, uo, np.uint8).tobytes()
+        best, refused, out = timed()
+        # EVERY block against zlib (round 5 compared a sample of 256)
         t0 = time.perf_counter()
-        ok = all(zlib.decompress(raw[blocks[i][0]:blocks[i][0] + blocks[i][1]], -15) == out[arr[i].out_off:arr[i].out_off + arr[i].out_len].tobytes()
-                 for i in sample)
+        want = b"".join(zlib.decompress(raw[io:io + il], -15) for io, il, ol, crc in blocks)
         zs = time.perf_counter() - t0
-        zbytes = sum(blocks[i][2] for i in sample)
+        ok = out == want
+        # the lane-parallel kernel (round 6, MSX_INFLATE_LANES=1: 256 self-synchronising lanes per deflate block) on the same blocks
+        ctx.to_dev(d_out, np.zeros(uo, np.uint8))
+        os.environ["MSX_INFLATE_LANES"] = "1"
+        try:
+            best_l, refused_l, out_l = timed()
+        finally:
+            del os.environ["MSX_INFLATE_LANES"]
         return {"blocks": n, "compressed_MB": round(pos / 1e6, 1), "inflated_MB": round(uo / 1e6, 1), "ms": round(best * 1e3, 3),
-                "GBps_inflated": round(uo / best / 1e9, 1), "blocks_refused": int(ref.value),
-                "sample_equals_zlib": bool(ok), "sample_blocks": len(sample),
-                "zlib_one_core_GBps": round(zbytes / zs / 1e9, 2),
+                "GBps_inflated": round(uo / best / 1e9, 1), "blocks_refused": refused,
+                "every_block_equals_zlib": bool(ok), "blocks_compared": n,
+                "zlib_one_core_GBps": round(uo / zs / 1e9, 2),
                 "frac_of_hbm_peak": round((pos + uo) / best / 8e12, 4),
-                "bound": "not memory: one wave per block decodes serially -- scalar issue and LDS latency (DESIGN.md section 5)"}
+                "bound": "not memory: one wave per block decodes serially -- scalar issue and LDS latency (DESIGN.md section 3)",
+                "lane_parallel_kernel": {"ms": round(best_l * 1e3, 3), "GBps_inflated": round(uo / best_l / 1e9, 1), "blocks_refused": refused_l,
+                                         "every_block_equals_zlib": bool(out_l == want),
+                                         "note": "MSX_INFLATE_LANES=1; not the default: profiles/round6/inflate_lanes.md"}}
     finally:
         for q in (d_comp, d_blk, d_out, d_st):
             ctx.free(q)
@@ -542,6 +554,27 @@ def e2e_cli(groups, refs, expect=None, seq=False, probe=None, marginal_groups=0,
         return {"error": str(exc)[:300]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def headline(out):
+    """The figures a reader of the line looks for first, in one small object at its very end: the step, the dominant kernel's
+    fraction of the roof, and -- in M alignments/s -- the reference's two-process pipe (-bu and -b), the one-process form (-bu and
+    -b), the same with SEQ/QUAL records (configs[2]'s size), the inflater's rate and coverage's time."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    e, q = out.get("e2e"), out.get("e2e_seq")
+    h = {"ms_step": out.get("ms_per_step"), "frac": g(out, "roofline", "frac"),
+         "pipe_bu": g(e, "M_alignments_per_s"), "pipe_b": g(e, "pipe_compressed", "M_alignments_per_s"),
+         "one_bu": g(e, "one_process_tee", "M_alignments_per_s"), "one_b": g(e, "compressed_out", "M_alignments_per_s"),
+         "marginal_bu": g(e, "one_process_tee", "marginal", "marginal_M_alignments_per_s"),
+         "seq_records": g(q, "records"), "seq_pipe_bu": g(q, "M_alignments_per_s"), "seq_one_bu": g(q, "one_process_tee", "M_alignments_per_s"),
+         "seq_one_b": g(q, "compressed_out", "M_alignments_per_s"),
+         "inflate_GBps": g(e, "inflate", "GBps_inflated"), "seq_inflate_GBps": g(q, "inflate", "GBps_inflated"),
+         "cov_ms": g(out, "coverage", "ms"), "e2e_parity": g(e, "parity_ok"), "seq_parity": g(q, "parity_ok"),
+         "unit": "M alignments/s unless named"}
+    return {k: v for k, v in h.items() if v is not None}
 
 
 def exchange_comm_id(m, rank, world):
@@ -1112,6 +1145,7 @@ def main():
         if isinstance(out.get("coverage"), dict) and "error" not in out["coverage"]:
             out["coverage"]["cli"] = coverage_cli()
     if rank == 0:
+        out["headline"] = headline(out)         # (LAST key, <= 600 bytes: a record that keeps only the line's tail keeps these)
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line
         try:
             import ctypes

@@ -72,6 +72,7 @@ static inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_
 const uint8_t *msh_aux_get(const uint8_t *rec, size_t len, const char tag[2]);
 /* bam_aux2i: c C s S i I, 0 for anything else */
 int64_t msh_aux2i(const uint8_t *type_ptr);
+const uint8_t *msh_real_cigar(const uint8_t *r, size_t len, uint32_t *n_out, const uint8_t **cg_tag);   /* the CIGAR to compute from: the record's own, or its CG:B:I tag's (htslib: bam_tag2cigar) */
 /* size in bytes of the aux field starting at its type byte (type + payload) */
 size_t msh_aux_size(const uint8_t *type_ptr, const uint8_t *end);
 void msh_rec_check(const uint8_t *r, size_t len);       /* dies unless the fields the record announces fit its length */

@@ -212,6 +212,7 @@ void rb_mark_group(rbatch *b) {   /* a pool starts at the record about to be app
 void rb_append(rbatch *b, const uint8_t *r, size_t len, int want_stats) {
 	size_t i = b->n;
 	uint32_t nc = (msh_rec_check(r, len), REC_NCIGAR(r));
+	const uint8_t *cigw = msh_real_cigar(r, len, &nc, NULL);       /* (a long CIGAR kept in CG:B:I) */
 	const uint8_t *p, *end = r + len, *md = NULL, *nm = NULL, *as = NULL;
 	rb_reserve(b);
 	{
@@ -243,7 +244,7 @@ void rb_append(rbatch *b, const uint8_t *r, size_t len, int want_stats) {
 			b->md = (uint8_t *)realloc(b->md, b->md_cap);
 		}
 		if (!b->cigar || !b->md) mDie("Out of memory");
-		memcpy(b->cigar + b->cigar_off[i], REC_CIGAR(r), 4 * (size_t)nc);
+		memcpy(b->cigar + b->cigar_off[i], cigw, 4 * (size_t)nc);
 		if (ml) memcpy(b->md + b->md_off[i], md + 1, ml);
 		b->cigar_off[i + 1] = b->cigar_off[i] + nc;
 		b->md_off[i + 1] = b->md_off[i] + (uint32_t)ml;

@@ -345,6 +345,29 @@ const uint8_t *msh_aux_get(const uint8_t *rec, size_t len, const char tag[2]) {
 	return NULL;
 }
 
+/* The CIGAR the reference computes from (htslib's bam_tag2cigar under sam_read1, msam_helper.c:246-268): a CIGAR of more than
+ * 65535 operations is stored as the placeholder <l_seq>S<reference length>N with the real one in a CG:B:I tag (SAMv1 4.2.2),
+ * and the reader swaps it in -- for a mapped record whose first operation is S of l_seq bases and whose first CG tag is an
+ * array of I / i with at least n_cigar elements (fewer than 2^29).  Returns the words to use and their number; *cg_tag (if
+ * asked for) is the tag's first byte when the swap applies, NULL otherwise.  The record's bytes pass through as they are. */
+const uint8_t *msh_real_cigar(const uint8_t *r, size_t len, uint32_t *n_out, const uint8_t **cg_tag) {
+	const uint32_t n = REC_NCIGAR(r);
+	const uint8_t *cig = REC_CIGAR(r), *cg;
+	uint32_t c0, cnt;
+	*n_out = n;
+	if (cg_tag) *cg_tag = NULL;
+	if (n == 0 || REC_TID(r) < 0 || REC_POS(r) < 0) return cig;
+	c0 = (uint32_t)le32(cig);
+	if ((c0 & 15) != 4 || (c0 >> 4) != (uint32_t)REC_LSEQ(r)) return cig;
+	cg = msh_aux_get(r, len, "CG");
+	if (!cg || cg[0] != 'B' || (cg[1] != 'I' && cg[1] != 'i')) return cig;
+	cnt = (uint32_t)le32(cg + 2);
+	if (cnt < n || cnt >= (1u << 29)) return cig;
+	*n_out = cnt;
+	if (cg_tag) *cg_tag = cg - 2;
+	return cg + 6;
+}
+
 int64_t msh_aux2i(const uint8_t *s) {
 	switch (*s) {
 	case 'c': return (int8_t)s[1];
@@ -922,9 +945,10 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 	char *f[12], *p = line, *aux = NULL;
 	int nf = 0, i;
 	int32_t tid, mtid, pos, mpos, tlen;
-	uint32_t flag, mapq, n_cigar = 0, l_seq;
+	uint32_t flag, mapq, n_cigar = 0, l_seq, n_long = 0;
 	int64_t reflen = 0;
 	size_t qn_len, core_at;
+	static __thread kstr long_cigar;
 	while (nf < 11) {
 		char *t = strchr(p, '\t');
 		f[nf++] = p;
@@ -955,6 +979,7 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 	ks_put(rec, f[0], qn_len + 1);
 	if (strcmp(f[5], "*") != 0) {
 		char *c = f[5];
+		const size_t cigar_at = rec->l;
 		while (*c) {
 			char *e;
 			unsigned long len = strtoul(c, &e, 10);
@@ -967,6 +992,19 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 			}
 			n_cigar++;
 			c = e + 1;
+		}
+		if (n_cigar > 65535) {
+			/* more operations than BAM's 16-bit count holds: the placeholder <l_seq>S<reference length>N in the CIGAR's place and
+			 * the real one in a CG:B:I tag behind the other optional fields -- what htslib's bam_write1 stores (SAMv1 4.2.2) and
+			 * its reader swaps back (msh_real_cigar) */
+			ks_reserve(&long_cigar, 4 * (size_t)n_cigar);
+			memcpy(long_cigar.s, rec->s + cigar_at, 4 * (size_t)n_cigar);
+			long_cigar.l = 4 * (size_t)n_cigar;
+			n_long = n_cigar;
+			rec->l = cigar_at;
+			put_le32(rec, l_seq << 4 | 4u);
+			put_le32(rec, (uint32_t)reflen << 4 | 3u);
+			n_cigar = 2;
 		}
 	}
 	{   /* SEQ, 4-bit packed */
@@ -1036,6 +1074,11 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 		}
 		aux = t ? t + 1 : NULL;
 	}
+	if (n_long) {
+		ks_put(rec, "CGBI", 4);
+		put_le32(rec, n_long);
+		ks_put(rec, long_cigar.s, long_cigar.l);
+	}
 	{   /* fixed-length core */
 		uint8_t *c = (uint8_t *)rec->s + core_at;
 		int64_t end = pos + (reflen > 0 ? reflen : 1);
@@ -1056,7 +1099,8 @@ void msh_sam_format(const msh_hdr *h, const uint8_t *r, size_t len, kstr *o) {
 	int32_t tid = (msh_rec_check(r, len), REC_TID(r)), mtid = le32(r + 20);
 	uint32_t n_cigar = REC_NCIGAR(r), l_seq = (uint32_t)REC_LSEQ(r), k;
 	const uint8_t *cig = REC_CIGAR(r), *seq = cig + 4 * n_cigar, *qual = seq + (l_seq + 1) / 2;
-	const uint8_t *p = qual + l_seq, *end = r + len;
+	const uint8_t *p = qual + l_seq, *end = r + len, *cg_tag = NULL;
+	cig = msh_real_cigar(r, len, &n_cigar, &cg_tag);     /* (a long CIGAR kept in CG:B:I is printed in its place, the tag left out: what htslib's reader hands sam_format1) */
 	ks_puts(o, REC_QNAME(r));
 	ks_printf(o, "\t%u\t", REC_FLAG(r));
 	ks_puts(o, tid >= 0 && tid < h->n_targets ? h->target_name[tid] : "*");
@@ -1087,6 +1131,7 @@ void msh_sam_format(const msh_hdr *h, const uint8_t *r, size_t len, kstr *o) {
 	while (p + 3 <= end) {
 		int ty = p[2];
 		const size_t fsz = msh_aux_size(p + 2, end);       /* (checks that the field ends inside the record) */
+		if (p == cg_tag) { p += 2 + fsz; continue; }
 		ks_putc(o, '\t');
 		ks_put(o, p, 2);
 		switch (ty) {

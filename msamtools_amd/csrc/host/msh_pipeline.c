@@ -118,7 +118,7 @@ static void pack_scan(void *arg, int tid, int nth) {
 		b->as[i] = as ? (int32_t)msh_aux2i(as) : 0;
 		if (J->want_stats) {
 			size_t ml = (md && *md == 'Z') ? strlen((const char *)md + 1) : 0;
-			b->cigar_off[i + 1] = REC_NCIGAR(r);           /* counts; prefix-summed afterwards */
+			{ uint32_t nc_; (void)msh_real_cigar(r, len, &nc_, NULL); b->cigar_off[i + 1] = nc_; }    /* counts (the real CIGAR's: CG:B:I); prefix-summed afterwards */
 			b->md_off[i + 1] = (uint32_t)ml;
 			b->md_rel[i] = ml ? (uint32_t)(md + 1 - r) : 0;
 		} else {
@@ -139,7 +139,7 @@ static void pack_copy(void *arg, int tid, int nth) {
 	for (i = lo; i < hi; i++) {
 		const uint8_t *r = J->base + b->rec_off[i] + 4;
 		uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i], ml = b->md_off[i + 1] - b->md_off[i];
-		if (nc) memcpy(b->cigar + b->cigar_off[i], REC_CIGAR(r), 4 * (size_t)nc);
+		if (nc) { uint32_t n_; memcpy(b->cigar + b->cigar_off[i], msh_real_cigar(r, b->rec_off[i + 1] - b->rec_off[i] - 4, &n_, NULL), 4 * (size_t)nc); }
 		if (ml) memcpy(b->md + b->md_off[i], r + b->md_rel[i], ml);
 	}
 }

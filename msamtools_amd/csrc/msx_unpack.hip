@@ -68,7 +68,7 @@ struct msx_unpack {
 	} pre[2];
 	int ahead_head = 0, ahead_n = 0;   // the oldest pending set, how many are pending
 	hipStream_t inf_stream = nullptr, h2d_stream = nullptr;
-	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
+	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cig_src, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
 	    group_off, tile_last, cigar, md, out_len, out_off, out, framed;
 	char *prev_name = nullptr;     // device, 256 bytes
 	up_state *d_state = nullptr, *h_state = nullptr;
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restr
                                                           uint16_t *__restrict__ flag, uint8_t *__restrict__ rflags,
                                                           int32_t *__restrict__ tid, int32_t *__restrict__ pos,
                                                           int32_t *__restrict__ nm, int32_t *__restrict__ as,
-                                                          uint32_t *__restrict__ cig_cnt, uint32_t *__restrict__ md_len,
-                                                          uint32_t *__restrict__ md_src, up_state *st) {
+                                                          uint32_t *__restrict__ cig_cnt, uint32_t *__restrict__ cig_src,
+                                                          uint32_t *__restrict__ md_len, uint32_t *__restrict__ md_src, up_state *st) {
 	const uint32_t i = blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (i >= n_rec) return;
 	const uint32_t o = rec_off[i], len = rec_off[i + 1] - o - 4u;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restr
 	// msh_rec_check: the fields the record announces fit its length, the name is terminated
 	if (ls < 0 || lq < 1u || aux0 > len || r[32 + lq - 1] != 0) {
 		st->status = MSX_UP_CORRUPT;
-		flag[i] = 4; rflags[i] = 0; tid[i] = -1; pos[i] = 0; nm[i] = 0; as[i] = 0; cig_cnt[i] = 0; md_len[i] = 0; md_src[i] = 0;
+		flag[i] = 4; rflags[i] = 0; tid[i] = -1; pos[i] = 0; nm[i] = 0; as[i] = 0; cig_cnt[i] = 0; cig_src[i] = 0; md_len[i] = 0; md_src[i] = 0;
 		return;
 	}
 	flag[i] = (uint16_t)fl;
@@ -306,9 +306,17 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restr
 	pos[i] = (int32_t)ld32(r + 4);
 	uint32_t rf = 0, ml = 0, msrc = 0;
 	int32_t vnm = 0, vas = 0;
-	if (want_aux) {
+	// A CIGAR of more than 65535 operations is stored as the placeholder <l_seq>S<reference length>N with the real one in a
+	// CG:B:I tag (SAMv1 4.2.2); htslib's sam_read1 (under mSamRead, msam_helper.c:246-268: bam_tag2cigar) swaps it in, so
+	// the reference's statistics (mBamVector.c:23-133) and pile-up (msam_coverage.c:33-87) are computed from the real one.
+	// The same rule here: mapped, first operation S of l_seq bases, the first CG tag of type B with I / i elements and at
+	// least n_cigar of them (fewer than 2^29).  The record's bytes pass through as they are.
+	uint32_t csrc = (uint32_t)(r + 32 + lq - u), cn = nc;
+	const bool placeholder = nc >= 1u && (int32_t)ld32(r) >= 0 && (int32_t)ld32(r + 4) >= 0 &&
+	                         (ld32(r + 32 + lq) & 15u) == (uint32_t)MSX_OP_SOFT_CLIP && (ld32(r + 32 + lq) >> 4) == (uint32_t)ls;
+	if (want_aux || (placeholder && want_stats)) {
 		const uint8_t *p = r + aux0, *end = r + len;
-		bool md = false, hnm = false, has = false;
+		bool md = false, hnm = false, has = false, hcg = false;
 		bool bad = false;
 		while (p + 3 <= end && !bad) {
 			const uint32_t sz = aux_size(p + 2, end, &bad);
@@ -318,15 +326,24 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restr
 				if (p[2] == 'Z') { ml = sz - 2u; msrc = (uint32_t)(p + 3 - u); }      // type byte and NUL are not part of the string
 			} else if (p[0] == 'N' && p[1] == 'M' && !hnm) { hnm = true; vnm = aux2i(p + 2); }
 			else if (p[0] == 'A' && p[1] == 'S' && !has) { has = true; vas = aux2i(p + 2); }
+			else if (p[0] == 'C' && p[1] == 'G' && !hcg) {
+				hcg = true;
+				if (placeholder && p[2] == 'B' && (p[3] == 'I' || p[3] == 'i')) {
+					const uint32_t k = ld32(p + 4);
+					if (k >= nc && k < (1u << 29)) { cn = k; csrc = (uint32_t)(p + 8 - u); }
+				}
+			}
 			p += 2 + sz;
 		}
 		if (bad) st->status = MSX_UP_CORRUPT;
-		rf = (md ? MSX_HAS_MD : 0u) | (hnm ? MSX_HAS_NM : 0u) | (has ? MSX_HAS_AS : 0u);
+		if (want_aux) rf = (md ? MSX_HAS_MD : 0u) | (hnm ? MSX_HAS_NM : 0u) | (has ? MSX_HAS_AS : 0u);
+		else { ml = 0; msrc = 0; vnm = 0; vas = 0; }
 	}
 	rflags[i] = (uint8_t)rf;
 	nm[i] = vnm;
 	as[i] = vas;
-	cig_cnt[i] = want_stats ? nc : 0u;
+	cig_cnt[i] = want_stats ? cn : 0u;
+	cig_src[i] = csrc;
 	md_len[i] = want_stats ? ml : 0u;
 	md_src[i] = msrc;
 }
@@ -334,14 +351,13 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_rec_fields(const uint8_t *__restr
 __global__ __launch_bounds__(MSX_BLOCK) void k_rec_payload(const uint8_t *__restrict__ u, uint32_t n_rec,
                                                            const uint32_t *__restrict__ rec_off,
                                                            const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ md_off,
-                                                           const uint32_t *__restrict__ md_src, uint32_t *__restrict__ cigar,
-                                                           uint8_t *__restrict__ md) {
+                                                           const uint32_t *__restrict__ md_src, const uint32_t *__restrict__ cig_src,
+                                                           uint32_t *__restrict__ cigar, uint8_t *__restrict__ md) {
 	const uint32_t i = blockIdx.x * MSX_BLOCK + threadIdx.x;
 	if (i >= n_rec) return;
 	const uint32_t c0 = cigar_off[i], nc = cigar_off[i + 1] - c0;
 	if (nc) {
-		const uint8_t *r = u + rec_off[i] + 4;
-		const uint8_t *cg = r + 32 + r[8];
+		const uint8_t *cg = u + cig_src[i];            // the record's own CIGAR, or its CG:B:I tag's array (k_rec_fields)
 		for (uint32_t k = 0; k < nc; k++) cigar[c0 + k] = ld32(cg + 4 * k);
 	}
 	const uint32_t m0 = md_off[i], ml = md_off[i + 1] - m0;
@@ -598,7 +614,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 			if (c.used && u->inf_stream && c.stream == u->inf_stream) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
 	}
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
-	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
+	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cig_src, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
 	                   &u->out_off, &u->out, &u->framed, &u->eo[0], &u->eo[1], &u->ef[0], &u->ef[1], &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
 	                   &u->pre[0].status, &u->pre[0].out, &u->pre[0].cnt, &u->pre[1].comp, &u->pre[1].blk, &u->pre[1].status,
@@ -919,7 +935,7 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	}
 	const size_t c = (size_t)nr + 8;
 	UP_RES(flag, c * 2); UP_RES(rflags, c); UP_RES(tid, c * 4); UP_RES(pos, c * 4); UP_RES(nm, c * 4); UP_RES(as, c * 4);
-	UP_RES(cig_cnt, c * 4); UP_RES(cigar_off, (c + 1) * 4); UP_RES(md_len, c * 4); UP_RES(md_off, (c + 1) * 4); UP_RES(md_src, c * 4);
+	UP_RES(cig_cnt, c * 4); UP_RES(cig_src, c * 4); UP_RES(cigar_off, (c + 1) * 4); UP_RES(md_len, c * 4); UP_RES(md_off, (c + 1) * 4); UP_RES(md_src, c * 4);
 	UP_RES(bd, c); UP_RES(pidx, (c + 1) * 4); UP_RES(gflag, c * 4); UP_RES(gpos, (c + 1) * 4); UP_RES(group_off, (c + 1) * 4);
 	const uint32_t n_tiles = (nr + 1 + UP_TILE - 1) / UP_TILE;
 	UP_RES(tile_last, (size_t)(n_tiles + 2) * 4);
@@ -927,7 +943,7 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	const uint32_t *rec_off = (const uint32_t *)u->rec_off.p;
 	hipLaunchKernelGGL(k_rec_fields, dim3(gr), dim3(MSX_BLOCK), 0, ctx->stream, raw, nr, rec_off, P.want_aux, P.want_stats,
 	                   (uint16_t *)u->flag.p, (uint8_t *)u->rflags.p, (int32_t *)u->tid.p, (int32_t *)u->pos.p, (int32_t *)u->nm.p,
-	                   (int32_t *)u->as.p, (uint32_t *)u->cig_cnt.p, (uint32_t *)u->md_len.p, (uint32_t *)u->md_src.p, u->d_state);
+	                   (int32_t *)u->as.p, (uint32_t *)u->cig_cnt.p, (uint32_t *)u->cig_src.p, (uint32_t *)u->md_len.p, (uint32_t *)u->md_src.p, u->d_state);
 	if (P.want_stats) {
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->cig_cnt.p, (uint32_t *)u->cigar_off.p, nr))) return rc;
 		if ((rc = msx_scan_u32(ctx, (const uint32_t *)u->md_len.p, (uint32_t *)u->md_off.p, nr))) return rc;
@@ -935,7 +951,7 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 		UP_RES(cigar, n + 64);
 		UP_RES(md, n + 64);
 		hipLaunchKernelGGL(k_rec_payload, dim3(gr), dim3(MSX_BLOCK), 0, ctx->stream, raw, nr, rec_off, (const uint32_t *)u->cigar_off.p,
-		                   (const uint32_t *)u->md_off.p, (const uint32_t *)u->md_src.p, (uint32_t *)u->cigar.p, (uint8_t *)u->md.p);
+		                   (const uint32_t *)u->md_off.p, (const uint32_t *)u->md_src.p, (const uint32_t *)u->cig_src.p, (uint32_t *)u->cigar.p, (uint8_t *)u->md.p);
 	}
 	if (P.pool_mode != 0) {
 		hipLaunchKernelGGL(k_name_tile_last, dim3(n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, nr, P.pool_mode, P.unmapped_visible,

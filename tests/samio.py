@@ -223,6 +223,24 @@ def read_bam(path):
         cigar = list(struct.unpack_from(f"<{n_cig}I", rec, q))
         q += 4 * n_cig + (l_seq + 1) // 2 + l_seq
         md = nm = as_ = None
+        # a CIGAR of more than 65535 operations: placeholder <l_seq>S<ref_len>N + the real one in the first CG tag if that is
+        # B,I / B,i with at least n_cigar elements (htslib: bam_tag2cigar under sam_read1, msam_helper.c:246-268)
+        if n_cig >= 1 and tid >= 0 and pos >= 0 and (cigar[0] & 15) == 4 and (cigar[0] >> 4) == l_seq:
+            a, n_aux = q, len(rec)
+            while a + 3 <= n_aux:
+                ty = chr(rec[a + 2])
+                if rec[a:a + 2] == b"CG":
+                    if ty == "B" and chr(rec[a + 3]) in "Ii":
+                        cnt = struct.unpack_from("<I", rec, a + 4)[0]
+                        if n_cig <= cnt < (1 << 29):
+                            cigar = list(struct.unpack_from(f"<{cnt}I", rec, a + 8))
+                    break
+                if ty in _AUX_FIXED:
+                    a += 3 + _AUX_FIXED[ty]
+                elif ty in "ZH":
+                    a = rec.index(b"\0", a + 3) + 1
+                else:
+                    a += 8 + struct.unpack_from("<I", rec, a + 4)[0] * _AUX_FIXED[chr(rec[a + 3])]
         for tag, ty, val in _walk_aux(rec[q:]):
             if tag == b"MD" and md is None:
                 md = val if ty == "Z" else b""
