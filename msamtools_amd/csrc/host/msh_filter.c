@@ -66,7 +66,6 @@ typedef struct {
 	msx_profile *prof;          /* filter --profile-out: this device's part of the sample */
 	pthread_t th;
 	double t_ctx, t_upload, t_gpu, t_fetch, t_wait;
-	size_t n_prefetched;
 	double t_ctx_end;
 	double t_end[64];            /* MSX_TIMING: when the first batches left this stage */
 	int n_end;
@@ -231,7 +230,6 @@ void *filter_dev_thread(void *arg) {
 	int pending = PQ_NONE;             /* a slot taken off the queue ahead of its turn (its bytes are being sent up) */
 	int held = -1;                     /* (-b) the batch whose records the encoder is working on */
 	ahead_q ahead = {{PQ_NONE, PQ_NONE}, 0, 0};
-	const int prefetch_on = getenv("MSX_PREFETCH") != NULL;
 	{
 		double t0 = now_s();
 		/* HIP start-up runs beside the decoding of the first batch.  Should it fail, the input's own faults are
@@ -293,21 +291,6 @@ void *filter_dev_thread(void *arg) {
 			if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
 			unpack_slot_finish(P, s, unpack, &up, &ur, &db);
 			if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);        /* (not decoded yet a moment ago?) */
-			/* MSX_PREFETCH=1: the next batch, if it is decoded already, starts its way up now -- behind the bytes this
-			 * batch carried over -- and travels while this one is filtered and its output gathered and fetched.  Off by
-			 * default: measured, it changes nothing (upload phase 0.35-0.40 s of the 100 M-record run either way).  The
-			 * copies are not what that phase spends its time on (rocprofv3: 2.3 ms of upload per 130 MB batch at 56 GB/s,
-			 * 48 GB/s each way when both directions are busy -- scripts/micro/pcie_rate.hip -- in a phase of 6.5 ms):
-			 * the device thread synchronises five times per batch and has to be scheduled again each time on a host whose
-			 * granted CPUs are all busy inflating. */
-			if (F->n_dev == 1 && prefetch_on && !P->comp_mode) {
-				pending = pq_try_pop(&P->q_dev);
-				if (pending >= 0 && P->slot[pending].raw && !P->slot[pending].has_seed && !P->slot[pending].comp) {
-					pin_wait(P, &P->slot[pending]);
-					MSX(msx_unpack_prefetch(g_ctx, unpack, P->slot[pending].rbuf, P->slot[pending].rlen));
-					D->n_prefetched++;
-				}
-			}
 			D->t_upload += now_s() - t1; t1 = now_s();
 			b->n = (size_t)ur.n_records;
 			s->n_emit = 0;
@@ -622,7 +605,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 		for (k = 0; k < F.n_dev; k++) {
 			t_ctx += F.dev[k].t_ctx; t_up += F.dev[k].t_upload; t_gpu += F.dev[k].t_gpu; t_fetch += F.dev[k].t_fetch; t_dw += F.dev[k].t_wait;
 		}
-		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.comp_mode ? P.n_ahead : F.dev[0].n_prefetched,
+		fprintf(stderr, "# batches: %zu (%zu sent ahead)%s\n", n_batches, P.comp_mode ? P.n_ahead : (size_t)0,
 		        P.comp_mode ? "; BGZF blocks inflated on the device" : "");
 		if (P.n_host_inflated) fprintf(stderr, "# %zu batches inflated on the host (blocks the device refused)%s\n", P.n_host_inflated,
 		                               P.comp_given_up ? "; the device was not asked any more after that" : "");

@@ -1755,10 +1755,6 @@ struct msh_out {
 	uint8_t *ubuf;       /* BGZF payload being filled */
 	uint32_t ulen;
 	int level;
-	/* msh_write_framed: finished blocks written from where they are.  A regular file opened without O_APPEND takes
-	 * them as pwrite()s of disjoint ranges from several threads (par_threads > 1), the descriptor's offset moved behind
-	 * them afterwards */
-	int par_threads;     /* -1: not looked at yet */
 };
 #define BGZF_PAYLOAD 0xff00
 #define WCHUNK_BLOCKS 2048          /* blocks per chunk handed to the writer thread */
@@ -1951,7 +1947,6 @@ msh_out *msh_out_open(FILE *fp, int mode, const msh_hdr *h, const char *hdr_text
 	o->mode = mode;
 	o->hdr = h;
 	o->fd = -1;
-	o->par_threads = -1;
 	setvbuf(fp, NULL, _IOFBF, 1 << 20);
 	if (mode == MSH_OUT_BAM || mode == MSH_OUT_UBAM) {
 		fflush(fp);
@@ -2297,22 +2292,11 @@ void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n) {
 
 /* Finished BGZF blocks, back to back, as the device framed them (msx_unpack_emit_gather_bgzf): nothing is copied or
  * summed here.  The block a host-side writer call left open goes out first, as a short block of its own.
- * Regular file: written from where they are -- by MSX_WRITE_THREADS threads as pwrite()s of disjoint ranges when the
- * descriptor allows it (no O_APPEND, seekable).  Pipe: the bytes are copied once, by all threads, into a fresh
+ * Regular file: written from where they are by this one thread (pwrite()s of disjoint ranges from 4 / 8 / 16 threads
+ * measured 11.6 / 11.7 / 10.9 GB/s against 12.1 for one write(): the inode lock -- profiles/round4/write_rate.log; that path,
+ * MSX_WRITE_THREADS, was taken out in round 6).  Pipe: the bytes are copied once, by all threads, into a fresh
  * mapping that is handed over by reference (the caller's buffer is page-locked and reused, so it cannot be). */
-#include "msh_split.h"
-typedef struct { int fd; const uint8_t *src; uint8_t *dst; size_t n; off_t off; } fjob;
-static void framed_pwrite_worker(void *arg, int tid, int nth) {
-	const fjob *j = (const fjob *)arg;
-	size_t lo, hi;
-	msh_split_aligned(j->n, nth, tid, (size_t)1 << 20, &lo, &hi);
-	while (lo < hi) {
-		ssize_t k = pwrite(j->fd, j->src + lo, hi - lo, j->off + (off_t)lo);
-		if (k < 0 && errno == EINTR) continue;
-		if (k <= 0) mDie("Write failed");
-		lo += (size_t)k;
-	}
-}
+typedef struct { const uint8_t *src; uint8_t *dst; size_t n; } fjob;
 static void framed_copy_worker(void *arg, int tid, int nth) {
 	const fjob *j = (const fjob *)arg;
 	const size_t lo = j->n * (size_t)tid / (size_t)nth, hi = j->n * (size_t)(tid + 1) / (size_t)nth;
@@ -2325,18 +2309,8 @@ void msh_write_framed(msh_out *o, const uint8_t *blocks, size_t n) {
 	if (o->mode != MSH_OUT_BAM && o->mode != MSH_OUT_UBAM) mDie("msh_write_framed: not a BAM output");
 	if (o->ulen) bgz_flush_block(o);
 	writer_drain(o);
-	if (o->par_threads < 0) {
-		const char *e = getenv("MSX_WRITE_THREADS");
-		struct stat st;
-		const int fl = fcntl(o->fd, F_GETFL);
-		o->par_threads = 1;
-		if (fstat(o->fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND) && lseek(o->fd, 0, SEEK_CUR) >= 0)
-			o->par_threads = e ? atoi(e) : 1;
-		if (o->par_threads < 1) o->par_threads = 1;
-		if (o->par_threads > msh_threads()) o->par_threads = msh_threads();
-	}
 	memset(&J, 0, sizeof J);
-	J.fd = o->fd; J.src = blocks; J.n = n;
+	J.src = blocks; J.n = n;
 	if (__atomic_load_n(&o->is_pipe, __ATOMIC_RELAXED)) {
 		struct wchunk *c = (struct wchunk *)calloc(1, sizeof(*c));
 		int nth = msh_threads();
@@ -2350,12 +2324,6 @@ void msh_write_framed(msh_out *o, const uint8_t *blocks, size_t n) {
 		if ((size_t)nth > n / 65536 + 1) nth = (int)(n / 65536 + 1);
 		msh_parallel(nth, framed_copy_worker, &J);
 		writer_put(o, c);
-		return;
-	}
-	if (o->par_threads > 1 && n >= ((size_t)8 << 20)) {
-		J.off = lseek(o->fd, 0, SEEK_CUR);
-		msh_parallel(o->par_threads, framed_pwrite_worker, &J);
-		if (lseek(o->fd, J.off + (off_t)n, SEEK_SET) < 0) mDie("Write failed");
 		return;
 	}
 	while (n) {

@@ -581,8 +581,10 @@ void pipe_enable_raw(pipe_t *P, int with_obuf) {
  * its segment from there; the segments are then stitched in order: where a worker's first offset
  * is not the true one the stitcher walks on by itself until both chains meet (from any true start
  * the chain is the true chain).  Guesses only decide how much of the walk ran in parallel. */
-static int chase_sloppy = -1;      /* MSX_CHASE_SLOPPY=1 (tests): accept almost anything as a record start, so that
-                                      most guesses are wrong and the stitcher has to repair them */
+#ifdef MSX_DEBUG_SWITCHES
+static int chase_sloppy = -1;      /* MSX_CHASE_SLOPPY=1 (msamtools-dbg only; tests): accept almost anything as a record start, so
+                                      that most guesses are wrong and the stitcher has to repair them */
+#endif
 static int rec_plausible(const uint8_t *u, size_t off, size_t len, int32_t nt) {
 	const uint8_t *r;
 	int32_t bs, tid, pos, mtid, mpos, ls;
@@ -590,11 +592,13 @@ static int rec_plausible(const uint8_t *u, size_t off, size_t len, int32_t nt) {
 	if (off + 36 > len) return 0;
 	bs = le32(u + off);
 	if (bs < 32 || bs > (64 << 20)) return 0;
+#ifdef MSX_DEBUG_SWITCHES
 	{
 		int sl = __atomic_load_n(&chase_sloppy, __ATOMIC_RELAXED);      /* (every thread would compute the same value) */
 		if (sl < 0) { sl = getenv("MSX_CHASE_SLOPPY") != NULL; __atomic_store_n(&chase_sloppy, sl, __ATOMIC_RELAXED); }
 		if (sl) return bs < 4096;
 	}
+#endif
 	r = u + off + 4;
 	tid = REC_TID(r); pos = REC_POS(r); mtid = le32(r + 20); mpos = le32(r + 24);
 	if (tid < -1 || tid >= nt || mtid < -1 || mtid >= nt || pos < -1 || mpos < -1) return 0;

@@ -823,7 +823,7 @@ static int cov_pieces_finish(msx_ctx *ctx, uint32_t *items, const uint8_t *sups,
 	uint4 *units = (uint4 *)(((uintptr_t)(st + 1) + 15) & ~(uintptr_t)15);
 	MSX_HIP(ctx, hipMemsetAsync(st, 0, sizeof(cv2_state), ctx->stream));
 	if ((rc = msx_sort_k32v8(ctx, items, sups, items1, n_items, 24, &ctx->cv_hist, &ctx->cv_off, counted, 255, lay))) return rc;
-	static const uint32_t heavy_from = getenv("MSX_COV_HEAVY") ? (uint32_t)atoll(getenv("MSX_COV_HEAVY")) : CV2_HEAVY;
+	const uint32_t heavy_from = CV2_HEAVY;
 	hipLaunchKernelGGL(k_cov_starts3, dim3((unsigned)((2 * n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 	                   (const uint32_t *)items, (const uint32_t *)lay, n_tiles, start);
 	hipLaunchKernelGGL(k_cov_heavy_list3, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
@@ -832,7 +832,7 @@ static int cov_pieces_finish(msx_ctx *ctx, uint32_t *items, const uint8_t *sups,
 	hipLaunchKernelGGL(k_cov_heavy_add3, dim3(unit_cap < 2048u ? unit_cap : 2048u), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items,
 	                   (int32_t *)ctx->cv_side.p, (const cv2_state *)st, (const uint4 *)units, unit_cap);
 	hipLaunchKernelGGL(k_cov_depths3, dim3((unsigned)n_tiles), dim3(MSX_BLOCK), 0, ctx->stream, (const uint32_t *)items, (const uint32_t *)start,
-	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov, (getenv("MSX_COV_NO_NT") || acc) ? 0 : 1, acc);
+	                   (const int32_t *)slot_of, (const int32_t *)ctx->cv_side.p, total_len, cov, acc ? 0 : 1, acc);
 	MSX_HIP(ctx, hipGetLastError());
 	if (heavy_overflow) {
 		cv2_state h;
@@ -1094,7 +1094,7 @@ extern "C" int msx_coverage_depths(msx_ctx *ctx, const msx_batch *b, const int64
 		                          &sel, counted)))
 			return rc;
 		const uint32_t *sorted = (const uint32_t *)ctx->cv_key[sel].p;
-		static const uint32_t heavy_from = getenv("MSX_COV_HEAVY") ? (uint32_t)atoll(getenv("MSX_COV_HEAVY")) : CV2_HEAVY;
+		const uint32_t heavy_from = CV2_HEAVY;
 		hipLaunchKernelGGL(k_cov_starts2, dim3((unsigned)((2 * (n_tiles + 1) + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   sorted, n_items, n_tiles, sign_shift, start);
 		hipLaunchKernelGGL(k_cov_heavy_list, dim3((unsigned)((n_tiles + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,

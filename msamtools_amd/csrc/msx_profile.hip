@@ -327,12 +327,14 @@ int msx_profile_count_prepare(msx_ctx *ctx, msx_profile *p, const msx_batch *b, 
 		// Staging-table size (measured on MI355X): with ~1 M features a large table is needed to
 		// catch the hot references among the cold ones (2048: 1.5 ms vs 256: 2.7 ms at 20 M pools);
 		// with ~10 k features every slot is hot and the end-of-kernel flush dominates (256: 0.29 ms
-		// vs 2048: 0.56 ms at 2 M pools).  MSX_UI_TBL overrides.
+		// vs 2048: 0.56 ms at 2 M pools).
 		int tbl = p->n_features > 100000 ? UI_TBL : 256;
-		if (const char *e = getenv("MSX_UI_TBL")) {
+#ifdef MSX_DEBUG_SWITCHES
+		if (const char *e = getenv("MSX_UI_TBL")) {          // (libmsamtools_amd_dbg only: how the two sizes were chosen)
 			int v = atoi(e);
 			if (v >= 1) { tbl = 1; while (tbl < v && tbl < UI_TBL) tbl <<= 1; }
 		}
+#endif
 		A.tbl_mask = (uint32_t)tbl - 1u;
 	}
 	// uniquely mapped inserts: counted by partition when there are enough pools to pay for the six

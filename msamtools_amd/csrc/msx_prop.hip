@@ -1473,6 +1473,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_prop_purged(const unsigned long l
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+#ifdef MSX_DEBUG_SWITCHES
 // MSX_SR_CLASSES=1: how many entries of the derived store have 0 / 1 / 2 / 3 other features in their value, how many
 // belong to general lists (what a class-major order would have to work with)
 __global__ __launch_bounds__(MSX_BLOCK) void k_sr_classes(const unsigned long long *__restrict__ csr_tot, const unsigned long long *__restrict__ t_val,
@@ -1487,14 +1488,19 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_sr_classes(const unsigned long lo
 	}
 	for (int k = 0; k < 5; k++) if (c[k]) atomicAdd(&out[k], c[k]);
 }
+#endif
 
 // waves of one k_share_reduce launch: what the chip holds at once
 int64_t msx_share_waves(msx_ctx *ctx) {
+#ifdef MSX_DEBUG_SWITCHES
 	static const int wps = [] {
-		const char *e = getenv("MSX_SR_WPS");          // experiments: waves per SIMD the launch is sized for
+		const char *e = getenv("MSX_SR_WPS");          // experiments (libmsamtools_amd_dbg only): waves per SIMD the launch is sized for
 		const int v = e ? atoi(e) : 0;
 		return (v >= 1 && v <= 8) ? v : SR_WAVES_PER_SIMD;
 	}();
+#else
+	const int wps = SR_WAVES_PER_SIMD;
+#endif
 	return (int64_t)ctx->num_cu * 4 * wps;
 }
 int64_t msx_apply_blocks(int32_t nf) { return nf > 0 ? ((int64_t)nf + PA_FPB - 1) / PA_FPB : 1; }
@@ -1668,12 +1674,15 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 		if (hash_bits > 12) hash_bits = 12;
 		if (hash_bits < 0) hash_bits = 0;
 		int key_bits_total = bits + hash_bits;
+		int coarse = 0;
+#ifdef MSX_DEBUG_SWITCHES
+		// (libmsamtools_amd_dbg only; both measured and dropped in round 3)
 		if (const char *e = getenv("MSX_LIST_KEY_HASH")) {        // experiment: the sort key is a hash of the set alone, this many bits
 			const int v = atoi(e);
 			if (v >= 8 && v <= 32) { hash_bits = -v; key_bits_total = v; }
 		}
-		int coarse = 0;
 		if (const char *e = getenv("MSX_LIST_KEY_COARSE")) { const int v = atoi(e); if (v >= 0 && v < key_bits_total - 4) coarse = v; }
+#endif
 		if ((rc = msx_reserve(ctx, &p->m_off_alt, p->m_off.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->m_fid_alt, p->m_fid.cap + 64))) return rc;
 		if ((rc = msx_reserve(ctx, &p->head, (size_t)(lub + 8) * 4))) return rc;
@@ -1728,15 +1737,18 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 	{
 		const int64_t W = msx_share_waves(ctx);
 		MSX_HIP(ctx, hipMemsetAsync(p->owned.p, 0, (size_t)(p->n_features / 32 + 1) * 4, ctx->stream));
+		if (2 * W > (int64_t)PR_BLOCK * PR_PER_MAX) {              // (before the timing bracket opens and with the side lanes joined)
+			msx_join(ctx);
+			return msx_fail(ctx, MSX_ERR_ARG, "k_share_reduce with %lld waves: k_part_runs lists at most %d partial slots", (long long)W, PR_BLOCK * PR_PER_MAX);
+		}
 		msx_time_begin(ctx, MSX_K_LIST_ORDER);
 		hipLaunchKernelGGL(k_part_index, dim3(msx_grid(ctx, 2 * W, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[cur].p, bits, W,
 		                   (uint32_t *)p->part_key.p, p->d_tot);
-		if (2 * W > (int64_t)PR_BLOCK * PR_PER_MAX)
-			return msx_fail(ctx, MSX_ERR_ARG, "k_share_reduce with %lld waves: k_part_runs lists at most %d partial slots", (long long)W, PR_BLOCK * PR_PER_MAX);
 		hipLaunchKernelGGL(k_part_runs, dim3(1), dim3(PR_BLOCK), 0, ctx->stream,
 		                   (const uint32_t *)p->part_key.p, 2 * W, (PartRun *)p->runs.p, (uint32_t *)p->owned.p, p->d_tot);
 		msx_time_end(ctx);
+#ifdef MSX_DEBUG_SWITCHES
 		if (getenv("MSX_SR_CLASSES")) {
 			unsigned long long h[5] = {0, 0, 0, 0, 0}, *d = (unsigned long long *)p->part_val.p;      // (not in use yet)
 			MSX_HIP(ctx, hipMemsetAsync(d, 0, 40, ctx->stream));
@@ -1747,6 +1759,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 			fprintf(stderr, "# derived store: entries with 0 / 1 / 2 / 3 other features: %llu / %llu / %llu / %llu, of general lists: %llu\n",
 			        h[0], h[1], h[2], h[3], h[4]);
 		}
+#endif
 	}
 	p->transposed_valid = true;
 	MSX_HIP(ctx, hipGetLastError());
@@ -1776,7 +1789,13 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 		                             recip_args(p), (const int32_t *)p->iter_state));
 		p->recip_valid = true;
 	}
+#ifdef MSX_DEBUG_SWITCHES
+	// MSX_SR_GATHERS=1|2 (libmsamtools_amd_dbg only): the kernel instantiated for fewer operand gathers -- WRONG SUMS, the right
+	// instruction stream: round 4's pricing of a class-major order.  Not in the product library.
 	static const int ng = [] { const char *e = getenv("MSX_SR_GATHERS"); const int v = e ? atoi(e) : 3; return (v >= 1 && v <= 3) ? v : 3; }();
+#else
+	constexpr int ng = 3;
+#endif
 #define SR_LAUNCH(NG_)                                                                                                          \
 	hipLaunchKernelGGL(k_share_reduce<NG_>, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,                      \
 	                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,                        \
@@ -1784,7 +1803,12 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	                   (double *)p->part_val.p, (const int32_t *)p->iter_state,                                                  \
 	                   (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u), p->recip_at)
 	msx_time_begin(ctx, MSX_K_SHARE_REDUCE);
+#ifdef MSX_DEBUG_SWITCHES
 	if (ng == 3) SR_LAUNCH(3); else if (ng == 2) SR_LAUNCH(2); else SR_LAUNCH(1);
+#else
+	(void)ng;
+	SR_LAUNCH(3);
+#endif
 	msx_time_end(ctx);
 #undef SR_LAUNCH
 	if (complete) {

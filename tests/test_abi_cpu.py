@@ -122,3 +122,36 @@ def test_grouping_rules():
     assert len(off) - 1 == len(dict.fromkeys(names))
     hdr, rec = samio.read_sam(fixture_path("profile_unmapped.sam"))
     assert m.profile_pools(rec).tolist() == [0, 2]
+
+
+def _switch_lists():
+    text = open(os.path.join(ROOT, "README.md")).read()
+    prod = re.search(r"<!-- switches: product -->(.*?)<!-- /switches -->", text, re.S).group(1)
+    dbg = re.search(r"<!-- switches: debug -->(.*?)<!-- /switches -->", text, re.S).group(1)
+    names = lambda t: set(re.findall(r"MSX_[A-Z][A-Z0-9_]+", t))
+    return names(prod), names(dbg) - {"MSX_DEBUG_SWITCHES", "MSX_LIB_PATH"}
+
+
+def _names_in(path):
+    # (constants of the header that end up in error texts are not switches)
+    not_switches = {"MSX_NCCL_FLOAT64", "MSX_NCCL_SUM", "MSX_NCCL_UINT32", "MSX_POOLS_FILTER"}
+    return {m.decode() for m in re.findall(rb"MSX_[A-Z][A-Z0-9_]+", open(path, "rb").read())} - not_switches
+
+
+def test_the_product_knows_no_switch_that_readme_does_not_list_and_none_of_the_debug_ones():
+    """switches that make the library return wrong results (MSX_SR_GATHERS) and test hooks
+    (MSX_INFLATE_REFUSE, MSX_CHASE_SLOPPY) were live in the product.  They are compiled in only with -DMSX_DEBUG_SWITCHES now
+    (msamtools_amd/dbg/libmsamtools_amd.so, bin/msamtools-dev); README.md lists both sets and this test holds the binaries to it."""
+    from msamtools_amd import _lib
+    prod, dbg = _switch_lists()
+    assert prod and dbg and not (prod & dbg)
+    lib = _names_in(os.path.join(ROOT, "msamtools_amd", "libmsamtools_amd.so"))
+    exe = _names_in(os.path.join(ROOT, "msamtools_amd", "bin", "msamtools"))
+    assert not ((lib | exe) & dbg), sorted((lib | exe) & dbg)
+    assert (lib | exe) <= prod, sorted((lib | exe) - prod)
+    dlib = os.path.join(ROOT, "msamtools_amd", "dbg", "libmsamtools_amd.so")
+    ddev = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
+    assert dbg <= (_names_in(dlib) | _names_in(ddev)), sorted(dbg - (_names_in(dlib) | _names_in(ddev)))
+    # the debug library is the same ABI
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dlib]).decode()
+    assert set(declared_functions()) <= set(re.findall(r" T (msx_[a-z0-9_]+)", out))

@@ -159,6 +159,10 @@ def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
     """BGZF blocks are inflated on the device (msx_inflate.hip); batches with a block the device refuses (here: every 7th
     block, by a test switch) are inflated on the host instead; MSX_HOST_INFLATE=1 inflates everything there.  Same output."""
     out, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    if "MSX_INFLATE_REFUSE" in env:
+        # a test hook: only the debug build of the library knows it (msamtools_amd/dbg, -DMSX_DEBUG_SWITCHES); the product
+        # binary finds its library through a RUNPATH, which LD_LIBRARY_PATH precedes
+        env = dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "msamtools_amd", "dbg") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {out}", MSX_TIMING=1, **env)
     assert n_batches(r.stderr) >= 20
     err = r.stderr.decode()
