@@ -19,6 +19,32 @@
 #include <zlib.h>
 
 #include "msh_io_int.h"
+#include <poll.h>
+#include <time.h>
+
+/* A producer that trickles (an aligner writing SAM or BAM into the pipe as it goes): the reference writes a read's alignments
+ * as soon as the next read's first record has arrived (msam_filter.c:120-125,186); a batch pipeline that waits for its
+ * 96 MB would sit on them.  So a batch also ends when the input has had nothing to give for this long (MSX_IDLE_MS,
+ * default 50; 0: never): the reader thread hands over what it holds, the text reader returns what it has, and
+ * msh_input_ready tells the decode stage not to wait for more. */
+int msh_idle_ms(void) {
+	static int v = -1;
+	int c = __atomic_load_n(&v, __ATOMIC_RELAXED);
+	if (c < 0) {
+		const char *e = getenv("MSX_IDLE_MS");
+		c = e ? atoi(e) : 50;
+		if (c < 0) c = 0;
+		__atomic_store_n(&v, c, __ATOMIC_RELAXED);
+	}
+	return c;
+}
+static int fd_readable_within(int fd, int ms) {       /* 1: bytes (or the end of the input) can be read now */
+	struct pollfd pf;
+	int r;
+	pf.fd = fd; pf.events = POLLIN; pf.revents = 0;
+	do r = poll(&pf, 1, ms); while (r < 0 && errno == EINTR);
+	return r != 0;
+}
 
 /* ------------------------------------------------------------------------ */
 /* BGZF reader: batches of raw blocks inflated in parallel into one           */
@@ -135,7 +161,10 @@ static void *bgz_reader_main(void *arg) {
 			b->rd_prefill = 0;
 		}
 		while (n < b->ccap) {
-			ssize_t k = read(b->fd, b->rd_buf[slot] + RD_HEAD + n, b->ccap - n);
+			ssize_t k;
+			/* (the parser is waiting and the producer has gone quiet: what is here goes over now) */
+			if (n > 0 && msh_idle_ms() > 0 && __atomic_load_n(&b->rd_wait, __ATOMIC_RELAXED) && !fd_readable_within(b->fd, msh_idle_ms())) break;
+			k = read(b->fd, b->rd_buf[slot] + RD_HEAD + n, b->ccap - n);
 			if (k < 0 && errno == EINTR) continue;
 			if (k < 0) mDie("Read failed");
 			if (k == 0) { eof = 1; break; }
@@ -336,6 +365,8 @@ struct msh_in {
 	char *tbuf;
 	size_t tcap, tlen;   /* tbuf[0, tlen): text read but not parsed yet (an incomplete last line) */
 	int text_eof;
+	int text_raw;        /* stdio's buffer has been drained: the text is read from the descriptor (msh_sam_append) */
+	int idle_hit;        /* the last append returned early: the producer had gone quiet (msh_input_ready) */
 	/* gzip / bgzip-compressed SAM text (htslib's sam_open reads it like any other SAM): a thread inflates the stream into a
 	 * pipe, fp is the pipe's reading end and everything downstream sees plain text */
 	uint8_t *pre;        /* what msh_open read ahead of a gzip stream (at most PRE_MAX bytes) */
@@ -545,9 +576,25 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 			in->tbuf[in->tlen++] = '\n';
 		}
 		if (!in->text_eof) {
-			const size_t got = fread(in->tbuf + in->tlen, 1, SAM_CHUNK, in->fp);
+			/* what stdio holds from the header scan first, then the descriptor itself: a chunk, or less when the producer has
+			 * had nothing to give for msh_idle_ms() and at least a line is here (a regular file is always readable) */
+			size_t got = 0;
+			const int fd = fileno(in->fp), idle = msh_idle_ms();
+			if (!in->text_raw) {
+				const size_t pend = (size_t)(in->fp->_IO_read_end - in->fp->_IO_read_ptr);
+				if (pend) got = fread(in->tbuf + in->tlen, 1, pend < SAM_CHUNK ? pend : SAM_CHUNK, in->fp);
+				if (got == pend) in->text_raw = 1;            /* stdio's buffer is empty: from here on read(2) */
+			}
+			while (in->text_raw && got < SAM_CHUNK) {
+				ssize_t k;
+				if (idle > 0 && memchr(in->tbuf, '\n', in->tlen + got) && !fd_readable_within(fd, idle)) { in->idle_hit = 1; break; }
+				k = read(fd, in->tbuf + in->tlen + got, SAM_CHUNK - got);
+				if (k < 0 && errno == EINTR) continue;
+				if (k < 0) mDie("Read failed");
+				if (k == 0) { in->text_eof = 1; gz_text_check(in); break; }
+				got += (size_t)k;
+			}
 			in->tlen += got;
-			if (got < SAM_CHUNK) { in->text_eof = 1; gz_text_check(in); }
 		}
 		if (in->tlen == 0) return 0;
 		/* the chunk ends behind its last newline; at the end of the input the rest is a line as well */
@@ -588,6 +635,53 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 	in->tlen -= end;
 	if (total == 0 && (in->tlen > 0 || !in->text_eof)) return msh_sam_append(in, buf, len, cap);   /* (a chunk of empty lines) */
 	return total;
+}
+
+/* Can the next append make progress without waiting longer than `ms` for the producer?  (A mapped file: always.  BAM through
+ * a pipe: a whole block is in the buffer being parsed, or the reader thread has the next buffer, or the input has ended -- else
+ * wait that long for the reader, who hands over what it has once the producer goes quiet.  Text: a line is here, or the
+ * descriptor is readable.)  The decode stage asks this before it adds to a batch that already holds records. */
+int msh_input_ready(msh_in *in, int ms) {
+	if (in->is_bam) {
+		bgz_in *b = &in->bz;
+		int ok;
+		if (b->map || b->eof) return 1;
+		if (b->span_end > b->span_beg) return 1;
+		if (b->cur >= 0 && b->cend - b->cbeg >= 18) {
+			const uint8_t *h = b->cbuf + b->cbeg;
+			const size_t have = b->cend - b->cbeg;
+			const uint32_t xlen = le16(h + 10);
+			uint32_t p = 0, bsize = 0;
+			if (have >= 12 + (size_t)xlen)
+				while (p + 4 <= xlen) {
+					const uint32_t sl = le16(h + 12 + p + 2);
+					if (h[12 + p] == 'B' && h[12 + p + 1] == 'C' && sl == 2) bsize = le16(h + 12 + p + 4) + 1;
+					p += 4 + sl;
+				}
+			if (bsize && have >= bsize) return 1;
+		}
+		if (!b->rd_started) return 1;
+		pthread_mutex_lock(&b->rd_mu);
+		ok = b->rd_full[b->rd_head] || b->rd_eof;
+		if (!ok && ms > 0) {
+			struct timespec ts;
+			clock_gettime(CLOCK_REALTIME, &ts);
+			ts.tv_nsec += (long)(ms % 1000) * 1000000L;
+			ts.tv_sec += ms / 1000 + ts.tv_nsec / 1000000000L;
+			ts.tv_nsec %= 1000000000L;
+			__atomic_store_n(&b->rd_wait, 1, __ATOMIC_RELAXED);
+			while (!b->rd_full[b->rd_head] && !b->rd_eof)
+				if (pthread_cond_timedwait(&b->rd_cv_full, &b->rd_mu, &ts) != 0) break;
+			__atomic_store_n(&b->rd_wait, 0, __ATOMIC_RELAXED);
+			ok = b->rd_full[b->rd_head] || b->rd_eof;
+		}
+		pthread_mutex_unlock(&b->rd_mu);
+		return ok;
+	}
+	if (in->text_eof || in->has_pending) return 1;
+	if (in->idle_hit) { in->idle_hit = 0; return 0; }
+	if (!in->text_raw) return 1;
+	return fd_readable_within(fileno(in->fp), ms);
 }
 
 #define PRE_MAX 65536

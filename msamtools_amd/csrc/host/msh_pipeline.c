@@ -799,6 +799,7 @@ static void offs_worker(void *arg, int tid, int nth) {
 static size_t pipe_fill(pipe_t *P, pslot *s) {
 	rbatch *b = &s->b;
 	size_t n = 0, tail = 0, n_batch, i;
+	int must_read = 0;      /* what is here is not a batch yet (no whole record, one pool only): the next bytes are waited for */
 	pack_job J;
 	s->ulen = 0;
 	if (P->carry.l) {
@@ -817,8 +818,13 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 	for (;;) {
 		size_t want = P->batch_bytes;
 		double tq = now_s(), tq2;
-		while (!P->in_eof && s->ulen < want)
+		/* a batch behind the first (which holds the preflight's window, as the reference's look-ahead does) also ends where the
+		 * producer goes quiet: the reference writes pool by pool (msam_filter.c:120-125,186) */
+		while (!P->in_eof && s->ulen < want) {
+			if (!must_read && P->have_first && s->ulen > 0 && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;
+			must_read = 0;
 			if (!pipe_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
+		}
 		tq2 = now_s(); P->t_inflate += tq2 - tq; tq = tq2;
 		if (s->ulen == 0) return 0;
 		n = chase_records(P, b, s->ubuf, s->ulen, P->cap_rec, &tail);
@@ -826,11 +832,13 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		if (P->in_eof && n < P->cap_rec && tail != s->ulen) mDie("Truncated BAM record");
 		if (!P->have_first && n < COORD_ORDER_CHECK_RECORDS && !P->in_eof) {   /* the preflight window (msam_helper.c:4-6) */
 			P->batch_bytes += P->batch_bytes;
+			must_read = 1;
 			continue;
 		}
 		if (n == 0) {
 			if (P->in_eof) return 0;
-			P->batch_bytes += P->batch_bytes;            /* a record larger than the batch: read on */
+			if (s->ulen >= want) P->batch_bytes += P->batch_bytes;            /* a record larger than the batch: read on */
+			must_read = 1;
 			continue;
 		}
 		/* aux scan, SoA scalars, pool boundaries */
@@ -855,7 +863,8 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 			if (n_batch == 0) {          /* one pool fills the whole batch: take more bytes */
 				if (P->in_eof && tail == s->ulen) { n_batch = n; break; }
 				if (n >= P->cap_rec) mDie("A single QNAME group exceeds the batch capacity (%zu records); raise MSX_BATCH_RECORDS", P->cap_rec);
-				P->batch_bytes += P->batch_bytes / 2;
+				if (s->ulen >= want) P->batch_bytes += P->batch_bytes / 2;
+				must_read = 1;
 				continue;
 			}
 		}
@@ -968,16 +977,22 @@ void *pipe_decode_thread(void *arg) {
 					const size_t before = s->rlen;
 					if (s->rcap / 65536 < per + 2) per = s->rcap / 65536 > 2 ? s->rcap / 65536 - 2 : 1;
 					msh_inflate_limit((int)per);
-					while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + (per + 1) * 65536 + 64 <= s->rcap)
+					while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + (per + 1) * 65536 + 64 <= s->rcap) {
+						if (s->rlen > before && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;
 						if (!pipe_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
+					}
 					msh_inflate_limit(0);
 					if (s->rlen == before && !P->in_eof) mDie("The batch buffers are too small for a BGZF block (MSX_COMP_BYTES)");
 				} else if (P->comp_mode) {
-					while (!P->in_eof && s->n_blk < P->comp_blocks && (s->rcap - s->rlen) / (65536 + 1024) > 0)
+					while (!P->in_eof && s->n_blk < P->comp_blocks && (s->rcap - s->rlen) / (65536 + 1024) > 0) {
+						if (s->n_blk > 0 && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;      /* (the producer has gone quiet) */
 						if (!msh_raw_append(P->in, s->rbuf, s->rcap, &s->rlen, s->blk, &s->n_blk, P->comp_blocks, &s->inflated)) P->in_eof = 1;
+					}
 				} else
-				while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + BGZF_INFLATE_MAX + 64 <= s->rcap)
+				while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + BGZF_INFLATE_MAX + 64 <= s->rcap) {
+					if (s->rlen > 0 && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;
 					if (!pipe_append(P->in, &s->rbuf, &s->rlen, &s->rcap)) P->in_eof = 1;
+				}
 				s->last = P->in_eof;
 				if (s->last) P->raw_done = 1;
 				n = 1;                       /* (a slot: possibly without bytes, its `last` flag flushes the device's carry) */
