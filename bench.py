@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--e2e-seq-groups", type=int, default=20_000_000,
                     help="QNAME groups of the end-to-end BAM with SEQ/QUAL (~221 B per record); the default is BASELINE configs[2]'s "
                          "size (100 M records, 22 GB of BAM inflated) as for the lean file; 0 = skip")
+    ap.add_argument("--e2e-sam-groups", type=int, default=4_000_000,
+                    help="QNAME groups of the SAM-text leg (SEQ/QUAL records, ~20 M of them, ~7 GB of text: the reference's documented "
+                         "workflow is an aligner piping SAM into `filter -S`); 0 = skip")
     ap.add_argument("--dry-launch", action="store_true",
                     help="ranks print their launch environment as JSON and exit (tests of the launcher; no GPU)")
     return ap.parse_args()
@@ -572,9 +575,88 @@ def headline(out):
          "seq_records": g(q, "records"), "seq_pipe_bu": g(q, "M_alignments_per_s"), "seq_one_bu": g(q, "one_process_tee", "M_alignments_per_s"),
          "seq_one_b": g(q, "compressed_out", "M_alignments_per_s"),
          "inflate_GBps": g(e, "inflate", "GBps_inflated"), "seq_inflate_GBps": g(q, "inflate", "GBps_inflated"),
+         "sam_pipe": g(out, "e2e_sam", "pipe", "M_alignments_per_s"), "sam_one": g(out, "e2e_sam", "one_process", "M_alignments_per_s"),
          "cov_ms": g(out, "coverage", "ms"), "e2e_parity": g(e, "parity_ok"), "seq_parity": g(q, "parity_ok"),
          "unit": "M alignments/s unless named"}
     return {k: v for k, v in h.items() if v is not None}
+
+
+def e2e_sam(groups, refs, expect=None):
+    """The reference's documented workflow is SAM TEXT on stdin from the aligner (`bwa-mem2 mem ... | msamtools filter -S -bu ...
+    --besthit - | msamtools profile ... -`, the reference's README.md:133-134, :197-199; input mode "r", msam.h:105): `groups`
+    QNAME groups of SEQ/QUAL records as SAM text, written by `cat` into the pipe, through (a) that two-process pipe and (b) the
+    one-process form; the text is parsed into BAM records on the host cores (msh_sam.c, all threads), everything behind that is
+    the pipeline of the BAM legs.  Parity: filter's records against the oracle's emit list for the same stream (count and the
+    order-sensitive digest of QNAME / FLAG / tid / pos), the profile's header counts against the oracle's."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools")
+    dev = os.path.join(ROOT, "msamtools_amd", "bin", "msamtools-dev")
+    tmp = tempfile.mkdtemp(prefix="msx_sam_", dir="/tmp")
+    filt = "filter -S -l 80 -p 95 -z 80 --besthit -bu"
+    env = dict(os.environ, MSX_TIMING="1")
+
+    def run(cmd):
+        time.sleep(1.0)
+        t = time.perf_counter()
+        r = subprocess.run(cmd, shell=True, env=env, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+        dt = time.perf_counter() - t
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr.decode()[-500:])
+        return dt, r.stderr.decode()
+
+    def stage(err, kind, key, pat):
+        for line in err.split("\n"):
+            if line.startswith(f"# {kind} pipeline:"):
+                mm = re.search(pat, line)
+                if mm:
+                    return float(mm.group(1))
+        return None
+    try:
+        t0 = time.perf_counter()
+        subprocess.check_call(f"{dev} synth --groups {groups} --refs {refs} --seq -h > {tmp}/in.sam", shell=True)
+        synth_s = time.perf_counter() - t0
+        size = os.path.getsize(f"{tmp}/in.sam")
+        subprocess.check_call(f"cat {tmp}/in.sam > /dev/null", shell=True)
+        dt_p, err_p = run(f"cat {tmp}/in.sam | {exe} {filt} - | {exe} profile --label S -o {tmp}/p.gz -")
+        dt_p2, err_p2 = run(f"cat {tmp}/in.sam | {exe} {filt} - | {exe} profile --label S -o {tmp}/p.gz -")
+        if dt_p2 < dt_p:
+            dt_p, err_p = dt_p2, err_p2
+        dt_t, err_t = run(f"cat {tmp}/in.sam | {exe} {filt} --profile-out {tmp}/pt.gz --label S - > {tmp}/ft.bam")
+        dt_t2, err_t2 = run(f"cat {tmp}/in.sam | {exe} {filt} --profile-out {tmp}/pt.gz --label S - > {tmp}/ft.bam")
+        if dt_t2 < dt_t:
+            dt_t, err_t = dt_t2, err_t2
+        out = subprocess.check_output([dev, "digest", f"{tmp}/ft.bam"]).decode().split()
+        n_out, dg = int(out[0].split("=")[1]), out[1].split("=")[1]
+        n = int(subprocess.check_output(f"grep -vc '^@' {tmp}/in.sam", shell=True).decode())
+        res = {"records": n, "text_MB": round(size / 1e6, 1), "bytes_per_record": round(size / max(n, 1), 1), "synth_s": round(synth_s, 1),
+               "pipe": {"command": f"cat in.sam | msamtools {filt} - | msamtools profile --label S -o p.gz -",
+                        "M_alignments_per_s": round(n / dt_p / 1e6, 2), "seconds": round(dt_p, 3),
+                        "filter_decode_s": stage(err_p, "filter", "decode_s", r"decode ([0-9.]+) s"),
+                        "filter_wall_s": stage(err_p, "filter", "wall_s", r"wall ([0-9.]+) s")},
+               "one_process": {"command": f"cat in.sam | msamtools {filt} --profile-out p.gz --label S - > f.bam",
+                               "M_alignments_per_s": round(n / dt_t / 1e6, 2), "seconds": round(dt_t, 3),
+                               "decode_s": stage(err_t, "filter", "decode_s", r"decode ([0-9.]+) s"),
+                               "wall_s": stage(err_t, "filter", "wall_s", r"wall ([0-9.]+) s"),
+                               "text_GBps": round(size / dt_t / 1e9, 2)},
+               "threads": granted_cpus(),
+               "bound": "the text is parsed into BAM records on the granted host cores (decode_s is that stage's busy time)"}
+        if expect is not None:
+            par = {"filter_records_out": n_out, "filter_records_oracle": int(expect["n_emit"])}
+            par["filter_ok"] = bool(n_out == expect["n_emit"] and ("emit_digest" not in expect or dg == f"{expect['emit_digest']:016x}"))
+            if "pipe" in expect:
+                par["pipe_profile"] = profile_parity(f"{tmp}/p.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, 4496)
+                par["one_process_profile"] = profile_parity(f"{tmp}/pt.gz", expect["pipe"]["stats"], expect["pipe"]["abundance"], refs, 4496)
+            par["parity_ok"] = bool(par["filter_ok"] and all(v.get("ok", True) for v in par.values() if isinstance(v, dict)))
+            res["parity"] = par
+            res["parity_ok"] = par["parity_ok"]
+        return res
+    except Exception as exc:
+        return {"error": str(exc)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def exchange_comm_id(m, rank, world):
@@ -1005,6 +1087,16 @@ def main():
                 goff_s = int(hs.group_off[args.e2e_seq_groups])
                 e2e_seq_expect = {"n_emit": int(np.searchsorted(em, goff_s))}
                 e2e_seq_expect["emit"] = em[:e2e_seq_expect["n_emit"]]       # (pools are independent: the prefix's emit list is the list's prefix)
+            elif args.e2e_seq_groups == ng:
+                e2e_seq_expect = e2e_expect               # the same stream with SEQ and QUAL: same records kept, same profile
+            if args.e2e_sam_groups and args.e2e_sam_groups <= ng:
+                # the SAM-text leg reads a prefix of the same stream: filter's records are the emit list's prefix (count and digest)
+                n_s = int(np.searchsorted(em, int(hs.group_off[args.e2e_sam_groups])))
+                counts_s = np.diff(hs.group_off[:args.e2e_sam_groups + 1].astype(np.int64))
+                gidx_s = np.repeat(np.arange(counts_s.size, dtype=np.int64), counts_s)
+                ems = em[:n_s]
+                h_s, cnt_s = dg.stream_digest(hs.flag[ems], hs.tid[ems], hs.pos[ems], dg.fnv_sim_names(gidx_s[ems]))
+                e2e_sam_expect = {"n_emit": cnt_s, "emit_digest": h_s}
         out["cpu_baseline"] = {
             "value": round(hs.n_records / best / 1e6, 3), "unit": "M alignments/s", "cores": 1, "kind": "port",
             "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_granted": granted_cpus(),
@@ -1142,6 +1234,8 @@ def main():
         if args.e2e_seq_groups:
             out["e2e_seq"] = e2e_cli(args.e2e_seq_groups, e2e_refs, locals().get("e2e_seq_expect"), seq=True, probe=probe,
                                      marginal_groups=args.e2e_seq_groups // 4)
+        if args.e2e_sam_groups:
+            out["e2e_sam"] = e2e_sam(args.e2e_sam_groups, e2e_refs, locals().get("e2e_sam_expect"))
         if isinstance(out.get("coverage"), dict) and "error" not in out["coverage"]:
             out["coverage"]["cli"] = coverage_cli()
     if rank == 0:

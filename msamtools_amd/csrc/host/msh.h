@@ -98,6 +98,7 @@ void msh_inflate_table(const uint8_t *comp, const msx_bgzf_block *blk, int n, ui
 void msh_inflate_limit(int blocks);      /* at most this many BGZF blocks per msh_inflate_append call (0: the default batch) */
 /* the same for SAM text: the next chunk of lines parsed on all threads into BAM records; at most MSH_SAM_APPEND_MAX bytes */
 size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap);
+extern void (*msh_exit_hook)(int rc);     /* set by msh_main.c under MSX_DETACH=1; called before every _exit */
 int msh_idle_ms(void);                       /* MSX_IDLE_MS: a batch ends when the producer has been quiet this long (default 50; 0: never) */
 int msh_input_ready(msh_in *in, int ms);     /* the next append can make progress without waiting longer than ms for the producer */
 #define MSH_SAM_APPEND_MAX ((size_t)48 << 20)

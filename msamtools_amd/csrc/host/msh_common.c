@@ -75,9 +75,10 @@ void fast_exit(void) {
 	if (getenv("MSX_CLEAN_EXIT")) { runtime_warmup_join(); return; }
 	/* MSX_GUARD=1 (tests): nothing is freed on this way out, so the guard bytes around the library's device allocations are
 	 * looked at here (include/msamtools_amd.h: msx_debug_guard_check) */
-	if (getenv("MSX_GUARD") && msx_debug_guard_check() > 0) { fflush(NULL); _exit(70); }
+	if (getenv("MSX_GUARD") && msx_debug_guard_check() > 0) { fflush(NULL); if (msh_exit_hook) msh_exit_hook(70); _exit(70); }
 	fflush(stdout);
 	fflush(stderr);
+	if (msh_exit_hook) msh_exit_hook(0);
 	_exit(0);
 }
 

@@ -96,7 +96,8 @@ int synth_main(int argc, char *argv[]) {
 		else if (strcmp(argv[i], "--seq") == 0) with_seq = 1;
 		else if (strcmp(argv[i], "-b") == 0) mode = MSH_OUT_BAM;
 		else if (strcmp(argv[i], "-u") == 0) mode = MSH_OUT_UBAM;
-		else mQuit("usage: %s synth --groups N --refs R [--seed S] [--seq] [-b|-u]", PROGRAM);
+		else if (strcmp(argv[i], "-h") == 0) mode = MSH_OUT_SAM_HDR;      /* SAM text with its header: what an aligner pipes into `filter -S` */
+		else mQuit("usage: %s synth --groups N --refs R [--seed S] [--seq] [-b|-u|-h]", PROGRAM);
 	}
 	if (msx_synth_host(&sp, &hb, &sz) != MSX_OK) mDie("%s", msx_last_error(NULL));
 	memset(&hdr, 0, sizeof hdr);

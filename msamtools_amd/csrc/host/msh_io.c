@@ -24,6 +24,7 @@
 /* ------------------------------------------------------------------------ */
 pthread_t msh_main_thread;
 int msh_main_thread_set;
+void (*msh_exit_hook)(int rc);     /* msh_main.c, MSX_DETACH=1: called with the exit code by whatever is about to _exit */
 
 void mDie(const char *fmt, ...) {
 	va_list ap;
@@ -39,6 +40,7 @@ void mDie(const char *fmt, ...) {
 	 * and stderr; NOT fflush(NULL): that locks every open stream in turn, the input's among them, and a reader sitting in a
 	 * read of a pipe holds its stream's lock for as long as the other end is silent -- the error would wait with it */
 	fflush(stderr);
+	if (msh_exit_hook) msh_exit_hook(EXIT_FAILURE);
 	if (msh_main_thread_set) _exit(EXIT_FAILURE);       /* (the command line: device, reader or writer threads may be running) */
 	exit(EXIT_FAILURE);
 }
