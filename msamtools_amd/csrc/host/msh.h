@@ -122,7 +122,8 @@ void msh_write_many(msh_out *o, const uint8_t *base, const size_t *rec_off, cons
 void msh_write_stream(msh_out *o, const uint8_t *bytes, size_t n);
 /* finished BGZF blocks, back to back (framed on the device): written as they are */
 void msh_write_framed(msh_out *o, const uint8_t *blocks, size_t n);
-void msh_out_drain(msh_out *o);     /* before dying: what was handed to the writer is written out */
+void msh_out_drain(msh_out *o);
+void msh_out_flush(msh_out *o);          /* the open block and stdio's buffer go out now (the writer is about to wait for input) */     /* before dying: what was handed to the writer is written out */
 void msh_out_close(msh_out *o);
 
 /* SAM text <-> BAM record */

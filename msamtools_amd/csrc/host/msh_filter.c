@@ -400,8 +400,8 @@ void *filter_dev_thread(void *arg) {
 }
 
 /* the writer's side of q_out: the slot that holds batch `seq` (device threads finish in any order), or PQ_END */
-static int pq_pop_seq(pq *q, const pipe_t *P, size_t seq) {
-	int i, v = PQ_END - 1;
+static int pq_pop_seq(pq *q, const pipe_t *P, size_t seq, msh_out *out) {
+	int i, v = PQ_END - 1, flushed = 0;
 	pthread_mutex_lock(&q->mu);
 	for (;;) {
 		int end = 0;
@@ -416,6 +416,15 @@ static int pq_pop_seq(pq *q, const pipe_t *P, size_t seq) {
 			break;
 		}
 		if (end) { v = PQ_END; break; }       /* (pushed after every batch: nothing more can arrive) */
+		if (out && !flushed) {
+			/* the writer has to wait for its next batch (a producer that trickles): what earlier batches left in the
+			 * output's buffers -- an open BGZF block, stdio's share of the text -- goes out first (msh_out_flush) */
+			flushed = 1;
+			pthread_mutex_unlock(&q->mu);
+			msh_out_flush(out);
+			pthread_mutex_lock(&q->mu);
+			continue;
+		}
 		pthread_cond_wait(&q->cv, &q->mu);
 	}
 	pthread_mutex_unlock(&q->mu);
@@ -527,7 +536,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	}
 	for (;;) {                                   /* this thread is the encode stage: batches in input order */
 		double t0 = now_s(), t1;
-		const int si = pq_pop_seq(&P.q_out, &P, seq);
+		const int si = pq_pop_seq(&P.q_out, &P, seq, seq > 0 ? F.out : NULL);     /* (behind batch 0: the output is open) */
 		pslot *s;
 		MSH_TRACE("writer has batch %zu (slot %d)", seq, si);
 		t1 = now_s();

@@ -617,6 +617,15 @@ void msh_write_framed(msh_out *o, const uint8_t *blocks, size_t n) {
 	}
 }
 
+/* Nothing written so far stays in this process: the open BGZF block goes out as a short block of its own, stdio's buffer
+ * is flushed.  Called by a writer that has to wait for its next batch (a slow producer must see its output). */
+void msh_out_flush(msh_out *o) {
+	if (!o) return;
+	if ((o->mode == MSH_OUT_BAM || o->mode == MSH_OUT_UBAM) && o->ulen) bgz_flush_block(o);
+	writer_drain(o);
+	fflush(o->fp);
+}
+
 /* everything handed over so far is in the descriptor; the open block is NOT written (a fatal error follows: the
  * reference dies with its last buffer unwritten too) */
 void msh_out_drain(msh_out *o) {

@@ -818,10 +818,11 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 	for (;;) {
 		size_t want = P->batch_bytes;
 		double tq = now_s(), tq2;
-		/* a batch behind the first (which holds the preflight's window, as the reference's look-ahead does) also ends where the
-		 * producer goes quiet: the reference writes pool by pool (msam_filter.c:120-125,186) */
+		/* a batch also ends where the producer goes quiet: the reference writes pool by pool (msam_filter.c:120-125,186).  (The
+		 * first batch still holds the preflight's window -- 100 000 records, as the reference's own look-ahead does,
+		 * msam_helper.c:295-484: what is here when the producer pauses is looked at, and if it is less, waited for) */
 		while (!P->in_eof && s->ulen < want) {
-			if (!must_read && P->have_first && s->ulen > 0 && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;
+			if (!must_read && s->ulen > 0 && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;
 			must_read = 0;
 			if (!pipe_append(P->in, &s->ubuf, &s->ulen, &s->ucap)) P->in_eof = 1;
 		}
@@ -831,7 +832,7 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 		tq2 = now_s(); P->t_chase += tq2 - tq; tq = tq2;
 		if (P->in_eof && n < P->cap_rec && tail != s->ulen) mDie("Truncated BAM record");
 		if (!P->have_first && n < COORD_ORDER_CHECK_RECORDS && !P->in_eof) {   /* the preflight window (msam_helper.c:4-6) */
-			P->batch_bytes += P->batch_bytes;
+			if (s->ulen >= want) P->batch_bytes += P->batch_bytes;
 			must_read = 1;
 			continue;
 		}

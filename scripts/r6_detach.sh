@@ -9,8 +9,7 @@ T=/tmp/msx_detach; mkdir -p $T
 $DEV synth --groups $G --refs 1000000 -b > $T/in.bam
 ls -l $T/in.bam | tee $OUT/log.txt
 F="filter -l 80 -p 95 -z 80 --besthit"
-now() { date +%s.%N; }
-t() { local a=$(now); "$@"; local b=$(now); echo "$b - $a" | bc -l; }
+t() { local a=$EPOCHREALTIME; "$@"; local b=$EPOCHREALTIME; python3 -c "print($b - $a)"; }
 one_bu()  { $EXE $F -bu --profile-out $T/p.gz --label S $T/in.bam > $T/f.bam; }
 one_b()   { $EXE $F -b --profile-out $T/p.gz --label S $T/in.bam > $T/fb.bam; }
 prof()    { $EXE profile --label S -o $T/p1.gz $T/in.bam; }
