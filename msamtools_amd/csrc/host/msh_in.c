@@ -635,6 +635,9 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 		pthread_mutex_init(&in->tr_mu, NULL);
 		pthread_cond_init(&in->tr_cv_full, NULL);
 		pthread_cond_init(&in->tr_cv_free, NULL);
+#ifdef F_SETPIPE_SZ
+		(void)fcntl(fileno(in->fp), F_SETPIPE_SZ, 1 << 20);      /* a pipe from the aligner: fewer, larger transfers (the most an unprivileged process may ask for) */
+#endif
 		if (pthread_create(&in->tr_thr, NULL, text_reader_main, in) != 0) mDie("Cannot start the reader thread");
 		in->tr_started = 1;
 	}

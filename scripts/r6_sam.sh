@@ -16,6 +16,13 @@ for rep in 1 2 3; do
   python3 -c "print('one process: %.3f s' % ($b - $a))" | tee -a $OUT/log.txt
   grep "decode stage\|filter pipeline" $OUT/one_$rep.err | cut -c1-400 | tee -a $OUT/log.txt
 done
+for bb in 16777216 33554432; do
+  a=$EPOCHREALTIME
+  cat $T/in.sam | MSX_BATCH_BYTES=$bb MSX_TIMING=1 $EXE $F --profile-out $T/p.gz --label S - 2> $OUT/bb_$bb.err > $T/f.bam
+  b=$EPOCHREALTIME
+  python3 -c "print('MSX_BATCH_BYTES=$bb: %.3f s' % ($b - $a))" | tee -a $OUT/log.txt
+  grep "filter pipeline\|# process" $OUT/bb_$bb.err | cut -c1-300 | tee -a $OUT/log.txt
+done
 a=$EPOCHREALTIME; MSX_TIMING=1 $EXE $F --profile-out $T/p.gz --label S $T/in.sam 2> $OUT/file.err > $T/f.bam; b=$EPOCHREALTIME
 python3 -c "print('from the file, no pipe: %.3f s' % ($b - $a))" | tee -a $OUT/log.txt
 grep "decode stage\|filter pipeline" $OUT/file.err | cut -c1-400 | tee -a $OUT/log.txt
