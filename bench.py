@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE),
 # filled from profiles/ when measured for the default workload; None = not measured.
 TRAFFIC = {}
-_PMC = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_traffic_c3.json") for r in ("round5", "round4", "round3")) if os.path.exists(p)),
+_PMC = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_traffic_c3.json") for r in ("round6", "round5", "round4", "round3")) if os.path.exists(p)),
             os.path.join(ROOT, "profiles", "round5", "pmc_traffic_c3.json"))
 TRAFFIC_STALE = []          # kernel sources that have changed since the PMC passes were collected
 

@@ -62,10 +62,9 @@ for k, v in json.load(open(f"{out}/pmc_traffic_c3.json"))["kernels"].items():
     print(k, v["hbm_bytes_per_launch"])
 PY
 tail -2 $OUT/cov.log $OUT/deflate.log
-# the inflater both ways (MSX_INFLATE_VEC): SQ instruction counters per kernel launch
-msamtools_amd/bin/msamtools-dev synth --groups 4000000 --refs 1000 -b > /tmp/prof_a.bam
-for v in 0 1; do
-  MSX_INFLATE_VEC=$v python3 scripts/bench_inflate.py /tmp/prof_a.bam 8192 2>&1 | tail -1 > $OUT/inflate_vec$v.txt
-  MSX_INFLATE_VEC=$v pmc inflate_sq_vec$v "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python3 scripts/bench_inflate.py /tmp/prof_a.bam 8192
-done
-cat $OUT/inflate_vec0.txt $OUT/inflate_vec1.txt
+# the inflater: the serial kernel and the lane-parallel one (bench_inflate.py runs both on the same blocks): kernel statistics and
+# SQ instruction counters per launch
+msamtools_amd/bin/msamtools-dev synth --groups 1800000 --refs 1000 -b > /tmp/prof_a.bam
+stats inflate python3 scripts/bench_inflate.py /tmp/prof_a.bam 8192
+pmc inflate_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python3 scripts/bench_inflate.py /tmp/prof_a.bam 8192
+cat $OUT/inflate.log | tail -3
