@@ -699,9 +699,9 @@ __device__ __forceinline__ uint32_t ip_d_entry(uint32_t s) {
 // and consumes it with the same arithmetic either way (code length, extra bits, base + extra); a code longer than the
 // primary table's index finds its place in sorted[] from register-held limits (mode | 2) and reads its entry there in the
 // next iteration; both of those rare paths sit behind wave-uniform branches.
-template <bool EMIT>
-__device__ __forceinline__ IpLane ip_walk(IpShared &S, const IpLong &Q, uint32_t start, uint32_t limit, uint32_t win_dw0, uint32_t end_bit,
-                                          uint32_t base, uint32_t rshift, uint2 *__restrict__ ml, uint32_t &bad_dist) {
+template <bool EMIT, class SH, class LIT>
+__device__ __forceinline__ IpLane ip_walk(SH &S, const IpLong &Q, uint32_t start, uint32_t limit, uint32_t win_dw0, uint32_t end_bit,
+                                          uint32_t base, LIT lit, uint2 *__restrict__ ml, uint32_t &bad_dist) {
 	uint32_t ip = (start >> 5) - win_dw0;
 	uint64_t buf = (uint64_t)S.seg[IP_SKEW(ip)] | (uint64_t)S.seg[IP_SKEW(ip + 1u)] << 32;
 	ip += 2u;
@@ -763,7 +763,7 @@ __device__ __forceinline__ IpLane ip_walk(IpShared &S, const IpLong &Q, uint32_t
 		cnt -= (int32_t)((e & 15u) + x);
 		if (mode == 0u) {
 			if (kind == IF_LIT) {
-				if (EMIT) S.out[rshift + base + r.nb] = (uint8_t)val;
+				if (EMIT) lit[base + r.nb] = (uint8_t)val;
 				r.nb++;
 				if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
 			} else if (kind == IF_BASE) {
@@ -806,9 +806,10 @@ __device__ __forceinline__ IpLane ip_walk(IpShared &S, const IpLong &Q, uint32_t
 }
 
 // the next IP_SEG_DW + 8 words of the stream from word w0 into seg[] (what lies behind the readable bytes: zeros)
-__device__ __forceinline__ void ip_stage(IpShared &S, const IfIn &I, uint32_t w0, uint32_t tid) {
+template <class SH>
+__device__ __forceinline__ void ip_stage(SH &S, const IfIn &I, uint32_t w0, uint32_t tid, uint32_t seg_dw = IP_SEG_DW, uint32_t threads = IP_THREADS) {
 	const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
-	for (uint32_t k = tid; k < IP_SEG_DW + 8u; k += IP_THREADS) {
+	for (uint32_t k = tid; k < seg_dw + 8u; k += threads) {
 		const uint32_t d = w0 + k;
 		uint32_t v;
 		if (4u * (uint64_t)d + 4u <= I.n_bytes) v = I.g[d];
@@ -824,6 +825,128 @@ __device__ __forceinline__ uint32_t ip_wave_incl(uint32_t v, uint32_t lane) {
 		if (lane >= d) v += o;
 	}
 	return v;
+}
+
+// One deflate block's header, parsed by ONE wave on wave-uniform values off the staged stream (seg[0] = word win_dw0 of the
+// block's aligned base, `at` the header's first bit): stored / fixed / dynamic, the code lengths of a dynamic block into S.lens.
+// Returns 0 or the IF_* code that refuses the block.
+struct IpHeader { uint32_t type, last, hlit, hdist, stored_len, at; };
+template <class SH>
+__device__ __forceinline__ uint32_t ip_header(SH &S, uint32_t at, uint32_t win_dw0, uint32_t end_bit, uint32_t out_left, uint32_t lane, IpHeader &H) {
+	// the stream's words in a register, 64 at a time (lane i: word hbase + i), fetched by v_readlane: a dynamic
+	// header's ~150 code-length symbols were two LDS round trips each (stream word, table entry: 115 K clocks per
+	// block); its table is held the same way (pre0 / pre1 below)
+	uint32_t hip_ = 0u, hbase = 0u;
+	uint32_t hw = S.seg[IP_SKEW(lane)];
+	uint64_t hb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, 0) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, 1) << 32;
+	hip_ += 2u;
+	hb >>= (at & 31u);
+	int32_t hc = 64 - (int32_t)(at & 31u);
+#define IH_AT() ((win_dw0 + hip_) * 32u - (uint32_t)hc)
+#define IH_REFILL() do { if (hc <= 32) {                                                                     \
+		if (hip_ - hbase >= 64u) { hbase += 64u; hw = S.seg[IP_SKEW(hbase + lane)]; }                    \
+		hb |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, (int)(hip_ - hbase)) << hc; hc += 32; hip_++; } } while (0)
+#define IH_PEEK(n) ((uint32_t)(hb & ((1ull << (n)) - 1ull)))
+#define IH_DROP(n) do { hb >>= (n); hc -= (int32_t)(n); } while (0)
+	uint32_t herr = 0u, hlit = 288u, hdist = 32u, stored_len = 0u;
+	const uint32_t lastb = IH_PEEK(1);
+	const uint32_t type = (uint32_t)(hb >> 1) & 3u;
+	IH_DROP(3);
+	do {
+		if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
+		if (type == 3u) { herr = IF_BAD_TYPE; break; }
+		if (type == 0u) {
+			IH_DROP((uint32_t)hc & 7u);
+			IH_REFILL();
+			stored_len = IH_PEEK(16);
+			IH_DROP(16);
+			const uint32_t nlen = IH_PEEK(16);
+			IH_DROP(16);
+			if ((stored_len ^ 0xffffu) != nlen) { herr = IF_BAD_STORED; break; }
+			if ((uint64_t)IH_AT() + 8ull * stored_len > end_bit) { herr = IF_IN_OVER; break; }
+			if (stored_len > out_left) { herr = IF_OUT_OVER; break; }
+			break;
+		}
+		if (type == 1u) {
+			for (uint32_t s = lane; s < 320u; s += 64u)
+				S.lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 5u);
+			break;
+		}
+		IH_REFILL();
+		hlit = IH_PEEK(5) + 257u; IH_DROP(5);
+		hdist = IH_PEEK(5) + 1u; IH_DROP(5);
+		const uint32_t hclen = IH_PEEK(4) + 4u; IH_DROP(4);
+		if (hlit > 286u || hdist > 30u) { herr = IF_BAD_LENS; break; }
+		if (lane < 19u) S.pl[lane] = 0;
+		for (uint32_t i = 0; i < hclen; i++) {
+			IH_REFILL();
+			const uint32_t o = (uint32_t)((i < 12u ? IF_ORDER_LO >> (5u * i) : IF_ORDER_HI >> (5u * (i - 12u))) & 31ull);
+			if (lane == 0) S.pl[o] = (uint8_t)IH_PEEK(3);
+			IH_DROP(3);
+		}
+		if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
+		{
+			const uint32_t Lp = lane < 19u ? (uint32_t)S.pl[lane] : 0u;
+			uint32_t code = 0u, nxt = 0u;
+			int32_t left = 1;
+			const unsigned long long lt = (1ull << lane) - 1ull;
+			for (uint32_t len = 1; len <= 7u; len++) {
+				const unsigned long long b = __ballot(Lp == len);
+				const uint32_t cnt = (uint32_t)__popcll(b);
+				if (Lp == len) code = nxt + (uint32_t)__popcll(b & lt);
+				left = left * 2 - (int32_t)cnt;
+				nxt = (nxt + cnt) << 1;
+				if (left < 0) break;
+			}
+			if (left != 0) { herr = IF_BAD_LENS; break; }
+			S.pre[lane] = 0u; S.pre[lane + 64u] = 0u;
+			if (Lp) {
+				const uint32_t rev = __brev(code) >> (32u - Lp);
+				for (uint32_t k = rev; k < 128u; k += 1u << Lp) S.pre[k] = Lp | (lane << 8) | 0x10000u;
+			}
+		}
+		const uint32_t total = hlit + hdist;
+		const uint32_t pre0 = S.pre[lane], pre1 = S.pre[lane + 64u];
+		uint32_t n = 0u, prev = 0u;
+		while (n < total) {
+			IH_REFILL();
+			const uint32_t pk = IH_PEEK(7);
+			const uint32_t e = pk < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)pre0, (int)pk)
+			                            : (uint32_t)__builtin_amdgcn_readlane((int)pre1, (int)(pk - 64u));
+			if (!e) { herr = IF_BAD_CODE; break; }
+			IH_DROP(e & 0xffu);
+			const uint32_t sym = (e >> 8) & 0xffu;
+			if (sym < 16u) {
+				if (lane == 0) S.lens[n] = (uint8_t)sym;
+				prev = sym;
+				n++;
+			} else {
+				uint32_t rep, v = 0u;
+				if (sym == 16u) {
+					if (n == 0u) { herr = IF_BAD_LENS; break; }
+					v = prev;
+					rep = 3u + IH_PEEK(2); IH_DROP(2);
+				} else if (sym == 17u) {
+					rep = 3u + IH_PEEK(3); IH_DROP(3);
+					prev = 0u;
+				} else {
+					rep = 11u + IH_PEEK(7); IH_DROP(7);
+					prev = 0u;
+				}
+				if (n + rep > total) { herr = IF_BAD_LENS; break; }
+				for (uint32_t i = lane; i < rep; i += 64u) S.lens[n + i] = (uint8_t)v;
+				n += rep;
+			}
+			if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
+		}
+		if (!herr && S.lens[256] == 0) herr = IF_BAD_LENS;
+	} while (0);
+	H.type = type; H.last = lastb; H.hlit = hlit; H.hdist = hdist; H.stored_len = stored_len; H.at = IH_AT();
+#undef IH_AT
+#undef IH_REFILL
+#undef IH_PEEK
+#undef IH_DROP
+	return herr;
 }
 
 // (PH: MSX_INFLATE_STATS=3 -- thread 0's clock at the phase boundaries, summed over the blocks into stats[8..])
@@ -882,122 +1005,12 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 			__syncthreads();
 			IP_PH(1);
 			if (wave == 0u) {
-				// the stream's words in a register, 64 at a time (lane i: word hbase + i), fetched by v_readlane: a dynamic
-				// header's ~150 code-length symbols were two LDS round trips each (stream word, table entry: 115 K clocks per
-				// block); its table is held the same way (pre0 / pre1 below)
-				uint32_t hip_ = 0u, hbase = 0u;
-				uint32_t hw = S.seg[IP_SKEW(lane)];
-				uint64_t hb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, 0) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, 1) << 32;
-				hip_ += 2u;
-				hb >>= (at & 31u);
-				int32_t hc = 64 - (int32_t)(at & 31u);
-#define IH_AT() ((win_dw0 + hip_) * 32u - (uint32_t)hc)
-#define IH_REFILL() do { if (hc <= 32) {                                                                     \
-					if (hip_ - hbase >= 64u) { hbase += 64u; hw = S.seg[IP_SKEW(hbase + lane)]; }                    \
-					hb |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hw, (int)(hip_ - hbase)) << hc; hc += 32; hip_++; } } while (0)
-#define IH_PEEK(n) ((uint32_t)(hb & ((1ull << (n)) - 1ull)))
-#define IH_DROP(n) do { hb >>= (n); hc -= (int32_t)(n); } while (0)
-				uint32_t herr = 0u, hlit = 288u, hdist = 32u, stored_len = 0u;
-				const uint32_t lastb = IH_PEEK(1);
-				const uint32_t type = (uint32_t)(hb >> 1) & 3u;
-				IH_DROP(3);
-				do {
-					if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
-					if (type == 3u) { herr = IF_BAD_TYPE; break; }
-					if (type == 0u) {
-						IH_DROP((uint32_t)hc & 7u);
-						IH_REFILL();
-						stored_len = IH_PEEK(16);
-						IH_DROP(16);
-						const uint32_t nlen = IH_PEEK(16);
-						IH_DROP(16);
-						if ((stored_len ^ 0xffffu) != nlen) { herr = IF_BAD_STORED; break; }
-						if ((uint64_t)IH_AT() + 8ull * stored_len > end_bit) { herr = IF_IN_OVER; break; }
-						if (stored_len > out_len - pos) { herr = IF_OUT_OVER; break; }
-						break;
-					}
-					if (type == 1u) {
-						for (uint32_t s = lane; s < 320u; s += 64u)
-							S.lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 5u);
-						break;
-					}
-					IH_REFILL();
-					hlit = IH_PEEK(5) + 257u; IH_DROP(5);
-					hdist = IH_PEEK(5) + 1u; IH_DROP(5);
-					const uint32_t hclen = IH_PEEK(4) + 4u; IH_DROP(4);
-					if (hlit > 286u || hdist > 30u) { herr = IF_BAD_LENS; break; }
-					if (lane < 19u) S.pl[lane] = 0;
-					for (uint32_t i = 0; i < hclen; i++) {
-						IH_REFILL();
-						const uint32_t o = (uint32_t)((i < 12u ? IF_ORDER_LO >> (5u * i) : IF_ORDER_HI >> (5u * (i - 12u))) & 31ull);
-						if (lane == 0) S.pl[o] = (uint8_t)IH_PEEK(3);
-						IH_DROP(3);
-					}
-					if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
-					{
-						const uint32_t Lp = lane < 19u ? (uint32_t)S.pl[lane] : 0u;
-						uint32_t code = 0u, nxt = 0u;
-						int32_t left = 1;
-						const unsigned long long lt = (1ull << lane) - 1ull;
-						for (uint32_t len = 1; len <= 7u; len++) {
-							const unsigned long long b = __ballot(Lp == len);
-							const uint32_t cnt = (uint32_t)__popcll(b);
-							if (Lp == len) code = nxt + (uint32_t)__popcll(b & lt);
-							left = left * 2 - (int32_t)cnt;
-							nxt = (nxt + cnt) << 1;
-							if (left < 0) break;
-						}
-						if (left != 0) { herr = IF_BAD_LENS; break; }
-						S.pre[lane] = 0u; S.pre[lane + 64u] = 0u;
-						if (Lp) {
-							const uint32_t rev = __brev(code) >> (32u - Lp);
-							for (uint32_t k = rev; k < 128u; k += 1u << Lp) S.pre[k] = Lp | (lane << 8) | 0x10000u;
-						}
-					}
-					const uint32_t total = hlit + hdist;
-					const uint32_t pre0 = S.pre[lane], pre1 = S.pre[lane + 64u];
-					uint32_t n = 0u, prev = 0u;
-					while (n < total) {
-						IH_REFILL();
-						const uint32_t pk = IH_PEEK(7);
-						const uint32_t e = pk < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)pre0, (int)pk)
-						                            : (uint32_t)__builtin_amdgcn_readlane((int)pre1, (int)(pk - 64u));
-						if (!e) { herr = IF_BAD_CODE; break; }
-						IH_DROP(e & 0xffu);
-						const uint32_t sym = (e >> 8) & 0xffu;
-						if (sym < 16u) {
-							if (lane == 0) S.lens[n] = (uint8_t)sym;
-							prev = sym;
-							n++;
-						} else {
-							uint32_t rep, v = 0u;
-							if (sym == 16u) {
-								if (n == 0u) { herr = IF_BAD_LENS; break; }
-								v = prev;
-								rep = 3u + IH_PEEK(2); IH_DROP(2);
-							} else if (sym == 17u) {
-								rep = 3u + IH_PEEK(3); IH_DROP(3);
-								prev = 0u;
-							} else {
-								rep = 11u + IH_PEEK(7); IH_DROP(7);
-								prev = 0u;
-							}
-							if (n + rep > total) { herr = IF_BAD_LENS; break; }
-							for (uint32_t i = lane; i < rep; i += 64u) S.lens[n + i] = (uint8_t)v;
-							n += rep;
-						}
-						if (IH_AT() > end_bit) { herr = IF_IN_OVER; break; }
-					}
-					if (!herr && S.lens[256] == 0) herr = IF_BAD_LENS;
-				} while (0);
+				IpHeader H;
+				const uint32_t herr = ip_header(S, at, win_dw0, end_bit, out_len - pos, lane, H);
 				if (lane == 0) {
-					S.xw[8] = herr; S.xw[9] = type; S.xw[10] = lastb; S.xw[11] = hlit; S.xw[12] = hdist;
-					S.xw[13] = IH_AT(); S.xw[14] = stored_len;
+					S.xw[8] = herr; S.xw[9] = H.type; S.xw[10] = H.last; S.xw[11] = H.hlit; S.xw[12] = H.hdist;
+					S.xw[13] = H.at; S.xw[14] = H.stored_len;
 				}
-#undef IH_AT
-#undef IH_REFILL
-#undef IH_PEEK
-#undef IH_DROP
 			}
 			__syncthreads();
 			IP_PH(2);
@@ -1049,7 +1062,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 					used = seg0 + tid * sub;
 					limit = used + sub < win_end ? used + sub : win_end;
 					r.st = IP_DEAD; r.end = 0u; r.nb = 0u; r.nm = 0u; r.trips = 0u;
-					if (tid < nl && (tid == 0u || used < end_bit)) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+					if (tid < nl && (tid == 0u || used < end_bit)) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, (uint8_t *)nullptr, nullptr, dummy);
 					if (PH) {
 						uint32_t tmax = r.trips, tsum = r.trips;
 						for (uint32_t d = 32u; d >= 1u; d >>= 1) { tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, d)); tsum += (uint32_t)__shfl_xor((int)tsum, d); }
@@ -1071,7 +1084,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 							if (ns != used) { used = ns; ch = true; }
 						}
 						if (!__syncthreads_or(ch)) { converged = true; break; }
-						if (ch) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, 0u, nullptr, dummy);
+						if (ch) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, (uint8_t *)nullptr, nullptr, dummy);
 						if (PH && tid == 0) ph[10]++;
 					}
 					IP_PH(5);
@@ -1100,7 +1113,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 				IP_PH(6);
 				// pass C
 				uint32_t bad_dist = 0u;
-				if (tid <= lastl && r.st != IP_DEAD) (void)ip_walk<true>(S, Q, used, limit, win_dw0, end_bit, base, rshift, ml + mbase, bad_dist);
+				if (tid <= lastl && r.st != IP_DEAD) (void)ip_walk<true>(S, Q, used, limit, win_dw0, end_bit, base, S.out + rshift, ml + mbase, bad_dist);
 				if (__syncthreads_or(bad_dist != 0u)) { fail = IF_BAD_DIST; break; }
 				IP_PH(7);
 				// resolve: a window of 256 pieces at a time, one per thread.  No workgroup barrier inside a window: every wave
@@ -1214,6 +1227,269 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 	}
 }
 
+
+// ---------------------------------------------------------------------------
+// The same lanes, one WAVE per block (round 6, second form)
+// ---------------------------------------------------------------------------
+// The four-wave form above keeps a block's whole output in LDS: 80 KB per block, two blocks per compute unit, two waves per
+// SIMD -- and the counters say what that costs: per 8192 lean blocks it issues 2.14 G vector, 1.72 G scalar and 0.20 G LDS
+// wave-instructions (profiles/round6/inflate_sq_counters.json), 4.1 + 3.3 + ~2 ms of its units' time if nothing overlapped --
+// and with two waves per SIMD hardly anything does: 11.0 ms.  This form gives a block ONE wave and 8.6 KB of LDS (the two
+// tables, the staged stream), so a compute unit holds a dozen blocks and one block's table reads wait beside another's
+// arithmetic; nothing inside a block is ordered by a barrier (the lanes exchange their ends by shuffles, their votes by
+// ballots).  The price: the output has no LDS to live in.  Literals go straight to the block's place in global memory, the
+// matches' 16-byte pieces are resolved THERE, a window of 64 pieces at a time, level by level of their dependencies (done bits
+// in a register pair; a level's stores are waited for before the next level's loads: the wave reads its own stores through
+// its compute unit's L1, as the serial kernel's far matches do).  Same walk (ip_walk), same segments of 256 bits per lane --
+// 64 lanes, so 16 384 bits per segment --, same restarts and hand-backs.
+#define IW_SEG_DW 512u
+#define IW_SEG_BITS (IW_SEG_DW * 32u)
+struct IwShared {
+	uint32_t ll[1 << IF_LL_ROOT];
+	uint32_t dt[1 << IF_D_ROOT];
+	uint32_t seg[IP_SKEW(IW_SEG_DW + 8u) + 1u];
+	uint32_t lim[2][16], first[2][16];
+	uint16_t off[2][16];
+	union {
+		uint16_t sorted[320];
+		uint32_t pre[128];
+	};
+	uint8_t lens[352];
+	uint8_t pl[32];
+};
+
+struct __attribute__((packed, aligned(1))) iw_u16 { unsigned long long lo, hi; };
+
+template <bool PH>
+__global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restrict__ comp, size_t comp_len,
+                                                          const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
+                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                          uint32_t *__restrict__ ticket, uint2 *__restrict__ match_scratch,
+                                                          uint32_t *__restrict__ retry_list, uint32_t *__restrict__ retry_n,
+                                                          unsigned long long *__restrict__ stats) {
+	__shared__ IwShared S;
+	const uint32_t lane = threadIdx.x, tid = lane;
+	uint2 *const ml = match_scratch + (size_t)blockIdx.x * IP_MATCH_CAP;
+	unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	long long t_ph = PH ? clock64() : 0;
+	for (;;) {
+		uint32_t bi = 0u;
+		if (lane == 0) bi = atomicAdd(ticket, 1u);
+		bi = IFU(bi);
+		if (bi >= n_blocks) {
+			if (PH && tid == 0) for (int k = 0; k < 16; k++) atomicAdd(&stats[k], ph[k]);
+			return;
+		}
+		const msx_bgzf_block B = blk[bi];
+		uint8_t *og = out + B.out_off;
+		const uint32_t out_len = B.out_len;
+		if (out_len == 0u) {
+			if (lane == 0) status[bi] = IF_OK;
+			continue;
+		}
+		IfIn I;
+		{
+			const uintptr_t p = (uintptr_t)(comp + B.in_off);
+			I.g = reinterpret_cast<const uint32_t *>(p & ~(uintptr_t)3);
+			const size_t from = (size_t)((const uint8_t *)I.g - comp);
+			const size_t avail = comp_len > from ? comp_len - from : 0u;
+			I.n_bytes = avail > 0xfffffff0u ? 0xfffffff0u : (uint32_t)avail;
+		}
+		const uint32_t skew = (uint32_t)((uintptr_t)(comp + B.in_off) & 3u);
+		const uint32_t end_bit = (skew + B.in_len) * 8u;
+		uint32_t at = skew * 8u, pos = 0u, fail = 0u;
+		bool last_block = false;
+		if (out_len > 65536u || B.in_len > 0x100000u) fail = IF_OUT_OVER;
+		IP_PH(0);
+		while (!fail && !last_block) {
+			uint32_t win_dw0 = at >> 5;
+			ip_stage(S, I, win_dw0, lane, IW_SEG_DW, 64u);
+			IP_PH(1);
+			IpHeader H;
+			fail = ip_header(S, at, win_dw0, end_bit, out_len - pos, lane, H);
+			IP_PH(2);
+			if (fail) break;
+			last_block = H.last != 0u;
+			at = H.at;
+			if (H.type == 0u) {
+				const uint8_t *src = reinterpret_cast<const uint8_t *>(I.g) + (at >> 3);
+				for (uint32_t i = lane; i < H.stored_len; i += 64u) og[pos + i] = src[i];
+				pos += H.stored_len;
+				at += 8u * H.stored_len;
+				continue;
+			}
+			if (!if_build<true>(S, 0u, 0u, H.hlit, lane) || !if_build<true>(S, 1u, H.hlit, H.hdist, lane)) { fail = IF_BAD_LENS; break; }
+			IpLong Q;
+#pragma unroll
+			for (uint32_t k = 0; k < 5u; k++) {
+				const uint32_t len = IF_LL_ROOT + 1u + k;
+				Q.lim0[k] = IFU(S.lim[0][len]);
+				Q.k0[k] = (int32_t)IFU(S.off[0][len]) - (int32_t)(IFU(S.first[0][len]) >> (15u - len));
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 7u; k++) {
+				const uint32_t len = IF_D_ROOT + 1u + k;
+				Q.lim1[k] = IFU(S.lim[1][len]);
+				Q.k1[k] = (int32_t)IFU(S.off[1][len]) - (int32_t)(IFU(S.first[1][len]) >> (15u - len));
+			}
+			IP_PH(3);
+			uint32_t sub = IP_SUB0;
+			for (;;) {
+				const uint32_t seg0 = at;
+				uint32_t nl, used = 0u, limit = 0u;
+				IpLane r;
+				uint32_t dummy = 0u;
+				for (;;) {
+					const uint32_t win_end = win_dw0 * 32u + IW_SEG_BITS;
+					nl = (win_end - seg0 + sub - 1u) / sub;
+					if (nl > 64u) nl = 64u;
+					used = seg0 + lane * sub;
+					limit = used + sub < win_end ? used + sub : win_end;
+					r.st = IP_DEAD; r.end = 0u; r.nb = 0u; r.nm = 0u; r.trips = 0u;
+					if (lane < nl && (lane == 0u || used < end_bit)) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, (uint8_t *)nullptr, nullptr, dummy);
+					IP_PH(4);
+					bool converged = false;
+					for (uint32_t rounds = 0u; rounds < IP_MAX_ROUNDS || nl == 1u; rounds++) {
+						const uint32_t mine = r.end | (r.st << 24);
+						const unsigned long long bal = __ballot(lane < nl && r.st != IP_OK);
+						const uint32_t stop = bal ? (uint32_t)__ffsll((unsigned long long)bal) - 1u : 0xffffu;
+						const uint32_t left = (uint32_t)__shfl_up((int)mine, 1);
+						bool ch = false;
+						if (lane >= 1u && lane < nl && lane <= stop) {
+							const uint32_t ns = left & 0xffffffu;
+							if (ns != used) { used = ns; ch = true; }
+						}
+						if (!__ballot(ch)) { converged = true; break; }
+						if (ch) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, (uint8_t *)nullptr, nullptr, dummy);
+						if (PH && tid == 0) ph[10]++;
+					}
+					IP_PH(5);
+					if (converged) break;
+					sub *= 4u;
+					if (sub >= IP_HANDBACK_SUB) { fail = IF_RETRY; break; }
+				}
+				if (fail) break;
+				const unsigned long long bal = __ballot(lane < nl && r.st != IP_OK);
+				const uint32_t stop = bal ? (uint32_t)__ffsll((unsigned long long)bal) - 1u : 0xffffu;
+				const uint32_t lastl = stop < nl ? stop : nl - 1u;
+				const uint32_t le = (uint32_t)__shfl((int)(r.end | (r.st << 24)), (int)lastl);
+				const uint32_t st_last = le >> 24;
+				if (st_last != IP_OK && st_last != IP_EOB) { fail = st_last == IP_PAST ? IF_IN_OVER : IF_BAD_CODE; break; }
+				const uint32_t my_nb = lane <= lastl ? r.nb : 0u, my_nm = lane <= lastl ? r.nm : 0u;
+				const uint32_t inb = ip_wave_incl(my_nb, lane), inm = ip_wave_incl(my_nm, lane);
+				const uint32_t total = (uint32_t)__shfl((int)inb, 63), mtot = (uint32_t)__shfl((int)inm, 63);
+				if (total > out_len - pos) { fail = IF_OUT_OVER; break; }
+				IP_PH(6);
+				uint32_t bad_dist = 0u;
+				if (lane <= lastl && r.st != IP_DEAD)
+					(void)ip_walk<true>(S, Q, used, limit, win_dw0, end_bit, pos + inb - my_nb, og, ml + (inm - my_nm), bad_dist);
+				if (__ballot(bad_dist != 0u)) { fail = IF_BAD_DIST; break; }
+				// what pass C stored -- literals, the list -- is read below by other lanes of this wave
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				IP_PH(7);
+				for (uint32_t w0 = 0u; w0 < mtot; w0 += 64u) {
+					const bool have = w0 + lane < mtot;
+					uint2 m = make_uint2(0u, 0u);
+					if (have) m = ml[w0 + lane];
+					const uint32_t p = m.x & 0xffffu, l = ((m.x >> 16) & 15u) + 1u, ph0 = m.x >> 20, from = m.y & 0xffffu, per = m.y >> 16;
+					const uint32_t send = from + (per ? per : l);
+					const uint32_t wp = have ? p : 0x7fffffffu, we = p + l;
+					const uint32_t wp0 = (uint32_t)__shfl((int)wp, 0);
+					uint32_t a0 = 0u, b = 0u;
+					bool dep = false;
+					// the earlier pieces of the window this one reads from, [a0, b]: two searches over the lanes' positions
+					{
+						const bool look = have && lane > 0u && send > wp0;
+						uint32_t lo = 0u, hi = look ? lane : 0u, lo2 = 0u, hi2 = hi;
+#pragma unroll
+						for (int it = 0; it < 6; it++) {                 // (64 lanes: six halvings; every lane takes part in the shuffles)
+							const uint32_t mid = (lo + hi) >> 1, mid2 = (lo2 + hi2) >> 1;
+							const uint32_t v = (uint32_t)__shfl((int)wp, (int)(mid & 63u)), v2 = (uint32_t)__shfl((int)wp, (int)(mid2 & 63u));
+							if (lo < hi) { if (v < send) lo = mid + 1u; else hi = mid; }
+							if (lo2 < hi2) { if (v2 <= from) lo2 = mid2 + 1u; else hi2 = mid2; }
+						}
+						// (a seventh step for the range [0, 63]: lo < hi can still hold after six halvings of 63)
+						{
+							const uint32_t mid = (lo + hi) >> 1, mid2 = (lo2 + hi2) >> 1;
+							const uint32_t v = (uint32_t)__shfl((int)wp, (int)(mid & 63u)), v2 = (uint32_t)__shfl((int)wp, (int)(mid2 & 63u));
+							if (lo < hi) { if (v < send) lo = mid + 1u; else hi = mid; }
+							if (lo2 < hi2) { if (v2 <= from) lo2 = mid2 + 1u; else hi2 = mid2; }
+						}
+						const uint32_t a_ = lo2 ? lo2 - 1u : 0u;
+						const uint32_t ea = (uint32_t)__shfl((int)we, (int)(a_ & 63u));
+						if (look) {
+							b = lo - 1u;
+							a0 = a_ + (ea <= from ? 1u : 0u);
+							dep = a0 <= b;
+						}
+					}
+					const unsigned long long need = dep ? ((b == 63u ? ~0ull : ((1ull << (b + 1u)) - 1ull)) & ~((1ull << a0) - 1ull)) : 0ull;
+					bool done = !have;
+					for (uint32_t level = 0u;; level++) {
+						const unsigned long long dm = __ballot(done);
+						if (dm == ~0ull) break;
+						if (level > 64u) { fail = IF_RETRY; break; }              // (cannot happen: the lowest open piece is always ready)
+						const bool ready = !done && (dm & need) == need;
+						if (ready) {
+							const uint8_t *src = og + from;
+							uint8_t *dst = og + p;
+							if (per == 0u) {
+								// 16 bytes in one load wherever the piece ends (what lies behind it is not used; the output buffers
+								// carry 64 bytes of slack), stored as 16 / 8 / 4 / 2 / 1 bytes: one cache-line visit per lane and
+								// instruction instead of sixteen -- with a byte at a time a level cost 2 K cycles of the address path
+								iw_u16 q;
+								__builtin_memcpy(&q, src, 16);
+								if (l == 16u) {
+									__builtin_memcpy(dst, &q, 16);
+								} else {
+									unsigned long long lo = q.lo, hi = q.hi;
+									uint32_t o = 0u;
+									if (l & 8u) { __builtin_memcpy(dst, &lo, 8); lo = hi; o = 8u; }
+									if (l & 4u) { const uint32_t w = (uint32_t)lo; __builtin_memcpy(dst + o, &w, 4); lo >>= 32; o += 4u; }
+									if (l & 2u) { const uint16_t w = (uint16_t)lo; __builtin_memcpy(dst + o, &w, 2); lo >>= 16; o += 2u; }
+									if (l & 1u) dst[o] = (uint8_t)lo;
+								}
+							} else {
+								uint8_t v[IP_PIECE];
+								const float rf = 1.0f / (float)per;
+#pragma unroll
+								for (uint32_t j = 0; j < IP_PIECE; j++) {
+									const uint32_t x = ph0 + j;
+									const uint32_t q = (uint32_t)(((float)x + 0.5f) * rf);
+									v[j] = j < l ? src[x - q * per] : (uint8_t)0;
+								}
+#pragma unroll
+								for (uint32_t j = 0; j < IP_PIECE; j++) if (j < l) dst[j] = v[j];
+							}
+							done = true;
+						}
+						// this level's stores are in place before the next level's loads
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+						if (PH && tid == 0) ph[11]++;
+					}
+					if (fail) break;
+				}
+				IP_PH(8);
+				if (fail) break;
+				pos += total;
+				if ((le & 0xffffffu) <= at) { fail = IF_BAD_CODE; break; }
+				at = le & 0xffffffu;
+				if (st_last == IP_EOB) break;
+				win_dw0 = at >> 5;
+				ip_stage(S, I, win_dw0, lane, IW_SEG_DW, 64u);
+			}
+		}
+		if (!fail && pos != out_len) fail = IF_LEN_MISMATCH;
+		if (lane == 0) {
+			if (!fail) status[bi] = IF_OK;
+			else { status[bi] = IF_RETRY; retry_list[atomicAdd(retry_n, 1u)] = bi; }
+		}
+		IP_PH(9);
+	}
+}
+
 // ---------------------------------------------------------------------------
 // CRC-32 (the gzip polynomial, reflected) of every block's output
 // ---------------------------------------------------------------------------
@@ -1255,6 +1531,7 @@ __global__ void k_bgzf_refuse(uint32_t n_blocks, uint32_t every, uint32_t *__res
 // ---------------------------------------------------------------------------
 #define IF_PER_CU 14                      // serial kernel: waves per compute unit, what its LDS holds
 #define IP_PER_CU 2                       // lane-parallel kernel: workgroups per compute unit (80 KB of LDS each)
+#define IW_PER_CU 16                      // its one-wave form: waves per compute unit (8.6 KB of LDS and 116 VGPRs each: four per SIMD)
 static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate only): device counters
 static unsigned long long *ip_phase_stats = nullptr;      // MSX_INFLATE_STATS=3: the lane-parallel kernel's clocks per phase
 
@@ -1268,7 +1545,8 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 	// with SEQ/QUAL at 75 against 108 (profiles/round6/inflate_lanes.md has the clocks per phase and why) -- every block
 	// equal to zlib's either way.  Read per launch: the tests switch it.
 	const char *so_ = getenv("MSX_INFLATE_LANES");
-	const int serial_only = !(so_ && atoi(so_) != 0);
+	const int lanes_form = so_ ? atoi(so_) : 0;         // 1: four waves per block, output in LDS; 2: one wave per block, output resolved in global memory
+	const int serial_only = !(lanes_form == 1 || lanes_form == 2);
 	static const int per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
 	int per_cu = per_cu_env > 0 ? per_cu_env : waves_per_cu > 0 ? waves_per_cu : IF_PER_CU;
 	if (per_cu > IF_PER_CU) per_cu = IF_PER_CU;
@@ -1286,9 +1564,10 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 		for (auto &c : ctx->inf) if (c.used && c.stream == stream) is = &c;
 		if (!is) for (auto &c : ctx->inf) if (!c.used) { is = &c; c.used = true; c.stream = stream; break; }
 		if (!is) return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_inflate_launch: more than four streams inflate on one context");
-		int64_t pgrid = (int64_t)IP_PER_CU * ctx->num_cu;
+		const int per_cu_p = lanes_form == 2 ? ((per_cu_env > 0 && per_cu_env <= 18) ? per_cu_env : IW_PER_CU) : IP_PER_CU;
+		int64_t pgrid = (int64_t)per_cu_p * ctx->num_cu;
 		if (pgrid > n_blocks) pgrid = n_blocks;
-		const size_t want_m = (size_t)IP_PER_CU * ctx->num_cu * IP_MATCH_CAP * sizeof(uint2);
+		const size_t want_m = (size_t)per_cu_p * ctx->num_cu * IP_MATCH_CAP * sizeof(uint2);
 		const size_t want_r = ((size_t)n_blocks + 64) * 4;
 		if (is->matches.cap < want_m || is->retry.cap < want_r) {
 			MSX_HIP(ctx, hipStreamSynchronize(stream));             // (an earlier launch of this stream may still read them)
@@ -1296,7 +1575,14 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 			if ((rc = msx_reserve(ctx, &is->matches, want_m))) return rc;
 			if ((rc = msx_reserve(ctx, &is->retry, want_r < (1u << 18) ? (1u << 18) : want_r))) return rc;
 		}
-		if (ip_phase_stats)
+		if (lanes_form == 2) {
+			if (ip_phase_stats)
+				hipLaunchKernelGGL(k_bgzf_inflate_wave<true>, dim3((unsigned)pgrid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+				                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, ip_phase_stats);
+			else
+				hipLaunchKernelGGL(k_bgzf_inflate_wave<false>, dim3((unsigned)pgrid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+				                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, (unsigned long long *)nullptr);
+		} else if (ip_phase_stats)
 			hipLaunchKernelGGL(k_bgzf_inflate_par<true>, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
 			                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, ip_phase_stats);
 		else
@@ -1374,4 +1660,5 @@ void msx_touch_inflate(void) {
 	hipFuncAttributes attr;
 	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_crc));
 	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_par<false>));
+	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_wave<false>));
 }

@@ -50,7 +50,7 @@ want = b"".join(zlib.decompress(raw[io:io + il], -15) for io, il, ol, crc in blo
 zlib_s = time.perf_counter() - t0
 res = {"file": os.path.basename(path), "blocks": n, "compressed_MB": round(cin / 1e6, 1), "inflated_MB": round(uo / 1e6, 1),
        "zlib_one_core_GBps": round(uo / zlib_s / 1e9, 3)}
-for name, env in (("lanes", "1"), ("serial", None)):
+for name, env in (("wave", "2"), ("lanes", "1"), ("serial", None)):
     if env:
         os.environ["MSX_INFLATE_LANES"] = env
     else:

@@ -22,12 +22,12 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["lanes", "serial"])
+@pytest.fixture(autouse=True, params=["lanes", "wave", "serial"])
 def kernel(request, monkeypatch):
     """every test twice: the lane-parallel kernel (MSX_INFLATE_LANES=1, k_bgzf_inflate_par: 256 lanes per deflate block, what
     it hands back goes to the serial one) and the serial kernel alone (one wave per block: the default)"""
-    if request.param == "lanes":
-        monkeypatch.setenv("MSX_INFLATE_LANES", "1")
+    if request.param in ("lanes", "wave"):
+        monkeypatch.setenv("MSX_INFLATE_LANES", "1" if request.param == "lanes" else "2")       # (2: one wave per block, output resolved in global memory)
     else:
         monkeypatch.delenv("MSX_INFLATE_LANES", raising=False)
     return request.param
