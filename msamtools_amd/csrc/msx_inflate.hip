@@ -669,6 +669,7 @@ struct IpShared {
 	};
 	uint8_t lens[352];
 	uint8_t pl[32];
+	int32_t qk[2][8];                      // long codes: per length, off[len] - (first[len] >> (15 - len)) (IpLong)
 	uint32_t lend[IP_THREADS];             // a lane's end (24 bits) and state, for its right neighbour
 	uint32_t xw[16];                       // the waves' words: first stopped lane, sums, header fields
 	unsigned long long dmask[4];           // resolve: the waves' done bits
@@ -678,7 +679,7 @@ struct IpShared {
 // codes longer than the primary tables' index, without a loop: the per-length limits (left-aligned to 15 bits, ascending)
 // and K[len] = off[len] - (first[len] >> (15 - len)), wave-uniform, read once per deflate block.  A code c (15 bits,
 // left-aligned) has the first length whose limit exceeds it, and its symbol is sorted[K[len] + (c >> (15 - len))].
-struct IpLong { uint32_t lim0[5]; int32_t k0[5]; uint32_t lim1[7]; int32_t k1[7]; };
+struct IpLong { uint32_t lim0[5]; uint32_t lim1[7]; };
 
 struct IpLane { uint32_t end, nb, nm, st, trips; };
 
@@ -711,14 +712,18 @@ __device__ __forceinline__ IpLane ip_walk(SH &S, const IpLong &Q, uint32_t start
 	IpLane r;
 	r.st = IP_OK; r.nb = 0u; r.nm = 0u; r.trips = 0u;
 	uint32_t mode = 0u, mlen = 0u, sidx = 0u, slen = 0u;
-	const uint32_t *tab = S.ll;            // (dt follows ll in IpShared: one array of 1024 + 256 entries)
-#define IP_AT() ((win_dw0 + ip) * 32u - (uint32_t)cnt)
+	const uint32_t *tab = S.ll;            // (dt follows ll in the shared struct: one array of 1024 + 256 entries)
+	const uint32_t bit0 = win_dw0 * 32u;
+	// (written flat: every `if` around a few instructions costs a save / restore of the execution mask and a branch -- the
+	//  nested form of this loop compiled to 146 scalar instructions per trip beside 135 vector ones; the cases are selects,
+	//  the only branches are the two ways out, the two rare long-code paths and, in pass C, the stores)
 	for (;;) {
 		r.trips++;
-		if (mode == 0u) {
-			const uint32_t at = IP_AT();
-			if (at >= limit) break;
-			if (at >= end_bit) { r.st = IP_PAST; break; }
+		{
+			const uint32_t at = bit0 + ip * 32u - (uint32_t)cnt;
+			const bool tok = mode == 0u;
+			const bool s_lim = tok && at >= limit, s_end = tok && at >= end_bit;
+			if (s_lim || s_end) { if (!s_lim) r.st = IP_PAST; break; }
 		}
 		{
 			const bool take = cnt <= 32;
@@ -729,53 +734,45 @@ __device__ __forceinline__ IpLane ip_walk(SH &S, const IpLong &Q, uint32_t start
 			w = S.seg[IP_SKEW(ip)];
 		}
 		const uint32_t bits = (uint32_t)buf;
-		uint32_t e = tab[(mode & 1u) ? (1u << IF_LL_ROOT) + (bits & ((1u << IF_D_ROOT) - 1u)) : (bits & ((1u << IF_LL_ROOT) - 1u))];
-		if (__ballot(mode >= 2u)) {
-			// (a long code's entry: what sorted[] holds at the place computed an iteration ago)
-			const uint32_t sv = IF_SORTED(S, mode & 1u)[sidx];
-			const uint32_t el = (mode & 1u) ? ip_d_entry(sv) : if_unpack16(sv);
-			if (mode >= 2u) e = ((el >> 4) & 15u) ? (el | slen) : 0u;
+		const bool pend = mode >= 2u;
+		const uint32_t m = mode & 1u;
+		uint32_t e = tab[m ? (1u << IF_LL_ROOT) + (bits & ((1u << IF_D_ROOT) - 1u)) : (bits & ((1u << IF_LL_ROOT) - 1u))];
+		if (__ballot(pend)) {
+			// (a long code's entry: what sorted[] holds at the place computed a trip ago)
+			const uint32_t sv = IF_SORTED(S, m)[sidx];
+			const uint32_t el = m ? ip_d_entry(sv) : if_unpack16(sv);
+			const uint32_t eo = ((el >> 4) & 15u) ? (el | slen) : 0u;
+			e = pend ? eo : e;
 		}
-		bool skip = false;
-		if (__ballot(mode < 2u && ((e >> 4) & 15u) == IF_LONG)) {
+		const bool is_long = !pend && ((e >> 4) & 15u) == IF_LONG;
+		bool bad = false;
+		if (__ballot(is_long)) {
+			// the code's length from the register-held limits, its place in sorted[] from the per-length constants in LDS
 			const uint32_t c15 = __brev(bits & 0x7fffu) >> 17;
 			const uint32_t n0 = (uint32_t)(c15 >= Q.lim0[0]) + (uint32_t)(c15 >= Q.lim0[1]) + (uint32_t)(c15 >= Q.lim0[2]) + (uint32_t)(c15 >= Q.lim0[3]);
 			const uint32_t n1 = (uint32_t)(c15 >= Q.lim1[0]) + (uint32_t)(c15 >= Q.lim1[1]) + (uint32_t)(c15 >= Q.lim1[2]) + (uint32_t)(c15 >= Q.lim1[3]) +
 			                    (uint32_t)(c15 >= Q.lim1[4]) + (uint32_t)(c15 >= Q.lim1[5]);
-			const int32_t k0 = n0 == 0u ? Q.k0[0] : n0 == 1u ? Q.k0[1] : n0 == 2u ? Q.k0[2] : n0 == 3u ? Q.k0[3] : Q.k0[4];
-			const int32_t k1 = n1 == 0u ? Q.k1[0] : n1 == 1u ? Q.k1[1] : n1 == 2u ? Q.k1[2] : n1 == 3u ? Q.k1[3] : n1 == 4u ? Q.k1[4] : n1 == 5u ? Q.k1[5] : Q.k1[6];
-			if (mode < 2u && ((e >> 4) & 15u) == IF_LONG) {
-				const bool d = mode != 0u;
-				if (c15 >= (d ? Q.lim1[6] : Q.lim0[4])) { r.st = IP_BAD; break; }
-				slen = d ? IF_D_ROOT + 1u + n1 : IF_LL_ROOT + 1u + n0;
-				sidx = (uint32_t)((d ? k1 : k0) + (int32_t)(c15 >> (15u - slen)));
-				mode |= 2u;
-				skip = true;
-			}
+			const uint32_t n = m ? n1 : n0;
+			const int32_t k = S.qk[m][n];
+			const uint32_t sl = (m ? IF_D_ROOT + 1u : IF_LL_ROOT + 1u) + n;
+			bad = is_long && c15 >= (m ? Q.lim1[6] : Q.lim0[4]);
+			slen = is_long ? sl : slen;
+			sidx = is_long ? (uint32_t)(k + (int32_t)(c15 >> (15u - sl))) : sidx;
 		}
-		if (skip) continue;
-		mode &= 1u;
-		// the entry consumed: code, extra bits, value
-		const uint32_t kind = (e >> 4) & 15u, x = (e >> 8) & 15u;
-		buf >>= (e & 15u);
+		// the entry consumed (a long code consumes nothing yet): code, extra bits, value
+		const uint32_t kind = (e >> 4) & 15u;
+		const uint32_t n1_ = is_long ? 0u : (e & 15u), x = is_long ? 0u : ((e >> 8) & 15u);
+		buf >>= n1_;
 		const uint32_t val = (e >> 16) + ((uint32_t)buf & ((1u << x) - 1u));
 		buf >>= x;
-		cnt -= (int32_t)((e & 15u) + x);
-		if (mode == 0u) {
-			if (kind == IF_LIT) {
-				if (EMIT) lit[base + r.nb] = (uint8_t)val;
-				r.nb++;
-				if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
-			} else if (kind == IF_BASE) {
-				mlen = val;
-				mode = 1u;
-			} else {
-				r.st = kind == IF_EOB ? IP_EOB : IP_BAD;
-				break;
-			}
-		} else {
-			if (kind != IF_BASE) { r.st = IP_BAD; break; }
-			if (EMIT) {
+		cnt -= (int32_t)(n1_ + x);
+		const bool ll = !is_long && m == 0u, dd = !is_long && m == 1u;
+		const bool is_lit = ll && kind == IF_LIT, is_len = ll && kind == IF_BASE, is_eob = ll && kind == IF_EOB;
+		const bool is_dist = dd && kind == IF_BASE;
+		bad = bad || (ll && !(is_lit || is_len || is_eob)) || (dd && !is_dist);
+		if (EMIT) {
+			if (is_lit) lit[base + r.nb] = (uint8_t)val;
+			if (is_dist) {
 				// the match as pieces of at most 16 bytes: {position | length - 1 << 16 | phase << 20, source | period << 16}.  A piece
 				// of a match that does not overlap itself reads `length` bytes from `source`; one that does (distance < length) reads
 				// byte (phase + i) mod period from the period in front of the match -- never what the match itself writes.
@@ -794,14 +791,15 @@ __device__ __forceinline__ IpLane ip_walk(SH &S, const IpLong &Q, uint32_t start
 					}
 				}
 			}
-			r.nm += (mlen + IP_PIECE - 1u) / IP_PIECE;
-			r.nb += mlen;
-			mode = 0u;
-			if (IP_AT() > end_bit) { r.st = IP_PAST; break; }
 		}
+		r.nb += is_lit ? 1u : is_dist ? mlen : 0u;
+		r.nm += is_dist ? (mlen + IP_PIECE - 1u) / IP_PIECE : 0u;
+		mlen = is_len ? val : mlen;
+		mode = is_long ? (m | 2u) : is_len ? 1u : 0u;
+		const bool past = (is_lit || is_dist) && (bit0 + ip * 32u - (uint32_t)cnt) > end_bit;
+		if (is_eob || bad || past) { r.st = is_eob ? IP_EOB : bad ? IP_BAD : IP_PAST; break; }
 	}
-	r.end = IP_AT();
-#undef IP_AT
+	r.end = bit0 + ip * 32u - (uint32_t)cnt;
 	return r;
 }
 
@@ -1034,17 +1032,14 @@ __global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *
 			if (__syncthreads_or(!ok)) { fail = IF_BAD_LENS; break; }
 			IpLong Q;
 #pragma unroll
-			for (uint32_t k = 0; k < 5u; k++) {
-				const uint32_t len = IF_LL_ROOT + 1u + k;
-				Q.lim0[k] = IFU(S.lim[0][len]);
-				Q.k0[k] = (int32_t)IFU(S.off[0][len]) - (int32_t)(IFU(S.first[0][len]) >> (15u - len));
-			}
+			for (uint32_t k = 0; k < 5u; k++) Q.lim0[k] = IFU(S.lim[0][IF_LL_ROOT + 1u + k]);
 #pragma unroll
-			for (uint32_t k = 0; k < 7u; k++) {
-				const uint32_t len = IF_D_ROOT + 1u + k;
-				Q.lim1[k] = IFU(S.lim[1][len]);
-				Q.k1[k] = (int32_t)IFU(S.off[1][len]) - (int32_t)(IFU(S.first[1][len]) >> (15u - len));
+			for (uint32_t k = 0; k < 7u; k++) Q.lim1[k] = IFU(S.lim[1][IF_D_ROOT + 1u + k]);
+			if (tid < 16u) {
+				const uint32_t wq = tid >> 3, kq = tid & 7u, len = (wq ? IF_D_ROOT : IF_LL_ROOT) + 1u + kq;
+				S.qk[wq][kq] = len <= 15u ? (int32_t)S.off[wq][len] - (int32_t)(S.first[wq][len] >> (15u - len)) : 0;
 			}
+			__syncthreads();
 			IP_PH(3);
 			// ---- the block's symbols, segment by segment ----
 			uint32_t sub = IP_SUB0;
@@ -1256,6 +1251,7 @@ struct IwShared {
 	};
 	uint8_t lens[352];
 	uint8_t pl[32];
+	int32_t qk[2][8];                      // long codes: per length, off[len] - (first[len] >> (15 - len))
 };
 
 struct __attribute__((packed, aligned(1))) iw_u16 { unsigned long long lo, hi; };
@@ -1321,16 +1317,12 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restr
 			if (!if_build<true>(S, 0u, 0u, H.hlit, lane) || !if_build<true>(S, 1u, H.hlit, H.hdist, lane)) { fail = IF_BAD_LENS; break; }
 			IpLong Q;
 #pragma unroll
-			for (uint32_t k = 0; k < 5u; k++) {
-				const uint32_t len = IF_LL_ROOT + 1u + k;
-				Q.lim0[k] = IFU(S.lim[0][len]);
-				Q.k0[k] = (int32_t)IFU(S.off[0][len]) - (int32_t)(IFU(S.first[0][len]) >> (15u - len));
-			}
+			for (uint32_t k = 0; k < 5u; k++) Q.lim0[k] = IFU(S.lim[0][IF_LL_ROOT + 1u + k]);
 #pragma unroll
-			for (uint32_t k = 0; k < 7u; k++) {
-				const uint32_t len = IF_D_ROOT + 1u + k;
-				Q.lim1[k] = IFU(S.lim[1][len]);
-				Q.k1[k] = (int32_t)IFU(S.off[1][len]) - (int32_t)(IFU(S.first[1][len]) >> (15u - len));
+			for (uint32_t k = 0; k < 7u; k++) Q.lim1[k] = IFU(S.lim[1][IF_D_ROOT + 1u + k]);
+			if (tid < 16u) {
+				const uint32_t wq = tid >> 3, kq = tid & 7u, len = (wq ? IF_D_ROOT : IF_LL_ROOT) + 1u + kq;
+				S.qk[wq][kq] = len <= 15u ? (int32_t)S.off[wq][len] - (int32_t)(S.first[wq][len] >> (15u - len)) : 0;
 			}
 			IP_PH(3);
 			uint32_t sub = IP_SUB0;
