@@ -253,22 +253,23 @@ def inflate_probe(m, ctx, path, n_blocks=8192):
         want = b"".join(zlib.decompress(raw[io:io + il], -15) for io, il, ol, crc in blocks)
         zs = time.perf_counter() - t0
         ok = out == want
-        # the lane-parallel kernel (round 6, MSX_INFLATE_LANES=1: 256 self-synchronising lanes per deflate block) on the same blocks
+        # the serial kernel of rounds 3-5 (MSX_INFLATE_SERIAL=1: one wave per block, one symbol after the other) on the same blocks
         ctx.to_dev(d_out, np.zeros(uo, np.uint8))
-        os.environ["MSX_INFLATE_LANES"] = "1"
+        os.environ["MSX_INFLATE_SERIAL"] = "1"
         try:
             best_l, refused_l, out_l = timed()
         finally:
-            del os.environ["MSX_INFLATE_LANES"]
+            del os.environ["MSX_INFLATE_SERIAL"]
         return {"blocks": n, "compressed_MB": round(pos / 1e6, 1), "inflated_MB": round(uo / 1e6, 1), "ms": round(best * 1e3, 3),
                 "GBps_inflated": round(uo / best / 1e9, 1), "blocks_refused": refused,
                 "every_block_equals_zlib": bool(ok), "blocks_compared": n,
                 "zlib_one_core_GBps": round(uo / zs / 1e9, 2),
                 "frac_of_hbm_peak": round((pos + uo) / best / 8e12, 4),
-                "bound": "not memory: one wave per block decodes serially -- scalar issue and LDS latency (DESIGN.md section 3)",
-                "lane_parallel_kernel": {"ms": round(best_l * 1e3, 3), "GBps_inflated": round(uo / best_l / 1e9, 1), "blocks_refused": refused_l,
-                                         "every_block_equals_zlib": bool(out_l == want),
-                                         "note": "MSX_INFLATE_LANES=1; not the default: profiles/round6/inflate_lanes.md"}}
+                "bound": "not memory: the 64 lanes of a wave decode one deflate block's symbols at once (self-synchronising Huffman "
+                         "decoding, 5-6 walks per segment), vector-instruction issue; DESIGN.md section 3, profiles/round6/inflate_lanes.md",
+                "serial_kernel": {"ms": round(best_l * 1e3, 3), "GBps_inflated": round(uo / best_l / 1e9, 1), "blocks_refused": refused_l,
+                                  "every_block_equals_zlib": bool(out_l == want),
+                                  "note": "MSX_INFLATE_SERIAL=1: rounds 3-5's kernel, now the fallback for blocks the lanes hand back"}}
     finally:
         for q in (d_comp, d_blk, d_out, d_st):
             ctx.free(q)

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n) {
 	__shared__ IfShared S;
 	const uint32_t lane = threadIdx.x;
-	// list: only the blocks k_bgzf_inflate_par handed back (list_n of them, written by that kernel)
+	// list: only the blocks k_bgzf_inflate_wave handed back (list_n of them, written by that kernel)
 	if (list) n_blocks = IFU(*list_n);
 	// the launch holds as many waves as are to run at a time; each takes block after block
 	for (;;) {
@@ -619,62 +619,45 @@ done:
 // ---------------------------------------------------------------------------
 // The lane-parallel inflater (round 6)
 // ---------------------------------------------------------------------------
-// One wave per block, one symbol after the other, is a latency chain: a batch of the command line takes what ONE block
-// takes (3.5 ms per 64 KB), and the compute unit's scalar unit is busy with 55 instructions per symbol.  But Huffman decoding
-// self-synchronises: a decoder started at a wrong bit decodes garbage for a few symbols and then falls onto a true code
-// boundary, from where it IS the true chain.  So a deflate block's symbols are decoded by 256 lanes at once (the algorithm,
-// its passes and what it refuses are restated one lane after the other in msx_inflate_par_model.h, which the CPU tests run
-// against zlib):
-//   a workgroup of four waves per BGZF block; the block's WHOLE output lives in LDS (64 KB: every distance a match can have
-//   is an LDS address -- no ring, no far matches, no fences), two blocks per compute unit;
-//   segment   8 KB of the stream staged in LDS (skewed by one word per 32 so that lanes a whole number of words apart do not
+// One wave per block, one symbol after the other, is a latency chain on the compute unit's ONE scalar unit (55 scalar
+// instructions per symbol, 14 waves sharing the unit: 50 GB/s).  But Huffman decoding self-synchronises: a decoder started at a
+// wrong bit decodes garbage for a few symbols and then falls onto a true code boundary, from where it IS the true chain.  So a
+// deflate block's symbols are decoded by the 64 lanes of its wave at once (the algorithm, its passes and what it refuses are
+// restated one lane after the other in msx_inflate_par_model.h, which the CPU tests run against zlib):
+//   segment   2 KB of the stream staged in LDS (skewed by one word per 32 so that lanes a whole number of words apart do not
 //             share a bank); lane L owns the tokens that begin in bits [seg + L * sub, seg + (L + 1) * sub), sub = 256;
-//   pass A    every lane walks its range from its first bit (lane 0: from the true position), counting bytes and matches;
-//   pass B    rounds: a lane whose left neighbour ended elsewhere than it started walks again from there; lanes behind the
-//             first one that stopped (end of block, no code, payload's end) sit out.  No change: converged.  Eight rounds
-//             without convergence (long tokens, few per lane: a BAM header's text): four times the bits per lane, again;
+//   pass A    every lane walks its range from its first bit (lane 0: from the true position), counting bytes and pieces;
+//   pass B    rounds: a lane whose left neighbour ended elsewhere than it started walks again from there (ends by shuffle,
+//             votes by ballot); lanes behind the first one that stopped (end of block, no code, payload's end) sit out.  No
+//             change: converged.  Eight rounds without convergence (long tokens, few per lane: a BAM header's text): four
+//             times the bits per lane, again; at 4096 bits per lane the block is handed back;
 //   pass C    exclusive sums of the counts place every lane in the output; the lanes walk a last time, literals go straight
-//             to their bytes in LDS, matches -- position, length, distance, 8 bytes -- to a list in global memory;
-//   resolve   256 matches at a time, one per thread: a match whose source reaches into the outputs of earlier matches of the
-//             window waits until exactly those are done (two binary searches over the window's positions, done bits by
-//             ballot), everything else copies at once, eight bytes in flight per thread (a self-overlapping match reads
-//             byte i mod distance: independent of its own stores);
-//   then the next segment, or the next deflate block's header (parsed by wave 0 on wave-uniform values, as the serial kernel
-//   does; the two tables built by waves 0 and 1 side by side), and at the end the block goes out as 16-byte vectors.
+//             to their bytes of the output IN GLOBAL MEMORY, matches -- in pieces of at most 16 bytes: position, length,
+//             source, 8 bytes -- to a list in global memory;
+//   resolve   64 pieces at a time, one per lane: a piece whose source reaches into the outputs of earlier pieces of the
+//             window waits until exactly those are done (two searches over the window's positions by shuffle, done bits in a
+//             register pair), everything else copies at once -- one 16-byte load, 16 / 8 / 4 / 2 / 1-byte stores; a
+//             self-overlapping match reads byte i mod distance: independent of its own stores -- and a level's stores are
+//             waited for before the next level's loads (the wave reads its own stores through its compute unit's L1, as the
+//             serial kernel's far matches do);
+//   then the next segment, or the next deflate block's header (wave-uniform values, as the serial kernel parses it).
+// A first form gave a block four waves and kept its WHOLE output in LDS (80 KB: two blocks per compute unit, two waves per
+// SIMD).  It was correct and no faster than the serial kernel (47.8 against 50.2 GB/s): per 8192 lean blocks it issued 2.14 G
+// vector, 1.72 G scalar and 0.20 G LDS wave-instructions -- 4.1 + 3.3 + ~2 ms of its units' time if nothing overlapped -- and
+// with two waves per SIMD hardly anything did (profiles/round6/inflate_lanes.md).  This form takes 8.7 KB of LDS and 127
+// registers per block: sixteen blocks per compute unit, one block's table reads beside another's arithmetic, no barrier
+// anywhere.  100 GB/s on lean records, 184 GB/s with SEQ/QUAL (the serial kernel: 50 / 108), every block equal to zlib's.
 // Whatever is wrong on the true chain hands the block to the serial kernel (IF_RETRY: a list of block numbers, a second
 // launch over it), whose verdict stands as before.
-#define IP_THREADS 256u
-#define IP_SEG_DW 2048u
-#define IP_SEG_BITS (IP_SEG_DW * 32u)
 #define IP_SUB0 256u
 #define IP_MAX_ROUNDS 8u
 #define IP_SKEW(d) ((d) + ((d) >> 5))
 #define IP_PIECE 16u                     // a match goes to the list in pieces of at most 16 bytes
-#define IP_MATCH_CAP 26000u              // pieces of one segment: a third of a block's bytes (matches) + a sixteenth (their further pieces)
+#define IP_MATCH_CAP 12800u              // pieces of one segment: 16 384 bits hold at most 8192 matches (two bits each), a block's 64 KB at most 4096 further pieces
 #define IP_HANDBACK_SUB 4096u            // a segment that needs this many bits per lane to converge goes to the serial kernel
 #define IF_RETRY 10u
 
 enum { IP_OK = 0u, IP_EOB = 1u, IP_BAD = 2u, IP_PAST = 3u, IP_DEAD = 4u };
-
-struct IpShared {
-	__attribute__((aligned(16))) uint8_t out[65536 + 16];
-	uint32_t ll[1 << IF_LL_ROOT];
-	uint32_t dt[1 << IF_D_ROOT];
-	uint32_t seg[IP_SKEW(IP_SEG_DW + 8u) + 1u];   // the staged stream; during resolve: the window's positions and ends
-	uint32_t lim[2][16], first[2][16];
-	uint16_t off[2][16];
-	union {
-		uint16_t sorted[320];
-		uint32_t pre[128];
-	};
-	uint8_t lens[352];
-	uint8_t pl[32];
-	int32_t qk[2][8];                      // long codes: per length, off[len] - (first[len] >> (15 - len)) (IpLong)
-	uint32_t lend[IP_THREADS];             // a lane's end (24 bits) and state, for its right neighbour
-	uint32_t xw[16];                       // the waves' words: first stopped lane, sums, header fields
-	unsigned long long dmask[4];           // resolve: the waves' done bits
-	uint32_t rfail;                        // resolve: a wave gave up waiting (cannot happen; the block is handed back)
-};
 
 // codes longer than the primary tables' index, without a loop: the per-length limits (left-aligned to 15 bits, ascending)
 // and K[len] = off[len] - (first[len] >> (15 - len)), wave-uniform, read once per deflate block.  A code c (15 bits,
@@ -803,9 +786,9 @@ __device__ __forceinline__ IpLane ip_walk(SH &S, const IpLong &Q, uint32_t start
 	return r;
 }
 
-// the next IP_SEG_DW + 8 words of the stream from word w0 into seg[] (what lies behind the readable bytes: zeros)
+// the next seg_dw + 8 words of the stream from word w0 into seg[] (what lies behind the readable bytes: zeros)
 template <class SH>
-__device__ __forceinline__ void ip_stage(SH &S, const IfIn &I, uint32_t w0, uint32_t tid, uint32_t seg_dw = IP_SEG_DW, uint32_t threads = IP_THREADS) {
+__device__ __forceinline__ void ip_stage(SH &S, const IfIn &I, uint32_t w0, uint32_t tid, uint32_t seg_dw, uint32_t threads) {
 	const uint8_t *p = reinterpret_cast<const uint8_t *>(I.g);
 	for (uint32_t k = tid; k < seg_dw + 8u; k += threads) {
 		const uint32_t d = w0 + k;
@@ -949,294 +932,7 @@ __device__ __forceinline__ uint32_t ip_header(SH &S, uint32_t at, uint32_t win_d
 
 // (PH: MSX_INFLATE_STATS=3 -- thread 0's clock at the phase boundaries, summed over the blocks into stats[8..])
 #define IP_PH(k) do { if (PH) { const long long now_ = clock64(); if (tid == 0) ph[k] += (unsigned long long)(now_ - t_ph); t_ph = now_; } } while (0)
-template <bool PH>
-__global__ __launch_bounds__(IP_THREADS) void k_bgzf_inflate_par(const uint8_t *__restrict__ comp, size_t comp_len,
-                                                                 const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
-                                                                 uint8_t *__restrict__ out, uint32_t *__restrict__ status,
-                                                                 uint32_t *__restrict__ ticket, uint2 *__restrict__ match_scratch,
-                                                                 uint32_t *__restrict__ retry_list, uint32_t *__restrict__ retry_n,
-                                                                 unsigned long long *__restrict__ stats) {
-	__shared__ IpShared S;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	long long t_ph = PH ? clock64() : 0;
-	uint2 *const ml = match_scratch + (size_t)blockIdx.x * IP_MATCH_CAP;
-	uint32_t *const wpos = S.seg;                      // resolve: the window's match positions ...
-	uint32_t *const wend = S.seg + IP_THREADS + 1u;    // ... and ends (the staged stream is done with by then)
-	for (;;) {
-		if (tid == 0) { S.xw[15] = atomicAdd(ticket, 1u); S.rfail = 0u; }
-		__syncthreads();
-		const uint32_t bi = S.xw[15];
-		__syncthreads();
-		if (bi >= n_blocks) {
-			if (PH && tid == 0) for (int k = 0; k < 16; k++) atomicAdd(&stats[k], ph[k]);
-			return;
-		}
-		const msx_bgzf_block B = blk[bi];
-		uint8_t *og = out + B.out_off;
-		const uint32_t out_len = B.out_len;
-		if (out_len == 0u) {
-			if (tid == 0) status[bi] = IF_OK;
-			continue;
-		}
-		IfIn I;
-		{
-			const uintptr_t p = (uintptr_t)(comp + B.in_off);
-			I.g = reinterpret_cast<const uint32_t *>(p & ~(uintptr_t)3);
-			const size_t from = (size_t)((const uint8_t *)I.g - comp);
-			const size_t avail = comp_len > from ? comp_len - from : 0u;
-			I.n_bytes = avail > 0xfffffff0u ? 0xfffffff0u : (uint32_t)avail;
-		}
-		const uint32_t skew = (uint32_t)((uintptr_t)(comp + B.in_off) & 3u);
-		const uint32_t end_bit = (skew + B.in_len) * 8u;
-		IP_PH(0);
-		const uint32_t rshift = (uint32_t)((uintptr_t)og & 15u);
-		uint32_t at = skew * 8u;            // the stream's read position (bits from the aligned base): workgroup-uniform
-		uint32_t pos = 0u;                  // bytes produced
-		uint32_t fail = 0u;
-		bool last_block = false;
-		if (out_len > 65536u || B.in_len > 0x100000u) fail = IF_OUT_OVER;      // (not a BGZF block: the serial kernel's)
-		while (!fail && !last_block) {
-			// ---- a deflate block's header: wave 0, wave-uniform, off the staged stream ----
-			uint32_t win_dw0 = at >> 5;
-			ip_stage(S, I, win_dw0, tid);
-			__syncthreads();
-			IP_PH(1);
-			if (wave == 0u) {
-				IpHeader H;
-				const uint32_t herr = ip_header(S, at, win_dw0, end_bit, out_len - pos, lane, H);
-				if (lane == 0) {
-					S.xw[8] = herr; S.xw[9] = H.type; S.xw[10] = H.last; S.xw[11] = H.hlit; S.xw[12] = H.hdist;
-					S.xw[13] = H.at; S.xw[14] = H.stored_len;
-				}
-			}
-			__syncthreads();
-			IP_PH(2);
-			if (S.xw[8]) { fail = S.xw[8]; break; }
-			const uint32_t type = S.xw[9], hlit = S.xw[11], hdist = S.xw[12];
-			last_block = S.xw[10] != 0u;
-			at = S.xw[13];
-			if (type == 0u) {
-				const uint32_t len = S.xw[14];
-				const uint8_t *src = reinterpret_cast<const uint8_t *>(I.g) + (at >> 3);
-				for (uint32_t i = tid; i < len; i += IP_THREADS) S.out[rshift + pos + i] = src[i];
-				pos += len;
-				at += 8u * len;
-				__syncthreads();
-				continue;
-			}
-			// the two tables side by side
-			uint32_t ok = 1u;
-			if (wave == 0u) ok = if_build<true>(S, 0u, 0u, hlit, lane);
-			else if (wave == 1u) ok = if_build<true>(S, 1u, hlit, hdist, lane);
-			if (__syncthreads_or(!ok)) { fail = IF_BAD_LENS; break; }
-			IpLong Q;
-#pragma unroll
-			for (uint32_t k = 0; k < 5u; k++) Q.lim0[k] = IFU(S.lim[0][IF_LL_ROOT + 1u + k]);
-#pragma unroll
-			for (uint32_t k = 0; k < 7u; k++) Q.lim1[k] = IFU(S.lim[1][IF_D_ROOT + 1u + k]);
-			if (tid < 16u) {
-				const uint32_t wq = tid >> 3, kq = tid & 7u, len = (wq ? IF_D_ROOT : IF_LL_ROOT) + 1u + kq;
-				S.qk[wq][kq] = len <= 15u ? (int32_t)S.off[wq][len] - (int32_t)(S.first[wq][len] >> (15u - len)) : 0;
-			}
-			__syncthreads();
-			IP_PH(3);
-			// ---- the block's symbols, segment by segment ----
-			uint32_t sub = IP_SUB0;
-			for (;;) {
-				const uint32_t seg0 = at;
-				uint32_t nl, used = 0u, limit = 0u;
-				IpLane r;
-				uint32_t dummy = 0u;
-				for (;;) {
-					// lanes of the segment: what the staged window holds behind seg0 (the last lane's range may be short)
-					const uint32_t win_end = win_dw0 * 32u + IP_SEG_BITS;
-					nl = (win_end - seg0 + sub - 1u) / sub;
-					if (nl > IP_THREADS) nl = IP_THREADS;
-					// pass A
-					used = seg0 + tid * sub;
-					limit = used + sub < win_end ? used + sub : win_end;
-					r.st = IP_DEAD; r.end = 0u; r.nb = 0u; r.nm = 0u; r.trips = 0u;
-					if (tid < nl && (tid == 0u || used < end_bit)) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, (uint8_t *)nullptr, nullptr, dummy);
-					if (PH) {
-						uint32_t tmax = r.trips, tsum = r.trips;
-						for (uint32_t d = 32u; d >= 1u; d >>= 1) { tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, d)); tsum += (uint32_t)__shfl_xor((int)tsum, d); }
-						if (tid == 0) { ph[12] += tmax; ph[13] += tsum; ph[14]++; }
-						__syncthreads();
-					}
-					IP_PH(4);
-					// pass B
-					bool converged = false;
-					for (uint32_t rounds = 0u; rounds < IP_MAX_ROUNDS || nl == 1u; rounds++) {
-						S.lend[tid] = r.end | (r.st << 24);
-						const unsigned long long bal = __ballot(tid < nl && r.st != IP_OK);
-						if (lane == 0u) S.xw[wave] = bal ? 64u * wave + (uint32_t)__ffsll((unsigned long long)bal) - 1u : 0xffffu;
-						__syncthreads();
-						const uint32_t stop = min(min(S.xw[0], S.xw[1]), min(S.xw[2], S.xw[3]));
-						bool ch = false;
-						if (tid >= 1u && tid < nl && tid <= stop) {
-							const uint32_t ns = S.lend[tid - 1u] & 0xffffffu;
-							if (ns != used) { used = ns; ch = true; }
-						}
-						if (!__syncthreads_or(ch)) { converged = true; break; }
-						if (ch) r = ip_walk<false>(S, Q, used, limit, win_dw0, end_bit, 0u, (uint8_t *)nullptr, nullptr, dummy);
-						if (PH && tid == 0) ph[10]++;
-					}
-					IP_PH(5);
-					if (converged) break;
-					sub *= 4u;
-					if (sub >= IP_HANDBACK_SUB) { fail = IF_RETRY; break; }      // lanes this long are no faster than the serial kernel's one
-				}
-				if (fail) break;
-				// the true chain's lanes: up to the first that stopped
-				const uint32_t stop = min(min(S.xw[0], S.xw[1]), min(S.xw[2], S.xw[3]));
-				const uint32_t lastl = stop < nl ? stop : nl - 1u;
-				const uint32_t le = S.lend[lastl];
-				const uint32_t st_last = le >> 24;
-				if (st_last != IP_OK && st_last != IP_EOB) { fail = st_last == IP_PAST ? IF_IN_OVER : IF_BAD_CODE; break; }
-				// exclusive sums of bytes and matches over the lanes of the chain
-				const uint32_t my_nb = tid <= lastl ? r.nb : 0u, my_nm = tid <= lastl ? r.nm : 0u;
-				const uint32_t inb = ip_wave_incl(my_nb, lane), inm = ip_wave_incl(my_nm, lane);
-				__syncthreads();                        // (lend / xw read above)
-				if (lane == 63u) { S.xw[wave] = inb; S.xw[4u + wave] = inm; }
-				__syncthreads();
-				uint32_t base = pos + inb - my_nb, mbase = inm - my_nm;
-				for (uint32_t w = 0; w < wave; w++) { base += S.xw[w]; mbase += S.xw[4u + w]; }
-				const uint32_t total = S.xw[0] + S.xw[1] + S.xw[2] + S.xw[3];
-				const uint32_t mtot = S.xw[4] + S.xw[5] + S.xw[6] + S.xw[7];
-				if (total > out_len - pos) { fail = IF_OUT_OVER; break; }
-				IP_PH(6);
-				// pass C
-				uint32_t bad_dist = 0u;
-				if (tid <= lastl && r.st != IP_DEAD) (void)ip_walk<true>(S, Q, used, limit, win_dw0, end_bit, base, S.out + rshift, ml + mbase, bad_dist);
-				if (__syncthreads_or(bad_dist != 0u)) { fail = IF_BAD_DIST; break; }
-				IP_PH(7);
-				// resolve: a window of 256 pieces at a time, one per thread.  No workgroup barrier inside a window: every wave
-				// keeps the done bits of its own pieces in a register pair, publishes them in LDS when they change and polls
-				// the words of the waves in front of it (a piece depends on earlier pieces only); a wave leaves the window when
-				// its own pieces are done.  LDS keeps a wave's operations in order, so whoever sees a done bit sees the bytes.
-				for (uint32_t w0 = 0u; w0 < mtot; w0 += IP_THREADS) {
-					const bool have = w0 + tid < mtot;
-					uint2 m = make_uint2(0u, 0u);
-					if (have) m = ml[w0 + tid];
-					const uint32_t p = m.x & 0xffffu, l = ((m.x >> 16) & 15u) + 1u, ph0 = m.x >> 20, from = m.y & 0xffffu, per = m.y >> 16;
-					const uint32_t send = from + (per ? per : l);                  // the source bytes end here (a period: at the match's start)
-					wpos[tid] = have ? p : 0x7fffffffu;
-					wend[tid] = p + l;
-					unsigned long long mine = __ballot(!have);
-					if (lane == 0u) __hip_atomic_store(&S.dmask[wave], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					__syncthreads();
-					// the earlier pieces of the window this one reads from: [a0, b]
-					uint32_t a0 = 0u, b = 0u;
-					bool dep = false;
-					if (have && tid > 0u && send > wpos[0]) {
-						uint32_t lo = 0u, hi = tid;                      // first j in [0, tid) with wpos[j] >= send
-						while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (wpos[mid] < send) lo = mid + 1u; else hi = mid; }
-						b = lo - 1u;                                      // (lo >= 1: wpos[0] < send)
-						lo = 0u; hi = tid;                               // first j with wpos[j] > from
-						while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (wpos[mid] <= from) lo = mid + 1u; else hi = mid; }
-						a0 = lo ? lo - 1u : 0u;
-						if (wend[a0] <= from) a0++;                      // that piece ends in front of the source: literals in between
-						dep = a0 <= b;
-					}
-					bool done = !have;
-					uint8_t *const o = S.out + rshift;
-					for (uint32_t spins = 0u; mine != ~0ull; spins++) {
-						if (spins > (1u << 20)) { if (lane == 0u) S.rfail = 1u; break; }      // (cannot happen: the lowest open piece is always ready)
-						bool ready = !done;
-						if (ready && dep) {
-							for (uint32_t w = a0 >> 6; w <= (b >> 6); w++) {
-								const unsigned long long dm = w == wave ? mine : __hip_atomic_load(&S.dmask[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-								const uint32_t f = w == (a0 >> 6) ? (a0 & 63u) : 0u, t = w == (b >> 6) ? (b & 63u) : 63u;
-								const unsigned long long need = (t == 63u ? ~0ull : ((1ull << (t + 1u)) - 1ull)) & ~((1ull << f) - 1ull);
-								if ((dm & need) != need) ready = false;
-							}
-						}
-						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-						if (ready) {
-							uint8_t v[IP_PIECE];
-							if (per == 0u) {
-#pragma unroll
-								for (uint32_t j = 0; j < IP_PIECE; j++) v[j] = j < l ? o[from + j] : (uint8_t)0;
-							} else {
-								const float rf = 1.0f / (float)per;
-#pragma unroll
-								for (uint32_t j = 0; j < IP_PIECE; j++) {
-									const uint32_t x = ph0 + j;
-									const uint32_t q = (uint32_t)(((float)x + 0.5f) * rf);
-									v[j] = j < l ? o[from + (x - q * per)] : (uint8_t)0;
-								}
-							}
-#pragma unroll
-							for (uint32_t j = 0; j < IP_PIECE; j++) if (j < l) o[p + j] = v[j];
-							done = true;
-						}
-						const unsigned long long now = __ballot(done);
-						if (now != mine) {
-							mine = now;
-							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-							if (lane == 0u) __hip_atomic_store(&S.dmask[wave], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						} else {
-							__builtin_amdgcn_s_sleep(1);
-						}
-					}
-					__syncthreads();
-					if (PH && tid == 0) ph[11]++;
-				}
-				if (S.rfail) fail = IF_RETRY;
-				IP_PH(8);
-				if (fail) break;
-				pos += total;
-				if ((le & 0xffffffu) <= at) { fail = IF_BAD_CODE; break; }              // (cannot happen: a segment consumes bits)
-				at = le & 0xffffffu;
-				if (st_last == IP_EOB) break;
-				// the next segment of the same deflate block
-				__syncthreads();
-				win_dw0 = at >> 5;
-				ip_stage(S, I, win_dw0, tid);
-				__syncthreads();
-			}
-			__syncthreads();
-		}
-		if (!fail && pos != out_len) fail = IF_LEN_MISMATCH;
-		__syncthreads();
-		if (!fail) {
-			// the block goes out: 16-byte vectors where the global address allows, bytes at the edges
-			const uintptr_t lo = (uintptr_t)og, hi = (uintptr_t)og + out_len;
-			const uintptr_t a = lo & ~(uintptr_t)15;
-			for (uintptr_t va = a + 16u * tid; va < hi; va += 16u * IP_THREADS) {
-				const uint32_t ri = (uint32_t)(va - a);
-				if (va >= lo && va + 16u <= hi) {
-					*reinterpret_cast<uint4 *>(va) = *reinterpret_cast<const uint4 *>(&S.out[ri]);
-				} else {
-					for (uint32_t k = 0; k < 16u; k++)
-						if (va + k >= lo && va + k < hi) *reinterpret_cast<uint8_t *>(va + k) = S.out[ri + k];
-				}
-			}
-			if (tid == 0) status[bi] = IF_OK;
-		} else if (tid == 0) {
-			status[bi] = IF_RETRY;
-			retry_list[atomicAdd(retry_n, 1u)] = bi;
-		}
-		IP_PH(9);
-	}
-}
-
-
-// ---------------------------------------------------------------------------
-// The same lanes, one WAVE per block (round 6, second form)
-// ---------------------------------------------------------------------------
-// The four-wave form above keeps a block's whole output in LDS: 80 KB per block, two blocks per compute unit, two waves per
-// SIMD -- and the counters say what that costs: per 8192 lean blocks it issues 2.14 G vector, 1.72 G scalar and 0.20 G LDS
-// wave-instructions (profiles/round6/inflate_sq_counters.json), 4.1 + 3.3 + ~2 ms of its units' time if nothing overlapped --
-// and with two waves per SIMD hardly anything does: 11.0 ms.  This form gives a block ONE wave and 8.6 KB of LDS (the two
-// tables, the staged stream), so a compute unit holds a dozen blocks and one block's table reads wait beside another's
-// arithmetic; nothing inside a block is ordered by a barrier (the lanes exchange their ends by shuffles, their votes by
-// ballots).  The price: the output has no LDS to live in.  Literals go straight to the block's place in global memory, the
-// matches' 16-byte pieces are resolved THERE, a window of 64 pieces at a time, level by level of their dependencies (done bits
-// in a register pair; a level's stores are waited for before the next level's loads: the wave reads its own stores through
-// its compute unit's L1, as the serial kernel's far matches do).  Same walk (ip_walk), same segments of 256 bits per lane --
-// 64 lanes, so 16 384 bits per segment --, same restarts and hand-backs.
+// the kernel: one wave per block (16 per compute unit: IW_PER_CU)
 #define IW_SEG_DW 512u
 #define IW_SEG_BITS (IW_SEG_DW * 32u)
 struct IwShared {
@@ -1522,8 +1218,7 @@ __global__ void k_bgzf_refuse(uint32_t n_blocks, uint32_t every, uint32_t *__res
 // ABI
 // ---------------------------------------------------------------------------
 #define IF_PER_CU 14                      // serial kernel: waves per compute unit, what its LDS holds
-#define IP_PER_CU 2                       // lane-parallel kernel: workgroups per compute unit (80 KB of LDS each)
-#define IW_PER_CU 16                      // its one-wave form: waves per compute unit (8.6 KB of LDS and 116 VGPRs each: four per SIMD)
+#define IW_PER_CU 16                      // lane-parallel kernel: waves per compute unit (8.7 KB of LDS and 127 VGPRs each: four per SIMD)
 static uint32_t *if_stats = nullptr;      // MSX_INFLATE_STATS (msx_bgzf_inflate only): device counters
 static unsigned long long *ip_phase_stats = nullptr;      // MSX_INFLATE_STATS=3: the lane-parallel kernel's clocks per phase
 
@@ -1532,34 +1227,33 @@ static unsigned long long *ip_phase_stats = nullptr;      // MSX_INFLATE_STATS=3
 int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, const uint8_t *d_comp, size_t comp_len,
                             const msx_bgzf_block *d_blocks, int64_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_n_bad) {
 	if (n_blocks <= 0) return MSX_OK;
-	// MSX_INFLATE_LANES=1: the lane-parallel kernel (round 6) for every block, what it hands back to the serial one.  Off by
-	// default: measured on 8192 blocks it inflates lean records at 47.8 GB/s against the serial kernel's 50.2 and records
-	// with SEQ/QUAL at 75 against 108 (profiles/round6/inflate_lanes.md has the clocks per phase and why) -- every block
-	// equal to zlib's either way.  Read per launch: the tests switch it.
-	const char *so_ = getenv("MSX_INFLATE_LANES");
-	const int lanes_form = so_ ? atoi(so_) : 0;         // 1: four waves per block, output in LDS; 2: one wave per block, output resolved in global memory
-	const int serial_only = !(lanes_form == 1 || lanes_form == 2);
-	static const int per_cu_env = getenv("MSX_INFLATE_WAVES") ? atoi(getenv("MSX_INFLATE_WAVES")) : 0;
+	// The lane-parallel kernel for every block, the serial kernel for what it hands back.  MSX_INFLATE_SERIAL=1: the serial
+	// kernel alone (rounds 3-5: one wave per block, one symbol after the other) -- the A/B of scripts/bench_inflate.py, and
+	// what the hand-backs' path is tested with.  Read per launch: the tests switch it.
+	const char *so_ = getenv("MSX_INFLATE_SERIAL");
+	const int serial_only = so_ && atoi(so_) != 0;
+	const char *we_ = getenv("MSX_INFLATE_WAVES");
+	const int per_cu_env = we_ ? atoi(we_) : 0;
 	int per_cu = per_cu_env > 0 ? per_cu_env : waves_per_cu > 0 ? waves_per_cu : IF_PER_CU;
 	if (per_cu > IF_PER_CU) per_cu = IF_PER_CU;
 	int64_t grid = (int64_t)per_cu * ctx->num_cu;
 	if (grid > n_blocks) grid = n_blocks;
 	MSX_HIP(ctx, hipMemsetAsync(d_n_bad + 1, 0, 12, stream));      // tickets and the hand-back count
-	if (serial_only || if_stats) {
 #define IF_LAUNCH(D, L, LN) hipLaunchKernelGGL((k_bgzf_inflate<D>), dim3((unsigned)grid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, \
 	                   (uint32_t)n_blocks, d_out, d_status, d_n_bad + 3, if_stats, (const uint32_t *)(L), (const uint32_t *)(LN))
-		if (if_stats) IF_LAUNCH(4, nullptr, nullptr);                // (4: the same kernel counting its symbols, MSX_INFLATE_STATS)
+	if (serial_only || if_stats) {
+		if (if_stats) IF_LAUNCH(4, nullptr, nullptr);                // (4: the same kernel counting its symbols, MSX_INFLATE_STATS=1)
 		else IF_LAUNCH(0, nullptr, nullptr);
 	} else {
-		// the set of this stream
+		// the scratch set of this stream: the pieces' lists of the resident waves, the list of blocks handed back
 		msx_ctx::inf_set *is = nullptr;
 		for (auto &c : ctx->inf) if (c.used && c.stream == stream) is = &c;
 		if (!is) for (auto &c : ctx->inf) if (!c.used) { is = &c; c.used = true; c.stream = stream; break; }
 		if (!is) return msx_fail(ctx, MSX_ERR_ARG, "msx_bgzf_inflate_launch: more than four streams inflate on one context");
-		const int per_cu_p = lanes_form == 2 ? ((per_cu_env > 0 && per_cu_env <= 18) ? per_cu_env : IW_PER_CU) : IP_PER_CU;
-		int64_t pgrid = (int64_t)per_cu_p * ctx->num_cu;
-		if (pgrid > n_blocks) pgrid = n_blocks;
-		const size_t want_m = (size_t)per_cu_p * ctx->num_cu * IP_MATCH_CAP * sizeof(uint2);
+		const int per_cu_w = (per_cu_env > 0 && per_cu_env <= IW_PER_CU) ? per_cu_env : IW_PER_CU;
+		int64_t wgrid = (int64_t)per_cu_w * ctx->num_cu;
+		if (wgrid > n_blocks) wgrid = n_blocks;
+		const size_t want_m = (size_t)IW_PER_CU * ctx->num_cu * IP_MATCH_CAP * sizeof(uint2);
 		const size_t want_r = ((size_t)n_blocks + 64) * 4;
 		if (is->matches.cap < want_m || is->retry.cap < want_r) {
 			MSX_HIP(ctx, hipStreamSynchronize(stream));             // (an earlier launch of this stream may still read them)
@@ -1567,25 +1261,17 @@ int msx_bgzf_inflate_launch(msx_ctx *ctx, hipStream_t stream, int waves_per_cu, 
 			if ((rc = msx_reserve(ctx, &is->matches, want_m))) return rc;
 			if ((rc = msx_reserve(ctx, &is->retry, want_r < (1u << 18) ? (1u << 18) : want_r))) return rc;
 		}
-		if (lanes_form == 2) {
-			if (ip_phase_stats)
-				hipLaunchKernelGGL(k_bgzf_inflate_wave<true>, dim3((unsigned)pgrid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
-				                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, ip_phase_stats);
-			else
-				hipLaunchKernelGGL(k_bgzf_inflate_wave<false>, dim3((unsigned)pgrid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
-				                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, (unsigned long long *)nullptr);
-		} else if (ip_phase_stats)
-			hipLaunchKernelGGL(k_bgzf_inflate_par<true>, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+		if (ip_phase_stats)
+			hipLaunchKernelGGL(k_bgzf_inflate_wave<true>, dim3((unsigned)wgrid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
 			                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, ip_phase_stats);
 		else
-			hipLaunchKernelGGL(k_bgzf_inflate_par<false>, dim3((unsigned)pgrid), dim3(IP_THREADS), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
+			hipLaunchKernelGGL(k_bgzf_inflate_wave<false>, dim3((unsigned)wgrid), dim3(64), 0, stream, d_comp, comp_len, d_blocks, (uint32_t)n_blocks,
 			                   d_out, d_status, d_n_bad + 1, (uint2 *)is->matches.p, (uint32_t *)is->retry.p, d_n_bad + 2, (unsigned long long *)nullptr);
 		// what it handed back: the serial kernel over that list (a launch that finds the list empty returns at once)
-		int64_t sgrid = grid < 4 * ctx->num_cu ? grid : 4 * ctx->num_cu;
-		grid = sgrid;
+		if (grid > 4 * (int64_t)ctx->num_cu) grid = 4 * (int64_t)ctx->num_cu;
 		IF_LAUNCH(0, is->retry.p, d_n_bad + 2);
-#undef IF_LAUNCH
 	}
+#undef IF_LAUNCH
 	hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_blocks, (uint32_t)n_blocks,
 	                   (const uint8_t *)d_out, d_status, d_n_bad);
 #ifdef MSX_DEBUG_SWITCHES
@@ -1651,6 +1337,5 @@ extern "C" int msx_bgzf_inflate(msx_ctx *ctx, const void *d_comp, size_t comp_le
 void msx_touch_inflate(void) {
 	hipFuncAttributes attr;
 	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_crc));
-	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_par<false>));
 	(void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_bgzf_inflate_wave<false>));
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""msx_bgzf_inflate on the blocks of a BAM file: rate of the lane-parallel kernel (MSX_INFLATE_LANES=1) and of the serial one (the default)
+"""msx_bgzf_inflate on the blocks of a BAM file: rate of the lane-parallel kernel (the default) and of the serial one (MSX_INFLATE_SERIAL=1)
 on the same blocks in one process, and EVERY block's output against zlib's.
 usage: bench_inflate.py file.bam n_blocks [--skip-bytes N] [--json out.json]"""
 import ctypes as C
@@ -50,11 +50,11 @@ want = b"".join(zlib.decompress(raw[io:io + il], -15) for io, il, ol, crc in blo
 zlib_s = time.perf_counter() - t0
 res = {"file": os.path.basename(path), "blocks": n, "compressed_MB": round(cin / 1e6, 1), "inflated_MB": round(uo / 1e6, 1),
        "zlib_one_core_GBps": round(uo / zlib_s / 1e9, 3)}
-for name, env in (("wave", "2"), ("lanes", "1"), ("serial", None)):
+for name, env in (("lanes", None), ("serial", "1")):
     if env:
-        os.environ["MSX_INFLATE_LANES"] = env
+        os.environ["MSX_INFLATE_SERIAL"] = env
     else:
-        os.environ.pop("MSX_INFLATE_LANES", None)
+        os.environ.pop("MSX_INFLATE_SERIAL", None)
     ts = []
     for it in range(6):
         ctx.sync()
@@ -80,7 +80,7 @@ for name, env in (("wave", "2"), ("lanes", "1"), ("serial", None)):
           f"refused {ref.value}, status!=0: {int((st != 0).sum())}, every block equals zlib: {equal} {first_bad or ''}", flush=True)
     # the memory the next kernel writes must not already hold the answer
     ctx.to_dev(d_out, np.zeros(uo, np.uint8))
-os.environ.pop("MSX_INFLATE_LANES", None)
+os.environ.pop("MSX_INFLATE_SERIAL", None)
 if jpath:
     with open(jpath, "w") as f:
         json.dump(res, f, indent=1)

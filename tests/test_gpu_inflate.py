@@ -22,14 +22,15 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["lanes", "wave", "serial"])
+@pytest.fixture(autouse=True, params=["lanes", "serial"])
 def kernel(request, monkeypatch):
-    """every test twice: the lane-parallel kernel (MSX_INFLATE_LANES=1, k_bgzf_inflate_par: 256 lanes per deflate block, what
-    it hands back goes to the serial one) and the serial kernel alone (one wave per block: the default)"""
-    if request.param in ("lanes", "wave"):
-        monkeypatch.setenv("MSX_INFLATE_LANES", "1" if request.param == "lanes" else "2")       # (2: one wave per block, output resolved in global memory)
+    """every test twice: the lane-parallel kernel (the default, k_bgzf_inflate_wave: the 64 lanes of a wave decode one deflate
+    block's symbols at once; what it hands back goes to the serial kernel) and the serial kernel alone (MSX_INFLATE_SERIAL=1: one
+    symbol after the other, rounds 3-5)"""
+    if request.param == "serial":
+        monkeypatch.setenv("MSX_INFLATE_SERIAL", "1")
     else:
-        monkeypatch.delenv("MSX_INFLATE_LANES", raising=False)
+        monkeypatch.delenv("MSX_INFLATE_SERIAL", raising=False)
     return request.param
 
 
