@@ -1,30 +1,35 @@
-/* msx_inflate_par_model.h -- the lane-parallel BGZF inflater (msx_inflate.hip: k_bgzf_inflate_par) restated on the host,
+/* msx_inflate_par_model.h -- the lane-parallel BGZF inflater (msx_inflate.hip: k_bgzf_inflate_wave) restated on the host,
  * one lane after the other.  Test infrastructure (tests/c/inflate_par_twin.c): it pins the ALGORITHM -- which lane decodes
- * what from where, how the lanes' chains are joined, when a deflate block ends, what is refused -- on real streams without
- * a GPU; the kernel's bytes are checked against zlib's on the device (tests/test_gpu_inflate.py).
+ * what from where, how the lanes' chains are joined, when a deflate block ends, how matches become pieces and in which order
+ * pieces may be copied, what is refused -- on real streams without a GPU; the kernel's bytes are checked against zlib's on the
+ * device (tests/test_gpu_inflate.py, scripts/bench_inflate.py: every block).
  *
  * The reader loop's BGZF layer (htslib's bgzf_read under mSamRead, msam_helper.c:246-268) inflates one block at a time, one
  * symbol after the other: a DEFLATE code's position depends on every code before it.  What breaks the chain is that Huffman
  * decoding SELF-SYNCHRONISES: a decoder started at a wrong bit position decodes garbage for a few symbols and then, with high
  * probability, falls onto a true code boundary and stays on the true chain from there on.  So the symbols of a deflate block
- * are decoded by many lanes at once:
+ * are decoded by the 64 lanes of a wave at once:
  *
  *   segment    the next IP_LANES x IP_SUB_BITS bits of the stream behind the block's header; lane L owns the tokens (a
  *              literal, or length + distance with their extra bits, or the end-of-block code) that BEGIN in
  *              [seg + L * SUB, seg + (L + 1) * SUB)
  *   pass A     every lane decodes from the first bit of its range (lane 0: from the true position) to the first token
- *              boundary at or behind its range's end, counting only: where it ended, how many bytes and matches it saw
+ *              boundary at or behind its range's end, counting only: where it ended, how many bytes and pieces it saw
  *   pass B     rounds: lane L takes the end of lane L - 1 as its start; if that differs from the start it used, it decodes
  *              again.  Lane 0 is true from the start, lane L after L rounds at the latest; almost every lane has fallen onto
  *              the true chain inside its own range in pass A already, so its END was right although its start was not, and
- *              the second round finds next to nothing to do.  A lane that meets the end-of-block code, an invalid code or the
- *              payload's end stops there and the lanes behind it are dead.
- *              Not converged after IP_MAX_ROUNDS rounds (long tokens: few per lane): four times the bits per lane, again.
- *   pass C     exclusive sums of the lanes' byte and match counts give every lane its place in the output; the lanes decode
- *              a last time, literals go straight to their bytes, matches (position, length, distance) to a list
- *   resolve    the matches are copied in list order (a match reads what earlier matches wrote)
+ *              the later rounds find next to nothing to do.  A lane that meets the end-of-block code, an invalid code or the
+ *              payload's end stops there and the lanes behind it sit out.
+ *              Not converged after IP_MAX_ROUNDS rounds (long tokens: few per lane): four times the bits per lane, again
+ *              (the kernel hands the block to the serial kernel when that reaches 4096 bits; the model goes on, counting it).
+ *   pass C     exclusive sums of the lanes' byte and piece counts give every lane its place in the output; the lanes decode
+ *              a last time, literals go straight to their bytes, matches to a list -- in PIECES of at most 16 bytes: a piece
+ *              of a match that does not overlap itself copies `len` bytes from `from`; one that does (distance < length)
+ *              copies byte (phase + i) mod period from the period in front of the match, never what the match itself writes
+ *   resolve    a window of IP_LANES pieces at a time, one per lane: a piece whose source reaches into the outputs of earlier
+ *              pieces of the window waits until exactly those are done, the others copy at once
  *
- * then the next segment from where lane IP_LANES - 1 ended, or the next deflate block's header behind the end-of-block code.
+ * then the next segment from where the last lane ended, or the next deflate block's header behind the end-of-block code.
  * Whatever is wrong on the TRUE chain -- a code without a symbol, a distance before the block's start, more bytes than ISIZE --
  * refuses the block (the serial kernel, then the host's decoder and zlib produce the diagnostics, as before).
  */
@@ -34,7 +39,7 @@
 #include <string.h>
 
 #ifndef IP_LANES
-#define IP_LANES 256
+#define IP_LANES 64
 #endif
 #ifndef IP_SUB_BITS
 #define IP_SUB_BITS 256u               /* bits per lane to begin with */
@@ -59,7 +64,7 @@ typedef struct {
 	uint32_t out_len, pos;         /* bytes produced */
 	ip_code ll, d;
 	/* statistics */
-	uint64_t lane_decodes, tokens, segments, rounds, max_rounds, deflate_blocks, round_hist[16], restarts, resolve_rounds, resolve_windows;
+	uint64_t lane_decodes, tokens, segments, rounds, max_rounds, deflate_blocks, round_hist[16], restarts, handbacks, resolve_rounds, resolve_windows;
 } ip_state;
 
 static inline uint32_t ip_bits(const ip_state *S, uint64_t at, int n) {      /* n <= 16 bits at bit `at`; zeros behind the end */
@@ -102,7 +107,8 @@ static const uint8_t ip_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2,
 static const uint16_t ip_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 static const uint8_t ip_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-typedef struct { uint32_t pos; uint16_t len, dist; } ip_match;
+#define IP_PIECE 16u
+typedef struct { uint32_t pos, from; uint16_t len, period, phase; } ip_match;      /* a piece: len <= IP_PIECE; period 0: no overlap */
 
 /* A lane's walk: tokens from `start` while they begin in front of `limit`.  emit: pass C (base = the lane's first output
  * byte, ml = its first slot of the match list); otherwise counting only.  Returns 0 only in pass C, for what refuses the block. */
@@ -129,10 +135,17 @@ static int ip_walk(ip_state *S, uint64_t start, uint64_t limit, ip_lane *r, int 
 			const uint32_t dist = ip_dbase[ds] + ip_bits(S, at, ip_dext[ds]);
 			at += ip_dext[ds];
 			if (emit) {
-				if (dist > base + nb || len > S->out_len - (base + nb)) return 0;
-				ml[nm].pos = base + nb; ml[nm].len = (uint16_t)len; ml[nm].dist = (uint16_t)(dist - 1u);
+				const uint32_t p = base + nb;
+				uint32_t k = 0;
+				if (dist > p || len > S->out_len - p) return 0;
+				for (uint32_t o = 0; o < len; o += IP_PIECE, k++) {
+					ip_match *q = &ml[nm + k];
+					q->pos = p + o; q->len = (uint16_t)(len - o < IP_PIECE ? len - o : IP_PIECE);
+					if (dist >= len) { q->from = p + o - dist; q->period = 0; q->phase = 0; }
+					else { q->from = p - dist; q->period = (uint16_t)dist; q->phase = (uint16_t)(o % dist); }
+				}
 			}
-			nm++;
+			nm += (len + IP_PIECE - 1u) / IP_PIECE;
 			nb += len;
 		}
 		if (at > S->end_bit) { r->st = IP_PAST; break; }
@@ -185,6 +198,7 @@ static int ip_block_symbols(ip_state *S, uint64_t *at, ip_match *ml) {
 			if (converged) break;
 			sub *= 4u;
 			S->restarts++;
+			if (sub == 4096u) S->handbacks++;
 		}
 		S->rounds += rounds;
 		if (rounds > S->max_rounds) S->max_rounds = rounds;
@@ -214,7 +228,7 @@ static int ip_block_symbols(ip_state *S, uint64_t *at, ip_match *ml) {
 			uint32_t a0[IP_LANES], bb[IP_LANES];
 			uint8_t dep[IP_LANES], done[IP_LANES];
 			for (uint32_t t = 0; t < nw; t++) {
-				const uint32_t p = W[t].pos, l = W[t].len, d = (uint32_t)W[t].dist + 1u, from = p - d, send = from + (l < d ? l : d);
+				const uint32_t from = W[t].from, send = from + (W[t].period ? W[t].period : W[t].len);
 				dep[t] = 0; done[t] = 0; a0[t] = bb[t] = 0;
 				if (t > 0 && send > W[0].pos) {
 					uint32_t lo = 0, hi = t;
@@ -236,8 +250,8 @@ static int ip_block_symbols(ip_state *S, uint64_t *at, ip_match *ml) {
 					int ready = 1;
 					if (dep[t]) for (uint32_t j = a0[t]; j <= bb[t]; j++) if (!snap[j]) ready = 0;
 					if (!ready) continue;
-					const uint32_t p = W[t].pos, l = W[t].len, d = (uint32_t)W[t].dist + 1u, from = p - d;
-					for (uint32_t i = 0; i < l; i++) S->out[p + i] = S->out[from + (d >= l ? i : i % d)];
+					for (uint32_t i = 0; i < W[t].len; i++)
+						S->out[W[t].pos + i] = S->out[W[t].from + (W[t].period ? (W[t].phase + i) % W[t].period : i)];
 					done[t] = 1;
 					left--;
 				}

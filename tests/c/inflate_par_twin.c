@@ -17,18 +17,18 @@ static size_t deflate_raw(const unsigned char *in, size_t n, unsigned char *out,
 }
 static void stats(const ip_state *S, size_t blocks, size_t out_bytes) {
 	printf("  %zu blocks, %zu bytes out: %llu deflate blocks, %llu segments, %llu lane walks (%.2f per lane and segment), "
-	       "%llu symbols decoded (%.2f per output symbol-equivalent), rounds: %.2f per segment, max %llu, %llu restarts with longer lanes\n",
+	       "%llu symbols decoded (%.2f per output symbol-equivalent), rounds: %.2f per segment, max %llu, %llu restarts with longer lanes (%llu reach 4096 bits: handed back by the kernel)\n",
 	       blocks, out_bytes, (unsigned long long)S->deflate_blocks, (unsigned long long)S->segments,
 	       (unsigned long long)S->lane_decodes, (double)S->lane_decodes / ((double)S->segments * IP_LANES + 1e-9),
-	       (unsigned long long)S->tokens, 0.0, (double)S->rounds / ((double)S->segments + 1e-9), (unsigned long long)S->max_rounds, (unsigned long long)S->restarts);
-	printf("  resolve: %.2f rounds per window of %d matches\n", (double)S->resolve_rounds / ((double)S->resolve_windows + 1e-9), IP_LANES);
+	       (unsigned long long)S->tokens, 0.0, (double)S->rounds / ((double)S->segments + 1e-9), (unsigned long long)S->max_rounds, (unsigned long long)S->restarts, (unsigned long long)S->handbacks);
+	printf("  resolve: %.2f levels per window of %d pieces\n", (double)S->resolve_rounds / ((double)S->resolve_windows + 1e-9), IP_LANES);
 	printf("  rounds per segment:");
 	for (int k = 0; k < 16; k++) printf(" %llu", (unsigned long long)S->round_hist[k]);
 	printf("\n");
 }
 int main(int argc, char **argv) {
 	static ip_state S;
-	static ip_match ml[65536 / 3 + 8];
+	static ip_match ml[65536 / 3 + 65536 / 16 + 64];
 	static unsigned char out[65536 + 64], ref[65536 + 64];
 	if (argc > 1) {
 		FILE *f = fopen(argv[1], "rb");
