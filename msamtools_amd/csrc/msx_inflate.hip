@@ -630,7 +630,7 @@ done:
 //   pass B    rounds: a lane whose left neighbour ended elsewhere than it started walks again from there (ends by shuffle,
 //             votes by ballot); lanes behind the first one that stopped (end of block, no code, payload's end) sit out.  No
 //             change: converged.  Eight rounds without convergence (long tokens, few per lane: a BAM header's text): four
-//             times the bits per lane would be next (the host model goes on like that); the kernel hands the block back;
+//             times the bits per lane, again; at 4096 bits per lane the block is handed back;
 //   pass C    exclusive sums of the counts place every lane in the output; the lanes walk a last time, literals go straight
 //             to their bytes of the output IN GLOBAL MEMORY, matches -- in pieces of at most 16 bytes: position, length,
 //             source, 8 bytes -- to a list in global memory;
@@ -654,8 +654,9 @@ done:
 #define IP_SKEW(d) ((d) + ((d) >> 5))
 #define IP_PIECE 16u                     // a match goes to the list in pieces of at most 16 bytes
 #define IP_MATCH_CAP 12800u              // pieces of one segment: 16 384 bits hold at most 8192 matches (two bits each), a block's 64 KB at most 4096 further pieces
-#define IP_HANDBACK_SUB 1024u            // a segment that does not converge at 256 bits per lane goes to the serial kernel (header text: it would
-                                         // not at 1024 either, and the lanes' time is better spent on the blocks that do)
+#define IP_HANDBACK_SUB 4096u            // a segment that needs this many bits per lane to converge goes to the serial kernel.  (Not 1024: four
+                                         // in a thousand record blocks restart once, and a block handed back costs the launch a serial kernel's
+                                         // tail -- 32 hand-backs of 8192 blocks: 100 -> 69 GB/s)
 #define IF_RETRY 10u
 
 enum { IP_OK = 0u, IP_EOB = 1u, IP_BAD = 2u, IP_PAST = 3u, IP_DEAD = 4u };

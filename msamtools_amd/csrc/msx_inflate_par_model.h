@@ -21,7 +21,7 @@
  *              the later rounds find next to nothing to do.  A lane that meets the end-of-block code, an invalid code or the
  *              payload's end stops there and the lanes behind it sit out.
  *              Not converged after IP_MAX_ROUNDS rounds (long tokens: few per lane): four times the bits per lane, again
- *              (the kernel hands the block to the serial kernel at the first such restart; the model goes on, counting it).
+ *              (the kernel hands the block to the serial kernel when that reaches 4096 bits; the model goes on, counting it).
  *   pass C     exclusive sums of the lanes' byte and piece counts give every lane its place in the output; the lanes decode
  *              a last time, literals go straight to their bytes, matches to a list -- in PIECES of at most 16 bytes: a piece
  *              of a match that does not overlap itself copies `len` bytes from `from`; one that does (distance < length)
@@ -198,7 +198,7 @@ static int ip_block_symbols(ip_state *S, uint64_t *at, ip_match *ml) {
 			if (converged) break;
 			sub *= 4u;
 			S->restarts++;
-			if (sub == 1024u) S->handbacks++;
+			if (sub == 4096u) S->handbacks++;
 		}
 		S->rounds += rounds;
 		if (rounds > S->max_rounds) S->max_rounds = rounds;

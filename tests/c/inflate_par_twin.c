@@ -17,7 +17,7 @@ static size_t deflate_raw(const unsigned char *in, size_t n, unsigned char *out,
 }
 static void stats(const ip_state *S, size_t blocks, size_t out_bytes) {
 	printf("  %zu blocks, %zu bytes out: %llu deflate blocks, %llu segments, %llu lane walks (%.2f per lane and segment), "
-	       "%llu symbols decoded (%.2f per output symbol-equivalent), rounds: %.2f per segment, max %llu, %llu restarts with longer lanes (%llu blocks at their first: handed back by the kernel)\n",
+	       "%llu symbols decoded (%.2f per output symbol-equivalent), rounds: %.2f per segment, max %llu, %llu restarts with longer lanes (%llu reach 4096 bits: handed back by the kernel)\n",
 	       blocks, out_bytes, (unsigned long long)S->deflate_blocks, (unsigned long long)S->segments,
 	       (unsigned long long)S->lane_decodes, (double)S->lane_decodes / ((double)S->segments * IP_LANES + 1e-9),
 	       (unsigned long long)S->tokens, 0.0, (double)S->rounds / ((double)S->segments + 1e-9), (unsigned long long)S->max_rounds, (unsigned long long)S->restarts, (unsigned long long)S->handbacks);
