@@ -624,13 +624,15 @@ done:
 // wrong bit decodes garbage for a few symbols and then falls onto a true code boundary, from where it IS the true chain.  So a
 // deflate block's symbols are decoded by the 64 lanes of its wave at once (the algorithm, its passes and what it refuses are
 // restated one lane after the other in msx_inflate_par_model.h, which the CPU tests run against zlib):
-//   segment   2 KB of the stream staged in LDS (skewed by one word per 32 so that lanes a whole number of words apart do not
-//             share a bank); lane L owns the tokens that begin in bits [seg + L * sub, seg + (L + 1) * sub), sub = 256;
+//   segment   3 KB of the stream staged in LDS (skewed by one word per 32 so that lanes a whole number of words apart do not
+//             share a bank); lane L owns the tokens that begin in bits [seg + L * sub, seg + (L + 1) * sub), sub = 384 (measured:
+//             256 / 320 / 384 / 448 / 512 / 640 bits give 100 / 119 / 122 / 116 / 117 / 116 GB/s on lean records and 183 / 187 / 199 /
+//             182 / 180 / 163 with SEQ/QUAL -- fewer rounds of pass B against fewer waves per compute unit and idler last segments);
 //   pass A    every lane walks its range from its first bit (lane 0: from the true position), counting bytes and pieces;
 //   pass B    rounds: a lane whose left neighbour ended elsewhere than it started walks again from there (ends by shuffle,
 //             votes by ballot); lanes behind the first one that stopped (end of block, no code, payload's end) sit out.  No
 //             change: converged.  Eight rounds without convergence (long tokens, few per lane: a BAM header's text): four
-//             times the bits per lane, again; at 4096 bits per lane the block is handed back;
+//             times the bits per lane, again (384, 1536); beyond 4096 bits per lane the block is handed back;
 //   pass C    exclusive sums of the counts place every lane in the output; the lanes walk a last time, literals go straight
 //             to their bytes of the output IN GLOBAL MEMORY, matches -- in pieces of at most 16 bytes: position, length,
 //             source, 8 bytes -- to a list in global memory;
@@ -644,16 +646,19 @@ done:
 // A first form gave a block four waves and kept its WHOLE output in LDS (80 KB: two blocks per compute unit, two waves per
 // SIMD).  It was correct and no faster than the serial kernel (47.8 against 50.2 GB/s): per 8192 lean blocks it issued 2.14 G
 // vector, 1.72 G scalar and 0.20 G LDS wave-instructions -- 4.1 + 3.3 + ~2 ms of its units' time if nothing overlapped -- and
-// with two waves per SIMD hardly anything did (profiles/round6/inflate_lanes.md).  This form takes 8.7 KB of LDS and 127
+// with two waves per SIMD hardly anything did (profiles/round6/inflate_lanes.md).  This form takes 9.8 KB of LDS and 127
 // registers per block: sixteen blocks per compute unit, one block's table reads beside another's arithmetic, no barrier
-// anywhere.  100 GB/s on lean records, 184 GB/s with SEQ/QUAL (the serial kernel: 50 / 108), every block equal to zlib's.
+// anywhere.  122 GB/s on lean records, 198 GB/s with SEQ/QUAL (the serial kernel: 50 / 108), every block equal to zlib's.
 // Whatever is wrong on the true chain hands the block to the serial kernel (IF_RETRY: a list of block numbers, a second
 // launch over it), whose verdict stands as before.
-#define IP_SUB0 256u
+#ifndef IP_SUB0
+#define IP_SUB0 384u
+#endif
 #define IP_MAX_ROUNDS 8u
 #define IP_SKEW(d) ((d) + ((d) >> 5))
 #define IP_PIECE 16u                     // a match goes to the list in pieces of at most 16 bytes
-#define IP_MATCH_CAP 12800u              // pieces of one segment: 16 384 bits hold at most 8192 matches (two bits each), a block's 64 KB at most 4096 further pieces
+#define IP_MATCH_CAP 8192u               // pieces of one segment the list holds (24 576 bits could hold 12 288 two-bit matches and a block's 64 KB
+                                         // 4096 further pieces: a segment with more than the list holds goes to the serial kernel)
 #define IP_HANDBACK_SUB 4096u            // a segment that needs this many bits per lane to converge goes to the serial kernel.  (Not 1024: four
                                          // in a thousand record blocks restart once, and a block handed back costs the launch a serial kernel's
                                          // tail -- 32 hand-backs of 8192 blocks: 100 -> 69 GB/s)
@@ -935,7 +940,9 @@ __device__ __forceinline__ uint32_t ip_header(SH &S, uint32_t at, uint32_t win_d
 // (PH: MSX_INFLATE_STATS=3 -- thread 0's clock at the phase boundaries, summed over the blocks into stats[8..])
 #define IP_PH(k) do { if (PH) { const long long now_ = clock64(); if (tid == 0) ph[k] += (unsigned long long)(now_ - t_ph); t_ph = now_; } } while (0)
 // the kernel: one wave per block (16 per compute unit: IW_PER_CU)
-#define IW_SEG_DW 512u
+#ifndef IW_SEG_DW
+#define IW_SEG_DW 768u
+#endif
 #define IW_SEG_BITS (IW_SEG_DW * 32u)
 struct IwShared {
 	uint32_t ll[1 << IF_LL_ROOT];
@@ -1069,6 +1076,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restr
 				const uint32_t inb = ip_wave_incl(my_nb, lane), inm = ip_wave_incl(my_nm, lane);
 				const uint32_t total = (uint32_t)__shfl((int)inb, 63), mtot = (uint32_t)__shfl((int)inm, 63);
 				if (total > out_len - pos) { fail = IF_OUT_OVER; break; }
+				if (mtot > IP_MATCH_CAP) { fail = IF_RETRY; break; }
 				IP_PH(6);
 				uint32_t bad_dist = 0u;
 				if (lane <= lastl && r.st != IP_DEAD)

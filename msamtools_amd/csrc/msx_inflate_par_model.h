@@ -42,7 +42,7 @@
 #define IP_LANES 64
 #endif
 #ifndef IP_SUB_BITS
-#define IP_SUB_BITS 256u               /* bits per lane to begin with */
+#define IP_SUB_BITS 384u               /* bits per lane to begin with */
 #endif
 #define IP_SEG_BITS (IP_LANES * IP_SUB_BITS)
 #ifndef IP_MAX_ROUNDS
@@ -198,7 +198,7 @@ static int ip_block_symbols(ip_state *S, uint64_t *at, ip_match *ml) {
 			if (converged) break;
 			sub *= 4u;
 			S->restarts++;
-			if (sub == 4096u) S->handbacks++;
+			if (sub >= 4096u && sub < 4u * 4096u) S->handbacks++;
 		}
 		S->rounds += rounds;
 		if (rounds > S->max_rounds) S->max_rounds = rounds;
