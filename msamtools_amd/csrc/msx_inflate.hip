@@ -962,7 +962,7 @@ struct IwShared {
 struct __attribute__((packed, aligned(1))) iw_u16 { unsigned long long lo, hi; };
 
 template <bool PH>
-__global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restrict__ comp, size_t comp_len,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bgzf_inflate_wave(const uint8_t *__restrict__ comp, size_t comp_len,
                                                           const msx_bgzf_block *__restrict__ blk, uint32_t n_blocks,
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ status,
                                                           uint32_t *__restrict__ ticket, uint2 *__restrict__ match_scratch,
@@ -1086,10 +1086,14 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restr
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				IP_PH(7);
+				uint2 m_next = make_uint2(0u, 0u);
+				if (lane < mtot) m_next = ml[lane];
 				for (uint32_t w0 = 0u; w0 < mtot; w0 += 64u) {
 					const bool have = w0 + lane < mtot;
-					uint2 m = make_uint2(0u, 0u);
-					if (have) m = ml[w0 + lane];
+					const uint2 m = m_next;
+					// (the next window's entries are on their way while this one's are searched and copied)
+					m_next = make_uint2(0u, 0u);
+					if (w0 + 64u + lane < mtot) m_next = ml[w0 + 64u + lane];
 					const uint32_t p = m.x & 0xffffu, l = ((m.x >> 16) & 15u) + 1u, ph0 = m.x >> 20, from = m.y & 0xffffu, per = m.y >> 16;
 					const uint32_t send = from + (per ? per : l);
 					const uint32_t wp = have ? p : 0x7fffffffu, we = p + l;
@@ -1129,6 +1133,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restr
 						if (dm == ~0ull) break;
 						if (level > 64u) { fail = IF_RETRY; break; }              // (cannot happen: the lowest open piece is always ready)
 						const bool ready = !done && (dm & need) == need;
+						// the stores of the level before (of the window before) are in place before this level's loads: waited for
+						// here and not behind the stores -- the searches above ran while they were on their way
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 						if (ready) {
 							const uint8_t *src = og + from;
 							uint8_t *dst = og + p;
@@ -1162,9 +1170,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *__restr
 							}
 							done = true;
 						}
-						// this level's stores are in place before the next level's loads
-						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 						if (PH && tid == 0) ph[11]++;
 					}
 					if (fail) break;
