@@ -87,6 +87,7 @@ void msh_close(msh_in *in);
 /* bulk access for BAM input: a contiguous span of inflated bytes holding whole records
  * (each with its 4-byte block_size prefix) and possibly one trailing partial record */
 int msh_is_bam(const msh_in *in);
+int64_t msh_in_bytes(const msh_in *in);    /* size of a regular input file; -1 otherwise */
 int msh_span_fill(msh_in *in);                        /* inflate the next batch of blocks; 0 at EOF */
 const uint8_t *msh_span(msh_in *in, size_t *len);     /* unconsumed bytes; invalidated by msh_span_fill */
 void msh_span_consume(msh_in *in, size_t n);

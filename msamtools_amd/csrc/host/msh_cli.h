@@ -139,6 +139,10 @@ typedef struct {
 	size_t n_comp_done;            /* compressed batches the device stage is through with */
 	int comp_given_up;             /* (decode thread) the input's blocks are inflated on the host from here on */
 	size_t n_ahead;                /* batches whose blocks were sent and inflated ahead (msx_unpack_prefetch_bgzf) */
+	int comp_ramp;                 /* ... batches from this one on take twice comp_blocks, in larger buffers (0: none do) */
+	size_t big_rcap;
+	int big_from;                  /* the pin thread makes the larger buffers when this many batches have been filled */
+	uint8_t *big_rbuf[PIPE_SLOTS_MAX];
 	int comp_mode, comp_blocks;    /* ... and inflated there as well: the decode stage only copies the blocks' payloads */
 	size_t ocap_cfg;
 	/* output buffers are a pool of their own: a slot is the decode stage's unit (a buffer of compressed blocks), and the

@@ -504,7 +504,7 @@ static int filter_pipelined(msh_in *in, const msx_filter_params *fp, int pools, 
 	 * round 3's form, inflate and walk on the host for every batch). */
 	if ((F.n_dev == 1 || !getenv("MSX_MULTI_HOST_WALK")) && !fp->rescore && (out_mode == MSH_OUT_BAM || out_mode == MSH_OUT_UBAM) &&
 	    !getenv("MSX_HOST_UNPACK"))
-		pipe_enable_raw(&P, 1);
+		pipe_enable_raw(&P, out_mode == MSH_OUT_BAM ? 2 : 1);      /* (2: deflated output -- the batches may grow, msh_pipeline.c) */
 	if (fp->rescore)
 		for (k = 0; k < P.n_slots; k++) P.slot[k].as_out = (int32_t *)xmalloc((P.cap_rec + 8) * 4);
 	if (po) prof_features(po, P.hdr, &pf);

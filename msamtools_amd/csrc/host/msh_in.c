@@ -386,6 +386,12 @@ struct msh_in {
 
 static void gz_text_check(msh_in *in);
 int msh_is_bam(const msh_in *in) { return in->is_bam; }
+/* bytes of the input file, if it is a regular file (-1: a pipe, a terminal, ...) */
+int64_t msh_in_bytes(const msh_in *in) {
+	struct stat st;
+	if (!in || !in->fp || fstat(fileno(in->fp), &st) != 0 || !S_ISREG(st.st_mode)) return -1;
+	return (int64_t)st.st_size;
+}
 
 /* ensure at least n unconsumed bytes in the span (BAM); returns 0 if EOF comes first */
 static int span_need(msh_in *in, size_t n) {

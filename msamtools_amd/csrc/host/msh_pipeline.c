@@ -379,6 +379,25 @@ static void *pin_thread(void *arg) {
 			ob_release(P, j);
 		}
 	}
+	/* phase 3 (filter -b over a long input: comp_ramp): once the command is under way, a larger buffer for every slot --
+	 * allocated, faulted in and page-locked here, taken by the decode stage the next time it holds the slot (pipe_fill).  A
+	 * command that ends before that never pays for them; one whose buffers are late goes on with the small batches. */
+	if (P->comp_ramp) {
+		for (;;) {
+			struct timespec ts = {0, 1000000};
+			if (__atomic_load_n(&P->pin_quit, __ATOMIC_ACQUIRE)) return NULL;
+			if (__atomic_load_n(&P->n_filled, __ATOMIC_ACQUIRE) >= (size_t)P->big_from) break;
+			nanosleep(&ts, NULL);
+		}
+		for (k = A->first; k < P->n_slots; k += A->step) {
+			uint8_t *b;
+			if (__atomic_load_n(&P->pin_quit, __ATOMIC_ACQUIRE)) return NULL;
+			b = io_alloc(P->big_rcap);
+			io_populate(b, P->big_rcap);
+			if (!getenv("MSX_NO_PIN")) MSX(msx_host_register(g_ctx, b, P->big_rcap));
+			__atomic_store_n(&P->big_rbuf[k], b, __ATOMIC_RELEASE);
+		}
+	}
 	return NULL;
 }
 /* the threads are started by pipe_enable_raw (they populate the buffers); the device thread hands them its context here */
@@ -546,7 +565,20 @@ void pipe_enable_raw(pipe_t *P, int with_obuf) {
 	 * or what fits the slot's buffer, whichever comes first. */
 	P->comp_mode = msh_is_bam(P->in) && !getenv("MSX_HOST_INFLATE");
 	/* (MSX_BATCH_BYTES, the inflated size of a batch, translates into blocks) */
+	/* filter on one device (with_obuf): 4096 blocks once the command is under way -- batch after batch pays the same four
+	 * dozen small launches of the record walk and the filter, each slowed to ~50 us beside the inflater's and the encoder's
+	 * resident waves, so a batch of twice the records costs the device stage little more (the 400 M-record file: 1.28 ->
+	 * 1.19 s) -- and 2048 for the first eight, which decide when the first output leaves, and for as long as the larger
+	 * buffers are not ready (pin_thread, phase 3: a 100 M-record file paid 20-30 ms for buffers of that size allocated at
+	 * start-up).  -bu stays at 2048 (its output buffers would have to grow with the batches); profile and coverage too:
+	 * they lost a little with larger ones (profiles/round6/batch_geometry.log). */
+	P->comp_ramp = 0;
+	if (!getenv("MSX_COMP_BLOCKS") && !getenv("MSX_BATCH_BYTES") && !getenv("MSX_COMP_BYTES") && with_obuf == 2 && P->n_consumers == 1) P->comp_ramp = 8;
 	P->comp_blocks = (int)env_size("MSX_COMP_BLOCKS", getenv("MSX_BATCH_BYTES") ? P->batch_bytes_cfg / 65280 : 2048);
+	P->big_rcap = (size_t)64 << 20;
+	/* when the larger buffers are made: at once for a file of 3 GB and more; otherwise when 32 batches have shown that the
+	 * input is long (a 100 M-record file -- 13 batches -- lost up to 0.1 s to half a gigabyte page-locked beside its last batches) */
+	P->big_from = msh_in_bytes(P->in) >= ((int64_t)3 << 30) ? 4 : 32;
 	if (P->comp_blocks < 1) P->comp_blocks = 1;
 	if (P->comp_blocks > (1 << 16)) P->comp_blocks = 1 << 16;
 	/* compressed batches need nothing of a slot but its buffer of payloads: two more of them (batch 0, walked on the host,
@@ -558,7 +590,7 @@ void pipe_enable_raw(pipe_t *P, int with_obuf) {
 		if (P->comp_mode) {
 			s->rcap = env_size("MSX_COMP_BYTES", (size_t)40 << 20);
 			if (s->rcap < ((size_t)2 << 20)) s->rcap = (size_t)2 << 20;
-			s->blk = (msx_bgzf_block *)xmalloc((size_t)P->comp_blocks * sizeof(msx_bgzf_block));
+			s->blk = (msx_bgzf_block *)xmalloc((size_t)P->comp_blocks * (P->comp_ramp ? 2 : 1) * sizeof(msx_bgzf_block));
 			/* (the output buffer starts at half of what the blocks inflate to -- page-locking is paid per byte, at start-up --
 			 * and is replaced by a larger one when a batch keeps more: filter_dev_thread) */
 			P->ocap_cfg = (size_t)P->comp_blocks * 32768 + ((size_t)8 << 20);
@@ -985,9 +1017,16 @@ void *pipe_decode_thread(void *arg) {
 					msh_inflate_limit(0);
 					if (s->rlen == before && !P->in_eof) mDie("The batch buffers are too small for a BGZF block (MSX_COMP_BYTES)");
 				} else if (P->comp_mode) {
-					while (!P->in_eof && s->n_blk < P->comp_blocks && (s->rcap - s->rlen) / (65536 + 1024) > 0) {
+					int cb = P->comp_blocks;
+					if (P->comp_ramp && P->n_filled >= (size_t)P->comp_ramp) {
+						/* (the larger buffer, if the pin thread has it ready: nothing of the device reads a free slot's old one) */
+						uint8_t *big = __atomic_load_n(&P->big_rbuf[si], __ATOMIC_ACQUIRE);
+						if (big && s->rbuf != big && s->rlen == 0) { s->rbuf = big; s->rcap = P->big_rcap; }
+						if (s->rbuf == big) cb = 2 * P->comp_blocks;
+					}
+					while (!P->in_eof && s->n_blk < cb && (s->rcap - s->rlen) / (65536 + 1024) > 0) {
 						if (s->n_blk > 0 && msh_idle_ms() > 0 && !msh_input_ready(P->in, msh_idle_ms())) break;      /* (the producer has gone quiet) */
-						if (!msh_raw_append(P->in, s->rbuf, s->rcap, &s->rlen, s->blk, &s->n_blk, P->comp_blocks, &s->inflated)) P->in_eof = 1;
+						if (!msh_raw_append(P->in, s->rbuf, s->rcap, &s->rlen, s->blk, &s->n_blk, cb, &s->inflated)) P->in_eof = 1;
 					}
 				} else
 				while (!P->in_eof && s->rlen < P->batch_bytes_cfg && s->rlen + BGZF_INFLATE_MAX + 64 <= s->rcap) {

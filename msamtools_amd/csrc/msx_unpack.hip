@@ -67,7 +67,7 @@ struct msx_unpack {
 		bool used = false;              // `freed` has been recorded at least once
 	} pre[2];
 	int ahead_head = 0, ahead_n = 0;   // the oldest pending set, how many are pending
-	hipStream_t inf_stream = nullptr, h2d_stream = nullptr;
+	hipStream_t inf_stream[2] = {nullptr, nullptr}, h2d_stream = nullptr;   // (one inflating stream per set: two batches' blocks side by side fill the chip)
 	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cig_src, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
 	    group_off, tile_last, cigar, md, out_len, out_off, out, framed;
 	char *prev_name = nullptr;     // device, 256 bytes
@@ -603,7 +603,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (!u) return;
 	if (ctx && ctx->stream) { msx_join(ctx); (void)hipStreamSynchronize(ctx->stream); }
 	if (u->h2d_stream) (void)hipStreamSynchronize(u->h2d_stream);
-	if (u->inf_stream) (void)hipStreamSynchronize(u->inf_stream);
+	for (auto st : u->inf_stream) if (st) (void)hipStreamSynchronize(st);
 	if (u->df_stream) (void)hipStreamSynchronize(u->df_stream);
 	if (u->copy_stream) (void)hipStreamSynchronize(u->copy_stream);
 	// what the context remembers of this unpacker's streams must not outlive them: the encoder's scratch was last used on
@@ -611,7 +611,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (ctx) {
 		if (u->df_stream && ctx->df_last == u->df_stream) { ctx->df_last = nullptr; ctx->df_used = false; }
 		for (auto &c : ctx->inf)
-			if (c.used && u->inf_stream && c.stream == u->inf_stream) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
+			if (c.used && c.stream && (c.stream == u->inf_stream[0] || c.stream == u->inf_stream[1])) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
 	}
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cig_src, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
@@ -621,7 +621,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	                   &u->pre[1].out, &u->pre[1].cnt};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
-	if (u->inf_stream) { (void)hipStreamSynchronize(u->inf_stream); (void)hipStreamDestroy(u->inf_stream); }
+	for (auto st : u->inf_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	if (u->h2d_stream) { (void)hipStreamSynchronize(u->h2d_stream); (void)hipStreamDestroy(u->h2d_stream); }
 	for (auto &ps : u->pre) {
 		if (ps.h2d_done) (void)hipEventDestroy(ps.h2d_done);
@@ -800,10 +800,10 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 	int rc;
 	size_t n_new = 0;
 	if ((rc = up_check_table(ctx, host_blocks, n_blocks, comp_len, &n_new))) return rc;
-	if (!u->inf_stream) {
+	if (!u->inf_stream[0]) {
 		int lo = 0, hi = 0;
 		MSX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));           // (lo: the least urgent)
-		MSX_HIP(ctx, hipStreamCreateWithPriority(&u->inf_stream, hipStreamNonBlocking, lo));
+		for (auto &st : u->inf_stream) MSX_HIP(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo));
 		MSX_HIP(ctx, hipStreamCreateWithFlags(&u->h2d_stream, hipStreamNonBlocking));
 		for (auto &ps : u->pre) {
 			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.h2d_done, hipEventDisableTiming));
@@ -811,7 +811,9 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.freed, hipEventDisableTiming));
 		}
 	}
-	msx_unpack::pre_set &ps = u->pre[(u->ahead_head + u->ahead_n) & 1];
+	const int set = (u->ahead_head + u->ahead_n) & 1;
+	msx_unpack::pre_set &ps = u->pre[set];
+	hipStream_t inf = u->inf_stream[set];
 	// (the set may still be read by the copy of the batch that used it last: its upload waits for that copy; buffers are
 	// grown only when nothing of the set is in flight any more)
 	if (ps.used) MSX_HIP(ctx, hipStreamWaitEvent(u->h2d_stream, ps.freed, 0));
@@ -819,7 +821,7 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 	    ps.out.cap < n_new + 64 || ps.cnt.cap < 64) {
 		if (ps.used) MSX_HIP(ctx, hipEventSynchronize(ps.freed));
 		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
-		MSX_HIP(ctx, hipStreamSynchronize(u->inf_stream));
+		for (auto st : u->inf_stream) MSX_HIP(ctx, hipStreamSynchronize(st));
 	}
 	if ((rc = msx_reserve(ctx, &ps.comp, comp_len + 64))) return rc;
 	if ((rc = msx_reserve(ctx, &ps.blk, (size_t)n_blocks * sizeof(msx_bgzf_block)))) return rc;
@@ -830,15 +832,16 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 	MSX_HIP(ctx, hipMemcpyAsync(ps.comp.p, host_comp, comp_len, hipMemcpyHostToDevice, u->h2d_stream));
 	MSX_HIP(ctx, hipMemcpyAsync(ps.blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, u->h2d_stream));
 	MSX_HIP(ctx, hipEventRecord(ps.h2d_done, u->h2d_stream));
-	// ... the inflater behind it, and behind the inflater of the batch before.
+	// ... the inflater behind it, on this set's own stream: beside the inflater of the batch before, if that is still at work
+	// (a batch of 2048 blocks is eight waves per compute unit, the kernel keeps sixteen: two batches fill the chip).
 	// (eight waves per compute unit: the batch beside it needs LDS too -- k_besthit_select waited a whole inflate kernel for
 	// its share when ten were resident -- and the command line's batches of 2048 blocks are eight per compute unit anyway)
-	MSX_HIP(ctx, hipStreamWaitEvent(u->inf_stream, ps.h2d_done, 0));
-	MSX_HIP(ctx, hipMemsetAsync(ps.cnt.p, 0, 8, u->inf_stream));
-	if ((rc = msx_bgzf_inflate_launch(ctx, u->inf_stream, 8, (const uint8_t *)ps.comp.p, comp_len, (const msx_bgzf_block *)ps.blk.p,
+	MSX_HIP(ctx, hipStreamWaitEvent(inf, ps.h2d_done, 0));
+	MSX_HIP(ctx, hipMemsetAsync(ps.cnt.p, 0, 8, inf));
+	if ((rc = msx_bgzf_inflate_launch(ctx, inf, 8, (const uint8_t *)ps.comp.p, comp_len, (const msx_bgzf_block *)ps.blk.p,
 	                                  n_blocks, (uint8_t *)ps.out.p, (uint32_t *)ps.status.p, (uint32_t *)ps.cnt.p)))
 		return rc;
-	MSX_HIP(ctx, hipEventRecord(ps.inf_done, u->inf_stream));
+	MSX_HIP(ctx, hipEventRecord(ps.inf_done, inf));
 	ps.key = host_comp;
 	ps.comp_len = comp_len;
 	ps.nblk = n_blocks;
@@ -863,7 +866,7 @@ extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_
 	const bool sent = u->ahead_n > 0 && ps.key == host_comp && ps.comp_len == comp_len && ps.nblk == n_blocks;
 	if (u->ahead_n > 0 && !sent) {
 		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
-		MSX_HIP(ctx, hipStreamSynchronize(u->inf_stream));
+		for (auto st : u->inf_stream) MSX_HIP(ctx, hipStreamSynchronize(st));
 		u->ahead_n = 0;
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: other blocks than msx_unpack_prefetch_bgzf sent ahead");
 	}
