@@ -98,35 +98,40 @@ typedef struct {
 	size_t span_beg, span_end, span_cap;
 } bgz_in;
 
-/* one block's DEFLATE stream into `out` (isize bytes expected, CRC-32 `crc`) */
-static void inflate_payload(const uint8_t *data, size_t dlen, uint8_t *out, uint32_t isize, uint32_t crc) {
+/* one block's DEFLATE stream into `out` (isize bytes expected, CRC-32 `crc`); NULL, or what is wrong with it */
+static const char *inflate_payload_try(const uint8_t *data, size_t dlen, uint8_t *out, uint32_t isize, uint32_t crc) {
 	/* one stream per thread, reset between blocks: initialising one per block means an allocation per
 	 * block, and with a hundred threads those serialise inside the allocator */
 	static __thread z_stream zs;
 	static __thread int zs_ready = 0;
 	static int fast_flag = -1;
 	int fast = __atomic_load_n(&fast_flag, __ATOMIC_RELAXED);
-	if (isize == 0) return;
+	if (isize == 0) return NULL;
 	if (fast < 0) {
 		fast = !getenv("MSX_NO_FAST_INFLATE");
 		__atomic_store_n(&fast_flag, fast, __ATOMIC_RELAXED);
 	}
 	/* the decoder of msh_inflate.c first (twice zlib's speed on BAM records); whatever it does not vouch for,
 	 * and whatever fails the CRC afterwards, is decoded again by zlib, whose verdict stands */
-	if (fast && msh_fast_inflate(data, dlen, out, isize) && msh_crc32(out, isize) == crc) return;
+	if (fast && msh_fast_inflate(data, dlen, out, isize) && msh_crc32(out, isize) == crc) return NULL;
 	if (!zs_ready) {
 		memset(&zs, 0, sizeof zs);
-		if (inflateInit2(&zs, -15) != Z_OK) mDie("zlib inflateInit2 failed");
+		if (inflateInit2(&zs, -15) != Z_OK) return "zlib inflateInit2 failed";
 		zs_ready = 1;
 	} else if (inflateReset(&zs) != Z_OK) {
-		mDie("zlib inflateReset failed");
+		return "zlib inflateReset failed";
 	}
 	zs.next_in = (Bytef *)data;
 	zs.avail_in = (uInt)dlen;
 	zs.next_out = out;
 	zs.avail_out = isize;
-	if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize) mDie("Corrupt BGZF block (inflate failed)");
-	if (msh_crc32(out, isize) != crc) mDie("Corrupt BGZF block (CRC mismatch)");
+	if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize) return "Corrupt BGZF block (inflate failed)";
+	if (msh_crc32(out, isize) != crc) return "Corrupt BGZF block (CRC mismatch)";
+	return NULL;
+}
+static void inflate_payload(const uint8_t *data, size_t dlen, uint8_t *out, uint32_t isize, uint32_t crc) {
+	const char *err = inflate_payload_try(data, dlen, out, isize, crc);
+	if (err) mDie("%s", err);
 }
 
 static void inflate_block(bgz_in *b, int i) {
@@ -830,22 +835,107 @@ static void gz_write_all(int fd, const uint8_t *p, size_t n) {
 	}
 }
 
-/* compressed SAM text: every gzip member of the stream (plain gzip has one, bgzip one per block), inflated into the pipe */
+/* a BGZF member at p (n bytes on hand): its size, 0 if what begins there is not one (a gzip member of another kind, or
+ * damage), -1 if more bytes are needed to tell */
+static long bgzf_member_at(const uint8_t *p, size_t n) {
+	uint32_t xlen, o;
+	if (n < 12) return -1;
+	if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+	xlen = le16(p + 10);
+	if (n < 12 + (size_t)xlen) return -1;
+	for (o = 0; o + 4 <= xlen; ) {
+		const uint8_t *f = p + 12 + o;
+		const uint32_t slen = le16(f + 2);
+		if (f[0] == 'B' && f[1] == 'C' && slen == 2 && o + 6 <= xlen) {
+			const long bsize = (long)le16(f + 4) + 1;
+			return bsize >= (long)(12 + xlen + 8) ? bsize : 0;
+		}
+		o += 4 + slen;
+	}
+	return 0;
+}
+
+/* bgzip'd text: the members on hand inflated side by side on the reader's pool (the BAM path's host decoder: msh_inflate.c,
+ * then zlib), in order into the pipe */
+#define GZT_BLOCKS 512
+typedef struct { const uint8_t *src; const msx_bgzf_block *blk; int n; uint8_t *out; const char *err; } gzt_job;
+static void gzt_worker(void *arg, int tid, int nth) {
+	gzt_job *J = (gzt_job *)arg;
+	int i;
+	for (i = tid; i < J->n; i += nth) {
+		const char *e = inflate_payload_try(J->src + J->blk[i].in_off, J->blk[i].in_len, J->out + J->blk[i].out_off, J->blk[i].out_len, J->blk[i].crc32);
+		if (e) __atomic_store_n(&J->err, e, __ATOMIC_RELAXED);
+	}
+}
+
+/* compressed SAM text: every gzip member of the stream (plain gzip has one, bgzip one per block), inflated into the pipe.
+ * BGZF members say how long they are and what they inflate to: as many as are on hand are inflated at once; anything else
+ * goes through one zlib stream, member after member. */
 static void *gz_text_main(void *arg) {
 	msh_in *in = (msh_in *)arg;
 	const int fd = fileno(in->gz_src);
-	const size_t ICAP = (size_t)1 << 20, OCAP = (size_t)4 << 20;
+	const size_t ICAP = (size_t)GZT_BLOCKS * 65536 + PRE_MAX, OCAP = (size_t)GZT_BLOCKS * 65536;
 	uint8_t *ibuf = (uint8_t *)malloc(ICAP), *obuf = (uint8_t *)malloc(OCAP);
+	msx_bgzf_block *blk = (msx_bgzf_block *)malloc(GZT_BLOCKS * sizeof(msx_bgzf_block));
+	size_t have = 0, at = 0;                  /* ibuf[at, have): read, not yet inflated */
 	z_stream zs;
-	int at_member_start = 1, eof = 0;
-	if (!ibuf || !obuf) mDie("Out of memory");
+	int zs_on = 0, at_member_start = 1, eof = 0;
+	if (!ibuf || !obuf || !blk) mDie("Out of memory");
+	memcpy(ibuf, in->pre, in->npre);
+	have = in->npre;
+	/* ---- BGZF members, as long as that is what comes ---- */
+	for (;;) {
+		int n = 0;
+		size_t out_total = 0, p = at;
+		long m = 0;
+		while (n < GZT_BLOCKS && (m = bgzf_member_at(ibuf + p, have - p)) > 0 && p + (size_t)m <= have) {
+			const uint8_t *c = ibuf + p;
+			const uint32_t xlen = le16(c + 10), isize = (uint32_t)le32(c + m - 4);
+			if (isize > 65536u) { m = 0; break; }      /* (no BGZF block inflates to more: some other gzip member) */
+			blk[n].in_off = p + 12 + xlen;
+			blk[n].in_len = (uint32_t)((size_t)m - 12 - xlen - 8);
+			blk[n].out_off = out_total;
+			blk[n].out_len = isize;
+			blk[n].crc32 = (uint32_t)le32(c + m - 8);
+			blk[n].reserved_ = 0;
+			out_total += isize;
+			p += (size_t)m;
+			n++;
+		}
+		if (n > 0) {
+			gzt_job J;
+			J.src = ibuf; J.blk = blk; J.n = n; J.out = obuf; J.err = NULL;
+			msh_parallel(msh_threads() < n ? msh_threads() : n, gzt_worker, &J);
+			if (J.err) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Corrupt gzip stream in SAM input (%s)", J.err); goto fail; }
+			gz_write_all(in->gz_wfd, obuf, out_total);
+			at = p;
+			continue;
+		}
+		if (m == 0 && have > p) break;             /* something else begins here: the zlib loop takes over */
+		/* a member is cut by what has been read (or nothing is left): more bytes */
+		if (eof) {
+			if (have > at) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Truncated gzip stream in SAM input"); goto fail; }
+			goto done;
+		}
+		memmove(ibuf, ibuf + at, have - at);
+		have -= at; at = 0;
+		{
+			ssize_t k;
+			do k = read(fd, ibuf + have, ICAP - have); while (k < 0 && errno == EINTR);
+			if (k < 0) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Read failed"); goto fail; }
+			if (k == 0) eof = 1;
+			have += (size_t)k;
+		}
+	}
+	/* ---- any gzip member: one stream ---- */
 	memset(&zs, 0, sizeof zs);
 	if (inflateInit2(&zs, 15 + 32) != Z_OK) mDie("inflateInit2 failed");
-	zs.next_in = in->pre; zs.avail_in = (uInt)in->npre;
+	zs_on = 1;
+	zs.next_in = ibuf + at; zs.avail_in = (uInt)(have - at);
 	for (;;) {
 		if (zs.avail_in == 0 && !eof) {
 			ssize_t k;
-			do k = read(fd, ibuf, ICAP); while (k < 0 && errno == EINTR);
+			do k = read(fd, ibuf, ICAP < ((size_t)1 << 20) ? ICAP : ((size_t)1 << 20)); while (k < 0 && errno == EINTR);
 			if (k < 0) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Read failed"); goto fail; }
 			if (k == 0) eof = 1;
 			zs.next_in = ibuf; zs.avail_in = (uInt)k;
@@ -854,7 +944,7 @@ static void *gz_text_main(void *arg) {
 			if (!at_member_start) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "Truncated gzip stream in SAM input"); goto fail; }
 			break;
 		}
-		zs.next_out = obuf; zs.avail_out = (uInt)OCAP;
+		zs.next_out = obuf; zs.avail_out = (uInt)((size_t)4 << 20);
 		{
 			const int rc = inflate(&zs, Z_NO_FLUSH);
 			if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
@@ -862,7 +952,7 @@ static void *gz_text_main(void *arg) {
 				goto fail;
 			}
 			at_member_start = 0;
-			gz_write_all(in->gz_wfd, obuf, OCAP - zs.avail_out);
+			gz_write_all(in->gz_wfd, obuf, ((size_t)4 << 20) - zs.avail_out);
 			if (rc == Z_STREAM_END) {                    /* the next member, if any */
 				if (inflateReset(&zs) != Z_OK) { snprintf(in->gz_errmsg, sizeof in->gz_errmsg, "inflateReset failed"); goto fail; }
 				at_member_start = 1;
@@ -876,9 +966,11 @@ fail:
 		 * The reason is left for the reader, which sees the end of the pipe next and dies with it (gz_text_check). */
 		__atomic_store_n(&in->gz_err, 1, __ATOMIC_RELEASE);
 	}
-	inflateEnd(&zs);
+done:
+	if (zs_on) inflateEnd(&zs);
 	free(ibuf);
 	free(obuf);
+	free(blk);
 	close(in->gz_wfd);
 	return NULL;
 }
