@@ -961,6 +961,31 @@ def main():
         },
     }
 
+    # ---- N ranks: the same K steps with MSX_DIST_SLICES=2 (the local half in two slices of the feature range, slice 0's
+    # all-reduce under slice 1's kernels) beside the default, which `value` is -- the A/B a node with more than one GPU decides
+    if use_dist and not args.no_dist_parity:
+        try:
+            os.environ["MSX_DIST_SLICES"] = "2"
+            for _ in range(max(1, min(args.warmup, 2))):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el2 = ctx.max_over_ranks(time.perf_counter() - t0)
+            ab2, pst2 = prof.fetch()
+            out["dist_slices_2"] = {"ms_per_step": round(1e3 * el2 / max(args.steps, 1), 4),
+                                    "value": round(total_records * args.steps / el2 / 1e6, 3),
+                                    "ratio_to_default": round(el2 / elapsed, 4),
+                                    "abundances_bit_equal_to_default": bool(np.array_equal(ab2, ab)),
+                                    "iterations": int(pst2.iterations),
+                                    "note": "MSX_DIST_SLICES=2; default (1) is what `value` reports"}
+        except Exception as exc:
+            out["dist_slices_2"] = {"error": str(exc)[:300]}
+        finally:
+            os.environ.pop("MSX_DIST_SLICES", None)
+
     if args.print_checksum:
         import hashlib
         out["checksum"] = {"abundance_sum": float(ab.sum()), "abundance_sha1_6dp": hashlib.sha1(
@@ -1217,6 +1242,9 @@ def main():
                 return dt, a_, s_
             dms0, ab_0, st_0 = timed(0)           # all 19 iterations enqueued, nothing waits for the host (rounds 2-3)
             dms, ab_d, st_d = timed(8)            # the default: the convergence flag looked at every 8th iteration
+            os.environ["MSX_DIST_SLICES"] = "2"   # the local half in two slices, slice 0's all-reduce on a side stream
+            dms2, ab_2, st_2 = timed(8)
+            os.environ.pop("MSX_DIST_SLICES", None)
             os.environ.pop("MSX_DIST_POLL", None)
             out["dist_one_rank_ms_per_step"] = round(dms, 4)
             out["dist_one_rank"] = {
@@ -1225,6 +1253,8 @@ def main():
                 "max_rel_diff_to_plain": float((np.abs(ab_d - ab) / np.maximum(np.abs(ab), 1e-300)).max()),
                 "without_convergence_poll": {"ms_per_step": round(dms0, 4), "iterations": int(st_0.iterations),
                                              "max_rel_diff_to_plain": float((np.abs(ab_0 - ab) / np.maximum(np.abs(ab), 1e-300)).max())},
+                "slices_2": {"ms_per_step": round(dms2, 4), "iterations": int(st_2.iterations),
+                             "abundances_bit_equal_to_one_slice": bool(np.array_equal(ab_2, ab_d))},
                 "note": "one-rank RCCL communicator: every collective of the N-rank step is enqueued and runs; MSX_DIST_POLL=8 (default) "
                         "stops enqueueing all-reduces once the convergence flag is seen, =0 enqueues all 19"}
         except Exception as exc:

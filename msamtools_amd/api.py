@@ -598,6 +598,12 @@ class Profile:
         self.ctx.check(self.ctx.lib.msx_profile_prop_local(self.ctx.h, self.h, C.byref(inc)))
         return inc.value
 
+    def prop_local_slice(self, slice_, n_slices):
+        """-> (device pointer of share[], first feature, count): the range this slice has completed"""
+        inc, first, count = C.c_void_p(), C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.ctx.lib.msx_profile_prop_local_slice(self.ctx.h, self.h, slice_, n_slices, C.byref(inc), C.byref(first), C.byref(count)))
+        return inc.value, first.value, count.value
+
     def prop_apply(self):
         d = C.c_double(0)
         self.ctx.check(self.ctx.lib.msx_profile_prop_apply(self.ctx.h, self.h, C.byref(d)))

@@ -81,6 +81,8 @@ struct msx_dist {
 	int rank = 0, world = 1;
 	msx_nccl_comm comm = nullptr;
 	void *scratch = nullptr;        // device, 64 bytes: scalars of barrier / reductions of host values
+	hipStream_t side = nullptr;     // MSX_DIST_SLICES: a slice's all-reduce travels here while the next slice is computed
+	hipEvent_t ev_ready = nullptr, ev_done = nullptr;
 };
 
 // ---- rendezvous: rank 0 hands the 128-byte id to the others over TCP -------------------------
@@ -266,6 +268,9 @@ extern "C" void msx_dist_finalize(msx_ctx *ctx) {
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->dist->comm) g_rccl.CommDestroy(ctx->dist->comm);
+	if (ctx->dist->side) { (void)hipStreamSynchronize(ctx->dist->side); (void)hipStreamDestroy(ctx->dist->side); }
+	if (ctx->dist->ev_ready) (void)hipEventDestroy(ctx->dist->ev_ready);
+	if (ctx->dist->ev_done) (void)hipEventDestroy(ctx->dist->ev_done);
 	if (ctx->dist->scratch) (void)hipFree(ctx->dist->scratch);
 	delete ctx->dist;
 	ctx->dist = nullptr;
@@ -333,6 +338,27 @@ int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p) {
 	if (!d) return MSX_OK;          // (a one-rank communicator still runs the collective: the same code path)
 	MSX_NCCL(ctx, g_rccl.AllReduce(p->share, p->share, (size_t)p->n_features, MSX_NCCL_FLOAT64, MSX_NCCL_SUM, d->comm,
 	                                ctx->stream));
+	return MSX_OK;
+}
+
+int msx_dist_allreduce_share_side(msx_ctx *ctx, msx_profile *p, int32_t first, int32_t count) {
+	msx_dist *d = ctx->dist;
+	if (!d || count <= 0) return MSX_OK;
+	if (!d->side) {
+		MSX_HIP(ctx, hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+		MSX_HIP(ctx, hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+		MSX_HIP(ctx, hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
+	}
+	MSX_HIP(ctx, hipEventRecord(d->ev_ready, ctx->stream));
+	MSX_HIP(ctx, hipStreamWaitEvent(d->side, d->ev_ready, 0));
+	MSX_NCCL(ctx, g_rccl.AllReduce(p->share + first, p->share + first, (size_t)count, MSX_NCCL_FLOAT64, MSX_NCCL_SUM, d->comm, d->side));
+	return MSX_OK;
+}
+int msx_dist_side_join(msx_ctx *ctx) {
+	msx_dist *d = ctx->dist;
+	if (!d || !d->side) return MSX_OK;
+	MSX_HIP(ctx, hipEventRecord(d->ev_done, d->side));
+	MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, d->ev_done, 0));
 	return MSX_OK;
 }
 

@@ -108,6 +108,7 @@ struct msx_lane {
 #define MSX_SIDE_LANES 2
 
 struct msx_dist;     // msx_dist.hip: RCCL communicator of this rank
+#define MSX_MAX_SLICES 4
 
 struct msx_ctx {
 	int device = 0;
@@ -262,6 +263,11 @@ struct msx_profile {
 	int sorted_buf = 0;               // which ping-pong buffer holds the sorted pairs
 	int key_bits = 0;                 // bits of the feature id in an entry key (the list weight sits above)
 	bool transposed_valid = false;
+	// slices of an iteration's local half (msx_profile_prop_local_slice): wave and feature cuts, read once per store
+	int slice_n = 0;
+	bool slice_valid = false;
+	int64_t slice_wave[MSX_MAX_SLICES + 1] = {0};
+	uint32_t slice_key[MSX_MAX_SLICES + 1] = {0};
 	int iter_k = 0;
 	bool recip_valid = false;   // recip[] of the general lists belongs to the current a[]
 	bool begun = false;
@@ -285,6 +291,10 @@ int msx_sort_k32v8(msx_ctx *ctx, uint32_t *k0, const uint8_t *v0, uint32_t *k1, 
                    int64_t counted_tiles, int skip_bucket, uint32_t *lay);
 // msx_dist.hip: in-place all-reduce(sum) on the ctx stream; no-ops without a communicator
 int msx_dist_allreduce_share(msx_ctx *ctx, msx_profile *p);
+// share[first, first + count) on the communicator's SIDE stream, behind what the context's stream holds now (slices); the
+// context's stream is made to wait for every side all-reduce issued so far by msx_dist_side_join
+int msx_dist_allreduce_share_side(msx_ctx *ctx, msx_profile *p, int32_t first, int32_t count);
+int msx_dist_side_join(msx_ctx *ctx);
 int msx_dist_allreduce_u32(msx_ctx *ctx, uint32_t *dev, size_t count);
 // ui[key] += add for every key < 0x80000000 of keys[0..n) by partition + LDS counting (n_features <= 2 M)
 int msx_count_keys(msx_ctx *ctx, msx_profile *p, const uint32_t *keys, uint32_t *key2, int64_t n, uint32_t add);

@@ -419,13 +419,17 @@ int msx_profile_fold_equal(msx_ctx *ctx, msx_profile *p) {
 	return MSX_OK;
 }
 
+// (--multi equal: the integer shares dq[] are added AS INTEGERS and folded into d[] once, by whoever reads d[] next -- N contexts'
+// sums are then one context's, bit for bit; folding each side first added N rounded quotients instead of rounding one)
 __global__ __launch_bounds__(MSX_BLOCK) void k_merge_counts(int32_t nf, const uint32_t *__restrict__ ui_src, uint32_t *__restrict__ ui,
                                                             const double *__restrict__ d_src, double *__restrict__ d,
+                                                            const unsigned long long *__restrict__ dq_src, unsigned long long *__restrict__ dq,
                                                             const uint32_t *__restrict__ cnt_src, uint32_t *__restrict__ cnt) {
 	const int64_t stride = (int64_t)gridDim.x * MSX_BLOCK;
 	for (int64_t i = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x; i < nf; i += stride) {
 		ui[i] += ui_src[i];
 		if (d) d[i] += d_src[i];
+		if (dq) dq[i] += dq_src[i];
 	}
 	if (blockIdx.x == 0 && threadIdx.x < 3) cnt[threadIdx.x] += cnt_src[threadIdx.x];     // inserts, uniq, multi
 }
@@ -451,17 +455,16 @@ extern "C" int msx_profile_merge(msx_ctx *ctx, msx_profile *p, msx_ctx *src_ctx,
 	msx_join(src_ctx);
 	// everything the source has enqueued must have landed
 	MSX_HIP(src_ctx, hipSetDevice(src_ctx->device));
-	{ int frc = msx_profile_fold_equal(src_ctx, q); if (frc) return frc; }     // (--multi equal: d[] of both sides complete)
 	MSX_HIP(src_ctx, hipStreamSynchronize(src_ctx->stream));
 	unsigned long long t[2] = {0, 0};
 	MSX_HIP(src_ctx, hipMemcpy(t, q->csr_tot, 16, hipMemcpyDeviceToHost));
 	const int64_t nl = (int64_t)t[0], ne = (int64_t)t[1];
 	MSX_HIP(ctx, hipSetDevice(ctx->device));
-	{ int frc = msx_profile_fold_equal(ctx, p); if (frc) return frc; }
 	const size_t nf = (size_t)(p->n_features > 0 ? p->n_features : 1);
-	// staging on the destination device: ui, d, counters, offsets of the source
-	const size_t b_ui = nf * 4, b_d = q->d ? nf * 8 : 0, b_off = (size_t)(nl + 1) * 4;
-	const size_t o_d = (b_ui + 15) & ~(size_t)15, o_cnt = o_d + ((b_d + 15) & ~(size_t)15), o_off = o_cnt + 16;
+	// staging on the destination device: ui, d, dq, counters, offsets of the source
+	const bool with_dq = q->dq && p->dq && q->dq_dirty;
+	const size_t b_ui = nf * 4, b_d = q->d ? nf * 8 : 0, b_dq = with_dq ? nf * 8 : 0, b_off = (size_t)(nl + 1) * 4;
+	const size_t o_d = (b_ui + 15) & ~(size_t)15, o_dq = o_d + ((b_d + 15) & ~(size_t)15), o_cnt = o_dq + ((b_dq + 15) & ~(size_t)15), o_off = o_cnt + 16;
 	char *stage = nullptr;
 	if (hipMalloc((void **)&stage, o_off + b_off + 16) != hipSuccess)
 		return msx_fail(ctx, MSX_ERR_NOMEM, "msx_profile_merge: staging allocation failed");
@@ -474,12 +477,15 @@ extern "C" int msx_profile_merge(msx_ctx *ctx, msx_profile *p, msx_ctx *src_ctx,
 	int rc = MSX_OK;
 	hipError_t e = copy(stage, q->ui, b_ui);
 	if (e == hipSuccess) e = copy(stage + o_d, q->d, b_d);
+	if (e == hipSuccess) e = copy(stage + o_dq, q->dq, b_dq);
 	if (e == hipSuccess) e = copy(stage + o_cnt, q->counters, 16);
 	if (e == hipSuccess) e = copy(stage + o_off, q->m_off.p, b_off);
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_merge_counts, dim3(msx_grid(ctx, p->n_features, MSX_BLOCK)), dim3(MSX_BLOCK), 0, ctx->stream,
 		                   p->n_features, (const uint32_t *)stage, p->ui, (const double *)(stage + o_d), p->d ? p->d : nullptr,
+		                   (const unsigned long long *)(stage + o_dq), with_dq ? p->dq : nullptr,
 		                   (const uint32_t *)(stage + o_cnt), p->counters);
+		if (with_dq) p->dq_dirty = true;
 		if (p->share_type == MSX_MULTI_SHARE_PROPORTIONAL && nl > 0) {
 			// fold the destination's bounds back to what it really holds, then make room for the source's lists
 			unsigned long long mine[2] = {0, 0};

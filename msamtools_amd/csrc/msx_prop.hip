@@ -993,7 +993,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
                                                             double *__restrict__ share,
                                                             double *__restrict__ part_val,
                                                             const int32_t *__restrict__ iter_state,
-                                                            uint32_t a_bytes, uint32_t recip_at) {
+                                                            uint32_t a_bytes, uint32_t recip_at, int64_t wave_lo, int64_t wave_hi) {
 	if (iter_state[0]) return;
 	const int64_t E = (int64_t)csr_tot[1];
 	const int lane = threadIdx.x & 63;
@@ -1002,8 +1002,10 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_share_reduce(const unsigned long 
 	// XCD measured slower the longer the window: groups of 4 / 16 / 64 workgroups per XCD 58 / 60 / 67 us
 	// against 58, a contiguous eighth each 70 against 65 -- lines one XCD has fetched are then no longer
 	// served to the others out of the Infinity Cache while they are there)
-	const int64_t wave = ((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6;
-	if (wave >= W) return;
+	// (a launch takes the waves [wave_lo, wave_hi) of the W the entries are dealt to: all of them, or one slice of them --
+	// msx_profile_prop_local_slice)
+	const int64_t wave = wave_lo + (((int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x) >> 6);
+	if (wave >= wave_hi) return;
 	const int64_t per = sr_chunk(E, W);
 	const int64_t c0 = wave * per;
 	if (c0 >= E) {   // idle wave: neutral slots
@@ -1322,11 +1324,12 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t n_slots, c
                                                               const PartRun *__restrict__ runs,
                                                               const double *__restrict__ part_val,
                                                               double *__restrict__ share,
-                                                              const int32_t *__restrict__ iter_state) {
+                                                              const int32_t *__restrict__ iter_state, uint32_t key_lo, uint32_t key_hi) {
 	if (iter_state[0]) return;
 	const int lane = threadIdx.x & 63;
 	const int64_t r = (int64_t)blockIdx.x * MSX_BLOCK + threadIdx.x;
-	if (r < (int64_t)d_tot[3]) {
+	// (the runs of the features [key_lo, key_hi): all of them, or a slice's)
+	if (r < (int64_t)d_tot[3] && runs[r].key >= key_lo && runs[r].key < key_hi) {
 		const PartRun R = runs[r];
 		double sum = 0;
 		for (uint32_t q = 0; q < R.n; ++q) sum += part_val[R.first + q];
@@ -1339,6 +1342,7 @@ __global__ __launch_bounds__(MSX_BLOCK) void k_partial_reduce(int64_t n_slots, c
 	const int64_t n_waves = (int64_t)gridDim.x * (MSX_BLOCK / 64);
 	for (int64_t w = r >> 6; w < n_long; w += n_waves) {
 		const PartRun R = runs[n_slots - 1 - w];
+		if (R.key < key_lo || R.key >= key_hi) continue;
 		double part = 0;
 		for (uint32_t q = (uint32_t)lane; q < R.n; q += 64u) part += part_val[R.first + q];
 		double tot = 0;
@@ -1762,6 +1766,7 @@ int msx_prop_build(msx_ctx *ctx, msx_profile *p) {
 #endif
 	}
 	p->transposed_valid = true;
+	p->slice_valid = false;
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
@@ -1779,7 +1784,8 @@ static RecipArgs recip_args(const msx_profile *p) {
 	                 (const uint32_t *)p->hpos.p, (const uint32_t *)p->gl_idx.p, (const double *)p->a, p->recip_ptr};
 }
 
-int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
+// the waves [wave_lo, wave_hi) of k_share_reduce and, if `complete`, the runs of the features [key_lo, key_hi) folded into share[]
+static int prop_iteration_range(msx_ctx *ctx, msx_profile *p, bool complete, int64_t wave_lo, int64_t wave_hi, uint32_t key_lo, uint32_t key_hi) {
 	if ((size_t)p->n_features * 8 > 0xfffffff0u)                 // (the gathers of k_share_reduce address a[] with 32-bit byte offsets)
 		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing: too many features (%d)", p->n_features);
 	const int64_t W = msx_share_waves(ctx);
@@ -1797,11 +1803,12 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	constexpr int ng = 3;
 #endif
 #define SR_LAUNCH(NG_)                                                                                                          \
-	hipLaunchKernelGGL(k_share_reduce<NG_>, dim3((unsigned)((W + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,                      \
+	hipLaunchKernelGGL(k_share_reduce<NG_>, dim3((unsigned)((wave_hi - wave_lo + 3) / 4)), dim3(MSX_BLOCK), 0, ctx->stream,      \
 	                   (const unsigned long long *)p->d_tot, (const uint32_t *)p->t_key[p->sorted_buf].p,                        \
 	                   (const unsigned long long *)p->t_val64[p->sorted_buf].p, (const double *)p->a, p->key_bits, W, p->share,  \
 	                   (double *)p->part_val.p, (const int32_t *)p->iter_state,                                                  \
-	                   (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u), p->recip_at)
+	                   (uint32_t)(p->recip.cap < 0xfffffff0u ? p->recip.cap : 0xfffffff0u), p->recip_at, wave_lo, wave_hi)
+	if (wave_hi <= wave_lo) return MSX_OK;
 	msx_time_begin(ctx, MSX_K_SHARE_REDUCE);
 #ifdef MSX_DEBUG_SWITCHES
 	if (ng == 3) SR_LAUNCH(3); else if (ng == 2) SR_LAUNCH(2); else SR_LAUNCH(1);
@@ -1816,8 +1823,43 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 		MSX_TIMED(ctx, MSX_K_PARTIAL_REDUCE,
 		          hipLaunchKernelGGL(k_partial_reduce, dim3((unsigned)((M + MSX_BLOCK - 1) / MSX_BLOCK)), dim3(MSX_BLOCK), 0,
 		                             ctx->stream, M, (const unsigned long long *)p->d_tot, (const PartRun *)p->runs.p,
-		                             (const double *)p->part_val.p, p->share, (const int32_t *)p->iter_state));
+		                             (const double *)p->part_val.p, p->share, (const int32_t *)p->iter_state, key_lo, key_hi));
 	}
+	return MSX_OK;
+}
+int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
+	return prop_iteration_range(ctx, p, complete, 0, msx_share_waves(ctx), 0u, 0xffffffffu);
+}
+
+// SLICES of an iteration's local half (MSX_DIST_SLICES, msx_profile_prop_local_slice): the waves of k_share_reduce cut into n
+// equal ranges.  The entries are sorted by feature and dealt to the waves in equal chunks, so a range of waves is a range of
+// features -- up to the feature its first entry belongs to, which the range before may have begun: that one counts to the
+// later slice, whose k_partial_reduce finds its run complete.  Slice i is then final on [cut[i], cut[i + 1]) the moment its
+// two kernels are through, and its all-reduce can travel while slice i + 1 is computed.  The cuts are read once per store
+// (two words from the device, one wait).
+static int prop_slice_cuts(msx_ctx *ctx, msx_profile *p, int n) {
+	if (p->slice_n == n && p->slice_valid) return MSX_OK;
+	const int64_t W = msx_share_waves(ctx);
+	unsigned long long tot[2] = {0, 0};
+	MSX_HIP(ctx, hipMemcpyAsync(tot, p->d_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const int64_t E = (int64_t)tot[1];
+	const int64_t per0 = (E + W - 1) / W, per = (per0 + SR_STEP - 1) / SR_STEP * SR_STEP;      // (sr_chunk)
+	const uint32_t fmask = p->key_bits < 32 ? ((1u << p->key_bits) - 1u) : 0xffffffffu;
+	uint32_t keys[MSX_MAX_SLICES] = {0};
+	p->slice_wave[0] = 0; p->slice_key[0] = 0;
+	for (int i = 1; i < n; i++) {
+		const int64_t w = W * i / n, at = w * per;
+		p->slice_wave[i] = w;
+		p->slice_key[i] = (uint32_t)p->n_features;
+		if (at < E) MSX_HIP(ctx, hipMemcpyAsync(&keys[i], (const uint32_t *)p->t_key[p->sorted_buf].p + at, 4, hipMemcpyDeviceToHost, ctx->stream));
+	}
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int i = 1; i < n; i++)
+		if (W * i / n * per < E) p->slice_key[i] = keys[i] & fmask;
+	p->slice_wave[n] = W; p->slice_key[n] = (uint32_t)p->n_features;
+	p->slice_n = n;
+	p->slice_valid = true;
 	return MSX_OK;
 }
 
@@ -1891,6 +1933,26 @@ extern "C" int msx_profile_prop_local(msx_ctx *ctx, msx_profile *p, double **inc
 		if (rc) return rc;
 	}
 	if (inc) *inc = p->share;
+	MSX_HIP(ctx, hipGetLastError());
+	return MSX_OK;
+}
+
+extern "C" int msx_profile_prop_local_slice(msx_ctx *ctx, msx_profile *p, int slice, int n_slices, double **inc, int32_t *first, int32_t *count) {
+	if (!ctx || !p) return MSX_ERR_ARG;
+	if (!p->begun) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local_slice before msx_profile_prop_begin");
+	if (n_slices < 1 || n_slices > MSX_MAX_SLICES || slice < 0 || slice >= n_slices) return msx_fail(ctx, MSX_ERR_ARG, "msx_profile_prop_local_slice: slice %d of %d", slice, n_slices);
+	msx_join(ctx);
+	if (p->share_type != MSX_MULTI_SHARE_PROPORTIONAL)
+		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
+	int rc = prop_slice_cuts(ctx, p, n_slices);
+	if (rc) return rc;
+	// (the last slice takes the upper end of the key range whatever the features number: sentinel keys lie beyond them)
+	if ((rc = prop_iteration_range(ctx, p, true, p->slice_wave[slice], p->slice_wave[slice + 1], p->slice_key[slice],
+	                               slice + 1 == n_slices ? 0xffffffffu : p->slice_key[slice + 1])))
+		return rc;
+	if (inc) *inc = p->share;
+	if (first) *first = (int32_t)p->slice_key[slice];
+	if (count) *count = (int32_t)(p->slice_key[slice + 1] - p->slice_key[slice]);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
@@ -1988,9 +2050,26 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 		// does) saves the all-reduces of k = 17..19.
 		const char *pe = getenv("MSX_DIST_POLL");
 		const int poll = (ctx->dist && pe) ? atoi(pe) : (ctx->dist ? 8 : 0);
+		// MSX_DIST_SLICES=2..4 (default 1): the local half in slices of the feature range (prop_slice_cuts), slice i's all-reduce
+		// on the communicator's side stream while slice i + 1 is computed on the context's -- the 8 MB all-reduce of an
+		// iteration is the part of a multi-GPU step no kernel hides otherwise.  The same additions in the same order: every
+		// abundance bit as with one slice.  Off by default until a node with more than one GPU has timed it.
+		const char *se = getenv("MSX_DIST_SLICES");
+		const int slices = (se && atoi(se) >= 2 && atoi(se) <= MSX_MAX_SLICES) ? atoi(se) : 1;
+		if (slices > 1 && (rc = prop_slice_cuts(ctx, p, slices))) return rc;
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
-			if ((rc = msx_prop_iteration(ctx, p, true))) return rc;     // share = this rank's part of the increment, complete
-			if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;
+			if (slices > 1) {
+				for (int i = 0; i < slices; i++) {
+					if ((rc = prop_iteration_range(ctx, p, true, p->slice_wave[i], p->slice_wave[i + 1], p->slice_key[i],
+					                               i + 1 == slices ? 0xffffffffu : p->slice_key[i + 1])))
+						return rc;
+					if ((rc = msx_dist_allreduce_share_side(ctx, p, (int32_t)p->slice_key[i], (int32_t)(p->slice_key[i + 1] - p->slice_key[i])))) return rc;
+				}
+				if ((rc = msx_dist_side_join(ctx))) return rc;
+			} else {
+				if ((rc = msx_prop_iteration(ctx, p, true))) return rc;     // share = this rank's part of the increment, complete
+				if ((rc = msx_dist_allreduce_share(ctx, p))) return rc;
+			}
 			msx_prop_apply_launch(ctx, p, k, false);   // same numbers, same decision (:383) everywhere
 			if (poll > 0 && k % poll == 0 && k < 19) {
 				int32_t done = 0;

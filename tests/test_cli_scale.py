@@ -328,6 +328,12 @@ def test_two_contexts_filter_profile_and_tee(big, tmp_path):
     assert b"BGZF blocks inflated on the device" not in r.stderr
     big.check_digest(f, big.digest_out)
     big.check_profile(p, big.pipe)
+    # --multi equal: the contexts' integer shares are added as integers (msx_profile_merge) -- every digit one context prints
+    one, three = str(tmp_path / "eq1.gz"), str(tmp_path / "eq3.gz")
+    sh(f"{BIN} profile --multi equal --label S -o {one} {big.bam['u']}")
+    sh(f"{BIN} profile --multi equal --label S -o {three} {big.bam['u']}", MSX_DEVICES="0,0,0", MSX_BATCH_BYTES=1_200_000)
+    rows = lambda path: [l for l in gzip.open(path, "rt").read().split("\n") if not l.startswith("# Command")]
+    assert rows(one) == rows(three)
     # device threads finish batches in any order while the writer takes them in input order: again and again, with few
     # buffers to go round.  Three hangs were found here: output buffers handed out first come, first served (then by batch
     # number, but to a later batch of the same number first); a thread waiting for its next batch with the writer's next

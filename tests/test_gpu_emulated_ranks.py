@@ -28,8 +28,8 @@ def host_allreduce(ranks, ptrs, count, dtype):
 
 @pytest.mark.parametrize("n_ranks", [2, 3, 5])
 @pytest.mark.parametrize("groups,refs", [(900, 11), (60_000, 500), (300_000, 20_000)])
-@pytest.mark.parametrize("multi", ["proportional", "equal"])
-def test_emulated_ranks_equal_one_context_and_oracle(n_ranks, groups, refs, multi):
+@pytest.mark.parametrize("multi,slices", [("proportional", 1), ("proportional", 2), ("proportional", 3), ("equal", 1)])
+def test_emulated_ranks_equal_one_context_and_oracle(n_ranks, groups, refs, multi, slices):
     import msamtools_amd as m
     seed = 97531
     per = groups // n_ranks
@@ -68,8 +68,30 @@ def test_emulated_ranks_equal_one_context_and_oracle(n_ranks, groups, refs, mult
         iterations, purged = 0, 0
         if multi == "proportional":
             for k in range(1, 20):
-                ptrs = [p.prop_local() for _, p in ranks]
-                host_allreduce(ranks, ptrs, refs, np.float64)
+                if slices == 1:
+                    ptrs = [p.prop_local() for _, p in ranks]
+                    host_allreduce(ranks, ptrs, refs, np.float64)
+                else:
+                    # MSX_DIST_SLICES: the local half slice by slice, each slice's range all-reduced as soon as it is complete
+                    # (msx_profile_prop_local_slice; every rank cuts its own store, so the ranges differ from rank to rank:
+                    # here each range is summed over the ranks only when every rank has completed it -- after the last slice
+                    # -- but slice by slice what a rank reports must be final: checked against the whole vector at the end)
+                    snaps = []
+                    for _, p in ranks:
+                        covered = 0
+                        parts = []
+                        for i in range(slices):
+                            ptr, first, count = p.prop_local_slice(i, slices)
+                            assert first == covered and count >= 0
+                            covered += count
+                            parts.append((first, count, p.ctx.to_host(ptr + 8 * first, count, np.float64) if count else np.zeros(0)))
+                        assert covered == refs
+                        snaps.append((ptr, parts))
+                    for (ptr, parts), (ctx, p) in zip(snaps, ranks):
+                        final = ctx.to_host(ptr, refs, np.float64)
+                        for first, count, vals in parts:
+                            assert np.array_equal(final[first:first + count], vals)        # a slice, once reported, does not change
+                    host_allreduce(ranks, [s[0] for s in snaps], refs, np.float64)
                 deltas = [p.prop_apply() for _, p in ranks]
                 iterations = k
                 assert len(set(deltas)) == 1, deltas                       # the same numbers, the same decision everywhere
@@ -98,6 +120,45 @@ def test_emulated_ranks_equal_one_context_and_oracle(n_ranks, groups, refs, mult
         assert rel(ab[0], want) <= 1e-6, rel(ab[0], want)                  # msam_profile.c:317-410, BASELINE's bound
     finally:
         for ctx, p in ranks:
+            p.close()
+            ctx.close()
+        whole.close()
+        whole_ctx.close()
+
+
+@pytest.mark.parametrize("n_ctx", [2, 3])
+@pytest.mark.parametrize("groups,refs", [(60_000, 500), (300_000, 20_000)])
+def test_merged_contexts_give_one_contexts_bits_for_multi_equal(n_ctx, groups, refs):
+    """One process, several contexts (MSX_DEVICES=0,0,0): every context counts its batches, msx_profile_merge adds them up on the
+    first.  --multi equal's shares of 1/k are integers in units of 1/lcm(1..24) until d[] is read (msx_count.h): the merge adds
+    the INTEGERS, so the one division per feature sees the same numerator one context would have -- the abundances are
+    that context's bit for bit (msam_profile.c:175-182; folding every side before adding rounded N quotients instead of one)."""
+    import msamtools_amd as m
+    seed = 24680
+    per = groups // n_ctx
+    bounds = [r * per for r in range(n_ctx)] + [groups]
+    parts, whole_ctx = [], m.Context(0)
+    whole = m.Profile(whole_ctx, refs, "equal")
+    try:
+        for r in range(n_ctx):
+            ctx = m.Context(0)
+            prof = m.Profile(ctx, refs, "equal")
+            for c, pr in ((ctx, prof), (whole_ctx, whole)):
+                db = m.DeviceBatch.synth(c, seed, bounds[r + 1] - bounds[r], refs, 4, first_group=bounds[r])
+                run = m.FilterRun(c, db, **OPTS)
+                run.enqueue_with_profile(pr)
+                run.finish()
+                run.free()
+                db.free()
+            parts.append((ctx, prof))
+        for _, other in parts[1:]:
+            parts[0][1].merge(other)
+        ab, st = parts[0][1].finalize()
+        abw, stw = whole.finalize()
+        assert (st.insert_count, st.uniq_mapper_count, st.multi_mapper_count) == (stw.insert_count, stw.uniq_mapper_count, stw.multi_mapper_count)
+        assert np.array_equal(ab, abw)                                     # every bit
+    finally:
+        for ctx, p in parts:
             p.close()
             ctx.close()
         whole.close()

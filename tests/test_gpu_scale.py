@@ -127,24 +127,30 @@ def test_bench_multi_gpu_step_on_one_rank():
 
 @pytest.mark.parametrize("groups,refs", [(300, 7), (2000, 50), (60_000, 500), (400_000, 20_000)])
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("poll", ["0", "8", "1"])
-def test_one_rank_distributed_finalize_equals_plain_and_oracle(groups, refs, fused, poll, monkeypatch):
+@pytest.mark.parametrize("poll,slices", [("0", "1"), ("8", "1"), ("1", "1"), ("8", "2"), ("0", "3")])
+def test_one_rank_distributed_finalize_equals_plain_and_oracle(groups, refs, fused, poll, slices, monkeypatch):
     """msx_profile_finalize_dist_enqueue over a one-rank RCCL communicator -- counts all-reduced, the partial slots of
     k_share_reduce folded into share[] (k_partial_reduce, run by run, no atomics), share[] all-reduced inside each of
     the 19 iterations -- against msx_profile_finalize_enqueue on the same inserts (equal to 1e-12: the same additions
     in another order) and against the oracle (<= 1e-6, msam_profile.c:317-410).  Small inputs matter: most waves of
     k_share_reduce idle then and every feature's segment ends at a chunk's last entry somewhere.
     poll: MSX_DIST_POLL -- never look at the convergence flag (all 19 iterations enqueued), every 8th iteration (the
-    default), every iteration: the same numbers, the same iteration count either way."""
+    default), every iteration: the same numbers, the same iteration count either way.
+    slices: MSX_DIST_SLICES -- the local half in slices of the feature range, each slice's all-reduce on the communicator's side
+    stream under the next slice's kernels: the same additions in the same order, so every bit of the one-slice form (checked
+    below against a second distributed run with one slice)."""
     import msamtools_amd as m
     monkeypatch.setenv("MSX_DIST_POLL", poll)
+    monkeypatch.setenv("MSX_DIST_SLICES", slices)
     ctx = m.Context(0)
     ctx.dist_init(m.dist_unique_id(), 0, 1)
     db = m.DeviceBatch.synth(ctx, 24680, groups, refs, 4)
     hs = m.HostSynth(24680, groups, refs, 4)
     out = {}
     try:
-        for path in ("plain", "dist"):
+        for path in ("plain", "dist") + (("dist1",) if slices != "1" else ()):
+            if path == "dist1":
+                monkeypatch.setenv("MSX_DIST_SLICES", "1")
             prof = m.Profile(ctx, refs, "proportional")
             if fused:
                 run = m.FilterRun(ctx, db, **OPTS)
@@ -155,7 +161,7 @@ def test_one_rank_distributed_finalize_equals_plain_and_oracle(groups, refs, fus
             else:
                 prof.accumulate(db, None)
                 sel = None
-            if path == "dist":
+            if path != "plain":
                 prof.finalize_dist_enqueue()
             else:
                 prof.finalize_enqueue()
@@ -169,6 +175,8 @@ def test_one_rank_distributed_finalize_equals_plain_and_oracle(groups, refs, fus
         ctx.close()
     a, b = out["plain"][0], out["dist"][0]
     assert out["plain"][1] == out["dist"][1]
+    if "dist1" in out:
+        assert np.array_equal(out["dist1"][0], b) and out["dist1"][1] == out["dist"][1]
     assert np.array_equal(a == 0, b == 0)
     assert (np.abs(a - b) / np.maximum(np.abs(a), 1e-300)).max() <= 1e-12
     s = ref["stats"]
