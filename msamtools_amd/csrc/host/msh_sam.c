@@ -47,6 +47,16 @@ static void aux_put_int(kstr *rec, int64_t v) {   /* smallest fitting type, as h
 	}
 }
 
+static uint8_t nt16[256];
+static pthread_once_t nt16_once = PTHREAD_ONCE_INIT;
+static void nt16_fill(void) {
+	int c;
+	for (c = 0; c < 256; c++) {
+		const char *a = strchr(SEQ_NT16, toupper(c));
+		nt16[c] = (uint8_t)((a && c) ? a - SEQ_NT16 : 15);
+	}
+}
+
 void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 	char *f[12], *p = line, *aux = NULL;
 	int nf = 0, i;
@@ -115,20 +125,11 @@ void msh_sam_parse(const msh_hdr *h, char *line, kstr *rec) {
 	}
 	{   /* SEQ, 4-bit packed, and QUAL: a table look-up per base and one pass per string (a strchr per base and a ks_putc per
 	     * byte were most of the parser's time: 322 MB/s of text per core; the reference's documented workflow feeds SAM text) */
-		static uint8_t nt16[256];
-		static int nt16_ready;
 		const size_t nseq = ((size_t)l_seq + 1) / 2;
 		uint8_t *o;
 		const uint8_t *q = (const uint8_t *)f[9];
 		uint32_t k;
-		if (!__atomic_load_n(&nt16_ready, __ATOMIC_ACQUIRE)) {       /* (every thread would write the same bytes) */
-			int c;
-			for (c = 0; c < 256; c++) {
-				const char *a = strchr(SEQ_NT16, toupper(c));
-				nt16[c] = (uint8_t)((a && c) ? a - SEQ_NT16 : 15);
-			}
-			__atomic_store_n(&nt16_ready, 1, __ATOMIC_RELEASE);
-		}
+		pthread_once(&nt16_once, nt16_fill);       /* (the parser runs on every thread of the pool) */
 		ks_reserve(rec, nseq + l_seq + 8);
 		o = (uint8_t *)rec->s + rec->l;
 		for (k = 0; k + 1 < l_seq; k += 2) *o++ = (uint8_t)(nt16[q[k]] << 4 | nt16[q[k + 1]]);
