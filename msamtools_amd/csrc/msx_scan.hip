@@ -3,6 +3,11 @@
 // (u32), the radix passes, and for compacting multi-mapper lists, where one u64
 // scan carries (list count << 32 | entry count) and reads the 4-byte per-pool
 // words directly.  HBM-bound: reads the input twice, writes once.
+// (Round 6 tried ONE pass of chained tiles -- a ticket per tile, sums and prefixes published under device-scope release /
+// acquire, 64 predecessors per look back: correct (tests/test_gpu_scan.py) and slow here: 260 us per scan of the c3 step's
+// 10^8 items against ~45, the step 6.9 ms against 3.95 -- a tile's walk back over the thousands of tiles in flight costs a
+// memory round trip per look across the eight XCDs' L2s -- and the command line, whose batches it was meant for, did not
+// gain: profiles/round6/scan_chain.md.)
 #include "msx_internal.h"
 
 #define SCAN_ITEMS 8
@@ -253,6 +258,19 @@ int msx_scan_pinfo(msx_ctx *ctx, const uint32_t *pinfo, uint64_t *out, int64_t m
 	return MSX_OK;
 }
 
+
+#ifdef MSX_DEBUG_SWITCHES
+// (libmsamtools_amd_dbg only; tests/test_gpu_scan.py) the scan by itself on device arrays: exclusive (out[n] = total: n + 1 words)
+// or inclusive in place; n_dev: a device-side length (null: n), as msx_scan_u32_len takes it
+extern "C" int msx_debug_scan_u32(msx_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, int inclusive, const unsigned long long *n_dev) {
+	if (!ctx || n < 0) return MSX_ERR_ARG;
+	msx_join(ctx);
+	int rc = inclusive ? msx_scan_inclusive_u32(ctx, d_out, n) : n_dev ? msx_scan_u32_len(ctx, d_in, d_out, n, n_dev, 1, 1) : msx_scan_u32(ctx, d_in, d_out, n);
+	if (rc) return rc;
+	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MSX_OK;
+}
+#endif
 
 // msx_runtime_warmup: this translation unit's code object loaded onto the device ahead of its first launch (the runtime loads a
 // module when one of its kernels is first asked for: 2-10 ms each, otherwise paid by the first batches of a command)
