@@ -454,16 +454,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 				const bool v4 = need && c4 != 0u && p - a4 <= (uint32_t)WINDOW;
 				const bool v8 = need && c8 != 0u && p - a8 <= (uint32_t)WINDOW && !(v4 && c8 == c4);
 				// The candidates in a fixed order -- near, 4-byte table, 8-byte table; a later one must be strictly longer.
-				// One loop for all of them: every trip compares 16 bytes of each lane's current candidate, a lane that has
-				// finished one moves on to its next (the wave then waits for the lane with the most bytes to compare in all,
-				// not for the longest match of each kind in turn).  A later candidate is first looked at where it would have
-				// to match to be longer -- the 16 bytes that end behind the best length so far -- and dropped there mostly.
+				// FIRST their first 16 bytes, all three side by side against the same 16 bytes at the position: on BAM records most
+				// matches end there, and most steps with them (one look instead of one trip per candidate and lane).  THEN one loop
+				// for those that go on: every trip compares 16 more bytes of each lane's current candidate, a lane that has finished
+				// one moves on to its next (the wave waits for the lane with the most bytes to compare in all, not for the longest
+				// match of each kind in turn).  A later candidate is first looked at where it would have to match to be longer --
+				// the 16 bytes that end behind the best length so far -- and dropped there mostly.
 				const uint32_t NONE = 0xffffffffu;
-				uint32_t q0 = nd ? p - nd : NONE, q1 = v4 ? a4 : NONE, q2 = v8 ? a8 : NONE;
-				if (q0 == NONE) { q0 = q1; q1 = q2; q2 = NONE; }
-				if (q0 == NONE) { q0 = q1; q1 = q2; q2 = NONE; }
-				if (q1 == NONE) { q1 = q2; q2 = NONE; }
-				uint32_t cur = q0, l = 0;
+				const uint32_t c0 = nd ? p - nd : NONE, c1 = v4 ? a4 : NONE, c2 = v8 ? a8 : NONE;
+				uint32_t q0 = NONE, q1 = NONE, q2 = NONE;         // the candidates that match their first 16 bytes, in order
+				{
+					uint32_t b0, b1, b2, b3;
+					df_ring128<DF_RMASK>(S.lz.ring, p, b0, b1, b2, b3);
+					const uint32_t cap16 = maxl < 16u ? maxl : 16u;
+#define DF_FIRST16(C) do { \
+					uint32_t a0, a1, a2, a3; \
+					df_ring128<DF_RMASK>(S.lz.ring, (C) != NONE ? (C) : p, a0, a1, a2, a3); \
+					const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3; \
+					/* the first differing byte: one count of trailing zeros on the first word that differs (| 1u << 31 keeps it defined) */ \
+					const uint32_t xs = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3, at = x0 ? 0u : x1 ? 4u : x2 ? 8u : 12u; \
+					uint32_t l16 = (x0 | x1 | x2 | x3) ? at + ((uint32_t)__builtin_ctz(xs | 0x80000000u) >> 3) : 16u; \
+					l16 = l16 > cap16 ? cap16 : l16; \
+					const bool here = (C) != NONE; \
+					const bool goes_on = here && l16 == 16u && maxl > 16u; \
+					const bool take = here && !goes_on && l16 >= 4u && l16 > bl; \
+					bd = take ? p - (C) : bd; \
+					bl = take ? l16 : bl; \
+					const uint32_t s_ = goes_on ? (C) : NONE; \
+					q2 = (q0 != NONE && q1 != NONE) ? s_ : q2; \
+					q1 = (q0 != NONE && q1 == NONE) ? s_ : q1; \
+					q0 = q0 == NONE ? s_ : q0; \
+				} while (0)
+					DF_FIRST16(c0);
+					DF_FIRST16(c1);
+					DF_FIRST16(c2);
+#undef DF_FIRST16
+				}
+				uint32_t cur = q0, l = 16u;
 				bool quick = false, act = need && cur != NONE;
 				while (__ballot(act)) {
 					if (act) {                                   // (one masked region; inside it selects, no branches)
@@ -473,23 +500,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 						df_ring128<DF_RMASK>(S.lz.ring, p + off, b0, b1, b2, b3);
 						const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
 						const bool diff = (x0 | x1 | x2 | x3) != 0u;
-						// where the first differing byte sits (diff) -- __builtin_ctz of 0 is not asked for: | 1u << 31 keeps it defined
-						const uint32_t f0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, f1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3),
-						               f2 = 8u + ((uint32_t)__builtin_ctz(x2 | 0x80000000u) >> 3), f3 = 12u + ((uint32_t)__builtin_ctz(x3 | 0x80000000u) >> 3);
-						const uint32_t fd = x0 ? f0 : x1 ? f1 : x2 ? f2 : f3;
+						const uint32_t xs = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3, at = x0 ? 0u : x1 ? 4u : x2 ? 8u : 12u;
+						const uint32_t fd = at + ((uint32_t)__builtin_ctz(xs | 0x80000000u) >> 3);
 						const uint32_t l16 = l + 16u;
 						const bool end = !diff && l16 >= maxl;            // (measuring) ran into the longest a match may be
-						const bool fin = quick ? diff : (diff || end);    // quick: a difference drops the candidate; none: measure it from 0
+						const bool fin = quick ? diff : (diff || end);    // quick: a difference drops the candidate; none: measure it from byte 16
 						uint32_t len = quick ? 0u : (diff ? l + fd : maxl);
 						len = len > maxl ? maxl : len;
 						const bool take = fin && len >= 4u && len > bl;
 						bd = take ? p - cur : bd;
 						bl = take ? len : bl;
-						l = (quick || fin) ? 0u : l16;
+						l = (quick || fin) ? 16u : l16;
 						cur = fin ? q1 : cur;
 						q1 = fin ? q2 : q1;
 						q2 = fin ? NONE : q2;
-						quick = fin && bl >= 16u;
+						quick = fin && bl >= 32u;
 						act = fin ? (cur != NONE && bl < maxl) : true;
 					}
 				}
