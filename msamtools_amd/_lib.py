@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (MSX_LIB_PATH: another build of the same library -- scripts/build_asan_lib.sh puts one with its host code under
+# (MSX_LIB_PATH: another build of the same library -- scripts/archive/build_asan_lib.sh (a one-off of round 5, not part of the routine gate) puts one with its host code under
 #  AddressSanitizer into build/asanlib; there is no other implementation to point it at)
 LIB_PATH = os.environ.get("MSX_LIB_PATH") or os.path.join(_HERE, "libmsamtools_amd.so")
 

@@ -19,7 +19,7 @@
 // msx_debug_guard_check is called -- a kernel that writes past the end (or before the start) of what it was given aborts the
 // process with the allocation's size and the first damaged byte instead of spoiling a neighbour.  With the guard on,
 // msx_reserve hands out exactly what was asked for (no slack), so "past the end" means past the request.  Reads are not seen
-// (MSX_POISON covers unwritten words).  Every translation unit allocates through these two names (msx_ctx.hip has the bodies).
+// (MSX_POISON covers unwritten words).  Every translation unit allocates through these two names (msx_guard.hip has the bodies).
 hipError_t msx_guard_malloc(void **p, size_t n);
 hipError_t msx_guard_free(void *p);
 bool msx_guard_on();

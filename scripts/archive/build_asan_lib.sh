@@ -3,7 +3,7 @@
 # not available on this pool) -> build/asanlib/libmsamtools_amd.so.  Used through MSX_LIB_PATH (python) / LD_LIBRARY_PATH (the
 # command line) with gcc's libasan preloaded (python) or linked (msamtools-asan): scripts/archive/r5_asan_lib.sh.
 set -e
-cd "$(dirname "$0")/../msamtools_amd/csrc"
+cd "$(dirname "$0")/../../msamtools_amd/csrc"
 OUT=../../build/asanlib
 mkdir -p $OUT
 FLAGS="-O1 -g --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the library's host code under AddressSanitizer on the GPU box (scripts/build_asan_lib.sh), through the python tests and the
+# the library's host code under AddressSanitizer on the GPU box (scripts/archive/build_asan_lib.sh), through the python tests and the
 # command line; gcc's libasan is preloaded for python; the command line is msamtools-asan (make asan), which links it
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r5asanlib; rm -rf $OUT; mkdir -p $OUT

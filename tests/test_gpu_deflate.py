@@ -251,3 +251,23 @@ def test_encoder_beside_the_next_batch(ctx):
     for d in dptrs:
         ctx.free(d)
     up.close()
+    # the context remembered the closed unpacker's encoder stream as the last user of the encoder's scratch; a
+    # later call that has to GROW that scratch drained the remembered stream -- a destroyed handle (a spurious MSX_ERR_HIP).
+    # msx_unpack_destroy forgets it now: a larger input on the same context, then a new unpacker's encoder, both go through
+    big = bytes(rng.integers(0, 4, 6_000_000, dtype=np.uint8))
+    one, n_blk = m.bgzf_deflate(ctx, big, 6)
+    assert gzip.decompress(one) == big and n_blk == (len(big) + PAYLOAD - 1) // PAYLOAD
+    up2 = m.Unpack(ctx)
+    up2.seed()
+    recs = records(90000, b"z")
+    stream = b"".join(recs)
+    up2.enqueue(stream, pool_mode=0, n_targets=5, last=True)
+    res, view = up2.finish()
+    emit = np.arange(int(res.n_records), dtype=np.int32)
+    d = ctx.alloc(4 * emit.size)
+    ctx.to_dev(d, emit)
+    up2.emit_bgzf_enqueue(d, emit.size, 6)
+    blocks, _ = up2.emit_bgzf_complete()
+    assert gzip.decompress(blocks) == stream
+    ctx.free(d)
+    up2.close()
