@@ -572,13 +572,20 @@ void pipe_enable_raw(pipe_t *P, int with_obuf) {
 	 * buffers are not ready (pin_thread, phase 3: a 100 M-record file paid 20-30 ms for buffers of that size allocated at
 	 * start-up).  -bu stays at 2048 (its output buffers would have to grow with the batches); profile and coverage too:
 	 * they lost a little with larger ones (profiles/round6/batch_geometry.log). */
+	/* MSX_COMP_RAMP_FROM=<batch>: the batch from which on twice MSX_COMP_BLOCKS are taken (0: never), whatever the other
+	 * settings say (tests: a ramp within a small file; the larger buffers are then made at once, twice MSX_COMP_BYTES) */
 	P->comp_ramp = 0;
-	if (!getenv("MSX_COMP_BLOCKS") && !getenv("MSX_BATCH_BYTES") && !getenv("MSX_COMP_BYTES") && with_obuf == 2 && P->n_consumers == 1) P->comp_ramp = 8;
+	if (with_obuf == 2 && P->n_consumers == 1) {
+		const char *re = getenv("MSX_COMP_RAMP_FROM");
+		if (re) P->comp_ramp = atoi(re) > 0 ? atoi(re) : 0;
+		else if (!getenv("MSX_COMP_BLOCKS") && !getenv("MSX_BATCH_BYTES") && !getenv("MSX_COMP_BYTES")) P->comp_ramp = 8;
+	}
 	P->comp_blocks = (int)env_size("MSX_COMP_BLOCKS", getenv("MSX_BATCH_BYTES") ? P->batch_bytes_cfg / 65280 : 2048);
-	P->big_rcap = (size_t)64 << 20;
+	P->big_rcap = getenv("MSX_COMP_BYTES") ? 2 * env_size("MSX_COMP_BYTES", (size_t)40 << 20) : (size_t)64 << 20;
+	if (P->big_rcap < ((size_t)4 << 20)) P->big_rcap = (size_t)4 << 20;
 	/* when the larger buffers are made: at once for a file of 3 GB and more; otherwise when 32 batches have shown that the
 	 * input is long (a 100 M-record file -- 13 batches -- lost up to 0.1 s to half a gigabyte page-locked beside its last batches) */
-	P->big_from = msh_in_bytes(P->in) >= ((int64_t)3 << 30) ? 4 : 32;
+	P->big_from = (getenv("MSX_COMP_RAMP_FROM") || msh_in_bytes(P->in) >= ((int64_t)3 << 30)) ? (P->comp_ramp < 4 ? 1 : 4) : 32;
 	if (P->comp_blocks < 1) P->comp_blocks = 1;
 	if (P->comp_blocks > (1 << 16)) P->comp_blocks = 1 << 16;
 	/* compressed batches need nothing of a slot but its buffer of payloads: two more of them (batch 0, walked on the host,

@@ -181,6 +181,25 @@ def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
     big.check_profile(p, big.plain)
 
 
+def test_batches_that_grow_once_the_command_is_under_way(big, tmp_path):
+    """filter -b over a long input takes batches of twice the blocks from its eighth batch on, in larger buffers the pin thread
+    makes while the command runs and the decode stage swaps in when it next holds the slot (msh_pipeline.c: comp_ramp, phase 3
+    of pin_thread).  Here the same at a small scale (MSX_COMP_RAMP_FROM): 16-block batches, 32 from the third on -- fewer
+    batches, the same records, the same profile."""
+    out, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
+    base = dict(MSX_COMP_BLOCKS=16, MSX_COMP_BYTES=2 << 20, MSX_TIMING=1)
+    r0 = sh(f"{BIN} {' '.join(FILT)} -b --profile-out {p} --label S {big.bam['b']} > {out}", MSX_COMP_RAMP_FROM=0, **base)
+    big.check_digest(out, big.digest_out)
+    r1 = sh(f"{BIN} {' '.join(FILT)} -b --profile-out {p} --label S {big.bam['b']} > {out}", MSX_COMP_RAMP_FROM=3, **base)
+    big.check_digest(out, big.digest_out)
+    big.check_profile(p, big.pipe)
+    assert n_batches(r0.stderr) >= 20 and n_batches(r1.stderr) < n_batches(r0.stderr) * 0.8, (n_batches(r0.stderr), n_batches(r1.stderr))
+    # -bu never ramps (its output buffers would have to grow with the batches)
+    r2 = sh(f"{BIN} {' '.join(FILT)} -bu {big.bam['b']} > {out}", MSX_COMP_RAMP_FROM=3, **base)
+    big.check_digest(out, big.digest_out)
+    assert n_batches(r2.stderr) == n_batches(sh(f"{BIN} {' '.join(FILT)} -bu {big.bam['b']} > {out}", MSX_COMP_RAMP_FROM=0, **base).stderr)
+
+
 def test_coverage_through_the_pipeline(mid, tmp_path):
     """`coverage` on a many-batch BAM: the pipeline of filter and profile (batches as compressed blocks, inflated and
     walked on the device) against the oracle's pile-up (msam_coverage.c:33-87), and against the serial reader."""
