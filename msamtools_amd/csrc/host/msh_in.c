@@ -710,6 +710,7 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 	}
 	J.lo[nth] = end;
 	if (end == tlen) text[end] = 0;           /* (room for the terminator of an unterminated last line) */
+	if (last && tlen > 0 && text[tlen - 1] != '\n') gz_text_check(in);      /* (cut by a decompressor that gave up? its verdict comes first) */
 	msh_parallel(nth, sam_worker, &J);
 	for (t = 0; t < nth; t++) { off[t] = total; total += J.out[t].l; }
 	if (*len + total + 64 > *cap) {
@@ -1143,6 +1144,8 @@ int msh_read(msh_in *in, kstr *rec) {
 			} else {
 				n = getline(&in->line, &in->line_cap, in->fp);
 				if (n <= 0) { gz_text_check(in); return -1; }
+				/* (a last line without its newline: the text's end -- or where a decompressor gave up, whose verdict comes first) */
+				if (in->line[n - 1] != '\n') gz_text_check(in);
 				ln = in->line;
 			}
 			while (n > 0 && (ln[n - 1] == '\n' || ln[n - 1] == '\r')) ln[--n] = 0;

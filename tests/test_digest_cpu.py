@@ -105,7 +105,10 @@ def test_compressed_sam_text_is_read_like_sam_text(tmp_path):
     text = open(sam, "rb").read()
     want = digest("--full", sam)
     forms = {"one_member.sam.gz": gz.compress(text, 6), "bgzip.sam.gz": bgzf_blocks(text),
-             "three_members.sam.gz": gz.compress(text[:1000], 1) + gz.compress(text[1000:70001], 9) + gz.compress(text[70001:], 6)}
+             "three_members.sam.gz": gz.compress(text[:1000], 1) + gz.compress(text[1000:70001], 9) + gz.compress(text[70001:], 6),
+             # BGZF members (inflated side by side on the reader's pool), then a gzip member of another kind (one zlib stream
+             # takes over where the first such member begins), then BGZF members again (which that stream reads like any other)
+             "mixed.sam.gz": bgzf_blocks(text[:200000])[:-28] + gz.compress(text[200000:300000], 6) + bgzf_blocks(text[300000:])}
     for name, data in forms.items():
         path = str(tmp_path / name)
         open(path, "wb").write(data)
@@ -126,6 +129,15 @@ def test_compressed_sam_text_is_read_like_sam_text(tmp_path):
     open(cut, "wb").write(bytes(bad))
     r = subprocess.run([DEV, "digest", cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0
+    # the same for bgzip'd text: cut inside a block, a damaged block (the block-parallel path reports through the same door)
+    open(cut, "wb").write(forms["bgzip.sam.gz"][:-3000])
+    r = subprocess.run([DEV, "digest", cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"gzip stream" in r.stderr
+    bad = bytearray(forms["bgzip.sam.gz"])
+    bad[len(bad) // 2] ^= 0x55
+    open(cut, "wb").write(bytes(bad))
+    r = subprocess.run([DEV, "digest", cut], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"gzip stream" in r.stderr
 
 
 def test_cram_is_named_not_misparsed(tmp_path):
