@@ -452,7 +452,7 @@ int  msx_profile_prop_apply(msx_ctx *ctx, msx_profile *p, double *delta);
 /* The local half in SLICES of the feature range (what MSX_DIST_SLICES has msx_profile_finalize_dist_enqueue do with RCCL): call
  * with slice = 0 .. n_slices - 1 (n_slices <= 4) in order; after call i, share[*first, *first + *count) -- *inc is the vector --
  * is this rank's complete part for those features and may be all-reduced while the next slice is computed.  The slices
- * cover [0, n_features) without overlap; a slice may be empty. */
+ * are the n_slices equal parts of [0, n_features): the same ranges on every rank, whatever its shard holds. */
 int  msx_profile_prop_local_slice(msx_ctx *ctx, msx_profile *p, int slice, int n_slices, double **inc, int32_t *first, int32_t *count);
 int  msx_profile_prop_purged(msx_ctx *ctx, msx_profile *p, uint32_t *purged_local);
 

@@ -267,7 +267,7 @@ struct msx_profile {
 	int slice_n = 0;
 	bool slice_valid = false;
 	int64_t slice_wave[MSX_MAX_SLICES + 1] = {0};
-	uint32_t slice_key[MSX_MAX_SLICES + 1] = {0};
+	uint32_t slice_key[MSX_MAX_SLICES + 1] = {0}, slice_feat[MSX_MAX_SLICES + 1] = {0};
 	int iter_k = 0;
 	bool recip_valid = false;   // recip[] of the general lists belongs to the current a[]
 	bool begun = false;

@@ -18,6 +18,7 @@
 // rounding (<= a few ulp, inside the 1e-6 relative bound of BASELINE.json).
 // Across ranks `share` is the vector to all-reduce (C1 in SURVEY.md section 2).
 #include "msx_internal.h"
+#include <vector>
 #include "msx_count.h"
 
 #include <cstdlib>
@@ -1831,12 +1832,13 @@ int msx_prop_iteration(msx_ctx *ctx, msx_profile *p, bool complete) {
 	return prop_iteration_range(ctx, p, complete, 0, msx_share_waves(ctx), 0u, 0xffffffffu);
 }
 
-// SLICES of an iteration's local half (MSX_DIST_SLICES, msx_profile_prop_local_slice): the waves of k_share_reduce cut into n
-// equal ranges.  The entries are sorted by feature and dealt to the waves in equal chunks, so a range of waves is a range of
-// features -- up to the feature its first entry belongs to, which the range before may have begun: that one counts to the
-// later slice, whose k_partial_reduce finds its run complete.  Slice i is then final on [cut[i], cut[i + 1]) the moment its
-// two kernels are through, and its all-reduce can travel while slice i + 1 is computed.  The cuts are read once per store
-// (two words from the device, one wait).
+// SLICES of an iteration's local half (MSX_DIST_SLICES, msx_profile_prop_local_slice).  The feature range is cut into n equal
+// parts [feat[i], feat[i + 1]) -- the SAME cuts on every rank, whatever its shard holds: they are what the ranks all-reduce.
+// The entries are sorted by feature and dealt to the waves of k_share_reduce in equal chunks, so the entries of the features
+// below feat[i + 1] end in front of the first wave whose first entry is at or beyond it: wave[i + 1].  Slice i launches the waves
+// [wave[i], wave[i + 1]) and folds the runs of the features [key[i], key[i + 1]) -- key[i] = the feature of wave[i]'s first entry,
+// >= feat[i] -- and with that every feature below feat[i + 1] is final: its all-reduce can travel while slice i + 1 is computed.
+// The cuts are found once per store (the waves' first keys in one strided copy, one wait).
 static int prop_slice_cuts(msx_ctx *ctx, msx_profile *p, int n) {
 	if (p->slice_n == n && p->slice_valid) return MSX_OK;
 	const int64_t W = msx_share_waves(ctx);
@@ -1846,18 +1848,29 @@ static int prop_slice_cuts(msx_ctx *ctx, msx_profile *p, int n) {
 	const int64_t E = (int64_t)tot[1];
 	const int64_t per0 = (E + W - 1) / W, per = (per0 + SR_STEP - 1) / SR_STEP * SR_STEP;      // (sr_chunk)
 	const uint32_t fmask = p->key_bits < 32 ? ((1u << p->key_bits) - 1u) : 0xffffffffu;
-	uint32_t keys[MSX_MAX_SLICES] = {0};
-	p->slice_wave[0] = 0; p->slice_key[0] = 0;
-	for (int i = 1; i < n; i++) {
-		const int64_t w = W * i / n, at = w * per;
-		p->slice_wave[i] = w;
-		p->slice_key[i] = (uint32_t)p->n_features;
-		if (at < E) MSX_HIP(ctx, hipMemcpyAsync(&keys[i], (const uint32_t *)p->t_key[p->sorted_buf].p + at, 4, hipMemcpyDeviceToHost, ctx->stream));
+	const int64_t live = per > 0 ? (E + per - 1) / per : 0;       // waves that hold entries
+	std::vector<uint32_t> first((size_t)(live > 0 ? live : 1), 0u);
+	if (live > 0) {
+		MSX_HIP(ctx, hipMemcpy2DAsync(first.data(), 4, (const uint32_t *)p->t_key[p->sorted_buf].p, (size_t)per * 4, 4, (size_t)live,
+		                              hipMemcpyDeviceToHost, ctx->stream));
+		MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	MSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	for (int i = 1; i < n; i++)
-		if (W * i / n * per < E) p->slice_key[i] = keys[i] & fmask;
-	p->slice_wave[n] = W; p->slice_key[n] = (uint32_t)p->n_features;
+	const uint32_t nf = (uint32_t)p->n_features;
+	p->slice_wave[0] = 0; p->slice_key[0] = 0; p->slice_feat[0] = 0;
+	for (int i = 1; i < n; i++) {
+		const uint32_t F = (uint32_t)((uint64_t)nf * (uint64_t)i / (uint64_t)n);
+		int64_t lo = 0, hi = live;                                  // the first wave whose first entry's feature is >= F
+		while (lo < hi) {
+			const int64_t mid = (lo + hi) >> 1;
+			if ((first[(size_t)mid] & fmask) >= F) hi = mid; else lo = mid + 1;
+		}
+		p->slice_feat[i] = F;
+		p->slice_wave[i] = lo < live ? lo : W;                      // (beyond the live waves: the idle ones go with the last slice that has any)
+		p->slice_key[i] = lo < live ? (first[(size_t)lo] & fmask) : 0xffffffffu;
+	}
+	p->slice_wave[n] = W; p->slice_key[n] = 0xffffffffu; p->slice_feat[n] = nf;
+	// (idle waves write their neutral slots: they must be launched by exactly one slice -- the last)
+	for (int i = 1; i < n; i++) if (p->slice_wave[i] > p->slice_wave[i + 1]) p->slice_wave[i] = p->slice_wave[i + 1];
 	p->slice_n = n;
 	p->slice_valid = true;
 	return MSX_OK;
@@ -1946,13 +1959,11 @@ extern "C" int msx_profile_prop_local_slice(msx_ctx *ctx, msx_profile *p, int sl
 		return msx_fail(ctx, MSX_ERR_ARG, "proportional sharing was not selected for this profile");
 	int rc = prop_slice_cuts(ctx, p, n_slices);
 	if (rc) return rc;
-	// (the last slice takes the upper end of the key range whatever the features number: sentinel keys lie beyond them)
-	if ((rc = prop_iteration_range(ctx, p, true, p->slice_wave[slice], p->slice_wave[slice + 1], p->slice_key[slice],
-	                               slice + 1 == n_slices ? 0xffffffffu : p->slice_key[slice + 1])))
+	if ((rc = prop_iteration_range(ctx, p, true, p->slice_wave[slice], p->slice_wave[slice + 1], p->slice_key[slice], p->slice_key[slice + 1])))
 		return rc;
 	if (inc) *inc = p->share;
-	if (first) *first = (int32_t)p->slice_key[slice];
-	if (count) *count = (int32_t)(p->slice_key[slice + 1] - p->slice_key[slice]);
+	if (first) *first = (int32_t)p->slice_feat[slice];
+	if (count) *count = (int32_t)(p->slice_feat[slice + 1] - p->slice_feat[slice]);
 	MSX_HIP(ctx, hipGetLastError());
 	return MSX_OK;
 }
@@ -2060,10 +2071,9 @@ extern "C" int msx_profile_finalize_dist_enqueue(msx_ctx *ctx, msx_profile *p) {
 		for (int k = 1; k < 20; k++) {            // msam_profile.c:331
 			if (slices > 1) {
 				for (int i = 0; i < slices; i++) {
-					if ((rc = prop_iteration_range(ctx, p, true, p->slice_wave[i], p->slice_wave[i + 1], p->slice_key[i],
-					                               i + 1 == slices ? 0xffffffffu : p->slice_key[i + 1])))
+					if ((rc = prop_iteration_range(ctx, p, true, p->slice_wave[i], p->slice_wave[i + 1], p->slice_key[i], p->slice_key[i + 1])))
 						return rc;
-					if ((rc = msx_dist_allreduce_share_side(ctx, p, (int32_t)p->slice_key[i], (int32_t)(p->slice_key[i + 1] - p->slice_key[i])))) return rc;
+					if ((rc = msx_dist_allreduce_share_side(ctx, p, (int32_t)p->slice_feat[i], (int32_t)(p->slice_feat[i + 1] - p->slice_feat[i])))) return rc;
 				}
 				if ((rc = msx_dist_side_join(ctx))) return rc;
 			} else {

@@ -45,7 +45,7 @@ def shard_counts(hs, emit, n_refs):
     return ui, lists, len(bounds) - 1, uniq, multi
 
 
-def worker(rank, world, port, out):
+def worker(rank, world, port, out, slices):
     import torch
     import torch.distributed as dist
     import msamtools_amd as m
@@ -69,7 +69,16 @@ def worker(rank, world, port, out):
         S = np.bincount(owner, weights=a[flat], minlength=len(lists))
         recip = np.where(S > 0, 1.0 / np.where(S > 0, S, 1.0), 0.0)
         share = torch.from_numpy(np.bincount(flat, weights=recip[owner], minlength=REFS))
-        dist.all_reduce(share)                                       # the per-iteration collective
+        if slices == 1:
+            dist.all_reduce(share)                                   # the per-iteration collective
+        else:
+            # MSX_DIST_SLICES: the same vector in equal parts of the feature range -- the SAME cuts on every rank (the library
+            # computes slice i's part while slice i - 1's all-reduce travels: msx_prop.hip prop_slice_cuts)
+            for i in range(slices):
+                lo, hi = REFS * i // slices, REFS * (i + 1) // slices
+                part = share[lo:hi].clone()
+                dist.all_reduce(part)
+                share[lo:hi] = part
         new = U + a * share.numpy()
         new[new < 1e-20] = 0
         delta = float(((new - a) ** 2).sum() / REFS)
@@ -86,13 +95,14 @@ def worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_profile_equals_single_process(tmp_path):
+@pytest.mark.parametrize("slices", [1, 2, 3])
+def test_two_rank_sharded_profile_equals_single_process(tmp_path, slices):
     import torch.multiprocessing as mp
     import msamtools_amd as m
     import oracle_lib as orc
     out = str(tmp_path / "rank0.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * slices
+    mp.spawn(worker, args=(2, port, out, slices), nprocs=2, join=True)
     got = np.load(out)
     whole = m.HostSynth(SEED, 2 * G, REFS, 4)
     sel = orc.run_filter(whole, **OPTS)["emit"]
