@@ -94,7 +94,8 @@ int msx_bgzf_store_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_in,
 // 2 KB staging area in LDS, whole kilobytes written out).  A block that would be shorter with the fixed codes or
 // stored is written that way.  The same algorithm, one position at a time, is msx_deflate_model.h (host, tests): the
 // kernel's blocks equal its blocks bit for bit (tests/test_gpu_deflate.py).
-// LDS: 32 KB ring + tables in pass 1, reused by the coder; 34 KB per wave -> 4 waves per compute unit.
+// LDS: ring + tables in pass 1, reused by the coder: 13 KB per wave at the geometry -b takes -> 12 waves per compute unit
+// (msx_bgzf_deflate_launch lists the geometries).
 #define DF_SLOT (BZ_PAYLOAD + 1024u)  // bytes reserved per block while it is being built
 #define DF_OUT0 32u                   // a slot's DEFLATE stream starts here (16-byte aligned); the block itself at DF_OUT0 - 18
 #define DF_AHEAD 336u                 // bytes a step reads beyond its first position (63 + 258 + 8, rounded up)
@@ -128,7 +129,8 @@ struct df_hf {
 template <int RING_DW, int HB4, int HB8>
 struct df_lds {
 	union {
-		struct { uint32_t ring[RING_DW + 8]; uint32_t h4[1u << HB4]; uint32_t h8[1u << HB8]; } lz;   // (ring: its first 8 dwords once more behind the end)
+		struct { uint32_t ring[RING_DW + 8]; uint16_t h4[1u << HB4]; uint16_t h8[1u << HB8]; } lz;   // (ring: its first 8 dwords once more behind the end;
+		                                                                                               //  a table entry is a position + 1 <= 0xff00: 16 bits)
 		df_hf hf;
 	};
 	uint32_t lf[288], dq[32], clf[32];
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 	// MSX_DEFLATE_STATS: kinds[0..2] count the blocks written stored / with the fixed codes / with codes of their own; behind them
 	// (as 64-bit words from kinds + 4 on) the clocks the waves spent per phase
 	unsigned long long *prof = kinds ? reinterpret_cast<unsigned long long *>(kinds + 4) : nullptr;
-	unsigned long long t_mark = 0, t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t_mark = 0, t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DF_T0() do { if (prof) t_mark = __builtin_readcyclecounter(); } while (0)
 #define DF_T(i) do { if (prof) { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[i] += now_ - t_mark; t_mark = now_; } } while (0)
 	static_assert(4 * RING_DW >= WINDOW + 64 + (int)DF_AHEAD + 1024, "the ring holds window, step, look-ahead and a kilobyte of fill");
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 		uint8_t *slot = slots + (size_t)bi * DF_SLOT;
 		// ---- pass 1: tokens and their histogram ----
 		DF_T0();
-		for (uint32_t i = lane * 4u; i < (1u << HB4) + (1u << HB8); i += 256u)
-			*reinterpret_cast<uint4 *>(&S.lz.h4[i]) = make_uint4(0, 0, 0, 0);     // (h8 follows h4)
+		for (uint32_t i = lane * 8u; i < (1u << HB4) + (1u << HB8); i += 512u)
+			*reinterpret_cast<uint4 *>(&S.lz.h4[i]) = make_uint4(0, 0, 0, 0);     // (h8 follows h4; eight 16-bit entries per store)
 		for (uint32_t i = lane; i < 288u; i += 64u) S.lf[i] = 0;
 		if (lane < 32u) { S.dq[lane] = 0; S.clf[lane] = 0; }
 		uint32_t filled = 0, next_free = 0, nt = 0;
@@ -442,8 +444,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 #pragma unroll
 				for (uint32_t d = 4; d >= 1u; d--) if ((uint32_t)(A >> (8u * (4u - d))) == W2 && d <= p) nd = d;
 			}
-			if (has4 && !nd) atomicMax(&S.lz.h4[h4i], p + 1u);
-			if (has8 && !nd) atomicMax(&S.lz.h8[h8i], p + 1u);
+			// Entering the step's positions: the highest position of a step wins a slot (earlier steps' entries are lower: a plain
+			// store replaces them).  16-bit entries have no atomic max in LDS: every lane stores, reads back, and a lane that finds a
+			// LOWER position than its own in its slot stores again -- the lanes of a wave that meet in a slot (rare) settle in as
+			// many rounds as there are of them, one round otherwise.  (32-bit entries and ds_max_u32 cost 12 KB of tables instead of
+			// 6: nine waves per compute unit instead of twelve.)
+			{
+				bool w4 = has4 && !nd, w8 = has8 && !nd;
+				const uint16_t mine = (uint16_t)(p + 1u);
+				do {
+					if (w4) S.lz.h4[h4i] = mine;
+					if (w8) S.lz.h8[h8i] = mine;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					w4 = w4 && ((volatile uint16_t *)S.lz.h4)[h4i] < mine;
+					w8 = w8 && ((volatile uint16_t *)S.lz.h8)[h8i] < mine;
+				} while (__ballot(w4 || w8));
+			}
 			uint32_t bl = 0, bd = 0;
 			const bool need = active && p >= next_free;
 			DF_T(1);
@@ -537,6 +554,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 				cur = j + (uint32_t)__builtin_amdgcn_readlane((int)bl, (int)j);
 			}
 			next_free = p0 + cur;
+			DF_T(9);
 			if ((tokmask >> lane) & 1ull) {
 				const uint32_t rank = (uint32_t)__popcll(tokmask & ((1ull << lane) - 1ull));
 				uint32_t t;
@@ -754,9 +772,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 			bz_trailer(blk + 18u + nbytes, crc, n);
 			bsize[bi] = 18u + nbytes + 8u;
 			if (kinds) atomicAdd(&kinds[kind], 1u);
-			if (prof) for (int i = 0; i < 9; i++) { atomicAdd(&prof[i], t_acc[i]); }
+			if (prof) for (int i = 0; i < 10; i++) { atomicAdd(&prof[i], t_acc[i]); }
 		}
-		if (prof) for (int i = 0; i < 9; i++) t_acc[i] = 0;
+		if (prof) for (int i = 0; i < 10; i++) t_acc[i] = 0;
 	}
 }
 
@@ -816,13 +834,16 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	const size_t nblk = (n_cap + BZ_PAYLOAD - 1) / BZ_PAYLOAD;
 	int rc;
 	// The geometry of pass 1, <ring dwords, bits of the 4-byte table, bits of the 8-byte table, window>, by LEVEL -- what the level
-	// dials is the LDS a wave takes, hence the waves a compute unit keeps resident, hence the rate (round 5; measured on 250 MB of
-	// lean records / 290 MB with SEQ/QUAL, profiles/round5/deflate_geometries.log):
-	//   levels 7-9: <4096, 11, 11, 8192>  34 KB, 4 waves per compute unit  22 GB/s   1.078 / 1.119 of zlib -6's size   (round 4)
-	//   levels 4-6: <1024, 10, 11, 2560>  18 KB, 9 waves                    40 GB/s   1.085 / 1.128          (-b: htslib's default 6)
-	//   levels 1-3: <1024, 10, 10, 2560>  14 KB, 11 waves                   44 GB/s   1.091 / 1.133
+	// dials is the LDS a wave takes, hence the waves a compute unit keeps resident, hence the rate.  Round 6, 16-bit table entries,
+	// measured on 1 GB of lean records / 1.16 GB with SEQ/QUAL (15 249 / 17 782 blocks: several rounds of waves -- a launch of fewer
+	// blocks than waves measures one block's latency, 2.7 ms, not the rate; profiles/round6/deflate_geometries.log):
+	//   levels 7-9: <4096, 11, 11, 8192>  26 KB, 6 waves per compute unit   34.5 / 34.5 GB/s   1.079 / 1.120 of zlib -6's size
+	//   levels 4-6: <1024, 10, 11, 2560>  13 KB, 12 waves                   53.9 / 52.6        1.087 / 1.129   (-b: htslib's default 6)
+	//   levels 1-3: <1024, 10, 10, 2560>  11 KB, 12 waves (registers)       53.9 / 52.3        1.093 / 1.134
+	// (round 5, 32-bit entries: 4 / 9 / 11 waves, 22 / 40 / 44 GB/s.)
 	// MSX_DEFLATE_GEOM=0..5 overrides the level (0, 4, 3 are the three above; 1 = <2048, 11, 11, 6144>, 2 = <2048, 10, 10, 6144>,
-	// 5 = <1024, 11, 11, 2560>: measured, not mapped).  The host twin follows: df_opts_for_level (msx_deflate_model.h).
+	// 5 = <1024, 11, 11, 2560>: 46 GB/s at 8 waves, held there by their registers: measured, not mapped).  The host twin follows:
+	// df_opts_for_level (msx_deflate_model.h).
 	// (several device threads of one process launch the encoder at once: the lazily filled tables are filled under a lock)
 	static std::mutex geom_mu;
 	static int per_cu[6] = {0, 0, 0, 0, 0, 0};
@@ -884,14 +905,14 @@ int msx_bgzf_deflate_launch(msx_ctx *ctx, hipStream_t stream, const uint8_t *d_i
 	ctx->df_last = stream;
 	ctx->df_used = true;
 	if (want_kinds) {
-		uint32_t h[4 + 2 * 10];
+		uint32_t h[4 + 2 * 10 + 2];
 		MSX_HIP(ctx, hipMemcpyAsync(h, misc + 4, sizeof h, hipMemcpyDeviceToHost, stream));
 		MSX_HIP(ctx, hipStreamSynchronize(stream));
 		const unsigned long long *t = reinterpret_cast<const unsigned long long *>(h + 4);
 		const double nb = (double)(h[0] + h[1] + h[2] ? h[0] + h[1] + h[2] : 1);
 		fprintf(stderr, "# deflate: %zu blocks at most: %u stored, %u with the fixed codes, %u with codes of their own; clocks per block: ring+keys %.0f, "
-		        "tables %.0f, matches %.0f, resolve+tokens %.0f, crc %.0f, two trees %.0f, run lengths %.0f, third tree+costs %.0f, coding %.0f\n",
-		        nblk, h[0], h[1], h[2], t[0] / nb, t[1] / nb, t[2] / nb, t[3] / nb, t[4] / nb, t[5] / nb, t[6] / nb, t[7] / nb, t[8] / nb);
+		        "tables %.0f, matches %.0f, resolve %.0f, tokens %.0f, crc %.0f, two trees %.0f, run lengths %.0f, third tree+costs %.0f, coding %.0f\n",
+		        nblk, h[0], h[1], h[2], t[0] / nb, t[1] / nb, t[2] / nb, t[9] / nb, t[3] / nb, t[4] / nb, t[5] / nb, t[6] / nb, t[7] / nb, t[8] / nb);
 	}
 	return MSX_OK;
 }

@@ -27,7 +27,7 @@ pmc cov_write WRITE_SIZE python3 scripts/bench_coverage.py 10000000 2 depths
 pmc cov_c4_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" python3 scripts/bench_coverage.py 10000000 2 depths
 # the encoder's input is written BEFORE the profiler starts: under rocprofv3 (with --pmc certainly) every child process has
 # the GPU initialised by the preloaded tool library, and a child that execs is what this pool forbids
-msamtools_amd/bin/msamtools-dev synth --groups 400000 --refs 1000 -u > /tmp/prof_d.bam
+msamtools_amd/bin/msamtools-dev synth --groups 3200000 --refs 1000 -u > /tmp/prof_d.bam      # (15 000 blocks: several rounds of waves)
 stats deflate python3 scripts/bench_deflate.py /tmp/prof_d.bam
 pmc deflate_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python3 scripts/bench_deflate.py /tmp/prof_d.bam
 python3 - $OUT <<'PY'
