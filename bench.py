@@ -870,6 +870,12 @@ def main():
                           "child": os.environ.get("MSX_BENCH_RANK_CHILD") == "1"}), flush=True)
         return
 
+    # stdout carries ONE line, the JSON: whatever the libraries print through C stdio or Python (RCCL's version banner, warnings)
+    # goes to stderr -- file descriptor 1 is pointed there for the run, the line is written to the real one at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import msamtools_amd as m
@@ -1297,7 +1303,7 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
