@@ -597,6 +597,10 @@ def test_cli_profile_over_a_one_rank_communicator(tmp_path, synth_bams):
     assert r.returncode == 0, r.stderr.decode()
     text = lambda p: "\n".join(l for l in gzip.open(p, "rt").read().split("\n") if not l.startswith("# Command"))
     assert text(a) == text(b)
+    # MSX_DIST_SLICES: the per-iteration all-reduce in slices of the feature range, on a side stream -- the same file
+    r = run(base + ["-o", b, synth_bams["b"]], env={"MSX_FORCE_DIST": "1", "MSX_CLEAN_EXIT": "1", "MSX_DIST_SLICES": "3"})
+    assert r.returncode == 0, r.stderr.decode()
+    assert text(a) == text(b)
     shard = str(tmp_path / "shard0.bam")
     os.link(synth_bams["b"], shard)
     r = run(base + ["-o", c, str(tmp_path / "shard{rank}.bam")],
