@@ -37,6 +37,7 @@ typedef struct {
 	size_t l, m;
 } kstr;
 void ks_reserve(kstr *k, size_t extra);
+void msh_huge_hint(void *p, size_t n);       /* a heap block of 8 MB and more: its 2 MB-aligned part advised to huge pages */
 void ks_put(kstr *k, const void *p, size_t n);
 void ks_puts(kstr *k, const char *s);
 void ks_putc(kstr *k, int c);

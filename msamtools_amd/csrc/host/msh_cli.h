@@ -104,6 +104,7 @@ typedef struct {
 	size_t seq;                /* number of the batch in the input: the writer's order */
 	int eof;                   /* end-of-stream marker */
 	int pinned;
+	size_t pin_rec, pin_cig, pin_md, pin_grp;   /* what of the SoA arrays is page-locked (records, CIGAR words, MD bytes, pools) */
 	/* device unpack (msx_unpack): the slot carries inflated bytes only, cut anywhere */
 	int raw, last;             /* raw: ubuf[0, ulen) is all there is; last: nothing follows */
 	int has_seed, seed_has_name;

@@ -32,17 +32,20 @@ void mem_report(const char *tag) {
 	FILE *f;
 	char line[256], head[256] = "";
 	long rss = 0, ahp = 0;
+	char flags[128] = "";
 	if (!e || atoi(e) < 2 || !(f = fopen("/proc/self/smaps", "r"))) return;
 	fprintf(stderr, "# mappings at %s:\n", tag);
 	while (fgets(line, sizeof line, f)) {
 		if (!strstr(line, " kB") && strchr(line, '-') && ((line[0] >= '0' && line[0] <= '9') || (line[0] >= 'a' && line[0] <= 'f'))) {
-			if (rss > 32768) fprintf(stderr, "#   %ld MB resident (%ld MB in huge pages): %s", rss >> 10, ahp >> 10, head);
+			if (rss > 32768) fprintf(stderr, "#   %ld MB resident (%ld MB in huge pages; %s): %s", rss >> 10, ahp >> 10, flags, head);
 			snprintf(head, sizeof head, "%s", line);
 			rss = ahp = 0;
+			flags[0] = 0;
 		} else if (!strncmp(line, "Rss:", 4)) rss = atol(line + 4);
 		else if (!strncmp(line, "AnonHugePages:", 14)) ahp = atol(line + 14);
+		else if (!strncmp(line, "VmFlags:", 8)) { snprintf(flags, sizeof flags, "%.100s", line + 9); flags[strcspn(flags, "\n")] = 0; }
 	}
-	if (rss > 32768) fprintf(stderr, "#   %ld MB resident (%ld MB in huge pages): %s", rss >> 10, ahp >> 10, head);
+	if (rss > 32768) fprintf(stderr, "#   %ld MB resident (%ld MB in huge pages; %s): %s", rss >> 10, ahp >> 10, flags, head);
 	fclose(f);
 }
 

@@ -441,6 +441,7 @@ size_t msh_inflate_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 		size_t nc = *cap ? *cap : ((size_t)16 << 20);
 		while (nc < *len + total + 64) nc += nc >> 1;
 		*buf = (uint8_t *)realloc(*buf, nc);
+		msh_huge_hint(*buf, nc);
 		if (!*buf) mDie("Out of memory");
 		*cap = nc;
 	}
@@ -641,8 +642,10 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 			ks_reserve(&in->carry_text, pend);
 			in->carry_text.l += fread(in->carry_text.s + in->carry_text.l, 1, pend, in->fp);
 		}
-		for (i = 0; i < 2; i++)
+		for (i = 0; i < 2; i++) {
 			if (!(in->tr_buf[i] = (char *)malloc(TR_HEAD + SAM_CHUNK + 2))) mDie("Out of memory");
+			msh_huge_hint(in->tr_buf[i], TR_HEAD + SAM_CHUNK + 2);
+		}
 		pthread_mutex_init(&in->tr_mu, NULL);
 		pthread_cond_init(&in->tr_cv_full, NULL);
 		pthread_cond_init(&in->tr_cv_free, NULL);
@@ -717,6 +720,7 @@ size_t msh_sam_append(msh_in *in, uint8_t **buf, size_t *len, size_t *cap) {
 		size_t nc = *cap ? *cap : ((size_t)16 << 20);
 		while (nc < *len + total + 64) nc += nc >> 1;
 		*buf = (uint8_t *)realloc(*buf, nc);
+		msh_huge_hint(*buf, nc);
 		if (!*buf) mDie("Out of memory");
 		*cap = nc;
 	}
@@ -877,6 +881,7 @@ static void *gz_text_main(void *arg) {
 	const int fd = fileno(in->gz_src);
 	const size_t ICAP = (size_t)GZT_BLOCKS * 65536 + PRE_MAX, OCAP = (size_t)GZT_BLOCKS * 65536;
 	uint8_t *ibuf = (uint8_t *)malloc(ICAP), *obuf = (uint8_t *)malloc(OCAP);
+	msh_huge_hint(ibuf, ICAP); msh_huge_hint(obuf, OCAP);
 	msx_bgzf_block *blk = (msx_bgzf_block *)malloc(GZT_BLOCKS * sizeof(msx_bgzf_block));
 	size_t have = 0, at = 0;                  /* ibuf[at, have): read, not yet inflated */
 	z_stream zs;

@@ -54,6 +54,20 @@ void mQuit(const char *fmt, ...) {
 	exit(EXIT_FAILURE);
 }
 
+/* A large heap block asked to be backed by huge pages (where the system leaves that to madvise): the 2 MB-aligned part of it.
+ * The text path's buffers -- parsed records per thread, a batch's bytes, the SoA arrays -- are a couple of gigabytes; in 4 KB
+ * pages they cost 700 000 page faults while the first batches are parsed and half a second of tear-down after the
+ * command's last line (SAM text, 20 M records: 1.81 s, 0.48 of them after exit). */
+void msh_huge_hint(void *p, size_t n) {
+#ifdef MADV_HUGEPAGE
+	const uintptr_t al = (uintptr_t)2 << 20;
+	const uintptr_t a = ((uintptr_t)p + al - 1) & ~(al - 1), b = ((uintptr_t)p + n) & ~(al - 1);
+	if (p && n >= ((size_t)8 << 20) && b > a) (void)madvise((void *)a, (size_t)(b - a), MADV_HUGEPAGE);
+#else
+	(void)p; (void)n;
+#endif
+}
+
 void ks_reserve(kstr *k, size_t extra) {
 	if (k->l + extra + 1 > k->m) {
 		size_t m = k->m ? k->m : 64;
@@ -61,6 +75,7 @@ void ks_reserve(kstr *k, size_t extra) {
 		k->s = (char *)realloc(k->s, m);
 		if (!k->s) mDie("Out of memory");
 		k->m = m;
+		msh_huge_hint(k->s, m);
 	}
 }
 void ks_put(kstr *k, const void *p, size_t n) {

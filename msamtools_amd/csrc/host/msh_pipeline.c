@@ -206,8 +206,8 @@ void fill_batch_bulk(reader *rd, rbatch *b, size_t target, int mode, int want_st
 	}
 	if (want_stats) {
 		size_t nc = b->cigar_off[n_batch], nm = b->md_off[n_batch];
-		if (nc + 4 > b->cigar_cap) { b->cigar_cap = nc + nc / 4 + 1024; b->cigar = (uint32_t *)realloc(b->cigar, b->cigar_cap * 4); }
-		if (nm + 16 > b->md_cap) { b->md_cap = nm + nm / 4 + 4096; b->md = (uint8_t *)realloc(b->md, b->md_cap); }
+		if (nc + 4 > b->cigar_cap) { b->cigar_cap = nc + nc / 4 + 1024; b->cigar = (uint32_t *)realloc(b->cigar, b->cigar_cap * 4); msh_huge_hint(b->cigar, b->cigar_cap * 4); }
+		if (nm + 16 > b->md_cap) { b->md_cap = nm + nm / 4 + 4096; b->md = (uint8_t *)realloc(b->md, b->md_cap); msh_huge_hint(b->md, b->md_cap); }
 		if (!b->cigar || !b->md) mDie("Out of memory");
 		J.n = n_batch;
 		msh_parallel(msh_threads(), pack_copy, &J);
@@ -272,6 +272,7 @@ static size_t env_size(const char *name, size_t dflt) {
 void *xmalloc(size_t n) {
 	void *p = malloc(n ? n : 1);
 	if (!p) mDie("Out of memory");
+	msh_huge_hint(p, n);
 	return p;
 }
 
@@ -841,8 +842,20 @@ static size_t pipe_fill(pipe_t *P, pslot *s) {
 	int must_read = 0;      /* what is here is not a batch yet (no whole record, one pool only): the next bytes are waited for */
 	pack_job J;
 	s->ulen = 0;
+	/* SAM text: the slot's buffer at the size a batch will take, in one piece and before anything is written to it -- it used to
+	 * grow by halves under the parser (16 MB -> 182 MB in seven steps, each a move of the mapping): every page of it a 4 KB page,
+	 * 1.2 GB of them over the slots, and their tear-down 0.3 s of the command's exit */
+	if (!msh_is_bam(P->in) && s->ucap < P->carry.l + P->batch_bytes + ((size_t)40 << 20)) {
+		const size_t nc = P->carry.l + P->batch_bytes + ((size_t)40 << 20);
+		uint8_t *nb = (uint8_t *)malloc(nc);
+		if (!nb) mDie("Out of memory");
+		msh_huge_hint(nb, nc);
+		free(s->ubuf);
+		s->ubuf = nb;
+		s->ucap = nc;
+	}
 	if (P->carry.l) {
-		if (P->carry.l + 64 > s->ucap) { s->ucap = P->carry.l + P->batch_bytes + 64; s->ubuf = (uint8_t *)realloc(s->ubuf, s->ucap); if (!s->ubuf) mDie("Out of memory"); }
+		if (P->carry.l + 64 > s->ucap) { s->ucap = P->carry.l + P->batch_bytes + 64; s->ubuf = (uint8_t *)realloc(s->ubuf, s->ucap); if (!s->ubuf) mDie("Out of memory"); msh_huge_hint(s->ubuf, s->ucap); }
 		memcpy(s->ubuf, P->carry.s, P->carry.l);
 		s->ulen = P->carry.l;
 		P->carry.l = 0;
@@ -1078,14 +1091,48 @@ void *pipe_decode_thread(void *arg) {
 	}
 }
 
-/* page-lock the slot's SoA arrays once (they never move): uploads become asynchronous DMA */
+/* page-lock the slot's SoA arrays (they never move): uploads become asynchronous DMA.  Not their whole capacity -- 3 M records,
+ * 173 MB a slot, of which a 96 MB batch of records with SEQ/QUAL fills a seventh: what the batch at hand needs and a quarter
+ * more, locked again (larger) only when a later batch outgrows it.  (Whole capacities were 0.9 GB of 4 KB pages over the slots of
+ * a SAM-text command: 20-40 ms each to lock on the device thread, 0.3 s to let go of after the command's last line.) */
 void pipe_pin_slot(pipe_t *P, pslot *s) {
 	rbatch *b = &s->b;
 	/* (device unpack: only batch 0 takes the host-side walk -- of its arrays just what it uses is page-locked: 170 MB for
 	 * one upload would cost more than the upload saves, and from pageable memory the dozen copies took 77 ms) */
-	const size_t c = P->raw_mode ? b->n + 8 : b->cap;
-	if (s->pinned || getenv("MSX_NO_PIN")) return;
+	size_t c, c_cig, c_md, c_grp;
+	if (getenv("MSX_NO_PIN")) return;
+	if (s->pinned && (P->raw_mode || (b->n + 8 <= s->pin_rec && (P->mode == 0 || b->n_groups + 8 <= s->pin_grp) &&
+	                                  (!P->want_stats || ((size_t)b->cigar_off[b->n] + 8 <= s->pin_cig && (size_t)b->md_off[b->n] + 64 <= s->pin_md)))))
+		return;
+	if (s->pinned) {                   /* a batch larger than any before it in this slot: let go, lock more */
+		MSX(msx_host_unregister(g_ctx, b->flag));
+		MSX(msx_host_unregister(g_ctx, b->rflags));
+		MSX(msx_host_unregister(g_ctx, b->tid));
+		if (P->mode != 2) {
+			MSX(msx_host_unregister(g_ctx, b->nm));
+			MSX(msx_host_unregister(g_ctx, b->as));
+			MSX(msx_host_unregister(g_ctx, s->emit));
+			if (s->as_out) MSX(msx_host_unregister(g_ctx, s->as_out));
+		}
+		if (P->want_stats) {
+			MSX(msx_host_unregister(g_ctx, b->cigar_off));
+			MSX(msx_host_unregister(g_ctx, b->md_off));
+			MSX(msx_host_unregister(g_ctx, b->cigar));
+			MSX(msx_host_unregister(g_ctx, b->md));
+		}
+		if (P->mode != 0) MSX(msx_host_unregister(g_ctx, b->group_off));
+	}
 	s->pinned = 1;
+	if (P->raw_mode) {
+		c = b->n + 8; c_grp = b->n_groups + 8;
+		c_cig = P->want_stats ? (size_t)b->cigar_off[b->n] + 8 : 0; c_md = P->want_stats ? (size_t)b->md_off[b->n] + 64 : 0;
+	} else {
+		c = b->n + b->n / 4 + 65536; if (c > b->cap) c = b->cap;
+		c_cig = P->want_stats ? (size_t)b->cigar_off[b->n] + (size_t)b->cigar_off[b->n] / 4 + 65536 : 0; if (c_cig > b->cigar_cap) c_cig = b->cigar_cap;
+		c_md = P->want_stats ? (size_t)b->md_off[b->n] + (size_t)b->md_off[b->n] / 4 + 65536 : 0; if (c_md > b->md_cap) c_md = b->md_cap;
+		c_grp = b->n_groups + b->n_groups / 4 + 65536; if (c_grp > b->group_cap) c_grp = b->group_cap;
+	}
+	s->pin_rec = c; s->pin_cig = c_cig; s->pin_md = c_md; s->pin_grp = c_grp;
 	MSX(msx_host_register(g_ctx, b->flag, c * 2));
 	MSX(msx_host_register(g_ctx, b->rflags, c));
 	MSX(msx_host_register(g_ctx, b->tid, c * 4));
@@ -1098,8 +1145,8 @@ void pipe_pin_slot(pipe_t *P, pslot *s) {
 	if (P->want_stats) {
 		MSX(msx_host_register(g_ctx, b->cigar_off, (c + 1) * 4));
 		MSX(msx_host_register(g_ctx, b->md_off, (c + 1) * 4));
-		MSX(msx_host_register(g_ctx, b->cigar, P->raw_mode ? ((size_t)b->cigar_off[b->n] + 8) * 4 : b->cigar_cap * 4));
-		MSX(msx_host_register(g_ctx, b->md, P->raw_mode ? (size_t)b->md_off[b->n] + 64 : b->md_cap));
+		MSX(msx_host_register(g_ctx, b->cigar, c_cig * 4));
+		MSX(msx_host_register(g_ctx, b->md, c_md));
 	}
-	if (P->mode != 0) MSX(msx_host_register(g_ctx, b->group_off, P->raw_mode ? (b->n_groups + 8) * 4 : b->group_cap * 4));
+	if (P->mode != 0) MSX(msx_host_register(g_ctx, b->group_off, c_grp * 4));
 }
