@@ -321,6 +321,8 @@ void pipe_init(pipe_t *P, msh_in *in, int mode, int want_stats, int n_consumers)
 		b->md_cap = P->cap_md; b->md = (uint8_t *)xmalloc(b->md_cap);
 		b->group_cap = c + 1; b->group_off = (uint32_t *)xmalloc(b->group_cap * 4);
 		s->emit = (int32_t *)xmalloc(c * 4);
+		if (getenv("MSX_TIMING") && atoi(getenv("MSX_TIMING")) >= 2)
+			fprintf(stderr, "# slot %d: SoA arrays from %p (rec_off) to %p (emit + %zu)\n", i, (void *)b->rec_off, (void *)s->emit, c * 4);
 		pq_push(&P->q_free, i);
 	}
 }
