@@ -327,7 +327,9 @@ int  msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_co
                              const msx_bgzf_block *host_blocks, int64_t n_blocks, const msx_unpack_params *prm);
 /* optional, at any time: upload and inflate the blocks of a coming msx_unpack_enqueue_bgzf on streams of their own, while
  * the current batch is walked, filtered and fetched.  Up to two batches may be on their way; they must be enqueued in
- * the order they were sent (each enqueue names the same buffer, length and block count as its prefetch). */
+ * the order they were sent (each enqueue names the same buffer, length and block count as its prefetch).  A batch sent
+ * ahead is walked in the buffer it was inflated into, and that buffer is filled again once the NEXT batch has been enqueued:
+ * whatever reads a batch's bytes (msx_unpack_emit*) must be enqueued before the batch after it is. */
 int  msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_t *host_comp, size_t comp_len,
                               const msx_bgzf_block *host_blocks, int64_t n_blocks);
 

@@ -65,9 +65,16 @@ struct msx_unpack {
 		size_t comp_len = 0, total = 0;
 		int64_t nblk = 0;
 		bool used = false;              // `freed` has been recorded at least once
-	} pre[2];
+	} pre[3];
 	int ahead_head = 0, ahead_n = 0;   // the oldest pending set, how many are pending
-	hipStream_t inf_stream[2] = {nullptr, nullptr}, h2d_stream = nullptr;   // (one inflating stream per set: two batches' blocks side by side fill the chip)
+	hipStream_t inf_stream[3] = {nullptr, nullptr, nullptr}, h2d_stream = nullptr;   // (one inflating stream per set)
+	// Round 6: a batch sent ahead is WALKED WHERE IT WAS INFLATED -- its set's `out`, which leaves UP_HEAD bytes free in front of
+	// the blocks' bytes: the carry (the open pool and the cut record of the batch before: kilobytes) is copied in front of them,
+	// instead of the batch (a quarter of a gigabyte) behind the carry.  bytes[parity]: where the batch of that parity begins --
+	// raw[parity].p, or inside a set; in_place[parity]: that set (until the batch after it is enqueued: its emits are through by then).
+	// Three sets: the batch at hand and two sent ahead.
+	uint8_t *bytes[2] = {nullptr, nullptr};
+	int in_place[2] = {-1, -1};
 	msx_buf rec_off, flag, rflags, tid, pos, nm, as, cig_cnt, cig_src, cigar_off, md_len, md_off, md_src, bd, pidx, gflag, gpos,
 	    group_off, tile_last, cigar, md, out_len, out_off, out, framed;
 	char *prev_name = nullptr;     // device, 256 bytes
@@ -611,14 +618,14 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (ctx) {
 		if (u->df_stream && ctx->df_last == u->df_stream) { ctx->df_last = nullptr; ctx->df_used = false; }
 		for (auto &c : ctx->inf)
-			if (c.used && c.stream && (c.stream == u->inf_stream[0] || c.stream == u->inf_stream[1])) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
+			if (c.used && c.stream && (c.stream == u->inf_stream[0] || c.stream == u->inf_stream[1] || c.stream == u->inf_stream[2])) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
 	}
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cig_src, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
 	                   &u->bd, &u->pidx, &u->gflag, &u->gpos, &u->group_off, &u->tile_last, &u->cigar, &u->md, &u->out_len,
 	                   &u->out_off, &u->out, &u->framed, &u->eo[0], &u->eo[1], &u->ef[0], &u->ef[1], &u->comp, &u->blk, &u->blk_status, &u->pre[0].comp, &u->pre[0].blk,
 	                   &u->pre[0].status, &u->pre[0].out, &u->pre[0].cnt, &u->pre[1].comp, &u->pre[1].blk, &u->pre[1].status,
-	                   &u->pre[1].out, &u->pre[1].cnt};
+	                   &u->pre[1].out, &u->pre[1].cnt, &u->pre[2].comp, &u->pre[2].blk, &u->pre[2].status, &u->pre[2].out, &u->pre[2].cnt};
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
 	for (auto st : u->inf_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -699,6 +706,31 @@ extern "C" int msx_unpack_carry(msx_ctx *ctx, msx_unpack *u, uint8_t *host, size
 }
 
 #define UP_RES(field, bytes) if ((rc = msx_reserve(ctx, &u->field, (bytes)))) return rc
+// room in front of a set's inflated bytes for the carry (a larger carry: the batch is copied, as before)
+#ifdef MSX_DEBUG_SWITCHES
+// (MSX_UP_HEAD=<bytes>, libmsamtools_amd_dbg only: a few hundred bytes make most batches take the copy -- tests)
+static size_t up_head() {
+	static const size_t v = [] { const char *e = getenv("MSX_UP_HEAD"); const long long n = e ? atoll(e) : 0; return n > 0 ? ((size_t)n + 255) & ~(size_t)255 : (size_t)4 << 20; }();
+	return v;
+}
+#define UP_HEAD up_head()
+#else
+#define UP_HEAD ((size_t)4 << 20)
+#endif
+
+// A new batch is being enqueued: the batches before it are through with their bytes (their walks have finished, their emits --
+// which must be enqueued before the next batch is -- lie in front of this point of the context's stream): the sets they were
+// walked in may be filled again.
+static int up_release_in_place(msx_ctx *ctx, msx_unpack *u) {
+	for (int par = 0; par < 2; par++) {
+		if (u->in_place[par] < 0) continue;
+		msx_unpack::pre_set &ps = u->pre[u->in_place[par]];
+		MSX_HIP(ctx, hipEventRecord(ps.freed, ctx->stream));
+		ps.used = true;
+		u->in_place[par] = -1;
+	}
+	return MSX_OK;
+}
 
 // The bytes of the NEXT msx_unpack_enqueue, sent ahead on a stream of their own: called after msx_unpack_finish of the
 // current batch (the carry's length is known then), they travel while the current batch is filtered and its output is
@@ -735,8 +767,10 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue: other bytes than msx_unpack_prefetch sent ahead");
 	}
 	u->pre_n = 0;
+	up_release_in_place(ctx, u);
 	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;     // (a corrupt record's name length may point 255 bytes past the data)
 	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	u->bytes[u->cur] = raw;
 	// the state of this batch (has_prev and prev_name carry over)
 	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 4, ctx->stream));
@@ -749,7 +783,7 @@ extern "C" int msx_unpack_enqueue(msx_ctx *ctx, msx_unpack *u, const uint8_t *ho
 // the batch's bytes are (or will be, in stream order) in raw[cur][0, n): find the records
 static int up_enqueue_walk(msx_ctx *ctx, msx_unpack *u, size_t n, const msx_unpack_params *prm) {
 	int rc;
-	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	uint8_t *raw = u->bytes[u->cur];
 	MSX_HIP(ctx, hipMemsetAsync(raw + n, 0, 64, ctx->stream));
 	u->n_bytes = n;
 	u->prm = *prm;
@@ -811,14 +845,14 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.freed, hipEventDisableTiming));
 		}
 	}
-	const int set = (u->ahead_head + u->ahead_n) & 1;
+	const int set = (u->ahead_head + u->ahead_n) % 3;
 	msx_unpack::pre_set &ps = u->pre[set];
 	hipStream_t inf = u->inf_stream[set];
 	// (the set may still be read by the copy of the batch that used it last: its upload waits for that copy; buffers are
 	// grown only when nothing of the set is in flight any more)
 	if (ps.used) MSX_HIP(ctx, hipStreamWaitEvent(u->h2d_stream, ps.freed, 0));
 	if (ps.comp.cap < comp_len + 64 || ps.blk.cap < (size_t)n_blocks * sizeof(msx_bgzf_block) || ps.status.cap < (size_t)n_blocks * 4 ||
-	    ps.out.cap < n_new + 64 || ps.cnt.cap < 64) {
+	    ps.out.cap < UP_HEAD + n_new + 2048 || ps.cnt.cap < 64) {
 		if (ps.used) MSX_HIP(ctx, hipEventSynchronize(ps.freed));
 		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
 		for (auto st : u->inf_stream) MSX_HIP(ctx, hipStreamSynchronize(st));
@@ -826,7 +860,7 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 	if ((rc = msx_reserve(ctx, &ps.comp, comp_len + 64))) return rc;
 	if ((rc = msx_reserve(ctx, &ps.blk, (size_t)n_blocks * sizeof(msx_bgzf_block)))) return rc;
 	if ((rc = msx_reserve(ctx, &ps.status, (size_t)n_blocks * 4))) return rc;
-	if ((rc = msx_reserve(ctx, &ps.out, n_new + 64))) return rc;
+	if ((rc = msx_reserve(ctx, &ps.out, UP_HEAD + n_new + 2048))) return rc;       // (+ what the walk may read and clear behind the bytes)
 	if ((rc = msx_reserve(ctx, &ps.cnt, 64))) return rc;
 	// the upload on a stream of its own (it travels while the batch before is being inflated) ...
 	MSX_HIP(ctx, hipMemcpyAsync(ps.comp.p, host_comp, comp_len, hipMemcpyHostToDevice, u->h2d_stream));
@@ -839,7 +873,7 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 	MSX_HIP(ctx, hipStreamWaitEvent(inf, ps.h2d_done, 0));
 	MSX_HIP(ctx, hipMemsetAsync(ps.cnt.p, 0, 8, inf));
 	if ((rc = msx_bgzf_inflate_launch(ctx, inf, 8, (const uint8_t *)ps.comp.p, comp_len, (const msx_bgzf_block *)ps.blk.p,
-	                                  n_blocks, (uint8_t *)ps.out.p, (uint32_t *)ps.status.p, (uint32_t *)ps.cnt.p)))
+	                                  n_blocks, (uint8_t *)ps.out.p + UP_HEAD, (uint32_t *)ps.status.p, (uint32_t *)ps.cnt.p)))
 		return rc;
 	MSX_HIP(ctx, hipEventRecord(ps.inf_done, inf));
 	ps.key = host_comp;
@@ -874,18 +908,27 @@ extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_
 	else if ((rc = up_check_table(ctx, host_blocks, n_blocks, comp_len, &n_new))) return rc;
 	const size_t n = u->carry_len + n_new;
 	if (n > 0xfffffff0ull - 64) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: more than 4 GiB in one batch");
-	if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;
+	up_release_in_place(ctx, u);
+	const bool in_place = sent && n_new > 0 && u->carry_len <= UP_HEAD;
+	if (!in_place && (rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, u->carry_len))) return rc;
 	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
 	MSX_HIP(ctx, hipMemsetAsync(u->d_state, 0, offsetof(up_state, has_prev), ctx->stream));
 	MSX_HIP(ctx, hipMemsetAsync(&u->d_state->emit_bytes, 0, 4, ctx->stream));
 	if (sent) {
-		// inflated already, in the staging buffer: behind the carry with it, and the verdict into this batch's state
 		MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ps.inf_done, 0));
-		if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, ps.out.p, n_new, hipMemcpyDeviceToDevice, ctx->stream));
+		if (in_place) {
+			// inflated already, UP_HEAD bytes into the set's buffer: the carry in front of it, the batch walked where it lies
+			raw = (uint8_t *)ps.out.p + UP_HEAD - u->carry_len;
+			if (u->carry_len) MSX_HIP(ctx, hipMemcpyAsync(raw, u->raw[u->cur].p, u->carry_len, hipMemcpyDeviceToDevice, ctx->stream));
+			u->in_place[u->cur] = u->ahead_head;
+		} else {
+			// (a carry larger than the room in front: the batch behind the carry, as until round 6)
+			if (n_new) MSX_HIP(ctx, hipMemcpyAsync(raw + u->carry_len, (const uint8_t *)ps.out.p + UP_HEAD, n_new, hipMemcpyDeviceToDevice, ctx->stream));
+			MSX_HIP(ctx, hipEventRecord(ps.freed, ctx->stream));
+			ps.used = true;
+		}
 		MSX_HIP(ctx, hipMemcpyAsync(&u->d_state->inflate_bad, ps.cnt.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
-		MSX_HIP(ctx, hipEventRecord(ps.freed, ctx->stream));
-		ps.used = true;
-		u->ahead_head ^= 1;
+		u->ahead_head = (u->ahead_head + 1) % 3;
 		u->ahead_n--;
 	} else if (n_blocks > 0) {
 		UP_RES(comp, comp_len + 64);
@@ -898,6 +941,7 @@ extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_
 			return rc;
 	}
 	u->bgzf = true;
+	u->bytes[u->cur] = raw;
 	return up_enqueue_walk(ctx, u, n, prm);
 }
 
@@ -916,7 +960,7 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	memset(dev, 0, sizeof *dev);
 	const msx_unpack_params &P = u->prm;
 	const size_t n = u->n_bytes;
-	uint8_t *raw = (uint8_t *)u->raw[u->cur].p;
+	uint8_t *raw = u->bytes[u->cur];
 	int rc;
 	if (n > 0) {
 		if ((rc = up_fetch_state(ctx, u))) return rc;               // sync 1: how many records
@@ -931,7 +975,12 @@ extern "C" int msx_unpack_finish(msx_ctx *ctx, msx_unpack *u, msx_unpack_result 
 	res->bad_guesses = n ? u->h_state->bad_segments : 0;
 	if (P.last && n && u->h_state->tail_off != (uint32_t)n) return msx_fail(ctx, MSX_ERR_ARG, "Truncated BAM record");
 	if (nr == 0) {
-		// nothing complete yet (or nothing at all): everything stays as the carry
+		// nothing complete yet (or nothing at all): everything stays as the carry -- which lives at the head of raw[cur]
+		if (n && raw != (uint8_t *)u->raw[u->cur].p) {              // (the batch was walked in its set: over it goes)
+			if ((rc = grow_keep_n(ctx, &u->raw[u->cur], n + 1024, 0))) return rc;
+			MSX_HIP(ctx, hipMemcpyAsync(u->raw[u->cur].p, raw, n, hipMemcpyDeviceToDevice, ctx->stream));
+			u->bytes[u->cur] = (uint8_t *)u->raw[u->cur].p;
+		}
 		res->carry_bytes = (int64_t)n;
 		u->carry_len = n;
 		return MSX_OK;
@@ -1020,7 +1069,7 @@ static int up_emit_gather(msx_ctx *ctx, msx_unpack *u, const int32_t *emit_idx_d
 	int rc;
 	const uint32_t ne = (uint32_t)n_emit;
 	// the batch's bytes are in the buffer the carry was NOT copied into
-	const uint8_t *raw = (const uint8_t *)u->raw[u->cur ^ 1].p;
+	const uint8_t *raw = u->bytes[u->cur ^ 1];
 	UP_RES(out_len, ((size_t)ne + 8) * 4);
 	UP_RES(out_off, ((size_t)ne + 8) * 4);
 	UP_RES(out, u->n_bytes + 64);
@@ -1106,7 +1155,7 @@ extern "C" int msx_unpack_emit_bgzf_enqueue(msx_ctx *ctx, msx_unpack *u, const i
 	if (n_emit <= 0) return MSX_OK;
 	if (n_emit > u->n_batch) return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_emit: more records than the batch holds");
 	const uint32_t ne = (uint32_t)n_emit;
-	const uint8_t *raw = (const uint8_t *)u->raw[u->cur ^ 1].p;
+	const uint8_t *raw = u->bytes[u->cur ^ 1];
 	// (this parity's record buffer was read by the encoder two batches ago)
 	if (u->deflated_used[par]) MSX_HIP(ctx, hipStreamWaitEvent(ctx->stream, u->ev_deflated[par], 0));
 	UP_RES(out_len, ((size_t)ne + 8) * 4);

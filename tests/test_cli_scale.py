@@ -154,14 +154,17 @@ def test_filter_digest_many_batches(big, tmp_path, inflag, outflag):
 
 
 @pytest.mark.parametrize("env", [dict(MSX_INFLATE_REFUSE=7), dict(MSX_INFLATE_REFUSE=1), dict(MSX_HOST_INFLATE=1),
-                                 dict(MSX_NO_INFLATE_AHEAD=1), dict(MSX_INFLATE_AHEAD=2), dict(MSX_INFLATE_WAVES=3)])
+                                 dict(MSX_NO_INFLATE_AHEAD=1), dict(MSX_INFLATE_AHEAD=2), dict(MSX_INFLATE_WAVES=3),
+                                 dict(MSX_UP_HEAD=256), dict(MSX_UP_HEAD=256, MSX_INFLATE_AHEAD=2)])
 def test_where_the_blocks_are_inflated_changes_nothing(big, tmp_path, env):
     """BGZF blocks are inflated on the device (msx_inflate.hip); batches with a block the device refuses (here: every 7th
     block, by a test switch) are inflated on the host instead; MSX_HOST_INFLATE=1 inflates everything there.  Same output."""
     out, p = str(tmp_path / "f.bam"), str(tmp_path / "p.gz")
-    if "MSX_INFLATE_REFUSE" in env:
-        # a test hook: only the debug build of the library knows it (msamtools_amd/dbg, -DMSX_DEBUG_SWITCHES); the product
-        # binary finds its library through a RUNPATH, which LD_LIBRARY_PATH precedes
+    if "MSX_INFLATE_REFUSE" in env or "MSX_UP_HEAD" in env:
+        # test hooks: only the debug build of the library knows them (msamtools_amd/dbg, -DMSX_DEBUG_SWITCHES); the product
+        # binary finds its library through a RUNPATH, which LD_LIBRARY_PATH precedes.  (MSX_UP_HEAD: a batch sent ahead is
+        # walked where it was inflated, the carry copied into the room in front of it; with 256 bytes of room most carries
+        # do not fit and the batch is copied behind the carry instead, as until round 6)
         env = dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "msamtools_amd", "dbg") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = sh(f"{BIN} {' '.join(FILT)} -bu --profile-out {p} --label S {big.bam['b']} > {out}", MSX_TIMING=1, **env)
     assert n_batches(r.stderr) >= 20
