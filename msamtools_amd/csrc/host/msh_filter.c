@@ -287,10 +287,20 @@ void *filter_dev_thread(void *arg) {
 			memset(&up, 0, sizeof up);
 			up.pool_mode = P->mode; up.unmapped_visible = P->unmapped_visible; up.want_aux = 1; up.want_stats = P->want_stats;
 			up.n_targets = P->hdr->n_targets; up.last = s->last; up.cut_mapped = P->cut_mapped;
-			unpack_slot_enqueue(P, s, unpack, &up);
-			if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
-			unpack_slot_finish(P, s, unpack, &up, &ur, &db);
-			if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);        /* (not decoded yet a moment ago?) */
+			{
+				/* (MSX_TIMING=2: the first device-walked batches step by step -- what the first of them pays beyond the others) */
+				const int tt = s->seq <= 3 && getenv("MSX_TIMING") && atoi(getenv("MSX_TIMING")) >= 2;
+				double ta = now_s(), tb, tc, td;
+				unpack_slot_enqueue(P, s, unpack, &up);
+				tb = now_s();
+				if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
+				tc = now_s();
+				unpack_slot_finish(P, s, unpack, &up, &ur, &db);
+				td = now_s();
+				if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);        /* (not decoded yet a moment ago?) */
+				if (tt) fprintf(stderr, "# batch %zu on the device thread: pin+seed %.1f ms, enqueue %.1f, send ahead %.1f, finish %.1f, send ahead %.1f\n",
+				                s->seq, (ta - t1) * 1e3, (tb - ta) * 1e3, (tc - tb) * 1e3, (td - tc) * 1e3, (now_s() - td) * 1e3);
+			}
 			D->t_upload += now_s() - t1; t1 = now_s();
 			b->n = (size_t)ur.n_records;
 			s->n_emit = 0;
@@ -312,6 +322,8 @@ void *filter_dev_thread(void *arg) {
 					fatal_refilter(F->fp, frc == MSX_ERR_NO_AS, P->mode != 0, go, ur.n_groups, NULL, unpack, &db, &fo, &st);
 					free(go);
 				}
+				if (s->seq <= 3 && getenv("MSX_TIMING") && atoi(getenv("MSX_TIMING")) >= 2)
+					fprintf(stderr, "# batch %zu on the device thread: outputs + filter + its wait %.1f ms\n", s->seq, (now_s() - t1) * 1e3);
 				D->t_gpu += now_s() - t1; t1 = now_s();
 				s->n_emit = st.n_emit;
 				if (F->n_dev == 1) unpack_slots_ahead(P, unpack, &ahead);
