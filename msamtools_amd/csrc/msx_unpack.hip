@@ -67,7 +67,11 @@ struct msx_unpack {
 		bool used = false;              // `freed` has been recorded at least once
 	} pre[3];
 	int ahead_head = 0, ahead_n = 0;   // the oldest pending set, how many are pending
-	hipStream_t inf_stream[3] = {nullptr, nullptr, nullptr}, h2d_stream = nullptr;   // (one inflating stream per set)
+	// a stream per batch on its way (two at most), made when first needed: the blocks go up and are inflated on it.  (Until the
+	// end of round 6 the first call made four streams -- one per set and one for the uploads: 30 ms on the device thread between
+	// batch 0 and batch 1, 7.5 ms a stream: its hardware queue and the queue's 173 MB of host memory -- of which the command
+	// line's one batch ahead ever used two.)
+	hipStream_t inf_stream[2] = {nullptr, nullptr};
 	// Round 6: a batch sent ahead is WALKED WHERE IT WAS INFLATED -- its set's `out`, which leaves UP_HEAD bytes free in front of
 	// the blocks' bytes: the carry (the open pool and the cut record of the batch before: kilobytes) is copied in front of them,
 	// instead of the batch (a quarter of a gigabyte) behind the carry.  bytes[parity]: where the batch of that parity begins --
@@ -609,7 +613,6 @@ extern "C" int msx_unpack_create(msx_ctx *ctx, msx_unpack **out) {
 extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (!u) return;
 	if (ctx && ctx->stream) { msx_join(ctx); (void)hipStreamSynchronize(ctx->stream); }
-	if (u->h2d_stream) (void)hipStreamSynchronize(u->h2d_stream);
 	for (auto st : u->inf_stream) if (st) (void)hipStreamSynchronize(st);
 	if (u->df_stream) (void)hipStreamSynchronize(u->df_stream);
 	if (u->copy_stream) (void)hipStreamSynchronize(u->copy_stream);
@@ -618,7 +621,7 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	if (ctx) {
 		if (u->df_stream && ctx->df_last == u->df_stream) { ctx->df_last = nullptr; ctx->df_used = false; }
 		for (auto &c : ctx->inf)
-			if (c.used && c.stream && (c.stream == u->inf_stream[0] || c.stream == u->inf_stream[1] || c.stream == u->inf_stream[2])) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
+			if (c.used && c.stream && (c.stream == u->inf_stream[0] || c.stream == u->inf_stream[1])) { c.used = false; c.stream = nullptr; }   // (the buffers stay for the next stream)
 	}
 	msx_buf *bufs[] = {&u->raw[0], &u->raw[1], &u->seg_first, &u->seg_end, &u->seg_cnt, &u->seg_base, &u->rec_off, &u->flag,
 	                   &u->rflags, &u->tid, &u->pos, &u->nm, &u->as, &u->cig_cnt, &u->cig_src, &u->cigar_off, &u->md_len, &u->md_off, &u->md_src,
@@ -629,7 +632,6 @@ extern "C" void msx_unpack_destroy(msx_ctx *ctx, msx_unpack *u) {
 	for (auto *b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 	if (u->copy_stream) { (void)hipStreamSynchronize(u->copy_stream); (void)hipStreamDestroy(u->copy_stream); }
 	for (auto st : u->inf_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-	if (u->h2d_stream) { (void)hipStreamSynchronize(u->h2d_stream); (void)hipStreamDestroy(u->h2d_stream); }
 	for (auto &ps : u->pre) {
 		if (ps.h2d_done) (void)hipEventDestroy(ps.h2d_done);
 		if (ps.inf_done) (void)hipEventDestroy(ps.inf_done);
@@ -834,43 +836,39 @@ extern "C" int msx_unpack_prefetch_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8
 	int rc;
 	size_t n_new = 0;
 	if ((rc = up_check_table(ctx, host_blocks, n_blocks, comp_len, &n_new))) return rc;
-	if (!u->inf_stream[0]) {
-		int lo = 0, hi = 0;
-		MSX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));           // (lo: the least urgent)
-		for (auto &st : u->inf_stream) MSX_HIP(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo));
-		MSX_HIP(ctx, hipStreamCreateWithFlags(&u->h2d_stream, hipStreamNonBlocking));
+	if (!u->pre[0].inf_done)
 		for (auto &ps : u->pre) {
 			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.h2d_done, hipEventDisableTiming));
 			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.inf_done, hipEventDisableTiming));
 			MSX_HIP(ctx, hipEventCreateWithFlags(&ps.freed, hipEventDisableTiming));
 		}
+	// the stream: by how many batches are on their way already (0 or 1) -- the second one only if a caller ever sends two ahead
+	if (!u->inf_stream[u->ahead_n]) {
+		int lo = 0, hi = 0;
+		MSX_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));           // (lo: the least urgent)
+		MSX_HIP(ctx, hipStreamCreateWithPriority(&u->inf_stream[u->ahead_n], hipStreamNonBlocking, lo));
 	}
+	hipStream_t inf = u->inf_stream[u->ahead_n];
 	const int set = (u->ahead_head + u->ahead_n) % 3;
 	msx_unpack::pre_set &ps = u->pre[set];
-	hipStream_t inf = u->inf_stream[set];
-	// (the set may still be read by the copy of the batch that used it last: its upload waits for that copy; buffers are
+	// (the set may still be read by the batch that was walked in it: its upload waits for that batch's release; buffers are
 	// grown only when nothing of the set is in flight any more)
-	if (ps.used) MSX_HIP(ctx, hipStreamWaitEvent(u->h2d_stream, ps.freed, 0));
+	if (ps.used) MSX_HIP(ctx, hipStreamWaitEvent(inf, ps.freed, 0));
 	if (ps.comp.cap < comp_len + 64 || ps.blk.cap < (size_t)n_blocks * sizeof(msx_bgzf_block) || ps.status.cap < (size_t)n_blocks * 4 ||
 	    ps.out.cap < UP_HEAD + n_new + 2048 || ps.cnt.cap < 64) {
 		if (ps.used) MSX_HIP(ctx, hipEventSynchronize(ps.freed));
-		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
-		for (auto st : u->inf_stream) MSX_HIP(ctx, hipStreamSynchronize(st));
+		for (auto st : u->inf_stream) if (st) MSX_HIP(ctx, hipStreamSynchronize(st));
 	}
 	if ((rc = msx_reserve(ctx, &ps.comp, comp_len + 64))) return rc;
 	if ((rc = msx_reserve(ctx, &ps.blk, (size_t)n_blocks * sizeof(msx_bgzf_block)))) return rc;
 	if ((rc = msx_reserve(ctx, &ps.status, (size_t)n_blocks * 4))) return rc;
 	if ((rc = msx_reserve(ctx, &ps.out, UP_HEAD + n_new + 2048))) return rc;       // (+ what the walk may read and clear behind the bytes)
 	if ((rc = msx_reserve(ctx, &ps.cnt, 64))) return rc;
-	// the upload on a stream of its own (it travels while the batch before is being inflated) ...
-	MSX_HIP(ctx, hipMemcpyAsync(ps.comp.p, host_comp, comp_len, hipMemcpyHostToDevice, u->h2d_stream));
-	MSX_HIP(ctx, hipMemcpyAsync(ps.blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, u->h2d_stream));
-	MSX_HIP(ctx, hipEventRecord(ps.h2d_done, u->h2d_stream));
-	// ... the inflater behind it, on this set's own stream: beside the inflater of the batch before, if that is still at work
-	// (a batch of 2048 blocks is eight waves per compute unit, the kernel keeps sixteen: two batches fill the chip).
-	// (eight waves per compute unit: the batch beside it needs LDS too -- k_besthit_select waited a whole inflate kernel for
-	// its share when ten were resident -- and the command line's batches of 2048 blocks are eight per compute unit anyway)
-	MSX_HIP(ctx, hipStreamWaitEvent(inf, ps.h2d_done, 0));
+	// the upload, and the inflater behind it on the same stream (a second batch sent ahead travels on the other stream while
+	// this one is being inflated)
+	MSX_HIP(ctx, hipMemcpyAsync(ps.comp.p, host_comp, comp_len, hipMemcpyHostToDevice, inf));
+	MSX_HIP(ctx, hipMemcpyAsync(ps.blk.p, host_blocks, (size_t)n_blocks * sizeof(msx_bgzf_block), hipMemcpyHostToDevice, inf));
+	MSX_HIP(ctx, hipEventRecord(ps.h2d_done, inf));
 	MSX_HIP(ctx, hipMemsetAsync(ps.cnt.p, 0, 8, inf));
 	if ((rc = msx_bgzf_inflate_launch(ctx, inf, 8, (const uint8_t *)ps.comp.p, comp_len, (const msx_bgzf_block *)ps.blk.p,
 	                                  n_blocks, (uint8_t *)ps.out.p + UP_HEAD, (uint32_t *)ps.status.p, (uint32_t *)ps.cnt.p)))
@@ -899,8 +897,7 @@ extern "C" int msx_unpack_enqueue_bgzf(msx_ctx *ctx, msx_unpack *u, const uint8_
 	msx_unpack::pre_set &ps = u->pre[u->ahead_head];
 	const bool sent = u->ahead_n > 0 && ps.key == host_comp && ps.comp_len == comp_len && ps.nblk == n_blocks;
 	if (u->ahead_n > 0 && !sent) {
-		MSX_HIP(ctx, hipStreamSynchronize(u->h2d_stream));
-		for (auto st : u->inf_stream) MSX_HIP(ctx, hipStreamSynchronize(st));
+		for (auto st : u->inf_stream) if (st) MSX_HIP(ctx, hipStreamSynchronize(st));
 		u->ahead_n = 0;
 		return msx_fail(ctx, MSX_ERR_ARG, "msx_unpack_enqueue_bgzf: other blocks than msx_unpack_prefetch_bgzf sent ahead");
 	}
