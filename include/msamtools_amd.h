@@ -165,6 +165,10 @@ int  msx_runtime_warmup(int device_id);
 /* Binds one GPU (one ctx per GPU / per rank).  Fails with MSX_ERR_NO_DEVICE if
  * there is no gfx950 device: the library has no CPU path. */
 int  msx_ctx_create(msx_ctx **ctx, int device_id);
+/* Side lanes: two more streams of the context on which a step's independent scans and compactions overlap (made when a step
+ * first uses them).  They pay for steps over ~10^7 records and more; a caller that feeds batches of a million records -- the
+ * command line -- turns them off (on = 0) and saves their creation and a fork / join per batch.  Results do not depend on it. */
+int  msx_ctx_set_lanes(msx_ctx *ctx, int on);
 void msx_ctx_destroy(msx_ctx *ctx);
 const char *msx_last_error(const msx_ctx *ctx);  /* ctx may be NULL: last create error */
 int  msx_abi_version(void);

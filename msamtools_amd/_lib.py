@@ -147,6 +147,7 @@ SYMBOLS = {
     "msx_profile_accumulators": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "msx_profile_prop_begin": (C.c_int, [_P, _P]),
     "msx_profile_prop_local": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "msx_ctx_set_lanes": (C.c_int, [_P, C.c_int]),
     "msx_profile_prop_local_slice": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "msx_profile_prop_apply": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "msx_profile_prop_purged": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),

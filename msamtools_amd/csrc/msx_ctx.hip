@@ -127,19 +127,37 @@ extern "C" int msx_ctx_create(msx_ctx **out, int device_id) {
 	ctx->main_stream = ctx->stream;
 	msx_modules_load(device_id);          // (waits for a warm-up thread that is in the middle of it; does it if nobody has)
 	{
+		// (the side lanes' streams are made when a step first forks: a stream is 7.5 ms -- its hardware queue and the queue's
+		// 173 MB of host memory -- and a caller may not want them at all: msx_ctx_set_lanes)
 		const char *ser = getenv("MSX_SERIAL");
-		bool ok = !(ser && atoi(ser) != 0) && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
-		for (int i = 0; ok && i < MSX_SIDE_LANES; i++)
-			ok = hipStreamCreateWithFlags(&ctx->side[i].stream, hipStreamNonBlocking) == hipSuccess &&
-			     hipEventCreateWithFlags(&ctx->side[i].done, hipEventDisableTiming) == hipSuccess;
-		ctx->lanes_ok = ok;      // without them everything simply runs on the main stream
+		ctx->lanes_state = (ser && atoi(ser) != 0) ? -1 : 0;
 	}
 	*out = ctx;
 	return MSX_OK;
 }
 
+// Side lanes on or off for this context (on: the default unless MSX_SERIAL=1).  A step over 10^8 records overlaps its independent
+// scans and compactions on them (the c3 step 4.00 against 4.05 ms); the command line's batches of a million records do not gain
+// what the two streams cost to make and to fork and join per batch (filter -b over 100 M records: pipeline 0.40 -> 0.37 s without).
+extern "C" int msx_ctx_set_lanes(msx_ctx *ctx, int on) {
+	if (!ctx) return MSX_ERR_ARG;
+	if (ctx->forked || ctx->in_lane >= 0) return msx_fail(ctx, MSX_ERR_ARG, "msx_ctx_set_lanes inside a forked step");
+	if (!on) { ctx->lanes_ok = false; ctx->lanes_state = -1; }
+	else if (ctx->lanes_state < 0) ctx->lanes_state = 0;          // (made at the next fork)
+	return MSX_OK;
+}
+
 // ---- side lanes -------------------------------------------------------------------------------
+static void lanes_make(msx_ctx *ctx) {
+	bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+	for (int i = 0; ok && i < MSX_SIDE_LANES; i++)
+		ok = hipStreamCreateWithFlags(&ctx->side[i].stream, hipStreamNonBlocking) == hipSuccess &&
+		     hipEventCreateWithFlags(&ctx->side[i].done, hipEventDisableTiming) == hipSuccess;
+	ctx->lanes_ok = ok;          // without them everything simply runs on the main stream
+	ctx->lanes_state = 1;
+}
 bool msx_fork(msx_ctx *ctx) {
+	if (ctx->lanes_state == 0 && !ctx->timing) lanes_make(ctx);
 	if (!ctx->lanes_ok || ctx->timing || ctx->forked) return false;
 	if (hipEventRecord(ctx->ev_fork, ctx->main_stream) != hipSuccess) return false;
 	for (int i = 0; i < MSX_SIDE_LANES; i++)

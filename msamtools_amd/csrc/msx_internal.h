@@ -121,6 +121,7 @@ struct msx_ctx {
 	int in_lane = -1;                  // side lane currently entered, -1 = main
 	bool forked = false;
 	bool lanes_ok = false;             // side lanes created; MSX_SERIAL=1 keeps everything on the main stream
+	int lanes_state = 0;               // 0: to be made at the first fork, 1: made (or failed: lanes_ok says), -1: not wanted
 	std::string err;
 	int num_cu = 256;
 	int blocks_per_cu = 8;            // grid cap of the grid-stride kernels (MSX_BLOCKS_PER_CU overrides)
