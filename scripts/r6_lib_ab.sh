@@ -12,7 +12,7 @@ run() { # name file flag env...
 ALT=$GRAFT_REPO_ROOT/msamtools_amd/alt
 $D synth --groups 20000000 --refs 1000000 -b > /tmp/lean100.bam
 $D synth --groups 20000000 --refs 1000000 --seq -b > /tmp/seq100.bam
-for rep in 1 2 3 4; do
+for rep in 1 2 3; do
   for f in lean100 seq100; do
     run base /tmp/$f.bam -b
     run alt /tmp/$f.bam -b LD_LIBRARY_PATH=$ALT
