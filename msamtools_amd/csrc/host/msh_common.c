@@ -126,7 +126,7 @@ void runtime_warmup_join(void) {
 void ctx_open_dev(int id) {
 	if (msx_ctx_create(&g_ctx, id) != MSX_OK) mDie("%s", msx_last_error(NULL));
 	/* (the command line's batches are a million records: the context's side lanes cost it more than they overlap) */
-	(void)msx_ctx_set_lanes(g_ctx, 0);
+	{ const char *e = getenv("MSX_SERIAL"); if (!(e && atoi(e) == 0)) (void)msx_ctx_set_lanes(g_ctx, 0); }     /* (MSX_SERIAL=0: keep them) */
 }
 void ctx_open(void) {
 	const char *dev = getenv("MSX_DEVICE"), *lr = getenv("LOCAL_RANK");

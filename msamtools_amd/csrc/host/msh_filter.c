@@ -241,7 +241,7 @@ void *filter_dev_thread(void *arg) {
 			mDie("%s", msx_last_error(NULL));
 		}
 		D->ctx = g_ctx;
-		(void)msx_ctx_set_lanes(g_ctx, 0);        /* (batches of a million records: msh_common.c ctx_open_dev) */
+		{ const char *e = getenv("MSX_SERIAL"); if (!(e && atoi(e) == 0)) (void)msx_ctx_set_lanes(g_ctx, 0); }     /* (batches of a million records: msh_common.c ctx_open_dev) */
 		MSX(msx_stage_create(g_ctx, &stage));
 		if (F->po)
 			MSX(msx_profile_create(g_ctx, &D->prof, F->pf->n_features, F->po->share_type, F->pf->fmap, P->hdr->n_targets));

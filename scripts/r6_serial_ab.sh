@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: the context's two side lanes (streams made at its creation: 7.5 ms each) against MSX_SERIAL=1 on the command line
+# round 6: the command line without the context's two side lanes (its default) against with them (MSX_SERIAL=0), alternating on one box
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 D=msamtools_amd/bin/msamtools-dev; B=msamtools_amd/bin/msamtools
 run() { # name file flag env...
@@ -10,10 +10,10 @@ run() { # name file flag env...
   echo "[$1 $3 $(basename $2)] $(python3 -c "print(round($b-$a,3))") s | $(grep 'filter pipeline' /tmp/err.log | cut -c1-200)"
 }
 $D synth --groups 20000000 --refs 1000000 -b > /tmp/lean100.bam
-$D synth --groups 5000000 --refs 1000000 -b > /tmp/lean25.bam
-for rep in 1 2 3 4; do
-  for f in lean100 lean25; do
-    run lanes /tmp/$f.bam -b
-    run serial /tmp/$f.bam -b MSX_SERIAL=1
+$D synth --groups 20000000 --refs 1000000 --seq -b > /tmp/seq100.bam
+for rep in 1 2 3 4 5; do
+  for f in lean100 seq100; do
+    run nolanes /tmp/$f.bam -b
+    run lanes /tmp/$f.bam -b MSX_SERIAL=0
   done
 done
