@@ -54,3 +54,34 @@ def test_abundance_bits_repeat(groups, refs, multi, fused):
     finally:
         ctx2.close()
     assert np.array_equal(first[0].view(np.uint64), fresh[0].view(np.uint64)) and first[1] == fresh[1]
+
+
+@pytest.mark.parametrize("groups,refs", [(250_000, 3000), (1_200_000, 150_000)])
+def test_side_lanes_change_nothing(groups, refs):
+    """msx_ctx_set_lanes: a context's side lanes (streams on which a step's independent scans and compactions overlap; the command
+    line turns them off, the Python layer and bench.py leave them on) decide WHEN kernels run, not what they compute: the same
+    abundance bits, the same DELTA^2 of every iteration, the same emit list with and without them."""
+    import msamtools_amd as m
+    res = []
+    for lanes in (1, 0, 1):
+        ctx = m.Context(0)
+        try:
+            ctx.check(ctx.lib.msx_ctx_set_lanes(ctx.h, lanes))
+            db = m.DeviceBatch.synth(ctx, 24680, groups, refs, 4)
+            prof = m.Profile(ctx, refs, "proportional")
+            run = m.FilterRun(ctx, db, **OPTS)
+            run.enqueue_with_profile(prof)
+            run.finish()
+            emit = run.result().emit.copy()
+            run.free()
+            prof.finalize_enqueue()
+            ab, st = prof.fetch()
+            res.append((ab.copy(), [st.delta[k] for k in range(20)], st.iterations, emit))
+            prof.close()
+            db.free()
+        finally:
+            ctx.close()
+    for other in res[1:]:
+        assert np.array_equal(res[0][0].view(np.uint64), other[0].view(np.uint64))
+        assert res[0][1] == other[1] and res[0][2] == other[2]
+        assert np.array_equal(res[0][3], other[3])
