@@ -977,31 +977,6 @@ def main():
         },
     }
 
-    # ---- N ranks: the same K steps with MSX_DIST_SLICES=2 (the local half in two slices of the feature range, slice 0's
-    # all-reduce under slice 1's kernels) beside the default, which `value` is -- the A/B a node with more than one GPU decides
-    if use_dist and not args.no_dist_parity:
-        try:
-            os.environ["MSX_DIST_SLICES"] = "2"
-            for _ in range(max(1, min(args.warmup, 2))):
-                step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            barrier()
-            el2 = ctx.max_over_ranks(time.perf_counter() - t0)
-            ab2, pst2 = prof.fetch()
-            out["dist_slices_2"] = {"ms_per_step": round(1e3 * el2 / max(args.steps, 1), 4),
-                                    "value": round(total_records * args.steps / el2 / 1e6, 3),
-                                    "ratio_to_default": round(el2 / elapsed, 4),
-                                    "abundances_bit_equal_to_default": bool(np.array_equal(ab2, ab)),
-                                    "iterations": int(pst2.iterations),
-                                    "note": "MSX_DIST_SLICES=2; default (1) is what `value` reports"}
-        except Exception as exc:
-            out["dist_slices_2"] = {"error": str(exc)[:300]}
-        finally:
-            os.environ.pop("MSX_DIST_SLICES", None)
-
     if args.print_checksum:
         import hashlib
         out["checksum"] = {"abundance_sum": float(ab.sum()), "abundance_sha1_6dp": hashlib.sha1(
@@ -1275,6 +1250,45 @@ def main():
                         "stops enqueueing all-reduces once the convergence flag is seen, =0 enqueues all 19"}
         except Exception as exc:
             out["dist_one_rank"] = {"error": str(exc)[:300]}
+
+    # ---- N ranks: the same K steps with MSX_DIST_SLICES=2 (the local half in two slices of the feature range, slice 0's
+    # all-reduce under slice 1's kernels) beside the default, which `value` is -- the A/B a node with more than one GPU decides.
+    # The last thing the run does, and under a watchdog: the form has only ever run on a one-rank communicator -- should it hang
+    # on a real one, rank 0 still prints the line (everything else is in it by now) and every rank leaves.
+    if use_dist and not args.no_dist_parity:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["dist_slices_2"] = {"error": "no answer within 120 s: abandoned"}
+                out["headline"] = headline(out)
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            os.environ["MSX_DIST_SLICES"] = "2"
+            for _ in range(max(1, min(args.warmup, 2))):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el2 = ctx.max_over_ranks(time.perf_counter() - t0)
+            ab2, pst2 = prof.fetch()
+            out["dist_slices_2"] = {"ms_per_step": round(1e3 * el2 / max(args.steps, 1), 4),
+                                    "value": round(total_records * args.steps / el2 / 1e6, 3),
+                                    "ratio_to_default": round(el2 / elapsed, 4),
+                                    "abundances_bit_equal_to_default": bool(np.array_equal(ab2, ab)),
+                                    "iterations": int(pst2.iterations),
+                                    "note": "MSX_DIST_SLICES=2; default (1) is what `value` reports"}
+        except Exception as exc:
+            out["dist_slices_2"] = {"error": str(exc)[:300]}
+        finally:
+            os.environ.pop("MSX_DIST_SLICES", None)
+            dog.cancel()
 
     prof.close()
     run.free()
